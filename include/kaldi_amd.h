@@ -1,0 +1,343 @@
+/* kaldi_amd.h -- C-ABI of the MI355X-native Kaldi decode hot path.
+ *
+ * One shared library (kaldi_amd/lib/libkaldi_amd.so) exports exactly the entry
+ * points below.  Plain pointers + sizes, POD structs, int status codes, no
+ * exceptions, no STL / OpenFst / Kaldi / torch types.  Every entry point cites the
+ * reference interface (path:line under the Kaldi tree) it replaces.
+ *
+ * Conventions
+ *   - functions returning int: 0 = ok, negative = error; kamd_last_error() gives
+ *     the thread-local message (reference convention: KALDI_ERR throws
+ *     KaldiFatalError, base/kaldi-error.h:89-140; a C-ABI must not throw).
+ *   - "d_" pointers are DEVICE (HBM) pointers, "h_"/unprefixed are host pointers.
+ *   - stream arguments are hipStream_t passed as void* (NULL = default stream).
+ *   - costs are positive = bad, log-likelihoods are negated on use, as in
+ *     decoder/lattice-faster-decoder.cc.
+ */
+#ifndef KALDI_AMD_H_
+#define KALDI_AMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KAMD_OK 0
+#define KAMD_ERR_ARG -1
+#define KAMD_ERR_HIP -2
+#define KAMD_ERR_CAPACITY -3   /* a device arena / hash overflowed; see message */
+#define KAMD_ERR_STATE -4
+
+/* ---------------------------------------------------------------- errors -- */
+const char *kamd_last_error(void);
+/* library + device probe: returns number of visible HIP devices (>=0) or <0. */
+int kamd_device_count(void);
+int kamd_set_device(int device);
+const char *kamd_version(void);
+
+/* -------------------------------------------------------------- features -- */
+/* feat/feature-window.h:40-66 FrameExtractionOptions (same defaults). */
+enum { KAMD_WIN_HANNING = 0, KAMD_WIN_HAMMING = 1, KAMD_WIN_POVEY = 2,
+       KAMD_WIN_RECTANGULAR = 3, KAMD_WIN_BLACKMAN = 4 };
+typedef struct {
+  float samp_freq;        /* 16000 */
+  float frame_shift_ms;   /* 10 */
+  float frame_length_ms;  /* 25 */
+  float dither;           /* reference default 1.0; device path requires 0 */
+  float preemph_coeff;    /* 0.97 */
+  int32_t remove_dc_offset;       /* 1 */
+  int32_t window_type;            /* KAMD_WIN_POVEY */
+  int32_t round_to_power_of_two;  /* 1 */
+  float blackman_coeff;           /* 0.42 */
+  int32_t snip_edges;             /* 1 */
+} kamd_frame_opts;
+
+/* feat/mel-computations.h:43-57 MelBanksOptions. */
+typedef struct {
+  int32_t num_bins;   /* 23 for MFCC default ctor, 40 hires */
+  float low_freq;     /* 20 */
+  float high_freq;    /* 0: nyquist; <0: offset from nyquist */
+  float vtln_low;     /* 100 */
+  float vtln_high;    /* -500 */
+  int32_t htk_mode;   /* 0 */
+} kamd_mel_opts;
+
+/* feat/feature-mfcc.h:38-56 MfccOptions. */
+typedef struct {
+  kamd_frame_opts frame;
+  kamd_mel_opts mel;
+  int32_t num_ceps;        /* 13 */
+  int32_t use_energy;      /* 1 */
+  float energy_floor;      /* 0 */
+  int32_t raw_energy;      /* 1 */
+  float cepstral_lifter;   /* 22 */
+  int32_t htk_compat;      /* 0 */
+} kamd_mfcc_opts;
+
+/* feat/feature-fbank.h FbankOptions. */
+typedef struct {
+  kamd_frame_opts frame;
+  kamd_mel_opts mel;
+  int32_t use_energy;      /* 0 */
+  float energy_floor;      /* 0 */
+  int32_t raw_energy;      /* 1 */
+  int32_t htk_compat;      /* 0 */
+  int32_t use_log_fbank;   /* 1 */
+  int32_t use_power;       /* 1 */
+} kamd_fbank_opts;
+
+void kamd_mfcc_opts_default(kamd_mfcc_opts *o);
+void kamd_fbank_opts_default(kamd_fbank_opts *o);
+
+typedef struct kamd_feat kamd_feat; /* an MfccComputer / FbankComputer on device */
+
+/* replaces MfccComputer::MfccComputer (feat/feature-mfcc.cc:82-115) /
+ * FbankComputer ctor; vtln_warp fixes the mel banks (GetMelBanks(vtln_warp)). */
+kamd_feat *kamd_mfcc_create(const kamd_mfcc_opts *opts, float vtln_warp);
+kamd_feat *kamd_fbank_create(const kamd_fbank_opts *opts, float vtln_warp);
+void kamd_feat_destroy(kamd_feat *f);
+/* Computer::Dim() (feat/feature-mfcc.h:73). */
+int kamd_feat_dim(const kamd_feat *f);
+/* NumFrames(num_samples, opts, flush=true) (feat/feature-window.cc:41-87). */
+int kamd_feat_num_frames(const kamd_feat *f, int64_t num_samples);
+/* OfflineFeatureTpl<F>::ComputeFeatures (feat/feature-common-inl.h:29-83):
+ * host wave (int16-range floats) -> host [num_frames x dim] row-major.
+ * Returns num_frames (>=0) or <0.  out_rows_cap bounds the output. */
+int kamd_feat_compute(kamd_feat *f, const float *wave, int64_t num_samples,
+                      float *out, int out_rows_cap);
+/* Batched device-resident variant: n_utts waveforms concatenated in d_waves;
+ * h_wave_off[n_utts+1] sample offsets (host); output rows of utterance u start at
+ * row h_row_off[u] of d_out (leading dimension ld_out floats, >= dim; columns
+ * dim..ld_out-1 are zero-filled).  Asynchronous on 'stream'. */
+int kamd_feat_compute_batch_device(kamd_feat *f, const float *d_waves,
+                                   const int64_t *h_wave_off, int n_utts,
+                                   float *d_out, const int64_t *h_row_off,
+                                   int ld_out, void *stream);
+
+/* ------------------------------------------------------------------ nnet -- */
+#define KAMD_MAX_OFFSETS 8
+/* One fused layer = TdnnComponent/AffineComponent/LinearComponent/FixedAffine
+ * (nnet3/nnet-tdnn-component.cc:181-212, nnet-simple-component.cc:1234,3209,3376)
+ * + RectifiedLinear (:957) + test-mode BatchNorm (nnet-normalize-component.cc:
+ * 453-464) + the NoOp bypass Sum(Scale(s, prev), this) of tdnnf-layer
+ * (steps/libs/nnet3/xconfig/composite_layers.py:201-215) + the final
+ * "-log_prior, *acoustic_scale" (nnet-am-decodable-simple.cc:268-271):
+ *
+ *   y[t] = ((bn_scale * relu(sum_i W_i x[t + off_i] + W_iv ivec + b) + bn_offset
+ *            + bypass_scale * z[t]) + post_offset) * post_scale
+ *
+ * W is [out_dim x (n_offsets*in_dim + ivector_dim)] row-major, column blocks in
+ * time_offsets order (TdnnComponent linear_params_ layout). NULL vectors = absent.
+ */
+typedef struct {
+  int32_t in_dim, out_dim;
+  int32_t n_offsets;
+  int32_t offsets[KAMD_MAX_OFFSETS];
+  int32_t input_layer;    /* producing layer index, -1 = the network input */
+  int32_t ivector_dim;    /* >0 only when input_layer == -1 */
+  int32_t bypass_layer;   /* -2 = none, -1 = network input, else layer index */
+  float bypass_scale;
+  int32_t relu;
+  const float *W;
+  const float *bias;       /* [out_dim] or NULL */
+  const float *bn_scale;   /* [out_dim] or NULL */
+  const float *bn_offset;  /* [out_dim] or NULL */
+  const float *post_offset;/* [out_dim] or NULL (= -log_priors) */
+  float post_scale;        /* acoustic scale on the last layer, else 1 */
+} kamd_layer_desc;
+
+typedef struct kamd_nnet kamd_nnet;
+/* Consumes the collapsed model (nnet3/nnet-utils.cc:2006 CollapseModel output) as
+ * a chain of fused layers.  Weights are copied to HBM.  frame_subsampling_factor
+ * as in NnetSimpleComputationOptions (nnet-am-decodable-simple.h:62-66). The last
+ * layer is the "output" node. */
+kamd_nnet *kamd_nnet_create(const kamd_layer_desc *layers, int n_layers,
+                            int input_dim, int frame_subsampling_factor);
+void kamd_nnet_destroy(kamd_nnet *n);
+int kamd_nnet_output_dim(const kamd_nnet *n);
+int kamd_nnet_left_context(const kamd_nnet *n);   /* ComputeSimpleNnetContext */
+int kamd_nnet_right_context(const kamd_nnet *n);
+/* DecodableNnetSimple semantics (nnet-am-decodable-simple.cc:40-47): number of
+ * output rows for T input frames = ceil(T / subsampling). */
+int kamd_nnet_num_output_frames(const kamd_nnet *n, int num_input_frames);
+/* Whole-batch forward, device resident.  Inputs: d_feats rows of utterance u at
+ * [h_in_row_off[u], h_in_row_off[u+1]) with leading dimension ld_in; optional
+ * per-utterance ivectors d_ivectors [n_utts x ivector_dim] (NULL if none).
+ * Output rows of utterance u start at h_out_row_off[u] in d_out (ld_out floats).
+ * Equals DecodableNnetSimple::GetOutputForFrame for every subsampled frame
+ * (edge frames clamped as nnet-am-decodable-simple.cc:147-160). */
+int kamd_nnet_forward_batch_device(kamd_nnet *n, const float *d_feats,
+                                   const int64_t *h_in_row_off, int ld_in,
+                                   const float *d_ivectors, int n_utts,
+                                   float *d_out, const int64_t *h_out_row_off,
+                                   int ld_out, void *stream);
+/* Host convenience (one utterance): feats [T x input_dim] -> out [T' x out_dim]. */
+int kamd_nnet_forward(kamd_nnet *n, const float *feats, int T,
+                      const float *ivector, float *out, int out_rows_cap);
+/* total multiply-accumulates of the last forward (for the MFMA roofline). */
+double kamd_nnet_last_flops(const kamd_nnet *n);
+
+/* ----------------------------------------------------------------- graph -- */
+/* == fst::StdArc memory layout (OpenFst 1.6.7 ArcTpl<TropicalWeight>):
+ * {int ilabel; int olabel; float weight; int nextstate}; ilabel is a 1-based
+ * transition-id, 0 = epsilon (decoder/lattice-faster-decoder.cc:792,879). */
+typedef struct {
+  int32_t ilabel;
+  int32_t olabel;
+  float weight;
+  int32_t nextstate;
+} kamd_arc;
+
+typedef struct kamd_graph kamd_graph;
+/* HCLG as CSR in OpenFst arc order: arcs of state s are arcs[arc_off[s] ..
+ * arc_off[s+1]); final_cost[s] = Final(s).Value() (+inf if not final).
+ * Replaces the fst::Fst<StdArc> argument of LatticeFasterDecoderTpl's ctor
+ * (decoder/lattice-faster-decoder.h:238-246) and ReadFstKaldiGeneric
+ * (fstext/kaldi-fst-io.cc:44-89).  The graph is copied to HBM, split into an
+ * emitting CSR and an epsilon CSR.  Epsilon cycles are rejected. */
+kamd_graph *kamd_graph_create(int32_t num_states, int32_t start_state,
+                              const int64_t *arc_off, const kamd_arc *arcs,
+                              const float *final_cost);
+void kamd_graph_destroy(kamd_graph *g);
+int32_t kamd_graph_num_states(const kamd_graph *g);
+int64_t kamd_graph_num_arcs(const kamd_graph *g);
+
+/* --------------------------------------------------------------- decoder -- */
+/* decoder/lattice-faster-decoder.h:38-64 LatticeFasterDecoderConfig. */
+typedef struct {
+  float beam;            /* 16 */
+  int32_t max_active;    /* INT32_MAX */
+  int32_t min_active;    /* 200 */
+  float lattice_beam;    /* 10 */
+  int32_t prune_interval;/* 25 */
+  float beam_delta;      /* 0.5 */
+  float hash_ratio;      /* 2.0 (unused on device; kept for drop-in) */
+  float prune_scale;     /* 0.1 */
+} kamd_decoder_config;
+void kamd_decoder_config_default(kamd_decoder_config *c);
+
+/* device sizing knobs (no reference counterpart: the reference mallocs). */
+typedef struct {
+  int32_t max_lanes;          /* concurrently live decoder instances */
+  int32_t hash_capacity;      /* per lane, power of two, tokens of one frame */
+  int64_t arena_tokens;       /* token records per lane */
+  int64_t arena_links;        /* forward-link records per lane */
+  int32_t max_frames;         /* frames per lane */
+} kamd_decoder_sizes;
+void kamd_decoder_sizes_default(kamd_decoder_sizes *s);
+
+typedef struct kamd_decoder kamd_decoder;
+/* LatticeFasterDecoderTpl(const FST&, const Config&) (lattice-faster-decoder.cc:
+ * 30-36).  tid2pdf[0..num_tids] is TransitionModel::id2pdf_id_
+ * (hmm/transition-model.h:310,334-345; index 0 unused) so that the device reads
+ * loglikes[frame][tid2pdf[ilabel]] like DecodableMatrixMapped
+ * (decoder/decodable-matrix.cc:62-69).  tid2pdf == NULL means identity-1
+ * (ilabel-1 indexes the loglike row directly, DecodableMatrixScaled). */
+kamd_decoder *kamd_decoder_create(const kamd_graph *g,
+                                  const kamd_decoder_config *cfg,
+                                  const kamd_decoder_sizes *sizes,
+                                  const int32_t *tid2pdf, int32_t num_tids);
+void kamd_decoder_destroy(kamd_decoder *d);
+int kamd_decoder_set_options(kamd_decoder *d, const kamd_decoder_config *cfg);
+
+/* One task = "advance lane L by n_frames frames of this log-likelihood matrix".
+ * d_loglikes points at the row of the first frame to decode (row stride ld). */
+typedef struct {
+  int32_t lane;
+  int32_t n_frames;
+  const float *d_loglikes;
+  int32_t ld;
+  int32_t reserved;
+} kamd_decode_task;
+
+/* InitDecoding() (lattice-faster-decoder.cc:56-73) for the given lanes. */
+int kamd_decoder_init(kamd_decoder *d, const int32_t *lanes, int n, void *stream);
+/* AdvanceDecoding() (lattice-faster-decoder.cc:593-632) for a set of lanes in
+ * one launch: one persistent workgroup per task.  Asynchronous. */
+int kamd_decoder_advance(kamd_decoder *d, const kamd_decode_task *tasks, int n,
+                         void *stream);
+/* FinalizeDecoding() (lattice-faster-decoder.cc:638-653): final-cost handling and
+ * the exact backward extra-cost fixpoint + pruning with lattice_beam. */
+int kamd_decoder_finalize(kamd_decoder *d, const int32_t *lanes, int n,
+                          void *stream);
+/* Blocks until all queued work of the decoder is done; reports device-side
+ * failures (arena/hash overflow) of any lane as KAMD_ERR_CAPACITY. */
+int kamd_decoder_sync(kamd_decoder *d);
+
+int kamd_decoder_num_frames_decoded(kamd_decoder *d, int lane);
+/* FinalRelativeCost() / ReachedFinal() (lattice-faster-decoder.h:283-300). */
+float kamd_decoder_final_relative_cost(kamd_decoder *d, int lane);
+int kamd_decoder_reached_final(kamd_decoder *d, int lane);
+
+/* GetRawLattice(&lat, use_final_probs=true) (lattice-faster-decoder.cc:113-196).
+ * Lattice states = surviving tokens, numbered frame by frame and, inside a frame,
+ * by HCLG state id (canonical; the reference numbering is pointer-order,
+ * SURVEY App. D.9).  Arc weights are (graph_cost, acoustic_cost - cost_offset).
+ * Two-call protocol: kamd_decoder_lattice_size, then _get with caller buffers. */
+typedef struct {
+  int32_t num_states;
+  int32_t num_arcs;
+  int32_t num_frames;
+  int32_t start;        /* lattice state of the start token (frame 0) */
+} kamd_lattice_size;
+typedef struct {
+  int32_t src, dst;      /* lattice state ids */
+  int32_t ilabel, olabel;
+  float graph_cost, acoustic_cost;
+} kamd_lat_arc;
+int kamd_decoder_lattice_size(kamd_decoder *d, int lane, kamd_lattice_size *sz);
+/* state_frame[num_states], state_hclg[num_states] (HCLG state of the token),
+ * state_cost[num_states] (forward tot_cost), state_final[num_states]
+ * (LatticeWeight(final_cost,0) value1; +inf = not final), arcs[num_arcs] sorted
+ * by (src,dst,ilabel,olabel). */
+int kamd_decoder_get_raw_lattice(kamd_decoder *d, int lane, int32_t *state_frame,
+                                 int32_t *state_hclg, float *state_cost,
+                                 float *state_final, kamd_lat_arc *arcs);
+/* GetBestPath (lattice-faster-decoder.cc:102-108) + GetLinearSymbolSequence
+ * (fstext/fstext-utils-inl.h:178): ShortestPath over the raw lattice with
+ * LatticeWeight ordering.  Outputs the alignment (transition-ids), words, and the
+ * total (graph, acoustic) weight.  Buffers sized by *_cap; returns counts. */
+int kamd_decoder_best_path(kamd_decoder *d, int lane, int32_t *alignment,
+                           int ali_cap, int *ali_len, int32_t *words,
+                           int words_cap, int *words_len, float *graph_cost,
+                           float *acoustic_cost);
+/* per-frame trace for parity debugging: ntok[f], cutoff[f], cost_offset[f]. */
+int kamd_decoder_get_trace(kamd_decoder *d, int lane, int32_t *ntok,
+                           float *cutoff, float *cost_offset, int cap);
+/* Algorithmic work counters of SURVEY 8(d), accumulated since init of the lane:
+ * [0]=N_exp tokens expanded, [1]=A_exp arcs iterated (emitting+epsilon),
+ * [2]=A_emit emitting arcs, [3]=K_surv arcs passing the cutoff,
+ * [4]=L_kept links written, [5]=N_tok tokens created, [6]=frames, [7]=reserved */
+int kamd_decoder_get_counters(kamd_decoder *d, int lane, int64_t counters[8]);
+/* device time (ms) of the last advance launch, measured with HIP events on the
+ * stream the kernel ran on (for bench.py's roofline). */
+float kamd_decoder_last_advance_ms(kamd_decoder *d);
+
+/* -------------------------------------------------------------- pipeline -- */
+/* wav -> features -> nnet -> decode for a batch of utterances, everything
+ * device-resident between stages (the reference crosses the device boundary per
+ * chunk: nnet-am-decodable-simple.cc:256,274; nnet-batch-compute.cc:412,469).
+ * Mirrors nnet3-latgen-faster-batch's per-utterance flow
+ * (nnet3bin/nnet3-latgen-faster-batch.cc:170-214). */
+typedef struct kamd_pipeline kamd_pipeline;
+kamd_pipeline *kamd_pipeline_create(kamd_feat *feat, kamd_nnet *nnet,
+                                    kamd_decoder *dec);
+void kamd_pipeline_destroy(kamd_pipeline *p);
+/* Upload a batch of waveforms (host, concatenated; h_wave_off[n_utts+1]). */
+int kamd_pipeline_load_batch(kamd_pipeline *p, const float *waves,
+                             const int64_t *h_wave_off, int n_utts);
+/* Run the hot path over the resident batch: lanes 0..n_utts-1 hold the results.
+ * Blocking; returns 0 or error.  stage_ms[3] = {features, nnet, decode(advance+
+ * finalize)} device times from HIP events. */
+int kamd_pipeline_run(kamd_pipeline *p, float stage_ms[4]);
+/* device pointer + shape of the resident log-likelihoods of utterance u. */
+int kamd_pipeline_get_loglikes(kamd_pipeline *p, int utt, float *out,
+                               int rows_cap, int *rows, int *cols);
+int kamd_pipeline_get_features(kamd_pipeline *p, int utt, float *out,
+                               int rows_cap, int *rows, int *cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KALDI_AMD_H_ */

@@ -1,0 +1,211 @@
+"""Seeded synthetic workloads (no corpora / models / HCLG files exist offline).
+
+* `make_hclg`  -- an HCLG-like decoding graph in OpenFst arc order (CSR of
+  fst::StdArc records): LM history states (hubs) with word arcs + epsilon back-off
+  arcs, per-(history, word) chains of HMM states (chain topology: one state per
+  phone-unit with a self-loop tid and a forward tid, 2 pdfs per unit), epsilon arcs
+  from word ends back into the LM, finals on LM states.  First-order statistics follow
+  SURVEY.md 8(d): ~2-3 arcs/state, ~10-15 % epsilon arcs, hub states with 10^2-10^4
+  arcs, olabels on ~1/8 of arcs, no epsilon cycles.
+* `sample_utterance` -- a random path through that graph (truth transcript) and
+  log-likelihood matrices peaked on the true pdf (a well-conditioned decode).
+* `make_wave` -- band-limited noise + sinusoids at int16 scale (Kaldi wave scale).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from .abi import ARC_DTYPE
+
+
+@dataclass
+class Hclg:
+    num_states: int
+    start: int
+    arc_off: np.ndarray      # int64 [S+1]
+    arcs: np.ndarray         # ARC_DTYPE [A]
+    final: np.ndarray        # float32 [S] (+inf = not final)
+    tid2pdf: np.ndarray      # int32 [num_tids+1], index 0 unused (=-1)
+    num_pdfs: int
+    # generator metadata (for sample_utterance)
+    n_hist: int = 0
+    pair_hist: np.ndarray = None
+    pair_word: np.ndarray = None
+    pair_base: np.ndarray = None
+    pair_len: np.ndarray = None
+    hist_pair_off: np.ndarray = None
+    word_next_hist: np.ndarray = None
+    chain_unit: np.ndarray = None   # unit of each chain state (index = state - n_hist)
+
+    @property
+    def num_arcs(self):
+        return int(self.arc_off[-1])
+
+
+def make_hclg(num_units=64, vocab=200, n_hist=50, fanout=(4, 24), pron_len=(2, 6),
+              seed=2, dtype_check=True):
+    """Build the synthetic graph.  States 0..n_hist-1 are LM states (0 = unigram hub,
+    start = min(1, n_hist-1)); the rest are chain states."""
+    rng = np.random.default_rng(seed)
+    U, V, H = num_units, vocab, n_hist
+    # pronunciations
+    wlen = rng.integers(pron_len[0], pron_len[1] + 1, V)
+    woff = np.concatenate([[0], np.cumsum(wlen)])
+    wunits = rng.integers(0, U, woff[-1])
+    word_next_hist = rng.integers(0, H, V)
+    # (history, word) pairs: unigram hub has every word, others a random subset
+    hs = [np.zeros(V, np.int64)]
+    ws = [np.arange(V, dtype=np.int64)]
+    if H > 1:
+        fo = rng.integers(fanout[0], fanout[1] + 1, H - 1)
+        hh = np.repeat(np.arange(1, H, dtype=np.int64), fo)
+        # zipf-ish word choice so frequent words recur across histories
+        ww = np.minimum((V * rng.random(hh.size) ** 2).astype(np.int64), V - 1)
+        key = np.unique(hh * V + ww)
+        hs.append(key // V)
+        ws.append(key % V)
+    pair_hist = np.concatenate(hs)
+    pair_word = np.concatenate(ws)
+    K = pair_hist.size
+    pair_len = wlen[pair_word]
+    pair_base = H + np.concatenate([[0], np.cumsum(pair_len)[:-1]])
+    n_chain = int(pair_len.sum())
+    S = H + n_chain
+    # per-chain-state info
+    chain_pair = np.repeat(np.arange(K), pair_len)
+    chain_pos = np.arange(n_chain) - np.repeat(pair_base - H, pair_len)
+    chain_word = pair_word[chain_pair]
+    chain_unit = wunits[woff[chain_word] + chain_pos]
+    chain_last = chain_pos == (pair_len[chain_pair] - 1)
+    # arc counts: LM state h: (#pairs with hist h) + (1 backoff if h>0); chain: 2
+    hist_cnt = np.bincount(pair_hist, minlength=H)
+    narcs = np.empty(S, np.int64)
+    narcs[:H] = hist_cnt + (np.arange(H) > 0)
+    narcs[H:] = 2
+    arc_off = np.concatenate([[0], np.cumsum(narcs)])
+    A = int(arc_off[-1])
+    arcs = np.zeros(A, ARC_DTYPE)
+    # LM arcs: backoff first (h>0), then word arcs in pair order
+    hist_pair_off = np.concatenate([[0], np.cumsum(hist_cnt)])
+    if H > 1:
+        bo = arc_off[1:H]
+        arcs["ilabel"][bo] = 0
+        arcs["olabel"][bo] = 0
+        arcs["weight"][bo] = rng.uniform(0.5, 3.0, H - 1)
+        arcs["nextstate"][bo] = 0
+    rank = np.arange(K) - hist_pair_off[pair_hist]
+    wa = arc_off[pair_hist] + (pair_hist > 0) + rank
+    first_unit = wunits[woff[pair_word]]
+    arcs["ilabel"][wa] = 1 + 2 * first_unit          # forward tid of first unit
+    arcs["olabel"][wa] = pair_word + 1
+    # LM cost: -log of a random distribution per history
+    raw = rng.gamma(1.0, 1.0, K) + 1e-3
+    tot = np.bincount(pair_hist, weights=raw, minlength=H)
+    arcs["weight"][wa] = -np.log(raw / tot[pair_hist])
+    arcs["nextstate"][wa] = pair_base
+    # chain arcs: [self-loop, forward-or-epsilon]
+    cs = H + np.arange(n_chain)
+    a0 = arc_off[cs]
+    selfp = rng.uniform(0.25, 0.6, n_chain)
+    arcs["ilabel"][a0] = 2 + 2 * chain_unit          # self-loop tid
+    arcs["weight"][a0] = -np.log(selfp)
+    arcs["nextstate"][a0] = cs
+    a1 = a0 + 1
+    nxt_unit = np.empty(n_chain, np.int64)
+    nxt_unit[:-1] = chain_unit[1:]
+    nxt_unit[-1] = 0
+    arcs["ilabel"][a1] = np.where(chain_last, 0, 1 + 2 * nxt_unit)
+    arcs["weight"][a1] = -np.log(1.0 - selfp)
+    arcs["nextstate"][a1] = np.where(chain_last, word_next_hist[chain_word], cs + 1)
+    final = np.full(S, np.inf, np.float32)
+    final[:H] = rng.uniform(0.5, 3.0, H)
+    tid2pdf = np.full(2 * U + 1, -1, np.int32)
+    tid2pdf[1:] = np.arange(2 * U)
+    g = Hclg(S, min(1, H - 1), arc_off.astype(np.int64), arcs, final, tid2pdf, 2 * U,
+             n_hist=H, pair_hist=pair_hist, pair_word=pair_word, pair_base=pair_base,
+             pair_len=pair_len, hist_pair_off=hist_pair_off,
+             word_next_hist=word_next_hist, chain_unit=chain_unit)
+    return g
+
+
+def make_random_graph(num_states=300, num_labels=40, mean_arcs=3.0, eps_frac=0.12,
+                      final_frac=0.05, seed=1):
+    """Unstructured random graph (SURVEY 6 probe style): stresses hashing and the
+    epsilon closure.  Epsilon arcs only go to higher state ids (no epsilon cycles)."""
+    rng = np.random.default_rng(seed)
+    S = num_states
+    n = np.maximum(1, rng.poisson(mean_arcs, S))
+    arc_off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    A = int(arc_off[-1])
+    src = np.repeat(np.arange(S), n)
+    arcs = np.zeros(A, ARC_DTYPE)
+    is_eps = (rng.random(A) < eps_frac) & (src < S - 1)
+    arcs["ilabel"] = np.where(is_eps, 0, rng.integers(1, num_labels + 1, A))
+    arcs["olabel"] = np.where(rng.random(A) < 0.125, rng.integers(1, 50, A), 0)
+    arcs["weight"] = rng.uniform(0.05, 3.0, A)
+    nxt = rng.integers(0, S, A)
+    nxt_eps = src + 1 + (rng.random(A) * (S - 1 - src)).astype(np.int64)
+    arcs["nextstate"] = np.where(is_eps, np.minimum(nxt_eps, S - 1), nxt)
+    final = np.where(rng.random(S) < final_frac, rng.uniform(0, 2, S), np.inf).astype(np.float32)
+    tid2pdf = np.full(num_labels + 1, -1, np.int32)
+    tid2pdf[1:] = rng.integers(0, max(2, num_labels // 2), num_labels)
+    return Hclg(S, 0, arc_off, arcs, final, tid2pdf, int(tid2pdf.max()) + 1)
+
+
+def sample_utterance(g, n_words=6, seed=0, peak=6.0, noise=1.0, dur_p=0.5):
+    """Random word sequence through `g` (from make_hclg) -> (loglikes [T,P], words,
+    pdf alignment).  loglike = noise*N(0,1) + peak on the true pdf, minus logsumexp."""
+    rng = np.random.default_rng(seed)
+    h = g.start
+    words, pdfs = [], []
+    for _ in range(n_words):
+        lo, hi = g.hist_pair_off[h], g.hist_pair_off[h + 1]
+        if hi == lo:                     # history without words: back off
+            h = 0
+            lo, hi = g.hist_pair_off[0], g.hist_pair_off[1]
+        k = int(rng.integers(lo, hi))
+        w = int(g.pair_word[k])
+        words.append(w + 1)
+        base, ln = int(g.pair_base[k]) - g.n_hist, int(g.pair_len[k])
+        for j in range(ln):
+            u = int(g.chain_unit[base + j])
+            pdfs.append(2 * u)           # forward pdf on entry
+            d = int(rng.geometric(dur_p)) - 1
+            pdfs.extend([2 * u + 1] * d)  # self-loop pdf
+        h = int(g.word_next_hist[w])
+    pdfs = np.asarray(pdfs, np.int64)
+    T = pdfs.size
+    ll = (noise * rng.standard_normal((T, g.num_pdfs))).astype(np.float32)
+    ll[np.arange(T), pdfs] += peak
+    m = ll.max(axis=1, keepdims=True)
+    ll = ll - (m + np.log(np.exp(ll - m).sum(axis=1, keepdims=True)))
+    return np.ascontiguousarray(ll, np.float32), words, pdfs
+
+
+def random_loglikes(T, P, seed=0, scale=1.0):
+    rng = np.random.default_rng(seed)
+    return np.ascontiguousarray(scale * rng.standard_normal((T, P)), np.float32)
+
+
+def make_wave(seconds, seed=0, samp_freq=16000):
+    """Synthetic 16 kHz utterance: band-limited noise + a few drifting sinusoids,
+    amplitude ~0.3*32768 (Kaldi keeps int16-scale floats, feat/wave-reader.cc:272)."""
+    rng = np.random.default_rng(seed)
+    n = int(seconds * samp_freq)
+    t = np.arange(n) / samp_freq
+    x = rng.standard_normal(n)
+    k = np.array([0.25, 0.5, 0.25])
+    x = np.convolve(x, k, mode="same")
+    for _ in range(4):
+        f0 = rng.uniform(100, 3500)
+        x += 2.0 * np.sin(2 * np.pi * (f0 * t + 40 * np.sin(2 * np.pi * rng.uniform(1, 4) * t)))
+    env = 0.6 + 0.4 * np.sin(2 * np.pi * rng.uniform(2, 5) * t + rng.uniform(0, 6))
+    x = x * env
+    x = x / np.abs(x).max() * (0.3 * 32768)
+    return np.round(x).astype(np.float32)
+
+
+def utterance_durations(n, seed=1, mu=7.0, sigma=0.6, lo=1.0, hi=35.0):
+    """LibriSpeech-like durations: lognormal(ln 7 s, 0.6) clipped to [1, 35] s."""
+    rng = np.random.default_rng(seed)
+    return np.clip(rng.lognormal(np.log(mu), sigma, n), lo, hi)

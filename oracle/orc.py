@@ -1,0 +1,194 @@
+"""Python face of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product package (kaldi_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from kaldi_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "_build", "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("orc_feat.cc", "orc_nnet.cc", "orc_decoder.cc")]
+    srcs.append(os.path.join(_HERE, "..", "include", "kaldi_amd.h"))
+    stale = (not os.path.exists(so)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        if not all(os.path.exists(s) for s in srcs):
+            if os.path.exists(so):
+                return so
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        fp, ip, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+        L.orc_feat_num_frames.argtypes = [C.POINTER(abi.FrameOpts), C.c_int64]
+        L.orc_mfcc_compute.argtypes = [C.POINTER(abi.MfccOpts), C.c_float, fp, C.c_int64, fp, C.c_int]
+        L.orc_fbank_compute.argtypes = [C.POINTER(abi.FbankOpts), C.c_float, fp, C.c_int64, fp, C.c_int]
+        L.orc_nnet_context.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, ip, ip]
+        L.orc_nnet_forward.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp,
+                                       C.c_int, fp, fp, C.c_int]
+        L.orc_decoder_create.restype = C.c_void_p
+        L.orc_decoder_create.argtypes = [C.c_int32, C.c_int32, i64p, C.c_void_p, fp,
+                                         C.POINTER(abi.DecoderConfig), ip, C.c_int32, C.c_int]
+        for f in ("destroy", "init", "finalize"):
+            getattr(L, "orc_decoder_" + f).argtypes = [C.c_void_p]
+            getattr(L, "orc_decoder_" + f).restype = None
+        L.orc_decoder_advance.argtypes = [C.c_void_p, fp, C.c_int, C.c_int]
+        L.orc_decoder_advance.restype = None
+        L.orc_decoder_num_frames_decoded.argtypes = [C.c_void_p]
+        L.orc_decoder_num_toks.argtypes = [C.c_void_p]
+        L.orc_decoder_final_relative_cost.argtypes = [C.c_void_p]
+        L.orc_decoder_final_relative_cost.restype = C.c_float
+        L.orc_decoder_lattice_size.argtypes = [C.c_void_p, C.POINTER(abi.LatticeSize)]
+        L.orc_decoder_get_raw_lattice.argtypes = [C.c_void_p, ip, ip, fp, fp, C.c_void_p]
+        L.orc_lattice_best_path.argtypes = [C.c_int, C.c_int, fp, C.c_int, C.c_void_p, ip, C.c_int,
+                                            ip, ip, C.c_int, ip, fp, fp]
+        L.orc_decoder_get_trace.argtypes = [C.c_void_p, ip, fp, fp, C.c_int]
+        L.orc_decoder_get_counters.argtypes = [C.c_void_p, i64p]
+        L.orc_decoder_get_counters.restype = None
+        _LIB = L
+    return _LIB
+
+
+# ------------------------------------------------------------------ features
+def mfcc(opts, wave, vtln_warp=1.0):
+    wave = np.ascontiguousarray(wave, np.float32)
+    T = lib().orc_feat_num_frames(C.byref(opts.frame), wave.size)
+    out = np.zeros((max(T, 0), opts.num_ceps), np.float32)
+    r = lib().orc_mfcc_compute(C.byref(opts), vtln_warp, abi.fptr(wave), wave.size,
+                               abi.fptr(out), out.shape[0])
+    assert r == T, r
+    return out
+
+
+def fbank(opts, wave, vtln_warp=1.0):
+    wave = np.ascontiguousarray(wave, np.float32)
+    T = lib().orc_feat_num_frames(C.byref(opts.frame), wave.size)
+    dim = opts.mel.num_bins + (1 if opts.use_energy else 0)
+    out = np.zeros((max(T, 0), dim), np.float32)
+    r = lib().orc_fbank_compute(C.byref(opts), vtln_warp, abi.fptr(wave), wave.size,
+                                abi.fptr(out), out.shape[0])
+    assert r == T, r
+    return out
+
+
+# ---------------------------------------------------------------------- nnet
+def nnet_forward(model, feats, ivector=None):
+    feats = np.ascontiguousarray(feats, np.float32)
+    T = feats.shape[0]
+    n_out = (T + model.subsampling - 1) // model.subsampling
+    P = model.layers[-1].out_dim
+    out = np.zeros((n_out, P), np.float32)
+    iv = None if ivector is None else np.ascontiguousarray(ivector, np.float32)
+    d = model.descs()
+    r = lib().orc_nnet_forward(d, len(model.layers), model.input_dim, model.subsampling,
+                               abi.fptr(feats), T, abi.fptr(iv), abi.fptr(out), n_out)
+    assert r == n_out, r
+    return out
+
+
+def nnet_context(model):
+    l, r = C.c_int32(), C.c_int32()
+    lib().orc_nnet_context(model.descs(), len(model.layers), C.byref(l), C.byref(r))
+    return l.value, r.value
+
+
+# ------------------------------------------------------------------- decoder
+class Lattice:
+    """Raw lattice in canonical numbering (see include/kaldi_amd.h)."""
+
+    def __init__(self, start, frame, hclg, cost, final, arcs, num_frames):
+        self.start, self.frame, self.hclg, self.cost = start, frame, hclg, cost
+        self.final, self.arcs, self.num_frames = final, arcs, num_frames
+
+    def best_path(self):
+        n, m = self.frame.size, self.arcs.size
+        ali = np.zeros(max(m, 1), np.int32)
+        words = np.zeros(max(m, 1), np.int32)
+        na, nw = C.c_int(), C.c_int()
+        g, a = C.c_float(), C.c_float()
+        arcs = np.ascontiguousarray(self.arcs)
+        r = lib().orc_lattice_best_path(n, self.start, abi.fptr(self.final), m,
+                                        arcs.ctypes.data_as(C.c_void_p),
+                                        abi.iptr(ali), ali.size, C.byref(na), abi.iptr(words),
+                                        words.size, C.byref(nw), C.byref(g), C.byref(a))
+        if r != 0:
+            return None
+        return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(),
+                    graph_cost=g.value, acoustic_cost=a.value)
+
+
+class Decoder:
+    """orc_decoder: mode 0 = faithful to the reference's order, 1 = canonical."""
+
+    def __init__(self, g, cfg, mode=1):
+        self.g, self.cfg, self.mode = g, cfg, mode
+        arcs = np.ascontiguousarray(g.arcs)
+        self._h = lib().orc_decoder_create(
+            g.num_states, g.start, abi.iptr(np.ascontiguousarray(g.arc_off, np.int64), C.c_int64),
+            arcs.ctypes.data_as(C.c_void_p), abi.fptr(np.ascontiguousarray(g.final, np.float32)),
+            C.byref(cfg), abi.iptr(np.ascontiguousarray(g.tid2pdf, np.int32)),
+            g.tid2pdf.size - 1, mode)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_decoder_destroy(self._h)
+            self._h = None
+
+    def InitDecoding(self):
+        lib().orc_decoder_init(self._h)
+
+    def AdvanceDecoding(self, loglikes):
+        ll = np.ascontiguousarray(loglikes, np.float32)
+        lib().orc_decoder_advance(self._h, abi.fptr(ll), ll.shape[1], ll.shape[0])
+
+    def FinalizeDecoding(self):
+        lib().orc_decoder_finalize(self._h)
+
+    def Decode(self, loglikes):
+        self.InitDecoding()
+        self.AdvanceDecoding(loglikes)
+        self.FinalizeDecoding()
+
+    def NumFramesDecoded(self):
+        return lib().orc_decoder_num_frames_decoded(self._h)
+
+    def FinalRelativeCost(self):
+        return lib().orc_decoder_final_relative_cost(self._h)
+
+    def GetRawLattice(self):
+        sz = abi.LatticeSize()
+        if lib().orc_decoder_lattice_size(self._h, C.byref(sz)) != 0:
+            return None
+        n, m = sz.num_states, sz.num_arcs
+        fr, hc = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        co, fi = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        arcs = np.zeros(m, abi.LAT_ARC_DTYPE)
+        lib().orc_decoder_get_raw_lattice(self._h, abi.iptr(fr), abi.iptr(hc), abi.fptr(co),
+                                          abi.fptr(fi), arcs.ctypes.data_as(C.c_void_p))
+        return Lattice(sz.start, fr, hc, co, fi, arcs, sz.num_frames)
+
+    def trace(self):
+        n = self.NumFramesDecoded()
+        nt, cu, of = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+        k = lib().orc_decoder_get_trace(self._h, abi.iptr(nt), abi.fptr(cu), abi.fptr(of), n)
+        return nt[:k], cu[:k], of[:k]
+
+    def counters(self):
+        c = np.zeros(8, np.int64)
+        lib().orc_decoder_get_counters(self._h, abi.iptr(c, C.c_int64))
+        return c

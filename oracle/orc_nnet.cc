@@ -1,0 +1,130 @@
+// oracle/orc_nnet.cc -- TEST INFRASTRUCTURE ONLY (CPU oracle; never shipped).
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load it.
+//
+// CPU restatement of the nnet3 inference slice for TDNN(-F) chain models:
+// what DecodableNnetSimple::GetOutputForFrame (nnet3/nnet-am-decodable-simple.cc:
+// 93-276) returns for every subsampled frame, evaluated the most naive way: a
+// memoised recursion over (layer, time) with scalar dot products.
+// PARITY UNPINNED against reference-run outputs: nnet3 cannot be built in this image
+// (base/kaldi-types.h:44 needs <fst/types.h>, base/version.h is generated, no
+// CBLAS headers), and nnet3's own tests are randomized self-consistency tests with
+// no golden vectors (nnet3/nnet-compute-test.cc).  It is cross-checked against an
+// independent float64 numpy evaluation in tests/test_oracle_nnet.py.
+//
+// Component semantics restated:
+//   TdnnComponent::Propagate      nnet3/nnet-tdnn-component.cc:181-212
+//   AffineComponent::Propagate    nnet3/nnet-simple-component.cc:1234-1243
+//   RectifiedLinearComponent      nnet3/nnet-simple-component.cc:957-965
+//   BatchNormComponent test mode  nnet3/nnet-normalize-component.cc:453-464
+//   tdnnf bypass Sum(Scale(s,x),y) steps/libs/nnet3/xconfig/composite_layers.py:201-215
+//   -log_priors, *acoustic_scale  nnet3/nnet-am-decodable-simple.cc:268-271
+//   edge clamping of input frames nnet3/nnet-am-decodable-simple.cc:147-160
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <unordered_map>
+#include <vector>
+
+#include "../include/kaldi_amd.h"
+
+namespace {
+
+struct Eval {
+  const kamd_layer_desc *L;
+  int n_layers, input_dim, T;
+  const float *feats, *ivector;
+  std::vector<std::unordered_map<int, std::vector<float> > > memo;
+
+  const float *Input(int t) const {
+    if (t < 0) t = 0;
+    if (t >= T) t = T - 1;
+    return feats + static_cast<int64_t>(t) * input_dim;
+  }
+  const float *Get(int layer, int t) {
+    if (layer == -1) return Input(t);
+    std::unordered_map<int, std::vector<float> > &m = memo[layer];
+    std::unordered_map<int, std::vector<float> >::iterator it = m.find(t);
+    if (it != m.end()) return it->second.data();
+    const kamd_layer_desc &l = L[layer];
+    int K = l.n_offsets * l.in_dim + l.ivector_dim;
+    std::vector<float> y(l.out_dim);
+    std::vector<const float *> xs(l.n_offsets);
+    for (int i = 0; i < l.n_offsets; i++) xs[i] = Get(l.input_layer, t + l.offsets[i]);
+    const float *z = NULL;
+    if (l.bypass_layer != -2) z = Get(l.bypass_layer, t);
+    for (int o = 0; o < l.out_dim; o++) {
+      const float *w = l.W + static_cast<int64_t>(o) * K;
+      float acc = l.bias ? l.bias[o] : 0.0f;   // bias first, then AddMatMat (:189-210)
+      for (int i = 0; i < l.n_offsets; i++) {
+        const float *x = xs[i], *wi = w + i * l.in_dim;
+        float s = 0.0f;
+        for (int k = 0; k < l.in_dim; k++) s += wi[k] * x[k];
+        acc += s;
+      }
+      if (l.ivector_dim > 0) {
+        const float *wi = w + l.n_offsets * l.in_dim;
+        float s = 0.0f;
+        for (int k = 0; k < l.ivector_dim; k++) s += wi[k] * ivector[k];
+        acc += s;
+      }
+      if (l.relu && acc < 0.0f) acc = 0.0f;
+      if (l.bn_scale) acc = acc * l.bn_scale[o] + l.bn_offset[o];
+      if (z) acc += l.bypass_scale * z[o];
+      if (l.post_offset) acc += l.post_offset[o];
+      acc *= l.post_scale;
+      y[o] = acc;
+    }
+    std::vector<float> &slot = memo[layer][t];
+    slot.swap(y);
+    return slot.data();
+  }
+};
+
+void Context(const kamd_layer_desc *L, int layer, int *left, int *right) {
+  // ComputeSimpleNnetContext (nnet3/nnet-utils.cc:146) for a layer chain.
+  if (layer == -1) { *left = 0; *right = 0; return; }
+  const kamd_layer_desc &l = L[layer];
+  int il, ir;
+  Context(L, l.input_layer, &il, &ir);
+  int mn = 0, mx = 0;
+  for (int i = 0; i < l.n_offsets; i++) {
+    mn = std::min(mn, l.offsets[i]);
+    mx = std::max(mx, l.offsets[i]);
+  }
+  *left = il - mn;
+  *right = ir + mx;
+  if (l.bypass_layer != -2) {
+    int bl, br;
+    Context(L, l.bypass_layer, &bl, &br);
+    *left = std::max(*left, bl);
+    *right = std::max(*right, br);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_nnet_context(const kamd_layer_desc *layers, int n_layers, int *left, int *right) {
+  Context(layers, n_layers - 1, left, right);
+}
+
+int orc_nnet_forward(const kamd_layer_desc *layers, int n_layers, int input_dim,
+                     int subsampling, const float *feats, int T, const float *ivector,
+                     float *out, int out_rows_cap) {
+  if (T <= 0) return 0;
+  int n_out = (T + subsampling - 1) / subsampling;  // nnet-am-decodable-simple.cc:44-46
+  if (n_out > out_rows_cap) return -1;
+  Eval e;
+  e.L = layers; e.n_layers = n_layers; e.input_dim = input_dim; e.T = T;
+  e.feats = feats; e.ivector = ivector;
+  e.memo.resize(n_layers);
+  int P = layers[n_layers - 1].out_dim;
+  for (int i = 0; i < n_out; i++) {
+    const float *y = e.Get(n_layers - 1, i * subsampling);
+    memcpy(out + static_cast<int64_t>(i) * P, y, sizeof(float) * P);
+  }
+  return n_out;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+"""Pins the feature oracle against the reference's own golden vectors:
+feat/feature-mfcc-test.cc UnitTestHTKCompare1..6 and feat/feature-fbank-test.cc
+UnitTestHTKCompare1..4 (same options, same HTK files, same row range; tolerances at
+least as tight as the reference's)."""
+import os
+
+import numpy as np
+import pytest
+
+from kaldi_amd import abi
+from oracle import orc
+from tests.util import GOLDEN, read_htk, read_wav
+
+FEAT = os.path.join(GOLDEN, "feat")
+
+
+def _htk_mfcc_opts(case):
+    op = abi.mfcc_opts_default()            # MfccOptions defaults (feature-mfcc.h:50-58)
+    op.frame.dither = 0.0
+    op.frame.window_type = abi.KAMD_WIN["hamming"]
+    op.frame.remove_dc_offset = 0
+    op.frame.round_to_power_of_two = 1
+    op.htk_compat = 1
+    warp = 1.0
+    if case == 1:      # feature-mfcc-test.cc:130-140
+        op.frame.preemph_coeff = 0.0; op.mel.low_freq = 0.0; op.mel.htk_mode = 1; op.use_energy = 0
+    elif case == 2:    # :215-224
+        op.frame.preemph_coeff = 0.0; op.mel.low_freq = 0.0; op.mel.htk_mode = 1; op.use_energy = 1
+    elif case == 3:    # :299-309
+        op.frame.preemph_coeff = 0.0; op.use_energy = 1; op.mel.low_freq = 20.0; op.mel.htk_mode = 1
+    elif case == 4:    # :384-392 (preemphasis stays at the 0.97 default)
+        op.mel.low_freq = 0.0; op.use_energy = 1; op.mel.htk_mode = 1
+    elif case == 5:    # :467-479 vtln warp 1.1
+        op.use_energy = 1; op.mel.low_freq = 0.0; op.mel.vtln_low = 100.0
+        op.mel.vtln_high = 7500.0; op.mel.htk_mode = 1; warp = 1.1
+    elif case == 6:    # :555-565
+        op.frame.preemph_coeff = 0.97; op.mel.num_bins = 24; op.mel.low_freq = 125.0
+        op.mel.high_freq = 7800.0; op.use_energy = 0
+    return op, warp
+
+
+def mfcc_htk_cases():
+    return [(c,) + _htk_mfcc_opts(c) for c in range(1, 7)]
+
+
+def fbank_htk_cases():
+    out = []
+    for c, low, warp in ((1, 0.0, 1.0), (2, 25.0, 1.0), (3, 25.0, 0.9), (4, 25.0, 1.1)):
+        op = abi.fbank_opts_default()       # feature-fbank-test.cc:132-140, 213-221, 293-305, 379-391
+        op.frame.dither = 0.0; op.frame.preemph_coeff = 0.0
+        op.frame.window_type = abi.KAMD_WIN["hamming"]; op.frame.remove_dc_offset = 0
+        op.frame.round_to_power_of_two = 1; op.mel.low_freq = low; op.htk_compat = 1
+        op.mel.htk_mode = 1; op.use_energy = 0
+        if c >= 3:
+            op.mel.vtln_low = 100.0; op.mel.vtln_high = 7500.0
+        out.append((c, op, warp))
+    return out
+
+
+@pytest.fixture(scope="module")
+def wave():
+    w, sr = read_wav(os.path.join(FEAT, "test.wav"))
+    assert sr == 16000
+    return w
+
+
+@pytest.mark.parametrize("case", range(1, 7))
+def test_mfcc_htk_golden(case, wave):
+    op, warp = _htk_mfcc_opts(case)
+    htk, _ = read_htk(os.path.join(FEAT, "test.wav.fea_htk.%d" % case))
+    got = orc.mfcc(op, wave, warp)
+    assert got.shape[0] == htk.shape[0]
+    C = got.shape[1]
+    # the HTK files hold MFCC_D_A (39 dims); the static 13 are the first columns.
+    d = np.abs(got[10:-10] - htk[10:-10, :C])
+    # reference tolerance is 1.0 absolute (feature-mfcc-test.cc:161); we hold 0.1.
+    assert d.max() < 0.1, d.max()
+
+
+@pytest.mark.parametrize("case,op,warp", fbank_htk_cases())
+def test_fbank_htk_golden(case, op, warp, wave):
+    htk, _ = read_htk(os.path.join(FEAT, "test.wav.fbank_htk.%d" % case))
+    got = orc.fbank(op, wave, warp)
+    assert got.shape == htk.shape
+    d = np.abs(got[10:-10] - htk[10:-10])
+    if case == 3:
+        d = d[:, :20]   # feature-fbank-test.cc:334: "We know the last couple of filterbanks differ"
+    tol = 0.01 if case == 4 else 0.001      # feature-fbank-test.cc:161,242,326,412
+    assert d.max() < tol, d.max()
+
+
+def test_num_frames_rules():
+    """NumFrames / FirstSampleOfFrame (feat/feature-window.cc:28-87)."""
+    op = abi.mfcc_opts_default()
+    L = orc.lib()
+    import ctypes as C
+    assert L.orc_feat_num_frames(C.byref(op.frame), 399) == 0
+    assert L.orc_feat_num_frames(C.byref(op.frame), 400) == 1
+    assert L.orc_feat_num_frames(C.byref(op.frame), 400 + 160 * 7 + 159) == 8
+    op.frame.snip_edges = 0
+    assert L.orc_feat_num_frames(C.byref(op.frame), 16000) == 100
+    assert L.orc_feat_num_frames(C.byref(op.frame), 80) == 1
+    assert L.orc_feat_num_frames(C.byref(op.frame), 79) == 0
+
+
+def test_snip_edges_false_reflection(wave):
+    """snip_edges=false uses reflected samples at both ends (feature-window.cc:191-208):
+    middle frames must agree with snip_edges=true frames shifted by the centre offset."""
+    op = abi.mfcc_opts_hires()
+    a = orc.mfcc(op, wave)
+    op.frame.snip_edges = 0
+    b = orc.mfcc(op, wave)
+    assert b.shape[0] == (wave.size + 80) // 160
+    assert np.isfinite(b).all()
+    # frame f (snip) starts at 160 f; frame g (no snip) starts at 160 g + 80 - 200.
+    # They never coincide exactly; check smoothness instead: neighbours are close.
+    assert np.abs(b[5:-5] - a[4:4 + b.shape[0] - 10]).mean() < np.abs(b[5:-5]).mean()
