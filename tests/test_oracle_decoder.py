@@ -201,7 +201,10 @@ def test_min_active_and_max_active_cutoffs():
     d = orc.Decoder(g, cfg, 1)
     d.Decode(ll)
     ntok, cutoff, off = d.trace()
-    assert (ntok > 0).all() and np.isfinite(cutoff).all()
+    assert (ntok > 0).all()
+    # ntok <= min_active leaves min_active_cutoff at +inf, which is > beam_cutoff, so the
+    # reference returns +inf with an infinite adaptive beam (lattice-faster-decoder.cc:704-718)
+    np.testing.assert_array_equal(np.isinf(cutoff), ntok <= cfg.min_active)
     assert d.GetRawLattice() is not None
 
 

@@ -1,0 +1,70 @@
+"""Cross-checks the nnet oracle (oracle/orc_nnet.cc) against an independent float64 numpy
+evaluation.  No reference-run outputs exist (nnet3 is unbuildable here and its tests are
+self-consistency only), so parity for this stage is 'unpinned' by the task's definition;
+tolerance: 2e-4 relative to the output scale (fp32 accumulation-order noise)."""
+import numpy as np
+import pytest
+
+from kaldi_amd import nnet
+from oracle import orc
+from tests.nnet_ref import forward_f64
+
+
+@pytest.mark.parametrize("T", [1, 2, 17, 50, 101])
+@pytest.mark.parametrize("ivec", [0, 10])
+def test_oracle_nnet_vs_f64(T, ivec):
+    m = nnet.tdnnf_tiny(num_pdfs=50, ivector_dim=ivec, seed=T + ivec)
+    rng = np.random.default_rng(T)
+    feats = rng.standard_normal((T, m.input_dim)).astype(np.float32) * 3
+    iv = rng.standard_normal(ivec).astype(np.float32) if ivec else None
+    got = orc.nnet_forward(m, feats, iv)
+    ref = forward_f64(m, feats, iv)
+    assert got.shape == ref.shape == ((T + 2) // 3, 50)
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() < 2e-4 * scale
+
+
+def test_context_matches_recipe_topologies():
+    """ComputeSimpleNnetContext: 1 + 3*1 + 0 + 12*3 = 40 for run_tdnn_1d."""
+    assert nnet.tdnnf_librispeech(num_pdfs=16).context() == (40, 40)
+    assert nnet.tdnnf_mini_librispeech(num_pdfs=16).context() == (28, 28)
+    m = nnet.tdnnf_tiny()
+    assert orc.nnet_context(m) == m.context() == (8, 8)
+
+
+def test_macs_per_output_frame_matches_survey_appendix_b():
+    """~23.5 M MAC per output frame for the 1d topology with P=6000
+    (the appendix omits the ivector columns of lda; we build without ivector here)."""
+    m = nnet.tdnnf_librispeech(num_pdfs=6000)
+    macs = m.macs_per_output_frame()
+    assert 22.0e6 < macs < 25.0e6, macs
+
+
+def test_chunk_invariance():
+    """Whole-utterance evaluation == per-chunk evaluation with clamped context
+    (what DecodableNnetSimple does chunk by chunk, frames_per_chunk=51)."""
+    m = nnet.tdnnf_tiny(num_pdfs=20)
+    rng = np.random.default_rng(0)
+    T = 120
+    feats = rng.standard_normal((T, 40)).astype(np.float32)
+    whole = orc.nnet_forward(m, feats)
+    left, right = m.context()
+    out = []
+    for s in range(0, (T + 2) // 3, 17):
+        n = min(17, (T + 2) // 3 - s)
+        first_out, last_out = 3 * s, 3 * (s + n - 1)
+        t = np.clip(np.arange(first_out - left, last_out + right + 1), 0, T - 1)
+        chunk = orc.nnet_forward(m, feats[t])             # chunk-local time 0 == first input row
+        # chunk-local output rows are at local t = left + 3k; the oracle evaluates at 0,3,6..
+        # so shift: evaluate on a chunk whose first row is time first_out-left and read rows
+        # (left + 3k)/3 only when left % 3 == 0; otherwise re-evaluate with padding.
+        assert left % 3 != 0 or True
+        padl = (-left) % 3
+        tt = np.clip(np.arange(first_out - left - padl, last_out + right + 1), 0, T - 1)
+        chunk = orc.nnet_forward(m, feats[tt])
+        k0 = (left + padl) // 3
+        out.append(chunk[k0:k0 + n])
+    chunked = np.concatenate(out)
+    # interior chunks see clamped-at-chunk-edge inputs only where the utterance itself is
+    # clamped, so results are identical up to fp32 summation order (none here: same code).
+    np.testing.assert_allclose(chunked, whole, rtol=0, atol=1e-5)
