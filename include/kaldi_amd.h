@@ -17,6 +17,7 @@
 #ifndef KALDI_AMD_H_
 #define KALDI_AMD_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -35,6 +36,13 @@ const char *kamd_last_error(void);
 int kamd_device_count(void);
 int kamd_set_device(int device);
 const char *kamd_version(void);
+/* HBM buffers for host languages without HIP bindings (cgo / JNI / ctypes callers):
+ * thin hipMalloc / hipFree / hipMemcpy wrappers.  Blocking. */
+void *kamd_malloc(size_t bytes);
+int kamd_free(void *d_ptr);
+int kamd_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
+int kamd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
+int kamd_device_synchronize(void);
 
 /* -------------------------------------------------------------- features -- */
 /* feat/feature-window.h:40-66 FrameExtractionOptions (same defaults). */

@@ -1,0 +1,120 @@
+"""Loader for the C-ABI shared library (kaldi_amd/lib/libkaldi_amd.so).
+
+The HIP library IS the product: if it is missing or cannot be loaded this module raises
+-- there is no CPU fallback anywhere in the package.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkaldi_amd.so")
+_LIB = None
+
+
+class KamdError(RuntimeError):
+    """Raised for a non-zero C-ABI status (mirrors KALDI_ERR -> KaldiFatalError,
+    base/kaldi-error.h:89-140)."""
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise KamdError("HIP library %s is missing: run `python -c 'import __graft_entry__ as g; "
+                        "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    fp, ip, i64p = C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    vp = C.c_void_p
+
+    def sig(name, res, args):
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+
+    sig("kamd_last_error", C.c_char_p, [])
+    sig("kamd_version", C.c_char_p, [])
+    sig("kamd_device_count", C.c_int, [])
+    sig("kamd_set_device", C.c_int, [C.c_int])
+    sig("kamd_malloc", vp, [C.c_size_t])
+    sig("kamd_free", C.c_int, [vp])
+    sig("kamd_memcpy_h2d", C.c_int, [vp, vp, C.c_size_t])
+    sig("kamd_memcpy_d2h", C.c_int, [vp, vp, C.c_size_t])
+    sig("kamd_device_synchronize", C.c_int, [])
+    sig("kamd_mfcc_opts_default", None, [C.POINTER(abi.MfccOpts)])
+    sig("kamd_fbank_opts_default", None, [C.POINTER(abi.FbankOpts)])
+    sig("kamd_mfcc_create", vp, [C.POINTER(abi.MfccOpts), C.c_float])
+    sig("kamd_fbank_create", vp, [C.POINTER(abi.FbankOpts), C.c_float])
+    sig("kamd_feat_destroy", None, [vp])
+    sig("kamd_feat_dim", C.c_int, [vp])
+    sig("kamd_feat_num_frames", C.c_int, [vp, C.c_int64])
+    sig("kamd_feat_compute", C.c_int, [vp, fp, C.c_int64, fp, C.c_int])
+    sig("kamd_feat_compute_batch_device", C.c_int, [vp, vp, i64p, C.c_int, vp, i64p, C.c_int, vp])
+    sig("kamd_nnet_create", vp, [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int])
+    sig("kamd_nnet_destroy", None, [vp])
+    sig("kamd_nnet_output_dim", C.c_int, [vp])
+    sig("kamd_nnet_left_context", C.c_int, [vp])
+    sig("kamd_nnet_right_context", C.c_int, [vp])
+    sig("kamd_nnet_num_output_frames", C.c_int, [vp, C.c_int])
+    sig("kamd_nnet_forward_batch_device", C.c_int, [vp, vp, i64p, C.c_int, vp, C.c_int, vp, i64p, C.c_int, vp])
+    sig("kamd_nnet_forward", C.c_int, [vp, fp, C.c_int, fp, fp, C.c_int])
+    sig("kamd_nnet_last_flops", C.c_double, [vp])
+    sig("kamd_graph_create", vp, [C.c_int32, C.c_int32, i64p, vp, fp])
+    sig("kamd_graph_destroy", None, [vp])
+    sig("kamd_graph_num_states", C.c_int32, [vp])
+    sig("kamd_graph_num_arcs", C.c_int64, [vp])
+    sig("kamd_decoder_config_default", None, [C.POINTER(abi.DecoderConfig)])
+    sig("kamd_decoder_sizes_default", None, [C.POINTER(abi.DecoderSizes)])
+    sig("kamd_decoder_create", vp, [vp, C.POINTER(abi.DecoderConfig), C.POINTER(abi.DecoderSizes), ip, C.c_int32])
+    sig("kamd_decoder_destroy", None, [vp])
+    sig("kamd_decoder_set_options", C.c_int, [vp, C.POINTER(abi.DecoderConfig)])
+    sig("kamd_decoder_init", C.c_int, [vp, ip, C.c_int, vp])
+    sig("kamd_decoder_advance", C.c_int, [vp, C.POINTER(abi.DecodeTask), C.c_int, vp])
+    sig("kamd_decoder_finalize", C.c_int, [vp, ip, C.c_int, vp])
+    sig("kamd_decoder_sync", C.c_int, [vp])
+    sig("kamd_decoder_num_frames_decoded", C.c_int, [vp, C.c_int])
+    sig("kamd_decoder_final_relative_cost", C.c_float, [vp, C.c_int])
+    sig("kamd_decoder_reached_final", C.c_int, [vp, C.c_int])
+    sig("kamd_decoder_lattice_size", C.c_int, [vp, C.c_int, C.POINTER(abi.LatticeSize)])
+    sig("kamd_decoder_get_raw_lattice", C.c_int, [vp, C.c_int, ip, ip, fp, fp, vp])
+    sig("kamd_decoder_best_path", C.c_int, [vp, C.c_int, ip, C.c_int, ip, ip, C.c_int, ip, fp, fp])
+    sig("kamd_decoder_get_trace", C.c_int, [vp, C.c_int, ip, fp, fp, C.c_int])
+    sig("kamd_decoder_get_counters", C.c_int, [vp, C.c_int, i64p])
+    sig("kamd_decoder_last_advance_ms", C.c_float, [vp])
+    sig("kamd_pipeline_create", vp, [vp, vp, vp])
+    sig("kamd_pipeline_destroy", None, [vp])
+    sig("kamd_pipeline_load_batch", C.c_int, [vp, fp, i64p, C.c_int])
+    sig("kamd_pipeline_run", C.c_int, [vp, fp])
+    sig("kamd_pipeline_get_loglikes", C.c_int, [vp, C.c_int, fp, C.c_int, ip, ip])
+    sig("kamd_pipeline_get_features", C.c_int, [vp, C.c_int, fp, C.c_int, ip, ip])
+    _LIB = L
+    return L
+
+
+EXPORTS = """kamd_malloc kamd_free kamd_memcpy_h2d kamd_memcpy_d2h kamd_device_synchronize kamd_last_error kamd_version kamd_device_count kamd_set_device kamd_mfcc_opts_default
+kamd_fbank_opts_default kamd_mfcc_create kamd_fbank_create kamd_feat_destroy kamd_feat_dim
+kamd_feat_num_frames kamd_feat_compute kamd_feat_compute_batch_device kamd_nnet_create
+kamd_nnet_destroy kamd_nnet_output_dim kamd_nnet_left_context kamd_nnet_right_context
+kamd_nnet_num_output_frames kamd_nnet_forward_batch_device kamd_nnet_forward kamd_nnet_last_flops
+kamd_graph_create kamd_graph_destroy kamd_graph_num_states kamd_graph_num_arcs
+kamd_decoder_config_default kamd_decoder_sizes_default kamd_decoder_create kamd_decoder_destroy
+kamd_decoder_set_options kamd_decoder_init kamd_decoder_advance kamd_decoder_finalize
+kamd_decoder_sync kamd_decoder_num_frames_decoded kamd_decoder_final_relative_cost
+kamd_decoder_reached_final kamd_decoder_lattice_size kamd_decoder_get_raw_lattice
+kamd_decoder_best_path kamd_decoder_get_trace kamd_decoder_get_counters
+kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch
+kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features""".split()
+
+
+def check(rc):
+    if rc is None or (isinstance(rc, int) and rc < 0):
+        raise KamdError(lib().kamd_last_error().decode())
+    return rc
+
+
+def require_gpu():
+    n = lib().kamd_device_count()
+    if n <= 0:
+        raise KamdError("no HIP device visible: the kaldi_amd hot path only runs on an MI355X")
+    return n

@@ -1,0 +1,1250 @@
+// decoder.hip -- LatticeFasterDecoder token passing on gfx950.
+//
+// Replaces LatticeFasterDecoderTpl<FST, StdToken> (decoder/lattice-faster-decoder.cc):
+// InitDecoding :56, AdvanceDecoding :593, GetCutoff :657, ProcessEmitting :727,
+// ProcessNonemitting :833, FindOrAddToken :266, PruneForwardLinks(Final) :312/:389,
+// FinalizeDecoding :638, GetRawLattice :113 -- and the HashList it runs on
+// (util/hash-list-inl.h).
+//
+// MI355X design
+//   * one decoder instance ("lane") = one persistent 1024-thread workgroup = one CU.
+//     Utterances are independent, so a launch carries one workgroup per utterance and
+//     the whole frame loop runs inside the kernel: no host round trip and no
+//     inter-workgroup synchronisation per frame; phases are separated by workgroup
+//     barriers only.  256 CUs => 256 utterances decode concurrently.
+//   * HCLG in HBM as two CSRs (emitting / epsilon) of 16-byte fst::StdArc records; a
+//     state's arcs are one contiguous (coalesced) run; hub states are expanded by a
+//     whole wavefront (64 arcs per load instruction).
+//   * state -> token map of the frame: open-addressing table of packed 64-bit
+//     {state, order-preserving cost}; insert = CAS, recombination = atomicMin_u64.
+//   * beam cutoff: min-reduce + counting pass; max-active / min-active by an exact
+//     LDS-histogram radix select (4 x 8 bit) -- the value std::nth_element returns.
+//   * token / forward-link arenas are append-only (wavefront-ballot allocation) and
+//     sized for HBM3E; lattice pruning is ONE exact backward sweep at finalize (the
+//     reference's periodic PruneActiveTokens is provably conservative).
+//   * results are order independent and bit-exact against oracle mode 1.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace kamd {
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+#define NT 1024
+#define NWAVES (NT / 64)
+#define BIGCAP 3072
+#define SMALL_DEG 4
+#define EMPTY64 0xFFFFFFFFFFFFFFFFull
+
+enum { ERR_HASH = 1, ERR_TOK = 2, ERR_LINK = 4, ERR_FRAMES = 8, ERR_WL = 16, ERR_INTERNAL = 32 };
+
+struct GraphDev {
+  int num_states, start;
+  const uint2 *off;       // [S+1]: .x emitting arc offset, .y epsilon arc offset
+  const kamd_arc *e_arcs; // emitting arcs (ilabel != 0)
+  const kamd_arc *n_arcs; // epsilon arcs (ilabel == 0)
+  const float *final;     // [S]
+};
+
+struct Link { int src, dst, ilabel, olabel; float graph, ac; };  // 24 B
+
+struct LaneState {
+  int frame;            // NumFramesDecoded()
+  int tok_used, lnk_used;
+  u32 round;
+  int error;
+  int finalized;
+  float final_relative_cost, final_best_cost;
+  int out_ntok, out_nlink, out_start;
+  int pad;
+  long long counters[8];
+};
+
+struct DecDev {
+  GraphDev g;
+  const int *tid2pdf;   // NULL => pdf = ilabel - 1
+  kamd_decoder_config cfg;
+  int hash_cap, hash_mask, max_frames;
+  int arena_tokens, arena_links;
+  u64 *H; u32 *slots; int *slot_tok; u32 *stamp; u32 *wl;  // per lane: hash_cap (wl: 2x)
+  int *tok_state; float *tok_cost; float *tok_extra; int *tok_map;  // per lane: arena_tokens
+  Link *links;                                                      // per lane: arena_links
+  int *tok_off;        // per lane: max_frames + 2
+  int *lnk_off;        // per lane: 2 * (max_frames + 2) + 1
+  float *cost_offsets; // per lane: max_frames + 1
+  int *trace_ntok; float *trace_cutoff;  // per lane: max_frames + 1
+  float *scratch;      // per lane: 2 * hash_cap
+  LaneState *st;
+};
+
+// per-lane view
+struct Ctx {
+  u64 *H; u32 *slots; int *slot_tok; u32 *stamp; u32 *wl0, *wl1;
+  int *tok_state; float *tok_cost; float *tok_extra; int *tok_map;
+  Link *links; int *tok_off; int *lnk_off; float *cost_offsets; int *trace_ntok;
+  float *trace_cutoff; float *scratch; LaneState *st;
+};
+
+__device__ inline Ctx MakeCtx(const DecDev &d, int lane) {
+  Ctx c;
+  size_t hc = d.hash_cap, at = d.arena_tokens, al = d.arena_links, mf = d.max_frames;
+  c.H = d.H + lane * hc; c.slots = d.slots + lane * hc; c.slot_tok = d.slot_tok + lane * hc;
+  c.stamp = d.stamp + lane * hc; c.wl0 = d.wl + lane * 2 * hc; c.wl1 = c.wl0 + hc;
+  c.tok_state = d.tok_state + lane * at; c.tok_cost = d.tok_cost + lane * at;
+  c.tok_extra = d.tok_extra + lane * at; c.tok_map = d.tok_map + lane * at;
+  c.links = d.links + lane * al; c.tok_off = d.tok_off + lane * (mf + 2);
+  c.lnk_off = d.lnk_off + lane * (2 * (mf + 2) + 1);
+  c.cost_offsets = d.cost_offsets + lane * (mf + 1);
+  c.trace_ntok = d.trace_ntok + lane * (mf + 1); c.trace_cutoff = d.trace_cutoff + lane * (mf + 1);
+  c.scratch = d.scratch + lane * 2 * hc; c.st = d.st + lane;
+  return c;
+}
+
+struct Sh {  // workgroup-shared state
+  u64 red64[NWAVES];
+  int redi[NWAVES];
+  int redj[NWAVES];
+  float redf[NWAVES];
+  u32 hist[256];
+  u32 next_cutoff_u;
+  int n_slots, n_links, wl_n[2], err, bigcnt, changed;
+  int sel_bin, sel_below;
+  int scan_total;
+  int big_tok[BIGCAP];
+  long long cnt[8];
+};
+
+// ---------------------------------------------------------------- primitives
+__device__ inline u64 LoadH(const u64 *p) {  // L1-bypassing load: the table is written by L2 atomics
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline u32 HashState(int s, int mask) {
+  return (static_cast<u32>(s) * 2654435761u >> 7) & static_cast<u32>(mask);
+}
+__device__ inline u64 Pack(int state, float cost) {
+  return (static_cast<u64>(static_cast<u32>(state)) << 32) | FloatToOrdered(cost);
+}
+__device__ inline float CostOf(u64 e) { return OrderedToFloat(static_cast<u32>(e)); }
+__device__ inline int StateOf(u64 e) { return static_cast<int>(e >> 32); }
+
+// one slot from a workgroup counter for every ACTIVE lane of the wavefront (call under
+// the predicate): wavefront-ballot aggregation => one LDS atomic per wavefront.
+__device__ inline int WaveAlloc(int *counter) {
+  const u64 m = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll(static_cast<long long>(m)) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader, 64);
+  return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+__device__ inline u64 BlockMin64(u64 v, Sh *sh) {
+  for (int o = 32; o > 0; o >>= 1) {
+    u64 t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh->red64[threadIdx.x >> 6] = v;
+  __syncthreads();
+  u64 r = sh->red64[0];
+  for (int i = 1; i < NWAVES; i++) r = sh->red64[i] < r ? sh->red64[i] : r;
+  return r;
+}
+__device__ inline void BlockSum2(int &a, int &b, Sh *sh) {
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sh->redi[threadIdx.x >> 6] = a; sh->redj[threadIdx.x >> 6] = b; }
+  __syncthreads();
+  a = 0; b = 0;
+  for (int i = 0; i < NWAVES; i++) { a += sh->redi[i]; b += sh->redj[i]; }
+}
+__device__ inline float BlockMinF(float v, Sh *sh) {
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh->redf[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh->redf[0];
+  for (int i = 1; i < NWAVES; i++) r = fminf(r, sh->redf[i]);
+  return r;
+}
+// deterministic (index ordered) exclusive scan of a 0/1 flag over the workgroup
+__device__ inline int BlockScanFlag(bool f, int *total, Sh *sh) {
+  const u64 m = __ballot(f);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh->redi[w] = __popcll(m);
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int i = 0; i < NWAVES; i++) { int c = sh->redi[i]; if (i < w) base += c; tot += c; }
+  *total = tot;
+  return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
+// wavefront-aggregated histogram add (costs of one frame cluster in few digits)
+__device__ inline void WaveHistAdd(u32 *hist, int bin, bool active) {
+  u64 todo = __ballot(active);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    const int leader = __ffsll(static_cast<long long>(todo)) - 1;
+    const int lb = __shfl(bin, leader, 64);
+    const u64 same = __ballot(active && bin == lb);
+    if (lane == leader) atomicAdd(&hist[lb], static_cast<u32>(__popcll(same)));
+    todo &= ~same;
+    if (bin == lb) active = false;
+  }
+}
+
+// exact k-th smallest (0-based) of cost[0..n): the value std::nth_element leaves at
+// position k (lattice-faster-decoder.cc:693-697, 707-712).  4-pass 8-bit radix select
+// on order-preserving keys with an LDS histogram.
+__device__ float BlockSelectKth(const float *cost, int n, int k, Sh *sh) {
+  u32 prefix = 0, mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    __syncthreads();
+    if (threadIdx.x < 256) sh->hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += NT) {
+      int i = base + threadIdx.x;
+      bool act = false; int bin = 0;
+      if (i < n) {
+        u32 key = FloatToOrdered(cost[i]);
+        act = (key & mask) == prefix;
+        bin = (key >> shift) & 255;
+      }
+      WaveHistAdd(sh->hist, bin, act);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int cum = 0, b = 0;
+      for (; b < 256; b++) { int c = sh->hist[b]; if (cum + c > k) break; cum += c; }
+      sh->sel_bin = b; sh->sel_below = cum;
+    }
+    __syncthreads();
+    prefix |= static_cast<u32>(sh->sel_bin) << shift;
+    mask |= 255u << shift;
+    k -= sh->sel_below;
+  }
+  return OrderedToFloat(prefix);
+}
+
+// FindOrAddToken (lattice-faster-decoder.cc:266-306) on the frame's table.
+// returns slot (or -1 on overflow); *improved = created, or strictly lowered the cost.
+__device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int state, float cost,
+                                 bool *improved) {
+  const u64 mine = Pack(state, cost);
+  u32 h = HashState(state, d.hash_mask);
+  for (int probe = 0; probe < d.hash_cap; probe++) {
+    u64 cur = LoadH(&c.H[h]);
+    if (cur == EMPTY64) {
+      u64 old = atomicCAS(&c.H[h], EMPTY64, mine);
+      if (old == EMPTY64) {
+        int idx = WaveAlloc(&sh->n_slots);
+        if (idx < d.hash_cap) c.slots[idx] = h; else sh->err = ERR_HASH;
+        *improved = true;
+        return static_cast<int>(h);
+      }
+      cur = old;
+    }
+    if (StateOf(cur) == state) {
+      u64 old = atomicMin(&c.H[h], mine);
+      *improved = old > mine;
+      return static_cast<int>(h);
+    }
+    h = (h + 1) & static_cast<u32>(d.hash_mask);
+  }
+  sh->err = ERR_HASH;
+  *improved = false;
+  return -1;
+}
+__device__ inline int HashFind(const DecDev &d, const Ctx &c, int state) {
+  u32 h = HashState(state, d.hash_mask);
+  for (int probe = 0; probe < d.hash_cap; probe++) {
+    u64 cur = LoadH(&c.H[h]);
+    if (cur == EMPTY64) return -1;
+    if (StateOf(cur) == state) return static_cast<int>(h);
+    h = (h + 1) & static_cast<u32>(d.hash_mask);
+  }
+  return -1;
+}
+
+__device__ inline float LogLike(const DecDev &d, const float *ll, int ilabel) {
+  // DecodableMatrixMapped::LogLikelihood (decoder/decodable-matrix.cc:62-69)
+  const int pdf = d.tid2pdf ? d.tid2pdf[ilabel] : ilabel - 1;
+  return ll[pdf];
+}
+
+// one emitting arc of one expanded token (lattice-faster-decoder.cc:791-809)
+__device__ inline void ProcessArc(const DecDev &d, const Ctx &c, Sh *sh, const float *ll,
+                                  const kamd_arc &arc, int src_tok, float cur_cost,
+                                  float cost_offset, float adaptive_beam, int link_base) {
+  const float ac_cost = cost_offset - LogLike(d, ll, arc.ilabel);
+  const float graph_cost = arc.weight;
+  const float tot_cost = cur_cost + ac_cost + graph_cost;
+  const float nc = OrderedToFloat(sh->next_cutoff_u);   // running bound (conservative)
+  if (tot_cost > nc) return;
+  const float cand = tot_cost + adaptive_beam;
+  if (cand < nc) atomicMin(&sh->next_cutoff_u, FloatToOrdered(cand));
+  bool improved;
+  const int slot = HashInsert(d, c, sh, arc.nextstate, tot_cost, &improved);
+  if (slot < 0) return;
+  const int li = link_base + WaveAlloc(&sh->n_links);
+  if (li >= d.arena_links) { sh->err = ERR_LINK; return; }
+  Link L; L.src = src_tok; L.dst = slot; L.ilabel = arc.ilabel; L.olabel = arc.olabel;
+  L.graph = graph_cost; L.ac = ac_cost;
+  c.links[li] = L;
+}
+
+// ProcessNonemitting (lattice-faster-decoder.cc:833-899) as a fixpoint relaxation, then
+// commit the frame: compact surviving tokens into the arena, resolve emitting links,
+// emit epsilon links, clear the table.  'list' is the token-list index being created.
+__device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff, int list,
+                            int emit_link_begin) {
+  const int tid = threadIdx.x;
+  LaneState *S = c.st;
+  __syncthreads();
+  // ---- epsilon closure: initial worklist = every token with epsilon arcs (:855-859)
+  {
+    const int ns = min(sh->n_slots, d.hash_cap);
+    for (int i = tid; i < ns; i += NT) {
+      const u32 slot = c.slots[i];
+      const u64 e = LoadH(&c.H[slot]);
+      const int s = StateOf(e);
+      const uint2 o0 = d.g.off[s], o1 = d.g.off[s + 1];
+      if (o1.y > o0.y && CostOf(e) <= cutoff) {
+        int p = WaveAlloc(&sh->wl_n[0]);
+        c.wl0[p] = slot;
+      }
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  u32 round = S->round;
+  while (sh->wl_n[cur] > 0) {   // uniform
+    round++;
+    const int nw = sh->wl_n[cur];
+    const u32 *wl_cur = cur ? c.wl1 : c.wl0;
+    u32 *wl_nxt = cur ? c.wl0 : c.wl1;
+    for (int i = tid; i < nw; i += NT) {
+      const u32 slot = wl_cur[i];
+      const u64 e = LoadH(&c.H[slot]);
+      const float cur_cost = CostOf(e);
+      if (cur_cost > cutoff) continue;      // :867
+      const int s = StateOf(e);
+      const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
+      for (u32 a = a0; a < a1; a++) {
+        const kamd_arc arc = d.g.n_arcs[a];
+        const float tot_cost = cur_cost + arc.weight;
+        if (tot_cost < cutoff) {            // :882
+          bool improved;
+          const int slot2 = HashInsert(d, c, sh, arc.nextstate, tot_cost, &improved);
+          if (slot2 >= 0 && improved) {
+            const uint2 p0 = d.g.off[arc.nextstate], p1 = d.g.off[arc.nextstate + 1];
+            if (p1.y > p0.y && atomicExch(&c.stamp[slot2], round) != round) {
+              int p = WaveAlloc(&sh->wl_n[cur ^ 1]);
+              if (p < d.hash_cap) wl_nxt[p] = static_cast<u32>(slot2); else sh->err = ERR_WL;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) sh->wl_n[cur] = 0;
+    cur ^= 1;
+    __syncthreads();
+    if (sh->err) break;
+  }
+  // ---- compaction: tokens with final cost <= cutoff become list 'list'
+  const int tok_base = c.tok_off[list];
+  const int ns = min(sh->n_slots, d.hash_cap);
+  int running = 0;
+  for (int base = 0; base < ns; base += NT) {
+    const int i = base + tid;
+    u32 slot = 0; u64 e = 0; bool keep = false;
+    if (i < ns) {
+      slot = c.slots[i];
+      e = LoadH(&c.H[slot]);
+      keep = CostOf(e) <= cutoff;
+    }
+    int total;
+    const int pos = BlockScanFlag(keep, &total, sh);
+    if (i < ns) {
+      int idx = -1;
+      if (keep) {
+        idx = tok_base + running + pos;
+        if (idx < d.arena_tokens) {
+          c.tok_state[idx] = StateOf(e);
+          c.tok_cost[idx] = CostOf(e);
+          c.tok_extra[idx] = 0.0f;
+        } else { sh->err = ERR_TOK; idx = -1; }
+      }
+      c.slot_tok[slot] = idx;
+    }
+    running += total;
+  }
+  const int n_new = running;
+  __syncthreads();
+  // ---- emitting links: keep iff the arc's own tot <= final cutoff; slot -> token
+  int k_surv = 0;
+  {
+    const int lb = emit_link_begin, le = emit_link_begin + sh->n_links;
+    for (int li = lb + tid; li < min(le, d.arena_links); li += NT) {
+      Link L = c.links[li];
+      const float tot = c.tok_cost[L.src] + L.ac + L.graph;
+      const bool valid = tot <= cutoff;
+      c.links[li].dst = valid ? c.slot_tok[L.dst] : -1;
+      k_surv += valid;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { sh->n_links = 0; }
+  __syncthreads();
+  // ---- epsilon links of the surviving tokens (final costs), :875-897
+  const int eps_link_begin = c.lnk_off[2 * list + 1];
+  int a_eps = 0;
+  for (int t = tok_base + tid; t < min(tok_base + n_new, d.arena_tokens); t += NT) {
+    const int s = c.tok_state[t];
+    const float cur_cost = c.tok_cost[t];
+    const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
+    a_eps += static_cast<int>(a1 - a0);
+    for (u32 a = a0; a < a1; a++) {
+      const kamd_arc arc = d.g.n_arcs[a];
+      const float tot_cost = cur_cost + arc.weight;
+      if (tot_cost < cutoff) {
+        const int slot2 = HashFind(d, c, arc.nextstate);
+        const int dst = slot2 >= 0 ? c.slot_tok[slot2] : -1;
+        if (dst < 0) { sh->err = ERR_INTERNAL; continue; }
+        const int li = eps_link_begin + WaveAlloc(&sh->n_links);
+        if (li >= d.arena_links) { sh->err = ERR_LINK; continue; }
+        Link L; L.src = t; L.dst = dst; L.ilabel = 0; L.olabel = arc.olabel;
+        L.graph = arc.weight; L.ac = 0.0f;
+        c.links[li] = L;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- clear the table, publish offsets and counters
+  for (int i = tid; i < ns; i += NT) c.H[c.slots[i]] = EMPTY64;
+  BlockSum2(k_surv, a_eps, sh);
+  if (tid == 0) {
+    const int n_eps_links = sh->n_links;
+    c.tok_off[list + 1] = tok_base + n_new;
+    c.lnk_off[2 * list + 2] = eps_link_begin + n_eps_links;
+    S->tok_used = tok_base + n_new;
+    S->lnk_used = eps_link_begin + n_eps_links;
+    S->round = round;
+    sh->cnt[1] += a_eps;                 // A_exp: epsilon arcs of surviving tokens
+    sh->cnt[3] += k_surv;                // K_surv
+    sh->cnt[4] += k_surv + n_eps_links;  // L_kept
+    sh->cnt[5] += n_new;                 // N_tok
+    sh->n_slots = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0;
+  }
+  __syncthreads();
+}
+
+// ComputeFinalCosts (lattice-faster-decoder.cc:549-590) over token list 'list'
+__device__ void FinalCosts(const DecDev &d, const Ctx &c, Sh *sh, int list, float *best_cost,
+                           float *best_with_final) {
+  const int tb = c.tok_off[list], te = c.tok_off[list + 1];
+  float b = INFINITY, bf = INFINITY;
+  for (int t = tb + threadIdx.x; t < te; t += NT) {
+    const float cost = c.tok_cost[t];
+    const float fc = d.g.final[c.tok_state[t]];
+    b = fminf(b, cost);
+    bf = fminf(bf, cost + fc);
+  }
+  *best_cost = BlockMinF(b, sh);
+  *best_with_final = BlockMinF(bf, sh);
+}
+
+__device__ void PublishLaneEnd(const DecDev &d, const Ctx &c, Sh *sh, int frame) {
+  float b, bf;
+  FinalCosts(d, c, sh, frame, &b, &bf);
+  if (threadIdx.x == 0) {
+    LaneState *S = c.st;
+    S->frame = frame;
+    S->final_relative_cost = (b == INFINITY && bf == INFINITY) ? INFINITY : bf - b;  // :574-582
+    S->error |= sh->err;
+    for (int i = 0; i < 8; i++) S->counters[i] += sh->cnt[i];
+  }
+}
+
+__device__ inline void InitSh(Sh *sh) {
+  if (threadIdx.x == 0) {
+    sh->n_slots = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
+    sh->bigcnt = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
+    for (int i = 0; i < 8; i++) sh->cnt[i] = 0;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ kernels
+// InitDecoding (lattice-faster-decoder.cc:56-73): start token + ProcessNonemitting(beam)
+__global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
+  __shared__ Sh sh;
+  const int lane = lanes[blockIdx.x];
+  const Ctx c = MakeCtx(d, lane);
+  InitSh(&sh);
+  LaneState *S = c.st;
+  if (threadIdx.x == 0) {
+    S->frame = 0; S->tok_used = 0; S->lnk_used = 0; S->error = 0; S->finalized = 0;
+    S->final_relative_cost = INFINITY; S->final_best_cost = INFINITY;
+    S->out_ntok = 0; S->out_nlink = 0; S->out_start = -1;
+    for (int i = 0; i < 8; i++) S->counters[i] = 0;
+    c.tok_off[0] = 0; c.lnk_off[0] = 0; c.lnk_off[1] = 0;
+    bool imp;
+    HashInsert(d, c, &sh, d.g.start, 0.0f, &imp);
+  }
+  __syncthreads();
+  CommitFrame(d, c, &sh, d.cfg.beam, 0, 0);
+  PublishLaneEnd(d, c, &sh, 0);
+}
+
+// AdvanceDecoding (lattice-faster-decoder.cc:593-632): the frame loop of one lane.
+__global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_task *tasks) {
+  __shared__ Sh sh;
+  const kamd_decode_task task = tasks[blockIdx.x];
+  const Ctx c = MakeCtx(d, task.lane);
+  const int tid = threadIdx.x;
+  InitSh(&sh);
+  LaneState *S = c.st;
+  int frame = S->frame;
+  if (S->error || S->finalized) return;
+  const kamd_decoder_config cfg = d.cfg;
+  for (int it = 0; it < task.n_frames; it++, frame++) {
+    if (frame >= d.max_frames) { if (tid == 0) sh.err = ERR_FRAMES; __syncthreads(); break; }
+    const float *ll = task.d_loglikes + static_cast<size_t>(it) * task.ld;
+    const int tb = c.tok_off[frame], n = c.tok_off[frame + 1] - tb;
+    const float *cost = c.tok_cost + tb;
+    const int *state = c.tok_state + tb;
+    // ---- GetCutoff (:657-724): best token (ties -> smallest state, as oracle mode 1)
+    u64 key = EMPTY64;
+    for (int i = tid; i < n; i += NT) {
+      u64 k = (static_cast<u64>(FloatToOrdered(cost[i])) << 32) | static_cast<u32>(state[i]);
+      key = k < key ? k : key;
+    }
+    key = BlockMin64(key, &sh);
+    float best = INFINITY; int best_state = -1;
+    if (n > 0) { best = OrderedToFloat(static_cast<u32>(key >> 32)); best_state = static_cast<int>(key & 0xFFFFFFFFu); }
+    float cur_cutoff, adaptive_beam;
+    const float beam_cutoff = best + cfg.beam;
+    if (cfg.max_active == 2147483647 && cfg.min_active == 0) {
+      cur_cutoff = beam_cutoff; adaptive_beam = cfg.beam;
+    } else {
+      int c_lt = 0, c_le = 0;
+      for (int i = tid; i < n; i += NT) { float w = cost[i]; c_lt += w < beam_cutoff; c_le += w <= beam_cutoff; }
+      BlockSum2(c_lt, c_le, &sh);
+      // nth_element(max_active) < beam_cutoff  <=>  more than max_active costs < beam_cutoff
+      if (n > cfg.max_active && c_lt > cfg.max_active) {
+        const float mac = BlockSelectKth(cost, n, cfg.max_active, &sh);
+        adaptive_beam = mac - best + cfg.beam_delta;   // :700-702
+        cur_cutoff = mac;
+      } else {
+        float mic = INFINITY;
+        if (n > cfg.min_active) {
+          if (cfg.min_active == 0) mic = best;
+          else if (c_le <= cfg.min_active) mic = BlockSelectKth(cost, n, cfg.min_active, &sh);
+          else mic = -INFINITY;  // nth_element(min_active) <= beam_cutoff: not looser than the beam
+        }
+        if (mic > beam_cutoff) { adaptive_beam = mic - best + cfg.beam_delta; cur_cutoff = mic; }  // :715-718
+        else { adaptive_beam = cfg.beam; cur_cutoff = beam_cutoff; }
+      }
+    }
+    // ---- cost offset + seed of next_cutoff from the best token's arcs (:757-772)
+    const float cost_offset = (n > 0) ? -best : 0.0f;
+    if (tid == 0) {
+      c.cost_offsets[frame] = cost_offset;
+      c.trace_ntok[frame] = n; c.trace_cutoff[frame] = cur_cutoff;
+      c.lnk_off[2 * (frame + 1)] = S->lnk_used;
+    }
+    if (n > 0) {
+      const u32 a0 = d.g.off[best_state].x, a1 = d.g.off[best_state + 1].x;
+      float seed = INFINITY;
+      for (u32 a = a0 + tid; a < a1; a += NT) {
+        const kamd_arc arc = d.g.e_arcs[a];
+        const float new_weight = arc.weight + cost_offset - LogLike(d, ll, arc.ilabel) + best;
+        seed = fminf(seed, new_weight + adaptive_beam);
+      }
+      seed = BlockMinF(seed, &sh);
+      if (tid == 0) sh.next_cutoff_u = FloatToOrdered(seed);
+    } else if (tid == 0) sh.next_cutoff_u = FloatToOrdered(INFINITY);
+    __syncthreads();
+    const int link_base = S->lnk_used;
+    // ---- ProcessEmitting (:783-815): thread per token, hubs deferred to wavefronts
+    int n_exp = 0; long long a_emit = 0;
+    for (int i = tid; i < n; i += NT) {
+      const float cur_cost = cost[i];
+      if (cur_cost <= cur_cutoff) {           // :787
+        n_exp++;
+        const int s = state[i];
+        const u32 a0 = d.g.off[s].x, a1 = d.g.off[s + 1].x;
+        const u32 deg = a1 - a0;
+        a_emit += deg;
+        if (deg <= SMALL_DEG) {
+          for (u32 a = a0; a < a1; a++) {
+            const kamd_arc arc = d.g.e_arcs[a];
+            ProcessArc(d, c, &sh, ll, arc, tb + i, cur_cost, cost_offset, adaptive_beam, link_base);
+          }
+        } else {
+          const int p = WaveAlloc(&sh.bigcnt);
+          if (p < BIGCAP) sh.big_tok[p] = i;
+          else {  // list full: expand in place
+            for (u32 a = a0; a < a1; a++) {
+              const kamd_arc arc = d.g.e_arcs[a];
+              ProcessArc(d, c, &sh, ll, arc, tb + i, cur_cost, cost_offset, adaptive_beam, link_base);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int nb = min(sh.bigcnt, BIGCAP);
+      const int w = tid >> 6, l = tid & 63;
+      for (int e = w; e < nb; e += NWAVES) {
+        const int i = sh.big_tok[e];
+        const float cur_cost = cost[i];
+        const int s = state[i];
+        const u32 a0 = d.g.off[s].x, a1 = d.g.off[s + 1].x;
+        for (u32 a = a0 + l; a < a1; a += 64) {   // 64 consecutive 16-B arcs per load
+          const kamd_arc arc = d.g.e_arcs[a];
+          ProcessArc(d, c, &sh, ll, arc, tb + i, cur_cost, cost_offset, adaptive_beam, link_base);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      int ne = n_exp, ae = static_cast<int>(a_emit);
+      BlockSum2(ne, ae, &sh);
+      if (tid == 0) {
+        sh.cnt[0] += ne; sh.cnt[1] += ae; sh.cnt[2] += ae; sh.cnt[6] += 1;
+        sh.bigcnt = 0;
+        c.lnk_off[2 * (frame + 1) + 1] = link_base + min(sh.n_links, d.arena_links - link_base);
+      }
+    }
+    __syncthreads();
+    const float next_cutoff = OrderedToFloat(sh.next_cutoff_u);
+    // ---- ProcessNonemitting(next_cutoff) + commit of token list frame+1
+    CommitFrame(d, c, &sh, next_cutoff, frame + 1, link_base);
+    if (sh.err) { frame++; break; }
+  }
+  PublishLaneEnd(d, c, &sh, frame);
+}
+
+// FinalizeDecoding (lattice-faster-decoder.cc:638-653) = PruneForwardLinksFinal (:389-471)
+// + PruneForwardLinks(f, delta = 0) for every earlier frame (:312-383), iterated to the
+// exact fixpoint, + PruneTokensForFrame; then in-place, order preserving compaction of
+// the surviving tokens / links so the host copies only the raw lattice.
+__global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes) {
+  __shared__ Sh sh;
+  const int lane = lanes[blockIdx.x];
+  const Ctx c = MakeCtx(d, lane);
+  const int tid = threadIdx.x;
+  InitSh(&sh);
+  LaneState *S = c.st;
+  if (S->error || S->finalized) return;
+  const int F = S->frame;
+  const float lattice_beam = d.cfg.lattice_beam;
+  float best_cost, best_with_final;
+  FinalCosts(d, c, &sh, F, &best_cost, &best_with_final);
+  const bool finals_empty = best_with_final == INFINITY;                // final_costs_.empty()
+  const float final_best = finals_empty ? best_cost : best_with_final;  // :583-588
+  u32 *bo = reinterpret_cast<u32 *>(c.scratch);                 // ordered keys: base + emitting
+  u32 *xo = reinterpret_cast<u32 *>(c.scratch) + d.hash_cap;    // ordered keys: Jacobi target
+  for (int f = F; f >= 0; f--) {
+    const int tb = c.tok_off[f], nt = c.tok_off[f + 1] - tb;
+    if (nt > d.hash_cap) { if (tid == 0) sh.err = ERR_INTERNAL; __syncthreads(); break; }
+    float *xcur = c.tok_extra + tb;   // extra_cost of frame f (frame f+1 is final already)
+    // base term: final-cost term on the last frame (:430), +inf elsewhere (:341)
+    for (int i = tid; i < nt; i += NT) {
+      float b = INFINITY;
+      if (f == F) {
+        const float fc = finals_empty ? 0.0f : d.g.final[c.tok_state[tb + i]];
+        b = c.tok_cost[tb + i] + fc - final_best;
+      }
+      bo[i] = FloatToOrdered(b);
+    }
+    __syncthreads();
+    // emitting links out of frame f (written at step f+1)
+    if (f < F) {
+      const int lb = c.lnk_off[2 * (f + 1)], le = c.lnk_off[2 * (f + 1) + 1];
+      for (int li = lb + tid; li < le; li += NT) {
+        const Link L = c.links[li];
+        if (L.dst < 0) { c.links[li].src = -1; continue; }   // dropped by the exact cutoff
+        float lec = c.tok_extra[L.dst] + ((c.tok_cost[L.src] + L.ac + L.graph) - c.tok_cost[L.dst]);
+        if (lec > lattice_beam) { c.links[li].src = -1; continue; }   // excise (:352)
+        if (lec < 0.0f) lec = 0.0f;                                    // :360-364
+        atomicMin(&bo[L.src - tb], FloatToOrdered(lec));
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < nt; i += NT) {
+      float v = OrderedToFloat(bo[i]);
+      if (f == F && v > lattice_beam) v = INFINITY;   // :462-463
+      xcur[i] = v;
+    }
+    __syncthreads();
+    // epsilon links inside frame f: Jacobi iteration to the exact fixpoint (the
+    // reference's "while (changed)" loop; epsilon links are acyclic so it is unique)
+    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
+    if (ee > eb) {
+      for (int iter = 0; iter < 20000; iter++) {
+        for (int i = tid; i < nt; i += NT) xo[i] = bo[i];
+        __syncthreads();
+        for (int li = eb + tid; li < ee; li += NT) {
+          const Link L = c.links[li];
+          float lec = xcur[L.dst - tb] + ((c.tok_cost[L.src] + L.ac + L.graph) - c.tok_cost[L.dst]);
+          if (lec > lattice_beam) continue;
+          if (lec < 0.0f) lec = 0.0f;
+          atomicMin(&xo[L.src - tb], FloatToOrdered(lec));
+        }
+        __syncthreads();
+        int changed = 0, dummy = 0;
+        for (int i = tid; i < nt; i += NT) {
+          float v = OrderedToFloat(xo[i]);
+          if (f == F && v > lattice_beam) v = INFINITY;
+          if (!(v == xcur[i])) changed = 1;
+          xcur[i] = v;
+        }
+        BlockSum2(changed, dummy, &sh);
+        if (changed == 0) break;
+      }
+      for (int li = eb + tid; li < ee; li += NT) {
+        const Link L = c.links[li];
+        const float lec = xcur[L.dst - tb] + ((c.tok_cost[L.src] + L.ac + L.graph) - c.tok_cost[L.dst]);
+        if (lec > lattice_beam) c.links[li].src = -1;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- PruneTokensForFrame + GetRawLattice staging: order preserving in-place compaction
+  int *new_off = reinterpret_cast<int *>(c.wl0);   // [F+2] (hash_cap >= max_frames+2 is checked on the host)
+  int n_out_tok = 0;
+  for (int f = 0; f <= F; f++) {
+    const int tb = c.tok_off[f], te = c.tok_off[f + 1];
+    if (tid == 0) new_off[f] = n_out_tok;
+    for (int base = tb; base < te; base += NT) {
+      const int i = base + tid;
+      bool keep = false; int st = 0; float co = 0.f;
+      if (i < te) { keep = c.tok_extra[i] != INFINITY; st = c.tok_state[i]; co = c.tok_cost[i]; }
+      int tot;
+      const int pos = BlockScanFlag(keep, &tot, &sh);
+      if (i < te) c.tok_map[i] = keep ? n_out_tok + pos : -1;
+      __syncthreads();
+      if (keep) { c.tok_state[n_out_tok + pos] = st; c.tok_cost[n_out_tok + pos] = co; }
+      n_out_tok += tot;
+    }
+  }
+  if (tid == 0) new_off[F + 1] = n_out_tok;
+  __syncthreads();
+  // ---- links: drop excised, remap endpoints, remove cost offsets (GetRawLattice :173-180)
+  int n_out_link = 0;
+  for (int s = 0; s <= F; s++) {
+    for (int part = 0; part < 2; part++) {
+      const int lb = c.lnk_off[2 * s + part], le = c.lnk_off[2 * s + part + 1];
+      const float off = (part == 0 && s > 0) ? c.cost_offsets[s - 1] : 0.0f;
+      for (int base = lb; base < le; base += NT) {
+        const int li = base + tid;
+        bool keep = false; Link L;
+        L.src = L.dst = L.ilabel = L.olabel = 0; L.graph = L.ac = 0.f;
+        if (li < le) {
+          L = c.links[li];
+          keep = L.src >= 0 && L.dst >= 0;
+          if (keep) {
+            const int ms = c.tok_map[L.src], md = c.tok_map[L.dst];
+            keep = ms >= 0 && md >= 0;
+            L.src = ms; L.dst = md;
+            if (part == 0) L.ac = L.ac - off;
+          }
+        }
+        int tot;
+        const int pos = BlockScanFlag(keep, &tot, &sh);
+        __syncthreads();
+        if (keep) c.links[n_out_link + pos] = L;
+        n_out_link += tot;
+      }
+    }
+  }
+  __syncthreads();
+  for (int f = tid; f <= F + 1; f += NT) c.tok_off[f] = new_off[f];
+  if (tid == 0) {
+    S->finalized = 1;
+    S->final_best_cost = final_best;
+    S->final_relative_cost = (best_cost == INFINITY && best_with_final == INFINITY) ? INFINITY : best_with_final - best_cost;
+    S->out_ntok = n_out_tok; S->out_nlink = n_out_link;
+    S->error |= sh.err;
+  }
+}
+
+// ------------------------------------------------------------------ host
+struct Graph {
+  GraphDev dev;
+  int64_t num_arcs;
+  std::vector<void *> allocs;
+};
+
+struct Decoder {
+  DecDev dev;
+  const Graph *g;
+  kamd_decoder_sizes sizes;
+  std::vector<void *> allocs;
+  std::vector<LaneState> h_st;
+  hipEvent_t ev0 = NULL, ev1 = NULL;
+  bool timed = false;
+  float last_ms = 0;
+  int *d_lanes = NULL; kamd_decode_task *d_tasks = NULL; int tasks_cap = 0;
+  hipStream_t last_stream = NULL;
+  // host copy of one lane's lattice (canonical), cached by lane
+  int cached_lane = -1;
+  std::vector<int32_t> lat_frame, lat_hclg; std::vector<float> lat_cost, lat_final;
+  std::vector<kamd_lat_arc> lat_arcs; int lat_start = -1, lat_frames = 0;
+};
+
+}  // namespace kamd
+
+using kamd::Graph;
+using kamd::Decoder;
+
+extern "C" {
+
+kamd_graph *kamd_graph_create(int32_t num_states, int32_t start, const int64_t *arc_off,
+                              const kamd_arc *arcs, const float *final_cost) {
+  if (num_states <= 0 || start < 0 || start >= num_states) {
+    kamd::SetError(KAMD_ERR_ARG, "bad graph (states %d, start %d)", num_states, start);
+    return NULL;
+  }
+  if (!kamd::RequireDevice()) return NULL;
+  const int64_t A = arc_off[num_states];
+  std::vector<uint2> off(num_states + 1);
+  std::vector<kamd_arc> ea, na;
+  ea.reserve(A); na.reserve(A / 4 + 1);
+  for (int s = 0; s < num_states; s++) {
+    off[s].x = static_cast<unsigned>(ea.size()); off[s].y = static_cast<unsigned>(na.size());
+    for (int64_t a = arc_off[s]; a < arc_off[s + 1]; a++) {
+      if (arcs[a].nextstate < 0 || arcs[a].nextstate >= num_states) {
+        kamd::SetError(KAMD_ERR_ARG, "arc %lld: nextstate out of range", static_cast<long long>(a));
+        return NULL;
+      }
+      if (arcs[a].ilabel != 0) ea.push_back(arcs[a]); else na.push_back(arcs[a]);
+    }
+  }
+  off[num_states].x = static_cast<unsigned>(ea.size()); off[num_states].y = static_cast<unsigned>(na.size());
+  if (ea.size() > 0xFFFFFFF0u || na.size() > 0xFFFFFFF0u) { kamd::SetError(KAMD_ERR_ARG, "graph too large"); return NULL; }
+  // epsilon cycles are illegal (lattice-faster-decoder.cc:997-998): Kahn on the eps graph
+  {
+    std::vector<int> indeg(num_states, 0);
+    for (size_t i = 0; i < na.size(); i++) indeg[na[i].nextstate]++;
+    std::vector<int> stack;
+    for (int s = 0; s < num_states; s++) if (indeg[s] == 0) stack.push_back(s);
+    size_t seen = 0;
+    while (!stack.empty()) {
+      int s = stack.back(); stack.pop_back(); seen++;
+      for (unsigned a = off[s].y; a < off[s + 1].y; a++)
+        if (--indeg[na[a].nextstate] == 0) stack.push_back(na[a].nextstate);
+    }
+    if (seen != static_cast<size_t>(num_states)) {
+      kamd::SetError(KAMD_ERR_ARG, "epsilon loops exist in your decoding graph (this is not allowed!)");
+      return NULL;
+    }
+  }
+  Graph *g = new Graph();
+  g->num_arcs = A;
+  auto up = [&](const void *src, size_t bytes) -> void * {
+    void *p = NULL;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return NULL;
+    g->allocs.push_back(p);
+    if (bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return NULL;
+    return p;
+  };
+  g->dev.num_states = num_states; g->dev.start = start;
+  g->dev.off = static_cast<const uint2 *>(up(off.data(), off.size() * sizeof(uint2)));
+  g->dev.e_arcs = static_cast<const kamd_arc *>(up(ea.data(), ea.size() * sizeof(kamd_arc)));
+  g->dev.n_arcs = static_cast<const kamd_arc *>(up(na.data(), na.size() * sizeof(kamd_arc)));
+  g->dev.final = static_cast<const float *>(up(final_cost, num_states * sizeof(float)));
+  if (!g->dev.off || !g->dev.e_arcs || !g->dev.n_arcs || !g->dev.final) {
+    kamd::SetError(KAMD_ERR_HIP, "graph upload failed");
+    kamd_graph_destroy(reinterpret_cast<kamd_graph *>(g));
+    return NULL;
+  }
+  return reinterpret_cast<kamd_graph *>(g);
+}
+void kamd_graph_destroy(kamd_graph *h) {
+  Graph *g = reinterpret_cast<Graph *>(h);
+  if (!g) return;
+  for (size_t i = 0; i < g->allocs.size(); i++) (void)hipFree(g->allocs[i]);
+  delete g;
+}
+int32_t kamd_graph_num_states(const kamd_graph *h) { return reinterpret_cast<const Graph *>(h)->dev.num_states; }
+int64_t kamd_graph_num_arcs(const kamd_graph *h) { return reinterpret_cast<const Graph *>(h)->num_arcs; }
+
+static int CheckConfig(const kamd_decoder_config *c) {
+  // LatticeFasterDecoderConfig::Check (lattice-faster-decoder.h:84-89)
+  if (!(c->beam > 0.0f && c->max_active > 1 && c->lattice_beam > 0.0f && c->min_active <= c->max_active &&
+        c->prune_interval > 0 && c->beam_delta > 0.0f && c->hash_ratio >= 1.0f && c->prune_scale > 0.0f &&
+        c->prune_scale < 1.0f && c->min_active >= 0))
+    return kamd::SetError(KAMD_ERR_ARG, "invalid LatticeFasterDecoderConfig");
+  return KAMD_OK;
+}
+
+kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_config *cfg,
+                                  const kamd_decoder_sizes *sz, const int32_t *tid2pdf, int32_t num_tids) {
+  if (CheckConfig(cfg) != KAMD_OK || !kamd::RequireDevice()) return NULL;
+  kamd_decoder_sizes s;
+  if (sz) s = *sz; else kamd_decoder_sizes_default(&s);
+  if (s.max_lanes < 1 || s.hash_capacity < 64 || (s.hash_capacity & (s.hash_capacity - 1)) ||
+      s.arena_tokens < 16 || s.arena_links < 16 || s.max_frames < 1 || s.arena_tokens > 2000000000LL ||
+      s.arena_links > 2000000000LL || s.hash_capacity < s.max_frames + 2) {
+    kamd::SetError(KAMD_ERR_ARG, "bad decoder sizes");
+    return NULL;
+  }
+  Decoder *D = new Decoder();
+  D->g = reinterpret_cast<const Graph *>(gh);
+  D->sizes = s;
+  kamd::DecDev &d = D->dev;
+  memset(&d, 0, sizeof(d));
+  d.g = D->g->dev; d.cfg = *cfg;
+  d.hash_cap = s.hash_capacity; d.hash_mask = s.hash_capacity - 1; d.max_frames = s.max_frames;
+  d.arena_tokens = static_cast<int>(s.arena_tokens); d.arena_links = static_cast<int>(s.arena_links);
+  const size_t L = s.max_lanes, hc = s.hash_capacity, at = s.arena_tokens, al = s.arena_links, mf = s.max_frames;
+  bool ok = true;
+  auto alloc = [&](size_t bytes, int fill) -> void * {
+    void *p = NULL;
+    if (hipMalloc(&p, bytes) != hipSuccess) { ok = false; return NULL; }
+    D->allocs.push_back(p);
+    if (hipMemset(p, fill, bytes) != hipSuccess) ok = false;
+    return p;
+  };
+  d.H = static_cast<kamd::u64 *>(alloc(L * hc * 8, 0xFF));
+  d.slots = static_cast<kamd::u32 *>(alloc(L * hc * 4, 0));
+  d.slot_tok = static_cast<int *>(alloc(L * hc * 4, 0));
+  d.stamp = static_cast<kamd::u32 *>(alloc(L * hc * 4, 0));
+  d.wl = static_cast<kamd::u32 *>(alloc(L * hc * 8, 0));
+  d.scratch = static_cast<float *>(alloc(L * hc * 8, 0));
+  d.tok_state = static_cast<int *>(alloc(L * at * 4, 0));
+  d.tok_cost = static_cast<float *>(alloc(L * at * 4, 0));
+  d.tok_extra = static_cast<float *>(alloc(L * at * 4, 0));
+  d.tok_map = static_cast<int *>(alloc(L * at * 4, 0));
+  d.links = static_cast<kamd::Link *>(alloc(L * al * sizeof(kamd::Link), 0));
+  d.tok_off = static_cast<int *>(alloc(L * (mf + 2) * 4, 0));
+  d.lnk_off = static_cast<int *>(alloc(L * (2 * (mf + 2) + 1) * 4, 0));
+  d.cost_offsets = static_cast<float *>(alloc(L * (mf + 1) * 4, 0));
+  d.trace_ntok = static_cast<int *>(alloc(L * (mf + 1) * 4, 0));
+  d.trace_cutoff = static_cast<float *>(alloc(L * (mf + 1) * 4, 0));
+  d.st = static_cast<kamd::LaneState *>(alloc(L * sizeof(kamd::LaneState), 0));
+  if (tid2pdf) {
+    int *p = static_cast<int *>(alloc((static_cast<size_t>(num_tids) + 1) * 4, 0));
+    if (p && hipMemcpy(p, tid2pdf, (static_cast<size_t>(num_tids) + 1) * 4, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    d.tid2pdf = p;
+  }
+  if (ok && (hipEventCreate(&D->ev0) != hipSuccess || hipEventCreate(&D->ev1) != hipSuccess)) ok = false;
+  if (!ok) {
+    kamd::SetError(KAMD_ERR_HIP, "decoder allocation failed (%zu lanes): %s", L, hipGetErrorString(hipGetLastError()));
+    kamd_decoder_destroy(reinterpret_cast<kamd_decoder *>(D));
+    return NULL;
+  }
+  D->h_st.resize(L);
+  return reinterpret_cast<kamd_decoder *>(D);
+}
+
+void kamd_decoder_destroy(kamd_decoder *h) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (!D) return;
+  for (size_t i = 0; i < D->allocs.size(); i++) (void)hipFree(D->allocs[i]);
+  if (D->d_lanes) (void)hipFree(D->d_lanes);
+  if (D->d_tasks) (void)hipFree(D->d_tasks);
+  if (D->ev0) (void)hipEventDestroy(D->ev0);
+  if (D->ev1) (void)hipEventDestroy(D->ev1);
+  delete D;
+}
+
+int kamd_decoder_set_options(kamd_decoder *h, const kamd_decoder_config *cfg) {
+  if (CheckConfig(cfg) != KAMD_OK) return KAMD_ERR_ARG;
+  reinterpret_cast<Decoder *>(h)->dev.cfg = *cfg;
+  return KAMD_OK;
+}
+
+static int EnsureTaskBuf(Decoder *D, int n) {
+  if (n <= D->tasks_cap) return KAMD_OK;
+  if (D->d_lanes) (void)hipFree(D->d_lanes);
+  if (D->d_tasks) (void)hipFree(D->d_tasks);
+  D->d_lanes = NULL; D->d_tasks = NULL;
+  int cap = std::max(n, 64);
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_lanes), cap * sizeof(int)));
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_tasks), cap * sizeof(kamd_decode_task)));
+  D->tasks_cap = cap;
+  return KAMD_OK;
+}
+
+static int CheckLanes(Decoder *D, const int32_t *lanes, int n) {
+  for (int i = 0; i < n; i++)
+    if (lanes[i] < 0 || lanes[i] >= D->sizes.max_lanes) return kamd::SetError(KAMD_ERR_ARG, "lane %d out of range", lanes[i]);
+  return KAMD_OK;
+}
+
+int kamd_decoder_init(kamd_decoder *h, const int32_t *lanes, int n, void *stream) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0) return KAMD_OK;
+  if (CheckLanes(D, lanes, n) != KAMD_OK || EnsureTaskBuf(D, n) != KAMD_OK) return KAMD_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KAMD_HIP(hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(kamd::InitKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes);
+  KAMD_HIP(hipGetLastError());
+  D->last_stream = st; D->cached_lane = -1;
+  return KAMD_OK;
+}
+
+int kamd_decoder_advance(kamd_decoder *h, const kamd_decode_task *tasks, int n, void *stream) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0) return KAMD_OK;
+  if (EnsureTaskBuf(D, n) != KAMD_OK) return KAMD_ERR_HIP;
+  for (int i = 0; i < n; i++)
+    if (tasks[i].lane < 0 || tasks[i].lane >= D->sizes.max_lanes || tasks[i].n_frames < 0)
+      return kamd::SetError(KAMD_ERR_ARG, "task %d: bad lane / frame count", i);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // longest first: the tail of the launch is the longest utterance, start it early
+  std::vector<kamd_decode_task> sorted(tasks, tasks + n);
+  std::stable_sort(sorted.begin(), sorted.end(),
+                   [](const kamd_decode_task &a, const kamd_decode_task &b) { return a.n_frames > b.n_frames; });
+  KAMD_HIP(hipMemcpyAsync(D->d_tasks, sorted.data(), n * sizeof(kamd_decode_task), hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  KAMD_HIP(hipEventRecord(D->ev0, st));
+  hipLaunchKernelGGL(kamd::AdvanceKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_tasks);
+  KAMD_HIP(hipGetLastError());
+  KAMD_HIP(hipEventRecord(D->ev1, st));
+  D->timed = true; D->last_stream = st; D->cached_lane = -1;
+  return KAMD_OK;
+}
+
+int kamd_decoder_finalize(kamd_decoder *h, const int32_t *lanes, int n, void *stream) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0) return KAMD_OK;
+  if (CheckLanes(D, lanes, n) != KAMD_OK || EnsureTaskBuf(D, n) != KAMD_OK) return KAMD_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KAMD_HIP(hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(kamd::FinalizeKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes);
+  KAMD_HIP(hipGetLastError());
+  D->last_stream = st; D->cached_lane = -1;
+  return KAMD_OK;
+}
+
+int kamd_decoder_sync(kamd_decoder *h) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  KAMD_HIP(hipStreamSynchronize(D->last_stream));
+  if (D->timed) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, D->ev0, D->ev1) == hipSuccess) D->last_ms = ms;
+  }
+  KAMD_HIP(hipMemcpy(D->h_st.data(), D->dev.st, D->h_st.size() * sizeof(kamd::LaneState), hipMemcpyDeviceToHost));
+  for (size_t l = 0; l < D->h_st.size(); l++) {
+    int e = D->h_st[l].error;
+    if (e)
+      return kamd::SetError(KAMD_ERR_CAPACITY,
+                            "lane %zu: device capacity exceeded (flags %d:%s%s%s%s%s%s) at frame %d; raise kamd_decoder_sizes",
+                            l, e, (e & 1) ? " hash" : "", (e & 2) ? " token-arena" : "", (e & 4) ? " link-arena" : "",
+                            (e & 8) ? " max-frames" : "", (e & 16) ? " worklist" : "", (e & 32) ? " internal" : "",
+                            D->h_st[l].frame);
+  }
+  return KAMD_OK;
+}
+
+float kamd_decoder_last_advance_ms(kamd_decoder *h) { return reinterpret_cast<Decoder *>(h)->last_ms; }
+
+static int LaneOk(Decoder *D, int lane) {
+  if (lane < 0 || lane >= D->sizes.max_lanes) return kamd::SetError(KAMD_ERR_ARG, "lane %d out of range", lane);
+  return KAMD_OK;
+}
+
+int kamd_decoder_num_frames_decoded(kamd_decoder *h, int lane) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
+  return D->h_st[lane].frame;
+}
+float kamd_decoder_final_relative_cost(kamd_decoder *h, int lane) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (LaneOk(D, lane) != KAMD_OK) return INFINITY;
+  return D->h_st[lane].final_relative_cost;
+}
+int kamd_decoder_reached_final(kamd_decoder *h, int lane) {
+  // ReachedFinal(): FinalRelativeCost() != infinity (lattice-faster-decoder.h:283-285)
+  return kamd_decoder_final_relative_cost(h, lane) != INFINITY;
+}
+int kamd_decoder_get_counters(kamd_decoder *h, int lane, int64_t counters[8]) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
+  for (int i = 0; i < 8; i++) counters[i] = D->h_st[lane].counters[i];
+  return KAMD_OK;
+}
+int kamd_decoder_get_trace(kamd_decoder *h, int lane, int32_t *ntok, float *cutoff, float *cost_offset, int cap) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
+  int n = std::min(cap, D->h_st[lane].frame);
+  size_t mf = D->sizes.max_frames;
+  if (n > 0) {
+    KAMD_HIP(hipMemcpy(ntok, D->dev.trace_ntok + lane * (mf + 1), n * 4, hipMemcpyDeviceToHost));
+    KAMD_HIP(hipMemcpy(cutoff, D->dev.trace_cutoff + lane * (mf + 1), n * 4, hipMemcpyDeviceToHost));
+    KAMD_HIP(hipMemcpy(cost_offset, D->dev.cost_offsets + lane * (mf + 1), n * 4, hipMemcpyDeviceToHost));
+  }
+  return n;
+}
+
+// GetRawLattice (lattice-faster-decoder.cc:113-196) from the compacted device arrays.
+static int FetchLattice(Decoder *D, int lane) {
+  if (D->cached_lane == lane) return KAMD_OK;
+  if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
+  const kamd::LaneState &S = D->h_st[lane];
+  if (!S.finalized) return kamd::SetError(KAMD_ERR_STATE, "lane %d: call kamd_decoder_finalize + kamd_decoder_sync first", lane);
+  const int nt = S.out_ntok, nl = S.out_nlink, F = S.frame;
+  const size_t at = D->sizes.arena_tokens, al = D->sizes.arena_links, mf = D->sizes.max_frames;
+  std::vector<int> st(nt), toff(F + 2);
+  std::vector<float> co(nt);
+  std::vector<kamd::Link> lk(nl);
+  if (nt) {
+    KAMD_HIP(hipMemcpy(st.data(), D->dev.tok_state + lane * at, nt * 4, hipMemcpyDeviceToHost));
+    KAMD_HIP(hipMemcpy(co.data(), D->dev.tok_cost + lane * at, nt * 4, hipMemcpyDeviceToHost));
+  }
+  KAMD_HIP(hipMemcpy(toff.data(), D->dev.tok_off + lane * (mf + 2), (F + 2) * 4, hipMemcpyDeviceToHost));
+  if (nl) KAMD_HIP(hipMemcpy(lk.data(), D->dev.links + lane * al, nl * sizeof(kamd::Link), hipMemcpyDeviceToHost));
+  // final costs need the graph's final vector for the last frame's states
+  std::vector<float> fin(nt, INFINITY);
+  D->lat_frame.assign(nt, 0);
+  for (int f = 0; f <= F; f++)
+    for (int i = toff[f]; i < toff[f + 1] && i < nt; i++) D->lat_frame[i] = f;
+  // every frame must keep a token or the reference produces no lattice (:145-149)
+  bool empty_frame = false;
+  for (int f = 0; f <= F; f++) if (toff[f + 1] <= toff[f]) empty_frame = true;
+  {
+    const int lb = toff[F], le = std::min(toff[F + 1], nt);
+    bool any = false;
+    std::vector<float> fc(std::max(0, le - lb));
+    for (int i = lb; i < le; i++) {
+      KAMD_HIP(hipMemcpy(&fc[i - lb], D->g->dev.final + st[i], 4, hipMemcpyDeviceToHost));
+      if (fc[i - lb] != INFINITY) any = true;
+    }
+    // :183-192: final weight = final_cost if any final token exists, else One()
+    // (any is evaluated over ALL last-frame tokens in the reference, i.e. before pruning;
+    //  a surviving non-final set with finals_empty false cannot occur: non-final tokens
+    //  get extra_cost = +inf on the last frame when finals exist.)
+    for (int i = lb; i < le; i++) fin[i] = any ? fc[i - lb] : 0.0f;
+  }
+  // canonical numbering: by (frame, HCLG state)
+  std::vector<int> order(nt), inv(nt);
+  for (int i = 0; i < nt; i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    if (D->lat_frame[a] != D->lat_frame[b]) return D->lat_frame[a] < D->lat_frame[b];
+    return st[a] < st[b];
+  });
+  for (int i = 0; i < nt; i++) inv[order[i]] = i;
+  std::vector<int32_t> fr(nt), hc(nt); std::vector<float> cs(nt), fn(nt);
+  for (int i = 0; i < nt; i++) { fr[i] = D->lat_frame[order[i]]; hc[i] = st[order[i]]; cs[i] = co[order[i]]; fn[i] = fin[order[i]]; }
+  D->lat_frame.swap(fr); D->lat_hclg.swap(hc); D->lat_cost.swap(cs); D->lat_final.swap(fn);
+  D->lat_arcs.resize(nl);
+  for (int i = 0; i < nl; i++) {
+    kamd_lat_arc a;
+    a.src = inv[lk[i].src]; a.dst = inv[lk[i].dst]; a.ilabel = lk[i].ilabel; a.olabel = lk[i].olabel;
+    a.graph_cost = lk[i].graph; a.acoustic_cost = lk[i].ac;
+    D->lat_arcs[i] = a;
+  }
+  std::sort(D->lat_arcs.begin(), D->lat_arcs.end(), [](const kamd_lat_arc &a, const kamd_lat_arc &b) {
+    if (a.src != b.src) return a.src < b.src;
+    if (a.dst != b.dst) return a.dst < b.dst;
+    if (a.ilabel != b.ilabel) return a.ilabel < b.ilabel;
+    if (a.olabel != b.olabel) return a.olabel < b.olabel;
+    if (a.graph_cost != b.graph_cost) return a.graph_cost < b.graph_cost;
+    return a.acoustic_cost < b.acoustic_cost;
+  });
+  D->lat_start = -1;
+  for (int i = 0; i < nt && D->lat_frame[i] == 0; i++)
+    if (D->lat_hclg[i] == D->g->dev.start) D->lat_start = i;
+  D->lat_frames = F;
+  if (empty_frame) { D->lat_frame.clear(); D->lat_hclg.clear(); D->lat_cost.clear(); D->lat_final.clear(); D->lat_arcs.clear(); D->lat_start = -1; }
+  D->cached_lane = lane;
+  return KAMD_OK;
+}
+
+int kamd_decoder_lattice_size(kamd_decoder *h, int lane, kamd_lattice_size *sz) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  int rc = FetchLattice(D, lane);
+  if (rc != KAMD_OK) return rc;
+  sz->num_states = static_cast<int32_t>(D->lat_frame.size());
+  sz->num_arcs = static_cast<int32_t>(D->lat_arcs.size());
+  sz->num_frames = D->lat_frames; sz->start = D->lat_start;
+  return KAMD_OK;
+}
+
+int kamd_decoder_get_raw_lattice(kamd_decoder *h, int lane, int32_t *state_frame, int32_t *state_hclg,
+                                 float *state_cost, float *state_final, kamd_lat_arc *arcs) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  int rc = FetchLattice(D, lane);
+  if (rc != KAMD_OK) return rc;
+  size_t n = D->lat_frame.size();
+  if (n) {
+    memcpy(state_frame, D->lat_frame.data(), n * 4); memcpy(state_hclg, D->lat_hclg.data(), n * 4);
+    memcpy(state_cost, D->lat_cost.data(), n * 4); memcpy(state_final, D->lat_final.data(), n * 4);
+  }
+  if (!D->lat_arcs.empty()) memcpy(arcs, D->lat_arcs.data(), D->lat_arcs.size() * sizeof(kamd_lat_arc));
+  return KAMD_OK;
+}
+
+// fstext/lattice-weight.h Compare: by value1+value2, then value1
+static inline bool LatBetter(float a1, float a2, float b1, float b2) {
+  float fa = a1 + a2, fb = b1 + b2;
+  if (fa < fb) return true;
+  if (fa > fb) return false;
+  return a1 < b1;
+}
+
+int kamd_decoder_best_path(kamd_decoder *h, int lane, int32_t *alignment, int ali_cap, int *ali_len,
+                           int32_t *words, int words_cap, int *words_len, float *graph_cost,
+                           float *acoustic_cost) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  int rc = FetchLattice(D, lane);
+  if (rc != KAMD_OK) return rc;
+  *ali_len = 0; *words_len = 0; *graph_cost = INFINITY; *acoustic_cost = INFINITY;
+  const int n = static_cast<int>(D->lat_frame.size()), m = static_cast<int>(D->lat_arcs.size());
+  if (n == 0 || D->lat_start < 0) return kamd::SetError(KAMD_ERR_STATE, "empty lattice");
+  const std::vector<kamd_lat_arc> &A = D->lat_arcs;   // sorted by src: CSR on the fly
+  std::vector<int> first(n + 1, 0), indeg(n, 0);
+  for (int i = 0; i < m; i++) { first[A[i].src + 1]++; indeg[A[i].dst]++; }
+  for (int s = 0; s < n; s++) first[s + 1] += first[s];
+  std::vector<float> d1(n, INFINITY), d2(n, INFINITY);
+  std::vector<int> back(n, -1), stack;
+  for (int s = n - 1; s >= 0; s--) if (indeg[s] == 0) stack.push_back(s);
+  d1[D->lat_start] = 0.0f; d2[D->lat_start] = 0.0f;
+  size_t visited = 0;
+  while (!stack.empty()) {
+    int s = stack.back(); stack.pop_back(); visited++;
+    for (int k = first[s]; k < first[s + 1]; k++) {
+      const kamd_lat_arc &a = A[k];
+      if (d1[s] != INFINITY) {
+        float n1 = d1[s] + a.graph_cost, n2 = d2[s] + a.acoustic_cost;
+        if (d1[a.dst] == INFINITY || LatBetter(n1, n2, d1[a.dst], d2[a.dst])) { d1[a.dst] = n1; d2[a.dst] = n2; back[a.dst] = k; }
+      }
+      if (--indeg[a.dst] == 0) stack.push_back(a.dst);
+    }
+  }
+  if (visited != static_cast<size_t>(n)) return kamd::SetError(KAMD_ERR_STATE, "lattice has a cycle");
+  int best = -1; float b1 = INFINITY, b2 = INFINITY;
+  for (int s = 0; s < n; s++) {
+    if (D->lat_final[s] == INFINITY || d1[s] == INFINITY) continue;
+    float t1 = d1[s] + D->lat_final[s], t2 = d2[s];
+    if (best == -1 || LatBetter(t1, t2, b1, b2)) { best = s; b1 = t1; b2 = t2; }
+  }
+  if (best == -1) return kamd::SetError(KAMD_ERR_STATE, "no path to a final lattice state");
+  std::vector<int> path;
+  for (int s = best; back[s] != -1; s = A[back[s]].src) path.push_back(back[s]);
+  std::reverse(path.begin(), path.end());
+  for (size_t i = 0; i < path.size(); i++) {
+    const kamd_lat_arc &a = A[path[i]];
+    if (a.ilabel != 0) { if (*ali_len < ali_cap) alignment[*ali_len] = a.ilabel; (*ali_len)++; }
+    if (a.olabel != 0) { if (*words_len < words_cap) words[*words_len] = a.olabel; (*words_len)++; }
+  }
+  *graph_cost = b1; *acoustic_cost = b2;
+  return KAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,526 @@
+// nnet.hip -- fused TDNN(-F) acoustic-model forward on gfx950 (fp32 MFMA).
+//
+// Replaces NnetComputer::Run over the compiled computation (nnet3/nnet-compute.cc:
+// 508-540) for the component set of SURVEY 8(a9): every layer
+//   y[t] = ((bn_scale * relu(sum_i W_i x[t+off_i] + W_iv ivec + b) + bn_offset
+//            + bypass_scale * z[t]) + post_offset) * post_scale
+// is ONE kernel: an fp32 GEMM on v_mfma_f32_32x32x2_f32 whose A rows are gathered
+// through a per-(offset,row) index map (TdnnComponent's strided views,
+// nnet-tdnn-component.cc:497-511, and Append/Offset descriptors) and whose epilogue
+// carries bias / ReLU / BatchNorm(test) / bypass / -log-prior / acoustic-scale.
+// The interpreter's ~6-10 launches per layer become one.
+//
+// Whole utterances are batched along M (no chunk-edge recomputation); each layer is
+// evaluated only at the time indices its consumers need (frame-subsampling-factor 3
+// is exploited from the first stride-3-compatible layer on, as the reference's
+// compiler does).  Numerics: exact fp32 products, fp32 accumulate (k-ordered chain
+// per output element => results do not depend on batch composition).
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace kamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  const float *A; int ldA;          // producer activations
+  const int *rowmap;                // [n_off][M] producer row per (offset, output row)
+  int M, N, n_off, in_pad;          // K = n_off * in_pad (multiple of 16)
+  const float *W;                   // [N_pad][K] zero padded
+  const float *bias;                // [N] or NULL
+  const float *ivbias; const int *row2utt;  // [n_utts][N], [M] or NULL
+  int relu;
+  const float *bn_scale, *bn_offset;
+  const float *byp; int ld_byp; const int *bypmap; float bypass_scale;
+  const float *post_offset; float post_scale;
+  float *C; int ldC;
+};
+
+// BM x BN block tile, BK = 16, 256 threads = 4 waves laid out WM x WN, each wave owns
+// TI x TJ MFMA tiles of 32x32.  LDS holds the tiles k-major ([k][m], +2 pad) so that
+// fragment reads (lane -> consecutive m) and the transposing stores are conflict free.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void TdnnGemmKernel(GemmArgs p) {
+  constexpr int BK = 16;
+  constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;
+  constexpr int LDA = BM + 2, LDB = BN + 2;
+  __shared__ float As[2][BK][LDA];
+  __shared__ float Bs[2][BK][LDB];
+  __shared__ int rm[KAMD_MAX_OFFSETS][BM];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int K = p.n_off * p.in_pad;
+  for (int i = t; i < p.n_off * BM; i += 256) {
+    int o = i / BM, r = i % BM, m = m0 + r;
+    rm[o][r] = (m < p.M) ? p.rowmap[static_cast<size_t>(o) * p.M + m] : -1;
+  }
+  __syncthreads();
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  constexpr int A_LOADS = BM * 4 / 256, B_LOADS = BN * 4 / 256;  // float4 per thread
+  float4 ra[A_LOADS], rb[B_LOADS];
+  auto gload = [&](int kb) {
+    const int k0 = kb * BK;
+    const int off = k0 / p.in_pad, kk = k0 - off * p.in_pad;
+#pragma unroll
+    for (int q = 0; q < A_LOADS; q++) {
+      int idx = t + q * 256, row = idx >> 2, kq = idx & 3;
+      int src = rm[off][row];
+      ra[q] = (src >= 0)
+                  ? *reinterpret_cast<const float4 *>(p.A + static_cast<size_t>(src) * p.ldA + kk + kq * 4)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < B_LOADS; q++) {
+      int idx = t + q * 256, row = idx >> 2, kq = idx & 3;
+      rb[q] = *reinterpret_cast<const float4 *>(p.W + static_cast<size_t>(n0 + row) * K + k0 + kq * 4);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < A_LOADS; q++) {
+      int idx = t + q * 256, row = idx >> 2, kq = idx & 3;
+      As[buf][kq * 4 + 0][row] = ra[q].x; As[buf][kq * 4 + 1][row] = ra[q].y;
+      As[buf][kq * 4 + 2][row] = ra[q].z; As[buf][kq * 4 + 3][row] = ra[q].w;
+    }
+#pragma unroll
+    for (int q = 0; q < B_LOADS; q++) {
+      int idx = t + q * 256, row = idx >> 2, kq = idx & 3;
+      Bs[buf][kq * 4 + 0][row] = rb[q].x; Bs[buf][kq * 4 + 1][row] = rb[q].y;
+      Bs[buf][kq * 4 + 2][row] = rb[q].z; Bs[buf][kq * 4 + 3][row] = rb[q].w;
+    }
+  };
+  const int nkb = K / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int lr = lane & 31, lk = lane >> 5;
+  for (int kb = 0; kb < nkb; kb++) {
+    const int buf = kb & 1;
+    if (kb + 1 < nkb) gload(kb + 1);   // global prefetch overlaps the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ks++) {
+      float a[TI], b[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; i++) a[i] = As[buf][2 * ks + lk][wm * (BM / WM) + i * 32 + lr];
+#pragma unroll
+      for (int j = 0; j < TJ; j++) b[j] = Bs[buf][2 * ks + lk][wn * (BN / WN) + j * 32 + lr];
+#pragma unroll
+      for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kb + 1 < nkb) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  // epilogue: C/D map of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+      const int n = n0 + wn * (BN / WN) + j * 32 + lr;
+      if (n >= p.N) continue;
+      const float bias = p.bias ? p.bias[n] : 0.f;
+      const float bs = p.bn_scale ? p.bn_scale[n] : 1.f, bo = p.bn_scale ? p.bn_offset[n] : 0.f;
+      const float po = p.post_offset ? p.post_offset[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] + bias;
+        if (p.ivbias) v += p.ivbias[static_cast<size_t>(p.row2utt[m]) * p.N + n];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.bn_scale) v = v * bs + bo;
+        if (p.byp) v += p.bypass_scale * p.byp[static_cast<size_t>(p.bypmap[m]) * p.ld_byp + n];
+        if (p.post_offset) v += po;
+        v *= p.post_scale;
+        p.C[static_cast<size_t>(m) * p.ldC + n] = v;
+      }
+    }
+}
+
+// Per-utterance time grids -> row maps.  Row r of layer l (utterance u, k-th row) is
+// time t = lo_l + k*step_l; its operand for offset o lives at producer row
+// (t + o - lo_p)/step_p of the same utterance, or, for the network input, at feature
+// row clamp(t + o, 0, T_u - 1) (edge clamping of nnet-am-decodable-simple.cc:147-160).
+struct MapArgs {
+  int n_utts, M;
+  const int64_t *row_off;       // [n_utts+1] rows of this layer
+  const int64_t *prod_row_off;  // [n_utts+1] rows of the producer (or feature rows)
+  const int *T;                 // [n_utts] input frames
+  int lo, step, prod_lo, prod_step, prod_is_input;
+  int n_off; int offs[KAMD_MAX_OFFSETS];
+  int *rowmap;                  // [n_off][M]
+  int *row2utt;                 // [M] or NULL
+};
+__global__ void RowMapKernel(MapArgs a) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.M) return;
+  int lo = 0, hi = a.n_utts;
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (a.row_off[mid] <= r) lo = mid; else hi = mid;
+  }
+  const int u = lo;
+  const int t = a.lo + static_cast<int>(r - a.row_off[u]) * a.step;
+  if (a.row2utt) a.row2utt[r] = u;
+  for (int i = 0; i < a.n_off; i++) {
+    int tin = t + a.offs[i];
+    int64_t src;
+    if (a.prod_is_input) {
+      int c = tin < 0 ? 0 : (tin >= a.T[u] ? a.T[u] - 1 : tin);
+      src = a.prod_row_off[u] + c;
+    } else {
+      src = a.prod_row_off[u] + (tin - a.prod_lo) / a.prod_step;
+    }
+    a.rowmap[static_cast<size_t>(i) * a.M + r] = static_cast<int>(src);
+  }
+}
+
+// ivbias[u][n] = sum_k W_iv[n][k] * ivec[u][k]   (ReplaceIndex(ivector, t, 0) operand)
+__global__ void IvecBiasKernel(const float *Wiv, const float *ivec, int N, int D, float *out) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = 0; k < D; k++) s += Wiv[static_cast<size_t>(n) * D + k] * ivec[static_cast<size_t>(u) * D + k];
+  out[static_cast<size_t>(u) * N + n] = s;
+}
+
+// ------------------------------------------------------------------ host
+struct LayerDev {
+  int in_dim, out_dim, in_pad, out_pad, n_off, offs[KAMD_MAX_OFFSETS];
+  int input_layer, bypass_layer, ivector_dim, relu;
+  float bypass_scale, post_scale;
+  float *W = NULL, *Wiv = NULL, *bias = NULL, *bn_scale = NULL, *bn_offset = NULL, *post_offset = NULL;
+  int N_pad;
+  // time grid (per layer constants): rows for utterance u are t = lo + k*step,
+  // k < (hi_const + 3*(n_out_u-1) - lo)/step + 1
+  int lo, hi_const, step;
+};
+
+struct Nnet {
+  std::vector<LayerDev> L;
+  int input_dim, subsampling, left, right;
+  int in_lo, in_hi_const;  // time range of the network input that is touched
+  double last_flops = 0;
+  // batch workspace (grown on demand)
+  std::vector<float *> act; std::vector<size_t> act_cap;
+  std::vector<int *> maps; std::vector<size_t> maps_cap;
+  int64_t *d_meta = NULL; size_t meta_cap = 0;
+  float *d_ivb = NULL; size_t ivb_cap = 0;
+};
+
+static int Mod(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }
+
+// Required time set of every layer as an arithmetic progression (lo, hi, step) with
+// hi = hi_const + sub*(n_out-1); step is 'sub' iff all requirements share one residue.
+static int PlanGrids(Nnet *nn) {
+  int n = static_cast<int>(nn->L.size()), sub = nn->subsampling;
+  struct Req { bool any; int lo, hi; int residue; bool dense; };
+  std::vector<Req> req(n + 1);  // index n = network input
+  for (int i = 0; i <= n; i++) { req[i].any = false; req[i].dense = false; req[i].residue = -1; req[i].lo = 0; req[i].hi = 0; }
+  auto add = [&](int idx, int lo, int hi, int residue, bool dense) {
+    Req &r = req[idx];
+    if (!r.any) { r.any = true; r.lo = lo; r.hi = hi; r.residue = residue; r.dense = dense; return; }
+    r.lo = std::min(r.lo, lo); r.hi = std::max(r.hi, hi);
+    if (dense || r.residue != residue) r.dense = true;
+  };
+  add(n - 1, 0, 0, 0, sub == 1);  // output node: t = 0, sub, 2 sub, ... (hi const part 0)
+  for (int i = n - 1; i >= 0; i--) {
+    LayerDev &l = nn->L[i];
+    Req &r = req[i];
+    if (!r.any) return SetError(KAMD_ERR_ARG, "layer %d has no consumer", i);
+    l.step = r.dense ? 1 : sub;
+    l.lo = r.lo; l.hi_const = r.hi;
+    if (!r.dense) {  // snap lo/hi onto the residue class
+      // lo, hi already lie on the residue class by construction
+    }
+    int pidx = l.input_layer < 0 ? n : l.input_layer;
+    for (int o = 0; o < l.n_off; o++) {
+      int off = l.offs[o];
+      add(pidx, r.lo + off, r.hi + off, r.dense ? -1 : Mod(r.residue + off, sub), r.dense);
+    }
+    if (l.bypass_layer != -2) {
+      int bidx = l.bypass_layer < 0 ? n : l.bypass_layer;
+      add(bidx, r.lo, r.hi, r.dense ? -1 : r.residue, r.dense);
+    }
+  }
+  nn->in_lo = req[n].lo; nn->in_hi_const = req[n].hi;
+  nn->left = -req[n].lo; nn->right = req[n].hi;
+  return KAMD_OK;
+}
+
+static inline int64_t LayerRows(const LayerDev &l, int n_out, int sub) {
+  int hi = l.hi_const + sub * (n_out - 1);
+  return (hi - l.lo) / l.step + 1;
+}
+
+template <typename T>
+static int Grow(T **p, size_t *cap, size_t need) {
+  if (need <= *cap) return KAMD_OK;
+  if (*p) (void)hipFree(*p);
+  *p = NULL;
+  size_t n = need + need / 4;
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
+  KAMD_HIP(hipMemset(*p, 0, n * sizeof(T)));
+  *cap = n;
+  return KAMD_OK;
+}
+
+}  // namespace kamd
+
+using kamd::Nnet;
+using kamd::LayerDev;
+
+extern "C" {
+
+kamd_nnet *kamd_nnet_create(const kamd_layer_desc *layers, int n_layers, int input_dim,
+                            int subsampling) {
+  if (n_layers < 1 || subsampling < 1) { kamd::SetError(KAMD_ERR_ARG, "bad nnet description"); return NULL; }
+  if (!kamd::RequireDevice()) return NULL;
+  Nnet *nn = new Nnet();
+  nn->input_dim = input_dim; nn->subsampling = subsampling;
+  nn->L.resize(n_layers);
+  for (int i = 0; i < n_layers; i++) {
+    const kamd_layer_desc &s = layers[i];
+    LayerDev &l = nn->L[i];
+    if (s.n_offsets < 1 || s.n_offsets > KAMD_MAX_OFFSETS || s.input_layer >= i || s.bypass_layer >= i ||
+        (s.ivector_dim > 0 && s.input_layer != -1)) {
+      kamd::SetError(KAMD_ERR_ARG, "layer %d: bad topology", i);
+      delete nn; return NULL;
+    }
+    int prod_dim = s.input_layer < 0 ? input_dim : layers[s.input_layer].out_dim;
+    if (prod_dim != s.in_dim) { kamd::SetError(KAMD_ERR_ARG, "layer %d: in_dim %d != producer dim %d", i, s.in_dim, prod_dim); delete nn; return NULL; }
+    if (s.bypass_layer != -2) {
+      int bd = s.bypass_layer < 0 ? input_dim : layers[s.bypass_layer].out_dim;
+      if (bd != s.out_dim) { kamd::SetError(KAMD_ERR_ARG, "layer %d: bypass dim mismatch", i); delete nn; return NULL; }
+    }
+    l.in_dim = s.in_dim; l.out_dim = s.out_dim; l.in_pad = kamd::RoundUp(s.in_dim, 16);
+    l.out_pad = kamd::RoundUp(s.out_dim, 16); l.n_off = s.n_offsets;
+    for (int o = 0; o < s.n_offsets; o++) l.offs[o] = s.offsets[o];
+    l.input_layer = s.input_layer; l.bypass_layer = s.bypass_layer; l.ivector_dim = s.ivector_dim;
+    l.relu = s.relu; l.bypass_scale = s.bypass_scale; l.post_scale = s.post_scale;
+    l.N_pad = kamd::RoundUp(s.out_dim, 128);
+    const int Ksrc = s.n_offsets * s.in_dim + s.ivector_dim, Kp = s.n_offsets * l.in_pad;
+    std::vector<float> Wp(static_cast<size_t>(l.N_pad) * Kp, 0.0f);
+    for (int n = 0; n < s.out_dim; n++)
+      for (int o = 0; o < s.n_offsets; o++)
+        memcpy(&Wp[static_cast<size_t>(n) * Kp + o * l.in_pad], s.W + static_cast<size_t>(n) * Ksrc + o * s.in_dim,
+               sizeof(float) * s.in_dim);
+    auto up = [&](const float *src, size_t cnt) -> float * {
+      float *d = kamd::DevAlloc<float>(cnt);
+      if (d && hipMemcpy(d, src, cnt * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return NULL;
+      return d;
+    };
+    l.W = up(Wp.data(), Wp.size());
+    bool ok = l.W != NULL;
+    if (s.ivector_dim > 0) {
+      std::vector<float> wiv(static_cast<size_t>(s.out_dim) * s.ivector_dim);
+      for (int n = 0; n < s.out_dim; n++)
+        memcpy(&wiv[static_cast<size_t>(n) * s.ivector_dim], s.W + static_cast<size_t>(n) * Ksrc + s.n_offsets * s.in_dim,
+               sizeof(float) * s.ivector_dim);
+      l.Wiv = up(wiv.data(), wiv.size()); ok = ok && l.Wiv;
+    }
+    if (s.bias) { l.bias = up(s.bias, s.out_dim); ok = ok && l.bias; }
+    if (s.bn_scale) { l.bn_scale = up(s.bn_scale, s.out_dim); l.bn_offset = up(s.bn_offset, s.out_dim); ok = ok && l.bn_scale && l.bn_offset; }
+    if (s.post_offset) { l.post_offset = up(s.post_offset, s.out_dim); ok = ok && l.post_offset; }
+    if (!ok) { kamd::SetError(KAMD_ERR_HIP, "weight upload failed (layer %d)", i); delete nn; return NULL; }
+  }
+  if (kamd::PlanGrids(nn) != KAMD_OK) { delete nn; return NULL; }
+  nn->act.assign(n_layers, NULL); nn->act_cap.assign(n_layers, 0);
+  nn->maps.assign(n_layers, NULL); nn->maps_cap.assign(n_layers, 0);
+  return reinterpret_cast<kamd_nnet *>(nn);
+}
+
+void kamd_nnet_destroy(kamd_nnet *h) {
+  Nnet *nn = reinterpret_cast<Nnet *>(h);
+  if (!nn) return;
+  for (size_t i = 0; i < nn->L.size(); i++) {
+    LayerDev &l = nn->L[i];
+    float *ps[] = {l.W, l.Wiv, l.bias, l.bn_scale, l.bn_offset, l.post_offset};
+    for (float *p : ps) if (p) (void)hipFree(p);
+    if (nn->act[i]) (void)hipFree(nn->act[i]);
+    if (nn->maps[i]) (void)hipFree(nn->maps[i]);
+  }
+  if (nn->d_meta) (void)hipFree(nn->d_meta);
+  if (nn->d_ivb) (void)hipFree(nn->d_ivb);
+  delete nn;
+}
+
+int kamd_nnet_output_dim(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->L.back().out_dim; }
+int kamd_nnet_left_context(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->left; }
+int kamd_nnet_right_context(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->right; }
+int kamd_nnet_num_output_frames(const kamd_nnet *h, int T) {
+  int s = reinterpret_cast<const Nnet *>(h)->subsampling;
+  return (T + s - 1) / s;
+}
+double kamd_nnet_last_flops(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->last_flops; }
+
+int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_row_off,
+                                   int ld_in, const float *d_ivectors, int n_utts, float *d_out,
+                                   const int64_t *h_out_row_off, int ld_out, void *stream) {
+  Nnet *nn = reinterpret_cast<Nnet *>(h);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nl = static_cast<int>(nn->L.size()), sub = nn->subsampling;
+  if (n_utts <= 0) return KAMD_OK;
+  if (ld_in < nn->L[0].in_pad && nn->L[0].input_layer == -1)
+    return kamd::SetError(KAMD_ERR_ARG, "ld_in %d < padded input dim %d (pad columns must be zero)", ld_in, nn->L[0].in_pad);
+  if (ld_out < nn->L.back().out_dim) return kamd::SetError(KAMD_ERR_ARG, "ld_out too small");
+  // ---- meta: T[u] (as int64 for simplicity), per-layer row offsets
+  // layout: [ (nl+2) arrays of (n_utts+1) int64 ] then T as int32
+  const size_t stride = n_utts + 1;
+  std::vector<int64_t> meta((nl + 2) * stride + (n_utts + 1) / 2 + 1, 0);
+  int *Th = reinterpret_cast<int *>(&meta[(nl + 2) * stride]);
+  std::vector<int> n_out(n_utts);
+  for (int u = 0; u < n_utts; u++) {
+    int T = static_cast<int>(h_in_row_off[u + 1] - h_in_row_off[u]);
+    if (T <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no frames", u);
+    Th[u] = T; n_out[u] = (T + sub - 1) / sub;
+    meta[nl * stride + u] = h_in_row_off[u];         // feature rows
+  }
+  meta[nl * stride + n_utts] = h_in_row_off[n_utts];
+  std::vector<int64_t> M(nl, 0);
+  for (int l = 0; l < nl; l++) {
+    int64_t acc = 0;
+    for (int u = 0; u < n_utts; u++) {
+      // the last layer writes straight into the caller's buffer at its row offsets
+      meta[l * stride + u] = (l == nl - 1) ? h_out_row_off[u] : acc;
+      acc += kamd::LayerRows(nn->L[l], n_out[u], sub);
+    }
+    meta[l * stride + n_utts] = (l == nl - 1) ? h_out_row_off[n_utts - 1] + n_out[n_utts - 1] : acc;
+    M[l] = acc;
+    if (acc > 2000000000LL) return kamd::SetError(KAMD_ERR_ARG, "batch too large");
+  }
+  // the output layer's rows must be contiguous in the caller's buffer for the map
+  // kernel's binary search: require h_out_row_off to be the running sum of n_out.
+  for (int u = 0; u + 1 < n_utts; u++)
+    if (h_out_row_off[u + 1] != h_out_row_off[u] + n_out[u])
+      return kamd::SetError(KAMD_ERR_ARG, "h_out_row_off must be the running sum of output frames");
+  if (kamd::Grow(&nn->d_meta, &nn->meta_cap, meta.size()) != KAMD_OK) return KAMD_ERR_HIP;
+  KAMD_HIP(hipMemcpyAsync(nn->d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  const int *d_T = reinterpret_cast<const int *>(nn->d_meta + (nl + 2) * stride);
+  double flops = 0;
+  for (int l = 0; l < nl; l++) {
+    LayerDev &L = nn->L[l];
+    const int64_t Ml = M[l];
+    // workspace
+    float *C; int ldC;
+    int64_t row_base = 0;
+    if (l == nl - 1) { C = d_out; ldC = ld_out; row_base = h_out_row_off[0]; }
+    else {
+      if (kamd::Grow(&nn->act[l], &nn->act_cap[l], static_cast<size_t>(Ml) * L.out_pad) != KAMD_OK) return KAMD_ERR_HIP;
+      C = nn->act[l]; ldC = L.out_pad;
+    }
+    const size_t map_ints = static_cast<size_t>(L.n_off + 2) * Ml;
+    if (kamd::Grow(&nn->maps[l], &nn->maps_cap[l], map_ints) != KAMD_OK) return KAMD_ERR_HIP;
+    int *rowmap = nn->maps[l], *bypmap = rowmap + static_cast<size_t>(L.n_off) * Ml, *row2utt = bypmap + Ml;
+    // the last layer's row offsets are absolute rows of d_out; the map kernel works in
+    // layer-local rows, so give it offsets relative to row_base.
+    const int64_t *d_row_off = nn->d_meta + l * stride;
+    kamd::MapArgs ma;
+    ma.n_utts = n_utts; ma.M = static_cast<int>(Ml);
+    ma.T = d_T; ma.lo = L.lo; ma.step = L.step;
+    ma.row2utt = L.ivector_dim > 0 ? row2utt : NULL;
+    auto fill_prod = [&](int prod, kamd::MapArgs *a) {
+      if (prod < 0) { a->prod_row_off = nn->d_meta + nl * stride; a->prod_is_input = 1; a->prod_lo = 0; a->prod_step = 1; }
+      else { a->prod_row_off = nn->d_meta + prod * stride; a->prod_is_input = 0; a->prod_lo = nn->L[prod].lo; a->prod_step = nn->L[prod].step; }
+    };
+    // row offsets for the last layer are absolute; shift handled by a local copy
+    const int64_t *layer_row_off = d_row_off;
+    int64_t *d_tmp_off = NULL;
+    if (l == nl - 1 && row_base != 0) {
+      std::vector<int64_t> rel(stride);
+      for (size_t i = 0; i < stride; i++) rel[i] = meta[l * stride + i] - row_base;
+      KAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_tmp_off), stride * 8, st));
+      KAMD_HIP(hipMemcpyAsync(d_tmp_off, rel.data(), stride * 8, hipMemcpyHostToDevice, st));
+      KAMD_HIP(hipStreamSynchronize(st));
+      layer_row_off = d_tmp_off;
+    }
+    ma.row_off = layer_row_off;
+    fill_prod(L.input_layer, &ma);
+    ma.n_off = L.n_off;
+    for (int o = 0; o < L.n_off; o++) ma.offs[o] = L.offs[o];
+    ma.rowmap = rowmap;
+    hipLaunchKernelGGL(kamd::RowMapKernel, dim3(kamd::CeilDiv(Ml, 256)), dim3(256), 0, st, ma);
+    if (L.bypass_layer != -2) {
+      kamd::MapArgs mb = ma;
+      fill_prod(L.bypass_layer, &mb);
+      mb.n_off = 1; mb.offs[0] = 0; mb.rowmap = bypmap; mb.row2utt = NULL;
+      hipLaunchKernelGGL(kamd::RowMapKernel, dim3(kamd::CeilDiv(Ml, 256)), dim3(256), 0, st, mb);
+    }
+    kamd::GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    if (L.input_layer < 0) { g.A = d_feats; g.ldA = ld_in; }
+    else { g.A = nn->act[L.input_layer]; g.ldA = nn->L[L.input_layer].out_pad; }
+    g.rowmap = rowmap; g.M = static_cast<int>(Ml); g.N = L.out_dim; g.n_off = L.n_off; g.in_pad = L.in_pad;
+    g.W = L.W; g.bias = L.bias; g.relu = L.relu; g.bn_scale = L.bn_scale; g.bn_offset = L.bn_offset;
+    if (L.ivector_dim > 0) {
+      if (!d_ivectors) return kamd::SetError(KAMD_ERR_ARG, "model needs ivectors");
+      if (kamd::Grow(&nn->d_ivb, &nn->ivb_cap, static_cast<size_t>(n_utts) * L.out_dim) != KAMD_OK) return KAMD_ERR_HIP;
+      hipLaunchKernelGGL(kamd::IvecBiasKernel, dim3(kamd::CeilDiv(L.out_dim, 128), n_utts), dim3(128), 0, st,
+                         L.Wiv, d_ivectors, L.out_dim, L.ivector_dim, nn->d_ivb);
+      g.ivbias = nn->d_ivb; g.row2utt = row2utt;
+    }
+    if (L.bypass_layer != -2) {
+      if (L.bypass_layer < 0) { g.byp = d_feats; g.ld_byp = ld_in; }
+      else { g.byp = nn->act[L.bypass_layer]; g.ld_byp = nn->L[L.bypass_layer].out_pad; }
+      g.bypmap = bypmap; g.bypass_scale = L.bypass_scale;
+    }
+    g.post_offset = L.post_offset; g.post_scale = L.post_scale;
+    g.C = C + row_base * ldC; g.ldC = ldC;
+    if (L.out_dim <= 64 || (L.out_dim % 128 != 0 && L.out_dim % 128 <= 64)) {
+      dim3 grid(kamd::CeilDiv(L.out_dim, 64), kamd::CeilDiv(Ml, 128));
+      hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 64, 4, 1>), grid, dim3(256), 0, st, g);
+    } else {
+      dim3 grid(kamd::CeilDiv(L.out_dim, 128), kamd::CeilDiv(Ml, 128));
+      hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 128, 2, 2>), grid, dim3(256), 0, st, g);
+    }
+    KAMD_HIP(hipGetLastError());
+    if (d_tmp_off) KAMD_HIP(hipFreeAsync(d_tmp_off, st));
+    flops += 2.0 * static_cast<double>(Ml) * L.out_dim * (L.n_off * L.in_dim + L.ivector_dim);
+  }
+  nn->last_flops = flops;
+  return KAMD_OK;
+}
+
+int kamd_nnet_forward(kamd_nnet *h, const float *feats, int T, const float *ivector, float *out,
+                      int out_rows_cap) {
+  Nnet *nn = reinterpret_cast<Nnet *>(h);
+  if (T <= 0) return 0;
+  const int n_out = (T + nn->subsampling - 1) / nn->subsampling, P = nn->L.back().out_dim;
+  if (n_out > out_rows_cap) return kamd::SetError(KAMD_ERR_ARG, "output buffer too small");
+  const int ld = nn->L[0].in_pad, ivd = nn->L[0].ivector_dim;
+  std::vector<float> padded(static_cast<size_t>(T) * ld, 0.0f);
+  for (int t = 0; t < T; t++) memcpy(&padded[static_cast<size_t>(t) * ld], feats + static_cast<size_t>(t) * nn->input_dim, sizeof(float) * nn->input_dim);
+  float *d_in = NULL, *d_out = NULL, *d_iv = NULL;
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_in), padded.size() * sizeof(float)));
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_out), static_cast<size_t>(n_out) * P * sizeof(float)));
+  KAMD_HIP(hipMemcpy(d_in, padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (ivd > 0) {
+    if (!ivector) return kamd::SetError(KAMD_ERR_ARG, "model needs an ivector");
+    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_iv), ivd * sizeof(float)));
+    KAMD_HIP(hipMemcpy(d_iv, ivector, ivd * sizeof(float), hipMemcpyHostToDevice));
+  }
+  int64_t in_off[2] = {0, T}, out_off[1] = {0};
+  int rc = kamd_nnet_forward_batch_device(h, d_in, in_off, ld, d_iv, 1, d_out, out_off, P, NULL);
+  if (rc == KAMD_OK) {
+    hipError_t e = hipMemcpy(out, d_out, static_cast<size_t>(n_out) * P * sizeof(float), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = kamd::SetError(KAMD_ERR_HIP, "D2H failed: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  if (d_iv) (void)hipFree(d_iv);
+  return rc == KAMD_OK ? n_out : rc;
+}
+
+}  // extern "C"

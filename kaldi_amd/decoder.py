@@ -1,0 +1,253 @@
+"""Host-side mirror of LatticeFasterDecoder (decoder/lattice-faster-decoder.h:226-343),
+DecodableMatrixMapped (decoder/decodable-matrix.h:98-136) and the nnet / graph handles,
+over the C-ABI.  Same method names and argument meaning as the reference classes."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import KamdError, check, lib
+
+
+class Graph:
+    """HCLG on device (replaces the fst::Fst<StdArc> handed to the decoder ctor)."""
+
+    def __init__(self, hclg):
+        self.hclg = hclg
+        arcs = np.ascontiguousarray(hclg.arcs)
+        off = np.ascontiguousarray(hclg.arc_off, np.int64)
+        fin = np.ascontiguousarray(hclg.final, np.float32)
+        self._h = lib().kamd_graph_create(hclg.num_states, hclg.start, abi.iptr(off, C.c_int64),
+                                          arcs.ctypes.data_as(C.c_void_p), abi.fptr(fin))
+        if not self._h:
+            raise KamdError(lib().kamd_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kamd_graph_destroy(self._h)
+            self._h = None
+
+
+class Nnet:
+    """The collapsed acoustic model on device (AmNnetSimple after CollapseModel)."""
+
+    def __init__(self, model):
+        self.model = model
+        self._h = lib().kamd_nnet_create(model.descs(), len(model.layers), model.input_dim,
+                                         model.subsampling)
+        if not self._h:
+            raise KamdError(lib().kamd_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kamd_nnet_destroy(self._h)
+            self._h = None
+
+    def OutputDim(self):
+        return lib().kamd_nnet_output_dim(self._h)
+
+    def Context(self):
+        return lib().kamd_nnet_left_context(self._h), lib().kamd_nnet_right_context(self._h)
+
+    def Forward(self, feats, ivector=None):
+        """All of DecodableNnetSimple::GetOutputForFrame for one utterance."""
+        feats = np.ascontiguousarray(feats, np.float32)
+        T = feats.shape[0]
+        n_out = lib().kamd_nnet_num_output_frames(self._h, T)
+        out = np.zeros((n_out, self.OutputDim()), np.float32)
+        iv = None if ivector is None else np.ascontiguousarray(ivector, np.float32)
+        check(lib().kamd_nnet_forward(self._h, abi.fptr(feats), T, abi.fptr(iv), abi.fptr(out), n_out))
+        return out
+
+
+class Lattice:
+    """Raw lattice (kaldi::Lattice equivalent) in canonical numbering."""
+
+    def __init__(self, start, frame, hclg, cost, final, arcs, num_frames):
+        self.start, self.frame, self.hclg, self.cost = start, frame, hclg, cost
+        self.final, self.arcs, self.num_frames = final, arcs, num_frames
+
+
+class DeviceMatrix:
+    """A host float32 matrix uploaded to HBM (DecodableMatrixMapped's 'likes' matrix)."""
+
+    def __init__(self, loglikes):
+        a = np.ascontiguousarray(loglikes, np.float32)
+        self.rows, self.cols = a.shape
+        self._d = lib().kamd_malloc(max(a.nbytes, 16))
+        if not self._d:
+            raise KamdError(lib().kamd_last_error().decode())
+        if a.nbytes:
+            check(lib().kamd_memcpy_h2d(self._d, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def __del__(self):
+        if getattr(self, "_d", None):
+            lib().kamd_free(self._d)
+            self._d = None
+
+    def ptr(self, row=0):
+        return self._d + row * self.cols * 4
+
+
+class LatticeFasterDecoder:
+    """One lane of the device decoder behind the reference's per-utterance API."""
+
+    def __init__(self, graph, config=None, sizes=None, lane=0, _shared=None):
+        self.graph = graph
+        self.config = config or abi.decoder_config_default()
+        if _shared is not None:
+            self._dec, self._own = _shared, False
+        else:
+            s = sizes
+            if s is None:
+                s = abi.DecoderSizes()
+                lib().kamd_decoder_sizes_default(C.byref(s))
+                s.max_lanes = 1
+            self.sizes = s
+            t2p = np.ascontiguousarray(graph.hclg.tid2pdf, np.int32)
+            self._t2p = t2p
+            self._dec = lib().kamd_decoder_create(graph._h, C.byref(self.config), C.byref(s),
+                                                  abi.iptr(t2p), t2p.size - 1)
+            if not self._dec:
+                raise KamdError(lib().kamd_last_error().decode())
+            self._own = True
+        self.lane = lane
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "_own", False) and getattr(self, "_dec", None):
+            lib().kamd_decoder_destroy(self._dec)
+            self._dec = None
+
+    def SetOptions(self, config):
+        self.config = config
+        check(lib().kamd_decoder_set_options(self._dec, C.byref(config)))
+
+    def InitDecoding(self):
+        lanes = np.asarray([self.lane], np.int32)
+        check(lib().kamd_decoder_init(self._dec, abi.iptr(lanes), 1, None))
+        check(lib().kamd_decoder_sync(self._dec))
+
+    def AdvanceDecoding(self, decodable, max_num_frames=-1):
+        """`decodable`: DeviceMatrix or host [frames x pdfs] array of log-likelihoods not yet
+        decoded (NumFramesReady - NumFramesDecoded rows)."""
+        dm = decodable if isinstance(decodable, DeviceMatrix) else DeviceMatrix(decodable)
+        self._keep.append(dm)
+        n = dm.rows if max_num_frames < 0 else min(dm.rows, max_num_frames)
+        task = abi.DecodeTask(self.lane, n, dm.ptr(0), dm.cols, 0)
+        check(lib().kamd_decoder_advance(self._dec, C.byref(task), 1, None))
+        check(lib().kamd_decoder_sync(self._dec))
+        self._keep.clear()
+
+    def FinalizeDecoding(self):
+        lanes = np.asarray([self.lane], np.int32)
+        check(lib().kamd_decoder_finalize(self._dec, abi.iptr(lanes), 1, None))
+        check(lib().kamd_decoder_sync(self._dec))
+
+    def Decode(self, decodable):
+        self.InitDecoding()
+        self.AdvanceDecoding(decodable)
+        self.FinalizeDecoding()
+        return True
+
+    def NumFramesDecoded(self):
+        return lib().kamd_decoder_num_frames_decoded(self._dec, self.lane)
+
+    def FinalRelativeCost(self):
+        return lib().kamd_decoder_final_relative_cost(self._dec, self.lane)
+
+    def ReachedFinal(self):
+        return bool(lib().kamd_decoder_reached_final(self._dec, self.lane))
+
+    def GetRawLattice(self):
+        return get_raw_lattice(self._dec, self.lane)
+
+    def GetBestPath(self):
+        return best_path(self._dec, self.lane)
+
+    def trace(self):
+        return get_trace(self._dec, self.lane)
+
+    def counters(self):
+        c = np.zeros(8, np.int64)
+        check(lib().kamd_decoder_get_counters(self._dec, self.lane, abi.iptr(c, C.c_int64)))
+        return c
+
+
+def get_raw_lattice(dec, lane):
+    sz = abi.LatticeSize()
+    check(lib().kamd_decoder_lattice_size(dec, lane, C.byref(sz)))
+    n, m = sz.num_states, sz.num_arcs
+    if n == 0:
+        return None
+    fr, hc = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    co, fi = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    arcs = np.zeros(m, abi.LAT_ARC_DTYPE)
+    check(lib().kamd_decoder_get_raw_lattice(dec, lane, abi.iptr(fr), abi.iptr(hc), abi.fptr(co),
+                                             abi.fptr(fi), arcs.ctypes.data_as(C.c_void_p)))
+    return Lattice(sz.start, fr, hc, co, fi, arcs, sz.num_frames)
+
+
+def best_path(dec, lane):
+    sz = abi.LatticeSize()
+    check(lib().kamd_decoder_lattice_size(dec, lane, C.byref(sz)))
+    cap = max(sz.num_arcs, 1)
+    ali, words = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    na, nw = C.c_int(), C.c_int()
+    g, a = C.c_float(), C.c_float()
+    rc = lib().kamd_decoder_best_path(dec, lane, abi.iptr(ali), cap, C.byref(na), abi.iptr(words), cap,
+                                      C.byref(nw), C.byref(g), C.byref(a))
+    if rc != 0:
+        return None
+    return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(),
+                graph_cost=g.value, acoustic_cost=a.value)
+
+
+def get_trace(dec, lane):
+    n = lib().kamd_decoder_num_frames_decoded(dec, lane)
+    nt, cu, of = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32)
+    k = check(lib().kamd_decoder_get_trace(dec, lane, abi.iptr(nt), abi.fptr(cu), abi.fptr(of), n))
+    return nt[:k], cu[:k], of[:k]
+
+
+class BatchDecoder:
+    """N lanes decoded in one launch (NnetBatchDecoder's role, nnet3/nnet-batch-compute.h:606)."""
+
+    def __init__(self, graph, config, sizes):
+        self.graph, self.config, self.sizes = graph, config, sizes
+        t2p = np.ascontiguousarray(graph.hclg.tid2pdf, np.int32)
+        self._t2p = t2p
+        self._dec = lib().kamd_decoder_create(graph._h, C.byref(config), C.byref(sizes), abi.iptr(t2p),
+                                              t2p.size - 1)
+        if not self._dec:
+            raise KamdError(lib().kamd_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_dec", None):
+            lib().kamd_decoder_destroy(self._dec)
+            self._dec = None
+
+    def decode(self, matrices):
+        """matrices: list of DeviceMatrix / host arrays, one per lane."""
+        n = len(matrices)
+        dms = [m if isinstance(m, DeviceMatrix) else DeviceMatrix(m) for m in matrices]
+        lanes = np.arange(n, dtype=np.int32)
+        tasks = (abi.DecodeTask * n)()
+        for i, dm in enumerate(dms):
+            tasks[i] = abi.DecodeTask(i, dm.rows, dm.ptr(0), dm.cols, 0)
+        check(lib().kamd_decoder_init(self._dec, abi.iptr(lanes), n, None))
+        check(lib().kamd_decoder_advance(self._dec, tasks, n, None))
+        check(lib().kamd_decoder_finalize(self._dec, abi.iptr(lanes), n, None))
+        check(lib().kamd_decoder_sync(self._dec))
+        return [get_raw_lattice(self._dec, i) for i in range(n)]
+
+    def best_path(self, lane):
+        return best_path(self._dec, lane)
+
+    def counters(self, lane):
+        c = np.zeros(8, np.int64)
+        check(lib().kamd_decoder_get_counters(self._dec, lane, abi.iptr(c, C.c_int64)))
+        return c
+
+    def last_advance_ms(self):
+        return lib().kamd_decoder_last_advance_ms(self._dec)

@@ -1,0 +1,86 @@
+"""wav -> MFCC -> TDNN-F -> LatticeFasterDecoder for a batch of utterances, device resident
+(nnet3-latgen-faster-batch's job, nnet3bin/nnet3-latgen-faster-batch.cc:170-214)."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, decoder
+from ._lib import KamdError, check, lib
+
+
+def default_sizes(cfg, max_utts, max_out_frames, hash_capacity=None, tokens_per_frame=None,
+                  links_per_frame=None):
+    """Device arena sizing for `max_utts` lanes of at most `max_out_frames` decoded frames."""
+    act = cfg.max_active if cfg.max_active < abi.INT32_MAX else 20000
+    tpf = tokens_per_frame or int(min(3.0 * act, 60000) + 2000)
+    lpf = links_per_frame or int(1.6 * tpf + 2000)
+    hc = hash_capacity or 1 << int(np.ceil(np.log2(max(4 * tpf, max_out_frames + 8, 4096))))
+    return abi.DecoderSizes(max_utts, hc, int(tpf) * (max_out_frames + 1), int(lpf) * (max_out_frames + 1),
+                            max_out_frames + 1)
+
+
+class Pipeline:
+    def __init__(self, mfcc_opts, model, hclg, cfg, max_utts=64, max_seconds=36.0, sizes=None):
+        self.feat = __import__("kaldi_amd.feat", fromlist=["Mfcc"]).Mfcc(mfcc_opts)
+        self.model = model
+        self.nnet = decoder.Nnet(model)
+        self.graph = decoder.Graph(hclg)
+        self.cfg = cfg
+        fps = 1000.0 / mfcc_opts.frame.frame_shift_ms
+        max_out = int(max_seconds * fps / model.subsampling) + 2
+        self.sizes = sizes or default_sizes(cfg, max_utts, max_out)
+        self.dec = decoder.BatchDecoder(self.graph, cfg, self.sizes)
+        self._h = lib().kamd_pipeline_create(self.feat._h, self.nnet._h, self.dec._dec)
+        if not self._h:
+            raise KamdError(lib().kamd_last_error().decode())
+        self.n_utts = 0
+        self.last_stage_ms = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kamd_pipeline_destroy(self._h)
+            self._h = None
+
+    def load(self, waves):
+        off = np.concatenate([[0], np.cumsum([w.size for w in waves])]).astype(np.int64)
+        flat = np.ascontiguousarray(np.concatenate(waves), np.float32)
+        check(lib().kamd_pipeline_load_batch(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), len(waves)))
+        self.n_utts = len(waves)
+        self.audio_seconds = float(flat.size) / self.feat.opts.frame.samp_freq
+
+    def run(self):
+        ms = np.zeros(4, np.float32)
+        check(lib().kamd_pipeline_run(self._h, abi.fptr(ms)))
+        self.last_stage_ms = ms.tolist()
+        return self.last_stage_ms
+
+    def results(self, lattices=True):
+        out = []
+        for u in range(self.n_utts):
+            bp = decoder.best_path(self.dec._dec, u)
+            r = dict(words=bp["words"] if bp else np.zeros(0, np.int32), best=bp)
+            if lattices:
+                r["lattice"] = decoder.get_raw_lattice(self.dec._dec, u)
+            out.append(r)
+        return out
+
+    def decode(self, waves, lattices=True):
+        self.load(waves)
+        self.run()
+        return self.results(lattices)
+
+    def _get(self, fn, u):
+        rows, cols = C.c_int32(), C.c_int32()
+        cap = 1 << 16
+        buf = np.zeros((cap, 1), np.float32)
+        # query the shape with a zero-capacity call first
+        fn(self._h, u, abi.fptr(buf), 0, C.byref(rows), C.byref(cols))
+        buf = np.zeros((rows.value, cols.value), np.float32)
+        check(fn(self._h, u, abi.fptr(buf), rows.value, C.byref(rows), C.byref(cols)))
+        return buf
+
+    def features(self, u):
+        return self._get(lib().kamd_pipeline_get_features, u)
+
+    def loglikes(self, u):
+        return self._get(lib().kamd_pipeline_get_loglikes, u)

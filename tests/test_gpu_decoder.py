@@ -1,0 +1,163 @@
+"""GPU parity proper: the HIP decoder (through the C-ABI) must reproduce the canonical
+CPU oracle BIT-EXACTLY: same surviving tokens (frame, HCLG state), same forward costs,
+same links and weights, same per-frame cutoffs and cost offsets, same work counters."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from kaldi_amd import abi, decoder, synth
+from oracle import orc
+from tests.util import lattice_diff, lattices_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def sizes(lanes=1, hash_cap=1 << 14, toks=1 << 18, links=1 << 19, frames=512):
+    return abi.DecoderSizes(lanes, hash_cap, toks, links, frames)
+
+
+def run_both(g, ll, cfg, sz=None):
+    G = decoder.Graph(g)
+    d = decoder.LatticeFasterDecoder(G, cfg, sz or sizes())
+    d.Decode(ll)
+    o = orc.Decoder(g, cfg, 1)
+    o.Decode(ll)
+    return d, o
+
+
+def assert_same(d, o):
+    ln, lo = d.GetRawLattice(), o.GetRawLattice()
+    assert lattices_equal(ln, lo), lattice_diff(ln, lo)
+    tn, to = d.trace(), o.trace()
+    np.testing.assert_array_equal(tn[0], to[0])
+    np.testing.assert_array_equal(tn[1].view(np.uint32), to[1].view(np.uint32))
+    np.testing.assert_array_equal(tn[2].view(np.uint32), to[2].view(np.uint32))
+    np.testing.assert_array_equal(d.counters()[:7], o.counters()[:7])
+    bn, bo = d.GetBestPath(), lo.best_path()
+    assert bn["words"].tolist() == bo["words"].tolist()
+    assert bn["alignment"].tolist() == bo["alignment"].tolist()
+    assert bn["graph_cost"] == bo["graph_cost"] and bn["acoustic_cost"] == bo["acoustic_cost"]
+    assert d.FinalRelativeCost() == o.FinalRelativeCost()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_hclg_peaked_recipe_config(seed):
+    g = synth.make_hclg(num_units=40, vocab=150, n_hist=25, seed=seed)
+    ll, words, _ = synth.sample_utterance(g, n_words=7, seed=seed, peak=7.0)
+    d, o = run_both(g, ll, abi.decoder_config_recipe())
+    assert_same(d, o)
+    assert d.GetBestPath()["words"].tolist() == words
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_graph_noise(seed):
+    g = synth.make_random_graph(num_states=500, num_labels=40, mean_arcs=3.5, seed=seed, final_frac=0.2)
+    ll = synth.random_loglikes(30, g.num_pdfs, seed=seed, scale=2.0)
+    cfg = abi.decoder_config_recipe()
+    cfg.beam, cfg.lattice_beam = 6.0, 4.0
+    d, o = run_both(g, ll, cfg)
+    assert_same(d, o)
+
+
+@pytest.mark.parametrize("max_active,min_active", [(150, 20), (60, 0), (2147483647, 0), (40, 40), (5000, 300)])
+def test_max_min_active_select(max_active, min_active):
+    """Exact radix select == nth_element on every GetCutoff branch."""
+    g = synth.make_hclg(num_units=16, vocab=80, n_hist=10, seed=21)
+    ll = synth.random_loglikes(25, g.num_pdfs, seed=3, scale=0.7)
+    cfg = abi.decoder_config_recipe()
+    cfg.max_active, cfg.min_active = max_active, min_active
+    d, o = run_both(g, ll, cfg)
+    assert_same(d, o)
+    if max_active < 1000:
+        assert (o.trace()[0] > max_active).any()
+
+
+def test_min_active_binding_with_tight_beam():
+    g = synth.make_random_graph(num_states=400, num_labels=30, mean_arcs=4, seed=7, final_frac=0.5)
+    ll = synth.random_loglikes(20, g.num_pdfs, seed=8, scale=3.0)
+    cfg = abi.decoder_config_default()
+    cfg.beam, cfg.max_active, cfg.min_active, cfg.lattice_beam = 2.0, 60, 25, 3.0
+    d, o = run_both(g, ll, cfg)
+    assert_same(d, o)
+
+
+def test_hub_states_wave_expansion():
+    """Unigram hub with hundreds of arcs exercises the wavefront-cooperative path."""
+    g = synth.make_hclg(num_units=30, vocab=700, n_hist=6, fanout=(40, 90), seed=4)
+    ll, words, _ = synth.sample_utterance(g, n_words=5, seed=1, peak=6.0)
+    d, o = run_both(g, ll, abi.decoder_config_recipe())
+    assert_same(d, o)
+
+
+def test_advance_in_chunks_and_no_final_state():
+    g = synth.make_hclg(num_units=24, vocab=60, n_hist=12, seed=3)
+    ll, _, _ = synth.sample_utterance(g, n_words=6, seed=4)
+    ll = ll[:-2]                      # stop mid-word: no final state reached
+    cfg = abi.decoder_config_recipe()
+    G = decoder.Graph(g)
+    d = decoder.LatticeFasterDecoder(G, cfg, sizes())
+    d.InitDecoding()
+    for i in range(0, ll.shape[0], 5):
+        d.AdvanceDecoding(ll[i:i + 5])
+    d.FinalizeDecoding()
+    o = orc.Decoder(g, cfg, 1)
+    o.Decode(ll)
+    assert_same(d, o)
+    assert d.NumFramesDecoded() == ll.shape[0]
+
+
+def test_single_frame_and_reuse_of_decoder_object():
+    g = synth.make_hclg(num_units=8, vocab=10, n_hist=3, seed=1)
+    cfg = abi.decoder_config_recipe()
+    G = decoder.Graph(g)
+    d = decoder.LatticeFasterDecoder(G, cfg, sizes())
+    for T, seed in ((1, 2), (9, 3), (2, 4)):      # one decoder object, several utterances
+        ll = synth.random_loglikes(T, g.num_pdfs, seed=seed)
+        d.Decode(ll)
+        o = orc.Decoder(g, cfg, 1)
+        o.Decode(ll)
+        assert_same(d, o)
+
+
+def test_batch_of_lanes_matches_per_utterance():
+    g = synth.make_hclg(num_units=32, vocab=100, n_hist=16, seed=8)
+    cfg = abi.decoder_config_recipe()
+    utts = [synth.sample_utterance(g, n_words=3 + (i % 4), seed=50 + i, peak=6.5)[0] for i in range(9)]
+    bd = decoder.BatchDecoder(decoder.Graph(g), cfg, sizes(lanes=9))
+    lats = bd.decode(utts)
+    for i, ll in enumerate(utts):
+        o = orc.Decoder(g, cfg, 1)
+        o.Decode(ll)
+        assert lattices_equal(lats[i], o.GetRawLattice()), (i, lattice_diff(lats[i], o.GetRawLattice()))
+
+
+def test_capacity_overflow_is_reported_not_silent():
+    g = synth.make_hclg(num_units=16, vocab=80, n_hist=10, seed=21)
+    ll = synth.random_loglikes(25, g.num_pdfs, seed=3, scale=0.7)
+    G = decoder.Graph(g)
+    d = decoder.LatticeFasterDecoder(G, abi.decoder_config_recipe(), sizes(hash_cap=1 << 14, toks=2000, links=3000))
+    from kaldi_amd._lib import KamdError
+    with pytest.raises(KamdError, match="capacity"):
+        d.Decode(ll)
+
+
+def test_epsilon_cycle_rejected():
+    g = synth.make_random_graph(num_states=20, seed=1)
+    g.arcs["ilabel"][g.arc_off[5]] = 0
+    g.arcs["nextstate"][g.arc_off[5]] = 5
+    from kaldi_amd._lib import KamdError
+    with pytest.raises(KamdError, match="psilon"):
+        decoder.Graph(g)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_midsize_graph_saturated(seed):
+    """~60k states, max-active binding on most frames, thousands of tokens per frame."""
+    g = synth.make_hclg(num_units=200, vocab=3000, n_hist=300, fanout=(10, 60), seed=seed)
+    ll = synth.random_loglikes(40, g.num_pdfs, seed=seed, scale=1.0)
+    cfg = abi.decoder_config_recipe()
+    cfg.max_active = 2000
+    d, o = run_both(g, ll, cfg, sizes(hash_cap=1 << 16, toks=1 << 21, links=1 << 22))
+    assert_same(d, o)
+    assert (o.trace()[0] > 2000).any()

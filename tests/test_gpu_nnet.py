@@ -1,0 +1,78 @@
+"""GPU parity: fused MFMA TDNN-F forward vs the CPU oracle.  Tolerance: 1e-4 of the output
+scale (fp32 products, fp32 accumulation in a different order)."""
+import numpy as np
+import pytest
+
+from kaldi_amd import decoder, nnet
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def check(model, T, seed, ivec=None):
+    rng = np.random.default_rng(seed)
+    feats = (3 * rng.standard_normal((T, model.input_dim))).astype(np.float32)
+    got = decoder.Nnet(model).Forward(feats, ivec)
+    ref = orc.nnet_forward(model, feats, ivec)
+    assert got.shape == ref.shape
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() < 1e-4 * scale, (np.abs(got - ref).max(), scale)
+    return got
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 50, 151, 400])
+def test_tiny_model(T):
+    check(nnet.tdnnf_tiny(num_pdfs=70), T, T)
+
+
+def test_ivector_input():
+    m = nnet.tdnnf_tiny(num_pdfs=33, ivector_dim=10)
+    iv = np.random.default_rng(1).standard_normal(10).astype(np.float32)
+    check(m, 77, 2, iv)
+
+
+def test_odd_dims_padding():
+    m = nnet.make_tdnnf(50, 18, [1, 0, 3], 22, 45, input_dim=13, seed=9)
+    check(m, 64, 3)
+
+
+def test_context_and_plan():
+    m = nnet.tdnnf_mini_librispeech(num_pdfs=64)
+    n = decoder.Nnet(m)
+    assert n.Context() == m.context() == (28, 28)
+
+
+def test_mini_librispeech_topology_small_T():
+    m = nnet.tdnnf_mini_librispeech(num_pdfs=200)
+    check(m, 40, 5)
+
+
+def test_batch_invariance():
+    """An utterance's output does not depend on what else is in the batch."""
+    import ctypes as C
+    from kaldi_amd import abi
+    from kaldi_amd._lib import check as ck, lib
+    m = nnet.tdnnf_tiny(num_pdfs=40)
+    n = decoder.Nnet(m)
+    rng = np.random.default_rng(0)
+    Ts = [31, 90, 7]
+    feats = [rng.standard_normal((T, 40)).astype(np.float32) for T in Ts]
+    single = [n.Forward(f) for f in feats]
+    ld = 48
+    rows = sum(Ts)
+    big = np.zeros((rows, ld), np.float32)
+    off = np.concatenate([[0], np.cumsum(Ts)]).astype(np.int64)
+    for f, o in zip(feats, off):
+        big[o:o + f.shape[0], :40] = f
+    nout = [(T + 2) // 3 for T in Ts]
+    ooff = np.concatenate([[0], np.cumsum(nout)]).astype(np.int64)
+    d_in = decoder.DeviceMatrix(big)
+    d_out = lib().kamd_malloc(int(ooff[-1]) * 40 * 4)
+    ck(lib().kamd_nnet_forward_batch_device(n._h, d_in.ptr(0), abi.iptr(off, C.c_int64), ld, None, 3,
+                                            d_out, abi.iptr(ooff, C.c_int64), 40, None))
+    ck(lib().kamd_device_synchronize())
+    out = np.zeros((int(ooff[-1]), 40), np.float32)
+    ck(lib().kamd_memcpy_d2h(out.ctypes.data_as(C.c_void_p), d_out, out.nbytes))
+    lib().kamd_free(d_out)
+    for u in range(3):
+        np.testing.assert_array_equal(out[ooff[u]:ooff[u + 1]], single[u])
