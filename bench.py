@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- decode RTF (audio-seconds per wall-second) of the MI355X hot path.
+
+One "step" = one pass of the whole hot path over one batch of synthetic utterances that
+is already resident in HBM: MFCC -> TDNN-F log-likelihoods -> LatticeFasterDecoder
+(init + advance + finalize) -> raw lattices / 1-best staged for the host.
+Workload = BASELINE.json configs[1]: mini_librispeech TDNN-F chain topology
+(run_tdnn_1h.sh: 768/96, P=2328), tgsmall-scale synthetic HCLG, batch = 64 utterances
+per GPU, recipe decoder settings (beam 15, max-active 7000, min-active 200,
+lattice-beam 8).  Weak scaling: every rank decodes its own 64-utterance shard.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(c):
+    """8 N_exp + 16 A_exp + 8 A_emit + 16 K_surv + 20 L_kept + 12 N_tok."""
+    return 8 * c[0] + 16 * c[1] + 8 * c[2] + 16 * c[3] + 20 * c[4] + 12 * c[5]
+
+
+def build_workload(args, rank):
+    from kaldi_amd import abi, nnet, synth
+    t0 = time.time()
+    if args.workload == "mini_librispeech":
+        g = synth.make_hclg(num_units=1164, vocab=args.vocab, n_hist=args.n_hist, fanout=(12, 64),
+                            pron_len=(3, 7), seed=2)
+        model = nnet.tdnnf_mini_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
+    elif args.workload == "librispeech":
+        g = synth.make_hclg(num_units=3000, vocab=args.vocab, n_hist=args.n_hist, fanout=(12, 64),
+                            pron_len=(3, 7), seed=2)
+        model = nnet.tdnnf_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
+    else:  # tiny (CI / CPU-less smoke of the script itself)
+        g = synth.make_hclg(num_units=64, vocab=400, n_hist=60, seed=2)
+        model = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
+    durs = synth.utterance_durations(args.utts, seed=1000 + rank)
+    if args.max_seconds:
+        durs = np.minimum(durs, args.max_seconds)
+    waves = [synth.make_wave(d, seed=rank * 100000 + i) for i, d in enumerate(durs)]
+    cfg = abi.decoder_config_recipe()
+    return g, model, waves, cfg, time.time() - t0
+
+
+def cpu_baseline(g, model, waves, cfg, budget_s):
+    """The CPU oracle (a port of the reference path: faithful decoder mode 0) timed
+    single-threaded on this host on a bounded sample of the same workload."""
+    from kaldi_amd import abi
+    from oracle import orc
+    order = np.argsort([w.size for w in waves])
+    t_total, audio, n = 0.0, 0.0, 0
+    sample = []
+    for idx in order:                      # shortest utterances first, until the budget is spent
+        w = waves[idx]
+        t0 = time.time()
+        feats = orc.mfcc(abi.mfcc_opts_hires(), w)
+        ll = orc.nnet_forward(model, feats)
+        d = orc.Decoder(g, cfg, 0)
+        d.Decode(ll)
+        lat = d.GetRawLattice()
+        if lat is not None:
+            lat.best_path()
+        t_total += time.time() - t0
+        audio += w.size / 16000.0
+        n += 1
+        sample.append(round(w.size / 16000.0, 2))
+        if t_total > budget_s:
+            break
+    return {"value": audio / t_total, "unit": "audio-sec/wall-sec", "cores": 1, "kind": "port",
+            "sample": "%d shortest utterance(s) of the batch (%.1f s audio, %.1f s CPU): whole path "
+                      "MFCC+nnet+LatticeFasterDecoder(order-faithful oracle)+best path" % (n, audio, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="mini_librispeech", choices=["mini_librispeech", "librispeech", "tiny"])
+    ap.add_argument("--utts", type=int, default=64)
+    ap.add_argument("--vocab", type=int, default=20000)
+    ap.add_argument("--n-hist", type=int, default=18000)
+    ap.add_argument("--output-scale", type=float, default=6.0,
+                    help="scale on the random output layer: sets how peaked the synthetic posteriors are")
+    ap.add_argument("--max-seconds", type=float, default=0.0)
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", action="store_true", help="check lane 0 against the oracle")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")      # RCCL; only barriers + the final max-reduce use it
+
+    from kaldi_amd import abi, pipeline
+    from kaldi_amd._lib import check, lib, require_gpu
+    require_gpu()
+    check(lib().kamd_set_device(local_rank))
+    g, model, waves, cfg, t_build = build_workload(args, rank)
+    audio = sum(w.size for w in waves) / 16000.0
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves),
+                             max_seconds=max(w.size for w in waves) / 16000.0 + 0.5,
+                             avg_seconds=audio / len(waves))
+    pipe.load(waves)                        # inputs resident in HBM before the timed region
+
+    def sync_all():
+        check(lib().kamd_device_synchronize())
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pipe.run()
+    sync_all()
+    t0 = time.time()
+    stage = np.zeros(4)
+    adv_ms = []
+    for _ in range(args.steps):
+        stage += np.asarray(pipe.run())
+        adv_ms.append(pipe.dec.last_advance_ms())
+    sync_all()
+    dt = time.time() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        a = torch.tensor([audio], device="cuda")
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        total_audio = float(a.item())
+    else:
+        total_audio = audio
+    if rank != 0:
+        return
+    counters = np.sum([pipe.dec.counters(u) for u in range(len(waves))], axis=0)
+    alg_bytes = float(algorithmic_bytes(counters))       # per launch (counters reset at init)
+    adv = float(np.mean(adv_ms))
+    frames = int(counters[6])
+    res = pipe.results(lattices=False)
+    out = {
+        "metric": "decode RTF (audio-sec/wall-sec)",
+        "value": total_audio * args.steps / dt,
+        "unit": "audio-sec/wall-sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s TDNN-F chain topology (random init), synthetic tgsmall-scale HCLG "
+                               "(%d states, %d arcs), batch=%d utterances/GPU (%.0f s audio), beam 15 "
+                               "max-active 7000 min-active 200 lattice-beam 8" %
+                               (args.workload, g.num_states, g.num_arcs, len(waves), audio),
+                   "utterances_per_gpu": len(waves), "output_scale": args.output_scale},
+        "stage_ms": {"features": stage[0] / args.steps, "nnet": stage[1] / args.steps,
+                     "decode_advance": stage[2] / args.steps, "decode_finalize": stage[3] / args.steps},
+        "decoder": {"frames": frames, "tokens_per_frame": counters[5] / max(frames, 1),
+                    "expanded_per_frame": counters[0] / max(frames, 1),
+                    "arcs_per_frame": counters[1] / max(frames, 1),
+                    "links_per_frame": counters[4] / max(frames, 1),
+                    "words_lane0": int(res[0]["words"].size)},
+        "roofline": {"bound": "hbm", "kernel": "kamd::AdvanceKernel",
+                     "achieved": alg_bytes / (adv * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg_bytes / (adv * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": adv},
+        "nnet_tflops": lib().kamd_nnet_last_flops(pipe.nnet._h) / (stage[1] / args.steps * 1e-3) / 1e12,
+        "setup_s": t_build,
+    }
+    if args.verify:
+        from oracle import orc
+        o = orc.Decoder(g, cfg, 1)
+        o.Decode(pipe.loglikes(0))
+        out["verify_lane0_words_equal"] = bool(o.GetRawLattice().best_path()["words"].tolist() == res[0]["words"].tolist())
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, args.cpu_budget)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out, default=float))
+
+
+if __name__ == "__main__":
+    main()

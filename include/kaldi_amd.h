@@ -229,8 +229,8 @@ void kamd_decoder_config_default(kamd_decoder_config *c);
 typedef struct {
   int32_t max_lanes;          /* concurrently live decoder instances */
   int32_t hash_capacity;      /* per lane, power of two, tokens of one frame */
-  int64_t arena_tokens;       /* token records per lane */
-  int64_t arena_links;        /* forward-link records per lane */
+  int64_t arena_tokens;       /* token records per lane (pool = max_lanes x this) */
+  int64_t arena_links;        /* forward-link records per lane (pool likewise) */
   int32_t max_frames;         /* frames per lane */
 } kamd_decoder_sizes;
 void kamd_decoder_sizes_default(kamd_decoder_sizes *s);
@@ -248,6 +248,10 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *g,
                                   const int32_t *tid2pdf, int32_t num_tids);
 void kamd_decoder_destroy(kamd_decoder *d);
 int kamd_decoder_set_options(kamd_decoder *d, const kamd_decoder_config *cfg);
+/* Optional: split the token / link pools between lanes 0..n-1 in proportion to the
+ * number of frames each will decode (utterance lengths differ 1-35 s); lanes >= n get
+ * nothing.  Default is a uniform split.  Call before kamd_decoder_init. */
+int kamd_decoder_reserve(kamd_decoder *d, const int32_t *lane_frames, int n);
 
 /* One task = "advance lane L by n_frames frames of this log-likelihood matrix".
  * d_loglikes points at the row of the first frame to decode (row stride ld). */

@@ -69,6 +69,7 @@ def lib():
     sig("kamd_decoder_create", vp, [vp, C.POINTER(abi.DecoderConfig), C.POINTER(abi.DecoderSizes), ip, C.c_int32])
     sig("kamd_decoder_destroy", None, [vp])
     sig("kamd_decoder_set_options", C.c_int, [vp, C.POINTER(abi.DecoderConfig)])
+    sig("kamd_decoder_reserve", C.c_int, [vp, ip, C.c_int])
     sig("kamd_decoder_init", C.c_int, [vp, ip, C.c_int, vp])
     sig("kamd_decoder_advance", C.c_int, [vp, C.POINTER(abi.DecodeTask), C.c_int, vp])
     sig("kamd_decoder_finalize", C.c_int, [vp, ip, C.c_int, vp])
@@ -99,7 +100,7 @@ kamd_nnet_destroy kamd_nnet_output_dim kamd_nnet_left_context kamd_nnet_right_co
 kamd_nnet_num_output_frames kamd_nnet_forward_batch_device kamd_nnet_forward kamd_nnet_last_flops
 kamd_graph_create kamd_graph_destroy kamd_graph_num_states kamd_graph_num_arcs
 kamd_decoder_config_default kamd_decoder_sizes_default kamd_decoder_create kamd_decoder_destroy
-kamd_decoder_set_options kamd_decoder_init kamd_decoder_advance kamd_decoder_finalize
+kamd_decoder_set_options kamd_decoder_reserve kamd_decoder_init kamd_decoder_advance kamd_decoder_finalize
 kamd_decoder_sync kamd_decoder_num_frames_decoded kamd_decoder_final_relative_cost
 kamd_decoder_reached_final kamd_decoder_lattice_size kamd_decoder_get_raw_lattice
 kamd_decoder_best_path kamd_decoder_get_trace kamd_decoder_get_counters

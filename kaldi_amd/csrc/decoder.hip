@@ -68,7 +68,8 @@ struct DecDev {
   const int *tid2pdf;   // NULL => pdf = ilabel - 1
   kamd_decoder_config cfg;
   int hash_cap, hash_mask, max_frames;
-  int arena_tokens, arena_links;
+  const long long *lane_tok_base, *lane_lnk_base;  // per lane: offset into the pools
+  const int *lane_tok_cap, *lane_lnk_cap;          // per lane: capacity (records)
   u64 *H; u32 *slots; int *slot_tok; u32 *stamp; u32 *wl;  // per lane: hash_cap (wl: 2x)
   int *tok_state; float *tok_cost; float *tok_extra; int *tok_map;  // per lane: arena_tokens
   Link *links;                                                      // per lane: arena_links
@@ -86,16 +87,19 @@ struct Ctx {
   int *tok_state; float *tok_cost; float *tok_extra; int *tok_map;
   Link *links; int *tok_off; int *lnk_off; float *cost_offsets; int *trace_ntok;
   float *trace_cutoff; float *scratch; LaneState *st;
+  int tok_cap, lnk_cap;
 };
 
 __device__ inline Ctx MakeCtx(const DecDev &d, int lane) {
   Ctx c;
-  size_t hc = d.hash_cap, at = d.arena_tokens, al = d.arena_links, mf = d.max_frames;
+  size_t hc = d.hash_cap, mf = d.max_frames;
+  const long long tbase = d.lane_tok_base[lane], lbase = d.lane_lnk_base[lane];
+  c.tok_cap = d.lane_tok_cap[lane]; c.lnk_cap = d.lane_lnk_cap[lane];
   c.H = d.H + lane * hc; c.slots = d.slots + lane * hc; c.slot_tok = d.slot_tok + lane * hc;
   c.stamp = d.stamp + lane * hc; c.wl0 = d.wl + lane * 2 * hc; c.wl1 = c.wl0 + hc;
-  c.tok_state = d.tok_state + lane * at; c.tok_cost = d.tok_cost + lane * at;
-  c.tok_extra = d.tok_extra + lane * at; c.tok_map = d.tok_map + lane * at;
-  c.links = d.links + lane * al; c.tok_off = d.tok_off + lane * (mf + 2);
+  c.tok_state = d.tok_state + tbase; c.tok_cost = d.tok_cost + tbase;
+  c.tok_extra = d.tok_extra + tbase; c.tok_map = d.tok_map + tbase;
+  c.links = d.links + lbase; c.tok_off = d.tok_off + lane * (mf + 2);
   c.lnk_off = d.lnk_off + lane * (2 * (mf + 2) + 1);
   c.cost_offsets = d.cost_offsets + lane * (mf + 1);
   c.trace_ntok = d.trace_ntok + lane * (mf + 1); c.trace_cutoff = d.trace_cutoff + lane * (mf + 1);
@@ -292,7 +296,7 @@ __device__ inline void ProcessArc(const DecDev &d, const Ctx &c, Sh *sh, const f
   const int slot = HashInsert(d, c, sh, arc.nextstate, tot_cost, &improved);
   if (slot < 0) return;
   const int li = link_base + WaveAlloc(&sh->n_links);
-  if (li >= d.arena_links) { sh->err = ERR_LINK; return; }
+  if (li >= c.lnk_cap) { sh->err = ERR_LINK; return; }
   Link L; L.src = src_tok; L.dst = slot; L.ilabel = arc.ilabel; L.olabel = arc.olabel;
   L.graph = graph_cost; L.ac = ac_cost;
   c.links[li] = L;
@@ -375,7 +379,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
       int idx = -1;
       if (keep) {
         idx = tok_base + running + pos;
-        if (idx < d.arena_tokens) {
+        if (idx < c.tok_cap) {
           c.tok_state[idx] = StateOf(e);
           c.tok_cost[idx] = CostOf(e);
           c.tok_extra[idx] = 0.0f;
@@ -391,7 +395,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
   int k_surv = 0;
   {
     const int lb = emit_link_begin, le = emit_link_begin + sh->n_links;
-    for (int li = lb + tid; li < min(le, d.arena_links); li += NT) {
+    for (int li = lb + tid; li < min(le, c.lnk_cap); li += NT) {
       Link L = c.links[li];
       const float tot = c.tok_cost[L.src] + L.ac + L.graph;
       const bool valid = tot <= cutoff;
@@ -405,7 +409,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
   // ---- epsilon links of the surviving tokens (final costs), :875-897
   const int eps_link_begin = c.lnk_off[2 * list + 1];
   int a_eps = 0;
-  for (int t = tok_base + tid; t < min(tok_base + n_new, d.arena_tokens); t += NT) {
+  for (int t = tok_base + tid; t < min(tok_base + n_new, c.tok_cap); t += NT) {
     const int s = c.tok_state[t];
     const float cur_cost = c.tok_cost[t];
     const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
@@ -418,7 +422,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
         const int dst = slot2 >= 0 ? c.slot_tok[slot2] : -1;
         if (dst < 0) { sh->err = ERR_INTERNAL; continue; }
         const int li = eps_link_begin + WaveAlloc(&sh->n_links);
-        if (li >= d.arena_links) { sh->err = ERR_LINK; continue; }
+        if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
         Link L; L.src = t; L.dst = dst; L.ilabel = 0; L.olabel = arc.olabel;
         L.graph = arc.weight; L.ac = 0.0f;
         c.links[li] = L;
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
       if (tid == 0) {
         sh.cnt[0] += ne; sh.cnt[1] += ae; sh.cnt[2] += ae; sh.cnt[6] += 1;
         sh.bigcnt = 0;
-        c.lnk_off[2 * (frame + 1) + 1] = link_base + min(sh.n_links, d.arena_links - link_base);
+        c.lnk_off[2 * (frame + 1) + 1] = link_base + min(sh.n_links, c.lnk_cap - link_base);
       }
     }
     __syncthreads();
@@ -796,6 +800,8 @@ struct Decoder {
   bool timed = false;
   float last_ms = 0;
   int *d_lanes = NULL; kamd_decode_task *d_tasks = NULL; int tasks_cap = 0;
+  long long *d_tok_base = NULL, *d_lnk_base = NULL; int *d_tok_cap = NULL, *d_lnk_cap = NULL;
+  std::vector<long long> h_tok_base, h_lnk_base; std::vector<int> h_tok_cap, h_lnk_cap;
   hipStream_t last_stream = NULL;
   // host copy of one lane's lattice (canonical), cached by lane
   int cached_lane = -1;
@@ -907,14 +913,13 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   memset(&d, 0, sizeof(d));
   d.g = D->g->dev; d.cfg = *cfg;
   d.hash_cap = s.hash_capacity; d.hash_mask = s.hash_capacity - 1; d.max_frames = s.max_frames;
-  d.arena_tokens = static_cast<int>(s.arena_tokens); d.arena_links = static_cast<int>(s.arena_links);
   const size_t L = s.max_lanes, hc = s.hash_capacity, at = s.arena_tokens, al = s.arena_links, mf = s.max_frames;
   bool ok = true;
   auto alloc = [&](size_t bytes, int fill) -> void * {
     void *p = NULL;
     if (hipMalloc(&p, bytes) != hipSuccess) { ok = false; return NULL; }
     D->allocs.push_back(p);
-    if (hipMemset(p, fill, bytes) != hipSuccess) ok = false;
+    if (fill >= 0 && hipMemset(p, fill, bytes) != hipSuccess) ok = false;
     return p;
   };
   d.H = static_cast<kamd::u64 *>(alloc(L * hc * 8, 0xFF));
@@ -923,17 +928,32 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   d.stamp = static_cast<kamd::u32 *>(alloc(L * hc * 4, 0));
   d.wl = static_cast<kamd::u32 *>(alloc(L * hc * 8, 0));
   d.scratch = static_cast<float *>(alloc(L * hc * 8, 0));
-  d.tok_state = static_cast<int *>(alloc(L * at * 4, 0));
-  d.tok_cost = static_cast<float *>(alloc(L * at * 4, 0));
-  d.tok_extra = static_cast<float *>(alloc(L * at * 4, 0));
-  d.tok_map = static_cast<int *>(alloc(L * at * 4, 0));
-  d.links = static_cast<kamd::Link *>(alloc(L * al * sizeof(kamd::Link), 0));
+  d.tok_state = static_cast<int *>(alloc(L * at * 4, -1));
+  d.tok_cost = static_cast<float *>(alloc(L * at * 4, -1));
+  d.tok_extra = static_cast<float *>(alloc(L * at * 4, -1));
+  d.tok_map = static_cast<int *>(alloc(L * at * 4, -1));
+  d.links = static_cast<kamd::Link *>(alloc(L * al * sizeof(kamd::Link), -1));
   d.tok_off = static_cast<int *>(alloc(L * (mf + 2) * 4, 0));
   d.lnk_off = static_cast<int *>(alloc(L * (2 * (mf + 2) + 1) * 4, 0));
   d.cost_offsets = static_cast<float *>(alloc(L * (mf + 1) * 4, 0));
   d.trace_ntok = static_cast<int *>(alloc(L * (mf + 1) * 4, 0));
   d.trace_cutoff = static_cast<float *>(alloc(L * (mf + 1) * 4, 0));
   d.st = static_cast<kamd::LaneState *>(alloc(L * sizeof(kamd::LaneState), 0));
+  D->d_tok_base = static_cast<long long *>(alloc(L * 8, 0)); D->d_lnk_base = static_cast<long long *>(alloc(L * 8, 0));
+  D->d_tok_cap = static_cast<int *>(alloc(L * 4, 0)); D->d_lnk_cap = static_cast<int *>(alloc(L * 4, 0));
+  d.lane_tok_base = D->d_tok_base; d.lane_lnk_base = D->d_lnk_base;
+  d.lane_tok_cap = D->d_tok_cap; d.lane_lnk_cap = D->d_lnk_cap;
+  D->h_tok_base.resize(L); D->h_lnk_base.resize(L); D->h_tok_cap.resize(L); D->h_lnk_cap.resize(L);
+  for (size_t l = 0; l < L; l++) {   // default: uniform partition of the pools
+    D->h_tok_base[l] = static_cast<long long>(l * at); D->h_lnk_base[l] = static_cast<long long>(l * al);
+    D->h_tok_cap[l] = static_cast<int>(at); D->h_lnk_cap[l] = static_cast<int>(al);
+  }
+  if (ok) {
+    if (hipMemcpy(D->d_tok_base, D->h_tok_base.data(), L * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(D->d_lnk_base, D->h_lnk_base.data(), L * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(D->d_tok_cap, D->h_tok_cap.data(), L * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(D->d_lnk_cap, D->h_lnk_cap.data(), L * 4, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+  }
   if (tid2pdf) {
     int *p = static_cast<int *>(alloc((static_cast<size_t>(num_tids) + 1) * 4, 0));
     if (p && hipMemcpy(p, tid2pdf, (static_cast<size_t>(num_tids) + 1) * 4, hipMemcpyHostToDevice) != hipSuccess) ok = false;
@@ -958,6 +978,33 @@ void kamd_decoder_destroy(kamd_decoder *h) {
   if (D->ev0) (void)hipEventDestroy(D->ev0);
   if (D->ev1) (void)hipEventDestroy(D->ev1);
   delete D;
+}
+
+int kamd_decoder_reserve(kamd_decoder *h, const int32_t *lane_frames, int n) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  const size_t L = D->sizes.max_lanes;
+  if (n < 0 || static_cast<size_t>(n) > L) return kamd::SetError(KAMD_ERR_ARG, "bad lane count");
+  const double pool_t = static_cast<double>(L) * D->sizes.arena_tokens, pool_l = static_cast<double>(L) * D->sizes.arena_links;
+  double tot = 0;
+  for (int i = 0; i < n; i++) {
+    if (lane_frames[i] < 0 || lane_frames[i] > D->sizes.max_frames) return kamd::SetError(KAMD_ERR_ARG, "lane %d: %d frames > max_frames", i, lane_frames[i]);
+    tot += lane_frames[i] + 2;
+  }
+  long long tb = 0, lb = 0;
+  for (size_t l = 0; l < L; l++) {
+    double share = (l < static_cast<size_t>(n) && tot > 0) ? (lane_frames[l] + 2) / tot : 0.0;
+    long long tc = static_cast<long long>(pool_t * share), lc = static_cast<long long>(pool_l * share);
+    if (tc > 2000000000LL) tc = 2000000000LL;
+    if (lc > 2000000000LL) lc = 2000000000LL;
+    D->h_tok_base[l] = tb; D->h_lnk_base[l] = lb;
+    D->h_tok_cap[l] = static_cast<int>(tc); D->h_lnk_cap[l] = static_cast<int>(lc);
+    tb += tc; lb += lc;
+  }
+  KAMD_HIP(hipMemcpy(D->d_tok_base, D->h_tok_base.data(), L * 8, hipMemcpyHostToDevice));
+  KAMD_HIP(hipMemcpy(D->d_lnk_base, D->h_lnk_base.data(), L * 8, hipMemcpyHostToDevice));
+  KAMD_HIP(hipMemcpy(D->d_tok_cap, D->h_tok_cap.data(), L * 4, hipMemcpyHostToDevice));
+  KAMD_HIP(hipMemcpy(D->d_lnk_cap, D->h_lnk_cap.data(), L * 4, hipMemcpyHostToDevice));
+  return KAMD_OK;
 }
 
 int kamd_decoder_set_options(kamd_decoder *h, const kamd_decoder_config *cfg) {
@@ -1099,16 +1146,17 @@ static int FetchLattice(Decoder *D, int lane) {
   const kamd::LaneState &S = D->h_st[lane];
   if (!S.finalized) return kamd::SetError(KAMD_ERR_STATE, "lane %d: call kamd_decoder_finalize + kamd_decoder_sync first", lane);
   const int nt = S.out_ntok, nl = S.out_nlink, F = S.frame;
-  const size_t at = D->sizes.arena_tokens, al = D->sizes.arena_links, mf = D->sizes.max_frames;
+  const size_t mf = D->sizes.max_frames;
+  const long long tbase = D->h_tok_base[lane], lbase = D->h_lnk_base[lane];
   std::vector<int> st(nt), toff(F + 2);
   std::vector<float> co(nt);
   std::vector<kamd::Link> lk(nl);
   if (nt) {
-    KAMD_HIP(hipMemcpy(st.data(), D->dev.tok_state + lane * at, nt * 4, hipMemcpyDeviceToHost));
-    KAMD_HIP(hipMemcpy(co.data(), D->dev.tok_cost + lane * at, nt * 4, hipMemcpyDeviceToHost));
+    KAMD_HIP(hipMemcpy(st.data(), D->dev.tok_state + tbase, nt * 4, hipMemcpyDeviceToHost));
+    KAMD_HIP(hipMemcpy(co.data(), D->dev.tok_cost + tbase, nt * 4, hipMemcpyDeviceToHost));
   }
   KAMD_HIP(hipMemcpy(toff.data(), D->dev.tok_off + lane * (mf + 2), (F + 2) * 4, hipMemcpyDeviceToHost));
-  if (nl) KAMD_HIP(hipMemcpy(lk.data(), D->dev.links + lane * al, nl * sizeof(kamd::Link), hipMemcpyDeviceToHost));
+  if (nl) KAMD_HIP(hipMemcpy(lk.data(), D->dev.links + lbase, nl * sizeof(kamd::Link), hipMemcpyDeviceToHost));
   // final costs need the graph's final vector for the last frame's states
   std::vector<float> fin(nt, INFINITY);
   D->lat_frame.assign(nt, 0);

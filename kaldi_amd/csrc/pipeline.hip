@@ -98,6 +98,12 @@ int kamd_pipeline_run(kamd_pipeline *h, float stage_ms[4]) {
     tasks[u].d_loglikes = p->d_ll + static_cast<size_t>(p->out_off[u]) * p->P;
     tasks[u].ld = p->P; tasks[u].reserved = 0;
   }
+  {
+    std::vector<int32_t> fr(n);
+    for (int u = 0; u < n; u++) fr[u] = tasks[u].n_frames;
+    rc = kamd_decoder_reserve(p->dec, fr.data(), n);
+    if (rc != KAMD_OK) return rc;
+  }
   rc = kamd_decoder_init(p->dec, lanes.data(), n, st);
   if (rc != KAMD_OK) return rc;
   rc = kamd_decoder_advance(p->dec, tasks.data(), n, st);

@@ -8,19 +8,22 @@ from . import abi, decoder
 from ._lib import KamdError, check, lib
 
 
-def default_sizes(cfg, max_utts, max_out_frames, hash_capacity=None, tokens_per_frame=None,
-                  links_per_frame=None):
-    """Device arena sizing for `max_utts` lanes of at most `max_out_frames` decoded frames."""
+def default_sizes(cfg, max_utts, max_out_frames, avg_out_frames=None, hash_capacity=None,
+                  tokens_per_frame=None, links_per_frame=None):
+    """Device sizing: `max_utts` lanes, each at most `max_out_frames` decoded frames; the
+    token / link pools hold `avg_out_frames` frames per lane on average (the pools are split
+    between lanes in proportion to utterance length, kamd_decoder_reserve)."""
     act = cfg.max_active if cfg.max_active < abi.INT32_MAX else 20000
     tpf = tokens_per_frame or int(min(3.0 * act, 60000) + 2000)
     lpf = links_per_frame or int(1.6 * tpf + 2000)
     hc = hash_capacity or 1 << int(np.ceil(np.log2(max(4 * tpf, max_out_frames + 8, 4096))))
-    return abi.DecoderSizes(max_utts, hc, int(tpf) * (max_out_frames + 1), int(lpf) * (max_out_frames + 1),
-                            max_out_frames + 1)
+    avg = (avg_out_frames or max_out_frames) + 2
+    return abi.DecoderSizes(max_utts, hc, int(tpf) * avg, int(lpf) * avg, max_out_frames + 1)
 
 
 class Pipeline:
-    def __init__(self, mfcc_opts, model, hclg, cfg, max_utts=64, max_seconds=36.0, sizes=None):
+    def __init__(self, mfcc_opts, model, hclg, cfg, max_utts=64, max_seconds=36.0, avg_seconds=None,
+                 sizes=None):
         self.feat = __import__("kaldi_amd.feat", fromlist=["Mfcc"]).Mfcc(mfcc_opts)
         self.model = model
         self.nnet = decoder.Nnet(model)
@@ -28,7 +31,8 @@ class Pipeline:
         self.cfg = cfg
         fps = 1000.0 / mfcc_opts.frame.frame_shift_ms
         max_out = int(max_seconds * fps / model.subsampling) + 2
-        self.sizes = sizes or default_sizes(cfg, max_utts, max_out)
+        avg_out = None if avg_seconds is None else int(avg_seconds * fps / model.subsampling) + 2
+        self.sizes = sizes or default_sizes(cfg, max_utts, max_out, avg_out)
         self.dec = decoder.BatchDecoder(self.graph, cfg, self.sizes)
         self._h = lib().kamd_pipeline_create(self.feat._h, self.nnet._h, self.dec._dec)
         if not self._h:
