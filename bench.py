@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check lane 0 against the oracle")
+    ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,12 +113,19 @@ def main():
     from kaldi_amd._lib import check, lib, require_gpu
     require_gpu()
     check(lib().kamd_set_device(local_rank))
+    def log(msg):
+        if args.verbose and rank == 0:
+            print("[bench %.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
+    T0 = time.time()
     g, model, waves, cfg, t_build = build_workload(args, rank)
+    log("workload built: %d states %d arcs, %d utts" % (g.num_states, g.num_arcs, len(waves)))
     audio = sum(w.size for w in waves) / 16000.0
     pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves),
                              max_seconds=max(w.size for w in waves) / 16000.0 + 0.5,
                              avg_seconds=audio / len(waves))
+    log("pipeline created")
     pipe.load(waves)                        # inputs resident in HBM before the timed region
+    log("batch loaded")
 
     def sync_all():
         check(lib().kamd_device_synchronize())
@@ -125,7 +133,8 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        pipe.run()
+        ms = pipe.run()
+        log("warmup step: stage ms %s" % ms)
     sync_all()
     t0 = time.time()
     stage = np.zeros(4)
@@ -135,6 +144,7 @@ def main():
         adv_ms.append(pipe.dec.last_advance_ms())
     sync_all()
     dt = time.time() - t0
+    log("timed steps done: %.3f s" % dt)
     if dist is not None:
         import torch
         t = torch.tensor([dt], device="cuda")
@@ -152,6 +162,7 @@ def main():
     adv = float(np.mean(adv_ms))
     frames = int(counters[6])
     res = pipe.results(lattices=False)
+    log("results fetched")
     out = {
         "metric": "decode RTF (audio-sec/wall-sec)",
         "value": total_audio * args.steps / dt,

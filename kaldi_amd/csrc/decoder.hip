@@ -125,6 +125,11 @@ struct Sh {  // workgroup-shared state
 __device__ inline u64 LoadH(const u64 *p) {  // L1-bypassing load: the table is written by L2 atomics
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ inline u32 LoadU32(const u32 *p) {  // for words updated by L2 atomics (L1 may be stale)
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// all of this wavefront's stores have reached L2 (write-through) before it continues
+__device__ inline void DrainStores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ inline u32 HashState(int s, int mask) {
   return (static_cast<u32>(s) * 2654435761u >> 7) & static_cast<u32>(mask);
 }
@@ -316,6 +321,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
     for (int i = tid; i < ns; i += NT) {
       const u32 slot = c.slots[i];
       const u64 e = LoadH(&c.H[slot]);
+      if (e == EMPTY64) { sh->err = ERR_INTERNAL; continue; }
       const int s = StateOf(e);
       const uint2 o0 = d.g.off[s], o1 = d.g.off[s + 1];
       if (o1.y > o0.y && CostOf(e) <= cutoff) {
@@ -336,7 +342,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
       const u32 slot = wl_cur[i];
       const u64 e = LoadH(&c.H[slot]);
       const float cur_cost = CostOf(e);
-      if (cur_cost > cutoff) continue;      // :867
+      if (e == EMPTY64 || cur_cost > cutoff) continue;      // :867
       const int s = StateOf(e);
       const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
       for (u32 a = a0; a < a1; a++) {
@@ -356,10 +362,11 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
       }
     }
     __syncthreads();
+    const int err_now = sh->err;   // read between two barriers: uniform
     if (tid == 0) sh->wl_n[cur] = 0;
     cur ^= 1;
     __syncthreads();
-    if (sh->err) break;
+    if (err_now) break;
   }
   // ---- compaction: tokens with final cost <= cutoff become list 'list'
   const int tok_base = c.tok_off[list];
@@ -371,7 +378,8 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
     if (i < ns) {
       slot = c.slots[i];
       e = LoadH(&c.H[slot]);
-      keep = CostOf(e) <= cutoff;
+      if (e == EMPTY64) sh->err = ERR_INTERNAL;   // a listed slot must hold a token
+      keep = e != EMPTY64 && CostOf(e) <= cutoff;
     }
     int total;
     const int pos = BlockScanFlag(keep, &total, sh);
@@ -431,7 +439,9 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
   }
   __syncthreads();
   // ---- clear the table, publish offsets and counters
-  for (int i = tid; i < ns; i += NT) c.H[c.slots[i]] = EMPTY64;
+  for (int i = tid; i < ns; i += NT)
+    __hip_atomic_store(&c.H[c.slots[i]], EMPTY64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  DrainStores();   // the next frame's CAS / atomicMin must find the cleared words in L2
   BlockSum2(k_surv, a_eps, sh);
   if (tid == 0) {
     const int n_eps_links = sh->n_links;
@@ -633,7 +643,9 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     const float next_cutoff = OrderedToFloat(sh.next_cutoff_u);
     // ---- ProcessNonemitting(next_cutoff) + commit of token list frame+1
     CommitFrame(d, c, &sh, next_cutoff, frame + 1, link_base);
-    if (sh.err) { frame++; break; }
+    const int err_now = sh.err;    // CommitFrame ends with a barrier; nobody writes err before the next one
+    __syncthreads();
+    if (err_now) { frame++; break; }
   }
   PublishLaneEnd(d, c, &sh, frame);
 }
@@ -669,8 +681,9 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
         const float fc = finals_empty ? 0.0f : d.g.final[c.tok_state[tb + i]];
         b = c.tok_cost[tb + i] + fc - final_best;
       }
-      bo[i] = FloatToOrdered(b);
+      __hip_atomic_store(&bo[i], FloatToOrdered(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    DrainStores();
     __syncthreads();
     // emitting links out of frame f (written at step f+1)
     if (f < F) {
@@ -686,7 +699,7 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
     }
     __syncthreads();
     for (int i = tid; i < nt; i += NT) {
-      float v = OrderedToFloat(bo[i]);
+      float v = OrderedToFloat(LoadU32(&bo[i]));
       if (f == F && v > lattice_beam) v = INFINITY;   // :462-463
       xcur[i] = v;
     }
@@ -696,7 +709,9 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
     const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
     if (ee > eb) {
       for (int iter = 0; iter < 20000; iter++) {
-        for (int i = tid; i < nt; i += NT) xo[i] = bo[i];
+        for (int i = tid; i < nt; i += NT)
+          __hip_atomic_store(&xo[i], LoadU32(&bo[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        DrainStores();
         __syncthreads();
         for (int li = eb + tid; li < ee; li += NT) {
           const Link L = c.links[li];
@@ -708,7 +723,7 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
         __syncthreads();
         int changed = 0, dummy = 0;
         for (int i = tid; i < nt; i += NT) {
-          float v = OrderedToFloat(xo[i]);
+          float v = OrderedToFloat(LoadU32(&xo[i]));
           if (f == F && v > lattice_beam) v = INFINITY;
           if (!(v == xcur[i])) changed = 1;
           xcur[i] = v;

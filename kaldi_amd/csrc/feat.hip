@@ -231,7 +231,7 @@ struct Feat {
   // scratch for the host-convenience entry point
   float *d_wave = NULL, *d_out = NULL;
   int64_t *d_meta = NULL;
-  size_t wave_cap = 0, out_cap = 0;
+  size_t wave_cap = 0, out_cap = 0, meta_cap = 0;
 };
 
 inline float MelScale(float f) { return 1127.0f * logf(1.0f + f / 700.0f); }
@@ -452,8 +452,14 @@ int kamd_feat_compute_batch_device(kamd_feat *h, const float *d_waves, const int
   meta[n_utts] = h_wave_off[n_utts];
   meta[(n_utts + 1) + n_utts] = tot;
   if (tot == 0) return KAMD_OK;
-  int64_t *d_meta = NULL;
-  KAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_meta), meta.size() * 8, st));
+  if (meta.size() > f->meta_cap) {
+    KAMD_HIP(hipStreamSynchronize(st));
+    if (f->d_meta) KAMD_HIP(hipFree(f->d_meta));
+    f->d_meta = NULL; f->meta_cap = 0;
+    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_meta), 2 * meta.size() * 8));
+    f->meta_cap = 2 * meta.size();
+  }
+  int64_t *d_meta = f->d_meta;
   KAMD_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));  // 'meta' is a host temporary
   int blocks = kamd::CeilDiv(tot, 4);
@@ -461,7 +467,6 @@ int kamd_feat_compute_batch_device(kamd_feat *h, const float *d_waves, const int
   hipLaunchKernelGGL(kamd::FeatKernel, dim3(blocks), dim3(256), lds, st, f->dev, d_waves, d_meta,
                      d_meta + (n_utts + 1), d_meta + 2 * (n_utts + 1), n_utts, d_out, ld_out);
   KAMD_HIP(hipGetLastError());
-  KAMD_HIP(hipFreeAsync(d_meta, st));
   return KAMD_OK;
 }
 

@@ -442,7 +442,7 @@ int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int
     if (l == nl - 1 && row_base != 0) {
       std::vector<int64_t> rel(stride);
       for (size_t i = 0; i < stride; i++) rel[i] = meta[l * stride + i] - row_base;
-      KAMD_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_tmp_off), stride * 8, st));
+      KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_tmp_off), stride * 8));
       KAMD_HIP(hipMemcpyAsync(d_tmp_off, rel.data(), stride * 8, hipMemcpyHostToDevice, st));
       KAMD_HIP(hipStreamSynchronize(st));
       layer_row_off = d_tmp_off;
@@ -487,7 +487,7 @@ int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int
       hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 128, 2, 2>), grid, dim3(256), 0, st, g);
     }
     KAMD_HIP(hipGetLastError());
-    if (d_tmp_off) KAMD_HIP(hipFreeAsync(d_tmp_off, st));
+    if (d_tmp_off) { KAMD_HIP(hipStreamSynchronize(st)); KAMD_HIP(hipFree(d_tmp_off)); }
     flops += 2.0 * static_cast<double>(Ml) * L.out_dim * (L.n_off * L.in_dim + L.ivector_dim);
   }
   nn->last_flops = flops;
