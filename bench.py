@@ -35,11 +35,11 @@ def build_workload(args, rank):
     t0 = time.time()
     if args.workload == "mini_librispeech":
         g = synth.make_hclg(num_units=1164, vocab=args.vocab, n_hist=args.n_hist, fanout=(12, 64),
-                            pron_len=(3, 7), seed=2)
+                            pron_len=(3, 7), seed=2, self_loop_prob=0.5, lm_scale=args.lm_scale)
         model = nnet.tdnnf_mini_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
     elif args.workload == "librispeech":
         g = synth.make_hclg(num_units=3000, vocab=args.vocab, n_hist=args.n_hist, fanout=(12, 64),
-                            pron_len=(3, 7), seed=2)
+                            pron_len=(3, 7), seed=2, self_loop_prob=0.5, lm_scale=args.lm_scale)
         model = nnet.tdnnf_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
     else:  # tiny (CI / CPU-less smoke of the script itself)
         g = synth.make_hclg(num_units=64, vocab=400, n_hist=60, seed=2)
@@ -50,6 +50,33 @@ def build_workload(args, rank):
     waves = [synth.make_wave(d, seed=rank * 100000 + i) for i, d in enumerate(durs)]
     cfg = abi.decoder_config_recipe()
     return g, model, waves, cfg, time.time() - t0
+
+
+def calibrate(model, target_std):
+    """Random weights give arbitrary output scale; rescale the output layer so that the
+    per-frame spread of the log-likelihoods across pdfs is `target_std` nats (chain models
+    in the wild: a few nats).  Runs on the GPU (this is workload synthesis, not parity)."""
+    from kaldi_amd import abi, decoder, feat, synth
+    w = synth.make_wave(3.0, seed=424242)
+    f = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(w)
+    ll = decoder.Nnet(model).Forward(f)
+    spread = float(np.mean(np.std(ll, axis=1)))
+    k = target_std / spread
+    out = model.layers[-1]
+    out.W = (out.W * k).astype(np.float32)
+    out.bias = (out.bias * k).astype(np.float32)
+    return spread, k
+
+
+PHASES = ["best", "cutoff", "seed", "expand", "expand_hub", "eps_closure", "compact", "fixup",
+          "eps_links", "clear", "fin_sweep", "fin_compact"]
+
+
+def phase_share(pipe, waves):
+    lane = int(np.argmax([w.size for w in waves]))
+    c = pipe.dec.phase_cycles(lane).astype(np.float64)[:len(PHASES)]
+    tot = max(c.sum(), 1.0)
+    return {k: round(float(v / tot), 3) for k, v in zip(PHASES, c)}
 
 
 def cpu_baseline(g, model, waves, cfg, budget_s):
@@ -90,8 +117,10 @@ def main():
     ap.add_argument("--utts", type=int, default=64)
     ap.add_argument("--vocab", type=int, default=20000)
     ap.add_argument("--n-hist", type=int, default=18000)
-    ap.add_argument("--output-scale", type=float, default=6.0,
-                    help="scale on the random output layer: sets how peaked the synthetic posteriors are")
+    ap.add_argument("--output-scale", type=float, default=1.0)
+    ap.add_argument("--lm-scale", type=float, default=1.0, help="scale on the synthetic LM costs")
+    ap.add_argument("--ll-std", type=float, default=3.0,
+                    help="per-frame std (nats) of the synthetic log-likelihoods across pdfs after calibration")
     ap.add_argument("--max-seconds", type=float, default=0.0)
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -118,6 +147,7 @@ def main():
             print("[bench %.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
     T0 = time.time()
     g, model, waves, cfg, t_build = build_workload(args, rank)
+    spread, k = calibrate(model, args.ll_std)
     log("workload built: %d states %d arcs, %d utts" % (g.num_states, g.num_arcs, len(waves)))
     audio = sum(w.size for w in waves) / 16000.0
     pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves),
@@ -175,7 +205,7 @@ def main():
                                "(%d states, %d arcs), batch=%d utterances/GPU (%.0f s audio), beam 15 "
                                "max-active 7000 min-active 200 lattice-beam 8" %
                                (args.workload, g.num_states, g.num_arcs, len(waves), audio),
-                   "utterances_per_gpu": len(waves), "output_scale": args.output_scale},
+                   "utterances_per_gpu": len(waves), "loglike_std_nats": args.ll_std},
         "stage_ms": {"features": stage[0] / args.steps, "nnet": stage[1] / args.steps,
                      "decode_advance": stage[2] / args.steps, "decode_finalize": stage[3] / args.steps},
         "decoder": {"frames": frames, "tokens_per_frame": counters[5] / max(frames, 1),
@@ -187,6 +217,7 @@ def main():
                      "achieved": alg_bytes / (adv * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (adv * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": adv},
+        "phase_share_longest_lane": phase_share(pipe, waves),
         "nnet_tflops": lib().kamd_nnet_last_flops(pipe.nnet._h) / (stage[1] / args.steps * 1e-3) / 1e12,
         "setup_s": t_build,
     }

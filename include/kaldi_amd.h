@@ -322,6 +322,12 @@ int kamd_decoder_get_trace(kamd_decoder *d, int lane, int32_t *ntok,
  * [2]=A_emit emitting arcs, [3]=K_surv arcs passing the cutoff,
  * [4]=L_kept links written, [5]=N_tok tokens created, [6]=frames, [7]=reserved */
 int kamd_decoder_get_counters(kamd_decoder *d, int lane, int64_t counters[8]);
+/* Diagnostic: shader cycles thread 0 of the lane's workgroup spent in each phase since
+ * init: [0] best-token reduce, [1] cutoff (count + radix select), [2] seed, [3] expand
+ * (thread per token), [4] expand (wavefront / workgroup per hub), [5] epsilon closure,
+ * [6] token compaction, [7] link fix-up, [8] epsilon links, [9] table clear + bookkeeping,
+ * [10] finalize backward sweep, [11] finalize compaction. */
+int kamd_decoder_get_phase_cycles(kamd_decoder *d, int lane, uint64_t cycles[16]);
 /* device time (ms) of the last advance launch, measured with HIP events on the
  * stream the kernel ran on (for bench.py's roofline). */
 float kamd_decoder_last_advance_ms(kamd_decoder *d);

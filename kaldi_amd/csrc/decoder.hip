@@ -35,7 +35,7 @@ typedef unsigned int u32;
 
 #define NT 1024
 #define NWAVES (NT / 64)
-#define BIGCAP 3072
+#define BIGCAP 3072     // tokens per flatten batch (deg > SMALL_DEG)
 #define SMALL_DEG 4
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
 
@@ -61,11 +61,14 @@ struct LaneState {
   int out_ntok, out_nlink, out_start;
   int pad;
   long long counters[8];
+  unsigned long long phase_cycles[16];   // diagnostic: shader cycles per phase (thread 0)
 };
 
 struct DecDev {
   GraphDev g;
   const int *tid2pdf;   // NULL => pdf = ilabel - 1
+  const int *e_pdf;     // [emitting arcs] pdf of each emitting arc (tid2pdf applied once)
+  int num_pdfs_lds;     // log-likelihood row entries staged in LDS per frame (0 = none)
   kamd_decoder_config cfg;
   int hash_cap, hash_mask, max_frames;
   const long long *lane_tok_base, *lane_lnk_base;  // per lane: offset into the pools
@@ -117,9 +120,22 @@ struct Sh {  // workgroup-shared state
   int n_slots, n_links, wl_n[2], err, bigcnt, changed;
   int sel_bin, sel_below;
   int scan_total;
-  int big_tok[BIGCAP];
+  int big_total;
   long long cnt[8];
+  unsigned long long ph[16];
+  unsigned long long t_prev;
 };
+
+// phase ids for the diagnostic cycle breakdown
+enum { PH_BEST = 0, PH_CUTOFF, PH_SEED, PH_EXPAND, PH_EXPAND_BIG, PH_EPS_CLOSURE, PH_COMPACT,
+       PH_FIXUP, PH_EPS_LINKS, PH_CLEAR, PH_FIN_SWEEP, PH_FIN_COMPACT, PH_OTHER };
+__device__ inline void Stamp(Sh *sh, int idx) {   // call right after a barrier
+  if (threadIdx.x == 0) {
+    const unsigned long long now = __builtin_amdgcn_s_memtime();
+    sh->ph[idx] += now - sh->t_prev;
+    sh->t_prev = now;
+  }
+}
 
 // ---------------------------------------------------------------- primitives
 __device__ inline u64 LoadH(const u64 *p) {  // L1-bypassing load: the table is written by L2 atomics
@@ -227,10 +243,18 @@ __device__ float BlockSelectKth(const float *cost, int n, int k, Sh *sh) {
       WaveHistAdd(sh->hist, bin, act);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-      int cum = 0, b = 0;
-      for (; b < 256; b++) { int c = sh->hist[b]; if (cum + c > k) break; cum += c; }
-      sh->sel_bin = b; sh->sel_below = cum;
+    if (threadIdx.x < 64) {   // one wavefront: 4 bins per lane, shuffle scan, locate rank k
+      const int l = threadIdx.x;
+      const int h0 = sh->hist[4 * l], h1 = sh->hist[4 * l + 1], h2 = sh->hist[4 * l + 2], h3 = sh->hist[4 * l + 3];
+      const int mine = h0 + h1 + h2 + h3;
+      int incl = mine;
+      for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (l >= o) incl += t; }
+      const int excl = incl - mine;
+      if (k >= excl && k < incl) {
+        int cum = excl, b = 4 * l;
+        if (cum + h0 > k) { } else { cum += h0; b++; if (cum + h1 > k) { } else { cum += h1; b++; if (cum + h2 > k) { } else { cum += h2; b++; } } }
+        sh->sel_bin = b; sh->sel_below = cum;
+      }
     }
     __syncthreads();
     prefix |= static_cast<u32>(sh->sel_bin) << shift;
@@ -285,12 +309,15 @@ __device__ inline float LogLike(const DecDev &d, const float *ll, int ilabel) {
   const int pdf = d.tid2pdf ? d.tid2pdf[ilabel] : ilabel - 1;
   return ll[pdf];
 }
+// the frame's row: LDS copy when it fits (every expanded arc reads it), else global
+struct LlRow { const float *g; const float *l; int n_lds; };
+__device__ inline float LogLikePdf(const LlRow &r, int pdf) { return pdf < r.n_lds ? r.l[pdf] : r.g[pdf]; }
 
 // one emitting arc of one expanded token (lattice-faster-decoder.cc:791-809)
-__device__ inline void ProcessArc(const DecDev &d, const Ctx &c, Sh *sh, const float *ll,
-                                  const kamd_arc &arc, int src_tok, float cur_cost,
+__device__ inline void ProcessArc(const DecDev &d, const Ctx &c, Sh *sh, const LlRow &ll,
+                                  const kamd_arc &arc, int pdf, int src_tok, float cur_cost,
                                   float cost_offset, float adaptive_beam, int link_base) {
-  const float ac_cost = cost_offset - LogLike(d, ll, arc.ilabel);
+  const float ac_cost = cost_offset - LogLikePdf(ll, pdf);
   const float graph_cost = arc.weight;
   const float tot_cost = cur_cost + ac_cost + graph_cost;
   const float nc = OrderedToFloat(sh->next_cutoff_u);   // running bound (conservative)
@@ -368,6 +395,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
     __syncthreads();
     if (err_now) break;
   }
+  Stamp(sh, PH_EPS_CLOSURE);
   // ---- compaction: tokens with final cost <= cutoff become list 'list'
   const int tok_base = c.tok_off[list];
   const int ns = min(sh->n_slots, d.hash_cap);
@@ -399,6 +427,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
   }
   const int n_new = running;
   __syncthreads();
+  Stamp(sh, PH_COMPACT);
   // ---- emitting links: keep iff the arc's own tot <= final cutoff; slot -> token
   int k_surv = 0;
   {
@@ -413,6 +442,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
   }
   __syncthreads();
   if (tid == 0) { sh->n_links = 0; }
+  Stamp(sh, PH_FIXUP);
   __syncthreads();
   // ---- epsilon links of the surviving tokens (final costs), :875-897
   const int eps_link_begin = c.lnk_off[2 * list + 1];
@@ -438,6 +468,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
     }
   }
   __syncthreads();
+  Stamp(sh, PH_EPS_LINKS);
   // ---- clear the table, publish offsets and counters
   for (int i = tid; i < ns; i += NT)
     __hip_atomic_store(&c.H[c.slots[i]], EMPTY64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -457,6 +488,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
     sh->n_slots = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0;
   }
   __syncthreads();
+  Stamp(sh, PH_CLEAR);
 }
 
 // ComputeFinalCosts (lattice-faster-decoder.cc:549-590) over token list 'list'
@@ -483,6 +515,7 @@ __device__ void PublishLaneEnd(const DecDev &d, const Ctx &c, Sh *sh, int frame)
     S->final_relative_cost = (b == INFINITY && bf == INFINITY) ? INFINITY : bf - b;  // :574-582
     S->error |= sh->err;
     for (int i = 0; i < 8; i++) S->counters[i] += sh->cnt[i];
+    for (int i = 0; i < 16; i++) S->phase_cycles[i] += sh->ph[i];
   }
 }
 
@@ -491,8 +524,17 @@ __device__ inline void InitSh(Sh *sh) {
     sh->n_slots = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
     sh->bigcnt = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
     for (int i = 0; i < 8; i++) sh->cnt[i] = 0;
+    for (int i = 0; i < 16; i++) sh->ph[i] = 0;
+    sh->t_prev = __builtin_amdgcn_s_memtime();
   }
   __syncthreads();
+}
+
+// pdf of every emitting arc, computed once per decoder (removes the dependent
+// tid -> pdf gather of TransitionIdToPdfFast from the per-arc critical path)
+__global__ void ArcPdfKernel(const kamd_arc *arcs, long long n, const int *tid2pdf, int *e_pdf) {
+  long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) { const int il = arcs[i].ilabel; e_pdf[i] = tid2pdf ? tid2pdf[il] : il - 1; }
 }
 
 // ------------------------------------------------------------------ kernels
@@ -508,6 +550,7 @@ __global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
     S->final_relative_cost = INFINITY; S->final_best_cost = INFINITY;
     S->out_ntok = 0; S->out_nlink = 0; S->out_start = -1;
     for (int i = 0; i < 8; i++) S->counters[i] = 0;
+    for (int i = 0; i < 16; i++) S->phase_cycles[i] = 0;
     c.tok_off[0] = 0; c.lnk_off[0] = 0; c.lnk_off[1] = 0;
     bool imp;
     HashInsert(d, c, &sh, d.g.start, 0.0f, &imp);
@@ -520,6 +563,11 @@ __global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
 // AdvanceDecoding (lattice-faster-decoder.cc:593-632): the frame loop of one lane.
 __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_task *tasks) {
   __shared__ Sh sh;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  int *big_tok = reinterpret_cast<int *>(dyn_lds);            // [BIGCAP] token (index in list)
+  u32 *big_a0 = reinterpret_cast<u32 *>(big_tok + BIGCAP);     // [BIGCAP] first emitting arc
+  int *big_scan = reinterpret_cast<int *>(big_a0 + BIGCAP);    // [BIGCAP] degree -> exclusive scan
+  float *ll_lds = reinterpret_cast<float *>(big_scan + BIGCAP);// [num_pdfs_lds]
   const kamd_decode_task task = tasks[blockIdx.x];
   const Ctx c = MakeCtx(d, task.lane);
   const int tid = threadIdx.x;
@@ -541,6 +589,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
       key = k < key ? k : key;
     }
     key = BlockMin64(key, &sh);
+    Stamp(&sh, PH_BEST);
     float best = INFINITY; int best_state = -1;
     if (n > 0) { best = OrderedToFloat(static_cast<u32>(key >> 32)); best_state = static_cast<int>(key & 0xFFFFFFFFu); }
     float cur_cutoff, adaptive_beam;
@@ -567,6 +616,8 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
         else { adaptive_beam = cfg.beam; cur_cutoff = beam_cutoff; }
       }
     }
+    __syncthreads();
+    Stamp(&sh, PH_CUTOFF);
     // ---- cost offset + seed of next_cutoff from the best token's arcs (:757-772)
     const float cost_offset = (n > 0) ? -best : 0.0f;
     if (tid == 0) {
@@ -574,68 +625,95 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
       c.trace_ntok[frame] = n; c.trace_cutoff[frame] = cur_cutoff;
       c.lnk_off[2 * (frame + 1)] = S->lnk_used;
     }
+    // stage the frame's log-likelihood row in LDS: every expanded arc gathers from it
+    for (int i = tid; i < d.num_pdfs_lds; i += NT) ll_lds[i] = ll[i];
+    LlRow row; row.g = ll; row.l = ll_lds; row.n_lds = d.num_pdfs_lds;
+    __syncthreads();
     if (n > 0) {
       const u32 a0 = d.g.off[best_state].x, a1 = d.g.off[best_state + 1].x;
       float seed = INFINITY;
       for (u32 a = a0 + tid; a < a1; a += NT) {
-        const kamd_arc arc = d.g.e_arcs[a];
-        const float new_weight = arc.weight + cost_offset - LogLike(d, ll, arc.ilabel) + best;
+        const float new_weight = d.g.e_arcs[a].weight + cost_offset - LogLikePdf(row, d.e_pdf[a]) + best;
         seed = fminf(seed, new_weight + adaptive_beam);
       }
       seed = BlockMinF(seed, &sh);
       if (tid == 0) sh.next_cutoff_u = FloatToOrdered(seed);
     } else if (tid == 0) sh.next_cutoff_u = FloatToOrdered(INFINITY);
     __syncthreads();
+    Stamp(&sh, PH_SEED);
     const int link_base = S->lnk_used;
-    // ---- ProcessEmitting (:783-815): thread per token, hubs deferred to wavefronts
+    // ---- ProcessEmitting (:783-815).  Tokens with <= SMALL_DEG arcs are expanded by
+    // their own thread; the rest (LM hubs, trie fan-outs) are queued and expanded
+    // ARC-parallel: a workgroup scan of the degrees flattens the queue so that thread j
+    // takes arc j (consecutive lanes read consecutive 16-B arcs of one state), whatever
+    // the degree distribution is.
     int n_exp = 0; long long a_emit = 0;
-    for (int i = tid; i < n; i += NT) {
-      const float cur_cost = cost[i];
-      if (cur_cost <= cur_cutoff) {           // :787
-        n_exp++;
-        const int s = state[i];
-        const u32 a0 = d.g.off[s].x, a1 = d.g.off[s + 1].x;
-        const u32 deg = a1 - a0;
-        a_emit += deg;
-        if (deg <= SMALL_DEG) {
-          for (u32 a = a0; a < a1; a++) {
-            const kamd_arc arc = d.g.e_arcs[a];
-            ProcessArc(d, c, &sh, ll, arc, tb + i, cur_cost, cost_offset, adaptive_beam, link_base);
-          }
-        } else {
-          const int p = WaveAlloc(&sh.bigcnt);
-          if (p < BIGCAP) sh.big_tok[p] = i;
-          else {  // list full: expand in place
-            for (u32 a = a0; a < a1; a++) {
-              const kamd_arc arc = d.g.e_arcs[a];
-              ProcessArc(d, c, &sh, ll, arc, tb + i, cur_cost, cost_offset, adaptive_beam, link_base);
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-    {
-      const int nb = min(sh.bigcnt, BIGCAP);
-      const int w = tid >> 6, l = tid & 63;
-      for (int e = w; e < nb; e += NWAVES) {
-        const int i = sh.big_tok[e];
+    for (int base = 0; base < n; base += NT) {
+      const int i = base + tid;
+      if (i < n) {
         const float cur_cost = cost[i];
-        const int s = state[i];
-        const u32 a0 = d.g.off[s].x, a1 = d.g.off[s + 1].x;
-        for (u32 a = a0 + l; a < a1; a += 64) {   // 64 consecutive 16-B arcs per load
-          const kamd_arc arc = d.g.e_arcs[a];
-          ProcessArc(d, c, &sh, ll, arc, tb + i, cur_cost, cost_offset, adaptive_beam, link_base);
+        if (cur_cost <= cur_cutoff) {           // :787
+          n_exp++;
+          const int s = state[i];
+          const u32 a0 = d.g.off[s].x, a1 = d.g.off[s + 1].x;
+          const u32 deg = a1 - a0;
+          a_emit += deg;
+          if (deg <= SMALL_DEG) {
+            for (u32 a = a0; a < a1; a++)
+              ProcessArc(d, c, &sh, row, d.g.e_arcs[a], d.e_pdf[a], tb + i, cur_cost, cost_offset,
+                         adaptive_beam, link_base);
+          } else {
+            const int p = WaveAlloc(&sh.bigcnt);   // < BIGCAP: flushed below before it can fill
+            big_tok[p] = i; big_a0[p] = a0; big_scan[p] = deg;
+          }
         }
+      }
+      __syncthreads();
+      const int nb = sh.bigcnt;                    // uniform: read between two barriers
+      __syncthreads();
+      if (nb > 0 && (nb > BIGCAP - NT || base + NT >= n)) {
+        Stamp(&sh, PH_EXPAND);
+        // exclusive scan of the queued degrees (3 entries per thread)
+        int v0 = 0, v1 = 0, v2 = 0;
+        const int e0 = 3 * tid;
+        if (e0 < nb) v0 = big_scan[e0];
+        if (e0 + 1 < nb) v1 = big_scan[e0 + 1];
+        if (e0 + 2 < nb) v2 = big_scan[e0 + 2];
+        const int mine = v0 + v1 + v2;
+        int incl = mine;
+        const int lane = tid & 63, w = tid >> 6;
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        __syncthreads();
+        if (lane == 63) sh.redi[w] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+        for (int k = 0; k < NWAVES; k++) { int cnum = sh.redi[k]; if (k < w) wbase += cnum; total += cnum; }
+        const int excl = wbase + incl - mine;
+        if (e0 < nb) big_scan[e0] = excl;
+        if (e0 + 1 < nb) big_scan[e0 + 1] = excl + v0;
+        if (e0 + 2 < nb) big_scan[e0 + 2] = excl + v0 + v1;
+        __syncthreads();
+        for (int j = tid; j < total; j += NT) {
+          int lo = 0, hi = nb;                    // largest e with big_scan[e] <= j
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
+          const int i2 = big_tok[lo];
+          const u32 a = big_a0[lo] + static_cast<u32>(j - big_scan[lo]);
+          ProcessArc(d, c, &sh, row, d.g.e_arcs[a], d.e_pdf[a], tb + i2, cost[i2], cost_offset,
+                     adaptive_beam, link_base);
+        }
+        __syncthreads();
+        if (tid == 0) sh.bigcnt = 0;
+        __syncthreads();
+        Stamp(&sh, PH_EXPAND_BIG);
       }
     }
     __syncthreads();
+    Stamp(&sh, PH_EXPAND);
     {
       int ne = n_exp, ae = static_cast<int>(a_emit);
       BlockSum2(ne, ae, &sh);
       if (tid == 0) {
         sh.cnt[0] += ne; sh.cnt[1] += ae; sh.cnt[2] += ae; sh.cnt[6] += 1;
-        sh.bigcnt = 0;
         c.lnk_off[2 * (frame + 1) + 1] = link_base + min(sh.n_links, c.lnk_cap - link_base);
       }
     }
@@ -739,6 +817,7 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
     }
     __syncthreads();
   }
+  Stamp(&sh, PH_FIN_SWEEP);
   // ---- PruneTokensForFrame + GetRawLattice staging: order preserving in-place compaction
   int *new_off = reinterpret_cast<int *>(c.wl0);   // [F+2] (hash_cap >= max_frames+2 is checked on the host)
   int n_out_tok = 0;
@@ -789,7 +868,9 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
   }
   __syncthreads();
   for (int f = tid; f <= F + 1; f += NT) c.tok_off[f] = new_off[f];
+  Stamp(&sh, PH_FIN_COMPACT);
   if (tid == 0) {
+    for (int i = 0; i < 16; i++) S->phase_cycles[i] += sh.ph[i];
     S->finalized = 1;
     S->final_best_cost = final_best;
     S->final_relative_cost = (best_cost == INFINITY && best_with_final == INFINITY) ? INFINITY : best_with_final - best_cost;
@@ -801,7 +882,8 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
 // ------------------------------------------------------------------ host
 struct Graph {
   GraphDev dev;
-  int64_t num_arcs;
+  int64_t num_arcs, num_emit;
+  int max_ilabel;
   std::vector<void *> allocs;
 };
 
@@ -872,7 +954,9 @@ kamd_graph *kamd_graph_create(int32_t num_states, int32_t start, const int64_t *
     }
   }
   Graph *g = new Graph();
-  g->num_arcs = A;
+  g->num_arcs = A; g->num_emit = static_cast<int64_t>(ea.size());
+  g->max_ilabel = 0;
+  for (size_t i = 0; i < ea.size(); i++) g->max_ilabel = std::max(g->max_ilabel, ea[i].ilabel);
   auto up = [&](const void *src, size_t bytes) -> void * {
     void *p = NULL;
     if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return NULL;
@@ -969,11 +1053,32 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
         hipMemcpy(D->d_tok_cap, D->h_tok_cap.data(), L * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(D->d_lnk_cap, D->h_lnk_cap.data(), L * 4, hipMemcpyHostToDevice) != hipSuccess) ok = false;
   }
+  int num_pdfs = D->g->max_ilabel;   // identity map: pdf = ilabel - 1
   if (tid2pdf) {
+    if (D->g->max_ilabel > num_tids) {
+      kamd::SetError(KAMD_ERR_ARG, "graph ilabel %d exceeds the transition-id table (%d)", D->g->max_ilabel, num_tids);
+      kamd_decoder_destroy(reinterpret_cast<kamd_decoder *>(D));
+      return NULL;
+    }
     int *p = static_cast<int *>(alloc((static_cast<size_t>(num_tids) + 1) * 4, 0));
     if (p && hipMemcpy(p, tid2pdf, (static_cast<size_t>(num_tids) + 1) * 4, hipMemcpyHostToDevice) != hipSuccess) ok = false;
     d.tid2pdf = p;
+    num_pdfs = 0;
+    for (int t = 1; t <= num_tids; t++) num_pdfs = std::max(num_pdfs, tid2pdf[t] + 1);
   }
+  {
+    int *ep = static_cast<int *>(alloc(static_cast<size_t>(std::max<int64_t>(D->g->num_emit, 1)) * 4, 0));
+    d.e_pdf = ep;
+    if (ok && D->g->num_emit > 0) {
+      hipLaunchKernelGGL(kamd::ArcPdfKernel, dim3(kamd::CeilDiv(D->g->num_emit, 256)), dim3(256), 0, 0, d.g.e_arcs,
+                         static_cast<long long>(D->g->num_emit), d.tid2pdf, ep);
+      if (hipDeviceSynchronize() != hipSuccess) ok = false;
+    }
+  }
+  d.num_pdfs_lds = num_pdfs <= 24576 ? num_pdfs : 0;   // LDS row: up to 96 KB of the CU's 160 KB
+  if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::AdvanceKernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * BIGCAP * 4 + d.num_pdfs_lds * 4) != hipSuccess)
+    ok = false;
   if (ok && (hipEventCreate(&D->ev0) != hipSuccess || hipEventCreate(&D->ev1) != hipSuccess)) ok = false;
   if (!ok) {
     kamd::SetError(KAMD_ERR_HIP, "decoder allocation failed (%zu lanes): %s", L, hipGetErrorString(hipGetLastError()));
@@ -1074,7 +1179,8 @@ int kamd_decoder_advance(kamd_decoder *h, const kamd_decode_task *tasks, int n, 
   KAMD_HIP(hipMemcpyAsync(D->d_tasks, sorted.data(), n * sizeof(kamd_decode_task), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
   KAMD_HIP(hipEventRecord(D->ev0, st));
-  hipLaunchKernelGGL(kamd::AdvanceKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_tasks);
+  const size_t lds = 3 * BIGCAP * 4 + static_cast<size_t>(D->dev.num_pdfs_lds) * 4;
+  hipLaunchKernelGGL(kamd::AdvanceKernel, dim3(n), dim3(NT), lds, st, D->dev, D->d_tasks);
   KAMD_HIP(hipGetLastError());
   KAMD_HIP(hipEventRecord(D->ev1, st));
   D->timed = true; D->last_stream = st; D->cached_lane = -1;
@@ -1139,6 +1245,12 @@ int kamd_decoder_get_counters(kamd_decoder *h, int lane, int64_t counters[8]) {
   Decoder *D = reinterpret_cast<Decoder *>(h);
   if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
   for (int i = 0; i < 8; i++) counters[i] = D->h_st[lane].counters[i];
+  return KAMD_OK;
+}
+int kamd_decoder_get_phase_cycles(kamd_decoder *h, int lane, uint64_t cycles[16]) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
+  for (int i = 0; i < 16; i++) cycles[i] = D->h_st[lane].phase_cycles[i];
   return KAMD_OK;
 }
 int kamd_decoder_get_trace(kamd_decoder *h, int lane, int32_t *ntok, float *cutoff, float *cost_offset, int cap) {

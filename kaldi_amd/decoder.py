@@ -249,5 +249,10 @@ class BatchDecoder:
         check(lib().kamd_decoder_get_counters(self._dec, lane, abi.iptr(c, C.c_int64)))
         return c
 
+    def phase_cycles(self, lane):
+        c = np.zeros(16, np.uint64)
+        check(lib().kamd_decoder_get_phase_cycles(self._dec, lane, c.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return c
+
     def last_advance_ms(self):
         return lib().kamd_decoder_last_advance_ms(self._dec)

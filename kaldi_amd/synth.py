@@ -31,7 +31,7 @@ class Hclg:
     n_hist: int = 0
     pair_hist: np.ndarray = None
     pair_word: np.ndarray = None
-    pair_base: np.ndarray = None
+    pair_base: np.ndarray = None   # [K, Lmax] trie node of each pronunciation position
     pair_len: np.ndarray = None
     hist_pair_off: np.ndarray = None
     word_next_hist: np.ndarray = None
@@ -42,24 +42,40 @@ class Hclg:
         return int(self.arc_off[-1])
 
 
+def _rank_within(keys):
+    """rank of each element among equal keys (stable), and the per-key counts."""
+    order = np.argsort(keys, kind="stable")
+    sk = keys[order]
+    first = np.concatenate([[True], sk[1:] != sk[:-1]])
+    start = np.maximum.accumulate(np.where(first, np.arange(sk.size), 0))
+    rank = np.empty(keys.size, np.int64)
+    rank[order] = np.arange(sk.size) - start
+    return rank
+
+
 def make_hclg(num_units=64, vocab=200, n_hist=50, fanout=(4, 24), pron_len=(2, 6),
-              seed=2, dtype_check=True):
-    """Build the synthetic graph.  States 0..n_hist-1 are LM states (0 = unigram hub,
-    start = min(1, n_hist-1)); the rest are chain states."""
+              seed=2, self_loop_prob=None, lm_scale=1.0):
+    """Build the synthetic graph.  States 0..n_hist-1 are LM history states (0 = unigram
+    back-off hub, start = min(1, n_hist-1)); the rest are nodes of per-history lexicon
+    prefix trees (det(L o G)-like: words sharing a pronunciation prefix share states, so
+    a hub's out-degree is bounded by the number of first units, not by the vocabulary).
+    LM costs are pushed toward the front: the arc into a trie node costs
+    -log(P(node)/P(parent)); the word-end epsilon arc carries the residual and the word."""
     rng = np.random.default_rng(seed)
     U, V, H = num_units, vocab, n_hist
-    # pronunciations
     wlen = rng.integers(pron_len[0], pron_len[1] + 1, V)
-    woff = np.concatenate([[0], np.cumsum(wlen)])
-    wunits = rng.integers(0, U, woff[-1])
+    Lmax = int(wlen.max())
+    wpron = np.full((V, Lmax), -1, np.int64)
+    for d in range(Lmax):
+        m = wlen > d
+        wpron[m, d] = rng.integers(0, U, int(m.sum()))
     word_next_hist = rng.integers(0, H, V)
-    # (history, word) pairs: unigram hub has every word, others a random subset
+    # (history, word) pairs: unigram hub has every word, others a zipf-ish random subset
     hs = [np.zeros(V, np.int64)]
     ws = [np.arange(V, dtype=np.int64)]
     if H > 1:
         fo = rng.integers(fanout[0], fanout[1] + 1, H - 1)
         hh = np.repeat(np.arange(1, H, dtype=np.int64), fo)
-        # zipf-ish word choice so frequent words recur across histories
         ww = np.minimum((V * rng.random(hh.size) ** 2).astype(np.int64), V - 1)
         key = np.unique(hh * V + ww)
         hs.append(key // V)
@@ -68,64 +84,87 @@ def make_hclg(num_units=64, vocab=200, n_hist=50, fanout=(4, 24), pron_len=(2, 6
     pair_word = np.concatenate(ws)
     K = pair_hist.size
     pair_len = wlen[pair_word]
-    pair_base = H + np.concatenate([[0], np.cumsum(pair_len)[:-1]])
-    n_chain = int(pair_len.sum())
-    S = H + n_chain
-    # per-chain-state info
-    chain_pair = np.repeat(np.arange(K), pair_len)
-    chain_pos = np.arange(n_chain) - np.repeat(pair_base - H, pair_len)
-    chain_word = pair_word[chain_pair]
-    chain_unit = wunits[woff[chain_word] + chain_pos]
-    chain_last = chain_pos == (pair_len[chain_pair] - 1)
-    # arc counts: LM state h: (#pairs with hist h) + (1 backoff if h>0); chain: 2
-    hist_cnt = np.bincount(pair_hist, minlength=H)
-    narcs = np.empty(S, np.int64)
-    narcs[:H] = hist_cnt + (np.arange(H) > 0)
-    narcs[H:] = 2
-    arc_off = np.concatenate([[0], np.cumsum(narcs)])
-    A = int(arc_off[-1])
-    arcs = np.zeros(A, ARC_DTYPE)
-    # LM arcs: backoff first (h>0), then word arcs in pair order
-    hist_pair_off = np.concatenate([[0], np.cumsum(hist_cnt)])
-    if H > 1:
-        bo = arc_off[1:H]
-        arcs["ilabel"][bo] = 0
-        arcs["olabel"][bo] = 0
-        arcs["weight"][bo] = rng.uniform(0.5, 3.0, H - 1)
-        arcs["nextstate"][bo] = 0
-    rank = np.arange(K) - hist_pair_off[pair_hist]
-    wa = arc_off[pair_hist] + (pair_hist > 0) + rank
-    first_unit = wunits[woff[pair_word]]
-    arcs["ilabel"][wa] = 1 + 2 * first_unit          # forward tid of first unit
-    arcs["olabel"][wa] = pair_word + 1
-    # LM cost: -log of a random distribution per history
     raw = rng.gamma(1.0, 1.0, K) + 1e-3
     tot = np.bincount(pair_hist, weights=raw, minlength=H)
-    arcs["weight"][wa] = -np.log(raw / tot[pair_hist])
-    arcs["nextstate"][wa] = pair_base
-    # chain arcs: [self-loop, forward-or-epsilon]
-    cs = H + np.arange(n_chain)
-    a0 = arc_off[cs]
-    selfp = rng.uniform(0.25, 0.6, n_chain)
-    arcs["ilabel"][a0] = 2 + 2 * chain_unit          # self-loop tid
+    pair_p = raw / tot[pair_hist]                       # p(w | h)
+    hist_cnt = np.bincount(pair_hist, minlength=H)
+    hist_pair_off = np.concatenate([[0], np.cumsum(hist_cnt)])
+    # ---- prefix-tree nodes, depth by depth
+    pron = wpron[pair_word]                              # [K, Lmax]
+    pair_nodes = np.full((K, Lmax), -1, np.int64)
+    node_unit, node_parent, node_prob = [], [], []       # parent < 0 encodes LM state -(h+1)
+    n_nodes = 0
+    parent_id = -(pair_hist + 1)
+    for d in range(Lmax):
+        valid = pair_len > d
+        keyd = (parent_id[valid] + H + 1) * U + pron[valid, d]   # parent ids shifted to >= 0
+        uq, inv = np.unique(keyd, return_inverse=True)
+        ids = n_nodes + inv
+        pair_nodes[valid, d] = ids
+        node_unit.append(uq % U)
+        node_parent.append(uq // U - (H + 1))
+        node_prob.append(np.bincount(inv, weights=pair_p[valid], minlength=uq.size))
+        n_nodes += uq.size
+        nxt = parent_id.copy()
+        nxt[valid] = ids
+        parent_id = nxt
+    node_unit = np.concatenate(node_unit)
+    node_parent = np.concatenate(node_parent)
+    node_prob = np.concatenate(node_prob)
+    N = n_nodes
+    S = H + N
+    node_state = H + np.arange(N)
+    par_is_lm = node_parent < 0
+    par_state = np.where(par_is_lm, -(node_parent + 1), H + node_parent)
+    par_prob = np.where(par_is_lm, 1.0, node_prob[np.maximum(node_parent, 0)])
+    child_cost = -lm_scale * np.log(node_prob / par_prob)   # lm_scale < 1 flattens the LM (wider search)
+    # word ends: pair k ends at node pair_nodes[k, len-1]
+    end_node = pair_nodes[np.arange(K), pair_len - 1]
+    end_cost = -lm_scale * np.log(np.minimum(1.0, pair_p / node_prob[end_node]))
+    # ---- arc counts per state
+    n_child = np.bincount(par_state, minlength=S)
+    n_end = np.bincount(H + end_node, minlength=S)
+    narcs = n_child + n_end
+    narcs[:H] += (np.arange(H) > 0)          # back-off epsilon
+    narcs[H:] += 1                           # self-loop
+    arc_off = np.concatenate([[0], np.cumsum(narcs)]).astype(np.int64)
+    A = int(arc_off[-1])
+    arcs = np.zeros(A, ARC_DTYPE)
+    # chain topology: transition probabilities are a fixed 0.5/0.5 (self_loop_prob=0.5);
+    # None draws per-state probabilities (more graph-side discrimination, easier search)
+    selfp = rng.uniform(0.25, 0.6, N) if self_loop_prob is None else np.full(N, float(self_loop_prob))
+    # back-off arcs (first arc of LM states h > 0)
+    if H > 1:
+        bo = arc_off[1:H]
+        arcs["weight"][bo] = lm_scale * rng.uniform(0.5, 3.0, H - 1)
+        arcs["nextstate"][bo] = 0
+    # self-loops (first arc of every node)
+    a0 = arc_off[node_state]
+    arcs["ilabel"][a0] = 2 + 2 * node_unit
     arcs["weight"][a0] = -np.log(selfp)
-    arcs["nextstate"][a0] = cs
-    a1 = a0 + 1
-    nxt_unit = np.empty(n_chain, np.int64)
-    nxt_unit[:-1] = chain_unit[1:]
-    nxt_unit[-1] = 0
-    arcs["ilabel"][a1] = np.where(chain_last, 0, 1 + 2 * nxt_unit)
-    arcs["weight"][a1] = -np.log(1.0 - selfp)
-    arcs["nextstate"][a1] = np.where(chain_last, word_next_hist[chain_word], cs + 1)
+    arcs["nextstate"][a0] = node_state
+    # child arcs: after the back-off / self-loop
+    lead = np.where(par_state < H, (par_state > 0).astype(np.int64), 1)
+    ca = arc_off[par_state] + lead + _rank_within(par_state)
+    stay = np.where(par_is_lm, 0.0, -np.log(1.0 - selfp[np.maximum(node_parent, 0)]))
+    arcs["ilabel"][ca] = 1 + 2 * node_unit               # forward tid of the child's unit
+    arcs["weight"][ca] = child_cost + stay
+    arcs["nextstate"][ca] = node_state
+    # word-end epsilon arcs: after self-loop and children
+    es = H + end_node
+    ea = arc_off[es] + 1 + n_child[es] + _rank_within(es)
+    arcs["ilabel"][ea] = 0
+    arcs["olabel"][ea] = pair_word + 1
+    arcs["weight"][ea] = end_cost - np.log(1.0 - selfp[end_node])
+    arcs["nextstate"][ea] = word_next_hist[pair_word]
     final = np.full(S, np.inf, np.float32)
     final[:H] = rng.uniform(0.5, 3.0, H)
     tid2pdf = np.full(2 * U + 1, -1, np.int32)
     tid2pdf[1:] = np.arange(2 * U)
-    g = Hclg(S, min(1, H - 1), arc_off.astype(np.int64), arcs, final, tid2pdf, 2 * U,
-             n_hist=H, pair_hist=pair_hist, pair_word=pair_word, pair_base=pair_base,
-             pair_len=pair_len, hist_pair_off=hist_pair_off,
-             word_next_hist=word_next_hist, chain_unit=chain_unit)
-    return g
+    return Hclg(S, min(1, H - 1), arc_off, arcs, final, tid2pdf, 2 * U, n_hist=H,
+                pair_hist=pair_hist, pair_word=pair_word, pair_base=pair_nodes,
+                pair_len=pair_len, hist_pair_off=hist_pair_off,
+                word_next_hist=word_next_hist, chain_unit=node_unit)
 
 
 def make_random_graph(num_states=300, num_labels=40, mean_arcs=3.0, eps_frac=0.12,
@@ -166,9 +205,9 @@ def sample_utterance(g, n_words=6, seed=0, peak=6.0, noise=1.0, dur_p=0.5):
         k = int(rng.integers(lo, hi))
         w = int(g.pair_word[k])
         words.append(w + 1)
-        base, ln = int(g.pair_base[k]) - g.n_hist, int(g.pair_len[k])
+        ln = int(g.pair_len[k])
         for j in range(ln):
-            u = int(g.chain_unit[base + j])
+            u = int(g.chain_unit[int(g.pair_base[k, j])])
             pdfs.append(2 * u)           # forward pdf on entry
             d = int(rng.geometric(dur_p)) - 1
             pdfs.extend([2 * u + 1] * d)  # self-loop pdf
