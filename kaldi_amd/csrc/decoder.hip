@@ -35,7 +35,7 @@ typedef unsigned int u32;
 
 #define NT 1024
 #define NWAVES (NT / 64)
-#define BIGCAP 3072     // tokens per flatten batch (deg > SMALL_DEG)
+#define BIGCAP 4096     // tokens per flatten batch (deg > SMALL_DEG)
 #define SMALL_DEG 4
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
 
@@ -264,6 +264,72 @@ __device__ float BlockSelectKth(const float *cost, int n, int k, Sh *sh) {
   return OrderedToFloat(prefix);
 }
 
+// max-active cutoff: the max_active-th smallest cost, known to lie below beam_cutoff.
+// One pass builds a 4096-bucket LDS histogram over the linear range [best, best+beam)
+// (monotone bucket map => lower buckets hold smaller costs); the bucket containing rank k
+// is then resolved EXACTLY by ranking its few members against each other.  Falls back to
+// the radix select when the bucket is too crowded.  `src` may point to LDS or global.
+#define LHBINS 4096
+#define LHCAND 1024
+__device__ float BlockSelectLinear(const float *src, int n, int k, float best, float beam,
+                                   u32 *lh /* [LHBINS] LDS */, float *cand /* [LHCAND] LDS */, Sh *sh) {
+  const float scale = static_cast<float>(LHBINS) / beam;
+  for (int i = threadIdx.x; i < LHBINS; i += NT) lh[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const float b = (src[i] - best) * scale;
+    if (b < static_cast<float>(LHBINS)) atomicAdd(&lh[b < 0.f ? 0 : static_cast<int>(b)], 1u);
+  }
+  __syncthreads();
+  // locate the bucket of rank k: 4 buckets per thread, workgroup scan
+  {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int h0 = lh[4 * t], h1 = lh[4 * t + 1], h2 = lh[4 * t + 2], h3 = lh[4 * t + 3];
+    const int mine = h0 + h1 + h2 + h3;
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) sh->redi[w] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int q = 0; q < w; q++) wbase += sh->redi[q];
+    const int excl = wbase + incl - mine;
+    if (t == 0) { sh->sel_bin = -1; sh->scan_total = 0; }
+    __syncthreads();
+    if (k >= excl && k < excl + mine) {
+      int cum = excl, b = 4 * t, cnt = h0;
+      if (cum + h0 <= k) { cum += h0; b++; cnt = h1; if (cum + h1 <= k) { cum += h1; b++; cnt = h2; if (cum + h2 <= k) { cum += h2; b++; cnt = h3; } } }
+      sh->sel_bin = b; sh->sel_below = cum; sh->changed = cnt;
+    }
+    __syncthreads();
+  }
+  const int bin = sh->sel_bin, below = sh->sel_below, members = sh->changed;
+  if (bin < 0 || members > LHCAND) return BlockSelectKth(src, n, k, sh);   // uniform decision
+  // gather the bucket's members
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const float v = src[i];
+    const float b = (v - best) * scale;
+    if (b < static_cast<float>(LHBINS) && (b < 0.f ? 0 : static_cast<int>(b)) == bin) {
+      const int p = WaveAlloc(&sh->scan_total);
+      if (p < LHCAND) cand[p] = v;
+    }
+  }
+  __syncthreads();
+  const int m = sh->scan_total, kk = k - below;     // kk-th smallest of the m members
+  __syncthreads();
+  if (threadIdx.x == 0) sh->sel_below = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < m; i += NT) {
+    const float v = cand[i];
+    int less = 0, eq = 0;
+    for (int j = 0; j < m; j++) { const float u = cand[j]; less += u < v; eq += u == v; }
+    if (kk >= less && kk < less + eq) sh->sel_below = static_cast<int>(FloatToOrdered(v));  // all writers agree
+  }
+  __syncthreads();
+  const float ans = OrderedToFloat(static_cast<u32>(sh->sel_below));
+  __syncthreads();
+  return ans;
+}
+
 // FindOrAddToken (lattice-faster-decoder.cc:266-306) on the frame's table.
 // returns slot (or -1 on overflow); *improved = created, or strictly lowered the cost.
 __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int state, float cost,
@@ -271,20 +337,19 @@ __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int stat
   const u64 mine = Pack(state, cost);
   u32 h = HashState(state, d.hash_mask);
   for (int probe = 0; probe < d.hash_cap; probe++) {
-    u64 cur = LoadH(&c.H[h]);
-    if (cur == EMPTY64) {
-      u64 old = atomicCAS(&c.H[h], EMPTY64, mine);
-      if (old == EMPTY64) {
-        int idx = WaveAlloc(&sh->n_slots);
-        if (idx < d.hash_cap) c.slots[idx] = h; else sh->err = ERR_HASH;
-        *improved = true;
-        return static_cast<int>(h);
-      }
-      cur = old;
+    // optimistic claim: one L2 round trip for a new token, and the returned word tells
+    // whether an existing token of this state already has a cost <= ours.
+    const u64 old = atomicCAS(&c.H[h], EMPTY64, mine);
+    if (old == EMPTY64) {
+      int idx = WaveAlloc(&sh->n_slots);
+      if (idx < d.hash_cap) c.slots[idx] = h; else sh->err = ERR_HASH;
+      *improved = true;
+      return static_cast<int>(h);
     }
-    if (StateOf(cur) == state) {
-      u64 old = atomicMin(&c.H[h], mine);
-      *improved = old > mine;
+    if (StateOf(old) == state) {
+      if (old <= mine) { *improved = false; return static_cast<int>(h); }   // :288 strict '>'
+      const u64 prev = atomicMin(&c.H[h], mine);
+      *improved = prev > mine;
       return static_cast<int>(h);
     }
     h = (h + 1) & static_cast<u32>(d.hash_mask);
@@ -568,6 +633,8 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
   u32 *big_a0 = reinterpret_cast<u32 *>(big_tok + BIGCAP);     // [BIGCAP] first emitting arc
   int *big_scan = reinterpret_cast<int *>(big_a0 + BIGCAP);    // [BIGCAP] degree -> exclusive scan
   float *ll_lds = reinterpret_cast<float *>(big_scan + BIGCAP);// [num_pdfs_lds]
+  u32 *lh_lds = reinterpret_cast<u32 *>(ll_lds + ((d.num_pdfs_lds + 3) & ~3));   // [LHBINS]
+  float *cand_lds = reinterpret_cast<float *>(lh_lds + LHBINS);                  // [LHCAND]
   const kamd_decode_task task = tasks[blockIdx.x];
   const Ctx c = MakeCtx(d, task.lane);
   const int tid = threadIdx.x;
@@ -598,18 +665,27 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
       cur_cutoff = beam_cutoff; adaptive_beam = cfg.beam;
     } else {
       int c_lt = 0, c_le = 0;
-      for (int i = tid; i < n; i += NT) { float w = cost[i]; c_lt += w < beam_cutoff; c_le += w <= beam_cutoff; }
+      // the flatten queue's LDS is idle during GetCutoff: cache the costs there so the
+      // radix-select passes read LDS instead of L2
+      float *cost_cache = reinterpret_cast<float *>(dyn_lds);
+      const bool cached = n <= 3 * BIGCAP;
+      for (int i = tid; i < n; i += NT) {
+        float w = cost[i];
+        if (cached) cost_cache[i] = w;
+        c_lt += w < beam_cutoff; c_le += w <= beam_cutoff;
+      }
       BlockSum2(c_lt, c_le, &sh);
+      const float *sel_src = cached ? cost_cache : cost;
       // nth_element(max_active) < beam_cutoff  <=>  more than max_active costs < beam_cutoff
       if (n > cfg.max_active && c_lt > cfg.max_active) {
-        const float mac = BlockSelectKth(cost, n, cfg.max_active, &sh);
+        const float mac = BlockSelectLinear(sel_src, n, cfg.max_active, best, cfg.beam, lh_lds, cand_lds, &sh);
         adaptive_beam = mac - best + cfg.beam_delta;   // :700-702
         cur_cutoff = mac;
       } else {
         float mic = INFINITY;
         if (n > cfg.min_active) {
           if (cfg.min_active == 0) mic = best;
-          else if (c_le <= cfg.min_active) mic = BlockSelectKth(cost, n, cfg.min_active, &sh);
+          else if (c_le <= cfg.min_active) mic = BlockSelectKth(sel_src, n, cfg.min_active, &sh);
           else mic = -INFINITY;  // nth_element(min_active) <= beam_cutoff: not looser than the beam
         }
         if (mic > beam_cutoff) { adaptive_beam = mic - best + cfg.beam_delta; cur_cutoff = mic; }  // :715-718
@@ -693,13 +769,35 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
         if (e0 + 1 < nb) big_scan[e0 + 1] = excl + v0;
         if (e0 + 2 < nb) big_scan[e0 + 2] = excl + v0 + v1;
         __syncthreads();
-        for (int j = tid; j < total; j += NT) {
-          int lo = 0, hi = nb;                    // largest e with big_scan[e] <= j
-          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
-          const int i2 = big_tok[lo];
-          const u32 a = big_a0[lo] + static_cast<u32>(j - big_scan[lo]);
-          ProcessArc(d, c, &sh, row, d.g.e_arcs[a], d.e_pdf[a], tb + i2, cost[i2], cost_offset,
-                     adaptive_beam, link_base);
+        {
+          // software pipelined: the next arc's loads are in flight while this one is hashed
+          auto lookup = [&](int j, u32 *a, int *i2) {
+            int lo = 0, hi = nb;                  // largest e with big_scan[e] <= j
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
+            *i2 = big_tok[lo];
+            *a = big_a0[lo] + static_cast<u32>(j - big_scan[lo]);
+          };
+          int j = tid;
+          bool have = j < total;
+          kamd_arc arc_cur; int pdf_cur = 0, tok_cur = 0; float cost_cur = 0.f;
+          arc_cur.ilabel = arc_cur.olabel = arc_cur.nextstate = 0; arc_cur.weight = 0.f;
+          if (have) {
+            u32 a; lookup(j, &a, &tok_cur);
+            arc_cur = d.g.e_arcs[a]; pdf_cur = d.e_pdf[a]; cost_cur = cost[tok_cur];
+          }
+          while (have) {
+            const int jn = j + NT;
+            const bool have_n = jn < total;
+            kamd_arc arc_n = arc_cur; int pdf_n = 0, tok_n = 0; float cost_n = 0.f;
+            if (have_n) {
+              u32 a; lookup(jn, &a, &tok_n);
+              arc_n = d.g.e_arcs[a]; pdf_n = d.e_pdf[a]; cost_n = cost[tok_n];
+            }
+            ProcessArc(d, c, &sh, row, arc_cur, pdf_cur, tb + tok_cur, cost_cur, cost_offset,
+                       adaptive_beam, link_base);
+            arc_cur = arc_n; pdf_cur = pdf_n; tok_cur = tok_n; cost_cur = cost_n;
+            j = jn; have = have_n;
+          }
         }
         __syncthreads();
         if (tid == 0) sh.bigcnt = 0;
@@ -1077,7 +1175,8 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   }
   d.num_pdfs_lds = num_pdfs <= 24576 ? num_pdfs : 0;   // LDS row: up to 96 KB of the CU's 160 KB
   if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::AdvanceKernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * BIGCAP * 4 + d.num_pdfs_lds * 4) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                3 * BIGCAP * 4 + ((d.num_pdfs_lds + 3) & ~3) * 4 + (LHBINS + LHCAND) * 4) != hipSuccess)
     ok = false;
   if (ok && (hipEventCreate(&D->ev0) != hipSuccess || hipEventCreate(&D->ev1) != hipSuccess)) ok = false;
   if (!ok) {
@@ -1179,7 +1278,7 @@ int kamd_decoder_advance(kamd_decoder *h, const kamd_decode_task *tasks, int n, 
   KAMD_HIP(hipMemcpyAsync(D->d_tasks, sorted.data(), n * sizeof(kamd_decode_task), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
   KAMD_HIP(hipEventRecord(D->ev0, st));
-  const size_t lds = 3 * BIGCAP * 4 + static_cast<size_t>(D->dev.num_pdfs_lds) * 4;
+  const size_t lds = 3 * BIGCAP * 4 + static_cast<size_t>((D->dev.num_pdfs_lds + 3) & ~3) * 4 + (LHBINS + LHCAND) * 4;
   hipLaunchKernelGGL(kamd::AdvanceKernel, dim3(n), dim3(NT), lds, st, D->dev, D->d_tasks);
   KAMD_HIP(hipGetLastError());
   KAMD_HIP(hipEventRecord(D->ev1, st));
