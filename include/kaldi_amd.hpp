@@ -1,0 +1,290 @@
+// kaldi_amd.hpp -- C++ host-side mirror of Kaldi's interfaces for the decode hot path,
+// layered on the C-ABI (kaldi_amd.h).  Header only; link with -lkaldi_amd.
+//
+// Same class names, method names, argument meaning and error behaviour as the reference
+// so that call sites read like Kaldi code:
+//   kaldi_amd::DecodableInterface         itf/decodable-itf.h:82-118
+//   kaldi_amd::LatticeFasterDecoderConfig decoder/lattice-faster-decoder.h:38-90
+//   kaldi_amd::LatticeFasterDecoder       decoder/lattice-faster-decoder.h:226-343
+//   kaldi_amd::DecodableMatrixMapped      decoder/decodable-matrix.h:98-136
+//   kaldi_amd::MfccOptions / Mfcc         feat/feature-mfcc.h:38-56, feature-common.h:111
+// Errors: the reference's KALDI_ERR throws kaldi::KaldiFatalError (std::runtime_error,
+// base/kaldi-error.h:89-140); here every non-zero C-ABI status throws
+// kaldi_amd::KaldiFatalError carrying kamd_last_error().
+// What is NOT here: fst::Fst / kaldi::Lattice types (OpenFst is not available in this
+// image); INTEGRATION.md shows the ~40-line adapters a Kaldi tree adds on top.
+#ifndef KALDI_AMD_HPP_
+#define KALDI_AMD_HPP_
+
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kaldi_amd.h"
+
+namespace kaldi_amd {
+
+typedef float BaseFloat;
+typedef int32_t int32;
+
+class KaldiFatalError : public std::runtime_error {
+ public:
+  explicit KaldiFatalError(const std::string &m) : std::runtime_error(m) {}
+};
+inline void Check(int rc) { if (rc < 0) throw KaldiFatalError(kamd_last_error()); }
+template <typename T> inline T *CheckPtr(T *p) { if (!p) throw KaldiFatalError(kamd_last_error()); return p; }
+
+// ------------------------------------------------------------------ itf/decodable-itf.h
+class DecodableInterface {
+ public:
+  /// Returns the log likelihood, which will be negated in the decoder.  'index' is a
+  /// 1-based transition-id; 'frame' is zero-based.
+  virtual BaseFloat LogLikelihood(int32 frame, int32 index) = 0;
+  virtual bool IsLastFrame(int32 frame) const = 0;
+  virtual int32 NumFramesReady() const { throw KaldiFatalError("NumFramesReady() not implemented for this decodable type."); }
+  virtual int32 NumIndices() const = 0;
+  virtual ~DecodableInterface() {}
+};
+
+// decoder/decodable-matrix.h:98-136: log-likes matrix [frames x pdfs] + tid->pdf map.
+// The matrix lives on the host here; the decoder uploads it once (or, for a matrix that is
+// already in HBM, use SetDevicePointer and nothing is copied).
+class DecodableMatrixMapped : public DecodableInterface {
+ public:
+  DecodableMatrixMapped(const std::vector<int32> &id2pdf /* [num_tids+1], [0] unused */,
+                        const float *likes, int32 num_frames, int32 num_pdfs, int32 frame_offset = 0)
+      : id2pdf_(id2pdf), likes_(likes), num_frames_(num_frames), num_pdfs_(num_pdfs),
+        frame_offset_(frame_offset), d_likes_(NULL) {}
+  BaseFloat LogLikelihood(int32 frame, int32 tid) override {
+    return likes_[static_cast<size_t>(frame - frame_offset_) * num_pdfs_ + id2pdf_[tid]];
+  }
+  bool IsLastFrame(int32 frame) const override { return frame == NumFramesReady() - 1; }
+  int32 NumFramesReady() const override { return frame_offset_ + num_frames_; }
+  int32 NumIndices() const override { return static_cast<int32>(id2pdf_.size()) - 1; }
+  // fast path used by LatticeFasterDecoder
+  const float *HostMatrix() const { return likes_; }
+  int32 NumPdfs() const { return num_pdfs_; }
+  int32 FrameOffset() const { return frame_offset_; }
+  void SetDevicePointer(const float *d) { d_likes_ = d; }
+  const float *DevicePointer() const { return d_likes_; }
+  const std::vector<int32> &Id2Pdf() const { return id2pdf_; }
+ private:
+  std::vector<int32> id2pdf_;
+  const float *likes_;
+  int32 num_frames_, num_pdfs_, frame_offset_;
+  const float *d_likes_;
+};
+
+// ------------------------------------------------- decoder/lattice-faster-decoder.h:38-90
+struct LatticeFasterDecoderConfig {
+  BaseFloat beam;
+  int32 max_active;
+  int32 min_active;
+  BaseFloat lattice_beam;
+  int32 prune_interval;
+  bool determinize_lattice;   // kept for source compatibility; determinization is host side
+  BaseFloat beam_delta;
+  BaseFloat hash_ratio;
+  BaseFloat prune_scale;
+  LatticeFasterDecoderConfig()
+      : beam(16.0), max_active(std::numeric_limits<int32>::max()), min_active(200), lattice_beam(10.0),
+        prune_interval(25), determinize_lattice(true), beam_delta(0.5), hash_ratio(2.0), prune_scale(0.1) {}
+  void Check() const {
+    if (!(beam > 0.0 && max_active > 1 && lattice_beam > 0.0 && min_active <= max_active && prune_interval > 0 &&
+          beam_delta > 0.0 && hash_ratio >= 1.0 && prune_scale > 0.0 && prune_scale < 1.0))
+      throw KaldiFatalError("invalid LatticeFasterDecoderConfig");
+  }
+  kamd_decoder_config ToC() const {
+    kamd_decoder_config c = {beam, max_active, min_active, lattice_beam, prune_interval, beam_delta, hash_ratio, prune_scale};
+    return c;
+  }
+};
+
+// Raw lattice as plain arrays (kaldi::Lattice = fst::VectorFst<LatticeArc>; lat/kaldi-lattice.h:44).
+struct LatticeArc { int32 ilabel, olabel; BaseFloat graph_cost, acoustic_cost; int32 nextstate; };
+struct Lattice {
+  int32 start;
+  std::vector<std::vector<LatticeArc> > arcs;   // per state
+  std::vector<BaseFloat> final_graph_cost;      // LatticeWeight(final, 0); +inf = not final
+  std::vector<int32> state_frame, state_hclg;   // annotations the reference discards
+  int32 NumStates() const { return static_cast<int32>(arcs.size()); }
+};
+
+// HCLG handle (what the reference passes as `const fst::Fst<fst::StdArc> &`).
+class DecodingGraph {
+ public:
+  DecodingGraph(int32 num_states, int32 start, const int64_t *arc_off, const kamd_arc *arcs, const float *final_cost)
+      : g_(CheckPtr(kamd_graph_create(num_states, start, arc_off, arcs, final_cost))) {}
+  ~DecodingGraph() { kamd_graph_destroy(g_); }
+  kamd_graph *Handle() const { return g_; }
+ private:
+  DecodingGraph(const DecodingGraph &);
+  kamd_graph *g_;
+};
+
+// -------------------------------------------- decoder/lattice-faster-decoder.h:226-343
+class LatticeFasterDecoder {
+ public:
+  // The reference ctor takes (fst, config); the transition-id -> pdf table comes from the
+  // decodable there (DecodableMatrixMapped holds the TransitionModel).  The device decoder
+  // resolves it once per arc at construction, so it is a ctor argument here.
+  LatticeFasterDecoder(const DecodingGraph &fst, const LatticeFasterDecoderConfig &config,
+                       const std::vector<int32> &id2pdf, const kamd_decoder_sizes *sizes = NULL)
+      : config_(config), id2pdf_(id2pdf), d_buf_(NULL), d_buf_bytes_(0) {
+    config.Check();
+    kamd_decoder_config c = config.ToC();
+    kamd_decoder_sizes s;
+    if (sizes) s = *sizes; else { kamd_decoder_sizes_default(&s); s.max_lanes = 1; }
+    dec_ = CheckPtr(kamd_decoder_create(fst.Handle(), &c, &s, id2pdf.empty() ? NULL : id2pdf.data(),
+                                        id2pdf.empty() ? 0 : static_cast<int32>(id2pdf.size()) - 1));
+  }
+  ~LatticeFasterDecoder() { if (d_buf_) kamd_free(d_buf_); kamd_decoder_destroy(dec_); }
+
+  void SetOptions(const LatticeFasterDecoderConfig &config) {
+    config.Check(); config_ = config; kamd_decoder_config c = config.ToC(); Check(kamd_decoder_set_options(dec_, &c));
+  }
+  const LatticeFasterDecoderConfig &GetOptions() const { return config_; }
+
+  /// Decodes until there are no more frames left in the "decodable" object.
+  bool Decode(DecodableInterface *decodable) {
+    InitDecoding();
+    AdvanceDecoding(decodable);
+    FinalizeDecoding();
+    kamd_lattice_size sz;
+    return kamd_decoder_lattice_size(dec_, 0, &sz) == 0 && sz.num_states > 0;
+  }
+  void InitDecoding() {
+    int32 lane = 0;
+    Check(kamd_decoder_init(dec_, &lane, 1, NULL));
+    Check(kamd_decoder_sync(dec_));
+  }
+  /// Decodes frames NumFramesDecoded() .. decodable->NumFramesReady()-1 (at most
+  /// max_num_frames of them).
+  void AdvanceDecoding(DecodableInterface *decodable, int32 max_num_frames = -1) {
+    const int32 done = NumFramesDecoded(), ready = decodable->NumFramesReady();
+    if (ready < done) throw KaldiFatalError("AdvanceDecoding: NumFramesReady() decreased");
+    int32 n = ready - done;
+    if (max_num_frames >= 0 && n > max_num_frames) n = max_num_frames;
+    if (n == 0) return;
+    kamd_decode_task task;
+    task.lane = 0; task.n_frames = n; task.reserved = 0;
+    DecodableMatrixMapped *mm = dynamic_cast<DecodableMatrixMapped *>(decodable);
+    if (mm && mm->Id2Pdf() == id2pdf_) {
+      const int32 P = mm->NumPdfs();
+      const size_t row0 = static_cast<size_t>(done - mm->FrameOffset());
+      if (mm->DevicePointer()) {
+        task.d_loglikes = mm->DevicePointer() + row0 * P;
+      } else {
+        Upload(mm->HostMatrix() + row0 * P, static_cast<size_t>(n) * P);
+        task.d_loglikes = static_cast<const float *>(d_buf_);
+      }
+      task.ld = P;
+    } else {
+      // any other DecodableInterface: materialise LogLikelihood(frame, tid) for every
+      // transition-id (what the reference does lazily, one virtual call per arc,
+      // lattice-faster-decoder.cc:767,794).  Needs a decoder built with an empty id2pdf.
+      if (!id2pdf_.empty()) throw KaldiFatalError("generic DecodableInterface needs a decoder constructed with an empty id2pdf (columns = transition-ids)");
+      const int32 nt = decodable->NumIndices();
+      std::vector<float> m(static_cast<size_t>(n) * nt);
+      for (int32 f = 0; f < n; f++)
+        for (int32 t = 1; t <= nt; t++) m[static_cast<size_t>(f) * nt + (t - 1)] = decodable->LogLikelihood(done + f, t);
+      Upload(m.data(), m.size());
+      task.d_loglikes = static_cast<const float *>(d_buf_);
+      task.ld = nt;
+    }
+    Check(kamd_decoder_advance(dec_, &task, 1, NULL));
+    Check(kamd_decoder_sync(dec_));
+  }
+  void FinalizeDecoding() {
+    int32 lane = 0;
+    Check(kamd_decoder_finalize(dec_, &lane, 1, NULL));
+    Check(kamd_decoder_sync(dec_));
+  }
+  BaseFloat FinalRelativeCost() const { return kamd_decoder_final_relative_cost(dec_, 0); }
+  bool ReachedFinal() const { return FinalRelativeCost() != std::numeric_limits<BaseFloat>::infinity(); }
+  int32 NumFramesDecoded() const { return kamd_decoder_num_frames_decoded(dec_, 0); }
+
+  /// Raw state-level lattice; requires FinalizeDecoding() (use_final_probs == true).
+  bool GetRawLattice(Lattice *ofst, bool use_final_probs = true) const {
+    if (!use_final_probs) throw KaldiFatalError("You cannot call FinalizeDecoding() and then call GetRawLattice() with use_final_probs == false");
+    kamd_lattice_size sz;
+    Check(kamd_decoder_lattice_size(dec_, 0, &sz));
+    ofst->arcs.assign(sz.num_states, std::vector<LatticeArc>());
+    ofst->final_graph_cost.assign(sz.num_states, 0.f);
+    ofst->state_frame.assign(sz.num_states, 0); ofst->state_hclg.assign(sz.num_states, 0);
+    ofst->start = sz.start;
+    if (sz.num_states == 0) return false;
+    std::vector<float> cost(sz.num_states);
+    std::vector<kamd_lat_arc> arcs(sz.num_arcs);
+    Check(kamd_decoder_get_raw_lattice(dec_, 0, ofst->state_frame.data(), ofst->state_hclg.data(), cost.data(),
+                                       ofst->final_graph_cost.data(), arcs.data()));
+    for (size_t i = 0; i < arcs.size(); i++) {
+      LatticeArc a = {arcs[i].ilabel, arcs[i].olabel, arcs[i].graph_cost, arcs[i].acoustic_cost, arcs[i].dst};
+      ofst->arcs[arcs[i].src].push_back(a);
+    }
+    return true;
+  }
+  /// Single best path: ShortestPath(raw lattice) + GetLinearSymbolSequence.
+  bool GetBestPath(std::vector<int32> *alignment, std::vector<int32> *words, BaseFloat *graph_cost,
+                   BaseFloat *acoustic_cost) const {
+    kamd_lattice_size sz;
+    Check(kamd_decoder_lattice_size(dec_, 0, &sz));
+    std::vector<int32> ali(sz.num_arcs + 1), wrd(sz.num_arcs + 1);
+    int na = 0, nw = 0;
+    if (kamd_decoder_best_path(dec_, 0, ali.data(), static_cast<int>(ali.size()), &na, wrd.data(),
+                               static_cast<int>(wrd.size()), &nw, graph_cost, acoustic_cost) != 0)
+      return false;
+    alignment->assign(ali.begin(), ali.begin() + na);
+    words->assign(wrd.begin(), wrd.begin() + nw);
+    return true;
+  }
+  kamd_decoder *Handle() const { return dec_; }
+
+ private:
+  void Upload(const float *h, size_t n) {
+    if (n * sizeof(float) > d_buf_bytes_) {
+      if (d_buf_) kamd_free(d_buf_);
+      d_buf_ = CheckPtr(kamd_malloc(n * sizeof(float)));
+      d_buf_bytes_ = n * sizeof(float);
+    }
+    Check(kamd_memcpy_h2d(d_buf_, h, n * sizeof(float)));
+  }
+  LatticeFasterDecoder(const LatticeFasterDecoder &);
+  LatticeFasterDecoderConfig config_;
+  std::vector<int32> id2pdf_;
+  kamd_decoder *dec_;
+  void *d_buf_;
+  size_t d_buf_bytes_;
+};
+
+// --------------------------------------------------------- feat/feature-mfcc.h:38-56
+struct FrameExtractionOptions : kamd_frame_opts {};
+struct MfccOptions {
+  kamd_mfcc_opts c;
+  MfccOptions() { kamd_mfcc_opts_default(&c); }   // NOTE dither defaults to 0 here (1.0 in Kaldi)
+};
+// OfflineFeatureTpl<MfccComputer> (feat/feature-common.h:111-160)
+class Mfcc {
+ public:
+  explicit Mfcc(const MfccOptions &opts, BaseFloat vtln_warp = 1.0f) : f_(CheckPtr(kamd_mfcc_create(&opts.c, vtln_warp))) {}
+  ~Mfcc() { kamd_feat_destroy(f_); }
+  int32 Dim() const { return kamd_feat_dim(f_); }
+  /// wave: int16-range samples; output row-major [num_frames x Dim()].
+  void ComputeFeatures(const std::vector<float> &wave, BaseFloat sample_freq, std::vector<float> *output,
+                       int32 *num_frames) {
+    (void)sample_freq;
+    const int T = kamd_feat_num_frames(f_, static_cast<int64_t>(wave.size()));
+    output->assign(static_cast<size_t>(T) * Dim(), 0.f);
+    if (T > 0) Check(kamd_feat_compute(f_, wave.data(), static_cast<int64_t>(wave.size()), output->data(), T));
+    *num_frames = T;
+  }
+ private:
+  Mfcc(const Mfcc &);
+  kamd_feat *f_;
+};
+
+}  // namespace kaldi_amd
+#endif  // KALDI_AMD_HPP_

@@ -1,0 +1,101 @@
+// Exercises the C++ host mirror (include/kaldi_amd.hpp) the way Kaldi code drives
+// LatticeFasterDecoder: Decode(DecodableInterface*) with (1) DecodableMatrixMapped and
+// (2) an arbitrary DecodableInterface subclass.  Input: a fixture file written by
+// tests/test_gpu_cxx_host.py.  Output: one line per decode, compared with the oracle there.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "kaldi_amd.hpp"
+
+using namespace kaldi_amd;
+
+template <typename T> static std::vector<T> ReadVec(FILE *f) {
+  int64_t n;
+  if (fread(&n, 8, 1, f) != 1) { fprintf(stderr, "bad fixture\n"); exit(2); }
+  std::vector<T> v(n);
+  if (n && fread(v.data(), sizeof(T), n, f) != static_cast<size_t>(n)) { fprintf(stderr, "bad fixture\n"); exit(2); }
+  return v;
+}
+
+// a decodable the decoder knows nothing about (like DecodableAmDiagGmmScaled would be)
+class ScaledDecodable : public DecodableInterface {
+ public:
+  ScaledDecodable(const std::vector<int32> &id2pdf, const std::vector<float> &ll, int32 T, int32 P)
+      : id2pdf_(id2pdf), ll_(ll), T_(T), P_(P) {}
+  BaseFloat LogLikelihood(int32 frame, int32 tid) override { return ll_[static_cast<size_t>(frame) * P_ + id2pdf_[tid]]; }
+  bool IsLastFrame(int32 frame) const override { return frame == T_ - 1; }
+  int32 NumFramesReady() const override { return T_; }
+  int32 NumIndices() const override { return static_cast<int32>(id2pdf_.size()) - 1; }
+ private:
+  const std::vector<int32> &id2pdf_;
+  const std::vector<float> &ll_;
+  int32 T_, P_;
+};
+
+static void Report(const char *tag, LatticeFasterDecoder &dec) {
+  std::vector<int32> ali, words;
+  BaseFloat g, a;
+  bool ok = dec.GetBestPath(&ali, &words, &g, &a);
+  Lattice lat;
+  dec.GetRawLattice(&lat);
+  size_t narcs = 0;
+  for (size_t s = 0; s < lat.arcs.size(); s++) narcs += lat.arcs[s].size();
+  printf("%s ok=%d frames=%d reached_final=%d states=%d arcs=%zu graph=%.9g acoustic=%.9g words=", tag, ok,
+         dec.NumFramesDecoded(), dec.ReachedFinal(), lat.NumStates(), narcs, g, a);
+  for (size_t i = 0; i < words.size(); i++) printf("%d%s", words[i], i + 1 < words.size() ? "," : "");
+  printf("\n");
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 2;
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  std::vector<int64_t> hdr = ReadVec<int64_t>(f);     // num_states, start, T, P
+  std::vector<int64_t> arc_off = ReadVec<int64_t>(f);
+  std::vector<kamd_arc> arcs = ReadVec<kamd_arc>(f);
+  std::vector<float> final_cost = ReadVec<float>(f);
+  std::vector<int32> id2pdf = ReadVec<int32>(f);
+  std::vector<float> ll = ReadVec<float>(f);
+  fclose(f);
+  const int32 S = static_cast<int32>(hdr[0]), start = static_cast<int32>(hdr[1]), T = static_cast<int32>(hdr[2]),
+              P = static_cast<int32>(hdr[3]);
+  try {
+    DecodingGraph fst(S, start, arc_off.data(), arcs.data(), final_cost.data());
+    LatticeFasterDecoderConfig config;
+    config.beam = 15.0; config.max_active = 7000; config.min_active = 200; config.lattice_beam = 8.0;
+    kamd_decoder_sizes sz;
+    kamd_decoder_sizes_default(&sz);
+    sz.max_lanes = 1; sz.hash_capacity = 1 << 14; sz.arena_tokens = 1 << 18; sz.arena_links = 1 << 19; sz.max_frames = 1024;
+    {
+      LatticeFasterDecoder decoder(fst, config, id2pdf, &sz);
+      DecodableMatrixMapped decodable(id2pdf, ll.data(), T, P);
+      decoder.Decode(&decodable);
+      Report("mapped", decoder);
+      // chunked AdvanceDecoding, as online2 drives it
+      decoder.InitDecoding();
+      for (int32 t = 0; t < T; t += 7) {
+        DecodableMatrixMapped part(id2pdf, ll.data(), std::min(T, t + 7), P);
+        decoder.AdvanceDecoding(&part);
+      }
+      decoder.FinalizeDecoding();
+      Report("chunked", decoder);
+    }
+    {
+      LatticeFasterDecoder decoder(fst, config, std::vector<int32>(), &sz);
+      ScaledDecodable decodable(id2pdf, ll, T, P);
+      decoder.Decode(&decodable);
+      Report("generic", decoder);
+    }
+    // error convention: a bad config throws like KALDI_ERR
+    try {
+      LatticeFasterDecoderConfig bad; bad.beam = -1;
+      LatticeFasterDecoder d2(fst, bad, id2pdf, &sz);
+      printf("badconfig no-throw\n");
+    } catch (const KaldiFatalError &e) { printf("badconfig threw\n"); }
+  } catch (const std::exception &e) {
+    fprintf(stderr, "FATAL: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
