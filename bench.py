@@ -69,7 +69,7 @@ def calibrate(model, target_std):
 
 
 PHASES = ["best", "cutoff", "seed", "expand", "expand_hub", "eps_closure", "compact", "fixup",
-          "eps_links", "clear", "fin_sweep", "fin_compact"]
+          "eps_links", "clear", "fin_sweep", "fin_compact", "flat_setup"]
 
 
 def phase_share(pipe, waves):

@@ -9,7 +9,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkaldi_amd.so")
+LIB_PATH = os.environ.get("KAMD_LIB") or os.path.join(_HERE, "lib", "libkaldi_amd.so")
 _LIB = None
 
 

@@ -37,6 +37,8 @@ typedef unsigned int u32;
 #define NWAVES (NT / 64)
 #define BIGCAP 4096     // tokens per flatten batch (deg > SMALL_DEG)
 #define SMALL_DEG 4
+#define ARCW 4           // arcs in flight per thread in the arc-parallel expansion
+#define CHUNKCAP 8192    // cached chunk owners (16 arcs each) per flatten batch
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
 
 enum { ERR_HASH = 1, ERR_TOK = 2, ERR_LINK = 4, ERR_FRAMES = 8, ERR_WL = 16, ERR_INTERNAL = 32 };
@@ -128,7 +130,7 @@ struct Sh {  // workgroup-shared state
 
 // phase ids for the diagnostic cycle breakdown
 enum { PH_BEST = 0, PH_CUTOFF, PH_SEED, PH_EXPAND, PH_EXPAND_BIG, PH_EPS_CLOSURE, PH_COMPACT,
-       PH_FIXUP, PH_EPS_LINKS, PH_CLEAR, PH_FIN_SWEEP, PH_FIN_COMPACT, PH_OTHER };
+       PH_FIXUP, PH_EPS_LINKS, PH_CLEAR, PH_FIN_SWEEP, PH_FIN_COMPACT, PH_FLAT_SETUP, PH_OTHER };
 __device__ inline void Stamp(Sh *sh, int idx) {   // call right after a barrier
   if (threadIdx.x == 0) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -223,10 +225,13 @@ __device__ inline void WaveHistAdd(u32 *hist, int bin, bool active) {
   }
 }
 
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+
 // exact k-th smallest (0-based) of cost[0..n): the value std::nth_element leaves at
 // position k (lattice-faster-decoder.cc:693-697, 707-712).  4-pass 8-bit radix select
 // on order-preserving keys with an LDS histogram.
-__device__ float BlockSelectKth(const float *cost, int n, int k, Sh *sh) {
+template <typename SrcPtr>
+__device__ float BlockSelectKth(SrcPtr cost, int n, int k, Sh *sh) {
   u32 prefix = 0, mask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     __syncthreads();
@@ -271,7 +276,8 @@ __device__ float BlockSelectKth(const float *cost, int n, int k, Sh *sh) {
 // the radix select when the bucket is too crowded.  `src` may point to LDS or global.
 #define LHBINS 4096
 #define LHCAND 1024
-__device__ float BlockSelectLinear(const float *src, int n, int k, float best, float beam,
+template <typename SrcPtr>
+__device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float beam,
                                    u32 *lh /* [LHBINS] LDS */, float *cand /* [LHCAND] LDS */, Sh *sh) {
   const float scale = static_cast<float>(LHBINS) / beam;
   for (int i = threadIdx.x; i < LHBINS; i += NT) lh[i] = 0;
@@ -358,6 +364,80 @@ __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int stat
   *improved = false;
   return -1;
 }
+// the frame's row: LDS copy when it fits (every expanded arc reads it), else global
+struct LlRow { const float *g; lds_cfloat *l; int n_lds; };
+__device__ inline float LogLikePdf(const LlRow &r, int pdf) {
+  if (pdf < r.n_lds) return r.l[pdf];   // ds_read (a generic pointer here would be a FLAT load: vmcnt(0)+lgkmcnt(0))
+  return r.g[pdf];
+}
+
+// HashInsert split in two so that several inserts of one thread overlap their L2 round
+// trips: HashIssue fires the optimistic CAS, HashResolve finishes (rarely probing on).
+__device__ inline u64 HashIssue(const DecDev &d, const Ctx &c, int state, u64 mine, u32 *h) {
+  *h = HashState(state, d.hash_mask);
+  return atomicCAS(&c.H[*h], EMPTY64, mine);
+}
+__device__ inline int HashResolve(const DecDev &d, const Ctx &c, Sh *sh, int state, u64 mine, u32 h, u64 old) {
+  for (int probe = 0; probe < d.hash_cap; probe++) {
+    if (old == EMPTY64) {
+      int idx = WaveAlloc(&sh->n_slots);
+      if (idx < d.hash_cap) c.slots[idx] = h; else sh->err = ERR_HASH;
+      return static_cast<int>(h);
+    }
+    if (StateOf(old) == state) {
+      if (old > mine) atomicMin(&c.H[h], mine);
+      return static_cast<int>(h);
+    }
+    h = (h + 1) & static_cast<u32>(d.hash_mask);
+    old = atomicCAS(&c.H[h], EMPTY64, mine);
+  }
+  sh->err = ERR_HASH;
+  return -1;
+}
+
+// W emitting arcs of one thread (lattice-faster-decoder.cc:791-809), evaluated together:
+// all cutoff tests first, then all table CASes in flight at once, then the links.
+template <int W>
+__device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const LlRow &ll,
+                                   const kamd_arc (&arc)[W], const int (&pdf)[W], const int (&src_tok)[W],
+                                   const float (&cur_cost)[W], const bool (&ok)[W], float cost_offset,
+                                   float adaptive_beam, int link_base) {
+  float ac[W], tot[W];
+  bool pass[W];
+#pragma unroll
+  for (int q = 0; q < W; q++) {
+    ac[q] = cost_offset - LogLikePdf(ll, ok[q] ? pdf[q] : 0);
+    tot[q] = cur_cost[q] + ac[q] + arc[q].weight;
+    const float nc = OrderedToFloat(sh->next_cutoff_u);   // running bound (conservative)
+    pass[q] = ok[q] && !(tot[q] > nc);
+    if (pass[q]) {
+      const float cand = tot[q] + adaptive_beam;
+      if (cand < nc) atomicMin(&sh->next_cutoff_u, FloatToOrdered(cand));
+    }
+  }
+#ifdef KAMD_EXP_NOINSERT   // timing experiment only (results are wrong)
+  { float sink = 0.f; for (int q = 0; q < W; q++) sink += pass[q] ? tot[q] : 0.f; if (sink == 123.456f) sh->err = 1; return; }
+#endif
+  u64 mine[W], old[W];
+  u32 h[W];
+#pragma unroll
+  for (int q = 0; q < W; q++) {
+    mine[q] = 0; old[q] = 0; h[q] = 0;
+    if (pass[q]) { mine[q] = Pack(arc[q].nextstate, tot[q]); old[q] = HashIssue(d, c, arc[q].nextstate, mine[q], &h[q]); }
+  }
+#pragma unroll
+  for (int q = 0; q < W; q++) {
+    if (!pass[q]) continue;
+    const int slot = HashResolve(d, c, sh, arc[q].nextstate, mine[q], h[q], old[q]);
+    if (slot < 0) continue;
+    const int li = link_base + WaveAlloc(&sh->n_links);
+    if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
+    Link L; L.src = src_tok[q]; L.dst = slot; L.ilabel = arc[q].ilabel; L.olabel = arc[q].olabel;
+    L.graph = arc[q].weight; L.ac = ac[q];
+    c.links[li] = L;
+  }
+}
+
 __device__ inline int HashFind(const DecDev &d, const Ctx &c, int state) {
   u32 h = HashState(state, d.hash_mask);
   for (int probe = 0; probe < d.hash_cap; probe++) {
@@ -374,10 +454,6 @@ __device__ inline float LogLike(const DecDev &d, const float *ll, int ilabel) {
   const int pdf = d.tid2pdf ? d.tid2pdf[ilabel] : ilabel - 1;
   return ll[pdf];
 }
-// the frame's row: LDS copy when it fits (every expanded arc reads it), else global
-struct LlRow { const float *g; const float *l; int n_lds; };
-__device__ inline float LogLikePdf(const LlRow &r, int pdf) { return pdf < r.n_lds ? r.l[pdf] : r.g[pdf]; }
-
 // one emitting arc of one expanded token (lattice-faster-decoder.cc:791-809)
 __device__ inline void ProcessArc(const DecDev &d, const Ctx &c, Sh *sh, const LlRow &ll,
                                   const kamd_arc &arc, int pdf, int src_tok, float cur_cost,
@@ -632,9 +708,10 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
   int *big_tok = reinterpret_cast<int *>(dyn_lds);            // [BIGCAP] token (index in list)
   u32 *big_a0 = reinterpret_cast<u32 *>(big_tok + BIGCAP);     // [BIGCAP] first emitting arc
   int *big_scan = reinterpret_cast<int *>(big_a0 + BIGCAP);    // [BIGCAP] degree -> exclusive scan
-  float *ll_lds = reinterpret_cast<float *>(big_scan + BIGCAP);// [num_pdfs_lds]
+  float *ll_lds = reinterpret_cast<float *>(big_scan + BIGCAP + 4);// [num_pdfs_lds]  (+4: sentinel)
   u32 *lh_lds = reinterpret_cast<u32 *>(ll_lds + ((d.num_pdfs_lds + 3) & ~3));   // [LHBINS]
   float *cand_lds = reinterpret_cast<float *>(lh_lds + LHBINS);                  // [LHCAND]
+  int *chunk_owner = reinterpret_cast<int *>(cand_lds + LHCAND);                 // [CHUNKCAP]
   const kamd_decode_task task = tasks[blockIdx.x];
   const Ctx c = MakeCtx(d, task.lane);
   const int tid = threadIdx.x;
@@ -675,17 +752,19 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
         c_lt += w < beam_cutoff; c_le += w <= beam_cutoff;
       }
       BlockSum2(c_lt, c_le, &sh);
-      const float *sel_src = cached ? cost_cache : cost;
+      lds_cfloat *cache_l = (lds_cfloat *)cost_cache;
       // nth_element(max_active) < beam_cutoff  <=>  more than max_active costs < beam_cutoff
       if (n > cfg.max_active && c_lt > cfg.max_active) {
-        const float mac = BlockSelectLinear(sel_src, n, cfg.max_active, best, cfg.beam, lh_lds, cand_lds, &sh);
+        const float mac = cached ? BlockSelectLinear(cache_l, n, cfg.max_active, best, cfg.beam, lh_lds, cand_lds, &sh)
+                                 : BlockSelectLinear(cost, n, cfg.max_active, best, cfg.beam, lh_lds, cand_lds, &sh);
         adaptive_beam = mac - best + cfg.beam_delta;   // :700-702
         cur_cutoff = mac;
       } else {
         float mic = INFINITY;
         if (n > cfg.min_active) {
           if (cfg.min_active == 0) mic = best;
-          else if (c_le <= cfg.min_active) mic = BlockSelectKth(sel_src, n, cfg.min_active, &sh);
+          else if (c_le <= cfg.min_active)
+            mic = cached ? BlockSelectKth(cache_l, n, cfg.min_active, &sh) : BlockSelectKth(cost, n, cfg.min_active, &sh);
           else mic = -INFINITY;  // nth_element(min_active) <= beam_cutoff: not looser than the beam
         }
         if (mic > beam_cutoff) { adaptive_beam = mic - best + cfg.beam_delta; cur_cutoff = mic; }  // :715-718
@@ -703,7 +782,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     }
     // stage the frame's log-likelihood row in LDS: every expanded arc gathers from it
     for (int i = tid; i < d.num_pdfs_lds; i += NT) ll_lds[i] = ll[i];
-    LlRow row; row.g = ll; row.l = ll_lds; row.n_lds = d.num_pdfs_lds;
+    LlRow row; row.g = ll; row.l = (lds_cfloat *)ll_lds; row.n_lds = d.num_pdfs_lds;
     __syncthreads();
     if (n > 0) {
       const u32 a0 = d.g.off[best_state].x, a1 = d.g.off[best_state + 1].x;
@@ -735,9 +814,15 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
           const u32 deg = a1 - a0;
           a_emit += deg;
           if (deg <= SMALL_DEG) {
-            for (u32 a = a0; a < a1; a++)
-              ProcessArc(d, c, &sh, row, d.g.e_arcs[a], d.e_pdf[a], tb + i, cur_cost, cost_offset,
-                         adaptive_beam, link_base);
+            kamd_arc arc[SMALL_DEG]; int pdf[SMALL_DEG], tok[SMALL_DEG]; float cst[SMALL_DEG]; bool ok[SMALL_DEG];
+#pragma unroll
+            for (int q = 0; q < SMALL_DEG; q++) {
+              ok[q] = static_cast<u32>(q) < deg;
+              tok[q] = tb + i; cst[q] = cur_cost; pdf[q] = 0;
+              arc[q].ilabel = arc[q].olabel = arc[q].nextstate = 0; arc[q].weight = 0.f;
+              if (ok[q]) { arc[q] = d.g.e_arcs[a0 + q]; pdf[q] = d.e_pdf[a0 + q]; }
+            }
+            ProcessArcs<SMALL_DEG>(d, c, &sh, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base);
           } else {
             const int p = WaveAlloc(&sh.bigcnt);   // < BIGCAP: flushed below before it can fill
             big_tok[p] = i; big_a0[p] = a0; big_scan[p] = deg;
@@ -770,33 +855,55 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
         if (e0 + 2 < nb) big_scan[e0 + 2] = excl + v0 + v1;
         __syncthreads();
         {
-          // software pipelined: the next arc's loads are in flight while this one is hashed
-          auto lookup = [&](int j, u32 *a, int *i2) {
-            int lo = 0, hi = nb;                  // largest e with big_scan[e] <= j
+          // owner of the first arc of every 16-arc chunk, computed once per batch.  Queued
+          // tokens have >= 5 arcs, so at most 4 of them start inside a chunk: the per-arc
+          // owner lookup is the chunk's owner plus three branch-free compare steps
+          // (big_scan[nb] = total is the sentinel).
+          const int nchunks = (total + 15) >> 4;
+          const int ncached = min(nchunks, CHUNKCAP);
+          if (tid == 0) big_scan[nb] = total;
+          for (int cidx = tid; cidx < ncached; cidx += NT) {
+            const int j = cidx << 4;
+            int lo = 0, hi = nb;
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
-            *i2 = big_tok[lo];
-            *a = big_a0[lo] + static_cast<u32>(j - big_scan[lo]);
-          };
-          int j = tid;
-          bool have = j < total;
-          kamd_arc arc_cur; int pdf_cur = 0, tok_cur = 0; float cost_cur = 0.f;
-          arc_cur.ilabel = arc_cur.olabel = arc_cur.nextstate = 0; arc_cur.weight = 0.f;
-          if (have) {
-            u32 a; lookup(j, &a, &tok_cur);
-            arc_cur = d.g.e_arcs[a]; pdf_cur = d.e_pdf[a]; cost_cur = cost[tok_cur];
+            chunk_owner[cidx] = lo;
           }
-          while (have) {
-            const int jn = j + NT;
-            const bool have_n = jn < total;
-            kamd_arc arc_n = arc_cur; int pdf_n = 0, tok_n = 0; float cost_n = 0.f;
-            if (have_n) {
-              u32 a; lookup(jn, &a, &tok_n);
-              arc_n = d.g.e_arcs[a]; pdf_n = d.e_pdf[a]; cost_n = cost[tok_n];
+          __syncthreads();
+          auto lookup = [&](int j, u32 *a, int *i2) {
+            const int cidx = j >> 4;
+            int e;
+            if (cidx < ncached) {
+              e = chunk_owner[cidx];
+              e += big_scan[e + 1] <= j;
+              e += big_scan[e + 1] <= j;
+              e += big_scan[e + 1] <= j;
+            } else {
+              int lo = 0, hi = nb;
+              while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
+              e = lo;
             }
-            ProcessArc(d, c, &sh, row, arc_cur, pdf_cur, tb + tok_cur, cost_cur, cost_offset,
-                       adaptive_beam, link_base);
-            arc_cur = arc_n; pdf_cur = pdf_n; tok_cur = tok_n; cost_cur = cost_n;
-            j = jn; have = have_n;
+            *i2 = big_tok[e];
+            *a = big_a0[e] + static_cast<u32>(j - big_scan[e]);
+          };
+          Stamp(&sh, PH_FLAT_SETUP);
+          // 4 arcs per thread per trip: all loads are issued before the first is consumed
+          // (memory-level parallelism; ~90 % of arcs fail the cutoff test and stop there)
+          for (int j0 = tid; j0 < total; j0 += ARCW * NT) {
+            kamd_arc arc[ARCW]; int pdf[ARCW], tok[ARCW]; float cst[ARCW]; bool ok[ARCW];
+#pragma unroll
+            for (int q = 0; q < ARCW; q++) {
+              const int j = j0 + q * NT;
+              ok[q] = j < total;
+              tok[q] = 0; pdf[q] = 0; cst[q] = 0.f;
+              arc[q].ilabel = arc[q].olabel = arc[q].nextstate = 0; arc[q].weight = 0.f;
+              if (ok[q]) {
+                u32 a; lookup(j, &a, &tok[q]);
+                arc[q] = d.g.e_arcs[a]; pdf[q] = d.e_pdf[a]; cst[q] = cost[tok[q]];
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < ARCW; q++) tok[q] += tb;
+            ProcessArcs<ARCW>(d, c, &sh, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base);
           }
         }
         __syncthreads();
@@ -1176,7 +1283,7 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   d.num_pdfs_lds = num_pdfs <= 24576 ? num_pdfs : 0;   // LDS row: up to 96 KB of the CU's 160 KB
   if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::AdvanceKernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                3 * BIGCAP * 4 + ((d.num_pdfs_lds + 3) & ~3) * 4 + (LHBINS + LHCAND) * 4) != hipSuccess)
+                                (3 * BIGCAP + 4) * 4 + ((d.num_pdfs_lds + 3) & ~3) * 4 + (LHBINS + LHCAND + CHUNKCAP) * 4) != hipSuccess)
     ok = false;
   if (ok && (hipEventCreate(&D->ev0) != hipSuccess || hipEventCreate(&D->ev1) != hipSuccess)) ok = false;
   if (!ok) {
@@ -1278,7 +1385,7 @@ int kamd_decoder_advance(kamd_decoder *h, const kamd_decode_task *tasks, int n, 
   KAMD_HIP(hipMemcpyAsync(D->d_tasks, sorted.data(), n * sizeof(kamd_decode_task), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
   KAMD_HIP(hipEventRecord(D->ev0, st));
-  const size_t lds = 3 * BIGCAP * 4 + static_cast<size_t>((D->dev.num_pdfs_lds + 3) & ~3) * 4 + (LHBINS + LHCAND) * 4;
+  const size_t lds = (3 * BIGCAP + 4) * 4 + static_cast<size_t>((D->dev.num_pdfs_lds + 3) & ~3) * 4 + (LHBINS + LHCAND + CHUNKCAP) * 4;
   hipLaunchKernelGGL(kamd::AdvanceKernel, dim3(n), dim3(NT), lds, st, D->dev, D->d_tasks);
   KAMD_HIP(hipGetLastError());
   KAMD_HIP(hipEventRecord(D->ev1, st));
