@@ -116,6 +116,11 @@ struct Sh {  // workgroup-shared state
   u64 red64[NWAVES];
   int redi[NWAVES];
   int redj[NWAVES];
+  int redk[NWAVES];
+  int redl[NWAVES];
+  u64 best_key;          // min {ordered cost, state} of the newest token list
+  int c_lt, c_le;        // #costs < / <= best+beam of the newest token list
+  int n_new;
   float redf[NWAVES];
   u32 hist[256];
   u32 next_cutoff_u;
@@ -188,6 +193,19 @@ __device__ inline void BlockSum2(int &a, int &b, Sh *sh) {
   __syncthreads();
   a = 0; b = 0;
   for (int i = 0; i < NWAVES; i++) { a += sh->redi[i]; b += sh->redj[i]; }
+}
+__device__ inline void BlockSum4(int &a, int &b, int &c2, int &d2, Sh *sh) {
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c2 += __shfl_xor(c2, o, 64); d2 += __shfl_xor(d2, o, 64);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    sh->redi[w] = a; sh->redj[w] = b; sh->redk[w] = c2; sh->redl[w] = d2;
+  }
+  __syncthreads();
+  a = 0; b = 0; c2 = 0; d2 = 0;
+  for (int i = 0; i < NWAVES; i++) { a += sh->redi[i]; b += sh->redj[i]; c2 += sh->redk[i]; d2 += sh->redl[i]; }
 }
 __device__ inline float BlockMinF(float v, Sh *sh) {
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
@@ -479,7 +497,7 @@ __device__ inline void ProcessArc(const DecDev &d, const Ctx &c, Sh *sh, const L
 // commit the frame: compact surviving tokens into the arena, resolve emitting links,
 // emit epsilon links, clear the table.  'list' is the token-list index being created.
 __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff, int list,
-                            int emit_link_begin) {
+                            int emit_link_begin, float *cost_cache, int cache_cap) {
   const int tid = threadIdx.x;
   LaneState *S = c.st;
   __syncthreads();
@@ -537,37 +555,32 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
     if (err_now) break;
   }
   Stamp(sh, PH_EPS_CLOSURE);
-  // ---- compaction: tokens with final cost <= cutoff become list 'list'
+  // ---- compaction: tokens with final cost <= cutoff become list 'list' (arena order is
+  // the allocation order; lattices are canonicalised by (frame, state) on the host).
+  // The same sweep finds the list's best token for the NEXT frame's GetCutoff.
   const int tok_base = c.tok_off[list];
   const int ns = min(sh->n_slots, d.hash_cap);
-  int running = 0;
-  for (int base = 0; base < ns; base += NT) {
-    const int i = base + tid;
-    u32 slot = 0; u64 e = 0; bool keep = false;
-    if (i < ns) {
-      slot = c.slots[i];
-      e = LoadH(&c.H[slot]);
-      if (e == EMPTY64) sh->err = ERR_INTERNAL;   // a listed slot must hold a token
-      keep = e != EMPTY64 && CostOf(e) <= cutoff;
+  u64 kmin = EMPTY64;
+  for (int i = tid; i < ns; i += NT) {
+    const u32 slot = c.slots[i];
+    const u64 e = LoadH(&c.H[slot]);
+    if (e == EMPTY64) sh->err = ERR_INTERNAL;   // a listed slot must hold a token
+    int idx = -1;
+    if (e != EMPTY64 && CostOf(e) <= cutoff) {
+      idx = tok_base + WaveAlloc(&sh->n_new);
+      if (idx < c.tok_cap) {
+        c.tok_state[idx] = StateOf(e);
+        c.tok_cost[idx] = CostOf(e);
+        c.tok_extra[idx] = 0.0f;
+        const u64 k = (static_cast<u64>(static_cast<u32>(e)) << 32) | static_cast<u32>(StateOf(e));
+        kmin = k < kmin ? k : kmin;
+      } else { sh->err = ERR_TOK; idx = -1; }
     }
-    int total;
-    const int pos = BlockScanFlag(keep, &total, sh);
-    if (i < ns) {
-      int idx = -1;
-      if (keep) {
-        idx = tok_base + running + pos;
-        if (idx < c.tok_cap) {
-          c.tok_state[idx] = StateOf(e);
-          c.tok_cost[idx] = CostOf(e);
-          c.tok_extra[idx] = 0.0f;
-        } else { sh->err = ERR_TOK; idx = -1; }
-      }
-      c.slot_tok[slot] = idx;
-    }
-    running += total;
+    c.slot_tok[slot] = idx;
   }
-  const int n_new = running;
-  __syncthreads();
+  kmin = BlockMin64(kmin, sh);
+  const int n_new = min(sh->n_new, c.tok_cap - tok_base);
+  const float next_beam_cutoff = (n_new > 0 ? OrderedToFloat(static_cast<u32>(kmin >> 32)) : INFINITY) + d.cfg.beam;
   Stamp(sh, PH_COMPACT);
   // ---- emitting links: keep iff the arc's own tot <= final cutoff; slot -> token
   int k_surv = 0;
@@ -581,16 +594,15 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
       k_surv += valid;
     }
   }
-  __syncthreads();
-  if (tid == 0) { sh->n_links = 0; }
-  Stamp(sh, PH_FIXUP);
-  __syncthreads();
-  // ---- epsilon links of the surviving tokens (final costs), :875-897
+  // ---- epsilon links of the surviving tokens (final costs), :875-897; the same sweep
+  // counts the costs against the next frame's beam cutoff and caches them in LDS
   const int eps_link_begin = c.lnk_off[2 * list + 1];
-  int a_eps = 0;
-  for (int t = tok_base + tid; t < min(tok_base + n_new, c.tok_cap); t += NT) {
+  int a_eps = 0, c_lt = 0, c_le = 0;
+  for (int t = tok_base + tid; t < tok_base + n_new; t += NT) {
     const int s = c.tok_state[t];
     const float cur_cost = c.tok_cost[t];
+    c_lt += cur_cost < next_beam_cutoff; c_le += cur_cost <= next_beam_cutoff;
+    if (t - tok_base < cache_cap) cost_cache[t - tok_base] = cur_cost;
     const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
     a_eps += static_cast<int>(a1 - a0);
     for (u32 a = a0; a < a1; a++) {
@@ -600,7 +612,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
         const int slot2 = HashFind(d, c, arc.nextstate);
         const int dst = slot2 >= 0 ? c.slot_tok[slot2] : -1;
         if (dst < 0) { sh->err = ERR_INTERNAL; continue; }
-        const int li = eps_link_begin + WaveAlloc(&sh->n_links);
+        const int li = eps_link_begin + WaveAlloc(&sh->wl_n[0]);   // worklists are idle here
         if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
         Link L; L.src = t; L.dst = dst; L.ilabel = 0; L.olabel = arc.olabel;
         L.graph = arc.weight; L.ac = 0.0f;
@@ -614,9 +626,9 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
   for (int i = tid; i < ns; i += NT)
     __hip_atomic_store(&c.H[c.slots[i]], EMPTY64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   DrainStores();   // the next frame's CAS / atomicMin must find the cleared words in L2
-  BlockSum2(k_surv, a_eps, sh);
+  BlockSum4(k_surv, a_eps, c_lt, c_le, sh);
   if (tid == 0) {
-    const int n_eps_links = sh->n_links;
+    const int n_eps_links = min(sh->wl_n[0], c.lnk_cap - eps_link_begin);
     c.tok_off[list + 1] = tok_base + n_new;
     c.lnk_off[2 * list + 2] = eps_link_begin + n_eps_links;
     S->tok_used = tok_base + n_new;
@@ -626,10 +638,34 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
     sh->cnt[3] += k_surv;                // K_surv
     sh->cnt[4] += k_surv + n_eps_links;  // L_kept
     sh->cnt[5] += n_new;                 // N_tok
-    sh->n_slots = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0;
+    sh->best_key = kmin; sh->c_lt = c_lt; sh->c_le = c_le;
+    sh->n_slots = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->n_new = 0;
   }
   __syncthreads();
   Stamp(sh, PH_CLEAR);
+}
+
+// best token and beam counts of token list 'list' (what CommitFrame leaves behind), for
+// the first frame of a launch
+__device__ void ComputeFrameStats(const DecDev &d, const Ctx &c, Sh *sh, int list, float *cost_cache,
+                                  int cache_cap) {
+  const int tb = c.tok_off[list], n = c.tok_off[list + 1] - tb;
+  u64 key = EMPTY64;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const u64 k = (static_cast<u64>(FloatToOrdered(c.tok_cost[tb + i])) << 32) | static_cast<u32>(c.tok_state[tb + i]);
+    key = k < key ? k : key;
+  }
+  key = BlockMin64(key, sh);
+  const float bc = (n > 0 ? OrderedToFloat(static_cast<u32>(key >> 32)) : INFINITY) + d.cfg.beam;
+  int c_lt = 0, c_le = 0;
+  for (int i = threadIdx.x; i < n; i += NT) {
+    const float w = c.tok_cost[tb + i];
+    if (i < cache_cap) cost_cache[i] = w;
+    c_lt += w < bc; c_le += w <= bc;
+  }
+  BlockSum2(c_lt, c_le, sh);
+  if (threadIdx.x == 0) { sh->best_key = key; sh->c_lt = c_lt; sh->c_le = c_le; }
+  __syncthreads();
 }
 
 // ComputeFinalCosts (lattice-faster-decoder.cc:549-590) over token list 'list'
@@ -663,7 +699,7 @@ __device__ void PublishLaneEnd(const DecDev &d, const Ctx &c, Sh *sh, int frame)
 __device__ inline void InitSh(Sh *sh) {
   if (threadIdx.x == 0) {
     sh->n_slots = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
-    sh->bigcnt = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
+    sh->bigcnt = 0; sh->n_new = 0; sh->best_key = EMPTY64; sh->c_lt = 0; sh->c_le = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
     for (int i = 0; i < 8; i++) sh->cnt[i] = 0;
     for (int i = 0; i < 16; i++) sh->ph[i] = 0;
     sh->t_prev = __builtin_amdgcn_s_memtime();
@@ -697,7 +733,7 @@ __global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
     HashInsert(d, c, &sh, d.g.start, 0.0f, &imp);
   }
   __syncthreads();
-  CommitFrame(d, c, &sh, d.cfg.beam, 0, 0);
+  CommitFrame(d, c, &sh, d.cfg.beam, 0, 0, NULL, 0);
   PublishLaneEnd(d, c, &sh, 0);
 }
 
@@ -720,20 +756,21 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
   int frame = S->frame;
   if (S->error || S->finalized) return;
   const kamd_decoder_config cfg = d.cfg;
+  ComputeFrameStats(d, c, &sh, frame, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
   for (int it = 0; it < task.n_frames; it++, frame++) {
     if (frame >= d.max_frames) { if (tid == 0) sh.err = ERR_FRAMES; __syncthreads(); break; }
     const float *ll = task.d_loglikes + static_cast<size_t>(it) * task.ld;
     const int tb = c.tok_off[frame], n = c.tok_off[frame + 1] - tb;
     const float *cost = c.tok_cost + tb;
     const int *state = c.tok_state + tb;
-    // ---- GetCutoff (:657-724): best token (ties -> smallest state, as oracle mode 1)
-    u64 key = EMPTY64;
-    for (int i = tid; i < n; i += NT) {
-      u64 k = (static_cast<u64>(FloatToOrdered(cost[i])) << 32) | static_cast<u32>(state[i]);
-      key = k < key ? k : key;
-    }
-    key = BlockMin64(key, &sh);
-    Stamp(&sh, PH_BEST);
+    // ---- GetCutoff (:657-724).  The best token (ties -> smallest state, as oracle mode 1)
+    // and the two beam counts were left behind by the sweep that created this token list
+    // (CommitFrame / ComputeFrameStats), together with an LDS copy of the costs.
+    const u64 key = sh.best_key;
+    const int c_lt = sh.c_lt, c_le = sh.c_le;
+    float *cost_cache = reinterpret_cast<float *>(dyn_lds);
+    const bool cached = n <= 3 * BIGCAP;
+    __syncthreads();   // everyone has read the stats before a select may reuse Sh scratch
     float best = INFINITY; int best_state = -1;
     if (n > 0) { best = OrderedToFloat(static_cast<u32>(key >> 32)); best_state = static_cast<int>(key & 0xFFFFFFFFu); }
     float cur_cutoff, adaptive_beam;
@@ -741,17 +778,6 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     if (cfg.max_active == 2147483647 && cfg.min_active == 0) {
       cur_cutoff = beam_cutoff; adaptive_beam = cfg.beam;
     } else {
-      int c_lt = 0, c_le = 0;
-      // the flatten queue's LDS is idle during GetCutoff: cache the costs there so the
-      // radix-select passes read LDS instead of L2
-      float *cost_cache = reinterpret_cast<float *>(dyn_lds);
-      const bool cached = n <= 3 * BIGCAP;
-      for (int i = tid; i < n; i += NT) {
-        float w = cost[i];
-        if (cached) cost_cache[i] = w;
-        c_lt += w < beam_cutoff; c_le += w <= beam_cutoff;
-      }
-      BlockSum2(c_lt, c_le, &sh);
       lds_cfloat *cache_l = (lds_cfloat *)cost_cache;
       // nth_element(max_active) < beam_cutoff  <=>  more than max_active costs < beam_cutoff
       if (n > cfg.max_active && c_lt > cfg.max_active) {
@@ -829,10 +855,12 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
           }
         }
       }
+      const bool last_chunk = base + NT >= n;
+      if (n <= BIGCAP && !last_chunk) continue;    // the queue cannot overflow: flush once (uniform)
       __syncthreads();
       const int nb = sh.bigcnt;                    // uniform: read between two barriers
       __syncthreads();
-      if (nb > 0 && (nb > BIGCAP - NT || base + NT >= n)) {
+      if (nb > 0 && (nb > BIGCAP - NT || last_chunk)) {
         Stamp(&sh, PH_EXPAND);
         // exclusive scan of the queued degrees (3 entries per thread)
         int v0 = 0, v1 = 0, v2 = 0;
@@ -925,7 +953,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     __syncthreads();
     const float next_cutoff = OrderedToFloat(sh.next_cutoff_u);
     // ---- ProcessNonemitting(next_cutoff) + commit of token list frame+1
-    CommitFrame(d, c, &sh, next_cutoff, frame + 1, link_base);
+    CommitFrame(d, c, &sh, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
     const int err_now = sh.err;    // CommitFrame ends with a barrier; nobody writes err before the next one
     __syncthreads();
     if (err_now) { frame++; break; }
