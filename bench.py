@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check lane 0 against the oracle")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo to "
+                    "exercise the N>1 code path with several ranks sharing one GPU")
+    ap.add_argument("--device", type=int, default=-1, help="override the HIP device (default LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -153,13 +156,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")      # RCCL; only barriers + the final max-reduce use it
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(args.dist_backend)   # nccl = RCCL; only barriers + two scalar reductions use it
 
     from kaldi_amd import abi, pipeline
     from kaldi_amd._lib import check, lib, require_gpu
     require_gpu()
-    check(lib().kamd_set_device(local_rank))
+    check(lib().kamd_set_device(args.device if args.device >= 0 else local_rank))
     def log(msg):
         if args.verbose and rank == 0:
             print("[bench %.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
@@ -195,10 +199,11 @@ def main():
     log("timed steps done: %.3f s" % dt)
     if dist is not None:
         import torch
-        t = torch.tensor([dt], device="cuda")
+        tdev = "cuda" if args.dist_backend == "nccl" else "cpu"
+        t = torch.tensor([dt], device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        a = torch.tensor([audio], device="cuda")
+        a = torch.tensor([audio], device=tdev)
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         total_audio = float(a.item())
     else:

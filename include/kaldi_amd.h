@@ -123,6 +123,27 @@ int kamd_feat_compute_batch_device(kamd_feat *f, const float *d_waves,
                                    float *d_out, const int64_t *h_row_off,
                                    int ld_out, void *stream);
 
+/* NumFrames with an explicit flush flag, and frames [first_frame, +num_frames) of one
+ * device-resident waveform (streaming building blocks). */
+int kamd_feat_num_frames_flush(const kamd_feat *f, int64_t num_samples, int flush);
+int kamd_feat_compute_frames_device(kamd_feat *f, const float *d_wave, int64_t num_samples,
+                                    int first_frame, int num_frames, float *d_out, int ld_out,
+                                    void *stream);
+
+/* OnlineGenericBaseFeature<C> (feat/online-feature.h:78, online-feature.cc:63-200;
+ * itf/online-feature-itf.h OnlineFeatureInterface): streaming MFCC / fbank.  The
+ * computer is borrowed, not owned. */
+typedef struct kamd_online_feat kamd_online_feat;
+kamd_online_feat *kamd_online_feat_create(kamd_feat *computer);
+void kamd_online_feat_destroy(kamd_online_feat *o);
+int kamd_online_feat_accept_waveform(kamd_online_feat *o, float sampling_rate, const float *wave, int64_t n);
+int kamd_online_feat_input_finished(kamd_online_feat *o);
+int kamd_online_feat_num_frames_ready(const kamd_online_feat *o);
+int kamd_online_feat_is_last_frame(const kamd_online_feat *o, int frame);
+int kamd_online_feat_get_frames(kamd_online_feat *o, int first, int n, float *out /* [n x dim] host */);
+/* device view of all frames computed so far ([frames x *ld], zero padded to *ld) */
+const float *kamd_online_feat_device_frames(const kamd_online_feat *o, int *ld);
+
 /* ------------------------------------------------------------------ nnet -- */
 #define KAMD_MAX_OFFSETS 8
 /* One fused layer = TdnnComponent/AffineComponent/LinearComponent/FixedAffine
@@ -169,6 +190,7 @@ int kamd_nnet_right_context(const kamd_nnet *n);
 /* DecodableNnetSimple semantics (nnet-am-decodable-simple.cc:40-47): number of
  * output rows for T input frames = ceil(T / subsampling). */
 int kamd_nnet_num_output_frames(const kamd_nnet *n, int num_input_frames);
+int kamd_nnet_frame_subsampling_factor(const kamd_nnet *n);
 /* Whole-batch forward, device resident.  Inputs: d_feats rows of utterance u at
  * [h_in_row_off[u], h_in_row_off[u+1]) with leading dimension ld_in; optional
  * per-utterance ivectors d_ivectors [n_utts x ivector_dim] (NULL if none).
@@ -183,6 +205,14 @@ int kamd_nnet_forward_batch_device(kamd_nnet *n, const float *d_feats,
 /* Host convenience (one utterance): feats [T x input_dim] -> out [T' x out_dim]. */
 int kamd_nnet_forward(kamd_nnet *n, const float *feats, int T,
                       const float *ivector, float *out, int out_rows_cap);
+/* Streaming (DecodableAmNnetLoopedOnline, nnet3/decodable-online-looped.cc:56-240):
+ * number of OUTPUT frames computable from feat_frames_ready input frames, and the rows
+ * [out_first, out_first+out_count) of the log-likelihood matrix, device to device.  Values
+ * equal the offline forward of the complete utterance (the right context is never guessed:
+ * a frame is ready only once its context exists, or when the input is finished). */
+int kamd_nnet_num_frames_ready(const kamd_nnet *n, int feat_frames_ready, int input_finished);
+int kamd_nnet_forward_range(kamd_nnet *n, const float *d_feats, int ld_in, int feat_frames_ready,
+                            int input_finished, int out_first, int out_count, float *d_out, int ld_out);
 /* total multiply-accumulates of the last forward (for the MFMA roofline). */
 double kamd_nnet_last_flops(const kamd_nnet *n);
 
@@ -314,6 +344,12 @@ int kamd_decoder_best_path(kamd_decoder *d, int lane, int32_t *alignment,
                            int ali_cap, int *ali_len, int32_t *words,
                            int words_cap, int *words_len, float *graph_cost,
                            float *acoustic_cost);
+/* Best path of an UN-finalized lane (streaming partial results):
+ * LatticeFasterOnlineDecoderTpl::GetBestPath = BestPathEnd + TraceBackBestPath
+ * (decoder/lattice-faster-online-decoder.cc:54-165).  Requires a prior kamd_decoder_sync. */
+int kamd_decoder_partial_best_path(kamd_decoder *d, int lane, int use_final_probs, int32_t *alignment,
+                                   int ali_cap, int *ali_len, int32_t *words, int words_cap,
+                                   int *words_len, float *graph_cost, float *acoustic_cost);
 /* per-frame trace for parity debugging: ntok[f], cutoff[f], cost_offset[f]. */
 int kamd_decoder_get_trace(kamd_decoder *d, int lane, int32_t *ntok,
                            float *cutoff, float *cost_offset, int cap);

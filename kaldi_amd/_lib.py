@@ -51,12 +51,25 @@ def lib():
     sig("kamd_feat_num_frames", C.c_int, [vp, C.c_int64])
     sig("kamd_feat_compute", C.c_int, [vp, fp, C.c_int64, fp, C.c_int])
     sig("kamd_feat_compute_batch_device", C.c_int, [vp, vp, i64p, C.c_int, vp, i64p, C.c_int, vp])
+    sig("kamd_feat_num_frames_flush", C.c_int, [vp, C.c_int64, C.c_int])
+    sig("kamd_feat_compute_frames_device", C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp, C.c_int, vp])
+    sig("kamd_online_feat_create", vp, [vp])
+    sig("kamd_online_feat_destroy", None, [vp])
+    sig("kamd_online_feat_accept_waveform", C.c_int, [vp, C.c_float, fp, C.c_int64])
+    sig("kamd_online_feat_input_finished", C.c_int, [vp])
+    sig("kamd_online_feat_num_frames_ready", C.c_int, [vp])
+    sig("kamd_online_feat_is_last_frame", C.c_int, [vp, C.c_int])
+    sig("kamd_online_feat_get_frames", C.c_int, [vp, C.c_int, C.c_int, fp])
+    sig("kamd_online_feat_device_frames", vp, [vp, ip])
+    sig("kamd_nnet_num_frames_ready", C.c_int, [vp, C.c_int, C.c_int])
+    sig("kamd_nnet_forward_range", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int])
     sig("kamd_nnet_create", vp, [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int])
     sig("kamd_nnet_destroy", None, [vp])
     sig("kamd_nnet_output_dim", C.c_int, [vp])
     sig("kamd_nnet_left_context", C.c_int, [vp])
     sig("kamd_nnet_right_context", C.c_int, [vp])
     sig("kamd_nnet_num_output_frames", C.c_int, [vp, C.c_int])
+    sig("kamd_nnet_frame_subsampling_factor", C.c_int, [vp])
     sig("kamd_nnet_forward_batch_device", C.c_int, [vp, vp, i64p, C.c_int, vp, C.c_int, vp, i64p, C.c_int, vp])
     sig("kamd_nnet_forward", C.c_int, [vp, fp, C.c_int, fp, fp, C.c_int])
     sig("kamd_nnet_last_flops", C.c_double, [vp])
@@ -80,6 +93,7 @@ def lib():
     sig("kamd_decoder_lattice_size", C.c_int, [vp, C.c_int, C.POINTER(abi.LatticeSize)])
     sig("kamd_decoder_get_raw_lattice", C.c_int, [vp, C.c_int, ip, ip, fp, fp, vp])
     sig("kamd_decoder_best_path", C.c_int, [vp, C.c_int, ip, C.c_int, ip, ip, C.c_int, ip, fp, fp])
+    sig("kamd_decoder_partial_best_path", C.c_int, [vp, C.c_int, C.c_int, ip, C.c_int, ip, ip, C.c_int, ip, fp, fp])
     sig("kamd_decoder_get_trace", C.c_int, [vp, C.c_int, ip, fp, fp, C.c_int])
     sig("kamd_decoder_get_counters", C.c_int, [vp, C.c_int, i64p])
     sig("kamd_decoder_get_phase_cycles", C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64)])
@@ -96,15 +110,15 @@ def lib():
 
 EXPORTS = """kamd_malloc kamd_free kamd_memcpy_h2d kamd_memcpy_d2h kamd_device_synchronize kamd_last_error kamd_version kamd_device_count kamd_set_device kamd_mfcc_opts_default
 kamd_fbank_opts_default kamd_mfcc_create kamd_fbank_create kamd_feat_destroy kamd_feat_dim
-kamd_feat_num_frames kamd_feat_compute kamd_feat_compute_batch_device kamd_nnet_create
+kamd_feat_num_frames kamd_feat_compute kamd_feat_compute_batch_device kamd_feat_num_frames_flush kamd_feat_compute_frames_device kamd_online_feat_create kamd_online_feat_destroy kamd_online_feat_accept_waveform kamd_online_feat_input_finished kamd_online_feat_num_frames_ready kamd_online_feat_is_last_frame kamd_online_feat_get_frames kamd_online_feat_device_frames kamd_nnet_num_frames_ready kamd_nnet_forward_range kamd_nnet_create
 kamd_nnet_destroy kamd_nnet_output_dim kamd_nnet_left_context kamd_nnet_right_context
-kamd_nnet_num_output_frames kamd_nnet_forward_batch_device kamd_nnet_forward kamd_nnet_last_flops
+kamd_nnet_num_output_frames kamd_nnet_frame_subsampling_factor kamd_nnet_forward_batch_device kamd_nnet_forward kamd_nnet_last_flops
 kamd_graph_create kamd_graph_destroy kamd_graph_num_states kamd_graph_num_arcs
 kamd_decoder_config_default kamd_decoder_sizes_default kamd_decoder_create kamd_decoder_destroy
 kamd_decoder_set_options kamd_decoder_reserve kamd_decoder_init kamd_decoder_advance kamd_decoder_finalize
 kamd_decoder_sync kamd_decoder_num_frames_decoded kamd_decoder_final_relative_cost
 kamd_decoder_reached_final kamd_decoder_lattice_size kamd_decoder_get_raw_lattice
-kamd_decoder_best_path kamd_decoder_get_trace kamd_decoder_get_counters
+kamd_decoder_best_path kamd_decoder_partial_best_path kamd_decoder_get_trace kamd_decoder_get_counters
 kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch
 kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features""".split()
 

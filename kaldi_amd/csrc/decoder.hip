@@ -1112,6 +1112,71 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
   }
 }
 
+// Best path WITHOUT finalizing (LatticeFasterOnlineDecoderTpl::BestPathEnd +
+// TraceBackBestPath, decoder/lattice-faster-online-decoder.cc:78-165): pick the best
+// token of the newest frame (with final-probs if any token is final and use_final_probs),
+// then walk back.  No backpointers are stored: the link that produced a token's cost is
+// recognised by exact equality  tok_cost[src] + ac + graph == tok_cost[dst]  (the very
+// expression that computed it); ties -> smallest link index.
+// Output: path arcs in REVERSE order in out_arcs (ilabel, olabel, graph, acoustic-offset).
+struct PathArc { int ilabel, olabel; float graph, ac; };
+__global__ __launch_bounds__(NT) void TracebackKernel(DecDev d, int lane, int use_final_probs,
+                                                      PathArc *out_arcs, int out_cap, int *out_n,
+                                                      float *out_final_cost) {
+  __shared__ Sh sh;
+  const Ctx c = MakeCtx(d, lane);
+  const int tid = threadIdx.x;
+  InitSh(&sh);
+  LaneState *S = c.st;
+  const int F = S->frame;
+  // best end token
+  float best_cost, best_with_final;
+  FinalCosts(d, c, &sh, F, &best_cost, &best_with_final);
+  const bool use_final = use_final_probs && best_with_final != INFINITY;
+  u64 key = EMPTY64;
+  for (int t = c.tok_off[F] + tid; t < c.tok_off[F + 1]; t += NT) {
+    const float fc = use_final ? d.g.final[c.tok_state[t]] : 0.0f;
+    const float v = c.tok_cost[t] + fc;
+    if (v != INFINITY) {
+      const u64 k = (static_cast<u64>(FloatToOrdered(v)) << 32) | static_cast<u32>(t);
+      key = k < key ? k : key;
+    }
+  }
+  key = BlockMin64(key, &sh);
+  if (key == EMPTY64) { if (tid == 0) { *out_n = -1; } return; }
+  int cur = static_cast<int>(key & 0xFFFFFFFFu);
+  if (tid == 0) *out_final_cost = use_final ? d.g.final[c.tok_state[cur]] : 0.0f;
+  int n_out = 0, f = F;
+  const int start_tok = 0;   // token 0 of list 0 is not necessarily the start: stop when no link found
+  (void)start_tok;
+  for (int guard = 0; guard < 4 * (F + 2) + 1024; guard++) {
+    // search the links that can end in 'cur': epsilon links of step f, emitting links of step f
+    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
+    const int mb = c.lnk_off[2 * f], me = c.lnk_off[2 * f + 1];
+    const float ccost = c.tok_cost[cur];
+    u32 found = 0xFFFFFFFFu;
+    for (int li = mb + tid; li < ee; li += NT) {   // [mb,me) emitting, [eb,ee) epsilon are adjacent
+      const Link L = c.links[li];
+      if (L.dst == cur && L.src >= 0 && c.tok_cost[L.src] + L.ac + L.graph == ccost) found = min(found, static_cast<u32>(li));
+    }
+    (void)eb; (void)me;
+    u64 fk = BlockMin64(static_cast<u64>(found), &sh);
+    if (fk >= 0xFFFFFFFFull) break;              // the start token: nothing produced it
+    const Link L = c.links[static_cast<int>(fk)];
+    const bool emitting = static_cast<int>(fk) < me;
+    if (tid == 0 && n_out < out_cap) {
+      PathArc a; a.ilabel = L.ilabel; a.olabel = L.olabel; a.graph = L.graph;
+      a.ac = emitting ? L.ac - c.cost_offsets[f - 1] : L.ac;
+      out_arcs[n_out] = a;
+    }
+    n_out++;
+    cur = L.src;
+    if (emitting) f--;
+    if (f < 0) break;
+  }
+  if (tid == 0) *out_n = n_out;
+}
+
 // ------------------------------------------------------------------ host
 struct Graph {
   GraphDev dev;
@@ -1481,6 +1546,37 @@ int kamd_decoder_get_counters(kamd_decoder *h, int lane, int64_t counters[8]) {
   for (int i = 0; i < 8; i++) counters[i] = D->h_st[lane].counters[i];
   return KAMD_OK;
 }
+int kamd_decoder_partial_best_path(kamd_decoder *h, int lane, int use_final_probs, int32_t *alignment,
+                                   int ali_cap, int *ali_len, int32_t *words, int words_cap, int *words_len,
+                                   float *graph_cost, float *acoustic_cost) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
+  if (D->h_st[lane].finalized) return kamd::SetError(KAMD_ERR_STATE, "lane %d is finalized: use kamd_decoder_best_path", lane);
+  const int cap = 4 * (D->h_st[lane].frame + 2) + 1024;
+  kamd::PathArc *d_arcs = NULL; int *d_n = NULL; float *d_fc = NULL;
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_arcs), cap * sizeof(kamd::PathArc)));
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_n), sizeof(int)));
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_fc), sizeof(float)));
+  hipLaunchKernelGGL(kamd::TracebackKernel, dim3(1), dim3(NT), 0, D->last_stream, D->dev, lane, use_final_probs, d_arcs, cap, d_n, d_fc);
+  int n = 0; float fc = 0;
+  hipError_t e1 = hipMemcpy(&n, d_n, sizeof(int), hipMemcpyDeviceToHost);
+  hipError_t e2 = hipMemcpy(&fc, d_fc, sizeof(float), hipMemcpyDeviceToHost);
+  std::vector<kamd::PathArc> arcs(n > 0 ? std::min(n, cap) : 0);
+  hipError_t e3 = arcs.empty() ? hipSuccess : hipMemcpy(arcs.data(), d_arcs, arcs.size() * sizeof(kamd::PathArc), hipMemcpyDeviceToHost);
+  (void)hipFree(d_arcs); (void)hipFree(d_n); (void)hipFree(d_fc);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return kamd::SetError(KAMD_ERR_HIP, "traceback copy failed");
+  *ali_len = 0; *words_len = 0; *graph_cost = INFINITY; *acoustic_cost = INFINITY;
+  if (n < 0) return kamd::SetError(KAMD_ERR_STATE, "no tokens alive on the newest frame");
+  float g = 0.f, a = 0.f;   // Times() along the path, start -> end (fstext/lattice-weight.h)
+  for (int i = static_cast<int>(arcs.size()) - 1; i >= 0; i--) {
+    if (arcs[i].ilabel != 0) { if (*ali_len < ali_cap) alignment[*ali_len] = arcs[i].ilabel; (*ali_len)++; }
+    if (arcs[i].olabel != 0) { if (*words_len < words_cap) words[*words_len] = arcs[i].olabel; (*words_len)++; }
+    g += arcs[i].graph; a += arcs[i].ac;
+  }
+  *graph_cost = g + fc; *acoustic_cost = a;
+  return KAMD_OK;
+}
+
 int kamd_decoder_get_phase_cycles(kamd_decoder *h, int lane, uint64_t cycles[16]) {
   Decoder *D = reinterpret_cast<Decoder *>(h);
   if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void FeatKernel(
     FeatDev fd, const float *__restrict__ waves, const int64_t *__restrict__ wave_off,
     const int64_t *__restrict__ frame_off /* [n_utts+1] cumulative frames */,
     const int64_t *__restrict__ row_off /* [n_utts] output row of frame 0 */, int n_utts,
-    float *__restrict__ out, int ld_out) {
+    float *__restrict__ out, int ld_out, int frame0 /* index of the first frame (streaming) */) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int N = fd.N;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void FeatKernel(
   const float *wav = waves;
   if (live) {
     u = FindUtt(frame_off, n_utts, g);
-    f = static_cast<int>(g - frame_off[u]);
+    f = static_cast<int>(g - frame_off[u]) + frame0;
     wav = waves + wave_off[u];
     nsamp = wave_off[u + 1] - wave_off[u];
   }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void FeatKernel(
   }
   __syncthreads();
   if (!live) return;
-  float *orow = out + (row_off[u] + f) * static_cast<int64_t>(ld_out);
+  float *orow = out + (row_off[u] + (f - frame0)) * static_cast<int64_t>(ld_out);
   if (fd.is_mfcc) {
     // feature-mfcc.cc:56-79: DCT, lifter, energy / C0, htk_compat reorder
     const int C = fd.num_ceps;
@@ -465,7 +465,43 @@ int kamd_feat_compute_batch_device(kamd_feat *h, const float *d_waves, const int
   int blocks = kamd::CeilDiv(tot, 4);
   size_t lds = 4 * (2 * f->dev.N + 128) * sizeof(float);
   hipLaunchKernelGGL(kamd::FeatKernel, dim3(blocks), dim3(256), lds, st, f->dev, d_waves, d_meta,
-                     d_meta + (n_utts + 1), d_meta + 2 * (n_utts + 1), n_utts, d_out, ld_out);
+                     d_meta + (n_utts + 1), d_meta + 2 * (n_utts + 1), n_utts, d_out, ld_out, 0);
+  KAMD_HIP(hipGetLastError());
+  return KAMD_OK;
+}
+
+int kamd_feat_num_frames_flush(const kamd_feat *h, int64_t num_samples, int flush) {
+  // NumFrames(num_samples, opts, flush) (feat/feature-window.cc:41-87)
+  const kamd::FeatDev &d = reinterpret_cast<const Feat *>(h)->dev;
+  const int64_t shift = d.frame_shift, len = d.frame_len;
+  if (d.snip_edges) return num_samples < len ? 0 : static_cast<int>(1 + (num_samples - len) / shift);
+  int num_frames = static_cast<int>((num_samples + shift / 2) / shift);
+  if (flush) return num_frames;
+  int64_t end_of_last = (shift * (num_frames - 1) + shift / 2 - len / 2) + len;
+  while (num_frames > 0 && end_of_last > num_samples) { num_frames--; end_of_last -= shift; }
+  return num_frames;
+}
+
+// frames [first_frame, first_frame + num_frames) of ONE waveform of num_samples samples
+// (streaming: the waveform grows, earlier frames were computed before)
+int kamd_feat_compute_frames_device(kamd_feat *h, const float *d_wave, int64_t num_samples, int first_frame,
+                                    int num_frames, float *d_out, int ld_out, void *stream) {
+  Feat *f = reinterpret_cast<Feat *>(h);
+  if (num_frames <= 0) return KAMD_OK;
+  if (ld_out < f->dev.num_out) return kamd::SetError(KAMD_ERR_ARG, "ld_out < feature dim");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t meta[5] = {0, num_samples, 0, num_frames, 0};   // wave_off[2] | frame_off[2] | row_off[1]
+  if (f->meta_cap < 8) {
+    if (f->d_meta) KAMD_HIP(hipFree(f->d_meta));
+    f->d_meta = NULL; f->meta_cap = 0;
+    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_meta), 64 * 8));
+    f->meta_cap = 64;
+  }
+  KAMD_HIP(hipMemcpyAsync(f->d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  const size_t lds = 4 * (2 * f->dev.N + 128) * sizeof(float);
+  hipLaunchKernelGGL(kamd::FeatKernel, dim3(kamd::CeilDiv(num_frames, 4)), dim3(256), lds, st, f->dev, d_wave, f->d_meta,
+                     f->d_meta + 2, f->d_meta + 4, 1, d_out, ld_out, first_frame);
   KAMD_HIP(hipGetLastError());
   return KAMD_OK;
 }

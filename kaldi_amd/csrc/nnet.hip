@@ -360,6 +360,7 @@ void kamd_nnet_destroy(kamd_nnet *h) {
 int kamd_nnet_output_dim(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->L.back().out_dim; }
 int kamd_nnet_left_context(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->left; }
 int kamd_nnet_right_context(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->right; }
+int kamd_nnet_frame_subsampling_factor(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->subsampling; }
 int kamd_nnet_num_output_frames(const kamd_nnet *h, int T) {
   int s = reinterpret_cast<const Nnet *>(h)->subsampling;
   return (T + s - 1) / s;

@@ -162,8 +162,12 @@ class LatticeFasterDecoder:
     def GetRawLattice(self):
         return get_raw_lattice(self._dec, self.lane)
 
-    def GetBestPath(self):
-        return best_path(self._dec, self.lane)
+    def GetBestPath(self, use_final_probs=True):
+        """After FinalizeDecoding: ShortestPath of the raw lattice.  Before it (streaming):
+        LatticeFasterOnlineDecoder::GetBestPath = BestPathEnd + TraceBackBestPath."""
+        if lib().kamd_decoder_lattice_size(self._dec, self.lane, C.byref(abi.LatticeSize())) == 0:
+            return best_path(self._dec, self.lane)
+        return partial_best_path(self._dec, self.lane, use_final_probs)
 
     def trace(self):
         return get_trace(self._dec, self.lane)
@@ -201,6 +205,18 @@ def best_path(dec, lane):
         return None
     return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(),
                 graph_cost=g.value, acoustic_cost=a.value)
+
+
+def partial_best_path(dec, lane, use_final_probs=True):
+    n = lib().kamd_decoder_num_frames_decoded(dec, lane)
+    cap = 4 * (n + 2) + 1024
+    ali, words = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    na, nw = C.c_int(), C.c_int()
+    g, a = C.c_float(), C.c_float()
+    check(lib().kamd_decoder_partial_best_path(dec, lane, int(use_final_probs), abi.iptr(ali), cap, C.byref(na),
+                                               abi.iptr(words), cap, C.byref(nw), C.byref(g), C.byref(a)))
+    return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(), graph_cost=g.value,
+                acoustic_cost=a.value)
 
 
 def get_trace(dec, lane):

@@ -1,0 +1,128 @@
+"""Streaming decode (BASELINE config 5), mirroring online2's classes over the C-ABI:
+
+  OnlineMfcc                 feat/online-feature.h:78 OnlineGenericBaseFeature<MfccComputer>
+  SingleUtteranceNnet3Decoder online2/online-nnet3-decoding.h:52 (feature pipeline +
+                             DecodableAmNnetLoopedOnline + LatticeFasterOnlineDecoder)
+as driven by online2bin/online2-wav-nnet3-latgen-faster.cc:211-285:
+  AcceptWaveform(chunk) -> AdvanceDecoding() ... InputFinished() -> AdvanceDecoding() ->
+  FinalizeDecoding() -> GetLattice / GetBestPath.
+Everything stays on the device between the calls (chunked features on-device)."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi, decoder, feat
+from ._lib import KamdError, check, lib
+
+
+class OnlineMfcc:
+    def __init__(self, opts=None):
+        self.computer = feat.Mfcc(opts)
+        self._h = lib().kamd_online_feat_create(self.computer._h)
+        if not self._h:
+            raise KamdError(lib().kamd_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kamd_online_feat_destroy(self._h)
+            self._h = None
+
+    def Dim(self):
+        return self.computer.Dim()
+
+    def AcceptWaveform(self, sampling_rate, waveform):
+        w = np.ascontiguousarray(waveform, np.float32)
+        check(lib().kamd_online_feat_accept_waveform(self._h, float(sampling_rate), abi.fptr(w), w.size))
+
+    def InputFinished(self):
+        check(lib().kamd_online_feat_input_finished(self._h))
+
+    def NumFramesReady(self):
+        return lib().kamd_online_feat_num_frames_ready(self._h)
+
+    def IsLastFrame(self, frame):
+        return bool(lib().kamd_online_feat_is_last_frame(self._h, frame))
+
+    def GetFrames(self, first, n):
+        out = np.zeros((n, self.Dim()), np.float32)
+        check(lib().kamd_online_feat_get_frames(self._h, first, n, abi.fptr(out)))
+        return out
+
+    def GetFrame(self, frame):
+        return self.GetFrames(frame, 1)[0]
+
+    def device_frames(self):
+        ld = C.c_int32()
+        p = lib().kamd_online_feat_device_frames(self._h, C.byref(ld))
+        return p, ld.value
+
+
+class SingleUtteranceNnet3Decoder:
+    def __init__(self, mfcc_opts, nnet, graph, config, sizes=None, max_seconds=40.0):
+        """nnet: decoder.Nnet, graph: decoder.Graph (shared, read-only), config: DecoderConfig."""
+        self.features = OnlineMfcc(mfcc_opts)
+        self.nnet, self.graph = nnet, graph
+        sub = lib().kamd_nnet_frame_subsampling_factor(nnet._h)
+        if sizes is None:
+            from .pipeline import default_sizes
+            sizes = default_sizes(config, 1, int(max_seconds * 100 / sub) + 2)
+        self.decoder = decoder.LatticeFasterDecoder(graph, config, sizes)
+        self.P = nnet.OutputDim()
+        self._finished = False
+        self._ll = None
+        self._ll_rows = 0
+        self.decoder.InitDecoding()          # online-nnet3-decoding.cc:40
+
+    def AcceptWaveform(self, sampling_rate, waveform):
+        self.features.AcceptWaveform(sampling_rate, waveform)
+
+    def InputFinished(self):
+        self.features.InputFinished()
+        self._finished = True
+
+    def NumFramesReady(self):
+        return lib().kamd_nnet_num_frames_ready(self.nnet._h, self.features.NumFramesReady(), int(self._finished))
+
+    def NumFramesDecoded(self):
+        return self.decoder.NumFramesDecoded()
+
+    def AdvanceDecoding(self):
+        """Decode every output frame that became ready (online-nnet3-decoding.cc:51-53)."""
+        done, ready = self.decoder.NumFramesDecoded(), self.NumFramesReady()
+        n = ready - done
+        if n <= 0:
+            return 0
+        nbytes = n * self.P * 4
+        d_ll = lib().kamd_malloc(nbytes)
+        if not d_ll:
+            raise KamdError(lib().kamd_last_error().decode())
+        try:
+            p, ld = self.features.device_frames()
+            check(lib().kamd_nnet_forward_range(self.nnet._h, p, ld, self.features.NumFramesReady(),
+                                                int(self._finished), done, n, d_ll, self.P))
+            task = abi.DecodeTask(0, n, d_ll, self.P, 0)
+            check(lib().kamd_decoder_advance(self.decoder._dec, C.byref(task), 1, None))
+            check(lib().kamd_decoder_sync(self.decoder._dec))
+            if self._ll is not None:       # keep a host copy for tests (loglikes())
+                buf = np.zeros((n, self.P), np.float32)
+                check(lib().kamd_memcpy_d2h(buf.ctypes.data_as(C.c_void_p), d_ll, nbytes))
+                self._ll.append(buf)
+        finally:
+            lib().kamd_free(d_ll)
+        return n
+
+    def record_loglikes(self):
+        self._ll = []
+
+    def loglikes(self):
+        return np.concatenate(self._ll) if self._ll else np.zeros((0, self.P), np.float32)
+
+    def FinalizeDecoding(self):
+        self.decoder.FinalizeDecoding()
+
+    def GetBestPath(self, end_of_utterance=True):
+        """online-nnet3-decoding.cc:81-85: use_final_probs = end_of_utterance."""
+        return self.decoder.GetBestPath(use_final_probs=end_of_utterance)
+
+    def GetRawLattice(self):
+        return self.decoder.GetRawLattice()

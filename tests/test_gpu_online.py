@@ -1,0 +1,111 @@
+"""Streaming (config 5) parity: chunked on-device features == offline features, streaming
+nnet rows == offline forward, chunk-wise decoding == one-shot decoding (bit-exact lattice),
+partial best path == oracle's best path over the un-finalized lattice."""
+import numpy as np
+import pytest
+
+from kaldi_amd import abi, decoder, feat, nnet, online, synth
+from oracle import orc
+from tests.util import lattice_diff, lattices_equal
+
+pytestmark = pytest.mark.gpu
+CHUNK = int(0.18 * 16000)      # online2-wav-nnet3-latgen-faster.cc:107 chunk-length 0.18 s
+
+
+@pytest.mark.parametrize("snip", [1, 0])
+def test_online_features_equal_offline(snip):
+    op = abi.mfcc_opts_hires()
+    op.frame.snip_edges = snip
+    w = synth.make_wave(2.37, seed=3)
+    off = feat.Mfcc(op).ComputeFeatures(w)
+    on = online.OnlineMfcc(op)
+    ready = []
+    for i in range(0, w.size, CHUNK):
+        on.AcceptWaveform(16000, w[i:i + CHUNK])
+        ready.append(on.NumFramesReady())
+        # NumFrames(total, opts, flush=false) (feat/feature-window.cc:41-87)
+        assert ready[-1] == orc.lib().orc_feat_num_frames(op.frame, min(i + CHUNK, w.size)) - (
+            0 if snip else _unflushed(op, min(i + CHUNK, w.size)))
+    on.InputFinished()
+    assert on.NumFramesReady() == off.shape[0] and on.IsLastFrame(off.shape[0] - 1)
+    np.testing.assert_array_equal(on.GetFrames(0, off.shape[0]), off)   # same kernel => bit-equal
+    assert ready == sorted(ready)
+    with pytest.raises(Exception):
+        on.AcceptWaveform(16000, w[:10])      # online-feature.cc:126: no waveform after InputFinished
+
+
+def _unflushed(op, n):
+    """frames whose window would run past the end when not flushing (snip_edges=false)."""
+    shift, length = 160, 400
+    nf = (n + shift // 2) // shift
+    end = (shift * (nf - 1) + shift // 2 - length // 2) + length
+    k = 0
+    while nf - k > 0 and end > n:
+        k += 1
+        end -= shift
+    return k
+
+
+def test_streaming_nnet_rows_equal_offline():
+    m = nnet.tdnnf_tiny(num_pdfs=40)
+    N = decoder.Nnet(m)
+    op = abi.mfcc_opts_hires()
+    w = synth.make_wave(3.1, seed=5)
+    feats = feat.Mfcc(op).ComputeFeatures(w)
+    whole = N.Forward(feats)
+    g = synth.make_hclg(num_units=20, vocab=30, n_hist=6, seed=1)
+    cfg = abi.decoder_config_recipe()
+    s = online.SingleUtteranceNnet3Decoder(op, N, decoder.Graph(g), cfg, sizes=abi.DecoderSizes(1, 1 << 14, 1 << 18, 1 << 19, 512))
+    s.record_loglikes()
+    for i in range(0, w.size, CHUNK):
+        s.AcceptWaveform(16000, w[i:i + CHUNK])
+        s.AdvanceDecoding()
+        assert s.NumFramesDecoded() == s.NumFramesReady() <= whole.shape[0]
+    s.InputFinished()
+    s.AdvanceDecoding()
+    got = s.loglikes()
+    assert got.shape == whole.shape
+    # same kernels, same k order; the per-row result does not depend on the slice
+    np.testing.assert_array_equal(got, whole)
+
+
+def test_streaming_decode_equals_offline_and_partial_results():
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=3.0)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    sz = abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512)
+    w = synth.make_wave(2.9, seed=9)
+    s = online.SingleUtteranceNnet3Decoder(op, N, G, cfg, sizes=sz)
+    s.record_loglikes()
+    partial_checked = 0
+    for i in range(0, w.size, CHUNK):
+        s.AcceptWaveform(16000, w[i:i + CHUNK])
+        if s.AdvanceDecoding() and s.NumFramesDecoded() > 3:
+            # partial result (end_of_utterance=false): compare with the oracle decoding the
+            # same rows so far, best path over its un-finalized lattice
+            o = orc.Decoder(g, cfg, 1)
+            o.InitDecoding()
+            o.AdvanceDecoding(s.loglikes())
+            for use_final in (False, True):
+                bp = s.GetBestPath(end_of_utterance=use_final)
+                lat = o.GetRawLattice()
+                if not use_final:
+                    lat.final[:] = np.where(lat.frame == lat.num_frames, 0.0, np.inf).astype(np.float32)
+                ob = lat.best_path()
+                assert bp["words"].tolist() == ob["words"].tolist()
+                assert bp["alignment"].tolist() == ob["alignment"].tolist()
+                assert abs((bp["graph_cost"] + bp["acoustic_cost"]) - (ob["graph_cost"] + ob["acoustic_cost"])) < 1e-3
+            partial_checked += 1
+    s.InputFinished()
+    s.AdvanceDecoding()
+    s.FinalizeDecoding()
+    assert partial_checked >= 3
+    ll = s.loglikes()
+    o = orc.Decoder(g, cfg, 1)
+    o.Decode(ll)
+    assert lattices_equal(s.GetRawLattice(), o.GetRawLattice()), lattice_diff(s.GetRawLattice(), o.GetRawLattice())
+    # and equal to the offline pipeline on the whole waveform
+    off = decoder.LatticeFasterDecoder(G, cfg, sz)
+    off.Decode(N.Forward(feat.Mfcc(op).ComputeFeatures(w)))
+    assert lattices_equal(s.GetRawLattice(), off.GetRawLattice())
