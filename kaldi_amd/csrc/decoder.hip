@@ -35,10 +35,11 @@ typedef unsigned int u32;
 
 #define NT 1024
 #define NWAVES (NT / 64)
-#define BIGCAP 4096     // tokens per flatten batch (deg > SMALL_DEG)
+#define BIGCAP 3072     // tokens per flatten batch (deg > SMALL_DEG)
+#define LDS_TABLE_CAP 8192   // level-1 table words (64 KB of the CU's 160 KB LDS)
 #define SMALL_DEG 4
 #define ARCW 4           // arcs in flight per thread in the arc-parallel expansion
-#define CHUNKCAP 8192    // cached chunk owners (16 arcs each) per flatten batch
+#define CHUNKCAP 5120    // cached chunk owners (16 arcs each) per flatten batch
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
 
 enum { ERR_HASH = 1, ERR_TOK = 2, ERR_LINK = 4, ERR_FRAMES = 8, ERR_WL = 16, ERR_INTERNAL = 32 };
@@ -71,6 +72,7 @@ struct DecDev {
   const int *tid2pdf;   // NULL => pdf = ilabel - 1
   const int *e_pdf;     // [emitting arcs] pdf of each emitting arc (tid2pdf applied once)
   int num_pdfs_lds;     // log-likelihood row entries staged in LDS per frame (0 = none)
+  int lds_table_cap;    // level-1 (LDS) table words, power of two or 0
   kamd_decoder_config cfg;
   int hash_cap, hash_mask, max_frames;
   const long long *lane_tok_base, *lane_lnk_base;  // per lane: offset into the pools
@@ -97,10 +99,10 @@ struct Ctx {
 
 __device__ inline Ctx MakeCtx(const DecDev &d, int lane) {
   Ctx c;
-  size_t hc = d.hash_cap, mf = d.max_frames;
+  size_t hc = static_cast<size_t>(d.hash_cap) + LDS_TABLE_CAP, mf = d.max_frames;
   const long long tbase = d.lane_tok_base[lane], lbase = d.lane_lnk_base[lane];
   c.tok_cap = d.lane_tok_cap[lane]; c.lnk_cap = d.lane_lnk_cap[lane];
-  c.H = d.H + lane * hc; c.slots = d.slots + lane * hc; c.slot_tok = d.slot_tok + lane * hc;
+  c.H = d.H + lane * static_cast<size_t>(d.hash_cap); c.slots = d.slots + lane * hc; c.slot_tok = d.slot_tok + lane * hc;
   c.stamp = d.stamp + lane * hc; c.wl0 = d.wl + lane * 2 * hc; c.wl1 = c.wl0 + hc;
   c.tok_state = d.tok_state + tbase; c.tok_cost = d.tok_cost + tbase;
   c.tok_extra = d.tok_extra + tbase; c.tok_map = d.tok_map + tbase;
@@ -354,10 +356,22 @@ __device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float b
   return ans;
 }
 
+// Two-level state -> token table of one frame.  Level 1 lives in LDS (lcap words, probe
+// window LWIN): the common case costs an LDS atomic (~100 cycles) instead of an L2 round
+// trip (~1-2k cycles).  A state whose window is full goes to the HBM table (level 2).
+// Entries are never removed inside a frame, so "window full / EMPTY seen" decide
+// membership consistently.  Slot ids: [0, lcap) = LDS, lcap + g = global slot g.
+#define LWIN 8
+struct Tbl { u64 *LH; int lcap; };
+__device__ inline u32 HashL(int s, int lcap) { return (static_cast<u32>(s) * 2654435761u >> 9) & static_cast<u32>(lcap - 1); }
+__device__ inline u64 TblLoad(const Ctx &c, const Tbl &t, int slot) {
+  return slot < t.lcap ? t.LH[slot] : LoadH(&c.H[slot - t.lcap]);
+}
+
 // FindOrAddToken (lattice-faster-decoder.cc:266-306) on the frame's table.
 // returns slot (or -1 on overflow); *improved = created, or strictly lowered the cost.
 __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int state, float cost,
-                                 bool *improved) {
+                                 bool *improved, int slot_bias) {
   const u64 mine = Pack(state, cost);
   u32 h = HashState(state, d.hash_mask);
   for (int probe = 0; probe < d.hash_cap; probe++) {
@@ -366,7 +380,7 @@ __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int stat
     const u64 old = atomicCAS(&c.H[h], EMPTY64, mine);
     if (old == EMPTY64) {
       int idx = WaveAlloc(&sh->n_slots);
-      if (idx < d.hash_cap) c.slots[idx] = h; else sh->err = ERR_HASH;
+      if (idx < d.hash_cap) c.slots[idx] = h + static_cast<u32>(slot_bias); else sh->err = ERR_HASH;
       *improved = true;
       return static_cast<int>(h);
     }
@@ -389,34 +403,12 @@ __device__ inline float LogLikePdf(const LlRow &r, int pdf) {
   return r.g[pdf];
 }
 
-// HashInsert split in two so that several inserts of one thread overlap their L2 round
-// trips: HashIssue fires the optimistic CAS, HashResolve finishes (rarely probing on).
-__device__ inline u64 HashIssue(const DecDev &d, const Ctx &c, int state, u64 mine, u32 *h) {
-  *h = HashState(state, d.hash_mask);
-  return atomicCAS(&c.H[*h], EMPTY64, mine);
-}
-__device__ inline int HashResolve(const DecDev &d, const Ctx &c, Sh *sh, int state, u64 mine, u32 h, u64 old) {
-  for (int probe = 0; probe < d.hash_cap; probe++) {
-    if (old == EMPTY64) {
-      int idx = WaveAlloc(&sh->n_slots);
-      if (idx < d.hash_cap) c.slots[idx] = h; else sh->err = ERR_HASH;
-      return static_cast<int>(h);
-    }
-    if (StateOf(old) == state) {
-      if (old > mine) atomicMin(&c.H[h], mine);
-      return static_cast<int>(h);
-    }
-    h = (h + 1) & static_cast<u32>(d.hash_mask);
-    old = atomicCAS(&c.H[h], EMPTY64, mine);
-  }
-  sh->err = ERR_HASH;
-  return -1;
-}
-
+__device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t, int state, float cost,
+                                bool *improved);
 // W emitting arcs of one thread (lattice-faster-decoder.cc:791-809), evaluated together:
-// all cutoff tests first, then all table CASes in flight at once, then the links.
+// all cutoff tests first (the arcs were loaded together), then the inserts and links.
 template <int W>
-__device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const LlRow &ll,
+__device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, const LlRow &ll,
                                    const kamd_arc (&arc)[W], const int (&pdf)[W], const int (&src_tok)[W],
                                    const float (&cur_cost)[W], const bool (&ok)[W], float cost_offset,
                                    float adaptive_beam, int link_base) {
@@ -433,20 +425,11 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
       if (cand < nc) atomicMin(&sh->next_cutoff_u, FloatToOrdered(cand));
     }
   }
-#ifdef KAMD_EXP_NOINSERT   // timing experiment only (results are wrong)
-  { float sink = 0.f; for (int q = 0; q < W; q++) sink += pass[q] ? tot[q] : 0.f; if (sink == 123.456f) sh->err = 1; return; }
-#endif
-  u64 mine[W], old[W];
-  u32 h[W];
-#pragma unroll
-  for (int q = 0; q < W; q++) {
-    mine[q] = 0; old[q] = 0; h[q] = 0;
-    if (pass[q]) { mine[q] = Pack(arc[q].nextstate, tot[q]); old[q] = HashIssue(d, c, arc[q].nextstate, mine[q], &h[q]); }
-  }
 #pragma unroll
   for (int q = 0; q < W; q++) {
     if (!pass[q]) continue;
-    const int slot = HashResolve(d, c, sh, arc[q].nextstate, mine[q], h[q], old[q]);
+    bool improved;
+    const int slot = TblInsert(d, c, sh, tbl, arc[q].nextstate, tot[q], &improved);
     if (slot < 0) continue;
     const int li = link_base + WaveAlloc(&sh->n_links);
     if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
@@ -467,36 +450,66 @@ __device__ inline int HashFind(const DecDev &d, const Ctx &c, int state) {
   return -1;
 }
 
+__device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t, int state, float cost,
+                                bool *improved) {
+  if (t.lcap > 0) {
+    const u64 mine = Pack(state, cost);
+    const u32 h0 = HashL(state, t.lcap), m = static_cast<u32>(t.lcap - 1);
+    // scan the window with plain LDS reads (pipelined), then one atomic on the chosen word
+    int w_empty = -1, w_match = -1;
+#pragma unroll
+    for (int w = 0; w < LWIN; w++) {
+      const u64 e = t.LH[(h0 + w) & m];
+      if (w_match < 0 && w_empty < 0) {
+        if (e == EMPTY64) w_empty = w;
+        else if (StateOf(e) == state) w_match = w;
+      }
+    }
+    int w = w_match >= 0 ? w_match : w_empty;
+    while (w >= 0 && w < LWIN) {
+      const u32 sl = (h0 + w) & m;
+      const u64 old = atomicCAS(&t.LH[sl], EMPTY64, mine);
+      if (old == EMPTY64) {
+        int idx = WaveAlloc(&sh->n_slots);
+        if (idx < d.hash_cap) c.slots[idx] = sl; else sh->err = ERR_HASH;
+        *improved = true;
+        return static_cast<int>(sl);
+      }
+      if (StateOf(old) == state) {
+        if (old <= mine) { *improved = false; return static_cast<int>(sl); }
+        const u64 prev = atomicMin(&t.LH[sl], mine);
+        *improved = prev > mine;
+        return static_cast<int>(sl);
+      }
+      w++;   // lost the word to another state: keep probing
+    }
+  }
+  const int g = HashInsert(d, c, sh, state, cost, improved, t.lcap);
+  return g < 0 ? g : g + t.lcap;
+}
+__device__ inline int TblFind(const DecDev &d, const Ctx &c, const Tbl &t, int state) {
+  if (t.lcap > 0) {
+    const u32 h0 = HashL(state, t.lcap);
+    for (int w = 0; w < LWIN; w++) {
+      const u32 sl = (h0 + w) & static_cast<u32>(t.lcap - 1);
+      const u64 cur = t.LH[sl];
+      if (cur == EMPTY64) return -1;
+      if (StateOf(cur) == state) return static_cast<int>(sl);
+    }
+  }
+  const int g = HashFind(d, c, state);
+  return g < 0 ? g : g + t.lcap;
+}
+
 __device__ inline float LogLike(const DecDev &d, const float *ll, int ilabel) {
   // DecodableMatrixMapped::LogLikelihood (decoder/decodable-matrix.cc:62-69)
   const int pdf = d.tid2pdf ? d.tid2pdf[ilabel] : ilabel - 1;
   return ll[pdf];
 }
-// one emitting arc of one expanded token (lattice-faster-decoder.cc:791-809)
-__device__ inline void ProcessArc(const DecDev &d, const Ctx &c, Sh *sh, const LlRow &ll,
-                                  const kamd_arc &arc, int pdf, int src_tok, float cur_cost,
-                                  float cost_offset, float adaptive_beam, int link_base) {
-  const float ac_cost = cost_offset - LogLikePdf(ll, pdf);
-  const float graph_cost = arc.weight;
-  const float tot_cost = cur_cost + ac_cost + graph_cost;
-  const float nc = OrderedToFloat(sh->next_cutoff_u);   // running bound (conservative)
-  if (tot_cost > nc) return;
-  const float cand = tot_cost + adaptive_beam;
-  if (cand < nc) atomicMin(&sh->next_cutoff_u, FloatToOrdered(cand));
-  bool improved;
-  const int slot = HashInsert(d, c, sh, arc.nextstate, tot_cost, &improved);
-  if (slot < 0) return;
-  const int li = link_base + WaveAlloc(&sh->n_links);
-  if (li >= c.lnk_cap) { sh->err = ERR_LINK; return; }
-  Link L; L.src = src_tok; L.dst = slot; L.ilabel = arc.ilabel; L.olabel = arc.olabel;
-  L.graph = graph_cost; L.ac = ac_cost;
-  c.links[li] = L;
-}
-
 // ProcessNonemitting (lattice-faster-decoder.cc:833-899) as a fixpoint relaxation, then
 // commit the frame: compact surviving tokens into the arena, resolve emitting links,
 // emit epsilon links, clear the table.  'list' is the token-list index being created.
-__device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff, int list,
+__device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
                             int emit_link_begin, float *cost_cache, int cache_cap) {
   const int tid = threadIdx.x;
   LaneState *S = c.st;
@@ -506,7 +519,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
     const int ns = min(sh->n_slots, d.hash_cap);
     for (int i = tid; i < ns; i += NT) {
       const u32 slot = c.slots[i];
-      const u64 e = LoadH(&c.H[slot]);
+      const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
       if (e == EMPTY64) { sh->err = ERR_INTERNAL; continue; }
       const int s = StateOf(e);
       const uint2 o0 = d.g.off[s], o1 = d.g.off[s + 1];
@@ -526,7 +539,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
     u32 *wl_nxt = cur ? c.wl0 : c.wl1;
     for (int i = tid; i < nw; i += NT) {
       const u32 slot = wl_cur[i];
-      const u64 e = LoadH(&c.H[slot]);
+      const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
       const float cur_cost = CostOf(e);
       if (e == EMPTY64 || cur_cost > cutoff) continue;      // :867
       const int s = StateOf(e);
@@ -536,7 +549,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
         const float tot_cost = cur_cost + arc.weight;
         if (tot_cost < cutoff) {            // :882
           bool improved;
-          const int slot2 = HashInsert(d, c, sh, arc.nextstate, tot_cost, &improved);
+          const int slot2 = TblInsert(d, c, sh, tbl, arc.nextstate, tot_cost, &improved);
           if (slot2 >= 0 && improved) {
             const uint2 p0 = d.g.off[arc.nextstate], p1 = d.g.off[arc.nextstate + 1];
             if (p1.y > p0.y && atomicExch(&c.stamp[slot2], round) != round) {
@@ -563,7 +576,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
   u64 kmin = EMPTY64;
   for (int i = tid; i < ns; i += NT) {
     const u32 slot = c.slots[i];
-    const u64 e = LoadH(&c.H[slot]);
+    const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
     if (e == EMPTY64) sh->err = ERR_INTERNAL;   // a listed slot must hold a token
     int idx = -1;
     if (e != EMPTY64 && CostOf(e) <= cutoff) {
@@ -609,7 +622,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
       const kamd_arc arc = d.g.n_arcs[a];
       const float tot_cost = cur_cost + arc.weight;
       if (tot_cost < cutoff) {
-        const int slot2 = HashFind(d, c, arc.nextstate);
+        const int slot2 = TblFind(d, c, tbl, arc.nextstate);
         const int dst = slot2 >= 0 ? c.slot_tok[slot2] : -1;
         if (dst < 0) { sh->err = ERR_INTERNAL; continue; }
         const int li = eps_link_begin + WaveAlloc(&sh->wl_n[0]);   // worklists are idle here
@@ -623,8 +636,11 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, float cutoff,
   __syncthreads();
   Stamp(sh, PH_EPS_LINKS);
   // ---- clear the table, publish offsets and counters
-  for (int i = tid; i < ns; i += NT)
-    __hip_atomic_store(&c.H[c.slots[i]], EMPTY64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = tid; i < ns; i += NT) {
+    const int sl = static_cast<int>(c.slots[i]);
+    if (sl < tbl.lcap) tbl.LH[sl] = EMPTY64;
+    else __hip_atomic_store(&c.H[sl - tbl.lcap], EMPTY64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   DrainStores();   // the next frame's CAS / atomicMin must find the cleared words in L2
   BlockSum4(k_surv, a_eps, c_lt, c_le, sh);
   if (tid == 0) {
@@ -730,10 +746,11 @@ __global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
     for (int i = 0; i < 16; i++) S->phase_cycles[i] = 0;
     c.tok_off[0] = 0; c.lnk_off[0] = 0; c.lnk_off[1] = 0;
     bool imp;
-    HashInsert(d, c, &sh, d.g.start, 0.0f, &imp);
+    HashInsert(d, c, &sh, d.g.start, 0.0f, &imp, 0);
   }
   __syncthreads();
-  CommitFrame(d, c, &sh, d.cfg.beam, 0, 0, NULL, 0);
+  Tbl tbl; tbl.LH = NULL; tbl.lcap = 0;     // InitKernel has no LDS table: level 2 only
+  CommitFrame(d, c, &sh, tbl, d.cfg.beam, 0, 0, NULL, 0);
   PublishLaneEnd(d, c, &sh, 0);
 }
 
@@ -747,7 +764,11 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
   float *ll_lds = reinterpret_cast<float *>(big_scan + BIGCAP + 4);// [num_pdfs_lds]  (+4: sentinel)
   u32 *lh_lds = reinterpret_cast<u32 *>(ll_lds + ((d.num_pdfs_lds + 3) & ~3));   // [LHBINS]
   float *cand_lds = reinterpret_cast<float *>(lh_lds + LHBINS);                  // [LHCAND]
-  int *chunk_owner = reinterpret_cast<int *>(cand_lds + LHCAND);                 // [CHUNKCAP]
+  int *chunk_owner = reinterpret_cast<int *>(lh_lds);   // [CHUNKCAP] aliases the select scratch (disjoint phases)
+  Tbl tbl;
+  tbl.LH = reinterpret_cast<u64 *>(lh_lds + (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP));
+  tbl.lcap = d.lds_table_cap;
+  for (int i = threadIdx.x; i < tbl.lcap; i += NT) tbl.LH[i] = EMPTY64;
   const kamd_decode_task task = tasks[blockIdx.x];
   const Ctx c = MakeCtx(d, task.lane);
   const int tid = threadIdx.x;
@@ -848,7 +869,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
               arc[q].ilabel = arc[q].olabel = arc[q].nextstate = 0; arc[q].weight = 0.f;
               if (ok[q]) { arc[q] = d.g.e_arcs[a0 + q]; pdf[q] = d.e_pdf[a0 + q]; }
             }
-            ProcessArcs<SMALL_DEG>(d, c, &sh, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base);
+            ProcessArcs<SMALL_DEG>(d, c, &sh, tbl, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base);
           } else {
             const int p = WaveAlloc(&sh.bigcnt);   // < BIGCAP: flushed below before it can fill
             big_tok[p] = i; big_a0[p] = a0; big_scan[p] = deg;
@@ -931,7 +952,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
             }
 #pragma unroll
             for (int q = 0; q < ARCW; q++) tok[q] += tb;
-            ProcessArcs<ARCW>(d, c, &sh, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base);
+            ProcessArcs<ARCW>(d, c, &sh, tbl, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base);
           }
         }
         __syncthreads();
@@ -953,7 +974,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     __syncthreads();
     const float next_cutoff = OrderedToFloat(sh.next_cutoff_u);
     // ---- ProcessNonemitting(next_cutoff) + commit of token list frame+1
-    CommitFrame(d, c, &sh, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
+    CommitFrame(d, c, &sh, tbl, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
     const int err_now = sh.err;    // CommitFrame ends with a barrier; nobody writes err before the next one
     __syncthreads();
     if (err_now) { frame++; break; }
@@ -1177,6 +1198,12 @@ __global__ __launch_bounds__(NT) void TracebackKernel(DecDev d, int lane, int us
   if (tid == 0) *out_n = n_out;
 }
 
+static inline size_t AdvanceLdsBytes(int num_pdfs_lds, int lds_table_cap) {
+  const size_t scratch = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP);
+  return (3 * BIGCAP + 4) * 4 + static_cast<size_t>((num_pdfs_lds + 3) & ~3) * 4 + scratch * 4 +
+         static_cast<size_t>(lds_table_cap) * 8;
+}
+
 // ------------------------------------------------------------------ host
 struct Graph {
   GraphDev dev;
@@ -1310,7 +1337,7 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   memset(&d, 0, sizeof(d));
   d.g = D->g->dev; d.cfg = *cfg;
   d.hash_cap = s.hash_capacity; d.hash_mask = s.hash_capacity - 1; d.max_frames = s.max_frames;
-  const size_t L = s.max_lanes, hc = s.hash_capacity, at = s.arena_tokens, al = s.arena_links, mf = s.max_frames;
+  const size_t L = s.max_lanes, hc = static_cast<size_t>(s.hash_capacity) + LDS_TABLE_CAP, at = s.arena_tokens, al = s.arena_links, mf = s.max_frames;
   bool ok = true;
   auto alloc = [&](size_t bytes, int fill) -> void * {
     void *p = NULL;
@@ -1319,7 +1346,7 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
     if (fill >= 0 && hipMemset(p, fill, bytes) != hipSuccess) ok = false;
     return p;
   };
-  d.H = static_cast<kamd::u64 *>(alloc(L * hc * 8, 0xFF));
+  d.H = static_cast<kamd::u64 *>(alloc(L * static_cast<size_t>(s.hash_capacity) * 8, 0xFF));
   d.slots = static_cast<kamd::u32 *>(alloc(L * hc * 4, 0));
   d.slot_tok = static_cast<int *>(alloc(L * hc * 4, 0));
   d.stamp = static_cast<kamd::u32 *>(alloc(L * hc * 4, 0));
@@ -1373,10 +1400,14 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
       if (hipDeviceSynchronize() != hipSuccess) ok = false;
     }
   }
-  d.num_pdfs_lds = num_pdfs <= 24576 ? num_pdfs : 0;   // LDS row: up to 96 KB of the CU's 160 KB
+  // LDS budget (160 KB per CU): static Sh + flatten queue + select/chunk scratch + level-1 table
+  // + the log-likelihood row when it still fits
+  d.lds_table_cap = LDS_TABLE_CAP;
+  d.num_pdfs_lds = 0;
+  if (kamd::AdvanceLdsBytes(num_pdfs, d.lds_table_cap) + sizeof(kamd::Sh) + 1024 <= 160 * 1024) d.num_pdfs_lds = num_pdfs;
   if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::AdvanceKernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (3 * BIGCAP + 4) * 4 + ((d.num_pdfs_lds + 3) & ~3) * 4 + (LHBINS + LHCAND + CHUNKCAP) * 4) != hipSuccess)
+                                static_cast<int>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, d.lds_table_cap))) != hipSuccess)
     ok = false;
   if (ok && (hipEventCreate(&D->ev0) != hipSuccess || hipEventCreate(&D->ev1) != hipSuccess)) ok = false;
   if (!ok) {
@@ -1478,7 +1509,7 @@ int kamd_decoder_advance(kamd_decoder *h, const kamd_decode_task *tasks, int n, 
   KAMD_HIP(hipMemcpyAsync(D->d_tasks, sorted.data(), n * sizeof(kamd_decode_task), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
   KAMD_HIP(hipEventRecord(D->ev0, st));
-  const size_t lds = (3 * BIGCAP + 4) * 4 + static_cast<size_t>((D->dev.num_pdfs_lds + 3) & ~3) * 4 + (LHBINS + LHCAND + CHUNKCAP) * 4;
+  const size_t lds = kamd::AdvanceLdsBytes(D->dev.num_pdfs_lds, D->dev.lds_table_cap);
   hipLaunchKernelGGL(kamd::AdvanceKernel, dim3(n), dim3(NT), lds, st, D->dev, D->d_tasks);
   KAMD_HIP(hipGetLastError());
   KAMD_HIP(hipEventRecord(D->ev1, st));
