@@ -425,18 +425,40 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
       if (cand < nc) atomicMin(&sh->next_cutoff_u, FloatToOrdered(cand));
     }
   }
+  // candidates are only RECORDED here (dst = HCLG state).  The table inserts run later as a
+  // dense sweep over the recorded links (InsertEmitted): with ~10 % of the arcs passing,
+  // inserting in place would run the expensive path at ~10 % lane utilisation.
 #pragma unroll
   for (int q = 0; q < W; q++) {
     if (!pass[q]) continue;
-    bool improved;
-    const int slot = TblInsert(d, c, sh, tbl, arc[q].nextstate, tot[q], &improved);
-    if (slot < 0) continue;
     const int li = link_base + WaveAlloc(&sh->n_links);
     if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
-    Link L; L.src = src_tok[q]; L.dst = slot; L.ilabel = arc[q].ilabel; L.olabel = arc[q].olabel;
+    Link L; L.src = src_tok[q]; L.dst = arc[q].nextstate; L.ilabel = arc[q].ilabel; L.olabel = arc[q].olabel;
     L.graph = arc[q].weight; L.ac = ac[q];
     c.links[li] = L;
   }
+}
+
+// Dense sweep over the frame's recorded emitting links (lattice-faster-decoder.cc:803-809):
+// FindOrAddToken for every link whose own tot passes the FINAL next_cutoff; the link's dst
+// becomes the table slot, or -1 when the arc is outside the final cutoff (the canonical
+// rule: no order-dependent extras ever enter the table).
+__device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, int link_begin,
+                                    int n_links, float cutoff) {
+  int k_surv = 0;
+  const int le = min(link_begin + n_links, c.lnk_cap);
+  for (int li = link_begin + threadIdx.x; li < le; li += NT) {
+    const Link L = c.links[li];
+    const float tot = c.tok_cost[L.src] + L.ac + L.graph;
+    int dst = -1;
+    if (tot <= cutoff) {                       // :798 with the frame's final cutoff
+      bool improved;
+      dst = TblInsert(d, c, sh, tbl, L.dst, tot, &improved);
+      k_surv += dst >= 0;
+    }
+    c.links[li].dst = dst;
+  }
+  return k_surv;
 }
 
 __device__ inline int HashFind(const DecDev &d, const Ctx &c, int state) {
@@ -510,7 +532,7 @@ __device__ inline float LogLike(const DecDev &d, const float *ll, int ilabel) {
 // commit the frame: compact surviving tokens into the arena, resolve emitting links,
 // emit epsilon links, clear the table.  'list' is the token-list index being created.
 __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
-                            int emit_link_begin, float *cost_cache, int cache_cap) {
+                            int emit_link_begin, float *cost_cache, int cache_cap, int k_surv) {
   const int tid = threadIdx.x;
   LaneState *S = c.st;
   __syncthreads();
@@ -596,15 +618,11 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
   const float next_beam_cutoff = (n_new > 0 ? OrderedToFloat(static_cast<u32>(kmin >> 32)) : INFINITY) + d.cfg.beam;
   Stamp(sh, PH_COMPACT);
   // ---- emitting links: keep iff the arc's own tot <= final cutoff; slot -> token
-  int k_surv = 0;
   {
     const int lb = emit_link_begin, le = emit_link_begin + sh->n_links;
     for (int li = lb + tid; li < min(le, c.lnk_cap); li += NT) {
-      Link L = c.links[li];
-      const float tot = c.tok_cost[L.src] + L.ac + L.graph;
-      const bool valid = tot <= cutoff;
-      c.links[li].dst = valid ? c.slot_tok[L.dst] : -1;
-      k_surv += valid;
+      const int slot = c.links[li].dst;
+      if (slot >= 0) c.links[li].dst = c.slot_tok[slot];
     }
   }
   // ---- epsilon links of the surviving tokens (final costs), :875-897; the same sweep
@@ -750,7 +768,7 @@ __global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
   }
   __syncthreads();
   Tbl tbl; tbl.LH = NULL; tbl.lcap = 0;     // InitKernel has no LDS table: level 2 only
-  CommitFrame(d, c, &sh, tbl, d.cfg.beam, 0, 0, NULL, 0);
+  CommitFrame(d, c, &sh, tbl, d.cfg.beam, 0, 0, NULL, 0, 0);
   PublishLaneEnd(d, c, &sh, 0);
 }
 
@@ -973,8 +991,11 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     }
     __syncthreads();
     const float next_cutoff = OrderedToFloat(sh.next_cutoff_u);
+    // ---- FindOrAddToken for the recorded links, against the final cutoff
+    const int k_surv = InsertEmitted(d, c, &sh, tbl, link_base, sh.n_links, next_cutoff);
+    Stamp(&sh, PH_FIXUP);
     // ---- ProcessNonemitting(next_cutoff) + commit of token list frame+1
-    CommitFrame(d, c, &sh, tbl, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
+    CommitFrame(d, c, &sh, tbl, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP, k_surv);
     const int err_now = sh.err;    // CommitFrame ends with a barrier; nobody writes err before the next one
     __syncthreads();
     if (err_now) { frame++; break; }
