@@ -46,6 +46,7 @@ enum { ERR_HASH = 1, ERR_TOK = 2, ERR_LINK = 4, ERR_FRAMES = 8, ERR_WL = 16, ERR
 
 struct GraphDev {
   int num_states, start;
+  int start_flagged;      // start | EPS_FLAG if the start state has epsilon arcs
   const uint2 *off;       // [S+1]: .x emitting arc offset, .y epsilon arc offset
   const kamd_arc *e_arcs; // emitting arcs (ilabel != 0)
   const kamd_arc *n_arcs; // epsilon arcs (ilabel == 0)
@@ -162,7 +163,11 @@ __device__ inline u64 Pack(int state, float cost) {
   return (static_cast<u64>(static_cast<u32>(state)) << 32) | FloatToOrdered(cost);
 }
 __device__ inline float CostOf(u64 e) { return OrderedToFloat(static_cast<u32>(e)); }
-__device__ inline int StateOf(u64 e) { return static_cast<int>(e >> 32); }
+// table keys / device arc targets carry "this state has epsilon arcs" in bit 31
+#define EPS_FLAG 0x80000000u
+__device__ inline int StateOf(u64 e) { return static_cast<int>(e >> 32); }           // flagged
+__device__ inline int PlainState(int flagged) { return flagged & 0x7FFFFFFF; }
+__device__ inline bool HasEps(int flagged) { return (static_cast<u32>(flagged) & EPS_FLAG) != 0; }
 
 // one slot from a workgroup counter for every ACTIVE lane of the wavefront (call under
 // the predicate): wavefront-ballot aggregation => one LDS atomic per wavefront.
@@ -543,9 +548,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
       const u32 slot = c.slots[i];
       const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
       if (e == EMPTY64) { sh->err = ERR_INTERNAL; continue; }
-      const int s = StateOf(e);
-      const uint2 o0 = d.g.off[s], o1 = d.g.off[s + 1];
-      if (o1.y > o0.y && CostOf(e) <= cutoff) {
+      if (HasEps(StateOf(e)) && CostOf(e) <= cutoff) {
         int p = WaveAlloc(&sh->wl_n[0]);
         c.wl0[p] = slot;
       }
@@ -564,7 +567,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
       const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
       const float cur_cost = CostOf(e);
       if (e == EMPTY64 || cur_cost > cutoff) continue;      // :867
-      const int s = StateOf(e);
+      const int s = PlainState(StateOf(e));
       const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
       for (u32 a = a0; a < a1; a++) {
         const kamd_arc arc = d.g.n_arcs[a];
@@ -573,8 +576,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
           bool improved;
           const int slot2 = TblInsert(d, c, sh, tbl, arc.nextstate, tot_cost, &improved);
           if (slot2 >= 0 && improved) {
-            const uint2 p0 = d.g.off[arc.nextstate], p1 = d.g.off[arc.nextstate + 1];
-            if (p1.y > p0.y && atomicExch(&c.stamp[slot2], round) != round) {
+            if (HasEps(arc.nextstate) && atomicExch(&c.stamp[slot2], round) != round) {
               int p = WaveAlloc(&sh->wl_n[cur ^ 1]);
               if (p < d.hash_cap) wl_nxt[p] = static_cast<u32>(slot2); else sh->err = ERR_WL;
             }
@@ -589,6 +591,8 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
     __syncthreads();
     if (err_now) break;
   }
+  if (tid == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; }
+  __syncthreads();
   Stamp(sh, PH_EPS_CLOSURE);
   // ---- compaction: tokens with final cost <= cutoff become list 'list' (arena order is
   // the allocation order; lattices are canonicalised by (frame, state) on the host).
@@ -604,10 +608,16 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
     if (e != EMPTY64 && CostOf(e) <= cutoff) {
       idx = tok_base + WaveAlloc(&sh->n_new);
       if (idx < c.tok_cap) {
-        c.tok_state[idx] = StateOf(e);
+        const int st = PlainState(StateOf(e));
+        c.tok_state[idx] = st;
         c.tok_cost[idx] = CostOf(e);
         c.tok_extra[idx] = 0.0f;
-        const u64 k = (static_cast<u64>(static_cast<u32>(e)) << 32) | static_cast<u32>(StateOf(e));
+        if (idx - tok_base < cache_cap) cost_cache[idx - tok_base] = CostOf(e);
+        if (HasEps(StateOf(e))) {           // dense list of the tokens that own epsilon arcs
+          const int p = WaveAlloc(&sh->wl_n[1]);
+          if (p < d.hash_cap) c.wl1[p] = static_cast<u32>(idx); else sh->err = ERR_WL;
+        }
+        const u64 k = (static_cast<u64>(static_cast<u32>(e)) << 32) | static_cast<u32>(st);
         kmin = k < kmin ? k : kmin;
       } else { sh->err = ERR_TOK; idx = -1; }
     }
@@ -625,31 +635,38 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
       if (slot >= 0) c.links[li].dst = c.slot_tok[slot];
     }
   }
-  // ---- epsilon links of the surviving tokens (final costs), :875-897; the same sweep
-  // counts the costs against the next frame's beam cutoff and caches them in LDS
+  // ---- epsilon links of the surviving tokens (final costs), :875-897: dense over the
+  // tokens that own epsilon arcs (collected during compaction)
   const int eps_link_begin = c.lnk_off[2 * list + 1];
   int a_eps = 0, c_lt = 0, c_le = 0;
-  for (int t = tok_base + tid; t < tok_base + n_new; t += NT) {
-    const int s = c.tok_state[t];
-    const float cur_cost = c.tok_cost[t];
-    c_lt += cur_cost < next_beam_cutoff; c_le += cur_cost <= next_beam_cutoff;
-    if (t - tok_base < cache_cap) cost_cache[t - tok_base] = cur_cost;
-    const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
-    a_eps += static_cast<int>(a1 - a0);
-    for (u32 a = a0; a < a1; a++) {
-      const kamd_arc arc = d.g.n_arcs[a];
-      const float tot_cost = cur_cost + arc.weight;
-      if (tot_cost < cutoff) {
-        const int slot2 = TblFind(d, c, tbl, arc.nextstate);
-        const int dst = slot2 >= 0 ? c.slot_tok[slot2] : -1;
-        if (dst < 0) { sh->err = ERR_INTERNAL; continue; }
-        const int li = eps_link_begin + WaveAlloc(&sh->wl_n[0]);   // worklists are idle here
-        if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
-        Link L; L.src = t; L.dst = dst; L.ilabel = 0; L.olabel = arc.olabel;
-        L.graph = arc.weight; L.ac = 0.0f;
-        c.links[li] = L;
+  {
+    const int ne = min(sh->wl_n[1], d.hash_cap);
+    for (int i = tid; i < ne; i += NT) {
+      const int t = static_cast<int>(c.wl1[i]);
+      const int s = c.tok_state[t];
+      const float cur_cost = c.tok_cost[t];
+      const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
+      a_eps += static_cast<int>(a1 - a0);
+      for (u32 a = a0; a < a1; a++) {
+        const kamd_arc arc = d.g.n_arcs[a];
+        const float tot_cost = cur_cost + arc.weight;
+        if (tot_cost < cutoff) {
+          const int slot2 = TblFind(d, c, tbl, arc.nextstate);
+          const int dst = slot2 >= 0 ? c.slot_tok[slot2] : -1;
+          if (dst < 0) { sh->err = ERR_INTERNAL; continue; }
+          const int li = eps_link_begin + WaveAlloc(&sh->wl_n[0]);   // worklist 0 is idle here
+          if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
+          Link L; L.src = t; L.dst = dst; L.ilabel = 0; L.olabel = arc.olabel;
+          L.graph = arc.weight; L.ac = 0.0f;
+          c.links[li] = L;
+        }
       }
     }
+  }
+  // ---- the next frame's GetCutoff counts, from the LDS copy of the costs
+  for (int i = tid; i < n_new; i += NT) {
+    const float w = i < cache_cap ? cost_cache[i] : c.tok_cost[tok_base + i];
+    c_lt += w < next_beam_cutoff; c_le += w <= next_beam_cutoff;
   }
   __syncthreads();
   Stamp(sh, PH_EPS_LINKS);
@@ -764,7 +781,7 @@ __global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
     for (int i = 0; i < 16; i++) S->phase_cycles[i] = 0;
     c.tok_off[0] = 0; c.lnk_off[0] = 0; c.lnk_off[1] = 0;
     bool imp;
-    HashInsert(d, c, &sh, d.g.start, 0.0f, &imp, 0);
+    HashInsert(d, c, &sh, d.g.start_flagged, 0.0f, &imp, 0);
   }
   __syncthreads();
   Tbl tbl; tbl.LH = NULL; tbl.lcap = 0;     // InitKernel has no LDS table: level 2 only
@@ -1299,6 +1316,9 @@ kamd_graph *kamd_graph_create(int32_t num_states, int32_t start, const int64_t *
       return NULL;
     }
   }
+  // device copies: arc targets carry the "has epsilon arcs" flag in bit 31
+  for (size_t i = 0; i < ea.size(); i++) { int ns = ea[i].nextstate; if (off[ns + 1].y > off[ns].y) ea[i].nextstate = static_cast<int>(static_cast<unsigned>(ns) | EPS_FLAG); }
+  for (size_t i = 0; i < na.size(); i++) { int ns = na[i].nextstate; if (off[ns + 1].y > off[ns].y) na[i].nextstate = static_cast<int>(static_cast<unsigned>(ns) | EPS_FLAG); }
   Graph *g = new Graph();
   g->num_arcs = A; g->num_emit = static_cast<int64_t>(ea.size());
   g->max_ilabel = 0;
@@ -1311,6 +1331,7 @@ kamd_graph *kamd_graph_create(int32_t num_states, int32_t start, const int64_t *
     return p;
   };
   g->dev.num_states = num_states; g->dev.start = start;
+  g->dev.start_flagged = (off[start + 1].y > off[start].y) ? static_cast<int>(static_cast<unsigned>(start) | EPS_FLAG) : start;
   g->dev.off = static_cast<const uint2 *>(up(off.data(), off.size() * sizeof(uint2)));
   g->dev.e_arcs = static_cast<const kamd_arc *>(up(ea.data(), ea.size() * sizeof(kamd_arc)));
   g->dev.n_arcs = static_cast<const kamd_arc *>(up(na.data(), na.size() * sizeof(kamd_arc)));
