@@ -1068,21 +1068,20 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
       }
     }
     __syncthreads();
+    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
     for (int i = tid; i < nt; i += NT) {
-      float v = OrderedToFloat(LoadU32(&bo[i]));
+      const u32 b = LoadU32(&bo[i]);
+      float v = OrderedToFloat(b);
       if (f == F && v > lattice_beam) v = INFINITY;   // :462-463
       xcur[i] = v;
+      if (ee > eb) __hip_atomic_store(&xo[i], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    DrainStores();
     __syncthreads();
     // epsilon links inside frame f: Jacobi iteration to the exact fixpoint (the
     // reference's "while (changed)" loop; epsilon links are acyclic so it is unique)
-    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
     if (ee > eb) {
       for (int iter = 0; iter < 20000; iter++) {
-        for (int i = tid; i < nt; i += NT)
-          __hip_atomic_store(&xo[i], LoadU32(&bo[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        DrainStores();
-        __syncthreads();
         for (int li = eb + tid; li < ee; li += NT) {
           const Link L = c.links[li];
           float lec = xcur[L.dst - tb] + ((c.tok_cost[L.src] + L.ac + L.graph) - c.tok_cost[L.dst]);
@@ -1097,7 +1096,9 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
           if (f == F && v > lattice_beam) v = INFINITY;
           if (!(v == xcur[i])) changed = 1;
           xcur[i] = v;
+          __hip_atomic_store(&xo[i], LoadU32(&bo[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
         }
+        DrainStores();
         BlockSum2(changed, dummy, &sh);
         if (changed == 0) break;
       }
@@ -1110,28 +1111,33 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
     __syncthreads();
   }
   Stamp(&sh, PH_FIN_SWEEP);
-  // ---- PruneTokensForFrame + GetRawLattice staging: order preserving in-place compaction
+  // ---- PruneTokensForFrame + GetRawLattice staging: in-place compaction toward the front,
+  // frames stay contiguous and in order (order inside a frame is arbitrary: the host sorts by
+  // HCLG state).  Per 1024-chunk: read into registers -> barrier -> wavefront-ballot
+  // allocated writes; a write never lands beyond the chunk that has already been read.
   int *new_off = reinterpret_cast<int *>(c.wl0);   // [F+2] (hash_cap >= max_frames+2 is checked on the host)
-  int n_out_tok = 0;
+  if (tid == 0) sh.n_new = 0;
+  __syncthreads();
   for (int f = 0; f <= F; f++) {
     const int tb = c.tok_off[f], te = c.tok_off[f + 1];
-    if (tid == 0) new_off[f] = n_out_tok;
+    if (tid == 0) new_off[f] = sh.n_new;     // ordered by the barriers of the previous chunk
     for (int base = tb; base < te; base += NT) {
       const int i = base + tid;
       bool keep = false; int st = 0; float co = 0.f;
       if (i < te) { keep = c.tok_extra[i] != INFINITY; st = c.tok_state[i]; co = c.tok_cost[i]; }
-      int tot;
-      const int pos = BlockScanFlag(keep, &tot, &sh);
-      if (i < te) c.tok_map[i] = keep ? n_out_tok + pos : -1;
       __syncthreads();
-      if (keep) { c.tok_state[n_out_tok + pos] = st; c.tok_cost[n_out_tok + pos] = co; }
-      n_out_tok += tot;
+      int pos = -1;
+      if (keep) { pos = WaveAlloc(&sh.n_new); c.tok_state[pos] = st; c.tok_cost[pos] = co; }
+      if (i < te) c.tok_map[i] = pos;
     }
+    __syncthreads();
   }
+  const int n_out_tok = sh.n_new;
   if (tid == 0) new_off[F + 1] = n_out_tok;
   __syncthreads();
   // ---- links: drop excised, remap endpoints, remove cost offsets (GetRawLattice :173-180)
-  int n_out_link = 0;
+  if (tid == 0) sh.n_links = 0;
+  __syncthreads();
   for (int s = 0; s <= F; s++) {
     for (int part = 0; part < 2; part++) {
       const int lb = c.lnk_off[2 * s + part], le = c.lnk_off[2 * s + part + 1];
@@ -1150,15 +1156,13 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
             if (part == 0) L.ac = L.ac - off;
           }
         }
-        int tot;
-        const int pos = BlockScanFlag(keep, &tot, &sh);
         __syncthreads();
-        if (keep) c.links[n_out_link + pos] = L;
-        n_out_link += tot;
+        if (keep) c.links[WaveAlloc(&sh.n_links)] = L;
       }
     }
   }
   __syncthreads();
+  const int n_out_link = sh.n_links;
   for (int f = tid; f <= F + 1; f += NT) c.tok_off[f] = new_off[f];
   Stamp(&sh, PH_FIN_COMPACT);
   if (tid == 0) {
