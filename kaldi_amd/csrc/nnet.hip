@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void TdnnGemmKernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  constexpr int A_LOADS = BM * 4 / 256, B_LOADS = BN * 4 / 256;  // float4 per thread
+  constexpr int A_LOADS = BM * 4 / 256, B_LOADS = (BN * 4 + 255) / 256;  // float4 per thread
   float4 ra[A_LOADS], rb[B_LOADS];
   auto gload = [&](int kb) {
     const int k0 = kb * BK;
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void TdnnGemmKernel(GemmArgs p) {
 #pragma unroll
     for (int q = 0; q < B_LOADS; q++) {
       int idx = t + q * 256, row = idx >> 2, kq = idx & 3;
-      rb[q] = *reinterpret_cast<const float4 *>(p.W + static_cast<size_t>(n0 + row) * K + k0 + kq * 4);
+      if (BN * 4 % 256 == 0 || row < BN)
+        rb[q] = *reinterpret_cast<const float4 *>(p.W + static_cast<size_t>(n0 + row) * K + k0 + kq * 4);
     }
   };
   auto sstore = [&](int buf) {
@@ -95,8 +96,10 @@ __global__ __launch_bounds__(256) void TdnnGemmKernel(GemmArgs p) {
 #pragma unroll
     for (int q = 0; q < B_LOADS; q++) {
       int idx = t + q * 256, row = idx >> 2, kq = idx & 3;
-      Bs[buf][kq * 4 + 0][row] = rb[q].x; Bs[buf][kq * 4 + 1][row] = rb[q].y;
-      Bs[buf][kq * 4 + 2][row] = rb[q].z; Bs[buf][kq * 4 + 3][row] = rb[q].w;
+      if (BN * 4 % 256 == 0 || row < BN) {
+        Bs[buf][kq * 4 + 0][row] = rb[q].x; Bs[buf][kq * 4 + 1][row] = rb[q].y;
+        Bs[buf][kq * 4 + 2][row] = rb[q].z; Bs[buf][kq * 4 + 3][row] = rb[q].w;
+      }
     }
   };
   const int nkb = K / BK;
@@ -480,9 +483,19 @@ int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int
     }
     g.post_offset = L.post_offset; g.post_scale = L.post_scale;
     g.C = C + row_base * ldC; g.ldC = ldC;
-    if (L.out_dim <= 64 || (L.out_dim % 128 != 0 && L.out_dim % 128 <= 64)) {
-      dim3 grid(kamd::CeilDiv(L.out_dim, 64), kamd::CeilDiv(Ml, 128));
-      hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 64, 4, 1>), grid, dim3(256), 0, st, g);
+    // tile choice: a narrow layer (bottleneck / prefinal, N <= 160) is ONE column tile as
+    // wide as the layer, so the (large) A operand is streamed exactly once; wide layers use
+    // the 128x128 tile.
+    const int nt32 = kamd::CeilDiv(L.out_dim, 32);
+    if (nt32 <= 5) {
+      dim3 grid(1, kamd::CeilDiv(Ml, 128));
+      switch (nt32) {
+        case 1: hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 32, 4, 1>), grid, dim3(256), 0, st, g); break;
+        case 2: hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 64, 4, 1>), grid, dim3(256), 0, st, g); break;
+        case 3: hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 96, 4, 1>), grid, dim3(256), 0, st, g); break;
+        case 4: hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 128, 4, 1>), grid, dim3(256), 0, st, g); break;
+        default: hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 160, 4, 1>), grid, dim3(256), 0, st, g); break;
+      }
     } else {
       dim3 grid(kamd::CeilDiv(L.out_dim, 128), kamd::CeilDiv(Ml, 128));
       hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 128, 2, 2>), grid, dim3(256), 0, st, g);
