@@ -43,6 +43,7 @@ int kamd_free(void *d_ptr);
 int kamd_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
 int kamd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
 int kamd_device_synchronize(void);
+int kamd_device_mem_info(size_t *free_bytes, size_t *total_bytes);   /* hipMemGetInfo */
 
 /* -------------------------------------------------------------- features -- */
 /* feat/feature-window.h:40-66 FrameExtractionOptions (same defaults). */

@@ -42,6 +42,7 @@ def lib():
     sig("kamd_memcpy_h2d", C.c_int, [vp, vp, C.c_size_t])
     sig("kamd_memcpy_d2h", C.c_int, [vp, vp, C.c_size_t])
     sig("kamd_device_synchronize", C.c_int, [])
+    sig("kamd_device_mem_info", C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)])
     sig("kamd_mfcc_opts_default", None, [C.POINTER(abi.MfccOpts)])
     sig("kamd_fbank_opts_default", None, [C.POINTER(abi.FbankOpts)])
     sig("kamd_mfcc_create", vp, [C.POINTER(abi.MfccOpts), C.c_float])
@@ -108,7 +109,7 @@ def lib():
     return L
 
 
-EXPORTS = """kamd_malloc kamd_free kamd_memcpy_h2d kamd_memcpy_d2h kamd_device_synchronize kamd_last_error kamd_version kamd_device_count kamd_set_device kamd_mfcc_opts_default
+EXPORTS = """kamd_malloc kamd_free kamd_memcpy_h2d kamd_memcpy_d2h kamd_device_synchronize kamd_device_mem_info kamd_last_error kamd_version kamd_device_count kamd_set_device kamd_mfcc_opts_default
 kamd_fbank_opts_default kamd_mfcc_create kamd_fbank_create kamd_feat_destroy kamd_feat_dim
 kamd_feat_num_frames kamd_feat_compute kamd_feat_compute_batch_device kamd_feat_num_frames_flush kamd_feat_compute_frames_device kamd_online_feat_create kamd_online_feat_destroy kamd_online_feat_accept_waveform kamd_online_feat_input_finished kamd_online_feat_num_frames_ready kamd_online_feat_is_last_frame kamd_online_feat_get_frames kamd_online_feat_device_frames kamd_nnet_num_frames_ready kamd_nnet_forward_range kamd_nnet_create
 kamd_nnet_destroy kamd_nnet_output_dim kamd_nnet_left_context kamd_nnet_right_context

@@ -48,6 +48,7 @@ int kamd_free(void *p) { KAMD_HIP(hipFree(p)); return KAMD_OK; }
 int kamd_memcpy_h2d(void *d, const void *h, size_t bytes) { KAMD_HIP(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return KAMD_OK; }
 int kamd_memcpy_d2h(void *h, const void *d, size_t bytes) { KAMD_HIP(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return KAMD_OK; }
 int kamd_device_synchronize(void) { KAMD_HIP(hipDeviceSynchronize()); return KAMD_OK; }
+int kamd_device_mem_info(size_t *free_bytes, size_t *total_bytes) { KAMD_HIP(hipMemGetInfo(free_bytes, total_bytes)); return KAMD_OK; }
 void kamd_mfcc_opts_default(kamd_mfcc_opts *o) {
   // feat/feature-window.h:54-66, feat/feature-mfcc.h:50-58 (dither forced to 0)
   kamd_frame_opts f = {16000.0f, 10.0f, 25.0f, 0.0f, 0.97f, 1, KAMD_WIN_POVEY, 1, 0.42f, 1};

@@ -18,6 +18,14 @@ def default_sizes(cfg, max_utts, max_out_frames, avg_out_frames=None, hash_capac
     lpf = links_per_frame or int(1.6 * tpf + 2000)
     hc = hash_capacity or 1 << int(np.ceil(np.log2(max(4 * tpf, max_out_frames + 8, 4096))))
     avg = (avg_out_frames or max_out_frames) + 2
+    # keep the arenas within half of the free HBM (16 B per token record incl. map, 24 B per link)
+    free, total = C.c_size_t(), C.c_size_t()
+    if lib().kamd_device_mem_info(C.byref(free), C.byref(total)) == 0 and free.value > 0:
+        need = max_utts * avg * (16.0 * tpf + 24.0 * lpf)
+        budget = 0.5 * free.value
+        if need > budget:
+            k = budget / need
+            tpf, lpf = max(4000, int(tpf * k)), max(6000, int(lpf * k))
     return abi.DecoderSizes(max_utts, hc, int(tpf) * avg, int(lpf) * avg, max_out_frames + 1)
 
 
@@ -46,21 +54,41 @@ class Pipeline:
             self._h = None
 
     def load(self, waves):
-        off = np.concatenate([[0], np.cumsum([w.size for w in waves])]).astype(np.int64)
-        flat = np.ascontiguousarray(np.concatenate(waves), np.float32)
-        check(lib().kamd_pipeline_load_batch(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), len(waves)))
-        self.n_utts = len(waves)
-        self.audio_seconds = float(flat.size) / self.feat.opts.frame.samp_freq
+        """Utterances too short for a single frame are skipped with a None result, like the
+        reference's "Zero-length utterance" warning (nnet3bin/nnet3-latgen-faster.cc:148-152)."""
+        self._lane_of = []
+        keep = []
+        for w in waves:
+            if self.feat.NumFrames(np.asarray(w).size) > 0:
+                self._lane_of.append(len(keep))
+                keep.append(np.asarray(w, np.float32))
+            else:
+                self._lane_of.append(-1)
+        self.n_utts = len(keep)
+        self.n_input = len(waves)
+        self.audio_seconds = float(sum(np.asarray(w).size for w in waves)) / self.feat.opts.frame.samp_freq
+        if not keep:
+            return
+        off = np.concatenate([[0], np.cumsum([w.size for w in keep])]).astype(np.int64)
+        flat = np.ascontiguousarray(np.concatenate(keep), np.float32)
+        check(lib().kamd_pipeline_load_batch(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), len(keep)))
 
     def run(self):
         ms = np.zeros(4, np.float32)
+        if self.n_utts == 0:
+            self.last_stage_ms = ms.tolist()
+            return self.last_stage_ms
         check(lib().kamd_pipeline_run(self._h, abi.fptr(ms)))
         self.last_stage_ms = ms.tolist()
         return self.last_stage_ms
 
     def results(self, lattices=True):
         out = []
-        for u in range(self.n_utts):
+        for lane in getattr(self, "_lane_of", range(self.n_utts)):
+            if lane < 0:
+                out.append(None)
+                continue
+            u = lane
             bp = decoder.best_path(self.dec._dec, u)
             r = dict(words=bp["words"] if bp else np.zeros(0, np.int32), best=bp)
             if lattices:

@@ -161,3 +161,28 @@ def test_midsize_graph_saturated(seed):
     d, o = run_both(g, ll, cfg, sizes(hash_cap=1 << 16, toks=1 << 21, links=1 << 22))
     assert_same(d, o)
     assert (o.trace()[0] > 2000).any()
+
+
+def test_pipeline_ragged_batch_with_empty_and_tiny_utterances():
+    """Ragged batch: empty waveform, one shorter than a frame, a one-frame utterance, and
+    normal ones; the short ones are skipped (None), the rest decode as if alone."""
+    from kaldi_amd import nnet, pipeline
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=3.0)
+    cfg = abi.decoder_config_recipe()
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, cfg, max_utts=6, max_seconds=3.0)
+    waves = [np.zeros(0, np.float32), synth.make_wave(1.1, seed=1), np.zeros(399, np.float32),
+             synth.make_wave(0.025, seed=2), synth.make_wave(2.0, seed=3)]
+    res = pipe.decode(waves)
+    assert res[0] is None and res[2] is None
+    assert res[3]["lattice"].num_frames == 1
+    solo = pipe.decode([waves[4]])
+    assert lattices_equal(solo[0]["lattice"], res[4]["lattice"])      # batch independence
+    res2 = pipe.decode(waves)
+    assert lattices_equal(res2[4]["lattice"], res[4]["lattice"])
+    for u in (1, 3, 4):
+        o = orc.Decoder(g, cfg, 1)
+        lane = [i for i in (1, 3, 4)].index(u)
+        o.Decode(pipe.loglikes(lane))
+        assert lattices_equal(res2[u]["lattice"], o.GetRawLattice())
+    assert pipe.decode([np.zeros(10, np.float32)]) == [None]
