@@ -36,6 +36,7 @@ typedef unsigned int u32;
 #define NT 1024
 #define NWAVES (NT / 64)
 #define BIGCAP 3072     // tokens per flatten batch (deg > SMALL_DEG)
+#define FIN_CAP 6144         // tokens per frame the finalize sweep keeps in LDS (6 arrays)
 #define LDS_TABLE_CAP 8192   // level-1 table words (64 KB of the CU's 160 KB LDS)
 #define SMALL_DEG 4
 #define ARCW 4           // arcs in flight per thread in the arc-parallel expansion
@@ -1040,10 +1041,90 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
   const float final_best = finals_empty ? best_cost : best_with_final;  // :583-588
   u32 *bo = reinterpret_cast<u32 *>(c.scratch);                 // ordered keys: base + emitting
   u32 *xo = reinterpret_cast<u32 *>(c.scratch) + d.hash_cap;    // ordered keys: Jacobi target
+  // LDS working set of the sweep (frames of up to FIN_CAP tokens): extra costs / forward
+  // costs of frame f and of frame f+1 plus the two ordered-key accumulators.
+  extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
+  u32 *l_bo = reinterpret_cast<u32 *>(fin_lds);
+  u32 *l_xo = l_bo + FIN_CAP;
+  float *l_x[2] = {reinterpret_cast<float *>(l_xo + FIN_CAP), reinterpret_cast<float *>(l_xo + 2 * FIN_CAP)};
+  float *l_c[2] = {reinterpret_cast<float *>(l_xo + 3 * FIN_CAP), reinterpret_cast<float *>(l_xo + 4 * FIN_CAP)};
+  bool next_in_lds = false;   // frame f+1's extras / costs are in l_x[1-cur], l_c[1-cur]
+  int cur = 0;
   for (int f = F; f >= 0; f--) {
     const int tb = c.tok_off[f], nt = c.tok_off[f + 1] - tb;
     if (nt > d.hash_cap) { if (tid == 0) sh.err = ERR_INTERNAL; __syncthreads(); break; }
     float *xcur = c.tok_extra + tb;   // extra_cost of frame f (frame f+1 is final already)
+    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
+    const bool in_lds = nt <= FIN_CAP && (f == F || next_in_lds);
+    if (in_lds) {
+      // ================= LDS path: no L2 atomics, no cold gathers of frame f+1 =========
+      float *lx = l_x[cur], *lc = l_c[cur], *nx = l_x[cur ^ 1], *nc = l_c[cur ^ 1];
+      const int tbn = c.tok_off[f + 1];
+      for (int i = tid; i < nt; i += NT) {
+        const float co = c.tok_cost[tb + i];
+        lc[i] = co;
+        float b = INFINITY;
+        if (f == F) {
+          const float fc = finals_empty ? 0.0f : d.g.final[c.tok_state[tb + i]];
+          b = co + fc - final_best;
+        }
+        l_bo[i] = FloatToOrdered(b);
+      }
+      __syncthreads();
+      if (f < F) {
+        const int lb = c.lnk_off[2 * (f + 1)], le = c.lnk_off[2 * (f + 1) + 1];
+        for (int li = lb + tid; li < le; li += NT) {
+          const Link L = c.links[li];
+          if (L.dst < 0) { c.links[li].src = -1; continue; }   // dropped by the exact cutoff
+          float lec = nx[L.dst - tbn] + ((lc[L.src - tb] + L.ac + L.graph) - nc[L.dst - tbn]);
+          if (lec > lattice_beam) { c.links[li].src = -1; continue; }   // excise (:352)
+          if (lec < 0.0f) lec = 0.0f;                                    // :360-364
+          atomicMin(&l_bo[L.src - tb], FloatToOrdered(lec));
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < nt; i += NT) {
+        const u32 b = l_bo[i];
+        float v = OrderedToFloat(b);
+        if (f == F && v > lattice_beam) v = INFINITY;   // :462-463
+        lx[i] = v;
+        l_xo[i] = b;
+      }
+      __syncthreads();
+      if (ee > eb) {
+        for (int iter = 0; iter < 20000; iter++) {
+          for (int li = eb + tid; li < ee; li += NT) {
+            const Link L = c.links[li];
+            float lec = lx[L.dst - tb] + ((lc[L.src - tb] + L.ac + L.graph) - lc[L.dst - tb]);
+            if (lec > lattice_beam) continue;
+            if (lec < 0.0f) lec = 0.0f;
+            atomicMin(&l_xo[L.src - tb], FloatToOrdered(lec));
+          }
+          __syncthreads();
+          int changed = 0;
+          for (int i = tid; i < nt; i += NT) {
+            float v = OrderedToFloat(l_xo[i]);
+            if (f == F && v > lattice_beam) v = INFINITY;
+            if (!(v == lx[i])) changed = 1;
+            lx[i] = v;
+            l_xo[i] = l_bo[i];   // re-arm
+          }
+          if (!__syncthreads_or(changed)) break;
+        }
+        for (int li = eb + tid; li < ee; li += NT) {
+          const Link L = c.links[li];
+          const float lec = lx[L.dst - tb] + ((lc[L.src - tb] + L.ac + L.graph) - lc[L.dst - tb]);
+          if (lec > lattice_beam) c.links[li].src = -1;
+        }
+      }
+      for (int i = tid; i < nt; i += NT) xcur[i] = lx[i];   // the compaction reads extra_cost from HBM
+      __syncthreads();
+      next_in_lds = true;
+      cur ^= 1;
+      continue;
+    }
+    next_in_lds = false;
+    // ================= HBM path (frames larger than FIN_CAP tokens) ======================
     // base term: final-cost term on the last frame (:430), +inf elsewhere (:341)
     for (int i = tid; i < nt; i += NT) {
       float b = INFINITY;
@@ -1068,7 +1149,6 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
       }
     }
     __syncthreads();
-    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
     for (int i = tid; i < nt; i += NT) {
       const u32 b = LoadU32(&bo[i]);
       float v = OrderedToFloat(b);
@@ -1451,6 +1531,9 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   d.lds_table_cap = LDS_TABLE_CAP;
   d.num_pdfs_lds = 0;
   if (kamd::AdvanceLdsBytes(num_pdfs, d.lds_table_cap) + sizeof(kamd::Sh) + 1024 <= 160 * 1024) d.num_pdfs_lds = num_pdfs;
+  if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess)
+    ok = false;
   if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::AdvanceKernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, d.lds_table_cap))) != hipSuccess)
@@ -1570,7 +1653,7 @@ int kamd_decoder_finalize(kamd_decoder *h, const int32_t *lanes, int n, void *st
   hipStream_t st = static_cast<hipStream_t>(stream);
   KAMD_HIP(hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
-  hipLaunchKernelGGL(kamd::FinalizeKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes);
+  hipLaunchKernelGGL(kamd::FinalizeKernel, dim3(n), dim3(NT), 6 * FIN_CAP * 4, st, D->dev, D->d_lanes);
   KAMD_HIP(hipGetLastError());
   D->last_stream = st; D->cached_lane = -1;
   return KAMD_OK;
