@@ -382,6 +382,11 @@ void kamd_pipeline_destroy(kamd_pipeline *p);
 /* Upload a batch of waveforms (host, concatenated; h_wave_off[n_utts+1]). */
 int kamd_pipeline_load_batch(kamd_pipeline *p, const float *waves,
                              const int64_t *h_wave_off, int n_utts);
+/* One ivector per utterance of the resident batch ([n_utts x dim], host), the
+ * `--ivectors` rspecifier of nnet3-latgen-faster (nnet3bin/nnet3-latgen-faster.cc:153-170).
+ * dim = 0 clears them.  Online (per-chunk) ivectors are not supported: their values depend
+ * on the reference's chunk boundaries (nnet-am-decodable-simple.cc:178-212). */
+int kamd_pipeline_set_ivectors(kamd_pipeline *p, const float *ivectors, int dim);
 /* Run the hot path over the resident batch: lanes 0..n_utts-1 hold the results.
  * Blocking; returns 0 or error.  stage_ms[3] = {features, nnet, decode(advance+
  * finalize)} device times from HIP events. */

@@ -102,6 +102,7 @@ def lib():
     sig("kamd_pipeline_create", vp, [vp, vp, vp])
     sig("kamd_pipeline_destroy", None, [vp])
     sig("kamd_pipeline_load_batch", C.c_int, [vp, fp, i64p, C.c_int])
+    sig("kamd_pipeline_set_ivectors", C.c_int, [vp, fp, C.c_int])
     sig("kamd_pipeline_run", C.c_int, [vp, fp])
     sig("kamd_pipeline_get_loglikes", C.c_int, [vp, C.c_int, fp, C.c_int, ip, ip])
     sig("kamd_pipeline_get_features", C.c_int, [vp, C.c_int, fp, C.c_int, ip, ip])
@@ -120,7 +121,7 @@ kamd_decoder_set_options kamd_decoder_reserve kamd_decoder_init kamd_decoder_adv
 kamd_decoder_sync kamd_decoder_num_frames_decoded kamd_decoder_final_relative_cost
 kamd_decoder_reached_final kamd_decoder_lattice_size kamd_decoder_get_raw_lattice
 kamd_decoder_best_path kamd_decoder_partial_best_path kamd_decoder_get_trace kamd_decoder_get_counters
-kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch
+kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch kamd_pipeline_set_ivectors
 kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features""".split()
 
 

@@ -16,8 +16,9 @@ struct Pipeline {
   kamd_feat *feat; kamd_nnet *nnet; kamd_decoder *dec;
   int n_utts = 0, feat_dim = 0, ld_feat = 0, P = 0;
   std::vector<int64_t> wave_off, feat_off, out_off;
-  float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL;
-  size_t waves_cap = 0, feats_cap = 0, ll_cap = 0;
+  float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL, *d_iv = NULL;
+  size_t waves_cap = 0, feats_cap = 0, ll_cap = 0, iv_cap = 0;
+  int iv_dim = 0;
   hipEvent_t ev[5];
 };
 template <typename T>
@@ -51,6 +52,7 @@ void kamd_pipeline_destroy(kamd_pipeline *h) {
   if (p->d_waves) (void)hipFree(p->d_waves);
   if (p->d_feats) (void)hipFree(p->d_feats);
   if (p->d_ll) (void)hipFree(p->d_ll);
+  if (p->d_iv) (void)hipFree(p->d_iv);
   for (int i = 0; i < 5; i++) (void)hipEventDestroy(p->ev[i]);
   delete p;
 }
@@ -76,6 +78,17 @@ int kamd_pipeline_load_batch(kamd_pipeline *h, const float *waves, const int64_t
   return KAMD_OK;
 }
 
+int kamd_pipeline_set_ivectors(kamd_pipeline *h, const float *ivectors, int dim) {
+  Pipeline *p = reinterpret_cast<Pipeline *>(h);
+  if (dim <= 0 || !ivectors) { p->iv_dim = 0; return KAMD_OK; }
+  if (p->n_utts <= 0) return kamd::SetError(KAMD_ERR_STATE, "load the batch before its ivectors");
+  const size_t n = static_cast<size_t>(p->n_utts) * dim;
+  if (kamd::GrowBuf(&p->d_iv, &p->iv_cap, n) != KAMD_OK) return KAMD_ERR_HIP;
+  KAMD_HIP(hipMemcpy(p->d_iv, ivectors, n * sizeof(float), hipMemcpyHostToDevice));
+  p->iv_dim = dim;
+  return KAMD_OK;
+}
+
 int kamd_pipeline_run(kamd_pipeline *h, float stage_ms[4]) {
   Pipeline *p = reinterpret_cast<Pipeline *>(h);
   const int n = p->n_utts;
@@ -86,7 +99,7 @@ int kamd_pipeline_run(kamd_pipeline *h, float stage_ms[4]) {
                                           p->feat_off.data(), p->ld_feat, st);
   if (rc != KAMD_OK) return rc;
   KAMD_HIP(hipEventRecord(p->ev[1], st));
-  rc = kamd_nnet_forward_batch_device(p->nnet, p->d_feats, p->feat_off.data(), p->ld_feat, NULL, n,
+  rc = kamd_nnet_forward_batch_device(p->nnet, p->d_feats, p->feat_off.data(), p->ld_feat, p->iv_dim > 0 ? p->d_iv : NULL, n,
                                       p->d_ll, p->out_off.data(), p->P, st);
   if (rc != KAMD_OK) return rc;
   KAMD_HIP(hipEventRecord(p->ev[2], st));

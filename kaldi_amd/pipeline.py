@@ -73,6 +73,14 @@ class Pipeline:
         flat = np.ascontiguousarray(np.concatenate(keep), np.float32)
         check(lib().kamd_pipeline_load_batch(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), len(keep)))
 
+    def set_ivectors(self, ivectors):
+        """One ivector per (non-skipped) utterance of the loaded batch."""
+        if ivectors is None:
+            check(lib().kamd_pipeline_set_ivectors(self._h, None, 0))
+            return
+        iv = np.ascontiguousarray([v for v, lane in zip(ivectors, self._lane_of) if lane >= 0], np.float32)
+        check(lib().kamd_pipeline_set_ivectors(self._h, abi.fptr(iv), iv.shape[1]))
+
     def run(self):
         ms = np.zeros(4, np.float32)
         if self.n_utts == 0:

@@ -76,3 +76,25 @@ def test_batch_invariance():
     lib().kamd_free(d_out)
     for u in range(3):
         np.testing.assert_array_equal(out[ooff[u]:ooff[u + 1]], single[u])
+
+
+def test_pipeline_with_per_utterance_ivectors():
+    """nnet3-latgen-faster --ivectors: one constant ivector per utterance through the batched
+    pipeline == the single-utterance forward with that ivector == the oracle."""
+    from kaldi_amd import abi, feat, pipeline, synth
+    g = synth.make_hclg(num_units=20, vocab=30, n_hist=6, seed=1)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, ivector_dim=10, output_scale=2.0)
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, abi.decoder_config_recipe(), max_utts=3, max_seconds=3.0)
+    waves = [synth.make_wave(s, seed=i) for i, s in enumerate((0.9, 1.7, 0.4))]
+    rng = np.random.default_rng(4)
+    ivs = rng.standard_normal((3, 10)).astype(np.float32)
+    pipe.load(waves)
+    pipe.set_ivectors(ivs)
+    pipe.run()
+    N = decoder.Nnet(m)
+    for u in range(3):
+        f = pipe.features(u)
+        want = N.Forward(f, ivs[u])
+        np.testing.assert_array_equal(pipe.loglikes(u), want)
+        ref = orc.nnet_forward(m, f, ivs[u])
+        assert np.abs(want - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
