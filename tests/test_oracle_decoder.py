@@ -165,6 +165,23 @@ def test_faithful_vs_canonical_saturated_same_best_path(seed):
     np.testing.assert_array_equal(res[0][2][2], res[1][2][2])
 
 
+def test_intermediate_pruning_is_conservative():
+    """PruneActiveTokens every 25 frames (reference) vs pruning only at the end: same final
+    lattice, also when max-active binds (4 prune passes over 110 frames)."""
+    g = synth.make_hclg(num_units=60, vocab=400, n_hist=80, seed=3, self_loop_prob=0.5, lm_scale=0.1)
+    ll, _, _ = synth.sample_utterance(g, n_words=14, seed=2, peak=3.0, noise=1.3)
+    assert ll.shape[0] > 75
+    lats = []
+    for interval in (25, 1 << 30):
+        cfg = abi.decoder_config_recipe()
+        cfg.max_active, cfg.min_active, cfg.prune_interval = 1500, 100, interval
+        d = orc.Decoder(g, cfg, 0)
+        d.Decode(ll)
+        lats.append(d.GetRawLattice())
+        assert (d.trace()[0] > cfg.max_active).any()
+    assert lattices_equal(lats[0], lats[1]), lattice_diff(lats[0], lats[1])
+
+
 def test_truth_recovered_and_lattice_contains_it():
     g = synth.make_hclg(num_units=40, vocab=120, n_hist=20, seed=5)
     ll, words, pdfs = synth.sample_utterance(g, n_words=8, seed=9, peak=8.0)
