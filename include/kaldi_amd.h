@@ -154,8 +154,15 @@ const float *kamd_online_feat_device_frames(const kamd_online_feat *o, int *ld);
  * (steps/libs/nnet3/xconfig/composite_layers.py:201-215) + the final
  * "-log_prior, *acoustic_scale" (nnet-am-decodable-simple.cc:268-271):
  *
- *   y[t] = ((bn_scale * relu(sum_i W_i x[t + off_i] + W_iv ivec + b) + bn_offset
- *            + bypass_scale * z[t]) + post_offset) * post_scale
+ *   a[t] = bn_scale * relu(sum_i W_i x[t + off_i] + W_iv ivec + b) + bn_offset
+ *            + bypass_scale * z[t]
+ *   if (log_softmax) a[t] -= log(sum_j exp(a[t][j]))
+ *   y[t] = (a[t] + post_offset) * post_scale
+ *
+ * log_softmax = LogSoftmaxComponent (nnet-simple-component.cc:3599,
+ * ApplyLogSoftMaxPerRow) of a non-chain "output" node.  FixedScaleComponent,
+ * PerElementScale/OffsetComponent and test-mode Dropout scale (:3669,2021,2191,
+ * 138-150) are per-element affine maps and go into bn_scale / bn_offset.
  *
  * W is [out_dim x (n_offsets*in_dim + ivector_dim)] row-major, column blocks in
  * time_offsets order (TdnnComponent linear_params_ layout). NULL vectors = absent.
@@ -169,6 +176,7 @@ typedef struct {
   int32_t bypass_layer;   /* -2 = none, -1 = network input, else layer index */
   float bypass_scale;
   int32_t relu;
+  int32_t log_softmax;    /* row log-softmax over out_dim before post_offset */
   const float *W;
   const float *bias;       /* [out_dim] or NULL */
   const float *bn_scale;   /* [out_dim] or NULL */

@@ -83,7 +83,7 @@ class LayerDesc(C.Structure):
     _fields_ = [("in_dim", C.c_int32), ("out_dim", C.c_int32), ("n_offsets", C.c_int32),
                 ("offsets", C.c_int32 * KAMD_MAX_OFFSETS), ("input_layer", C.c_int32),
                 ("ivector_dim", C.c_int32), ("bypass_layer", C.c_int32),
-                ("bypass_scale", C.c_float), ("relu", C.c_int32),
+                ("bypass_scale", C.c_float), ("relu", C.c_int32), ("log_softmax", C.c_int32),
                 ("W", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float)),
                 ("bn_scale", C.POINTER(C.c_float)), ("bn_offset", C.POINTER(C.c_float)),
                 ("post_offset", C.POINTER(C.c_float)), ("post_scale", C.c_float)]

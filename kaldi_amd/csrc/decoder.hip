@@ -63,8 +63,9 @@ struct LaneState {
   int error;
   int finalized;
   float final_relative_cost, final_best_cost;
-  int out_ntok, out_nlink, out_start;
-  int pad;
+  int out_ntok, out_nlink;
+  int out_tok_base, out_lnk_base;   // where the finalized lattice starts inside the lane's arenas
+  int out_cost_in_map, pad;         // staged token costs live in tok_map (FinalizeKernel2)
   long long counters[8];
   unsigned long long phase_cycles[16];   // diagnostic: shader cycles per phase (thread 0)
 };
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
   if (threadIdx.x == 0) {
     S->frame = 0; S->tok_used = 0; S->lnk_used = 0; S->error = 0; S->finalized = 0;
     S->final_relative_cost = INFINITY; S->final_best_cost = INFINITY;
-    S->out_ntok = 0; S->out_nlink = 0; S->out_start = -1;
+    S->out_ntok = 0; S->out_nlink = 0; S->out_tok_base = 0; S->out_lnk_base = 0;
     for (int i = 0; i < 8; i++) S->counters[i] = 0;
     for (int i = 0; i < 16; i++) S->phase_cycles[i] = 0;
     c.tok_off[0] = 0; c.lnk_off[0] = 0; c.lnk_off[1] = 0;
@@ -1251,6 +1252,356 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
     S->final_best_cost = final_best;
     S->final_relative_cost = (best_cost == INFINITY && best_with_final == INFINITY) ? INFINITY : best_with_final - best_cost;
     S->out_ntok = n_out_tok; S->out_nlink = n_out_link;
+    S->out_tok_base = 0; S->out_lnk_base = 0; S->out_cost_in_map = 0;
+    S->error |= sh.err;
+  }
+}
+
+// one slot from a workgroup counter that counts DOWN (staging areas grow from the top of the
+// arena toward the data still to be swept); call under the predicate.
+__device__ inline int WaveAllocDown(int *top) {
+  const u64 m = __ballot(1);
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll(static_cast<long long>(m)) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicSub(top, __popcll(m));
+  base = __shfl(base, leader, 64);
+  return base - 1 - __popcll(m & ((1ull << lane) - 1ull));
+}
+
+struct LinkLite { int src, dst; float graph, ac; };   // what the sweep needs of a Link
+__device__ inline LinkLite Lite(const Link &L) { LinkLite r; r.src = L.src; r.dst = L.dst; r.graph = L.graph; r.ac = L.ac; return r; }
+#define FIN_PF 4                          // links per thread held in registers (one frame ahead)
+#define FIN_TPT ((FIN_CAP + NT - 1) / NT) // tokens per thread held in registers
+
+// FinalizeDecoding, second generation: the same exact backward sweep as FinalizeKernel, with
+//  * the surviving tokens / links of frame f emitted to a staging area as soon as frame f is
+//    final (no marking pass, no separate compaction sweeps over the whole arena).  Staging
+//    grows DOWN from the top of the lane's arenas: after frames F..f it holds at most as many
+//    records as those frames held, so it never reaches data that is still to be swept;
+//  * frame f-1's token costs / states and links loaded into registers while frame f is being
+//    processed (the sweep is a chain of dependent per-frame steps: latency, not bandwidth);
+//  * the epsilon fixpoint iterated in place on one ordered-key array (values only decrease,
+//    so chaotic relaxation reaches the same unique fixpoint as the Jacobi form).
+// Output: tokens in tok_state / tok_map (cost bits) at [out_tok_base, tok_cap), frame by
+// frame; links at [out_lnk_base, lnk_cap) with src/dst = arena positions of the tokens.
+__global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes) {
+  __shared__ Sh sh;
+  __shared__ int s_tok_top, s_lnk_top;
+  const int lane = lanes[blockIdx.x];
+  const Ctx c = MakeCtx(d, lane);
+  const int tid = threadIdx.x;
+  InitSh(&sh);
+  LaneState *S = c.st;
+  if (S->error || S->finalized) return;
+  const int F = S->frame;
+  const float lattice_beam = d.cfg.lattice_beam;
+  float best_cost, best_with_final;
+  FinalCosts(d, c, &sh, F, &best_cost, &best_with_final);
+  const bool finals_empty = best_with_final == INFINITY;                // final_costs_.empty()
+  const float final_best = finals_empty ? best_cost : best_with_final;  // :583-588
+  const u32 INF_O = FloatToOrdered(INFINITY);
+  u32 *bo = reinterpret_cast<u32 *>(c.scratch);                 // HBM mode: base + emitting
+  u32 *xo = reinterpret_cast<u32 *>(c.scratch) + d.hash_cap;    // HBM mode: Jacobi target
+  int *gpos[2] = {c.slot_tok, reinterpret_cast<int *>(c.stamp)}; // HBM mode: frame-local token -> staged position
+  int *new_off = reinterpret_cast<int *>(c.wl0);                 // [F+2] staged start of every frame
+  float *stage_cost = reinterpret_cast<float *>(c.tok_map);
+  extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
+  // LDS: [2] ordered extra costs, [2] forward costs, [2] staged positions (frame f / frame f+1)
+  u32 *l_base = reinterpret_cast<u32 *>(fin_lds);
+  if (tid == 0) { s_tok_top = c.tok_cap; s_lnk_top = c.lnk_cap; new_off[F + 1] = c.tok_cap; }
+  // registers: frame f (cur) and frame f-1 (nxt)
+  LinkLite rl[FIN_PF], nl[FIN_PF];
+  float rc[FIN_TPT], nc_[FIN_TPT];
+  auto prefetch = [&](int f, LinkLite *pl, float *pc) {
+    if (f < 0) return;
+    const int tb = c.tok_off[f], nt = c.tok_off[f + 1] - tb;
+    const int eb = c.lnk_off[2 * f + 1];
+    const int le = f < F ? c.lnk_off[2 * (f + 1) + 1] : c.lnk_off[2 * f + 2];
+#pragma unroll
+    for (int k = 0; k < FIN_TPT; k++) {
+      const int i = tid + k * NT;
+      pc[k] = 0.f;
+      if (i < nt) pc[k] = c.tok_cost[tb + i];
+    }
+#pragma unroll
+    for (int k = 0; k < FIN_PF; k++) {
+      const int li = eb + tid + k * NT;
+      pl[k].src = -1; pl[k].dst = -1; pl[k].graph = 0.f; pl[k].ac = 0.f;
+      if (li < le) {
+        const int2 sd = *reinterpret_cast<const int2 *>(&c.links[li].src);
+        const float2 ga = *reinterpret_cast<const float2 *>(&c.links[li].graph);
+        pl[k].src = sd.x; pl[k].dst = sd.y; pl[k].graph = ga.x; pl[k].ac = ga.y;
+      }
+    }
+  };
+  prefetch(F, rl, rc);
+  __syncthreads();
+  bool prev_lds = false;   // frame f+1 was processed in LDS mode (its x / cost / pos are in LDS)
+  int cur = 0;
+  for (int f = F; f >= 0; f--) {
+    const int tb = c.tok_off[f], nt = c.tok_off[f + 1] - tb;
+    const int tbn = c.tok_off[f + 1], ntn = f < F ? c.tok_off[f + 2] - tbn : 0;
+    if (nt > d.hash_cap) { if (tid == 0) sh.err = ERR_INTERNAL; __syncthreads(); break; }
+    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];       // epsilon links inside frame f
+    const int le = f < F ? c.lnk_off[2 * (f + 1) + 1] : ee;              // emitting links f -> f+1: [ee, le)
+    const float emit_off = c.cost_offsets[f < F ? f : 0];                 // GetRawLattice :173-180 (used for f < F only)
+    prefetch(f - 1, nl, nc_);
+    const int lnk_top0 = s_lnk_top, tok_top0 = s_tok_top;   // uniform: the previous iteration ended with a barrier
+    const bool lds_mode = nt <= FIN_CAP && ntn <= FIN_CAP;
+    const bool next_hbm_mode = f > 0 && ((c.tok_off[f] - c.tok_off[f - 1]) > FIN_CAP || nt > FIN_CAP);
+    int *gp = gpos[f & 1], *gpn = gpos[(f + 1) & 1];
+    if (lds_mode) {
+      u32 *lx = l_base + cur * FIN_CAP, *nx = l_base + (cur ^ 1) * FIN_CAP;
+      float *lc = reinterpret_cast<float *>(l_base + (2 + cur) * FIN_CAP), *nc = reinterpret_cast<float *>(l_base + (2 + (cur ^ 1)) * FIN_CAP);
+      int *lp = reinterpret_cast<int *>(l_base + (4 + cur) * FIN_CAP), *np = reinterpret_cast<int *>(l_base + (4 + (cur ^ 1)) * FIN_CAP);
+      if (f < F && !prev_lds) {   // frame f+1 went through HBM mode: fetch its results
+        for (int i = tid; i < ntn; i += NT) {
+          nx[i] = FloatToOrdered(c.tok_extra[tbn + i]); nc[i] = c.tok_cost[tbn + i]; np[i] = gpn[i];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < FIN_TPT; k++) {
+        const int i = tid + k * NT;
+        if (i < nt) {
+          lc[i] = rc[k];
+          float b = INFINITY;
+          if (f == F) b = rc[k] + (finals_empty ? 0.0f : d.g.final[c.tok_state[tb + i]]) - final_best;   // :430
+          lx[i] = FloatToOrdered(b);
+        }
+      }
+      __syncthreads();
+      // link_extra_cost (:346-350 / :437-441) of a link held as L; x of the last frame reads
+      // as +inf above lattice_beam (:462-463)
+      auto xval = [&](const u32 *arr, int i, bool last) {
+        const float v = OrderedToFloat(arr[i]);
+        return (last && v > lattice_beam) ? INFINITY : v;
+      };
+      auto relax_emit = [&](const LinkLite &L) {
+        if (L.dst < 0) return;                       // dropped by the exact cutoff
+        float lec = xval(nx, L.dst - tbn, false) + ((lc[L.src - tb] + L.ac + L.graph) - nc[L.dst - tbn]);
+        if (lec > lattice_beam) return;              // excised (:352)
+        if (lec < 0.0f) lec = 0.0f;                  // :360-364
+        atomicMin(&lx[L.src - tb], FloatToOrdered(lec));
+      };
+      const int n_reg = min(le - eb, FIN_PF * NT);   // links of this frame held in registers
+#pragma unroll
+      for (int k = 0; k < FIN_PF; k++) {
+        const int li = eb + tid + k * NT;
+        if (li >= ee && li < le) relax_emit(rl[k]);
+      }
+      for (int li = max(ee, eb + n_reg) + tid; li < le; li += NT) relax_emit(Lite(c.links[li]));
+      __syncthreads();
+      if (ee > eb) {
+        const bool last = f == F;
+        auto relax_eps = [&](const LinkLite &L) -> int {
+          float lec = xval(lx, L.dst - tb, last) + ((lc[L.src - tb] + L.ac + L.graph) - lc[L.dst - tb]);
+          if (lec > lattice_beam) return 0;
+          if (lec < 0.0f) lec = 0.0f;
+          const u32 key = FloatToOrdered(lec);
+          return atomicMin(&lx[L.src - tb], key) > key;
+        };
+        for (int iter = 0; iter < 20000; iter++) {
+          int changed = 0;
+#pragma unroll
+          for (int k = 0; k < FIN_PF; k++) {
+            const int li = eb + tid + k * NT;
+            if (li < ee) changed |= relax_eps(rl[k]);
+          }
+          for (int li = eb + n_reg + tid; li < ee; li += NT) changed |= relax_eps(Lite(c.links[li]));
+          if (!__syncthreads_or(changed)) break;
+        }
+      }
+      if (f == F) {   // store the clamped values: later reads need no special case
+        for (int i = tid; i < nt; i += NT) if (OrderedToFloat(lx[i]) > lattice_beam) lx[i] = INF_O;
+        __syncthreads();
+      }
+      // ---- PruneTokensForFrame (:492-511) + staging of the survivors (their HCLG states are
+      // fetched now: a handful per frame).  Staged tokens land in [tok_top - survivors,
+      // tok_top): if that can reach this frame's own records, read -> barrier -> write.
+      const bool tok_slack_ok = tok_top0 - nt >= tbn;
+      {
+        int st[FIN_TPT];
+#pragma unroll
+        for (int k = 0; k < FIN_TPT; k++) {
+          const int i = tid + k * NT;
+          st[k] = 0;
+          if (i < nt && lx[i] != INF_O) st[k] = c.tok_state[tb + i];
+        }
+        if (!tok_slack_ok) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < FIN_TPT; k++) {
+          const int i = tid + k * NT;
+          if (i < nt) {
+            const bool alive = lx[i] != INF_O;
+            int pos = -1;
+            if (alive) { pos = WaveAllocDown(&s_tok_top); c.tok_state[pos] = st[k]; stage_cost[pos] = rc[k]; }
+            lp[i] = pos;
+            if (next_hbm_mode) { c.tok_extra[tb + i] = OrderedToFloat(lx[i]); gp[i] = pos; }
+          }
+        }
+      }
+      __syncthreads();
+      if (tid == 0) new_off[f] = s_tok_top;
+      // ---- surviving links (the same expressions, now on final values), remapped.  A staged
+      // link lands in [lnk_top - survivors, lnk_top); when that cannot reach this frame's own
+      // range (the normal case: the arena has a frame of slack) reads and writes need no
+      // ordering, otherwise every chunk is read -> barrier -> written, top-down.
+      const bool slack_ok = lnk_top0 - (le - eb) >= le;
+      auto survives = [&](const LinkLite &L, bool is_eps) -> bool {
+        if (L.dst < 0) return false;
+        float lec;
+        if (is_eps) lec = OrderedToFloat(lx[L.dst - tb]) + ((lc[L.src - tb] + L.ac + L.graph) - lc[L.dst - tb]);
+        else lec = OrderedToFloat(nx[L.dst - tbn]) + ((lc[L.src - tb] + L.ac + L.graph) - nc[L.dst - tbn]);
+        return !(lec > lattice_beam);
+      };
+      auto stage_link = [&](Link L, bool is_eps) {
+        const int ps2 = lp[L.src - tb], pd = is_eps ? lp[L.dst - tb] : np[L.dst - tbn];
+        if (ps2 < 0 || pd < 0) { sh.err = ERR_INTERNAL; return; }
+        L.src = ps2; L.dst = pd;
+        if (!is_eps) L.ac = L.ac - emit_off;
+        c.links[WaveAllocDown(&s_lnk_top)] = L;
+      };
+      if (slack_ok) {
+        for (int li = eb + n_reg + tid; li < le; li += NT) {
+          const Link L = c.links[li];
+          if (survives(Lite(L), li < ee)) stage_link(L, li < ee);
+        }
+#pragma unroll
+        for (int k = 0; k < FIN_PF; k++) {
+          const int li = eb + tid + k * NT;
+          if (li < le && survives(rl[k], li < ee)) stage_link(c.links[li], li < ee);
+        }
+      } else {
+        for (int hi = le; hi > eb; hi -= NT) {
+          const int li = hi - NT + tid;
+          Link L; L.src = -1; L.dst = -1; L.ilabel = 0; L.olabel = 0; L.graph = 0.f; L.ac = 0.f;
+          const bool in = li >= eb && li < le;
+          if (in) L = c.links[li];
+          __syncthreads();
+          if (in && survives(Lite(L), li < ee)) stage_link(L, li < ee);
+        }
+      }
+      __syncthreads();
+      prev_lds = true;
+      cur ^= 1;
+    } else {
+      // ================= HBM mode (a frame larger than FIN_CAP tokens is involved) =========
+      float *xcur = c.tok_extra + tb;
+      // (if frame f+1 went through LDS mode it has written its extra costs and positions
+      // to HBM: next_hbm_mode was set there)
+      for (int i = tid; i < nt; i += NT) {
+        float b = INFINITY;
+        if (f == F) {
+          const float fc = finals_empty ? 0.0f : d.g.final[c.tok_state[tb + i]];
+          b = c.tok_cost[tb + i] + fc - final_best;
+        }
+        __hip_atomic_store(&bo[i], FloatToOrdered(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      DrainStores();
+      __syncthreads();
+      for (int li = ee + tid; li < le; li += NT) {
+        const Link L = c.links[li];
+        if (L.dst < 0) { c.links[li].src = -1; continue; }
+        float lec = c.tok_extra[L.dst] + ((c.tok_cost[L.src] + L.ac + L.graph) - c.tok_cost[L.dst]);
+        if (lec > lattice_beam) { c.links[li].src = -1; continue; }
+        if (lec < 0.0f) lec = 0.0f;
+        atomicMin(&bo[L.src - tb], FloatToOrdered(lec));
+      }
+      __syncthreads();
+      for (int i = tid; i < nt; i += NT) {
+        const u32 b = LoadU32(&bo[i]);
+        float v = OrderedToFloat(b);
+        if (f == F && v > lattice_beam) v = INFINITY;
+        xcur[i] = v;
+        if (ee > eb) __hip_atomic_store(&xo[i], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      DrainStores();
+      __syncthreads();
+      if (ee > eb) {
+        for (int iter = 0; iter < 20000; iter++) {
+          for (int li = eb + tid; li < ee; li += NT) {
+            const Link L = c.links[li];
+            float lec = xcur[L.dst - tb] + ((c.tok_cost[L.src] + L.ac + L.graph) - c.tok_cost[L.dst]);
+            if (lec > lattice_beam) continue;
+            if (lec < 0.0f) lec = 0.0f;
+            atomicMin(&xo[L.src - tb], FloatToOrdered(lec));
+          }
+          __syncthreads();
+          int changed = 0, dummy = 0;
+          for (int i = tid; i < nt; i += NT) {
+            float v = OrderedToFloat(LoadU32(&xo[i]));
+            if (f == F && v > lattice_beam) v = INFINITY;
+            if (!(v == xcur[i])) changed = 1;
+            xcur[i] = v;
+            __hip_atomic_store(&xo[i], LoadU32(&bo[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+          }
+          DrainStores();
+          BlockSum2(changed, dummy, &sh);
+          if (changed == 0) break;
+        }
+        for (int li = eb + tid; li < ee; li += NT) {
+          const Link L = c.links[li];
+          const float lec = xcur[L.dst - tb] + ((c.tok_cost[L.src] + L.ac + L.graph) - c.tok_cost[L.dst]);
+          if (lec > lattice_beam) c.links[li].src = -1;
+        }
+      }
+      __syncthreads();
+      // ---- staging, top-down in chunks (read -> barrier -> write)
+      for (int hi = nt; hi > 0; hi -= NT) {
+        const int i = hi - NT + tid;
+        bool alive = false; int st = 0; float co = 0.f;
+        if (i >= 0) { alive = xcur[i] != INFINITY; st = c.tok_state[tb + i]; co = c.tok_cost[tb + i]; }
+        __syncthreads();
+        if (i >= 0) {
+          int pos = -1;
+          if (alive) { pos = WaveAllocDown(&s_tok_top); c.tok_state[pos] = st; stage_cost[pos] = co; }
+          gp[i] = pos;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) new_off[f] = s_tok_top;
+      for (int hi = le; hi > eb; hi -= NT) {
+        const int li = hi - NT + tid;
+        Link L; L.src = -1; L.dst = -1; L.ilabel = 0; L.olabel = 0; L.graph = 0.f; L.ac = 0.f;
+        const bool in = li >= eb && li < le;
+        if (in) L = c.links[li];
+        __syncthreads();
+        if (in && L.src >= 0 && L.dst >= 0) {
+          const bool is_eps = li < ee;
+          const int ps2 = gp[L.src - tb];
+          const int pd = is_eps ? gp[L.dst - tb] : gpn[L.dst - tbn];
+          if (ps2 < 0 || pd < 0) { sh.err = ERR_INTERNAL; }
+          else {
+            L.src = ps2; L.dst = pd;
+            if (!is_eps) L.ac = L.ac - emit_off;
+            c.links[WaveAllocDown(&s_lnk_top)] = L;
+          }
+        }
+      }
+      __syncthreads();
+      prev_lds = false;
+    }
+#pragma unroll
+    for (int k = 0; k < FIN_PF; k++) rl[k] = nl[k];
+#pragma unroll
+    for (int k = 0; k < FIN_TPT; k++) rc[k] = nc_[k];
+  }
+  __syncthreads();
+  Stamp(&sh, PH_FIN_SWEEP);
+  const int tok_base = s_tok_top, lnk_base = s_lnk_top;
+  const int n_out_tok = c.tok_cap - tok_base, n_out_link = c.lnk_cap - lnk_base;
+  __syncthreads();
+  for (int f = tid; f <= F + 1; f += NT) c.tok_off[f] = new_off[f] - tok_base;
+  __syncthreads();
+  Stamp(&sh, PH_FIN_COMPACT);
+  if (tid == 0) {
+    for (int i = 0; i < 16; i++) S->phase_cycles[i] += sh.ph[i];
+    S->finalized = 1;
+    S->final_best_cost = final_best;
+    S->final_relative_cost = (best_cost == INFINITY && best_with_final == INFINITY) ? INFINITY : best_with_final - best_cost;
+    S->out_ntok = n_out_tok; S->out_nlink = n_out_link;
+    S->out_tok_base = tok_base; S->out_lnk_base = lnk_base; S->out_cost_in_map = 1;
     S->error |= sh.err;
   }
 }
@@ -1531,8 +1882,10 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   d.lds_table_cap = LDS_TABLE_CAP;
   d.num_pdfs_lds = 0;
   if (kamd::AdvanceLdsBytes(num_pdfs, d.lds_table_cap) + sizeof(kamd::Sh) + 1024 <= 160 * 1024) d.num_pdfs_lds = num_pdfs;
-  if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess)
+  if (ok && (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess ||
+             hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel2),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess))
     ok = false;
   if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::AdvanceKernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1653,7 +2006,10 @@ int kamd_decoder_finalize(kamd_decoder *h, const int32_t *lanes, int n, void *st
   hipStream_t st = static_cast<hipStream_t>(stream);
   KAMD_HIP(hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
-  hipLaunchKernelGGL(kamd::FinalizeKernel, dim3(n), dim3(NT), 6 * FIN_CAP * 4, st, D->dev, D->d_lanes);
+  // KAMD_FINALIZE_V1=1 selects the first-generation kernel (mark, then compact in place)
+  static const bool v1 = getenv("KAMD_FINALIZE_V1") != NULL && getenv("KAMD_FINALIZE_V1")[0] == '1';
+  if (v1) hipLaunchKernelGGL(kamd::FinalizeKernel, dim3(n), dim3(NT), 6 * FIN_CAP * 4, st, D->dev, D->d_lanes);
+  else hipLaunchKernelGGL(kamd::FinalizeKernel2, dim3(n), dim3(NT), 6 * FIN_CAP * 4, st, D->dev, D->d_lanes);
   KAMD_HIP(hipGetLastError());
   D->last_stream = st; D->cached_lane = -1;
   return KAMD_OK;
@@ -1764,13 +2120,15 @@ static int FetchLattice(Decoder *D, int lane) {
   if (!S.finalized) return kamd::SetError(KAMD_ERR_STATE, "lane %d: call kamd_decoder_finalize + kamd_decoder_sync first", lane);
   const int nt = S.out_ntok, nl = S.out_nlink, F = S.frame;
   const size_t mf = D->sizes.max_frames;
-  const long long tbase = D->h_tok_base[lane], lbase = D->h_lnk_base[lane];
+  const long long tbase = D->h_tok_base[lane] + S.out_tok_base, lbase = D->h_lnk_base[lane] + S.out_lnk_base;
   std::vector<int> st(nt), toff(F + 2);
   std::vector<float> co(nt);
   std::vector<kamd::Link> lk(nl);
   if (nt) {
     KAMD_HIP(hipMemcpy(st.data(), D->dev.tok_state + tbase, nt * 4, hipMemcpyDeviceToHost));
-    KAMD_HIP(hipMemcpy(co.data(), D->dev.tok_cost + tbase, nt * 4, hipMemcpyDeviceToHost));
+    const void *cost_src = S.out_cost_in_map ? static_cast<const void *>(D->dev.tok_map + tbase)
+                                             : static_cast<const void *>(D->dev.tok_cost + tbase);
+    KAMD_HIP(hipMemcpy(co.data(), cost_src, nt * 4, hipMemcpyDeviceToHost));
   }
   KAMD_HIP(hipMemcpy(toff.data(), D->dev.tok_off + lane * (mf + 2), (F + 2) * 4, hipMemcpyDeviceToHost));
   if (nl) KAMD_HIP(hipMemcpy(lk.data(), D->dev.links + lbase, nl * sizeof(kamd::Link), hipMemcpyDeviceToHost));
@@ -1810,7 +2168,9 @@ static int FetchLattice(Decoder *D, int lane) {
   D->lat_arcs.resize(nl);
   for (int i = 0; i < nl; i++) {
     kamd_lat_arc a;
-    a.src = inv[lk[i].src]; a.dst = inv[lk[i].dst]; a.ilabel = lk[i].ilabel; a.olabel = lk[i].olabel;
+    const int ls = lk[i].src - S.out_tok_base, ld = lk[i].dst - S.out_tok_base;
+    if (ls < 0 || ls >= nt || ld < 0 || ld >= nt) return kamd::SetError(KAMD_ERR_STATE, "lane %d: lattice link %d out of range", lane, i);
+    a.src = inv[ls]; a.dst = inv[ld]; a.ilabel = lk[i].ilabel; a.olabel = lk[i].olabel;
     a.graph_cost = lk[i].graph; a.acoustic_cost = lk[i].ac;
     D->lat_arcs[i] = a;
   }

@@ -152,6 +152,29 @@ __global__ __launch_bounds__(256) void TdnnGemmKernel(GemmArgs p) {
     }
 }
 
+// LogSoftmaxComponent::Propagate = ApplyLogSoftMaxPerRow (nnet-simple-component.cc:3599;
+// matrix/kaldi-vector.cc:876-884) fused with DecodableNnetSimple's "-log_prior, *scale"
+// (nnet-am-decodable-simple.cc:268-271): one wavefront per row, the row (<= 24 KB) was just
+// written by the GEMM and is read back from L2.  HBM-trivial: 2 x 4 B per element.
+__global__ __launch_bounds__(256) void LogSoftmaxRowsKernel(float *C, int ldC, int M, int N,
+                                                            const float *post_offset, float post_scale) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float *x = C + static_cast<size_t>(row) * ldC;
+  float mx = -INFINITY;
+  for (int n = lane; n < N; n += 64) mx = fmaxf(mx, x[n]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int n = lane; n < N; n += 64) sum += expf(x[n] - mx);
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float lse = logf(sum);
+  for (int n = lane; n < N; n += 64) {
+    float v = (x[n] - mx) - lse;
+    if (post_offset) v += post_offset[n];
+    x[n] = v * post_scale;
+  }
+}
+
 // Per-utterance time grids -> row maps.  Row r of layer l (utterance u, k-th row) is
 // time t = lo_l + k*step_l; its operand for offset o lives at producer row
 // (t + o - lo_p)/step_p of the same utterance, or, for the network input, at feature
@@ -202,7 +225,7 @@ __global__ void IvecBiasKernel(const float *Wiv, const float *ivec, int N, int D
 // ------------------------------------------------------------------ host
 struct LayerDev {
   int in_dim, out_dim, in_pad, out_pad, n_off, offs[KAMD_MAX_OFFSETS];
-  int input_layer, bypass_layer, ivector_dim, relu;
+  int input_layer, bypass_layer, ivector_dim, relu, log_softmax;
   float bypass_scale, post_scale;
   float *W = NULL, *Wiv = NULL, *bias = NULL, *bn_scale = NULL, *bn_offset = NULL, *post_offset = NULL;
   int N_pad;
@@ -312,7 +335,7 @@ kamd_nnet *kamd_nnet_create(const kamd_layer_desc *layers, int n_layers, int inp
     l.out_pad = kamd::RoundUp(s.out_dim, 16); l.n_off = s.n_offsets;
     for (int o = 0; o < s.n_offsets; o++) l.offs[o] = s.offsets[o];
     l.input_layer = s.input_layer; l.bypass_layer = s.bypass_layer; l.ivector_dim = s.ivector_dim;
-    l.relu = s.relu; l.bypass_scale = s.bypass_scale; l.post_scale = s.post_scale;
+    l.relu = s.relu; l.log_softmax = s.log_softmax; l.bypass_scale = s.bypass_scale; l.post_scale = s.post_scale;
     l.N_pad = kamd::RoundUp(s.out_dim, 128);
     const int Ksrc = s.n_offsets * s.in_dim + s.ivector_dim, Kp = s.n_offsets * l.in_pad;
     std::vector<float> Wp(static_cast<size_t>(l.N_pad) * Kp, 0.0f);
@@ -481,7 +504,7 @@ int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int
       else { g.byp = nn->act[L.bypass_layer]; g.ld_byp = nn->L[L.bypass_layer].out_pad; }
       g.bypmap = bypmap; g.bypass_scale = L.bypass_scale;
     }
-    g.post_offset = L.post_offset; g.post_scale = L.post_scale;
+    g.post_offset = L.log_softmax ? NULL : L.post_offset; g.post_scale = L.log_softmax ? 1.0f : L.post_scale;
     g.C = C + row_base * ldC; g.ldC = ldC;
     // tile choice: a narrow layer (bottleneck / prefinal, N <= 160) is ONE column tile as
     // wide as the layer, so the (large) A operand is streamed exactly once; wide layers use
@@ -500,6 +523,9 @@ int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int
       dim3 grid(kamd::CeilDiv(L.out_dim, 128), kamd::CeilDiv(Ml, 128));
       hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 128, 2, 2>), grid, dim3(256), 0, st, g);
     }
+    if (L.log_softmax)
+      hipLaunchKernelGGL(kamd::LogSoftmaxRowsKernel, dim3(kamd::CeilDiv(Ml, 4)), dim3(256), 0, st, g.C, g.ldC,
+                         static_cast<int>(Ml), L.out_dim, L.post_offset, L.post_scale);
     KAMD_HIP(hipGetLastError());
     if (d_tmp_off) { KAMD_HIP(hipStreamSynchronize(st)); KAMD_HIP(hipFree(d_tmp_off)); }
     flops += 2.0 * static_cast<double>(Ml) * L.out_dim * (L.n_off * L.in_dim + L.ivector_dim);

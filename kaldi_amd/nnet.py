@@ -32,6 +32,7 @@ class Layer:
     ivector_dim: int = 0
     post_offset: Optional[np.ndarray] = None
     post_scale: float = 1.0
+    log_softmax: bool = False     # LogSoftmaxComponent on the output node (non-chain models)
 
 
 @dataclass
@@ -61,6 +62,7 @@ class Model:
                     setattr(l, nm, a)
                 setattr(d, nm, abi.fptr(a))
             d.post_scale = l.post_scale
+            d.log_softmax = int(l.log_softmax)
         self._keep.append(arr)
         return arr
 

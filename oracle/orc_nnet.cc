@@ -20,6 +20,7 @@
 //   -log_priors, *acoustic_scale  nnet3/nnet-am-decodable-simple.cc:268-271
 //   edge clamping of input frames nnet3/nnet-am-decodable-simple.cc:147-160
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <unordered_map>
@@ -70,6 +71,17 @@ struct Eval {
       if (l.relu && acc < 0.0f) acc = 0.0f;
       if (l.bn_scale) acc = acc * l.bn_scale[o] + l.bn_offset[o];
       if (z) acc += l.bypass_scale * z[o];
+      y[o] = acc;
+    }
+    if (l.log_softmax) {   // VectorBase::ApplyLogSoftMax (matrix/kaldi-vector.cc:876-884), per row
+      float mx = y[0], sum = 0.0f;
+      for (int o = 1; o < l.out_dim; o++) mx = std::max(mx, y[o]);
+      for (int o = 0; o < l.out_dim; o++) sum += expf((y[o] -= mx));
+      sum = logf(sum);
+      for (int o = 0; o < l.out_dim; o++) y[o] -= sum;
+    }
+    for (int o = 0; o < l.out_dim; o++) {
+      float acc = y[o];
       if (l.post_offset) acc += l.post_offset[o];
       acc *= l.post_scale;
       y[o] = acc;

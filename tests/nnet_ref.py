@@ -33,6 +33,9 @@ def forward_f64(model, feats, ivector=None):
             y = y * l.bn_scale.astype(np.float64) + l.bn_offset.astype(np.float64)
         if l.bypass_layer != -2:
             y = y + l.bypass_scale * acts[l.bypass_layer]
+        if getattr(l, 'log_softmax', False):
+            m = y.max(axis=1, keepdims=True)
+            y = y - (m + np.log(np.exp(y - m).sum(axis=1, keepdims=True)))
         if l.post_offset is not None:
             y = y + l.post_offset.astype(np.float64)
         y = y * l.post_scale

@@ -163,6 +163,78 @@ def test_midsize_graph_saturated(seed):
     assert (o.trace()[0] > 2000).any()
 
 
+def _mixed_load(g):
+    """frames of tens of thousands of tokens (flat scores) alternating with frames of a few
+    tokens (sharply peaked scores): both finalize modes and both transitions between them"""
+    a = synth.random_loglikes(12, g.num_pdfs, seed=1, scale=0.6)
+    u, _, _ = synth.sample_utterance(g, n_words=3, seed=2, peak=9.0, noise=0.5)
+    b = synth.random_loglikes(12, g.num_pdfs, seed=3, scale=0.6)
+    return np.concatenate([a, u[:14], b, u[14:24], a[:6]]).astype(np.float32)
+
+
+def test_finalize_frames_larger_than_lds_working_set():
+    g = synth.make_hclg(num_units=200, vocab=3000, n_hist=300, fanout=(10, 60), seed=0)
+    ll = _mixed_load(g)
+    cfg = abi.decoder_config_recipe()
+    cfg.max_active = 30000
+    d, o = run_both(g, ll, cfg, sizes(hash_cap=1 << 16, toks=1 << 21, links=1 << 23))
+    ntok = o.trace()[0]
+    assert ntok.max() > 20000 and ntok[15:25].max() < 1000
+    assert_same(d, o)
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_finalize_with_no_slack_in_the_arenas(big):
+    """Finalize stages the surviving lattice from the top of the arenas downward; it must
+    stay exact when the arenas are only just large enough for the decode itself."""
+    from kaldi_amd._lib import KamdError
+    if big:
+        g = synth.make_hclg(num_units=200, vocab=3000, n_hist=300, fanout=(10, 60), seed=0)
+        ll = _mixed_load(g)[:30]
+        cfg = abi.decoder_config_recipe()
+        cfg.max_active = 30000
+        hc = 1 << 16
+    else:
+        g = synth.make_hclg(num_units=24, vocab=60, n_hist=12, seed=4)
+        ll = synth.random_loglikes(30, g.num_pdfs, seed=5, scale=0.4)   # nearly everything survives
+        cfg = abi.decoder_config_recipe()
+        hc = 1 << 14
+    G = decoder.Graph(g)
+
+    def fits(toks, links):
+        d = decoder.LatticeFasterDecoder(G, cfg, sizes(hash_cap=hc, toks=toks, links=links))
+        try:
+            d.Decode(ll)
+        except KamdError:
+            return None
+        return d
+
+    def smallest(f, lo, hi):        # smallest size in (lo, hi] for which f(size) succeeds
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if f(mid) is not None:
+                hi = mid
+            else:
+                lo = mid
+        return hi
+
+    T, L = 1 << 21, 1 << 23
+    assert fits(T, L) is not None
+    t_min = smallest(lambda t: fits(t, L), 0, T)
+    l_min = smallest(lambda l: fits(t_min, l), 0, L)
+    # the number of candidate links a frame records depends on the order in which the running
+    # cutoff tightens (not on the result), so the link threshold moves a little run to run
+    d = None
+    for extra in range(0, 2048, 32):
+        d = fits(t_min, l_min + extra)
+        if d is not None:
+            break
+    assert d is not None and fits(t_min - 1, L) is None
+    o = orc.Decoder(g, cfg, 1)
+    o.Decode(ll)
+    assert_same(d, o)
+
+
 def test_pipeline_ragged_batch_with_empty_and_tiny_utterances():
     """Ragged batch: empty waveform, one shorter than a frame, a one-frame utterance, and
     normal ones; the short ones are skipped (None), the rest decode as if alone."""

@@ -36,6 +36,16 @@ def test_odd_dims_padding():
     check(m, 64, 3)
 
 
+@pytest.mark.parametrize("P", [33, 2328])
+def test_log_softmax_output(P):
+    m = nnet.tdnnf_tiny(num_pdfs=P, seed=5)
+    m.layers[-1].log_softmax = True
+    got = check(m, 91, 6)
+    out = m.layers[-1]
+    lp = got / out.post_scale - out.post_offset
+    np.testing.assert_allclose(np.exp(lp.astype(np.float64)).sum(axis=1), 1.0, atol=1e-3)
+
+
 def test_context_and_plan():
     m = nnet.tdnnf_mini_librispeech(num_pdfs=64)
     n = decoder.Nnet(m)

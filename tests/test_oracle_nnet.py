@@ -24,6 +24,22 @@ def test_oracle_nnet_vs_f64(T, ivec):
     assert np.abs(got - ref).max() < 2e-4 * scale
 
 
+def test_oracle_log_softmax_output():
+    """LogSoftmaxComponent on the output node (non-chain models): rows are normalised
+    before -log(prior) and the acoustic scale are applied."""
+    m = nnet.tdnnf_tiny(num_pdfs=61, seed=4)
+    out = m.layers[-1]
+    out.log_softmax = True
+    rng = np.random.default_rng(0)
+    feats = rng.standard_normal((40, m.input_dim)).astype(np.float32) * 3
+    got = orc.nnet_forward(m, feats)
+    ref = forward_f64(m, feats)
+    assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max()
+    # undo "(+post_offset) * post_scale": what is left must be a normalised distribution
+    lp = got / out.post_scale - out.post_offset
+    np.testing.assert_allclose(np.exp(lp.astype(np.float64)).sum(axis=1), 1.0, atol=1e-4)
+
+
 def test_context_matches_recipe_topologies():
     """ComputeSimpleNnetContext: 1 + 3*1 + 0 + 12*3 = 40 for run_tdnn_1d."""
     assert nnet.tdnnf_librispeech(num_pdfs=16).context() == (40, 40)
