@@ -133,6 +133,10 @@ struct Sh {  // workgroup-shared state
   int sel_bin, sel_below;
   int scan_total;
   int big_total;
+  // per-lane running state mirrored in LDS (the global copies are written for the host and
+  // for the next launch; reading them back every frame would be an L2 round trip each)
+  int cur_tb, cur_n;     // newest token list: first token, count
+  int lnk_used; u32 round;
   long long cnt[8];
   unsigned long long ph[16];
   unsigned long long t_prev;
@@ -158,6 +162,17 @@ __device__ inline u32 LoadU32(const u32 *p) {  // for words updated by L2 atomic
 }
 // all of this wavefront's stores have reached L2 (write-through) before it continues
 __device__ inline void DrainStores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Workgroup barrier that orders LDS accesses only: s_waitcnt lgkmcnt(0) + s_barrier.  A plain
+// __syncthreads() is also a release of the wave's GLOBAL stores, i.e. s_waitcnt vmcnt(0) —
+// which on gfx9 drains every outstanding load too (one counter): register prefetches and
+// fire-and-forget stores would be waited for at every barrier.  Use only where no thread reads
+// global data another thread of the workgroup wrote since the last full barrier.
+__device__ inline void LdsBarrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ inline u32 HashState(int s, int mask) {
   return (static_cast<u32>(s) * 2654435761u >> 7) & static_cast<u32>(mask);
 }
@@ -195,32 +210,36 @@ __device__ inline u64 BlockMin64(u64 v, Sh *sh) {
   for (int i = 1; i < NWAVES; i++) r = sh->red64[i] < r ? sh->red64[i] : r;
   return r;
 }
+template <bool kLdsOnly = false> __device__ inline void Bar() { if (kLdsOnly) LdsBarrier(); else __syncthreads(); }
+template <bool kLdsOnly = false>
 __device__ inline void BlockSum2(int &a, int &b, Sh *sh) {
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-  __syncthreads();
+  Bar<kLdsOnly>();
   if ((threadIdx.x & 63) == 0) { sh->redi[threadIdx.x >> 6] = a; sh->redj[threadIdx.x >> 6] = b; }
-  __syncthreads();
+  Bar<kLdsOnly>();
   a = 0; b = 0;
   for (int i = 0; i < NWAVES; i++) { a += sh->redi[i]; b += sh->redj[i]; }
 }
+template <bool kLdsOnly = false>
 __device__ inline void BlockSum4(int &a, int &b, int &c2, int &d2, Sh *sh) {
   for (int o = 32; o > 0; o >>= 1) {
     a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c2 += __shfl_xor(c2, o, 64); d2 += __shfl_xor(d2, o, 64);
   }
-  __syncthreads();
+  Bar<kLdsOnly>();
   if ((threadIdx.x & 63) == 0) {
     const int w = threadIdx.x >> 6;
     sh->redi[w] = a; sh->redj[w] = b; sh->redk[w] = c2; sh->redl[w] = d2;
   }
-  __syncthreads();
+  Bar<kLdsOnly>();
   a = 0; b = 0; c2 = 0; d2 = 0;
   for (int i = 0; i < NWAVES; i++) { a += sh->redi[i]; b += sh->redj[i]; c2 += sh->redk[i]; d2 += sh->redl[i]; }
 }
+template <bool kLdsOnly = false>
 __device__ inline float BlockMinF(float v, Sh *sh) {
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-  __syncthreads();
+  Bar<kLdsOnly>();
   if ((threadIdx.x & 63) == 0) sh->redf[threadIdx.x >> 6] = v;
-  __syncthreads();
+  Bar<kLdsOnly>();
   float r = sh->redf[0];
   for (int i = 1; i < NWAVES; i++) r = fminf(r, sh->redf[i]);
   return r;
@@ -558,7 +577,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
   }
   __syncthreads();
   int cur = 0;
-  u32 round = S->round;
+  u32 round = sh->round;
   while (sh->wl_n[cur] > 0) {   // uniform
     round++;
     const int nw = sh->wl_n[cur];
@@ -590,16 +609,16 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
     const int err_now = sh->err;   // read between two barriers: uniform
     if (tid == 0) sh->wl_n[cur] = 0;
     cur ^= 1;
-    __syncthreads();
+    LdsBarrier();
     if (err_now) break;
   }
   if (tid == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; }
-  __syncthreads();
+  LdsBarrier();
   Stamp(sh, PH_EPS_CLOSURE);
   // ---- compaction: tokens with final cost <= cutoff become list 'list' (arena order is
   // the allocation order; lattices are canonicalised by (frame, state) on the host).
   // The same sweep finds the list's best token for the NEXT frame's GetCutoff.
-  const int tok_base = c.tok_off[list];
+  const int tok_base = sh->cur_tb + sh->cur_n;   // == c.tok_off[list]
   const int ns = min(sh->n_slots, d.hash_cap);
   u64 kmin = EMPTY64;
   for (int i = tid; i < ns; i += NT) {
@@ -639,7 +658,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
   }
   // ---- epsilon links of the surviving tokens (final costs), :875-897: dense over the
   // tokens that own epsilon arcs (collected during compaction)
-  const int eps_link_begin = c.lnk_off[2 * list + 1];
+  const int eps_link_begin = emit_link_begin + min(sh->n_links, c.lnk_cap - emit_link_begin);   // == c.lnk_off[2 * list + 1]
   int a_eps = 0, c_lt = 0, c_le = 0;
   {
     const int ne = min(sh->wl_n[1], d.hash_cap);
@@ -670,7 +689,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
     const float w = i < cache_cap ? cost_cache[i] : c.tok_cost[tok_base + i];
     c_lt += w < next_beam_cutoff; c_le += w <= next_beam_cutoff;
   }
-  __syncthreads();
+  LdsBarrier();
   Stamp(sh, PH_EPS_LINKS);
   // ---- clear the table, publish offsets and counters
   for (int i = tid; i < ns; i += NT) {
@@ -679,7 +698,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
     else __hip_atomic_store(&c.H[sl - tbl.lcap], EMPTY64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   DrainStores();   // the next frame's CAS / atomicMin must find the cleared words in L2
-  BlockSum4(k_surv, a_eps, c_lt, c_le, sh);
+  BlockSum4<true>(k_surv, a_eps, c_lt, c_le, sh);
   if (tid == 0) {
     const int n_eps_links = min(sh->wl_n[0], c.lnk_cap - eps_link_begin);
     c.tok_off[list + 1] = tok_base + n_new;
@@ -687,6 +706,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
     S->tok_used = tok_base + n_new;
     S->lnk_used = eps_link_begin + n_eps_links;
     S->round = round;
+    sh->round = round; sh->lnk_used = eps_link_begin + n_eps_links; sh->cur_tb = tok_base; sh->cur_n = n_new;
     sh->cnt[1] += a_eps;                 // A_exp: epsilon arcs of surviving tokens
     sh->cnt[3] += k_surv;                // K_surv
     sh->cnt[4] += k_surv + n_eps_links;  // L_kept
@@ -694,7 +714,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
     sh->best_key = kmin; sh->c_lt = c_lt; sh->c_le = c_le;
     sh->n_slots = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->n_new = 0;
   }
-  __syncthreads();
+  LdsBarrier();
   Stamp(sh, PH_CLEAR);
 }
 
@@ -753,6 +773,7 @@ __device__ inline void InitSh(Sh *sh) {
   if (threadIdx.x == 0) {
     sh->n_slots = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
     sh->bigcnt = 0; sh->n_new = 0; sh->best_key = EMPTY64; sh->c_lt = 0; sh->c_le = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
+    sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0;
     for (int i = 0; i < 8; i++) sh->cnt[i] = 0;
     for (int i = 0; i < 16; i++) sh->ph[i] = 0;
     sh->t_prev = __builtin_amdgcn_s_memtime();
@@ -782,6 +803,7 @@ __global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
     for (int i = 0; i < 8; i++) S->counters[i] = 0;
     for (int i = 0; i < 16; i++) S->phase_cycles[i] = 0;
     c.tok_off[0] = 0; c.lnk_off[0] = 0; c.lnk_off[1] = 0;
+    sh.round = S->round;   // stamps persist across utterances: never reset
     bool imp;
     HashInsert(d, c, &sh, d.g.start_flagged, 0.0f, &imp, 0);
   }
@@ -814,11 +836,23 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
   int frame = S->frame;
   if (S->error || S->finalized) return;
   const kamd_decoder_config cfg = d.cfg;
+  if (tid == 0) {
+    sh.cur_tb = c.tok_off[frame]; sh.cur_n = c.tok_off[frame + 1] - c.tok_off[frame];
+    sh.lnk_used = S->lnk_used; sh.round = S->round;
+  }
+  constexpr int LLPF = 3;                         // row entries per thread held in registers
+  const bool ll_pf = d.num_pdfs_lds > 0 && d.num_pdfs_lds <= LLPF * NT;
+  float llp[LLPF];
+#pragma unroll
+  for (int k = 0; k < LLPF; k++) {
+    const int i = tid + k * NT;
+    llp[k] = (ll_pf && task.n_frames > 0 && i < d.num_pdfs_lds) ? task.d_loglikes[i] : 0.f;
+  }
   ComputeFrameStats(d, c, &sh, frame, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
   for (int it = 0; it < task.n_frames; it++, frame++) {
     if (frame >= d.max_frames) { if (tid == 0) sh.err = ERR_FRAMES; __syncthreads(); break; }
     const float *ll = task.d_loglikes + static_cast<size_t>(it) * task.ld;
-    const int tb = c.tok_off[frame], n = c.tok_off[frame + 1] - tb;
+    const int tb = sh.cur_tb, n = sh.cur_n;   // == c.tok_off[frame], c.tok_off[frame + 1] - tb
     const float *cost = c.tok_cost + tb;
     const int *state = c.tok_state + tb;
     // ---- GetCutoff (:657-724).  The best token (ties -> smallest state, as oracle mode 1)
@@ -828,7 +862,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     const int c_lt = sh.c_lt, c_le = sh.c_le;
     float *cost_cache = reinterpret_cast<float *>(dyn_lds);
     const bool cached = n <= 3 * BIGCAP;
-    __syncthreads();   // everyone has read the stats before a select may reuse Sh scratch
+    LdsBarrier();   // everyone has read the stats before a select may reuse Sh scratch
     float best = INFINITY; int best_state = -1;
     if (n > 0) { best = OrderedToFloat(static_cast<u32>(key >> 32)); best_state = static_cast<int>(key & 0xFFFFFFFFu); }
     float cur_cutoff, adaptive_beam;
@@ -855,19 +889,30 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
         else { adaptive_beam = cfg.beam; cur_cutoff = beam_cutoff; }
       }
     }
-    __syncthreads();
+    LdsBarrier();
     Stamp(&sh, PH_CUTOFF);
     // ---- cost offset + seed of next_cutoff from the best token's arcs (:757-772)
     const float cost_offset = (n > 0) ? -best : 0.0f;
     if (tid == 0) {
       c.cost_offsets[frame] = cost_offset;
       c.trace_ntok[frame] = n; c.trace_cutoff[frame] = cur_cutoff;
-      c.lnk_off[2 * (frame + 1)] = S->lnk_used;
+      c.lnk_off[2 * (frame + 1)] = sh.lnk_used;
     }
-    // stage the frame's log-likelihood row in LDS: every expanded arc gathers from it
-    for (int i = tid; i < d.num_pdfs_lds; i += NT) ll_lds[i] = ll[i];
+    // stage the frame's log-likelihood row in LDS: every expanded arc gathers from it.  The
+    // row was loaded into registers one frame ago (a cold 9 KB HBM read off the critical path)
+    if (ll_pf) {
+#pragma unroll
+      for (int k = 0; k < LLPF; k++) { const int i = tid + k * NT; if (i < d.num_pdfs_lds) ll_lds[i] = llp[k]; }
+      if (it + 1 < task.n_frames) {
+        const float *lln = ll + task.ld;
+#pragma unroll
+        for (int k = 0; k < LLPF; k++) { const int i = tid + k * NT; if (i < d.num_pdfs_lds) llp[k] = lln[i]; }
+      }
+    } else {
+      for (int i = tid; i < d.num_pdfs_lds; i += NT) ll_lds[i] = ll[i];
+    }
     LlRow row; row.g = ll; row.l = (lds_cfloat *)ll_lds; row.n_lds = d.num_pdfs_lds;
-    __syncthreads();
+    LdsBarrier();
     if (n > 0) {
       const u32 a0 = d.g.off[best_state].x, a1 = d.g.off[best_state + 1].x;
       float seed = INFINITY;
@@ -875,12 +920,12 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
         const float new_weight = d.g.e_arcs[a].weight + cost_offset - LogLikePdf(row, d.e_pdf[a]) + best;
         seed = fminf(seed, new_weight + adaptive_beam);
       }
-      seed = BlockMinF(seed, &sh);
+      seed = BlockMinF<true>(seed, &sh);
       if (tid == 0) sh.next_cutoff_u = FloatToOrdered(seed);
     } else if (tid == 0) sh.next_cutoff_u = FloatToOrdered(INFINITY);
-    __syncthreads();
+    LdsBarrier();
     Stamp(&sh, PH_SEED);
-    const int link_base = S->lnk_used;
+    const int link_base = sh.lnk_used;
     // ---- ProcessEmitting (:783-815).  Tokens with <= SMALL_DEG arcs are expanded by
     // their own thread; the rest (LM hubs, trie fan-outs) are queued and expanded
     // ARC-parallel: a workgroup scan of the degrees flattens the queue so that thread j
@@ -915,9 +960,9 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
       }
       const bool last_chunk = base + NT >= n;
       if (n <= BIGCAP && !last_chunk) continue;    // the queue cannot overflow: flush once (uniform)
-      __syncthreads();
+      LdsBarrier();
       const int nb = sh.bigcnt;                    // uniform: read between two barriers
-      __syncthreads();
+      LdsBarrier();
       if (nb > 0 && (nb > BIGCAP - NT || last_chunk)) {
         Stamp(&sh, PH_EXPAND);
         // exclusive scan of the queued degrees (3 entries per thread)
@@ -930,16 +975,16 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
         int incl = mine;
         const int lane = tid & 63, w = tid >> 6;
         for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        __syncthreads();
+        LdsBarrier();
         if (lane == 63) sh.redi[w] = incl;
-        __syncthreads();
+        LdsBarrier();
         int wbase = 0, total = 0;
         for (int k = 0; k < NWAVES; k++) { int cnum = sh.redi[k]; if (k < w) wbase += cnum; total += cnum; }
         const int excl = wbase + incl - mine;
         if (e0 < nb) big_scan[e0] = excl;
         if (e0 + 1 < nb) big_scan[e0 + 1] = excl + v0;
         if (e0 + 2 < nb) big_scan[e0 + 2] = excl + v0 + v1;
-        __syncthreads();
+        LdsBarrier();
         {
           // owner of the first arc of every 16-arc chunk, computed once per batch.  Queued
           // tokens have >= 5 arcs, so at most 4 of them start inside a chunk: the per-arc
@@ -954,7 +999,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
             chunk_owner[cidx] = lo;
           }
-          __syncthreads();
+          LdsBarrier();
           auto lookup = [&](int j, u32 *a, int *i2) {
             const int cidx = j >> 4;
             int e;
@@ -992,23 +1037,23 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
             ProcessArcs<ARCW>(d, c, &sh, tbl, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base);
           }
         }
-        __syncthreads();
+        LdsBarrier();
         if (tid == 0) sh.bigcnt = 0;
-        __syncthreads();
+        LdsBarrier();
         Stamp(&sh, PH_EXPAND_BIG);
       }
     }
-    __syncthreads();
+    LdsBarrier();
     Stamp(&sh, PH_EXPAND);
     {
       int ne = n_exp, ae = static_cast<int>(a_emit);
-      BlockSum2(ne, ae, &sh);
+      BlockSum2<true>(ne, ae, &sh);
       if (tid == 0) {
         sh.cnt[0] += ne; sh.cnt[1] += ae; sh.cnt[2] += ae; sh.cnt[6] += 1;
-        c.lnk_off[2 * (frame + 1) + 1] = link_base + min(sh.n_links, c.lnk_cap - link_base);
+        c.lnk_off[2 * (frame + 1) + 1] = link_base + min(sh.n_links, c.lnk_cap - link_base);   // for finalize / the host
       }
     }
-    __syncthreads();
+    __syncthreads();   // FULL barrier: InsertEmitted reads the links other threads recorded (global)
     const float next_cutoff = OrderedToFloat(sh.next_cutoff_u);
     // ---- FindOrAddToken for the recorded links, against the final cutoff
     const int k_surv = InsertEmitted(d, c, &sh, tbl, link_base, sh.n_links, next_cutoff);
@@ -1016,7 +1061,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     // ---- ProcessNonemitting(next_cutoff) + commit of token list frame+1
     CommitFrame(d, c, &sh, tbl, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP, k_surv);
     const int err_now = sh.err;    // CommitFrame ends with a barrier; nobody writes err before the next one
-    __syncthreads();
+    LdsBarrier();
     if (err_now) { frame++; break; }
   }
   PublishLaneEnd(d, c, &sh, frame);
@@ -1269,8 +1314,16 @@ __device__ inline int WaveAllocDown(int *top) {
   return base - 1 - __popcll(m & ((1ull << lane) - 1ull));
 }
 
-struct LinkLite { int src, dst; float graph, ac; };   // what the sweep needs of a Link
-__device__ inline LinkLite Lite(const Link &L) { LinkLite r; r.src = L.src; r.dst = L.dst; r.graph = L.graph; r.ac = L.ac; return r; }
+// what the sweep needs of a Link, with the endpoints as frame-local 16-bit indices
+// (src - first token of frame f) | (dst - first token of dst's frame) << 16; 0xFFFF = dropped
+struct LinkLite { u32 sd; float graph, ac; };
+__device__ inline LinkLite Lite(const Link &L, int src_base, int dst_base) {
+  LinkLite r;
+  r.sd = static_cast<u32>(L.src - src_base) & 0xFFFFu;
+  r.sd |= (L.dst < 0 ? 0xFFFFu : (static_cast<u32>(L.dst - dst_base) & 0xFFFFu)) << 16;
+  r.graph = L.graph; r.ac = L.ac;
+  return r;
+}
 #define FIN_PF 4                          // links per thread held in registers (one frame ahead)
 #define FIN_TPT ((FIN_CAP + NT - 1) / NT) // tokens per thread held in registers
 
@@ -1287,7 +1340,7 @@ __device__ inline LinkLite Lite(const Link &L) { LinkLite r; r.src = L.src; r.ds
 // frame; links at [out_lnk_base, lnk_cap) with src/dst = arena positions of the tokens.
 __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes) {
   __shared__ Sh sh;
-  __shared__ int s_tok_top, s_lnk_top;
+  __shared__ int s_tok_top, s_lnk_top, s_chg[3];
   const int lane = lanes[blockIdx.x];
   const Ctx c = MakeCtx(d, lane);
   const int tid = threadIdx.x;
@@ -1309,11 +1362,13 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
   extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
   // LDS: [2] ordered extra costs, [2] forward costs, [2] staged positions (frame f / frame f+1)
   u32 *l_base = reinterpret_cast<u32 *>(fin_lds);
-  if (tid == 0) { s_tok_top = c.tok_cap; s_lnk_top = c.lnk_cap; new_off[F + 1] = c.tok_cap; }
+  if (tid == 0) { s_tok_top = c.tok_cap; s_lnk_top = c.lnk_cap; new_off[F + 1] = c.tok_cap; s_chg[0] = s_chg[1] = s_chg[2] = 0; }
   // registers: frame f (cur) and frame f-1 (nxt)
-  LinkLite rl[FIN_PF], nl[FIN_PF];
+  LinkLite rl[FIN_PF];     // frame f, packed
+  int2 nsd[FIN_PF]; float2 nga[FIN_PF];   // frame f-1 as loaded (nothing may be computed on them before the next iteration: that would wait for the loads)
   float rc[FIN_TPT], nc_[FIN_TPT];
-  auto prefetch = [&](int f, LinkLite *pl, float *pc) {
+  int rs[FIN_TPT], ns_[FIN_TPT];
+  auto prefetch = [&](int f, int2 *psd, float2 *pga, float *pc, int *ps) {
     if (f < 0) return;
     const int tb = c.tok_off[f], nt = c.tok_off[f + 1] - tb;
     const int eb = c.lnk_off[2 * f + 1];
@@ -1321,23 +1376,36 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
 #pragma unroll
     for (int k = 0; k < FIN_TPT; k++) {
       const int i = tid + k * NT;
-      pc[k] = 0.f;
-      if (i < nt) pc[k] = c.tok_cost[tb + i];
+      pc[k] = 0.f; ps[k] = 0;
+      if (i < nt) { pc[k] = c.tok_cost[tb + i]; ps[k] = c.tok_state[tb + i]; }
     }
 #pragma unroll
     for (int k = 0; k < FIN_PF; k++) {
       const int li = eb + tid + k * NT;
-      pl[k].src = -1; pl[k].dst = -1; pl[k].graph = 0.f; pl[k].ac = 0.f;
+      psd[k] = make_int2(0, -1); pga[k] = make_float2(0.f, 0.f);
       if (li < le) {
-        const int2 sd = *reinterpret_cast<const int2 *>(&c.links[li].src);
-        const float2 ga = *reinterpret_cast<const float2 *>(&c.links[li].graph);
-        pl[k].src = sd.x; pl[k].dst = sd.y; pl[k].graph = ga.x; pl[k].ac = ga.y;
+        psd[k] = *reinterpret_cast<const int2 *>(&c.links[li].src);
+        pga[k] = *reinterpret_cast<const float2 *>(&c.links[li].graph);
       }
     }
   };
-  prefetch(F, rl, rc);
+  auto promote = [&](int f) {   // pack the registers loaded for frame f
+    if (f < 0) return;
+    const int tb = c.tok_off[f], tbn = c.tok_off[f + 1];
+    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
+#pragma unroll
+    for (int k = 0; k < FIN_PF; k++) {
+      Link L; L.src = nsd[k].x; L.dst = nsd[k].y; L.graph = nga[k].x; L.ac = nga[k].y; L.ilabel = 0; L.olabel = 0;
+      rl[k] = Lite(L, tb, (eb + tid + k * NT) < ee ? tb : tbn);
+    }
+#pragma unroll
+    for (int k = 0; k < FIN_TPT; k++) { rc[k] = nc_[k]; rs[k] = ns_[k]; }
+  };
+  prefetch(F, nsd, nga, nc_, ns_);
+  promote(F);
   __syncthreads();
   bool prev_lds = false;   // frame f+1 was processed in LDS mode (its x / cost / pos are in LDS)
+  int jit = 0;             // epsilon-fixpoint rounds so far (all frames)
   int cur = 0;
   for (int f = F; f >= 0; f--) {
     const int tb = c.tok_off[f], nt = c.tok_off[f + 1] - tb;
@@ -1346,8 +1414,8 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
     const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];       // epsilon links inside frame f
     const int le = f < F ? c.lnk_off[2 * (f + 1) + 1] : ee;              // emitting links f -> f+1: [ee, le)
     const float emit_off = c.cost_offsets[f < F ? f : 0];                 // GetRawLattice :173-180 (used for f < F only)
-    prefetch(f - 1, nl, nc_);
-    const int lnk_top0 = s_lnk_top, tok_top0 = s_tok_top;   // uniform: the previous iteration ended with a barrier
+    prefetch(f - 1, nsd, nga, nc_, ns_);
+    const int lnk_top0 = s_lnk_top;   // uniform: the previous iteration ended with a barrier
     const bool lds_mode = nt <= FIN_CAP && ntn <= FIN_CAP;
     const bool next_hbm_mode = f > 0 && ((c.tok_off[f] - c.tok_off[f - 1]) > FIN_CAP || nt > FIN_CAP);
     int *gp = gpos[f & 1], *gpn = gpos[(f + 1) & 1];
@@ -1366,11 +1434,11 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
         if (i < nt) {
           lc[i] = rc[k];
           float b = INFINITY;
-          if (f == F) b = rc[k] + (finals_empty ? 0.0f : d.g.final[c.tok_state[tb + i]]) - final_best;   // :430
+          if (f == F) b = rc[k] + (finals_empty ? 0.0f : d.g.final[rs[k]]) - final_best;   // :430
           lx[i] = FloatToOrdered(b);
         }
       }
-      __syncthreads();
+      LdsBarrier();
       // link_extra_cost (:346-350 / :437-441) of a link held as L; x of the last frame reads
       // as +inf above lattice_beam (:462-463)
       auto xval = [&](const u32 *arr, int i, bool last) {
@@ -1378,11 +1446,12 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
         return (last && v > lattice_beam) ? INFINITY : v;
       };
       auto relax_emit = [&](const LinkLite &L) {
-        if (L.dst < 0) return;                       // dropped by the exact cutoff
-        float lec = xval(nx, L.dst - tbn, false) + ((lc[L.src - tb] + L.ac + L.graph) - nc[L.dst - tbn]);
+        const int ls = L.sd & 0xFFFFu, ld = L.sd >> 16;
+        if (ld == 0xFFFF) return;                    // dropped by the exact cutoff
+        float lec = xval(nx, ld, false) + ((lc[ls] + L.ac + L.graph) - nc[ld]);
         if (lec > lattice_beam) return;              // excised (:352)
         if (lec < 0.0f) lec = 0.0f;                  // :360-364
-        atomicMin(&lx[L.src - tb], FloatToOrdered(lec));
+        atomicMin(&lx[ls], FloatToOrdered(lec));
       };
       const int n_reg = min(le - eb, FIN_PF * NT);   // links of this frame held in registers
 #pragma unroll
@@ -1390,16 +1459,17 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
         const int li = eb + tid + k * NT;
         if (li >= ee && li < le) relax_emit(rl[k]);
       }
-      for (int li = max(ee, eb + n_reg) + tid; li < le; li += NT) relax_emit(Lite(c.links[li]));
-      __syncthreads();
+      for (int li = max(ee, eb + n_reg) + tid; li < le; li += NT) relax_emit(Lite(c.links[li], tb, tbn));
+      LdsBarrier();
       if (ee > eb) {
         const bool last = f == F;
         auto relax_eps = [&](const LinkLite &L) -> int {
-          float lec = xval(lx, L.dst - tb, last) + ((lc[L.src - tb] + L.ac + L.graph) - lc[L.dst - tb]);
+          const int ls = L.sd & 0xFFFFu, ld = L.sd >> 16;
+          float lec = xval(lx, ld, last) + ((lc[ls] + L.ac + L.graph) - lc[ld]);
           if (lec > lattice_beam) return 0;
           if (lec < 0.0f) lec = 0.0f;
           const u32 key = FloatToOrdered(lec);
-          return atomicMin(&lx[L.src - tb], key) > key;
+          return atomicMin(&lx[ls], key) > key;
         };
         for (int iter = 0; iter < 20000; iter++) {
           int changed = 0;
@@ -1408,40 +1478,36 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
             const int li = eb + tid + k * NT;
             if (li < ee) changed |= relax_eps(rl[k]);
           }
-          for (int li = eb + n_reg + tid; li < ee; li += NT) changed |= relax_eps(Lite(c.links[li]));
-          if (!__syncthreads_or(changed)) break;
+          for (int li = eb + n_reg + tid; li < ee; li += NT) changed |= relax_eps(Lite(c.links[li], tb, tb));
+          // workgroup OR through three rotating LDS flags (LDS-only barrier; the flag reset of
+          // round k+1 is two barriers away from its last readers)
+          if (__any(changed) && (tid & 63) == 0) atomicOr(&s_chg[jit % 3], 1);
+          if (tid == 0) s_chg[(jit + 1) % 3] = 0;
+          LdsBarrier();
+          const int any_changed = s_chg[jit % 3];
+          jit++;                      // keeps rotating across frames: a flag left set is reset before its next use
+          if (!any_changed) break;
         }
       }
       if (f == F) {   // store the clamped values: later reads need no special case
         for (int i = tid; i < nt; i += NT) if (OrderedToFloat(lx[i]) > lattice_beam) lx[i] = INF_O;
-        __syncthreads();
+        LdsBarrier();
       }
-      // ---- PruneTokensForFrame (:492-511) + staging of the survivors (their HCLG states are
-      // fetched now: a handful per frame).  Staged tokens land in [tok_top - survivors,
-      // tok_top): if that can reach this frame's own records, read -> barrier -> write.
-      const bool tok_slack_ok = tok_top0 - nt >= tbn;
-      {
-        int st[FIN_TPT];
+      // ---- PruneTokensForFrame (:492-511) + staging of the survivors.  Staged tokens land in
+      // [tok_top - survivors, tok_top): frame f's own records are in registers already and
+      // everything above them is dead, so no ordering is needed.
 #pragma unroll
-        for (int k = 0; k < FIN_TPT; k++) {
-          const int i = tid + k * NT;
-          st[k] = 0;
-          if (i < nt && lx[i] != INF_O) st[k] = c.tok_state[tb + i];
-        }
-        if (!tok_slack_ok) __syncthreads();
-#pragma unroll
-        for (int k = 0; k < FIN_TPT; k++) {
-          const int i = tid + k * NT;
-          if (i < nt) {
-            const bool alive = lx[i] != INF_O;
-            int pos = -1;
-            if (alive) { pos = WaveAllocDown(&s_tok_top); c.tok_state[pos] = st[k]; stage_cost[pos] = rc[k]; }
-            lp[i] = pos;
-            if (next_hbm_mode) { c.tok_extra[tb + i] = OrderedToFloat(lx[i]); gp[i] = pos; }
-          }
+      for (int k = 0; k < FIN_TPT; k++) {
+        const int i = tid + k * NT;
+        if (i < nt) {
+          const bool alive = lx[i] != INF_O;
+          int pos = -1;
+          if (alive) { pos = WaveAllocDown(&s_tok_top); c.tok_state[pos] = rs[k]; stage_cost[pos] = rc[k]; }
+          lp[i] = pos;
+          if (next_hbm_mode) { c.tok_extra[tb + i] = OrderedToFloat(lx[i]); gp[i] = pos; }
         }
       }
-      __syncthreads();
+      LdsBarrier();
       if (tid == 0) new_off[f] = s_tok_top;
       // ---- surviving links (the same expressions, now on final values), remapped.  A staged
       // link lands in [lnk_top - survivors, lnk_top); when that cannot reach this frame's own
@@ -1449,10 +1515,11 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
       // ordering, otherwise every chunk is read -> barrier -> written, top-down.
       const bool slack_ok = lnk_top0 - (le - eb) >= le;
       auto survives = [&](const LinkLite &L, bool is_eps) -> bool {
-        if (L.dst < 0) return false;
+        const int ls = L.sd & 0xFFFFu, ld = L.sd >> 16;
+        if (ld == 0xFFFF) return false;
         float lec;
-        if (is_eps) lec = OrderedToFloat(lx[L.dst - tb]) + ((lc[L.src - tb] + L.ac + L.graph) - lc[L.dst - tb]);
-        else lec = OrderedToFloat(nx[L.dst - tbn]) + ((lc[L.src - tb] + L.ac + L.graph) - nc[L.dst - tbn]);
+        if (is_eps) lec = OrderedToFloat(lx[ld]) + ((lc[ls] + L.ac + L.graph) - lc[ld]);
+        else lec = OrderedToFloat(nx[ld]) + ((lc[ls] + L.ac + L.graph) - nc[ld]);
         return !(lec > lattice_beam);
       };
       auto stage_link = [&](Link L, bool is_eps) {
@@ -1465,7 +1532,7 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
       if (slack_ok) {
         for (int li = eb + n_reg + tid; li < le; li += NT) {
           const Link L = c.links[li];
-          if (survives(Lite(L), li < ee)) stage_link(L, li < ee);
+          if (survives(Lite(L, tb, li < ee ? tb : tbn), li < ee)) stage_link(L, li < ee);
         }
 #pragma unroll
         for (int k = 0; k < FIN_PF; k++) {
@@ -1478,11 +1545,11 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
           Link L; L.src = -1; L.dst = -1; L.ilabel = 0; L.olabel = 0; L.graph = 0.f; L.ac = 0.f;
           const bool in = li >= eb && li < le;
           if (in) L = c.links[li];
-          __syncthreads();
-          if (in && survives(Lite(L), li < ee)) stage_link(L, li < ee);
+          __syncthreads();   // full barrier: global reads before global writes
+          if (in && survives(Lite(L, tb, li < ee ? tb : tbn), li < ee)) stage_link(L, li < ee);
         }
       }
-      __syncthreads();
+      if (next_hbm_mode) __syncthreads(); else LdsBarrier();   // HBM mode reads tok_extra / positions from global
       prev_lds = true;
       cur ^= 1;
     } else {
@@ -1582,10 +1649,7 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
       __syncthreads();
       prev_lds = false;
     }
-#pragma unroll
-    for (int k = 0; k < FIN_PF; k++) rl[k] = nl[k];
-#pragma unroll
-    for (int k = 0; k < FIN_TPT; k++) rc[k] = nc_[k];
+    promote(f - 1);
   }
   __syncthreads();
   Stamp(&sh, PH_FIN_SWEEP);
