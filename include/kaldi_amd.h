@@ -246,6 +246,19 @@ typedef struct kamd_graph kamd_graph;
 kamd_graph *kamd_graph_create(int32_t num_states, int32_t start_state,
                               const int64_t *arc_off, const kamd_arc *arcs,
                               const float *final_cost);
+/* ReadFstKaldiGeneric (fstext/kaldi-fst-io.cc:44-89): an OpenFst binary file holding a
+ * "vector" or "const" FST over StdArc (HCLG.fst as the recipes write it,
+ * egs/librispeech/s5/local/chain/run_tdnn_1d.sh:299-303), symbol tables skipped. */
+kamd_graph *kamd_graph_read_openfst(const char *path);
+/* The same file into malloc'ed host arrays (release with kamd_host_free); needs no GPU. */
+int kamd_openfst_read(const char *path, int32_t *num_states, int32_t *start_state,
+                      int64_t **arc_off, kamd_arc **arcs, float **final_cost);
+/* fst::Fst::Write for StdArc: fst_type 0 = VectorFst, 1 = ConstFst (align != 0: the 16-byte
+ * aligned variant, fst/const-fst.h). */
+int kamd_openfst_write(const char *path, int fst_type, int align, int32_t num_states,
+                       int32_t start_state, const int64_t *arc_off, const kamd_arc *arcs,
+                       const float *final_cost);
+void kamd_host_free(void *p);
 void kamd_graph_destroy(kamd_graph *g);
 int32_t kamd_graph_num_states(const kamd_graph *g);
 int64_t kamd_graph_num_arcs(const kamd_graph *g);
@@ -353,6 +366,22 @@ int kamd_decoder_best_path(kamd_decoder *d, int lane, int32_t *alignment,
                            int ali_cap, int *ali_len, int32_t *words,
                            int words_cap, int *words_len, float *graph_cost,
                            float *acoustic_cost);
+/* LatticeWriter entry (util/kaldi-table TableWriter + LatticeHolder::Write,
+ * lat/kaldi-lattice.h:75-118; WriteLattice lat/kaldi-lattice.cc:96-130): appends
+ * "key " + the lattice, binary (OpenFst VectorFst of "lattice4" arcs, no Kaldi binary
+ * marker) or text (FstPrinter lines between two newlines).  state_final[2s], [2s+1] =
+ * final LatticeWeight (graph, acoustic); graph = +inf means not final.  arcs sorted by
+ * src (as kamd_decoder_get_raw_lattice returns them).  What nnet3-latgen-faster writes
+ * with --determinize-lattice=false (decoder/decoder-wrappers.cc:251-262). */
+int kamd_lattice_write(const char *path, int append, const char *key, int binary,
+                       int32_t num_states, int32_t start, const float *state_final,
+                       const kamd_lat_arc *arcs, int32_t num_arcs);
+/* Next entry of a lattice archive at byte *offset (advanced past it); either form is
+ * accepted (first byte 214 = binary, lat/kaldi-lattice.cc:366-386).  Returns 1 at end of
+ * file.  state_final / arcs are malloc'ed: kamd_host_free. */
+int kamd_lattice_read(const char *path, int64_t *offset, char *key, int key_cap,
+                      int32_t *num_states, int32_t *start, float **state_final,
+                      kamd_lat_arc **arcs, int32_t *num_arcs);
 /* Best path of an UN-finalized lane (streaming partial results):
  * LatticeFasterOnlineDecoderTpl::GetBestPath = BestPathEnd + TraceBackBestPath
  * (decoder/lattice-faster-online-decoder.cc:54-165).  Requires a prior kamd_decoder_sync. */

@@ -22,6 +22,23 @@ class Graph:
         if not self._h:
             raise KamdError(lib().kamd_last_error().decode())
 
+    @classmethod
+    def from_file(cls, path):
+        """ReadFstKaldiGeneric (fstext/kaldi-fst-io.cc:44-89): HCLG.fst ("vector" or "const"
+        OpenFst binary over StdArc) straight into HBM."""
+        self = cls.__new__(cls)
+        self.hclg = None
+        self._h = lib().kamd_graph_read_openfst(str(path).encode())
+        if not self._h:
+            raise KamdError(lib().kamd_last_error().decode())
+        return self
+
+    def num_states(self):
+        return lib().kamd_graph_num_states(self._h)
+
+    def num_arcs(self):
+        return lib().kamd_graph_num_arcs(self._h)
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().kamd_graph_destroy(self._h)
@@ -92,7 +109,9 @@ class DeviceMatrix:
 class LatticeFasterDecoder:
     """One lane of the device decoder behind the reference's per-utterance API."""
 
-    def __init__(self, graph, config=None, sizes=None, lane=0, _shared=None):
+    def __init__(self, graph, config=None, sizes=None, lane=0, _shared=None, tid2pdf=None):
+        """tid2pdf: TransitionModel::id2pdf_id_ (index 0 unused); defaults to the graph's own
+        table when the graph came from kaldi_amd.synth."""
         self.graph = graph
         self.config = config or abi.decoder_config_default()
         if _shared is not None:
@@ -104,7 +123,7 @@ class LatticeFasterDecoder:
                 lib().kamd_decoder_sizes_default(C.byref(s))
                 s.max_lanes = 1
             self.sizes = s
-            t2p = np.ascontiguousarray(graph.hclg.tid2pdf, np.int32)
+            t2p = np.ascontiguousarray(tid2pdf if tid2pdf is not None else graph.hclg.tid2pdf, np.int32)
             self._t2p = t2p
             self._dec = lib().kamd_decoder_create(graph._h, C.byref(self.config), C.byref(s),
                                                   abi.iptr(t2p), t2p.size - 1)

@@ -1,0 +1,99 @@
+"""On-disk formats either side of the decode path (host side, no GPU needed):
+OpenFst binary HCLG files (fstext/kaldi-fst-io.cc:44-89 ReadFstKaldiGeneric) and Kaldi
+lattice archives (lat/kaldi-lattice.cc:62-130, util/kaldi-table TableWriter entries).
+Thin wrappers over the C-ABI (kaldi_amd/csrc/fst_io.cc)."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import check, lib
+
+
+def write_openfst(path, g, fst_type="const", align=False):
+    """fst::Fst::Write of an HCLG held as CSR arrays (kaldi_amd.synth.Hclg or anything with
+    num_states / start / arc_off / arcs / final)."""
+    arcs = np.ascontiguousarray(g.arcs)
+    off = np.ascontiguousarray(g.arc_off, np.int64)
+    fin = np.ascontiguousarray(g.final, np.float32)
+    check(lib().kamd_openfst_write(str(path).encode(), {"vector": 0, "const": 1}[fst_type], int(align),
+                                   g.num_states, g.start, abi.iptr(off, C.c_int64),
+                                   arcs.ctypes.data_as(C.c_void_p), abi.fptr(fin)))
+
+
+class FstArrays:
+    """CSR view of an FST read from disk (same field names as synth.Hclg)."""
+
+    def __init__(self, num_states, start, arc_off, arcs, final):
+        self.num_states, self.start, self.arc_off, self.arcs, self.final = num_states, start, arc_off, arcs, final
+
+    @property
+    def num_arcs(self):
+        return int(self.arc_off[-1])
+
+
+def read_openfst(path):
+    n, st = C.c_int32(), C.c_int32()
+    off, fin = C.POINTER(C.c_int64)(), C.POINTER(C.c_float)()
+    arcs = C.c_void_p()
+    check(lib().kamd_openfst_read(str(path).encode(), C.byref(n), C.byref(st), C.byref(off), C.byref(arcs),
+                                  C.byref(fin)))
+    try:
+        S = n.value
+        a_off = np.ctypeslib.as_array(off, (S + 1,)).copy()
+        A = int(a_off[-1])
+        a = np.zeros(A, abi.ARC_DTYPE)
+        if A:
+            C.memmove(a.ctypes.data, arcs.value, A * abi.ARC_DTYPE.itemsize)
+        f = np.ctypeslib.as_array(fin, (max(S, 1),)).copy()[:S]
+    finally:
+        lib().kamd_host_free(C.cast(off, C.c_void_p))
+        lib().kamd_host_free(arcs)
+        lib().kamd_host_free(C.cast(fin, C.c_void_p))
+    return FstArrays(S, st.value, a_off, a, f)
+
+
+def lattice_arrays(lat, acoustic_scale=1.0):
+    """(start, final[2S], arcs) of a decoder Lattice (kaldi_amd.decoder.Lattice / oracle
+    Lattice).  acoustic_scale != 1 divides the acoustic costs by it, the
+    ScaleLattice(AcousticLatticeScale(1/acoustic_scale)) step of
+    decoder/decoder-wrappers.cc:251-256."""
+    S = lat.frame.size
+    fin = np.full(2 * S, np.inf, np.float32)
+    is_final = np.isfinite(lat.final)
+    fin[0::2][is_final] = lat.final[is_final]
+    fin[1::2][is_final] = 0.0
+    arcs = lat.arcs.copy()
+    if acoustic_scale != 1.0:
+        arcs["acoustic_cost"] = arcs["acoustic_cost"] / np.float32(acoustic_scale)
+    return int(lat.start), fin, arcs
+
+
+def write_lattice(path, key, lat, binary=True, append=True, acoustic_scale=1.0):
+    start, fin, arcs = lattice_arrays(lat, acoustic_scale)
+    check(lib().kamd_lattice_write(str(path).encode(), int(append), key.encode(), int(binary), lat.frame.size, start,
+                                   abi.fptr(fin), arcs.ctypes.data_as(C.c_void_p), arcs.size))
+
+
+def read_lattices(path):
+    """Yields (key, start, final[2S], arcs) for every entry of a lattice archive."""
+    off = C.c_int64(0)
+    key = C.create_string_buffer(4096)
+    while True:
+        n, st, m = C.c_int32(), C.c_int32(), C.c_int32()
+        fin = C.POINTER(C.c_float)()
+        arcs = C.c_void_p()
+        rc = lib().kamd_lattice_read(str(path).encode(), C.byref(off), key, 4096, C.byref(n), C.byref(st), C.byref(fin),
+                                     C.byref(arcs), C.byref(m))
+        if rc == 1:
+            return
+        check(rc)
+        try:
+            f = np.ctypeslib.as_array(fin, (max(2 * n.value, 1),)).copy()[:2 * n.value]
+            a = np.zeros(m.value, abi.LAT_ARC_DTYPE)
+            if m.value:
+                C.memmove(a.ctypes.data, arcs.value, m.value * abi.LAT_ARC_DTYPE.itemsize)
+        finally:
+            lib().kamd_host_free(C.cast(fin, C.c_void_p))
+            lib().kamd_host_free(arcs)
+        yield key.value.decode(), st.value, f, a

@@ -235,6 +235,27 @@ def test_finalize_with_no_slack_in_the_arenas(big):
     assert_same(d, o)
 
 
+def test_graph_from_openfst_file_and_lattice_archive(tmp_path):
+    """HCLG.fst -> kamd_graph_read_openfst -> decode -> lattice archive, the file-level drop-in
+    of nnet3-latgen-faster --determinize-lattice=false."""
+    from kaldi_amd import io as kio
+    g = synth.make_hclg(num_units=24, vocab=60, n_hist=12, seed=3)
+    ll, words, _ = synth.sample_utterance(g, n_words=5, seed=4, peak=6.0)
+    cfg = abi.decoder_config_recipe()
+    kio.write_openfst(tmp_path / "HCLG.fst", g, "const")
+    G = decoder.Graph.from_file(tmp_path / "HCLG.fst")
+    assert G.num_states() == g.num_states and G.num_arcs() == g.num_arcs
+    d = decoder.LatticeFasterDecoder(G, cfg, sizes(), tid2pdf=g.tid2pdf)
+    d.Decode(ll)
+    o = orc.Decoder(g, cfg, 1)
+    o.Decode(ll)
+    assert_same(d, o)
+    lat = d.GetRawLattice()
+    kio.write_lattice(tmp_path / "lat.1", "utt1", lat, binary=True, append=False)
+    (key, st, fin, arcs), = list(kio.read_lattices(tmp_path / "lat.1"))
+    assert key == "utt1" and st == lat.start and np.array_equal(arcs, lat.arcs)
+
+
 def test_pipeline_ragged_batch_with_empty_and_tiny_utterances():
     """Ragged batch: empty waveform, one shorter than a frame, a one-frame utterance, and
     normal ones; the short ones are skipped (None), the rest decode as if alone."""
