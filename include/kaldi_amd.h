@@ -382,6 +382,52 @@ int kamd_lattice_write(const char *path, int append, const char *key, int binary
 int kamd_lattice_read(const char *path, int64_t *offset, char *key, int key_cap,
                       int32_t *num_states, int32_t *start, float **state_final,
                       kamd_lat_arc **arcs, int32_t *num_arcs);
+/* ------------------------------------------------- lattice determinization -- */
+/* DeterminizeLatticePhonePrunedOptions + DeterminizeLatticePrunedOptions
+ * (lat/determinize-lattice-pruned.h:126-141, 214-245), same defaults.  minimize is not
+ * offered (the recipes leave it false). */
+typedef struct {
+  float delta;               /* 2^-10: weight tolerance when two subsets are compared */
+  int32_t max_mem;           /* 50000000 bytes (approximate accounting); <= 0: unlimited */
+  int32_t phone_determinize; /* 1: first pass on phone + word labels */
+  int32_t word_determinize;  /* 1: second pass on word labels */
+  int32_t max_loop;          /* 0 = no limit on epsilon-closure iterations */
+  float retry_cutoff;        /* 0.5 */
+} kamd_determinize_opts;
+void kamd_determinize_opts_default(kamd_determinize_opts *o);
+/* One arc of a CompactLattice (acceptor: label = word): weight (graph, acoustic) plus the
+ * transition-id string strings[str_begin .. str_begin + str_len). */
+typedef struct {
+  int32_t src, dst, label;
+  float graph_cost, acoustic_cost;
+  int32_t str_begin, str_len;
+} kamd_clat_arc;
+typedef struct kamd_compact_lattice kamd_compact_lattice;
+/* DeterminizeLatticePhonePrunedWrapper (lat/determinize-lattice-pruned.cc:1484-1509) on a
+ * raw lattice as kamd_decoder_get_raw_lattice / kamd_lattice_read return it (ilabel =
+ * transition-id, olabel = word; state_final[2s], [2s+1]; arcs sorted by src): Invert, TopSort,
+ * ArcSort, phone pass, word pass, Connect.  tid_phone[tid] (tid in 1..num_tids) is the phone
+ * of a transition-id that ENTERS a phone (TransitionIdToHmmState == 0 and not a self-loop,
+ * :1316-1318) and 0 for every other transition-id; may be NULL when phone_determinize = 0.
+ * beam = config.lattice_beam (decoder/decoder-wrappers.cc:272-277).  Host code, no GPU. */
+kamd_compact_lattice *kamd_lattice_determinize_phone_pruned(
+    int32_t num_states, int32_t start, const float *state_final, const kamd_lat_arc *arcs,
+    int32_t num_arcs, const int32_t *tid_phone, int32_t num_tids, double beam,
+    const kamd_determinize_opts *opts);
+void kamd_compact_lattice_destroy(kamd_compact_lattice *c);
+/* *reached_beam = 0 when determinization stopped early (memory limit) and the result is
+ * pruned tighter than asked, the reference's "return false" case. */
+int kamd_compact_lattice_sizes(const kamd_compact_lattice *c, int32_t *num_states, int32_t *num_arcs,
+                               int32_t *num_labels, int32_t *start, int32_t *reached_beam);
+int kamd_compact_lattice_get(const kamd_compact_lattice *c, float *state_final /* [2S] */,
+                             int32_t *final_str_begin, int32_t *final_str_len /* [S] */,
+                             kamd_clat_arc *arcs, int32_t *strings /* [num_labels] */);
+/* CompactLatticeWriter entry (lat/kaldi-lattice.cc:62-94): "key " + the lattice, binary
+ * ("compactlattice44" VectorFst) or text.  Acoustic costs are divided by acoustic_scale
+ * (decoder/decoder-wrappers.cc:282-284) when it is neither 0 nor 1. */
+int kamd_compact_lattice_write(const char *path, int append, const char *key, int binary,
+                               const kamd_compact_lattice *c, float acoustic_scale);
+
 /* Best path of an UN-finalized lane (streaming partial results):
  * LatticeFasterOnlineDecoderTpl::GetBestPath = BestPathEnd + TraceBackBestPath
  * (decoder/lattice-faster-online-decoder.cc:54-165).  Requires a prior kamd_decoder_sync. */

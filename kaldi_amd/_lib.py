@@ -84,6 +84,13 @@ def lib():
     sig("kamd_lattice_read", C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.c_char_p, C.c_int, C.POINTER(C.c_int32),
                                        C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_float)), C.POINTER(vp),
                                        C.POINTER(C.c_int32)])
+    sig("kamd_determinize_opts_default", None, [C.POINTER(abi.DeterminizeOpts)])
+    sig("kamd_lattice_determinize_phone_pruned", vp, [C.c_int32, C.c_int32, fp, vp, C.c_int32, ip, C.c_int32, C.c_double,
+                                                      C.POINTER(abi.DeterminizeOpts)])
+    sig("kamd_compact_lattice_destroy", None, [vp])
+    sig("kamd_compact_lattice_sizes", C.c_int, [vp] + [C.POINTER(C.c_int32)] * 5)
+    sig("kamd_compact_lattice_get", C.c_int, [vp, fp, ip, ip, vp, ip])
+    sig("kamd_compact_lattice_write", C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, vp, C.c_float])
     sig("kamd_graph_destroy", None, [vp])
     sig("kamd_graph_num_states", C.c_int32, [vp])
     sig("kamd_graph_num_arcs", C.c_int64, [vp])
@@ -126,6 +133,7 @@ kamd_nnet_destroy kamd_nnet_output_dim kamd_nnet_left_context kamd_nnet_right_co
 kamd_nnet_num_output_frames kamd_nnet_frame_subsampling_factor kamd_nnet_forward_batch_device kamd_nnet_forward kamd_nnet_last_flops
 kamd_graph_create kamd_graph_destroy kamd_graph_num_states kamd_graph_num_arcs
 kamd_graph_read_openfst kamd_openfst_read kamd_openfst_write kamd_host_free kamd_lattice_write kamd_lattice_read
+kamd_determinize_opts_default kamd_lattice_determinize_phone_pruned kamd_compact_lattice_destroy kamd_compact_lattice_sizes kamd_compact_lattice_get kamd_compact_lattice_write
 kamd_decoder_config_default kamd_decoder_sizes_default kamd_decoder_create kamd_decoder_destroy
 kamd_decoder_set_options kamd_decoder_reserve kamd_decoder_init kamd_decoder_advance kamd_decoder_finalize
 kamd_decoder_sync kamd_decoder_num_frames_decoded kamd_decoder_final_relative_cost

@@ -134,6 +134,13 @@ class LatticeSize(C.Structure):
                 ("num_frames", C.c_int32), ("start", C.c_int32)]
 
 
+class DeterminizeOpts(C.Structure):
+    _fields_ = [("delta", C.c_float), ("max_mem", C.c_int32), ("phone_determinize", C.c_int32),
+                ("word_determinize", C.c_int32), ("max_loop", C.c_int32), ("retry_cutoff", C.c_float)]
+
+
+CLAT_ARC_DTYPE = np.dtype([("src", "<i4"), ("dst", "<i4"), ("label", "<i4"), ("graph_cost", "<f4"),
+                           ("acoustic_cost", "<f4"), ("str_begin", "<i4"), ("str_len", "<i4")])
 LAT_ARC_DTYPE = np.dtype([("src", "<i4"), ("dst", "<i4"), ("ilabel", "<i4"),
                           ("olabel", "<i4"), ("graph_cost", "<f4"),
                           ("acoustic_cost", "<f4")])

@@ -97,3 +97,64 @@ def read_lattices(path):
             lib().kamd_host_free(C.cast(fin, C.c_void_p))
             lib().kamd_host_free(arcs)
         yield key.value.decode(), st.value, f, a
+
+
+class CompactLattice:
+    """Determinized word lattice (kaldi::CompactLattice): acceptor on word labels, every arc
+    and final weight carries (graph, acoustic) costs and a transition-id string."""
+
+    def __init__(self, handle):
+        self._h = handle
+        n, m, k, st, ok = (C.c_int32() for _ in range(5))
+        check(lib().kamd_compact_lattice_sizes(handle, C.byref(n), C.byref(m), C.byref(k), C.byref(st), C.byref(ok)))
+        self.num_states, self.start, self.reached_beam = n.value, st.value, bool(ok.value)
+        self.final = np.zeros(2 * n.value, np.float32)
+        self.final_str_begin = np.zeros(n.value, np.int32)
+        self.final_str_len = np.zeros(n.value, np.int32)
+        self.arcs = np.zeros(m.value, abi.CLAT_ARC_DTYPE)
+        self.strings = np.zeros(k.value, np.int32)
+        check(lib().kamd_compact_lattice_get(handle, abi.fptr(self.final), abi.iptr(self.final_str_begin),
+                                             abi.iptr(self.final_str_len), self.arcs.ctypes.data_as(C.c_void_p),
+                                             abi.iptr(self.strings)))
+
+    def arc_string(self, i):
+        a = self.arcs[i]
+        return self.strings[a["str_begin"]:a["str_begin"] + a["str_len"]]
+
+    def final_string(self, s):
+        return self.strings[self.final_str_begin[s]:self.final_str_begin[s] + self.final_str_len[s]]
+
+    def write(self, path, key, binary=True, append=True, acoustic_scale=1.0):
+        check(lib().kamd_compact_lattice_write(str(path).encode(), int(append), key.encode(), int(binary), self._h,
+                                               float(acoustic_scale)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kamd_compact_lattice_destroy(self._h)
+            self._h = None
+
+
+def determinize_opts_default():
+    o = abi.DeterminizeOpts()
+    lib().kamd_determinize_opts_default(C.byref(o))
+    return o
+
+
+def determinize_lattice(lat, beam, tid_phone=None, opts=None):
+    """DeterminizeLatticePhonePrunedWrapper (lat/determinize-lattice-pruned.cc:1484-1509) of a
+    raw lattice.  tid_phone[tid] = phone entered by that transition-id, 0 otherwise."""
+    from ._lib import KamdError
+    start, fin, arcs = lattice_arrays(lat)
+    o = opts or determinize_opts_default()
+    if tid_phone is None:
+        o.phone_determinize = 0
+        tp, nt = None, 0
+    else:
+        tp = np.ascontiguousarray(tid_phone, np.int32)
+        nt = tp.size - 1
+    h = lib().kamd_lattice_determinize_phone_pruned(lat.frame.size, start, abi.fptr(fin), arcs.ctypes.data_as(C.c_void_p),
+                                                    arcs.size, abi.iptr(tp) if tp is not None else None, nt,
+                                                    float(beam), C.byref(o))
+    if not h:
+        raise KamdError(lib().kamd_last_error().decode())
+    return CompactLattice(h)
