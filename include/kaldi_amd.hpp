@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -118,6 +119,8 @@ class DecodingGraph {
  public:
   DecodingGraph(int32 num_states, int32 start, const int64_t *arc_off, const kamd_arc *arcs, const float *final_cost)
       : g_(CheckPtr(kamd_graph_create(num_states, start, arc_off, arcs, final_cost))) {}
+  /// ReadFstKaldiGeneric (fstext/kaldi-fst-io.cc:44-89): "vector" or "const" OpenFst file.
+  explicit DecodingGraph(const std::string &rxfilename) : g_(CheckPtr(kamd_graph_read_openfst(rxfilename.c_str()))) {}
   ~DecodingGraph() { kamd_graph_destroy(g_); }
   kamd_graph *Handle() const { return g_; }
  private:
@@ -259,6 +262,154 @@ class LatticeFasterDecoder {
   void *d_buf_;
   size_t d_buf_bytes_;
 };
+
+// ------------------------------------------ lat/kaldi-lattice.h, lat/determinize-lattice-pruned.h
+/// Flat form of a Lattice for the C-ABI (arcs grouped by source state).
+inline void FlattenLattice(const Lattice &lat, std::vector<float> *state_final, std::vector<kamd_lat_arc> *arcs) {
+  const float inf = std::numeric_limits<float>::infinity();
+  state_final->assign(2 * lat.arcs.size(), inf);
+  arcs->clear();
+  for (size_t s = 0; s < lat.arcs.size(); s++) {
+    if (lat.final_graph_cost[s] != inf) { (*state_final)[2 * s] = lat.final_graph_cost[s]; (*state_final)[2 * s + 1] = 0.0f; }
+    for (size_t k = 0; k < lat.arcs[s].size(); k++) {
+      const LatticeArc &a = lat.arcs[s][k];
+      kamd_lat_arc f = {static_cast<int32>(s), a.nextstate, a.ilabel, a.olabel, a.graph_cost, a.acoustic_cost};
+      arcs->push_back(f);
+    }
+  }
+}
+
+/// kaldi::CompactLattice: owns the determinized lattice.
+class CompactLattice {
+ public:
+  CompactLattice() : c_(NULL) {}
+  ~CompactLattice() { Reset(NULL); }
+  void Reset(kamd_compact_lattice *c) { if (c_) kamd_compact_lattice_destroy(c_); c_ = c; }
+  int32 NumStates() const { int32 n = 0, m, k, st, ok; if (c_) kamd_compact_lattice_sizes(c_, &n, &m, &k, &st, &ok); return n; }
+  int32 NumArcs() const { int32 n, m = 0, k, st, ok; if (c_) kamd_compact_lattice_sizes(c_, &n, &m, &k, &st, &ok); return m; }
+  const kamd_compact_lattice *Handle() const { return c_; }
+ private:
+  CompactLattice(const CompactLattice &);
+  kamd_compact_lattice *c_;
+};
+
+struct DeterminizeLatticePhonePrunedOptions {   // lat/determinize-lattice-pruned.h:214-245
+  kamd_determinize_opts c;
+  DeterminizeLatticePhonePrunedOptions() { kamd_determinize_opts_default(&c); }
+};
+
+/// DeterminizeLatticePhonePrunedWrapper (lat/determinize-lattice-pruned.cc:1484-1509).  The
+/// TransitionModel argument is replaced by what the function reads from it: tid_phone[tid] =
+/// TransitionIdToPhone(tid) if TransitionIdToHmmState(tid) == 0 && !IsSelfLoop(tid), else 0.
+inline bool DeterminizeLatticePhonePrunedWrapper(const std::vector<int32> &tid_phone, const Lattice &ifst, double beam,
+                                                 CompactLattice *ofst,
+                                                 DeterminizeLatticePhonePrunedOptions opts = DeterminizeLatticePhonePrunedOptions()) {
+  std::vector<float> fin;
+  std::vector<kamd_lat_arc> arcs;
+  FlattenLattice(ifst, &fin, &arcs);
+  if (tid_phone.empty()) opts.c.phone_determinize = 0;
+  kamd_compact_lattice *c = CheckPtr(kamd_lattice_determinize_phone_pruned(
+      ifst.NumStates(), ifst.start, fin.data(), arcs.data(), static_cast<int32>(arcs.size()),
+      tid_phone.empty() ? NULL : tid_phone.data(), static_cast<int32>(tid_phone.size()) - 1, beam, &opts.c));
+  ofst->Reset(c);
+  int32 n, m, k, st, ok;
+  kamd_compact_lattice_sizes(c, &n, &m, &k, &st, &ok);
+  return ok != 0;
+}
+
+/// TableWriter<LatticeHolder> / <CompactLatticeHolder> / Int32VectorWriter for the wspecifier
+/// forms "ark:FILE" (binary) and "ark,t:FILE" (text) (util/kaldi-table.h:277-330).
+class TableWriterBase {
+ public:
+  explicit TableWriterBase(const std::string &wspecifier) : first_(true) {
+    const size_t colon = wspecifier.find(':');
+    if (colon == std::string::npos || wspecifier.compare(0, 3, "ark") != 0) throw KaldiFatalError("unsupported wspecifier " + wspecifier);
+    binary_ = wspecifier.substr(0, colon).find(",t") == std::string::npos;
+    path_ = wspecifier.substr(colon + 1);
+  }
+  bool IsOpen() const { return !path_.empty(); }
+ protected:
+  int Append() { const int a = first_ ? 0 : 1; first_ = false; return a; }
+  std::string path_;
+  bool binary_, first_;
+};
+class LatticeWriter : public TableWriterBase {
+ public:
+  explicit LatticeWriter(const std::string &w) : TableWriterBase(w) {}
+  void Write(const std::string &key, const Lattice &lat) {
+    std::vector<float> fin; std::vector<kamd_lat_arc> arcs;
+    FlattenLattice(lat, &fin, &arcs);
+    Check(kamd_lattice_write(path_.c_str(), Append(), key.c_str(), binary_, lat.NumStates(), lat.start, fin.data(), arcs.data(),
+                             static_cast<int32>(arcs.size())));
+  }
+};
+class CompactLatticeWriter : public TableWriterBase {
+ public:
+  explicit CompactLatticeWriter(const std::string &w) : TableWriterBase(w) {}
+  /// acoustic_scale: ScaleLattice(AcousticLatticeScale(1/acoustic_scale)) applied on output
+  void Write(const std::string &key, const CompactLattice &clat, BaseFloat acoustic_scale = 1.0f) {
+    Check(kamd_compact_lattice_write(path_.c_str(), Append(), key.c_str(), binary_, clat.Handle(), acoustic_scale));
+  }
+};
+class Int32VectorWriter : public TableWriterBase {   // BasicVectorHolder<int32> (util/kaldi-holder-inl.h)
+ public:
+  explicit Int32VectorWriter(const std::string &w) : TableWriterBase(w) {}
+  void Write(const std::string &key, const std::vector<int32> &v) {
+    FILE *f = fopen(path_.c_str(), Append() ? "ab" : "wb");
+    if (!f) throw KaldiFatalError("cannot open " + path_);
+    fputs(key.c_str(), f); fputc(' ', f);
+    if (binary_) {                       // "\0B", then WriteIntegerVector: size byte, int32 count, raw data
+      fputc('\0', f); fputc('B', f); fputc(4, f);
+      const int32 n = static_cast<int32>(v.size());
+      fwrite(&n, 4, 1, f);
+      if (n) fwrite(v.data(), 4, v.size(), f);
+    } else {
+      for (size_t i = 0; i < v.size(); i++) fprintf(f, "%d ", v[i]);
+      fputc('\n', f);
+    }
+    fclose(f);
+  }
+};
+
+/// DecodeUtteranceLatticeFaster (decoder/decoder-wrappers.cc:201-296): decode, word-level
+/// traceback, raw lattice, optional determinization, inverse acoustic scaling, write.
+/// trans_model is replaced by tid_phone (see DeterminizeLatticePhonePrunedWrapper); writers
+/// may be NULL.  Returns false (after a warning on stderr) where the reference does.
+inline bool DecodeUtteranceLatticeFaster(LatticeFasterDecoder &decoder, DecodableInterface &decodable,
+                                         const std::vector<int32> &tid_phone, const std::string &utt, double acoustic_scale,
+                                         bool determinize, bool allow_partial, Int32VectorWriter *alignment_writer,
+                                         Int32VectorWriter *words_writer, CompactLatticeWriter *compact_lattice_writer,
+                                         LatticeWriter *lattice_writer, double *like_ptr) {
+  if (!decoder.Decode(&decodable)) { fprintf(stderr, "WARNING Failed to decode utterance with id %s\n", utt.c_str()); return false; }
+  if (!decoder.ReachedFinal()) {
+    if (allow_partial) fprintf(stderr, "WARNING Outputting partial output for utterance %s since no final-state reached\n", utt.c_str());
+    else { fprintf(stderr, "WARNING Not producing output for utterance %s since no final-state reached and --allow-partial=false.\n", utt.c_str()); return false; }
+  }
+  std::vector<int32> alignment, words;
+  BaseFloat g = 0, a = 0;
+  if (!decoder.GetBestPath(&alignment, &words, &g, &a)) throw KaldiFatalError("Failed to get traceback for utterance " + utt);
+  const int32 num_frames = static_cast<int32>(alignment.size());
+  if (words_writer) words_writer->Write(utt, words);
+  if (alignment_writer) alignment_writer->Write(utt, alignment);
+  const double likelihood = -(static_cast<double>(g) + a);
+  Lattice lat;
+  if (!decoder.GetRawLattice(&lat) || lat.NumStates() == 0) throw KaldiFatalError("Unexpected problem getting lattice for utterance " + utt);
+  // fst::Connect(&lat): the exactly pruned raw lattice is connected by construction
+  if (determinize) {
+    CompactLattice clat;
+    if (!DeterminizeLatticePhonePrunedWrapper(tid_phone, lat, decoder.GetOptions().lattice_beam, &clat))
+      fprintf(stderr, "WARNING Determinization finished earlier than the beam for utterance %s\n", utt.c_str());
+    if (compact_lattice_writer) compact_lattice_writer->Write(utt, clat, acoustic_scale != 0.0 ? static_cast<BaseFloat>(acoustic_scale) : 1.0f);
+  } else if (lattice_writer) {
+    if (acoustic_scale != 0.0 && acoustic_scale != 1.0)
+      for (size_t s = 0; s < lat.arcs.size(); s++)
+        for (size_t k = 0; k < lat.arcs[s].size(); k++) lat.arcs[s][k].acoustic_cost /= static_cast<BaseFloat>(acoustic_scale);
+    lattice_writer->Write(utt, lat);
+  }
+  fprintf(stderr, "LOG Log-like per frame for utterance %s is %g over %d frames.\n", utt.c_str(), likelihood / num_frames, num_frames);
+  if (like_ptr) *like_ptr = likelihood;
+  return true;
+}
 
 // --------------------------------------------------------- feat/feature-mfcc.h:38-56
 struct FrameExtractionOptions : kamd_frame_opts {};

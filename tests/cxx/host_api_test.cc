@@ -87,6 +87,26 @@ int main(int argc, char **argv) {
       decoder.Decode(&decodable);
       Report("generic", decoder);
     }
+    // the nnet3-latgen-faster tail: DecodeUtteranceLatticeFaster with and without determinization,
+    // graph read back from an OpenFst file
+    if (argc >= 3) {
+      const std::string dir = argv[2];
+      Check(kamd_openfst_write((dir + "/HCLG.fst").c_str(), 1, 0, S, start, arc_off.data(), arcs.data(), final_cost.data()));
+      DecodingGraph fst2(dir + "/HCLG.fst");
+      LatticeFasterDecoder decoder(fst2, config, id2pdf, &sz);
+      std::vector<int32> tid_phone(id2pdf.size(), 0);
+      for (size_t t = 1; t < tid_phone.size(); t += 2) tid_phone[t] = static_cast<int32>((t + 1) / 2);
+      Int32VectorWriter words_writer("ark,t:" + dir + "/words.txt"), ali_writer("ark:" + dir + "/ali.ark");
+      CompactLatticeWriter clat_writer("ark:" + dir + "/clat.ark");
+      LatticeWriter lat_writer("ark,t:" + dir + "/lat.txt");
+      double like = 0;
+      for (int rep = 0; rep < 2; rep++) {
+        DecodableMatrixMapped decodable(id2pdf, ll.data(), T, P);
+        const bool ok = DecodeUtteranceLatticeFaster(decoder, decodable, tid_phone, rep ? "utt-raw" : "utt-det", 0.5, rep == 0, true,
+                                                     &ali_writer, &words_writer, &clat_writer, &lat_writer, &like);
+        printf("wrapper ok=%d like=%.6g\n", ok, like);
+      }
+    }
     // error convention: a bad config throws like KALDI_ERR
     try {
       LatticeFasterDecoderConfig bad; bad.beam = -1;

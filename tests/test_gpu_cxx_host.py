@@ -39,7 +39,7 @@ def test_cxx_host_api(tmp_path):
         vec(f, g.tid2pdf.astype(np.int32))
         vec(f, ll)
     exe = build_cxx(str(tmp_path))
-    out = subprocess.check_output([exe, str(fx)], text=True).strip().splitlines()
+    out = subprocess.check_output([exe, str(fx), str(tmp_path)], text=True, stderr=subprocess.DEVNULL).strip().splitlines()
     o = orc.Decoder(g, abi.decoder_config_recipe(), 1)
     o.Decode(ll)
     lat = o.GetRawLattice()
@@ -50,5 +50,19 @@ def test_cxx_host_api(tmp_path):
     assert out[0] == "mapped " + want
     assert out[1] == "chunked " + want
     assert out[2] == "generic " + want
-    assert out[3] == "badconfig threw"
+    assert out[-1] == "badconfig threw"
+    # DecodeUtteranceLatticeFaster: words / alignment / lattice archives
+    like = -(bp["graph_cost"] + bp["acoustic_cost"])
+    assert out[3].startswith("wrapper ok=1") and out[4].startswith("wrapper ok=1")
+    assert abs(float(out[3].split("like=")[1]) - like) < 1e-3 * abs(like)
+    wl = open(tmp_path / "words.txt").read().splitlines()
+    assert wl[0].split() == ["utt-det"] + [str(w) for w in words] and wl[1].split()[0] == "utt-raw"
+    raw = open(tmp_path / "ali.ark", "rb").read()
+    assert raw.startswith(b"utt-det \0B\x04") and int.from_bytes(raw[11:15], "little") == ll.shape[0]
+    from kaldi_amd import io as kio
+    (key, st, fin, arcs), = list(kio.read_lattices(tmp_path / "lat.txt"))
+    assert key == "utt-raw" and arcs.size == lat.arcs.size
+    assert np.allclose(arcs["acoustic_cost"], lat.arcs["acoustic_cost"] / np.float32(0.5), rtol=1e-5)
+    clat = open(tmp_path / "clat.ark", "rb").read()
+    assert clat.startswith(b"utt-det ") and clat[8] == 214 and b"compactlattice44" in clat[:64]
     assert bp["words"].tolist() == words
