@@ -1,0 +1,60 @@
+"""Turns gpurun_out/round/ (written by tools/profile_round.sh on the GPU box) into the files
+committed under profiles/: the bench lines, the rocprofv3 --stats kernel table and the PMC
+summary bench.py reads back for roofline.traffic.  usage: python tools/collect_profiles.py r01"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = "gpurun_out/round"
+P = "profiles"
+os.makedirs(P, exist_ok=True)
+
+
+def line(path):
+    for l in open(path):
+        if l.startswith("{"):
+            return json.loads(l)
+    return None
+
+
+def counter(dirname, name, kernel):
+    vals = []
+    for f in glob.glob(os.path.join(R, dirname, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == name and kernel in row["Kernel_Name"]:
+                vals.append(float(row["Counter_Value"]))
+    return vals
+
+
+for name in ("default", "light", "saturated", "b256", "b512"):
+    d = line(os.path.join(R, "bench_%s.json" % name))
+    if d:
+        json.dump(d, open(os.path.join(P, "%s_bench_%s.json" % (tag, name)), "w"), indent=1)
+d = line(os.path.join(R, "bench_under_rocprof.json"))
+if d:
+    json.dump(d, open(os.path.join(P, "%s_bench_under_rocprof.json" % tag), "w"), indent=1)
+for f in glob.glob(os.path.join(R, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(P, "%s_kernel_stats_bench_default.csv" % tag))
+base = line(os.path.join(R, "bench_default.json"))
+out = {"round": tag, "device": "MI355X (gfx950), ROCm 7.2",
+       "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "
+                  "--warmup 1 --no-cpu-baseline",
+       "note": "gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section); "
+               "read bytes = 2*FETCH_SIZE*1024 is therefore an upper bound for this kernel's narrow random reads.",
+       "workload_key": "mini_librispeech/64/1.3/0.1"}
+for kern, key in (("AdvanceKernel", "advance"), ("FinalizeKernel", "finalize")):
+    fe, wr = counter("pmc_fetch", "FETCH_SIZE", kern), counter("pmc_write", "WRITE_SIZE", kern)
+    if fe and wr:
+        out[key] = {"launches": len(fe), "FETCH_SIZE_KB_mean": sum(fe) / len(fe), "WRITE_SIZE_KB_mean": sum(wr) / len(wr),
+                    "traffic_bytes_per_launch": 2 * 1024 * sum(fe) / len(fe) + 1024 * sum(wr) / len(wr)}
+if "advance" in out:
+    out["kernel"] = "kamd::AdvanceKernel"
+    out["traffic_bytes_per_launch"] = out["advance"]["traffic_bytes_per_launch"]
+    if base:
+        out["algorithmic_bytes_per_launch"] = base["roofline"]["algorithmic_bytes_per_launch"]
+    json.dump(out, open(os.path.join(P, "%s_pmc.json" % tag), "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): default bench line, rocprofv3 kernel stats of the same command,
+# separate PMC passes (FETCH_SIZE / WRITE_SIZE), and the load / batch sweep.  Everything lands
+# in gpurun_out/round/; tools/collect_profiles.py turns it into profiles/rNN_*.
+# usage: tools/profile_round.sh
+set -u
+export TMPDIR=/tmp
+O=gpurun_out/round
+rm -rf $O; mkdir -p $O
+timeout 300 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.err
+for cfg in "light --ll-std 2.0" "saturated --ll-std 1.0" "b256 --utts 256" "b512 --utts 512"; do
+  set -- $cfg; name=$1; shift
+  timeout 400 python3 bench.py --no-cpu-baseline "$@" > $O/bench_$name.json 2> $O/bench_$name.err
+done
+# keep the merged directory small: only the per-kernel CSVs
+find $O -name "*_kernel_trace.csv" -size +20M -delete
+ls -la $O $O/*/* 2>/dev/null | head -40
