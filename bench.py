@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--ll-std", type=float, default=1.3,
                     help="per-frame std (nats) of the synthetic log-likelihoods across pdfs after calibration")
     ap.add_argument("--max-seconds", type=float, default=0.0)
+    ap.add_argument("--hash-capacity", type=int, default=0, help="tokens of one frame per lane (power of two); "
+                    "0 = derived from max-active")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="check lane 0 against the oracle")
@@ -172,9 +174,14 @@ def main():
     spread, k = calibrate(model, args.ll_std)
     log("workload built: %d states %d arcs, %d utts" % (g.num_states, g.num_arcs, len(waves)))
     audio = sum(w.size for w in waves) / 16000.0
-    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves),
-                             max_seconds=max(w.size for w in waves) / 16000.0 + 0.5,
-                             avg_seconds=audio / len(waves))
+    max_s = max(w.size for w in waves) / 16000.0 + 0.5
+    sizes = None
+    if args.hash_capacity:
+        fps = 100.0 / model.subsampling
+        sizes = pipeline.default_sizes(cfg, len(waves), int(max_s * fps) + 2, int(audio / len(waves) * fps) + 2,
+                                       hash_capacity=args.hash_capacity)
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves), max_seconds=max_s,
+                             avg_seconds=audio / len(waves), sizes=sizes)
     log("pipeline created")
     pipe.load(waves)                        # inputs resident in HBM before the timed region
     log("batch loaded")
@@ -224,7 +231,7 @@ def main():
         "ms_per_step": 1000.0 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s TDNN-F chain topology (random init), synthetic tgsmall-scale HCLG "
+        "config": {"workload": "%s TDNN-F chain topology (random init), synthetic " + ("tglarge" if g.num_states > 2e7 else "tgsmall") + "-scale HCLG "
                                "(%d states, %d arcs), batch=%d utterances/GPU (%.0f s audio), beam 15 "
                                "max-active 7000 min-active 200 lattice-beam 8" %
                                (args.workload, g.num_states, g.num_arcs, len(waves), audio),
