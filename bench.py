@@ -231,10 +231,11 @@ def main():
         "ms_per_step": 1000.0 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s TDNN-F chain topology (random init), synthetic " + ("tglarge" if g.num_states > 2e7 else "tgsmall") + "-scale HCLG "
+        "config": {"workload": "%s TDNN-F chain topology (random init), synthetic %s-scale HCLG "
                                "(%d states, %d arcs), batch=%d utterances/GPU (%.0f s audio), beam 15 "
                                "max-active 7000 min-active 200 lattice-beam 8" %
-                               (args.workload, g.num_states, g.num_arcs, len(waves), audio),
+                               (args.workload, "tglarge" if g.num_states > 2e7 else "tgsmall", g.num_states,
+                                g.num_arcs, len(waves), audio),
                    "utterances_per_gpu": len(waves), "loglike_std_nats": args.ll_std},
         "stage_ms": {"features": stage[0] / args.steps, "nnet": stage[1] / args.steps,
                      "decode_advance": stage[2] / args.steps, "decode_finalize": stage[3] / args.steps},
