@@ -1,0 +1,55 @@
+"""Randomised parity sweep: many small (graph, scores, config) triples, HIP decoder vs the
+canonical oracle, bit-exact (the same comparison as tests/test_gpu_decoder.py)."""
+import numpy as np
+import pytest
+
+from kaldi_amd import abi, decoder, synth
+from oracle import orc
+from tests.test_gpu_decoder import assert_same, sizes
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(rng):
+    kind = rng.integers(3)
+    if kind == 0:
+        g = synth.make_random_graph(num_states=int(rng.integers(20, 400)), num_labels=int(rng.integers(5, 60)),
+                                    mean_arcs=float(rng.uniform(1.5, 5.0)), eps_frac=float(rng.uniform(0.0, 0.3)),
+                                    seed=int(rng.integers(1 << 30)))
+        ll = synth.random_loglikes(int(rng.integers(1, 60)), g.num_pdfs, seed=int(rng.integers(1 << 30)),
+                                   scale=float(rng.uniform(0.3, 3.0)))
+    else:
+        g = synth.make_hclg(num_units=int(rng.integers(8, 60)), vocab=int(rng.integers(20, 400)),
+                            n_hist=int(rng.integers(3, 50)), seed=int(rng.integers(1 << 30)),
+                            self_loop_prob=float(rng.uniform(0.2, 0.7)), lm_scale=float(rng.uniform(0.1, 1.0)))
+        if kind == 1:
+            ll, _, _ = synth.sample_utterance(g, n_words=int(rng.integers(1, 8)), seed=int(rng.integers(1 << 30)),
+                                              peak=float(rng.uniform(1.0, 8.0)), noise=float(rng.uniform(0.3, 2.0)))
+        else:
+            ll = synth.random_loglikes(int(rng.integers(1, 50)), g.num_pdfs, seed=int(rng.integers(1 << 30)),
+                                       scale=float(rng.uniform(0.3, 2.0)))
+    cfg = abi.decoder_config_recipe()
+    cfg.beam = float(rng.choice([4.0, 8.0, 12.0, 15.0, 20.0]))
+    cfg.lattice_beam = float(rng.choice([0.5, 2.0, 6.0, 8.0, 10.0]))
+    cfg.max_active = int(rng.choice([40, 200, 1000, 7000, abi.INT32_MAX]))
+    cfg.min_active = int(rng.choice([0, 5, 20, 200]))
+    if cfg.min_active >= cfg.max_active:
+        cfg.min_active = 0
+    return g, ll, cfg
+
+
+@pytest.mark.parametrize("block", range(6))
+def test_random_cases(block):
+    rng = np.random.default_rng(1234 + block)
+    for i in range(20):
+        g, ll, cfg = random_case(rng)
+        G = decoder.Graph(g)
+        d = decoder.LatticeFasterDecoder(G, cfg, sizes(hash_cap=1 << 15, toks=1 << 20, links=1 << 21, frames=256))
+        d.Decode(ll)
+        o = orc.Decoder(g, cfg, 1)
+        o.Decode(ll)
+        try:
+            assert_same(d, o)
+        except AssertionError as e:
+            raise AssertionError("block %d case %d (%d states, %d frames, beam %g lattice_beam %g max %d min %d): %s" % (
+                block, i, g.num_states, ll.shape[0], cfg.beam, cfg.lattice_beam, cfg.max_active, cfg.min_active, e))
