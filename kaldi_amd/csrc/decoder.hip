@@ -129,7 +129,7 @@ struct Sh {  // workgroup-shared state
   float redf[NWAVES];
   u32 hist[256];
   u32 next_cutoff_u;
-  int n_slots, n_links, wl_n[2], err, bigcnt, changed;
+  int n_slots, n_slots1, n_links, wl_n[2], err, bigcnt, changed;   // n_slots: level-2 (HBM) entries, n_slots1: level-1 (LDS)
   int sel_bin, sel_below;
   int scan_total;
   int big_total;
@@ -388,7 +388,7 @@ __device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float b
 // Entries are never removed inside a frame, so "window full / EMPTY seen" decide
 // membership consistently.  Slot ids: [0, lcap) = LDS, lcap + g = global slot g.
 #define LWIN 8
-struct Tbl { u64 *LH; int lcap; };
+struct Tbl { u64 *LH; int lcap; unsigned short *lslots; };   // lslots: level-1 slots in use (dense list, LDS)
 __device__ inline u32 HashL(int s, int lcap) { return (static_cast<u32>(s) * 2654435761u >> 9) & static_cast<u32>(lcap - 1); }
 __device__ inline u64 TblLoad(const Ctx &c, const Tbl &t, int slot) {
   return slot < t.lcap ? t.LH[slot] : LoadH(&c.H[slot - t.lcap]);
@@ -465,15 +465,16 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
   }
 }
 
+#define COMMIT_KEEP 2
 // Dense sweep over the frame's recorded emitting links (lattice-faster-decoder.cc:803-809):
 // FindOrAddToken for every link whose own tot passes the FINAL next_cutoff; the link's dst
 // becomes the table slot, or -1 when the arc is outside the final cutoff (the canonical
 // rule: no order-dependent extras ever enter the table).
 __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, int link_begin,
-                                    int n_links, float cutoff) {
+                                    int n_links, float cutoff, int (&my_slot)[COMMIT_KEEP]) {
   int k_surv = 0;
   const int le = min(link_begin + n_links, c.lnk_cap);
-  for (int li = link_begin + threadIdx.x; li < le; li += NT) {
+  auto one = [&](int li) -> int {
     const Link L = c.links[li];
     const float tot = c.tok_cost[L.src] + L.ac + L.graph;
     int dst = -1;
@@ -482,8 +483,20 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
       dst = TblInsert(d, c, sh, tbl, L.dst, tot, &improved);
       k_surv += dst >= 0;
     }
-    c.links[li].dst = dst;
+    return dst;
+  };
+  // the first COMMIT_KEEP links of a thread: the slot stays in a register until the commit
+  // resolves it to a token (only a rejection is written back now)
+#pragma unroll
+  for (int k = 0; k < COMMIT_KEEP; k++) {
+    const int li = link_begin + threadIdx.x + k * NT;
+    my_slot[k] = -1;
+    if (li < le) {
+      my_slot[k] = one(li);
+      if (my_slot[k] < 0) c.links[li].dst = -1;
+    }
   }
+  for (int li = link_begin + threadIdx.x + COMMIT_KEEP * NT; li < le; li += NT) c.links[li].dst = one(li);
   return k_surv;
 }
 
@@ -518,8 +531,7 @@ __device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl
       const u32 sl = (h0 + w) & m;
       const u64 old = atomicCAS(&t.LH[sl], EMPTY64, mine);
       if (old == EMPTY64) {
-        int idx = WaveAlloc(&sh->n_slots);
-        if (idx < d.hash_cap) c.slots[idx] = sl; else sh->err = ERR_HASH;
+        t.lslots[WaveAlloc(&sh->n_slots1)] = static_cast<unsigned short>(sl);   // cannot overflow: one entry per table word
         *improved = true;
         return static_cast<int>(sl);
       }
@@ -718,6 +730,230 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
   Stamp(sh, PH_CLEAR);
 }
 
+// LDS scratch of CommitFrame2 (regions of the dynamic LDS that are idle while a frame commits)
+struct CommitLds {
+  u32 *wl0, *wl1; int wl_cap;    // epsilon-closure worklists (table slots): the flatten-queue region
+  uint2 *owners; int owners_cap; // {slot, cost bits} of the tokens that own epsilon arcs: select/chunk scratch
+};
+
+// CommitFrame for a lane with a level-1 (LDS) table: the same steps, but everything that
+// concerns level-1 entries stays in LDS — the entries are found by scanning the 8192-word
+// table instead of through a slot list in HBM, a committed entry's cost half is overwritten
+// with its token index (so links resolve slot -> token with one ds_read), worklists and the
+// epsilon-owner list live in idle LDS regions, and the per-round "already queued" test is a
+// bit per slot.  Level-2 (HBM) entries keep the global lists; when a frame has none, no
+// barrier of the commit has to wait for global memory.
+// my_slot[k] = table slot of this thread's k-th recorded link (link_begin + tid + k*NT), or
+// -1: kept in registers from InsertEmitted so the links are not read back.
+__device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
+                             int emit_link_begin, float *cost_cache, int cache_cap, int k_surv,
+                             const CommitLds &L, const int (&my_slot)[COMMIT_KEEP]) {
+  const int tid = threadIdx.x;
+  LaneState *S = c.st;
+  const int lcap = tbl.lcap;
+  LdsBarrier();
+  const int n2 = min(sh->n_slots, d.hash_cap);      // level-2 entries created by the emitting inserts
+  if (n2 > 0) __syncthreads();                      // their slot list lives in HBM
+  auto wl_put = [&](int which, int p, u32 v) { if (p < L.wl_cap) (which ? L.wl1 : L.wl0)[p] = v; else if (p < d.hash_cap) (which ? c.wl1 : c.wl0)[p] = v; else sh->err = ERR_WL; };
+  auto wl_get = [&](int which, int p) -> u32 { return p < L.wl_cap ? (which ? L.wl1 : L.wl0)[p] : (which ? c.wl1 : c.wl0)[p]; };
+  // ---- epsilon closure: initial worklist = every token with epsilon arcs (:855-859)
+  const int n1a = sh->n_slots1;
+  for (int i = tid; i < n1a; i += NT) {
+    const u32 sl = tbl.lslots[i];
+    const u64 e = tbl.LH[sl];
+    if (HasEps(StateOf(e)) && CostOf(e) <= cutoff) wl_put(0, WaveAlloc(&sh->wl_n[0]), sl);
+  }
+  for (int i = tid; i < n2; i += NT) {
+    const u32 slot = c.slots[i];
+    const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
+    if (e == EMPTY64) { sh->err = ERR_INTERNAL; continue; }
+    if (HasEps(StateOf(e)) && CostOf(e) <= cutoff) wl_put(0, WaveAlloc(&sh->wl_n[0]), slot);
+  }
+  if (tid < 256) sh->hist[tid] = 0;                 // "queued this round" bits of the level-1 slots
+  LdsBarrier();
+  if (sh->wl_n[0] > L.wl_cap) __syncthreads();
+  int cur = 0;
+  u32 round = sh->round;
+  while (sh->wl_n[cur] > 0) {   // uniform
+    round++;
+    const int nw = sh->wl_n[cur];
+    for (int i = tid; i < nw; i += NT) {
+      const u32 slot = wl_get(cur, i);
+      const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
+      const float cur_cost = CostOf(e);
+      if (e == EMPTY64 || cur_cost > cutoff) continue;      // :867
+      const int s = PlainState(StateOf(e));
+      const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
+      for (u32 a = a0; a < a1; a++) {
+        const kamd_arc arc = d.g.n_arcs[a];
+        const float tot_cost = cur_cost + arc.weight;
+        if (tot_cost < cutoff) {            // :882
+          bool improved;
+          const int slot2 = TblInsert(d, c, sh, tbl, arc.nextstate, tot_cost, &improved);
+          if (slot2 >= 0 && improved && HasEps(arc.nextstate)) {
+            bool first;
+            if (slot2 < lcap) first = (atomicOr(&sh->hist[slot2 >> 5], 1u << (slot2 & 31)) & (1u << (slot2 & 31))) == 0;
+            else first = atomicExch(&c.stamp[slot2], round) != round;
+            if (first) wl_put(cur ^ 1, WaveAlloc(&sh->wl_n[cur ^ 1]), static_cast<u32>(slot2));
+          }
+        }
+      }
+    }
+    LdsBarrier();
+    if (sh->wl_n[cur ^ 1] > L.wl_cap) __syncthreads();   // uniform: the overflow of the next worklist is in HBM
+    const int err_now = sh->err;     // read between two barriers: uniform
+    if (tid == 0) sh->wl_n[cur] = 0;
+    if (tid < 256) sh->hist[tid] = 0;
+    cur ^= 1;
+    LdsBarrier();
+    if (err_now) break;
+  }
+  if (tid == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; }
+  LdsBarrier();
+  if (sh->n_slots > 0) __syncthreads();   // uniform: level-2 slot list (HBM) complete before it is read
+  Stamp(sh, PH_EPS_CLOSURE);
+  // ---- compaction: every table entry becomes a token of list 'list' (all of them are within
+  // the cutoff: the inserts tested it).  The same sweep finds the list's best token for the
+  // NEXT frame's GetCutoff and collects the owners of epsilon arcs.
+  const int tok_base = sh->cur_tb + sh->cur_n;   // == c.tok_off[list]
+  const int ns2 = min(sh->n_slots, d.hash_cap);  // level-2 entries (emitting + closure)
+  u64 kmin = EMPTY64;
+  auto commit_entry = [&](u64 e, int *idx_out) {
+    int idx = -1;
+    if (CostOf(e) <= cutoff) {
+      idx = tok_base + WaveAlloc(&sh->n_new);
+      if (idx < c.tok_cap) {
+        const int st = PlainState(StateOf(e));
+        c.tok_state[idx] = st;
+        c.tok_cost[idx] = CostOf(e);
+        if (idx - tok_base < cache_cap) cost_cache[idx - tok_base] = CostOf(e);
+        const u64 k = (static_cast<u64>(static_cast<u32>(e)) << 32) | static_cast<u32>(st);
+        kmin = k < kmin ? k : kmin;
+      } else { sh->err = ERR_TOK; idx = -1; }
+    }
+    *idx_out = idx;
+  };
+  auto add_owner = [&](u32 slot, u64 e) {
+    const int p = WaveAlloc(&sh->wl_n[1]);
+    if (p < L.owners_cap) L.owners[p] = make_uint2(slot, static_cast<u32>(e));
+    else if (p < d.hash_cap) { c.wl1[p] = slot; c.scratch[p] = CostOf(e); }
+    else sh->err = ERR_WL;
+  };
+  const int n1 = sh->n_slots1;                   // level-1 entries (emitting + closure)
+  for (int i = tid; i < n1; i += NT) {
+    const u32 sl = tbl.lslots[i];
+    const u64 e = tbl.LH[sl];
+    int idx;
+    commit_entry(e, &idx);
+    if (idx >= 0 && HasEps(StateOf(e))) add_owner(sl, e);
+    tbl.LH[sl] = (e & 0xFFFFFFFF00000000ull) | static_cast<u32>(idx);   // cost half -> token index
+  }
+  for (int i = tid; i < ns2; i += NT) {
+    const u32 slot = c.slots[i];
+    const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
+    if (e == EMPTY64) { sh->err = ERR_INTERNAL; continue; }
+    int idx;
+    commit_entry(e, &idx);
+    if (idx >= 0 && HasEps(StateOf(e))) add_owner(slot, e);
+    c.slot_tok[slot] = idx;
+  }
+  // full barrier only when level-2 entries or list overflow put data in HBM that others read
+  const bool hbm_lists = ns2 > 0;
+  if (hbm_lists) kmin = BlockMin64(kmin, sh); else {
+    for (int o = 32; o > 0; o >>= 1) { const u64 t = __shfl_xor(kmin, o, 64); kmin = t < kmin ? t : kmin; }
+    LdsBarrier();
+    if ((tid & 63) == 0) sh->red64[tid >> 6] = kmin;
+    LdsBarrier();
+    kmin = sh->red64[0];
+    for (int i = 1; i < NWAVES; i++) kmin = sh->red64[i] < kmin ? sh->red64[i] : kmin;
+  }
+  const int n_new = min(sh->n_new, c.tok_cap - tok_base);
+  const int n_owner = sh->wl_n[1];
+  if (n_owner > L.owners_cap && !hbm_lists) __syncthreads();   // overflowed owners went to HBM
+  const float next_beam_cutoff = (n_new > 0 ? OrderedToFloat(static_cast<u32>(kmin >> 32)) : INFINITY) + d.cfg.beam;
+  Stamp(sh, PH_COMPACT);
+  auto tok_of_slot = [&](int slot) -> int {
+    return slot < lcap ? static_cast<int>(static_cast<u32>(tbl.LH[slot])) : c.slot_tok[slot];
+  };
+  // ---- emitting links: slot -> token (the first COMMIT_KEEP per thread from registers)
+  {
+    const int lb = emit_link_begin, le = min(emit_link_begin + sh->n_links, c.lnk_cap);
+#pragma unroll
+    for (int k = 0; k < COMMIT_KEEP; k++) {
+      const int li = lb + tid + k * NT;
+      if (li < le && my_slot[k] >= 0) c.links[li].dst = tok_of_slot(my_slot[k]);
+    }
+    for (int li = lb + tid + COMMIT_KEEP * NT; li < le; li += NT) {
+      const int slot = c.links[li].dst;
+      if (slot >= 0) c.links[li].dst = tok_of_slot(slot);
+    }
+  }
+  // ---- epsilon links of the surviving tokens (final costs), :875-897
+  const int eps_link_begin = emit_link_begin + min(sh->n_links, c.lnk_cap - emit_link_begin);   // == c.lnk_off[2 * list + 1]
+  int a_eps = 0, c_lt = 0, c_le = 0;
+  {
+    const int ne = min(n_owner, d.hash_cap);
+    for (int i = tid; i < ne; i += NT) {
+      u32 slot; float cur_cost;
+      if (i < L.owners_cap) { const uint2 o = L.owners[i]; slot = o.x; cur_cost = OrderedToFloat(o.y); }
+      else { slot = c.wl1[i]; cur_cost = c.scratch[i]; }
+      const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
+      const int s = PlainState(StateOf(e));
+      const int t = tok_of_slot(static_cast<int>(slot));
+      const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
+      a_eps += static_cast<int>(a1 - a0);
+      for (u32 a = a0; a < a1; a++) {
+        const kamd_arc arc = d.g.n_arcs[a];
+        const float tot_cost = cur_cost + arc.weight;
+        if (tot_cost < cutoff) {
+          const int slot2 = TblFind(d, c, tbl, arc.nextstate);
+          const int dst = slot2 >= 0 ? tok_of_slot(slot2) : -1;
+          if (dst < 0) { sh->err = ERR_INTERNAL; continue; }
+          const int li = eps_link_begin + WaveAlloc(&sh->wl_n[0]);   // worklist 0 is idle here
+          if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
+          Link Lk; Lk.src = t; Lk.dst = dst; Lk.ilabel = 0; Lk.olabel = arc.olabel;
+          Lk.graph = arc.weight; Lk.ac = 0.0f;
+          c.links[li] = Lk;
+        }
+      }
+    }
+  }
+  // ---- the next frame's GetCutoff counts, from the LDS copy of the costs
+  for (int i = tid; i < n_new; i += NT) {
+    const float w = i < cache_cap ? cost_cache[i] : c.tok_cost[tok_base + i];
+    c_lt += w < next_beam_cutoff; c_le += w <= next_beam_cutoff;
+  }
+  LdsBarrier();
+  Stamp(sh, PH_EPS_LINKS);
+  // ---- clear the table, publish offsets and counters
+  for (int i = tid; i < n1; i += NT) tbl.LH[tbl.lslots[i]] = EMPTY64;
+  if (ns2 > 0) {
+    for (int i = tid; i < ns2; i += NT) {
+      const int sl = static_cast<int>(c.slots[i]);
+      __hip_atomic_store(&c.H[sl - lcap], EMPTY64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    DrainStores();   // the next frame's CAS / atomicMin must find the cleared words in L2
+  }
+  BlockSum4<true>(k_surv, a_eps, c_lt, c_le, sh);
+  if (tid == 0) {
+    const int n_eps_links = min(sh->wl_n[0], c.lnk_cap - eps_link_begin);
+    c.tok_off[list + 1] = tok_base + n_new;
+    c.lnk_off[2 * list + 2] = eps_link_begin + n_eps_links;
+    S->tok_used = tok_base + n_new;
+    S->lnk_used = eps_link_begin + n_eps_links;
+    S->round = round;
+    sh->round = round; sh->lnk_used = eps_link_begin + n_eps_links; sh->cur_tb = tok_base; sh->cur_n = n_new;
+    sh->cnt[1] += a_eps;                 // A_exp: epsilon arcs of surviving tokens
+    sh->cnt[3] += k_surv;                // K_surv
+    sh->cnt[4] += k_surv + n_eps_links;  // L_kept
+    sh->cnt[5] += n_new;                 // N_tok
+    sh->best_key = kmin; sh->c_lt = c_lt; sh->c_le = c_le;
+    sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->n_new = 0;
+  }
+  LdsBarrier();
+  Stamp(sh, PH_CLEAR);
+}
+
 // best token and beam counts of token list 'list' (what CommitFrame leaves behind), for
 // the first frame of a launch
 __device__ void ComputeFrameStats(const DecDev &d, const Ctx &c, Sh *sh, int list, float *cost_cache,
@@ -771,7 +1007,7 @@ __device__ void PublishLaneEnd(const DecDev &d, const Ctx &c, Sh *sh, int frame)
 
 __device__ inline void InitSh(Sh *sh) {
   if (threadIdx.x == 0) {
-    sh->n_slots = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
+    sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
     sh->bigcnt = 0; sh->n_new = 0; sh->best_key = EMPTY64; sh->c_lt = 0; sh->c_le = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
     sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0;
     for (int i = 0; i < 8; i++) sh->cnt[i] = 0;
@@ -808,7 +1044,7 @@ __global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
     HashInsert(d, c, &sh, d.g.start_flagged, 0.0f, &imp, 0);
   }
   __syncthreads();
-  Tbl tbl; tbl.LH = NULL; tbl.lcap = 0;     // InitKernel has no LDS table: level 2 only
+  Tbl tbl; tbl.LH = NULL; tbl.lcap = 0; tbl.lslots = NULL;     // InitKernel has no LDS table: level 2 only
   CommitFrame(d, c, &sh, tbl, d.cfg.beam, 0, 0, NULL, 0, 0);
   PublishLaneEnd(d, c, &sh, 0);
 }
@@ -827,6 +1063,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
   Tbl tbl;
   tbl.LH = reinterpret_cast<u64 *>(lh_lds + (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP));
   tbl.lcap = d.lds_table_cap;
+  tbl.lslots = reinterpret_cast<unsigned short *>(tbl.LH + tbl.lcap);
   for (int i = threadIdx.x; i < tbl.lcap; i += NT) tbl.LH[i] = EMPTY64;
   const kamd_decode_task task = tasks[blockIdx.x];
   const Ctx c = MakeCtx(d, task.lane);
@@ -1056,10 +1293,14 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     __syncthreads();   // FULL barrier: InsertEmitted reads the links other threads recorded (global)
     const float next_cutoff = OrderedToFloat(sh.next_cutoff_u);
     // ---- FindOrAddToken for the recorded links, against the final cutoff
-    const int k_surv = InsertEmitted(d, c, &sh, tbl, link_base, sh.n_links, next_cutoff);
+    int my_slot[COMMIT_KEEP];
+    const int k_surv = InsertEmitted(d, c, &sh, tbl, link_base, sh.n_links, next_cutoff, my_slot);
     Stamp(&sh, PH_FIXUP);
     // ---- ProcessNonemitting(next_cutoff) + commit of token list frame+1
-    CommitFrame(d, c, &sh, tbl, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP, k_surv);
+    CommitLds cl;
+    cl.wl0 = reinterpret_cast<u32 *>(dyn_lds); cl.wl1 = cl.wl0 + (3 * BIGCAP) / 2; cl.wl_cap = (3 * BIGCAP) / 2;
+    cl.owners = reinterpret_cast<uint2 *>(lh_lds); cl.owners_cap = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP) / 2;
+    CommitFrame2(d, c, &sh, tbl, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP, k_surv, cl, my_slot);
     const int err_now = sh.err;    // CommitFrame ends with a barrier; nobody writes err before the next one
     LdsBarrier();
     if (err_now) { frame++; break; }
@@ -1738,7 +1979,7 @@ __global__ __launch_bounds__(NT) void TracebackKernel(DecDev d, int lane, int us
 static inline size_t AdvanceLdsBytes(int num_pdfs_lds, int lds_table_cap) {
   const size_t scratch = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP);
   return (3 * BIGCAP + 4) * 4 + static_cast<size_t>((num_pdfs_lds + 3) & ~3) * 4 + scratch * 4 +
-         static_cast<size_t>(lds_table_cap) * 8;
+         static_cast<size_t>(lds_table_cap) * (8 + 2);   // table words + the dense list of used slots
 }
 
 // ------------------------------------------------------------------ host
