@@ -126,3 +126,76 @@ class SingleUtteranceNnet3Decoder:
 
     def GetRawLattice(self):
         return self.decoder.GetRawLattice()
+
+    # ---- endpointing (online2/online-nnet3-decoding.cc:88-97, online2/online-endpoint.cc:94-128)
+    def TrailingSilenceLength(self, tid2phone, silence_phones):
+        """Frames of silence at the end of the current best path (BestPathEnd without final-probs,
+        traced back until the first non-silence phone).  tid2phone[tid] =
+        TransitionModel::TransitionIdToPhone(tid)."""
+        return trailing_silence_length(self.decoder.GetBestPath(use_final_probs=False), tid2phone, silence_phones)
+
+    def EndpointDetected(self, config, tid2phone, silence_phones, frame_shift_in_seconds=None):
+        """frame_shift_in_seconds: of a DECODED frame (feature shift x frame-subsampling-factor,
+        online-nnet3-decoding.cc:93-95)."""
+        if frame_shift_in_seconds is None:
+            frame_shift_in_seconds = 0.01 * lib().kamd_nnet_frame_subsampling_factor(self.nnet._h)
+        n = self.decoder.NumFramesDecoded()
+        if n == 0:
+            return False
+        return endpoint_detected(config, n, self.TrailingSilenceLength(tid2phone, silence_phones),
+                                 frame_shift_in_seconds, self.decoder.FinalRelativeCost())
+
+
+class OnlineEndpointRule:
+    """online2/online-endpoint.h:87-100."""
+
+    def __init__(self, must_contain_nonsilence=True, min_trailing_silence=1.0, max_relative_cost=float("inf"),
+                 min_utterance_length=0.0):
+        self.must_contain_nonsilence = must_contain_nonsilence
+        self.min_trailing_silence = min_trailing_silence
+        self.max_relative_cost = max_relative_cost
+        self.min_utterance_length = min_utterance_length
+
+
+class OnlineEndpointConfig:
+    """online2/online-endpoint.h:128-157, same five default rules."""
+
+    def __init__(self):
+        inf = float("inf")
+        self.rule1 = OnlineEndpointRule(False, 5.0, inf, 0.0)
+        self.rule2 = OnlineEndpointRule(True, 0.5, 2.0, 0.0)
+        self.rule3 = OnlineEndpointRule(True, 1.0, 8.0, 0.0)
+        self.rule4 = OnlineEndpointRule(True, 2.0, inf, 0.0)
+        self.rule5 = OnlineEndpointRule(False, 0.0, inf, 20.0)
+
+
+def _rule_activated(rule, trailing_silence, relative_cost, utterance_length):
+    contains_nonsilence = utterance_length > trailing_silence            # online-endpoint.cc:30
+    return ((contains_nonsilence or not rule.must_contain_nonsilence)
+            and trailing_silence >= rule.min_trailing_silence
+            and relative_cost <= rule.max_relative_cost
+            and utterance_length >= rule.min_utterance_length)
+
+
+def endpoint_detected(config, num_frames_decoded, trailing_silence_frames, frame_shift_in_seconds,
+                      final_relative_cost):
+    """EndpointDetected (online2/online-endpoint.cc:44-72)."""
+    assert num_frames_decoded >= trailing_silence_frames
+    utterance_length = num_frames_decoded * frame_shift_in_seconds
+    trailing_silence = trailing_silence_frames * frame_shift_in_seconds
+    return any(_rule_activated(r, trailing_silence, final_relative_cost, utterance_length)
+               for r in (config.rule1, config.rule2, config.rule3, config.rule4, config.rule5))
+
+
+def trailing_silence_length(best_path, tid2phone, silence_phones):
+    """TrailingSilenceLength (online2/online-endpoint.cc:74-110) on a best-path alignment."""
+    if best_path is None:
+        return 0
+    sil = set(int(p) for p in silence_phones)
+    n = 0
+    for tid in reversed(best_path["alignment"].tolist()):
+        if int(tid2phone[tid]) in sil:
+            n += 1
+        else:
+            break
+    return n
