@@ -2184,9 +2184,15 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   }
   // LDS budget (160 KB per CU): static Sh + flatten queue + select/chunk scratch + level-1 table
   // + the log-likelihood row when it still fits
+  // LDS budget (160 KB per CU): static Sh + flatten queue + select/chunk scratch + level-1 table
+  // and its slot list + as much of the log-likelihood row as still fits (pdfs beyond that are
+  // read from HBM: LogLikePdf)
   d.lds_table_cap = LDS_TABLE_CAP;
   d.num_pdfs_lds = 0;
-  if (kamd::AdvanceLdsBytes(num_pdfs, d.lds_table_cap) + sizeof(kamd::Sh) + 1024 <= 160 * 1024) d.num_pdfs_lds = num_pdfs;
+  const size_t lds_budget = 160 * 1024 - sizeof(kamd::Sh) - 1024;
+  const size_t fixed = kamd::AdvanceLdsBytes(0, LDS_TABLE_CAP);
+  if (fixed < lds_budget) d.num_pdfs_lds = static_cast<int>(std::min<size_t>(static_cast<size_t>(num_pdfs), (lds_budget - fixed) / 4) & ~static_cast<size_t>(3));
+  if (d.num_pdfs_lds + 3 >= num_pdfs && kamd::AdvanceLdsBytes(num_pdfs, LDS_TABLE_CAP) <= lds_budget) d.num_pdfs_lds = num_pdfs;
   if (ok && (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess ||
              hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel2),

@@ -256,6 +256,15 @@ def test_graph_from_openfst_file_and_lattice_archive(tmp_path):
     assert key == "utt1" and st == lat.start and np.array_equal(arcs, lat.arcs)
 
 
+def test_more_pdfs_than_the_lds_row_holds():
+    """P = 9000: only part of the log-likelihood row is staged in LDS, the rest is read from HBM."""
+    g = synth.make_hclg(num_units=4500, vocab=300, n_hist=20, seed=8)
+    assert g.num_pdfs == 9000
+    ll = synth.random_loglikes(20, g.num_pdfs, seed=9, scale=1.0)
+    d, o = run_both(g, ll, abi.decoder_config_recipe(), sizes(hash_cap=1 << 16, toks=1 << 21, links=1 << 22))
+    assert_same(d, o)
+
+
 def test_pipeline_ragged_batch_with_empty_and_tiny_utterances():
     """Ragged batch: empty waveform, one shorter than a frame, a one-frame utterance, and
     normal ones; the short ones are skipped (None), the rest decode as if alone."""
