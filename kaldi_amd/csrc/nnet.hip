@@ -36,6 +36,7 @@ struct GemmArgs {
   const float *byp; int ld_byp; const int *bypmap; float bypass_scale;
   const float *post_offset; float post_scale;
   float *C; int ldC;
+  int gx, gy;                       // > 0: 1-D launch, XCD-aware tile order (see the kernel)
 };
 
 // BM x BN block tile, BK = 16, 256 threads = 4 waves laid out WM x WN, each wave owns
@@ -51,7 +52,17 @@ __global__ __launch_bounds__(256) void TdnnGemmKernel(GemmArgs p) {
   __shared__ int rm[KAMD_MAX_OFFSETS][BM];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  With a 2-D grid the
+  // column tiles of one row block (which all stream the same A rows) would land on different
+  // XCDs and every L2 would fetch the block once; the 1-D order below gives all column tiles
+  // of a row block the same id mod 8 (speed only: any placement is correct).
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.gx > 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    by = xcd + 8 * (slot / p.gx); bx = slot % p.gx;
+    if (by >= p.gy) return;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const int K = p.n_off * p.in_pad;
   for (int i = t; i < p.n_off * BM; i += 256) {
     int o = i / BM, r = i % BM, m = m0 + r;
@@ -520,7 +531,8 @@ int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int
         default: hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 160, 4, 1>), grid, dim3(256), 0, st, g); break;
       }
     } else {
-      dim3 grid(kamd::CeilDiv(L.out_dim, 128), kamd::CeilDiv(Ml, 128));
+      g.gx = kamd::CeilDiv(L.out_dim, 128); g.gy = static_cast<int>(kamd::CeilDiv(Ml, 128));
+      dim3 grid(static_cast<unsigned>(g.gx) * static_cast<unsigned>(kamd::RoundUp(g.gy, 8)));
       hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 128, 2, 2>), grid, dim3(256), 0, st, g);
     }
     if (L.log_softmax)

@@ -51,6 +51,18 @@ for kern, key in (("AdvanceKernel", "advance"), ("FinalizeKernel", "finalize")):
     if fe and wr:
         out[key] = {"launches": len(fe), "FETCH_SIZE_KB_mean": sum(fe) / len(fe), "WRITE_SIZE_KB_mean": sum(wr) / len(wr),
                     "traffic_bytes_per_launch": 2 * 1024 * sum(fe) / len(fe) + 1024 * sum(wr) / len(wr)}
+mf = {}
+for f in glob.glob(os.path.join(R, "pmc_mfma", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        if row["Counter_Name"] == "MfmaUtil" and "TdnnGemmKernel" in row["Kernel_Name"]:
+            dur = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            k = row["Kernel_Name"].split("(")[0].replace("void kamd::", "")
+            a = mf.setdefault(k, [0.0, 0.0, 0])
+            a[0] += float(row["Counter_Value"]) * dur; a[1] += dur; a[2] += 1
+if mf:
+    out["mfma_util_percent"] = {k: {"launches": v[2], "time_weighted_MfmaUtil": v[0] / max(v[1], 1.0)} for k, v in mf.items()}
+    out["mfma_note"] = ("MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * SIMD_NUM) * 100, own pass "
+                        "(rocprofv3 --pmc MfmaUtil); fp32 MFMA peak 157 TFLOP/s")
 if "advance" in out:
     out["kernel"] = "kamd::AdvanceKernel"
     out["traffic_bytes_per_launch"] = out["advance"]["traffic_bytes_per_launch"]

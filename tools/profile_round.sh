@@ -11,6 +11,7 @@ timeout 300 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.err
+timeout 300 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $O/pmc_mfma -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_mfma.json 2> $O/pmc_mfma.err
 for cfg in "light --ll-std 2.0" "saturated --ll-std 1.0" "b256 --utts 256" "b512 --utts 512"; do
   set -- $cfg; name=$1; shift
   timeout 400 python3 bench.py --no-cpu-baseline "$@" > $O/bench_$name.json 2> $O/bench_$name.err
