@@ -39,11 +39,15 @@ struct GemmArgs {
   int gx, gy;                       // > 0: 1-D launch, XCD-aware tile order (see the kernel)
 };
 
+// (256, 4): four workgroups per CU.  The main loop waits for its global prefetch and at a
+// barrier once per k-block; what hides that is other workgroups on the same SIMDs, so the
+// register budget is capped at 128 (measured: 48 -> 53 TFLOP/s at batch 64, 63 -> 70 at 512;
+// BK = 32 halves the barriers but its LDS footprint drops the occupancy to 2: 43 / 51).
 // BM x BN block tile, BK = 16, 256 threads = 4 waves laid out WM x WN, each wave owns
 // TI x TJ MFMA tiles of 32x32.  LDS holds the tiles k-major ([k][m], +2 pad) so that
 // fragment reads (lane -> consecutive m) and the transposing stores are conflict free.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void TdnnGemmKernel(GemmArgs p) {
+__global__ __launch_bounds__(256, 4) void TdnnGemmKernel(GemmArgs p) {
   constexpr int BK = 16;
   constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;
   constexpr int LDA = BM + 2, LDB = BN + 2;
