@@ -1,0 +1,50 @@
+"""BASELINE configs[4] (online2-wav-nnet3-latgen-faster style streaming): one stream, audio fed
+in chunks, per-chunk latency of features + looped nnet + AdvanceDecoding on the device, and the
+cost of a partial result (BestPathEnd + TraceBackBestPath).  Run on the GPU box."""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from kaldi_amd import abi, decoder, nnet, online, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=12.0)
+ap.add_argument("--chunk", type=float, default=0.24)
+ap.add_argument("--ll-std", type=float, default=1.3)
+a = ap.parse_args()
+g = synth.make_hclg(num_units=1164, vocab=20000, n_hist=18000, fanout=(12, 64), pron_len=(3, 7), seed=2,
+                    self_loop_prob=0.5, lm_scale=0.1)
+model = nnet.tdnnf_mini_librispeech(num_pdfs=g.num_pdfs)
+cfg = abi.decoder_config_recipe()
+wave = synth.make_wave(a.seconds, seed=7)
+# calibrate the output scale like bench.py does
+from bench import calibrate
+calibrate(model, a.ll_std)
+N, G = decoder.Nnet(model), decoder.Graph(g)
+for rep in range(2):                      # first pass warms up allocations / code objects
+    d = online.SingleUtteranceNnet3Decoder(abi.mfcc_opts_hires(), N, G, cfg, max_seconds=a.seconds + 1)
+    step = int(a.chunk * 16000)
+    lat, part = [], []
+    for i in range(0, wave.size, step):
+        t0 = time.perf_counter()
+        d.AcceptWaveform(16000.0, wave[i:i + step])
+        if i + step >= wave.size:
+            d.InputFinished()
+        d.AdvanceDecoding()
+        lat.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        d.GetBestPath(end_of_utterance=False)
+        part.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    d.FinalizeDecoding()
+    bp = d.GetBestPath()
+    fin = time.perf_counter() - t0
+lat, part = np.asarray(lat) * 1e3, np.asarray(part) * 1e3
+print("stream of %.1f s in %.0f ms chunks: %d chunks, %d frames decoded" % (a.seconds, a.chunk * 1e3, lat.size, d.NumFramesDecoded()))
+print("per chunk (features + nnet + AdvanceDecoding, incl. host sync): median %.2f ms, p95 %.2f ms, max %.2f ms  => %.0f x real time"
+      % (np.median(lat), np.percentile(lat, 95), lat.max(), a.seconds * 1e3 / lat.sum()))
+print("partial best path (BestPathEnd + traceback): median %.2f ms, max %.2f ms (grows with the utterance)" % (np.median(part), part.max()))
+print("FinalizeDecoding + GetBestPath at the end: %.2f ms" % (fin * 1e3))
