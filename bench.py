@@ -144,7 +144,6 @@ def main():
                     "0 = derived from max-active")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="check lane 0 against the oracle")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo to "
                     "exercise the N>1 code path with several ranks sharing one GPU")
@@ -252,11 +251,6 @@ def main():
         "nnet_tflops": lib().kamd_nnet_last_flops(pipe.nnet._h) / (stage[1] / args.steps * 1e-3) / 1e12,
         "setup_s": t_build,
     }
-    if args.verify:
-        from oracle import orc
-        o = orc.Decoder(g, cfg, 1)
-        o.Decode(pipe.loglikes(0))
-        out["verify_lane0_words_equal"] = bool(o.GetRawLattice().best_path()["words"].tolist() == res[0]["words"].tolist())
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, args.cpu_budget)
     else:
