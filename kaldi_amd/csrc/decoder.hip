@@ -466,6 +466,8 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
 }
 
 #define COMMIT_KEEP 2
+static_assert(LDS_TABLE_CAP <= 256 * 32, "CommitFrame2 keeps one 'queued' bit per level-1 slot in Sh::hist[256]");
+static_assert(LDS_TABLE_CAP <= 65536, "level-1 slots are listed as 16-bit values");
 // Dense sweep over the frame's recorded emitting links (lattice-faster-decoder.cc:803-809):
 // FindOrAddToken for every link whose own tot passes the FINAL next_cutoff; the link's dst
 // becomes the table slot, or -1 when the arc is outside the final cutoff (the canonical
