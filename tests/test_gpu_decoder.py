@@ -256,6 +256,36 @@ def test_graph_from_openfst_file_and_lattice_archive(tmp_path):
     assert key == "utt1" and st == lat.start and np.array_equal(arcs, lat.arcs)
 
 
+def test_python_decode_utterance_lattice_faster(tmp_path):
+    """kaldi_amd.wrappers: the DecodeUtteranceLatticeFaster tail in Python."""
+    import io as pyio
+    from kaldi_amd import io as kio
+    from kaldi_amd import wrappers
+    g = synth.make_hclg(num_units=24, vocab=60, n_hist=12, seed=3)
+    ll, words, _ = synth.sample_utterance(g, n_words=5, seed=4, peak=3.0)
+    cfg = abi.decoder_config_recipe()
+    d = decoder.LatticeFasterDecoder(decoder.Graph(g), cfg, sizes())
+    tid_phone = np.zeros(g.tid2pdf.size, np.int32)
+    tid_phone[1::2] = np.arange(1, (g.tid2pdf.size - 1) // 2 + 1)
+    log = pyio.StringIO()
+    out = {}
+    ok, like, w = wrappers.decode_utterance_lattice_faster(d, ll, "u1", acoustic_scale=0.5, determinize=True,
+                                                           tid_phone=tid_phone, lattice_path=tmp_path / "clat.ark",
+                                                           words_out=out, log=log)
+    o = orc.Decoder(g, cfg, 1)
+    o.Decode(ll)
+    bp = o.GetRawLattice().best_path()
+    assert ok and w == bp["words"].tolist() == out["u1"]
+    assert abs(like + bp["graph_cost"] + bp["acoustic_cost"]) < 1e-3
+    raw = open(tmp_path / "clat.ark", "rb").read()
+    assert raw.startswith(b"u1 ") and raw[3] == 214 and b"compactlattice44" in raw[:64]
+    assert "Log-like per frame for utterance u1" in log.getvalue()
+    ok, _, _ = wrappers.decode_utterance_lattice_faster(d, ll, "u2", determinize=False, lattice_path=tmp_path / "lat.ark",
+                                                        log=log)
+    (key, st, fin, arcs), = list(kio.read_lattices(tmp_path / "lat.ark"))
+    assert ok and key == "u2" and arcs.size == o.GetRawLattice().arcs.size
+
+
 def test_more_pdfs_than_the_lds_row_holds():
     """P = 9000: only part of the log-likelihood row is staged in LDS, the rest is read from HBM."""
     g = synth.make_hclg(num_units=4500, vocab=300, n_hist=20, seed=8)
