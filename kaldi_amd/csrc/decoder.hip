@@ -39,6 +39,7 @@ typedef unsigned int u32;
 #define FIN_CAP 6144         // tokens per frame the finalize sweep keeps in LDS (6 arrays)
 #define LDS_TABLE_CAP 8192   // level-1 table words (64 KB of the CU's 160 KB LDS)
 #define SMALL_DEG 4
+#define EXPT 3            // tokens per thread whose records are fetched together (EXPT * NT == BIGCAP)
 #define ARCW 4           // arcs in flight per thread in the arc-parallel expansion
 #define CHUNKCAP 5120    // cached chunk owners (16 arcs each) per flatten batch
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
@@ -466,6 +467,8 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
 }
 
 #define COMMIT_KEEP 2
+#define INSB 4            // links per thread fetched together in InsertEmitted (>= COMMIT_KEEP)
+static_assert(EXPT * NT == BIGCAP, "one outer expansion iteration must fit the flatten queue");
 static_assert(LDS_TABLE_CAP <= 256 * 32, "CommitFrame2 keeps one 'queued' bit per level-1 slot in Sh::hist[256]");
 static_assert(LDS_TABLE_CAP <= 65536, "level-1 slots are listed as 16-bit values");
 // Dense sweep over the frame's recorded emitting links (lattice-faster-decoder.cc:803-809):
@@ -476,29 +479,40 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
                                     int n_links, float cutoff, int (&my_slot)[COMMIT_KEEP]) {
   int k_surv = 0;
   const int le = min(link_begin + n_links, c.lnk_cap);
-  auto one = [&](int li) -> int {
-    const Link L = c.links[li];
-    const float tot = c.tok_cost[L.src] + L.ac + L.graph;
-    int dst = -1;
-    if (tot <= cutoff) {                       // :798 with the frame's final cutoff
-      bool improved;
-      dst = TblInsert(d, c, sh, tbl, L.dst, tot, &improved);
-      k_surv += dst >= 0;
-    }
-    return dst;
-  };
-  // the first COMMIT_KEEP links of a thread: the slot stays in a register until the commit
-  // resolves it to a token (only a rejection is written back now)
 #pragma unroll
-  for (int k = 0; k < COMMIT_KEEP; k++) {
-    const int li = link_begin + threadIdx.x + k * NT;
-    my_slot[k] = -1;
-    if (li < le) {
-      my_slot[k] = one(li);
-      if (my_slot[k] < 0) c.links[li].dst = -1;
+  for (int k = 0; k < COMMIT_KEEP; k++) my_slot[k] = -1;
+  // INSB links per thread per trip: the records, then the source costs, are loaded for the
+  // whole batch before the first insert (two dependent round trips per batch, not per link)
+  for (int g0 = 0; link_begin + g0 * NT < le; g0 += INSB) {
+    Link L[INSB]; float cs[INSB];
+#pragma unroll
+    for (int k = 0; k < INSB; k++) {
+      const int li = link_begin + threadIdx.x + (g0 + k) * NT;
+      L[k].src = 0; L[k].dst = 0; L[k].ilabel = 0; L[k].olabel = 0; L[k].graph = 0.f; L[k].ac = 0.f;
+      if (li < le) L[k] = c.links[li];
+    }
+#pragma unroll
+    for (int k = 0; k < INSB; k++) {
+      const int li = link_begin + threadIdx.x + (g0 + k) * NT;
+      cs[k] = li < le ? c.tok_cost[L[k].src] : INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < INSB; k++) {
+      const int li = link_begin + threadIdx.x + (g0 + k) * NT;
+      if (li >= le) continue;
+      const float tot = cs[k] + L[k].ac + L[k].graph;
+      int dst = -1;
+      if (tot <= cutoff) {                       // :798 with the frame's final cutoff
+        bool improved;
+        dst = TblInsert(d, c, sh, tbl, L[k].dst, tot, &improved);
+        k_surv += dst >= 0;
+      }
+      // the first COMMIT_KEEP links of a thread: the slot stays in a register until the commit
+      // resolves it to a token (only a rejection is written back now)
+      if (g0 == 0 && k < COMMIT_KEEP) { my_slot[k] = dst; if (dst < 0) c.links[li].dst = -1; }
+      else c.links[li].dst = dst;
     }
   }
-  for (int li = link_begin + threadIdx.x + COMMIT_KEEP * NT; li < le; li += NT) c.links[li].dst = one(li);
   return k_surv;
 }
 
@@ -1171,14 +1185,30 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     // takes arc j (consecutive lanes read consecutive 16-B arcs of one state), whatever
     // the degree distribution is.
     int n_exp = 0; long long a_emit = 0;
-    for (int base = 0; base < n; base += NT) {
-      const int i = base + tid;
-      if (i < n) {
-        const float cur_cost = cost[i];
-        if (cur_cost <= cur_cutoff) {           // :787
+    // EXPT tokens per thread per outer iteration: their costs, states and arc ranges are all
+    // loaded before the first one is expanded (three dependent round trips per BATCH of
+    // tokens instead of per token).  EXPT * NT = BIGCAP tokens are queued at most, so the
+    // queue is flushed after every outer iteration and cannot overflow.
+    for (int base = 0; base < n; base += EXPT * NT) {
+      float tcost[EXPT]; int tstate[EXPT]; u32 ta0[EXPT], ta1[EXPT];
+#pragma unroll
+      for (int k = 0; k < EXPT; k++) {
+        const int i = base + tid + k * NT;
+        tcost[k] = INFINITY; tstate[k] = 0;
+        if (i < n) { tcost[k] = cost[i]; tstate[k] = state[i]; }
+      }
+#pragma unroll
+      for (int k = 0; k < EXPT; k++) {
+        ta0[k] = 0; ta1[k] = 0;
+        if (base + tid + k * NT < n && tcost[k] <= cur_cutoff) { ta0[k] = d.g.off[tstate[k]].x; ta1[k] = d.g.off[tstate[k] + 1].x; }   // :787 (the cutoff may be +inf)
+      }
+#pragma unroll
+      for (int k = 0; k < EXPT; k++) {
+        const int i = base + tid + k * NT;
+        if (i < n && tcost[k] <= cur_cutoff) {
+          const float cur_cost = tcost[k];
           n_exp++;
-          const int s = state[i];
-          const u32 a0 = d.g.off[s].x, a1 = d.g.off[s + 1].x;
+          const u32 a0 = ta0[k], a1 = ta1[k];
           const u32 deg = a1 - a0;
           a_emit += deg;
           if (deg <= SMALL_DEG) {
@@ -1192,13 +1222,12 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
             }
             ProcessArcs<SMALL_DEG>(d, c, &sh, tbl, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base);
           } else {
-            const int p = WaveAlloc(&sh.bigcnt);   // < BIGCAP: flushed below before it can fill
+            const int p = WaveAlloc(&sh.bigcnt);   // < BIGCAP: at most EXPT * NT entries per outer iteration
             big_tok[p] = i; big_a0[p] = a0; big_scan[p] = deg;
           }
         }
       }
-      const bool last_chunk = base + NT >= n;
-      if (n <= BIGCAP && !last_chunk) continue;    // the queue cannot overflow: flush once (uniform)
+      const bool last_chunk = true;                // the queue is flushed after every outer iteration
       LdsBarrier();
       const int nb = sh.bigcnt;                    // uniform: read between two barriers
       LdsBarrier();
