@@ -97,7 +97,18 @@ def pmc_traffic(args):
     return best
 
 
-def cpu_baseline(g, model, waves, cfg, budget_s):
+def _edit_distance(a, b):
+    """Levenshtein distance between two word sequences (bin/compute-wer.cc semantics)."""
+    prev = list(range(len(b) + 1))
+    for i, x in enumerate(a, 1):
+        cur = [i]
+        for j, y in enumerate(b, 1):
+            cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (x != y)))
+        prev = cur
+    return prev[-1]
+
+
+def cpu_baseline(g, model, waves, cfg, budget_s, gpu_results=None):
     """The CPU oracle (a port of the reference path: faithful decoder mode 0) timed
     single-threaded on this host on a bounded sample of the same workload."""
     from kaldi_amd import abi
@@ -105,6 +116,7 @@ def cpu_baseline(g, model, waves, cfg, budget_s):
     order = np.argsort([w.size for w in waves])
     t_total, audio, n = 0.0, 0.0, 0
     sample = []
+    errs, ref_words = 0, 0
     for idx in order:                      # shortest utterances first, until the budget is spent
         w = waves[idx]
         t0 = time.time()
@@ -113,17 +125,25 @@ def cpu_baseline(g, model, waves, cfg, budget_s):
         d = orc.Decoder(g, cfg, 0)
         d.Decode(ll)
         lat = d.GetRawLattice()
-        if lat is not None:
-            lat.best_path()
+        bp = lat.best_path() if lat is not None else None
         t_total += time.time() - t0
+        if gpu_results is not None and bp is not None and gpu_results[idx] is not None:
+            ref = bp["words"].tolist()                         # the CPU path's 1-best is the "reference transcript"
+            errs += _edit_distance(ref, gpu_results[idx]["words"].tolist())
+            ref_words += len(ref)
         audio += w.size / 16000.0
         n += 1
         sample.append(round(w.size / 16000.0, 2))
         if t_total > budget_s:
             break
-    return {"value": audio / t_total, "unit": "audio-sec/wall-sec", "cores": 1, "kind": "port",
-            "sample": "%d shortest utterance(s) of the batch (%.1f s audio, %.1f s CPU): whole path "
-                      "MFCC+nnet+LatticeFasterDecoder(order-faithful oracle)+best path" % (n, audio, t_total)}
+    out = {"value": audio / t_total, "unit": "audio-sec/wall-sec", "cores": 1, "kind": "port",
+           "sample": "%d shortest utterance(s) of the batch (%.1f s audio, %.1f s CPU): whole path "
+                     "MFCC+nnet+LatticeFasterDecoder(order-faithful oracle)+best path" % (n, audio, t_total)}
+    if gpu_results is not None and ref_words > 0:
+        # BASELINE's "WER-equal" clause on synthetic data: word errors of the device 1-best
+        # against the CPU path's 1-best on the same utterances
+        out["wer_vs_cpu_1best"] = {"errors": errs, "ref_words": ref_words, "wer_percent": 100.0 * errs / ref_words}
+    return out
 
 
 def main():
@@ -252,7 +272,7 @@ def main():
         "setup_s": t_build,
     }
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, args.cpu_budget)
+        out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, args.cpu_budget, res)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out, default=float))
