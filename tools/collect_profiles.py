@@ -51,6 +51,17 @@ for kern, key in (("AdvanceKernel", "advance"), ("FinalizeKernel", "finalize")):
     if fe and wr:
         out[key] = {"launches": len(fe), "FETCH_SIZE_KB_mean": sum(fe) / len(fe), "WRITE_SIZE_KB_mean": sum(wr) / len(wr),
                     "traffic_bytes_per_launch": 2 * 1024 * sum(fe) / len(fe) + 1024 * sum(wr) / len(wr)}
+sq = {}
+for dname in ("pmc_sq1", "pmc_sq2", "pmc_sq3"):
+    for f in glob.glob(os.path.join(R, dname, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "AdvanceKernel" in row["Kernel_Name"]:
+                sq.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+if sq:
+    out["advance_sq_counters_per_launch"] = {k: sum(v) / len(v) for k, v in sq.items()}
+    w = out["advance_sq_counters_per_launch"]
+    if "SQ_WAVE_CYCLES" in w and "SQ_WAIT_ANY" in w and w["SQ_WAVE_CYCLES"] > 0:
+        out["advance_wait_fraction"] = w["SQ_WAIT_ANY"] / w["SQ_WAVE_CYCLES"]
 mf = {}
 for f in glob.glob(os.path.join(R, "pmc_mfma", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):

@@ -12,6 +12,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o 
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write.json 2> $O/pmc_write.err
 timeout 300 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $O/pmc_mfma -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_mfma.json 2> $O/pmc_mfma.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq1 -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_sq1.json 2> $O/pmc_sq1.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $O/pmc_sq2 -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_sq2.json 2> $O/pmc_sq2.err
+timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq3 -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_sq3.json 2> $O/pmc_sq3.err
 for cfg in "light --ll-std 2.0" "saturated --ll-std 1.0" "b256 --utts 256" "b512 --utts 512"; do
   set -- $cfg; name=$1; shift
   timeout 400 python3 bench.py --no-cpu-baseline "$@" > $O/bench_$name.json 2> $O/bench_$name.err
