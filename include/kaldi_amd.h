@@ -382,6 +382,35 @@ int kamd_lattice_write(const char *path, int append, const char *key, int binary
 int kamd_lattice_read(const char *path, int64_t *offset, char *key, int key_cap,
                       int32_t *num_states, int32_t *start, float **state_final,
                       kamd_lat_arc **arcs, int32_t *num_arcs);
+/* ------------------------------------------------------- batched streaming -- */
+/* N concurrent SingleUtteranceNnet3Decoder streams (online2/online-nnet3-decoding.{h,cc})
+ * driven together: stream s is decoder lane s of `dec` (created with max_lanes >= max_streams).
+ * Waveforms and features of all streams live in two pooled HBM buffers; one tick costs one
+ * feature launch, one batched nnet forward and one AdvanceKernel launch, whatever the number of
+ * streams.  Results per stream through the decoder entry points with lane = stream
+ * (kamd_decoder_partial_best_path while streaming; kamd_decoder_finalize + lattice at the end). */
+typedef struct kamd_stream_batch kamd_stream_batch;
+kamd_stream_batch *kamd_stream_batch_create(kamd_feat *feat, kamd_nnet *nnet, kamd_decoder *dec,
+                                            int max_streams, float max_seconds, float samp_freq);
+void kamd_stream_batch_destroy(kamd_stream_batch *b);
+/* new utterance on these streams (InitDecoding, online-nnet3-decoding.cc:40) */
+int kamd_stream_batch_start(kamd_stream_batch *b, const int32_t *streams, int n);
+/* AcceptWaveform (+ InputFinished when input_finished != 0); host samples, int16 range */
+int kamd_stream_batch_accept(kamd_stream_batch *b, int stream, const float *wave, int64_t n,
+                             int input_finished);
+/* AdvanceDecoding for all listed streams; frames_decoded[n] may be NULL */
+int kamd_stream_batch_advance(kamd_stream_batch *b, const int32_t *streams, int n, int32_t *frames_decoded);
+int kamd_stream_batch_num_frames_ready(const kamd_stream_batch *b, int stream);
+/* building blocks of the above: frames [first, first+count) of n waveforms that are not
+ * adjacent in memory, and an nnet forward over n non-adjacent feature slices */
+int kamd_feat_compute_ranges_device(kamd_feat *f, const float *d_waves, const int64_t *h_wave_start,
+                                    const int64_t *h_wave_len, const int32_t *h_first_frame,
+                                    const int32_t *h_num_frames, int n, float *d_out,
+                                    const int64_t *h_row_off, int ld_out, void *stream);
+int kamd_nnet_forward_slices_device(kamd_nnet *n, const float *d_feats, const int64_t *h_in_start,
+                                    const int32_t *h_in_len, int ld_in, const float *d_ivectors, int n_items,
+                                    float *d_out, const int64_t *h_out_row_off, int ld_out, void *stream);
+
 /* ------------------------------------------------- lattice determinization -- */
 /* DeterminizeLatticePhonePrunedOptions + DeterminizeLatticePrunedOptions
  * (lat/determinize-lattice-pruned.h:126-141, 214-245), same defaults.  minimize is not

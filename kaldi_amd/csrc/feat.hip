@@ -59,13 +59,16 @@ __global__ __launch_bounds__(256) void FeatKernel(
     FeatDev fd, const float *__restrict__ waves, const int64_t *__restrict__ wave_off,
     const int64_t *__restrict__ frame_off /* [n_utts+1] cumulative frames */,
     const int64_t *__restrict__ row_off /* [n_utts] output row of frame 0 */, int n_utts,
-    float *__restrict__ out, int ld_out, int frame0 /* index of the first frame (streaming) */) {
+    float *__restrict__ out, int ld_out, int frame0 /* index of the first frame (streaming) */,
+    const int *__restrict__ frame0_per_utt /* or NULL: per-utterance first frame (batched streaming) */) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int N = fd.N;
   float *re = smem + wave * (2 * N + 128);
   float *im = re + N;
   float *aux = im + N;  // [128]: log-mel energies etc.
+  const bool pairs = n_utts < 0;          // wave_off holds (start, end) pairs: items are not adjacent
+  if (pairs) n_utts = -n_utts;
   const int64_t total = frame_off[n_utts];
   const int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wave;
   const bool live = g < total;
@@ -74,9 +77,10 @@ __global__ __launch_bounds__(256) void FeatKernel(
   const float *wav = waves;
   if (live) {
     u = FindUtt(frame_off, n_utts, g);
+    if (frame0_per_utt) frame0 = frame0_per_utt[u];
     f = static_cast<int>(g - frame_off[u]) + frame0;
-    wav = waves + wave_off[u];
-    nsamp = wave_off[u + 1] - wave_off[u];
+    wav = waves + (pairs ? wave_off[2 * u] : wave_off[u]);
+    nsamp = pairs ? wave_off[2 * u + 1] - wave_off[2 * u] : wave_off[u + 1] - wave_off[u];
   }
   // --- ExtractWindow: FirstSampleOfFrame + reflection (feature-window.cc:28-39,191-208)
   int64_t start;
@@ -465,7 +469,49 @@ int kamd_feat_compute_batch_device(kamd_feat *h, const float *d_waves, const int
   int blocks = kamd::CeilDiv(tot, 4);
   size_t lds = 4 * (2 * f->dev.N + 128) * sizeof(float);
   hipLaunchKernelGGL(kamd::FeatKernel, dim3(blocks), dim3(256), lds, st, f->dev, d_waves, d_meta,
-                     d_meta + (n_utts + 1), d_meta + 2 * (n_utts + 1), n_utts, d_out, ld_out, 0);
+                     d_meta + (n_utts + 1), d_meta + 2 * (n_utts + 1), n_utts, d_out, ld_out, 0, NULL);
+  KAMD_HIP(hipGetLastError());
+  return KAMD_OK;
+}
+
+// Frames [first_frame[u], first_frame[u] + num_frames[u]) of n device-resident waveforms in
+// ONE launch (batched streaming: the frames that became computable on every stream).
+int kamd_feat_compute_ranges_device(kamd_feat *h, const float *d_waves, const int64_t *h_wave_start,
+                                    const int64_t *h_wave_len, const int32_t *h_first_frame,
+                                    const int32_t *h_num_frames, int n, float *d_out, const int64_t *h_row_off,
+                                    int ld_out, void *stream) {
+  Feat *f = reinterpret_cast<Feat *>(h);
+  if (n <= 0) return KAMD_OK;
+  if (ld_out < f->dev.num_out) return kamd::SetError(KAMD_ERR_ARG, "ld_out < feature dim");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // meta: (wave start, wave end) pairs [2(n+1)] | frame_off[n+1] | row_off[n+1] | first_frame[n] (int32);
+  // n_utts is passed negated to tell the kernel that the wave offsets are pairs
+  std::vector<int64_t> meta(4 * (n + 1) + (n + 1) / 2 + 1, 0);
+  int64_t tot = 0;
+  int32_t *f0 = reinterpret_cast<int32_t *>(&meta[4 * (n + 1)]);
+  for (int u = 0; u < n; u++) {
+    meta[2 * u] = h_wave_start[u]; meta[2 * u + 1] = h_wave_start[u] + h_wave_len[u];
+    meta[2 * (n + 1) + u] = tot;
+    tot += h_num_frames[u] > 0 ? h_num_frames[u] : 0;
+    meta[3 * (n + 1) + u] = h_row_off[u];
+    f0[u] = h_first_frame[u];
+  }
+  meta[2 * (n + 1) + n] = tot;
+  if (tot == 0) return KAMD_OK;
+  if (meta.size() > f->meta_cap) {
+    KAMD_HIP(hipStreamSynchronize(st));
+    if (f->d_meta) KAMD_HIP(hipFree(f->d_meta));
+    f->d_meta = NULL; f->meta_cap = 0;
+    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&f->d_meta), 2 * meta.size() * 8));
+    f->meta_cap = 2 * meta.size();
+  }
+  int64_t *d_meta = f->d_meta;
+  KAMD_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));  // 'meta' is a host temporary
+  const size_t lds = 4 * (2 * f->dev.N + 128) * sizeof(float);
+  hipLaunchKernelGGL(kamd::FeatKernel, dim3(kamd::CeilDiv(tot, 4)), dim3(256), lds, st, f->dev, d_waves, d_meta,
+                     d_meta + 2 * (n + 1), d_meta + 3 * (n + 1), -n, d_out, ld_out, 0,
+                     reinterpret_cast<const int *>(d_meta + 4 * (n + 1)));
   KAMD_HIP(hipGetLastError());
   return KAMD_OK;
 }
@@ -501,7 +547,7 @@ int kamd_feat_compute_frames_device(kamd_feat *h, const float *d_wave, int64_t n
   KAMD_HIP(hipStreamSynchronize(st));
   const size_t lds = 4 * (2 * f->dev.N + 128) * sizeof(float);
   hipLaunchKernelGGL(kamd::FeatKernel, dim3(kamd::CeilDiv(num_frames, 4)), dim3(256), lds, st, f->dev, d_wave, f->d_meta,
-                     f->d_meta + 2, f->d_meta + 4, 1, d_out, ld_out, first_frame);
+                     f->d_meta + 2, f->d_meta + 4, 1, d_out, ld_out, first_frame, NULL);
   KAMD_HIP(hipGetLastError());
   return KAMD_OK;
 }

@@ -408,9 +408,11 @@ int kamd_nnet_num_output_frames(const kamd_nnet *h, int T) {
 }
 double kamd_nnet_last_flops(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->last_flops; }
 
-int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_row_off,
-                                   int ld_in, const float *d_ivectors, int n_utts, float *d_out,
-                                   const int64_t *h_out_row_off, int ld_out, void *stream) {
+// h_in_start[u] / h_in_len[u]: first feature row and number of input frames of item u (the
+// items need not be adjacent: streaming slices of different streams live in one pooled buffer)
+static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_start, const int32_t *h_in_len,
+                        int ld_in, const float *d_ivectors, int n_utts, float *d_out,
+                        const int64_t *h_out_row_off, int ld_out, void *stream) {
   Nnet *nn = reinterpret_cast<Nnet *>(h);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nl = static_cast<int>(nn->L.size()), sub = nn->subsampling;
@@ -425,12 +427,12 @@ int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int
   int *Th = reinterpret_cast<int *>(&meta[(nl + 2) * stride]);
   std::vector<int> n_out(n_utts);
   for (int u = 0; u < n_utts; u++) {
-    int T = static_cast<int>(h_in_row_off[u + 1] - h_in_row_off[u]);
+    int T = h_in_len[u];
     if (T <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no frames", u);
     Th[u] = T; n_out[u] = (T + sub - 1) / sub;
-    meta[nl * stride + u] = h_in_row_off[u];         // feature rows
+    meta[nl * stride + u] = h_in_start[u];           // feature rows
   }
-  meta[nl * stride + n_utts] = h_in_row_off[n_utts];
+  meta[nl * stride + n_utts] = h_in_start[n_utts - 1] + h_in_len[n_utts - 1];
   std::vector<int64_t> M(nl, 0);
   for (int l = 0; l < nl; l++) {
     int64_t acc = 0;
@@ -548,6 +550,21 @@ int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int
   }
   nn->last_flops = flops;
   return KAMD_OK;
+}
+
+int kamd_nnet_forward_batch_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_row_off,
+                                   int ld_in, const float *d_ivectors, int n_utts, float *d_out,
+                                   const int64_t *h_out_row_off, int ld_out, void *stream) {
+  if (n_utts <= 0) return KAMD_OK;
+  std::vector<int32_t> len(n_utts);
+  for (int u = 0; u < n_utts; u++) len[u] = static_cast<int32_t>(h_in_row_off[u + 1] - h_in_row_off[u]);
+  return ForwardItems(h, d_feats, h_in_row_off, len.data(), ld_in, d_ivectors, n_utts, d_out, h_out_row_off, ld_out, stream);
+}
+
+int kamd_nnet_forward_slices_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_start,
+                                    const int32_t *h_in_len, int ld_in, const float *d_ivectors, int n_items,
+                                    float *d_out, const int64_t *h_out_row_off, int ld_out, void *stream) {
+  return ForwardItems(h, d_feats, h_in_start, h_in_len, ld_in, d_ivectors, n_items, d_out, h_out_row_off, ld_out, stream);
 }
 
 int kamd_nnet_forward(kamd_nnet *h, const float *feats, int T, const float *ivector, float *out,

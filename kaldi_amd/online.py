@@ -199,3 +199,54 @@ def trailing_silence_length(best_path, tid2phone, silence_phones):
         else:
             break
     return n
+
+
+class StreamBatch:
+    """N concurrent streams decoded together (kamd_stream_batch_*): stream s = decoder lane s."""
+
+    def __init__(self, mfcc_opts, nnet, graph, config, max_streams, max_seconds=40.0, sizes=None):
+        self.feat = __import__("kaldi_amd.feat", fromlist=["Mfcc"]).Mfcc(mfcc_opts)
+        self.nnet, self.graph, self.config = nnet, graph, config
+        sub = lib().kamd_nnet_frame_subsampling_factor(nnet._h)
+        if sizes is None:
+            from .pipeline import default_sizes
+            sizes = default_sizes(config, max_streams, int(max_seconds * 100 / sub) + 2)
+        self.dec = decoder.BatchDecoder(graph, config, sizes)
+        self._h = lib().kamd_stream_batch_create(self.feat._h, nnet._h, self.dec._dec, max_streams, max_seconds,
+                                                 mfcc_opts.frame.samp_freq)
+        if not self._h:
+            raise KamdError(lib().kamd_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kamd_stream_batch_destroy(self._h)
+            self._h = None
+
+    def start(self, streams):
+        s = np.ascontiguousarray(streams, np.int32)
+        check(lib().kamd_stream_batch_start(self._h, abi.iptr(s), s.size))
+
+    def accept(self, stream, waveform, input_finished=False):
+        w = np.ascontiguousarray(waveform, np.float32)
+        check(lib().kamd_stream_batch_accept(self._h, int(stream), abi.fptr(w), w.size, int(input_finished)))
+
+    def advance(self, streams):
+        """One tick for these streams; returns NumFramesDecoded of each."""
+        s = np.ascontiguousarray(streams, np.int32)
+        out = np.zeros(s.size, np.int32)
+        check(lib().kamd_stream_batch_advance(self._h, abi.iptr(s), s.size, abi.iptr(out)))
+        return out
+
+    def partial_best_path(self, stream, use_final_probs=False):
+        return decoder.partial_best_path(self.dec._dec, int(stream), use_final_probs)
+
+    def finalize(self, streams):
+        s = np.ascontiguousarray(streams, np.int32)
+        check(lib().kamd_decoder_finalize(self.dec._dec, abi.iptr(s), s.size, None))
+        check(lib().kamd_decoder_sync(self.dec._dec))
+
+    def raw_lattice(self, stream):
+        return decoder.get_raw_lattice(self.dec._dec, int(stream))
+
+    def best_path(self, stream):
+        return decoder.best_path(self.dec._dec, int(stream))

@@ -109,3 +109,58 @@ def test_streaming_decode_equals_offline_and_partial_results():
     off = decoder.LatticeFasterDecoder(G, cfg, sz)
     off.Decode(N.Forward(feat.Mfcc(op).ComputeFeatures(w)))
     assert lattices_equal(s.GetRawLattice(), off.GetRawLattice())
+
+
+def test_batched_streams_equal_offline():
+    """Five streams of different lengths fed in unequal, unaligned chunks and decoded together:
+    every stream's lattice equals the offline decode of its whole waveform, and a stream slot
+    can be reused for a new utterance."""
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=3.0)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    S = 5
+    sb = online.StreamBatch(op, N, G, cfg, S, max_seconds=6.0, sizes=abi.DecoderSizes(S, 1 << 14, 1 << 19, 1 << 20, 512))
+    rng = np.random.default_rng(0)
+    durs = [2.9, 1.3, 4.1, 0.7, 3.3]
+    waves = [synth.make_wave(d, seed=20 + i) for i, d in enumerate(durs)]
+    off_sz = abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512)
+
+    def offline(w):
+        d = decoder.LatticeFasterDecoder(G, cfg, off_sz)
+        d.Decode(N.Forward(feat.Mfcc(op).ComputeFeatures(w)))
+        return d.GetRawLattice()
+
+    sb.start(np.arange(S))
+    pos = [0] * S
+    done = [False] * S
+    ticks = 0
+    while not all(done):
+        live = [s for s in range(S) if not done[s]]
+        for s in live:
+            n = int(rng.integers(800, 6000))                 # 50 .. 375 ms, different per stream and tick
+            chunk = waves[s][pos[s]:pos[s] + n]
+            pos[s] += chunk.size
+            sb.accept(s, chunk, input_finished=pos[s] >= waves[s].size)
+        before = [int(x) for x in sb.advance(live)]
+        for s, nd in zip(live, before):
+            if pos[s] >= waves[s].size:
+                done[s] = True
+        ticks += 1
+    assert ticks > 5
+    sb.finalize(np.arange(S))
+    for s in range(S):
+        want = offline(waves[s])
+        got = sb.raw_lattice(s)
+        assert lattices_equal(got, want), (s, lattice_diff(got, want))
+    # reuse slot 1 for another utterance while the others keep their results
+    w2 = synth.make_wave(1.9, seed=77)
+    sb.start([1])
+    for i in range(0, w2.size, CHUNK):
+        sb.accept(1, w2[i:i + CHUNK], input_finished=i + CHUNK >= w2.size)
+        sb.advance([1])
+        if i > 3 * CHUNK:
+            assert sb.partial_best_path(1) is not None
+    sb.finalize([1])
+    assert lattices_equal(sb.raw_lattice(1), offline(w2))
+    assert lattices_equal(sb.raw_lattice(2), offline(waves[2]))

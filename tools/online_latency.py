@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=12.0)
 ap.add_argument("--chunk", type=float, default=0.24)
 ap.add_argument("--ll-std", type=float, default=1.3)
+ap.add_argument("--streams", type=int, default=0, help="> 0: that many concurrent streams through kamd_stream_batch")
 a = ap.parse_args()
 g = synth.make_hclg(num_units=1164, vocab=20000, n_hist=18000, fanout=(12, 64), pron_len=(3, 7), seed=2,
                     self_loop_prob=0.5, lm_scale=0.1)
@@ -24,6 +25,32 @@ wave = synth.make_wave(a.seconds, seed=7)
 from bench import calibrate
 calibrate(model, a.ll_std)
 N, G = decoder.Nnet(model), decoder.Graph(g)
+if a.streams > 0:
+    S = a.streams
+    waves = [synth.make_wave(a.seconds, seed=100 + i) for i in range(S)]
+    sb = online.StreamBatch(abi.mfcc_opts_hires(), N, G, cfg, S, max_seconds=a.seconds + 1)
+    step = int(a.chunk * 16000)
+    for rep in range(2):
+        sb.start(np.arange(S))
+        lat = []
+        for i in range(0, waves[0].size, step):
+            t0 = time.perf_counter()
+            for s_ in range(S):
+                sb.accept(s_, waves[s_][i:i + step], input_finished=i + step >= waves[s_].size)
+            t1 = time.perf_counter()
+            nd = sb.advance(np.arange(S))
+            lat.append((time.perf_counter() - t1, t1 - t0))
+        t0 = time.perf_counter()
+        sb.finalize(np.arange(S))
+        fin = time.perf_counter() - t0
+    adv = np.asarray([x[0] for x in lat]) * 1e3
+    up = np.asarray([x[1] for x in lat]) * 1e3
+    print("%d streams x %.1f s in %.0f ms chunks: %d ticks, %d frames decoded per stream" % (S, a.seconds, a.chunk * 1e3, adv.size, int(nd[0])))
+    print("per tick: upload %.2f ms + features/nnet/AdvanceDecoding for all streams %.2f ms median (p95 %.2f, max %.2f)"
+          % (np.median(up), np.median(adv), np.percentile(adv, 95), adv.max()))
+    print("aggregate %.0f x real time (compute only %.0f x); FinalizeDecoding of all streams %.2f ms"
+          % (S * a.seconds * 1e3 / (adv.sum() + up.sum()), S * a.seconds * 1e3 / adv.sum(), fin * 1e3))
+    sys.exit(0)
 for rep in range(2):                      # first pass warms up allocations / code objects
     d = online.SingleUtteranceNnet3Decoder(abi.mfcc_opts_hires(), N, G, cfg, max_seconds=a.seconds + 1)
     step = int(a.chunk * 16000)
