@@ -437,5 +437,84 @@ class Mfcc {
   kamd_feat *f_;
 };
 
+// ------------------------------------------------ online2/online-nnet3-decoding.h:52-121
+/// The acoustic model handle (nnet3::AmNnetSimple after CollapseModel): kamd_layer_desc list.
+class AmNnetSimple {
+ public:
+  AmNnetSimple(const std::vector<kamd_layer_desc> &layers, int32 input_dim, int32 frame_subsampling_factor)
+      : n_(CheckPtr(kamd_nnet_create(layers.data(), static_cast<int>(layers.size()), input_dim, frame_subsampling_factor))) {}
+  ~AmNnetSimple() { kamd_nnet_destroy(n_); }
+  kamd_nnet *Handle() const { return n_; }
+  int32 OutputDim() const { return kamd_nnet_output_dim(n_); }
+ private:
+  AmNnetSimple(const AmNnetSimple &);
+  kamd_nnet *n_;
+};
+
+/// SingleUtteranceNnet3DecoderTpl<fst::Fst<fst::StdArc>>: streaming decode of one utterance.
+/// OnlineNnet2FeaturePipeline is reduced to its MFCC part (no ivector / pitch), the
+/// DecodableNnetLoopedOnline to the rows kamd_nnet_forward_range serves.
+class SingleUtteranceNnet3Decoder {
+ public:
+  SingleUtteranceNnet3Decoder(const LatticeFasterDecoderConfig &decoder_opts, const std::vector<int32> &id2pdf,
+                              const AmNnetSimple &am_nnet, const DecodingGraph &fst, const MfccOptions &mfcc_opts,
+                              const kamd_decoder_sizes *sizes = NULL)
+      : nnet_(am_nnet.Handle()), feat_(CheckPtr(kamd_mfcc_create(&mfcc_opts.c, 1.0f))),
+        online_(CheckPtr(kamd_online_feat_create(feat_))), decoder_(fst, decoder_opts, id2pdf, sizes), finished_(false) {
+    decoder_.InitDecoding();                          // online-nnet3-decoding.cc:40
+  }
+  ~SingleUtteranceNnet3Decoder() { kamd_online_feat_destroy(online_); kamd_feat_destroy(feat_); }
+  void AcceptWaveform(BaseFloat sampling_rate, const std::vector<float> &waveform) {
+    Check(kamd_online_feat_accept_waveform(online_, sampling_rate, waveform.data(), static_cast<int64_t>(waveform.size())));
+  }
+  void InputFinished() { Check(kamd_online_feat_input_finished(online_)); finished_ = true; }
+  /// advances the decoding as far as we can (online-nnet3-decoding.cc:51-53)
+  void AdvanceDecoding() {
+    const int32 done = decoder_.NumFramesDecoded();
+    const int32 feat_ready = kamd_online_feat_num_frames_ready(online_);
+    const int32 n = kamd_nnet_num_frames_ready(nnet_, feat_ready, finished_) - done;
+    if (n <= 0) return;
+    const int32 P = kamd_nnet_output_dim(nnet_);
+    float *d_ll = static_cast<float *>(CheckPtr(kamd_malloc(static_cast<size_t>(n) * P * sizeof(float))));
+    int ld = 0;
+    const float *d_feats = kamd_online_feat_device_frames(online_, &ld);
+    int rc = kamd_nnet_forward_range(nnet_, d_feats, ld, feat_ready, finished_, done, n, d_ll, P);
+    if (rc == 0) {
+      kamd_decode_task t = {0, n, d_ll, P, 0};
+      rc = kamd_decoder_advance(decoder_.Handle(), &t, 1, NULL);
+      if (rc == 0) rc = kamd_decoder_sync(decoder_.Handle());
+    }
+    kamd_free(d_ll);
+    Check(rc);
+  }
+  void FinalizeDecoding() { decoder_.FinalizeDecoding(); }
+  int32 NumFramesDecoded() const { return decoder_.NumFramesDecoded(); }
+  /// GetBestPath(end_of_utterance, &best_path) (online-nnet3-decoding.cc:81-85): before
+  /// FinalizeDecoding this is BestPathEnd + TraceBackBestPath of the online decoder.
+  bool GetBestPath(bool end_of_utterance, std::vector<int32> *alignment, std::vector<int32> *words,
+                   BaseFloat *graph_cost, BaseFloat *acoustic_cost) const {
+    kamd_lattice_size sz;
+    if (kamd_decoder_lattice_size(decoder_.Handle(), 0, &sz) == 0)      // finalized
+      return decoder_.GetBestPath(alignment, words, graph_cost, acoustic_cost);
+    const int cap = 4 * (decoder_.NumFramesDecoded() + 2) + 1024;
+    std::vector<int32> ali(cap), wrd(cap);
+    int na = 0, nw = 0;
+    if (kamd_decoder_partial_best_path(decoder_.Handle(), 0, end_of_utterance ? 1 : 0, ali.data(), cap, &na, wrd.data(), cap,
+                                       &nw, graph_cost, acoustic_cost) != 0)
+      return false;
+    alignment->assign(ali.begin(), ali.begin() + na);
+    words->assign(wrd.begin(), wrd.begin() + nw);
+    return true;
+  }
+  const LatticeFasterDecoder &Decoder() const { return decoder_; }
+ private:
+  SingleUtteranceNnet3Decoder(const SingleUtteranceNnet3Decoder &);
+  kamd_nnet *nnet_;
+  kamd_feat *feat_;
+  kamd_online_feat *online_;
+  LatticeFasterDecoder decoder_;
+  bool finished_;
+};
+
 }  // namespace kaldi_amd
 #endif  // KALDI_AMD_HPP_

@@ -4,6 +4,7 @@
 // tests/test_gpu_cxx_host.py.  Output: one line per decode, compared with the oracle there.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "kaldi_amd.hpp"
@@ -106,6 +107,57 @@ int main(int argc, char **argv) {
                                                      &ali_writer, &words_writer, &clat_writer, &lat_writer, &like);
         printf("wrapper ok=%d like=%.6g\n", ok, like);
       }
+    }
+    // streaming: SingleUtteranceNnet3Decoder fed in 0.18 s chunks (model + waveform from a second fixture)
+    if (argc >= 4) {
+      FILE *mf = fopen(argv[3], "rb");
+      if (!mf) return 2;
+      std::vector<int64_t> mh = ReadVec<int64_t>(mf);        // n_layers, input_dim, subsampling
+      const int nl = static_cast<int>(mh[0]);
+      std::vector<kamd_layer_desc> layers(nl);
+      std::vector<std::vector<float> > keep;
+      for (int l = 0; l < nl; l++) {
+        std::vector<int32> li = ReadVec<int32>(mf);          // in_dim out_dim n_off off[8] input_layer ivector_dim bypass_layer relu log_softmax
+        std::vector<float> lf = ReadVec<float>(mf);          // bypass_scale post_scale
+        kamd_layer_desc &d = layers[l];
+        memset(&d, 0, sizeof(d));
+        d.in_dim = li[0]; d.out_dim = li[1]; d.n_offsets = li[2];
+        for (int k = 0; k < 8; k++) d.offsets[k] = li[3 + k];
+        d.input_layer = li[11]; d.ivector_dim = li[12]; d.bypass_layer = li[13]; d.relu = li[14]; d.log_softmax = li[15];
+        d.bypass_scale = lf[0]; d.post_scale = lf[1];
+        const float **slots[5] = {&d.W, &d.bias, &d.bn_scale, &d.bn_offset, &d.post_offset};
+        for (int k = 0; k < 5; k++) {
+          keep.push_back(ReadVec<float>(mf));
+          *slots[k] = keep.back().empty() ? NULL : keep.back().data();
+        }
+      }
+      // (vectors inside 'keep' may have moved while it grew: re-point)
+      for (int l = 0; l < nl; l++) {
+        const float **slots[5] = {&layers[l].W, &layers[l].bias, &layers[l].bn_scale, &layers[l].bn_offset, &layers[l].post_offset};
+        for (int k = 0; k < 5; k++) *slots[k] = keep[5 * l + k].empty() ? NULL : keep[5 * l + k].data();
+      }
+      std::vector<float> wave = ReadVec<float>(mf);
+      fclose(mf);
+      AmNnetSimple am(layers, static_cast<int32>(mh[1]), static_cast<int32>(mh[2]));
+      MfccOptions mo;
+      mo.c.frame.dither = 0.0f; mo.c.use_energy = 0; mo.c.mel.num_bins = 40; mo.c.num_ceps = 40; mo.c.mel.low_freq = 20; mo.c.mel.high_freq = -400;
+      SingleUtteranceNnet3Decoder sdec(config, id2pdf, am, fst, mo, &sz);
+      const size_t chunk = 2880;
+      int partials = 0;
+      for (size_t i = 0; i < wave.size(); i += chunk) {
+        std::vector<float> part(wave.begin() + i, wave.begin() + std::min(wave.size(), i + chunk));
+        sdec.AcceptWaveform(16000.0f, part);
+        if (i + chunk >= wave.size()) sdec.InputFinished();
+        sdec.AdvanceDecoding();
+        std::vector<int32> ali, words; BaseFloat g, a;
+        if (sdec.NumFramesDecoded() > 0 && sdec.GetBestPath(false, &ali, &words, &g, &a)) partials++;
+      }
+      sdec.FinalizeDecoding();
+      std::vector<int32> ali, words; BaseFloat g = 0, a = 0;
+      const bool ok = sdec.GetBestPath(true, &ali, &words, &g, &a);
+      printf("streaming ok=%d frames=%d partials=%d graph=%.9g acoustic=%.9g words=", ok, sdec.NumFramesDecoded(), partials > 0, g, a);
+      for (size_t i = 0; i < words.size(); i++) printf("%d%s", words[i], i + 1 < words.size() ? "," : "");
+      printf("\n");
     }
     // error convention: a bad config throws like KALDI_ERR
     try {

@@ -38,8 +38,24 @@ def test_cxx_host_api(tmp_path):
         vec(f, g.final.astype(np.float32))
         vec(f, g.tid2pdf.astype(np.int32))
         vec(f, ll)
+    # second fixture: a small TDNN-F model over this graph's pdfs + a waveform, for the streaming mirror
+    from kaldi_amd import decoder, feat, nnet
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=3.0)
+    wave = synth.make_wave(2.3, seed=11)
+    mfx = tmp_path / "model.bin"
+    with open(mfx, "wb") as f:
+        vec(f, np.asarray([len(m.layers), m.input_dim, m.subsampling], np.int64))
+        for l in m.layers:
+            offs = list(l.offsets) + [0] * (8 - len(l.offsets))
+            vec(f, np.asarray([l.in_dim, l.out_dim, len(l.offsets)] + offs + [l.input_layer, l.ivector_dim, l.bypass_layer,
+                               int(l.relu), int(l.log_softmax)], np.int32))
+            vec(f, np.asarray([l.bypass_scale, l.post_scale], np.float32))
+            for nm in ("W", "bias", "bn_scale", "bn_offset", "post_offset"):
+                a = getattr(l, nm)
+                vec(f, np.zeros(0, np.float32) if a is None else np.ascontiguousarray(a, np.float32))
+        vec(f, wave.astype(np.float32))
     exe = build_cxx(str(tmp_path))
-    out = subprocess.check_output([exe, str(fx), str(tmp_path)], text=True, stderr=subprocess.DEVNULL).strip().splitlines()
+    out = subprocess.check_output([exe, str(fx), str(tmp_path), str(mfx)], text=True, stderr=subprocess.DEVNULL).strip().splitlines()
     o = orc.Decoder(g, abi.decoder_config_recipe(), 1)
     o.Decode(ll)
     lat = o.GetRawLattice()
@@ -63,6 +79,14 @@ def test_cxx_host_api(tmp_path):
     (key, st, fin, arcs), = list(kio.read_lattices(tmp_path / "lat.txt"))
     assert key == "utt-raw" and arcs.size == lat.arcs.size
     assert np.allclose(arcs["acoustic_cost"], lat.arcs["acoustic_cost"] / np.float32(0.5), rtol=1e-5)
+    # streaming mirror == offline decode of the same waveform through the Python mirror
+    off = decoder.LatticeFasterDecoder(decoder.Graph(g), abi.decoder_config_recipe())
+    off.Decode(decoder.Nnet(m).Forward(feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(wave)))
+    ob = off.GetBestPath()
+    srow = [l for l in out if l.startswith("streaming ")][0]
+    assert srow.startswith("streaming ok=1 frames=%d partials=1 " % off.NumFramesDecoded())
+    assert srow.endswith("words=" + ",".join(str(w) for w in ob["words"]))
+    assert abs(float(srow.split("graph=")[1].split()[0]) - ob["graph_cost"]) < 1e-3
     clat = open(tmp_path / "clat.ark", "rb").read()
     assert clat.startswith(b"utt-det ") and clat[8] == 214 and b"compactlattice44" in clat[:64]
     assert bp["words"].tolist() == words
