@@ -410,6 +410,18 @@ int kamd_feat_compute_ranges_device(kamd_feat *f, const float *d_waves, const in
 int kamd_nnet_forward_slices_device(kamd_nnet *n, const float *d_feats, const int64_t *h_in_start,
                                     const int32_t *h_in_len, int ld_in, const float *d_ivectors, int n_items,
                                     float *d_out, const int64_t *h_out_row_off, int ld_out, void *stream);
+/* DecodableNnetSimple with ONLINE ivectors (--online-ivectors / --online-ivector-period of
+ * nnet3-latgen-faster, nnet3/nnet-am-decodable-simple.cc:93-214) for a batch of utterances:
+ * the output is computed chunk by chunk (frames_per_chunk input frames, rounded up to a
+ * multiple of the subsampling factor as CheckAndFixConfigs does, :278-310), every chunk with
+ * the ivector row GetCurrentIvector picks for its middle (:181-211) and with its own context,
+ * clamped at the utterance edges only.  d_online_ivectors: [rows x iv_dim] on the device,
+ * utterance u owns rows [h_iv_row_off[u], h_iv_row_off[u+1]) (one row per ivector_period
+ * frames).  All chunks of all utterances are items of one batched forward. */
+int kamd_nnet_forward_chunked_device(kamd_nnet *n, const float *d_feats, const int64_t *h_in_row_off, int ld_in,
+                                     const float *d_online_ivectors, const int64_t *h_iv_row_off, int iv_dim,
+                                     int ivector_period, int frames_per_chunk, int n_utts, float *d_out,
+                                     const int64_t *h_out_row_off, int ld_out, void *stream);
 
 /* ------------------------------------------------- lattice determinization -- */
 /* DeterminizeLatticePhonePrunedOptions + DeterminizeLatticePrunedOptions
@@ -499,6 +511,11 @@ int kamd_pipeline_load_batch(kamd_pipeline *p, const float *waves,
  * dim = 0 clears them.  Online (per-chunk) ivectors are not supported: their values depend
  * on the reference's chunk boundaries (nnet-am-decodable-simple.cc:178-212). */
 int kamd_pipeline_set_ivectors(kamd_pipeline *p, const float *ivectors, int dim);
+/* --online-ivectors=... --online-ivector-period=N (nnet3bin/nnet3-latgen-faster.cc:60-75):
+ * utterance u of the loaded batch owns rows [h_row_off[u], h_row_off[u+1]); the nnet stage then
+ * runs chunk by chunk (kamd_nnet_forward_chunked_device).  dim <= 0 switches it off. */
+int kamd_pipeline_set_online_ivectors(kamd_pipeline *p, const float *ivectors, const int64_t *h_row_off, int dim,
+                                      int ivector_period, int frames_per_chunk);
 /* Run the hot path over the resident batch: lanes 0..n_utts-1 hold the results.
  * Blocking; returns 0 or error.  stage_ms[3] = {features, nnet, decode(advance+
  * finalize)} device times from HIP events. */

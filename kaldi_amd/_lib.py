@@ -99,6 +99,9 @@ def lib():
     sig("kamd_stream_batch_num_frames_ready", C.c_int, [vp, C.c_int])
     sig("kamd_feat_compute_ranges_device", C.c_int, [vp, vp, i64p, i64p, ip, ip, C.c_int, vp, i64p, C.c_int, vp])
     sig("kamd_nnet_forward_slices_device", C.c_int, [vp, vp, i64p, ip, C.c_int, vp, C.c_int, vp, i64p, C.c_int, vp])
+    sig("kamd_nnet_forward_chunked_device", C.c_int, [vp, vp, i64p, C.c_int, vp, i64p, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+                                                      i64p, C.c_int, vp])
+    sig("kamd_pipeline_set_online_ivectors", C.c_int, [vp, fp, i64p, C.c_int, C.c_int, C.c_int])
     sig("kamd_graph_destroy", None, [vp])
     sig("kamd_graph_num_states", C.c_int32, [vp])
     sig("kamd_graph_num_arcs", C.c_int64, [vp])
@@ -141,14 +144,14 @@ kamd_nnet_destroy kamd_nnet_output_dim kamd_nnet_left_context kamd_nnet_right_co
 kamd_nnet_num_output_frames kamd_nnet_frame_subsampling_factor kamd_nnet_forward_batch_device kamd_nnet_forward kamd_nnet_last_flops
 kamd_graph_create kamd_graph_destroy kamd_graph_num_states kamd_graph_num_arcs
 kamd_graph_read_openfst kamd_openfst_read kamd_openfst_write kamd_host_free kamd_lattice_write kamd_lattice_read
-kamd_stream_batch_create kamd_stream_batch_destroy kamd_stream_batch_start kamd_stream_batch_accept kamd_stream_batch_advance kamd_stream_batch_num_frames_ready kamd_feat_compute_ranges_device kamd_nnet_forward_slices_device
+kamd_stream_batch_create kamd_stream_batch_destroy kamd_stream_batch_start kamd_stream_batch_accept kamd_stream_batch_advance kamd_stream_batch_num_frames_ready kamd_feat_compute_ranges_device kamd_nnet_forward_slices_device kamd_nnet_forward_chunked_device
 kamd_determinize_opts_default kamd_lattice_determinize_phone_pruned kamd_compact_lattice_destroy kamd_compact_lattice_sizes kamd_compact_lattice_get kamd_compact_lattice_write
 kamd_decoder_config_default kamd_decoder_sizes_default kamd_decoder_create kamd_decoder_destroy
 kamd_decoder_set_options kamd_decoder_reserve kamd_decoder_init kamd_decoder_advance kamd_decoder_finalize
 kamd_decoder_sync kamd_decoder_num_frames_decoded kamd_decoder_final_relative_cost
 kamd_decoder_reached_final kamd_decoder_lattice_size kamd_decoder_get_raw_lattice
 kamd_decoder_best_path kamd_decoder_partial_best_path kamd_decoder_get_trace kamd_decoder_get_counters
-kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch kamd_pipeline_set_ivectors
+kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch kamd_pipeline_set_ivectors kamd_pipeline_set_online_ivectors
 kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features""".split()
 
 

@@ -567,6 +567,109 @@ int kamd_nnet_forward_slices_device(kamd_nnet *h, const float *d_feats, const in
   return ForwardItems(h, d_feats, h_in_start, h_in_len, ld_in, d_ivectors, n_items, d_out, h_out_row_off, ld_out, stream);
 }
 
+}  // extern "C"
+namespace kamd {
+// rows [src_row[i], +count[i]) of src -> rows [dst_row[i], ...) of dst, one workgroup row per copy item
+__global__ void CopyRowBlocksKernel(const float *src, int ld_src, float *dst, int ld_dst, const int64_t *src_row,
+                                    const int64_t *dst_row, const int *count, int cols) {
+  const int item = blockIdx.y;
+  for (int r = blockIdx.x; r < count[item]; r += gridDim.x)
+    for (int c = threadIdx.x; c < cols; c += blockDim.x)
+      dst[(dst_row[item] + r) * ld_dst + c] = src[(src_row[item] + r) * ld_src + c];
+}
+}  // namespace kamd
+extern "C" {
+
+// DecodableNnetSimple with online ivectors, for a batch of utterances (nnet3/nnet-am-decodable-
+// simple.cc:93-214; the chunk arithmetic NnetBatchComputer shares, nnet-batch-compute.cc:774-829):
+// every chunk of frames_per_chunk input frames (rounded up to a multiple of the subsampling
+// factor, :278-310) is one item of a single batched forward, with its own left / right context
+// (clamped at the utterance edges only) and the ivector row GetCurrentIvector picks for the middle
+// of the chunk (:181-211).  The context rows are recomputed per chunk, as the reference does.
+int kamd_nnet_forward_chunked_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_row_off, int ld_in,
+                                     const float *d_online_ivectors, const int64_t *h_iv_row_off, int iv_dim,
+                                     int ivector_period, int frames_per_chunk, int n_utts, float *d_out,
+                                     const int64_t *h_out_row_off, int ld_out, void *stream) {
+  Nnet *nn = reinterpret_cast<Nnet *>(h);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_utts <= 0) return KAMD_OK;
+  const int sub = nn->subsampling, P = nn->L.back().out_dim;
+  if (iv_dim != nn->L[0].ivector_dim || iv_dim <= 0) return kamd::SetError(KAMD_ERR_ARG, "model expects ivector dim %d, got %d", nn->L[0].ivector_dim, iv_dim);
+  if (ivector_period <= 0 || frames_per_chunk <= 0) return kamd::SetError(KAMD_ERR_ARG, "bad ivector period / frames per chunk");
+  if (frames_per_chunk % sub != 0) frames_per_chunk = sub * ((frames_per_chunk + sub - 1) / sub);
+  const int C = frames_per_chunk / sub;
+  const int Lc = kamd_nnet_left_context(h), Rc = kamd_nnet_right_context(h);
+  std::vector<int64_t> in_start, tmp_off, iv_row, src_row, dst_row;
+  std::vector<int32_t> in_len, cnt;
+  int64_t tmp_rows = 0;
+  for (int u = 0; u < n_utts; u++) {
+    const int T = static_cast<int>(h_in_row_off[u + 1] - h_in_row_off[u]);
+    const int n_iv = static_cast<int>(h_iv_row_off[u + 1] - h_iv_row_off[u]);
+    if (T <= 0 || n_iv <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no frames / ivectors", u);
+    const int n_out = (T + sub - 1) / sub;
+    for (int start = 0; start < n_out; start += C) {
+      const int num = std::min(n_out - start, C);
+      const int first_out = start * sub, last_out = (start + num - 1) * sub;
+      int ivf = (first_out + (last_out - first_out) / 2) / ivector_period;
+      if (ivf >= n_iv) {
+        if ((ivf - (n_iv - 1)) * ivector_period > 50)
+          return kamd::SetError(KAMD_ERR_ARG, "utterance %d: could not get iVector for frame %d (mismatched --online-ivector-period?)", u, first_out);
+        ivf = n_iv - 1;
+      }
+      const int k0 = std::min(start, (Lc + sub - 1) / sub);          // leading outputs that only carry context
+      const int in_first = sub * (start - k0);
+      const int in_last = std::min(T - 1, last_out + Rc);
+      in_start.push_back(h_in_row_off[u] + in_first); in_len.push_back(in_last - in_first + 1);
+      tmp_off.push_back(tmp_rows);
+      iv_row.push_back(h_iv_row_off[u] + ivf);
+      src_row.push_back(tmp_rows + k0); dst_row.push_back(h_out_row_off[u] + start); cnt.push_back(num);
+      tmp_rows += (in_last - in_first + 1 + sub - 1) / sub;
+    }
+  }
+  const int n_items = static_cast<int>(in_start.size());
+  // per-item ivectors (gathered rows), temporary outputs, copy descriptors
+  float *d_iv = NULL, *d_tmp = NULL; int64_t *d_desc = NULL;
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_iv), static_cast<size_t>(n_items) * iv_dim * sizeof(float)));
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_tmp), static_cast<size_t>(tmp_rows) * P * sizeof(float)));
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_desc), static_cast<size_t>(n_items) * (3 * 8 + 4) + 64));
+  int64_t *d_src = d_desc, *d_dst = d_desc + n_items, *d_ivr = d_desc + 2 * n_items;
+  int *d_cnt = reinterpret_cast<int *>(d_desc + 3 * n_items);
+  int rc = KAMD_OK;
+  hipError_t e = hipMemcpyAsync(d_src, src_row.data(), n_items * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst_row.data(), n_items * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ivr, iv_row.data(), n_items * 8, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_cnt, cnt.data(), n_items * 4, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) rc = kamd::SetError(KAMD_ERR_HIP, "descriptor upload failed: %s", hipGetErrorString(e));
+  if (rc == KAMD_OK) {
+    // gather the chunk ivectors: reuse the row-block copy (1 row per item)
+    std::vector<int64_t> iota(n_items);
+    std::vector<int> ones(n_items, 1);
+    for (int i = 0; i < n_items; i++) iota[i] = i;
+    int64_t *d_iota = NULL; int *d_ones = NULL;
+    if (hipMalloc(reinterpret_cast<void **>(&d_iota), n_items * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&d_ones), n_items * 4) != hipSuccess ||
+        hipMemcpy(d_iota, iota.data(), n_items * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ones, ones.data(), n_items * 4, hipMemcpyHostToDevice) != hipSuccess)
+      rc = kamd::SetError(KAMD_ERR_HIP, "allocation failed");
+    if (rc == KAMD_OK) {
+      hipLaunchKernelGGL(kamd::CopyRowBlocksKernel, dim3(1, n_items), dim3(128), 0, st, d_online_ivectors, iv_dim, d_iv, iv_dim,
+                         d_ivr, d_iota, d_ones, iv_dim);
+      rc = ForwardItems(h, d_feats, in_start.data(), in_len.data(), ld_in, d_iv, n_items, d_tmp, tmp_off.data(), P, stream);
+    }
+    if (rc == KAMD_OK) {
+      hipLaunchKernelGGL(kamd::CopyRowBlocksKernel, dim3(std::min(C, 32), n_items), dim3(256), 0, st, d_tmp, P, d_out, ld_out,
+                         d_src, d_dst, d_cnt, P);
+      if (hipStreamSynchronize(st) != hipSuccess) rc = kamd::SetError(KAMD_ERR_HIP, "chunked forward failed");
+    }
+    if (d_iota) (void)hipFree(d_iota);
+    if (d_ones) (void)hipFree(d_ones);
+  }
+  (void)hipFree(d_iv); (void)hipFree(d_tmp); (void)hipFree(d_desc);
+  (void)nn;
+  return rc;
+}
+
 int kamd_nnet_forward(kamd_nnet *h, const float *feats, int T, const float *ivector, float *out,
                       int out_rows_cap) {
   Nnet *nn = reinterpret_cast<Nnet *>(h);

@@ -19,6 +19,8 @@ struct Pipeline {
   float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL, *d_iv = NULL;
   size_t waves_cap = 0, feats_cap = 0, ll_cap = 0, iv_cap = 0;
   int iv_dim = 0;
+  // online ivectors (one row per ivector_period frames) instead of one ivector per utterance
+  float *d_oiv = NULL; size_t oiv_cap = 0; std::vector<int64_t> oiv_off; int oiv_period = 0, frames_per_chunk = 50;
   hipEvent_t ev[5];
 };
 template <typename T>
@@ -53,6 +55,7 @@ void kamd_pipeline_destroy(kamd_pipeline *h) {
   if (p->d_feats) (void)hipFree(p->d_feats);
   if (p->d_ll) (void)hipFree(p->d_ll);
   if (p->d_iv) (void)hipFree(p->d_iv);
+  if (p->d_oiv) (void)hipFree(p->d_oiv);
   for (int i = 0; i < 5; i++) (void)hipEventDestroy(p->ev[i]);
   delete p;
 }
@@ -85,7 +88,25 @@ int kamd_pipeline_set_ivectors(kamd_pipeline *h, const float *ivectors, int dim)
   const size_t n = static_cast<size_t>(p->n_utts) * dim;
   if (kamd::GrowBuf(&p->d_iv, &p->iv_cap, n) != KAMD_OK) return KAMD_ERR_HIP;
   KAMD_HIP(hipMemcpy(p->d_iv, ivectors, n * sizeof(float), hipMemcpyHostToDevice));
-  p->iv_dim = dim;
+  p->iv_dim = dim; p->oiv_period = 0;
+  return KAMD_OK;
+}
+
+// --online-ivectors / --online-ivector-period of nnet3-latgen-faster: utterance u (in the order of
+// the loaded batch) owns rows [h_row_off[u], h_row_off[u+1]) of `ivectors`; the nnet stage then
+// runs chunk by chunk like DecodableNnetSimple (kamd_nnet_forward_chunked_device).
+int kamd_pipeline_set_online_ivectors(kamd_pipeline *h, const float *ivectors, const int64_t *h_row_off, int dim,
+                                      int ivector_period, int frames_per_chunk) {
+  Pipeline *p = reinterpret_cast<Pipeline *>(h);
+  if (dim <= 0 || !ivectors) { p->oiv_period = 0; p->oiv_off.clear(); return KAMD_OK; }
+  if (p->n_utts <= 0) return kamd::SetError(KAMD_ERR_STATE, "load the batch before its ivectors");
+  if (ivector_period <= 0 || frames_per_chunk <= 0) return kamd::SetError(KAMD_ERR_ARG, "bad ivector period / frames per chunk");
+  const size_t n = static_cast<size_t>(h_row_off[p->n_utts] - h_row_off[0]) * dim;
+  if (kamd::GrowBuf(&p->d_oiv, &p->oiv_cap, n) != KAMD_OK) return KAMD_ERR_HIP;
+  KAMD_HIP(hipMemcpy(p->d_oiv, ivectors + h_row_off[0] * dim, n * sizeof(float), hipMemcpyHostToDevice));
+  p->oiv_off.assign(h_row_off, h_row_off + p->n_utts + 1);
+  for (int u = p->n_utts; u >= 0; u--) p->oiv_off[u] -= h_row_off[0];
+  p->iv_dim = dim; p->oiv_period = ivector_period; p->frames_per_chunk = frames_per_chunk;
   return KAMD_OK;
 }
 
@@ -99,8 +120,12 @@ int kamd_pipeline_run(kamd_pipeline *h, float stage_ms[4]) {
                                           p->feat_off.data(), p->ld_feat, st);
   if (rc != KAMD_OK) return rc;
   KAMD_HIP(hipEventRecord(p->ev[1], st));
-  rc = kamd_nnet_forward_batch_device(p->nnet, p->d_feats, p->feat_off.data(), p->ld_feat, p->iv_dim > 0 ? p->d_iv : NULL, n,
-                                      p->d_ll, p->out_off.data(), p->P, st);
+  if (p->oiv_period > 0)
+    rc = kamd_nnet_forward_chunked_device(p->nnet, p->d_feats, p->feat_off.data(), p->ld_feat, p->d_oiv, p->oiv_off.data(),
+                                          p->iv_dim, p->oiv_period, p->frames_per_chunk, n, p->d_ll, p->out_off.data(), p->P, st);
+  else
+    rc = kamd_nnet_forward_batch_device(p->nnet, p->d_feats, p->feat_off.data(), p->ld_feat, p->iv_dim > 0 ? p->d_iv : NULL, n,
+                                        p->d_ll, p->out_off.data(), p->P, st);
   if (rc != KAMD_OK) return rc;
   KAMD_HIP(hipEventRecord(p->ev[2], st));
   std::vector<int32_t> lanes(n);

@@ -77,6 +77,29 @@ class Nnet:
         return out
 
 
+    def ForwardChunked(self, feats_list, online_ivectors_list, ivector_period=10, frames_per_chunk=50):
+        """DecodableNnetSimple with online ivectors for a batch of utterances: one ivector per
+        chunk (nnet3/nnet-am-decodable-simple.cc:93-214).  Returns one [n_out x P] array each."""
+        ld = (self.model.input_dim + 15) // 16 * 16
+        n = len(feats_list)
+        in_off = np.zeros(n + 1, np.int64); iv_off = np.zeros(n + 1, np.int64); out_off = np.zeros(n + 1, np.int64)
+        for u, (f, iv) in enumerate(zip(feats_list, online_ivectors_list)):
+            in_off[u + 1] = in_off[u] + f.shape[0]
+            iv_off[u + 1] = iv_off[u] + iv.shape[0]
+            out_off[u + 1] = out_off[u] + lib().kamd_nnet_num_output_frames(self._h, f.shape[0])
+        feats = np.zeros((int(in_off[-1]), ld), np.float32)
+        for u, f in enumerate(feats_list):
+            feats[in_off[u]:in_off[u + 1], :f.shape[1]] = f
+        ivs = np.ascontiguousarray(np.concatenate(online_ivectors_list), np.float32)
+        P = self.OutputDim()
+        d_f, d_iv, d_o = DeviceMatrix(feats), DeviceMatrix(ivs), DeviceMatrix(np.zeros((int(out_off[-1]), P), np.float32))
+        check(lib().kamd_nnet_forward_chunked_device(self._h, d_f.ptr(0), abi.iptr(in_off, C.c_int64), ld, d_iv.ptr(0),
+                                                     abi.iptr(iv_off, C.c_int64), ivs.shape[1], ivector_period,
+                                                     frames_per_chunk, n, d_o.ptr(0), abi.iptr(out_off, C.c_int64), P, None))
+        out = d_o.download()
+        return [out[out_off[u]:out_off[u + 1]] for u in range(n)]
+
+
 class Lattice:
     """Raw lattice (kaldi::Lattice equivalent) in canonical numbering."""
 
@@ -104,6 +127,12 @@ class DeviceMatrix:
 
     def ptr(self, row=0):
         return self._d + row * self.cols * 4
+
+    def download(self):
+        out = np.zeros((self.rows, self.cols), np.float32)
+        if out.nbytes:
+            check(lib().kamd_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self._d, out.nbytes))
+        return out
 
 
 class LatticeFasterDecoder:

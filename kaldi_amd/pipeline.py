@@ -81,6 +81,19 @@ class Pipeline:
         iv = np.ascontiguousarray([v for v, lane in zip(ivectors, self._lane_of) if lane >= 0], np.float32)
         check(lib().kamd_pipeline_set_ivectors(self._h, abi.fptr(iv), iv.shape[1]))
 
+    def set_online_ivectors(self, ivector_matrices, ivector_period=10, frames_per_chunk=50):
+        """--online-ivectors / --online-ivector-period: one [rows x dim] matrix per utterance of the
+        loaded batch (a row per `ivector_period` frames); the nnet stage then runs chunk by chunk."""
+        if ivector_matrices is None:
+            check(lib().kamd_pipeline_set_online_ivectors(self._h, None, None, 0, 0, 0))
+            return
+        mats = [np.ascontiguousarray(v, np.float32) for v, lane in zip(ivector_matrices, self._lane_of) if lane >= 0]
+        off = np.zeros(len(mats) + 1, np.int64)
+        off[1:] = np.cumsum([m.shape[0] for m in mats])
+        iv = np.ascontiguousarray(np.concatenate(mats), np.float32)
+        check(lib().kamd_pipeline_set_online_ivectors(self._h, abi.fptr(iv), abi.iptr(off, C.c_int64), iv.shape[1],
+                                                      ivector_period, frames_per_chunk))
+
     def run(self):
         ms = np.zeros(4, np.float32)
         if self.n_utts == 0:

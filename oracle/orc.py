@@ -41,6 +41,8 @@ def lib():
         L.orc_nnet_context.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, ip, ip]
         L.orc_nnet_forward.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp,
                                        C.c_int, fp, fp, C.c_int]
+        L.orc_nnet_forward_chunked.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int,
+                                               C.c_int, C.c_int, C.c_int, fp, C.c_int]
         L.orc_decoder_create.restype = C.c_void_p
         L.orc_decoder_create.argtypes = [C.c_int32, C.c_int32, i64p, C.c_void_p, fp,
                                          C.POINTER(abi.DecoderConfig), ip, C.c_int32, C.c_int]
@@ -97,6 +99,21 @@ def nnet_forward(model, feats, ivector=None):
     d = model.descs()
     r = lib().orc_nnet_forward(d, len(model.layers), model.input_dim, model.subsampling,
                                abi.fptr(feats), T, abi.fptr(iv), abi.fptr(out), n_out)
+    assert r == n_out, r
+    return out
+
+
+def nnet_forward_chunked(model, feats, online_ivectors, ivector_period=10, frames_per_chunk=50):
+    """DecodableNnetSimple with online ivectors: one ivector per chunk of frames_per_chunk."""
+    feats = np.ascontiguousarray(feats, np.float32)
+    iv = np.ascontiguousarray(online_ivectors, np.float32)
+    T = feats.shape[0]
+    n_out = (T + model.subsampling - 1) // model.subsampling
+    out = np.zeros((n_out, model.layers[-1].out_dim), np.float32)
+    d = model.descs()
+    r = lib().orc_nnet_forward_chunked(d, len(model.layers), model.input_dim, model.subsampling, abi.fptr(feats), T,
+                                       abi.fptr(iv), iv.shape[0], iv.shape[1], ivector_period, frames_per_chunk,
+                                       abi.fptr(out), n_out)
     assert r == n_out, r
     return out
 

@@ -139,4 +139,40 @@ int orc_nnet_forward(const kamd_layer_desc *layers, int n_layers, int input_dim,
   return n_out;
 }
 
+
+// DecodableNnetSimple with online ivectors (nnet3/nnet-am-decodable-simple.cc:93-214): the
+// decoder asks for frames in order, so chunks start at 0, C, 2C, ... with C =
+// frames_per_chunk / subsampling after CheckAndFixConfigs (:278-310) rounded frames_per_chunk
+// up to a multiple of the subsampling factor; every chunk is evaluated with ONE ivector, the
+// row GetCurrentIvector (:181-211) picks for the middle of the chunk.
+int orc_nnet_forward_chunked(const kamd_layer_desc *layers, int n_layers, int input_dim, int subsampling,
+                             const float *feats, int T, const float *online_ivectors, int n_iv_rows, int iv_dim,
+                             int ivector_period, int frames_per_chunk, float *out, int out_rows_cap) {
+  if (T <= 0) return 0;
+  const int n_out = (T + subsampling - 1) / subsampling;
+  if (n_out > out_rows_cap) return -1;
+  if (frames_per_chunk % subsampling != 0) frames_per_chunk = subsampling * ((frames_per_chunk + subsampling - 1) / subsampling);
+  const int C = frames_per_chunk / subsampling;
+  const int P = layers[n_layers - 1].out_dim;
+  for (int start = 0; start < n_out; start += C) {
+    const int num = std::min(n_out - start, C);
+    const int first_output_frame = start * subsampling, last_output_frame = (start + num - 1) * subsampling;
+    const int frame_to_search = first_output_frame + (last_output_frame - first_output_frame) / 2;
+    int ivector_frame = frame_to_search / ivector_period;
+    if (ivector_frame >= n_iv_rows) {
+      if ((ivector_frame - (n_iv_rows - 1)) * ivector_period > 50) return -2;   // "Could not get iVector for frame"
+      ivector_frame = n_iv_rows - 1;
+    }
+    Eval e;
+    e.L = layers; e.n_layers = n_layers; e.input_dim = input_dim; e.T = T;
+    e.feats = feats; e.ivector = online_ivectors + static_cast<int64_t>(ivector_frame) * iv_dim;
+    e.memo.resize(n_layers);
+    for (int i = 0; i < num; i++) {
+      const float *y = e.Get(n_layers - 1, (start + i) * subsampling);
+      memcpy(out + static_cast<int64_t>(start + i) * P, y, sizeof(float) * P);
+    }
+  }
+  return n_out;
+}
+
 }  // extern "C"

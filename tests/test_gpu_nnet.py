@@ -46,6 +46,30 @@ def test_log_softmax_output(P):
     np.testing.assert_allclose(np.exp(lp.astype(np.float64)).sum(axis=1), 1.0, atol=1e-3)
 
 
+def test_chunked_forward_with_online_ivectors():
+    """kamd_nnet_forward_chunked_device == the oracle's DecodableNnetSimple with online ivectors,
+    for a ragged batch; frames_per_chunk 50 (-> 51) and 21."""
+    m = nnet.tdnnf_tiny(num_pdfs=41, ivector_dim=10, seed=7)
+    N = decoder.Nnet(m)
+    rng = np.random.default_rng(2)
+    feats, ivs = [], []
+    for T in (140, 17, 1, 263):
+        feats.append((2 * rng.standard_normal((T, m.input_dim))).astype(np.float32))
+        ivs.append(rng.standard_normal(((T + 9) // 10, 10)).astype(np.float32))
+    for fpc in (50, 21):
+        got = N.ForwardChunked(feats, ivs, 10, fpc)
+        for f, iv, g in zip(feats, ivs, got):
+            ref = orc.nnet_forward_chunked(m, f, iv, 10, fpc)
+            assert g.shape == ref.shape
+            assert np.abs(g - ref).max() < 1e-4 * np.abs(ref).max()
+    # one ivector per utterance: chunked == plain forward
+    const = [np.tile(iv[:1], (iv.shape[0], 1)) for iv in ivs]
+    got = N.ForwardChunked(feats, const, 10, 50)
+    for f, iv, g in zip(feats, const, got):
+        plain = N.Forward(f, iv[0])
+        assert np.abs(g - plain).max() < 1e-4 * np.abs(plain).max()
+
+
 def test_context_and_plan():
     m = nnet.tdnnf_mini_librispeech(num_pdfs=64)
     n = decoder.Nnet(m)
@@ -108,3 +132,28 @@ def test_pipeline_with_per_utterance_ivectors():
         np.testing.assert_array_equal(pipe.loglikes(u), want)
         ref = orc.nnet_forward(m, f, ivs[u])
         assert np.abs(want - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_pipeline_with_online_ivectors():
+    """wav -> MFCC -> chunked nnet with online ivectors -> decoder: the log-likelihoods the
+    decoder consumed are the oracle's DecodableNnetSimple rows."""
+    from kaldi_amd import abi, feat, pipeline, synth
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, ivector_dim=10, seed=1)
+    cfg = abi.decoder_config_recipe()
+    waves = [synth.make_wave(d, seed=30 + i) for i, d in enumerate((1.4, 0.6, 2.2))]
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, cfg, max_utts=3, max_seconds=3.0)
+    pipe.load(waves)
+    rng = np.random.default_rng(5)
+    mf = feat.Mfcc(abi.mfcc_opts_hires())
+    feats = [mf.ComputeFeatures(w) for w in waves]
+    ivs = [rng.standard_normal(((f.shape[0] + 9) // 10, 10)).astype(np.float32) for f in feats]
+    pipe.set_online_ivectors(ivs, 10, 50)
+    pipe.run()
+    for u in range(3):
+        ref = orc.nnet_forward_chunked(m, feats[u], ivs[u], 10, 50)
+        got = pipe.loglikes(u)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-4 * np.abs(ref).max()
+    pipe.set_online_ivectors(None)
+    with pytest.raises(Exception):
+        pipe.run()                      # the model needs ivectors

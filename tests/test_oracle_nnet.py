@@ -40,6 +40,31 @@ def test_oracle_log_softmax_output():
     np.testing.assert_allclose(np.exp(lp.astype(np.float64)).sum(axis=1), 1.0, atol=1e-4)
 
 
+def test_chunked_forward_with_online_ivectors():
+    """DecodableNnetSimple chunk semantics: with one ivector for the whole utterance the chunked
+    evaluation equals the plain one; with time-varying ivectors every chunk uses the row picked
+    for its middle (nnet-am-decodable-simple.cc:181-211)."""
+    m = nnet.tdnnf_tiny(num_pdfs=30, ivector_dim=10, seed=3)
+    rng = np.random.default_rng(1)
+    T = 140
+    feats = rng.standard_normal((T, m.input_dim)).astype(np.float32)
+    iv1 = rng.standard_normal(10).astype(np.float32)
+    const = np.tile(iv1, (T // 10 + 1, 1))
+    a = orc.nnet_forward_chunked(m, feats, const, 10, 50)
+    b = orc.nnet_forward(m, feats, iv1)
+    np.testing.assert_array_equal(a, b)
+    ivs = rng.standard_normal((T // 10 + 1, 10)).astype(np.float32)
+    c = orc.nnet_forward_chunked(m, feats, ivs, 10, 50)           # 50 -> 51: 17 output frames per chunk
+    n_out = (T + 2) // 3
+    for start in range(0, n_out, 17):
+        num = min(17, n_out - start)
+        first, last = 3 * start, 3 * (start + num - 1)
+        row = min((first + (last - first) // 2) // 10, ivs.shape[0] - 1)
+        want = orc.nnet_forward(m, feats, ivs[row])[start:start + num]
+        np.testing.assert_array_equal(c[start:start + num], want)
+    assert np.abs(c - b).max() > 1e-3                              # the ivectors matter
+
+
 def test_context_matches_recipe_topologies():
     """ComputeSimpleNnetContext: 1 + 3*1 + 0 + 12*3 = 40 for run_tdnn_1d."""
     assert nnet.tdnnf_librispeech(num_pdfs=16).context() == (40, 40)
