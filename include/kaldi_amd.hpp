@@ -79,6 +79,24 @@ class DecodableMatrixMapped : public DecodableInterface {
   const float *d_likes_;
 };
 
+// DecodableMatrixScaledMapped (decoder/decodable-matrix.h:34-84): scale * likes(frame, pdf(tid)).
+// Goes through the generic DecodableInterface path of AdvanceDecoding.
+class DecodableMatrixScaledMapped : public DecodableInterface {
+ public:
+  DecodableMatrixScaledMapped(const std::vector<int32> &id2pdf, const float *likes, int32 num_frames, int32 num_pdfs,
+                              BaseFloat scale)
+      : id2pdf_(id2pdf), likes_(likes), num_frames_(num_frames), num_pdfs_(num_pdfs), scale_(scale) {}
+  BaseFloat LogLikelihood(int32 frame, int32 tid) override { return scale_ * likes_[static_cast<size_t>(frame) * num_pdfs_ + id2pdf_[tid]]; }
+  bool IsLastFrame(int32 frame) const override { return frame == num_frames_ - 1; }
+  int32 NumFramesReady() const override { return num_frames_; }
+  int32 NumIndices() const override { return static_cast<int32>(id2pdf_.size()) - 1; }
+ private:
+  const std::vector<int32> &id2pdf_;
+  const float *likes_;
+  int32 num_frames_, num_pdfs_;
+  BaseFloat scale_;
+};
+
 // ------------------------------------------------- decoder/lattice-faster-decoder.h:38-90
 struct LatticeFasterDecoderConfig {
   BaseFloat beam;
@@ -434,6 +452,28 @@ class Mfcc {
   }
  private:
   Mfcc(const Mfcc &);
+  kamd_feat *f_;
+};
+
+// OfflineFeatureTpl<FbankComputer> (feat/feature-fbank.h:39-98, feat/feature-common.h:111-160)
+struct FbankOptions {
+  kamd_fbank_opts c;
+  FbankOptions() { kamd_fbank_opts_default(&c); }
+};
+class Fbank {
+ public:
+  explicit Fbank(const FbankOptions &opts, BaseFloat vtln_warp = 1.0f) : f_(CheckPtr(kamd_fbank_create(&opts.c, vtln_warp))) {}
+  ~Fbank() { kamd_feat_destroy(f_); }
+  int32 Dim() const { return kamd_feat_dim(f_); }
+  void ComputeFeatures(const std::vector<float> &wave, BaseFloat sample_freq, std::vector<float> *output, int32 *num_frames) {
+    (void)sample_freq;
+    const int T = kamd_feat_num_frames(f_, static_cast<int64_t>(wave.size()));
+    output->assign(static_cast<size_t>(T) * Dim(), 0.f);
+    if (T > 0) Check(kamd_feat_compute(f_, wave.data(), static_cast<int64_t>(wave.size()), output->data(), T));
+    *num_frames = T;
+  }
+ private:
+  Fbank(const Fbank &);
   kamd_feat *f_;
 };
 
