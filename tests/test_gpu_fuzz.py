@@ -38,7 +38,10 @@ def random_case(rng):
     return g, ll, cfg
 
 
-@pytest.mark.parametrize("block", range(6))
+import os
+
+
+@pytest.mark.parametrize("block", range(int(os.environ.get("KAMD_FUZZ_BLOCKS", "6"))))
 def test_random_cases(block):
     rng = np.random.default_rng(1234 + block)
     for i in range(20):
