@@ -72,6 +72,7 @@ class Pipeline:
         off = np.concatenate([[0], np.cumsum([w.size for w in keep])]).astype(np.int64)
         flat = np.ascontiguousarray(np.concatenate(keep), np.float32)
         check(lib().kamd_pipeline_load_batch(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), len(keep)))
+        self._loaded = (flat, off, len(keep))      # kept for grow(): the reference never runs out of room
 
     def set_ivectors(self, ivectors):
         """One ivector per (non-skipped) utterance of the loaded batch."""
@@ -94,12 +95,39 @@ class Pipeline:
         check(lib().kamd_pipeline_set_online_ivectors(self._h, abi.fptr(iv), abi.iptr(off, C.c_int64), iv.shape[1],
                                                       ivector_period, frames_per_chunk))
 
-    def run(self):
+    def grow(self, factor=2):
+        """Rebuilds the decoder with `factor` x the frame table and arenas and reloads the batch
+        (the reference's HashList and token lists simply grow; here a lane that overflows reports
+        KAMD_ERR_CAPACITY and the caller decides)."""
+        s = self.sizes
+        self.sizes = abi.DecoderSizes(s.max_lanes, s.hash_capacity * factor, s.arena_tokens * factor,
+                                      s.arena_links * factor, s.max_frames)
+        lib().kamd_pipeline_destroy(self._h)
+        self._h = None
+        self.dec = decoder.BatchDecoder(self.graph, self.cfg, self.sizes)
+        self._h = lib().kamd_pipeline_create(self.feat._h, self.nnet._h, self.dec._dec)
+        if not self._h:
+            raise KamdError(lib().kamd_last_error().decode())
+        if getattr(self, "_loaded", None) is not None and self.n_utts > 0:
+            flat, off, n = self._loaded
+            check(lib().kamd_pipeline_load_batch(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), n))
+
+    def run(self, auto_grow=0):
+        """auto_grow = how many times a capacity overflow may be answered by grow() + rerun
+        (per-utterance / online ivectors must be set again by the caller after a grow)."""
         ms = np.zeros(4, np.float32)
         if self.n_utts == 0:
             self.last_stage_ms = ms.tolist()
             return self.last_stage_ms
-        check(lib().kamd_pipeline_run(self._h, abi.fptr(ms)))
+        while True:
+            try:
+                check(lib().kamd_pipeline_run(self._h, abi.fptr(ms)))
+                break
+            except KamdError as e:
+                if auto_grow <= 0 or "capacity" not in str(e):
+                    raise
+                auto_grow -= 1
+                self.grow()
         self.last_stage_ms = ms.tolist()
         return self.last_stage_ms
 

@@ -286,6 +286,26 @@ def test_python_decode_utterance_lattice_faster(tmp_path):
     assert ok and key == "u2" and arcs.size == o.GetRawLattice().arcs.size
 
 
+def test_pipeline_grows_on_capacity_overflow():
+    from kaldi_amd import nnet, pipeline
+    from kaldi_amd._lib import KamdError
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=0.5)
+    cfg = abi.decoder_config_recipe()
+    waves = [synth.make_wave(d, seed=40 + i) for i, d in enumerate((1.5, 0.9))]
+    small = abi.DecoderSizes(2, 1 << 12, 3000, 4000, 128)
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, cfg, max_utts=2, max_seconds=2.0, sizes=small)
+    pipe.load(waves)
+    with pytest.raises(KamdError, match="capacity"):
+        pipe.run()
+    pipe.run(auto_grow=8)
+    assert pipe.sizes.arena_tokens > small.arena_tokens
+    res = pipe.results()
+    ref = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, cfg, max_utts=2, max_seconds=2.0).decode(waves)
+    for a, b in zip(res, ref):
+        assert lattices_equal(a["lattice"], b["lattice"])
+
+
 def test_more_pdfs_than_the_lds_row_holds():
     """P = 9000: only part of the log-likelihood row is staged in LDS, the rest is read from HBM."""
     g = synth.make_hclg(num_units=4500, vocab=300, n_hist=20, seed=8)
