@@ -382,6 +382,24 @@ int kamd_lattice_write(const char *path, int append, const char *key, int binary
 int kamd_lattice_read(const char *path, int64_t *offset, char *key, int key_cap,
                       int32_t *num_states, int32_t *start, float **state_final,
                       kamd_lat_arc **arcs, int32_t *num_arcs);
+/* ----------------------------------------------------- input-side formats -- */
+/* WaveData::Read (feat/wave-reader.cc:113-318): RIFF / RIFX 16-bit PCM, filler chunks,
+ * WAVE_FORMAT_EXTENSIBLE, streamed sizes.  *data: num_channels rows of num_samples floats in
+ * int16 range (malloc'ed: kamd_host_free). */
+int kamd_wave_read(const char *path, float *samp_freq, int32_t *num_channels, int64_t *num_samples,
+                   float **data);
+/* Next entry of a Kaldi float-matrix archive ("ark": key, space, object) at byte *offset
+ * (advanced past it): binary FM / DM, compressed CM / CM2 / CM3 or text
+ * (matrix/kaldi-matrix.cc:1378-1512, matrix/compressed-matrix.cc:566-650).  Returns 1 at end of
+ * file.  *data row-major [rows x cols], malloc'ed. */
+int kamd_ark_read_matrix(const char *path, int64_t *offset, char *key, int key_cap, int32_t *rows,
+                         int32_t *cols, float **data);
+int kamd_ark_write_matrix(const char *path, int append, const char *key, int binary, int32_t rows,
+                          int32_t cols, const float *data);
+/* Next Int32VectorHolder entry (alignments, word sequences, a dumped transition-id -> pdf table) */
+int kamd_ark_read_int32_vector(const char *path, int64_t *offset, char *key, int key_cap, int32_t *n,
+                               int32_t **data);
+
 /* ------------------------------------------------------- batched streaming -- */
 /* N concurrent SingleUtteranceNnet3Decoder streams (online2/online-nnet3-decoding.{h,cc})
  * driven together: stream s is decoder lane s of `dec` (created with max_lanes >= max_streams).

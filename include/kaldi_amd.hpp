@@ -376,11 +376,11 @@ class Int32VectorWriter : public TableWriterBase {   // BasicVectorHolder<int32>
     FILE *f = fopen(path_.c_str(), Append() ? "ab" : "wb");
     if (!f) throw KaldiFatalError("cannot open " + path_);
     fputs(key.c_str(), f); fputc(' ', f);
-    if (binary_) {                       // "\0B", then WriteIntegerVector: size byte, int32 count, raw data
-      fputc('\0', f); fputc('B', f); fputc(4, f);
+    if (binary_) {                       // "\0B", WriteBasicType(count), WriteBasicType(element)... (kaldi-holder-inl.h:230-250)
+      fputc('\0', f); fputc('B', f);
       const int32 n = static_cast<int32>(v.size());
-      fwrite(&n, 4, 1, f);
-      if (n) fwrite(v.data(), 4, v.size(), f);
+      fputc(4, f); fwrite(&n, 4, 1, f);
+      for (size_t i = 0; i < v.size(); i++) { fputc(4, f); fwrite(&v[i], 4, 1, f); }
     } else {
       for (size_t i = 0; i < v.size(); i++) fprintf(f, "%d ", v[i]);
       fputc('\n', f);

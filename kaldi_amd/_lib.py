@@ -102,6 +102,13 @@ def lib():
     sig("kamd_nnet_forward_chunked_device", C.c_int, [vp, vp, i64p, C.c_int, vp, i64p, C.c_int, C.c_int, C.c_int, C.c_int, vp,
                                                       i64p, C.c_int, vp])
     sig("kamd_pipeline_set_online_ivectors", C.c_int, [vp, fp, i64p, C.c_int, C.c_int, C.c_int])
+    sig("kamd_wave_read", C.c_int, [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int64),
+                                    C.POINTER(C.POINTER(C.c_float))])
+    sig("kamd_ark_read_matrix", C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.c_char_p, C.c_int, C.POINTER(C.c_int32),
+                                          C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_float))])
+    sig("kamd_ark_write_matrix", C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int32, C.c_int32, fp])
+    sig("kamd_ark_read_int32_vector", C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.c_char_p, C.c_int, C.POINTER(C.c_int32),
+                                                C.POINTER(C.POINTER(C.c_int32))])
     sig("kamd_graph_destroy", None, [vp])
     sig("kamd_graph_num_states", C.c_int32, [vp])
     sig("kamd_graph_num_arcs", C.c_int64, [vp])
@@ -145,6 +152,7 @@ kamd_nnet_num_output_frames kamd_nnet_frame_subsampling_factor kamd_nnet_forward
 kamd_graph_create kamd_graph_destroy kamd_graph_num_states kamd_graph_num_arcs
 kamd_graph_read_openfst kamd_openfst_read kamd_openfst_write kamd_host_free kamd_lattice_write kamd_lattice_read
 kamd_stream_batch_create kamd_stream_batch_destroy kamd_stream_batch_start kamd_stream_batch_accept kamd_stream_batch_advance kamd_stream_batch_num_frames_ready kamd_feat_compute_ranges_device kamd_nnet_forward_slices_device kamd_nnet_forward_chunked_device
+kamd_wave_read kamd_ark_read_matrix kamd_ark_write_matrix kamd_ark_read_int32_vector
 kamd_determinize_opts_default kamd_lattice_determinize_phone_pruned kamd_compact_lattice_destroy kamd_compact_lattice_sizes kamd_compact_lattice_get kamd_compact_lattice_write
 kamd_decoder_config_default kamd_decoder_sizes_default kamd_decoder_create kamd_decoder_destroy
 kamd_decoder_set_options kamd_decoder_reserve kamd_decoder_init kamd_decoder_advance kamd_decoder_finalize

@@ -158,3 +158,59 @@ def determinize_lattice(lat, beam, tid_phone=None, opts=None):
     if not h:
         raise KamdError(lib().kamd_last_error().decode())
     return CompactLattice(h)
+
+
+def read_wave(path):
+    """WaveData::Read (feat/wave-reader.cc:272-318): (samp_freq, data[num_channels, num_samples])
+    with samples in int16 range."""
+    sf, nc, ns = C.c_float(), C.c_int32(), C.c_int64()
+    p = C.POINTER(C.c_float)()
+    check(lib().kamd_wave_read(str(path).encode(), C.byref(sf), C.byref(nc), C.byref(ns), C.byref(p)))
+    try:
+        a = np.ctypeslib.as_array(p, (nc.value * ns.value,)).copy().reshape(nc.value, ns.value)
+    finally:
+        lib().kamd_host_free(C.cast(p, C.c_void_p))
+    return sf.value, a
+
+
+def read_matrix_ark(path):
+    """Yields (key, matrix) for every entry of a Kaldi float-matrix archive (binary, compressed
+    or text)."""
+    off = C.c_int64(0)
+    key = C.create_string_buffer(4096)
+    while True:
+        r, c = C.c_int32(), C.c_int32()
+        p = C.POINTER(C.c_float)()
+        rc = lib().kamd_ark_read_matrix(str(path).encode(), C.byref(off), key, 4096, C.byref(r), C.byref(c), C.byref(p))
+        if rc == 1:
+            return
+        check(rc)
+        try:
+            n = r.value * c.value
+            a = np.ctypeslib.as_array(p, (max(n, 1),)).copy()[:n].reshape(r.value, c.value)
+        finally:
+            lib().kamd_host_free(C.cast(p, C.c_void_p))
+        yield key.value.decode(), a
+
+
+def write_matrix_ark(path, key, matrix, binary=True, append=True):
+    m = np.ascontiguousarray(matrix, np.float32)
+    check(lib().kamd_ark_write_matrix(str(path).encode(), int(append), key.encode(), int(binary), m.shape[0], m.shape[1],
+                                      abi.fptr(m)))
+
+
+def read_int32_vector_ark(path):
+    off = C.c_int64(0)
+    key = C.create_string_buffer(4096)
+    while True:
+        n = C.c_int32()
+        p = C.POINTER(C.c_int32)()
+        rc = lib().kamd_ark_read_int32_vector(str(path).encode(), C.byref(off), key, 4096, C.byref(n), C.byref(p))
+        if rc == 1:
+            return
+        check(rc)
+        try:
+            a = np.ctypeslib.as_array(p, (max(n.value, 1),)).copy()[:n.value]
+        finally:
+            lib().kamd_host_free(C.cast(p, C.c_void_p))
+        yield key.value.decode(), a

@@ -75,6 +75,9 @@ def test_cxx_host_api(tmp_path):
     assert wl[0].split() == ["utt-det"] + [str(w) for w in words] and wl[1].split()[0] == "utt-raw"
     raw = open(tmp_path / "ali.ark", "rb").read()
     assert raw.startswith(b"utt-det \0B\x04") and int.from_bytes(raw[11:15], "little") == ll.shape[0]
+    from kaldi_amd import io as kio2
+    alis = dict(kio2.read_int32_vector_ark(tmp_path / "ali.ark"))
+    assert alis["utt-det"].tolist() == bp["alignment"].tolist()
     from kaldi_amd import io as kio
     (key, st, fin, arcs), = list(kio.read_lattices(tmp_path / "lat.txt"))
     assert key == "utt-raw" and arcs.size == lat.arcs.size

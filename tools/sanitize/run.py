@@ -44,4 +44,28 @@ for beam in (1e30, 3.0, 0.5):
     for binary in (0, 1):
         assert L.kamd_compact_lattice_write(os.path.join(tmp, "c%d" % binary).encode(), 0, b"u", binary, C.c_void_p(h), C.c_float(0.5)) == 0
     L.kamd_compact_lattice_destroy(C.c_void_p(h))
+# wave + archives
+import struct, wave
+wp = os.path.join(tmp, "a.wav")
+x = np.random.default_rng(0).integers(-30000, 30000, (777, 2)).astype("<i2")
+with wave.open(wp, "wb") as w:
+    w.setnchannels(2); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.tobytes())
+sf, nc, ns = C.c_float(), C.c_int32(), C.c_int64(); pw = C.c_void_p()
+assert L.kamd_wave_read(wp.encode(), C.byref(sf), C.byref(nc), C.byref(ns), C.byref(pw)) == 0 and ns.value == 777
+L.kamd_host_free(pw)
+open(wp, "wb").write(open(wp, "rb").read()[:60])
+assert L.kamd_wave_read(wp.encode(), C.byref(sf), C.byref(nc), C.byref(ns), C.byref(pw)) == 0     # truncated data: warning only
+L.kamd_host_free(pw)
+m = np.random.default_rng(1).standard_normal((9, 4)).astype(np.float32)
+for binary in (0, 1):
+    ap = os.path.join(tmp, "m%d.ark" % binary).encode()
+    assert L.kamd_ark_write_matrix(ap, 0, b"a", binary, 9, 4, m.ctypes.data_as(C.c_void_p)) == 0
+    assert L.kamd_ark_write_matrix(ap, 1, b"b", binary, 0, 0, m.ctypes.data_as(C.c_void_p)) == 0
+    offp = C.c_int64(0); key = C.create_string_buffer(64); cnt = 0
+    while True:
+        r, c = C.c_int32(), C.c_int32(); pm = C.c_void_p()
+        rc = L.kamd_ark_read_matrix(ap, C.byref(offp), key, 64, C.byref(r), C.byref(c), C.byref(pm))
+        if rc == 1: break
+        assert rc == 0; L.kamd_host_free(pm); cnt += 1
+    assert cnt == 2
 print("sanitized host paths ok; raw lattice", S, la.size)
