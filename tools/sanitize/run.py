@@ -53,7 +53,8 @@ with wave.open(wp, "wb") as w:
 sf, nc, ns = C.c_float(), C.c_int32(), C.c_int64(); pw = C.c_void_p()
 assert L.kamd_wave_read(wp.encode(), C.byref(sf), C.byref(nc), C.byref(ns), C.byref(pw)) == 0 and ns.value == 777
 L.kamd_host_free(pw)
-open(wp, "wb").write(open(wp, "rb").read()[:60])
+head = open(wp, "rb").read()[:60]
+open(wp, "wb").write(head)
 assert L.kamd_wave_read(wp.encode(), C.byref(sf), C.byref(nc), C.byref(ns), C.byref(pw)) == 0     # truncated data: warning only
 L.kamd_host_free(pw)
 m = np.random.default_rng(1).standard_normal((9, 4)).astype(np.float32)
