@@ -306,6 +306,36 @@ def test_pipeline_grows_on_capacity_overflow():
         assert lattices_equal(a["lattice"], b["lattice"])
 
 
+def test_latgen_faster_mapped_tool(tmp_path):
+    """files in / files out: id2pdf + HCLG.fst + loglikes.ark -> lat.ark + words, against a direct decode."""
+    import subprocess
+    import sys
+    from kaldi_amd import io as kio
+    g = synth.make_hclg(num_units=24, vocab=60, n_hist=12, seed=6)
+    utts = {}
+    for i in range(3):
+        ll, words, _ = synth.sample_utterance(g, n_words=3 + i, seed=30 + i, peak=5.0)
+        utts["utt%d" % i] = (ll, words)
+        kio.write_matrix_ark(tmp_path / "ll.ark", "utt%d" % i, ll, binary=bool(i % 2), append=i > 0)
+    kio.write_openfst(tmp_path / "HCLG.fst", g, "const")
+    (tmp_path / "id2pdf.int").write_text("id2pdf " + " ".join(str(int(x)) for x in g.tid2pdf) + " \n")
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    cmd = [sys.executable, root + "/tools/latgen_faster_mapped.py", "--acoustic-scale=1.0", "--beam=15", "--lattice-beam=8",
+           "--max-active=7000", "--determinize-lattice=0", str(tmp_path / "id2pdf.int"), str(tmp_path / "HCLG.fst"),
+           str(tmp_path / "ll.ark"), str(tmp_path / "lat.ark"), str(tmp_path / "words.txt")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Done 3 utterances, failed for 0" in r.stderr
+    got_words = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(tmp_path / "words.txt")}
+    lats = {k: (st, fin, arcs) for k, st, fin, arcs in kio.read_lattices(tmp_path / "lat.ark")}
+    cfg = abi.decoder_config_recipe()
+    for key, (ll, words) in utts.items():
+        assert got_words[key] == words
+        o = orc.Decoder(g, cfg, 1)
+        o.Decode(ll)
+        assert lats[key][2].size == o.GetRawLattice().arcs.size
+
+
 def test_more_pdfs_than_the_lds_row_holds():
     """P = 9000: only part of the log-likelihood row is staged in LDS, the rest is read from HBM."""
     g = synth.make_hclg(num_units=4500, vocab=300, n_hist=20, seed=8)
