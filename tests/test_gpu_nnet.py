@@ -157,3 +157,17 @@ def test_pipeline_with_online_ivectors():
     pipe.set_online_ivectors(None)
     with pytest.raises(Exception):
         pipe.run()                      # the model needs ivectors
+
+
+def test_model_read_from_mdl_file(tmp_path):
+    """final.mdl -> kaldi_amd.mdl.read_mdl -> device forward == the model it was written from"""
+    from kaldi_amd import mdl
+    from tests.mdl_writer import write_mdl
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, 50, input_dim=40, seed=11)
+    write_mdl(tmp_path / "final.mdl", m, num_units=25)
+    got, id2pdf, tid_phone = mdl.read_mdl(tmp_path / "final.mdl", acoustic_scale=m.layers[-1].post_scale)
+    feats = (2 * np.random.default_rng(3).standard_normal((90, 40))).astype(np.float32)
+    a = decoder.Nnet(got).Forward(feats)
+    b = decoder.Nnet(m).Forward(feats)
+    assert np.abs(a - b).max() < 1e-4 * np.abs(b).max()
+    assert id2pdf.size == 51 and tid_phone.max() == 25
