@@ -336,6 +336,41 @@ def test_latgen_faster_mapped_tool(tmp_path):
         assert lats[key][2].size == o.GetRawLattice().arcs.size
 
 
+def test_nnet3_latgen_faster_tool(tmp_path):
+    """final.mdl + HCLG.fst + wav.scp -> CompactLattice archive + words, against the in-memory pipeline."""
+    import subprocess
+    import sys
+    import wave
+    from kaldi_amd import io as kio
+    from kaldi_amd import nnet, pipeline
+    from tests.mdl_writer import write_mdl
+    g = synth.make_hclg(num_units=25, vocab=60, n_hist=12, seed=6)
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, seed=12, output_scale=3.0)
+    write_mdl(tmp_path / "final.mdl", m, num_units=25)
+    kio.write_openfst(tmp_path / "HCLG.fst", g, "const")
+    waves = [np.round(synth.make_wave(d, seed=50 + i)).astype(np.float32) for i, d in enumerate((1.2, 2.0, 0.8))]
+    with open(tmp_path / "wav.scp", "w") as scp:
+        for i, w in enumerate(waves):
+            with wave.open(str(tmp_path / ("u%d.wav" % i)), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+                f.writeframes(w.astype("<i2").tobytes())
+            scp.write("utt%d %s\n" % (i, tmp_path / ("u%d.wav" % i)))
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    cmd = [sys.executable, root + "/tools/nnet3_latgen_faster.py", "--batch=2", str(tmp_path / "final.mdl"),
+           str(tmp_path / "HCLG.fst"), str(tmp_path / "wav.scp"), str(tmp_path / "lat.ark"), str(tmp_path / "words.txt")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Done 3 utterances, failed for 0" in r.stderr
+    # the same through the in-memory pipeline with the ORIGINAL model and a table built like the writer's
+    g.tid2pdf = np.concatenate([[-1], np.stack([2 * np.arange(25) + 1, 2 * np.arange(25)], 1).reshape(-1)]).astype(np.int32)
+    ref = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, abi.decoder_config_recipe(), max_utts=3, max_seconds=2.5).decode(waves)
+    got = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(tmp_path / "words.txt")}
+    for i in range(3):
+        assert got["utt%d" % i] == ref[i]["words"].tolist()
+    raw = open(tmp_path / "lat.ark", "rb").read()
+    assert raw.startswith(b"utt0 ") and raw.count(b"compactlattice44") == 3
+
+
 def test_more_pdfs_than_the_lds_row_holds():
     """P = 9000: only part of the log-likelihood row is staged in LDS, the rest is read from HBM."""
     g = synth.make_hclg(num_units=4500, vocab=300, n_hist=20, seed=8)
