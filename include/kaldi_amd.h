@@ -389,7 +389,8 @@ int kamd_lattice_read(const char *path, int64_t *offset, char *key, int key_cap,
 int kamd_wave_read(const char *path, float *samp_freq, int32_t *num_channels, int64_t *num_samples,
                    float **data);
 /* Next entry of a Kaldi float-matrix archive ("ark": key, space, object) at byte *offset
- * (advanced past it): binary FM / DM, compressed CM / CM2 / CM3 or text
+ * (advanced past it; key == NULL: the object itself starts at *offset, as an scp line's
+ * "file:offset" points): binary FM / DM, compressed CM / CM2 / CM3 or text
  * (matrix/kaldi-matrix.cc:1378-1512, matrix/compressed-matrix.cc:566-650).  Returns 1 at end of
  * file.  *data row-major [rows x cols], malloc'ed. */
 int kamd_ark_read_matrix(const char *path, int64_t *offset, char *key, int key_cap, int32_t *rows,
@@ -399,6 +400,29 @@ int kamd_ark_write_matrix(const char *path, int append, const char *key, int bin
 /* Next Int32VectorHolder entry (alignments, word sequences, a dumped transition-id -> pdf table) */
 int kamd_ark_read_int32_vector(const char *path, int64_t *offset, char *key, int key_cap, int32_t *n,
                                int32_t **data);
+
+/* ------------------------------------- extended filenames and table specifiers -- */
+/* ClassifyRxfilename / ClassifyWxfilename (util/kaldi-io.cc:85-186); values follow the
+ * reference's InputType / OutputType enums (util/kaldi-io.h:89-111). */
+enum { KAMD_RX_NONE = 0, KAMD_RX_FILE = 1, KAMD_RX_STDIN = 2, KAMD_RX_OFFSET_FILE = 3, KAMD_RX_PIPE = 4 };
+enum { KAMD_WX_NONE = 0, KAMD_WX_FILE = 1, KAMD_WX_STDOUT = 2, KAMD_WX_PIPE = 3 };
+int kamd_classify_rxfilename(const char *filename);
+int kamd_classify_wxfilename(const char *filename);
+/* ClassifyRspecifier (util/kaldi-table.cc:225-310): 0 = not an rspecifier, 1 = "ark:", 2 = "scp:";
+ * option letters o / s / cs / p / bg as bits.  -1 if the buffer is too small. */
+enum { KAMD_RSPEC_ONCE = 1, KAMD_RSPEC_SORTED = 2, KAMD_RSPEC_CALLED_SORTED = 4, KAMD_RSPEC_PERMISSIVE = 8,
+       KAMD_RSPEC_BACKGROUND = 16 };
+int kamd_classify_rspecifier(const char *rspecifier, char *rxfilename, int cap, int *opts);
+/* ClassifyWspecifier (util/kaldi-table.cc:115-222): 0 none, 1 "ark:", 2 "scp:", 3 "ark,scp:a,b";
+ * binary defaults to set ("t" clears it). */
+enum { KAMD_WSPEC_BINARY = 1, KAMD_WSPEC_FLUSH = 2, KAMD_WSPEC_PERMISSIVE = 4 };
+int kamd_classify_wspecifier(const char *wspecifier, char *archive_wxfilename, int ark_cap,
+                             char *script_wxfilename, int scp_cap, int *opts);
+/* Any rxfilename -> a seekable (path, offset) the readers above take: "file", "file:offset",
+ * "command |" and "-" (the last two spooled to a temporary file: *is_temp = 1, the caller
+ * unlinks it).  Input::Open's dispatch (util/kaldi-io.cc:760-800). */
+int kamd_rx_materialize(const char *rxfilename, char *path, int cap, int64_t *offset, int *is_temp);
+
 
 /* ------------------------------------------------------- batched streaming -- */
 /* N concurrent SingleUtteranceNnet3Decoder streams (online2/online-nnet3-decoding.{h,cc})
@@ -524,6 +548,10 @@ void kamd_pipeline_destroy(kamd_pipeline *p);
 /* Upload a batch of waveforms (host, concatenated; h_wave_off[n_utts+1]). */
 int kamd_pipeline_load_batch(kamd_pipeline *p, const float *waves,
                              const int64_t *h_wave_off, int n_utts);
+/* Features computed elsewhere (the features-rspecifier of nnet3bin/nnet3-latgen-faster.cc:166-200)
+ * instead of waveforms: utterance u owns rows [row_off[u], row_off[u+1]) of host matrix `feats`
+ * with `dim` columns; kamd_pipeline_run then skips the feature stage. */
+int kamd_pipeline_load_features(kamd_pipeline *p, const float *feats, const int64_t *row_off, int n_utts, int dim);
 /* One ivector per utterance of the resident batch ([n_utts x dim], host), the
  * `--ivectors` rspecifier of nnet3-latgen-faster (nnet3bin/nnet3-latgen-faster.cc:153-170).
  * dim = 0 clears them.  Online (per-chunk) ivectors are not supported: their values depend

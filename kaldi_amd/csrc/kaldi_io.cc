@@ -223,17 +223,21 @@ int kamd_ark_read_matrix(const char *path, int64_t *offset, char *key, int key_c
   if (!f.f) return Fail("cannot open", path);
   if (fseek(f.f, static_cast<long>(*offset), SEEK_SET) != 0) return Fail("seek failed", path);
   int c;
-  while ((c = f.Get()) != EOF && (c == '\n' || c == ' ')) {}
-  if (c == EOF) return 1;
-  std::string k(1, static_cast<char>(c));
-  while ((c = f.Get()) != EOF && c != ' ' && c != '\n') k.push_back(static_cast<char>(c));
-  if (c != ' ' || static_cast<int>(k.size()) + 1 > key_cap) return Fail("bad archive key", path);
-  memcpy(key, k.c_str(), k.size() + 1);
+  const char *shown = "(scp entry)";
+  if (key) {
+    while ((c = f.Get()) != EOF && (c == '\n' || c == ' ')) {}
+    if (c == EOF) return 1;
+    std::string k(1, static_cast<char>(c));
+    while ((c = f.Get()) != EOF && c != ' ' && c != '\n') k.push_back(static_cast<char>(c));
+    if (c != ' ' || static_cast<int>(k.size()) + 1 > key_cap) return Fail("bad archive key", path);
+    memcpy(key, k.c_str(), k.size() + 1);
+    shown = key;
+  } else if (f.Peek() == EOF) return Fail("offset past the end", path);
   bool binary = false;
   if (f.Peek() == '\0') { f.Get(); if (f.Get() != 'B') return Fail("bad binary marker", path); binary = true; }
   std::vector<float> m;
   std::string err;
-  if (!ReadMatrixBody(&f, binary, &m, rows, cols, &err)) return kamd::SetError(KAMD_ERR_ARG, "%s: key %s: %s", path, key, err.c_str());
+  if (!ReadMatrixBody(&f, binary, &m, rows, cols, &err)) return kamd::SetError(KAMD_ERR_ARG, "%s: key %s: %s", path, shown, err.c_str());
   *offset = ftell(f.f);
   *data = static_cast<float *>(malloc(sizeof(float) * (m.size() + 1)));
   if (!*data) return kamd::SetError(KAMD_ERR_ARG, "out of host memory");
@@ -273,13 +277,17 @@ int kamd_ark_read_int32_vector(const char *path, int64_t *offset, char *key, int
   File f(fopen(path, "rb"));
   if (!f.f) return Fail("cannot open", path);
   if (fseek(f.f, static_cast<long>(*offset), SEEK_SET) != 0) return Fail("seek failed", path);
-  int c;
-  while ((c = f.Get()) != EOF && (c == '\n' || c == ' ')) {}
-  if (c == EOF) return 1;
-  std::string k(1, static_cast<char>(c));
-  while ((c = f.Get()) != EOF && c != ' ' && c != '\n') k.push_back(static_cast<char>(c));
-  if ((c != ' ' && c != '\n') || static_cast<int>(k.size()) + 1 > key_cap) return Fail("bad archive key", path);
-  memcpy(key, k.c_str(), k.size() + 1);
+  int c = ' ';
+  const char *shown = "(scp entry)";
+  if (key) {
+    while ((c = f.Get()) != EOF && (c == '\n' || c == ' ')) {}
+    if (c == EOF) return 1;
+    std::string k(1, static_cast<char>(c));
+    while ((c = f.Get()) != EOF && c != ' ' && c != '\n') k.push_back(static_cast<char>(c));
+    if ((c != ' ' && c != '\n') || static_cast<int>(k.size()) + 1 > key_cap) return Fail("bad archive key", path);
+    memcpy(key, k.c_str(), k.size() + 1);
+    shown = key;
+  }
   std::vector<int32_t> v;
   if (c == ' ' && f.Peek() == '\0') {
     f.Get();
@@ -298,7 +306,7 @@ int kamd_ark_read_int32_vector(const char *path, int64_t *offset, char *key, int
       if (!*p) break;
       char *e;
       const long x = strtol(p, &e, 10);
-      if (e == p) return kamd::SetError(KAMD_ERR_ARG, "%s: key %s: bad integer", path, key);
+      if (e == p) return kamd::SetError(KAMD_ERR_ARG, "%s: key %s: bad integer", path, shown);
       v.push_back(static_cast<int32_t>(x)); p = e;
     }
   }

@@ -19,6 +19,7 @@ struct Pipeline {
   float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL, *d_iv = NULL;
   size_t waves_cap = 0, feats_cap = 0, ll_cap = 0, iv_cap = 0;
   int iv_dim = 0;
+  bool have_feats = false;      // features were handed in (kamd_pipeline_load_features): skip the feature stage
   // online ivectors (one row per ivector_period frames) instead of one ivector per utterance
   float *d_oiv = NULL; size_t oiv_cap = 0; std::vector<int64_t> oiv_off; int oiv_period = 0, frames_per_chunk = 50;
   hipEvent_t ev[5];
@@ -63,7 +64,7 @@ void kamd_pipeline_destroy(kamd_pipeline *h) {
 int kamd_pipeline_load_batch(kamd_pipeline *h, const float *waves, const int64_t *h_wave_off, int n_utts) {
   Pipeline *p = reinterpret_cast<Pipeline *>(h);
   if (n_utts <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty batch");
-  p->n_utts = n_utts;
+  p->n_utts = n_utts; p->have_feats = false;
   p->wave_off.assign(h_wave_off, h_wave_off + n_utts + 1);
   p->feat_off.assign(n_utts + 1, 0); p->out_off.assign(n_utts + 1, 0);
   for (int u = 0; u < n_utts; u++) {
@@ -78,6 +79,30 @@ int kamd_pipeline_load_batch(kamd_pipeline *h, const float *waves, const int64_t
   if (kamd::GrowBuf(&p->d_ll, &p->ll_cap, static_cast<size_t>(p->out_off[n_utts]) * p->P) != KAMD_OK) return KAMD_ERR_HIP;
   KAMD_HIP(hipMemcpy(p->d_waves, waves + h_wave_off[0], ns * sizeof(float), hipMemcpyHostToDevice));
   if (h_wave_off[0] != 0) for (int u = 0; u <= n_utts; u++) p->wave_off[u] -= h_wave_off[0];
+  return KAMD_OK;
+}
+
+// The features-rspecifier case of nnet3-latgen-faster (nnet3bin/nnet3-latgen-faster.cc:166-200: a
+// SequentialBaseFloatMatrixReader of features some other tool computed): utterance u owns rows
+// [h_row_off[u], h_row_off[u+1]) of `feats` (row-major, `dim` columns = the model's input dim).
+int kamd_pipeline_load_features(kamd_pipeline *h, const float *feats, const int64_t *h_row_off, int n_utts, int dim) {
+  Pipeline *p = reinterpret_cast<Pipeline *>(h);
+  if (n_utts <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty batch");
+  if (dim != p->feat_dim) return kamd::SetError(KAMD_ERR_ARG, "feature dim %d, the pipeline's feature stage has %d", dim, p->feat_dim);
+  p->n_utts = n_utts; p->have_feats = true;
+  p->feat_off.assign(n_utts + 1, 0); p->out_off.assign(n_utts + 1, 0);
+  for (int u = 0; u < n_utts; u++) {
+    const int64_t T = h_row_off[u + 1] - h_row_off[u];
+    if (T <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no frames", u);
+    p->feat_off[u + 1] = p->feat_off[u] + T;
+    p->out_off[u + 1] = p->out_off[u] + kamd_nnet_num_output_frames(p->nnet, static_cast<int>(T));
+  }
+  const size_t rows = static_cast<size_t>(p->feat_off[n_utts]);
+  if (kamd::GrowBuf(&p->d_feats, &p->feats_cap, rows * p->ld_feat) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowBuf(&p->d_ll, &p->ll_cap, static_cast<size_t>(p->out_off[n_utts]) * p->P) != KAMD_OK) return KAMD_ERR_HIP;
+  if (p->ld_feat != dim) KAMD_HIP(hipMemset(p->d_feats, 0, rows * p->ld_feat * sizeof(float)));
+  KAMD_HIP(hipMemcpy2D(p->d_feats, p->ld_feat * sizeof(float), feats + h_row_off[0] * dim, dim * sizeof(float),
+                       dim * sizeof(float), rows, hipMemcpyHostToDevice));
   return KAMD_OK;
 }
 
@@ -116,8 +141,10 @@ int kamd_pipeline_run(kamd_pipeline *h, float stage_ms[4]) {
   if (n <= 0) return kamd::SetError(KAMD_ERR_STATE, "no batch loaded");
   hipStream_t st = NULL;
   KAMD_HIP(hipEventRecord(p->ev[0], st));
-  int rc = kamd_feat_compute_batch_device(p->feat, p->d_waves, p->wave_off.data(), n, p->d_feats,
-                                          p->feat_off.data(), p->ld_feat, st);
+  int rc = KAMD_OK;
+  if (!p->have_feats)
+    rc = kamd_feat_compute_batch_device(p->feat, p->d_waves, p->wave_off.data(), n, p->d_feats,
+                                        p->feat_off.data(), p->ld_feat, st);
   if (rc != KAMD_OK) return rc;
   KAMD_HIP(hipEventRecord(p->ev[1], st));
   if (p->oiv_period > 0)

@@ -72,21 +72,49 @@ class Pipeline:
         off = np.concatenate([[0], np.cumsum([w.size for w in keep])]).astype(np.int64)
         flat = np.ascontiguousarray(np.concatenate(keep), np.float32)
         check(lib().kamd_pipeline_load_batch(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), len(keep)))
-        self._loaded = (flat, off, len(keep))      # kept for grow(): the reference never runs out of room
+        self._loaded = ("waves", flat, off, len(keep))     # kept for grow(): the reference never runs out of room
+        self._iv_loaded = None
+
+    def load_features(self, feats):
+        """Feature matrices computed elsewhere (the features-rspecifier of nnet3-latgen-faster)
+        instead of waveforms; empty matrices are skipped with a None result."""
+        self._lane_of, keep = [], []
+        for f in feats:
+            f = np.asarray(f, np.float32)
+            if f.ndim != 2:
+                raise KamdError("features must be [frames x dim] matrices")
+            if f.shape[0] > 0:
+                self._lane_of.append(len(keep))
+                keep.append(f)
+            else:
+                self._lane_of.append(-1)
+        self.n_utts, self.n_input = len(keep), len(feats)
+        shift_s = self.feat.opts.frame.frame_shift_ms * 1e-3
+        self.audio_seconds = float(sum(f.shape[0] for f in keep)) * shift_s
+        if not keep:
+            return
+        off = np.concatenate([[0], np.cumsum([f.shape[0] for f in keep])]).astype(np.int64)
+        flat = np.ascontiguousarray(np.concatenate(keep), np.float32)
+        check(lib().kamd_pipeline_load_features(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), len(keep), flat.shape[1]))
+        self._loaded = ("feats", flat, off, len(keep))
+        self._iv_loaded = None
 
     def set_ivectors(self, ivectors):
         """One ivector per (non-skipped) utterance of the loaded batch."""
         if ivectors is None:
             check(lib().kamd_pipeline_set_ivectors(self._h, None, 0))
+            self._iv_loaded = None
             return
         iv = np.ascontiguousarray([v for v, lane in zip(ivectors, self._lane_of) if lane >= 0], np.float32)
         check(lib().kamd_pipeline_set_ivectors(self._h, abi.fptr(iv), iv.shape[1]))
+        self._iv_loaded = ("utt", iv)
 
     def set_online_ivectors(self, ivector_matrices, ivector_period=10, frames_per_chunk=50):
         """--online-ivectors / --online-ivector-period: one [rows x dim] matrix per utterance of the
         loaded batch (a row per `ivector_period` frames); the nnet stage then runs chunk by chunk."""
         if ivector_matrices is None:
             check(lib().kamd_pipeline_set_online_ivectors(self._h, None, None, 0, 0, 0))
+            self._iv_loaded = None
             return
         mats = [np.ascontiguousarray(v, np.float32) for v, lane in zip(ivector_matrices, self._lane_of) if lane >= 0]
         off = np.zeros(len(mats) + 1, np.int64)
@@ -94,6 +122,7 @@ class Pipeline:
         iv = np.ascontiguousarray(np.concatenate(mats), np.float32)
         check(lib().kamd_pipeline_set_online_ivectors(self._h, abi.fptr(iv), abi.iptr(off, C.c_int64), iv.shape[1],
                                                       ivector_period, frames_per_chunk))
+        self._iv_loaded = ("online", iv, off, ivector_period, frames_per_chunk)
 
     def grow(self, factor=2):
         """Rebuilds the decoder with `factor` x the frame table and arenas and reloads the batch
@@ -109,12 +138,21 @@ class Pipeline:
         if not self._h:
             raise KamdError(lib().kamd_last_error().decode())
         if getattr(self, "_loaded", None) is not None and self.n_utts > 0:
-            flat, off, n = self._loaded
-            check(lib().kamd_pipeline_load_batch(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), n))
+            kind, flat, off, n = self._loaded
+            if kind == "waves":
+                check(lib().kamd_pipeline_load_batch(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), n))
+            else:
+                check(lib().kamd_pipeline_load_features(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), n, flat.shape[1]))
+            iv = getattr(self, "_iv_loaded", None)
+            if iv is not None and iv[0] == "utt":
+                check(lib().kamd_pipeline_set_ivectors(self._h, abi.fptr(iv[1]), iv[1].shape[1]))
+            elif iv is not None:
+                check(lib().kamd_pipeline_set_online_ivectors(self._h, abi.fptr(iv[1]), abi.iptr(iv[2], C.c_int64), iv[1].shape[1],
+                                                              iv[3], iv[4]))
 
     def run(self, auto_grow=0):
         """auto_grow = how many times a capacity overflow may be answered by grow() + rerun
-        (per-utterance / online ivectors must be set again by the caller after a grow)."""
+        (the batch and its ivectors are reloaded)."""
         ms = np.zeros(4, np.float32)
         if self.n_utts == 0:
             self.last_stage_ms = ms.tolist()

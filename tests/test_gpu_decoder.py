@@ -356,19 +356,43 @@ def test_nnet3_latgen_faster_tool(tmp_path):
                 f.writeframes(w.astype("<i2").tobytes())
             scp.write("utt%d %s\n" % (i, tmp_path / ("u%d.wav" % i)))
     root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
-    cmd = [sys.executable, root + "/tools/nnet3_latgen_faster.py", "--batch=2", str(tmp_path / "final.mdl"),
-           str(tmp_path / "HCLG.fst"), str(tmp_path / "wav.scp"), str(tmp_path / "lat.ark"), str(tmp_path / "words.txt")]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    (tmp_path / "decode.config").write_text("--beam=15.0   # steps/nnet3/decode.sh\n--max-active=7000\n--lattice_beam=8.0\n")
+    tool = [sys.executable, root + "/tools/nnet3_latgen_faster.py", "--config=%s" % (tmp_path / "decode.config"),
+            "--acoustic-scale=1.0", "--frame-subsampling-factor=3", "--batch=2"]
+    gz = tmp_path / "lat.1.gz"
+    r = subprocess.run(tool + ["--wav", str(tmp_path / "final.mdl"), str(tmp_path / "HCLG.fst"), "scp:%s" % (tmp_path / "wav.scp"),
+                               "ark:| gzip -c > %s" % gz, "ark,t:%s" % (tmp_path / "words.txt")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Done 3 utterances, failed for 0" in r.stderr
     # the same through the in-memory pipeline with the ORIGINAL model and a table built like the writer's
     g.tid2pdf = np.concatenate([[-1], np.stack([2 * np.arange(25) + 1, 2 * np.arange(25)], 1).reshape(-1)]).astype(np.int32)
-    ref = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, abi.decoder_config_recipe(), max_utts=3, max_seconds=2.5).decode(waves)
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, abi.decoder_config_recipe(), max_utts=3, max_seconds=2.5)
+    ref = pipe.decode(waves)
     got = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(tmp_path / "words.txt")}
     for i in range(3):
         assert got["utt%d" % i] == ref[i]["words"].tolist()
-    raw = open(tmp_path / "lat.ark", "rb").read()
+    import gzip
+    raw = gzip.open(gz).read()
     assert raw.startswith(b"utt0 ") and raw.count(b"compactlattice44") == 3
+    # features-rspecifier form: features dumped to an ark,scp pair (as compute-mfcc-feats would), raw lattices out
+    from kaldi_amd import table
+    with table.TableWriter("ark,scp:%s,%s" % (tmp_path / "feats.ark", tmp_path / "feats.scp"), "matrix") as w:
+        for i in range(3):
+            w.write("utt%d" % i, pipe.features(i))
+    r = subprocess.run(tool + ["--determinize-lattice=false", str(tmp_path / "final.mdl"), str(tmp_path / "HCLG.fst"),
+                               "scp:%s" % (tmp_path / "feats.scp"), "ark:%s" % (tmp_path / "raw.lat"),
+                               "ark,t:%s" % (tmp_path / "words2.txt"), "ark:%s" % (tmp_path / "ali.ark")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(tmp_path / "words2.txt").read() == open(tmp_path / "words.txt").read()
+    alis = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "ali.ark"), "int32"))
+    lats = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "raw.lat"), "lattice"))
+    for i in range(3):
+        assert alis["utt%d" % i].tolist() == ref[i]["best"]["alignment"].tolist()
+        start, final, arcs = lats["utt%d" % i]
+        assert arcs.size == ref[i]["lattice"].arcs.shape[0]
+    # bad usage is an error exit, like KALDI_ERR
+    r = subprocess.run(tool + ["--no-such-option=1", "a", "b", "c", "d"], capture_output=True, text=True)
+    assert r.returncode == 255 and "Invalid option" in r.stderr
 
 
 def test_more_pdfs_than_the_lds_row_holds():

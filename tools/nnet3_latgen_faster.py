@@ -1,94 +1,160 @@
-"""nnet3-latgen-faster (nnet3bin/nnet3-latgen-faster.cc) end to end on the device, files in / files out:
+"""nnet3-latgen-faster (nnet3bin/nnet3-latgen-faster.cc:37-270) on the device:
 
-    python tools/nnet3_latgen_faster.py [options] final.mdl HCLG.fst wav.scp lat.ark [words.ark]
+  nnet3_latgen_faster.py [options] <nnet-in> <fst-in> <features-rspecifier> <lattice-wspecifier>
+                         [<words-wspecifier> [<alignments-wspecifier>]]
+  e.g.  nnet3_latgen_faster.py --config=conf/decode.config --acoustic-scale=1.0 --frame-subsampling-factor=3 \\
+          --online-ivectors=scp:ivector_online.scp --online-ivector-period=10 \\
+          final.mdl HCLG.fst scp:feats.scp "ark:|gzip -c > lat.1.gz"
 
-  final.mdl   binary chain TDNN / TDNN-F model (kaldi_amd/mdl.py)
-  HCLG.fst    OpenFst vector / const FST
-  wav.scp     lines "utt-id /path/to/file.wav" (16-bit PCM RIFF; pipes are not supported)
-  lat.ark     CompactLattice archive (or Lattice with --determinize-lattice=0)
-Features are MFCC with the options of conf/mfcc_hires.conf, computed on the device.  Utterances
-are decoded --batch at a time, whole path in one pass per batch."""
-import argparse
+The reference's options, extended filenames and table specifiers are accepted as they are.  One
+addition: with --wav the third argument is a waveform rspecifier (scp:wav.scp, entries files or
+commands) and the MFCCs are computed on the device with the options of --mfcc-config (the
+options of compute-mfcc-feats; default conf/mfcc_hires.conf's values).  Utterances are decoded
+--batch at a time; every stage of a batch is one pass on the GPU."""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from kaldi_amd import abi, decoder, mdl, pipeline
+from kaldi_amd import abi, mdl, options, pipeline, table
 from kaldi_amd import io as kio
+from kaldi_amd._lib import KamdError, lib
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--beam", type=float, default=15.0)
-    ap.add_argument("--max-active", type=int, default=7000)
-    ap.add_argument("--min-active", type=int, default=200)
-    ap.add_argument("--lattice-beam", type=float, default=8.0)
-    ap.add_argument("--acoustic-scale", type=float, default=1.0)
-    ap.add_argument("--frame-subsampling-factor", type=int, default=3)
-    ap.add_argument("--frames-per-chunk", type=int, default=50)
-    ap.add_argument("--online-ivectors", default="", help="matrix archive, one entry per utterance")
-    ap.add_argument("--online-ivector-period", type=int, default=10)
-    ap.add_argument("--determinize-lattice", type=int, default=1)
-    ap.add_argument("--allow-partial", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--text", action="store_true")
-    ap.add_argument("model"), ap.add_argument("hclg"), ap.add_argument("wav_scp"), ap.add_argument("lattices")
-    ap.add_argument("words", nargs="?")
-    a = ap.parse_args()
-    model, id2pdf, tid_phone = mdl.read_mdl(a.model, a.acoustic_scale, a.frame_subsampling_factor)
-    cfg = abi.decoder_config_default()
-    cfg.beam, cfg.max_active, cfg.min_active, cfg.lattice_beam = a.beam, a.max_active, a.min_active, a.lattice_beam
-    g = kio.read_openfst(a.hclg)
+def main(argv):
+    po = table.ParseOptions(__doc__)
+    options.register_decoder(po)
+    options.register_nnet_simple(po)
+    po.register("word-symbol-table", str, "", "Symbol table for words [for debug output]")
+    po.register("allow-partial", bool, False, "If true, produce output even if end state was not reached.")
+    po.register("ivectors", str, "", "Rspecifier for iVectors as vectors (i.e. not estimated online); per utterance "
+                "by default, or per speaker if you provide the --utt2spk option.")
+    po.register("utt2spk", str, "", "Rspecifier for utt2spk option used to get ivectors per speaker")
+    po.register("online-ivectors", str, "", "Rspecifier for iVectors estimated online, as matrices.")
+    po.register("online-ivector-period", int, 0, "Number of frames between iVectors in matrices supplied to the "
+                "--online-ivectors option")
+    po.register("wav", bool, False, "The third argument is a waveform rspecifier; features are computed on the device")
+    po.register("mfcc-config", str, "", "Config file with compute-mfcc-feats options (only with --wav)")
+    po.register("batch", int, 64, "Utterances decoded per pass")
+    args = po.read(argv)
+    if not 4 <= len(args) <= 6:
+        po.print_usage()
+        return 1
+    model_in, fst_in, feat_rspec, lat_wspec = args[:4]
+    words_wspec = args[4] if len(args) > 4 else ""
+    ali_wspec = args[5] if len(args) > 5 else ""
+    if po["ivectors"]:
+        raise KamdError("--ivectors (one vector per utterance / speaker) needs a vector table reader, which is not built; "
+                        "use --online-ivectors")
+    if po["online-ivectors"] and po["online-ivector-period"] <= 0:
+        raise KamdError("--online-ivector-period must be set with --online-ivectors")       # nnet3-latgen-faster.cc:94-99
+    cfg = options.decoder_config(po)
+    mpo = table.ParseOptions("compute-mfcc-feats options")
+    options.register_mfcc(mpo)
+    if po["mfcc-config"]:
+        mpo.read_config_file(po["mfcc-config"])
+        mfcc = options.mfcc_opts(mpo)
+    else:
+        mfcc = abi.mfcc_opts_hires()
+    acwt = po["acoustic-scale"]
+    model, id2pdf, tid_phone = mdl.read_mdl(model_in, acwt, po["frame-subsampling-factor"])
+    with table.Input(fst_in) as (path, off):
+        if off:
+            raise KamdError("the decoding graph cannot be read from inside an archive: " + fst_in)
+        g = kio.read_openfst(path)
     g.tid2pdf, g.num_pdfs = id2pdf, model.num_pdfs
-    ivecs = dict(kio.read_matrix_ark(a.online_ivectors)) if a.online_ivectors else None
-    utts = [l.split(None, 1) for l in open(a.wav_scp) if l.strip()]
-    for p in (a.lattices, a.words):
-        if p and os.path.exists(p):
-            os.remove(p)
+    ivecs = table.RandomAccessTableReader(po["online-ivectors"], "matrix") if po["online-ivectors"] else None
+    lat_kind = "compact_lattice" if po["determinize-lattice"] else "lattice"
+    lat_w = table.TableWriter(lat_wspec, lat_kind, acoustic_scale=acwt)
+    words_w = table.TableWriter(words_wspec, "int32") if words_wspec else None
+    ali_w = table.TableWriter(ali_wspec, "int32") if ali_wspec else None
+    det = kio.determinize_opts_default()
+    det.delta, det.phone_determinize, det.word_determinize = po["delta"], int(po["phone-determinize"]), int(po["word-determinize"])
     n_done = n_fail = 0
-    tot_like, tot_frames, audio = 0.0, 0, 0.0
-    pipe = None
-    for b0 in range(0, len(utts), a.batch):
-        chunk = utts[b0:b0 + a.batch]
-        waves = []
-        for key, path in chunk:
-            sf, data = kio.read_wave(path.strip())
-            if sf != 16000.0:
-                raise SystemExit("%s: sampling rate %g, the hires MFCC config expects 16000" % (key, sf))
-            waves.append(data[0])
-            audio += data.shape[1] / sf
-        max_s = max(w.size for w in waves) / 16000.0 + 0.5
-        if pipe is None or max_s > pipe_max_s or len(waves) > pipe_n:
-            pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves), max_seconds=max_s)
-            pipe_max_s, pipe_n = max_s, len(waves)
-        pipe.load(waves)
+    tot_like, tot_frames = 0.0, 0
+    shift = mfcc.frame.frame_shift_ms * 1e-3
+    state = {"pipe": None, "max_s": 0.0, "n": 0}
+
+    def decode_batch(batch):
+        nonlocal n_done, n_fail, tot_like, tot_frames
+        keys = [k for k, _ in batch]
         if ivecs is not None:
-            pipe.set_online_ivectors([ivecs[k] for k, _ in chunk], a.online_ivector_period, a.frames_per_chunk)
+            missing = [k for k in keys if k not in ivecs]
+            for k in missing:
+                print("WARNING No iVectors available for utterance " + k, file=sys.stderr)     # nnet3-latgen-faster.cc:176-181
+            n_fail += len(missing)
+            batch = [(k, v) for k, v in batch if k not in missing]
+            keys = [k for k, _ in batch]
+        if not batch:
+            return
+        vals = [v for _, v in batch]
+        secs = max((v.size / mfcc.frame.samp_freq) if po["wav"] else v.shape[0] * shift for v in vals) + 0.5
+        if state["pipe"] is None or secs > state["max_s"] or len(vals) > state["n"]:
+            state["pipe"] = pipeline.Pipeline(mfcc, model, g, cfg, max_utts=max(len(vals), state["n"]),
+                                              max_seconds=max(secs, state["max_s"]))
+            state["max_s"], state["n"] = max(secs, state["max_s"]), max(len(vals), state["n"])
+        pipe = state["pipe"]
+        if po["wav"]:
+            pipe.load(vals)
+        else:
+            pipe.load_features(vals)
+        if ivecs is not None:
+            pipe.set_online_ivectors([ivecs[k] for k in keys], po["online-ivector-period"], po["frames-per-chunk"])
         pipe.run(auto_grow=4)
-        for (key, _), res in zip(chunk, pipe.results(lattices=True)):
-            bp = None if res is None else res["best"]
-            if bp is None or res["lattice"] is None:
-                print("WARNING Failed to decode utterance with id " + key, file=sys.stderr)
+        for key, res, lane in zip(keys, pipe.results(lattices=True), pipe._lane_of):
+            if res is None:
+                print("WARNING Zero-length utterance: " + key, file=sys.stderr)
                 n_fail += 1
                 continue
-            lat = res["lattice"]
-            if a.determinize_lattice:
-                kio.determinize_lattice(lat, cfg.lattice_beam, tid_phone).write(
-                    a.lattices, key, binary=not a.text, append=True, acoustic_scale=a.acoustic_scale)
+            bp, lat = res["best"], res["lattice"]
+            reached = bool(lib().kamd_decoder_reached_final(pipe.dec._dec, lane))
+            if bp is None or lat is None or (not reached and not po["allow-partial"]):
+                print("WARNING Not producing output for utterance %s since no final-state reached%s" %
+                      (key, "" if po["allow-partial"] else " and --allow-partial=false."), file=sys.stderr)
+                n_fail += 1
+                continue
+            if not reached:
+                print("WARNING Outputting partial output for utterance %s since no final-state reached" % key, file=sys.stderr)
+            if po["determinize-lattice"]:
+                lat_w.write(key, kio.determinize_lattice(lat, cfg.lattice_beam, tid_phone, det))
             else:
-                kio.write_lattice(a.lattices, key, lat, binary=not a.text, append=True, acoustic_scale=a.acoustic_scale)
-            if a.words:
-                with open(a.words, "a") as f:
-                    f.write(key + " " + " ".join(str(w) for w in bp["words"]) + " \n")
+                lat_w.write(key, lat)
+            if words_w:
+                words_w.write(key, bp["words"])
+            if ali_w:
+                ali_w.write(key, bp["alignment"])
             like = -(bp["graph_cost"] + bp["acoustic_cost"])
             nf = max(len(bp["alignment"]), 1)
             tot_like += like; tot_frames += nf; n_done += 1
             print("LOG Log-like per frame for utterance %s is %g over %d frames." % (key, like / nf, nf), file=sys.stderr)
-    print("LOG Done %d utterances, failed for %d (%.1f s of audio)" % (n_done, n_fail, audio), file=sys.stderr)
+
+    batch = []
+    for key, val in table.SequentialTableReader(feat_rspec, "wave" if po["wav"] else "matrix"):
+        if po["wav"]:
+            sf, data = val
+            if sf != mfcc.frame.samp_freq:
+                raise KamdError("%s: sampling rate %g, the feature config expects %g" % (key, sf, mfcc.frame.samp_freq))
+            val = data[0]
+        elif val.shape[0] == 0:
+            print("WARNING Zero-length utterance: " + key, file=sys.stderr)
+            n_fail += 1
+            continue
+        batch.append((key, val))
+        if len(batch) == po["batch"]:
+            decode_batch(batch)
+            batch = []
+    decode_batch(batch)
+    for w in (lat_w, words_w, ali_w):
+        if w:
+            w.close()
+    print("LOG Done %d utterances, failed for %d" % (n_done, n_fail), file=sys.stderr)
     print("LOG Overall log-likelihood per frame is %g over %d frames." % (tot_like / max(tot_frames, 1), tot_frames), file=sys.stderr)
     return 0 if n_done else 1
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    try:
+        sys.exit(main(sys.argv))
+    except KamdError as e:
+        print("ERROR " + str(e), file=sys.stderr)
+        sys.exit(255)
