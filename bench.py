@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--max-seconds", type=float, default=0.0)
     ap.add_argument("--hash-capacity", type=int, default=0, help="tokens of one frame per lane (power of two); "
                     "0 = derived from max-active")
+    ap.add_argument("--overlap", default="", help="output-frame indices (e.g. '48') at which the nnet stage is cut in "
+                    "time; each later slice's forward runs while the decoder lanes advance over the slice before it.  Same "
+                    "lattices, but measured SLOWER at batch 64 (DESIGN.md section 5), so off by default")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -210,16 +213,23 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # one unsliced pass first: the stage split and the GEMM rate without any overlap
+    plain_ms = pipe.run()
+    plain_flops = lib().kamd_nnet_last_flops(pipe.nnet._h)
+    log("unsliced pass: stage ms %s" % plain_ms)
+    bounds = [int(x) for x in args.overlap.split(",") if x.strip()]
+    pipe.set_overlap(bounds)
     for _ in range(args.warmup):
         ms = pipe.run()
         log("warmup step: stage ms %s" % ms)
     sync_all()
     t0 = time.time()
     stage = np.zeros(4)
-    adv_ms = []
+    adv_ms, launches = [], 1
     for _ in range(args.steps):
         stage += np.asarray(pipe.run())
         adv_ms.append(pipe.dec.last_advance_ms())
+        launches = lib().kamd_decoder_last_advance_launches(pipe.dec._dec)
     sync_all()
     dt = time.time() - t0
     log("timed steps done: %.3f s" % dt)
@@ -237,8 +247,10 @@ def main():
     if rank != 0:
         return
     counters = np.sum([pipe.dec.counters(u) for u in range(len(waves))], axis=0)
-    alg_bytes = float(algorithmic_bytes(counters))       # per launch (counters reset at init)
-    adv = float(np.mean(adv_ms))
+    # counters are reset at InitDecoding: per step = per batch, spread over `launches` AdvanceKernel
+    # launches when the nnet stage is sliced (every lane continues where it stopped)
+    alg_bytes = float(algorithmic_bytes(counters)) / launches
+    adv = float(np.mean(adv_ms)) / launches
     frames = int(counters[6])
     res = pipe.results(lattices=False)
     log("results fetched")
@@ -256,8 +268,11 @@ def main():
                                (args.workload, "tglarge" if g.num_states > 2e7 else "tgsmall", g.num_states,
                                 g.num_arcs, len(waves), audio),
                    "utterances_per_gpu": len(waves), "loglike_std_nats": args.ll_std},
-        "stage_ms": {"features": stage[0] / args.steps, "nnet": stage[1] / args.steps,
+        "stage_ms": {"features": stage[0] / args.steps, "nnet_before_search": stage[1] / args.steps,
                      "decode_advance": stage[2] / args.steps, "decode_finalize": stage[3] / args.steps},
+        "stage_ms_unsliced": {"features": plain_ms[0], "nnet": plain_ms[1], "decode_advance": plain_ms[2],
+                              "decode_finalize": plain_ms[3]},
+        "nnet_overlap": {"slice_bounds_output_frames": bounds, "advance_launches_per_step": launches},
         "decoder": {"frames": frames, "tokens_per_frame": counters[5] / max(frames, 1),
                     "expanded_per_frame": counters[0] / max(frames, 1),
                     "arcs_per_frame": counters[1] / max(frames, 1),
@@ -266,9 +281,9 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "kamd::AdvanceKernel",
                      "achieved": alg_bytes / (adv * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg_bytes / (adv * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
-                     "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": adv},
+                     "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": adv, "launches_per_step": launches},
         "phase_share_longest_lane": phase_share(pipe, waves),
-        "nnet_tflops": lib().kamd_nnet_last_flops(pipe.nnet._h) / (stage[1] / args.steps * 1e-3) / 1e12,
+        "nnet_tflops": plain_flops / (plain_ms[1] * 1e-3) / 1e12,
         "setup_s": t_build,
     }
     if not args.no_cpu_baseline and world == 1:

@@ -531,9 +531,11 @@ int kamd_decoder_get_counters(kamd_decoder *d, int lane, int64_t counters[8]);
  * [6] token compaction, [7] link fix-up, [8] epsilon links, [9] table clear + bookkeeping,
  * [10] finalize backward sweep, [11] finalize compaction. */
 int kamd_decoder_get_phase_cycles(kamd_decoder *d, int lane, uint64_t cycles[16]);
-/* device time (ms) of the last advance launch, measured with HIP events on the
- * stream the kernel ran on (for bench.py's roofline). */
+/* device time (ms) of the AdvanceKernel launches since the last kamd_decoder_init (summed; at most
+ * the last 8), measured with HIP events on the stream the kernel ran on (for bench.py's roofline),
+ * and how many launches that was.  Valid after kamd_decoder_sync. */
 float kamd_decoder_last_advance_ms(kamd_decoder *d);
+int kamd_decoder_last_advance_launches(kamd_decoder *d);
 
 /* -------------------------------------------------------------- pipeline -- */
 /* wav -> features -> nnet -> decode for a batch of utterances, everything
@@ -562,6 +564,14 @@ int kamd_pipeline_set_ivectors(kamd_pipeline *p, const float *ivectors, int dim)
  * runs chunk by chunk (kamd_nnet_forward_chunked_device).  dim <= 0 switches it off. */
 int kamd_pipeline_set_online_ivectors(kamd_pipeline *p, const float *ivectors, const int64_t *h_row_off, int dim,
                                       int ivector_period, int frames_per_chunk);
+/* Overlap of the nnet stage with the search inside one kamd_pipeline_run: the batch's output frames
+ * are cut in time at n_bounds boundaries (output-frame indices, increasing); the log-likelihoods of
+ * slice k+1 are computed on a second stream while the decoder lanes advance over slice k (the 64
+ * lanes of the headline batch leave 192 CUs idle).  Lattices are identical to the unsliced run:
+ * a frame's log-likelihood row does not depend on the slice it was computed in, and AdvanceDecoding
+ * in pieces is AdvanceDecoding.  n_bounds = 0 (the default) turns it off.  Ignored (one slice) when
+ * ivectors are set. */
+int kamd_pipeline_set_overlap(kamd_pipeline *p, const int32_t *bounds, int n_bounds);
 /* Run the hot path over the resident batch: lanes 0..n_utts-1 hold the results.
  * Blocking; returns 0 or error.  stage_ms[3] = {features, nnet, decode(advance+
  * finalize)} device times from HIP events. */

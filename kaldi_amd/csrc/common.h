@@ -19,6 +19,9 @@ std::string &LastError();
 int SetError(int code, const char *fmt, ...);
 // true iff a HIP device is usable; otherwise sets the error (no CPU fallback exists).
 bool RequireDevice();
+// rows [src_row[i], +count[i]) of src -> rows [dst_row[i], ...) of dst (descriptors on the device); nnet.hip
+int CopyRowBlocks(const float *src, int ld_src, float *dst, int ld_dst, const int64_t *d_src_row, const int64_t *d_dst_row,
+                  const int *d_count, int n_items, int max_count, int cols, hipStream_t st);
 
 #define KAMD_HIP(call)                                                              \
   do {                                                                              \

@@ -2027,8 +2027,11 @@ struct Decoder {
   kamd_decoder_sizes sizes;
   std::vector<void *> allocs;
   std::vector<LaneState> h_st;
-  hipEvent_t ev0 = NULL, ev1 = NULL;
-  bool timed = false;
+  // HIP-event pairs around the AdvanceKernel launches since the last kamd_decoder_init (a batch may be
+  // advanced in several launches: the pipeline overlaps the later nnet slices with the first ones)
+  static constexpr int kMaxTimed = 8;
+  hipEvent_t ev[2 * kMaxTimed] = {};
+  int n_timed = 0;
   float last_ms = 0;
   int *d_lanes = NULL; kamd_decode_task *d_tasks = NULL; int tasks_cap = 0;
   long long *d_tok_base = NULL, *d_lnk_base = NULL; int *d_tok_cap = NULL, *d_lnk_cap = NULL;
@@ -2233,7 +2236,7 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, d.lds_table_cap))) != hipSuccess)
     ok = false;
-  if (ok && (hipEventCreate(&D->ev0) != hipSuccess || hipEventCreate(&D->ev1) != hipSuccess)) ok = false;
+  for (int i = 0; ok && i < 2 * Decoder::kMaxTimed; i++) if (hipEventCreate(&D->ev[i]) != hipSuccess) ok = false;
   if (!ok) {
     kamd::SetError(KAMD_ERR_HIP, "decoder allocation failed (%zu lanes): %s", L, hipGetErrorString(hipGetLastError()));
     kamd_decoder_destroy(reinterpret_cast<kamd_decoder *>(D));
@@ -2249,8 +2252,7 @@ void kamd_decoder_destroy(kamd_decoder *h) {
   for (size_t i = 0; i < D->allocs.size(); i++) (void)hipFree(D->allocs[i]);
   if (D->d_lanes) (void)hipFree(D->d_lanes);
   if (D->d_tasks) (void)hipFree(D->d_tasks);
-  if (D->ev0) (void)hipEventDestroy(D->ev0);
-  if (D->ev1) (void)hipEventDestroy(D->ev1);
+  for (int i = 0; i < 2 * Decoder::kMaxTimed; i++) if (D->ev[i]) (void)hipEventDestroy(D->ev[i]);
   delete D;
 }
 
@@ -2314,7 +2316,7 @@ int kamd_decoder_init(kamd_decoder *h, const int32_t *lanes, int n, void *stream
   KAMD_HIP(hipStreamSynchronize(st));
   hipLaunchKernelGGL(kamd::InitKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes);
   KAMD_HIP(hipGetLastError());
-  D->last_stream = st; D->cached_lane = -1;
+  D->last_stream = st; D->cached_lane = -1; D->n_timed = 0;
   return KAMD_OK;
 }
 
@@ -2332,12 +2334,13 @@ int kamd_decoder_advance(kamd_decoder *h, const kamd_decode_task *tasks, int n, 
                    [](const kamd_decode_task &a, const kamd_decode_task &b) { return a.n_frames > b.n_frames; });
   KAMD_HIP(hipMemcpyAsync(D->d_tasks, sorted.data(), n * sizeof(kamd_decode_task), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
-  KAMD_HIP(hipEventRecord(D->ev0, st));
+  const int slot = D->n_timed < Decoder::kMaxTimed ? D->n_timed : Decoder::kMaxTimed - 1;   // streaming: the last pair is reused
+  KAMD_HIP(hipEventRecord(D->ev[2 * slot], st));
   const size_t lds = kamd::AdvanceLdsBytes(D->dev.num_pdfs_lds, D->dev.lds_table_cap);
   hipLaunchKernelGGL(kamd::AdvanceKernel, dim3(n), dim3(NT), lds, st, D->dev, D->d_tasks);
   KAMD_HIP(hipGetLastError());
-  KAMD_HIP(hipEventRecord(D->ev1, st));
-  D->timed = true; D->last_stream = st; D->cached_lane = -1;
+  KAMD_HIP(hipEventRecord(D->ev[2 * slot + 1], st));
+  D->n_timed = slot + 1; D->last_stream = st; D->cached_lane = -1;
   return KAMD_OK;
 }
 
@@ -2360,9 +2363,13 @@ int kamd_decoder_finalize(kamd_decoder *h, const int32_t *lanes, int n, void *st
 int kamd_decoder_sync(kamd_decoder *h) {
   Decoder *D = reinterpret_cast<Decoder *>(h);
   KAMD_HIP(hipStreamSynchronize(D->last_stream));
-  if (D->timed) {
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, D->ev0, D->ev1) == hipSuccess) D->last_ms = ms;
+  if (D->n_timed > 0) {
+    float sum = 0;
+    for (int i = 0; i < D->n_timed; i++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, D->ev[2 * i], D->ev[2 * i + 1]) == hipSuccess) sum += ms;
+    }
+    D->last_ms = sum;
   }
   KAMD_HIP(hipMemcpy(D->h_st.data(), D->dev.st, D->h_st.size() * sizeof(kamd::LaneState), hipMemcpyDeviceToHost));
   for (size_t l = 0; l < D->h_st.size(); l++) {
@@ -2378,6 +2385,7 @@ int kamd_decoder_sync(kamd_decoder *h) {
 }
 
 float kamd_decoder_last_advance_ms(kamd_decoder *h) { return reinterpret_cast<Decoder *>(h)->last_ms; }
+int kamd_decoder_last_advance_launches(kamd_decoder *h) { return reinterpret_cast<Decoder *>(h)->n_timed; }
 
 static int LaneOk(Decoder *D, int lane) {
   if (lane < 0 || lane >= D->sizes.max_lanes) return kamd::SetError(KAMD_ERR_ARG, "lane %d out of range", lane);

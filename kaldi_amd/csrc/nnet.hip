@@ -577,6 +577,14 @@ __global__ void CopyRowBlocksKernel(const float *src, int ld_src, float *dst, in
     for (int c = threadIdx.x; c < cols; c += blockDim.x)
       dst[(dst_row[item] + r) * ld_dst + c] = src[(src_row[item] + r) * ld_src + c];
 }
+int CopyRowBlocks(const float *src, int ld_src, float *dst, int ld_dst, const int64_t *d_src_row, const int64_t *d_dst_row,
+                  const int *d_count, int n_items, int max_count, int cols, hipStream_t st) {
+  if (n_items <= 0) return KAMD_OK;
+  hipLaunchKernelGGL(CopyRowBlocksKernel, dim3(std::max(1, std::min(max_count, 64)), n_items), dim3(256), 0, st, src, ld_src, dst, ld_dst,
+                     d_src_row, d_dst_row, d_count, cols);
+  KAMD_HIP(hipGetLastError());
+  return KAMD_OK;
+}
 }  // namespace kamd
 extern "C" {
 

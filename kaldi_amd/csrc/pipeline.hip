@@ -23,6 +23,12 @@ struct Pipeline {
   // online ivectors (one row per ivector_period frames) instead of one ivector per utterance
   float *d_oiv = NULL; size_t oiv_cap = 0; std::vector<int64_t> oiv_off; int oiv_period = 0, frames_per_chunk = 50;
   hipEvent_t ev[5];
+  // nnet / search overlap (kamd_pipeline_set_overlap)
+  std::vector<int32_t> bounds;
+  hipStream_t s_nnet = NULL, s_dec = NULL;
+  std::vector<hipEvent_t> slice_done;
+  float *d_tmp = NULL; size_t tmp_cap = 0;
+  int64_t *d_desc = NULL; size_t desc_cap = 0;
 };
 template <typename T>
 static int GrowBuf(T **p, size_t *cap, size_t need) {
@@ -58,6 +64,11 @@ void kamd_pipeline_destroy(kamd_pipeline *h) {
   if (p->d_iv) (void)hipFree(p->d_iv);
   if (p->d_oiv) (void)hipFree(p->d_oiv);
   for (int i = 0; i < 5; i++) (void)hipEventDestroy(p->ev[i]);
+  for (hipEvent_t e : p->slice_done) (void)hipEventDestroy(e);
+  if (p->s_nnet) (void)hipStreamDestroy(p->s_nnet);
+  if (p->s_dec) (void)hipStreamDestroy(p->s_dec);
+  if (p->d_tmp) (void)hipFree(p->d_tmp);
+  if (p->d_desc) (void)hipFree(p->d_desc);
   delete p;
 }
 
@@ -135,10 +146,117 @@ int kamd_pipeline_set_online_ivectors(kamd_pipeline *h, const float *ivectors, c
   return KAMD_OK;
 }
 
+int kamd_pipeline_set_overlap(kamd_pipeline *h, const int32_t *bounds, int n_bounds) {
+  Pipeline *p = reinterpret_cast<Pipeline *>(h);
+  if (n_bounds < 0 || n_bounds > 6) return kamd::SetError(KAMD_ERR_ARG, "0 .. 6 slice boundaries");
+  for (int i = 0; i < n_bounds; i++)
+    if (bounds[i] <= (i ? bounds[i - 1] : 0)) return kamd::SetError(KAMD_ERR_ARG, "slice boundaries must be positive and increasing");
+  p->bounds.assign(bounds, bounds + n_bounds);
+  if (n_bounds > 0 && !p->s_nnet) {
+    KAMD_HIP(hipStreamCreateWithFlags(&p->s_nnet, hipStreamNonBlocking));
+    KAMD_HIP(hipStreamCreateWithFlags(&p->s_dec, hipStreamNonBlocking));
+  }
+  while (static_cast<int>(p->slice_done.size()) < n_bounds + 1) {
+    hipEvent_t e;
+    KAMD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    p->slice_done.push_back(e);
+  }
+  return KAMD_OK;
+}
+
+// kamd_pipeline_run with the nnet stage cut in time (kamd_pipeline_set_overlap).  Stream s_nnet:
+// features, then per slice one batched forward over (utterance, output-frame range) items -- each
+// with the left / right context it needs, clamped only at the utterance's own edges, computed into
+// a scratch matrix -- and a row copy of the frames the slice owns into the log-likelihood matrix.
+// Stream s_dec: InitDecoding, then per slice "wait for the slice, AdvanceDecoding over its frames".
+// stage_ms: [0] features, [1] the first slice's forward (all the search waits for), [2] first
+// AdvanceKernel launch .. last one's end (the later forwards run inside it), [3] finalize.
+static int RunOverlapped(Pipeline *p, float stage_ms[4]) {
+  const int n = p->n_utts, sub = kamd_nnet_frame_subsampling_factor(p->nnet);
+  const int Lc = kamd_nnet_left_context(p->nnet), Rc = kamd_nnet_right_context(p->nnet);
+  const int kctx = (Lc + sub - 1) / sub;
+  hipStream_t s1 = p->s_nnet, s2 = p->s_dec;
+  std::vector<int32_t> lanes(n), fr(n);
+  for (int u = 0; u < n; u++) { lanes[u] = u; fr[u] = static_cast<int>(p->out_off[u + 1] - p->out_off[u]); }
+  int rc = kamd_decoder_reserve(p->dec, fr.data(), n);
+  if (rc != KAMD_OK) return rc;
+  KAMD_HIP(hipEventRecord(p->ev[0], s1));
+  if (!p->have_feats)
+    rc = kamd_feat_compute_batch_device(p->feat, p->d_waves, p->wave_off.data(), n, p->d_feats, p->feat_off.data(), p->ld_feat, s1);
+  if (rc != KAMD_OK) return rc;
+  KAMD_HIP(hipEventRecord(p->ev[1], s1));
+  rc = kamd_decoder_init(p->dec, lanes.data(), n, s2);
+  if (rc != KAMD_OK) return rc;
+  const int n_slices = static_cast<int>(p->bounds.size()) + 1;
+  // scratch: the largest slice's items (rows incl. context) x P
+  for (int s = 0; s < n_slices; s++) {
+    const int b0 = s ? p->bounds[s - 1] : 0, b1 = s < n_slices - 1 ? p->bounds[s] : 2147483647;
+    std::vector<int64_t> in_start, tmp_off, src_row, dst_row;
+    std::vector<int32_t> in_len, cnt;
+    std::vector<kamd_decode_task> tasks;
+    int64_t tmp_rows = 0;
+    int max_cnt = 1;
+    for (int u = 0; u < n; u++) {
+      const int T = static_cast<int>(p->feat_off[u + 1] - p->feat_off[u]), n_out = fr[u];
+      if (n_out <= b0) continue;
+      const int o1 = std::min(n_out, b1), num = o1 - b0;
+      const int k0 = std::min(b0, kctx);
+      const int in_first = sub * (b0 - k0), in_last = std::min(T - 1, (o1 - 1) * sub + Rc);
+      in_start.push_back(p->feat_off[u] + in_first); in_len.push_back(in_last - in_first + 1);
+      tmp_off.push_back(tmp_rows);
+      src_row.push_back(tmp_rows + k0); dst_row.push_back(p->out_off[u] + b0); cnt.push_back(num);
+      tmp_rows += (in_last - in_first + 1 + sub - 1) / sub;
+      max_cnt = std::max(max_cnt, num);
+      kamd_decode_task t;
+      t.lane = u; t.n_frames = num; t.d_loglikes = p->d_ll + static_cast<size_t>(p->out_off[u] + b0) * p->P; t.ld = p->P; t.reserved = 0;
+      tasks.push_back(t);
+    }
+    const int n_items = static_cast<int>(in_start.size());
+    if (n_items == 0) break;
+    if (kamd::GrowBuf(&p->d_tmp, &p->tmp_cap, static_cast<size_t>(tmp_rows) * p->P) != KAMD_OK) return KAMD_ERR_HIP;
+    if (kamd::GrowBuf(&p->d_desc, &p->desc_cap, static_cast<size_t>(n_slices) * (3 * n + 8)) != KAMD_OK) return KAMD_ERR_HIP;
+    // a slice's descriptors live in their own part of d_desc: the copy kernel of slice s may
+    // still be queued when the host writes those of slice s + 1
+    int64_t *d_src = p->d_desc + static_cast<size_t>(s) * (3 * n + 8), *d_dst = d_src + n;
+    int *d_cnt = reinterpret_cast<int *>(d_dst + n);
+    // the scratch matrix is reused by the next slice's forward: stream order on s1 (forward s,
+    // copy s, forward s + 1) keeps that safe
+    rc = kamd_nnet_forward_slices_device(p->nnet, p->d_feats, in_start.data(), in_len.data(), p->ld_feat, NULL, n_items, p->d_tmp,
+                                         tmp_off.data(), p->P, s1);
+    if (rc != KAMD_OK) return rc;
+    KAMD_HIP(hipMemcpyAsync(d_src, src_row.data(), n_items * 8, hipMemcpyHostToDevice, s1));
+    KAMD_HIP(hipMemcpyAsync(d_dst, dst_row.data(), n_items * 8, hipMemcpyHostToDevice, s1));
+    KAMD_HIP(hipMemcpyAsync(d_cnt, cnt.data(), n_items * 4, hipMemcpyHostToDevice, s1));
+    rc = kamd::CopyRowBlocks(p->d_tmp, p->P, p->d_ll, p->P, d_src, d_dst, d_cnt, n_items, max_cnt, p->P, s1);
+    if (rc != KAMD_OK) return rc;
+    KAMD_HIP(hipEventRecord(p->slice_done[s], s1));
+    if (s == 0) KAMD_HIP(hipEventRecord(p->ev[2], s1));
+    KAMD_HIP(hipStreamSynchronize(s1));   // the descriptor vectors above are pageable host memory; the search needs the slice anyway
+    KAMD_HIP(hipStreamWaitEvent(s2, p->slice_done[s], 0));
+    rc = kamd_decoder_advance(p->dec, tasks.data(), static_cast<int>(tasks.size()), s2);
+    if (rc != KAMD_OK) return rc;
+  }
+  KAMD_HIP(hipEventRecord(p->ev[3], s2));
+  rc = kamd_decoder_finalize(p->dec, lanes.data(), n, s2);
+  if (rc != KAMD_OK) return rc;
+  KAMD_HIP(hipEventRecord(p->ev[4], s2));
+  rc = kamd_decoder_sync(p->dec);
+  KAMD_HIP(hipStreamSynchronize(s1));
+  if (stage_ms) {
+    for (int i = 0; i < 4; i++) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, p->ev[i], p->ev[i + 1]);
+      stage_ms[i] = ms;
+    }
+  }
+  return rc;
+}
+
 int kamd_pipeline_run(kamd_pipeline *h, float stage_ms[4]) {
   Pipeline *p = reinterpret_cast<Pipeline *>(h);
   const int n = p->n_utts;
   if (n <= 0) return kamd::SetError(KAMD_ERR_STATE, "no batch loaded");
+  if (!p->bounds.empty() && p->iv_dim == 0 && p->oiv_period == 0) return RunOverlapped(p, stage_ms);
   hipStream_t st = NULL;
   KAMD_HIP(hipEventRecord(p->ev[0], st));
   int rc = KAMD_OK;

@@ -124,6 +124,13 @@ class Pipeline:
                                                       ivector_period, frames_per_chunk))
         self._iv_loaded = ("online", iv, off, ivector_period, frames_per_chunk)
 
+    def set_overlap(self, bounds):
+        """Cuts the nnet stage in time at these output-frame indices and overlaps every later slice's
+        forward with the search over the slice before it (kamd_pipeline_set_overlap); [] = off."""
+        b = np.ascontiguousarray(bounds, np.int32)
+        check(lib().kamd_pipeline_set_overlap(self._h, abi.iptr(b) if b.size else None, int(b.size)))
+        self._overlap = b.tolist()
+
     def grow(self, factor=2):
         """Rebuilds the decoder with `factor` x the frame table and arenas and reloads the batch
         (the reference's HashList and token lists simply grow; here a lane that overflows reports
@@ -143,6 +150,8 @@ class Pipeline:
                 check(lib().kamd_pipeline_load_batch(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), n))
             else:
                 check(lib().kamd_pipeline_load_features(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), n, flat.shape[1]))
+            if getattr(self, "_overlap", None):
+                self.set_overlap(self._overlap)
             iv = getattr(self, "_iv_loaded", None)
             if iv is not None and iv[0] == "utt":
                 check(lib().kamd_pipeline_set_ivectors(self._h, abi.fptr(iv[1]), iv[1].shape[1]))

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from kaldi_amd import abi, decoder, synth
+from kaldi_amd._lib import lib
 from oracle import orc
 from tests.util import lattice_diff, lattices_equal
 
@@ -427,3 +428,30 @@ def test_pipeline_ragged_batch_with_empty_and_tiny_utterances():
         o.Decode(pipe.loglikes(lane))
         assert lattices_equal(res2[u]["lattice"], o.GetRawLattice())
     assert pipe.decode([np.zeros(10, np.float32)]) == [None]
+
+
+@pytest.mark.parametrize("bounds", [[5], [7, 30], [3, 4, 60, 1000]])
+def test_pipeline_overlapped_nnet_slices_give_the_same_lattices(bounds):
+    """kamd_pipeline_set_overlap: the nnet stage cut in time and overlapped with the search.  Same
+    log-likelihood rows (bit-equal), same lattices, whatever the boundaries (inside the model's
+    context, past the end of short utterances, past the end of all)."""
+    from kaldi_amd import nnet, pipeline
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=3.0)
+    cfg = abi.decoder_config_recipe()
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, cfg, max_utts=6, max_seconds=4.0)
+    waves = [synth.make_wave(d, seed=10 + i) for i, d in enumerate((3.1, 0.2, 1.0, 0.025, 2.4, 0.6))]
+    want = pipe.decode(waves)
+    want_ll = [pipe.loglikes(u).copy() for u in range(len(waves))]
+    pipe.set_overlap(bounds)
+    got = pipe.decode(waves)
+    for u in range(len(waves)):
+        np.testing.assert_array_equal(pipe.loglikes(u), want_ll[u])
+        assert lattices_equal(got[u]["lattice"], want[u]["lattice"]), (u, lattice_diff(got[u]["lattice"], want[u]["lattice"]))
+        assert got[u]["words"].tolist() == want[u]["words"].tolist()
+    assert lib().kamd_decoder_last_advance_launches(pipe.dec._dec) == min(len(bounds) + 1, 1 + sum(b < want_ll[0].shape[0] for b in bounds))
+    assert all(x >= 0 for x in pipe.last_stage_ms)
+    pipe.set_overlap([])
+    again = pipe.decode(waves)
+    assert lattices_equal(again[0]["lattice"], want[0]["lattice"])
+    assert lib().kamd_decoder_last_advance_launches(pipe.dec._dec) == 1
