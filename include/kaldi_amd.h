@@ -401,6 +401,56 @@ int kamd_ark_write_matrix(const char *path, int append, const char *key, int bin
 int kamd_ark_read_int32_vector(const char *path, int64_t *offset, char *key, int key_cap, int32_t *n,
                                int32_t **data);
 
+/* --------------------------------------------------- online i-vector extraction -- */
+/* OnlineIvectorFeature as ivector-extract-online2 drives it (online2/online-ivector-feature.cc:
+ * 150-420, online2bin/ivector-extract-online2.cc:95-175; use_most_recent_ivector = false, no frame
+ * weights, a fresh adaptation state per utterance): base features -> OnlineCmvn (sliding window
+ * smoothed with the global stats) -> splice -> LDA for the UBM posteriors; splice -> LDA of the
+ * raw features for the statistics; diagonal-UBM log-likelihoods -> VectorToPosteriorEntry
+ * (hmm/posterior.cc:440-508) scaled by posterior_scale; OnlineIvectorEstimationStats::AccStats
+ * (ivector/ivector-extractor.cc:611-668); every ivector_period frames num_cg_iters steps of
+ * LinearCgd (matrix/optimization.cc:453-557) from the previous estimate.  Row i of the result is
+ * the estimate after frames 0 .. i * ivector_period, minus the prior offset in dimension 0: what
+ * nnet3-latgen-faster takes as --online-ivectors. */
+typedef struct kamd_ivector_extractor kamd_ivector_extractor;
+typedef struct kamd_ivector_desc {
+  int32_t feat_dim;                 /* base features (e.g. 40 hires MFCCs) */
+  int32_t splice_left, splice_right;/* OnlineSpliceOptions (feat/online-feature.h:446-456) */
+  int32_t lda_rows, lda_cols;       /* final.mat: cols = feat_dim*(left+1+right) [+1: offset column] */
+  const float *lda;                 /* [lda_rows x lda_cols] row-major */
+  const double *global_cmvn_stats;  /* [2 x (feat_dim+1)]: sums, counts; row 1 = sums of squares */
+  int32_t cmn_window, speaker_frames, global_frames;   /* OnlineCmvnOptions (feat/online-feature.h:200-230) */
+  int32_t normalize_mean, normalize_variance;          /* variance normalisation is not supported */
+  int32_t num_gauss;                /* diagonal UBM over the lda_rows-dimensional features (final.dubm) */
+  const float *ubm_gconsts;         /* [num_gauss] */
+  const float *ubm_means_invvars;   /* [num_gauss x lda_rows] */
+  const float *ubm_inv_vars;        /* [num_gauss x lda_rows] */
+  int32_t ivector_dim;              /* <= 128 */
+  const double *M;                  /* IvectorExtractor::M_: [num_gauss][lda_rows][ivector_dim] */
+  const double *sigma_inv;          /* Sigma_inv_: [num_gauss][lda_rows*(lda_rows+1)/2] packed lower triangle */
+  double prior_offset;
+  int32_t ivector_period, num_gselect, num_cg_iters;   /* 10, 5, 15 */
+  float min_post, posterior_scale, max_count;          /* 0.025, 0.1, 0 */
+} kamd_ivector_desc;
+kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *desc);
+void kamd_ivector_extractor_destroy(kamd_ivector_extractor *e);
+int kamd_ivector_dim(const kamd_ivector_extractor *e);
+int kamd_ivector_period(const kamd_ivector_extractor *e);
+/* rows of the result for an utterance of num_frames frames: ceil(num_frames / period) */
+int kamd_ivector_num_ivectors(const kamd_ivector_extractor *e, int num_frames);
+/* Batch form: utterance u owns rows [h_row_off[u], h_row_off[u+1]) of the device feature matrix
+ * (leading dimension ld_feat >= feat_dim) and rows [h_out_row_off[u], ...) of d_out
+ * [rows x ivector_dim]. */
+int kamd_ivector_extract_online_device(kamd_ivector_extractor *e, const float *d_feats, const int64_t *h_row_off,
+                                       int ld_feat, int n_utts, float *d_out, const int64_t *h_out_row_off,
+                                       void *stream);
+/* one utterance, host in / host out; returns the number of rows written or < 0 */
+int kamd_ivector_extract_online(kamd_ivector_extractor *e, const float *feats, int num_frames, float *out,
+                                int out_rows_cap);
+/* diagnostic: the per-frame posteriors of the last batch (frame-major, num_gselect slots per frame,
+ * gaussian -1 = empty slot) */
+int kamd_ivector_last_posteriors(kamd_ivector_extractor *e, int32_t *gauss, float *weight, int64_t frames_cap);
+
 /* ------------------------------------- extended filenames and table specifiers -- */
 /* ClassifyRxfilename / ClassifyWxfilename (util/kaldi-io.cc:85-186); values follow the
  * reference's InputType / OutputType enums (util/kaldi-io.h:89-111). */
@@ -572,6 +622,10 @@ int kamd_pipeline_set_online_ivectors(kamd_pipeline *p, const float *ivectors, c
  * in pieces is AdvanceDecoding.  n_bounds = 0 (the default) turns it off.  Ignored (one slice) when
  * ivectors are set. */
 int kamd_pipeline_set_overlap(kamd_pipeline *p, const int32_t *bounds, int n_bounds);
+/* i-vectors estimated on the device from the batch's own features (instead of
+ * kamd_pipeline_set_online_ivectors): run() then does features -> i-vectors -> chunked nnet
+ * (frames_per_chunk as in DecodableNnetSimple) -> search.  e = NULL turns it off. */
+int kamd_pipeline_set_ivector_extractor(kamd_pipeline *p, kamd_ivector_extractor *e, int frames_per_chunk);
 /* Run the hot path over the resident batch: lanes 0..n_utts-1 hold the results.
  * Blocking; returns 0 or error.  stage_ms[3] = {features, nnet, decode(advance+
  * finalize)} device times from HIP events. */

@@ -134,6 +134,21 @@ class LatticeSize(C.Structure):
                 ("num_frames", C.c_int32), ("start", C.c_int32)]
 
 
+class IvectorDesc(C.Structure):
+    """kamd_ivector_desc (include/kaldi_amd.h)."""
+    _fields_ = [("feat_dim", C.c_int32), ("splice_left", C.c_int32), ("splice_right", C.c_int32),
+                ("lda_rows", C.c_int32), ("lda_cols", C.c_int32), ("lda", C.POINTER(C.c_float)),
+                ("global_cmvn_stats", C.POINTER(C.c_double)),
+                ("cmn_window", C.c_int32), ("speaker_frames", C.c_int32), ("global_frames", C.c_int32),
+                ("normalize_mean", C.c_int32), ("normalize_variance", C.c_int32),
+                ("num_gauss", C.c_int32), ("ubm_gconsts", C.POINTER(C.c_float)),
+                ("ubm_means_invvars", C.POINTER(C.c_float)), ("ubm_inv_vars", C.POINTER(C.c_float)),
+                ("ivector_dim", C.c_int32), ("M", C.POINTER(C.c_double)), ("sigma_inv", C.POINTER(C.c_double)),
+                ("prior_offset", C.c_double),
+                ("ivector_period", C.c_int32), ("num_gselect", C.c_int32), ("num_cg_iters", C.c_int32),
+                ("min_post", C.c_float), ("posterior_scale", C.c_float), ("max_count", C.c_float)]
+
+
 class DeterminizeOpts(C.Structure):
     _fields_ = [("delta", C.c_float), ("max_mem", C.c_int32), ("phone_determinize", C.c_int32),
                 ("word_determinize", C.c_int32), ("max_loop", C.c_int32), ("retry_cutoff", C.c_float)]

@@ -19,6 +19,7 @@ struct Pipeline {
   float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL, *d_iv = NULL;
   size_t waves_cap = 0, feats_cap = 0, ll_cap = 0, iv_cap = 0;
   int iv_dim = 0;
+  kamd_ivector_extractor *iv_extractor = NULL;   // i-vectors estimated from the batch's own features
   bool have_feats = false;      // features were handed in (kamd_pipeline_load_features): skip the feature stage
   // online ivectors (one row per ivector_period frames) instead of one ivector per utterance
   float *d_oiv = NULL; size_t oiv_cap = 0; std::vector<int64_t> oiv_off; int oiv_period = 0, frames_per_chunk = 50;
@@ -146,6 +147,14 @@ int kamd_pipeline_set_online_ivectors(kamd_pipeline *h, const float *ivectors, c
   return KAMD_OK;
 }
 
+int kamd_pipeline_set_ivector_extractor(kamd_pipeline *h, kamd_ivector_extractor *e, int frames_per_chunk) {
+  Pipeline *p = reinterpret_cast<Pipeline *>(h);
+  if (!e) { p->iv_extractor = NULL; p->oiv_period = 0; p->iv_dim = 0; p->oiv_off.clear(); return KAMD_OK; }
+  if (frames_per_chunk <= 0) return kamd::SetError(KAMD_ERR_ARG, "bad frames per chunk");
+  p->iv_extractor = e; p->frames_per_chunk = frames_per_chunk;
+  return KAMD_OK;
+}
+
 int kamd_pipeline_set_overlap(kamd_pipeline *h, const int32_t *bounds, int n_bounds) {
   Pipeline *p = reinterpret_cast<Pipeline *>(h);
   if (n_bounds < 0 || n_bounds > 6) return kamd::SetError(KAMD_ERR_ARG, "0 .. 6 slice boundaries");
@@ -256,7 +265,7 @@ int kamd_pipeline_run(kamd_pipeline *h, float stage_ms[4]) {
   Pipeline *p = reinterpret_cast<Pipeline *>(h);
   const int n = p->n_utts;
   if (n <= 0) return kamd::SetError(KAMD_ERR_STATE, "no batch loaded");
-  if (!p->bounds.empty() && p->iv_dim == 0 && p->oiv_period == 0) return RunOverlapped(p, stage_ms);
+  if (!p->bounds.empty() && p->iv_dim == 0 && p->oiv_period == 0 && !p->iv_extractor) return RunOverlapped(p, stage_ms);
   hipStream_t st = NULL;
   KAMD_HIP(hipEventRecord(p->ev[0], st));
   int rc = KAMD_OK;
@@ -264,6 +273,17 @@ int kamd_pipeline_run(kamd_pipeline *h, float stage_ms[4]) {
     rc = kamd_feat_compute_batch_device(p->feat, p->d_waves, p->wave_off.data(), n, p->d_feats,
                                         p->feat_off.data(), p->ld_feat, st);
   if (rc != KAMD_OK) return rc;
+  if (p->iv_extractor) {
+    // OnlineIvectorFeature on the features just computed, straight into the matrix the chunked
+    // forward reads its per-chunk i-vectors from (counted with the feature stage)
+    p->oiv_off.assign(n + 1, 0);
+    for (int u = 0; u < n; u++)
+      p->oiv_off[u + 1] = p->oiv_off[u] + kamd_ivector_num_ivectors(p->iv_extractor, static_cast<int>(p->feat_off[u + 1] - p->feat_off[u]));
+    p->iv_dim = kamd_ivector_dim(p->iv_extractor); p->oiv_period = kamd_ivector_period(p->iv_extractor);
+    if (kamd::GrowBuf(&p->d_oiv, &p->oiv_cap, static_cast<size_t>(p->oiv_off[n]) * p->iv_dim) != KAMD_OK) return KAMD_ERR_HIP;
+    rc = kamd_ivector_extract_online_device(p->iv_extractor, p->d_feats, p->feat_off.data(), p->ld_feat, n, p->d_oiv, p->oiv_off.data(), st);
+    if (rc != KAMD_OK) return rc;
+  }
   KAMD_HIP(hipEventRecord(p->ev[1], st));
   if (p->oiv_period > 0)
     rc = kamd_nnet_forward_chunked_device(p->nnet, p->d_feats, p->feat_off.data(), p->ld_feat, p->d_oiv, p->oiv_off.data(),

@@ -124,6 +124,12 @@ class Pipeline:
                                                       ivector_period, frames_per_chunk))
         self._iv_loaded = ("online", iv, off, ivector_period, frames_per_chunk)
 
+    def set_ivector_extractor(self, extractor, frames_per_chunk=50):
+        """i-vectors estimated on the device from the batch's own features (kaldi_amd.ivector.IvectorExtractor),
+        fed to the nnet chunk by chunk like --online-ivectors; None = off."""
+        check(lib().kamd_pipeline_set_ivector_extractor(self._h, extractor._h if extractor is not None else None, frames_per_chunk))
+        self._ie = (extractor, frames_per_chunk)
+
     def set_overlap(self, bounds):
         """Cuts the nnet stage in time at these output-frame indices and overlaps every later slice's
         forward with the search over the slice before it (kamd_pipeline_set_overlap); [] = off."""
@@ -152,6 +158,8 @@ class Pipeline:
                 check(lib().kamd_pipeline_load_features(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), n, flat.shape[1]))
             if getattr(self, "_overlap", None):
                 self.set_overlap(self._overlap)
+            if getattr(self, "_ie", None) and self._ie[0] is not None:
+                self.set_ivector_extractor(*self._ie)
             iv = getattr(self, "_iv_loaded", None)
             if iv is not None and iv[0] == "utt":
                 check(lib().kamd_pipeline_set_ivectors(self._h, abi.fptr(iv[1]), iv[1].shape[1]))

@@ -43,6 +43,13 @@ def lib():
                                        C.c_int, fp, fp, C.c_int]
         L.orc_nnet_forward_chunked.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int,
                                                C.c_int, C.c_int, C.c_int, fp, C.c_int]
+        dp = C.POINTER(C.c_double)
+        L.orc_ivector_extract_online.argtypes = [C.POINTER(abi.IvectorDesc), fp, C.c_int, fp, C.c_int, fp, fp, ip, fp, ip]
+        L.orc_linear_cgd.argtypes = [C.c_int, C.c_int, dp, dp, dp]
+        L.orc_online_cmvn.argtypes = [C.POINTER(abi.IvectorDesc), fp, C.c_int, fp]
+        L.orc_online_cmvn.restype = None
+        L.orc_posterior_entry.argtypes = [fp, C.c_int, C.c_int, C.c_float, ip, fp, ip]
+        L.orc_posterior_entry.restype = C.c_float
         L.orc_decoder_create.restype = C.c_void_p
         L.orc_decoder_create.argtypes = [C.c_int32, C.c_int32, i64p, C.c_void_p, fp,
                                          C.POINTER(abi.DecoderConfig), ip, C.c_int32, C.c_int]
@@ -116,6 +123,50 @@ def nnet_forward_chunked(model, feats, online_ivectors, ivector_period=10, frame
                                        abi.fptr(out), n_out)
     assert r == n_out, r
     return out
+
+
+def ivector_extract_online(info, feats, diagnostics=False):
+    """ivector-extract-online2 for one utterance (fresh adaptation state): [ceil(T/period) x dim]."""
+    f = np.ascontiguousarray(feats, np.float32)
+    T = f.shape[0]
+    d = info.desc()
+    n = (T + info.ivector_period - 1) // info.ivector_period
+    out = np.zeros((n, info.ivector_dim), np.float32)
+    D, ng = info.lda.shape[0], info.num_gselect
+    nl, rl = np.zeros((T, D), np.float32), np.zeros((T, D), np.float32)
+    pg, pw = np.zeros((T, ng), np.int32), np.zeros((T, ng), np.float32)
+    worse = C.c_int32()
+    r = lib().orc_ivector_extract_online(C.byref(d), abi.fptr(f), T, abi.fptr(out), n, abi.fptr(nl), abi.fptr(rl), abi.iptr(pg),
+                                         abi.fptr(pw), C.byref(worse))
+    assert r == n, r
+    if diagnostics:
+        return out, dict(norm_lda=nl, raw_lda=rl, post_gauss=pg, post_weight=pw, cg_got_worse=worse.value)
+    return out
+
+
+def linear_cgd(A_packed, b, x0, max_iters):
+    A = np.ascontiguousarray(A_packed, np.float64)
+    bb = np.ascontiguousarray(b, np.float64)
+    x = np.array(x0, np.float64)
+    dp = C.POINTER(C.c_double)
+    k = lib().orc_linear_cgd(max_iters, bb.size, A.ctypes.data_as(dp), bb.ctypes.data_as(dp), x.ctypes.data_as(dp))
+    return x, k
+
+
+def online_cmvn(info, feats):
+    f = np.ascontiguousarray(feats, np.float32)
+    out = np.zeros_like(f)
+    d = info.desc()
+    lib().orc_online_cmvn(C.byref(d), abi.fptr(f), f.shape[0], abi.fptr(out))
+    return out
+
+
+def posterior_entry(loglikes, num_gselect, min_post):
+    ll = np.ascontiguousarray(loglikes, np.float32)
+    g, p = np.zeros(ll.size, np.int32), np.zeros(ll.size, np.float32)
+    n = C.c_int32()
+    r = lib().orc_posterior_entry(abi.fptr(ll), ll.size, num_gselect, min_post, abi.iptr(g), abi.fptr(p), C.byref(n))
+    return r, g[:n.value], p[:n.value]
 
 
 def nnet_context(model):

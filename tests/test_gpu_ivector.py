@@ -1,0 +1,78 @@
+"""Online i-vector extraction on the device against the CPU oracle (oracle/orc_ivector.cc).
+Tolerances: UBM posteriors 2e-6 absolute (same float operation order, device expf / 1.0f/x differ in
+the last place); i-vectors 1e-4 relative to the largest component (the statistics are accumulated in
+fp64 on both sides, in a different order, and 15 warm-started CG steps amplify that slightly)."""
+import numpy as np
+import pytest
+
+from kaldi_amd import abi, feat, ivector, nnet, pipeline, synth
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def check(info, ie, x):
+    got = ie.extract_online(x)
+    want, dg = orc.ivector_extract_online(info, x, diagnostics=True)
+    assert dg["cg_got_worse"] == 0
+    g, w = ie.last_posteriors(x.shape[0])
+    np.testing.assert_array_equal(g, dg["post_gauss"])
+    np.testing.assert_allclose(w, dg["post_weight"], rtol=0, atol=2e-6)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * max(1.0, np.abs(want).max()))
+    return got
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(ivector_period=4, max_count=1.5), dict(cmn_window=25, speaker_frames=25, global_frames=10),
+                                  dict(num_gselect=2, min_post=0.2), dict(normalize_mean=False, num_cg_iters=3)])
+def test_small_extractor_matches_oracle(opts):
+    info = ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=70, ivector_dim=10, seed=3, splice_left=2, splice_right=1, **opts)
+    ie = ivector.IvectorExtractor(info)
+    rng = np.random.default_rng(1)
+    for T in (1, 2, 9, 10, 11, 53, 160):
+        check(info, ie, (rng.standard_normal((T, 8)) * 1.5 + 0.3).astype(np.float32))
+
+
+def test_recipe_size_extractor_on_mfcc_features():
+    """hires MFCC 40 -> splice +-3 -> LDA 40 -> 512 Gaussians -> 100-dim i-vectors, period 10."""
+    op = abi.mfcc_opts_hires()
+    feats = [feat.Mfcc(op).ComputeFeatures(synth.make_wave(d, seed=40 + i)) for i, d in enumerate((2.3, 0.4, 7.1))]
+    allf = np.concatenate(feats)
+    info = ivector.make_synthetic(seed=5, feat_mean=allf.mean(0), feat_std=allf.std(0), max_count=100.0)
+    ie = ivector.IvectorExtractor(info)
+    solo = [check(info, ie, f) for f in feats]
+    assert solo[2].shape == (71, 100)
+    # the i-vector moves away from the prior as frames come in, and it is not constant
+    assert np.linalg.norm(solo[2][-1]) > np.linalg.norm(solo[2][0])
+    assert np.abs(np.diff(solo[2], axis=0)).max() > 1e-3
+
+
+def test_pipeline_with_the_extractor_equals_precomputed_online_ivectors():
+    """features -> i-vectors -> chunked nnet -> search in one run(), against --online-ivectors with the
+    matrices the extractor returns for the same features, and against the oracle's matrices."""
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, ivector_dim=20, seed=12, output_scale=3.0)
+    cfg = abi.decoder_config_recipe()
+    waves = [synth.make_wave(d, seed=70 + i) for i, d in enumerate((1.7, 3.2, 0.9))]
+    op = abi.mfcc_opts_hires()
+    feats = [feat.Mfcc(op).ComputeFeatures(w) for w in waves]
+    allf = np.concatenate(feats)
+    info = ivector.make_synthetic(num_gauss=64, ivector_dim=20, seed=6, feat_mean=allf.mean(0), feat_std=allf.std(0))
+    ie = ivector.IvectorExtractor(info)
+    pipe = pipeline.Pipeline(op, m, g, cfg, max_utts=3, max_seconds=4.0)
+    pipe.load(waves)
+    pipe.set_ivector_extractor(ie, frames_per_chunk=50)
+    pipe.run()
+    got = pipe.results()
+    got_ll = [pipe.loglikes(u).copy() for u in range(3)]
+    mats = [ie.extract_online(f) for f in feats]
+    pipe.set_ivector_extractor(None)
+    pipe.load(waves)
+    pipe.set_online_ivectors(mats, info.ivector_period, 50)
+    pipe.run()
+    ref = pipe.results()
+    for u in range(3):
+        np.testing.assert_array_equal(pipe.loglikes(u), got_ll[u])        # same kernels, same inputs
+        assert got[u]["words"].tolist() == ref[u]["words"].tolist()
+        want = orc.nnet_forward_chunked(m, feats[u], orc.ivector_extract_online(info, feats[u]), info.ivector_period, 50)
+        np.testing.assert_allclose(got_ll[u], want, rtol=0, atol=2e-3)
