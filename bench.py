@@ -36,11 +36,13 @@ def build_workload(args, rank):
     if args.workload == "mini_librispeech":
         g = synth.make_hclg(num_units=1164, vocab=args.vocab, n_hist=args.n_hist, fanout=(12, 64),
                             pron_len=(3, 7), seed=2, self_loop_prob=0.5, lm_scale=args.lm_scale)
-        model = nnet.tdnnf_mini_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
+        model = nnet.tdnnf_mini_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale,
+                                            ivector_dim=100 if args.ivectors else 0)
     elif args.workload == "librispeech":
         g = synth.make_hclg(num_units=3000, vocab=args.vocab, n_hist=args.n_hist, fanout=(12, 64),
                             pron_len=(3, 7), seed=2, self_loop_prob=0.5, lm_scale=args.lm_scale)
-        model = nnet.tdnnf_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
+        model = nnet.tdnnf_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale,
+                                       ivector_dim=100 if args.ivectors else 0)
     else:  # tiny (CI / CPU-less smoke of the script itself)
         g = synth.make_hclg(num_units=64, vocab=400, n_hist=60, seed=2)
         model = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
@@ -59,7 +61,8 @@ def calibrate(model, target_std):
     from kaldi_amd import abi, decoder, feat, synth
     w = synth.make_wave(3.0, seed=424242)
     f = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(w)
-    ll = decoder.Nnet(model).Forward(f)
+    ivd = model.layers[0].ivector_dim
+    ll = decoder.Nnet(model).Forward(f, ivector=np.zeros(ivd, np.float32) if ivd else None)
     spread = float(np.mean(np.std(ll, axis=1)))
     k = target_std / spread
     out = model.layers[-1]
@@ -165,6 +168,9 @@ def main():
     ap.add_argument("--overlap", default="", help="output-frame indices (e.g. '48') at which the nnet stage is cut in "
                     "time; each later slice's forward runs while the decoder lanes advance over the slice before it.  Same "
                     "lattices, but measured SLOWER at batch 64 (DESIGN.md section 5), so off by default")
+    ap.add_argument("--ivectors", action="store_true", help="variant: the model takes 100-dim online i-vectors, estimated "
+                    "on the device from the batch's features (512-Gaussian UBM, period 10) and fed chunk by chunk "
+                    "(frames-per-chunk 50) like nnet3-latgen-faster --online-ivectors; no CPU baseline for this variant")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -205,6 +211,12 @@ def main():
     pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves), max_seconds=max_s,
                              avg_seconds=audio / len(waves), sizes=sizes)
     log("pipeline created")
+    if args.ivectors:
+        from kaldi_amd import feat, ivector
+        sample = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(waves[0][:16000 * 5])
+        ie = ivector.IvectorExtractor(ivector.make_synthetic(seed=11, feat_mean=sample.mean(0), feat_std=sample.std(0), max_count=100.0))
+        pipe.set_ivector_extractor(ie, 50)
+        log("i-vector extractor created")
     pipe.load(waves)                        # inputs resident in HBM before the timed region
     log("batch loaded")
 
@@ -286,7 +298,11 @@ def main():
         "nnet_tflops": plain_flops / (plain_ms[1] * 1e-3) / 1e12,
         "setup_s": t_build,
     }
-    if not args.no_cpu_baseline and world == 1:
+    if args.ivectors:
+        out["config"]["workload"] += ", 100-dim online i-vectors estimated on the device"
+        out["stage_ms"]["features"] = None
+        out["stage_ms"]["features_and_ivectors"] = stage[0] / args.steps
+    if not args.no_cpu_baseline and world == 1 and not args.ivectors:
         out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, args.cpu_budget, res)
     else:
         out["cpu_baseline"] = None

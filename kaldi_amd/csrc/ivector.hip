@@ -1,7 +1,7 @@
 // ivector.hip -- online i-vector extraction on the device (gfx950), what ivector-extract-online2
 // computes per utterance (online2/online-ivector-feature.cc:206-320; see include/kaldi_amd.h).
 //
-// Four kernels per batch of utterances, features already in HBM (written by feat.hip):
+// Five kernels per batch of utterances, features already in HBM (written by feat.hip):
 //   PrefixKernel   per utterance: running sums of the base features in double -> the sliding-window
 //                  statistics of OnlineCmvn for any frame are S[t] - S[t - window]
 //   FrontKernel    per 16-frame tile: CMVN (window sums smoothed with the global stats), splice
@@ -10,8 +10,11 @@
 //   PostKernel     one wavefront per frame: diagonal-UBM log-likelihoods (lane = Gaussian, the
 //                  UBM stored transposed so lanes read consecutive floats), top num_gselect by
 //                  repeated wave arg-max, VectorToPosteriorEntry's pruning and renormalisation
-//   SolveKernel    one workgroup per utterance, sequential over the i-vector steps: the step's
-//                  posterior-weighted U_g (fp64, streamed from L2) and Sigma_inv_M_g^T x into the
+//   StepStatsKernel one workgroup per i-vector step of every utterance: that step's posterior-weighted
+//                  U_g (fp64, 40 KB per selected Gaussian, L2 / Infinity-Cache resident) and
+//                  Sigma_inv_M_g^T x, written as per-step increments
+//   SolveKernel    one workgroup per utterance, sequential over the i-vector steps: adds the step's
+//                  increment (prefetched into registers during the previous step's CG) to the
 //                  quadratic / linear terms held in LDS, then num_cg_iters conjugate-gradient steps by
 //                  wavefront 0 (rows in lanes, packed symmetric matrix in LDS, wave reductions; no
 //                  workgroup barrier inside the CG loop)
@@ -52,6 +55,8 @@ struct IvBatch {
   int32_t *post_g; float *post_w;  // [rows][ng]
   float *out;                    // [iv rows][I]
   int64_t row_base;              // row_off[0]: workspaces are indexed relative to it
+  int64_t out_base;              // out_off[0]
+  double *dquad, *dlin, *dtotw;  // per i-vector step: its own statistics [iv rows][Q], [iv rows][I], [iv rows]
 };
 
 // ---------------------------------------------------------------- running sums
@@ -197,116 +202,242 @@ __device__ inline double WaveSum(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
-  extern __shared__ double sl[];               // quad[Q], lin[I], x[I], r[I], p[I], Ap[I], xf[D]
-  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ---------------------------------------------------------------- per-step statistics
+// AccStats (ivector-extractor.cc:611-668) for the frames of ONE i-vector step, every step of every
+// utterance in parallel: the 40 KB rows of U_g and the 32 KB of Sigma_inv_M_g per selected Gaussian
+// are the bulk of the traffic (L2 / Infinity-Cache resident: 37 MB for the recipe's extractor) and
+// must not sit on the per-utterance sequential chain.  grid (max steps, utterances).
+__global__ __launch_bounds__(256) void StepStatsKernel(IvDev d, IvBatch b) {
+  extern __shared__ double ss[];               // xf[period][D], pw[cap], then int pg[cap], pt[cap]
+  const int u = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t r0 = b.row_off[u] - b.row_base;
   const int T = static_cast<int>(b.row_off[u + 1] - b.row_off[u]);
-  const int I = d.I, Q = d.Q, D = d.D;
-  double *quad = sl, *lin = quad + Q, *x = lin + I, *r = x + I, *p = r + I, *Ap = p + I, *xf = Ap + I;
-  __shared__ double s_num_frames, s_totw;
-  // OnlineIvectorEstimationStats(ivector_dim, prior_offset, max_count) (ivector-extractor.cc:786-795)
-  for (int q = tid; q < Q; q += 256) quad[q] = 0.0;
-  for (int j = tid; j < I; j += 256) { lin[j] = 0.0; x[j] = 0.0; }
-  __syncthreads();
-  if (tid < I) quad[TriIdx(tid, tid)] = 1.0;
-  if (tid == 0) { lin[0] = d.prior_offset; s_num_frames = 0.0; }
-  __syncthreads();
   const int n_iv = (T + d.period - 1) / d.period;
-  for (int i = 0; i < n_iv; i++) {
-    const int f0 = i == 0 ? 0 : (i - 1) * d.period + 1, f1 = i * d.period;
-    if (tid == 0) s_totw = 0.0;
-    // ---- AccStats (ivector-extractor.cc:611-668), pair by pair
-    for (int t = f0; t <= f1; t++) {
-      for (int k = tid; k < D; k += 256) xf[k] = static_cast<double>(b.raw_lda[(r0 + t) * D + k]);
-      __syncthreads();
-      for (int j = 0; j < d.ng; j++) {
-        const int g = b.post_g[(r0 + t) * d.ng + j];
-        if (g < 0) break;                      // uniform: slots are filled from the front
-        const double wgt = static_cast<double>(b.post_w[(r0 + t) * d.ng + j]);
-        const double *Ug = d.U + static_cast<size_t>(g) * Q;
-        for (int q = tid; q < Q; q += 256) quad[q] += wgt * Ug[q];
-        if (tid < I) {
-          const double *SM = d.SM + static_cast<size_t>(g) * D * I;
-          double acc = 0;
-          for (int a = 0; a < D; a++) acc += SM[static_cast<size_t>(a) * I + tid] * xf[a];
-          lin[tid] += wgt * acc;
-        }
-        if (tid == 0) s_totw += wgt;
-      }
-      __syncthreads();
+  if (i >= n_iv) return;
+  const int I = d.I, Q = d.Q, D = d.D;
+  const int f0 = i == 0 ? 0 : (i - 1) * d.period + 1, f1 = i * d.period, nf = f1 - f0 + 1;
+  const int cap = d.period * d.ng;
+  double *xf = ss, *pw = xf + d.period * D;
+  int *pg = reinterpret_cast<int *>(pw + cap), *pt = pg + cap;
+  __shared__ int s_wcnt[4];
+  __shared__ double s_half[IV_MAX_DIM];
+  for (int k = tid; k < nf * D; k += 256) xf[k] = static_cast<double>(b.raw_lda[(r0 + f0) * D + k]);
+  // compact the step's (gaussian, weight, frame) triples, in frame order
+  int n_pairs = 0;
+  for (int base = 0; base < nf * d.ng; base += 256) {
+    const int e = base + tid;
+    int g = -1; float wv = 0.f;
+    if (e < nf * d.ng) { g = b.post_g[(r0 + f0) * d.ng + e]; wv = b.post_w[(r0 + f0) * d.ng + e]; }
+    const unsigned long long m = __ballot(g >= 0);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = n_pairs;
+    for (int w2 = 0; w2 < wave; w2++) off += s_wcnt[w2];
+    if (g >= 0) {
+      const int pos = off + __popcll(m & ((1ull << lane) - 1));
+      pg[pos] = g; pw[pos] = static_cast<double>(wv); pt[pos] = e / d.ng;
     }
+    n_pairs += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
+  }
+  const int64_t row = b.out_off[u] - b.out_base + i;
+  for (int q = tid; q < Q; q += 256) {
+    double acc = 0;
+#pragma unroll 8
+    for (int e = 0; e < n_pairs; e++) acc += pw[e] * d.U[static_cast<size_t>(pg[e]) * Q + q];
+    b.dquad[row * Q + q] = acc;
+  }
+  {
+    const int j = tid & 127, half = tid >> 7;
+    double acc = 0;
+    if (j < I)
+      for (int e = 0; e < n_pairs; e++) {
+        const double *SM = d.SM + static_cast<size_t>(pg[e]) * D * I;
+        const double *xr = xf + pt[e] * D;
+        double a2 = 0;
+#pragma unroll 8
+        for (int a = half; a < D; a += 2) a2 += SM[static_cast<size_t>(a) * I + j] * xr[a];
+        acc += pw[e] * a2;
+      }
+    if (half == 1 && j < I) s_half[j] = acc;
+    __syncthreads();
+    if (half == 0 && j < I) b.dlin[row * I + j] = acc + s_half[j];
+  }
+  if (tid == 0) {
+    double tw = 0;
+    for (int e = 0; e < n_pairs; e++) tw += pw[e];
+    b.dtotw[row] = tw;
+  }
+}
+
+// ---------------------------------------------------------------- running statistics + CG
+// wave-wide sum of a double with DPP row shifts / broadcasts (GFX9 row_shr, row_bcast15 / 31): six
+// dependent steps of two 32-bit moves and one add, against twelve LDS-crossbar permutes for
+// __shfl_xor.  Returns the total in every lane (read from lane 63).
+template <int kCtrl, int kRowMask>
+__device__ inline double DppAdd(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, kCtrl, kRowMask, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, kCtrl, kRowMask, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ inline double WaveSumDpp(double v) {
+  v = DppAdd<0x111, 0xf>(v);   // row_shr:1
+  v = DppAdd<0x112, 0xf>(v);   // row_shr:2
+  v = DppAdd<0x114, 0xf>(v);   // row_shr:4
+  v = DppAdd<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of every row holds its row's sum
+  v = DppAdd<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = DppAdd<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// LDS-only workgroup barrier (cf. decoder.hip): __syncthreads() would also wait for the prefetch
+// loads that are deliberately left in flight across the CG loop
+__device__ inline void LdsBar() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// One workgroup per utterance, sequential over its i-vector steps.  The symmetric quadratic term
+// lives in REGISTERS: wavefront w owns columns [w*CW, (w+1)*CW), lane l rows l and l+64 of them
+// (2*CW doubles per thread).  y = A v is four partial products (one per wavefront, v broadcast
+// from LDS) and one LDS exchange; wavefront 0 runs LinearCgd itself (vectors in registers, dot
+// products by DPP), wavefronts 1-3 serve its matrix-vector requests.  Step i+1's increment is
+// fetched into registers while step i iterates and parked in LDS between the two.
+constexpr int IV_CW = IV_MAX_DIM / 4;
+__global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
+  extern __shared__ double sl[];               // stage[Q], v[IV_MAX_DIM], part[4][IV_MAX_DIM], lin[IV_MAX_DIM]
+  const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int T = static_cast<int>(b.row_off[u + 1] - b.row_off[u]);
+  const int I = d.I, Q = d.Q;
+  double *stage = sl, *vsh = stage + Q, *part = vsh + IV_MAX_DIM, *lin = part + 4 * IV_MAX_DIM;
+  __shared__ double s_num_frames, s_totw;
+  __shared__ int s_cmd;                         // 1: another matrix-vector product follows, 0: the step's CG is over
+  const int ra = lane, rb = lane + 64;
+  const bool ha = ra < I, hb = rb < I;
+  const int c0 = wave * IV_CW;
+  // OnlineIvectorEstimationStats(ivector_dim, prior_offset, max_count) (ivector-extractor.cc:786-795): quadratic = I
+  double Aa[IV_CW], Ab[IV_CW];
+#pragma unroll
+  for (int k = 0; k < IV_CW; k++) { Aa[k] = (c0 + k == ra && ha) ? 1.0 : 0.0; Ab[k] = (c0 + k == rb && hb) ? 1.0 : 0.0; }
+  for (int j = tid; j < IV_MAX_DIM; j += 256) { lin[j] = 0.0; vsh[j] = 0.0; }
+  if (tid == 0) s_num_frames = 0.0;
+  __syncthreads();
+  if (tid == 0) lin[0] = d.prior_offset;
+  double xa = 0.0, xb = 0.0;                    // wavefront 0: the current estimate (rows ra, rb)
+  const int n_iv = (T + d.period - 1) / d.period;
+  const int64_t row0 = b.out_off[u] - b.out_base;
+  constexpr int QPT = (IV_MAX_DIM * (IV_MAX_DIM + 1) / 2 + 255) / 256;
+  for (int q = tid; q < Q; q += 256) stage[q] = b.dquad[row0 * Q + q];
+  double nl = tid < I ? b.dlin[row0 * I + tid] : 0.0;
+  double ntw = b.dtotw[row0];
+  __syncthreads();
+
+  // partial product of this wavefront's columns with v (in vsh), exchanged through `part`
+  auto partial = [&]() {
+    double sa = 0, sb = 0;
+#pragma unroll
+    for (int k = 0; k < IV_CW; k++) { const double vc = vsh[c0 + k]; sa += Aa[k] * vc; sb += Ab[k] * vc; }
+    part[wave * IV_MAX_DIM + ra] = sa; part[wave * IV_MAX_DIM + rb] = sb;
+  };
+
+  for (int i = 0; i < n_iv; i++) {
+    // ---- this step's increment: packed lower triangle in `stage` -> the register tile
+#pragma unroll
+    for (int k = 0; k < IV_CW; k++) {
+      const int c = c0 + k;
+      if (c < I) {
+        if (ha) Aa[k] += stage[ra >= c ? ra * (ra + 1) / 2 + c : c * (c + 1) / 2 + ra];
+        if (hb) Ab[k] += stage[rb >= c ? rb * (rb + 1) / 2 + c : c * (c + 1) / 2 + rb];
+      }
+    }
+    if (tid < I) lin[tid] += nl;
+    if (tid == 0) s_totw = ntw;
+    // the next step's increment, in flight during this step's CG
+    double nq[QPT];
+    const bool more = i + 1 < n_iv;
+    const int64_t rn = row0 + i + 1;
+#pragma unroll
+    for (int m = 0; m < QPT; m++) { const int q = tid + 256 * m; nq[m] = (more && q < Q) ? b.dquad[rn * Q + q] : 0.0; }
+    if (more) { nl = tid < I ? b.dlin[rn * I + tid] : 0.0; ntw = b.dtotw[rn]; }
+    LdsBar();
     if (d.max_count > 0.0) {
       const double old_n = s_num_frames, new_n = s_num_frames + s_totw;
       const double change = fmax(new_n, d.max_count) / d.max_count - fmax(old_n, d.max_count) / d.max_count;
       if (change != 0.0) {
-        if (tid < I) quad[TriIdx(tid, tid)] += change;
+#pragma unroll
+        for (int k = 0; k < IV_CW; k++) { if (ha && c0 + k == ra) Aa[k] += change; if (hb && c0 + k == rb) Ab[k] += change; }
         if (tid == 0) lin[0] += d.prior_offset * change;
       }
     }
-    __syncthreads();
+    LdsBar();
     if (tid == 0) s_num_frames += s_totw;
-    __syncthreads();
+    LdsBar();
+    const bool have = s_num_frames > 0.0;
     // ---- GetIvector (ivector-extractor.cc:732-756): LinearCgd from the previous estimate
-    if (wave == 0) {
-      const int ra = lane, rb = lane + 64;
-      const bool ha = ra < I, hb = rb < I;
-      if (s_num_frames > 0.0) {
-        if (lane == 0 && x[0] == 0.0) x[0] = d.prior_offset;
-        __builtin_amdgcn_wave_barrier();
-        auto spvec = [&](const double *v, double *ya, double *yb) {     // y = A v for this lane's rows
-          double sa = 0, sb = 0;
-          for (int c = 0; c < I; c++) {
-            const double vc = v[c];
-            if (ha) sa += quad[TriIdx(ra, c)] * vc;
-            if (hb) sb += quad[TriIdx(rb, c)] * vc;
-          }
-          *ya = sa; *yb = sb;
+    if (wave != 0) {
+      if (have)
+        for (;;) {                               // serve wavefront 0's products until it says the step is over
+          LdsBar();                              // B1: v and the command are published
+          if (s_cmd == 0) break;
+          partial();
+          LdsBar();                              // B2: partials are published
+        }
+    } else {
+      if (have) {
+        // y = A v for rows ra, rb; v is given distributed (va, vb)
+        auto spvec = [&](double va, double vb, double *ya, double *yb) {
+          if (ha) vsh[ra] = va;
+          if (hb) vsh[rb] = vb;
+          if (lane == 0) s_cmd = 1;
+          LdsBar();                              // B1
+          partial();
+          LdsBar();                              // B2
+          *ya = ha ? part[ra] + part[IV_MAX_DIM + ra] + part[2 * IV_MAX_DIM + ra] + part[3 * IV_MAX_DIM + ra] : 0.0;
+          *yb = hb ? part[rb] + part[IV_MAX_DIM + rb] + part[2 * IV_MAX_DIM + rb] + part[3 * IV_MAX_DIM + rb] : 0.0;
         };
+        if (lane == 0 && xa == 0.0) xa = d.prior_offset;       // "(*ivector)(0) == 0.0": better initial guess
+        const double la = ha ? lin[ra] : 0.0, lb = hb ? lin[rb] : 0.0;
         double ya, yb;
-        spvec(x, &ya, &yb);
-        double pa = 0, pb = 0, rra = 0, rrb = 0;
-        if (ha) { pa = lin[ra] - ya; rra = -pa; p[ra] = pa; r[ra] = rra; }
-        if (hb) { pb = lin[rb] - yb; rrb = -pb; p[rb] = pb; r[rb] = rrb; }
-        double r_cur = WaveSum(rra * rra + rrb * rrb);
+        spvec(xa, xb, &ya, &yb);
+        double pa = ha ? la - ya : 0.0, pb = hb ? lb - yb : 0.0;
+        double rra = -pa, rrb = -pb;
+        double r_cur = WaveSumDpp(rra * rra + rrb * rrb);
         double r_recompute = r_cur;
         const double residual_factor = 1.0e-4, inv_residual_factor = 1.0e4, max_error_sq = 2.2250738585072014e-308;
-        __builtin_amdgcn_wave_barrier();
         for (int k = 0; k < I + 5 && k != d.cg_iters; k++) {
-          spvec(p, &ya, &yb);
-          if (ha) Ap[ra] = ya;
-          if (hb) Ap[rb] = yb;
-          const double pr = WaveSum((ha ? p[ra] * r[ra] : 0.0) + (hb ? p[rb] * r[rb] : 0.0));
-          const double pAp = WaveSum((ha ? p[ra] * ya : 0.0) + (hb ? p[rb] * yb : 0.0));
+          spvec(pa, pb, &ya, &yb);
+          const double pr = WaveSumDpp(pa * rra + pb * rrb);
+          const double pAp = WaveSumDpp(pa * ya + pb * yb);
           const double alpha = -pr / pAp;
-          double na = 0, nb = 0;
-          if (ha) { x[ra] += alpha * p[ra]; na = r[ra] + alpha * ya; r[ra] = na; }
-          if (hb) { x[rb] += alpha * p[rb]; nb = r[rb] + alpha * yb; r[rb] = nb; }
-          double r_next = WaveSum(na * na + nb * nb);
-          __builtin_amdgcn_wave_barrier();
+          xa += alpha * pa; xb += alpha * pb;
+          rra += alpha * ya; rrb += alpha * yb;
+          double r_next = WaveSumDpp(rra * rra + rrb * rrb);
           if (r_next < residual_factor * r_recompute || r_next > inv_residual_factor * r_recompute) {
-            spvec(x, &ya, &yb);
-            if (ha) { na = ya - lin[ra]; r[ra] = na; }
-            if (hb) { nb = yb - lin[rb]; r[rb] = nb; }
-            r_next = WaveSum(na * na + nb * nb);
+            spvec(xa, xb, &ya, &yb);
+            rra = ha ? ya - la : 0.0; rrb = hb ? yb - lb : 0.0;
+            r_next = WaveSumDpp(rra * rra + rrb * rrb);
             r_recompute = r_next;
           }
           if (r_next <= max_error_sq) break;
           const double beta = r_next / r_cur;
-          if (ha) p[ra] = beta * p[ra] - r[ra];
-          if (hb) p[rb] = beta * p[rb] - r[rb];
+          pa = beta * pa - rra; pb = beta * pb - rrb;
           r_cur = r_next;
-          __builtin_amdgcn_wave_barrier();
         }
+        if (lane == 0) s_cmd = 0;
+        LdsBar();                                // the workers' B1: they leave their loop
       } else {
-        if (ha) x[ra] = ra == 0 ? d.prior_offset : 0.0;
-        if (hb) x[rb] = 0.0;
+        xa = lane == 0 ? d.prior_offset : 0.0; xb = 0.0;
       }
-      __builtin_amdgcn_wave_barrier();
       float *o = b.out + (b.out_off[u] + i) * I;
-      if (ha) { float v = static_cast<float>(x[ra]); if (ra == 0) v = static_cast<float>(static_cast<double>(v) - d.prior_offset); o[ra] = v; }
-      if (hb) o[rb] = static_cast<float>(x[rb]);
+      if (ha) { float v = static_cast<float>(xa); if (ra == 0) v = static_cast<float>(static_cast<double>(v) - d.prior_offset); o[ra] = v; }
+      if (hb) o[rb] = static_cast<float>(xb);
     }
+    // park the prefetched increment in LDS for the next step (everybody is past the reads of `stage`)
+#pragma unroll
+    for (int m = 0; m < QPT; m++) { const int q = tid + 256 * m; if (q < Q) stage[q] = nq[m]; }
     __syncthreads();
   }
 }
@@ -322,6 +453,7 @@ struct IvExtractor {
   float *d_nl = NULL, *d_rl = NULL; size_t lda_cap = 0;
   int32_t *d_pg = NULL; float *d_pw = NULL; size_t post_cap = 0;
   int64_t *d_off = NULL; size_t off_cap = 0;
+  double *d_dquad = NULL, *d_dlin = NULL, *d_dtotw = NULL; size_t dq_cap = 0, dl_cap = 0, dt_cap = 0;
   int64_t last_rows = 0;
 };
 
@@ -406,6 +538,12 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
   v.I = I; v.Q = Q; v.U = e->d_U; v.SM = e->d_SM;
   v.prior_offset = d.prior_offset; v.max_count = d.max_count;
   v.period = d.ivector_period; v.ng = d.num_gselect; v.cg_iters = d.num_cg_iters;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::SolveKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          static_cast<int>((static_cast<size_t>(Q) + 6 * kamd::IV_MAX_DIM) * sizeof(double))) != hipSuccess) {
+    kamd::SetError(KAMD_ERR_HIP, "i-vector extractor: cannot reserve LDS for the solver");
+    kamd_ivector_extractor_destroy(reinterpret_cast<kamd_ivector_extractor *>(e));
+    return NULL;
+  }
   v.min_post = d.min_post; v.log_min_post = d.min_post > 0 ? logf(d.min_post) : -INFINITY; v.post_scale = d.posterior_scale;
   return reinterpret_cast<kamd_ivector_extractor *>(e);
 }
@@ -413,7 +551,7 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
 void kamd_ivector_extractor_destroy(kamd_ivector_extractor *h) {
   IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
   if (!e) return;
-  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_S, e->d_nl, e->d_rl, e->d_pg, e->d_pw, e->d_off};
+  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_S, e->d_nl, e->d_rl, e->d_pg, e->d_pw, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw};
   for (void *p : ps) if (p) (void)hipFree(p);
   delete e;
 }
@@ -449,19 +587,27 @@ int kamd_ivector_extract_online_device(kamd_ivector_extractor *h, const float *d
   if (kamd::GrowDev(&e->d_pg, &e->post_cap, static_cast<size_t>(rows) * v.ng) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&e->d_pw, &cap3, static_cast<size_t>(rows) * v.ng) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&e->d_off, &e->off_cap, static_cast<size_t>(2 * (n_utts + 1))) != KAMD_OK) return KAMD_ERR_HIP;
+  const int64_t iv_rows = h_out_row_off[n_utts] - h_out_row_off[0];
+  if (kamd::GrowDev(&e->d_dquad, &e->dq_cap, static_cast<size_t>(iv_rows) * v.Q) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&e->d_dlin, &e->dl_cap, static_cast<size_t>(iv_rows) * v.I) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&e->d_dtotw, &e->dt_cap, static_cast<size_t>(iv_rows)) != KAMD_OK) return KAMD_ERR_HIP;
   KAMD_HIP(hipMemcpyAsync(e->d_off, h_row_off, (n_utts + 1) * 8, hipMemcpyHostToDevice, st));
   KAMD_HIP(hipMemcpyAsync(e->d_off + n_utts + 1, h_out_row_off, (n_utts + 1) * 8, hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));          // the offset arrays are pageable host memory
   kamd::IvBatch b;
   b.feats = d_feats; b.ld = ld_feat; b.row_off = e->d_off; b.out_off = e->d_off + n_utts + 1;
   b.S = e->d_S; b.norm_lda = e->d_nl; b.raw_lda = e->d_rl; b.post_g = e->d_pg; b.post_w = e->d_pw; b.out = d_out;
-  b.row_base = h_row_off[0];
+  b.row_base = h_row_off[0]; b.out_base = h_out_row_off[0];
+  b.dquad = e->d_dquad; b.dlin = e->d_dlin; b.dtotw = e->d_dtotw;
   hipLaunchKernelGGL(kamd::PrefixKernel, dim3(n_utts), dim3(256), 0, st, v, b);
   const size_t lds_front = static_cast<size_t>(2) * (kamd::IV_FT + v.L + v.R) * v.feat_dim * sizeof(float);
   hipLaunchKernelGGL(kamd::FrontKernel, dim3(kamd::CeilDiv(max_T, kamd::IV_FT), n_utts), dim3(256), lds_front, st, v, b);
   const size_t lds_post = static_cast<size_t>(4) * (v.D + v.G) * sizeof(float);
   hipLaunchKernelGGL(kamd::PostKernel, dim3(kamd::CeilDiv(rows, 4)), dim3(256), lds_post, st, v, b, rows);
-  const size_t lds_solve = (static_cast<size_t>(v.Q) + 5 * v.I + v.D) * sizeof(double);
+  const int max_iv = (max_T + v.period - 1) / v.period, pair_cap = v.period * v.ng;
+  const size_t lds_step = (static_cast<size_t>(v.period) * v.D + pair_cap) * sizeof(double) + static_cast<size_t>(2) * pair_cap * sizeof(int);
+  hipLaunchKernelGGL(kamd::StepStatsKernel, dim3(max_iv, n_utts), dim3(256), lds_step, st, v, b);
+  const size_t lds_solve = (static_cast<size_t>(v.Q) + 6 * kamd::IV_MAX_DIM) * sizeof(double);
   hipLaunchKernelGGL(kamd::SolveKernel, dim3(n_utts), dim3(256), lds_solve, st, v, b);
   KAMD_HIP(hipGetLastError());
   e->last_rows = rows;
