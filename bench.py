@@ -54,7 +54,7 @@ def build_workload(args, rank):
     return g, model, waves, cfg, time.time() - t0
 
 
-def calibrate(model, target_std):
+def calibrate(model, target_std, extractor=None):
     """Random weights give arbitrary output scale; rescale the output layer so that the
     per-frame spread of the log-likelihoods across pdfs is `target_std` nats (chain models
     in the wild: a few nats).  Runs on the GPU (this is workload synthesis, not parity)."""
@@ -62,7 +62,10 @@ def calibrate(model, target_std):
     w = synth.make_wave(3.0, seed=424242)
     f = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(w)
     ivd = model.layers[0].ivector_dim
-    ll = decoder.Nnet(model).Forward(f, ivector=np.zeros(ivd, np.float32) if ivd else None)
+    iv = None
+    if ivd:      # a typical i-vector (the last one of the sample), not zeros: it shifts every output
+        iv = extractor.extract_online(f)[-1] if extractor is not None else np.zeros(ivd, np.float32)
+    ll = decoder.Nnet(model).Forward(f, ivector=iv)
     spread = float(np.mean(np.std(ll, axis=1)))
     k = target_std / spread
     out = model.layers[-1]
@@ -199,7 +202,21 @@ def main():
             print("[bench %.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
     T0 = time.time()
     g, model, waves, cfg, t_build = build_workload(args, rank)
-    spread, k = calibrate(model, args.ll_std)
+    ie = None
+    if args.ivectors:
+        from kaldi_amd import feat, ivector
+        sample = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(waves[0][:16000 * 5])
+        ie = ivector.IvectorExtractor(ivector.make_synthetic(seed=11, feat_mean=sample.mean(0), feat_std=sample.std(0), max_count=100.0))
+        log("i-vector extractor created")
+        # random first-layer weights would let the 100 i-vector inputs swamp the 3 x 40 cepstra (a trained
+        # model sees them through the LDA-like first affine, roughly unit variance in total): damp those
+        # columns so that the synthetic search load stays what --ll-std asks for
+        ivs = ie.extract_online(sample)
+        l0 = model.layers[0]
+        nf = l0.W.shape[1] - l0.ivector_dim
+        ratio = np.std(l0.W[:, :nf] @ np.tile(sample[:50], (1, nf // sample.shape[1])).T) / max(np.std(l0.W[:, nf:] @ ivs.T), 1e-9)
+        l0.W[:, nf:] *= np.float32(0.3 * ratio)
+    spread, k = calibrate(model, args.ll_std, ie)
     log("workload built: %d states %d arcs, %d utts" % (g.num_states, g.num_arcs, len(waves)))
     audio = sum(w.size for w in waves) / 16000.0
     max_s = max(w.size for w in waves) / 16000.0 + 0.5
@@ -211,12 +228,8 @@ def main():
     pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves), max_seconds=max_s,
                              avg_seconds=audio / len(waves), sizes=sizes)
     log("pipeline created")
-    if args.ivectors:
-        from kaldi_amd import feat, ivector
-        sample = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(waves[0][:16000 * 5])
-        ie = ivector.IvectorExtractor(ivector.make_synthetic(seed=11, feat_mean=sample.mean(0), feat_std=sample.std(0), max_count=100.0))
+    if ie is not None:
         pipe.set_ivector_extractor(ie, 50)
-        log("i-vector extractor created")
     pipe.load(waves)                        # inputs resident in HBM before the timed region
     log("batch loaded")
 

@@ -76,3 +76,55 @@ def test_pipeline_with_the_extractor_equals_precomputed_online_ivectors():
         assert got[u]["words"].tolist() == ref[u]["words"].tolist()
         want = orc.nnet_forward_chunked(m, feats[u], orc.ivector_extract_online(info, feats[u]), info.ivector_period, 50)
         np.testing.assert_allclose(got_ll[u], want, rtol=0, atol=2e-3)
+
+
+def test_latgen_tool_with_device_ivectors_and_with_online_ivector_archives(tmp_path):
+    """tools/nnet3_latgen_faster.py: --ivector-extraction-config (estimated on the device) gives the
+    same word sequences as --online-ivectors with the matrices dumped to an archive, and as the
+    in-memory pipeline; the extractor is read back from final.ie / final.dubm / final.mat / conf files."""
+    import subprocess
+    import sys
+    import wave
+    import os
+    from kaldi_amd import io as kio
+    from kaldi_amd import table
+    from tests.mdl_writer import write_mdl
+    g = synth.make_hclg(num_units=25, vocab=60, n_hist=12, seed=6)
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, ivector_dim=20, seed=12, output_scale=3.0)
+    write_mdl(tmp_path / "final.mdl", m, num_units=25)
+    kio.write_openfst(tmp_path / "HCLG.fst", g, "const")
+    waves = [np.round(synth.make_wave(d, seed=80 + i)).astype(np.float32) for i, d in enumerate((1.4, 2.6))]
+    op = abi.mfcc_opts_hires()
+    feats = [feat.Mfcc(op).ComputeFeatures(w) for w in waves]
+    allf = np.concatenate(feats)
+    info = ivector.make_synthetic(num_gauss=64, ivector_dim=20, seed=6, feat_mean=allf.mean(0), feat_std=allf.std(0), max_count=100.0)
+    conf = ivector.write_config_dir(tmp_path / "ivector_extractor", info)
+    with open(tmp_path / "wav.scp", "w") as scp:
+        for i, w in enumerate(waves):
+            with wave.open(str(tmp_path / ("u%d.wav" % i)), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+                f.writeframes(w.astype("<i2").tobytes())
+            scp.write("utt%d %s\n" % (i, tmp_path / ("u%d.wav" % i)))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = [sys.executable, root + "/tools/nnet3_latgen_faster.py", "--beam=15", "--max-active=7000", "--lattice-beam=8",
+            "--acoustic-scale=1.0", "--frame-subsampling-factor=3", "--wav", str(tmp_path / "final.mdl"), str(tmp_path / "HCLG.fst"),
+            "scp:%s" % (tmp_path / "wav.scp")]
+    r = subprocess.run(tool[:6] + ["--ivector-extraction-config=%s" % conf] + tool[6:] +
+                       ["ark:%s" % (tmp_path / "lat1.ark"), "ark,t:%s" % (tmp_path / "w1.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ie = ivector.IvectorExtractor(ivector.IvectorExtractionInfo.from_config(conf))
+    with table.TableWriter("ark:%s" % (tmp_path / "ivector_online.ark"), "matrix") as w:
+        for i, f in enumerate(feats):
+            w.write("utt%d" % i, ie.extract_online(f))
+    r = subprocess.run(tool[:6] + ["--online-ivectors=ark:%s" % (tmp_path / "ivector_online.ark"), "--online-ivector-period=10"] + tool[6:] +
+                       ["ark:%s" % (tmp_path / "lat2.ark"), "ark,t:%s" % (tmp_path / "w2.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(tmp_path / "w1.txt").read() == open(tmp_path / "w2.txt").read()
+    assert open(tmp_path / "lat1.ark", "rb").read() == open(tmp_path / "lat2.ark", "rb").read()
+    g.tid2pdf = np.concatenate([[-1], np.stack([2 * np.arange(25) + 1, 2 * np.arange(25)], 1).reshape(-1)]).astype(np.int32)
+    pipe = pipeline.Pipeline(op, m, g, abi.decoder_config_recipe(), max_utts=2, max_seconds=3.0)
+    pipe.set_ivector_extractor(ie, 50)
+    ref = pipe.decode(waves)
+    got = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(tmp_path / "w1.txt")}
+    for i in range(2):
+        assert got["utt%d" % i] == ref[i]["words"].tolist()

@@ -33,6 +33,9 @@ def main(argv):
     po.register("online-ivectors", str, "", "Rspecifier for iVectors estimated online, as matrices.")
     po.register("online-ivector-period", int, 0, "Number of frames between iVectors in matrices supplied to the "
                 "--online-ivectors option")
+    po.register("ivector-extraction-config", str, "", "Not in the reference binary: estimate the online i-vectors on the device "
+                "from the utterance's own features (the config file ivector-extract-online2 and the online2 binaries take: "
+                "--lda-matrix, --global-cmvn-stats, --diag-ubm, --ivector-extractor, ...), fresh state per utterance")
     po.register("wav", bool, False, "The third argument is a waveform rspecifier; features are computed on the device")
     po.register("mfcc-config", str, "", "Config file with compute-mfcc-feats options (only with --wav)")
     po.register("batch", int, 64, "Utterances decoded per pass")
@@ -46,6 +49,8 @@ def main(argv):
     if po["ivectors"]:
         raise KamdError("--ivectors (one vector per utterance / speaker) needs a vector table reader, which is not built; "
                         "use --online-ivectors")
+    if po["online-ivectors"] and po["ivector-extraction-config"]:
+        raise KamdError("--online-ivectors and --ivector-extraction-config exclude each other")
     if po["online-ivectors"] and po["online-ivector-period"] <= 0:
         raise KamdError("--online-ivector-period must be set with --online-ivectors")       # nnet3-latgen-faster.cc:94-99
     cfg = options.decoder_config(po)
@@ -64,6 +69,10 @@ def main(argv):
         g = kio.read_openfst(path)
     g.tid2pdf, g.num_pdfs = id2pdf, model.num_pdfs
     ivecs = table.RandomAccessTableReader(po["online-ivectors"], "matrix") if po["online-ivectors"] else None
+    extractor = None
+    if po["ivector-extraction-config"]:
+        from kaldi_amd import ivector
+        extractor = ivector.IvectorExtractor(ivector.IvectorExtractionInfo.from_config(po["ivector-extraction-config"]))
     lat_kind = "compact_lattice" if po["determinize-lattice"] else "lattice"
     lat_w = table.TableWriter(lat_wspec, lat_kind, acoustic_scale=acwt)
     words_w = table.TableWriter(words_wspec, "int32") if words_wspec else None
@@ -100,6 +109,8 @@ def main(argv):
             pipe.load_features(vals)
         if ivecs is not None:
             pipe.set_online_ivectors([ivecs[k] for k in keys], po["online-ivector-period"], po["frames-per-chunk"])
+        if extractor is not None:
+            pipe.set_ivector_extractor(extractor, po["frames-per-chunk"])
         pipe.run(auto_grow=4)
         for key, res, lane in zip(keys, pipe.results(lattices=True), pipe._lane_of):
             if res is None:
