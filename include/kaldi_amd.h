@@ -444,9 +444,24 @@ int kamd_ivector_num_ivectors(const kamd_ivector_extractor *e, int num_frames);
 int kamd_ivector_extract_online_device(kamd_ivector_extractor *e, const float *d_feats, const int64_t *h_row_off,
                                        int ld_feat, int n_utts, float *d_out, const int64_t *h_out_row_off,
                                        void *stream);
+/* The same with the speaker's adaptation state (OnlineIvectorExtractorAdaptationState, SetAdaptationState /
+ * GetAdaptationState, online2/online-ivector-feature.cc:400-435), as ivector-extract-online2 carries it
+ * from one utterance of a speaker to the next (online2bin/ivector-extract-online2.cc:95-170).  A state is
+ * kamd_ivector_state_size() doubles: [2 x (feat_dim+1)] speaker CMVN stats, the packed quadratic term,
+ * the linear term, the frame count.  h_state_in / h_state_out: n_utts states on the host, either may
+ * be NULL (fresh state / not wanted); the utterances of one call must belong to different speakers.
+ * The state returned is the one BEFORE LimitFrames: apply kamd_ivector_state_limit_frames (host
+ * arithmetic) with --max-remembered-frames before handing it to the speaker's next utterance. */
+int kamd_ivector_state_size(const kamd_ivector_extractor *e);
+int kamd_ivector_extract_online_adapt_device(kamd_ivector_extractor *e, const float *d_feats, const int64_t *h_row_off,
+                                             int ld_feat, int n_utts, float *d_out, const int64_t *h_out_row_off,
+                                             const double *h_state_in, double *h_state_out, void *stream);
+int kamd_ivector_state_limit_frames(const kamd_ivector_extractor *e, double *state, float max_remembered_frames);
 /* one utterance, host in / host out; returns the number of rows written or < 0 */
 int kamd_ivector_extract_online(kamd_ivector_extractor *e, const float *feats, int num_frames, float *out,
                                 int out_rows_cap);
+int kamd_ivector_extract_online_adapt(kamd_ivector_extractor *e, const float *feats, int num_frames, float *out,
+                                      int out_rows_cap, const double *state_in, double *state_out);
 /* diagnostic: the per-frame posteriors of the last batch (frame-major, num_gselect slots per frame,
  * gaussian -1 = empty slot) */
 int kamd_ivector_last_posteriors(kamd_ivector_extractor *e, int32_t *gauss, float *weight, int64_t frames_cap);

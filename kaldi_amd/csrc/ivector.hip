@@ -36,7 +36,7 @@ struct IvDev {
   const float *ldaT;             // [sd (+1)][D]
   const double *gsum;            // [feat_dim] global sums
   double gcount;
-  int cmn_window, global_frames, normalize_mean;
+  int cmn_window, speaker_frames, global_frames, normalize_mean;
   int G;
   const float *gconsts, *mivT, *ivT;   // [G], [D][G], [D][G] (inv_vars premultiplied by -0.5)
   int I, Q;
@@ -57,6 +57,9 @@ struct IvBatch {
   int64_t row_base;              // row_off[0]: workspaces are indexed relative to it
   int64_t out_base;              // out_off[0]
   double *dquad, *dlin, *dtotw;  // per i-vector step: its own statistics [iv rows][Q], [iv rows][I], [iv rows]
+  // adaptation state carried over from the speaker's previous utterance (NULL: fresh), [n][state size]:
+  // 2 x (feat_dim+1) speaker CMVN stats | packed quadratic term | linear term | num_frames
+  const double *state_in; double *state_out; int state_size;
 };
 
 // ---------------------------------------------------------------- running sums
@@ -76,11 +79,30 @@ __global__ __launch_bounds__(256) void PrefixKernel(IvDev d, IvBatch b) {
   __syncthreads();
   double run = 0;
   for (int c2 = 0; c2 < c; c2++) run += csum[c2 * dpw + k];
+  double sq = 0;
   if (k < d.feat_dim)
     for (int t = t0; t < t1; t++) {
-      run += static_cast<double>(b.feats[(r0 + t) * b.ld + k]);
+      const double v = static_cast<double>(b.feats[(r0 + t) * b.ld + k]);
+      run += v; sq += v * v;
       b.S[(r0 - b.row_base + t) * d.feat_dim + k] = run;
     }
+  if (b.state_out) {
+    // OnlineCmvn::GetState(T - 1) (feat/online-feature.cc:455-475): incoming speaker stats + all T frames
+    __syncthreads();
+    csum[tid] = sq;
+    __syncthreads();
+    if (c == 0 && k < d.feat_dim) {
+      double s2 = 0, s1 = 0;
+      for (int c2 = 0; c2 < chunks; c2++) s2 += csum[c2 * dpw + k];
+      s1 = b.S[(r0 - b.row_base + T - 1) * d.feat_dim + k];
+      const int sd1 = d.feat_dim + 1;
+      const double *in = b.state_in ? b.state_in + static_cast<size_t>(u) * b.state_size : NULL;
+      double *out = b.state_out + static_cast<size_t>(u) * b.state_size;
+      out[k] = (in ? in[k] : 0.0) + s1;
+      out[sd1 + k] = (in ? in[sd1 + k] : 0.0) + s2;
+      if (k == 0) { out[d.feat_dim] = (in ? in[d.feat_dim] : 0.0) + T; out[sd1 + d.feat_dim] = in ? in[sd1 + d.feat_dim] : 0.0; }
+    }
+  }
 }
 
 // ---------------------------------------------------------------- CMVN + splice + LDA
@@ -106,6 +128,14 @@ __global__ __launch_bounds__(256) void FrontKernel(IvDev d, IvBatch b) {
       double win = S[static_cast<size_t>(t2) * dim + k];
       double cnt = t2 + 1;
       if (t2 - d.cmn_window >= 0) { win -= S[static_cast<size_t>(t2 - d.cmn_window) * dim + k]; cnt = d.cmn_window; }
+      if (cnt < d.cmn_window && b.state_in != NULL) {          // speaker stats of the carried-over state first
+        const double *sp = b.state_in + static_cast<size_t>(u) * b.state_size;
+        const double speaker_count = sp[dim];
+        double from_speaker = d.cmn_window - cnt;
+        if (from_speaker > d.speaker_frames) from_speaker = d.speaker_frames;
+        if (from_speaker > speaker_count) from_speaker = speaker_count;
+        if (from_speaker > 0.0) { win += from_speaker / speaker_count * sp[k]; cnt += from_speaker / speaker_count * speaker_count; }
+      }
       if (cnt < d.cmn_window) {
         double from_global = d.cmn_window - cnt;
         if (from_global > d.global_frames) from_global = d.global_frames;
@@ -319,13 +349,22 @@ __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
   const bool ha = ra < I, hb = rb < I;
   const int c0 = wave * IV_CW;
   // OnlineIvectorEstimationStats(ivector_dim, prior_offset, max_count) (ivector-extractor.cc:786-795): quadratic = I
+  // ... or the statistics the speaker's previous utterance left (SetAdaptationState, online-ivector-feature.cc:427-435)
+  const double *sin = b.state_in ? b.state_in + static_cast<size_t>(u) * b.state_size + 2 * (d.feat_dim + 1) : NULL;
   double Aa[IV_CW], Ab[IV_CW];
 #pragma unroll
-  for (int k = 0; k < IV_CW; k++) { Aa[k] = (c0 + k == ra && ha) ? 1.0 : 0.0; Ab[k] = (c0 + k == rb && hb) ? 1.0 : 0.0; }
-  for (int j = tid; j < IV_MAX_DIM; j += 256) { lin[j] = 0.0; vsh[j] = 0.0; }
-  if (tid == 0) s_num_frames = 0.0;
+  for (int k = 0; k < IV_CW; k++) {
+    const int c = c0 + k;
+    Aa[k] = (c == ra && ha) ? 1.0 : 0.0; Ab[k] = (c == rb && hb) ? 1.0 : 0.0;
+    if (sin && c < I) {
+      if (ha) Aa[k] = sin[ra >= c ? ra * (ra + 1) / 2 + c : c * (c + 1) / 2 + ra];
+      if (hb) Ab[k] = sin[rb >= c ? rb * (rb + 1) / 2 + c : c * (c + 1) / 2 + rb];
+    }
+  }
+  for (int j = tid; j < IV_MAX_DIM; j += 256) { lin[j] = (sin && j < I) ? sin[Q + j] : 0.0; vsh[j] = 0.0; }
+  if (tid == 0) s_num_frames = sin ? sin[Q + I] : 0.0;
   __syncthreads();
-  if (tid == 0) lin[0] = d.prior_offset;
+  if (tid == 0 && !sin) lin[0] = d.prior_offset;
   double xa = 0.0, xb = 0.0;                    // wavefront 0: the current estimate (rows ra, rb)
   const int n_iv = (T + d.period - 1) / d.period;
   const int64_t row0 = b.out_off[u] - b.out_base;
@@ -440,6 +479,19 @@ __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
     for (int m = 0; m < QPT; m++) { const int q = tid + 256 * m; if (q < Q) stage[q] = nq[m]; }
     __syncthreads();
   }
+  if (b.state_out) {                             // GetAdaptationState: the statistics as of the last i-vector
+    double *so = b.state_out + static_cast<size_t>(u) * b.state_size + 2 * (d.feat_dim + 1);
+#pragma unroll
+    for (int k = 0; k < IV_CW; k++) {
+      const int c = c0 + k;
+      if (c < I) {
+        if (ha && ra >= c) so[ra * (ra + 1) / 2 + c] = Aa[k];
+        if (hb && rb >= c) so[rb * (rb + 1) / 2 + c] = Ab[k];
+      }
+    }
+    if (tid < I) so[Q + tid] = lin[tid];
+    if (tid == 0) so[Q + I] = s_num_frames;
+  }
 }
 
 struct IvExtractor {
@@ -454,6 +506,7 @@ struct IvExtractor {
   int32_t *d_pg = NULL; float *d_pw = NULL; size_t post_cap = 0;
   int64_t *d_off = NULL; size_t off_cap = 0;
   double *d_dquad = NULL, *d_dlin = NULL, *d_dtotw = NULL; size_t dq_cap = 0, dl_cap = 0, dt_cap = 0;
+  double *d_state_in = NULL, *d_state_out = NULL; size_t si_cap = 0, so_cap = 0;
   int64_t last_rows = 0;
 };
 
@@ -533,7 +586,7 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
   kamd::IvDev &v = e->dev;
   v.feat_dim = dim; v.L = d.splice_left; v.R = d.splice_right; v.sd = sd; v.D = D; v.affine = d.lda_cols == sd + 1;
   v.ldaT = e->d_ldaT; v.gsum = e->d_gsum; v.gcount = d.global_cmvn_stats[dim];
-  v.cmn_window = d.cmn_window; v.global_frames = d.global_frames; v.normalize_mean = d.normalize_mean;
+  v.cmn_window = d.cmn_window; v.speaker_frames = d.speaker_frames; v.global_frames = d.global_frames; v.normalize_mean = d.normalize_mean;
   v.G = G; v.gconsts = e->d_gconsts; v.mivT = e->d_mivT; v.ivT = e->d_ivT;
   v.I = I; v.Q = Q; v.U = e->d_U; v.SM = e->d_SM;
   v.prior_offset = d.prior_offset; v.max_count = d.max_count;
@@ -551,7 +604,7 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
 void kamd_ivector_extractor_destroy(kamd_ivector_extractor *h) {
   IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
   if (!e) return;
-  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_S, e->d_nl, e->d_rl, e->d_pg, e->d_pw, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw};
+  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_S, e->d_nl, e->d_rl, e->d_pg, e->d_pw, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw, e->d_state_in, e->d_state_out};
   for (void *p : ps) if (p) (void)hipFree(p);
   delete e;
 }
@@ -563,8 +616,19 @@ int kamd_ivector_num_ivectors(const kamd_ivector_extractor *h, int num_frames) {
   return num_frames <= 0 ? 0 : (num_frames + P - 1) / P;
 }
 
+int kamd_ivector_state_size(const kamd_ivector_extractor *h) {
+  const kamd::IvDev &v = reinterpret_cast<const IvExtractor *>(h)->dev;
+  return 2 * (v.feat_dim + 1) + v.Q + v.I + 1;
+}
+
 int kamd_ivector_extract_online_device(kamd_ivector_extractor *h, const float *d_feats, const int64_t *h_row_off, int ld_feat,
                                        int n_utts, float *d_out, const int64_t *h_out_row_off, void *stream) {
+  return kamd_ivector_extract_online_adapt_device(h, d_feats, h_row_off, ld_feat, n_utts, d_out, h_out_row_off, NULL, NULL, stream);
+}
+
+int kamd_ivector_extract_online_adapt_device(kamd_ivector_extractor *h, const float *d_feats, const int64_t *h_row_off, int ld_feat,
+                                             int n_utts, float *d_out, const int64_t *h_out_row_off, const double *h_state_in,
+                                             double *h_state_out, void *stream) {
   IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_utts <= 0) return KAMD_OK;
@@ -599,6 +663,18 @@ int kamd_ivector_extract_online_device(kamd_ivector_extractor *h, const float *d
   b.S = e->d_S; b.norm_lda = e->d_nl; b.raw_lda = e->d_rl; b.post_g = e->d_pg; b.post_w = e->d_pw; b.out = d_out;
   b.row_base = h_row_off[0]; b.out_base = h_out_row_off[0];
   b.dquad = e->d_dquad; b.dlin = e->d_dlin; b.dtotw = e->d_dtotw;
+  const int SS = kamd_ivector_state_size(h);
+  b.state_in = NULL; b.state_out = NULL; b.state_size = SS;
+  if (h_state_in) {
+    if (kamd::GrowDev(&e->d_state_in, &e->si_cap, static_cast<size_t>(n_utts) * SS) != KAMD_OK) return KAMD_ERR_HIP;
+    KAMD_HIP(hipMemcpyAsync(e->d_state_in, h_state_in, static_cast<size_t>(n_utts) * SS * 8, hipMemcpyHostToDevice, st));
+    KAMD_HIP(hipStreamSynchronize(st));
+    b.state_in = e->d_state_in;
+  }
+  if (h_state_out) {
+    if (kamd::GrowDev(&e->d_state_out, &e->so_cap, static_cast<size_t>(n_utts) * SS) != KAMD_OK) return KAMD_ERR_HIP;
+    b.state_out = e->d_state_out;
+  }
   hipLaunchKernelGGL(kamd::PrefixKernel, dim3(n_utts), dim3(256), 0, st, v, b);
   const size_t lds_front = static_cast<size_t>(2) * (kamd::IV_FT + v.L + v.R) * v.feat_dim * sizeof(float);
   hipLaunchKernelGGL(kamd::FrontKernel, dim3(kamd::CeilDiv(max_T, kamd::IV_FT), n_utts), dim3(256), lds_front, st, v, b);
@@ -611,10 +687,49 @@ int kamd_ivector_extract_online_device(kamd_ivector_extractor *h, const float *d
   hipLaunchKernelGGL(kamd::SolveKernel, dim3(n_utts), dim3(256), lds_solve, st, v, b);
   KAMD_HIP(hipGetLastError());
   e->last_rows = rows;
+  if (h_state_out) {
+    KAMD_HIP(hipMemcpyAsync(h_state_out, e->d_state_out, static_cast<size_t>(n_utts) * SS * 8, hipMemcpyDeviceToHost, st));
+    KAMD_HIP(hipStreamSynchronize(st));
+  }
+  return KAMD_OK;
+}
+
+// OnlineIvectorExtractorAdaptationState::LimitFrames (online2/online-ivector-feature.cc:96-117) with
+// OnlineIvectorEstimationStats::Scale (ivector/ivector-extractor.cc:671-694): host arithmetic on one state
+int kamd_ivector_state_limit_frames(const kamd_ivector_extractor *h, double *state, float max_remembered_frames) {
+  const IvExtractor *e = reinterpret_cast<const IvExtractor *>(h);
+  const kamd::IvDev &v = e->dev;
+  if (max_remembered_frames < 0) return kamd::SetError(KAMD_ERR_ARG, "max_remembered_frames < 0");
+  const int sdim = v.feat_dim + 1, I = v.I, Q = v.Q;
+  const float count = static_cast<float>(state[v.feat_dim]);
+  if (count > max_remembered_frames)
+    for (int k = 0; k < 2 * sdim; k++) state[k] *= max_remembered_frames / count;
+  double *quad = state + 2 * sdim, *lin = quad + Q, *nf = lin + I;
+  const float scaled = max_remembered_frames * v.post_scale;
+  if (*nf > scaled) {
+    const double scale = scaled / *nf, old_n = *nf;
+    *nf *= scale;
+    for (int q = 0; q < Q; q++) quad[q] *= scale;
+    for (int j = 0; j < I; j++) lin[j] *= scale;
+    double add_lin, add_diag;
+    if (v.max_count == 0.0) { add_lin = v.prior_offset * (1.0 - scale); add_diag = 1.0 - scale; }
+    else {
+      const double mc = v.max_count;
+      const double old_ps = scale * std::max(old_n, mc) / mc, new_ps = std::max(*nf, mc) / mc;
+      add_lin = v.prior_offset * (new_ps - old_ps); add_diag = new_ps - old_ps;
+    }
+    lin[0] += add_lin;
+    for (int i = 0; i < I; i++) quad[static_cast<size_t>(i) * (i + 1) / 2 + i] += add_diag;
+  }
   return KAMD_OK;
 }
 
 int kamd_ivector_extract_online(kamd_ivector_extractor *h, const float *feats, int num_frames, float *out, int out_rows_cap) {
+  return kamd_ivector_extract_online_adapt(h, feats, num_frames, out, out_rows_cap, NULL, NULL);
+}
+
+int kamd_ivector_extract_online_adapt(kamd_ivector_extractor *h, const float *feats, int num_frames, float *out, int out_rows_cap,
+                                      const double *state_in, double *state_out) {
   IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
   if (num_frames <= 0) return 0;
   const int n = kamd_ivector_num_ivectors(h, num_frames), I = e->dev.I, dim = e->dev.feat_dim;
@@ -629,7 +744,7 @@ int kamd_ivector_extract_online(kamd_ivector_extractor *h, const float *feats, i
   if (hipMemcpy(d_f, feats, static_cast<size_t>(num_frames) * dim * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
     rc = kamd::SetError(KAMD_ERR_HIP, "upload failed");
   const int64_t ro[2] = {0, num_frames}, oo[2] = {0, n};
-  if (rc == KAMD_OK) rc = kamd_ivector_extract_online_device(h, d_f, ro, dim, 1, d_o, oo, NULL);
+  if (rc == KAMD_OK) rc = kamd_ivector_extract_online_adapt_device(h, d_f, ro, dim, 1, d_o, oo, state_in, state_out, NULL);
   if (rc == KAMD_OK && hipMemcpy(out, d_o, static_cast<size_t>(n) * I * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
     rc = kamd::SetError(KAMD_ERR_HIP, "i-vector extraction failed: %s", hipGetErrorString(hipGetLastError()));
   (void)hipFree(d_f); (void)hipFree(d_o);

@@ -76,6 +76,10 @@ class IvectorExtractionInfo:
             raise KamdError("OnlineCmvnOptions::Check failed")
         self.ivector_dim = self.M.shape[2]
 
+    def state_size(self):
+        """doubles in an adaptation state: 2 x (feat_dim+1) speaker CMVN stats, packed quadratic term, linear term, count"""
+        return 2 * (self.feat_dim + 1) + self.ivector_dim * (self.ivector_dim + 1) // 2 + self.ivector_dim + 1
+
     def desc(self):
         d = abi.IvectorDesc()
         d.feat_dim, d.splice_left, d.splice_right = self.feat_dim, self.splice_left, self.splice_right
@@ -346,15 +350,28 @@ class IvectorExtractor:
     def num_ivectors(self, num_frames):
         return lib().kamd_ivector_num_ivectors(self._h, num_frames)
 
-    def extract_online(self, feats):
+    def extract_online(self, feats, state=None, return_state=False, max_remembered_frames=1000.0):
+        """[ceil(T / period) x dim] for one utterance.  state: the adaptation state the speaker's previous
+        utterance left (None = fresh); return_state: also the state after this utterance with LimitFrames
+        applied (--max-remembered-frames), ready for the speaker's next one."""
         f = np.ascontiguousarray(feats, np.float32)
         if f.ndim != 2 or f.shape[1] != self.info.feat_dim:
             raise KamdError("features must be [frames x %d]" % self.info.feat_dim)
         n = self.num_ivectors(f.shape[0])
         out = np.zeros((n, self.dim()), np.float32)
-        r = lib().kamd_ivector_extract_online(self._h, abi.fptr(f), f.shape[0], abi.fptr(out), n)
+        dp = C.POINTER(C.c_double)
+        si = np.ascontiguousarray(state, np.float64) if state is not None else None
+        if si is not None and si.size != self.info.state_size():
+            raise KamdError("adaptation state has %d entries, expected %d" % (si.size, self.info.state_size()))
+        so = np.zeros(self.info.state_size(), np.float64) if return_state else None
+        r = lib().kamd_ivector_extract_online_adapt(self._h, abi.fptr(f), f.shape[0], abi.fptr(out), n,
+                                                    si.ctypes.data_as(dp) if si is not None else None,
+                                                    so.ctypes.data_as(dp) if so is not None else None)
         if r < 0:
             raise KamdError(lib().kamd_last_error().decode())
+        if return_state:
+            check(lib().kamd_ivector_state_limit_frames(self._h, so.ctypes.data_as(dp), max_remembered_frames))
+            return out[:r], so
         return out[:r]
 
     def last_posteriors(self, frames):

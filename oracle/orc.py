@@ -44,7 +44,9 @@ def lib():
         L.orc_nnet_forward_chunked.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int,
                                                C.c_int, C.c_int, C.c_int, fp, C.c_int]
         dp = C.POINTER(C.c_double)
-        L.orc_ivector_extract_online.argtypes = [C.POINTER(abi.IvectorDesc), fp, C.c_int, fp, C.c_int, fp, fp, ip, fp, ip]
+        L.orc_ivector_extract_online.argtypes = [C.POINTER(abi.IvectorDesc), fp, C.c_int, fp, C.c_int, fp, fp, ip, fp, ip, dp, dp]
+        L.orc_ivector_state_limit_frames.argtypes = [C.POINTER(abi.IvectorDesc), dp, C.c_float]
+        L.orc_ivector_state_limit_frames.restype = None
         L.orc_linear_cgd.argtypes = [C.c_int, C.c_int, dp, dp, dp]
         L.orc_online_cmvn.argtypes = [C.POINTER(abi.IvectorDesc), fp, C.c_int, fp]
         L.orc_online_cmvn.restype = None
@@ -125,8 +127,10 @@ def nnet_forward_chunked(model, feats, online_ivectors, ivector_period=10, frame
     return out
 
 
-def ivector_extract_online(info, feats, diagnostics=False):
-    """ivector-extract-online2 for one utterance (fresh adaptation state): [ceil(T/period) x dim]."""
+def ivector_extract_online(info, feats, diagnostics=False, state=None, return_state=False, max_remembered_frames=1000.0):
+    """ivector-extract-online2 for one utterance: [ceil(T/period) x dim].  state = the adaptation state
+    left by the speaker's previous utterance (None: fresh); return_state: also the state after this
+    one, LimitFrames applied, as the binary carries it to the speaker's next utterance."""
     f = np.ascontiguousarray(feats, np.float32)
     T = f.shape[0]
     d = info.desc()
@@ -136,12 +140,21 @@ def ivector_extract_online(info, feats, diagnostics=False):
     nl, rl = np.zeros((T, D), np.float32), np.zeros((T, D), np.float32)
     pg, pw = np.zeros((T, ng), np.int32), np.zeros((T, ng), np.float32)
     worse = C.c_int32()
+    dp = C.POINTER(C.c_double)
+    ss = info.state_size()
+    st_in = np.ascontiguousarray(state, np.float64) if state is not None else None
+    st_out = np.zeros(ss, np.float64)
     r = lib().orc_ivector_extract_online(C.byref(d), abi.fptr(f), T, abi.fptr(out), n, abi.fptr(nl), abi.fptr(rl), abi.iptr(pg),
-                                         abi.fptr(pw), C.byref(worse))
+                                         abi.fptr(pw), C.byref(worse), st_in.ctypes.data_as(dp) if st_in is not None else None,
+                                         st_out.ctypes.data_as(dp))
     assert r == n, r
+    if return_state:
+        lib().orc_ivector_state_limit_frames(C.byref(d), st_out.ctypes.data_as(dp), max_remembered_frames)
     if diagnostics:
-        return out, dict(norm_lda=nl, raw_lda=rl, post_gauss=pg, post_weight=pw, cg_got_worse=worse.value)
-    return out
+        res = out, dict(norm_lda=nl, raw_lda=rl, post_gauss=pg, post_weight=pw, cg_got_worse=worse.value)
+    else:
+        res = out
+    return (res, st_out) if return_state else res
 
 
 def linear_cgd(A_packed, b, x0, max_iters):

@@ -112,7 +112,7 @@ struct Extractor {
 };
 
 // OnlineCmvn over a whole matrix, frame by frame with the sliding window the reference keeps
-void OnlineCmvn(const Desc &d, const float *feats, int T, std::vector<float> *out) {
+void OnlineCmvn(const Desc &d, const float *feats, int T, std::vector<float> *out, const double *speaker_stats = NULL) {
   const int dim = d.feat_dim;
   out->assign(static_cast<size_t>(T) * dim, 0.f);
   std::vector<double> sum(dim, 0.0);
@@ -128,7 +128,17 @@ void OnlineCmvn(const Desc &d, const float *feats, int T, std::vector<float> *ou
     }
     std::vector<double> st(sum);
     double cnt = count;
-    if (cnt < d.cmn_window) {                 // SmoothOnlineCmvnStats; no speaker stats (fresh state)
+    if (cnt < d.cmn_window && speaker_stats != NULL) {      // SmoothOnlineCmvnStats: speaker stats first
+      double from_speaker = d.cmn_window - cnt;
+      const double speaker_count = speaker_stats[dim];
+      if (from_speaker > d.speaker_frames) from_speaker = d.speaker_frames;
+      if (from_speaker > speaker_count) from_speaker = speaker_count;
+      if (from_speaker > 0.0) {
+        for (int k = 0; k < dim; k++) st[k] += from_speaker / speaker_count * speaker_stats[k];
+        cnt += from_speaker / speaker_count * speaker_count;
+      }
+    }
+    if (cnt < d.cmn_window) {                 // ... then the global stats
       double from_global = d.cmn_window - cnt;
       const double gcount = gs[dim];
       if (from_global > d.global_frames) from_global = d.global_frames;
@@ -269,8 +279,12 @@ extern "C" {
 
 // diag outputs may be NULL.  norm_lda / raw_lda: [T x lda_rows]; post_g / post_w: [T x num_gselect]
 // (gaussian -1 = empty).  Returns the number of i-vector rows written (ceil(T / period)).
+// state_in / state_out (either may be NULL = fresh / not wanted): OnlineIvectorExtractorAdaptationState as
+// doubles [2 x (feat_dim+1) speaker CMVN stats | packed quadratic term | linear term | num_frames]
+// (GetAdaptationState / SetAdaptationState, online2/online-ivector-feature.cc:400-435; without LimitFrames).
 int orc_ivector_extract_online(const kamd_ivector_desc *desc, const float *feats, int T, float *out, int out_rows_cap,
-                               float *norm_lda, float *raw_lda, int32_t *post_g, float *post_w, int *cg_got_worse) {
+                               float *norm_lda, float *raw_lda, int32_t *post_g, float *post_w, int *cg_got_worse,
+                               const double *state_in, double *state_out) {
   const Desc &d = *desc;
   if (T <= 0) return 0;
   const int P = d.ivector_period, n_iv = (T + P - 1) / P, I = d.ivector_dim, D = d.lda_rows;
@@ -278,12 +292,20 @@ int orc_ivector_extract_online(const kamd_ivector_desc *desc, const float *feats
   if (d.normalize_variance) return -2;
   Extractor e(d);
   std::vector<float> cm, nl, rl;
-  OnlineCmvn(d, feats, T, &cm);
+  const int sdim = d.feat_dim + 1, Qn = I * (I + 1) / 2;
+  const bool have_spk = state_in != NULL && state_in[d.feat_dim] > 0.0;
+  OnlineCmvn(d, feats, T, &cm, have_spk ? state_in : NULL);
   SpliceLda(d, cm.data(), T, &nl);
   SpliceLda(d, feats, T, &rl);
   if (norm_lda) memcpy(norm_lda, nl.data(), nl.size() * sizeof(float));
   if (raw_lda) memcpy(raw_lda, rl.data(), rl.size() * sizeof(float));
   Stats st(I, d.prior_offset, d.max_count);
+  if (state_in != NULL) {
+    const double *q = state_in + 2 * sdim;
+    st.quad.assign(q, q + Qn);
+    st.lin.assign(q + Qn, q + Qn + I);
+    st.num_frames = q[Qn + I];
+  }
   std::vector<double> cur(I, 0.0);
   std::vector<float> ll;
   int worse_total = 0;
@@ -319,7 +341,49 @@ int orc_ivector_extract_online(const kamd_ivector_desc *desc, const float *feats
     }
   }
   if (cg_got_worse) *cg_got_worse = worse_total;
+  if (state_out != NULL) {
+    // OnlineCmvn::GetState(T - 1): the incoming speaker stats plus every frame of this utterance
+    for (int k = 0; k < 2 * sdim; k++) state_out[k] = state_in != NULL ? state_in[k] : 0.0;
+    for (int t = 0; t < T; t++) {
+      for (int k = 0; k < d.feat_dim; k++) {
+        const double v = feats[static_cast<size_t>(t) * d.feat_dim + k];
+        state_out[k] += v; state_out[sdim + k] += v * v;
+      }
+      state_out[d.feat_dim] += 1.0;
+    }
+    double *q = state_out + 2 * sdim;
+    std::copy(st.quad.begin(), st.quad.end(), q);
+    std::copy(st.lin.begin(), st.lin.end(), q + Qn);
+    q[Qn + I] = st.num_frames;
+  }
   return n_iv;
+}
+
+// OnlineIvectorExtractorAdaptationState::LimitFrames (online2/online-ivector-feature.cc:96-117) with
+// OnlineIvectorEstimationStats::Scale (ivector/ivector-extractor.cc:671-694), in place
+void orc_ivector_state_limit_frames(const kamd_ivector_desc *desc, double *state, float max_remembered_frames) {
+  const Desc &d = *desc;
+  const int sdim = d.feat_dim + 1, I = d.ivector_dim, Qn = I * (I + 1) / 2;
+  const float count = static_cast<float>(state[d.feat_dim]);
+  if (count > max_remembered_frames)
+    for (int k = 0; k < 2 * sdim; k++) state[k] *= max_remembered_frames / count;
+  double *quad = state + 2 * sdim, *lin = quad + Qn, *nf = lin + I;
+  const float scaled = max_remembered_frames * d.posterior_scale;
+  if (*nf > scaled) {
+    const double scale = scaled / *nf, old_n = *nf;
+    *nf *= scale;
+    for (int q = 0; q < Qn; q++) quad[q] *= scale;
+    for (int j = 0; j < I; j++) lin[j] *= scale;
+    if (d.max_count == 0.0) {
+      lin[0] += d.prior_offset * (1.0 - scale);
+      for (int i = 0; i < I; i++) quad[Tri(i, i)] += 1.0 - scale;
+    } else {
+      const double mc = d.max_count;
+      const double old_ps = scale * std::max(old_n, mc) / mc, new_ps = std::max(*nf, mc) / mc;
+      lin[0] += d.prior_offset * (new_ps - old_ps);
+      for (int i = 0; i < I; i++) quad[Tri(i, i)] += new_ps - old_ps;
+    }
+  }
 }
 
 // pieces, for the closed-form tests

@@ -128,3 +128,58 @@ def test_latgen_tool_with_device_ivectors_and_with_online_ivector_archives(tmp_p
     got = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(tmp_path / "w1.txt")}
     for i in range(2):
         assert got["utt%d" % i] == ref[i]["words"].tolist()
+
+
+@pytest.mark.parametrize("max_count", [0.0, 3.0])
+def test_speaker_adaptation_state_carried_across_utterances(max_count):
+    """ivector-extract-online2 with a spk2utt that groups utterances: the second and third utterance
+    start from the CMVN speaker statistics and the i-vector statistics the earlier ones left
+    (LimitFrames applied in between), on the device as in the oracle."""
+    info = ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=40, ivector_dim=10, seed=4, splice_left=2, splice_right=1,
+                                  cmn_window=60, speaker_frames=40, global_frames=10, max_count=max_count, ivector_period=5)
+    ie = ivector.IvectorExtractor(info)
+    rng = np.random.default_rng(7)
+    utts = [(rng.standard_normal((T, 8)) * 1.2 + 0.5).astype(np.float32) for T in (90, 31, 140)]
+    st_d, st_o = None, None
+    for i, x in enumerate(utts):
+        got, st_d = ie.extract_online(x, state=st_d, return_state=True, max_remembered_frames=100.0)
+        want, st_o = orc.ivector_extract_online(info, x, state=st_o, return_state=True, max_remembered_frames=100.0)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-4 * max(1.0, np.abs(want).max()))
+        np.testing.assert_allclose(st_d, st_o, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(st_o).max()))
+        if i > 0:   # the carried state matters: a fresh start gives something else
+            fresh = ie.extract_online(x)
+            assert np.abs(fresh[0] - got[0]).max() > 1e-3
+    # LimitFrames: the speaker's CMVN count is scaled back to max_remembered_frames (float arithmetic, as there)
+    assert abs(st_d[8] - 100.0) < 1e-3
+
+
+def test_ivector_extract_online2_tool(tmp_path):
+    """spk2utt with two speakers (two and one utterances), features from an scp: the archive written equals
+    the oracle run utterance by utterance with the speaker's state carried over."""
+    import subprocess
+    import sys
+    import os
+    from kaldi_amd import table
+    info = ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=40, ivector_dim=10, seed=4, splice_left=2, splice_right=1, max_count=5.0)
+    conf = ivector.write_config_dir(tmp_path / "ie", info)
+    rng = np.random.default_rng(9)
+    feats = {"a1": 47, "a2": 130, "b1": 80}
+    feats = {k: (rng.standard_normal((T, 8)) + 0.2).astype(np.float32) for k, T in feats.items()}
+    with table.TableWriter("ark,scp:%s,%s" % (tmp_path / "f.ark", tmp_path / "f.scp"), "matrix") as w:
+        for k in ("a1", "a2", "b1"):
+            w.write(k, feats[k])
+    (tmp_path / "spk2utt").write_text("spkA a1 a2\nspkB b1\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, root + "/tools/ivector_extract_online2.py", "--config=%s" % conf, "--max-remembered-frames=60",
+                        "ark:%s" % (tmp_path / "spk2utt"), "scp:%s" % (tmp_path / "f.scp"), "ark:%s" % (tmp_path / "iv.ark")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Estimated iVectors for 3 files, 0 with errors." in r.stderr
+    got = list(table.SequentialTableReader("ark:%s" % (tmp_path / "iv.ark"), "matrix"))
+    assert [k for k, _ in got] == ["a1", "a2", "b1"]
+    got = dict(got)
+    w1, st = orc.ivector_extract_online(info, feats["a1"], return_state=True, max_remembered_frames=60.0)
+    w2 = orc.ivector_extract_online(info, feats["a2"], state=st)
+    w3 = orc.ivector_extract_online(info, feats["b1"])
+    for k, w in (("a1", w1), ("a2", w2), ("b1", w3)):
+        np.testing.assert_allclose(got[k], w, rtol=0, atol=1e-4 * max(1.0, np.abs(w).max()))
