@@ -30,7 +30,7 @@ def counter(dirname, name, kernel):
     return vals
 
 
-for name in ("default", "light", "saturated", "b256", "b512"):
+for name in ("default", "light", "saturated", "b256", "b512", "ivectors"):
     d = line(os.path.join(R, "bench_%s.json" % name))
     if d:
         json.dump(d, open(os.path.join(P, "%s_bench_%s.json" % (tag, name)), "w"), indent=1)
@@ -39,6 +39,8 @@ if d:
     json.dump(d, open(os.path.join(P, "%s_bench_under_rocprof.json" % tag), "w"), indent=1)
 for f in glob.glob(os.path.join(R, "stats", "**", "*kernel_stats.csv"), recursive=True):
     shutil.copy(f, os.path.join(P, "%s_kernel_stats_bench_default.csv" % tag))
+for f in glob.glob(os.path.join(R, "stats_iv", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(P, "%s_kernel_stats_bench_ivectors.csv" % tag))
 base = line(os.path.join(R, "bench_default.json"))
 out = {"round": tag, "device": "MI355X (gfx950), ROCm 7.2",
        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 "

@@ -19,6 +19,9 @@ for cfg in "light --ll-std 2.0" "saturated --ll-std 1.0" "b256 --utts 256" "b512
   set -- $cfg; name=$1; shift
   timeout 400 python3 bench.py --no-cpu-baseline "$@" > $O/bench_$name.json 2> $O/bench_$name.err
 done
+# the i-vector variant (secondary measurement): bench line + kernel stats
+timeout 400 python3 bench.py --ivectors --ll-std 1.8 --no-cpu-baseline > $O/bench_ivectors.json 2> $O/bench_ivectors.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_iv -o run -- python3 bench.py --ivectors --ll-std 1.8 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_ivectors_under_rocprof.json 2> $O/stats_iv.err
 # keep the merged directory small: only the per-kernel CSVs
 find $O -name "*_kernel_trace.csv" -size +20M -delete
 ls -la $O $O/*/* 2>/dev/null | head -40
