@@ -556,5 +556,45 @@ class SingleUtteranceNnet3Decoder {
   bool finished_;
 };
 
+// ---- online i-vectors: OnlineIvectorFeature over a whole utterance (online2/online-ivector-feature.h:246-330)
+// with the speaker's OnlineIvectorExtractorAdaptationState, as ivector-extract-online2 uses it.
+class OnlineIvectorExtractorAdaptationState {
+ public:
+  bool empty() const { return state_.empty(); }
+  std::vector<double> state_;          // kamd_ivector_state_size() doubles once set
+};
+class OnlineIvectorExtractor {
+ public:
+  // desc: the fields of OnlineIvectorExtractionInfo (lda_mat, global_cmvn_stats, diag_ubm, extractor M_ / Sigma_inv_, options)
+  explicit OnlineIvectorExtractor(const kamd_ivector_desc &desc, BaseFloat max_remembered_frames = 1000.0)
+      : h_(kamd_ivector_extractor_create(&desc)), max_remembered_frames_(max_remembered_frames) {
+    if (!h_) throw KaldiFatalError(kamd_last_error());
+  }
+  ~OnlineIvectorExtractor() { kamd_ivector_extractor_destroy(h_); }
+  OnlineIvectorExtractor(const OnlineIvectorExtractor &) = delete;
+  OnlineIvectorExtractor &operator=(const OnlineIvectorExtractor &) = delete;
+  int32 Dim() const { return kamd_ivector_dim(h_); }
+  int32 NumIvectors(int32 num_frames) const { return kamd_ivector_num_ivectors(h_, num_frames); }
+  // feats: [num_frames x feat_dim] row-major; ivectors: resized to [NumIvectors x Dim()].  adaptation_state (may be
+  // NULL) is read if set (SetAdaptationState) and replaced by the state after this utterance with LimitFrames
+  // applied (GetAdaptationState), ready for the speaker's next utterance.
+  void ExtractOnline(const float *feats, int32 num_frames, std::vector<float> *ivectors,
+                     OnlineIvectorExtractorAdaptationState *adaptation_state = NULL) {
+    const int32 n = NumIvectors(num_frames);
+    ivectors->assign(static_cast<size_t>(n) * Dim(), 0.0f);
+    std::vector<double> out_state(adaptation_state ? kamd_ivector_state_size(h_) : 0);
+    const double *in = (adaptation_state && !adaptation_state->empty()) ? adaptation_state->state_.data() : NULL;
+    Check(kamd_ivector_extract_online_adapt(h_, feats, num_frames, ivectors->data(), n, in, adaptation_state ? out_state.data() : NULL));
+    if (adaptation_state) {
+      Check(kamd_ivector_state_limit_frames(h_, out_state.data(), max_remembered_frames_));
+      adaptation_state->state_.swap(out_state);
+    }
+  }
+  kamd_ivector_extractor *handle() { return h_; }
+ private:
+  kamd_ivector_extractor *h_;
+  BaseFloat max_remembered_frames_;
+};
+
 }  // namespace kaldi_amd
 #endif  // KALDI_AMD_HPP_

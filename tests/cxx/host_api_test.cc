@@ -108,6 +108,32 @@ int main(int argc, char **argv) {
         printf("wrapper ok=%d like=%.6g\n", ok, like);
       }
     }
+    // online i-vectors with the speaker's adaptation state: two utterances of one speaker (third fixture)
+    if (argc >= 5) {
+      FILE *xf = fopen(argv[4], "rb");
+      if (!xf) return 2;
+      std::vector<int32> ih = ReadVec<int32>(xf);   // feat_dim L R lda_rows lda_cols G I period ng cg T1 T2 cmn_window speaker_frames global_frames
+      std::vector<float> lda = ReadVec<float>(xf), gc = ReadVec<float>(xf), miv = ReadVec<float>(xf), iv = ReadVec<float>(xf);
+      std::vector<double> gstats = ReadVec<double>(xf), M = ReadVec<double>(xf), sinv = ReadVec<double>(xf), sc = ReadVec<double>(xf);
+      std::vector<float> f1 = ReadVec<float>(xf), f2 = ReadVec<float>(xf);
+      fclose(xf);
+      kamd_ivector_desc d;
+      memset(&d, 0, sizeof(d));
+      d.feat_dim = ih[0]; d.splice_left = ih[1]; d.splice_right = ih[2]; d.lda_rows = ih[3]; d.lda_cols = ih[4]; d.lda = lda.data();
+      d.global_cmvn_stats = gstats.data(); d.cmn_window = ih[12]; d.speaker_frames = ih[13]; d.global_frames = ih[14];
+      d.normalize_mean = 1; d.num_gauss = ih[5]; d.ubm_gconsts = gc.data(); d.ubm_means_invvars = miv.data(); d.ubm_inv_vars = iv.data();
+      d.ivector_dim = ih[6]; d.M = M.data(); d.sigma_inv = sinv.data(); d.prior_offset = sc[0];
+      d.ivector_period = ih[7]; d.num_gselect = ih[8]; d.num_cg_iters = ih[9];
+      d.min_post = static_cast<float>(sc[1]); d.posterior_scale = static_cast<float>(sc[2]); d.max_count = static_cast<float>(sc[3]);
+      OnlineIvectorExtractor extractor(d, 60.0);
+      OnlineIvectorExtractorAdaptationState state;
+      std::vector<float> out;
+      extractor.ExtractOnline(f1.data(), ih[10], &out, &state);
+      extractor.ExtractOnline(f2.data(), ih[11], &out, &state);
+      printf("ivector rows=%d dim=%d", extractor.NumIvectors(ih[11]), extractor.Dim());
+      for (int k = 0; k < extractor.Dim(); k++) printf(" %.9g", out[out.size() - extractor.Dim() + k]);
+      printf("\n");
+    }
     // streaming: SingleUtteranceNnet3Decoder fed in 0.18 s chunks (model + waveform from a second fixture)
     if (argc >= 4) {
       FILE *mf = fopen(argv[3], "rb");

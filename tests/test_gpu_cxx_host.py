@@ -54,8 +54,30 @@ def test_cxx_host_api(tmp_path):
                 a = getattr(l, nm)
                 vec(f, np.zeros(0, np.float32) if a is None else np.ascontiguousarray(a, np.float32))
         vec(f, wave.astype(np.float32))
+    # third fixture: a small i-vector extractor and two utterances of one speaker
+    from kaldi_amd import ivector
+    info = ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=40, ivector_dim=10, seed=4, splice_left=2, splice_right=1, max_count=5.0,
+                                  cmn_window=60, speaker_frames=40, global_frames=10)
+    rng = np.random.default_rng(9)
+    f1, f2 = [(rng.standard_normal((T, 8)) + 0.2).astype(np.float32) for T in (47, 95)]
+    xfx = tmp_path / "ivector.bin"
+    with open(xfx, "wb") as f:
+        vec(f, np.asarray([8, 2, 1, info.lda.shape[0], info.lda.shape[1], 40, 10, info.ivector_period, info.num_gselect, info.num_cg_iters,
+                           47, 95, 60, 40, 10], np.int32))
+        for a in (info.lda, info.ubm_gconsts, info.ubm_means_invvars, info.ubm_inv_vars):
+            vec(f, np.ascontiguousarray(a, np.float32))
+        for a in (info.global_cmvn_stats, info.M, info.sigma_inv, np.asarray([info.prior_offset, info.min_post, info.posterior_scale, info.max_count])):
+            vec(f, np.ascontiguousarray(a, np.float64))
+        vec(f, f1); vec(f, f2)
     exe = build_cxx(str(tmp_path))
-    out = subprocess.check_output([exe, str(fx), str(tmp_path), str(mfx)], text=True, stderr=subprocess.DEVNULL).strip().splitlines()
+    out = subprocess.check_output([exe, str(fx), str(tmp_path), str(mfx), str(xfx)], text=True, stderr=subprocess.DEVNULL).strip().splitlines()
+    ie = ivector.IvectorExtractor(info)
+    _, st = ie.extract_online(f1, return_state=True, max_remembered_frames=60.0)
+    want_iv = ie.extract_online(f2, state=st)
+    iv_line = [l for l in out if l.startswith("ivector ")][0].split()
+    assert iv_line[1:3] == ["rows=%d" % want_iv.shape[0], "dim=10"]
+    np.testing.assert_array_equal(np.asarray([float(x) for x in iv_line[3:]], np.float32), want_iv[-1])
+    out = [l for l in out if not l.startswith("ivector ")]
     o = orc.Decoder(g, abi.decoder_config_recipe(), 1)
     o.Decode(ll)
     lat = o.GetRawLattice()

@@ -33,6 +33,23 @@ def test_small_extractor_matches_oracle(opts):
         check(info, ie, (rng.standard_normal((T, 8)) * 1.5 + 0.3).astype(np.float32))
 
 
+@pytest.mark.parametrize("shape", [dict(feat_dim=13, lda_dim=20, num_gauss=130, ivector_dim=128, num_gselect=8, ivector_period=3),
+                                   dict(feat_dim=80, lda_dim=24, num_gauss=64, ivector_dim=65, splice_left=0, splice_right=0),
+                                   dict(feat_dim=5, lda_dim=5, num_gauss=3, ivector_dim=1, num_gselect=5, min_post=0.0)])
+def test_extractor_shapes_at_the_limits(shape):
+    """the largest i-vector dimension (two rows per lane), more Gaussians than lanes but not a multiple of 64,
+    num_gselect 8 and more than there are Gaussians, no splicing, a 1-dimensional i-vector, min_post 0"""
+    info = ivector.make_synthetic(seed=8, **shape)
+    ie = ivector.IvectorExtractor(info)
+    rng = np.random.default_rng(3)
+    for T in (1, 7, 64):
+        check(info, ie, (rng.standard_normal((T, shape["feat_dim"])) * 1.3).astype(np.float32))
+    with pytest.raises(Exception):
+        ivector.IvectorExtractor(ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=8, ivector_dim=129))
+    with pytest.raises(Exception):
+        ivector.IvectorExtractor(ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=8, ivector_dim=10, normalize_variance=True))
+
+
 def test_recipe_size_extractor_on_mfcc_features():
     """hires MFCC 40 -> splice +-3 -> LDA 40 -> 512 Gaussians -> 100-dim i-vectors, period 10."""
     op = abi.mfcc_opts_hires()
