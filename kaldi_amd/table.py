@@ -123,14 +123,60 @@ def _read_wave_at(path, off):
     return kio.read_wave(path)
 
 
-_AT = {"matrix": _read_matrix_at, "int32": _read_int32_at, "wave": _read_wave_at}
-_ARK = {"matrix": kio.read_matrix_ark, "int32": kio.read_int32_vector_ark,
+def _parse_vector(buf, pos):
+    """Vector<float>::Read (matrix/kaldi-vector.cc:1113-1230) at buf[pos:]: binary FV / DV or text " [ 1 2 3 ]".
+    -> (vector, position after it)"""
+    import struct
+    if buf[pos:pos + 2] == b"\0B":
+        tok = buf[pos + 2:pos + 5]
+        if tok not in (b"FV ", b"DV ") or buf[pos + 5] != 4:
+            raise KamdError("vector expected, got %r" % tok)
+        n = struct.unpack_from("<i", buf, pos + 6)[0]
+        w = 4 if tok == b"FV " else 8
+        v = np.frombuffer(buf, "<f4" if w == 4 else "<f8", n, pos + 10).astype(np.float32)
+        return v, pos + 10 + w * n
+    e = buf.index(b"]", pos)
+    txt = buf[pos:e].decode().replace("[", " ").split()
+    nl = buf.find(b"\n", e)
+    return np.asarray([float(x) for x in txt], np.float32), (nl + 1 if nl >= 0 else len(buf))
+
+
+def _read_vector_at(path, off):
+    with open(path, "rb") as f:
+        f.seek(off)
+        return _parse_vector(f.read(), 0)[0]
+
+
+def _read_vector_ark(path):
+    buf = open(path, "rb").read()
+    pos = 0
+    while True:
+        while pos < len(buf) and buf[pos:pos + 1] in (b" ", b"\n"):
+            pos += 1
+        if pos >= len(buf):
+            return
+        e = buf.index(b" ", pos)
+        key = buf[pos:e].decode()
+        v, pos = _parse_vector(buf, e + 1)
+        yield key, v
+
+
+def _read_token_ark(path):
+    """TokenHolder / TokenVectorHolder text archives (utt2spk, spk2utt): key, then the tokens of the line"""
+    for line in open(path):
+        parts = line.split()
+        if parts:
+            yield parts[0], parts[1:]
+
+
+_AT = {"matrix": _read_matrix_at, "int32": _read_int32_at, "wave": _read_wave_at, "vector": _read_vector_at}
+_ARK = {"matrix": kio.read_matrix_ark, "int32": kio.read_int32_vector_ark, "vector": _read_vector_ark, "tokens": _read_token_ark,
         "lattice": lambda path: ((k, (start, final, arcs)) for k, start, final, arcs in kio.read_lattices(path))}
 
 
 class SequentialTableReader:
     """for key, value in SequentialTableReader("ark:feats.ark" | "scp:wav.scp" | "ark:gunzip -c x.gz |", kind)
-    kind: "matrix" | "int32" | "wave" | "lattice".  With the `p` (permissive) option scp entries
+    kind: "matrix" | "vector" | "int32" | "wave" | "lattice" | "tokens" (text lines: utt2spk, spk2utt).  With the `p` (permissive) option scp entries
     that cannot be read are skipped, as the reference does; otherwise they raise."""
 
     def __init__(self, rspecifier, kind):

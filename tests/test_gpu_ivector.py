@@ -138,8 +138,23 @@ def test_latgen_tool_with_device_ivectors_and_with_online_ivector_archives(tmp_p
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(tmp_path / "w1.txt").read() == open(tmp_path / "w2.txt").read()
     assert open(tmp_path / "lat1.ark", "rb").read() == open(tmp_path / "lat2.ark", "rb").read()
+    # --ivectors + --utt2spk: one constant i-vector per speaker (RandomAccessBaseFloatVectorReaderMapped)
+    spk_iv = np.linspace(-1, 1, 20).astype(np.float32)
+    (tmp_path / "spk_iv.ark").write_text("spkA  [ " + " ".join("%.9g" % x for x in spk_iv) + " ]\n")
+    (tmp_path / "utt2spk").write_text("utt0 spkA\nutt1 spkA\n")
+    r = subprocess.run(tool[:6] + ["--ivectors=ark:%s" % (tmp_path / "spk_iv.ark"), "--utt2spk=ark:%s" % (tmp_path / "utt2spk")] + tool[6:] +
+                       ["ark:%s" % (tmp_path / "lat3.ark"), "ark,t:%s" % (tmp_path / "w3.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
     g.tid2pdf = np.concatenate([[-1], np.stack([2 * np.arange(25) + 1, 2 * np.arange(25)], 1).reshape(-1)]).astype(np.int32)
     pipe = pipeline.Pipeline(op, m, g, abi.decoder_config_recipe(), max_utts=2, max_seconds=3.0)
+    pipe.load(waves)
+    pipe.set_ivectors([spk_iv, spk_iv])
+    pipe.run()
+    ref3 = pipe.results()
+    got3 = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(tmp_path / "w3.txt")}
+    for i in range(2):
+        assert got3["utt%d" % i] == ref3[i]["words"].tolist()
+    pipe.set_ivectors(None)
     pipe.set_ivector_extractor(ie, 50)
     ref = pipe.decode(waves)
     got = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(tmp_path / "w1.txt")}

@@ -209,3 +209,23 @@ def test_int32_and_wave_tables(tmp_path, binary):
         assert sf == 16000.0
         np.testing.assert_array_equal(data[0], pcm.astype(np.float32))
     assert not [p for p in os.listdir(os.environ.get("TMPDIR", "/tmp")) if p.startswith("kamd_rx_")]
+
+
+def test_vector_and_token_tables(tmp_path):
+    """per-utterance / per-speaker i-vector archives (binary FV, DV, text) and utt2spk-style token lines"""
+    import struct
+    ark = str(tmp_path / "iv.ark")
+    v1, v2, v3 = np.array([1.5, -2, 3], np.float32), np.array([0.25, 4], np.float64), np.array([7, 8.5, -9, 10], np.float32)
+    with open(ark, "wb") as f:
+        f.write(b"spk1 \0BFV \x04" + struct.pack("<i", 3) + v1.tobytes())
+        f.write(b"spk2 \0BDV \x04" + struct.pack("<i", 2) + v2.tobytes())
+        f.write(b"spk3  [ 7 8.5 -9 10 ]\n")
+    got = list(T.SequentialTableReader("ark:" + ark, "vector"))
+    assert [k for k, _ in got] == ["spk1", "spk2", "spk3"]
+    for (_, g), w in zip(got, (v1, v2, v3)):
+        np.testing.assert_array_equal(g, w.astype(np.float32))
+    off2 = open(ark, "rb").read().index(b"spk2 ") + 5
+    open(tmp_path / "iv.scp", "w").write("a %s:%d\n" % (ark, off2))
+    np.testing.assert_array_equal(T.RandomAccessTableReader("scp:%s" % (tmp_path / "iv.scp"), "vector")["a"], v2.astype(np.float32))
+    (tmp_path / "utt2spk").write_text("utt1 spk1\nutt2 spk1\nutt3 spk2\n")
+    assert dict(T.SequentialTableReader("ark:%s" % (tmp_path / "utt2spk"), "tokens")) == {"utt1": ["spk1"], "utt2": ["spk1"], "utt3": ["spk2"]}

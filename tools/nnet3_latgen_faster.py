@@ -46,9 +46,8 @@ def main(argv):
     model_in, fst_in, feat_rspec, lat_wspec = args[:4]
     words_wspec = args[4] if len(args) > 4 else ""
     ali_wspec = args[5] if len(args) > 5 else ""
-    if po["ivectors"]:
-        raise KamdError("--ivectors (one vector per utterance / speaker) needs a vector table reader, which is not built; "
-                        "use --online-ivectors")
+    if po["ivectors"] and (po["online-ivectors"] or po["ivector-extraction-config"]):
+        raise KamdError("--ivectors excludes --online-ivectors and --ivector-extraction-config")      # nnet3-latgen-faster.cc:88-92
     if po["online-ivectors"] and po["ivector-extraction-config"]:
         raise KamdError("--online-ivectors and --ivector-extraction-config exclude each other")
     if po["online-ivectors"] and po["online-ivector-period"] <= 0:
@@ -69,6 +68,9 @@ def main(argv):
         g = kio.read_openfst(path)
     g.tid2pdf, g.num_pdfs = id2pdf, model.num_pdfs
     ivecs = table.RandomAccessTableReader(po["online-ivectors"], "matrix") if po["online-ivectors"] else None
+    # RandomAccessBaseFloatVectorReaderMapped(ivector_rspecifier, utt2spk_rspecifier) (nnet3-latgen-faster.cc:135-137)
+    const_ivecs = table.RandomAccessTableReader(po["ivectors"], "vector") if po["ivectors"] else None
+    utt2spk = {k: v[0] for k, v in table.SequentialTableReader(po["utt2spk"], "tokens")} if po["utt2spk"] else None
     extractor = None
     if po["ivector-extraction-config"]:
         from kaldi_amd import ivector
@@ -87,8 +89,14 @@ def main(argv):
     def decode_batch(batch):
         nonlocal n_done, n_fail, tot_like, tot_frames
         keys = [k for k, _ in batch]
-        if ivecs is not None:
-            missing = [k for k in keys if k not in ivecs]
+        def ivkey(k):
+            if utt2spk is None:
+                return k
+            if k not in utt2spk:
+                raise KamdError("utterance %s not in the utt2spk map %s" % (k, po["utt2spk"]))
+            return utt2spk[k]
+        if ivecs is not None or const_ivecs is not None:
+            missing = [k for k in keys if (k not in ivecs if ivecs is not None else ivkey(k) not in const_ivecs)]
             for k in missing:
                 print("WARNING No iVectors available for utterance " + k, file=sys.stderr)     # nnet3-latgen-faster.cc:176-181
             n_fail += len(missing)
@@ -109,6 +117,8 @@ def main(argv):
             pipe.load_features(vals)
         if ivecs is not None:
             pipe.set_online_ivectors([ivecs[k] for k in keys], po["online-ivector-period"], po["frames-per-chunk"])
+        if const_ivecs is not None:
+            pipe.set_ivectors([const_ivecs[ivkey(k)] for k in keys])
         if extractor is not None:
             pipe.set_ivector_extractor(extractor, po["frames-per-chunk"])
         pipe.run(auto_grow=4)
