@@ -401,6 +401,19 @@ int kamd_ark_write_matrix(const char *path, int append, const char *key, int bin
 int kamd_ark_read_int32_vector(const char *path, int64_t *offset, char *key, int key_cap, int32_t *n,
                                int32_t **data);
 
+/* ----------------------------------------------------------------- CMVN -- */
+/* compute-cmvn-stats: AccCmvnStats (transform/cmvn.cc:30-62) over every utterance of a batch of device
+ * features; utterance u owns rows [row_off[u], row_off[u+1]).  h_stats: n_utts x [2 x (dim+1)] doubles
+ * (sums | count, sums of squares | unused), ACCUMULATED into (zero it for fresh statistics; pass a
+ * speaker's running statistics to add an utterance to them). */
+int kamd_cmvn_acc_stats_device(const float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts,
+                               double *h_stats, void *stream);
+/* apply-cmvn: ApplyCmvn (transform/cmvn.cc:64-118) in place, utterance u with statistics h_stats[u]
+ * (its own, its speaker's, or global ones).  norm_means = 0 leaves the features unchanged, as the
+ * binary does; norm_vars without norm_means is an error (featbin/apply-cmvn.cc:63-64). */
+int kamd_cmvn_apply_device(float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts,
+                           const double *h_stats, int norm_means, int norm_vars, void *stream);
+
 /* --------------------------------------------------- online i-vector extraction -- */
 /* OnlineIvectorFeature as ivector-extract-online2 drives it (online2/online-ivector-feature.cc:
  * 150-420, online2bin/ivector-extract-online2.cc:95-175; use_most_recent_ivector = false, no frame

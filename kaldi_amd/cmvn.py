@@ -1,0 +1,61 @@
+"""compute-cmvn-stats / apply-cmvn (transform/cmvn.cc:30-118, featbin/apply-cmvn.cc) on the device.
+Statistics are [2 x (dim+1)] float64 matrices as Kaldi stores them: row 0 sums and, in the last
+column, the count; row 1 sums of squares."""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import KamdError, check, lib
+
+
+class _Dev:
+    def __init__(self, host):
+        self.n = host.nbytes
+        self.p = lib().kamd_malloc(max(self.n, 4))
+        if not self.p:
+            raise KamdError(lib().kamd_last_error().decode())
+        check(lib().kamd_memcpy_h2d(self.p, host.ctypes.data_as(C.c_void_p), self.n))
+
+    def download(self, out):
+        check(lib().kamd_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.p, self.n))
+
+    def __del__(self):
+        if getattr(self, "p", None):
+            lib().kamd_free(self.p)
+            self.p = None
+
+
+def _batch(mats):
+    mats = [np.ascontiguousarray(m, np.float32) for m in mats]
+    dim = mats[0].shape[1]
+    if any(m.ndim != 2 or m.shape[1] != dim for m in mats):
+        raise KamdError("cmvn: feature matrices must share one dimension")
+    off = np.zeros(len(mats) + 1, np.int64)
+    off[1:] = np.cumsum([m.shape[0] for m in mats])
+    return mats, np.ascontiguousarray(np.concatenate(mats) if off[-1] else np.zeros((0, dim), np.float32)), off, dim
+
+
+def acc_stats(mats, stats=None):
+    """AccCmvnStats for every matrix; stats (optional): [n, 2, dim+1] running statistics to add to."""
+    mats, flat, off, dim = _batch(mats)
+    st = np.zeros((len(mats), 2, dim + 1), np.float64) if stats is None else np.array(stats, np.float64).reshape(len(mats), 2, dim + 1)
+    if off[-1] == 0:
+        return st
+    d = _Dev(flat)
+    check(lib().kamd_cmvn_acc_stats_device(d.p, abi.iptr(off, C.c_int64), dim, dim, len(mats), st.ctypes.data_as(C.POINTER(C.c_double)), None))
+    return st
+
+
+def apply(mats, stats, norm_means=True, norm_vars=False):
+    """ApplyCmvn: matrix i normalised with stats[i] ([2, dim+1]); returns new matrices."""
+    mats, flat, off, dim = _batch(mats)
+    st = np.ascontiguousarray(stats, np.float64).reshape(len(mats), 2, dim + 1)
+    if off[-1] == 0:
+        return [m.copy() for m in mats]
+    d = _Dev(flat)
+    check(lib().kamd_cmvn_apply_device(d.p, abi.iptr(off, C.c_int64), dim, dim, len(mats), st.ctypes.data_as(C.POINTER(C.c_double)),
+                                       int(norm_means), int(norm_vars), None))
+    out = np.zeros_like(flat)
+    d.download(out)
+    return [out[off[i]:off[i + 1]].copy() for i in range(len(mats))]

@@ -1,0 +1,126 @@
+// cmvn.hip -- compute-cmvn-stats / apply-cmvn on the device (transform/cmvn.cc:30-118), per utterance
+// of a batch whose features are already in HBM.  Elementwise, HBM-trivial: one pass to accumulate
+// [sum, sum of squares, count] in fp64, one pass x <- x * scale + offset.
+#include <vector>
+
+#include "common.h"
+
+namespace kamd {
+
+// stats[u] = [2][dim + 1] doubles: row 0 sums and (last column) the count, row 1 sums of squares
+__global__ __launch_bounds__(256) void CmvnStatsKernel(const float *feats, int ld, int dim, const int64_t *row_off, double *stats) {
+  __shared__ double s1[256], s2[256];
+  const int u = blockIdx.x, tid = threadIdx.x;
+  const int64_t r0 = row_off[u];
+  const int T = static_cast<int>(row_off[u + 1] - r0);
+  int dpw = 1;
+  while (dpw < dim) dpw <<= 1;
+  const int chunks = 256 / dpw, k = tid % dpw, c = tid / dpw;
+  double a = 0, b = 0;
+  if (k < dim)
+    for (int t = c; t < T; t += chunks) {
+      const float x = feats[(r0 + t) * ld + k];
+      a += static_cast<double>(x);                 // AccCmvnStats: *mean_ptr += *feats_ptr * weight, weight = 1
+      b += static_cast<double>(x * x);             //               *var_ptr += *feats_ptr * *feats_ptr * weight (float product)
+    }
+  s1[tid] = a; s2[tid] = b;
+  __syncthreads();
+  if (c == 0 && k < dim) {
+    for (int c2 = 1; c2 < chunks; c2++) { a += s1[c2 * dpw + k]; b += s2[c2 * dpw + k]; }
+    double *o = stats + static_cast<size_t>(u) * 2 * (dim + 1);
+    o[k] += a; o[dim + 1 + k] += b;
+    if (k == 0) o[dim] += static_cast<double>(T);
+  }
+}
+
+// ApplyCmvn (transform/cmvn.cc:64-118): means only: x + float(-sum / count); with variances:
+// x * float(1 / sqrt(var)) + float(-mean / sqrt(var)), var floored at 1e-20
+__global__ __launch_bounds__(256) void CmvnApplyKernel(float *feats, int ld, int dim, const int64_t *row_off, const double *stats,
+                                                       int norm_vars, int *bad) {
+  extern __shared__ float norm[];                  // offset[dim], scale[dim]
+  const int u = blockIdx.y, tid = threadIdx.x;
+  const int64_t r0 = row_off[u];
+  const int T = static_cast<int>(row_off[u + 1] - r0);
+  const double *st = stats + static_cast<size_t>(u) * 2 * (dim + 1);
+  const double count = st[dim];
+  if (count < 1.0) { if (tid == 0 && blockIdx.x == 0) atomicExch(bad, u + 1); return; }   // "Insufficient stats"
+  for (int k = tid; k < dim; k += 256) {
+    if (!norm_vars) { norm[k] = static_cast<float>(-1.0 / count * st[k]); norm[dim + k] = 1.0f; }
+    else {
+      const double mean = st[k] / count;
+      double var = st[dim + 1 + k] / count - mean * mean;
+      if (var < 1.0e-20) var = 1.0e-20;
+      const double scale = 1.0 / sqrt(var);
+      norm[k] = static_cast<float>(-(mean * scale)); norm[dim + k] = static_cast<float>(scale);
+    }
+  }
+  __syncthreads();
+  const int rows_per_block = 64;
+  const int t0 = blockIdx.x * rows_per_block, t1 = min(T, t0 + rows_per_block);
+  for (int i = tid; i < (t1 - t0) * dim; i += 256) {
+    const int t = t0 + i / dim, k = i % dim;
+    float x = feats[(r0 + t) * ld + k];
+    if (norm_vars) x = x * norm[dim + k];          // MulColsVec, then AddVecToRows: two roundings
+    feats[(r0 + t) * ld + k] = x + norm[k];
+  }
+}
+
+}  // namespace kamd
+
+extern "C" {
+
+int kamd_cmvn_acc_stats_device(const float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, double *h_stats,
+                               void *stream) {
+  if (!kamd::RequireDevice()) return KAMD_ERR_HIP;
+  if (n_utts <= 0) return KAMD_OK;
+  if (dim <= 0 || dim > 256 || ld < dim) return kamd::SetError(KAMD_ERR_ARG, "cmvn: bad feature dim / leading dimension");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t n = static_cast<size_t>(n_utts) * 2 * (dim + 1);
+  double *d_stats = NULL; int64_t *d_off = NULL;
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_stats), n * sizeof(double)));
+  if (hipMalloc(reinterpret_cast<void **>(&d_off), (n_utts + 1) * sizeof(int64_t)) != hipSuccess) { (void)hipFree(d_stats); return kamd::SetError(KAMD_ERR_HIP, "allocation failed"); }
+  int rc = KAMD_OK;
+  if (hipMemcpyAsync(d_stats, h_stats, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_off, h_row_off, (n_utts + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess)
+    rc = kamd::SetError(KAMD_ERR_HIP, "cmvn: upload failed");
+  if (rc == KAMD_OK) {
+    hipLaunchKernelGGL(kamd::CmvnStatsKernel, dim3(n_utts), dim3(256), 0, st, d_feats, ld, dim, d_off, d_stats);
+    if (hipMemcpyAsync(h_stats, d_stats, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      rc = kamd::SetError(KAMD_ERR_HIP, "cmvn: statistics kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  (void)hipFree(d_stats); (void)hipFree(d_off);
+  return rc;
+}
+
+int kamd_cmvn_apply_device(float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, const double *h_stats,
+                           int norm_means, int norm_vars, void *stream) {
+  if (!kamd::RequireDevice()) return KAMD_ERR_HIP;
+  if (n_utts <= 0) return KAMD_OK;
+  if (dim <= 0 || ld < dim) return kamd::SetError(KAMD_ERR_ARG, "cmvn: bad feature dim / leading dimension");
+  if (norm_vars && !norm_means) return kamd::SetError(KAMD_ERR_ARG, "You cannot normalize the variance but not the mean.");   // apply-cmvn.cc:63-64
+  if (!norm_means) return KAMD_OK;                 // apply-cmvn copies the features unchanged
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t n = static_cast<size_t>(n_utts) * 2 * (dim + 1);
+  double *d_stats = NULL; int64_t *d_off = NULL; int *d_bad = NULL;
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_stats), n * sizeof(double) + 16));
+  if (hipMalloc(reinterpret_cast<void **>(&d_off), (n_utts + 1) * sizeof(int64_t)) != hipSuccess) { (void)hipFree(d_stats); return kamd::SetError(KAMD_ERR_HIP, "allocation failed"); }
+  d_bad = reinterpret_cast<int *>(d_stats + n);
+  int rc = KAMD_OK, bad = 0, max_T = 0;
+  for (int u = 0; u < n_utts; u++) max_T = std::max<int>(max_T, static_cast<int>(h_row_off[u + 1] - h_row_off[u]));
+  if (hipMemcpyAsync(d_stats, h_stats, n * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemsetAsync(d_bad, 0, 4, st) != hipSuccess ||
+      hipMemcpyAsync(d_off, h_row_off, (n_utts + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess)
+    rc = kamd::SetError(KAMD_ERR_HIP, "cmvn: upload failed");
+  if (rc == KAMD_OK && max_T > 0) {
+    hipLaunchKernelGGL(kamd::CmvnApplyKernel, dim3(kamd::CeilDiv(max_T, 64), n_utts), dim3(256), 2 * dim * sizeof(float), st, d_feats, ld, dim,
+                       d_off, d_stats, norm_vars, d_bad);
+    if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      rc = kamd::SetError(KAMD_ERR_HIP, "cmvn: apply kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  (void)hipFree(d_stats); (void)hipFree(d_off);
+  if (rc == KAMD_OK && bad)
+    return kamd::SetError(KAMD_ERR_ARG, "Insufficient stats for cepstral mean and variance normalization: utterance %d, count < 1", bad - 1);
+  return rc;
+}
+
+}  // extern "C"

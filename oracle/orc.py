@@ -52,6 +52,9 @@ def lib():
         L.orc_online_cmvn.restype = None
         L.orc_posterior_entry.argtypes = [fp, C.c_int, C.c_int, C.c_float, ip, fp, ip]
         L.orc_posterior_entry.restype = C.c_float
+        L.orc_cmvn_acc_stats.argtypes = [fp, C.c_int, C.c_int, dp]
+        L.orc_cmvn_acc_stats.restype = None
+        L.orc_cmvn_apply.argtypes = [dp, C.c_int, fp, C.c_int, C.c_int]
         L.orc_decoder_create.restype = C.c_void_p
         L.orc_decoder_create.argtypes = [C.c_int32, C.c_int32, i64p, C.c_void_p, fp,
                                          C.POINTER(abi.DecoderConfig), ip, C.c_int32, C.c_int]
@@ -180,6 +183,21 @@ def posterior_entry(loglikes, num_gselect, min_post):
     n = C.c_int32()
     r = lib().orc_posterior_entry(abi.fptr(ll), ll.size, num_gselect, min_post, abi.iptr(g), abi.fptr(p), C.byref(n))
     return r, g[:n.value], p[:n.value]
+
+
+def cmvn_acc_stats(feats, stats=None):
+    f = np.ascontiguousarray(feats, np.float32)
+    st = np.zeros((2, f.shape[1] + 1), np.float64) if stats is None else np.array(stats, np.float64)
+    lib().orc_cmvn_acc_stats(abi.fptr(f), f.shape[0], f.shape[1], st.ctypes.data_as(C.POINTER(C.c_double)))
+    return st
+
+
+def cmvn_apply(feats, stats, norm_vars=False):
+    f = np.array(feats, np.float32)
+    st = np.ascontiguousarray(stats, np.float64)
+    r = lib().orc_cmvn_apply(st.ctypes.data_as(C.POINTER(C.c_double)), int(norm_vars), abi.fptr(f), f.shape[0], f.shape[1])
+    assert r == 0, "Insufficient stats"
+    return f
 
 
 def nnet_context(model):

@@ -335,3 +335,37 @@ int orc_fbank_compute(const kamd_fbank_opts *op, float vtln_warp, const float *w
 }
 
 }  // extern "C"
+
+// ---- CMVN (test infrastructure, like the rest of this file): AccCmvnStats (transform/cmvn.cc:30-62) and
+// ApplyCmvn (transform/cmvn.cc:64-118) restated.  PARITY UNPINNED: the reference holds no test for them.
+extern "C" void orc_cmvn_acc_stats(const float *feats, int T, int dim, double *stats /* [2][dim+1], added to */) {
+  for (int t = 0; t < T; t++) {
+    stats[dim] += 1.0f;
+    for (int k = 0; k < dim; k++) {
+      const float x = feats[static_cast<size_t>(t) * dim + k];
+      stats[k] += x * 1.0f;
+      stats[dim + 1 + k] += x * x * 1.0f;
+    }
+  }
+}
+extern "C" int orc_cmvn_apply(const double *stats, int var_norm, float *feats, int T, int dim) {
+  const double count = stats[dim];
+  if (count < 1.0) return -1;
+  for (int k = 0; k < dim; k++) {
+    float offset, scale = 1.0f;
+    if (!var_norm) offset = static_cast<float>(-1.0 / count * stats[k]);
+    else {
+      const double mean = stats[k] / count;
+      double var = stats[dim + 1 + k] / count - mean * mean;
+      if (var < 1.0e-20) var = 1.0e-20;
+      const double s = 1.0 / sqrt(var);
+      offset = static_cast<float>(-(mean * s)); scale = static_cast<float>(s);
+    }
+    for (int t = 0; t < T; t++) {
+      float x = feats[static_cast<size_t>(t) * dim + k];
+      if (var_norm) x = x * scale;
+      feats[static_cast<size_t>(t) * dim + k] = x + offset;
+    }
+  }
+  return 0;
+}

@@ -70,3 +70,50 @@ def test_energy_variants():
     fo = abi.fbank_opts_default()
     fo.use_energy, fo.use_power, fo.mel.num_bins = 1, 0, 40
     assert np.abs(feat.Fbank(fo).ComputeFeatures(w) - orc.fbank(fo, w)).max() < TOL
+
+
+def test_cmvn_stats_and_apply_match_the_oracle(tmp_path):
+    """compute-cmvn-stats / apply-cmvn on the device: statistics 1e-12 relative (fp64, other order of summation),
+    normalised features bit-equal given the same statistics (same float operations), per utterance and per speaker;
+    the two command-line tools chained through files."""
+    import subprocess
+    import sys
+    from kaldi_amd import cmvn, table
+    rng = np.random.default_rng(0)
+    mats = [(rng.standard_normal((T, 13)) * np.linspace(0.5, 4, 13) + 2).astype(np.float32) for T in (1, 37, 300, 1000)]
+    st = cmvn.acc_stats(mats)
+    for m, s in zip(mats, st):
+        want = orc.cmvn_acc_stats(m)
+        np.testing.assert_allclose(s, want, rtol=1e-12, atol=1e-12)
+    for nv in (False, True):
+        got = cmvn.apply(mats[1:], [orc.cmvn_acc_stats(m) for m in mats[1:]], norm_vars=nv)
+        for m, g in zip(mats[1:], got):
+            np.testing.assert_array_equal(g, orc.cmvn_apply(m, orc.cmvn_acc_stats(m), nv))
+    same = cmvn.apply(mats, st, norm_means=False)
+    for m, g in zip(mats, same):
+        np.testing.assert_array_equal(m, g)
+    with pytest.raises(Exception):
+        cmvn.apply(mats[:1], np.zeros((1, 2, 14)))                      # "Insufficient stats"
+    with pytest.raises(Exception):
+        cmvn.apply(mats[:1], st[:1], norm_means=False, norm_vars=True)
+    # running statistics: a speaker's second utterance added to the first
+    both = cmvn.acc_stats([mats[2]], stats=cmvn.acc_stats([mats[1]]))
+    np.testing.assert_allclose(both[0], orc.cmvn_acc_stats(mats[2], orc.cmvn_acc_stats(mats[1])), rtol=1e-12)
+    # tools: per-speaker statistics, then apply with utt2spk
+    with table.TableWriter("ark:%s" % (tmp_path / "f.ark"), "matrix") as w:
+        for i, m in enumerate(mats):
+            w.write("u%d" % i, m)
+    (tmp_path / "spk2utt").write_text("A u0 u1\nB u2 u3\n")
+    (tmp_path / "utt2spk").write_text("u0 A\nu1 A\nu2 B\nu3 B\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cmd in ([root + "/tools/compute_cmvn_stats.py", "--spk2utt=ark:%s" % (tmp_path / "spk2utt"), "ark:%s" % (tmp_path / "f.ark"),
+                 "ark:%s" % (tmp_path / "cmvn.ark")],
+                [root + "/tools/apply_cmvn.py", "--norm-vars=true", "--utt2spk=ark:%s" % (tmp_path / "utt2spk"), "ark:%s" % (tmp_path / "cmvn.ark"),
+                 "ark:%s" % (tmp_path / "f.ark"), "ark:%s" % (tmp_path / "out.ark")]):
+        r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+    out = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "out.ark"), "matrix"))
+    spkB = np.concatenate(mats[2:])
+    np.testing.assert_allclose(np.concatenate([out["u2"], out["u3"]]).mean(0), 0, atol=2e-5)
+    np.testing.assert_allclose(np.concatenate([out["u2"], out["u3"]]).std(0), 1, atol=1e-4)
+    assert abs(float(spkB.mean())) > 1                                   # it was not normalised before

@@ -115,3 +115,22 @@ def test_snip_edges_false_reflection(wave):
     # frame f (snip) starts at 160 f; frame g (no snip) starts at 160 g + 80 - 200.
     # They never coincide exactly; check smoothness instead: neighbours are close.
     assert np.abs(b[5:-5] - a[4:4 + b.shape[0] - 10]).mean() < np.abs(b[5:-5]).mean()
+
+
+def test_cmvn_oracle_against_numpy():
+    """AccCmvnStats / ApplyCmvn restatement: sums, float-product squares, mean-only and mean+variance forms."""
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((200, 7)) * [1, 2, 3, 4, 5, 6, 7] + 3).astype(np.float32)
+    st = orc.cmvn_acc_stats(x)
+    np.testing.assert_allclose(st[0, :7], x.astype(np.float64).sum(0), rtol=1e-12)
+    np.testing.assert_allclose(st[1, :7], (x * x).astype(np.float64).sum(0), rtol=1e-12)      # squares in float, as the reference
+    assert st[0, 7] == 200 and st[1, 7] == 0
+    st2 = orc.cmvn_acc_stats(x[:50], st)                      # running statistics
+    assert st2[0, 7] == 250
+    y = orc.cmvn_apply(x, st)
+    np.testing.assert_allclose(y.mean(0), 0, atol=2e-6)
+    z = orc.cmvn_apply(x, st, norm_vars=True)
+    np.testing.assert_allclose(z.mean(0), 0, atol=1e-6)
+    np.testing.assert_allclose(z.std(0), 1, atol=1e-5)
+    with pytest.raises(AssertionError):
+        orc.cmvn_apply(x, np.zeros((2, 8)))
