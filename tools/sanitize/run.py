@@ -69,4 +69,27 @@ for binary in (0, 1):
         if rc == 1: break
         assert rc == 0; L.kamd_host_free(pm); cnt += 1
     assert cnt == 2
+# extended filenames, specifiers, scp offsets, pipes
+for name in ("", "-", "a", "a ", " a", "b|", "|b", "a b c:123", "x:", "ark,s,cs:a b c", "scp:a", "a|b", ":", "1", ":1"):
+    L.kamd_classify_rxfilename(name.encode()); L.kamd_classify_wxfilename(name.encode())
+buf, buf2 = C.create_string_buffer(8), C.create_string_buffer(8)
+o = C.c_int()
+for spec in ("ark:foo|", "b,ark:foo|", "scp,scp,b:foo|", "s,scp,no:foo|", "", "scp", "ark:foo ", " t,ark:boo", "t,ark,scp:a b,c,d", "b,ark,scp:,", "ark:a-very-long-name-that-does-not-fit"):
+    L.kamd_classify_rspecifier(spec.encode(), buf, 8, C.byref(o))
+    L.kamd_classify_wspecifier(spec.encode(), buf, 8, buf2, 8, C.byref(o))
+    L.kamd_classify_rspecifier(spec.encode(), None, 0, None)
+path = C.create_string_buffer(4096); off64 = C.c_int64(); tmpf = C.c_int()
+ap = os.path.join(tmp, "m1.ark")
+assert L.kamd_rx_materialize(("cat %s |" % ap).encode(), path, 4096, C.byref(off64), C.byref(tmpf)) == 0 and tmpf.value == 1
+r, c = C.c_int32(), C.c_int32(); pm = C.c_void_p(); key = C.create_string_buffer(64); offp = C.c_int64(0)
+assert L.kamd_ark_read_matrix(path.value, C.byref(offp), key, 64, C.byref(r), C.byref(c), C.byref(pm)) == 0 and r.value == 9
+L.kamd_host_free(pm); os.unlink(path.value)
+assert L.kamd_rx_materialize(b"false |", path, 4096, C.byref(off64), C.byref(tmpf)) != 0
+assert L.kamd_rx_materialize(("%s:2" % ap).encode(), path, 4096, C.byref(off64), C.byref(tmpf)) == 0 and off64.value == 2
+offp = C.c_int64(2)
+assert L.kamd_ark_read_matrix(path.value, C.byref(offp), None, 0, C.byref(r), C.byref(c), C.byref(pm)) == 0 and (r.value, c.value) == (9, 4)
+L.kamd_host_free(pm)
+offp = C.c_int64(10 ** 6)
+assert L.kamd_ark_read_matrix(path.value, C.byref(offp), None, 0, C.byref(r), C.byref(c), C.byref(pm)) != 0
+assert L.kamd_rx_materialize(ap.encode(), path, 4, C.byref(off64), C.byref(tmpf)) != 0          # buffer too small
 print("sanitized host paths ok; raw lattice", S, la.size)
