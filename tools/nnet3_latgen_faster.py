@@ -39,6 +39,9 @@ def main(argv):
     po.register("wav", bool, False, "The third argument is a waveform rspecifier; features are computed on the device")
     po.register("mfcc-config", str, "", "Config file with compute-mfcc-feats options (only with --wav)")
     po.register("batch", int, 64, "Utterances decoded per pass")
+    po.register("device", int, -1, "HIP device to run on (default: device 0 of HIP_VISIBLE_DEVICES); with decode.sh-style "
+                "splitting, job JOB of --nj 8 passes --device=$[JOB-1]: utterances shard across the GPUs of a node with "
+                "no communication")
     args = po.read(argv)
     if not 4 <= len(args) <= 6:
         po.print_usage()
@@ -52,6 +55,9 @@ def main(argv):
         raise KamdError("--online-ivectors and --ivector-extraction-config exclude each other")
     if po["online-ivectors"] and po["online-ivector-period"] <= 0:
         raise KamdError("--online-ivector-period must be set with --online-ivectors")       # nnet3-latgen-faster.cc:94-99
+    if po["device"] >= 0:
+        from kaldi_amd._lib import check
+        check(lib().kamd_set_device(po["device"]))
     cfg = options.decoder_config(po)
     mpo = table.ParseOptions("compute-mfcc-feats options")
     options.register_mfcc(mpo)
