@@ -530,6 +530,17 @@ int kamd_feat_compute_ranges_device(kamd_feat *f, const float *d_waves, const in
 int kamd_nnet_forward_slices_device(kamd_nnet *n, const float *d_feats, const int64_t *h_in_start,
                                     const int32_t *h_in_len, int ld_in, const float *d_ivectors, int n_items,
                                     float *d_out, const int64_t *h_out_row_off, int ld_out, void *stream);
+/* The same with the looped decodable's i-vectors (DecodableNnetLoopedOnline: ModifyNnetIvectorPeriod makes
+ * the network read the ivector input at Round(t, period), nnet3/nnet-compile-looped.cc:164-207): the
+ * first layer's row at absolute time t of item i uses row slot_base[i] + clamp(floor(t / period) -
+ * slot_first[i], 0, slot_count[i] - 1) of d_ivector_table [table_rows x ivector_dim]; abs_t0[i] = absolute
+ * time of the item's first input frame. */
+int kamd_nnet_forward_slices_slots_device(kamd_nnet *n, const float *d_feats, const int64_t *h_in_start,
+                                          const int32_t *h_in_len, int ld_in, const float *d_ivector_table,
+                                          int table_rows, int period, const int32_t *h_slot_base,
+                                          const int32_t *h_slot_first, const int32_t *h_slot_count,
+                                          const int32_t *h_abs_t0, int n_items, float *d_out,
+                                          const int64_t *h_out_row_off, int ld_out, void *stream);
 /* DecodableNnetSimple with ONLINE ivectors (--online-ivectors / --online-ivector-period of
  * nnet3-latgen-faster, nnet3/nnet-am-decodable-simple.cc:93-214) for a batch of utterances:
  * the output is computed chunk by chunk (frames_per_chunk input frames, rounded up to a

@@ -203,6 +203,10 @@ struct MapArgs {
   int n_off; int offs[KAMD_MAX_OFFSETS];
   int *rowmap;                  // [n_off][M]
   int *row2utt;                 // [M] or NULL
+  // per-row i-vector slots (the looped decodable's Round(ivector, period)): row2utt[r] then indexes a table
+  // of i-vectors, slot_base[u] + clamp(floor((abs_t0[u] + t) / period) - slot_first[u], 0, slot_count[u] - 1)
+  int slot_period;              // 0: one i-vector per item
+  const int *slot_base, *slot_first, *slot_count, *abs_t0;
 };
 __global__ void RowMapKernel(MapArgs a) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,7 +218,14 @@ __global__ void RowMapKernel(MapArgs a) {
   }
   const int u = lo;
   const int t = a.lo + static_cast<int>(r - a.row_off[u]) * a.step;
-  if (a.row2utt) a.row2utt[r] = u;
+  if (a.row2utt) {
+    if (a.slot_period > 0) {
+      const int ta = a.abs_t0[u] + t;
+      int sl = (ta >= 0 ? ta / a.slot_period : -((-ta + a.slot_period - 1) / a.slot_period)) - a.slot_first[u];
+      sl = sl < 0 ? 0 : (sl >= a.slot_count[u] ? a.slot_count[u] - 1 : sl);
+      a.row2utt[r] = a.slot_base[u] + sl;
+    } else a.row2utt[r] = u;
+  }
   for (int i = 0; i < a.n_off; i++) {
     int tin = t + a.offs[i];
     int64_t src;
@@ -410,9 +421,13 @@ double kamd_nnet_last_flops(const kamd_nnet *h) { return reinterpret_cast<const 
 
 // h_in_start[u] / h_in_len[u]: first feature row and number of input frames of item u (the
 // items need not be adjacent: streaming slices of different streams live in one pooled buffer)
+struct SlotSpec {                 // host arrays, one entry per item; table rows = sum of slot_count
+  int period, table_rows;
+  const int32_t *slot_base, *slot_first, *slot_count, *abs_t0;
+};
 static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_start, const int32_t *h_in_len,
                         int ld_in, const float *d_ivectors, int n_utts, float *d_out,
-                        const int64_t *h_out_row_off, int ld_out, void *stream) {
+                        const int64_t *h_out_row_off, int ld_out, void *stream, const SlotSpec *slots = NULL) {
   Nnet *nn = reinterpret_cast<Nnet *>(h);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nl = static_cast<int>(nn->L.size()), sub = nn->subsampling;
@@ -423,8 +438,17 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
   // ---- meta: T[u] (as int64 for simplicity), per-layer row offsets
   // layout: [ (nl+2) arrays of (n_utts+1) int64 ] then T as int32
   const size_t stride = n_utts + 1;
-  std::vector<int64_t> meta((nl + 2) * stride + (n_utts + 1) / 2 + 1, 0);
+  const size_t t_words = (n_utts + 1) / 2 + 1, slot_words = slots ? static_cast<size_t>(2 * n_utts + 2) : 0;
+  std::vector<int64_t> meta((nl + 2) * stride + t_words + slot_words, 0);
   int *Th = reinterpret_cast<int *>(&meta[(nl + 2) * stride]);
+  int *Sh = reinterpret_cast<int *>(&meta[(nl + 2) * stride + t_words]);      // slot_base | slot_first | slot_count | abs_t0
+  if (slots)
+    for (int u = 0; u < n_utts; u++) {
+      Sh[u] = slots->slot_base[u]; Sh[n_utts + u] = slots->slot_first[u];
+      Sh[2 * n_utts + u] = slots->slot_count[u]; Sh[3 * n_utts + u] = slots->abs_t0[u];
+      if (slots->slot_count[u] <= 0 || slots->slot_base[u] < 0 || slots->slot_base[u] + slots->slot_count[u] > slots->table_rows)
+        return kamd::SetError(KAMD_ERR_ARG, "item %d: bad i-vector slot range", u);
+    }
   std::vector<int> n_out(n_utts);
   for (int u = 0; u < n_utts; u++) {
     int T = h_in_len[u];
@@ -476,6 +500,12 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     ma.n_utts = n_utts; ma.M = static_cast<int>(Ml);
     ma.T = d_T; ma.lo = L.lo; ma.step = L.step;
     ma.row2utt = L.ivector_dim > 0 ? row2utt : NULL;
+    ma.slot_period = 0; ma.slot_base = ma.slot_first = ma.slot_count = ma.abs_t0 = NULL;
+    if (slots && L.ivector_dim > 0) {
+      const int *d_S = reinterpret_cast<const int *>(nn->d_meta + (nl + 2) * stride + t_words);
+      ma.slot_period = slots->period;
+      ma.slot_base = d_S; ma.slot_first = d_S + n_utts; ma.slot_count = d_S + 2 * n_utts; ma.abs_t0 = d_S + 3 * n_utts;
+    }
     auto fill_prod = [&](int prod, kamd::MapArgs *a) {
       if (prod < 0) { a->prod_row_off = nn->d_meta + nl * stride; a->prod_is_input = 1; a->prod_lo = 0; a->prod_step = 1; }
       else { a->prod_row_off = nn->d_meta + prod * stride; a->prod_is_input = 0; a->prod_lo = nn->L[prod].lo; a->prod_step = nn->L[prod].step; }
@@ -511,8 +541,9 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     g.W = L.W; g.bias = L.bias; g.relu = L.relu; g.bn_scale = L.bn_scale; g.bn_offset = L.bn_offset;
     if (L.ivector_dim > 0) {
       if (!d_ivectors) return kamd::SetError(KAMD_ERR_ARG, "model needs ivectors");
-      if (kamd::Grow(&nn->d_ivb, &nn->ivb_cap, static_cast<size_t>(n_utts) * L.out_dim) != KAMD_OK) return KAMD_ERR_HIP;
-      hipLaunchKernelGGL(kamd::IvecBiasKernel, dim3(kamd::CeilDiv(L.out_dim, 128), n_utts), dim3(128), 0, st,
+      const int iv_rows = slots ? slots->table_rows : n_utts;
+      if (kamd::Grow(&nn->d_ivb, &nn->ivb_cap, static_cast<size_t>(iv_rows) * L.out_dim) != KAMD_OK) return KAMD_ERR_HIP;
+      hipLaunchKernelGGL(kamd::IvecBiasKernel, dim3(kamd::CeilDiv(L.out_dim, 128), iv_rows), dim3(128), 0, st,
                          L.Wiv, d_ivectors, L.out_dim, L.ivector_dim, nn->d_ivb);
       g.ivbias = nn->d_ivb; g.row2utt = row2utt;
     }
@@ -565,6 +596,20 @@ int kamd_nnet_forward_slices_device(kamd_nnet *h, const float *d_feats, const in
                                     const int32_t *h_in_len, int ld_in, const float *d_ivectors, int n_items,
                                     float *d_out, const int64_t *h_out_row_off, int ld_out, void *stream) {
   return ForwardItems(h, d_feats, h_in_start, h_in_len, ld_in, d_ivectors, n_items, d_out, h_out_row_off, ld_out, stream);
+}
+
+// The looped decodable's i-vector semantics (nnet3/nnet-compile-looped.cc:164-207 + ModifyNnetIvectorPeriod:
+// the ivector input is read at Round(t, period)): the first layer's row at absolute time t takes row
+// slot_base[i] + clamp(floor(t / period) - slot_first[i]) of the i-vector table; abs_t0[i] is the absolute
+// time of item i's first input frame.  Everything else as kamd_nnet_forward_slices_device.
+int kamd_nnet_forward_slices_slots_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_start, const int32_t *h_in_len,
+                                          int ld_in, const float *d_ivector_table, int table_rows, int period,
+                                          const int32_t *h_slot_base, const int32_t *h_slot_first, const int32_t *h_slot_count,
+                                          const int32_t *h_abs_t0, int n_items, float *d_out, const int64_t *h_out_row_off,
+                                          int ld_out, void *stream) {
+  if (period <= 0 || table_rows <= 0) return kamd::SetError(KAMD_ERR_ARG, "bad i-vector slot table");
+  SlotSpec sp = {period, table_rows, h_slot_base, h_slot_first, h_slot_count, h_abs_t0};
+  return ForwardItems(h, d_feats, h_in_start, h_in_len, ld_in, d_ivector_table, n_items, d_out, h_out_row_off, ld_out, stream, &sp);
 }
 
 }  // extern "C"

@@ -77,6 +77,33 @@ class Nnet:
         return out
 
 
+    def ForwardSlots(self, feats, slot_table, slot_first, period, slices=None):
+        """The looped decodable's i-vectors (Round(ivector, period)): first-layer row at time t reads
+        slot_table[floor(t / period) - slot_first] (clamped).  slices: [(first input frame, frames)] items of one
+        batched forward, each treated like a separate utterance at its edges (default: the whole matrix);
+        returns the output rows of each item."""
+        ld = (self.model.input_dim + 15) // 16 * 16
+        f = np.zeros((feats.shape[0], ld), np.float32)
+        f[:, :feats.shape[1]] = feats
+        slices = slices or [(0, feats.shape[0])]
+        n = len(slices)
+        tab = np.ascontiguousarray(slot_table, np.float32)
+        in_start = np.asarray([a for a, _ in slices], np.int64)
+        in_len = np.asarray([b for _, b in slices], np.int32)
+        out_off = np.zeros(n + 1, np.int64)
+        for i, (_, b) in enumerate(slices):
+            out_off[i + 1] = out_off[i] + lib().kamd_nnet_num_output_frames(self._h, int(b))
+        base = np.zeros(n, np.int32); first = np.full(n, slot_first, np.int32); cnt = np.full(n, tab.shape[0], np.int32)
+        t0 = np.asarray([a for a, _ in slices], np.int32)
+        P = self.OutputDim()
+        d_f, d_t, d_o = DeviceMatrix(f), DeviceMatrix(tab), DeviceMatrix(np.zeros((int(out_off[-1]), P), np.float32))
+        check(lib().kamd_nnet_forward_slices_slots_device(self._h, d_f.ptr(0), abi.iptr(in_start, C.c_int64), abi.iptr(in_len), ld,
+                                                          d_t.ptr(0), tab.shape[0], period, abi.iptr(base), abi.iptr(first),
+                                                          abi.iptr(cnt), abi.iptr(t0), n, d_o.ptr(0),
+                                                          abi.iptr(out_off, C.c_int64), P, None))
+        out = d_o.download()
+        return [out[out_off[i]:out_off[i + 1]] for i in range(n)]
+
     def ForwardChunked(self, feats_list, online_ivectors_list, ivector_period=10, frames_per_chunk=50):
         """DecodableNnetSimple with online ivectors for a batch of utterances: one ivector per
         chunk (nnet3/nnet-am-decodable-simple.cc:93-214).  Returns one [n_out x P] array each."""

@@ -41,6 +41,8 @@ def lib():
         L.orc_nnet_context.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, ip, ip]
         L.orc_nnet_forward.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp,
                                        C.c_int, fp, fp, C.c_int]
+        L.orc_nnet_forward_slots.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, fp, C.c_int]
         L.orc_nnet_forward_chunked.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int,
                                                C.c_int, C.c_int, C.c_int, fp, C.c_int]
         dp = C.POINTER(C.c_double)
@@ -111,6 +113,19 @@ def nnet_forward(model, feats, ivector=None):
     d = model.descs()
     r = lib().orc_nnet_forward(d, len(model.layers), model.input_dim, model.subsampling,
                                abi.fptr(feats), T, abi.fptr(iv), abi.fptr(out), n_out)
+    assert r == n_out, r
+    return out
+
+
+def nnet_forward_slots(model, feats, slot_table, slot_first, period):
+    """looped-decodable i-vectors: first-layer row t reads slot_table[floor(t / period) - slot_first] (clamped)"""
+    feats = np.ascontiguousarray(feats, np.float32)
+    tab = np.ascontiguousarray(slot_table, np.float32)
+    T = feats.shape[0]
+    n_out = (T + model.subsampling - 1) // model.subsampling
+    out = np.zeros((n_out, model.layers[-1].out_dim), np.float32)
+    r = lib().orc_nnet_forward_slots(model.descs(), len(model.layers), model.input_dim, model.subsampling, abi.fptr(feats), T,
+                                     abi.fptr(tab), slot_first, tab.shape[0], tab.shape[1], period, abi.fptr(out), n_out)
     assert r == n_out, r
     return out
 

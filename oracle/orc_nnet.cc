@@ -34,6 +34,14 @@ struct Eval {
   const kamd_layer_desc *L;
   int n_layers, input_dim, T;
   const float *feats, *ivector;
+  // looped-decodable i-vectors: row t of the first layer reads table row clamp(floor(t / period) - slot_first)
+  const float *slot_table = NULL; int slot_period = 0, slot_first = 0, slot_count = 0, iv_dim = 0;
+  const float *IvectorAt(int t) const {
+    if (slot_period <= 0) return ivector;
+    int sl = (t >= 0 ? t / slot_period : -((-t + slot_period - 1) / slot_period)) - slot_first;
+    sl = sl < 0 ? 0 : (sl >= slot_count ? slot_count - 1 : sl);
+    return slot_table + static_cast<int64_t>(sl) * iv_dim;
+  }
   std::vector<std::unordered_map<int, std::vector<float> > > memo;
 
   const float *Input(int t) const {
@@ -65,7 +73,8 @@ struct Eval {
       if (l.ivector_dim > 0) {
         const float *wi = w + l.n_offsets * l.in_dim;
         float s = 0.0f;
-        for (int k = 0; k < l.ivector_dim; k++) s += wi[k] * ivector[k];
+        const float *iv = IvectorAt(t);
+        for (int k = 0; k < l.ivector_dim; k++) s += wi[k] * iv[k];
         acc += s;
       }
       if (l.relu && acc < 0.0f) acc = 0.0f;
@@ -139,6 +148,25 @@ int orc_nnet_forward(const kamd_layer_desc *layers, int n_layers, int input_dim,
   return n_out;
 }
 
+
+// DecodableNnetLoopedOnline's i-vector semantics over a whole utterance: Round(ivector, period)
+// (nnet3/nnet-compile-looped.cc:186-207, ModifyNnetIvectorPeriod): the first layer's row at time t reads
+// slot floor(t / period); slot_table holds slots slot_first .. slot_first + slot_count - 1.
+int orc_nnet_forward_slots(const kamd_layer_desc *layers, int n_layers, int input_dim, int subsampling, const float *feats, int T,
+                           const float *slot_table, int slot_first, int slot_count, int iv_dim, int period, float *out,
+                           int out_rows_cap) {
+  if (T <= 0) return 0;
+  int n_out = (T + subsampling - 1) / subsampling;
+  if (n_out > out_rows_cap) return -1;
+  Eval e;
+  e.L = layers; e.n_layers = n_layers; e.input_dim = input_dim; e.T = T;
+  e.feats = feats; e.ivector = NULL;
+  e.slot_table = slot_table; e.slot_period = period; e.slot_first = slot_first; e.slot_count = slot_count; e.iv_dim = iv_dim;
+  e.memo.resize(n_layers);
+  int P = layers[n_layers - 1].out_dim;
+  for (int i = 0; i < n_out; i++) memcpy(out + static_cast<int64_t>(i) * P, e.Get(n_layers - 1, i * subsampling), sizeof(float) * P);
+  return n_out;
+}
 
 // DecodableNnetSimple with online ivectors (nnet3/nnet-am-decodable-simple.cc:93-214): the
 // decoder asks for frames in order, so chunks start at 0, C, 2C, ... with C =

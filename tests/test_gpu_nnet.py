@@ -171,3 +171,32 @@ def test_model_read_from_mdl_file(tmp_path):
     b = decoder.Nnet(m).Forward(feats)
     assert np.abs(a - b).max() < 1e-4 * np.abs(b).max()
     assert id2pdf.size == 51 and tid_phone.max() == 25
+
+
+def test_looped_ivector_slots():
+    """Round(ivector, period): first-layer rows read the i-vector slot of their own time.  Whole utterance against
+    the oracle; slices in the middle of the utterance give the same rows as the whole (bit-equal), which is what
+    lets the streaming path recompute context rows without changing them."""
+    from kaldi_amd import decoder
+    m = nnet.tdnnf_tiny(num_pdfs=40, ivector_dim=12)
+    N = decoder.Nnet(m)
+    rng = np.random.default_rng(4)
+    T = 131
+    x = rng.standard_normal((T, 40)).astype(np.float32)
+    period = 20
+    first = -2
+    tab = rng.standard_normal((10, 12)).astype(np.float32)          # slots -2 .. 7 cover t in [-40, 160)
+    whole = N.ForwardSlots(x, tab, first, period)[0]
+    want = orc.nnet_forward_slots(m, x, tab, first, period)
+    np.testing.assert_allclose(whole, want, rtol=0, atol=1e-4 * max(1.0, np.abs(want).max()))
+    # a table whose slots are all equal is the per-utterance i-vector
+    same = N.ForwardSlots(x, np.tile(tab[3], (10, 1)), first, period)[0]
+    np.testing.assert_array_equal(same, N.Forward(x, ivector=tab[3]))
+    L, R = N.Context()
+    sub = m.subsampling
+    o0, o1 = 9, 30                                                   # output frames [9, 30)
+    k0 = min(o0, (L + sub - 1) // sub)
+    in_first, in_last = sub * (o0 - k0), min(T - 1, sub * (o1 - 1) + R)
+    part = N.ForwardSlots(x, tab, first, period, slices=[(in_first, in_last - in_first + 1), (0, T)])
+    np.testing.assert_array_equal(part[0][k0:k0 + (o1 - o0)], whole[o0:o1])
+    np.testing.assert_array_equal(part[1], whole)
