@@ -470,6 +470,21 @@ int kamd_ivector_extract_online_adapt_device(kamd_ivector_extractor *e, const fl
                                              int ld_feat, int n_utts, float *d_out, const int64_t *h_out_row_off,
                                              const double *h_state_in, double *h_state_out, void *stream);
 int kamd_ivector_state_limit_frames(const kamd_ivector_extractor *e, double *state, float max_remembered_frames);
+/* Streaming form: OnlineIvectorFeature::GetFrame with use_most_recent_ivector = true (online2/online-ivector-
+ * feature.cc:206-320), for n streams at once.  Stream item i has h_n_base[i] base-feature frames so far at rows
+ * h_feat_row[i].. of d_feats (the extractor's workspaces mirror that row space: ws_rows_total rows); frames
+ * [h_n_done[i], h_n_upto[i]) are new (h_n_upto <= h_n_base - splice_right unless the input is finished): they enter
+ * the statistics as one batch, then num_cg_iters CG steps run from the stream's current estimate.  A stream's
+ * record = kamd_ivector_stream_record_size() doubles on the device (adaptation state | current estimate),
+ * started from kamd_ivector_stream_record_init and updated in place; h_record[i] = index of item i's record in
+ * d_records.  d_out row i = the estimate, prior offset removed from dimension 0.  The speaker CMVN part of the
+ * record is NOT advanced (add the utterance with kamd_cmvn_acc_stats_device when it ends). */
+int kamd_ivector_stream_record_size(const kamd_ivector_extractor *e);
+int kamd_ivector_stream_record_init(const kamd_ivector_extractor *e, const double *state, double *record);
+int kamd_ivector_stream_update_device(kamd_ivector_extractor *e, const float *d_feats, int ld_feat, int64_t ws_rows_total,
+                                      const int64_t *h_feat_row, const int32_t *h_n_base, const int32_t *h_n_done,
+                                      const int32_t *h_n_upto, const int32_t *h_record, int n, double *d_records,
+                                      float *d_out, void *stream);
 /* one utterance, host in / host out; returns the number of rows written or < 0 */
 int kamd_ivector_extract_online(kamd_ivector_extractor *e, const float *feats, int num_frames, float *out,
                                 int out_rows_cap);

@@ -46,28 +46,41 @@ struct IvDev {
   float min_post, log_min_post, post_scale;
 };
 
+struct IvUtt {                    // one per utterance (or stream) of a call
+  int64_t feat_row;               // its first row in the feature matrix
+  int64_t ws_row;                 // its first row in the workspaces (S, LDA outputs, posteriors)
+  int64_t out_row;                // its first output row
+  int64_t inc_row;                // its first row in the per-step increments
+  int T;                          // base frames available (splicing clamps at T - 1)
+  int proc_first, proc_end;       // frames whose LDA features and posteriors this call computes
+  int stats_first, stats_end;     // mode 1: frames that enter the statistics in this call
+  int mode;                       // 0: ivector-extract-online2 stepping (step i = frames (i-1)P+1 .. iP, CG at every step, a row per step)
+                                  // 1: streaming GetFrame: steps of P frames from stats_first, CG after the last one only, one row
+  int n_steps;
+  int state_idx;                  // record in the state arrays, or -1
+};
+
 struct IvBatch {
   const float *feats; int ld;
-  const int64_t *row_off;        // [n + 1] feature rows
-  const int64_t *out_off;        // [n + 1] i-vector rows
+  const IvUtt *utt;              // [n]
   double *S;                     // [rows][feat_dim]
   float *norm_lda, *raw_lda;     // [rows][D]
   int32_t *post_g; float *post_w;  // [rows][ng]
-  float *out;                    // [iv rows][I]
-  int64_t row_base;              // row_off[0]: workspaces are indexed relative to it
-  int64_t out_base;              // out_off[0]
-  double *dquad, *dlin, *dtotw;  // per i-vector step: its own statistics [iv rows][Q], [iv rows][I], [iv rows]
-  // adaptation state carried over from the speaker's previous utterance (NULL: fresh), [n][state size]:
-  // 2 x (feat_dim+1) speaker CMVN stats | packed quadratic term | linear term | num_frames
+  float *out;                    // [rows][I]
+  double *dquad, *dlin, *dtotw;  // per step: its own statistics [steps][Q], [steps][I], [steps]
+  // adaptation state carried over (NULL: fresh / not wanted), records of state_size doubles:
+  // 2 x (feat_dim+1) speaker CMVN stats | packed quadratic term | linear term | num_frames [| current estimate]
   const double *state_in; double *state_out; int state_size;
+  int x_off;                     // offset of the current estimate inside a record (streaming), or -1
 };
 
 // ---------------------------------------------------------------- running sums
 __global__ __launch_bounds__(256) void PrefixKernel(IvDev d, IvBatch b) {
   __shared__ double csum[256];
   const int u = blockIdx.x, tid = threadIdx.x;
-  const int64_t r0 = b.row_off[u];
-  const int T = static_cast<int>(b.row_off[u + 1] - r0);
+  const IvUtt ut = b.utt[u];
+  const int64_t r0 = ut.feat_row;
+  const int T = ut.T;
   int dpw = 1;
   while (dpw < d.feat_dim) dpw <<= 1;          // dims padded to a power of two <= 256
   const int chunks = 256 / dpw, k = tid % dpw, c = tid / dpw;
@@ -84,9 +97,9 @@ __global__ __launch_bounds__(256) void PrefixKernel(IvDev d, IvBatch b) {
     for (int t = t0; t < t1; t++) {
       const double v = static_cast<double>(b.feats[(r0 + t) * b.ld + k]);
       run += v; sq += v * v;
-      b.S[(r0 - b.row_base + t) * d.feat_dim + k] = run;
+      b.S[(ut.ws_row + t) * d.feat_dim + k] = run;
     }
-  if (b.state_out) {
+  if (b.state_out && ut.mode == 0 && ut.state_idx >= 0) {
     // OnlineCmvn::GetState(T - 1) (feat/online-feature.cc:455-475): incoming speaker stats + all T frames
     __syncthreads();
     csum[tid] = sq;
@@ -94,10 +107,10 @@ __global__ __launch_bounds__(256) void PrefixKernel(IvDev d, IvBatch b) {
     if (c == 0 && k < d.feat_dim) {
       double s2 = 0, s1 = 0;
       for (int c2 = 0; c2 < chunks; c2++) s2 += csum[c2 * dpw + k];
-      s1 = b.S[(r0 - b.row_base + T - 1) * d.feat_dim + k];
+      s1 = b.S[(ut.ws_row + T - 1) * d.feat_dim + k];
       const int sd1 = d.feat_dim + 1;
-      const double *in = b.state_in ? b.state_in + static_cast<size_t>(u) * b.state_size : NULL;
-      double *out = b.state_out + static_cast<size_t>(u) * b.state_size;
+      const double *in = b.state_in ? b.state_in + static_cast<size_t>(ut.state_idx) * b.state_size : NULL;
+      double *out = b.state_out + static_cast<size_t>(ut.state_idx) * b.state_size;
       out[k] = (in ? in[k] : 0.0) + s1;
       out[sd1 + k] = (in ? in[sd1 + k] : 0.0) + s2;
       if (k == 0) { out[d.feat_dim] = (in ? in[d.feat_dim] : 0.0) + T; out[sd1 + d.feat_dim] = in ? in[sd1 + d.feat_dim] : 0.0; }
@@ -109,10 +122,11 @@ __global__ __launch_bounds__(256) void PrefixKernel(IvDev d, IvBatch b) {
 __global__ __launch_bounds__(256) void FrontKernel(IvDev d, IvBatch b) {
   extern __shared__ float tile[];              // raw[(FT+L+R)][dim], nrm[(FT+L+R)][dim]
   const int u = blockIdx.y, tid = threadIdx.x;
-  const int64_t r0 = b.row_off[u];
-  const int T = static_cast<int>(b.row_off[u + 1] - r0);
-  const int t0 = blockIdx.x * IV_FT;
-  if (t0 >= T) return;
+  const IvUtt ut = b.utt[u];
+  const int64_t r0 = ut.feat_row;
+  const int T = ut.T;
+  const int t0 = ut.proc_first + blockIdx.x * IV_FT;
+  if (t0 >= ut.proc_end) return;
   const int dim = d.feat_dim, span = IV_FT + d.L + d.R;
   float *raw = tile, *nrm = tile + span * dim;
   for (int i = tid; i < span * dim; i += 256) {
@@ -124,12 +138,12 @@ __global__ __launch_bounds__(256) void FrontKernel(IvDev d, IvBatch b) {
     float nv = v;
     if (d.normalize_mean) {
       // OnlineCmvn: window [t2 - W + 1, t2], topped up with the global stats (feat/online-feature.cc:325-407)
-      const double *S = b.S + (r0 - b.row_base) * dim;
+      const double *S = b.S + ut.ws_row * dim;
       double win = S[static_cast<size_t>(t2) * dim + k];
       double cnt = t2 + 1;
       if (t2 - d.cmn_window >= 0) { win -= S[static_cast<size_t>(t2 - d.cmn_window) * dim + k]; cnt = d.cmn_window; }
-      if (cnt < d.cmn_window && b.state_in != NULL) {          // speaker stats of the carried-over state first
-        const double *sp = b.state_in + static_cast<size_t>(u) * b.state_size;
+      if (cnt < d.cmn_window && b.state_in != NULL && ut.state_idx >= 0) {   // speaker stats of the carried-over state first
+        const double *sp = b.state_in + static_cast<size_t>(ut.state_idx) * b.state_size;
         const double speaker_count = sp[dim];
         double from_speaker = d.cmn_window - cnt;
         if (from_speaker > d.speaker_frames) from_speaker = d.speaker_frames;
@@ -146,23 +160,25 @@ __global__ __launch_bounds__(256) void FrontKernel(IvDev d, IvBatch b) {
     nrm[i] = nv;
   }
   __syncthreads();
-  const int nf = min(IV_FT, T - t0);
+  const int nf = min(IV_FT, ut.proc_end - t0);
   for (int i = tid; i < 2 * nf * d.D; i += 256) {
     const int which = i / (nf * d.D), rem = i - which * nf * d.D;
     const int f = rem / d.D, o = rem - f * d.D;
     const float *src = (which ? raw : nrm) + f * dim;        // spliced vector = rows f .. f + L + R of the tile
     float acc = d.affine ? d.ldaT[static_cast<size_t>(d.sd) * d.D + o] : 0.f;
     for (int k = 0; k < d.sd; k++) acc = acc + d.ldaT[static_cast<size_t>(k) * d.D + o] * src[k];
-    (which ? b.raw_lda : b.norm_lda)[(r0 - b.row_base + t0 + f) * d.D + o] = acc;
+    (which ? b.raw_lda : b.norm_lda)[(ut.ws_row + t0 + f) * d.D + o] = acc;
   }
 }
 
 // ---------------------------------------------------------------- UBM posteriors
-__global__ __launch_bounds__(256) void PostKernel(IvDev d, IvBatch b, int64_t rows) {
+__global__ __launch_bounds__(256) void PostKernel(IvDev d, IvBatch b) {
   extern __shared__ float plds[];              // per wave: x[D], p[G]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * 4 + w;
-  if (row >= rows) return;
+  const IvUtt ut = b.utt[blockIdx.y];
+  const int frame = ut.proc_first + blockIdx.x * 4 + w;
+  if (frame >= ut.proc_end) return;
+  const int64_t row = ut.ws_row + frame;
   float *x = plds + w * (d.D + d.G), *p = x + d.D;
   for (int k = lane; k < d.D; k += 64) x[k] = b.norm_lda[row * d.D + k];
   __builtin_amdgcn_wave_barrier();
@@ -240,12 +256,14 @@ __device__ inline double WaveSum(double v) {
 __global__ __launch_bounds__(256) void StepStatsKernel(IvDev d, IvBatch b) {
   extern __shared__ double ss[];               // xf[period][D], pw[cap], then int pg[cap], pt[cap]
   const int u = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t r0 = b.row_off[u] - b.row_base;
-  const int T = static_cast<int>(b.row_off[u + 1] - b.row_off[u]);
-  const int n_iv = (T + d.period - 1) / d.period;
-  if (i >= n_iv) return;
+  const IvUtt ut = b.utt[u];
+  const int64_t r0 = ut.ws_row;
+  if (i >= ut.n_steps) return;
   const int I = d.I, Q = d.Q, D = d.D;
-  const int f0 = i == 0 ? 0 : (i - 1) * d.period + 1, f1 = i * d.period, nf = f1 - f0 + 1;
+  int f0, f1;
+  if (ut.mode == 0) { f0 = i == 0 ? 0 : (i - 1) * d.period + 1; f1 = i * d.period; }
+  else { f0 = ut.stats_first + i * d.period; f1 = min(ut.stats_end, f0 + d.period) - 1; }
+  const int nf = f1 - f0 + 1;
   const int cap = d.period * d.ng;
   double *xf = ss, *pw = xf + d.period * D;
   int *pg = reinterpret_cast<int *>(pw + cap), *pt = pg + cap;
@@ -270,7 +288,7 @@ __global__ __launch_bounds__(256) void StepStatsKernel(IvDev d, IvBatch b) {
     n_pairs += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
     __syncthreads();
   }
-  const int64_t row = b.out_off[u] - b.out_base + i;
+  const int64_t row = ut.inc_row + i;
   for (int q = tid; q < Q; q += 256) {
     double acc = 0;
 #pragma unroll 8
@@ -340,7 +358,7 @@ constexpr int IV_CW = IV_MAX_DIM / 4;
 __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
   extern __shared__ double sl[];               // stage[Q], v[IV_MAX_DIM], part[4][IV_MAX_DIM], lin[IV_MAX_DIM]
   const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int T = static_cast<int>(b.row_off[u + 1] - b.row_off[u]);
+  const IvUtt ut = b.utt[u];
   const int I = d.I, Q = d.Q;
   double *stage = sl, *vsh = stage + Q, *part = vsh + IV_MAX_DIM, *lin = part + 4 * IV_MAX_DIM;
   __shared__ double s_num_frames, s_totw;
@@ -350,7 +368,8 @@ __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
   const int c0 = wave * IV_CW;
   // OnlineIvectorEstimationStats(ivector_dim, prior_offset, max_count) (ivector-extractor.cc:786-795): quadratic = I
   // ... or the statistics the speaker's previous utterance left (SetAdaptationState, online-ivector-feature.cc:427-435)
-  const double *sin = b.state_in ? b.state_in + static_cast<size_t>(u) * b.state_size + 2 * (d.feat_dim + 1) : NULL;
+  const double *rec_in = (b.state_in && ut.state_idx >= 0) ? b.state_in + static_cast<size_t>(ut.state_idx) * b.state_size : NULL;
+  const double *sin = rec_in ? rec_in + 2 * (d.feat_dim + 1) : NULL;
   double Aa[IV_CW], Ab[IV_CW];
 #pragma unroll
   for (int k = 0; k < IV_CW; k++) {
@@ -366,8 +385,9 @@ __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
   __syncthreads();
   if (tid == 0 && !sin) lin[0] = d.prior_offset;
   double xa = 0.0, xb = 0.0;                    // wavefront 0: the current estimate (rows ra, rb)
-  const int n_iv = (T + d.period - 1) / d.period;
-  const int64_t row0 = b.out_off[u] - b.out_base;
+  if (rec_in && b.x_off >= 0) { if (ha) xa = rec_in[b.x_off + ra]; if (hb) xb = rec_in[b.x_off + rb]; }
+  const int n_iv = ut.n_steps;
+  const int64_t row0 = ut.inc_row;
   constexpr int QPT = (IV_MAX_DIM * (IV_MAX_DIM + 1) / 2 + 255) / 256;
   for (int q = tid; q < Q; q += 256) stage[q] = b.dquad[row0 * Q + q];
   double nl = tid < I ? b.dlin[row0 * I + tid] : 0.0;
@@ -414,7 +434,8 @@ __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
     LdsBar();
     if (tid == 0) s_num_frames += s_totw;
     LdsBar();
-    const bool have = s_num_frames > 0.0;
+    const bool have = s_num_frames > 0.0 && (ut.mode == 0 || i == n_iv - 1);   // streaming: one GetIvector, after the last block
+    const bool emit = ut.mode == 0 || i == n_iv - 1;
     // ---- GetIvector (ivector-extractor.cc:732-756): LinearCgd from the previous estimate
     if (wave != 0) {
       if (have)
@@ -467,20 +488,24 @@ __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
         }
         if (lane == 0) s_cmd = 0;
         LdsBar();                                // the workers' B1: they leave their loop
-      } else {
+      } else if (emit) {
         xa = lane == 0 ? d.prior_offset : 0.0; xb = 0.0;
       }
-      float *o = b.out + (b.out_off[u] + i) * I;
+      float *o = b.out + (ut.out_row + (ut.mode == 0 ? i : 0)) * I;
+      if (emit) {
       if (ha) { float v = static_cast<float>(xa); if (ra == 0) v = static_cast<float>(static_cast<double>(v) - d.prior_offset); o[ra] = v; }
       if (hb) o[rb] = static_cast<float>(xb);
+      }
     }
     // park the prefetched increment in LDS for the next step (everybody is past the reads of `stage`)
 #pragma unroll
     for (int m = 0; m < QPT; m++) { const int q = tid + 256 * m; if (q < Q) stage[q] = nq[m]; }
     __syncthreads();
   }
-  if (b.state_out) {                             // GetAdaptationState: the statistics as of the last i-vector
-    double *so = b.state_out + static_cast<size_t>(u) * b.state_size + 2 * (d.feat_dim + 1);
+  if (b.state_out && ut.state_idx >= 0) {        // GetAdaptationState: the statistics as of the last i-vector
+    double *rec = b.state_out + static_cast<size_t>(ut.state_idx) * b.state_size;
+    if (wave == 0 && b.x_off >= 0) { if (ha) rec[b.x_off + ra] = xa; if (hb) rec[b.x_off + rb] = xb; }
+    double *so = rec + 2 * (d.feat_dim + 1);
 #pragma unroll
     for (int k = 0; k < IV_CW; k++) {
       const int c = c0 + k;
@@ -507,6 +532,7 @@ struct IvExtractor {
   int64_t *d_off = NULL; size_t off_cap = 0;
   double *d_dquad = NULL, *d_dlin = NULL, *d_dtotw = NULL; size_t dq_cap = 0, dl_cap = 0, dt_cap = 0;
   double *d_state_in = NULL, *d_state_out = NULL; size_t si_cap = 0, so_cap = 0;
+  IvUtt *d_utt = NULL; size_t utt_cap = 0;
   int64_t last_rows = 0;
 };
 
@@ -604,7 +630,7 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
 void kamd_ivector_extractor_destroy(kamd_ivector_extractor *h) {
   IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
   if (!e) return;
-  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_S, e->d_nl, e->d_rl, e->d_pg, e->d_pw, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw, e->d_state_in, e->d_state_out};
+  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_S, e->d_nl, e->d_rl, e->d_pg, e->d_pw, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw, e->d_state_in, e->d_state_out, e->d_utt};
   for (void *p : ps) if (p) (void)hipFree(p);
   delete e;
 }
@@ -626,6 +652,52 @@ int kamd_ivector_extract_online_device(kamd_ivector_extractor *h, const float *d
   return kamd_ivector_extract_online_adapt_device(h, d_feats, h_row_off, ld_feat, n_utts, d_out, h_out_row_off, NULL, NULL, stream);
 }
 
+// workspaces for ws_rows feature rows and inc_rows statistic increments; uploads the descriptors; launches
+static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std::vector<kamd::IvUtt> &utts, int64_t ws_rows,
+                    int64_t inc_rows, float *d_out, const double *d_state_in, double *d_state_out, int state_size, int x_off,
+                    hipStream_t st) {
+  const kamd::IvDev &v = e->dev;
+  const int n = static_cast<int>(utts.size());
+  if (kamd::GrowDev(&e->d_S, &e->S_cap, static_cast<size_t>(ws_rows) * v.feat_dim) != KAMD_OK) return KAMD_ERR_HIP;
+  size_t cap2 = e->lda_cap;
+  if (kamd::GrowDev(&e->d_nl, &e->lda_cap, static_cast<size_t>(ws_rows) * v.D) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&e->d_rl, &cap2, static_cast<size_t>(ws_rows) * v.D) != KAMD_OK) return KAMD_ERR_HIP;
+  size_t cap3 = e->post_cap;
+  if (kamd::GrowDev(&e->d_pg, &e->post_cap, static_cast<size_t>(ws_rows) * v.ng) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&e->d_pw, &cap3, static_cast<size_t>(ws_rows) * v.ng) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&e->d_dquad, &e->dq_cap, static_cast<size_t>(inc_rows) * v.Q) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&e->d_dlin, &e->dl_cap, static_cast<size_t>(inc_rows) * v.I) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&e->d_dtotw, &e->dt_cap, static_cast<size_t>(inc_rows)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&e->d_utt, &e->utt_cap, static_cast<size_t>(n)) != KAMD_OK) return KAMD_ERR_HIP;
+  KAMD_HIP(hipMemcpyAsync(e->d_utt, utts.data(), n * sizeof(kamd::IvUtt), hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));          // the descriptors are pageable host memory
+  int max_T = 0, max_proc = 0, max_steps = 0;
+  for (const kamd::IvUtt &u : utts) {
+    max_T = std::max(max_T, u.T); max_proc = std::max(max_proc, u.proc_end - u.proc_first); max_steps = std::max(max_steps, u.n_steps);
+  }
+  kamd::IvBatch b;
+  b.feats = d_feats; b.ld = ld_feat; b.utt = e->d_utt;
+  b.S = e->d_S; b.norm_lda = e->d_nl; b.raw_lda = e->d_rl; b.post_g = e->d_pg; b.post_w = e->d_pw; b.out = d_out;
+  b.dquad = e->d_dquad; b.dlin = e->d_dlin; b.dtotw = e->d_dtotw;
+  b.state_in = d_state_in; b.state_out = d_state_out; b.state_size = state_size; b.x_off = x_off;
+  hipLaunchKernelGGL(kamd::PrefixKernel, dim3(n), dim3(256), 0, st, v, b);
+  if (max_proc > 0) {
+    const size_t lds_front = static_cast<size_t>(2) * (kamd::IV_FT + v.L + v.R) * v.feat_dim * sizeof(float);
+    hipLaunchKernelGGL(kamd::FrontKernel, dim3(kamd::CeilDiv(max_proc, kamd::IV_FT), n), dim3(256), lds_front, st, v, b);
+    const size_t lds_post = static_cast<size_t>(4) * (v.D + v.G) * sizeof(float);
+    hipLaunchKernelGGL(kamd::PostKernel, dim3(kamd::CeilDiv(max_proc, 4), n), dim3(256), lds_post, st, v, b);
+  }
+  if (max_steps > 0) {
+    const int pair_cap = v.period * v.ng;
+    const size_t lds_step = (static_cast<size_t>(v.period) * v.D + pair_cap) * sizeof(double) + static_cast<size_t>(2) * pair_cap * sizeof(int);
+    hipLaunchKernelGGL(kamd::StepStatsKernel, dim3(max_steps, n), dim3(256), lds_step, st, v, b);
+    const size_t lds_solve = (static_cast<size_t>(v.Q) + 6 * kamd::IV_MAX_DIM) * sizeof(double);
+    hipLaunchKernelGGL(kamd::SolveKernel, dim3(n), dim3(256), lds_solve, st, v, b);
+  }
+  KAMD_HIP(hipGetLastError());
+  return KAMD_OK;
+}
+
 int kamd_ivector_extract_online_adapt_device(kamd_ivector_extractor *h, const float *d_feats, const int64_t *h_row_off, int ld_feat,
                                              int n_utts, float *d_out, const int64_t *h_out_row_off, const double *h_state_in,
                                              double *h_state_out, void *stream) {
@@ -634,64 +706,91 @@ int kamd_ivector_extract_online_adapt_device(kamd_ivector_extractor *h, const fl
   if (n_utts <= 0) return KAMD_OK;
   const kamd::IvDev &v = e->dev;
   if (ld_feat < v.feat_dim) return kamd::SetError(KAMD_ERR_ARG, "ld_feat %d < feature dim %d", ld_feat, v.feat_dim);
-  int max_T = 0;
+  std::vector<kamd::IvUtt> utts(n_utts);
   for (int u = 0; u < n_utts; u++) {
     const int64_t T = h_row_off[u + 1] - h_row_off[u];
     if (T <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no frames", u);
-    if (h_out_row_off[u + 1] - h_out_row_off[u] < (T + v.period - 1) / v.period)
+    const int n_iv = static_cast<int>((T + v.period - 1) / v.period);
+    if (h_out_row_off[u + 1] - h_out_row_off[u] < n_iv)
       return kamd::SetError(KAMD_ERR_ARG, "utterance %d: output rows too few for %lld frames", u, static_cast<long long>(T));
-    max_T = std::max<int>(max_T, static_cast<int>(T));
+    kamd::IvUtt &x = utts[u];
+    x.feat_row = h_row_off[u]; x.ws_row = h_row_off[u] - h_row_off[0]; x.out_row = h_out_row_off[u]; x.inc_row = h_out_row_off[u] - h_out_row_off[0];
+    x.T = static_cast<int>(T); x.proc_first = 0; x.proc_end = x.T; x.stats_first = 0; x.stats_end = x.T; x.mode = 0; x.n_steps = n_iv;
+    x.state_idx = (h_state_in || h_state_out) ? u : -1;
   }
-  const int64_t rows = h_row_off[n_utts] - h_row_off[0];
-  if (kamd::GrowDev(&e->d_S, &e->S_cap, static_cast<size_t>(rows) * v.feat_dim) != KAMD_OK) return KAMD_ERR_HIP;
-  size_t cap2 = e->lda_cap;
-  if (kamd::GrowDev(&e->d_nl, &e->lda_cap, static_cast<size_t>(rows) * v.D) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&e->d_rl, &cap2, static_cast<size_t>(rows) * v.D) != KAMD_OK) return KAMD_ERR_HIP;
-  size_t cap3 = e->post_cap;
-  if (kamd::GrowDev(&e->d_pg, &e->post_cap, static_cast<size_t>(rows) * v.ng) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&e->d_pw, &cap3, static_cast<size_t>(rows) * v.ng) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&e->d_off, &e->off_cap, static_cast<size_t>(2 * (n_utts + 1))) != KAMD_OK) return KAMD_ERR_HIP;
-  const int64_t iv_rows = h_out_row_off[n_utts] - h_out_row_off[0];
-  if (kamd::GrowDev(&e->d_dquad, &e->dq_cap, static_cast<size_t>(iv_rows) * v.Q) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&e->d_dlin, &e->dl_cap, static_cast<size_t>(iv_rows) * v.I) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&e->d_dtotw, &e->dt_cap, static_cast<size_t>(iv_rows)) != KAMD_OK) return KAMD_ERR_HIP;
-  KAMD_HIP(hipMemcpyAsync(e->d_off, h_row_off, (n_utts + 1) * 8, hipMemcpyHostToDevice, st));
-  KAMD_HIP(hipMemcpyAsync(e->d_off + n_utts + 1, h_out_row_off, (n_utts + 1) * 8, hipMemcpyHostToDevice, st));
-  KAMD_HIP(hipStreamSynchronize(st));          // the offset arrays are pageable host memory
-  kamd::IvBatch b;
-  b.feats = d_feats; b.ld = ld_feat; b.row_off = e->d_off; b.out_off = e->d_off + n_utts + 1;
-  b.S = e->d_S; b.norm_lda = e->d_nl; b.raw_lda = e->d_rl; b.post_g = e->d_pg; b.post_w = e->d_pw; b.out = d_out;
-  b.row_base = h_row_off[0]; b.out_base = h_out_row_off[0];
-  b.dquad = e->d_dquad; b.dlin = e->d_dlin; b.dtotw = e->d_dtotw;
+  const int64_t rows = h_row_off[n_utts] - h_row_off[0], iv_rows = h_out_row_off[n_utts] - h_out_row_off[0];
   const int SS = kamd_ivector_state_size(h);
-  b.state_in = NULL; b.state_out = NULL; b.state_size = SS;
+  const double *d_in = NULL; double *d_so = NULL;
   if (h_state_in) {
     if (kamd::GrowDev(&e->d_state_in, &e->si_cap, static_cast<size_t>(n_utts) * SS) != KAMD_OK) return KAMD_ERR_HIP;
     KAMD_HIP(hipMemcpyAsync(e->d_state_in, h_state_in, static_cast<size_t>(n_utts) * SS * 8, hipMemcpyHostToDevice, st));
     KAMD_HIP(hipStreamSynchronize(st));
-    b.state_in = e->d_state_in;
+    d_in = e->d_state_in;
   }
   if (h_state_out) {
     if (kamd::GrowDev(&e->d_state_out, &e->so_cap, static_cast<size_t>(n_utts) * SS) != KAMD_OK) return KAMD_ERR_HIP;
-    b.state_out = e->d_state_out;
+    d_so = e->d_state_out;
   }
-  hipLaunchKernelGGL(kamd::PrefixKernel, dim3(n_utts), dim3(256), 0, st, v, b);
-  const size_t lds_front = static_cast<size_t>(2) * (kamd::IV_FT + v.L + v.R) * v.feat_dim * sizeof(float);
-  hipLaunchKernelGGL(kamd::FrontKernel, dim3(kamd::CeilDiv(max_T, kamd::IV_FT), n_utts), dim3(256), lds_front, st, v, b);
-  const size_t lds_post = static_cast<size_t>(4) * (v.D + v.G) * sizeof(float);
-  hipLaunchKernelGGL(kamd::PostKernel, dim3(kamd::CeilDiv(rows, 4)), dim3(256), lds_post, st, v, b, rows);
-  const int max_iv = (max_T + v.period - 1) / v.period, pair_cap = v.period * v.ng;
-  const size_t lds_step = (static_cast<size_t>(v.period) * v.D + pair_cap) * sizeof(double) + static_cast<size_t>(2) * pair_cap * sizeof(int);
-  hipLaunchKernelGGL(kamd::StepStatsKernel, dim3(max_iv, n_utts), dim3(256), lds_step, st, v, b);
-  const size_t lds_solve = (static_cast<size_t>(v.Q) + 6 * kamd::IV_MAX_DIM) * sizeof(double);
-  hipLaunchKernelGGL(kamd::SolveKernel, dim3(n_utts), dim3(256), lds_solve, st, v, b);
-  KAMD_HIP(hipGetLastError());
+  const int rc = RunBatch(e, d_feats, ld_feat, utts, rows, iv_rows, d_out, d_in, d_so, SS, -1, st);
+  if (rc != KAMD_OK) return rc;
   e->last_rows = rows;
   if (h_state_out) {
     KAMD_HIP(hipMemcpyAsync(h_state_out, e->d_state_out, static_cast<size_t>(n_utts) * SS * 8, hipMemcpyDeviceToHost, st));
     KAMD_HIP(hipStreamSynchronize(st));
   }
   return KAMD_OK;
+}
+
+// Streaming form: OnlineIvectorFeature::GetFrame with use_most_recent_ivector = true
+// (online2/online-ivector-feature.cc:206-320): item i is a stream whose base features so far are rows
+// [h_feat_row[i], + h_n_base[i]) of d_feats (and of the workspaces: the caller reserves ws_rows_total rows);
+// frames [h_n_done[i], h_n_upto[i]) are new: their LDA features and posteriors are computed, they enter
+// the statistics as one batch, then num_cg_iters CG steps run from the stream's current estimate.
+// d_records: the streams' records of kamd_ivector_stream_record_size() doubles (adaptation state | current
+// estimate), device resident, updated in place; h_record[i] says which record item i owns.  d_out row i
+// receives the estimate (prior offset removed from dimension 0).
+int kamd_ivector_stream_record_size(const kamd_ivector_extractor *h) {
+  return kamd_ivector_state_size(h) + reinterpret_cast<const IvExtractor *>(h)->dev.I;
+}
+
+// a record for a new utterance: the speaker's adaptation state (NULL: fresh) and no estimate yet
+int kamd_ivector_stream_record_init(const kamd_ivector_extractor *h, const double *state, double *record) {
+  const kamd::IvDev &v = reinterpret_cast<const IvExtractor *>(h)->dev;
+  const int SS = kamd_ivector_state_size(h), sdim = v.feat_dim + 1;
+  if (state) memcpy(record, state, sizeof(double) * SS);
+  else {
+    memset(record, 0, sizeof(double) * SS);
+    double *quad = record + 2 * sdim, *lin = quad + v.Q;
+    for (int i = 0; i < v.I; i++) quad[static_cast<size_t>(i) * (i + 1) / 2 + i] = 1.0;
+    lin[0] = v.prior_offset;
+  }
+  memset(record + SS, 0, sizeof(double) * v.I);
+  return KAMD_OK;
+}
+
+int kamd_ivector_stream_update_device(kamd_ivector_extractor *h, const float *d_feats, int ld_feat, int64_t ws_rows_total,
+                                      const int64_t *h_feat_row, const int32_t *h_n_base, const int32_t *h_n_done,
+                                      const int32_t *h_n_upto, const int32_t *h_record, int n, double *d_records, float *d_out,
+                                      void *stream) {
+  IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0) return KAMD_OK;
+  const kamd::IvDev &v = e->dev;
+  if (ld_feat < v.feat_dim) return kamd::SetError(KAMD_ERR_ARG, "ld_feat %d < feature dim %d", ld_feat, v.feat_dim);
+  std::vector<kamd::IvUtt> utts(n);
+  int64_t inc = 0;
+  for (int i = 0; i < n; i++) {
+    if (h_n_done[i] < 0 || h_n_upto[i] <= h_n_done[i] || h_n_upto[i] > h_n_base[i] || h_feat_row[i] < 0 ||
+        h_feat_row[i] + h_n_base[i] > ws_rows_total)
+      return kamd::SetError(KAMD_ERR_ARG, "stream item %d: bad frame ranges", i);
+    kamd::IvUtt &x = utts[i];
+    x.feat_row = h_feat_row[i]; x.ws_row = h_feat_row[i]; x.out_row = i; x.inc_row = inc;
+    x.T = h_n_base[i]; x.proc_first = h_n_done[i]; x.proc_end = h_n_upto[i]; x.stats_first = h_n_done[i]; x.stats_end = h_n_upto[i];
+    x.mode = 1; x.n_steps = (h_n_upto[i] - h_n_done[i] + v.period - 1) / v.period; x.state_idx = h_record[i];
+    inc += x.n_steps;
+  }
+  const int RS = kamd_ivector_stream_record_size(h);
+  return RunBatch(e, d_feats, ld_feat, utts, ws_rows_total, inc, d_out, d_records, d_records, RS, RS - v.I, st);
 }
 
 // OnlineIvectorExtractorAdaptationState::LimitFrames (online2/online-ivector-feature.cc:96-117) with

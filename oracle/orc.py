@@ -47,6 +47,7 @@ def lib():
                                                C.c_int, C.c_int, C.c_int, fp, C.c_int]
         dp = C.POINTER(C.c_double)
         L.orc_ivector_extract_online.argtypes = [C.POINTER(abi.IvectorDesc), fp, C.c_int, fp, C.c_int, fp, fp, ip, fp, ip, dp, dp]
+        L.orc_ivector_extract_streaming.argtypes = [C.POINTER(abi.IvectorDesc), fp, C.c_int, ip, C.c_int, fp, dp, dp]
         L.orc_ivector_state_limit_frames.argtypes = [C.POINTER(abi.IvectorDesc), dp, C.c_float]
         L.orc_ivector_state_limit_frames.restype = None
         L.orc_linear_cgd.argtypes = [C.c_int, C.c_int, dp, dp, dp]
@@ -173,6 +174,21 @@ def ivector_extract_online(info, feats, diagnostics=False, state=None, return_st
     else:
         res = out
     return (res, st_out) if return_state else res
+
+
+def ivector_extract_streaming(info, feats, upto, state=None):
+    """OnlineIvectorFeature::GetFrame(upto[c] - 1) for c = 0, 1, ... with use_most_recent_ivector: [n_calls x dim]"""
+    f = np.ascontiguousarray(feats, np.float32)
+    u = np.ascontiguousarray(upto, np.int32)
+    d = info.desc()
+    out = np.zeros((u.size, info.ivector_dim), np.float32)
+    dp = C.POINTER(C.c_double)
+    st_in = np.ascontiguousarray(state, np.float64) if state is not None else None
+    st_out = np.zeros(info.state_size(), np.float64)
+    r = lib().orc_ivector_extract_streaming(C.byref(d), abi.fptr(f), f.shape[0], abi.iptr(u), u.size, abi.fptr(out),
+                                            st_in.ctypes.data_as(dp) if st_in is not None else None, st_out.ctypes.data_as(dp))
+    assert r == u.size, r
+    return out, st_out
 
 
 def linear_cgd(A_packed, b, x0, max_iters):

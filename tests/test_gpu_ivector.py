@@ -215,3 +215,60 @@ def test_ivector_extract_online2_tool(tmp_path):
     w3 = orc.ivector_extract_online(info, feats["b1"])
     for k, w in (("a1", w1), ("a2", w2), ("b1", w3)):
         np.testing.assert_allclose(got[k], w, rtol=0, atol=1e-4 * max(1.0, np.abs(w).max()))
+
+
+def test_streaming_updates_match_the_oracle_schedule():
+    """kamd_ivector_stream_update_device: two streams with different arrival schedules (frames in uneven batches, one
+    batch longer than the i-vector period, a call without new frames in between is simply not made); every estimate
+    equals the oracle's GetFrame sequence, and the record's statistics equal the oracle's at the end."""
+    import ctypes as C
+    from kaldi_amd import cmvn
+    from kaldi_amd._lib import check, lib
+    from kaldi_amd.decoder import DeviceMatrix
+    info = ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=40, ivector_dim=10, seed=4, splice_left=2, splice_right=1,
+                                  max_count=2.0, cmn_window=50, speaker_frames=50, global_frames=20)
+    ie = ivector.IvectorExtractor(info)
+    rng = np.random.default_rng(5)
+    T = [97, 140]
+    max_frames = 160
+    feats = np.zeros((2 * max_frames, 8), np.float32)
+    x = [(rng.standard_normal((t, 8)) * 1.1 + 0.4).astype(np.float32) for t in T]
+    for s in range(2):
+        feats[s * max_frames:s * max_frames + T[s]] = x[s]
+    # base frames ready at each tick; frames that may enter the statistics = ready - splice_right until the end
+    sched = [[5, 23, 24, 60, 97], [30, 31, 95, 120, 140]]
+    RS = lib().kamd_ivector_stream_record_size(ie._h)
+    rec = np.zeros((2, RS), np.float64)
+    dp = C.POINTER(C.c_double)
+    for s in range(2):
+        check(lib().kamd_ivector_stream_record_init(ie._h, None, rec[s].ctypes.data_as(dp)))
+    d_feats, d_rec, d_out = DeviceMatrix(feats), cmvn._Dev(rec), DeviceMatrix(np.zeros((2, 10), np.float32))
+    done = [0, 0]
+    got = [[], []]
+    for tick in range(5):
+        items = []
+        for s in range(2):
+            ready = sched[s][tick]
+            upto = ready if ready == T[s] else max(0, ready - info.splice_right)
+            if upto > done[s]:
+                items.append((s, ready, done[s], upto))
+        fr = np.asarray([s * max_frames for s, _, _, _ in items], np.int64)
+        nb = np.asarray([r for _, r, _, _ in items], np.int32)
+        nd = np.asarray([d for _, _, d, _ in items], np.int32)
+        nu = np.asarray([u for _, _, _, u in items], np.int32)
+        ri = np.asarray([s for s, _, _, _ in items], np.int32)
+        check(lib().kamd_ivector_stream_update_device(ie._h, d_feats.ptr(0), 8, 2 * max_frames, abi.iptr(fr, C.c_int64), abi.iptr(nb), abi.iptr(nd),
+                                                      abi.iptr(nu), abi.iptr(ri), len(items), d_rec.p, d_out.ptr(0), None))
+        out = d_out.download()
+        for k, (s, _, _, u) in enumerate(items):
+            got[s].append((u, out[k].copy()))
+            done[s] = u
+    d_rec.download(rec)
+    for s in range(2):
+        uptos = [u for u, _ in got[s]]
+        want, st = orc.ivector_extract_streaming(info, x[s], uptos)
+        for (u, g), w in zip(got[s], want):
+            np.testing.assert_allclose(g, w, rtol=0, atol=1e-4 * max(1.0, np.abs(w).max()), err_msg="stream %d upto %d" % (s, u))
+        n0 = 2 * 9
+        np.testing.assert_allclose(rec[s][n0:info.state_size()], st[n0:], rtol=1e-9, atol=1e-9 * np.abs(st).max())
+    assert len(got[0]) == 5 and len(got[1]) == 5
