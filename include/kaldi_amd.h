@@ -536,6 +536,22 @@ int kamd_stream_batch_accept(kamd_stream_batch *b, int stream, const float *wave
 /* AdvanceDecoding for all listed streams; frames_decoded[n] may be NULL */
 int kamd_stream_batch_advance(kamd_stream_batch *b, const int32_t *streams, int n, int32_t *frames_decoded);
 int kamd_stream_batch_num_frames_ready(const kamd_stream_batch *b, int stream);
+/* Online i-vectors in the streaming path (online2-wav-nnet3-latgen-faster with an ivector-extraction config):
+ * OnlineIvectorFeature with use_most_recent_ivector feeding DecodableNnetLoopedOnline.  Call before any stream is
+ * started.  frames_per_chunk = the looped decodable's --frames-per-chunk (20 in the online recipes; its i-vector
+ * period), splice_right = the extractor's splicing right context.  With it the network is served chunk by chunk
+ * like the reference (chunk k once (k+1)*frames_per_chunk + right-context frames exist, or at the end); a tick
+ * that makes chunks computable advances the stream's estimate once, to the most recent frame
+ * (decodable-online-looped.cc:160-190), and the i-vector slots floor(t / frames_per_chunk) those chunks bring in
+ * (nnet3/nnet-compile-looped.cc:186-207) get that estimate. */
+int kamd_stream_batch_set_ivector_extractor(kamd_stream_batch *b, kamd_ivector_extractor *e, int frames_per_chunk,
+                                            int splice_right);
+/* start with the speakers' adaptation states (n x kamd_ivector_state_size() doubles; NULL = fresh) and read a
+ * stream's state back after its utterance (before LimitFrames) */
+int kamd_stream_batch_start_adapted(kamd_stream_batch *b, const int32_t *streams, int n, const double *states);
+int kamd_stream_batch_get_adaptation_state(kamd_stream_batch *b, int stream, double *state);
+int kamd_stream_batch_get_ivector_slots(kamd_stream_batch *b, int stream, float *out, int rows_cap, int *first_slot,
+                                        int *count);
 /* building blocks of the above: frames [first, first+count) of n waveforms that are not
  * adjacent in memory, and an nnet forward over n non-adjacent feature slices */
 int kamd_feat_compute_ranges_device(kamd_feat *f, const float *d_waves, const int64_t *h_wave_start,

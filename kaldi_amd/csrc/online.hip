@@ -170,9 +170,32 @@ extern "C" int kamd_feat_compute_ranges_device(kamd_feat *h, const float *d_wave
 extern "C" int kamd_nnet_forward_slices_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_start,
                                                const int32_t *h_in_len, int ld_in, const float *d_ivectors, int n_items,
                                                float *d_out, const int64_t *h_out_row_off, int ld_out, void *stream);
+extern "C" int kamd_nnet_forward_slices_slots_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_start, const int32_t *h_in_len,
+                                                     int ld_in, const float *d_ivector_table, int table_rows, int period,
+                                                     const int32_t *h_slot_base, const int32_t *h_slot_first, const int32_t *h_slot_count,
+                                                     const int32_t *h_abs_t0, int n_items, float *d_out, const int64_t *h_out_row_off,
+                                                     int ld_out, void *stream);
 namespace kamd {
+// rows src[src_row[i]] -> dst[dst_row[i] .. dst_row[i] + count[i]) (a stream's new i-vector slots all get the tick's estimate)
+__global__ void AssignSlotsKernel(const float *src, float *dst, const int *src_row, const int *dst_row, const int *count, int dim) {
+  const int i = blockIdx.x;
+  for (int r = 0; r < count[i]; r++)
+    for (int k = threadIdx.x; k < dim; k += blockDim.x) dst[static_cast<size_t>(dst_row[i] + r) * dim + k] = src[static_cast<size_t>(src_row[i]) * dim + k];
+}
 struct StreamBatch {
   kamd_feat *feat; kamd_nnet *nnet; kamd_decoder *dec;
+  // online i-vectors (kamd_stream_batch_set_ivector_extractor): DecodableNnetLoopedOnline's schedule.  The
+  // network is served chunk by chunk of `chunk` input frames (chunk k once (k+1)*chunk + right context frames
+  // are there, or the input is finished); when a tick makes new chunks computable the stream's estimate is
+  // advanced ONCE to the most recent frame (OnlineIvectorFeature::GetFrame, use_most_recent_ivector) and every
+  // i-vector slot floor(t / chunk) those chunks' input ranges introduce gets it (nnet-compile-looped.cc:186-207).
+  kamd_ivector_extractor *ie = NULL;
+  int chunk = 0, iv_dim = 0, splice_right = 0, slot_first = 0, max_slots = 0, rec_size = 0;
+  double *d_rec = NULL;          // [S][rec_size]
+  float *d_slots = NULL;         // [S][max_slots][iv_dim]
+  float *d_est = NULL;           // [S][iv_dim]: the tick's estimates (row = position in the update call)
+  int *d_assign = NULL;          // 3 x S ints
+  std::vector<int> chunks_done, iv_done, slots_assigned;
   int S = 0, dim = 0, ld = 0, P = 0, max_frames = 0;
   int64_t max_samples = 0;
   float *d_wave = NULL, *d_frames = NULL, *d_ll = NULL;
@@ -213,7 +236,79 @@ void kamd_stream_batch_destroy(kamd_stream_batch *h) {
   if (b->d_wave) (void)hipFree(b->d_wave);
   if (b->d_frames) (void)hipFree(b->d_frames);
   if (b->d_ll) (void)hipFree(b->d_ll);
+  if (b->d_rec) (void)hipFree(b->d_rec);
+  if (b->d_slots) (void)hipFree(b->d_slots);
+  if (b->d_est) (void)hipFree(b->d_est);
+  if (b->d_assign) (void)hipFree(b->d_assign);
   delete b;
+}
+
+int kamd_stream_batch_set_ivector_extractor(kamd_stream_batch *h, kamd_ivector_extractor *ie, int frames_per_chunk, int splice_right) {
+  StreamBatch *b = reinterpret_cast<StreamBatch *>(h);
+  for (int s = 0; s < b->S; s++) if (b->live[s]) return kamd::SetError(KAMD_ERR_STATE, "set the i-vector extractor before any stream is started");
+  const int sub = kamd_nnet_frame_subsampling_factor(b->nnet);
+  if (!ie || frames_per_chunk <= 0 || splice_right < 0) return kamd::SetError(KAMD_ERR_ARG, "bad i-vector extractor / frames per chunk");
+  // GetChunkSize (nnet3/nnet-utils / decodable-simple-looped.cc:52-56): rounded up to a multiple of the subsampling factor
+  frames_per_chunk = sub * ((frames_per_chunk + sub - 1) / sub);
+  b->ie = ie; b->chunk = frames_per_chunk; b->iv_dim = kamd_ivector_dim(ie); b->splice_right = splice_right;
+  const int lc = kamd_nnet_left_context(b->nnet), rc = kamd_nnet_right_context(b->nnet);
+  b->slot_first = -((lc + frames_per_chunk - 1) / frames_per_chunk);                   // floor(-lc / chunk)
+  b->max_slots = (b->max_frames + rc + frames_per_chunk) / frames_per_chunk + 2 - b->slot_first;
+  b->rec_size = kamd_ivector_stream_record_size(ie);
+  b->chunks_done.assign(b->S, 0); b->iv_done.assign(b->S, 0); b->slots_assigned.assign(b->S, 0);
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&b->d_rec), static_cast<size_t>(b->S) * b->rec_size * sizeof(double)));
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&b->d_slots), static_cast<size_t>(b->S) * b->max_slots * b->iv_dim * sizeof(float)));
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&b->d_est), static_cast<size_t>(b->S + 1) * b->iv_dim * sizeof(float)));
+  KAMD_HIP(hipMemset(b->d_est, 0, static_cast<size_t>(b->S + 1) * b->iv_dim * sizeof(float)));     // row S stays zero
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&b->d_assign), static_cast<size_t>(3) * b->S * sizeof(int)));
+  return KAMD_OK;
+}
+
+// like kamd_stream_batch_start, each stream with its speaker's adaptation state (states: n records of
+// kamd_ivector_state_size() doubles, or NULL = fresh): SetAdaptationState (online2-wav-nnet3-latgen-faster.cc:232-236)
+int kamd_stream_batch_start_adapted(kamd_stream_batch *h, const int32_t *streams, int n, const double *states) {
+  StreamBatch *b = reinterpret_cast<StreamBatch *>(h);
+  if (!b->ie) return kamd::SetError(KAMD_ERR_STATE, "no i-vector extractor set");
+  const int rc = kamd_stream_batch_start(h, streams, n);      // fresh records
+  if (rc != KAMD_OK || !states) return rc;
+  const int SS = kamd_ivector_state_size(b->ie);
+  std::vector<double> rec(b->rec_size);
+  for (int i = 0; i < n; i++) {
+    kamd_ivector_stream_record_init(b->ie, states + static_cast<size_t>(i) * SS, rec.data());
+    KAMD_HIP(hipMemcpy(b->d_rec + static_cast<size_t>(streams[i]) * b->rec_size, rec.data(), b->rec_size * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return KAMD_OK;
+}
+
+// diagnostic / tests: the i-vector slots assigned so far (slot first_slot + j = time range [(first_slot + j) * chunk, +chunk))
+int kamd_stream_batch_get_ivector_slots(kamd_stream_batch *h, int stream, float *out, int rows_cap, int *first_slot, int *count) {
+  StreamBatch *b = reinterpret_cast<StreamBatch *>(h);
+  if (!b->ie) return kamd::SetError(KAMD_ERR_STATE, "no i-vector extractor set");
+  if (stream < 0 || stream >= b->S) return kamd::SetError(KAMD_ERR_ARG, "stream %d out of range", stream);
+  *first_slot = b->slot_first; *count = b->slots_assigned[stream];
+  if (*count > rows_cap) return kamd::SetError(KAMD_ERR_ARG, "buffer too small for %d slots", *count);
+  KAMD_HIP(hipDeviceSynchronize());
+  if (*count > 0)
+    KAMD_HIP(hipMemcpy(out, b->d_slots + static_cast<size_t>(stream) * b->max_slots * b->iv_dim, static_cast<size_t>(*count) * b->iv_dim * sizeof(float),
+                       hipMemcpyDeviceToHost));
+  return KAMD_OK;
+}
+
+// GetAdaptationState after the utterance (online2-wav-nnet3-latgen-faster.cc:284): the i-vector statistics as they
+// are plus the speaker CMVN statistics advanced by every frame of this utterance; LimitFrames is the caller's
+// (kamd_ivector_state_limit_frames)
+int kamd_stream_batch_get_adaptation_state(kamd_stream_batch *h, int stream, double *state) {
+  StreamBatch *b = reinterpret_cast<StreamBatch *>(h);
+  if (!b->ie) return kamd::SetError(KAMD_ERR_STATE, "no i-vector extractor set");
+  if (stream < 0 || stream >= b->S || !b->live[stream]) return kamd::SetError(KAMD_ERR_ARG, "stream %d is not started", stream);
+  const int SS = kamd_ivector_state_size(b->ie);
+  KAMD_HIP(hipDeviceSynchronize());
+  KAMD_HIP(hipMemcpy(state, b->d_rec + static_cast<size_t>(stream) * b->rec_size, SS * sizeof(double), hipMemcpyDeviceToHost));
+  if (b->n_frames[stream] > 0) {
+    const int64_t off[2] = {static_cast<int64_t>(stream) * b->max_frames, static_cast<int64_t>(stream) * b->max_frames + b->n_frames[stream]};
+    return kamd_cmvn_acc_stats_device(b->d_frames, off, b->ld, b->dim, 1, state, NULL);
+  }
+  return KAMD_OK;
 }
 
 // a new utterance on these streams: SingleUtteranceNnet3DecoderTpl's constructor calls
@@ -223,7 +318,14 @@ int kamd_stream_batch_start(kamd_stream_batch *h, const int32_t *streams, int n)
   for (int i = 0; i < n; i++) {
     const int s = streams[i];
     if (s < 0 || s >= b->S) return kamd::SetError(KAMD_ERR_ARG, "stream %d out of range", s);
-    b->n_samp[s] = 0; b->n_frames[s] = 0; b->decoded[s] = 0; b->finished[s] = 0; b->live[s] = 1;
+    b->n_samp[s] = 0; b->n_frames[s] = 0; b->decoded[s] = 0; b->finished[s] = 0;
+    if (b->ie) {                  // a fresh adaptation state; kamd_stream_batch_start_adapted replaces it
+      std::vector<double> rec(b->rec_size);
+      kamd_ivector_stream_record_init(b->ie, NULL, rec.data());
+      KAMD_HIP(hipMemcpy(b->d_rec + static_cast<size_t>(s) * b->rec_size, rec.data(), b->rec_size * sizeof(double), hipMemcpyHostToDevice));
+      b->chunks_done[s] = 0; b->iv_done[s] = 0; b->slots_assigned[s] = 0;
+    }
+    b->live[s] = 1;
   }
   int rc = kamd_decoder_init(b->dec, streams, n, NULL);
   if (rc != KAMD_OK) return rc;
@@ -272,17 +374,83 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
                                              static_cast<int>(wstart.size()), b->d_frames, frow.data(), b->ld, st);
     if (rc != KAMD_OK) return rc;
   }
-  // ---- nnet: one item per stream with new output frames (DecodableAmNnetLoopedOnline's rows)
+  // ---- online i-vectors: which chunks became computable, one estimate update per stream, new slots
   const int sub = kamd_nnet_frame_subsampling_factor(b->nnet);
   const int L = kamd_nnet_left_context(b->nnet), R = kamd_nnet_right_context(b->nnet);
+  std::vector<int> ready_out(n, 0);
+  if (b->ie) {
+    std::vector<int64_t> u_row; std::vector<int32_t> u_base, u_done, u_upto, u_rec;
+    std::vector<int> a_src, a_dst, a_cnt;
+    for (int i = 0; i < n; i++) {
+      const int s = streams[i], F = b->n_frames[s], fin = b->finished[s] ? 1 : 0, C = b->chunk;
+      const int n_out_total = kamd_nnet_num_output_frames(b->nnet, F);
+      int k = b->chunks_done[s];
+      while (F > 0 && (fin ? k * C < n_out_total * sub : (k + 1) * C + R <= F)) k++;
+      ready_out[i] = fin ? n_out_total : std::min(n_out_total, k * C / sub);
+      if (k == b->chunks_done[s]) continue;
+      // the estimate the decodable fetches: GetFrame(min(most recent input frame, NumFramesReady() - 1)) (decodable-online-looped.cc:174-183)
+      const int iv_ready = fin ? F : std::max(0, F - b->splice_right);
+      int src = b->S;                                     // "leave the iVector zero": row S of d_est
+      if (iv_ready > b->iv_done[s]) {
+        src = static_cast<int>(u_row.size());
+        u_row.push_back(static_cast<int64_t>(s) * b->max_frames); u_base.push_back(F); u_done.push_back(b->iv_done[s]);
+        u_upto.push_back(iv_ready); u_rec.push_back(s);
+        b->iv_done[s] = iv_ready;
+      } else if (b->iv_done[s] > 0) src = -1 - s;         // no new frame: the stream's last estimate (kept in its last slot)
+      // slots the new chunks' input ranges introduce (nnet-compile-looped.cc:186-207)
+      const int hi_t = k * C + R - 1;                     // last input time of chunk k - 1
+      const int last_slot = (hi_t >= 0 ? hi_t / C : -1) - b->slot_first;
+      const int have = b->slots_assigned[s];
+      if (last_slot + 1 > b->max_slots) return kamd::SetError(KAMD_ERR_CAPACITY, "stream %d: i-vector slots exhausted", s);
+      if (last_slot + 1 > have) {
+        a_src.push_back(src); a_dst.push_back(s * b->max_slots + have); a_cnt.push_back(last_slot + 1 - have);
+        b->slots_assigned[s] = last_slot + 1;
+      }
+      b->chunks_done[s] = k;
+    }
+    if (!u_row.empty()) {
+      int rc = kamd_ivector_stream_update_device(b->ie, b->d_frames, b->ld, static_cast<int64_t>(b->S) * b->max_frames, u_row.data(),
+                                                 u_base.data(), u_done.data(), u_upto.data(), u_rec.data(), static_cast<int>(u_row.size()),
+                                                 b->d_rec, b->d_est, st);
+      if (rc != KAMD_OK) return rc;
+    }
+    if (!a_src.empty()) {
+      const int m = static_cast<int>(a_src.size());
+      // "no new frame" sources: copy from the stream's previous last slot (it holds the last estimate)
+      std::vector<int> src_row(m);
+      for (int j = 0; j < m; j++) src_row[j] = a_src[j];
+      const float *src_base = b->d_est;
+      // estimates and old slots live in different buffers: run two launches, one per source buffer
+      std::vector<int> e_src, e_dst, e_cnt, o_src, o_dst, o_cnt;
+      for (int j = 0; j < m; j++) {
+        if (a_src[j] >= 0) { e_src.push_back(a_src[j]); e_dst.push_back(a_dst[j]); e_cnt.push_back(a_cnt[j]); }
+        else { o_src.push_back(a_dst[j] - 1); o_dst.push_back(a_dst[j]); o_cnt.push_back(a_cnt[j]); }
+      }
+      for (int pass = 0; pass < 2; pass++) {
+        std::vector<int> &S1 = pass ? o_src : e_src, &D1 = pass ? o_dst : e_dst, &C1 = pass ? o_cnt : e_cnt;
+        const int mm = static_cast<int>(S1.size());
+        if (mm == 0) continue;
+        KAMD_HIP(hipMemcpyAsync(b->d_assign, S1.data(), mm * sizeof(int), hipMemcpyHostToDevice, st));
+        KAMD_HIP(hipMemcpyAsync(b->d_assign + b->S, D1.data(), mm * sizeof(int), hipMemcpyHostToDevice, st));
+        KAMD_HIP(hipMemcpyAsync(b->d_assign + 2 * b->S, C1.data(), mm * sizeof(int), hipMemcpyHostToDevice, st));
+        KAMD_HIP(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(kamd::AssignSlotsKernel, dim3(mm), dim3(128), 0, st, pass ? b->d_slots : src_base, b->d_slots, b->d_assign,
+                           b->d_assign + b->S, b->d_assign + 2 * b->S, b->iv_dim);
+        KAMD_HIP(hipGetLastError());
+        KAMD_HIP(hipStreamSynchronize(st));           // d_assign is reused by the second pass
+      }
+    }
+  }
+  // ---- nnet: one item per stream with new output frames (DecodableAmNnetLoopedOnline's rows)
   std::vector<int64_t> in_start, out_off;
   std::vector<int32_t> in_len;
   std::vector<kamd_decode_task> tasks;
   std::vector<int> k0s, counts, sid;
+  std::vector<int32_t> sl_base, sl_first, sl_count, sl_t0;
   int64_t rows = 0;
   for (int i = 0; i < n; i++) {
     const int s = streams[i];
-    const int ready = kamd_nnet_num_frames_ready(b->nnet, b->n_frames[s], b->finished[s] ? 1 : 0);
+    const int ready = b->ie ? ready_out[i] : kamd_nnet_num_frames_ready(b->nnet, b->n_frames[s], b->finished[s] ? 1 : 0);
     const int count = ready - b->decoded[s];
     if (count <= 0) continue;
     const int out_first = b->decoded[s];
@@ -294,6 +462,7 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
     out_off.push_back(rows);
     rows += kamd_nnet_num_output_frames(b->nnet, T);
     k0s.push_back(k0); counts.push_back(count); sid.push_back(s);
+    if (b->ie) { sl_base.push_back(s * b->max_slots); sl_first.push_back(b->slot_first); sl_count.push_back(b->slots_assigned[s]); sl_t0.push_back(in_first); }
   }
   if (!sid.empty()) {
     const size_t need = static_cast<size_t>(rows) * b->P;
@@ -304,8 +473,12 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
       KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&b->d_ll), 2 * need * sizeof(float)));
       b->ll_cap = 2 * need;
     }
-    int rc = kamd_nnet_forward_slices_device(b->nnet, b->d_frames, in_start.data(), in_len.data(), b->ld, NULL,
-                                             static_cast<int>(sid.size()), b->d_ll, out_off.data(), b->P, st);
+    int rc = b->ie
+      ? kamd_nnet_forward_slices_slots_device(b->nnet, b->d_frames, in_start.data(), in_len.data(), b->ld, b->d_slots, b->S * b->max_slots,
+                                              b->chunk, sl_base.data(), sl_first.data(), sl_count.data(), sl_t0.data(),
+                                              static_cast<int>(sid.size()), b->d_ll, out_off.data(), b->P, st)
+      : kamd_nnet_forward_slices_device(b->nnet, b->d_frames, in_start.data(), in_len.data(), b->ld, NULL,
+                                        static_cast<int>(sid.size()), b->d_ll, out_off.data(), b->P, st);
     if (rc != KAMD_OK) return rc;
     tasks.resize(sid.size());
     for (size_t k = 0; k < sid.size(); k++) {

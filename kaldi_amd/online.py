@@ -222,9 +222,40 @@ class StreamBatch:
             lib().kamd_stream_batch_destroy(self._h)
             self._h = None
 
-    def start(self, streams):
+    def set_ivector_extractor(self, extractor, frames_per_chunk=20):
+        """Online i-vectors as online2-wav-nnet3-latgen-faster computes them (OnlineIvectorFeature with
+        use_most_recent_ivector + DecodableNnetLoopedOnline's chunk schedule); before the first start()."""
+        check(lib().kamd_stream_batch_set_ivector_extractor(self._h, extractor._h, frames_per_chunk, extractor.info.splice_right))
+        sub = lib().kamd_nnet_frame_subsampling_factor(self.nnet._h)
+        self.extractor, self.frames_per_chunk = extractor, sub * ((frames_per_chunk + sub - 1) // sub)   # GetChunkSize rounding
+
+    def start(self, streams, states=None):
+        """states: one adaptation state per stream (the speaker's, after LimitFrames) or None = fresh"""
         s = np.ascontiguousarray(streams, np.int32)
-        check(lib().kamd_stream_batch_start(self._h, abi.iptr(s), s.size))
+        if states is None:
+            check(lib().kamd_stream_batch_start(self._h, abi.iptr(s), s.size))
+        else:
+            st = np.ascontiguousarray(states, np.float64).reshape(s.size, -1)
+            check(lib().kamd_stream_batch_start_adapted(self._h, abi.iptr(s), s.size, st.ctypes.data_as(C.POINTER(C.c_double))))
+
+    def adaptation_state(self, stream, max_remembered_frames=1000.0):
+        """GetAdaptationState + LimitFrames after the stream's utterance: what the speaker's next utterance starts from"""
+        st = np.zeros(self.extractor.info.state_size(), np.float64)
+        dp = C.POINTER(C.c_double)
+        check(lib().kamd_stream_batch_get_adaptation_state(self._h, int(stream), st.ctypes.data_as(dp)))
+        check(lib().kamd_ivector_state_limit_frames(self.extractor._h, st.ctypes.data_as(dp), max_remembered_frames))
+        return st
+
+    def ivector_slots(self, stream):
+        """(first slot number, [slots x dim]): slot j covers first-layer times [j * frames_per_chunk, +frames_per_chunk)"""
+        cap = 4096
+        out = np.zeros((cap, self.extractor.dim()), np.float32)
+        first, cnt = C.c_int32(), C.c_int32()
+        check(lib().kamd_stream_batch_get_ivector_slots(self._h, int(stream), abi.fptr(out), cap, C.byref(first), C.byref(cnt)))
+        return first.value, out[:cnt.value].copy()
+
+    def num_frames_ready(self, stream):
+        return lib().kamd_stream_batch_num_frames_ready(self._h, int(stream))
 
     def accept(self, stream, waveform, input_finished=False):
         w = np.ascontiguousarray(waveform, np.float32)

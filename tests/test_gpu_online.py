@@ -164,3 +164,89 @@ def test_batched_streams_equal_offline():
     sb.finalize([1])
     assert lattices_equal(sb.raw_lattice(1), offline(w2))
     assert lattices_equal(sb.raw_lattice(2), offline(waves[2]))
+
+
+def test_batched_streams_with_online_ivectors():
+    """online2-wav-nnet3-latgen-faster with an i-vector extractor, two streams fed in different chunkings:
+    (1) the slots' i-vectors equal the oracle's GetFrame sequence under the reference's chunk schedule
+        (chunk k computable once (k+1)*20 + right context frames exist; estimate advanced once per tick to
+        frames_ready - splice_right; slots floor(t/20) of the new chunks' input ranges get it);
+    (2) the lattice equals an offline decode of the network evaluated with exactly those slots (bit-equal);
+    (3) the adaptation state left for the speaker's next utterance equals the oracle's."""
+    from kaldi_amd import ivector
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, ivector_dim=16, seed=12, output_scale=3.0)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    waves = [synth.make_wave(d, seed=60 + i) for i, d in enumerate((3.0, 1.7))]
+    feats = [feat.Mfcc(op).ComputeFeatures(w) for w in waves]
+    allf = np.concatenate(feats)
+    info = ivector.make_synthetic(num_gauss=64, ivector_dim=16, seed=9, feat_mean=allf.mean(0), feat_std=allf.std(0), max_count=10.0)
+    ie = ivector.IvectorExtractor(info)
+    S, C_ = 2, 20
+    sb = online.StreamBatch(op, N, G, cfg, S, max_seconds=5.0, sizes=abi.DecoderSizes(S, 1 << 14, 1 << 19, 1 << 20, 512))
+    sb.set_ivector_extractor(ie, C_)
+    C_ = sb.frames_per_chunk
+    assert C_ == 21                       # --frames-per-chunk=20 rounded up to a multiple of the subsampling factor
+    sb.start([0, 1])
+    L, R = N.Context()
+    step = [int(0.18 * 16000), int(0.31 * 16000)]
+    pos = [0, 0]
+    calls = [[], []]                      # oracle schedule: upto of every estimate update
+    slot_src = [[], []]                   # per assigned slot: index into calls (or -1 = zero vector)
+    chunks_done, iv_done = [0, 0], [0, 0]
+    done = [False, False]
+    sub = m.subsampling
+    while not all(done):
+        live = [s for s in range(S) if not done[s]]
+        for s in live:
+            chunk = waves[s][pos[s]:pos[s] + step[s]]
+            pos[s] += chunk.size
+            sb.accept(s, chunk, input_finished=pos[s] >= waves[s].size)
+        sb.advance(live)
+        for s in live:
+            fin = pos[s] >= waves[s].size
+            F = sb.num_frames_ready(s)
+            n_out_total = (F + sub - 1) // sub
+            k = chunks_done[s]
+            while F > 0 and ((k * C_ < n_out_total * sub) if fin else ((k + 1) * C_ + R <= F)):
+                k += 1
+            if k > chunks_done[s]:
+                iv_ready = F if fin else max(0, F - info.splice_right)
+                if iv_ready > iv_done[s]:
+                    calls[s].append(iv_ready); iv_done[s] = iv_ready
+                src = len(calls[s]) - 1
+                slot_first = -((L + C_ - 1) // C_)
+                last = (k * C_ + R - 1) // C_ - slot_first
+                slot_src[s] += [src] * (last + 1 - len(slot_src[s]))
+                chunks_done[s] = k
+            if fin:
+                done[s] = True
+    sb.finalize([0, 1])
+    for s in range(S):
+        assert feats[s].shape[0] == sb.num_frames_ready(s)
+        first, slots = sb.ivector_slots(s)
+        assert first == -((L + C_ - 1) // C_) and slots.shape[0] == len(slot_src[s])
+        want_iv, want_state = orc.ivector_extract_streaming(info, feats[s], calls[s])
+        for j, src in enumerate(slot_src[s]):
+            w = want_iv[src] if src >= 0 else np.zeros(16, np.float32)
+            np.testing.assert_allclose(slots[j], w, rtol=0, atol=1e-4 * max(1.0, np.abs(w).max()), err_msg="stream %d slot %d" % (s, j))
+        assert len(set(slot_src[s])) >= 4                              # the estimate did move between chunks
+        ll = N.ForwardSlots(feats[s], slots, first, C_)[0]
+        off = decoder.LatticeFasterDecoder(G, cfg, abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512))
+        off.Decode(ll)
+        got = sb.raw_lattice(s)
+        assert lattices_equal(got, off.GetRawLattice()), (s, lattice_diff(got, off.GetRawLattice()))
+        # the network really saw different i-vectors over time, close to the oracle's evaluation of the same slots
+        np.testing.assert_allclose(ll, orc.nnet_forward_slots(m, feats[s], slots, first, C_), rtol=0, atol=2e-3)
+        st = sb.adaptation_state(s, max_remembered_frames=1e9)
+        np.testing.assert_allclose(st, want_state, rtol=1e-8, atol=1e-8 * np.abs(want_state).max())
+    # the speaker's next utterance starts from that state
+    st0 = sb.adaptation_state(0, max_remembered_frames=100.0)
+    sb.start([0], states=[st0])
+    sb.accept(0, waves[1], input_finished=True)
+    sb.advance([0])
+    sb.finalize([0])
+    _, slots2 = sb.ivector_slots(0)
+    want2, _ = orc.ivector_extract_streaming(info, feats[1], [feats[1].shape[0]], state=st0)
+    np.testing.assert_allclose(slots2[-1], want2[0], rtol=0, atol=1e-4 * max(1.0, np.abs(want2[0]).max()))
