@@ -15,20 +15,29 @@ ap.add_argument("--seconds", type=float, default=12.0)
 ap.add_argument("--chunk", type=float, default=0.24)
 ap.add_argument("--ll-std", type=float, default=1.3)
 ap.add_argument("--streams", type=int, default=0, help="> 0: that many concurrent streams through kamd_stream_batch")
+ap.add_argument("--ivectors", action="store_true", help="with --streams: the model takes 100-dim online i-vectors, estimated per "
+                "stream on the device (512-Gaussian UBM) and fed on DecodableNnetLoopedOnline's chunk schedule (--frames-per-chunk 20)")
 a = ap.parse_args()
 g = synth.make_hclg(num_units=1164, vocab=20000, n_hist=18000, fanout=(12, 64), pron_len=(3, 7), seed=2,
                     self_loop_prob=0.5, lm_scale=0.1)
-model = nnet.tdnnf_mini_librispeech(num_pdfs=g.num_pdfs)
+model = nnet.tdnnf_mini_librispeech(num_pdfs=g.num_pdfs, ivector_dim=100 if a.ivectors else 0)
 cfg = abi.decoder_config_recipe()
 wave = synth.make_wave(a.seconds, seed=7)
 # calibrate the output scale like bench.py does
 from bench import calibrate
-calibrate(model, a.ll_std)
+ie = None
+if a.ivectors:
+    from kaldi_amd import feat, ivector
+    sample = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(wave[:16000 * 5])
+    ie = ivector.IvectorExtractor(ivector.make_synthetic(seed=11, feat_mean=sample.mean(0), feat_std=sample.std(0), max_count=100.0))
+calibrate(model, a.ll_std, ie)
 N, G = decoder.Nnet(model), decoder.Graph(g)
 if a.streams > 0:
     S = a.streams
     waves = [synth.make_wave(a.seconds, seed=100 + i) for i in range(S)]
     sb = online.StreamBatch(abi.mfcc_opts_hires(), N, G, cfg, S, max_seconds=a.seconds + 1)
+    if ie is not None:
+        sb.set_ivector_extractor(ie, 20)
     step = int(a.chunk * 16000)
     for rep in range(2):
         sb.start(np.arange(S))
