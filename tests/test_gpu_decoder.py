@@ -335,6 +335,21 @@ def test_latgen_faster_mapped_tool(tmp_path):
         o = orc.Decoder(g, cfg, 1)
         o.Decode(ll)
         assert lats[key][2].size == o.GetRawLattice().arcs.size
+    # the same command line as a C++ host program over kaldi_amd.hpp (examples/latgen_faster_mapped.cc):
+    # identical words, alignments and raw lattice archive
+    exe = str(tmp_path / "latgen-faster-mapped-amd")
+    libdir = root + "/kaldi_amd/lib"
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", root + "/include", root + "/examples/latgen_faster_mapped.cc", "-o", exe,
+                           "-L", libdir, "-lkaldi_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"])
+    r = subprocess.run([exe, "--acoustic-scale=1.0", "--beam=15", "--lattice-beam=8", "--max-active=7000", "--determinize-lattice=false",
+                        str(tmp_path / "id2pdf.int"), str(tmp_path / "HCLG.fst"), "ark:%s" % (tmp_path / "ll.ark"),
+                        "ark:%s" % (tmp_path / "lat_cxx.ark"), "ark,t:%s" % (tmp_path / "words_cxx.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Done 3 utterances, failed for 0" in r.stderr
+    assert open(tmp_path / "words_cxx.txt").read() == open(tmp_path / "words.txt").read()
+    assert open(tmp_path / "lat_cxx.ark", "rb").read() == open(tmp_path / "lat.ark", "rb").read()
+    r = subprocess.run([exe, "--no-such=1", "a", "b", "c", "d"], capture_output=True, text=True)
+    assert r.returncode == 255
 
 
 def test_nnet3_latgen_faster_tool(tmp_path):
