@@ -264,7 +264,7 @@ class TableWriter:
         self.type, self.ark, self.scp, self.opts = classify_wspecifier(wspecifier)
         if self.type == NO_SPECIFIER:
             raise KamdError("invalid wspecifier " + wspecifier)
-        if kind not in ("matrix", "int32", "lattice", "compact_lattice"):
+        if kind not in ("matrix", "int32", "lattice", "compact_lattice", "raw"):
             raise KamdError("unknown table object type " + kind)
         self.kind, self.acoustic_scale, self.closed = kind, acoustic_scale, False
         self._scp_lines, self._tmp = [], None
@@ -294,6 +294,9 @@ class TableWriter:
         elif self.kind == "int32":
             with open(path, "ab") as f:
                 f.write(_int32_bytes(key, value, b))
+        elif self.kind == "raw":                     # value = the serialised object (after "key "), bytes
+            with open(path, "ab") as f:
+                f.write(key.encode() + b" " + value)
         elif self.kind == "lattice":
             kio.write_lattice(path, key, value, binary=b, append=True, acoustic_scale=self.acoustic_scale)
         else:
