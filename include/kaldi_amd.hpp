@@ -556,6 +556,70 @@ class SingleUtteranceNnet3Decoder {
   bool finished_;
 };
 
+// ---- N concurrent SingleUtteranceNnet3Decoder's behind one set of launches (kamd_stream_batch_*): stream s is decoder lane s.
+// With an OnlineIvectorExtractor the streams get online i-vectors as OnlineNnet2FeaturePipeline + DecodableAmNnetLoopedOnline
+// compute them (online2-wav-nnet3-latgen-faster.cc:200-290).
+class OnlineIvectorExtractor;
+class OnlineStreamBatch {
+ public:
+  OnlineStreamBatch(const LatticeFasterDecoderConfig &decoder_opts, const std::vector<int32> &id2pdf, const AmNnetSimple &am_nnet,
+                    const DecodingGraph &fst, const MfccOptions &mfcc_opts, int32 max_streams, BaseFloat max_seconds,
+                    const kamd_decoder_sizes &sizes)
+      : feat_(CheckPtr(kamd_mfcc_create(&mfcc_opts.c, 1.0f))), ie_(NULL) {
+    decoder_opts.Check();
+    kamd_decoder_config c = decoder_opts.ToC();
+    dec_ = CheckPtr(kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), static_cast<int32>(id2pdf.size())));
+    h_ = CheckPtr(kamd_stream_batch_create(feat_, am_nnet.Handle(), dec_, max_streams, max_seconds, mfcc_opts.c.frame.samp_freq));
+  }
+  ~OnlineStreamBatch() { kamd_stream_batch_destroy(h_); kamd_decoder_destroy(dec_); kamd_feat_destroy(feat_); }
+  OnlineStreamBatch(const OnlineStreamBatch &) = delete;
+  OnlineStreamBatch &operator=(const OnlineStreamBatch &) = delete;
+  /// before the first Start(): --ivector-extraction-config of the online2 binaries
+  void SetIvectorExtractor(kamd_ivector_extractor *extractor, int32 frames_per_chunk, int32 splice_right) {
+    Check(kamd_stream_batch_set_ivector_extractor(h_, extractor, frames_per_chunk, splice_right));
+    ie_ = extractor;
+  }
+  /// new utterances; adaptation_states (optional): one state per stream, kamd_ivector_state_size() doubles each
+  void Start(const std::vector<int32> &streams, const std::vector<double> *adaptation_states = NULL) {
+    if (adaptation_states && ie_) Check(kamd_stream_batch_start_adapted(h_, streams.data(), static_cast<int>(streams.size()), adaptation_states->data()));
+    else Check(kamd_stream_batch_start(h_, streams.data(), static_cast<int>(streams.size())));
+  }
+  void AcceptWaveform(int32 stream, const float *wave, int64_t n, bool input_finished) {
+    Check(kamd_stream_batch_accept(h_, stream, wave, n, input_finished ? 1 : 0));
+  }
+  /// one tick: AdvanceDecoding of all listed streams
+  void AdvanceDecoding(const std::vector<int32> &streams, std::vector<int32> *frames_decoded = NULL) {
+    if (frames_decoded) frames_decoded->resize(streams.size());
+    Check(kamd_stream_batch_advance(h_, streams.data(), static_cast<int>(streams.size()), frames_decoded ? frames_decoded->data() : NULL));
+  }
+  void FinalizeDecoding(const std::vector<int32> &streams) {
+    Check(kamd_decoder_finalize(dec_, streams.data(), static_cast<int>(streams.size()), NULL));
+    Check(kamd_decoder_sync(dec_));
+  }
+  bool GetBestPath(int32 stream, std::vector<int32> *alignment, std::vector<int32> *words, BaseFloat *graph_cost, BaseFloat *acoustic_cost) const {
+    kamd_lattice_size sz;
+    Check(kamd_decoder_lattice_size(dec_, stream, &sz));
+    const int cap = sz.num_arcs + 1;
+    std::vector<int32> ali(cap), wrd(cap);
+    int na = 0, nw = 0;
+    if (kamd_decoder_best_path(dec_, stream, ali.data(), cap, &na, wrd.data(), cap, &nw, graph_cost, acoustic_cost) != 0) return false;
+    alignment->assign(ali.begin(), ali.begin() + na); words->assign(wrd.begin(), wrd.begin() + nw);
+    return true;
+  }
+  /// GetAdaptationState + LimitFrames: what the speaker's next utterance starts from
+  void GetAdaptationState(int32 stream, BaseFloat max_remembered_frames, std::vector<double> *state) const {
+    state->resize(kamd_ivector_state_size(ie_));
+    Check(kamd_stream_batch_get_adaptation_state(h_, stream, state->data()));
+    Check(kamd_ivector_state_limit_frames(ie_, state->data(), max_remembered_frames));
+  }
+  kamd_decoder *DecoderHandle() { return dec_; }
+ private:
+  kamd_feat *feat_;
+  kamd_decoder *dec_;
+  kamd_stream_batch *h_;
+  kamd_ivector_extractor *ie_;
+};
+
 // ---- online i-vectors: OnlineIvectorFeature over a whole utterance (online2/online-ivector-feature.h:246-330)
 // with the speaker's OnlineIvectorExtractorAdaptationState, as ivector-extract-online2 uses it.
 class OnlineIvectorExtractorAdaptationState {

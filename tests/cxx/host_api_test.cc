@@ -108,6 +108,80 @@ int main(int argc, char **argv) {
         printf("wrapper ok=%d like=%.6g\n", ok, like);
       }
     }
+    // OnlineStreamBatch: two streams (one of them with online i-vectors from the third fixture's extractor, which
+    // reads the first 8 cepstra) against the Python mirror driving the same C-ABI (argv[3] model, argv[4] extractor)
+    if (argc >= 6) {
+      FILE *mf = fopen(argv[3], "rb"), *xf = fopen(argv[4], "rb");
+      if (!mf || !xf) return 2;
+      std::vector<int64_t> mh = ReadVec<int64_t>(mf);
+      const int nl = static_cast<int>(mh[0]);
+      std::vector<kamd_layer_desc> layers(nl);
+      std::vector<std::vector<float> > keep(5 * nl);
+      for (int l = 0; l < nl; l++) {
+        std::vector<int32> li = ReadVec<int32>(mf);
+        std::vector<float> lf = ReadVec<float>(mf);
+        kamd_layer_desc &d = layers[l];
+        memset(&d, 0, sizeof(d));
+        d.in_dim = li[0]; d.out_dim = li[1]; d.n_offsets = li[2];
+        for (int k = 0; k < 8; k++) d.offsets[k] = li[3 + k];
+        d.input_layer = li[11]; d.ivector_dim = li[12]; d.bypass_layer = li[13]; d.relu = li[14]; d.log_softmax = li[15];
+        d.bypass_scale = lf[0]; d.post_scale = lf[1];
+        for (int k = 0; k < 5; k++) keep[5 * l + k] = ReadVec<float>(mf);
+      }
+      for (int l = 0; l < nl; l++) {
+        const float **slots[5] = {&layers[l].W, &layers[l].bias, &layers[l].bn_scale, &layers[l].bn_offset, &layers[l].post_offset};
+        for (int k = 0; k < 5; k++) *slots[k] = keep[5 * l + k].empty() ? NULL : keep[5 * l + k].data();
+      }
+      std::vector<float> wave = ReadVec<float>(mf);
+      fclose(mf);
+      std::vector<int32> ih = ReadVec<int32>(xf);
+      std::vector<float> lda = ReadVec<float>(xf), gc = ReadVec<float>(xf), miv = ReadVec<float>(xf), iv = ReadVec<float>(xf);
+      std::vector<double> gstats = ReadVec<double>(xf), M = ReadVec<double>(xf), sinv = ReadVec<double>(xf), sc = ReadVec<double>(xf);
+      fclose(xf);
+      kamd_ivector_desc d;
+      memset(&d, 0, sizeof(d));
+      d.feat_dim = ih[0]; d.splice_left = ih[1]; d.splice_right = ih[2]; d.lda_rows = ih[3]; d.lda_cols = ih[4]; d.lda = lda.data();
+      d.global_cmvn_stats = gstats.data(); d.cmn_window = ih[12]; d.speaker_frames = ih[13]; d.global_frames = ih[14];
+      d.normalize_mean = 1; d.num_gauss = ih[5]; d.ubm_gconsts = gc.data(); d.ubm_means_invvars = miv.data(); d.ubm_inv_vars = iv.data();
+      d.ivector_dim = ih[6]; d.M = M.data(); d.sigma_inv = sinv.data(); d.prior_offset = sc[0];
+      d.ivector_period = ih[7]; d.num_gselect = ih[8]; d.num_cg_iters = ih[9];
+      d.min_post = static_cast<float>(sc[1]); d.posterior_scale = static_cast<float>(sc[2]); d.max_count = static_cast<float>(sc[3]);
+      OnlineIvectorExtractor extractor(d, 60.0);
+      AmNnetSimple am(layers, static_cast<int>(mh[1]), static_cast<int>(mh[2]));
+      MfccOptions mo;
+      kamd_mfcc_opts_default(&mo.c);
+      mo.c.use_energy = 0; mo.c.mel.num_bins = 40; mo.c.num_ceps = 40; mo.c.mel.low_freq = 20.0f; mo.c.mel.high_freq = -400.0f;
+      kamd_decoder_sizes bs = sz;
+      bs.max_lanes = 2;
+      OnlineStreamBatch batch(config, id2pdf, am, fst, mo, 2, 4.0f, bs);
+      batch.SetIvectorExtractor(extractor.handle(), 20, d.splice_right);
+      std::vector<int32> both = {0, 1};
+      batch.Start(both);
+      const size_t step[2] = {2880, 4960};
+      size_t pos[2] = {0, 0};
+      const size_t len[2] = {wave.size(), wave.size() * 2 / 3};
+      while (pos[0] < len[0] || pos[1] < len[1]) {
+        std::vector<int32> live;
+        for (int s = 0; s < 2; s++) {
+          if (pos[s] >= len[s]) continue;
+          const size_t n = std::min(step[s], len[s] - pos[s]);
+          batch.AcceptWaveform(s, wave.data() + pos[s], static_cast<int64_t>(n), pos[s] + n >= len[s]);
+          pos[s] += n; live.push_back(s);
+        }
+        batch.AdvanceDecoding(live);
+      }
+      batch.FinalizeDecoding(both);
+      for (int s = 0; s < 2; s++) {
+        std::vector<int32> ali, words; BaseFloat g = 0, a = 0;
+        const bool ok = batch.GetBestPath(s, &ali, &words, &g, &a);
+        std::vector<double> st;
+        batch.GetAdaptationState(s, 60.0f, &st);
+        printf("batch stream=%d ok=%d frames=%d cost=%.9g count=%.9g lin1=%.9g words=", s, ok, static_cast<int>(ali.size()), g + a, st[d.feat_dim],
+               st[2 * (d.feat_dim + 1) + d.ivector_dim * (d.ivector_dim + 1) / 2 + 1]);
+        for (size_t k = 0; k < words.size(); k++) printf("%s%d", k ? "," : "", words[k]);
+        printf("\n");
+      }
+    }
     // online i-vectors with the speaker's adaptation state: two utterances of one speaker (third fixture)
     if (argc >= 5) {
       FILE *xf = fopen(argv[4], "rb");

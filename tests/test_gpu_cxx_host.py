@@ -70,7 +70,37 @@ def test_cxx_host_api(tmp_path):
             vec(f, np.ascontiguousarray(a, np.float64))
         vec(f, f1); vec(f, f2)
     exe = build_cxx(str(tmp_path))
-    out = subprocess.check_output([exe, str(fx), str(tmp_path), str(mfx), str(xfx)], text=True, stderr=subprocess.DEVNULL).strip().splitlines()
+    out = subprocess.check_output([exe, str(fx), str(tmp_path), str(mfx), str(xfx), "batch"], text=True, stderr=subprocess.DEVNULL).strip().splitlines()
+    # OnlineStreamBatch with online i-vectors: the same two streams through the Python mirror
+    from kaldi_amd import online
+    N2, G2 = decoder.Nnet(m), decoder.Graph(g)
+    cfgb = abi.decoder_config_recipe()
+    sb = online.StreamBatch(abi.mfcc_opts_hires(), N2, G2, cfgb, 2, max_seconds=4.0, sizes=abi.DecoderSizes(2, 1 << 14, 1 << 18, 1 << 19, 1024))
+    ieb = ivector.IvectorExtractor(info)
+    sb.set_ivector_extractor(ieb, 20)
+    sb.start([0, 1])
+    wv = wave.astype(np.float32)
+    lens, steps, pos = [wv.size, wv.size * 2 // 3], [2880, 4960], [0, 0]
+    while pos[0] < lens[0] or pos[1] < lens[1]:
+        live = []
+        for s_ in range(2):
+            if pos[s_] >= lens[s_]:
+                continue
+            n_ = min(steps[s_], lens[s_] - pos[s_])
+            sb.accept(s_, wv[pos[s_]:pos[s_] + n_], input_finished=pos[s_] + n_ >= lens[s_])
+            pos[s_] += n_; live.append(s_)
+        sb.advance(live)
+    sb.finalize([0, 1])
+    batch_lines = [l for l in out if l.startswith("batch ")]
+    assert len(batch_lines) == 2
+    for s_ in range(2):
+        bp = sb.best_path(s_)
+        st_ = sb.adaptation_state(s_, max_remembered_frames=60.0)
+        want_line = "batch stream=%d ok=1 frames=%d cost=%.9g count=%.9g lin1=%.9g words=%s" % (
+            s_, len(bp["alignment"]), np.float32(bp["graph_cost"]) + np.float32(bp["acoustic_cost"]), st_[8], st_[2 * 9 + 55 + 1],
+            ",".join(str(w) for w in bp["words"]))
+        assert batch_lines[s_] == want_line
+    out = [l for l in out if not l.startswith("batch ")]
     ie = ivector.IvectorExtractor(info)
     _, st = ie.extract_online(f1, return_state=True, max_remembered_frames=60.0)
     want_iv = ie.extract_online(f2, state=st)
