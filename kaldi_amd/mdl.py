@@ -153,13 +153,15 @@ def read_transition_model(s):
     s.vector()
     s.expect("</LogProbs>")
     s.expect("</TransitionModel>")
-    id2pdf, tid_phone = [-1], [0]                           # ComputeDerived (transition-model.cc:144-188)
+    id2pdf, tid_phone, tid2phone = [-1], [0], [0]           # ComputeDerived (transition-model.cc:144-188)
     for ph, hs, fp, sp in tuples:
         trans = entries[phone2idx[ph]][hs][2]
         for dst, _ in trans:
             self_loop = dst == hs                           # IsSelfLoop (:319-327)
             id2pdf.append(sp if self_loop else fp)
             tid_phone.append(ph if (hs == 0 and not self_loop) else 0)
+            tid2phone.append(ph)                            # TransitionIdToPhone
+    read_transition_model.tid2phone = np.asarray(tid2phone, np.int32)
     return np.asarray(id2pdf, np.int32), np.asarray(tid_phone, np.int32), phones
 
 
@@ -202,6 +204,7 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
     if s.take(2) != b"\0B":
         raise MdlError("binary Kaldi file expected (text-mode models: nnet3-am-copy --binary=true)")
     id2pdf, tid_phone, _ = read_transition_model(s)
+    tid2phone = read_transition_model.tid2phone             # every transition-id's phone (endpointing)
     s.expect("<Nnet3>")
     # config section: text lines until an empty line (nnet-nnet.cc:601-610)
     end = s.b.index(b"\n\n", s.p)
@@ -329,4 +332,5 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
     out.post_scale = float(acoustic_scale)
     m = Model(layers, inputs["input"], inputs.get("ivector", 0), frame_subsampling_factor, out.out_dim,
               name=str(path))
+    m.tid2phone = tid2phone
     return m, id2pdf, tid_phone

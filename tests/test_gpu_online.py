@@ -250,3 +250,72 @@ def test_batched_streams_with_online_ivectors():
     _, slots2 = sb.ivector_slots(0)
     want2, _ = orc.ivector_extract_streaming(info, feats[1], [feats[1].shape[0]], state=st0)
     np.testing.assert_allclose(slots2[-1], want2[0], rtol=0, atol=1e-4 * max(1.0, np.abs(want2[0]).max()))
+
+
+def test_online2_wav_nnet3_latgen_faster_tool(tmp_path):
+    """final.mdl with an i-vector input + online.conf (mfcc config, i-vector extraction config) + spk2utt + wav.scp ->
+    CompactLattice archive.  Two speakers; streams are independent, so decoding them one at a time or together gives
+    the same archive; the first utterance equals a direct StreamBatch run; the second utterance of a speaker starts
+    from the first one's adaptation state (it differs from a fresh start)."""
+    import subprocess
+    import sys
+    import wave
+    import os
+    from kaldi_amd import io as kio
+    from kaldi_amd import ivector, latbin
+    from tests.mdl_writer import write_mdl
+    g = synth.make_hclg(num_units=25, vocab=60, n_hist=12, seed=6)
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, ivector_dim=16, seed=12, output_scale=3.0)
+    write_mdl(tmp_path / "final.mdl", m, num_units=25)
+    kio.write_openfst(tmp_path / "HCLG.fst", g, "const")
+    waves = {"a1": 2.1, "a2": 1.4, "b1": 1.8}
+    waves = {k: np.round(synth.make_wave(d, seed=90 + i)).astype(np.float32) for i, (k, d) in enumerate(waves.items())}
+    op = abi.mfcc_opts_hires()
+    allf = np.concatenate([feat.Mfcc(op).ComputeFeatures(w) for w in waves.values()])
+    info = ivector.make_synthetic(num_gauss=64, ivector_dim=16, seed=9, feat_mean=allf.mean(0), feat_std=allf.std(0), max_count=10.0)
+    iconf = ivector.write_config_dir(tmp_path / "ivector_extractor", info)
+    (tmp_path / "mfcc.conf").write_text("--use-energy=false\n--num-mel-bins=40\n--num-ceps=40\n--low-freq=20\n--high-freq=-400\n")
+    (tmp_path / "online.conf").write_text("--feature-type=mfcc\n--mfcc-config=%s\n--ivector-extraction-config=%s\n--endpoint.silence-phones=1:2\n" %
+                                          (tmp_path / "mfcc.conf", iconf))
+    with open(tmp_path / "wav.scp", "w") as scp:
+        for k, w in waves.items():
+            with wave.open(str(tmp_path / (k + ".wav")), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(w.astype("<i2").tobytes())
+            scp.write("%s %s\n" % (k, tmp_path / (k + ".wav")))
+    (tmp_path / "spk2utt").write_text("spkA a1 a2\nspkB b1\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, root + "/tools/online2_wav_nnet3_latgen_faster.py", "--config=%s" % (tmp_path / "online.conf"), "--beam=15",
+            "--max-active=7000", "--lattice-beam=8", "--acoustic-scale=1.0", "--frame-subsampling-factor=3", "--max-seconds=3",
+            "--chunk-length=0.18"]
+    outs = []
+    for batch in (1, 2):
+        lat = tmp_path / ("lat%d.ark" % batch)
+        r = subprocess.run(base + ["--batch=%d" % batch, str(tmp_path / "final.mdl"), str(tmp_path / "HCLG.fst"), "ark:%s" % (tmp_path / "spk2utt"),
+                                   "scp:%s" % (tmp_path / "wav.scp"), "ark:%s" % lat], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "Decoded 3 utterances, 0 with errors." in r.stderr
+        outs.append(open(lat, "rb").read())
+    assert outs[0] == outs[1]
+    got = {k: latbin.best_path(l)[0] for k, l in latbin.read_lattices("ark:%s" % (tmp_path / "lat1.ark"))}
+    assert list(got) == ["a1", "a2", "b1"]
+    # direct run of the first utterance, same chunking
+    g.tid2pdf = np.concatenate([[-1], np.stack([2 * np.arange(25) + 1, 2 * np.arange(25)], 1).reshape(-1)]).astype(np.int32)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    ie = ivector.IvectorExtractor(ivector.IvectorExtractionInfo.from_config(iconf))
+    sb = online.StreamBatch(op, N, G, abi.decoder_config_recipe(), 1, max_seconds=3.0)
+    sb.set_ivector_extractor(ie, 20)
+
+    def run(w, state=None):
+        sb.start([0], states=None if state is None else [state])
+        step = int(0.18 * 16000)
+        for i in range(0, w.size, step):
+            sb.accept(0, w[i:i + step], input_finished=i + step >= w.size)
+            sb.advance([0])
+        sb.finalize([0])
+        return sb.best_path(0)["words"].tolist(), sb.adaptation_state(0, 1000.0), sb.ivector_slots(0)[1]
+    w1, st1, _ = run(waves["a1"])
+    assert got["a1"] == w1
+    w2, _, slots_adapted = run(waves["a2"], st1)
+    assert got["a2"] == w2
+    _, _, slots_fresh = run(waves["a2"])
+    assert np.abs(slots_adapted[-1] - slots_fresh[-1]).max() > 1e-3
