@@ -205,7 +205,8 @@ class StreamBatch:
     """N concurrent streams decoded together (kamd_stream_batch_*): stream s = decoder lane s."""
 
     def __init__(self, mfcc_opts, nnet, graph, config, max_streams, max_seconds=40.0, sizes=None):
-        self.feat = __import__("kaldi_amd.feat", fromlist=["Mfcc"]).Mfcc(mfcc_opts)
+        featmod = __import__("kaldi_amd.feat", fromlist=["Mfcc"])
+        self.feat = featmod.Fbank(mfcc_opts) if isinstance(mfcc_opts, abi.FbankOpts) else featmod.Mfcc(mfcc_opts)
         self.nnet, self.graph, self.config = nnet, graph, config
         sub = lib().kamd_nnet_frame_subsampling_factor(nnet._h)
         if sizes is None:

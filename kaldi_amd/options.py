@@ -18,14 +18,30 @@ IGNORED = ("debug-computation", "extra-left-context", "extra-right-context", "ex
 
 def register_mfcc(po):
     d = abi.mfcc_opts_default()
-    f, m = d.frame, d.mel
+    _register_frame_mel(po, d.frame, d.mel)
+    po.register("num-ceps", int, d.num_ceps, "Number of cepstra in MFCC computation (including C0)")
+    po.register("use-energy", bool, bool(d.use_energy), "Use energy (not C0) in MFCC computation")
+    po.register("energy-floor", float, d.energy_floor, "Floor on energy (absolute, not relative) in MFCC computation")
+    po.register("raw-energy", bool, bool(d.raw_energy), "If true, compute energy before preemphasis and windowing")
+    po.register("cepstral-lifter", float, d.cepstral_lifter, "Constant that controls scaling of MFCCs")
+    po.register("htk-compat", bool, bool(d.htk_compat), "If true, put energy or C0 last")
+
+
+def mfcc_opts(po):
+    o = abi.mfcc_opts_default()
+    _frame_mel_from(po, o)
+    o.num_ceps, o.use_energy, o.energy_floor = po["num-ceps"], int(po["use-energy"]), po["energy-floor"]
+    o.raw_energy, o.cepstral_lifter, o.htk_compat = int(po["raw-energy"]), po["cepstral-lifter"], int(po["htk-compat"])
+    return o
+
+
+def _register_frame_mel(po, f, m):
     po.register("sample-frequency", float, f.samp_freq, "Waveform data sample frequency")
     po.register("frame-length", float, f.frame_length_ms, "Frame length in milliseconds")
     po.register("frame-shift", float, f.frame_shift_ms, "Frame shift in milliseconds")
     po.register("preemphasis-coefficient", float, f.preemph_coeff, "Coefficient for use in signal preemphasis")
     po.register("remove-dc-offset", bool, bool(f.remove_dc_offset), "Subtract mean from waveform on each frame")
-    po.register("dither", float, 0.0, "Dithering constant; only 0 (no dithering) is supported: the reference's "
-                "default of 1.0 adds random noise, which no bit-reproducible path can match")
+    po.register("dither", float, 0.0, "Dithering constant; only 0 is supported")
     po.register("window-type", str, "povey", "Type of window (hamming|hanning|povey|rectangular|blackman)")
     po.register("blackman-coeff", float, f.blackman_coeff, "Constant coefficient for generalized Blackman window.")
     po.register("round-to-power-of-two", bool, True, "Round window size to power of two by zero-padding")
@@ -38,16 +54,9 @@ def register_mfcc(po):
     po.register("vtln-low", float, m.vtln_low, "Low inflection point in piecewise linear VTLN warping function")
     po.register("vtln-high", float, m.vtln_high, "High inflection point in piecewise linear VTLN warping function")
     po.register("debug-mel", bool, False, "(ignored)")
-    po.register("num-ceps", int, d.num_ceps, "Number of cepstra in MFCC computation (including C0)")
-    po.register("use-energy", bool, bool(d.use_energy), "Use energy (not C0) in MFCC computation")
-    po.register("energy-floor", float, d.energy_floor, "Floor on energy (absolute, not relative) in MFCC computation")
-    po.register("raw-energy", bool, bool(d.raw_energy), "If true, compute energy before preemphasis and windowing")
-    po.register("cepstral-lifter", float, d.cepstral_lifter, "Constant that controls scaling of MFCCs")
-    po.register("htk-compat", bool, bool(d.htk_compat), "If true, put energy or C0 last")
 
 
-def mfcc_opts(po):
-    o = abi.mfcc_opts_default()
+def _frame_mel_from(po, o):
     if po["dither"] != 0.0:
         raise KamdError("--dither=%g: only --dither=0 is supported (dithering is random in the reference)" % po["dither"])
     if po["window-type"] not in abi.KAMD_WIN:
@@ -59,8 +68,25 @@ def mfcc_opts(po):
     f.round_to_power_of_two, f.snip_edges = int(po["round-to-power-of-two"]), int(po["snip-edges"])
     m.num_bins, m.low_freq, m.high_freq, m.vtln_low, m.vtln_high = (po["num-mel-bins"], po["low-freq"], po["high-freq"],
                                                                    po["vtln-low"], po["vtln-high"])
-    o.num_ceps, o.use_energy, o.energy_floor = po["num-ceps"], int(po["use-energy"]), po["energy-floor"]
-    o.raw_energy, o.cepstral_lifter, o.htk_compat = int(po["raw-energy"]), po["cepstral-lifter"], int(po["htk-compat"])
+
+
+def register_fbank(po):
+    """FbankOptions::Register (feat/feature-fbank.h:60-80)"""
+    d = abi.fbank_opts_default()
+    _register_frame_mel(po, d.frame, d.mel)
+    po.register("use-energy", bool, bool(d.use_energy), "Add an extra dimension with energy to the FBANK output.")
+    po.register("energy-floor", float, d.energy_floor, "Floor on energy (absolute, not relative) in FBANK computation")
+    po.register("raw-energy", bool, bool(d.raw_energy), "If true, compute energy before preemphasis and windowing")
+    po.register("htk-compat", bool, bool(d.htk_compat), "If true, put energy last.")
+    po.register("use-log-fbank", bool, bool(d.use_log_fbank), "If true, produce log-filterbank, else produce linear.")
+    po.register("use-power", bool, bool(d.use_power), "If true, use power, else use magnitude.")
+
+
+def fbank_opts(po):
+    o = abi.fbank_opts_default()
+    _frame_mel_from(po, o)
+    o.use_energy, o.energy_floor, o.raw_energy = int(po["use-energy"]), po["energy-floor"], int(po["raw-energy"])
+    o.htk_compat, o.use_log_fbank, o.use_power = int(po["htk-compat"]), int(po["use-log-fbank"]), int(po["use-power"])
     return o
 
 

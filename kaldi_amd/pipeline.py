@@ -32,7 +32,9 @@ def default_sizes(cfg, max_utts, max_out_frames, avg_out_frames=None, hash_capac
 class Pipeline:
     def __init__(self, mfcc_opts, model, hclg, cfg, max_utts=64, max_seconds=36.0, avg_seconds=None,
                  sizes=None):
-        self.feat = __import__("kaldi_amd.feat", fromlist=["Mfcc"]).Mfcc(mfcc_opts)
+        featmod = __import__("kaldi_amd.feat", fromlist=["Mfcc"])
+        # MfccOptions or FbankOptions (--feature-type of the online2 binaries; compute-fbank-feats recipes)
+        self.feat = featmod.Fbank(mfcc_opts) if isinstance(mfcc_opts, abi.FbankOpts) else featmod.Mfcc(mfcc_opts)
         self.model = model
         self.nnet = decoder.Nnet(model)
         self.graph = decoder.Graph(hclg)

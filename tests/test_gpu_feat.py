@@ -117,3 +117,63 @@ def test_cmvn_stats_and_apply_match_the_oracle(tmp_path):
     np.testing.assert_allclose(np.concatenate([out["u2"], out["u3"]]).mean(0), 0, atol=2e-5)
     np.testing.assert_allclose(np.concatenate([out["u2"], out["u3"]]).std(0), 1, atol=1e-4)
     assert abs(float(spkB.mean())) > 1                                   # it was not normalised before
+
+
+def test_featbin_and_nnet3_compute_tools(tmp_path):
+    """compute-mfcc-feats / compute-fbank-feats with --config files over a wav.scp (file and pipe entries, a stereo file
+    with --channel) and nnet3-compute over the resulting archive: the same matrices as the in-process calls."""
+    import subprocess
+    import sys
+    import wave
+    from kaldi_amd import decoder, nnet, table
+    from tests.mdl_writer import write_mdl
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    waves = {"u1": np.round(synth.make_wave(1.3, seed=1)).astype(np.float32), "u2": np.round(synth.make_wave(0.7, seed=2)).astype(np.float32)}
+    with open(tmp_path / "wav.scp", "w") as scp:
+        for i, (k, w) in enumerate(waves.items()):
+            with wave.open(str(tmp_path / (k + ".wav")), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(w.astype("<i2").tobytes())
+            scp.write("%s %s\n" % (k, ("cat %s |" if i else "%s") % (tmp_path / (k + ".wav"))))
+    (tmp_path / "mfcc.conf").write_text("--use-energy=false   # hires\n--num-mel-bins=40\n--num-ceps=40\n--low-freq=20\n--high-freq=-400\n")
+    (tmp_path / "fbank.conf").write_text("--num-mel-bins=40\n--use-energy=true\n")
+    for tool, conf, F in (("compute_mfcc_feats.py", "mfcc.conf", feat.Mfcc(abi.mfcc_opts_hires())), ("compute_fbank_feats.py", "fbank.conf", None)):
+        out = tmp_path / (tool + ".ark")
+        r = subprocess.run([sys.executable, root + "/tools/" + tool, "--config=%s" % (tmp_path / conf), "scp:%s" % (tmp_path / "wav.scp"), "ark:%s" % out],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert "Done 2 out of 2 utterances." in r.stderr
+        got = dict(table.SequentialTableReader("ark:%s" % out, "matrix"))
+        if F is None:
+            fo = abi.fbank_opts_default(); fo.mel.num_bins = 40; fo.use_energy = 1
+            F = feat.Fbank(fo)
+            assert got["u1"].shape[1] == 41
+        for k, w in waves.items():
+            np.testing.assert_array_equal(got[k], F.ComputeFeatures(w))
+    # --subtract-mean and a stereo file
+    st = np.stack([waves["u1"][:8000], waves["u2"][:8000]], 1).astype("<i2")
+    with wave.open(str(tmp_path / "st.wav"), "wb") as f:
+        f.setnchannels(2); f.setsampwidth(2); f.setframerate(16000); f.writeframes(st.tobytes())
+    (tmp_path / "st.scp").write_text("s %s\n" % (tmp_path / "st.wav"))
+    r = subprocess.run([sys.executable, root + "/tools/compute_mfcc_feats.py", "--config=%s" % (tmp_path / "mfcc.conf"), "--channel=1", "--subtract-mean=true",
+                        "scp:%s" % (tmp_path / "st.scp"), "ark:%s" % (tmp_path / "st.ark")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    s = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "st.ark"), "matrix"))["s"]
+    ref = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(waves["u2"][:8000])
+    np.testing.assert_allclose(s, ref - ref.mean(0), atol=2e-5)
+    # nnet3-compute on the MFCC archive
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, 50, input_dim=40, seed=12, output_scale=3.0)
+    write_mdl(tmp_path / "final.mdl", m, num_units=25)
+    for flag, keep_priors in (("--use-priors=false", False), ("--use-priors=true", True)):
+        r = subprocess.run([sys.executable, root + "/tools/nnet3_compute.py", flag, "--frame-subsampling-factor=3", str(tmp_path / "final.mdl"),
+                            "ark:%s" % (tmp_path / "compute_mfcc_feats.py.ark"), "ark:%s" % (tmp_path / "out.ark")], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        got = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "out.ark"), "matrix"))
+        m2 = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, 50, input_dim=40, seed=12, output_scale=3.0)
+        m2.layers[-1].post_scale = 1.0
+        if not keep_priors:
+            m2.layers[-1].post_offset = None
+        N = decoder.Nnet(m2)
+        mf = feat.Mfcc(abi.mfcc_opts_hires())
+        for k, w in waves.items():
+            want = N.Forward(mf.ComputeFeatures(w))
+            np.testing.assert_allclose(got[k], want, rtol=0, atol=1e-4 * max(1.0, np.abs(want).max()))
