@@ -401,6 +401,20 @@ int kamd_ark_write_matrix(const char *path, int append, const char *key, int bin
 int kamd_ark_read_int32_vector(const char *path, int64_t *offset, char *key, int key_cap, int32_t *n,
                                int32_t **data);
 
+/* ------------------------------------------------ GMM acoustic model (configs[0]) -- */
+/* AmDiagGmm (gmm/am-diag-gmm.h:40-120) behind DecodableAmDiagGmmScaled (gmm/decodable-am-diag-gmm.h:50-120, .cc:27-70):
+ * pdf p owns Gaussians [mix_off[p], mix_off[p+1]) of gconsts [G], means_invvars / inv_vars [G x dim] (DiagGmm's members).
+ * loglikes: out[t][p] = scale * LogSumExp over the pdf's Gaussians, a [rows x num_pdfs] matrix the decoder takes as a
+ * DecodableMatrixMapped with the transition model's id2pdf. */
+typedef struct kamd_am_gmm kamd_am_gmm;
+kamd_am_gmm *kamd_am_gmm_create(int32_t num_pdfs, int32_t dim, const int32_t *mix_off, const float *gconsts,
+                                const float *means_invvars, const float *inv_vars);
+void kamd_am_gmm_destroy(kamd_am_gmm *g);
+int kamd_am_gmm_num_pdfs(const kamd_am_gmm *g);
+int kamd_am_gmm_dim(const kamd_am_gmm *g);
+int kamd_am_gmm_loglikes_device(kamd_am_gmm *g, const float *d_feats, int ld, int64_t rows, float scale, float *d_out, void *stream);
+int kamd_am_gmm_loglikes(kamd_am_gmm *g, const float *feats, int num_frames, int feat_dim, float scale, float *out);
+
 /* ----------------------------------------------------------------- CMVN -- */
 /* compute-cmvn-stats: AccCmvnStats (transform/cmvn.cc:30-62) over every utterance of a batch of device
  * features; utterance u owns rows [row_off[u], row_off[u+1]).  h_stats: n_utts x [2 x (dim+1)] doubles

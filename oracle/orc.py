@@ -55,6 +55,8 @@ def lib():
         L.orc_online_cmvn.restype = None
         L.orc_posterior_entry.argtypes = [fp, C.c_int, C.c_int, C.c_float, ip, fp, ip]
         L.orc_posterior_entry.restype = C.c_float
+        L.orc_am_gmm_loglikes.argtypes = [C.c_int, C.c_int, ip, fp, fp, fp, fp, C.c_int, C.c_float, fp]
+        L.orc_am_gmm_loglikes.restype = None
         L.orc_cmvn_acc_stats.argtypes = [fp, C.c_int, C.c_int, dp]
         L.orc_cmvn_acc_stats.restype = None
         L.orc_cmvn_apply.argtypes = [dp, C.c_int, fp, C.c_int, C.c_int]
@@ -214,6 +216,15 @@ def posterior_entry(loglikes, num_gselect, min_post):
     n = C.c_int32()
     r = lib().orc_posterior_entry(abi.fptr(ll), ll.size, num_gselect, min_post, abi.iptr(g), abi.fptr(p), C.byref(n))
     return r, g[:n.value], p[:n.value]
+
+
+def am_gmm_loglikes(am, feats, scale=1.0):
+    """DecodableAmDiagGmmScaled's matrix [T x num_pdfs] for a kaldi_amd.gmm.AmDiagGmm"""
+    f = np.ascontiguousarray(feats, np.float32)
+    out = np.zeros((f.shape[0], am.num_pdfs), np.float32)
+    lib().orc_am_gmm_loglikes(am.num_pdfs, am.dim, abi.iptr(am.mix_off), abi.fptr(am.gconsts), abi.fptr(am.means_invvars),
+                              abi.fptr(am.inv_vars), abi.fptr(f), f.shape[0], scale, abi.fptr(out))
+    return out
 
 
 def cmvn_acc_stats(feats, stats=None):

@@ -369,3 +369,29 @@ extern "C" int orc_cmvn_apply(const double *stats, int var_norm, float *feats, i
   }
   return 0;
 }
+
+// ---- GMM acoustic model (test infrastructure): DecodableAmDiagGmmUnmapped::LogLikelihoodZeroBased
+// (gmm/decodable-am-diag-gmm.cc:27-70) with VectorBase<float>::LogSumExp(-1) (matrix/kaldi-vector.cc:760-778), times
+// the scale of DecodableAmDiagGmmScaled.  PARITY UNPINNED (no GMM model or features in the tree).
+extern "C" void orc_am_gmm_loglikes(int num_pdfs, int dim, const int32_t *mix_off, const float *gconsts, const float *means_invvars,
+                                    const float *inv_vars, const float *feats, int T, float scale, float *out) {
+  std::vector<float> ll;
+  for (int t = 0; t < T; t++) {
+    const float *x = feats + static_cast<size_t>(t) * dim;
+    for (int p = 0; p < num_pdfs; p++) {
+      ll.clear();
+      float mx = -INFINITY;
+      for (int g = mix_off[p]; g < mix_off[p + 1]; g++) {
+        float acc = gconsts[g];
+        const float *m = means_invvars + static_cast<size_t>(g) * dim, *v = inv_vars + static_cast<size_t>(g) * dim;
+        for (int k = 0; k < dim; k++) acc = acc + m[k] * x[k];
+        for (int k = 0; k < dim; k++) acc = acc + (-0.5f * v[k]) * (x[k] * x[k]);
+        ll.push_back(acc); mx = std::max(mx, acc);
+      }
+      const float cutoff = mx + logf(1.1920928955078125e-07f);          // kMinLogDiffFloat = Log(FLT_EPSILON)
+      double sum = 0.0;
+      for (size_t i = 0; i < ll.size(); i++) if (ll[i] >= cutoff) sum += expf(ll[i] - mx);
+      out[static_cast<size_t>(t) * num_pdfs + p] = scale * (mx + static_cast<float>(log(sum)));
+    }
+  }
+}
