@@ -416,6 +416,11 @@ int kamd_am_gmm_loglikes_device(kamd_am_gmm *g, const float *d_feats, int ld, in
 int kamd_am_gmm_loglikes(kamd_am_gmm *g, const float *feats, int num_frames, int feat_dim, float scale, float *out);
 
 /* ----------------------------------------------------------------- CMVN -- */
+/* add-deltas: ComputeDeltas / DeltaFeatures::Process (feat/feature-functions.cc:118-165, featbin/add-deltas.cc): every
+ * utterance's [T x dim] features -> [T x (order+1)*dim] (orders 0..order, window frames each side, clamped at the
+ * utterance's ends). */
+int kamd_feat_add_deltas_device(const float *d_in, int ld_in, float *d_out, int ld_out, const int64_t *h_row_off,
+                                int n_utts, int dim, int order, int window, void *stream);
 /* compute-cmvn-stats: AccCmvnStats (transform/cmvn.cc:30-62) over every utterance of a batch of device
  * features; utterance u owns rows [row_off[u], row_off[u+1]).  h_stats: n_utts x [2 x (dim+1)] doubles
  * (sums | count, sums of squares | unused), ACCUMULATED into (zero it for fresh statistics; pass a

@@ -59,3 +59,16 @@ def apply(mats, stats, norm_means=True, norm_vars=False):
     out = np.zeros_like(flat)
     d.download(out)
     return [out[off[i]:off[i + 1]].copy() for i in range(len(mats))]
+
+
+def add_deltas(mats, order=2, window=2):
+    """add-deltas (featbin/add-deltas.cc, ComputeDeltas): [T x dim] -> [T x (order+1)*dim] per matrix"""
+    mats, flat, off, dim = _batch(mats)
+    if off[-1] == 0:
+        return [np.zeros((0, (order + 1) * dim), np.float32) for _ in mats]
+    d_in = _Dev(flat)
+    out = np.zeros((flat.shape[0], (order + 1) * dim), np.float32)
+    d_out = _Dev(out)
+    check(lib().kamd_feat_add_deltas_device(d_in.p, dim, d_out.p, (order + 1) * dim, abi.iptr(off, C.c_int64), len(mats), dim, order, window, None))
+    d_out.download(out)
+    return [out[off[i]:off[i + 1]].copy() for i in range(len(mats))]

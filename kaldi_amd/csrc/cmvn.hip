@@ -65,9 +65,79 @@ __global__ __launch_bounds__(256) void CmvnApplyKernel(float *feats, int ld, int
   }
 }
 
+// add-deltas: DeltaFeatures::Process (feat/feature-functions.cc:142-165) for every frame of every utterance;
+// scales = the (order + 1) windows of DeltaFeatures::DeltaFeatures (:118-140), concatenated, scale_off[i] their starts
+__global__ __launch_bounds__(256) void AddDeltasKernel(const float *in, int ld_in, float *out, int ld_out, const int64_t *row_off, int dim, int order,
+                                                       const float *scales, const int *scale_off) {
+  const int u = blockIdx.y;
+  const int64_t r0 = row_off[u];
+  const int T = static_cast<int>(row_off[u + 1] - r0);
+  const int n = (order + 1) * dim;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; idx < static_cast<int64_t>(T) * n; idx += static_cast<int64_t>(gridDim.x) * 256) {
+    const int t = static_cast<int>(idx / n), c = static_cast<int>(idx - static_cast<int64_t>(t) * n), i = c / dim, k = c - i * dim;
+    const float *sc = scales + scale_off[i];
+    const int max_offset = (scale_off[i + 1] - scale_off[i] - 1) / 2;
+    float acc = 0.f;
+    for (int j = -max_offset; j <= max_offset; j++) {
+      int f = t + j;
+      f = f < 0 ? 0 : (f >= T ? T - 1 : f);
+      const float s = sc[j + max_offset];
+      if (s != 0.0f) acc = acc + s * in[(r0 + f) * ld_in + k];
+    }
+    out[(r0 + t) * ld_out + c] = acc;
+  }
+}
+
 }  // namespace kamd
 
 extern "C" {
+
+int kamd_feat_add_deltas_device(const float *d_in, int ld_in, float *d_out, int ld_out, const int64_t *h_row_off, int n_utts, int dim, int order,
+                                int window, void *stream) {
+  if (!kamd::RequireDevice()) return KAMD_ERR_HIP;
+  if (n_utts <= 0) return KAMD_OK;
+  if (order < 0 || order >= 1000 || window <= 0 || window >= 1000 || dim <= 0 || ld_in < dim || ld_out < (order + 1) * dim)
+    return kamd::SetError(KAMD_ERR_ARG, "add-deltas: bad order / window / dimensions");
+  // DeltaFeatures::DeltaFeatures: scales_[i] = scales_[i-1] convolved with j / sum(j^2), j = -window .. window (BaseFloat arithmetic)
+  std::vector<std::vector<float> > sc(order + 1);
+  sc[0].assign(1, 1.0f);
+  for (int i = 1; i <= order; i++) {
+    const std::vector<float> &prev = sc[i - 1];
+    std::vector<float> &cur = sc[i];
+    const int prev_offset = (static_cast<int>(prev.size()) - 1) / 2, cur_offset = prev_offset + window;
+    cur.assign(prev.size() + 2 * window, 0.0f);
+    float normalizer = 0.0f;
+    for (int j = -window; j <= window; j++) {
+      normalizer += j * j;
+      for (int k = -prev_offset; k <= prev_offset; k++) cur[j + k + cur_offset] += static_cast<float>(j) * prev[k + prev_offset];
+    }
+    for (float &v : cur) v *= 1.0f / normalizer;
+  }
+  std::vector<float> flat; std::vector<int> off(1, 0);
+  for (int i = 0; i <= order; i++) { flat.insert(flat.end(), sc[i].begin(), sc[i].end()); off.push_back(static_cast<int>(flat.size())); }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float *d_sc = NULL; int *d_off = NULL; int64_t *d_ro = NULL;
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_sc), flat.size() * sizeof(float)));
+  if (hipMalloc(reinterpret_cast<void **>(&d_off), off.size() * sizeof(int)) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&d_ro), (n_utts + 1) * sizeof(int64_t)) != hipSuccess) {
+    (void)hipFree(d_sc); if (d_off) (void)hipFree(d_off);
+    return kamd::SetError(KAMD_ERR_HIP, "allocation failed");
+  }
+  int rc = KAMD_OK, max_T = 0;
+  for (int u = 0; u < n_utts; u++) max_T = std::max<int>(max_T, static_cast<int>(h_row_off[u + 1] - h_row_off[u]));
+  if (hipMemcpyAsync(d_sc, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(d_ro, h_row_off, (n_utts + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess)
+    rc = kamd::SetError(KAMD_ERR_HIP, "add-deltas: upload failed");
+  if (rc == KAMD_OK && max_T > 0) {
+    const int64_t work = static_cast<int64_t>(max_T) * (order + 1) * dim;
+    hipLaunchKernelGGL(kamd::AddDeltasKernel, dim3(static_cast<unsigned>(std::min<int64_t>((work + 255) / 256, 4096)), n_utts), dim3(256), 0, st, d_in, ld_in,
+                       d_out, ld_out, d_ro, dim, order, d_sc, d_off);
+    if (hipStreamSynchronize(st) != hipSuccess) rc = kamd::SetError(KAMD_ERR_HIP, "add-deltas kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  (void)hipFree(d_sc); (void)hipFree(d_off); (void)hipFree(d_ro);
+  return rc;
+}
 
 int kamd_cmvn_acc_stats_device(const float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, double *h_stats,
                                void *stream) {

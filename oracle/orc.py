@@ -57,6 +57,8 @@ def lib():
         L.orc_posterior_entry.restype = C.c_float
         L.orc_am_gmm_loglikes.argtypes = [C.c_int, C.c_int, ip, fp, fp, fp, fp, C.c_int, C.c_float, fp]
         L.orc_am_gmm_loglikes.restype = None
+        L.orc_add_deltas.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, fp]
+        L.orc_add_deltas.restype = None
         L.orc_cmvn_acc_stats.argtypes = [fp, C.c_int, C.c_int, dp]
         L.orc_cmvn_acc_stats.restype = None
         L.orc_cmvn_apply.argtypes = [dp, C.c_int, fp, C.c_int, C.c_int]
@@ -224,6 +226,13 @@ def am_gmm_loglikes(am, feats, scale=1.0):
     out = np.zeros((f.shape[0], am.num_pdfs), np.float32)
     lib().orc_am_gmm_loglikes(am.num_pdfs, am.dim, abi.iptr(am.mix_off), abi.fptr(am.gconsts), abi.fptr(am.means_invvars),
                               abi.fptr(am.inv_vars), abi.fptr(f), f.shape[0], scale, abi.fptr(out))
+    return out
+
+
+def add_deltas(feats, order=2, window=2):
+    f = np.ascontiguousarray(feats, np.float32)
+    out = np.zeros((f.shape[0], (order + 1) * f.shape[1]), np.float32)
+    lib().orc_add_deltas(abi.fptr(f), f.shape[0], f.shape[1], order, window, abi.fptr(out))
     return out
 
 

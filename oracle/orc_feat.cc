@@ -395,3 +395,36 @@ extern "C" void orc_am_gmm_loglikes(int num_pdfs, int dim, const int32_t *mix_of
     }
   }
 }
+
+// ---- add-deltas (test infrastructure): DeltaFeatures ctor + Process (feat/feature-functions.cc:118-165). PARITY UNPINNED.
+extern "C" void orc_add_deltas(const float *in, int T, int dim, int order, int window, float *out) {
+  std::vector<std::vector<float> > sc(order + 1);
+  sc[0].assign(1, 1.0f);
+  for (int i = 1; i <= order; i++) {
+    const std::vector<float> &prev = sc[i - 1];
+    std::vector<float> &cur = sc[i];
+    const int po = (static_cast<int>(prev.size()) - 1) / 2, co = po + window;
+    cur.assign(prev.size() + 2 * window, 0.0f);
+    float normalizer = 0.0f;
+    for (int j = -window; j <= window; j++) {
+      normalizer += j * j;
+      for (int k = -po; k <= po; k++) cur[j + k + co] += static_cast<float>(j) * prev[k + po];
+    }
+    for (size_t k = 0; k < cur.size(); k++) cur[k] *= 1.0f / normalizer;
+  }
+  const int n = (order + 1) * dim;
+  for (int t = 0; t < T; t++)
+    for (int i = 0; i <= order; i++) {
+      const int mo = (static_cast<int>(sc[i].size()) - 1) / 2;
+      for (int k = 0; k < dim; k++) {
+        float acc = 0.f;
+        for (int j = -mo; j <= mo; j++) {
+          int f = t + j;
+          f = f < 0 ? 0 : (f >= T ? T - 1 : f);
+          const float s = sc[i][j + mo];
+          if (s != 0.0f) acc = acc + s * in[static_cast<size_t>(f) * dim + k];
+        }
+        out[static_cast<size_t>(t) * n + i * dim + k] = acc;
+      }
+    }
+}

@@ -177,3 +177,18 @@ def test_featbin_and_nnet3_compute_tools(tmp_path):
         for k, w in waves.items():
             want = N.Forward(mf.ComputeFeatures(w))
             np.testing.assert_allclose(got[k], want, rtol=0, atol=1e-4 * max(1.0, np.abs(want).max()))
+
+
+def test_add_deltas_matches_the_oracle_and_the_closed_form(tmp_path):
+    from kaldi_amd import cmvn
+    rng = np.random.default_rng(2)
+    mats = [rng.standard_normal((T, 13)).astype(np.float32) for T in (1, 3, 50, 400)]
+    for order, window in ((2, 2), (1, 3), (0, 2), (3, 1)):
+        got = cmvn.add_deltas(mats, order, window)
+        for m, g in zip(mats, got):
+            np.testing.assert_allclose(g, orc.add_deltas(m, order, window), rtol=0, atol=1e-6 * max(1.0, np.abs(g).max()))
+    # first-order delta, window 2: sum_j j x[t+j] / 10 with the ends clamped
+    x = mats[2].astype(np.float64)
+    pad = np.concatenate([x[:1], x[:1], x, x[-1:], x[-1:]])
+    d1 = sum(j * pad[2 + j:2 + j + x.shape[0]] for j in (-2, -1, 1, 2)) / 10.0
+    np.testing.assert_allclose(cmvn.add_deltas([mats[2]], 2, 2)[0][:, 13:26], d1, atol=1e-5)
