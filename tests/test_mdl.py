@@ -38,3 +38,32 @@ def test_descriptor_parser():
                             ("ReplaceIndex", "ivector")])
     d = mdl._parse_descriptor("Sum(Scale(0.66, tdnnf2.noop), tdnnf3.dropout)")
     assert d == ("Sum", ("Scale", 0.66, ("node", "tdnnf2.noop")), ("node", "tdnnf3.dropout"))
+
+
+def test_transition_model_three_state_hmm_topology_old_format():
+    """The GMM recipes' topology (3 emitting states, left to right, one pdf class per state: HmmTopology writes the
+    non-extended form, and the tuples are <Triples>): id2pdf / phone tables worked out by hand."""
+    from kaldi_amd import mdl
+    from tests.mdl_writer import f32, i32, int_vector, tok, vec
+    b = tok("<TransitionModel>") + tok("<Topology>")
+    b += int_vector(np.array([1, 2])) + int_vector(np.array([-1, 0, 0]))         # phones, phone2idx
+    b += i32(1)                                                                 # one topology entry, old format (no -1 marker)
+    b += i32(4)                                                                 # four states
+    for st in range(3):
+        b += i32(st) + i32(2) + i32(st) + f32(0.75) + i32(st + 1) + f32(0.25)   # pdf class, two transitions: self, next
+    b += i32(-1) + i32(0)                                                       # final state: no pdf class, no transitions
+    b += tok("</Topology>") + tok("<Triples>") + i32(6)
+    pdf = 0
+    for ph in (1, 2):
+        for hs in range(3):
+            b += i32(ph) + i32(hs) + i32(pdf)
+            pdf += 1
+    b += tok("</Triples>") + tok("<LogProbs>") + vec(np.zeros(13, np.float32)) + tok("</LogProbs>") + tok("</TransitionModel>")
+    s = mdl._Stream(b)
+    id2pdf, tid_phone, phones = mdl.read_transition_model(s)
+    assert list(phones) == [1, 2]
+    # transition-ids in tuple order, two per state (self-loop, forward): both map to the state's pdf
+    assert id2pdf.tolist() == [-1, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5]
+    # a phone is entered by the forward transition out of ... no: by any non-self-loop transition OF hmm-state 0
+    assert tid_phone.tolist() == [0, 0, 1, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0]
+    assert mdl.read_transition_model.tid2phone.tolist() == [0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2]
