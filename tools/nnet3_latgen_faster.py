@@ -16,6 +16,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+from concurrent.futures import ThreadPoolExecutor
 from kaldi_amd import abi, mdl, options, pipeline, table
 from kaldi_amd import io as kio
 from kaldi_amd._lib import KamdError, lib
@@ -39,6 +40,8 @@ def main(argv):
     po.register("wav", bool, False, "The third argument is a waveform rspecifier; features are computed on the device")
     po.register("mfcc-config", str, "", "Config file with compute-mfcc-feats options (only with --wav)")
     po.register("batch", int, 64, "Utterances decoded per pass")
+    po.register("num-threads", int, max(1, (os.cpu_count() or 2) - 1), "Host threads for lattice determinization (the host tail of a batch; "
+                "the reference's nnet3-latgen-faster-parallel uses a TaskSequencer for the same purpose)")
     po.register("device", int, -1, "HIP device to run on (default: device 0 of HIP_VISIBLE_DEVICES); with decode.sh-style "
                 "splitting, job JOB of --nj 8 passes --device=$[JOB-1]: utterances shard across the GPUs of a node with "
                 "no communication")
@@ -128,7 +131,15 @@ def main(argv):
         if extractor is not None:
             pipe.set_ivector_extractor(extractor, po["frames-per-chunk"])
         pipe.run(auto_grow=4)
-        for key, res, lane in zip(keys, pipe.results(lattices=True), pipe._lane_of):
+        results = pipe.results(lattices=True)
+        # determinization (host C code, releases the GIL) of the whole batch in parallel; output stays in input order
+        clats = {}
+        if po["determinize-lattice"]:
+            todo = [(k, r["lattice"]) for k, r in zip(keys, results) if r is not None and r["lattice"] is not None]
+            with ThreadPoolExecutor(max_workers=max(1, po["num-threads"])) as pool:
+                for (k, _), c in zip(todo, pool.map(lambda kv: kio.determinize_lattice(kv[1], cfg.lattice_beam, tid_phone, det), todo)):
+                    clats[k] = c
+        for key, res, lane in zip(keys, results, pipe._lane_of):
             if res is None:
                 print("WARNING Zero-length utterance: " + key, file=sys.stderr)
                 n_fail += 1
@@ -143,7 +154,7 @@ def main(argv):
             if not reached:
                 print("WARNING Outputting partial output for utterance %s since no final-state reached" % key, file=sys.stderr)
             if po["determinize-lattice"]:
-                lat_w.write(key, kio.determinize_lattice(lat, cfg.lattice_beam, tid_phone, det))
+                lat_w.write(key, clats[key])
             else:
                 lat_w.write(key, lat)
             if words_w:
