@@ -40,7 +40,7 @@ def main(argv):
     po.register("wav", bool, False, "The third argument is a waveform rspecifier; features are computed on the device")
     po.register("mfcc-config", str, "", "Config file with compute-mfcc-feats options (only with --wav)")
     po.register("batch", int, 64, "Utterances decoded per pass")
-    po.register("num-threads", int, max(1, (os.cpu_count() or 2) - 1), "Host threads for lattice determinization (the host tail of a batch; "
+    po.register("num-threads", int, max(1, min(4, (os.cpu_count() or 2) - 1)), "Host threads for lattice determinization (the host tail of a batch; "
                 "the reference's nnet3-latgen-faster-parallel uses a TaskSequencer for the same purpose)")
     po.register("device", int, -1, "HIP device to run on (default: device 0 of HIP_VISIBLE_DEVICES); with decode.sh-style "
                 "splitting, job JOB of --nj 8 passes --device=$[JOB-1]: utterances shard across the GPUs of a node with "
