@@ -470,3 +470,40 @@ def test_pipeline_overlapped_nnet_slices_give_the_same_lattices(bounds):
     again = pipe.decode(waves)
     assert lattices_equal(again[0]["lattice"], want[0]["lattice"])
     assert lib().kamd_decoder_last_advance_launches(pipe.dec._dec) == 1
+
+
+def test_no_device_memory_leak_over_create_destroy_cycles():
+    """A server creates and drops graphs, models, decoders, pipelines, extractors and stream batches for its whole
+    life: after warm-up, repeated cycles leave the free device memory where it was."""
+    import gc
+    from kaldi_amd import ivector, nnet, online, pipeline
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, ivector_dim=16)
+    info = ivector.make_synthetic(num_gauss=32, ivector_dim=16, seed=1)
+    waves = [synth.make_wave(1.0, seed=i) for i in range(3)]
+
+    def cycle():
+        ie = ivector.IvectorExtractor(info)
+        pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, abi.decoder_config_recipe(), max_utts=3, max_seconds=2.0)
+        pipe.set_ivector_extractor(ie, 50)
+        pipe.decode(waves)
+        sb = online.StreamBatch(abi.mfcc_opts_hires(), pipe.nnet, pipe.graph, abi.decoder_config_recipe(), 2, max_seconds=2.0,
+                                sizes=abi.DecoderSizes(2, 1 << 12, 1 << 16, 1 << 17, 256))
+        sb.set_ivector_extractor(ie, 20)
+        sb.start([0])
+        sb.accept(0, waves[0], input_finished=True)
+        sb.advance([0])
+        sb.finalize([0])
+        del sb, pipe, ie
+        gc.collect()
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert lib().kamd_device_mem_info(C.byref(f), C.byref(t)) == 0
+        return f.value
+    for _ in range(3):
+        cycle()
+    base = free_bytes()
+    for _ in range(10):
+        cycle()
+    assert abs(free_bytes() - base) < (8 << 20), (base, free_bytes())
