@@ -72,8 +72,9 @@ def test_product_never_imports_oracle():
     """The oracle is test infrastructure: nothing under kaldi_amd/ may import, link, dlopen or
     call it (comments may mention it)."""
     pat = re.compile(r"import\s+oracle|from\s+oracle|liboracle|oracle/|\borc_[a-z]|orc\.py")
-    for dp, _, fs in os.walk(os.path.join(ROOT, "kaldi_amd")):
-        for f in fs:
-            if f.endswith((".py", ".hip", ".cc", ".h", "Makefile")):
-                src = open(os.path.join(dp, f)).read()
-                assert not pat.search(src), os.path.join(dp, f)
+    for top in ("kaldi_amd", "tools", "examples", "include"):          # the product, its command lines and its headers
+        for dp, _, fs in os.walk(os.path.join(ROOT, top)):
+            for f in fs:
+                if f.endswith((".py", ".hip", ".cc", ".h", ".hpp", ".sh", "Makefile")):
+                    src = open(os.path.join(dp, f)).read()
+                    assert not pat.search(src), os.path.join(dp, f)
