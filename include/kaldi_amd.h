@@ -416,6 +416,15 @@ int kamd_am_gmm_loglikes_device(kamd_am_gmm *g, const float *d_feats, int ld, in
 int kamd_am_gmm_loglikes(kamd_am_gmm *g, const float *feats, int num_frames, int feat_dim, float scale, float *out);
 
 /* ----------------------------------------------------------------- CMVN -- */
+/* splice-feats | transform-feats (featbin/splice-feats.cc, transform-feats.cc:100-160): SpliceFrames with left / right
+ * context clamped at each utterance's ends, then y = M x, or M [x; 1] when M has one more column (LDA+MLLT final.mat,
+ * per-speaker fMLLR).  h_transforms: n_transforms matrices [xf_rows x xf_cols] back to back, utterance u uses
+ * h_utt_transform[u]; h_transforms == NULL: the spliced vectors are the output (left = right = 0 with a transform:
+ * transform-feats alone). */
+int kamd_feat_splice_transform_device(const float *d_in, int ld_in, float *d_out, int ld_out, const int64_t *h_row_off,
+                                      int n_utts, int dim, int left, int right, const float *h_transforms,
+                                      int n_transforms, const int32_t *h_utt_transform, int xf_rows, int xf_cols,
+                                      void *stream);
 /* add-deltas: ComputeDeltas / DeltaFeatures::Process (feat/feature-functions.cc:118-165, featbin/add-deltas.cc): every
  * utterance's [T x dim] features -> [T x (order+1)*dim] (orders 0..order, window frames each side, clamped at the
  * utterance's ends). */

@@ -72,3 +72,27 @@ def add_deltas(mats, order=2, window=2):
     check(lib().kamd_feat_add_deltas_device(d_in.p, dim, d_out.p, (order + 1) * dim, abi.iptr(off, C.c_int64), len(mats), dim, order, window, None))
     d_out.download(out)
     return [out[off[i]:off[i + 1]].copy() for i in range(len(mats))]
+
+
+def splice_transform(mats, left=0, right=0, transforms=None, utt_transform=None):
+    """splice-feats (left / right context, clamped) and / or transform-feats (linear or affine; `transforms`: one matrix for
+    all, or a list with utt_transform[i] = index of matrix i's transform) -> new matrices"""
+    mats, flat, off, dim = _batch(mats)
+    sd = dim * (left + 1 + right)
+    xf = None
+    if transforms is not None:
+        tl = [transforms] if np.asarray(transforms).ndim == 2 else list(transforms)
+        xf = np.ascontiguousarray(np.stack([np.asarray(t, np.float32) for t in tl]))
+        ux = np.zeros(len(mats), np.int32) if utt_transform is None else np.ascontiguousarray(utt_transform, np.int32)
+    n_out = xf.shape[1] if xf is not None else sd
+    if off[-1] == 0:
+        return [np.zeros((0, n_out), np.float32) for _ in mats]
+    d_in = _Dev(flat)
+    out = np.zeros((flat.shape[0], n_out), np.float32)
+    d_out = _Dev(out)
+    check(lib().kamd_feat_splice_transform_device(d_in.p, dim, d_out.p, n_out, abi.iptr(off, C.c_int64), len(mats), dim, left, right,
+                                                  abi.fptr(xf) if xf is not None else None, xf.shape[0] if xf is not None else 0,
+                                                  abi.iptr(ux) if xf is not None else None, xf.shape[1] if xf is not None else 0,
+                                                  xf.shape[2] if xf is not None else 0, None))
+    d_out.download(out)
+    return [out[off[i]:off[i + 1]].copy() for i in range(len(mats))]

@@ -88,9 +88,79 @@ __global__ __launch_bounds__(256) void AddDeltasKernel(const float *in, int ld_i
   }
 }
 
+// splice-feats | transform-feats: SpliceFrames (feat/feature-functions.cc:205-231, context clamped at the
+// utterance's ends) followed by y = M x (+ offset column when M has one more column), transform-feats.cc:120-150.
+// transform == NULL: the spliced vectors themselves.  utt_xf[u]: which of the uploaded transforms utterance u uses.
+__global__ __launch_bounds__(256) void SpliceTransformKernel(const float *in, int ld_in, float *out, int ld_out, const int64_t *row_off, int dim,
+                                                             int left, int right, const float *xf, const int *utt_xf, int xf_rows, int xf_cols) {
+  const int u = blockIdx.y;
+  const int64_t r0 = row_off[u];
+  const int T = static_cast<int>(row_off[u + 1] - r0);
+  const int sd = dim * (left + 1 + right), n = xf ? xf_rows : sd;
+  const float *M = xf ? xf + static_cast<size_t>(utt_xf[u]) * xf_rows * xf_cols : NULL;
+  for (int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; idx < static_cast<int64_t>(T) * n; idx += static_cast<int64_t>(gridDim.x) * 256) {
+    const int t = static_cast<int>(idx / n), o = static_cast<int>(idx - static_cast<int64_t>(t) * n);
+    float acc;
+    if (!M) {
+      int t2 = t - left + o / dim;
+      t2 = t2 < 0 ? 0 : (t2 >= T ? T - 1 : t2);
+      acc = in[(r0 + t2) * ld_in + o % dim];
+    } else {
+      acc = xf_cols == sd + 1 ? M[static_cast<size_t>(o) * xf_cols + sd] : 0.f;
+      for (int c = 0; c <= left + right; c++) {
+        int t2 = t - left + c;
+        t2 = t2 < 0 ? 0 : (t2 >= T ? T - 1 : t2);
+        const float *x = in + (r0 + t2) * ld_in, *m = M + static_cast<size_t>(o) * xf_cols + c * dim;
+        for (int k = 0; k < dim; k++) acc = acc + m[k] * x[k];
+      }
+    }
+    out[(r0 + t) * ld_out + o] = acc;
+  }
+}
+
 }  // namespace kamd
 
 extern "C" {
+
+int kamd_feat_splice_transform_device(const float *d_in, int ld_in, float *d_out, int ld_out, const int64_t *h_row_off, int n_utts, int dim,
+                                      int left, int right, const float *h_transforms, int n_transforms, const int32_t *h_utt_transform,
+                                      int xf_rows, int xf_cols, void *stream) {
+  if (!kamd::RequireDevice()) return KAMD_ERR_HIP;
+  if (n_utts <= 0) return KAMD_OK;
+  const int sd = dim * (left + 1 + right);
+  if (dim <= 0 || left < 0 || right < 0 || ld_in < dim) return kamd::SetError(KAMD_ERR_ARG, "splice / transform: bad dimensions");
+  if (h_transforms) {
+    if (n_transforms <= 0 || xf_rows <= 0 || (xf_cols != sd && xf_cols != sd + 1))
+      return kamd::SetError(KAMD_ERR_ARG, "Transform matrix has bad dimension %dx%d versus feat dim %d", xf_rows, xf_cols, sd);   // transform-feats.cc:139-145
+    for (int u = 0; u < n_utts; u++)
+      if (h_utt_transform[u] < 0 || h_utt_transform[u] >= n_transforms) return kamd::SetError(KAMD_ERR_ARG, "utterance %d: no such transform", u);
+  }
+  const int n_out = h_transforms ? xf_rows : sd;
+  if (ld_out < n_out) return kamd::SetError(KAMD_ERR_ARG, "splice / transform: output leading dimension too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float *d_xf = NULL; int *d_ux = NULL; int64_t *d_ro = NULL;
+  int rc = KAMD_OK, max_T = 0;
+  for (int u = 0; u < n_utts; u++) max_T = std::max<int>(max_T, static_cast<int>(h_row_off[u + 1] - h_row_off[u]));
+  if (hipMalloc(reinterpret_cast<void **>(&d_ro), (n_utts + 1) * sizeof(int64_t)) != hipSuccess) return kamd::SetError(KAMD_ERR_HIP, "allocation failed");
+  if (hipMemcpyAsync(d_ro, h_row_off, (n_utts + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess) rc = kamd::SetError(KAMD_ERR_HIP, "upload failed");
+  if (rc == KAMD_OK && h_transforms) {
+    const size_t n = static_cast<size_t>(n_transforms) * xf_rows * xf_cols;
+    if (hipMalloc(reinterpret_cast<void **>(&d_xf), n * sizeof(float)) != hipSuccess || hipMalloc(reinterpret_cast<void **>(&d_ux), n_utts * sizeof(int)) != hipSuccess ||
+        hipMemcpyAsync(d_xf, h_transforms, n * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_ux, h_utt_transform, n_utts * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess)
+      rc = kamd::SetError(KAMD_ERR_HIP, "transform upload failed");
+  }
+  if (rc == KAMD_OK && max_T > 0) {
+    const int64_t work = static_cast<int64_t>(max_T) * n_out;
+    hipLaunchKernelGGL(kamd::SpliceTransformKernel, dim3(static_cast<unsigned>(std::min<int64_t>((work + 255) / 256, 4096)), n_utts), dim3(256), 0, st, d_in,
+                       ld_in, d_out, ld_out, d_ro, dim, left, right, d_xf, d_ux, xf_rows, xf_cols);
+    if (hipStreamSynchronize(st) != hipSuccess) rc = kamd::SetError(KAMD_ERR_HIP, "splice / transform kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  if (d_xf) (void)hipFree(d_xf);
+  if (d_ux) (void)hipFree(d_ux);
+  (void)hipFree(d_ro);
+  return rc;
+}
 
 int kamd_feat_add_deltas_device(const float *d_in, int ld_in, float *d_out, int ld_out, const int64_t *h_row_off, int n_utts, int dim, int order,
                                 int window, void *stream) {

@@ -192,3 +192,40 @@ def test_add_deltas_matches_the_oracle_and_the_closed_form(tmp_path):
     pad = np.concatenate([x[:1], x[:1], x, x[-1:], x[-1:]])
     d1 = sum(j * pad[2 + j:2 + j + x.shape[0]] for j in (-2, -1, 1, 2)) / 10.0
     np.testing.assert_allclose(cmvn.add_deltas([mats[2]], 2, 2)[0][:, 13:26], d1, atol=1e-5)
+
+
+def test_splice_and_transform_feats(tmp_path):
+    """splice-feats | transform-feats: clamped context, linear and affine transforms, one transform per speaker"""
+    import subprocess
+    import sys
+    from kaldi_amd import cmvn, ivector, table
+    rng = np.random.default_rng(4)
+    mats = [rng.standard_normal((T, 5)).astype(np.float32) for T in (1, 2, 40)]
+    sp = cmvn.splice_transform(mats, 2, 1)
+    for m, s in zip(mats, sp):
+        T = m.shape[0]
+        want = np.concatenate([m[np.clip(np.arange(T) + o, 0, T - 1)] for o in (-2, -1, 0, 1)], 1)
+        np.testing.assert_array_equal(s, want)
+    lin, aff = rng.standard_normal((7, 20)).astype(np.float32), rng.standard_normal((7, 21)).astype(np.float32)
+    for M in (lin, aff):
+        got = cmvn.splice_transform(mats, 2, 1, transforms=M)
+        for s, g in zip(sp, got):
+            want = s.astype(np.float64) @ M[:, :20].T.astype(np.float64) + (M[:, 20] if M.shape[1] == 21 else 0)
+            np.testing.assert_allclose(g, want, rtol=0, atol=1e-5 * max(1.0, np.abs(want).max()))
+    two = cmvn.splice_transform(mats, 2, 1, transforms=[lin, aff[:, :20]], utt_transform=[0, 1, 0])
+    np.testing.assert_array_equal(two[1], cmvn.splice_transform([mats[1]], 2, 1, transforms=aff[:, :20])[0])
+    with pytest.raises(Exception):
+        cmvn.splice_transform(mats, 2, 1, transforms=lin[:, :19])
+    # the tools, chained: splice-feats | transform-feats with final.mat
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with table.TableWriter("ark:%s" % (tmp_path / "f.ark"), "matrix") as w:
+        for i, m in enumerate(mats):
+            w.write("u%d" % i, m)
+    ivector.write_kaldi_matrix(tmp_path / "final.mat", aff)
+    rspec = "ark:%s %s/tools/splice_feats.py --left-context=2 --right-context=1 ark:%s ark:- |" % (sys.executable, root, tmp_path / "f.ark")
+    r = subprocess.run([sys.executable, root + "/tools/transform_feats.py", str(tmp_path / "final.mat"), rspec, "ark:%s" % (tmp_path / "o.ark")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "o.ark"), "matrix"))
+    for i, m in enumerate(mats):
+        np.testing.assert_array_equal(out["u%d" % i], cmvn.splice_transform([m], 2, 1, transforms=aff)[0])
