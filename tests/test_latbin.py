@@ -109,3 +109,22 @@ def test_score_chain_through_pipes(tmp_path):
     lat2 = latbin.scale(next(latbin.read_lattices("ark:" + comp))[1], lm_scale=2.0, acoustic_scale=0.5, acoustic2lm_scale=0.25, lm2acoustic_scale=3.0)
     g1, a1 = [(g, a) for arcs in lat2.arcs for _, _, g, a, _ in arcs][0]
     assert abs(g1 - (2.0 * g0 + 0.25 * a0)) < 1e-5 and abs(a1 - (3.0 * g0 + 0.5 * a0)) < 1e-5
+
+
+def test_installed_wrappers_run_from_path(tmp_path):
+    """tools/install_wrappers.py: Kaldi's binary names on $PATH; every tool script it points at exists."""
+    bindir = tmp_path / "bin"
+    r = subprocess.run([sys.executable, ROOT + "/tools/install_wrappers.py", str(bindir)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    names = sorted(os.listdir(bindir))
+    assert "nnet3-latgen-faster" in names and "compute-wer" in names and len(names) >= 18
+    for n in names:
+        body = open(bindir / n).read()
+        script = [w for w in body.split() if w.endswith(".py")][0]
+        assert os.path.exists(script), script
+    (tmp_path / "ref").write_text("u1 a b c\n")
+    (tmp_path / "hyp").write_text("u1 a x c\n")
+    env = dict(os.environ, PATH=str(bindir) + os.pathsep + os.environ["PATH"])
+    r = subprocess.run(["compute-wer", "--text", "--mode=present", "ark:%s" % (tmp_path / "ref"), "ark:%s" % (tmp_path / "hyp")],
+                       capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and r.stdout.startswith("%WER 33.33 [ 1 / 3, 0 ins, 0 del, 1 sub ]"), (r.stdout, r.stderr)
