@@ -21,7 +21,10 @@
 #include <cstdio>
 #include <limits>
 #include <stdexcept>
+#include <cstdlib>
+#include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "kaldi_amd.h"
@@ -554,6 +557,183 @@ class SingleUtteranceNnet3Decoder {
   kamd_online_feat *online_;
   LatticeFasterDecoder decoder_;
   bool finished_;
+};
+
+// ---- util/parse-options.h:36-260: the subset the decode binaries use (typed --name=value options, bare --flag
+// for bools, name normalisation, --config=file, "--" ends the options, 1-based GetArg)
+class ParseOptions {
+ public:
+  explicit ParseOptions(const char *usage) : usage_(usage) {}
+  void Register(const std::string &name, bool *p, const std::string &doc) { Add(name, 'b', p, doc); }
+  void Register(const std::string &name, int32 *p, const std::string &doc) { Add(name, 'i', p, doc); }
+  void Register(const std::string &name, float *p, const std::string &doc) { Add(name, 'f', p, doc); }
+  void Register(const std::string &name, double *p, const std::string &doc) { Add(name, 'd', p, doc); }
+  void Register(const std::string &name, std::string *p, const std::string &doc) { Add(name, 's', p, doc); }
+  int Read(int argc, const char *const argv[]) {
+    for (int i = 1; i < argc; i++) {                       // first pass: config files
+      if (strncmp(argv[i], "--", 2) != 0 || !strcmp(argv[i], "--")) break;
+      std::string k, v; bool eq; Split(argv[i], &k, &v, &eq);
+      if (k == "config") ReadConfigFile(v);
+    }
+    int i = 1; bool dd = false;
+    for (; i < argc; i++) {
+      if (strncmp(argv[i], "--", 2) != 0) break;
+      if (!strcmp(argv[i], "--")) { i++; dd = true; break; }
+      std::string k, v; bool eq; Split(argv[i], &k, &v, &eq);
+      if (k != "config" && !Set(k, v, eq)) throw KaldiFatalError(std::string("Invalid option ") + argv[i]);
+    }
+    for (; i < argc; i++) {
+      if (!strcmp(argv[i], "--") && !dd) dd = true; else args_.push_back(argv[i]);
+    }
+    return i;
+  }
+  int NumArgs() const { return static_cast<int>(args_.size()); }
+  std::string GetArg(int i) const {
+    if (i < 1 || i > NumArgs()) throw KaldiFatalError("ParseOptions::GetArg, invalid index");
+    return args_[i - 1];
+  }
+  void PrintUsage() const {
+    fprintf(stderr, "\n%s\nOptions:\n", usage_.c_str());
+    for (size_t k = 0; k < names_.size(); k++) fprintf(stderr, "  --%-25s : %s\n", names_[k].c_str(), docs_[k].c_str());
+  }
+  void ReadConfigFile(const std::string &filename) {
+    FILE *f = fopen(filename.c_str(), "r");
+    if (!f) throw KaldiFatalError("Cannot open config file: " + filename);
+    char buf[4096];
+    while (fgets(buf, sizeof(buf), f)) {
+      std::string line(buf);
+      const size_t h = line.find('#');
+      if (h != std::string::npos) line.erase(h);
+      Trim(&line);
+      if (line.empty()) continue;
+      if (line.compare(0, 2, "--") != 0) { fclose(f); throw KaldiFatalError("Reading config file " + filename + ": line does not look like --x=y: " + line); }
+      std::string k, v; bool eq; Split(line.c_str(), &k, &v, &eq);
+      if (!Set(k, v, eq)) { fclose(f); throw KaldiFatalError("Invalid option " + line + " in config file " + filename); }
+    }
+    fclose(f);
+  }
+ private:
+  static void Trim(std::string *s) {
+    const size_t a = s->find_first_not_of(" \t\r\n"), b = s->find_last_not_of(" \t\r\n");
+    *s = a == std::string::npos ? "" : s->substr(a, b - a + 1);
+  }
+  static std::string Normalize(const std::string &n) {
+    std::string o;
+    for (size_t i = 0; i < n.size(); i++) o += n[i] == '_' ? '-' : static_cast<char>(tolower(n[i]));
+    return o;
+  }
+  static void Split(const char *arg, std::string *k, std::string *v, bool *eq) {
+    const std::string a(arg);
+    const size_t p = a.find('=');
+    if (p == 2) throw KaldiFatalError("Invalid option (no key): " + a);
+    *eq = p != std::string::npos;
+    *k = Normalize(a.substr(2, *eq ? p - 2 : std::string::npos));
+    *v = *eq ? a.substr(p + 1) : "";
+    Trim(v);
+  }
+  void Add(const std::string &name, char t, void *p, const std::string &doc) {
+    names_.push_back(Normalize(name)); types_.push_back(t); ptrs_.push_back(p); docs_.push_back(doc);
+  }
+  bool Set(const std::string &k, const std::string &v, bool eq) {
+    for (size_t i = 0; i < names_.size(); i++) {
+      if (names_[i] != k) continue;
+      char *e = NULL;
+      switch (types_[i]) {
+        case 'b': {
+          if (eq && v.empty()) throw KaldiFatalError("Invalid option --" + k + "=");
+          std::string l;
+          for (size_t c = 0; c < v.size(); c++) l += static_cast<char>(tolower(v[c]));
+          if (l == "true" || l == "t" || l == "1" || l.empty()) *static_cast<bool *>(ptrs_[i]) = true;
+          else if (l == "false" || l == "f" || l == "0") *static_cast<bool *>(ptrs_[i]) = false;
+          else throw KaldiFatalError("Invalid format for boolean argument [expected true or false]: " + v);
+          return true;
+        }
+        case 'i': { const long x = strtol(v.c_str(), &e, 10); if (v.empty() || *e) throw KaldiFatalError("Invalid integer option \"" + v + "\""); *static_cast<int32 *>(ptrs_[i]) = static_cast<int32>(x); return true; }
+        case 'f': { const double x = strtod(v.c_str(), &e); if (v.empty() || *e) throw KaldiFatalError("Invalid floating-point option \"" + v + "\""); *static_cast<float *>(ptrs_[i]) = static_cast<float>(x); return true; }
+        case 'd': { const double x = strtod(v.c_str(), &e); if (v.empty() || *e) throw KaldiFatalError("Invalid floating-point option \"" + v + "\""); *static_cast<double *>(ptrs_[i]) = x; return true; }
+        default:
+          if (!eq) throw KaldiFatalError("Invalid option --" + k + " (option format is --x=y).");
+          *static_cast<std::string *>(ptrs_[i]) = v;
+          return true;
+      }
+    }
+    return false;
+  }
+  std::string usage_;
+  std::vector<std::string> names_, docs_, args_;
+  std::vector<char> types_;
+  std::vector<void *> ptrs_;
+};
+
+// ---- SequentialBaseFloatMatrixReader (util/kaldi-table.h:278-360) over "ark:" and "scp:" rspecifiers with files,
+// file:offset entries, input pipes and standard input (kamd_classify_rspecifier / kamd_rx_materialize / kamd_ark_read_matrix)
+class SequentialBaseFloatMatrixReader {
+ public:
+  explicit SequentialBaseFloatMatrixReader(const std::string &rspecifier) : type_(0), off_(0), temp_(false), scp_pos_(0), done_(false), rows_(0), cols_(0) {
+    char rx[4096]; int opts = 0;
+    type_ = kamd_classify_rspecifier(rspecifier.c_str(), rx, sizeof(rx), &opts);
+    if (type_ != 1 && type_ != 2) throw KaldiFatalError("invalid rspecifier " + rspecifier);
+    if (type_ == 1) Materialize(rx, &path_, &off_, &temp_);
+    else {
+      std::string p; int64_t o; bool t;
+      Materialize(rx, &p, &o, &t);
+      FILE *f = fopen(p.c_str(), "r");
+      if (!f) throw KaldiFatalError("cannot open script file " + p);
+      char buf[8192];
+      while (fgets(buf, sizeof(buf), f)) {
+        std::string line(buf);
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        const size_t sp = line.find_first_of(" \t");
+        if (line.empty() || sp == std::string::npos || sp == 0) { fclose(f); throw KaldiFatalError("Invalid line in script file: \"" + line + "\""); }
+        scp_.push_back(std::make_pair(line.substr(0, sp), line.substr(line.find_first_not_of(" \t", sp))));
+      }
+      fclose(f);
+      if (t) remove(p.c_str());
+    }
+    Next();
+  }
+  ~SequentialBaseFloatMatrixReader() { if (temp_) remove(path_.c_str()); }
+  bool Done() const { return done_; }
+  const std::string &Key() const { return key_; }
+  const std::vector<float> &Value() const { return data_; }
+  int32 NumRows() const { return rows_; }
+  int32 NumCols() const { return cols_; }
+  void Next() {
+    float *p = NULL;
+    if (type_ == 1) {
+      char key[1024];
+      const int rc = kamd_ark_read_matrix(path_.c_str(), &off_, key, sizeof(key), &rows_, &cols_, &p);
+      if (rc == 1) { done_ = true; return; }
+      Check(rc);
+      key_ = key;
+    } else {
+      if (scp_pos_ >= scp_.size()) { done_ = true; return; }
+      key_ = scp_[scp_pos_].first;
+      std::string path; int64_t off; bool temp;
+      Materialize(scp_[scp_pos_].second.c_str(), &path, &off, &temp);
+      scp_pos_++;
+      const int rc = kamd_ark_read_matrix(path.c_str(), &off, NULL, 0, &rows_, &cols_, &p);
+      if (temp) remove(path.c_str());
+      Check(rc);
+    }
+    data_.assign(p, p + static_cast<size_t>(rows_) * cols_);
+    kamd_host_free(p);
+  }
+ private:
+  static void Materialize(const char *rx, std::string *path, int64_t *off, bool *temp) {
+    char buf[4096]; int t = 0;
+    Check(kamd_rx_materialize(rx, buf, sizeof(buf), off, &t));
+    *path = buf; *temp = t != 0;
+  }
+  int type_;
+  std::string path_, key_;
+  int64_t off_;
+  bool temp_;
+  std::vector<std::pair<std::string, std::string> > scp_;
+  size_t scp_pos_;
+  bool done_;
+  int32 rows_, cols_;
+  std::vector<float> data_;
 };
 
 // ---- N concurrent SingleUtteranceNnet3Decoder's behind one set of launches (kamd_stream_batch_*): stream s is decoder lane s.

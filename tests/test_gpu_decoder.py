@@ -350,6 +350,22 @@ def test_latgen_faster_mapped_tool(tmp_path):
     assert open(tmp_path / "lat_cxx.ark", "rb").read() == open(tmp_path / "lat.ark", "rb").read()
     r = subprocess.run([exe, "--no-such=1", "a", "b", "c", "d"], capture_output=True, text=True)
     assert r.returncode == 255
+    # --config file, scp input with file:offset entries and a pipe entry
+    from kaldi_amd import table
+    with table.TableWriter("ark,scp:%s,%s" % (tmp_path / "ll2.ark", tmp_path / "ll2.scp"), "matrix") as w2:
+        for k, (ll_, _) in utts.items():
+            w2.write(k, ll_)
+    lines = open(tmp_path / "ll2.scp").read().splitlines()
+    kio.write_matrix_ark(tmp_path / "one.ark", "zzz", utts["utt2"][0], binary=True, append=False)
+    lines[2] = "utt2 dd if=%s bs=1 skip=4 2>/dev/null |" % (tmp_path / "one.ark")         # the object without its "zzz " key
+    open(tmp_path / "ll2.scp", "w").write("\n".join(lines) + "\n")
+    (tmp_path / "dec.conf").write_text("--beam=15   # as above\n--lattice_beam=8\n--max-active=7000\n--Determinize-Lattice=false\n")
+    r = subprocess.run([exe, "--config=%s" % (tmp_path / "dec.conf"), "--acoustic-scale=1.0", str(tmp_path / "id2pdf.int"), str(tmp_path / "HCLG.fst"),
+                        "scp:%s" % (tmp_path / "ll2.scp"), "ark:%s" % (tmp_path / "lat_cxx2.ark"), "ark,t:%s" % (tmp_path / "words_cxx2.txt")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(tmp_path / "words_cxx2.txt").read() == open(tmp_path / "words.txt").read()
+    assert open(tmp_path / "lat_cxx2.ark", "rb").read() == open(tmp_path / "lat.ark", "rb").read()
 
 
 def test_nnet3_latgen_faster_tool(tmp_path):
