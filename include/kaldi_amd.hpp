@@ -16,6 +16,7 @@
 #ifndef KALDI_AMD_HPP_
 #define KALDI_AMD_HPP_
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -734,6 +735,55 @@ class SequentialBaseFloatMatrixReader {
   bool done_;
   int32 rows_, cols_;
   std::vector<float> data_;
+};
+
+// ---- nnet3-latgen-faster-batch's NnetBatchDecoder flow (nnet3/nnet-batch-compute.h:606-833: AcceptInput per utterance,
+// one compute thread, decoder threads) as ONE device pass per batch: waveforms (or features) -> log-likelihoods ->
+// lattices, nothing crossing PCIe in between (kamd_pipeline_*).
+class NnetBatchDecoder {
+ public:
+  NnetBatchDecoder(const LatticeFasterDecoderConfig &decoder_opts, const std::vector<int32> &id2pdf, const AmNnetSimple &am_nnet,
+                   const DecodingGraph &fst, const MfccOptions &mfcc_opts, const kamd_decoder_sizes &sizes)
+      : feat_(CheckPtr(kamd_mfcc_create(&mfcc_opts.c, 1.0f))) {
+    decoder_opts.Check();
+    kamd_decoder_config c = decoder_opts.ToC();
+    dec_ = CheckPtr(kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), static_cast<int32>(id2pdf.size())));
+    h_ = CheckPtr(kamd_pipeline_create(feat_, am_nnet.Handle(), dec_));
+  }
+  ~NnetBatchDecoder() { kamd_pipeline_destroy(h_); kamd_decoder_destroy(dec_); kamd_feat_destroy(feat_); }
+  NnetBatchDecoder(const NnetBatchDecoder &) = delete;
+  NnetBatchDecoder &operator=(const NnetBatchDecoder &) = delete;
+  /// waves: the batch's utterances (int16-range samples); decodes all of them (AcceptInput ... Finished)
+  void Decode(const std::vector<std::vector<float> > &waves) {
+    std::vector<int64_t> off(waves.size() + 1, 0);
+    for (size_t u = 0; u < waves.size(); u++) off[u + 1] = off[u] + static_cast<int64_t>(waves[u].size());
+    std::vector<float> flat(static_cast<size_t>(off.back()));
+    for (size_t u = 0; u < waves.size(); u++) std::copy(waves[u].begin(), waves[u].end(), flat.begin() + off[u]);
+    Check(kamd_pipeline_load_batch(h_, flat.data(), off.data(), static_cast<int>(waves.size())));
+    Check(kamd_pipeline_run(h_, stage_ms_));
+  }
+  /// online i-vectors estimated on the device from the batch's own features (or NULL to turn that off)
+  void SetIvectorExtractor(kamd_ivector_extractor *extractor, int32 frames_per_chunk = 50) {
+    Check(kamd_pipeline_set_ivector_extractor(h_, extractor, frames_per_chunk));
+  }
+  bool GetBestPath(int32 utt, std::vector<int32> *alignment, std::vector<int32> *words, BaseFloat *graph_cost, BaseFloat *acoustic_cost) const {
+    kamd_lattice_size sz;
+    Check(kamd_decoder_lattice_size(dec_, utt, &sz));
+    const int cap = sz.num_arcs + 1;
+    std::vector<int32> ali(cap), wrd(cap);
+    int na = 0, nw = 0;
+    if (kamd_decoder_best_path(dec_, utt, ali.data(), cap, &na, wrd.data(), cap, &nw, graph_cost, acoustic_cost) != 0) return false;
+    alignment->assign(ali.begin(), ali.begin() + na); words->assign(wrd.begin(), wrd.begin() + nw);
+    return true;
+  }
+  /// device time of the last batch: features, nnet, AdvanceDecoding, FinalizeDecoding (ms)
+  const float *StageMs() const { return stage_ms_; }
+  kamd_decoder *DecoderHandle() { return dec_; }
+ private:
+  kamd_feat *feat_;
+  kamd_decoder *dec_;
+  kamd_pipeline *h_;
+  float stage_ms_[4];
 };
 
 // ---- N concurrent SingleUtteranceNnet3Decoder's behind one set of launches (kamd_stream_batch_*): stream s is decoder lane s.

@@ -153,6 +153,19 @@ int main(int argc, char **argv) {
       mo.c.use_energy = 0; mo.c.mel.num_bins = 40; mo.c.num_ceps = 40; mo.c.mel.low_freq = 20.0f; mo.c.mel.high_freq = -400.0f;
       kamd_decoder_sizes bs = sz;
       bs.max_lanes = 2;
+      {   // NnetBatchDecoder: both utterances as one batch, offline
+        NnetBatchDecoder bd(config, id2pdf, am, fst, mo, bs);
+        std::vector<std::vector<float> > ws(2);
+        ws[0] = wave; ws[1].assign(wave.begin(), wave.begin() + wave.size() * 2 / 3);
+        bd.Decode(ws);
+        for (int u = 0; u < 2; u++) {
+          std::vector<int32> ali, words; BaseFloat g = 0, a = 0;
+          const bool ok = bd.GetBestPath(u, &ali, &words, &g, &a);
+          printf("offline utt=%d ok=%d frames=%d cost=%.9g words=", u, ok, static_cast<int>(ali.size()), g + a);
+          for (size_t k = 0; k < words.size(); k++) printf("%s%d", k ? "," : "", words[k]);
+          printf("\n");
+        }
+      }
       OnlineStreamBatch batch(config, id2pdf, am, fst, mo, 2, 4.0f, bs);
       batch.SetIvectorExtractor(extractor.handle(), 20, d.splice_right);
       std::vector<int32> both = {0, 1};

@@ -101,6 +101,17 @@ def test_cxx_host_api(tmp_path):
             ",".join(str(w) for w in bp["words"]))
         assert batch_lines[s_] == want_line
     out = [l for l in out if not l.startswith("batch ")]
+    # NnetBatchDecoder (offline batch) against the Python pipeline
+    from kaldi_amd import pipeline
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), m, g, cfgb, max_utts=2, max_seconds=4.0, sizes=abi.DecoderSizes(2, 1 << 14, 1 << 18, 1 << 19, 1024))
+    res = pipe.decode([wv, wv[:wv.size * 2 // 3]])
+    off_lines = [l for l in out if l.startswith("offline ")]
+    assert len(off_lines) == 2
+    for u_ in range(2):
+        bp = res[u_]["best"]
+        assert off_lines[u_] == "offline utt=%d ok=1 frames=%d cost=%.9g words=%s" % (
+            u_, len(bp["alignment"]), np.float32(bp["graph_cost"]) + np.float32(bp["acoustic_cost"]), ",".join(str(w) for w in bp["words"]))
+    out = [l for l in out if not l.startswith("offline ")]
     ie = ivector.IvectorExtractor(info)
     _, st = ie.extract_online(f1, return_state=True, max_remembered_frames=60.0)
     want_iv = ie.extract_online(f2, state=st)
