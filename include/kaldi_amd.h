@@ -415,7 +415,7 @@ int kamd_am_gmm_dim(const kamd_am_gmm *g);
 int kamd_am_gmm_loglikes_device(kamd_am_gmm *g, const float *d_feats, int ld, int64_t rows, float scale, float *d_out, void *stream);
 int kamd_am_gmm_loglikes(kamd_am_gmm *g, const float *feats, int num_frames, int feat_dim, float scale, float *out);
 
-/* ----------------------------------------------------------------- CMVN -- */
+/* -------- feature post-processing: CMVN, add-deltas, splice / transform -- */
 /* splice-feats | transform-feats (featbin/splice-feats.cc, transform-feats.cc:100-160): SpliceFrames with left / right
  * context clamped at each utterance's ends, then y = M x, or M [x; 1] when M has one more column (LDA+MLLT final.mat,
  * per-speaker fMLLR).  h_transforms: n_transforms matrices [xf_rows x xf_cols] back to back, utterance u uses
