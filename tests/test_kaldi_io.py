@@ -127,3 +127,31 @@ def test_int32_vector_archives(tmp_path):
     p.write_text("u1 1 2 3 \nu2 \nu3 42\n")
     got = list(kio.read_int32_vector_ark(p))
     assert [(k, v.tolist()) for k, v in got] == [("u1", [1, 2, 3]), ("u2", []), ("u3", [42])]
+
+
+def _wav_bytes(riff_len, channels, hz, data_len, samples):
+    """the byte layout of the reference's wave-reader-test.cc cases: fmt chunk of 18 bytes (WAVEFORMATEX with cbSize)"""
+    import struct
+    byps = hz * channels * 2
+    return (b"RIFF" + struct.pack("<I", riff_len & 0xFFFFFFFF) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHHH", 18, 1, channels, hz, byps, 2 * channels, 16, 0)
+            + b"data" + struct.pack("<I", data_len & 0xFFFFFFFF) + struct.pack("<%dh" % len(samples), *samples))
+
+
+@pytest.mark.parametrize("name,args,hz,want", [
+    # feat/wave-reader-test.cc:32-80 UnitTestStereo8K: interleaved L R L R L R -> two rows
+    ("stereo8k", (50, 2, 8000, 12, [0, -1, -32768, 0, 32767, 1]), 8000, [[0, -32768, 32767], [-1, 0, 1]]),
+    # :82-125 UnitTestMono22K
+    ("mono22k", (48, 1, 22050, 10, [0, -1, -32768, 32767, 1]), 22050, [[0, -1, -32768, 32767, 1]]),
+    # :127-162 UnitTestEndless1: RIFF and data lengths 0 = "unknown", read to the end of the stream
+    ("endless1", (0, 1, 8000, 0, [1, 2, 3]), 8000, [[1, 2, 3]]),
+    # :164-199 UnitTestEndless2: lengths 0xFFFFFFFF
+    ("endless2", (-1, 1, 8000, -1, [1, 2, 3]), 8000, [[1, 2, 3]]),
+])
+def test_wave_reader_reference_known_answers(tmp_path, name, args, hz, want):
+    """WaveData::Read pinned to the four byte-level cases of the reference's own unit test (restated as data)."""
+    p = tmp_path / (name + ".wav")
+    p.write_bytes(_wav_bytes(*args))
+    sf, data = kio.read_wave(p)
+    assert sf == hz
+    np.testing.assert_array_equal(data, np.asarray(want, np.float32))
+    assert abs(data.shape[1] / sf - len(want[0]) / hz) < 1e-6           # Duration()

@@ -128,3 +128,22 @@ def test_installed_wrappers_run_from_path(tmp_path):
     r = subprocess.run(["compute-wer", "--text", "--mode=present", "ark:%s" % (tmp_path / "ref"), "ark:%s" % (tmp_path / "hyp")],
                        capture_output=True, text=True, env=env)
     assert r.returncode == 0 and r.stdout.startswith("%WER 33.33 [ 1 / 3, 0 ins, 0 del, 1 sub ]"), (r.stdout, r.stderr)
+
+
+def test_edit_distance_reference_known_answers():
+    """util/edit-distance-test.cc:26-65 (totals as the pairs grow) and :112-144 (ins/del/sub split)"""
+    from kaldi_amd.latbin import edit_distance
+    a, b, totals = [], [], []
+    steps = [("a", 1), ("b", 1), ("b", 2), ("a", 2), ("a", 3), ("a", 4), ("b", 4), ("a", 5), ("b", 6), ("a", 1), ("b", 1), ("b", 10)]
+    check_after = {0: 1, 1: 0, 2: 1, 3: 0, 6: 1, 7: 2, 8: 2, 10: 2, 11: 3}
+    assert edit_distance(a, b)[0] == 0
+    for i, (which, v) in enumerate(steps):
+        (a if which == "a" else b).append(v)
+        if i in check_after:
+            assert edit_distance(a, b)[0] == check_after[i], (i, a, b)
+            assert edit_distance([str(x) for x in a], [str(x) for x in b])[0] == check_after[i]
+    hyp, ref = [1, 3, 4, 5], [2, 3, 4, 5, 6, 7]
+    assert edit_distance(ref, hyp) == (3, 0, 2, 1)
+    assert edit_distance(hyp, ref) == (3, 2, 0, 1)
+    assert edit_distance([1], [1]) == (0, 0, 0, 0)
+    assert edit_distance([1, 3], [1, 2]) == (1, 0, 0, 1)
