@@ -665,6 +665,31 @@ int kamd_compact_lattice_write(const char *path, int append, const char *key, in
 int kamd_decoder_partial_best_path(kamd_decoder *d, int lane, int use_final_probs, int32_t *alignment,
                                    int ali_cap, int *ali_len, int32_t *words, int words_cap,
                                    int *words_len, float *graph_cost, float *acoustic_cost);
+/* ---- endpointing (online2/online-endpoint.{h,cc}) ----
+ * OnlineEndpointRule / OnlineEndpointConfig (online-endpoint.h:113-170); the silence phones are handed to the
+ * decoder once (kamd_decoder_set_silence_phones) instead of travelling as a colon-separated string. */
+typedef struct {
+  int32_t must_contain_nonsilence;
+  float min_trailing_silence, max_relative_cost, min_utterance_length;
+} kamd_endpoint_rule;
+typedef struct { kamd_endpoint_rule rule[5]; } kamd_endpoint_config;
+void kamd_endpoint_config_default(kamd_endpoint_config *c);
+/* EndpointDetected(config, num_frames_decoded, trailing_silence_frames, frame_shift_in_seconds,
+ * final_relative_cost) (online-endpoint.cc:46-68): 1 / 0, -1 on a bad argument.  Host arithmetic only. */
+int kamd_endpoint_detected(const kamd_endpoint_config *c, int num_frames_decoded, int trailing_silence_frames,
+                           float frame_shift_in_seconds, float final_relative_cost);
+/* tid2phone[1..num_tids] = TransitionModel::TransitionIdToPhone; silence_phones = --endpoint.silence-phones
+ * (must be non-empty, no duplicates: online-endpoint.cc:77-82). */
+int kamd_decoder_set_silence_phones(kamd_decoder *d, const int32_t *tid2phone, int32_t num_tids,
+                                    const int32_t *silence_phones, int n_sil);
+/* TrailingSilenceLength (online-endpoint.cc:71-102) of n un-finalized lanes in one launch: frames of silence
+ * at the end of the best path taken WITHOUT final-probs.  Blocks. */
+int kamd_decoder_trailing_silence_frames(kamd_decoder *d, const int32_t *lanes, int n, int32_t *out);
+/* EndpointDetected(config, tmodel, frame_shift_in_seconds, decoder) (online-endpoint.cc:105-121) for n lanes;
+ * frame_shift_in_seconds is that of the decoder's frames (feature shift x frame-subsampling-factor,
+ * online-nnet3-decoding.cc:88-95).  detected[i] = 0 / 1; trailing_silence_frames may be NULL. */
+int kamd_decoder_endpoint_detected(kamd_decoder *d, const kamd_endpoint_config *cfg, const int32_t *lanes, int n,
+                                   float frame_shift_in_seconds, int32_t *detected, int32_t *trailing_silence_frames);
 /* per-frame trace for parity debugging: ntok[f], cutoff[f], cost_offset[f]. */
 int kamd_decoder_get_trace(kamd_decoder *d, int lane, int32_t *ntok,
                            float *cutoff, float *cost_offset, int cap);

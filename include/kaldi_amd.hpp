@@ -498,6 +498,87 @@ class AmNnetSimple {
 /// SingleUtteranceNnet3DecoderTpl<fst::Fst<fst::StdArc>>: streaming decode of one utterance.
 /// OnlineNnet2FeaturePipeline is reduced to its MFCC part (no ivector / pitch), the
 /// DecodableNnetLoopedOnline to the rows kamd_nnet_forward_range serves.
+// ---- online2/online-endpoint.h:113-200
+struct OnlineEndpointRule {
+  bool must_contain_nonsilence;
+  BaseFloat min_trailing_silence, max_relative_cost, min_utterance_length;
+  OnlineEndpointRule(bool must_contain_nonsilence = true, BaseFloat min_trailing_silence = 1.0,
+                     BaseFloat max_relative_cost = std::numeric_limits<BaseFloat>::infinity(), BaseFloat min_utterance_length = 0.0)
+      : must_contain_nonsilence(must_contain_nonsilence), min_trailing_silence(min_trailing_silence),
+        max_relative_cost(max_relative_cost), min_utterance_length(min_utterance_length) {}
+  template <typename Opts> void RegisterWithPrefix(const std::string &prefix, Opts *opts) {
+    opts->Register(prefix + ".must-contain-nonsilence", &must_contain_nonsilence,
+                   "If true, for this endpointing rule to apply there must be nonsilence in the best-path traceback.");
+    opts->Register(prefix + ".min-trailing-silence", &min_trailing_silence,
+                   "This endpointing rule requires duration of trailing silence (in seconds) to be >= this value.");
+    opts->Register(prefix + ".max-relative-cost", &max_relative_cost,
+                   "This endpointing rule requires relative-cost of final-states to be <= this value.");
+    opts->Register(prefix + ".min-utterance-length", &min_utterance_length,
+                   "This endpointing rule requires utterance-length (in seconds) to be >= this value.");
+  }
+};
+struct OnlineEndpointConfig {
+  std::string silence_phones;   ///< e.g. 1:2:3:4, colon separated list of phones
+  OnlineEndpointRule rule1, rule2, rule3, rule4, rule5;
+  OnlineEndpointConfig()
+      : rule1(false, 5.0, std::numeric_limits<BaseFloat>::infinity(), 0.0), rule2(true, 0.5, 2.0, 0.0), rule3(true, 1.0, 8.0, 0.0),
+        rule4(true, 2.0, std::numeric_limits<BaseFloat>::infinity(), 0.0), rule5(false, 0.0, std::numeric_limits<BaseFloat>::infinity(), 20.0) {}
+  template <typename Opts> void Register(Opts *opts) {
+    opts->Register("endpoint.silence-phones", &silence_phones, "List of phones that are considered to be silence phones by the endpointing code.");
+    rule1.RegisterWithPrefix("endpoint.rule1", opts); rule2.RegisterWithPrefix("endpoint.rule2", opts);
+    rule3.RegisterWithPrefix("endpoint.rule3", opts); rule4.RegisterWithPrefix("endpoint.rule4", opts);
+    rule5.RegisterWithPrefix("endpoint.rule5", opts);
+  }
+  kamd_endpoint_config ToC() const {
+    kamd_endpoint_config c;
+    const OnlineEndpointRule *r[5] = {&rule1, &rule2, &rule3, &rule4, &rule5};
+    for (int i = 0; i < 5; i++) {
+      c.rule[i].must_contain_nonsilence = r[i]->must_contain_nonsilence ? 1 : 0;
+      c.rule[i].min_trailing_silence = r[i]->min_trailing_silence;
+      c.rule[i].max_relative_cost = r[i]->max_relative_cost;
+      c.rule[i].min_utterance_length = r[i]->min_utterance_length;
+    }
+    return c;
+  }
+  /// SplitStringToIntegers(silence_phones, ":", false, ...) (online-endpoint.cc:75-77)
+  std::vector<int32> SilencePhones() const {
+    std::vector<int32> out;
+    size_t pos = 0;
+    while (pos <= silence_phones.size() && !silence_phones.empty()) {
+      const size_t e = silence_phones.find(':', pos);
+      const std::string tok = silence_phones.substr(pos, e == std::string::npos ? std::string::npos : e - pos);
+      char *end = NULL;
+      const long v = strtol(tok.c_str(), &end, 10);
+      if (tok.empty() || *end != 0) throw KaldiFatalError("Bad --silence-phones option in endpointing config: " + silence_phones);
+      out.push_back(static_cast<int32>(v));
+      if (e == std::string::npos) break;
+      pos = e + 1;
+    }
+    return out;
+  }
+};
+/// EndpointDetected on plain numbers (online-endpoint.cc:46-68)
+inline bool EndpointDetected(const OnlineEndpointConfig &config, int32 num_frames_decoded, int32 trailing_silence_frames,
+                             BaseFloat frame_shift_in_seconds, BaseFloat final_relative_cost) {
+  const kamd_endpoint_config c = config.ToC();
+  const int rc = kamd_endpoint_detected(&c, num_frames_decoded, trailing_silence_frames, frame_shift_in_seconds, final_relative_cost);
+  Check(rc);
+  return rc == 1;
+}
+/// EndpointDetected(config, tmodel, frame_shift, decoder) for a set of un-finalized lanes of one decoder handle, one
+/// device launch (online-endpoint.cc:105-121).  tid2phone[tid], tid = 1..size()-1, is TransitionIdToPhone.
+inline void EndpointDetected(const OnlineEndpointConfig &config, const std::vector<int32> &tid2phone, BaseFloat frame_shift_in_seconds,
+                             kamd_decoder *decoder, const std::vector<int32> &lanes, std::vector<int32> *detected,
+                             std::vector<int32> *trailing_silence_frames = NULL) {
+  const std::vector<int32> sil = config.SilencePhones();
+  Check(kamd_decoder_set_silence_phones(decoder, tid2phone.data(), static_cast<int32>(tid2phone.size()) - 1, sil.data(), static_cast<int>(sil.size())));
+  const kamd_endpoint_config c = config.ToC();
+  detected->assign(lanes.size(), 0);
+  if (trailing_silence_frames) trailing_silence_frames->assign(lanes.size(), 0);
+  Check(kamd_decoder_endpoint_detected(decoder, &c, lanes.data(), static_cast<int>(lanes.size()), frame_shift_in_seconds, detected->data(),
+                                       trailing_silence_frames ? trailing_silence_frames->data() : NULL));
+}
+
 class SingleUtteranceNnet3Decoder {
  public:
   SingleUtteranceNnet3Decoder(const LatticeFasterDecoderConfig &decoder_opts, const std::vector<int32> &id2pdf,
@@ -505,6 +586,7 @@ class SingleUtteranceNnet3Decoder {
                               const kamd_decoder_sizes *sizes = NULL)
       : nnet_(am_nnet.Handle()), feat_(CheckPtr(kamd_mfcc_create(&mfcc_opts.c, 1.0f))),
         online_(CheckPtr(kamd_online_feat_create(feat_))), decoder_(fst, decoder_opts, id2pdf, sizes), finished_(false) {
+    frame_shift_ = mfcc_opts.c.frame.frame_shift_ms * 1.0e-3f;
     decoder_.InitDecoding();                          // online-nnet3-decoding.cc:40
   }
   ~SingleUtteranceNnet3Decoder() { kamd_online_feat_destroy(online_); kamd_feat_destroy(feat_); }
@@ -550,9 +632,18 @@ class SingleUtteranceNnet3Decoder {
     words->assign(wrd.begin(), wrd.begin() + nw);
     return true;
   }
+  /// EndpointDetected(config) (online-nnet3-decoding.cc:88-95); the transition model's tid -> phone table is
+  /// passed here instead of at construction
+  bool EndpointDetected(const OnlineEndpointConfig &config, const std::vector<int32> &tid2phone) {
+    std::vector<int32> det;
+    kaldi_amd::EndpointDetected(config, tid2phone, frame_shift_ * kamd_nnet_frame_subsampling_factor(nnet_), decoder_.Handle(),
+                            std::vector<int32>(1, 0), &det);
+    return det[0] != 0;
+  }
   const LatticeFasterDecoder &Decoder() const { return decoder_; }
  private:
   SingleUtteranceNnet3Decoder(const SingleUtteranceNnet3Decoder &);
+  BaseFloat frame_shift_;
   kamd_nnet *nnet_;
   kamd_feat *feat_;
   kamd_online_feat *online_;
@@ -800,6 +891,7 @@ class OnlineStreamBatch {
     kamd_decoder_config c = decoder_opts.ToC();
     dec_ = CheckPtr(kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), static_cast<int32>(id2pdf.size())));
     h_ = CheckPtr(kamd_stream_batch_create(feat_, am_nnet.Handle(), dec_, max_streams, max_seconds, mfcc_opts.c.frame.samp_freq));
+    frame_shift_ = mfcc_opts.c.frame.frame_shift_ms * 1.0e-3f * kamd_nnet_frame_subsampling_factor(am_nnet.Handle());
   }
   ~OnlineStreamBatch() { kamd_stream_batch_destroy(h_); kamd_decoder_destroy(dec_); kamd_feat_destroy(feat_); }
   OnlineStreamBatch(const OnlineStreamBatch &) = delete;
@@ -842,8 +934,14 @@ class OnlineStreamBatch {
     Check(kamd_stream_batch_get_adaptation_state(h_, stream, state->data()));
     Check(kamd_ivector_state_limit_frames(ie_, state->data(), max_remembered_frames));
   }
+  /// EndpointDetected for these streams after a tick, one launch (online2-wav-nnet3-latgen-faster.cc --do-endpointing)
+  void EndpointDetected(const OnlineEndpointConfig &config, const std::vector<int32> &tid2phone, const std::vector<int32> &streams,
+                        std::vector<int32> *detected, std::vector<int32> *trailing_silence_frames = NULL) {
+    kaldi_amd::EndpointDetected(config, tid2phone, frame_shift_, dec_, streams, detected, trailing_silence_frames);
+  }
   kamd_decoder *DecoderHandle() { return dec_; }
  private:
+  BaseFloat frame_shift_;
   kamd_feat *feat_;
   kamd_decoder *dec_;
   kamd_stream_batch *h_;

@@ -149,6 +149,18 @@ class IvectorDesc(C.Structure):
                 ("min_post", C.c_float), ("posterior_scale", C.c_float), ("max_count", C.c_float)]
 
 
+class EndpointRule(C.Structure):
+    """online2/online-endpoint.h:113-143 OnlineEndpointRule."""
+    _fields_ = [("must_contain_nonsilence", C.c_int32), ("min_trailing_silence", C.c_float),
+                ("max_relative_cost", C.c_float), ("min_utterance_length", C.c_float)]
+
+
+class EndpointConfig(C.Structure):
+    """online2/online-endpoint.h:145-170 OnlineEndpointConfig (rule1..rule5); the decoder gets the silence
+    phones by kamd_decoder_set_silence_phones."""
+    _fields_ = [("rule", EndpointRule * 5)]
+
+
 class DeterminizeOpts(C.Structure):
     _fields_ = [("delta", C.c_float), ("max_mem", C.c_int32), ("phone_determinize", C.c_int32),
                 ("word_determinize", C.c_int32), ("max_loop", C.c_int32), ("retry_cutoff", C.c_float)]

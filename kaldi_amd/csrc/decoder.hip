@@ -1950,19 +1950,19 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
 // expression that computed it); ties -> smallest link index.
 // Output: path arcs in REVERSE order in out_arcs (ilabel, olabel, graph, acoustic-offset).
 struct PathArc { int ilabel, olabel; float graph, ac; };
-__global__ __launch_bounds__(NT) void TracebackKernel(DecDev d, int lane, int use_final_probs,
-                                                      PathArc *out_arcs, int out_cap, int *out_n,
-                                                      float *out_final_cost) {
-  __shared__ Sh sh;
-  const Ctx c = MakeCtx(d, lane);
+// The walk itself, shared by the best-path and the endpointing kernels.  visit(k, link, emitting, f) is called
+// by every thread (uniformly) for the k-th arc from the end; returning false stops the walk.  Returns the number
+// of arcs visited, or -1 when no token is alive on the newest frame.
+template <typename Visit>
+__device__ int WalkBestPath(const DecDev &d, const Ctx &c, Sh *sh, int use_final_probs, float *final_cost, Visit visit) {
   const int tid = threadIdx.x;
-  InitSh(&sh);
-  LaneState *S = c.st;
-  const int F = S->frame;
-  // best end token
-  float best_cost, best_with_final;
-  FinalCosts(d, c, &sh, F, &best_cost, &best_with_final);
-  const bool use_final = use_final_probs && best_with_final != INFINITY;
+  const int F = c.st->frame;
+  bool use_final = false;
+  if (use_final_probs) {
+    float best_cost, best_with_final;
+    FinalCosts(d, c, sh, F, &best_cost, &best_with_final);
+    use_final = best_with_final != INFINITY;
+  }
   u64 key = EMPTY64;
   for (int t = c.tok_off[F] + tid; t < c.tok_off[F + 1]; t += NT) {
     const float fc = use_final ? d.g.final[c.tok_state[t]] : 0.0f;
@@ -1972,39 +1972,71 @@ __global__ __launch_bounds__(NT) void TracebackKernel(DecDev d, int lane, int us
       key = k < key ? k : key;
     }
   }
-  key = BlockMin64(key, &sh);
-  if (key == EMPTY64) { if (tid == 0) { *out_n = -1; } return; }
+  key = BlockMin64(key, sh);
+  if (key == EMPTY64) return -1;
   int cur = static_cast<int>(key & 0xFFFFFFFFu);
-  if (tid == 0) *out_final_cost = use_final ? d.g.final[c.tok_state[cur]] : 0.0f;
+  *final_cost = use_final ? d.g.final[c.tok_state[cur]] : 0.0f;
   int n_out = 0, f = F;
-  const int start_tok = 0;   // token 0 of list 0 is not necessarily the start: stop when no link found
-  (void)start_tok;
   for (int guard = 0; guard < 4 * (F + 2) + 1024; guard++) {
-    // search the links that can end in 'cur': epsilon links of step f, emitting links of step f
-    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
-    const int mb = c.lnk_off[2 * f], me = c.lnk_off[2 * f + 1];
+    // the links that can end in 'cur': emitting links of step f in [mb, me), epsilon links of step f in [me, ee)
+    const int mb = c.lnk_off[2 * f], me = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
     const float ccost = c.tok_cost[cur];
     u32 found = 0xFFFFFFFFu;
-    for (int li = mb + tid; li < ee; li += NT) {   // [mb,me) emitting, [eb,ee) epsilon are adjacent
+    for (int li = mb + tid; li < ee; li += NT) {
       const Link L = c.links[li];
       if (L.dst == cur && L.src >= 0 && c.tok_cost[L.src] + L.ac + L.graph == ccost) found = min(found, static_cast<u32>(li));
     }
-    (void)eb; (void)me;
-    u64 fk = BlockMin64(static_cast<u64>(found), &sh);
+    const u64 fk = BlockMin64(static_cast<u64>(found), sh);
     if (fk >= 0xFFFFFFFFull) break;              // the start token: nothing produced it
     const Link L = c.links[static_cast<int>(fk)];
     const bool emitting = static_cast<int>(fk) < me;
-    if (tid == 0 && n_out < out_cap) {
-      PathArc a; a.ilabel = L.ilabel; a.olabel = L.olabel; a.graph = L.graph;
-      a.ac = emitting ? L.ac - c.cost_offsets[f - 1] : L.ac;
-      out_arcs[n_out] = a;
-    }
+    const bool go_on = visit(n_out, L, emitting, f);
     n_out++;
+    if (!go_on) break;
     cur = L.src;
     if (emitting) f--;
     if (f < 0) break;
   }
-  if (tid == 0) *out_n = n_out;
+  return n_out;
+}
+
+__global__ __launch_bounds__(NT) void TracebackKernel(DecDev d, int lane, int use_final_probs,
+                                                      PathArc *out_arcs, int out_cap, int *out_n,
+                                                      float *out_final_cost) {
+  __shared__ Sh sh;
+  const Ctx c = MakeCtx(d, lane);
+  const int tid = threadIdx.x;
+  InitSh(&sh);
+  float fc = 0.0f;
+  const int n = WalkBestPath(d, c, &sh, use_final_probs, &fc, [&](int k, const Link &L, bool emitting, int f) {
+    if (tid == 0 && k < out_cap) {
+      PathArc a; a.ilabel = L.ilabel; a.olabel = L.olabel; a.graph = L.graph;
+      a.ac = emitting ? L.ac - c.cost_offsets[f - 1] : L.ac;
+      out_arcs[k] = a;
+    }
+    return true;
+  });
+  if (tid == 0) { *out_n = n; if (n >= 0) *out_final_cost = fc; }
+}
+
+// TrailingSilenceLength (online2/online-endpoint.cc:71-102) for a batch of un-finalized lanes: the best path
+// without final-probs is walked back from the newest frame, counting transition-ids of silence phones until
+// the first one that is not (sil_tid[tid] = 1 for transition-ids of silence phones).
+__global__ __launch_bounds__(NT) void TrailingSilenceKernel(DecDev d, const int *lanes, const unsigned char *sil_tid,
+                                                            int n_tids, int *out) {
+  __shared__ Sh sh;
+  const Ctx c = MakeCtx(d, lanes[blockIdx.x]);
+  InitSh(&sh);
+  int n_sil = 0;
+  float fc = 0.0f;
+  if (c.st->frame > 0 && !c.st->error) {
+    WalkBestPath(d, c, &sh, 0, &fc, [&](int, const Link &L, bool, int) {
+      if (L.ilabel == 0) return true;
+      if (L.ilabel < n_tids && sil_tid[L.ilabel]) { n_sil++; return true; }
+      return false;
+    });
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = n_sil;
 }
 
 static inline size_t AdvanceLdsBytes(int num_pdfs_lds, int lds_table_cap) {
@@ -2037,6 +2069,7 @@ struct Decoder {
   long long *d_tok_base = NULL, *d_lnk_base = NULL; int *d_tok_cap = NULL, *d_lnk_cap = NULL;
   std::vector<long long> h_tok_base, h_lnk_base; std::vector<int> h_tok_cap, h_lnk_cap;
   hipStream_t last_stream = NULL;
+  unsigned char *d_sil_tid = NULL; int n_sil_tids = 0; int *d_sil_out = NULL; int sil_out_cap = 0;   // endpointing
   // host copy of one lane's lattice (canonical), cached by lane
   int cached_lane = -1;
   std::vector<int32_t> lat_frame, lat_hclg; std::vector<float> lat_cost, lat_final;
@@ -2250,6 +2283,8 @@ void kamd_decoder_destroy(kamd_decoder *h) {
   Decoder *D = reinterpret_cast<Decoder *>(h);
   if (!D) return;
   for (size_t i = 0; i < D->allocs.size(); i++) (void)hipFree(D->allocs[i]);
+  if (D->d_sil_tid) (void)hipFree(D->d_sil_tid);
+  if (D->d_sil_out) (void)hipFree(D->d_sil_out);
   if (D->d_lanes) (void)hipFree(D->d_lanes);
   if (D->d_tasks) (void)hipFree(D->d_tasks);
   for (int i = 0; i < 2 * Decoder::kMaxTimed; i++) if (D->ev[i]) (void)hipEventDestroy(D->ev[i]);
@@ -2440,6 +2475,97 @@ int kamd_decoder_partial_best_path(kamd_decoder *h, int lane, int use_final_prob
     g += arcs[i].graph; a += arcs[i].ac;
   }
   *graph_cost = g + fc; *acoustic_cost = a;
+  return KAMD_OK;
+}
+
+// ---- endpointing (online2/online-endpoint.{h,cc})
+void kamd_endpoint_config_default(kamd_endpoint_config *c) {
+  // OnlineEndpointConfig(), online2/online-endpoint.h:149-154
+  const kamd_endpoint_rule r[5] = {{0, 5.0f, INFINITY, 0.0f}, {1, 0.5f, 2.0f, 0.0f}, {1, 1.0f, 8.0f, 0.0f},
+                                   {1, 2.0f, INFINITY, 0.0f}, {0, 0.0f, INFINITY, 20.0f}};
+  for (int i = 0; i < 5; i++) c->rule[i] = r[i];
+}
+
+int kamd_endpoint_detected(const kamd_endpoint_config *c, int num_frames_decoded, int trailing_silence_frames,
+                           float frame_shift_in_seconds, float final_relative_cost) {
+  if (!c || num_frames_decoded < trailing_silence_frames || trailing_silence_frames < 0)
+  {
+    kamd::SetError(KAMD_ERR_ARG, "endpointing: %d frames decoded, %d trailing silence frames", num_frames_decoded, trailing_silence_frames);
+    return -1;
+  }
+  const float utterance_length = num_frames_decoded * frame_shift_in_seconds,
+              trailing_silence = trailing_silence_frames * frame_shift_in_seconds;
+  const bool contains_nonsilence = utterance_length > trailing_silence;
+  for (int i = 0; i < 5; i++) {   // RuleActivated, online-endpoint.cc:25-44
+    const kamd_endpoint_rule &r = c->rule[i];
+    if ((contains_nonsilence || !r.must_contain_nonsilence) && trailing_silence >= r.min_trailing_silence &&
+        final_relative_cost <= r.max_relative_cost && utterance_length >= r.min_utterance_length)
+      return 1;
+  }
+  return 0;
+}
+
+int kamd_decoder_set_silence_phones(kamd_decoder *h, const int32_t *tid2phone, int32_t num_tids,
+                                    const int32_t *silence_phones, int n_sil) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (!D || !tid2phone || num_tids <= 0) return kamd::SetError(KAMD_ERR_ARG, "endpointing needs the transition-id -> phone table");
+  // "Endpointing requires nonempty --endpoint.silence-phones option"; duplicates are an error too (:77-82)
+  if (!silence_phones || n_sil <= 0) return kamd::SetError(KAMD_ERR_ARG, "Endpointing requires nonempty --endpoint.silence-phones option");
+  std::vector<int32_t> sp(silence_phones, silence_phones + n_sil);
+  std::sort(sp.begin(), sp.end());
+  if (std::adjacent_find(sp.begin(), sp.end()) != sp.end())
+    return kamd::SetError(KAMD_ERR_ARG, "Duplicates in --silence-phones option in endpointing config");
+  std::vector<unsigned char> tbl(static_cast<size_t>(num_tids) + 1, 0);
+  for (int t = 1; t <= num_tids; t++) tbl[t] = std::binary_search(sp.begin(), sp.end(), tid2phone[t]) ? 1 : 0;
+  if (D->d_sil_tid) { (void)hipFree(D->d_sil_tid); D->d_sil_tid = NULL; }
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_sil_tid), tbl.size()));
+  KAMD_HIP(hipMemcpy(D->d_sil_tid, tbl.data(), tbl.size(), hipMemcpyHostToDevice));
+  D->n_sil_tids = num_tids + 1;
+  return KAMD_OK;
+}
+
+int kamd_decoder_trailing_silence_frames(kamd_decoder *h, const int32_t *lanes, int n, int32_t *out) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0) return KAMD_OK;
+  if (!D->d_sil_tid) return kamd::SetError(KAMD_ERR_STATE, "kamd_decoder_set_silence_phones has not been called");
+  if (CheckLanes(D, lanes, n) != KAMD_OK || EnsureTaskBuf(D, n) != KAMD_OK) return KAMD_ERR_ARG;
+  const int rc = kamd_decoder_sync(h);
+  if (rc != KAMD_OK) return rc;
+  for (int i = 0; i < n; i++)
+    if (D->h_st[lanes[i]].finalized)   // BestPathEnd: "decoding_finalized_ && !use_final_probs" is an error (:84-87)
+      return kamd::SetError(KAMD_ERR_STATE, "lane %d is finalized: no trailing-silence traceback without final-probs", lanes[i]);
+  if (n > D->sil_out_cap) {
+    if (D->d_sil_out) (void)hipFree(D->d_sil_out);
+    D->d_sil_out = NULL; D->sil_out_cap = 0;
+    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_sil_out), std::max(n, 64) * sizeof(int)));
+    D->sil_out_cap = std::max(n, 64);
+  }
+  hipStream_t st = D->last_stream;
+  KAMD_HIP(hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(kamd::TrailingSilenceKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes, D->d_sil_tid, D->n_sil_tids, D->d_sil_out);
+  KAMD_HIP(hipGetLastError());
+  KAMD_HIP(hipMemcpyAsync(out, D->d_sil_out, n * sizeof(int), hipMemcpyDeviceToHost, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  return KAMD_OK;
+}
+
+int kamd_decoder_endpoint_detected(kamd_decoder *h, const kamd_endpoint_config *cfg, const int32_t *lanes, int n,
+                                   float frame_shift_in_seconds, int32_t *detected, int32_t *trailing_silence_frames) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0) return KAMD_OK;
+  if (!cfg || !detected) return kamd::SetError(KAMD_ERR_ARG, "endpointing: null argument");
+  std::vector<int32_t> sil(n, 0);
+  // (syncs: FinalRelativeCost / NumFramesDecoded below are those of the newest frame)
+  const int rc = kamd_decoder_trailing_silence_frames(h, lanes, n, sil.data());
+  if (rc != KAMD_OK) return rc;
+  for (int i = 0; i < n; i++) {
+    const kamd::LaneState &S = D->h_st[lanes[i]];
+    // EndpointDetected(config, tmodel, shift, decoder): false before the first frame (:110)
+    detected[i] = S.frame == 0 ? 0 : kamd_endpoint_detected(cfg, S.frame, sil[i], frame_shift_in_seconds, S.final_relative_cost);
+    if (detected[i] < 0) return KAMD_ERR_ARG;
+    if (trailing_silence_frames) trailing_silence_frames[i] = sil[i];
+  }
   return KAMD_OK;
 }
 

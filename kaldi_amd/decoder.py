@@ -294,6 +294,45 @@ def partial_best_path(dec, lane, use_final_probs=True):
                 acoustic_cost=a.value)
 
 
+def endpoint_config_default():
+    """OnlineEndpointConfig() (online2/online-endpoint.h:149-154)"""
+    c = abi.EndpointConfig()
+    lib().kamd_endpoint_config_default(C.byref(c))
+    return c
+
+
+def endpoint_detected_from(config, num_frames_decoded, trailing_silence_frames, frame_shift_in_seconds, final_relative_cost):
+    """EndpointDetected on plain numbers (online2/online-endpoint.cc:46-68)"""
+    rc = lib().kamd_endpoint_detected(C.byref(config), int(num_frames_decoded), int(trailing_silence_frames),
+                                      float(frame_shift_in_seconds), float(final_relative_cost))
+    check(rc)
+    return bool(rc)
+
+
+def set_silence_phones(dec, tid2phone, silence_phones):
+    """tid2phone[tid] for tid in 1..num_tids (index 0 unused) = TransitionIdToPhone"""
+    tp = np.ascontiguousarray(tid2phone, np.int32)
+    sp = np.ascontiguousarray(list(silence_phones), np.int32)
+    check(lib().kamd_decoder_set_silence_phones(dec, abi.iptr(tp), tp.size - 1, abi.iptr(sp), sp.size))
+
+
+def trailing_silence_frames(dec, lanes):
+    """TrailingSilenceLength of these un-finalized lanes (online2/online-endpoint.cc:71-102), one launch"""
+    ln = np.ascontiguousarray(lanes, np.int32)
+    out = np.zeros(ln.size, np.int32)
+    check(lib().kamd_decoder_trailing_silence_frames(dec, abi.iptr(ln), ln.size, abi.iptr(out)))
+    return out
+
+
+def endpoint_detected(dec, config, lanes, frame_shift_in_seconds):
+    """EndpointDetected(config, tmodel, frame_shift, decoder) for these lanes -> (flags, trailing silence frames)"""
+    ln = np.ascontiguousarray(lanes, np.int32)
+    det, sil = np.zeros(ln.size, np.int32), np.zeros(ln.size, np.int32)
+    check(lib().kamd_decoder_endpoint_detected(dec, C.byref(config), abi.iptr(ln), ln.size, float(frame_shift_in_seconds),
+                                               abi.iptr(det), abi.iptr(sil)))
+    return det.astype(bool), sil
+
+
 def get_trace(dec, lane):
     n = lib().kamd_decoder_num_frames_decoded(dec, lane)
     nt, cu, of = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32)

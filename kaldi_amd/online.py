@@ -127,27 +127,34 @@ class SingleUtteranceNnet3Decoder:
     def GetRawLattice(self):
         return self.decoder.GetRawLattice()
 
-    # ---- endpointing (online2/online-nnet3-decoding.cc:88-97, online2/online-endpoint.cc:94-128)
+    # ---- endpointing (online2/online-nnet3-decoding.cc:88-97, online2/online-endpoint.cc:71-121)
     def TrailingSilenceLength(self, tid2phone, silence_phones):
-        """Frames of silence at the end of the current best path (BestPathEnd without final-probs,
-        traced back until the first non-silence phone).  tid2phone[tid] =
-        TransitionModel::TransitionIdToPhone(tid)."""
-        return trailing_silence_length(self.decoder.GetBestPath(use_final_probs=False), tid2phone, silence_phones)
+        """Frames of silence at the end of the current best path (BestPathEnd without final-probs, traced back on
+        the device until the first non-silence phone).  tid2phone[tid] = TransitionModel::TransitionIdToPhone(tid)."""
+        _set_silence(self.decoder, tid2phone, silence_phones)
+        return int(decoder.trailing_silence_frames(self.decoder._dec, [self.decoder.lane])[0])
 
     def EndpointDetected(self, config, tid2phone, silence_phones, frame_shift_in_seconds=None):
         """frame_shift_in_seconds: of a DECODED frame (feature shift x frame-subsampling-factor,
         online-nnet3-decoding.cc:93-95)."""
         if frame_shift_in_seconds is None:
             frame_shift_in_seconds = 0.01 * lib().kamd_nnet_frame_subsampling_factor(self.nnet._h)
-        n = self.decoder.NumFramesDecoded()
-        if n == 0:
-            return False
-        return endpoint_detected(config, n, self.TrailingSilenceLength(tid2phone, silence_phones),
-                                 frame_shift_in_seconds, self.decoder.FinalRelativeCost())
+        _set_silence(self.decoder, tid2phone, silence_phones)
+        det, _ = decoder.endpoint_detected(self.decoder._dec, config.to_c(), [self.decoder.lane], frame_shift_in_seconds)
+        return bool(det[0])
+
+
+def _set_silence(dec, tid2phone, silence_phones):
+    """kamd_decoder_set_silence_phones once per (table, phone list)"""
+    key = (id(tid2phone), tuple(int(p) for p in silence_phones))
+    if getattr(dec, "_silence_key", None) != key:
+        decoder.set_silence_phones(dec._dec, tid2phone, key[1])
+        dec._silence_key = key
+        dec._silence_tbl = tid2phone           # keeps id() stable
 
 
 class OnlineEndpointRule:
-    """online2/online-endpoint.h:87-100."""
+    """online2/online-endpoint.h:113-143."""
 
     def __init__(self, must_contain_nonsilence=True, min_trailing_silence=1.0, max_relative_cost=float("inf"),
                  min_utterance_length=0.0):
@@ -158,7 +165,7 @@ class OnlineEndpointRule:
 
 
 class OnlineEndpointConfig:
-    """online2/online-endpoint.h:128-157, same five default rules."""
+    """online2/online-endpoint.h:145-170, same five default rules."""
 
     def __init__(self):
         inf = float("inf")
@@ -168,27 +175,25 @@ class OnlineEndpointConfig:
         self.rule4 = OnlineEndpointRule(True, 2.0, inf, 0.0)
         self.rule5 = OnlineEndpointRule(False, 0.0, inf, 20.0)
 
-
-def _rule_activated(rule, trailing_silence, relative_cost, utterance_length):
-    contains_nonsilence = utterance_length > trailing_silence            # online-endpoint.cc:30
-    return ((contains_nonsilence or not rule.must_contain_nonsilence)
-            and trailing_silence >= rule.min_trailing_silence
-            and relative_cost <= rule.max_relative_cost
-            and utterance_length >= rule.min_utterance_length)
+    def to_c(self):
+        c = abi.EndpointConfig()
+        for i, r in enumerate((self.rule1, self.rule2, self.rule3, self.rule4, self.rule5)):
+            c.rule[i] = abi.EndpointRule(int(bool(r.must_contain_nonsilence)), r.min_trailing_silence, r.max_relative_cost,
+                                         r.min_utterance_length)
+        return c
 
 
 def endpoint_detected(config, num_frames_decoded, trailing_silence_frames, frame_shift_in_seconds,
                       final_relative_cost):
-    """EndpointDetected (online2/online-endpoint.cc:44-72)."""
-    assert num_frames_decoded >= trailing_silence_frames
-    utterance_length = num_frames_decoded * frame_shift_in_seconds
-    trailing_silence = trailing_silence_frames * frame_shift_in_seconds
-    return any(_rule_activated(r, trailing_silence, final_relative_cost, utterance_length)
-               for r in (config.rule1, config.rule2, config.rule3, config.rule4, config.rule5))
+    """EndpointDetected on plain numbers (online2/online-endpoint.cc:46-68): kamd_endpoint_detected, BaseFloat
+    arithmetic like the reference's."""
+    return decoder.endpoint_detected_from(config.to_c(), num_frames_decoded, trailing_silence_frames,
+                                          frame_shift_in_seconds, final_relative_cost)
 
 
 def trailing_silence_length(best_path, tid2phone, silence_phones):
-    """TrailingSilenceLength (online2/online-endpoint.cc:74-110) on a best-path alignment."""
+    """TrailingSilenceLength (online2/online-endpoint.cc:71-102) restated on a best-path alignment (host; the
+    decoders use kamd_decoder_trailing_silence_frames, which stops walking at the first non-silence frame)."""
     if best_path is None:
         return 0
     sil = set(int(p) for p in silence_phones)
@@ -271,6 +276,13 @@ class StreamBatch:
 
     def partial_best_path(self, stream, use_final_probs=False):
         return decoder.partial_best_path(self.dec._dec, int(stream), use_final_probs)
+
+    def endpoint_detected(self, config, streams, tid2phone, silence_phones, frame_shift_in_seconds=None):
+        """EndpointDetected for these streams in one launch -> (flags, trailing silence frames)"""
+        if frame_shift_in_seconds is None:
+            frame_shift_in_seconds = self.feat.opts.frame.frame_shift_ms * 1e-3 * lib().kamd_nnet_frame_subsampling_factor(self.nnet._h)
+        _set_silence(self.dec, tid2phone, silence_phones)
+        return decoder.endpoint_detected(self.dec._dec, config.to_c(), streams, frame_shift_in_seconds)
 
     def finalize(self, streams):
         s = np.ascontiguousarray(streams, np.int32)

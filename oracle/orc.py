@@ -74,6 +74,8 @@ def lib():
         L.orc_decoder_num_toks.argtypes = [C.c_void_p]
         L.orc_decoder_final_relative_cost.argtypes = [C.c_void_p]
         L.orc_decoder_final_relative_cost.restype = C.c_float
+        L.orc_endpoint_detected.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_float]
+        L.orc_trailing_silence_length.argtypes = [ip, C.c_int, ip, ip, C.c_int]
         L.orc_decoder_lattice_size.argtypes = [C.c_void_p, C.POINTER(abi.LatticeSize)]
         L.orc_decoder_get_raw_lattice.argtypes = [C.c_void_p, ip, ip, fp, fp, C.c_void_p]
         L.orc_lattice_best_path.argtypes = [C.c_int, C.c_int, fp, C.c_int, C.c_void_p, ip, C.c_int,
@@ -342,3 +344,17 @@ class Decoder:
         c = np.zeros(8, np.int64)
         lib().orc_decoder_get_counters(self._h, abi.iptr(c, C.c_int64))
         return c
+
+
+def endpoint_detected(rules, num_frames_decoded, trailing_silence_frames, frame_shift_in_seconds, final_relative_cost):
+    """rules: 5 x (must_contain_nonsilence, min_trailing_silence, max_relative_cost, min_utterance_length)"""
+    r = np.ascontiguousarray(rules, np.float32).reshape(5, 4)
+    return bool(lib().orc_endpoint_detected(abi.fptr(r), int(num_frames_decoded), int(trailing_silence_frames),
+                                            float(frame_shift_in_seconds), float(final_relative_cost)))
+
+
+def trailing_silence_length(alignment, tid2phone, silence_phones):
+    a = np.ascontiguousarray(alignment, np.int32)
+    tp = np.ascontiguousarray(tid2phone, np.int32)
+    sp = np.ascontiguousarray(list(silence_phones), np.int32)
+    return lib().orc_trailing_silence_length(abi.iptr(a), a.size, abi.iptr(tp), abi.iptr(sp), sp.size)

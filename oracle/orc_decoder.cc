@@ -790,4 +790,34 @@ int orc_decoder_get_trace(orc_decoder *d, int32_t *ntok, float *cutoff, float *c
 }
 void orc_decoder_get_counters(orc_decoder *d, int64_t c[8]) { memcpy(c, d->counters, 64); }
 
+// ---- endpointing (online2/online-endpoint.{h,cc}), BaseFloat arithmetic
+// rules[5][4] = {must_contain_nonsilence, min_trailing_silence, max_relative_cost, min_utterance_length}
+int orc_endpoint_detected(const float *rules, int num_frames_decoded, int trailing_silence_frames,
+                          float frame_shift_in_seconds, float final_relative_cost) {
+  float utterance_length = num_frames_decoded * frame_shift_in_seconds,        // online-endpoint.cc:53-54
+        trailing_silence = trailing_silence_frames * frame_shift_in_seconds;
+  for (int r = 0; r < 5; r++) {                                                 // RuleActivated, :25-44
+    const float *R = rules + 4 * r;
+    bool contains_nonsilence = (utterance_length > trailing_silence);
+    bool ans = (contains_nonsilence || R[0] == 0.0f) && trailing_silence >= R[1] &&
+               final_relative_cost <= R[2] && utterance_length >= R[3];
+    if (ans) return 1;
+  }
+  return 0;
+}
+// TrailingSilenceLength (:71-102) given the best path's transition-ids in time order (the iterator walks them
+// backwards, skipping epsilon arcs): count silence phones from the end, stop at the first other phone.
+int orc_trailing_silence_length(const int32_t *alignment, int n, const int32_t *tid2phone,
+                                const int32_t *silence_phones, int n_sil) {
+  int num_silence_frames = 0;
+  for (int i = n - 1; i >= 0; i--) {
+    int phone = tid2phone[alignment[i]];
+    bool is_sil = false;
+    for (int k = 0; k < n_sil; k++) is_sil = is_sil || silence_phones[k] == phone;
+    if (!is_sil) break;
+    num_silence_frames++;
+  }
+  return num_silence_frames;
+}
+
 }  // extern "C"

@@ -257,6 +257,23 @@ int main(int argc, char **argv) {
       SingleUtteranceNnet3Decoder sdec(config, id2pdf, am, fst, mo, &sz);
       const size_t chunk = 2880;
       int partials = 0;
+      // endpointing: options through ParseOptions like online2-wav-nnet3-latgen-faster; every unit counts as silence
+      // here (the walk goes all the way back; the stop at the first non-silence frame is covered by test_gpu_online.py)
+      OnlineEndpointConfig ep;
+      std::vector<int32> tid2phone(id2pdf.size(), 0);
+      for (size_t t = 1; t < tid2phone.size(); t++) tid2phone[t] = static_cast<int32>((t - 1) / 2 + 1);
+      std::string sil;
+      for (int32 p = 1; p <= tid2phone.back(); p++)
+        sil += (sil.empty() ? "" : ":") + std::to_string(p);
+      {
+        ParseOptions epo("endpoint options");
+        ep.Register(&epo);
+        const std::string a1 = "--endpoint.silence-phones=" + sil;
+        const char *eargv[] = {"x", a1.c_str(), "--endpoint.rule3.min-trailing-silence=0.03", "--endpoint.rule3.max-relative-cost=inf",
+                               "--endpoint.rule2.must-contain-nonsilence=false", "--endpoint.rule2.max-relative-cost=inf"};
+        epo.Read(6, eargv);
+      }
+      std::string ep_flags, ep_sil;
       for (size_t i = 0; i < wave.size(); i += chunk) {
         std::vector<float> part(wave.begin() + i, wave.begin() + std::min(wave.size(), i + chunk));
         sdec.AcceptWaveform(16000.0f, part);
@@ -264,7 +281,14 @@ int main(int argc, char **argv) {
         sdec.AdvanceDecoding();
         std::vector<int32> ali, words; BaseFloat g, a;
         if (sdec.NumFramesDecoded() > 0 && sdec.GetBestPath(false, &ali, &words, &g, &a)) partials++;
+        std::vector<int32> det, tsf;
+        EndpointDetected(ep, tid2phone, 0.03f, sdec.Decoder().Handle(), std::vector<int32>(1, 0), &det, &tsf);
+        if (det[0] != (sdec.EndpointDetected(ep, tid2phone) ? 1 : 0)) throw KaldiFatalError("the two endpointing calls disagree");
+        ep_flags += (ep_flags.empty() ? "" : ",") + std::to_string(det[0]);
+        ep_sil += (ep_sil.empty() ? "" : ",") + std::to_string(tsf[0]);
       }
+      printf("endpoint flags=%s silence=%s plain=%d%d\n", ep_flags.c_str(), ep_sil.c_str(), EndpointDetected(ep, 100, 17, 0.03f, 1.9f) ? 1 : 0,
+             EndpointDetected(ep, 100, 1, 0.03f, 9.0f) ? 1 : 0);
       sdec.FinalizeDecoding();
       std::vector<int32> ali, words; BaseFloat g = 0, a = 0;
       const bool ok = sdec.GetBestPath(true, &ali, &words, &g, &a);

@@ -153,6 +153,26 @@ def test_cxx_host_api(tmp_path):
     assert srow.startswith("streaming ok=1 frames=%d partials=1 " % off.NumFramesDecoded())
     assert srow.endswith("words=" + ",".join(str(w) for w in ob["words"]))
     assert abs(float(srow.split("graph=")[1].split()[0]) - ob["graph_cost"]) < 1e-3
+    # endpointing through the C++ mirror == the Python mirror on the same chunking
+    from kaldi_amd import online
+    ep = online.OnlineEndpointConfig()
+    ep.rule3.min_trailing_silence = 0.03; ep.rule3.max_relative_cost = float("inf"); ep.rule2.must_contain_nonsilence = False
+    tid2phone = np.concatenate([[0], np.arange(len(g.tid2pdf) - 1) // 2 + 1]).astype(np.int32)
+    sil = list(range(1, int(tid2phone.max()) + 1))
+    ep.rule2.max_relative_cost = float("inf")
+    sd = online.SingleUtteranceNnet3Decoder(abi.mfcc_opts_hires(), decoder.Nnet(m), decoder.Graph(g), abi.decoder_config_recipe())
+    flags, sils = [], []
+    for i in range(0, wave.size, 2880):
+        sd.AcceptWaveform(16000, wave[i:i + 2880])
+        if i + 2880 >= wave.size:
+            sd.InputFinished()
+        sd.AdvanceDecoding()
+        flags.append(int(sd.EndpointDetected(ep, tid2phone, sil)))
+        sils.append(sd.TrailingSilenceLength(tid2phone, sil) if sd.NumFramesDecoded() else 0)
+    erow = [l for l in out if l.startswith("endpoint ")][0]
+    assert erow == "endpoint flags=%s silence=%s plain=%d%d" % (",".join(map(str, flags)), ",".join(map(str, sils)),
+                                                               online.endpoint_detected(ep, 100, 17, 0.03, 1.9), online.endpoint_detected(ep, 100, 1, 0.03, 9.0))
+    assert 0 < sum(flags) and len(set(sils)) > 1, (flags, sils)
     clat = open(tmp_path / "clat.ark", "rb").read()
     assert clat.startswith(b"utt-det ") and clat[8] == 214 and b"compactlattice44" in clat[:64]
     assert bp["words"].tolist() == words

@@ -298,6 +298,21 @@ def test_online2_wav_nnet3_latgen_faster_tool(tmp_path):
     assert outs[0] == outs[1]
     got = {k: latbin.best_path(l)[0] for k, l in latbin.read_lattices("ark:%s" % (tmp_path / "lat1.ark"))}
     assert list(got) == ["a1", "a2", "b1"]
+    # --do-endpointing: the decision is per stream (one traceback launch per tick for the whole batch), so the
+    # batch size does not matter; with most phones called silence some utterance ends before its audio does
+    frames_full = {k: len(latbin.best_path(l)[1]) for k, l in latbin.read_lattices("ark:%s" % (tmp_path / "lat1.ark"))}
+    ends = []
+    for batch in (1, 3):
+        lat = tmp_path / ("lat_ep%d.ark" % batch)
+        r = subprocess.run(base + ["--batch=%d" % batch, "--do-endpointing=true", "--endpoint.silence-phones=" + ":".join(str(p) for p in range(1, 21)),
+                                   "--endpoint.rule3.min-trailing-silence=0.06", "--endpoint.rule3.max-relative-cost=inf",
+                                   str(tmp_path / "final.mdl"), str(tmp_path / "HCLG.fst"), "ark:%s" % (tmp_path / "spk2utt"),
+                                   "scp:%s" % (tmp_path / "wav.scp"), "ark:%s" % lat], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "Decoded 3 utterances, 0 with errors." in r.stderr
+        ends.append({k: len(latbin.best_path(l)[1]) for k, l in latbin.read_lattices("ark:%s" % lat)})
+    assert ends[0] == ends[1]
+    assert all(ends[0][k] <= frames_full[k] for k in frames_full) and any(ends[0][k] < frames_full[k] for k in frames_full), (ends[0], frames_full)
     # direct run of the first utterance, same chunking
     g.tid2pdf = np.concatenate([[-1], np.stack([2 * np.arange(25) + 1, 2 * np.arange(25)], 1).reshape(-1)]).astype(np.int32)
     N, G = decoder.Nnet(m), decoder.Graph(g)
@@ -319,3 +334,75 @@ def test_online2_wav_nnet3_latgen_faster_tool(tmp_path):
     assert got["a2"] == w2
     _, _, slots_fresh = run(waves["a2"])
     assert np.abs(slots_adapted[-1] - slots_fresh[-1]).max() > 1e-3
+
+
+def test_endpointing_on_the_device_equals_the_oracle():
+    """EndpointDetected / TrailingSilenceLength (online2/online-endpoint.cc:71-121).  Single stream: after every
+    chunk the device's trailing-silence count and decision equal the oracle's (its decoder fed the same rows: best
+    path without final-probs, walked back; FinalRelativeCost; the five rules).  Batch: one launch for all streams
+    gives what each stream's own partial best path gives."""
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=3.0)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    num_tids = len(g.tid2pdf) - 1
+    tid2phone = np.concatenate([[0], (np.arange(num_tids) // 2) + 1]).astype(np.int32)   # self-loop + forward tid per unit
+    n_phones = int(tid2phone.max())
+    sil = [p for p in range(1, n_phones + 1) if p % 3 != 0]            # 2/3 of the units count as silence
+    ep = online.OnlineEndpointConfig()
+    ep.rule2.min_trailing_silence = 0.09; ep.rule2.max_relative_cost = 30.0      # reachable within 3 s of noise
+    ep.rule3.min_trailing_silence = 0.06; ep.rule3.max_relative_cost = float("inf")
+    rules = [[float(r.must_contain_nonsilence), r.min_trailing_silence, r.max_relative_cost, r.min_utterance_length]
+             for r in (ep.rule1, ep.rule2, ep.rule3, ep.rule4, ep.rule5)]
+    sz = abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512)
+    w = synth.make_wave(2.9, seed=9)
+    s = online.SingleUtteranceNnet3Decoder(op, N, G, cfg, sizes=sz)
+    s.record_loglikes()
+    assert not s.EndpointDetected(ep, tid2phone, sil)                  # nothing decoded yet (:110)
+    seen, fired = set(), 0
+    for i in range(0, w.size, CHUNK):
+        s.AcceptWaveform(16000, w[i:i + CHUNK])
+        if not s.AdvanceDecoding():
+            continue
+        o = orc.Decoder(g, cfg, 1)
+        o.InitDecoding()
+        o.AdvanceDecoding(s.loglikes())
+        lat = o.GetRawLattice()
+        lat.final[:] = np.where(lat.frame == lat.num_frames, 0.0, np.inf).astype(np.float32)   # use_final_probs = false
+        want_sil = orc.trailing_silence_length(lat.best_path()["alignment"], tid2phone, sil)
+        got_sil = s.TrailingSilenceLength(tid2phone, sil)
+        assert got_sil == want_sil, (i, got_sil, want_sil)
+        want = orc.endpoint_detected(rules, o.NumFramesDecoded(), want_sil, 0.03, o.FinalRelativeCost())
+        assert s.EndpointDetected(ep, tid2phone, sil) == want
+        seen.add(want_sil); fired += int(want)
+    assert len(seen) >= 3 and 0 < fired                                # the counts vary and some rule fires
+    s.InputFinished(); s.AdvanceDecoding(); s.FinalizeDecoding()
+    with pytest.raises(Exception):                                     # BestPathEnd: finalized && !use_final_probs is an error
+        s.TrailingSilenceLength(tid2phone, sil)
+
+    S = 4
+    sb = online.StreamBatch(op, N, G, cfg, S, max_seconds=6.0, sizes=abi.DecoderSizes(S, 1 << 14, 1 << 19, 1 << 20, 512))
+    waves = [synth.make_wave(d, seed=40 + k) for k, d in enumerate([2.1, 1.2, 2.6, 0.9])]
+    sb.start(np.arange(S))
+    pos = [0] * S
+    rng = np.random.default_rng(3)
+    checked = 0
+    while any(pos[k] < waves[k].size for k in range(S)):
+        live = [k for k in range(S) if pos[k] < waves[k].size]
+        for k in live:
+            n = int(rng.integers(1500, 5000))
+            sb.accept(k, waves[k][pos[k]:pos[k] + n], input_finished=False)
+            pos[k] += n
+        nd = sb.advance(live)
+        cand = [k for k, d in zip(live, nd) if d > 0]
+        if not cand:
+            continue
+        flags, sil_frames = sb.endpoint_detected(ep, cand, tid2phone, sil)
+        for k, f, t in zip(cand, flags, sil_frames):
+            bp = sb.partial_best_path(k, use_final_probs=False)
+            want_sil = orc.trailing_silence_length(bp["alignment"], tid2phone, sil)
+            assert t == want_sil
+            frc = decoder.lib().kamd_decoder_final_relative_cost(sb.dec._dec, k)
+            assert bool(f) == orc.endpoint_detected(rules, len(bp["alignment"]), want_sil, 0.03, frc)
+            checked += 1
+    assert checked >= 8

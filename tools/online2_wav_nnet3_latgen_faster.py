@@ -120,17 +120,19 @@ def main(argv):
                 a["pos"] += piece.size
                 sb.accept(s, piece, input_finished=a["pos"] >= a["wave"].size)
             decoded = sb.advance(live)
+            endpointed = set()
+            if po["do-endpointing"]:                       # one traceback launch for every stream still listening
+                cand = [s for s, nd in zip(live, decoded) if nd > 0 and active[s]["pos"] < active[s]["wave"].size]
+                if cand:
+                    flags, _ = sb.endpoint_detected(ep, cand, model.tid2phone, sil, frame_shift)
+                    endpointed = {s for s, f in zip(cand, flags) if f}
             for s, nd in zip(live, decoded):
                 a = active[s]
                 ended = a["pos"] >= a["wave"].size
-                if not ended and po["do-endpointing"] and nd > 0:
-                    bp = sb.partial_best_path(s, use_final_probs=False)
-                    trailing = online.trailing_silence_length(bp, model.tid2phone, sil)
-                    frc = lib().kamd_decoder_final_relative_cost(sb.dec._dec, s)
-                    if online.endpoint_detected(ep, int(nd), trailing, frame_shift, frc):
-                        sb.accept(s, np.zeros(0, np.float32), input_finished=True)
-                        sb.advance([s])
-                        ended = True
+                if s in endpointed:
+                    sb.accept(s, np.zeros(0, np.float32), input_finished=True)
+                    sb.advance([s])
+                    ended = True
                 if ended:
                     sb.finalize([s])
                     bp = sb.best_path(s)
