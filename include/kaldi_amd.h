@@ -441,6 +441,10 @@ int kamd_cmvn_acc_stats_device(const float *d_feats, const int64_t *h_row_off, i
  * binary does; norm_vars without norm_means is an error (featbin/apply-cmvn.cc:63-64). */
 int kamd_cmvn_apply_device(float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts,
                            const double *h_stats, int norm_means, int norm_vars, void *stream);
+/* apply-cmvn --reverse: ApplyCmvnReverse (transform/cmvn.cc:120-168), same arguments: zero-mean (unit-variance)
+ * features get the statistics' mean (and variance) back. */
+int kamd_cmvn_apply_reverse_device(float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts,
+                           const double *h_stats, int norm_means, int norm_vars, void *stream);
 
 /* --------------------------------------------------- online i-vector extraction -- */
 /* OnlineIvectorFeature as ivector-extract-online2 drives it (online2/online-ivector-feature.cc:

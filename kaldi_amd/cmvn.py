@@ -47,15 +47,30 @@ def acc_stats(mats, stats=None):
     return st
 
 
-def apply(mats, stats, norm_means=True, norm_vars=False):
-    """ApplyCmvn: matrix i normalised with stats[i] ([2, dim+1]); returns new matrices."""
+def fake_stats_for_some_dims(stats, dims):
+    """FakeStatsForSomeDims (transform/cmvn.cc:171-182): statistics [..., 2, dim+1] under which the listed
+    dimensions stay as they are (mean 0, variance 1) -- apply-cmvn --skip-dims"""
+    st = np.array(stats, np.float64)
+    dim = st.shape[-1] - 1
+    for d in dims:
+        if not 0 <= int(d) < dim:
+            raise KamdError("skip-dims: dimension %d out of range (feature dim %d)" % (int(d), dim))
+        st[..., 0, int(d)] = 0.0
+        st[..., 1, int(d)] = st[..., 0, dim]
+    return st
+
+
+def apply(mats, stats, norm_means=True, norm_vars=False, reverse=False, skip_dims=()):
+    """ApplyCmvn (reverse: ApplyCmvnReverse): matrix i normalised with stats[i] ([2, dim+1]); returns new matrices."""
     mats, flat, off, dim = _batch(mats)
     st = np.ascontiguousarray(stats, np.float64).reshape(len(mats), 2, dim + 1)
+    if len(skip_dims):
+        st = np.ascontiguousarray(fake_stats_for_some_dims(st, skip_dims))
     if off[-1] == 0:
         return [m.copy() for m in mats]
     d = _Dev(flat)
-    check(lib().kamd_cmvn_apply_device(d.p, abi.iptr(off, C.c_int64), dim, dim, len(mats), st.ctypes.data_as(C.POINTER(C.c_double)),
-                                       int(norm_means), int(norm_vars), None))
+    fn = lib().kamd_cmvn_apply_reverse_device if reverse else lib().kamd_cmvn_apply_device
+    check(fn(d.p, abi.iptr(off, C.c_int64), dim, dim, len(mats), st.ctypes.data_as(C.POINTER(C.c_double)), int(norm_means), int(norm_vars), None))
     out = np.zeros_like(flat)
     d.download(out)
     return [out[off[i]:off[i + 1]].copy() for i in range(len(mats))]

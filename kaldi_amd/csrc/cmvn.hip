@@ -35,8 +35,9 @@ __global__ __launch_bounds__(256) void CmvnStatsKernel(const float *feats, int l
 
 // ApplyCmvn (transform/cmvn.cc:64-118): means only: x + float(-sum / count); with variances:
 // x * float(1 / sqrt(var)) + float(-mean / sqrt(var)), var floored at 1e-20
+// reverse: ApplyCmvnReverse (:120-168): x * float(sqrt(var)) + float(mean) (zero-mean unit-variance data -> the statistics')
 __global__ __launch_bounds__(256) void CmvnApplyKernel(float *feats, int ld, int dim, const int64_t *row_off, const double *stats,
-                                                       int norm_vars, int *bad) {
+                                                       int norm_vars, int reverse, int *bad) {
   extern __shared__ float norm[];                  // offset[dim], scale[dim]
   const int u = blockIdx.y, tid = threadIdx.x;
   const int64_t r0 = row_off[u];
@@ -45,7 +46,16 @@ __global__ __launch_bounds__(256) void CmvnApplyKernel(float *feats, int ld, int
   const double count = st[dim];
   if (count < 1.0) { if (tid == 0 && blockIdx.x == 0) atomicExch(bad, u + 1); return; }   // "Insufficient stats"
   for (int k = tid; k < dim; k += 256) {
-    if (!norm_vars) { norm[k] = static_cast<float>(-1.0 / count * st[k]); norm[dim + k] = 1.0f; }
+    if (reverse) {
+      const double mean = st[k] / count;
+      double scale = 1.0;
+      if (norm_vars) {
+        double var = st[dim + 1 + k] / count - mean * mean;
+        if (var < 1.0e-20) var = 1.0e-20;
+        scale = sqrt(var);
+      }
+      norm[k] = static_cast<float>(mean); norm[dim + k] = static_cast<float>(scale);
+    } else if (!norm_vars) { norm[k] = static_cast<float>(-1.0 / count * st[k]); norm[dim + k] = 1.0f; }
     else {
       const double mean = st[k] / count;
       double var = st[dim + 1 + k] / count - mean * mean;
@@ -232,8 +242,8 @@ int kamd_cmvn_acc_stats_device(const float *d_feats, const int64_t *h_row_off, i
   return rc;
 }
 
-int kamd_cmvn_apply_device(float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, const double *h_stats,
-                           int norm_means, int norm_vars, void *stream) {
+static int CmvnApply(float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, const double *h_stats,
+                     int norm_means, int norm_vars, int reverse, void *stream) {
   if (!kamd::RequireDevice()) return KAMD_ERR_HIP;
   if (n_utts <= 0) return KAMD_OK;
   if (dim <= 0 || ld < dim) return kamd::SetError(KAMD_ERR_ARG, "cmvn: bad feature dim / leading dimension");
@@ -253,7 +263,7 @@ int kamd_cmvn_apply_device(float *d_feats, const int64_t *h_row_off, int ld, int
     rc = kamd::SetError(KAMD_ERR_HIP, "cmvn: upload failed");
   if (rc == KAMD_OK && max_T > 0) {
     hipLaunchKernelGGL(kamd::CmvnApplyKernel, dim3(kamd::CeilDiv(max_T, 64), n_utts), dim3(256), 2 * dim * sizeof(float), st, d_feats, ld, dim,
-                       d_off, d_stats, norm_vars, d_bad);
+                       d_off, d_stats, norm_vars, reverse, d_bad);
     if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       rc = kamd::SetError(KAMD_ERR_HIP, "cmvn: apply kernel failed: %s", hipGetErrorString(hipGetLastError()));
   }
@@ -261,6 +271,15 @@ int kamd_cmvn_apply_device(float *d_feats, const int64_t *h_row_off, int ld, int
   if (rc == KAMD_OK && bad)
     return kamd::SetError(KAMD_ERR_ARG, "Insufficient stats for cepstral mean and variance normalization: utterance %d, count < 1", bad - 1);
   return rc;
+}
+
+int kamd_cmvn_apply_device(float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, const double *h_stats,
+                           int norm_means, int norm_vars, void *stream) {
+  return CmvnApply(d_feats, h_row_off, ld, dim, n_utts, h_stats, norm_means, norm_vars, 0, stream);
+}
+int kamd_cmvn_apply_reverse_device(float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, const double *h_stats,
+                                   int norm_means, int norm_vars, void *stream) {
+  return CmvnApply(d_feats, h_row_off, ld, dim, n_utts, h_stats, norm_means, norm_vars, 1, stream);
 }
 
 }  // extern "C"

@@ -62,6 +62,7 @@ def lib():
         L.orc_cmvn_acc_stats.argtypes = [fp, C.c_int, C.c_int, dp]
         L.orc_cmvn_acc_stats.restype = None
         L.orc_cmvn_apply.argtypes = [dp, C.c_int, fp, C.c_int, C.c_int]
+        L.orc_cmvn_apply_reverse.argtypes = [dp, C.c_int, fp, C.c_int, C.c_int]
         L.orc_decoder_create.restype = C.c_void_p
         L.orc_decoder_create.argtypes = [C.c_int32, C.c_int32, i64p, C.c_void_p, fp,
                                          C.POINTER(abi.DecoderConfig), ip, C.c_int32, C.c_int]
@@ -245,10 +246,10 @@ def cmvn_acc_stats(feats, stats=None):
     return st
 
 
-def cmvn_apply(feats, stats, norm_vars=False):
+def cmvn_apply(feats, stats, norm_vars=False, reverse=False):
     f = np.array(feats, np.float32)
     st = np.ascontiguousarray(stats, np.float64)
-    r = lib().orc_cmvn_apply(st.ctypes.data_as(C.POINTER(C.c_double)), int(norm_vars), abi.fptr(f), f.shape[0], f.shape[1])
+    r = (lib().orc_cmvn_apply_reverse if reverse else lib().orc_cmvn_apply)(st.ctypes.data_as(C.POINTER(C.c_double)), int(norm_vars), abi.fptr(f), f.shape[0], f.shape[1])
     assert r == 0, "Insufficient stats"
     return f
 

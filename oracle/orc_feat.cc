@@ -370,6 +370,28 @@ extern "C" int orc_cmvn_apply(const double *stats, int var_norm, float *feats, i
   return 0;
 }
 
+// ApplyCmvnReverse (transform/cmvn.cc:120-168)
+extern "C" int orc_cmvn_apply_reverse(const double *stats, int var_norm, float *feats, int T, int dim) {
+  const double count = stats[dim];
+  if (count < 1.0) return -1;
+  for (int k = 0; k < dim; k++) {
+    const double mean = stats[k] / count;
+    double scale = 1.0;
+    if (var_norm) {
+      double var = stats[dim + 1 + k] / count - mean * mean;
+      if (var < 1.0e-20) var = 1.0e-20;
+      scale = sqrt(var);
+    }
+    const float offset_f = static_cast<float>(mean), scale_f = static_cast<float>(scale);
+    for (int t = 0; t < T; t++) {
+      float x = feats[static_cast<size_t>(t) * dim + k];
+      if (var_norm) x = x * scale_f;
+      feats[static_cast<size_t>(t) * dim + k] = x + offset_f;
+    }
+  }
+  return 0;
+}
+
 // ---- GMM acoustic model (test infrastructure): DecodableAmDiagGmmUnmapped::LogLikelihoodZeroBased
 // (gmm/decodable-am-diag-gmm.cc:27-70) with VectorBase<float>::LogSumExp(-1) (matrix/kaldi-vector.cc:760-778), times
 // the scale of DecodableAmDiagGmmScaled.  PARITY UNPINNED (no GMM model or features in the tree).

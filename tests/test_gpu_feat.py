@@ -89,6 +89,24 @@ def test_cmvn_stats_and_apply_match_the_oracle(tmp_path):
         got = cmvn.apply(mats[1:], [orc.cmvn_acc_stats(m) for m in mats[1:]], norm_vars=nv)
         for m, g in zip(mats[1:], got):
             np.testing.assert_array_equal(g, orc.cmvn_apply(m, orc.cmvn_acc_stats(m), nv))
+    # --reverse (ApplyCmvnReverse) and --skip-dims (FakeStatsForSomeDims): bit-equal to the oracle; skipped dimensions
+    # come out untouched without variance normalisation, and reverse undoes forward up to rounding
+    for nv in (False, True):
+        stats = [orc.cmvn_acc_stats(m) for m in mats[1:]]
+        rev = cmvn.apply(mats[1:], stats, norm_vars=nv, reverse=True)
+        for m, s1, g in zip(mats[1:], stats, rev):
+            np.testing.assert_array_equal(g, orc.cmvn_apply(m, s1, nv, reverse=True))
+        back = cmvn.apply(cmvn.apply(mats[1:], stats, norm_vars=nv), stats, norm_vars=nv, reverse=True)
+        for m, b in zip(mats[1:], back):
+            np.testing.assert_allclose(b, m, atol=2e-5 * np.abs(m).max())
+        sk = cmvn.apply(mats[1:], stats, norm_vars=nv, skip_dims=[0, 5, 12])
+        for m, s1, g in zip(mats[1:], stats, sk):
+            np.testing.assert_array_equal(g, orc.cmvn_apply(m, cmvn.fake_stats_for_some_dims(s1, [0, 5, 12]), nv))
+            if not nv:
+                np.testing.assert_array_equal(g[:, [0, 5, 12]], m[:, [0, 5, 12]])
+            assert np.abs(g[:, 1] - m[:, 1]).max() > 0.1
+    with pytest.raises(Exception):
+        cmvn.apply(mats[1:2], [orc.cmvn_acc_stats(mats[1])], skip_dims=[13])
     same = cmvn.apply(mats, st, norm_means=False)
     for m, g in zip(mats, same):
         np.testing.assert_array_equal(m, g)
@@ -113,6 +131,15 @@ def test_cmvn_stats_and_apply_match_the_oracle(tmp_path):
         r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1500:]
     out = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "out.ark"), "matrix"))
+    r = subprocess.run([sys.executable, root + "/tools/apply_cmvn.py", "--norm-vars=true", "--reverse=true", "--skip-dims=1:2",
+                        "--utt2spk=ark:%s" % (tmp_path / "utt2spk"), "ark:%s" % (tmp_path / "cmvn.ark"), "ark:%s" % (tmp_path / "out.ark"),
+                        "ark:%s" % (tmp_path / "back.ark")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    back = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "back.ark"), "matrix"))
+    for i, m in enumerate(mats):
+        keep = [d for d in range(13) if d not in (1, 2)]
+        np.testing.assert_allclose(back["u%d" % i][:, keep], m[:, keep], atol=2e-5 * np.abs(m).max())     # reverse undoes forward
+        np.testing.assert_array_equal(back["u%d" % i][:, [1, 2]], out["u%d" % i][:, [1, 2]])               # skipped: left alone
     spkB = np.concatenate(mats[2:])
     np.testing.assert_allclose(np.concatenate([out["u2"], out["u3"]]).mean(0), 0, atol=2e-5)
     np.testing.assert_allclose(np.concatenate([out["u2"], out["u3"]]).std(0), 1, atol=1e-4)

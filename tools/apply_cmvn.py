@@ -1,7 +1,6 @@
 """apply-cmvn (featbin/apply-cmvn.cc) on the device:
-  apply_cmvn.py [--utt2spk=<rspecifier>] [--norm-means=true] [--norm-vars=false]
-                (<cmvn-stats-rspecifier>|<cmvn-stats-rxfilename>) <feats-rspecifier> <feats-wspecifier>
---reverse and --skip-dims are not supported."""
+  apply_cmvn.py [--utt2spk=<rspecifier>] [--norm-means=true] [--norm-vars=false] [--reverse=false] [--skip-dims=0:1:2]
+                (<cmvn-stats-rspecifier>|<cmvn-stats-rxfilename>) <feats-rspecifier> <feats-wspecifier>"""
 import os
 import sys
 
@@ -16,15 +15,18 @@ def main(argv):
     po.register("utt2spk", str, "", "rspecifier for utterance to speaker map")
     po.register("norm-vars", bool, False, "If true, normalize variances.")
     po.register("norm-means", bool, True, "You can set this to false to turn off mean normalization.")
-    po.register("skip-dims", str, "", "(not supported)")
-    po.register("reverse", bool, False, "(not supported)")
+    po.register("skip-dims", str, "", "Dimensions for which to skip normalization: colon-separated list of integers, e.g. 13:14:15")
+    po.register("reverse", bool, False, "If true, apply CMVN in a reverse sense, so as to transform zero-mean, unit-variance input into data "
+                "with the given mean and variance.")
     po.register("batch", int, 256, "utterances per device pass")
     args = po.read(argv)
     if len(args) != 3:
         po.print_usage()
         return 1
-    if po["skip-dims"] or po["reverse"]:
-        raise KamdError("--skip-dims / --reverse are not supported")
+    try:
+        skip = [int(x) for x in po["skip-dims"].split(":") if x != ""] if po["skip-dims"] else []
+    except ValueError:
+        raise KamdError("Bad --skip-dims option (should be colon-separated list of integers)")
     if po["norm-vars"] and not po["norm-means"]:
         raise KamdError("You cannot normalize the variance but not the mean.")
     glob = None
@@ -41,7 +43,8 @@ def main(argv):
         def flush():
             nonlocal n_done
             if batch:
-                out = cmvn.apply([m for _, m, _ in batch], [s for _, _, s in batch], po["norm-means"], po["norm-vars"])
+                out = cmvn.apply([m for _, m, _ in batch], [s for _, _, s in batch], po["norm-means"], po["norm-vars"],
+                                 reverse=po["reverse"], skip_dims=skip)
                 for (k, _, _), o in zip(batch, out):
                     w.write(k, o)
                 n_done += len(batch)
