@@ -436,6 +436,10 @@ int kamd_feat_add_deltas_device(const float *d_in, int ld_in, float *d_out, int 
  * speaker's running statistics to add an utterance to them). */
 int kamd_cmvn_acc_stats_device(const float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts,
                                double *h_stats, void *stream);
+/* compute-cmvn-stats --weights: AccCmvnStats(feats, &weights, stats) (transform/cmvn.cc:49-62); d_weights holds one
+ * float per row of the batch (device), frames of weight 0 are skipped, the count is the sum of the weights. */
+int kamd_cmvn_acc_stats_weighted_device(const float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts,
+                                        const float *d_weights, double *h_stats, void *stream);
 /* apply-cmvn: ApplyCmvn (transform/cmvn.cc:64-118) in place, utterance u with statistics h_stats[u]
  * (its own, its speaker's, or global ones).  norm_means = 0 leaves the features unchanged, as the
  * binary does; norm_vars without norm_means is an error (featbin/apply-cmvn.cc:63-64). */

@@ -36,14 +36,23 @@ def _batch(mats):
     return mats, np.ascontiguousarray(np.concatenate(mats) if off[-1] else np.zeros((0, dim), np.float32)), off, dim
 
 
-def acc_stats(mats, stats=None):
-    """AccCmvnStats for every matrix; stats (optional): [n, 2, dim+1] running statistics to add to."""
+def acc_stats(mats, stats=None, weights=None):
+    """AccCmvnStats for every matrix; stats (optional): [n, 2, dim+1] running statistics to add to; weights (optional):
+    one float vector per matrix, a weight per frame (compute-cmvn-stats --weights)."""
     mats, flat, off, dim = _batch(mats)
     st = np.zeros((len(mats), 2, dim + 1), np.float64) if stats is None else np.array(stats, np.float64).reshape(len(mats), 2, dim + 1)
     if off[-1] == 0:
         return st
     d = _Dev(flat)
-    check(lib().kamd_cmvn_acc_stats_device(d.p, abi.iptr(off, C.c_int64), dim, dim, len(mats), st.ctypes.data_as(C.POINTER(C.c_double)), None))
+    if weights is None:
+        check(lib().kamd_cmvn_acc_stats_device(d.p, abi.iptr(off, C.c_int64), dim, dim, len(mats), st.ctypes.data_as(C.POINTER(C.c_double)), None))
+        return st
+    weights = [np.ascontiguousarray(w, np.float32).reshape(-1) for w in weights]
+    if len(weights) != len(mats) or any(w.size != m.shape[0] for w, m in zip(weights, mats)):
+        raise KamdError("cmvn: one weight per frame is needed (weights->Dim() == num_frames)")
+    dw = _Dev(np.ascontiguousarray(np.concatenate(weights)))
+    check(lib().kamd_cmvn_acc_stats_weighted_device(d.p, abi.iptr(off, C.c_int64), dim, dim, len(mats), dw.p,
+                                                    st.ctypes.data_as(C.POINTER(C.c_double)), None))
     return st
 
 

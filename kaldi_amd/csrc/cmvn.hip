@@ -8,28 +8,34 @@
 namespace kamd {
 
 // stats[u] = [2][dim + 1] doubles: row 0 sums and (last column) the count, row 1 sums of squares
-__global__ __launch_bounds__(256) void CmvnStatsKernel(const float *feats, int ld, int dim, const int64_t *row_off, double *stats) {
-  __shared__ double s1[256], s2[256];
+// weights (optional, one per row of the batch): AccCmvnStats(frame, weight, stats) for frames of non-zero weight (:49-62)
+__global__ __launch_bounds__(256) void CmvnStatsKernel(const float *feats, int ld, int dim, const int64_t *row_off, const float *weights,
+                                                       double *stats) {
+  __shared__ double s1[256], s2[256], s3[256];
   const int u = blockIdx.x, tid = threadIdx.x;
   const int64_t r0 = row_off[u];
   const int T = static_cast<int>(row_off[u + 1] - r0);
   int dpw = 1;
   while (dpw < dim) dpw <<= 1;
   const int chunks = 256 / dpw, k = tid % dpw, c = tid / dpw;
-  double a = 0, b = 0;
+  double a = 0, b = 0, cnt = 0;
   if (k < dim)
     for (int t = c; t < T; t += chunks) {
       const float x = feats[(r0 + t) * ld + k];
-      a += static_cast<double>(x);                 // AccCmvnStats: *mean_ptr += *feats_ptr * weight, weight = 1
-      b += static_cast<double>(x * x);             //               *var_ptr += *feats_ptr * *feats_ptr * weight (float product)
+      const float w = weights ? weights[r0 + t] : 1.0f;
+      if (w != 0.0f) {
+        a += static_cast<double>(x * w);             // AccCmvnStats: *mean_ptr += *feats_ptr * weight (float product)
+        b += static_cast<double>(x * x * w);         //               *var_ptr += *feats_ptr * *feats_ptr * weight
+        cnt += static_cast<double>(w);               //               *count_ptr += weight
+      }
     }
-  s1[tid] = a; s2[tid] = b;
+  s1[tid] = a; s2[tid] = b; s3[tid] = cnt;
   __syncthreads();
   if (c == 0 && k < dim) {
-    for (int c2 = 1; c2 < chunks; c2++) { a += s1[c2 * dpw + k]; b += s2[c2 * dpw + k]; }
+    for (int c2 = 1; c2 < chunks; c2++) { a += s1[c2 * dpw + k]; b += s2[c2 * dpw + k]; cnt += s3[c2 * dpw + k]; }
     double *o = stats + static_cast<size_t>(u) * 2 * (dim + 1);
     o[k] += a; o[dim + 1 + k] += b;
-    if (k == 0) o[dim] += static_cast<double>(T);
+    if (k == 0) o[dim] += cnt;
   }
 }
 
@@ -219,8 +225,8 @@ int kamd_feat_add_deltas_device(const float *d_in, int ld_in, float *d_out, int 
   return rc;
 }
 
-int kamd_cmvn_acc_stats_device(const float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, double *h_stats,
-                               void *stream) {
+static int CmvnAccStats(const float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, const float *d_weights, double *h_stats,
+                        void *stream) {
   if (!kamd::RequireDevice()) return KAMD_ERR_HIP;
   if (n_utts <= 0) return KAMD_OK;
   if (dim <= 0 || dim > 256 || ld < dim) return kamd::SetError(KAMD_ERR_ARG, "cmvn: bad feature dim / leading dimension");
@@ -234,12 +240,22 @@ int kamd_cmvn_acc_stats_device(const float *d_feats, const int64_t *h_row_off, i
       hipMemcpyAsync(d_off, h_row_off, (n_utts + 1) * sizeof(int64_t), hipMemcpyHostToDevice, st) != hipSuccess)
     rc = kamd::SetError(KAMD_ERR_HIP, "cmvn: upload failed");
   if (rc == KAMD_OK) {
-    hipLaunchKernelGGL(kamd::CmvnStatsKernel, dim3(n_utts), dim3(256), 0, st, d_feats, ld, dim, d_off, d_stats);
+    hipLaunchKernelGGL(kamd::CmvnStatsKernel, dim3(n_utts), dim3(256), 0, st, d_feats, ld, dim, d_off, d_weights, d_stats);
     if (hipMemcpyAsync(h_stats, d_stats, n * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
       rc = kamd::SetError(KAMD_ERR_HIP, "cmvn: statistics kernel failed: %s", hipGetErrorString(hipGetLastError()));
   }
   (void)hipFree(d_stats); (void)hipFree(d_off);
   return rc;
+}
+
+int kamd_cmvn_acc_stats_device(const float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, double *h_stats,
+                               void *stream) {
+  return CmvnAccStats(d_feats, h_row_off, ld, dim, n_utts, NULL, h_stats, stream);
+}
+int kamd_cmvn_acc_stats_weighted_device(const float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, const float *d_weights,
+                                        double *h_stats, void *stream) {
+  if (!d_weights) return kamd::SetError(KAMD_ERR_ARG, "cmvn: null weights");
+  return CmvnAccStats(d_feats, h_row_off, ld, dim, n_utts, d_weights, h_stats, stream);
 }
 
 static int CmvnApply(float *d_feats, const int64_t *h_row_off, int ld, int dim, int n_utts, const double *h_stats,

@@ -2069,6 +2069,7 @@ struct Decoder {
   long long *d_tok_base = NULL, *d_lnk_base = NULL; int *d_tok_cap = NULL, *d_lnk_cap = NULL;
   std::vector<long long> h_tok_base, h_lnk_base; std::vector<int> h_tok_cap, h_lnk_cap;
   hipStream_t last_stream = NULL;
+  void *d_path = NULL; int path_cap = 0;   // partial best path: {n, final cost, pad} + arcs
   unsigned char *d_sil_tid = NULL; int n_sil_tids = 0; int *d_sil_out = NULL; int sil_out_cap = 0;   // endpointing
   // host copy of one lane's lattice (canonical), cached by lane
   int cached_lane = -1;
@@ -2283,6 +2284,7 @@ void kamd_decoder_destroy(kamd_decoder *h) {
   Decoder *D = reinterpret_cast<Decoder *>(h);
   if (!D) return;
   for (size_t i = 0; i < D->allocs.size(); i++) (void)hipFree(D->allocs[i]);
+  if (D->d_path) (void)hipFree(D->d_path);
   if (D->d_sil_tid) (void)hipFree(D->d_sil_tid);
   if (D->d_sil_out) (void)hipFree(D->d_sil_out);
   if (D->d_lanes) (void)hipFree(D->d_lanes);
@@ -2454,18 +2456,27 @@ int kamd_decoder_partial_best_path(kamd_decoder *h, int lane, int use_final_prob
   if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
   if (D->h_st[lane].finalized) return kamd::SetError(KAMD_ERR_STATE, "lane %d is finalized: use kamd_decoder_best_path", lane);
   const int cap = 4 * (D->h_st[lane].frame + 2) + 1024;
-  kamd::PathArc *d_arcs = NULL; int *d_n = NULL; float *d_fc = NULL;
-  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_arcs), cap * sizeof(kamd::PathArc)));
-  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_n), sizeof(int)));
-  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_fc), sizeof(float)));
-  hipLaunchKernelGGL(kamd::TracebackKernel, dim3(1), dim3(NT), 0, D->last_stream, D->dev, lane, use_final_probs, d_arcs, cap, d_n, d_fc);
-  int n = 0; float fc = 0;
-  hipError_t e1 = hipMemcpy(&n, d_n, sizeof(int), hipMemcpyDeviceToHost);
-  hipError_t e2 = hipMemcpy(&fc, d_fc, sizeof(float), hipMemcpyDeviceToHost);
+  if (cap > D->path_cap) {         // one buffer for the decoder's lifetime (a server asks for partial results every tick)
+    const int grow = std::max(cap, 2 * D->path_cap);
+    if (D->d_path) (void)hipFree(D->d_path);
+    D->d_path = NULL; D->path_cap = 0;
+    KAMD_HIP(hipMalloc(&D->d_path, 16 + static_cast<size_t>(grow) * sizeof(kamd::PathArc)));
+    D->path_cap = grow;
+  }
+  int *d_n = static_cast<int *>(D->d_path); float *d_fc = reinterpret_cast<float *>(d_n + 1);
+  kamd::PathArc *d_arcs = reinterpret_cast<kamd::PathArc *>(static_cast<char *>(D->d_path) + 16);
+  hipStream_t st = D->last_stream;
+  hipLaunchKernelGGL(kamd::TracebackKernel, dim3(1), dim3(NT), 0, st, D->dev, lane, use_final_probs, d_arcs, cap, d_n, d_fc);
+  KAMD_HIP(hipGetLastError());
+  struct { int n; float fc; } head = {0, 0.f};
+  KAMD_HIP(hipMemcpyAsync(&head, D->d_path, sizeof(head), hipMemcpyDeviceToHost, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  const int n = head.n; const float fc = head.fc;
   std::vector<kamd::PathArc> arcs(n > 0 ? std::min(n, cap) : 0);
-  hipError_t e3 = arcs.empty() ? hipSuccess : hipMemcpy(arcs.data(), d_arcs, arcs.size() * sizeof(kamd::PathArc), hipMemcpyDeviceToHost);
-  (void)hipFree(d_arcs); (void)hipFree(d_n); (void)hipFree(d_fc);
-  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) return kamd::SetError(KAMD_ERR_HIP, "traceback copy failed");
+  if (!arcs.empty()) {
+    KAMD_HIP(hipMemcpyAsync(arcs.data(), d_arcs, arcs.size() * sizeof(kamd::PathArc), hipMemcpyDeviceToHost, st));
+    KAMD_HIP(hipStreamSynchronize(st));
+  }
   *ali_len = 0; *words_len = 0; *graph_cost = INFINITY; *acoustic_cost = INFINITY;
   if (n < 0) return kamd::SetError(KAMD_ERR_STATE, "no tokens alive on the newest frame");
   float g = 0.f, a = 0.f;   // Times() along the path, start -> end (fstext/lattice-weight.h)

@@ -141,6 +141,61 @@ def _parse_vector(buf, pos):
     return np.asarray([float(x) for x in txt], np.float32), (nl + 1 if nl >= 0 else len(buf))
 
 
+def _parse_dmatrix(buf, pos):
+    """Matrix<double>::Read (matrix/kaldi-matrix.cc:1393-1580) at buf[pos:]: binary DM / FM (converted) or the text form
+    " [\n  1 2 \n  3 4 ]".  CMVN statistics travel as double matrices (DoubleMatrixWriter, compute-cmvn-stats.cc:93).
+    -> (float64 matrix, position after it)"""
+    import struct
+    if buf[pos:pos + 2] == b"\0B":
+        tok = buf[pos + 2:pos + 5]
+        if tok not in (b"FM ", b"DM ") or buf[pos + 5] != 4 or buf[pos + 10] != 4:
+            raise KamdError("matrix expected, got %r" % tok)
+        r, c = struct.unpack_from("<i", buf, pos + 6)[0], struct.unpack_from("<i", buf, pos + 11)[0]
+        w = 4 if tok == b"FM " else 8
+        m = np.frombuffer(buf, "<f4" if w == 4 else "<f8", r * c, pos + 15).astype(np.float64).reshape(r, c)
+        return m, pos + 15 + w * r * c
+    e = buf.index(b"]", pos)
+    rows = [[float(x) for x in ln.split()] for ln in buf[pos:e].decode().replace("[", " ").split("\n")]
+    rows = [r for r in rows if r]
+    if any(len(r) != len(rows[0]) for r in rows):
+        raise KamdError("text matrix with rows of different lengths")
+    nl = buf.find(b"\n", e)
+    return np.asarray(rows, np.float64).reshape(len(rows), len(rows[0]) if rows else 0), (nl + 1 if nl >= 0 else len(buf))
+
+
+def _read_dmatrix_at(path, off):
+    with open(path, "rb") as f:
+        f.seek(off)
+        return _parse_dmatrix(f.read(), 0)[0]
+
+
+def _read_dmatrix_ark(path):
+    buf = open(path, "rb").read()
+    pos = 0
+    while True:
+        while pos < len(buf) and buf[pos:pos + 1] in (b" ", b"\n"):
+            pos += 1
+        if pos >= len(buf):
+            return
+        e = buf.index(b" ", pos)
+        key = buf[pos:e].decode()
+        m, pos = _parse_dmatrix(buf, e + 1)
+        yield key, m
+
+
+def _dmatrix_bytes(m, binary):
+    """Matrix<double>::Write (matrix/kaldi-matrix.cc:1355-1391)"""
+    import struct
+    m = np.ascontiguousarray(m, np.float64)
+    if m.ndim != 2:
+        raise KamdError("matrix expected")
+    if binary:
+        return b"\0BDM \4" + struct.pack("<i", m.shape[0]) + b"\4" + struct.pack("<i", m.shape[1]) + m.tobytes()
+    if m.size == 0:
+        return b" [ ]\n"
+    return (" [" + "".join("\n  " + "".join("%.17g " % x for x in row) for row in m) + "]\n").encode()
+
+
 def _read_vector_at(path, off):
     with open(path, "rb") as f:
         f.seek(off)
@@ -169,14 +224,15 @@ def _read_token_ark(path):
             yield parts[0], parts[1:]
 
 
-_AT = {"matrix": _read_matrix_at, "int32": _read_int32_at, "wave": _read_wave_at, "vector": _read_vector_at}
+_AT = {"matrix": _read_matrix_at, "int32": _read_int32_at, "wave": _read_wave_at, "vector": _read_vector_at, "dmatrix": _read_dmatrix_at}
 _ARK = {"matrix": kio.read_matrix_ark, "int32": kio.read_int32_vector_ark, "vector": _read_vector_ark, "tokens": _read_token_ark,
+        "dmatrix": _read_dmatrix_ark,
         "lattice": lambda path: ((k, (start, final, arcs)) for k, start, final, arcs in kio.read_lattices(path))}
 
 
 class SequentialTableReader:
     """for key, value in SequentialTableReader("ark:feats.ark" | "scp:wav.scp" | "ark:gunzip -c x.gz |", kind)
-    kind: "matrix" | "vector" | "int32" | "wave" | "lattice" | "tokens" (text lines: utt2spk, spk2utt).  With the `p` (permissive) option scp entries
+    kind: "matrix" | "dmatrix" (double precision: CMVN statistics) | "vector" | "int32" | "wave" | "lattice" | "tokens" (text lines: utt2spk, spk2utt).  With the `p` (permissive) option scp entries
     that cannot be read are skipped, as the reference does; otherwise they raise."""
 
     def __init__(self, rspecifier, kind):
@@ -257,14 +313,14 @@ def _int32_bytes(key, v, binary):
 
 class TableWriter:
     """TableWriter("ark:lat.1" | "ark,t:-" | "ark:| gzip -c > lat.1.gz" | "ark,scp:f.ark,f.scp" | "scp:f.scp", kind)
-    kind: "matrix" | "int32" | "lattice" | "compact_lattice".  A script-only wspecifier names one
+    kind: "matrix" | "dmatrix" | "int32" | "lattice" | "compact_lattice".  A script-only wspecifier names one
     output file per key, as TableWriterScriptImpl does (no key inside the file)."""
 
     def __init__(self, wspecifier, kind, acoustic_scale=1.0):
         self.type, self.ark, self.scp, self.opts = classify_wspecifier(wspecifier)
         if self.type == NO_SPECIFIER:
             raise KamdError("invalid wspecifier " + wspecifier)
-        if kind not in ("matrix", "int32", "lattice", "compact_lattice", "raw"):
+        if kind not in ("matrix", "dmatrix", "int32", "lattice", "compact_lattice", "raw"):
             raise KamdError("unknown table object type " + kind)
         self.kind, self.acoustic_scale, self.closed = kind, acoustic_scale, False
         self._scp_lines, self._tmp = [], None
@@ -294,6 +350,9 @@ class TableWriter:
         elif self.kind == "int32":
             with open(path, "ab") as f:
                 f.write(_int32_bytes(key, value, b))
+        elif self.kind == "dmatrix":
+            with open(path, "ab") as f:
+                f.write((key.encode() + b" " if with_key else b"") + _dmatrix_bytes(value, b))
         elif self.kind == "raw":                     # value = the serialised object (after "key "), bytes
             with open(path, "ab") as f:
                 f.write(key.encode() + b" " + value)

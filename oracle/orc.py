@@ -61,6 +61,8 @@ def lib():
         L.orc_add_deltas.restype = None
         L.orc_cmvn_acc_stats.argtypes = [fp, C.c_int, C.c_int, dp]
         L.orc_cmvn_acc_stats.restype = None
+        L.orc_cmvn_acc_stats_weighted.argtypes = [fp, C.c_int, C.c_int, fp, dp]
+        L.orc_cmvn_acc_stats_weighted.restype = None
         L.orc_cmvn_apply.argtypes = [dp, C.c_int, fp, C.c_int, C.c_int]
         L.orc_cmvn_apply_reverse.argtypes = [dp, C.c_int, fp, C.c_int, C.c_int]
         L.orc_decoder_create.restype = C.c_void_p
@@ -239,9 +241,14 @@ def add_deltas(feats, order=2, window=2):
     return out
 
 
-def cmvn_acc_stats(feats, stats=None):
+def cmvn_acc_stats(feats, stats=None, weights=None):
     f = np.ascontiguousarray(feats, np.float32)
     st = np.zeros((2, f.shape[1] + 1), np.float64) if stats is None else np.array(stats, np.float64)
+    if weights is not None:
+        w = np.ascontiguousarray(weights, np.float32)
+        assert w.size == f.shape[0]
+        lib().orc_cmvn_acc_stats_weighted(abi.fptr(f), f.shape[0], f.shape[1], abi.fptr(w), st.ctypes.data_as(C.POINTER(C.c_double)))
+        return st
     lib().orc_cmvn_acc_stats(abi.fptr(f), f.shape[0], f.shape[1], st.ctypes.data_as(C.POINTER(C.c_double)))
     return st
 

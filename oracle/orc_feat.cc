@@ -348,6 +348,19 @@ extern "C" void orc_cmvn_acc_stats(const float *feats, int T, int dim, double *s
     }
   }
 }
+// AccCmvnStats(feats, &weights, stats) (transform/cmvn.cc:30-62)
+extern "C" void orc_cmvn_acc_stats_weighted(const float *feats, int T, int dim, const float *weights, double *stats) {
+  for (int t = 0; t < T; t++) {
+    const float weight = weights[t];
+    if (weight == 0.0f) continue;
+    stats[dim] += weight;
+    for (int k = 0; k < dim; k++) {
+      const float x = feats[static_cast<size_t>(t) * dim + k];
+      stats[k] += x * weight;
+      stats[dim + 1 + k] += x * x * weight;
+    }
+  }
+}
 extern "C" int orc_cmvn_apply(const double *stats, int var_norm, float *feats, int T, int dim) {
   const double count = stats[dim];
   if (count < 1.0) return -1;

@@ -35,6 +35,10 @@ def assert_same(d, o):
     np.testing.assert_array_equal(tn[1].view(np.uint32), to[1].view(np.uint32))
     np.testing.assert_array_equal(tn[2].view(np.uint32), to[2].view(np.uint32))
     np.testing.assert_array_equal(d.counters()[:7], o.counters()[:7])
+    assert d.FinalRelativeCost() == o.FinalRelativeCost()
+    if lo is None:                      # every token died (random graphs with dead ends): no lattice on either side
+        assert ln is None and d.GetBestPath() is None
+        return
     bn, bo = d.GetBestPath(), lo.best_path()
     assert bn["words"].tolist() == bo["words"].tolist()
     assert bn["alignment"].tolist() == bo["alignment"].tolist()

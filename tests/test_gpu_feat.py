@@ -89,6 +89,14 @@ def test_cmvn_stats_and_apply_match_the_oracle(tmp_path):
         got = cmvn.apply(mats[1:], [orc.cmvn_acc_stats(m) for m in mats[1:]], norm_vars=nv)
         for m, g in zip(mats[1:], got):
             np.testing.assert_array_equal(g, orc.cmvn_apply(m, orc.cmvn_acc_stats(m), nv))
+    # --weights: per-frame weights (zeros skipped, count = sum of the weights)
+    wts = [np.where(rng.random(m.shape[0]) < 0.3, 0.0, rng.random(m.shape[0]) * 2).astype(np.float32) for m in mats]
+    for s1, m, w in zip(cmvn.acc_stats(mats, weights=wts), mats, wts):
+        want = orc.cmvn_acc_stats(m, weights=w)
+        np.testing.assert_allclose(s1, want, rtol=1e-12, atol=1e-12)
+        assert abs(s1[0, -1] - w.astype(np.float64).sum()) < 1e-9
+    with pytest.raises(Exception):
+        cmvn.acc_stats(mats[:1], weights=[np.ones(5, np.float32)])
     # --reverse (ApplyCmvnReverse) and --skip-dims (FakeStatsForSomeDims): bit-equal to the oracle; skipped dimensions
     # come out untouched without variance normalisation, and reverse undoes forward up to rounding
     for nv in (False, True):
@@ -131,6 +139,17 @@ def test_cmvn_stats_and_apply_match_the_oracle(tmp_path):
         r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1500:]
     out = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "out.ark"), "matrix"))
+    # compute-cmvn-stats --weights through the command line (text archive of per-frame weights; u3 has none -> skipped)
+    with open(tmp_path / "w.ark", "w") as f:
+        for i in range(3):
+            f.write("u%d  [ %s ]\n" % (i, " ".join("%.9g" % x for x in wts[i])))
+    r = subprocess.run([sys.executable, root + "/tools/compute_cmvn_stats.py", "--weights=ark:%s" % (tmp_path / "w.ark"), "ark:%s" % (tmp_path / "f.ark"),
+                        "ark:%s" % (tmp_path / "cmvn_w.ark")], capture_output=True, text=True)
+    assert r.returncode == 0 and "No weights available for utterance u3" in r.stderr and "3 utterances; 1 had errors" in r.stderr, r.stderr[-1500:]
+    got_w = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "cmvn_w.ark"), "dmatrix"))      # statistics are double matrices
+    assert sorted(got_w) == ["u0", "u1", "u2"]
+    for i in range(3):
+        np.testing.assert_allclose(got_w["u%d" % i], orc.cmvn_acc_stats(mats[i], weights=wts[i]), rtol=1e-12, atol=1e-12)
     r = subprocess.run([sys.executable, root + "/tools/apply_cmvn.py", "--norm-vars=true", "--reverse=true", "--skip-dims=1:2",
                         "--utt2spk=ark:%s" % (tmp_path / "utt2spk"), "ark:%s" % (tmp_path / "cmvn.ark"), "ark:%s" % (tmp_path / "out.ark"),
                         "ark:%s" % (tmp_path / "back.ark")], capture_output=True, text=True)

@@ -43,7 +43,7 @@ import os
 
 @pytest.mark.parametrize("block", range(int(os.environ.get("KAMD_FUZZ_BLOCKS", "6"))))
 def test_random_cases(block):
-    rng = np.random.default_rng(1234 + block)
+    rng = np.random.default_rng(int(os.environ.get("KAMD_FUZZ_SEED", "1234")) + block)   # soak runs: other seeds, more blocks
     for i in range(20):
         g, ll, cfg = random_case(rng)
         G = decoder.Graph(g)

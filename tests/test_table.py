@@ -229,3 +229,30 @@ def test_vector_and_token_tables(tmp_path):
     np.testing.assert_array_equal(T.RandomAccessTableReader("scp:%s" % (tmp_path / "iv.scp"), "vector")["a"], v2.astype(np.float32))
     (tmp_path / "utt2spk").write_text("utt1 spk1\nutt2 spk1\nutt3 spk2\n")
     assert dict(T.SequentialTableReader("ark:%s" % (tmp_path / "utt2spk"), "tokens")) == {"utt1": ["spk1"], "utt2": ["spk1"], "utt3": ["spk2"]}
+
+
+def test_double_matrix_tables_round_trip(tmp_path):
+    """CMVN statistics are Matrix<double> tables (DoubleMatrixWriter / RandomAccessDoubleMatrixReader): binary DM, text,
+    ark+scp, and float (FM) archives read into doubles."""
+    from kaldi_amd import io as kio
+    rng = np.random.default_rng(0)
+    mats = {"spk%d" % i: rng.standard_normal((2, 14)) * 1e6 + np.pi for i in range(3)}
+    for spec in ("ark:%s" % (tmp_path / "a.ark"), "ark,t:%s" % (tmp_path / "t.ark"),
+                 "ark,scp:%s,%s" % (tmp_path / "b.ark", tmp_path / "b.scp")):
+        with T.TableWriter(spec, "dmatrix") as w:
+            for k, m in mats.items():
+                w.write(k, m)
+    assert open(tmp_path / "a.ark", "rb").read().startswith(b"spk0 \0BDM \x04\x02\x00\x00\x00\x04\x0e\x00\x00\x00")
+    assert open(tmp_path / "t.ark").read().startswith("spk0  [\n  ")
+    for spec in ("ark:%s" % (tmp_path / "a.ark"), "ark:%s" % (tmp_path / "t.ark"), "scp:%s" % (tmp_path / "b.scp")):
+        got = dict(T.SequentialTableReader(spec, "dmatrix"))
+        assert list(got) == list(mats)
+        for k in mats:
+            assert got[k].dtype == np.float64
+            np.testing.assert_array_equal(got[k], mats[k])                   # exact: doubles all the way (text: %.17g)
+    ra = T.RandomAccessTableReader("scp:%s" % (tmp_path / "b.scp"), "dmatrix")
+    np.testing.assert_array_equal(ra["spk2"], mats["spk2"])
+    kio.write_matrix_ark(tmp_path / "f.ark", "x", mats["spk1"].astype(np.float32), append=False)
+    (k, m), = list(T.SequentialTableReader("ark:%s" % (tmp_path / "f.ark"), "dmatrix"))
+    assert k == "x" and m.dtype == np.float64
+    np.testing.assert_array_equal(m, mats["spk1"].astype(np.float32).astype(np.float64))

@@ -34,7 +34,7 @@ def main(argv):
         glob = ivector.read_kaldi_matrix(args[0], np.float64)
         reader = None
     else:
-        reader = table.RandomAccessTableReader(args[0], "matrix")
+        reader = table.RandomAccessTableReader(args[0], "dmatrix")       # RandomAccessDoubleMatrixReaderMapped
     utt2spk = {k: v[0] for k, v in table.SequentialTableReader(po["utt2spk"], "tokens")} if po["utt2spk"] else None
     n_done = n_err = 0
     with table.TableWriter(args[2], "matrix") as w:
