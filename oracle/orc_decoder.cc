@@ -699,7 +699,7 @@ float orc_decoder_final_relative_cost(orc_decoder *d) {  // :474-484
 }
 int orc_decoder_num_toks(orc_decoder *d) { return d->num_toks; }
 
-static Decoder::RawLat g_lat;  // scratch between _size and _get (single-threaded tests)
+static thread_local Decoder::RawLat g_lat;  // scratch between _size and _get (both called from one thread)
 
 int orc_decoder_lattice_size(orc_decoder *d, kamd_lattice_size *sz) {
   bool ok = d->GetRawLattice(&g_lat);
