@@ -15,6 +15,7 @@ ap.add_argument("--seconds", type=float, default=12.0)
 ap.add_argument("--chunk", type=float, default=0.24)
 ap.add_argument("--ll-std", type=float, default=1.3)
 ap.add_argument("--streams", type=int, default=0, help="> 0: that many concurrent streams through kamd_stream_batch")
+ap.add_argument("--endpointing", action="store_true", help="with --streams: EndpointDetected for all streams after every tick (one traceback launch)")
 ap.add_argument("--ivectors", action="store_true", help="with --streams: the model takes 100-dim online i-vectors, estimated per "
                 "stream on the device (512-Gaussian UBM) and fed on DecodableNnetLoopedOnline's chunk schedule (--frames-per-chunk 20)")
 a = ap.parse_args()
@@ -39,16 +40,24 @@ if a.streams > 0:
     if ie is not None:
         sb.set_ivector_extractor(ie, 20)
     step = int(a.chunk * 16000)
+    ep = online.OnlineEndpointConfig()
+    num_tids = len(g.tid2pdf) - 1
+    tid2phone = np.concatenate([[0], np.arange(num_tids) // 2 + 1]).astype(np.int32)
+    sil_phones = [p for p in range(1, int(tid2phone.max()) + 1) if p % 3 != 0]     # arbitrary: two units of three
     for rep in range(2):
         sb.start(np.arange(S))
-        lat = []
+        lat, ep_ms, ep_sil = [], [], []
         for i in range(0, waves[0].size, step):
             t0 = time.perf_counter()
             for s_ in range(S):
                 sb.accept(s_, waves[s_][i:i + step], input_finished=i + step >= waves[s_].size)
             t1 = time.perf_counter()
             nd = sb.advance(np.arange(S))
-            lat.append((time.perf_counter() - t1, t1 - t0))
+            t2 = time.perf_counter()
+            if a.endpointing and nd[0] > 0 and i + step < waves[0].size:
+                flags, sil_fr = sb.endpoint_detected(ep, np.arange(S), tid2phone, sil_phones)
+                ep_ms.append((time.perf_counter() - t2) * 1e3); ep_sil.append(float(np.mean(sil_fr)))
+            lat.append((t2 - t1, t1 - t0))
         t0 = time.perf_counter()
         sb.finalize(np.arange(S))
         fin = time.perf_counter() - t0
@@ -57,6 +66,9 @@ if a.streams > 0:
     print("%d streams x %.1f s in %.0f ms chunks: %d ticks, %d frames decoded per stream" % (S, a.seconds, a.chunk * 1e3, adv.size, int(nd[0])))
     print("per tick: upload %.2f ms + features/nnet/AdvanceDecoding for all streams %.2f ms median (p95 %.2f, max %.2f)"
           % (np.median(up), np.median(adv), np.percentile(adv, 95), adv.max()))
+    if a.endpointing and ep_ms:
+        print("endpointing for all streams: %.2f ms median per tick (p95 %.2f), mean trailing silence %.1f frames"
+              % (np.median(ep_ms), np.percentile(ep_ms, 95), np.mean(ep_sil)))
     print("aggregate %.0f x real time (compute only %.0f x); FinalizeDecoding of all streams %.2f ms"
           % (S * a.seconds * 1e3 / (adv.sum() + up.sum()), S * a.seconds * 1e3 / adv.sum(), fin * 1e3))
     sys.exit(0)
