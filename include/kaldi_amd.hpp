@@ -934,6 +934,27 @@ class OnlineStreamBatch {
     Check(kamd_stream_batch_get_adaptation_state(h_, stream, state->data()));
     Check(kamd_ivector_state_limit_frames(ie_, state->data(), max_remembered_frames));
   }
+  /// partial results (GetBestPath(end_of_utterance = false)) of these streams after a tick, one launch; words[i] is empty and
+  /// ok[i] false for a stream with no token alive
+  void GetPartialBestPaths(const std::vector<int32> &streams, std::vector<std::vector<int32> > *words,
+                           std::vector<std::vector<int32> > *alignments = NULL, std::vector<char> *ok = NULL) {
+    const int n = static_cast<int>(streams.size());
+    int32 frames = 0;
+    for (int i = 0; i < n; i++) frames = std::max(frames, kamd_decoder_num_frames_decoded(dec_, streams[i]));
+    const int cap = 4 * (frames + 2) + 1024;
+    std::vector<int32> ali(static_cast<size_t>(n) * cap), wrd(static_cast<size_t>(n) * cap), na(n), nw(n);
+    std::vector<float> g(n), a(n);
+    Check(kamd_decoder_partial_best_paths(dec_, streams.data(), n, 0, ali.data(), cap, na.data(), wrd.data(), cap, nw.data(), g.data(), a.data()));
+    words->assign(n, std::vector<int32>());
+    if (alignments) alignments->assign(n, std::vector<int32>());
+    if (ok) ok->assign(n, 0);
+    for (int i = 0; i < n; i++) {
+      if (na[i] < 0) continue;
+      (*words)[i].assign(wrd.begin() + static_cast<size_t>(i) * cap, wrd.begin() + static_cast<size_t>(i) * cap + std::min(nw[i], cap));
+      if (alignments) (*alignments)[i].assign(ali.begin() + static_cast<size_t>(i) * cap, ali.begin() + static_cast<size_t>(i) * cap + std::min(na[i], cap));
+      if (ok) (*ok)[i] = 1;
+    }
+  }
   /// EndpointDetected for these streams after a tick, one launch (online2-wav-nnet3-latgen-faster.cc --do-endpointing)
   void EndpointDetected(const OnlineEndpointConfig &config, const std::vector<int32> &tid2phone, const std::vector<int32> &streams,
                         std::vector<int32> *detected, std::vector<int32> *trailing_silence_frames = NULL) {

@@ -2019,6 +2019,29 @@ __global__ __launch_bounds__(NT) void TracebackKernel(DecDev d, int lane, int us
   if (tid == 0) { *out_n = n; if (n >= 0) *out_final_cost = fc; }
 }
 
+// The same for a batch of lanes in one launch (a server's partial results after a tick): lane lanes[b] writes its
+// arcs at out_arcs + b * out_cap, its count / final cost at head[2b], head[2b+1] (count -1: no token alive).
+__global__ __launch_bounds__(NT) void TracebackBatchKernel(DecDev d, const int *lanes, int use_final_probs, PathArc *out_arcs,
+                                                           int out_cap, int *head) {
+  __shared__ Sh sh;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const Ctx c = MakeCtx(d, lanes[b]);
+  InitSh(&sh);
+  PathArc *out = out_arcs + static_cast<size_t>(b) * out_cap;
+  float fc = 0.0f;
+  int n = -1;
+  if (!c.st->error && !c.st->finalized)
+    n = WalkBestPath(d, c, &sh, use_final_probs, &fc, [&](int k, const Link &L, bool emitting, int f) {
+      if (tid == 0 && k < out_cap) {
+        PathArc a; a.ilabel = L.ilabel; a.olabel = L.olabel; a.graph = L.graph;
+        a.ac = emitting ? L.ac - c.cost_offsets[f - 1] : L.ac;
+        out[k] = a;
+      }
+      return true;
+    });
+  if (tid == 0) { head[2 * b] = n; head[2 * b + 1] = __float_as_int(fc); }
+}
+
 // TrailingSilenceLength (online2/online-endpoint.cc:71-102) for a batch of un-finalized lanes: the best path
 // without final-probs is walked back from the newest frame, counting transition-ids of silence phones until
 // the first one that is not (sil_tid[tid] = 1 for transition-ids of silence phones).
@@ -2578,6 +2601,62 @@ int kamd_decoder_endpoint_detected(kamd_decoder *h, const kamd_endpoint_config *
     if (trailing_silence_frames) trailing_silence_frames[i] = sil[i];
   }
   return KAMD_OK;
+}
+
+int kamd_decoder_partial_best_paths(kamd_decoder *h, const int32_t *lanes, int n, int use_final_probs, int32_t *alignments, int ali_cap,
+                                    int32_t *ali_len, int32_t *words, int words_cap, int32_t *words_len, float *graph_cost,
+                                    float *acoustic_cost) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0) return KAMD_OK;
+  if (CheckLanes(D, lanes, n) != KAMD_OK || EnsureTaskBuf(D, n) != KAMD_OK) return KAMD_ERR_ARG;
+  int max_frame = 0;
+  for (int i = 0; i < n; i++) {
+    if (D->h_st[lanes[i]].finalized) return kamd::SetError(KAMD_ERR_STATE, "lane %d is finalized: use kamd_decoder_best_path", lanes[i]);
+    max_frame = std::max(max_frame, D->h_st[lanes[i]].frame);
+  }
+  const int cap = 4 * (max_frame + 2) + 1024;
+  const size_t arcs_bytes = static_cast<size_t>(n) * cap * sizeof(kamd::PathArc), head_bytes = static_cast<size_t>(n) * 8;
+  void *d_buf = NULL;
+  KAMD_HIP(hipMalloc(&d_buf, arcs_bytes + head_bytes));
+  kamd::PathArc *d_arcs = static_cast<kamd::PathArc *>(d_buf);
+  int *d_head = reinterpret_cast<int *>(static_cast<char *>(d_buf) + arcs_bytes);
+  hipStream_t st = D->last_stream;
+  std::vector<int> head(2 * static_cast<size_t>(n));
+  std::vector<kamd::PathArc> arcs;
+  int rc = KAMD_OK;
+  if (hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    rc = kamd::SetError(KAMD_ERR_HIP, "traceback: upload failed");
+  if (rc == KAMD_OK) {
+    hipLaunchKernelGGL(kamd::TracebackBatchKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes, use_final_probs, d_arcs, cap, d_head);
+    if (hipMemcpyAsync(head.data(), d_head, head_bytes, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      rc = kamd::SetError(KAMD_ERR_HIP, "traceback kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  if (rc == KAMD_OK) {
+    int longest = 0;
+    for (int i = 0; i < n; i++) longest = std::max(longest, std::min(head[2 * i], cap));
+    // one strided copy of the used prefix of every lane's segment
+    arcs.resize(static_cast<size_t>(n) * std::max(longest, 1));
+    if (longest > 0 && hipMemcpy2D(arcs.data(), static_cast<size_t>(longest) * sizeof(kamd::PathArc), d_arcs, static_cast<size_t>(cap) * sizeof(kamd::PathArc),
+                                   static_cast<size_t>(longest) * sizeof(kamd::PathArc), n, hipMemcpyDeviceToHost) != hipSuccess)
+      rc = kamd::SetError(KAMD_ERR_HIP, "traceback copy failed");
+    for (int i = 0; rc == KAMD_OK && i < n; i++) {
+      int32_t *ali = alignments + static_cast<size_t>(i) * ali_cap, *wrd = words + static_cast<size_t>(i) * words_cap;
+      ali_len[i] = 0; words_len[i] = 0; graph_cost[i] = INFINITY; acoustic_cost[i] = INFINITY;
+      const int cnt = head[2 * i];
+      if (cnt < 0) { ali_len[i] = -1; words_len[i] = -1; continue; }      // no tokens alive on the newest frame
+      float fc; memcpy(&fc, &head[2 * i + 1], 4);
+      const kamd::PathArc *A = arcs.data() + static_cast<size_t>(i) * longest;
+      float gsum = 0.f, asum = 0.f;   // Times() along the path, start -> end
+      for (int k = std::min(cnt, cap) - 1; k >= 0; k--) {
+        if (A[k].ilabel != 0) { if (ali_len[i] < ali_cap) ali[ali_len[i]] = A[k].ilabel; ali_len[i]++; }
+        if (A[k].olabel != 0) { if (words_len[i] < words_cap) wrd[words_len[i]] = A[k].olabel; words_len[i]++; }
+        gsum += A[k].graph; asum += A[k].ac;
+      }
+      graph_cost[i] = gsum + fc; acoustic_cost[i] = asum;
+    }
+  }
+  (void)hipFree(d_buf);
+  return rc;
 }
 
 int kamd_decoder_get_phase_cycles(kamd_decoder *h, int lane, uint64_t cycles[16]) {

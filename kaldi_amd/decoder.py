@@ -294,6 +294,22 @@ def partial_best_path(dec, lane, use_final_probs=True):
                 acoustic_cost=a.value)
 
 
+def partial_best_paths(dec, lanes, use_final_probs=False):
+    """partial_best_path of several un-finalized lanes in one launch -> list of dicts (None: no token alive)"""
+    ln = np.ascontiguousarray(lanes, np.int32)
+    if ln.size == 0:
+        return []
+    nmax = max(lib().kamd_decoder_num_frames_decoded(dec, int(l)) for l in ln)
+    cap = 4 * (nmax + 2) + 1024
+    ali, words = np.zeros((ln.size, cap), np.int32), np.zeros((ln.size, cap), np.int32)
+    na, nw = np.zeros(ln.size, np.int32), np.zeros(ln.size, np.int32)
+    g, a = np.zeros(ln.size, np.float32), np.zeros(ln.size, np.float32)
+    check(lib().kamd_decoder_partial_best_paths(dec, abi.iptr(ln), ln.size, int(use_final_probs), abi.iptr(ali), cap, abi.iptr(na),
+                                                abi.iptr(words), cap, abi.iptr(nw), abi.fptr(g), abi.fptr(a)))
+    return [None if na[i] < 0 else dict(alignment=ali[i, :na[i]].copy(), words=words[i, :nw[i]].copy(), graph_cost=float(g[i]),
+                                        acoustic_cost=float(a[i])) for i in range(ln.size)]
+
+
 def endpoint_config_default():
     """OnlineEndpointConfig() (online2/online-endpoint.h:149-154)"""
     c = abi.EndpointConfig()

@@ -277,6 +277,10 @@ class StreamBatch:
     def partial_best_path(self, stream, use_final_probs=False):
         return decoder.partial_best_path(self.dec._dec, int(stream), use_final_probs)
 
+    def partial_best_paths(self, streams, use_final_probs=False):
+        """partial results of these streams in one launch"""
+        return decoder.partial_best_paths(self.dec._dec, streams, use_final_probs)
+
     def endpoint_detected(self, config, streams, tid2phone, silence_phones, frame_shift_in_seconds=None):
         """EndpointDetected for these streams in one launch -> (flags, trailing silence frames)"""
         if frame_shift_in_seconds is None:

@@ -182,6 +182,13 @@ int main(int argc, char **argv) {
           pos[s] += n; live.push_back(s);
         }
         batch.AdvanceDecoding(live);
+        // partial results of the live streams in one launch: one transition-id per decoded frame
+        std::vector<std::vector<int32> > pw, pa; std::vector<char> pok;
+        batch.GetPartialBestPaths(live, &pw, &pa, &pok);
+        for (size_t k = 0; k < live.size(); k++) {
+          const int32 nd = kamd_decoder_num_frames_decoded(batch.DecoderHandle(), live[k]);
+          if (nd > 0 && (!pok[k] || static_cast<int32>(pa[k].size()) != nd)) throw KaldiFatalError("partial best path: alignment length != frames decoded");
+        }
       }
       batch.FinalizeDecoding(both);
       for (int s = 0; s < 2; s++) {

@@ -398,6 +398,12 @@ def test_endpointing_on_the_device_equals_the_oracle():
         if not cand:
             continue
         flags, sil_frames = sb.endpoint_detected(ep, cand, tid2phone, sil)
+        for use_final in (False, True):                                 # all streams' partial results in one launch
+            many = sb.partial_best_paths(cand, use_final_probs=use_final)
+            for k, got in zip(cand, many):
+                one = sb.partial_best_path(k, use_final_probs=use_final)
+                assert got["alignment"].tolist() == one["alignment"].tolist() and got["words"].tolist() == one["words"].tolist()
+                assert got["graph_cost"] == one["graph_cost"] and got["acoustic_cost"] == one["acoustic_cost"]
         for k, f, t in zip(cand, flags, sil_frames):
             bp = sb.partial_best_path(k, use_final_probs=False)
             want_sil = orc.trailing_silence_length(bp["alignment"], tid2phone, sil)

@@ -15,6 +15,7 @@ ap.add_argument("--seconds", type=float, default=12.0)
 ap.add_argument("--chunk", type=float, default=0.24)
 ap.add_argument("--ll-std", type=float, default=1.3)
 ap.add_argument("--streams", type=int, default=0, help="> 0: that many concurrent streams through kamd_stream_batch")
+ap.add_argument("--partials", action="store_true", help="with --streams: partial best paths of all streams after every tick (one launch)")
 ap.add_argument("--endpointing", action="store_true", help="with --streams: EndpointDetected for all streams after every tick (one traceback launch)")
 ap.add_argument("--ivectors", action="store_true", help="with --streams: the model takes 100-dim online i-vectors, estimated per "
                 "stream on the device (512-Gaussian UBM) and fed on DecodableNnetLoopedOnline's chunk schedule (--frames-per-chunk 20)")
@@ -46,7 +47,7 @@ if a.streams > 0:
     sil_phones = [p for p in range(1, int(tid2phone.max()) + 1) if p % 3 != 0]     # arbitrary: two units of three
     for rep in range(2):
         sb.start(np.arange(S))
-        lat, ep_ms, ep_sil = [], [], []
+        lat, ep_ms, ep_sil, pb_ms = [], [], [], []
         for i in range(0, waves[0].size, step):
             t0 = time.perf_counter()
             for s_ in range(S):
@@ -57,6 +58,10 @@ if a.streams > 0:
             if a.endpointing and nd[0] > 0 and i + step < waves[0].size:
                 flags, sil_fr = sb.endpoint_detected(ep, np.arange(S), tid2phone, sil_phones)
                 ep_ms.append((time.perf_counter() - t2) * 1e3); ep_sil.append(float(np.mean(sil_fr)))
+            if a.partials and nd[0] > 0 and i + step < waves[0].size:
+                t3 = time.perf_counter()
+                pb = sb.partial_best_paths(np.arange(S))
+                pb_ms.append((time.perf_counter() - t3) * 1e3)
             lat.append((t2 - t1, t1 - t0))
         t0 = time.perf_counter()
         sb.finalize(np.arange(S))
@@ -66,6 +71,12 @@ if a.streams > 0:
     print("%d streams x %.1f s in %.0f ms chunks: %d ticks, %d frames decoded per stream" % (S, a.seconds, a.chunk * 1e3, adv.size, int(nd[0])))
     print("per tick: upload %.2f ms + features/nnet/AdvanceDecoding for all streams %.2f ms median (p95 %.2f, max %.2f)"
           % (np.median(up), np.median(adv), np.percentile(adv, 95), adv.max()))
+    if a.partials and pb_ms:
+        t3 = time.perf_counter()
+        sb.start(np.arange(2)); sb.accept(0, waves[0][:step * 8]); sb.accept(1, waves[1][:step * 8]); sb.advance([0, 1])
+        t3 = time.perf_counter(); sb.partial_best_path(0); one_ms = (time.perf_counter() - t3) * 1e3
+        print("partial best paths of all streams: %.2f ms median per tick (p95 %.2f, last tick %.2f; %d words in stream 0); one stream alone, "
+              "8 chunks in: %.2f ms" % (np.median(pb_ms), np.percentile(pb_ms, 95), pb_ms[-1], len(pb[0]["words"]), one_ms))
     if a.endpointing and ep_ms:
         print("endpointing for all streams: %.2f ms median per tick (p95 %.2f), mean trailing silence %.1f frames"
               % (np.median(ep_ms), np.percentile(ep_ms, 95), np.mean(ep_sil)))
