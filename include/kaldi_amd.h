@@ -569,6 +569,10 @@ int kamd_stream_batch_start(kamd_stream_batch *b, const int32_t *streams, int n)
 /* AcceptWaveform (+ InputFinished when input_finished != 0); host samples, int16 range */
 int kamd_stream_batch_accept(kamd_stream_batch *b, int stream, const float *wave, int64_t n,
                              int input_finished);
+/* AcceptWaveform for many streams at once: waves[offsets[i] .. offsets[i+1]) is appended to streams[i] (each stream at most
+ * once); one host-to-device copy and one scatter launch for the whole tick.  input_finished: [n] flags or NULL. */
+int kamd_stream_batch_accept_many(kamd_stream_batch *b, const int32_t *streams, int n, const float *waves,
+                                  const int64_t *offsets, const int32_t *input_finished);
 /* AdvanceDecoding for all listed streams; frames_decoded[n] may be NULL */
 int kamd_stream_batch_advance(kamd_stream_batch *b, const int32_t *streams, int n, int32_t *frames_decoded);
 int kamd_stream_batch_num_frames_ready(const kamd_stream_batch *b, int stream);

@@ -909,6 +909,13 @@ class OnlineStreamBatch {
   void AcceptWaveform(int32 stream, const float *wave, int64_t n, bool input_finished) {
     Check(kamd_stream_batch_accept(h_, stream, wave, n, input_finished ? 1 : 0));
   }
+  /// AcceptWaveform of several streams with one upload: waves[offsets[i] .. offsets[i+1]) goes to streams[i]
+  void AcceptWaveforms(const std::vector<int32> &streams, const float *waves, const std::vector<int64_t> &offsets,
+                       const std::vector<int32> *input_finished = NULL) {
+    if (offsets.size() != streams.size() + 1) throw KaldiFatalError("AcceptWaveforms: offsets must have one more entry than streams");
+    Check(kamd_stream_batch_accept_many(h_, streams.data(), static_cast<int>(streams.size()), waves, offsets.data(),
+                                        input_finished ? input_finished->data() : NULL));
+  }
   /// one tick: AdvanceDecoding of all listed streams
   void AdvanceDecoding(const std::vector<int32> &streams, std::vector<int32> *frames_decoded = NULL) {
     if (frames_decoded) frames_decoded->resize(streams.size());

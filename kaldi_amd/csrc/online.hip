@@ -199,6 +199,7 @@ struct StreamBatch {
   int S = 0, dim = 0, ld = 0, P = 0, max_frames = 0;
   int64_t max_samples = 0;
   float *d_wave = NULL, *d_frames = NULL, *d_ll = NULL;
+  void *d_stage = NULL; size_t stage_cap = 0;       // accept_many: {segment table, concatenated chunks}
   size_t ll_cap = 0;
   std::vector<int64_t> n_samp;
   std::vector<int> n_frames, decoded;
@@ -236,6 +237,7 @@ void kamd_stream_batch_destroy(kamd_stream_batch *h) {
   if (b->d_wave) (void)hipFree(b->d_wave);
   if (b->d_frames) (void)hipFree(b->d_frames);
   if (b->d_ll) (void)hipFree(b->d_ll);
+  if (b->d_stage) (void)hipFree(b->d_stage);
   if (b->d_rec) (void)hipFree(b->d_rec);
   if (b->d_slots) (void)hipFree(b->d_slots);
   if (b->d_est) (void)hipFree(b->d_est);
@@ -345,6 +347,61 @@ int kamd_stream_batch_accept(kamd_stream_batch *h, int stream, const float *wave
     b->n_samp[stream] += n;
   }
   if (input_finished) b->finished[stream] = 1;
+  return KAMD_OK;
+}
+
+namespace kamd {
+// segment i of the staged buffer -> its stream's waveform, appended (meta: dst offset, src offset, length per segment)
+__global__ __launch_bounds__(256) void ScatterWaveKernel(const float *stage, float *wave, const int64_t *meta) {
+  const int64_t dst = meta[3 * blockIdx.y], src = meta[3 * blockIdx.y + 1], len = meta[3 * blockIdx.y + 2];
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < len; i += static_cast<int64_t>(gridDim.x) * 256) wave[dst + i] = stage[src + i];
+}
+}  // namespace kamd
+
+// AcceptWaveform for many streams at once (a server's tick): ONE host-to-device copy of the concatenated chunks
+// (waves[offsets[i] .. offsets[i+1]) belongs to streams[i]) and one scatter launch, instead of a copy per stream.
+int kamd_stream_batch_accept_many(kamd_stream_batch *h, const int32_t *streams, int n, const float *waves, const int64_t *offsets,
+                                  const int32_t *input_finished) {
+  StreamBatch *b = reinterpret_cast<StreamBatch *>(h);
+  if (n <= 0) return KAMD_OK;
+  std::vector<int64_t> meta(3 * static_cast<size_t>(n));
+  std::vector<char> seen(b->S, 0);
+  int64_t longest = 0;
+  for (int i = 0; i < n; i++) {
+    const int s = streams[i];
+    const int64_t len = offsets[i + 1] - offsets[i];
+    if (s < 0 || s >= b->S || !b->live[s]) return kamd::SetError(KAMD_ERR_ARG, "stream %d is not started", s);
+    if (seen[s]) return kamd::SetError(KAMD_ERR_ARG, "stream %d listed twice", s);
+    seen[s] = 1;
+    if (len < 0) return kamd::SetError(KAMD_ERR_ARG, "stream %d: negative chunk length", s);
+    if (b->finished[s] && len > 0) return kamd::SetError(KAMD_ERR_STATE, "AcceptWaveform called after InputFinished");
+    if (b->n_samp[s] + len > b->max_samples) return kamd::SetError(KAMD_ERR_CAPACITY, "stream %d: more audio than max_seconds", s);
+    meta[3 * i] = static_cast<int64_t>(s) * b->max_samples + b->n_samp[s];
+    meta[3 * i + 1] = offsets[i] - offsets[0]; meta[3 * i + 2] = len;
+    longest = std::max(longest, len);
+  }
+  const int64_t total = offsets[n] - offsets[0];
+  if (total > 0) {
+    const size_t need = static_cast<size_t>(total) * sizeof(float) + meta.size() * sizeof(int64_t) + 16;
+    if (need > b->stage_cap) {
+      if (b->d_stage) (void)hipFree(b->d_stage);
+      b->d_stage = NULL; b->stage_cap = 0;
+      KAMD_HIP(hipMalloc(&b->d_stage, 2 * need));
+      b->stage_cap = 2 * need;
+    }
+    int64_t *d_meta = static_cast<int64_t *>(b->d_stage);
+    float *d_st = reinterpret_cast<float *>(d_meta + meta.size() + 2);
+    KAMD_HIP(hipMemcpy(d_meta, meta.data(), meta.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    KAMD_HIP(hipMemcpy(d_st, waves + offsets[0], static_cast<size_t>(total) * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(kamd::ScatterWaveKernel, dim3(static_cast<unsigned>(std::min<int64_t>((longest + 255) / 256, 64)), n), dim3(256), 0, NULL,
+                       d_st, b->d_wave, d_meta);
+    KAMD_HIP(hipGetLastError());
+    KAMD_HIP(hipStreamSynchronize(NULL));        // the staging buffer is reused by the next call
+  }
+  for (int i = 0; i < n; i++) {
+    b->n_samp[streams[i]] += offsets[i + 1] - offsets[i];
+    if (input_finished && input_finished[i]) b->finished[streams[i]] = 1;
+  }
   return KAMD_OK;
 }
 

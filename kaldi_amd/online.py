@@ -267,6 +267,19 @@ class StreamBatch:
         w = np.ascontiguousarray(waveform, np.float32)
         check(lib().kamd_stream_batch_accept(self._h, int(stream), abi.fptr(w), w.size, int(input_finished)))
 
+    def accept_many(self, streams, chunks, input_finished=None):
+        """AcceptWaveform for several streams with ONE upload: chunks[i] is appended to streams[i]"""
+        st = np.ascontiguousarray(streams, np.int32)
+        chunks = [np.ascontiguousarray(c, np.float32).reshape(-1) for c in chunks]
+        if len(chunks) != st.size:
+            raise KamdError("accept_many: one chunk per stream")
+        off = np.zeros(st.size + 1, np.int64)
+        off[1:] = np.cumsum([c.size for c in chunks])
+        flat = np.ascontiguousarray(np.concatenate(chunks)) if off[-1] else np.zeros(1, np.float32)
+        fin = None if input_finished is None else np.ascontiguousarray([int(bool(f)) for f in input_finished], np.int32)
+        check(lib().kamd_stream_batch_accept_many(self._h, abi.iptr(st), st.size, abi.fptr(flat), abi.iptr(off, C.c_int64),
+                                                  None if fin is None else abi.iptr(fin)))
+
     def advance(self, streams):
         """One tick for these streams; returns NumFramesDecoded of each."""
         s = np.ascontiguousarray(streams, np.int32)

@@ -137,11 +137,17 @@ def test_batched_streams_equal_offline():
     ticks = 0
     while not all(done):
         live = [s for s in range(S) if not done[s]]
+        pieces = []
         for s in live:
             n = int(rng.integers(800, 6000))                 # 50 .. 375 ms, different per stream and tick
             chunk = waves[s][pos[s]:pos[s] + n]
             pos[s] += chunk.size
-            sb.accept(s, chunk, input_finished=pos[s] >= waves[s].size)
+            pieces.append(chunk)
+        if ticks % 2:                                        # every other tick: one upload for all streams
+            sb.accept_many(live, pieces, [pos[s] >= waves[s].size for s in live])
+        else:
+            for s, chunk in zip(live, pieces):
+                sb.accept(s, chunk, input_finished=pos[s] >= waves[s].size)
         before = [int(x) for x in sb.advance(live)]
         for s, nd in zip(live, before):
             if pos[s] >= waves[s].size:
@@ -153,6 +159,8 @@ def test_batched_streams_equal_offline():
         want = offline(waves[s])
         got = sb.raw_lattice(s)
         assert lattices_equal(got, want), (s, lattice_diff(got, want))
+    with pytest.raises(Exception):                           # a stream may appear once per call
+        sb.accept_many([0, 0], [np.zeros(4, np.float32)] * 2)
     # reuse slot 1 for another utterance while the others keep their results
     w2 = synth.make_wave(1.9, seed=77)
     sb.start([1])

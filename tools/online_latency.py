@@ -15,6 +15,7 @@ ap.add_argument("--seconds", type=float, default=12.0)
 ap.add_argument("--chunk", type=float, default=0.24)
 ap.add_argument("--ll-std", type=float, default=1.3)
 ap.add_argument("--streams", type=int, default=0, help="> 0: that many concurrent streams through kamd_stream_batch")
+ap.add_argument("--accept-each", action="store_true", help="with --streams: one AcceptWaveform (one upload) per stream instead of accept_many")
 ap.add_argument("--partials", action="store_true", help="with --streams: partial best paths of all streams after every tick (one launch)")
 ap.add_argument("--endpointing", action="store_true", help="with --streams: EndpointDetected for all streams after every tick (one traceback launch)")
 ap.add_argument("--ivectors", action="store_true", help="with --streams: the model takes 100-dim online i-vectors, estimated per "
@@ -50,8 +51,11 @@ if a.streams > 0:
         lat, ep_ms, ep_sil, pb_ms = [], [], [], []
         for i in range(0, waves[0].size, step):
             t0 = time.perf_counter()
-            for s_ in range(S):
-                sb.accept(s_, waves[s_][i:i + step], input_finished=i + step >= waves[s_].size)
+            if a.accept_each:
+                for s_ in range(S):
+                    sb.accept(s_, waves[s_][i:i + step], input_finished=i + step >= waves[s_].size)
+            else:
+                sb.accept_many(np.arange(S), [w[i:i + step] for w in waves], [i + step >= w.size for w in waves])
             t1 = time.perf_counter()
             nd = sb.advance(np.arange(S))
             t2 = time.perf_counter()
@@ -69,8 +73,8 @@ if a.streams > 0:
     adv = np.asarray([x[0] for x in lat]) * 1e3
     up = np.asarray([x[1] for x in lat]) * 1e3
     print("%d streams x %.1f s in %.0f ms chunks: %d ticks, %d frames decoded per stream" % (S, a.seconds, a.chunk * 1e3, adv.size, int(nd[0])))
-    print("per tick: upload %.2f ms + features/nnet/AdvanceDecoding for all streams %.2f ms median (p95 %.2f, max %.2f)"
-          % (np.median(up), np.median(adv), np.percentile(adv, 95), adv.max()))
+    print("per tick: upload (%s) %.2f ms + features/nnet/AdvanceDecoding for all streams %.2f ms median (p95 %.2f, max %.2f)"
+          % ("one copy per stream" if a.accept_each else "one copy for all", np.median(up), np.median(adv), np.percentile(adv, 95), adv.max()))
     if a.partials and pb_ms:
         t3 = time.perf_counter()
         sb.start(np.arange(2)); sb.accept(0, waves[0][:step * 8]); sb.accept(1, waves[1][:step * 8]); sb.advance([0, 1])
