@@ -114,11 +114,12 @@ def main(argv):
                 break
             chunk = int(po["chunk-length"] * mfcc.frame.samp_freq) if po["chunk-length"] > 0 else 1 << 62
             live = sorted(active)
+            pieces = []
             for s in live:
                 a = active[s]
-                piece = a["wave"][a["pos"]:a["pos"] + chunk]
-                a["pos"] += piece.size
-                sb.accept(s, piece, input_finished=a["pos"] >= a["wave"].size)
+                pieces.append(a["wave"][a["pos"]:a["pos"] + chunk])
+                a["pos"] += pieces[-1].size
+            sb.accept_many(live, pieces, [active[s]["pos"] >= active[s]["wave"].size for s in live])     # one upload per tick
             decoded = sb.advance(live)
             endpointed = set()
             if po["do-endpointing"]:                       # one traceback launch for every stream still listening
