@@ -677,6 +677,11 @@ int kamd_compact_lattice_write(const char *path, int append, const char *key, in
 int kamd_decoder_partial_best_path(kamd_decoder *d, int lane, int use_final_probs, int32_t *alignment,
                                    int ali_cap, int *ali_len, int32_t *words, int words_cap,
                                    int *words_len, float *graph_cost, float *acoustic_cost);
+/* kamd_decoder_partial_best_path for n un-finalized lanes in one launch (a server's partial results after a tick).  alignments: [n][ali_cap],
+ * words: [n][words_cap]; ali_len[i] = words_len[i] = -1 for a lane with no token alive.  Requires a prior kamd_decoder_sync. */
+int kamd_decoder_partial_best_paths(kamd_decoder *d, const int32_t *lanes, int n, int use_final_probs, int32_t *alignments,
+                                    int ali_cap, int32_t *ali_len, int32_t *words, int words_cap, int32_t *words_len,
+                                    float *graph_cost, float *acoustic_cost);
 /* ---- endpointing (online2/online-endpoint.{h,cc}) ----
  * OnlineEndpointRule / OnlineEndpointConfig (online-endpoint.h:113-170); the silence phones are handed to the
  * decoder once (kamd_decoder_set_silence_phones) instead of travelling as a colon-separated string. */
@@ -702,11 +707,6 @@ int kamd_decoder_trailing_silence_frames(kamd_decoder *d, const int32_t *lanes, 
  * online-nnet3-decoding.cc:88-95).  detected[i] = 0 / 1; trailing_silence_frames may be NULL. */
 int kamd_decoder_endpoint_detected(kamd_decoder *d, const kamd_endpoint_config *cfg, const int32_t *lanes, int n,
                                    float frame_shift_in_seconds, int32_t *detected, int32_t *trailing_silence_frames);
-/* The same for n un-finalized lanes in one launch (a server's partial results after a tick).  alignments: [n][ali_cap],
- * words: [n][words_cap]; ali_len[i] = words_len[i] = -1 for a lane with no token alive.  Requires a prior kamd_decoder_sync. */
-int kamd_decoder_partial_best_paths(kamd_decoder *d, const int32_t *lanes, int n, int use_final_probs, int32_t *alignments,
-                                    int ali_cap, int32_t *ali_len, int32_t *words, int words_cap, int32_t *words_len,
-                                    float *graph_cost, float *acoustic_cost);
 /* per-frame trace for parity debugging: ntok[f], cutoff[f], cost_offset[f]. */
 int kamd_decoder_get_trace(kamd_decoder *d, int lane, int32_t *ntok,
                            float *cutoff, float *cost_offset, int cap);
