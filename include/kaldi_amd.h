@@ -366,6 +366,63 @@ int kamd_decoder_best_path(kamd_decoder *d, int lane, int32_t *alignment,
                            int ali_cap, int *ali_len, int32_t *words,
                            int words_cap, int *words_len, float *graph_cost,
                            float *acoustic_cost);
+/* ------------------------------------------ work queue over resident lanes -- */
+/* Test-set decoding.  NnetBatchDecoder keeps N decoder threads, each with its own
+ * LatticeFasterDecoder, pulling utterances as they become ready
+ * (nnet3/nnet-batch-compute.h:606-833, .cc:1156-1215 Decode()); decode.sh spreads a test
+ * set over --nj jobs (steps/nnet3/decode.sh:96,123).  Here `resident_lanes` persistent
+ * workgroups (one CU each) pop tasks from a device-side queue: InitDecoding,
+ * AdvanceDecoding over the utterance's log-likelihood rows, FinalizeDecoding, then the
+ * pruned raw lattice is copied into a device pool and a record is published in
+ * host-visible memory while the kernel keeps running. */
+typedef struct {
+  const float *d_loglikes;   /* first row of the utterance's log-likelihoods (device) */
+  int32_t ld;                /* row stride */
+  int32_t n_frames;
+  int32_t utt;               /* caller's utterance index: slot in the result table */
+  int32_t reserved;
+} kamd_queue_task;
+typedef struct {
+  int32_t status;            /* 0 = pending, 1 = done (written last, system-scope release) */
+  int32_t error;             /* capacity flags of kamd_decoder_sync's message; 64 = lattice pool exhausted */
+  int32_t lane, n_frames;    /* lane that decoded it; NumFramesDecoded() */
+  int32_t n_tok, n_link;     /* raw lattice: states, arcs */
+  int32_t n_last, pad;       /* tokens on the last frame (their final costs travel with the lattice) */
+  float final_relative_cost, final_best_cost;
+  int64_t blob_off, blob_bytes;   /* the lattice inside the device pool */
+  int64_t counters[8];       /* the work counters of kamd_decoder_get_counters */
+  uint64_t phase_cycles[16];
+} kamd_queue_result;
+/* Lattice pool in HBM (grow-only; default 1 GiB at the first launch). */
+int kamd_decoder_queue_configure(kamd_decoder *d, int64_t pool_bytes);
+/* Asynchronous launch on `stream`: tasks are handed out in the order given (pass the
+ * longest first).  resident_lanes <= max_lanes of the decoder; 0 = one per compute unit.
+ * Every lane uses the decoder's per-lane arena (uniform split). */
+int kamd_decoder_queue_launch(kamd_decoder *d, const kamd_queue_task *tasks, int n,
+                              int resident_lanes, void *stream);
+/* Non-blocking: utterance indices that finished since the last call, in completion
+ * order; returns how many were written to utts[0..cap). */
+int kamd_decoder_queue_poll(kamd_decoder *d, int32_t *utts, int cap);
+/* The record of a finished utterance (status == 1), copied out of the shared table. */
+int kamd_decoder_queue_result(kamd_decoder *d, int32_t utt, kamd_queue_result *out);
+/* Raw lattice of a finished utterance: D2H of its blob on `copy_stream` (a stream other
+ * than the launch stream: the queue kernel may still be running) + canonical numbering
+ * (states by (frame, HCLG state), arcs sorted), as kamd_decoder_get_raw_lattice.  All
+ * output arrays are malloc'ed (kamd_host_free); thread-safe for distinct utterances. */
+int kamd_decoder_queue_fetch_lattice(kamd_decoder *d, int32_t utt, void *copy_stream,
+                                     int32_t *num_states, int32_t *num_arcs, int32_t *start,
+                                     int32_t **state_frame, int32_t **state_hclg,
+                                     float **state_cost, float **state_final, kamd_lat_arc **arcs);
+/* Blocks until the queue kernel has ended; *ms = its duration (HIP events on the launch
+ * stream), *lanes = resident lanes used. */
+int kamd_decoder_queue_wait(kamd_decoder *d, float *ms, int32_t *lanes);
+/* GetBestPath over a raw lattice given as arrays (the same ShortestPath as
+ * kamd_decoder_best_path; no decoder state, thread-safe). */
+int kamd_lattice_best_path(int32_t num_states, int32_t start, const float *state_final,
+                           const kamd_lat_arc *arcs, int32_t num_arcs, int32_t *alignment,
+                           int ali_cap, int *ali_len, int32_t *words, int words_cap,
+                           int *words_len, float *graph_cost, float *acoustic_cost);
+
 /* LatticeWriter entry (util/kaldi-table TableWriter + LatticeHolder::Write,
  * lat/kaldi-lattice.h:75-118; WriteLattice lat/kaldi-lattice.cc:96-130): appends
  * "key " + the lattice, binary (OpenFst VectorFst of "lattice4" arcs, no Kaldi binary

@@ -151,6 +151,14 @@ def lib():
     sig("kamd_decoder_get_counters", C.c_int, [vp, C.c_int, i64p])
     sig("kamd_decoder_get_phase_cycles", C.c_int, [vp, C.c_int, C.POINTER(C.c_uint64)])
     sig("kamd_decoder_last_advance_ms", C.c_float, [vp])
+    sig("kamd_decoder_queue_configure", C.c_int, [vp, C.c_int64])
+    sig("kamd_decoder_queue_launch", C.c_int, [vp, C.POINTER(abi.QueueTask), C.c_int, C.c_int, vp])
+    sig("kamd_decoder_queue_poll", C.c_int, [vp, ip, C.c_int])
+    sig("kamd_decoder_queue_result", C.c_int, [vp, C.c_int32, C.POINTER(abi.QueueResult)])
+    sig("kamd_decoder_queue_fetch_lattice", C.c_int, [vp, C.c_int32, vp, ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(fp),
+                                                      C.POINTER(fp), C.POINTER(vp)])
+    sig("kamd_decoder_queue_wait", C.c_int, [vp, fp, ip])
+    sig("kamd_lattice_best_path", C.c_int, [C.c_int32, C.c_int32, fp, vp, C.c_int32, ip, C.c_int, ip, ip, C.c_int, ip, fp, fp])
     sig("kamd_pipeline_create", vp, [vp, vp, vp])
     sig("kamd_pipeline_destroy", None, [vp])
     sig("kamd_pipeline_load_batch", C.c_int, [vp, fp, i64p, C.c_int])
@@ -214,7 +222,8 @@ kamd_decoder_reached_final kamd_decoder_lattice_size kamd_decoder_get_raw_lattic
 kamd_decoder_best_path kamd_decoder_partial_best_path kamd_decoder_get_trace kamd_decoder_get_counters
 kamd_decoder_partial_best_paths kamd_endpoint_config_default kamd_endpoint_detected kamd_decoder_set_silence_phones kamd_decoder_trailing_silence_frames kamd_decoder_endpoint_detected
 kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch kamd_pipeline_set_ivectors kamd_pipeline_set_online_ivectors
-kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features""".split()
+kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features
+kamd_decoder_queue_configure kamd_decoder_queue_launch kamd_decoder_queue_poll kamd_decoder_queue_result kamd_decoder_queue_fetch_lattice kamd_decoder_queue_wait kamd_lattice_best_path""".split()
 
 
 def check(rc):

@@ -1042,10 +1042,8 @@ __global__ void ArcPdfKernel(const kamd_arc *arcs, long long n, const int *tid2p
 
 // ------------------------------------------------------------------ kernels
 // InitDecoding (lattice-faster-decoder.cc:56-73): start token + ProcessNonemitting(beam)
-__global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
-  __shared__ Sh sh;
-  const int lane = lanes[blockIdx.x];
-  const Ctx c = MakeCtx(d, lane);
+__device__ __forceinline__ void InitLane(const DecDev &d, const Ctx &c, Sh *shp) {
+  Sh &sh = *shp;
   InitSh(&sh);
   LaneState *S = c.st;
   if (threadIdx.x == 0) {
@@ -1060,15 +1058,19 @@ __global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
     HashInsert(d, c, &sh, d.g.start_flagged, 0.0f, &imp, 0);
   }
   __syncthreads();
-  Tbl tbl; tbl.LH = NULL; tbl.lcap = 0; tbl.lslots = NULL;     // InitKernel has no LDS table: level 2 only
+  Tbl tbl; tbl.LH = NULL; tbl.lcap = 0; tbl.lslots = NULL;     // InitDecoding has no LDS table: level 2 only
   CommitFrame(d, c, &sh, tbl, d.cfg.beam, 0, 0, NULL, 0, 0);
   PublishLaneEnd(d, c, &sh, 0);
 }
+__global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
+  __shared__ Sh sh;
+  const Ctx c = MakeCtx(d, lanes[blockIdx.x]);
+  InitLane(d, c, &sh);
+}
 
 // AdvanceDecoding (lattice-faster-decoder.cc:593-632): the frame loop of one lane.
-__global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_task *tasks) {
-  __shared__ Sh sh;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+__device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *shp, unsigned char *dyn_lds, const kamd_decode_task &task) {
+  Sh &sh = *shp;
   int *big_tok = reinterpret_cast<int *>(dyn_lds);            // [BIGCAP] token (index in list)
   u32 *big_a0 = reinterpret_cast<u32 *>(big_tok + BIGCAP);     // [BIGCAP] first emitting arc
   int *big_scan = reinterpret_cast<int *>(big_a0 + BIGCAP);    // [BIGCAP] degree -> exclusive scan
@@ -1081,8 +1083,6 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
   tbl.lcap = d.lds_table_cap;
   tbl.lslots = reinterpret_cast<unsigned short *>(tbl.LH + tbl.lcap);
   for (int i = threadIdx.x; i < tbl.lcap; i += NT) tbl.LH[i] = EMPTY64;
-  const kamd_decode_task task = tasks[blockIdx.x];
-  const Ctx c = MakeCtx(d, task.lane);
   const int tid = threadIdx.x;
   InitSh(&sh);
   LaneState *S = c.st;
@@ -1337,6 +1337,13 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
     if (err_now) { frame++; break; }
   }
   PublishLaneEnd(d, c, &sh, frame);
+}
+__global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_task *tasks) {
+  __shared__ Sh sh;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  const kamd_decode_task task = tasks[blockIdx.x];
+  const Ctx c = MakeCtx(d, task.lane);
+  AdvanceLane(d, c, &sh, dyn_lds, task);
 }
 
 // FinalizeDecoding (lattice-faster-decoder.cc:638-653) = PruneForwardLinksFinal (:389-471)
@@ -1610,11 +1617,11 @@ __device__ inline LinkLite Lite(const Link &L, int src_base, int dst_base) {
 //    so chaotic relaxation reaches the same unique fixpoint as the Jacobi form).
 // Output: tokens in tok_state / tok_map (cost bits) at [out_tok_base, tok_cap), frame by
 // frame; links at [out_lnk_base, lnk_cap) with src/dst = arena positions of the tokens.
-__global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes) {
-  __shared__ Sh sh;
-  __shared__ int s_tok_top, s_lnk_top, s_chg[3];
-  const int lane = lanes[blockIdx.x];
-  const Ctx c = MakeCtx(d, lane);
+struct FinSh { int tok_top, lnk_top, chg[3]; };
+__device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh *shp, FinSh *fs, unsigned char *fin_lds) {
+  Sh &sh = *shp;
+  int &s_tok_top = fs->tok_top, &s_lnk_top = fs->lnk_top;
+  int *s_chg = fs->chg;
   const int tid = threadIdx.x;
   InitSh(&sh);
   LaneState *S = c.st;
@@ -1628,10 +1635,11 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
   const u32 INF_O = FloatToOrdered(INFINITY);
   u32 *bo = reinterpret_cast<u32 *>(c.scratch);                 // HBM mode: base + emitting
   u32 *xo = reinterpret_cast<u32 *>(c.scratch) + d.hash_cap;    // HBM mode: Jacobi target
-  int *gpos[2] = {c.slot_tok, reinterpret_cast<int *>(c.stamp)}; // HBM mode: frame-local token -> staged position
+  // HBM mode: frame-local token -> staged position.  (Not c.stamp: the epsilon-closure stamps must survive into the
+  // lane's next utterance, a stale position equal to a later round number would suppress a re-queue.)
+  int *gpos[2] = {c.slot_tok, reinterpret_cast<int *>(c.wl1)};
   int *new_off = reinterpret_cast<int *>(c.wl0);                 // [F+2] staged start of every frame
   float *stage_cost = reinterpret_cast<float *>(c.tok_map);
-  extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
   // LDS: [2] ordered extra costs, [2] forward costs, [2] staged positions (frame f / frame f+1)
   u32 *l_base = reinterpret_cast<u32 *>(fin_lds);
   if (tid == 0) { s_tok_top = c.tok_cap; s_lnk_top = c.lnk_cap; new_off[F + 1] = c.tok_cap; s_chg[0] = s_chg[1] = s_chg[2] = 0; }
@@ -1941,6 +1949,118 @@ __global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes
     S->error |= sh.err;
   }
 }
+__global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes) {
+  __shared__ Sh sh;
+  __shared__ FinSh fs;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
+  const Ctx c = MakeCtx(d, lanes[blockIdx.x]);
+  FinalizeLane2(d, c, &sh, &fs, fin_lds);
+}
+
+// ---------------------------------------------------------------- work queue
+// Test-set decoding: R resident lanes (one workgroup = one CU each) pull utterances from a
+// device-side queue until it is empty, so a launch no longer lasts as long as its longest
+// utterance and every CU stays busy while work is left.  This is the GPU form of
+// NnetBatchDecoder's decoder threads (nnet3/nnet-batch-compute.cc:1156-1215 Decode(): each
+// thread takes the next utterance, InitDecoding / AdvanceDecoding / FinalizeDecoding, hands
+// the lattice on) and of decode.sh's --nj jobs (steps/nnet3/decode.sh:96,123).
+// Per utterance the lane runs InitLane, AdvanceLane, FinalizeLane2 and then copies the pruned
+// raw lattice out of its (reused) arenas into one contiguous blob of a device pool:
+//   [frame_off int32 x (F+2)] [tok_state int32 x nt] [tok_cost f32 x nt]
+//   [last_final f32 x n_last] [links 24 B x nl]     (link endpoints = lattice-local indices)
+// and publishes a record in host-visible memory (system-scope release), which the host polls
+// while the kernel is still running: D2H of finished lattices and the host tail (best path,
+// determinization) overlap with the search.
+struct QueueDev {
+  const kamd_queue_task *tasks; int n_tasks;
+  int *head;                         // next task to hand out (device)
+  int *done_count;                   // finished utterances (device)
+  unsigned char *pool; unsigned long long pool_cap; unsigned long long *pool_used;
+  kamd_queue_result *results;        // [n_tasks] host-visible, indexed by task.utt
+  int *done_ring;                    // [n_tasks] host-visible: utt + 1 in completion order (0 = not yet)
+};
+enum { ERR_POOL = 64 };
+
+__global__ __launch_bounds__(NT) void DecodeQueueKernel(DecDev d, QueueDev q) {
+  __shared__ Sh sh;
+  __shared__ FinSh fs;
+  __shared__ int s_task;
+  __shared__ unsigned long long s_off;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  const int tid = threadIdx.x;
+  const int lane = blockIdx.x;
+  const Ctx c = MakeCtx(d, lane);
+  LaneState *S = c.st;
+  for (;;) {
+    if (tid == 0) s_task = __hip_atomic_fetch_add(q.head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ti = s_task;
+    if (ti >= q.n_tasks) break;
+    const kamd_queue_task qt = q.tasks[ti];
+    kamd_decode_task task;
+    task.lane = lane; task.n_frames = qt.n_frames; task.d_loglikes = qt.d_loglikes; task.ld = qt.ld; task.reserved = 0;
+    InitLane(d, c, &sh);
+    __syncthreads();
+    AdvanceLane(d, c, &sh, dyn_lds, task);
+    __syncthreads();
+    FinalizeLane2(d, c, &sh, &fs, dyn_lds);
+    __syncthreads();
+    // ---- hand the lattice out
+    const int err = S->error, F = S->frame;
+    const int nt = err ? 0 : S->out_ntok, nl = err ? 0 : S->out_nlink;
+    const int tbase = S->out_tok_base, lbase = S->out_lnk_base;
+    const int n_last = err ? 0 : c.tok_off[F + 1] - c.tok_off[F];
+    const unsigned long long bytes = err ? 0ull : ((static_cast<unsigned long long>(F + 2) + 2ull * nt + n_last + 6ull * nl) * 4ull + 15ull) & ~15ull;
+    if (tid == 0) s_off = bytes ? __hip_atomic_fetch_add(q.pool_used, bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    __syncthreads();
+    const unsigned long long off = s_off;
+    const bool fits = off + bytes <= q.pool_cap;
+    if (bytes && fits) {
+      int *o_off = reinterpret_cast<int *>(q.pool + off);
+      int *o_state = o_off + (F + 2);
+      float *o_cost = reinterpret_cast<float *>(o_state + nt);
+      float *o_final = o_cost + nt;
+      int *o_link = reinterpret_cast<int *>(o_final + n_last);
+      for (int f = tid; f <= F + 1; f += NT) o_off[f] = c.tok_off[f];
+      const float *stage_cost = reinterpret_cast<const float *>(c.tok_map);
+      for (int i = tid; i < nt; i += NT) { o_state[i] = c.tok_state[tbase + i]; o_cost[i] = stage_cost[tbase + i]; }
+      const int lb = c.tok_off[F];
+      for (int i = tid; i < n_last; i += NT) o_final[i] = d.g.final[c.tok_state[tbase + lb + i]];
+      const int *lsrc = reinterpret_cast<const int *>(c.links + lbase);
+      for (int i = tid; i < 6 * nl; i += NT) {
+        int v = lsrc[i];
+        const int fld = i % 6;
+        if (fld < 2) v -= tbase;            // src / dst: arena position -> lattice-local index
+        o_link[i] = v;
+      }
+    }
+    // every wavefront's stores must have left the CU before the record is published
+    DrainStores();
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: L2 write-back, the copy engine reads HBM
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      kamd_queue_result *r = q.results + qt.utt;
+      r->error = err | ((bytes && !fits) ? ERR_POOL : 0);
+      r->lane = lane; r->n_frames = F; r->n_tok = fits ? nt : 0; r->n_link = fits ? nl : 0; r->n_last = fits ? n_last : 0;
+      r->final_relative_cost = S->final_relative_cost; r->final_best_cost = S->final_best_cost;
+      r->blob_off = static_cast<long long>(off); r->blob_bytes = fits ? static_cast<long long>(bytes) : 0;
+      for (int i = 0; i < 8; i++) r->counters[i] = S->counters[i];
+      for (int i = 0; i < 16; i++) r->phase_cycles[i] = S->phase_cycles[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int k = __hip_atomic_fetch_add(q.done_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&r->status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&q.done_ring[k], qt.utt + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (err) {
+      // an overflow can leave level-2 table words behind that no slot list names: wipe the lane's table
+      for (int i = tid; i < d.hash_cap; i += NT) __hip_atomic_store(&c.H[i], EMPTY64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      DrainStores();
+    }
+    __syncthreads();
+  }
+}
 
 // Best path WITHOUT finalizing (LatticeFasterOnlineDecoderTpl::BestPathEnd +
 // TraceBackBestPath, decoder/lattice-faster-online-decoder.cc:78-165): pick the best
@@ -2094,6 +2214,15 @@ struct Decoder {
   hipStream_t last_stream = NULL;
   void *d_path = NULL; int path_cap = 0;   // partial best path: {n, final cost, pad} + arcs
   unsigned char *d_sil_tid = NULL; int n_sil_tids = 0; int *d_sil_out = NULL; int sil_out_cap = 0;   // endpointing
+  // work queue (kamd_decoder_queue_*)
+  unsigned char *d_pool = NULL; unsigned long long pool_cap = 0;
+  unsigned long long *d_pool_used = NULL; int *d_qctl = NULL;       // d_qctl[0] = head, [1] = done count
+  kamd_queue_task *d_qtasks = NULL; int qtasks_cap = 0;
+  kamd_queue_result *h_results = NULL; int *h_ring = NULL; int ring_cap = 0;   // host-visible (hipHostMalloc, coherent)
+  int q_n = 0, q_next = 0, q_lanes = 0;
+  hipEvent_t qev[2] = {};
+  hipStream_t q_stream = NULL;
+  bool split_uniform = true;
   // host copy of one lane's lattice (canonical), cached by lane
   int cached_lane = -1;
   std::vector<int32_t> lat_frame, lat_hclg; std::vector<float> lat_cost, lat_final;
@@ -2293,7 +2422,11 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, d.lds_table_cap))) != hipSuccess)
     ok = false;
+  if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::DecodeQueueKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                static_cast<int>(std::max<size_t>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, d.lds_table_cap), 6 * FIN_CAP * 4))) != hipSuccess)
+    ok = false;
   for (int i = 0; ok && i < 2 * Decoder::kMaxTimed; i++) if (hipEventCreate(&D->ev[i]) != hipSuccess) ok = false;
+  for (int i = 0; ok && i < 2; i++) if (hipEventCreate(&D->qev[i]) != hipSuccess) ok = false;
   if (!ok) {
     kamd::SetError(KAMD_ERR_HIP, "decoder allocation failed (%zu lanes): %s", L, hipGetErrorString(hipGetLastError()));
     kamd_decoder_destroy(reinterpret_cast<kamd_decoder *>(D));
@@ -2313,6 +2446,13 @@ void kamd_decoder_destroy(kamd_decoder *h) {
   if (D->d_lanes) (void)hipFree(D->d_lanes);
   if (D->d_tasks) (void)hipFree(D->d_tasks);
   for (int i = 0; i < 2 * Decoder::kMaxTimed; i++) if (D->ev[i]) (void)hipEventDestroy(D->ev[i]);
+  if (D->d_pool) (void)hipFree(D->d_pool);
+  if (D->d_pool_used) (void)hipFree(D->d_pool_used);
+  if (D->d_qctl) (void)hipFree(D->d_qctl);
+  if (D->d_qtasks) (void)hipFree(D->d_qtasks);
+  if (D->h_results) (void)hipHostFree(D->h_results);
+  if (D->h_ring) (void)hipHostFree(D->h_ring);
+  for (int i = 0; i < 2; i++) if (D->qev[i]) (void)hipEventDestroy(D->qev[i]);
   delete D;
 }
 
@@ -2340,6 +2480,22 @@ int kamd_decoder_reserve(kamd_decoder *h, const int32_t *lane_frames, int n) {
   KAMD_HIP(hipMemcpy(D->d_lnk_base, D->h_lnk_base.data(), L * 8, hipMemcpyHostToDevice));
   KAMD_HIP(hipMemcpy(D->d_tok_cap, D->h_tok_cap.data(), L * 4, hipMemcpyHostToDevice));
   KAMD_HIP(hipMemcpy(D->d_lnk_cap, D->h_lnk_cap.data(), L * 4, hipMemcpyHostToDevice));
+  D->split_uniform = false;
+  return KAMD_OK;
+}
+
+static int ReserveUniform(Decoder *D) {
+  if (D->split_uniform) return KAMD_OK;
+  const size_t L = D->sizes.max_lanes, at = D->sizes.arena_tokens, al = D->sizes.arena_links;
+  for (size_t l = 0; l < L; l++) {
+    D->h_tok_base[l] = static_cast<long long>(l * at); D->h_lnk_base[l] = static_cast<long long>(l * al);
+    D->h_tok_cap[l] = static_cast<int>(at); D->h_lnk_cap[l] = static_cast<int>(al);
+  }
+  KAMD_HIP(hipMemcpy(D->d_tok_base, D->h_tok_base.data(), L * 8, hipMemcpyHostToDevice));
+  KAMD_HIP(hipMemcpy(D->d_lnk_base, D->h_lnk_base.data(), L * 8, hipMemcpyHostToDevice));
+  KAMD_HIP(hipMemcpy(D->d_tok_cap, D->h_tok_cap.data(), L * 4, hipMemcpyHostToDevice));
+  KAMD_HIP(hipMemcpy(D->d_lnk_cap, D->h_lnk_cap.data(), L * 4, hipMemcpyHostToDevice));
+  D->split_uniform = true;
   return KAMD_OK;
 }
 
@@ -2678,7 +2834,68 @@ int kamd_decoder_get_trace(kamd_decoder *h, int lane, int32_t *ntok, float *cuto
   return n;
 }
 
-// GetRawLattice (lattice-faster-decoder.cc:113-196) from the compacted device arrays.
+// GetRawLattice (lattice-faster-decoder.cc:113-196): canonical numbering of the surviving tokens / links.
+// st / co: [nt] HCLG state and forward cost in arena order (frame by frame, toff[f] = first token of frame f);
+// last_final: final cost of every token of frame F in arena order; lk: links whose endpoints are indices
+// into st (after subtracting link_index_base).
+struct RawLat {
+  std::vector<int32_t> frame, hclg; std::vector<float> cost, fin; std::vector<kamd_lat_arc> arcs;
+  int start = -1, frames = 0;
+};
+static int Canonicalize(int nt, int nl, int F, const int *st, const float *co, const int *toff, const float *last_final,
+                        const kamd::Link *lk, int link_index_base, int graph_start, RawLat *out) {
+  std::vector<float> fin(nt, INFINITY);
+  std::vector<int32_t> lat_frame(nt, 0);
+  for (int f = 0; f <= F; f++)
+    for (int i = toff[f]; i < toff[f + 1] && i < nt; i++) lat_frame[i] = f;
+  // every frame must keep a token or the reference produces no lattice (:145-149)
+  bool empty_frame = false;
+  for (int f = 0; f <= F; f++) if (toff[f + 1] <= toff[f]) empty_frame = true;
+  {
+    const int lb = toff[F], le = std::min(toff[F + 1], nt);
+    bool any = false;
+    for (int i = lb; i < le; i++) if (last_final[i - lb] != INFINITY) any = true;
+    // :183-192: final weight = final_cost if any final token exists, else One()
+    // (any is evaluated over ALL last-frame tokens in the reference, i.e. before pruning;
+    //  a surviving non-final set with finals_empty false cannot occur: non-final tokens
+    //  get extra_cost = +inf on the last frame when finals exist.)
+    for (int i = lb; i < le; i++) fin[i] = any ? last_final[i - lb] : 0.0f;
+  }
+  // canonical numbering: by (frame, HCLG state)
+  std::vector<int> order(nt), inv(nt);
+  for (int i = 0; i < nt; i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) {
+    if (lat_frame[a] != lat_frame[b]) return lat_frame[a] < lat_frame[b];
+    return st[a] < st[b];
+  });
+  for (int i = 0; i < nt; i++) inv[order[i]] = i;
+  out->frame.resize(nt); out->hclg.resize(nt); out->cost.resize(nt); out->fin.resize(nt);
+  for (int i = 0; i < nt; i++) { out->frame[i] = lat_frame[order[i]]; out->hclg[i] = st[order[i]]; out->cost[i] = co[order[i]]; out->fin[i] = fin[order[i]]; }
+  out->arcs.resize(nl);
+  for (int i = 0; i < nl; i++) {
+    kamd_lat_arc a;
+    const int ls = lk[i].src - link_index_base, ld = lk[i].dst - link_index_base;
+    if (ls < 0 || ls >= nt || ld < 0 || ld >= nt) return kamd::SetError(KAMD_ERR_STATE, "lattice link %d out of range", i);
+    a.src = inv[ls]; a.dst = inv[ld]; a.ilabel = lk[i].ilabel; a.olabel = lk[i].olabel;
+    a.graph_cost = lk[i].graph; a.acoustic_cost = lk[i].ac;
+    out->arcs[i] = a;
+  }
+  std::sort(out->arcs.begin(), out->arcs.end(), [](const kamd_lat_arc &a, const kamd_lat_arc &b) {
+    if (a.src != b.src) return a.src < b.src;
+    if (a.dst != b.dst) return a.dst < b.dst;
+    if (a.ilabel != b.ilabel) return a.ilabel < b.ilabel;
+    if (a.olabel != b.olabel) return a.olabel < b.olabel;
+    if (a.graph_cost != b.graph_cost) return a.graph_cost < b.graph_cost;
+    return a.acoustic_cost < b.acoustic_cost;
+  });
+  out->start = -1;
+  for (int i = 0; i < nt && out->frame[i] == 0; i++)
+    if (out->hclg[i] == graph_start) out->start = i;
+  out->frames = F;
+  if (empty_frame) { out->frame.clear(); out->hclg.clear(); out->cost.clear(); out->fin.clear(); out->arcs.clear(); out->start = -1; }
+  return KAMD_OK;
+}
+
 static int FetchLattice(Decoder *D, int lane) {
   if (D->cached_lane == lane) return KAMD_OK;
   if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
@@ -2698,61 +2915,15 @@ static int FetchLattice(Decoder *D, int lane) {
   }
   KAMD_HIP(hipMemcpy(toff.data(), D->dev.tok_off + lane * (mf + 2), (F + 2) * 4, hipMemcpyDeviceToHost));
   if (nl) KAMD_HIP(hipMemcpy(lk.data(), D->dev.links + lbase, nl * sizeof(kamd::Link), hipMemcpyDeviceToHost));
-  // final costs need the graph's final vector for the last frame's states
-  std::vector<float> fin(nt, INFINITY);
-  D->lat_frame.assign(nt, 0);
-  for (int f = 0; f <= F; f++)
-    for (int i = toff[f]; i < toff[f + 1] && i < nt; i++) D->lat_frame[i] = f;
-  // every frame must keep a token or the reference produces no lattice (:145-149)
-  bool empty_frame = false;
-  for (int f = 0; f <= F; f++) if (toff[f + 1] <= toff[f]) empty_frame = true;
-  {
-    const int lb = toff[F], le = std::min(toff[F + 1], nt);
-    bool any = false;
-    std::vector<float> fc(std::max(0, le - lb));
-    for (int i = lb; i < le; i++) {
-      KAMD_HIP(hipMemcpy(&fc[i - lb], D->g->dev.final + st[i], 4, hipMemcpyDeviceToHost));
-      if (fc[i - lb] != INFINITY) any = true;
-    }
-    // :183-192: final weight = final_cost if any final token exists, else One()
-    // (any is evaluated over ALL last-frame tokens in the reference, i.e. before pruning;
-    //  a surviving non-final set with finals_empty false cannot occur: non-final tokens
-    //  get extra_cost = +inf on the last frame when finals exist.)
-    for (int i = lb; i < le; i++) fin[i] = any ? fc[i - lb] : 0.0f;
-  }
-  // canonical numbering: by (frame, HCLG state)
-  std::vector<int> order(nt), inv(nt);
-  for (int i = 0; i < nt; i++) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](int a, int b) {
-    if (D->lat_frame[a] != D->lat_frame[b]) return D->lat_frame[a] < D->lat_frame[b];
-    return st[a] < st[b];
-  });
-  for (int i = 0; i < nt; i++) inv[order[i]] = i;
-  std::vector<int32_t> fr(nt), hc(nt); std::vector<float> cs(nt), fn(nt);
-  for (int i = 0; i < nt; i++) { fr[i] = D->lat_frame[order[i]]; hc[i] = st[order[i]]; cs[i] = co[order[i]]; fn[i] = fin[order[i]]; }
-  D->lat_frame.swap(fr); D->lat_hclg.swap(hc); D->lat_cost.swap(cs); D->lat_final.swap(fn);
-  D->lat_arcs.resize(nl);
-  for (int i = 0; i < nl; i++) {
-    kamd_lat_arc a;
-    const int ls = lk[i].src - S.out_tok_base, ld = lk[i].dst - S.out_tok_base;
-    if (ls < 0 || ls >= nt || ld < 0 || ld >= nt) return kamd::SetError(KAMD_ERR_STATE, "lane %d: lattice link %d out of range", lane, i);
-    a.src = inv[ls]; a.dst = inv[ld]; a.ilabel = lk[i].ilabel; a.olabel = lk[i].olabel;
-    a.graph_cost = lk[i].graph; a.acoustic_cost = lk[i].ac;
-    D->lat_arcs[i] = a;
-  }
-  std::sort(D->lat_arcs.begin(), D->lat_arcs.end(), [](const kamd_lat_arc &a, const kamd_lat_arc &b) {
-    if (a.src != b.src) return a.src < b.src;
-    if (a.dst != b.dst) return a.dst < b.dst;
-    if (a.ilabel != b.ilabel) return a.ilabel < b.ilabel;
-    if (a.olabel != b.olabel) return a.olabel < b.olabel;
-    if (a.graph_cost != b.graph_cost) return a.graph_cost < b.graph_cost;
-    return a.acoustic_cost < b.acoustic_cost;
-  });
-  D->lat_start = -1;
-  for (int i = 0; i < nt && D->lat_frame[i] == 0; i++)
-    if (D->lat_hclg[i] == D->g->dev.start) D->lat_start = i;
-  D->lat_frames = F;
-  if (empty_frame) { D->lat_frame.clear(); D->lat_hclg.clear(); D->lat_cost.clear(); D->lat_final.clear(); D->lat_arcs.clear(); D->lat_start = -1; }
+  // final costs of the last frame's states
+  const int lb = toff[F], le = std::min(toff[F + 1], nt);
+  std::vector<float> fc(std::max(0, le - lb));
+  for (int i = lb; i < le; i++) KAMD_HIP(hipMemcpy(&fc[i - lb], D->g->dev.final + st[i], 4, hipMemcpyDeviceToHost));
+  RawLat R;
+  const int rc = Canonicalize(nt, nl, F, st.data(), co.data(), toff.data(), fc.data(), lk.data(), S.out_tok_base, D->g->dev.start, &R);
+  if (rc != KAMD_OK) return rc;
+  D->lat_frame.swap(R.frame); D->lat_hclg.swap(R.hclg); D->lat_cost.swap(R.cost); D->lat_final.swap(R.fin);
+  D->lat_arcs.swap(R.arcs); D->lat_start = R.start; D->lat_frames = R.frames;
   D->cached_lane = lane;
   return KAMD_OK;
 }
@@ -2789,31 +2960,34 @@ static inline bool LatBetter(float a1, float a2, float b1, float b2) {
   return a1 < b1;
 }
 
-int kamd_decoder_best_path(kamd_decoder *h, int lane, int32_t *alignment, int ali_cap, int *ali_len,
-                           int32_t *words, int words_cap, int *words_len, float *graph_cost,
-                           float *acoustic_cost) {
-  Decoder *D = reinterpret_cast<Decoder *>(h);
-  int rc = FetchLattice(D, lane);
-  if (rc != KAMD_OK) return rc;
+int kamd_lattice_best_path(int32_t n, int32_t start, const float *state_final, const kamd_lat_arc *A, int32_t m,
+                           int32_t *alignment, int ali_cap, int *ali_len, int32_t *words, int words_cap, int *words_len,
+                           float *graph_cost, float *acoustic_cost) {
   *ali_len = 0; *words_len = 0; *graph_cost = INFINITY; *acoustic_cost = INFINITY;
-  const int n = static_cast<int>(D->lat_frame.size()), m = static_cast<int>(D->lat_arcs.size());
-  if (n == 0 || D->lat_start < 0) return kamd::SetError(KAMD_ERR_STATE, "empty lattice");
-  const std::vector<kamd_lat_arc> &A = D->lat_arcs;   // sorted by src: CSR on the fly
-  std::vector<int> first(n + 1, 0), indeg(n, 0);
-  for (int i = 0; i < m; i++) { first[A[i].src + 1]++; indeg[A[i].dst]++; }
+  if (n <= 0 || start < 0 || start >= n) return kamd::SetError(KAMD_ERR_STATE, "empty lattice");
+  // arcs need not be sorted: CSR by source
+  std::vector<int> first(n + 1, 0), indeg(n, 0), by_src(m);
+  for (int i = 0; i < m; i++) {
+    if (A[i].src < 0 || A[i].src >= n || A[i].dst < 0 || A[i].dst >= n) return kamd::SetError(KAMD_ERR_ARG, "lattice arc %d out of range", i);
+    first[A[i].src + 1]++; indeg[A[i].dst]++;
+  }
   for (int s = 0; s < n; s++) first[s + 1] += first[s];
+  {
+    std::vector<int> fill(first.begin(), first.end() - 1);
+    for (int i = 0; i < m; i++) by_src[fill[A[i].src]++] = i;
+  }
   std::vector<float> d1(n, INFINITY), d2(n, INFINITY);
   std::vector<int> back(n, -1), stack;
   for (int s = n - 1; s >= 0; s--) if (indeg[s] == 0) stack.push_back(s);
-  d1[D->lat_start] = 0.0f; d2[D->lat_start] = 0.0f;
+  d1[start] = 0.0f; d2[start] = 0.0f;
   size_t visited = 0;
   while (!stack.empty()) {
     int s = stack.back(); stack.pop_back(); visited++;
     for (int k = first[s]; k < first[s + 1]; k++) {
-      const kamd_lat_arc &a = A[k];
+      const kamd_lat_arc &a = A[by_src[k]];
       if (d1[s] != INFINITY) {
         float n1 = d1[s] + a.graph_cost, n2 = d2[s] + a.acoustic_cost;
-        if (d1[a.dst] == INFINITY || LatBetter(n1, n2, d1[a.dst], d2[a.dst])) { d1[a.dst] = n1; d2[a.dst] = n2; back[a.dst] = k; }
+        if (d1[a.dst] == INFINITY || LatBetter(n1, n2, d1[a.dst], d2[a.dst])) { d1[a.dst] = n1; d2[a.dst] = n2; back[a.dst] = by_src[k]; }
       }
       if (--indeg[a.dst] == 0) stack.push_back(a.dst);
     }
@@ -2821,8 +2995,8 @@ int kamd_decoder_best_path(kamd_decoder *h, int lane, int32_t *alignment, int al
   if (visited != static_cast<size_t>(n)) return kamd::SetError(KAMD_ERR_STATE, "lattice has a cycle");
   int best = -1; float b1 = INFINITY, b2 = INFINITY;
   for (int s = 0; s < n; s++) {
-    if (D->lat_final[s] == INFINITY || d1[s] == INFINITY) continue;
-    float t1 = d1[s] + D->lat_final[s], t2 = d2[s];
+    if (state_final[s] == INFINITY || d1[s] == INFINITY) continue;
+    float t1 = d1[s] + state_final[s], t2 = d2[s];
     if (best == -1 || LatBetter(t1, t2, b1, b2)) { best = s; b1 = t1; b2 = t2; }
   }
   if (best == -1) return kamd::SetError(KAMD_ERR_STATE, "no path to a final lattice state");
@@ -2835,6 +3009,162 @@ int kamd_decoder_best_path(kamd_decoder *h, int lane, int32_t *alignment, int al
     if (a.olabel != 0) { if (*words_len < words_cap) words[*words_len] = a.olabel; (*words_len)++; }
   }
   *graph_cost = b1; *acoustic_cost = b2;
+  return KAMD_OK;
+}
+
+int kamd_decoder_best_path(kamd_decoder *h, int lane, int32_t *alignment, int ali_cap, int *ali_len,
+                           int32_t *words, int words_cap, int *words_len, float *graph_cost,
+                           float *acoustic_cost) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  int rc = FetchLattice(D, lane);
+  if (rc != KAMD_OK) return rc;
+  return kamd_lattice_best_path(static_cast<int32_t>(D->lat_frame.size()), D->lat_start, D->lat_final.data(), D->lat_arcs.data(),
+                                static_cast<int32_t>(D->lat_arcs.size()), alignment, ali_cap, ali_len, words, words_cap, words_len,
+                                graph_cost, acoustic_cost);
+}
+
+// ---------------------------------------------------------------- work queue (host)
+int kamd_decoder_queue_configure(kamd_decoder *h, int64_t pool_bytes) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (pool_bytes < 4096) return kamd::SetError(KAMD_ERR_ARG, "lattice pool too small");
+  if (static_cast<unsigned long long>(pool_bytes) <= D->pool_cap) return KAMD_OK;
+  if (D->d_pool) (void)hipFree(D->d_pool);
+  D->d_pool = NULL; D->pool_cap = 0;
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_pool), static_cast<size_t>(pool_bytes)));
+  D->pool_cap = static_cast<unsigned long long>(pool_bytes);
+  return KAMD_OK;
+}
+
+int kamd_decoder_queue_launch(kamd_decoder *h, const kamd_queue_task *tasks, int n, int resident_lanes, void *stream) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty queue");
+  for (int i = 0; i < n; i++) {
+    if (tasks[i].n_frames < 0 || tasks[i].n_frames > D->sizes.max_frames)
+      return kamd::SetError(KAMD_ERR_ARG, "task %d: %d frames (max_frames %d)", i, tasks[i].n_frames, D->sizes.max_frames);
+    if (tasks[i].utt < 0 || tasks[i].utt >= n) return kamd::SetError(KAMD_ERR_ARG, "task %d: utterance index %d outside [0, %d)", i, tasks[i].utt, n);
+  }
+  int cus = 0;
+  {
+    int dev = 0; hipDeviceProp_t prop;
+    KAMD_HIP(hipGetDevice(&dev));
+    KAMD_HIP(hipGetDeviceProperties(&prop, dev));
+    cus = prop.multiProcessorCount;
+  }
+  int R = resident_lanes > 0 ? resident_lanes : cus;
+  R = std::min(std::min(R, n), D->sizes.max_lanes);
+  if (R < 1) return kamd::SetError(KAMD_ERR_ARG, "no resident lanes");
+  if (ReserveUniform(D) != KAMD_OK) return KAMD_ERR_HIP;
+  if (!D->d_pool && kamd_decoder_queue_configure(h, 1ll << 30) != KAMD_OK) return KAMD_ERR_HIP;
+  if (!D->d_pool_used) {
+    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_pool_used), 8));
+    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_qctl), 2 * sizeof(int)));
+  }
+  if (n > D->qtasks_cap) {
+    if (D->d_qtasks) (void)hipFree(D->d_qtasks);
+    D->d_qtasks = NULL; D->qtasks_cap = 0;
+    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_qtasks), static_cast<size_t>(n) * sizeof(kamd_queue_task)));
+    D->qtasks_cap = n;
+  }
+  if (n > D->ring_cap) {
+    if (D->h_results) (void)hipHostFree(D->h_results);
+    if (D->h_ring) (void)hipHostFree(D->h_ring);
+    D->h_results = NULL; D->h_ring = NULL; D->ring_cap = 0;
+    KAMD_HIP(hipHostMalloc(reinterpret_cast<void **>(&D->h_results), static_cast<size_t>(n) * sizeof(kamd_queue_result), hipHostMallocCoherent | hipHostMallocMapped));
+    KAMD_HIP(hipHostMalloc(reinterpret_cast<void **>(&D->h_ring), static_cast<size_t>(n) * sizeof(int), hipHostMallocCoherent | hipHostMallocMapped));
+    D->ring_cap = n;
+  }
+  memset(D->h_results, 0, static_cast<size_t>(n) * sizeof(kamd_queue_result));
+  memset(D->h_ring, 0, static_cast<size_t>(n) * sizeof(int));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KAMD_HIP(hipMemsetAsync(D->d_pool_used, 0, 8, st));
+  KAMD_HIP(hipMemsetAsync(D->d_qctl, 0, 2 * sizeof(int), st));
+  KAMD_HIP(hipMemcpyAsync(D->d_qtasks, tasks, static_cast<size_t>(n) * sizeof(kamd_queue_task), hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));      // `tasks` is the caller's (pageable) memory
+  kamd::QueueDev q;
+  q.tasks = D->d_qtasks; q.n_tasks = n; q.head = D->d_qctl; q.done_count = D->d_qctl + 1;
+  q.pool = D->d_pool; q.pool_cap = D->pool_cap; q.pool_used = D->d_pool_used;
+  void *dp = NULL;
+  KAMD_HIP(hipHostGetDevicePointer(&dp, D->h_results, 0));
+  q.results = static_cast<kamd_queue_result *>(dp);
+  KAMD_HIP(hipHostGetDevicePointer(&dp, D->h_ring, 0));
+  q.done_ring = static_cast<int *>(dp);
+  const size_t lds = std::max<size_t>(kamd::AdvanceLdsBytes(D->dev.num_pdfs_lds, D->dev.lds_table_cap), 6 * FIN_CAP * 4);
+  KAMD_HIP(hipEventRecord(D->qev[0], st));
+  hipLaunchKernelGGL(kamd::DecodeQueueKernel, dim3(R), dim3(NT), lds, st, D->dev, q);
+  KAMD_HIP(hipGetLastError());
+  KAMD_HIP(hipEventRecord(D->qev[1], st));
+  D->q_n = n; D->q_next = 0; D->q_lanes = R; D->q_stream = st; D->last_stream = st; D->cached_lane = -1;
+  return KAMD_OK;
+}
+
+int kamd_decoder_queue_poll(kamd_decoder *h, int32_t *utts, int cap) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  int got = 0;
+  while (got < cap && D->q_next < D->q_n) {
+    const int v = __atomic_load_n(&D->h_ring[D->q_next], __ATOMIC_ACQUIRE);
+    if (v == 0) break;
+    utts[got++] = v - 1;
+    D->q_next++;
+  }
+  return got;
+}
+
+int kamd_decoder_queue_result(kamd_decoder *h, int32_t utt, kamd_queue_result *out) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (utt < 0 || utt >= D->q_n) return kamd::SetError(KAMD_ERR_ARG, "utterance %d outside the queue", utt);
+  if (__atomic_load_n(&D->h_results[utt].status, __ATOMIC_ACQUIRE) != 1) return kamd::SetError(KAMD_ERR_STATE, "utterance %d has not finished", utt);
+  *out = D->h_results[utt];
+  return KAMD_OK;
+}
+
+int kamd_decoder_queue_fetch_lattice(kamd_decoder *h, int32_t utt, void *copy_stream, int32_t *num_states, int32_t *num_arcs,
+                                     int32_t *start, int32_t **state_frame, int32_t **state_hclg, float **state_cost,
+                                     float **state_final, kamd_lat_arc **arcs) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  kamd_queue_result r;
+  int rc = kamd_decoder_queue_result(h, utt, &r);
+  if (rc != KAMD_OK) return rc;
+  *num_states = 0; *num_arcs = 0; *start = -1;
+  *state_frame = NULL; *state_hclg = NULL; *state_cost = NULL; *state_final = NULL; *arcs = NULL;
+  if (r.error)
+    return kamd::SetError(KAMD_ERR_CAPACITY, "utterance %d: device capacity exceeded (flags %d:%s%s%s%s%s%s%s) at frame %d; raise kamd_decoder_sizes / the lattice pool",
+                          utt, r.error, (r.error & 1) ? " hash" : "", (r.error & 2) ? " token-arena" : "", (r.error & 4) ? " link-arena" : "",
+                          (r.error & 8) ? " max-frames" : "", (r.error & 16) ? " worklist" : "", (r.error & 32) ? " internal" : "",
+                          (r.error & 64) ? " lattice-pool" : "", r.n_frames);
+  const int F = r.n_frames, nt = r.n_tok, nl = r.n_link, n_last = r.n_last;
+  std::vector<unsigned char> blob(static_cast<size_t>(r.blob_bytes));
+  if (!blob.empty()) {
+    hipStream_t cs = static_cast<hipStream_t>(copy_stream);
+    KAMD_HIP(hipMemcpyAsync(blob.data(), D->d_pool + r.blob_off, blob.size(), hipMemcpyDeviceToHost, cs));
+    KAMD_HIP(hipStreamSynchronize(cs));
+  }
+  if (blob.size() < (static_cast<size_t>(F + 2) + 2ull * nt + n_last + 6ull * nl) * 4) return kamd::SetError(KAMD_ERR_STATE, "utterance %d: short lattice blob", utt);
+  const int *toff = reinterpret_cast<const int *>(blob.data());
+  const int *st = toff + (F + 2);
+  const float *co = reinterpret_cast<const float *>(st + nt);
+  const float *lf = co + nt;
+  const kamd::Link *lk = reinterpret_cast<const kamd::Link *>(lf + n_last);
+  RawLat R;
+  rc = Canonicalize(nt, nl, F, st, co, toff, lf, lk, 0, D->g->dev.start, &R);
+  if (rc != KAMD_OK) return rc;
+  const size_t n = R.frame.size(), m = R.arcs.size();
+  *num_states = static_cast<int32_t>(n); *num_arcs = static_cast<int32_t>(m); *start = R.start;
+  auto dup = [](const void *src, size_t bytes) -> void * { void *p = malloc(bytes ? bytes : 4); if (p && bytes) memcpy(p, src, bytes); return p; };
+  *state_frame = static_cast<int32_t *>(dup(R.frame.data(), n * 4)); *state_hclg = static_cast<int32_t *>(dup(R.hclg.data(), n * 4));
+  *state_cost = static_cast<float *>(dup(R.cost.data(), n * 4)); *state_final = static_cast<float *>(dup(R.fin.data(), n * 4));
+  *arcs = static_cast<kamd_lat_arc *>(dup(R.arcs.data(), m * sizeof(kamd_lat_arc)));
+  if (!*state_frame || !*state_hclg || !*state_cost || !*state_final || !*arcs) return kamd::SetError(KAMD_ERR_ARG, "out of host memory");
+  return KAMD_OK;
+}
+
+int kamd_decoder_queue_wait(kamd_decoder *h, float *ms, int32_t *lanes) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (D->q_n <= 0) return kamd::SetError(KAMD_ERR_STATE, "no queue launched");
+  KAMD_HIP(hipStreamSynchronize(D->q_stream));
+  float t = 0;
+  KAMD_HIP(hipEventElapsedTime(&t, D->qev[0], D->qev[1]));
+  if (ms) *ms = t;
+  if (lanes) *lanes = D->q_lanes;
   return KAMD_OK;
 }
 

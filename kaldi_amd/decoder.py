@@ -267,6 +267,46 @@ def get_raw_lattice(dec, lane):
     return Lattice(sz.start, fr, hc, co, fi, arcs, sz.num_frames)
 
 
+def queue_fetch_lattice(dec, utt, copy_stream=None):
+    """Raw lattice of a finished work-queue utterance (None: the reference would produce no lattice)."""
+    ns, na, st = C.c_int32(), C.c_int32(), C.c_int32()
+    ip, fp = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    p_fr, p_hc, p_co, p_fi, p_arcs = ip(), ip(), fp(), fp(), C.c_void_p()
+    check(lib().kamd_decoder_queue_fetch_lattice(dec, utt, copy_stream, C.byref(ns), C.byref(na), C.byref(st), C.byref(p_fr),
+                                                 C.byref(p_hc), C.byref(p_co), C.byref(p_fi), C.byref(p_arcs)))
+    n, m = ns.value, na.value
+    try:
+        if n == 0:
+            return None
+        fr = np.ctypeslib.as_array(p_fr, (n,)).copy(); hc = np.ctypeslib.as_array(p_hc, (n,)).copy()
+        co = np.ctypeslib.as_array(p_co, (n,)).copy(); fi = np.ctypeslib.as_array(p_fi, (n,)).copy()
+        arcs = np.zeros(m, abi.LAT_ARC_DTYPE)
+        if m:
+            C.memmove(arcs.ctypes.data, p_arcs, m * abi.LAT_ARC_DTYPE.itemsize)
+    finally:
+        for p in (p_fr, p_hc, p_co, p_fi):
+            lib().kamd_host_free(C.cast(p, C.c_void_p))
+        lib().kamd_host_free(p_arcs)
+    return Lattice(st.value, fr, hc, co, fi, arcs, int(fr.max()) if n else 0)
+
+
+def lattice_best_path(lat):
+    """GetBestPath of a raw Lattice held on the host (kamd_lattice_best_path)."""
+    if lat is None:
+        return None
+    cap = max(int(lat.arcs.size), 1)
+    ali, words = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    na, nw = C.c_int(), C.c_int()
+    g, a = C.c_float(), C.c_float()
+    fin = np.ascontiguousarray(lat.final, np.float32)
+    arcs = np.ascontiguousarray(lat.arcs)
+    rc = lib().kamd_lattice_best_path(int(lat.frame.size), int(lat.start), abi.fptr(fin), arcs.ctypes.data_as(C.c_void_p), int(arcs.size),
+                                      abi.iptr(ali), cap, C.byref(na), abi.iptr(words), cap, C.byref(nw), C.byref(g), C.byref(a))
+    if rc != 0:
+        return None
+    return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(), graph_cost=g.value, acoustic_cost=a.value)
+
+
 def best_path(dec, lane):
     sz = abi.LatticeSize()
     check(lib().kamd_decoder_lattice_size(dec, lane, C.byref(sz)))
@@ -386,6 +426,34 @@ class BatchDecoder:
         check(lib().kamd_decoder_finalize(self._dec, abi.iptr(lanes), n, None))
         check(lib().kamd_decoder_sync(self._dec))
         return [get_raw_lattice(self._dec, i) for i in range(n)]
+
+    def decode_queue(self, matrices, resident_lanes=0, order=None, pool_bytes=0):
+        """Work-queue decoding (kamd_decoder_queue_*): `resident_lanes` persistent lanes pull the
+        utterances (longest first unless `order` says otherwise); returns (lattices, records, kernel ms)."""
+        n = len(matrices)
+        dms = [m if isinstance(m, DeviceMatrix) else DeviceMatrix(m) for m in matrices]
+        if order is None:
+            order = sorted(range(n), key=lambda i: -dms[i].rows)
+        tasks = (abi.QueueTask * n)()
+        for k, i in enumerate(order):
+            tasks[k] = abi.QueueTask(dms[i].ptr(0), dms[i].cols, dms[i].rows, i, 0)
+        if pool_bytes:
+            check(lib().kamd_decoder_queue_configure(self._dec, pool_bytes))
+        check(lib().kamd_decoder_queue_launch(self._dec, tasks, n, resident_lanes, None))
+        ms, lanes = C.c_float(), C.c_int32()
+        check(lib().kamd_decoder_queue_wait(self._dec, C.byref(ms), C.byref(lanes)))
+        done = np.zeros(n, np.int32)
+        got = lib().kamd_decoder_queue_poll(self._dec, abi.iptr(done), n)
+        if got != n:
+            raise KamdError("queue kernel ended with %d of %d utterances published" % (got, n))
+        lats, recs = [], []
+        for i in range(n):
+            r = abi.QueueResult()
+            check(lib().kamd_decoder_queue_result(self._dec, i, C.byref(r)))
+            recs.append(r)
+            lats.append(queue_fetch_lattice(self._dec, i))
+        self.queue_order = done
+        return lats, recs, ms.value
 
     def best_path(self, lane):
         return best_path(self._dec, lane)
