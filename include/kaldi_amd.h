@@ -34,6 +34,8 @@ extern "C" {
 const char *kamd_last_error(void);
 /* library + device probe: returns number of visible HIP devices (>=0) or <0. */
 int kamd_device_count(void);
+/* compute units of the current device (0 when there is none): the natural number of resident decoder lanes */
+int kamd_device_num_cus(void);
 int kamd_set_device(int device);
 const char *kamd_version(void);
 /* HBM buffers for host languages without HIP bindings (cgo / JNI / ctypes callers):
@@ -832,6 +834,59 @@ int kamd_pipeline_get_loglikes(kamd_pipeline *p, int utt, float *out,
                                int rows_cap, int *rows, int *cols);
 int kamd_pipeline_get_features(kamd_pipeline *p, int utt, float *out,
                                int rows_cap, int *rows, int *cols);
+
+/* ------------------------------------------------ a test set per GPU ------ */
+/* NnetBatchDecoder (nnet3/nnet-batch-compute.h:606-833; AcceptInput :665, Finished :690,
+ * GetOutput :700) as used by nnet3-latgen-faster-batch (nnet3bin/nnet3-latgen-faster-batch.cc:
+ * 170-214): all utterances of a shard resident in HBM; features in one launch, the acoustic
+ * model in a few large passes, ONE work-queue launch of the decoder, and the per-utterance
+ * host tail of DecodeUtteranceLatticeFaster (decoder/decoder-wrappers.cc:217-296: best path,
+ * raw lattice, DeterminizeLatticePhonePrunedWrapper) on `host_threads` threads while the
+ * search is still running. */
+typedef struct {
+  int32_t resident_lanes;     /* decoder lanes kept busy by the queue; 0 = one per compute unit */
+  int32_t host_threads;       /* host-tail threads (NnetBatchDecoder's num_threads, :640) */
+  int32_t determinize;        /* --determinize-lattice (decoder-wrappers.cc:262-277) */
+  int32_t keep_raw_lattices;  /* keep the canonical raw lattice of every utterance on the host */
+  int64_t nnet_pass_frames;   /* input frames per acoustic-model pass */
+  int64_t lattice_pool_bytes; /* device pool the finished lattices wait in */
+  float lattice_beam;         /* determinization beam = config.lattice_beam */
+  kamd_determinize_opts det;
+} kamd_batch_opts;
+void kamd_batch_opts_default(kamd_batch_opts *o);
+typedef struct {
+  float feat_ms, nnet_ms, decode_ms;   /* device stages (HIP events) */
+  float host_tail_ms;                  /* wall time after the last utterance was published */
+  float first_result_ms;               /* wall time until the first utterance was published */
+  float total_ms;                      /* wall time of the whole run, results on the host */
+  double nnet_flops;
+  double host_thread_ms_sum;           /* CPU time spent in the host tail, all threads */
+  int32_t lanes, nnet_passes, n_failed, pad;
+} kamd_batch_stats;
+typedef struct kamd_batch_decoder kamd_batch_decoder;
+/* The stages are not owned.  tid_phone as kamd_lattice_determinize_phone_pruned (NULL: word
+ * determinization only).  The decoder's max_lanes bounds resident_lanes; every lane has the
+ * decoder's per-lane arena. */
+kamd_batch_decoder *kamd_batch_decoder_create(kamd_feat *feat, kamd_nnet *nnet, kamd_decoder *dec,
+                                              const kamd_batch_opts *opts, const int32_t *tid_phone,
+                                              int32_t num_tids);
+void kamd_batch_decoder_destroy(kamd_batch_decoder *b);
+/* AcceptInput for the whole shard: utterance u owns samples [wave_off[u], wave_off[u+1]). */
+int kamd_batch_decoder_load(kamd_batch_decoder *b, const float *waves, const int64_t *wave_off, int n_utts);
+/* Finished(): runs the shard and returns when every utterance's output is on the host.  A
+ * per-utterance failure (capacity) does not fail the run: see n_failed and _get_output. */
+int kamd_batch_decoder_run(kamd_batch_decoder *b, kamd_batch_stats *stats);
+/* GetOutput: best path (words, transition-ids, total weight) and the device record. */
+int kamd_batch_decoder_get_output(kamd_batch_decoder *b, int utt, int32_t *words, int words_cap, int *words_len,
+                                  int32_t *alignment, int ali_cap, int *ali_len, float *graph_cost,
+                                  float *acoustic_cost, kamd_queue_result *record);
+/* Borrowed pointers, valid until the next load / run / destroy. */
+int kamd_batch_decoder_get_raw_lattice(kamd_batch_decoder *b, int utt, int32_t *num_states, int32_t *num_arcs,
+                                       int32_t *start, const int32_t **state_frame, const int32_t **state_hclg,
+                                       const float **state_cost, const float **state_final,
+                                       const kamd_lat_arc **arcs);
+const kamd_compact_lattice *kamd_batch_decoder_get_compact_lattice(kamd_batch_decoder *b, int utt);
+int kamd_batch_decoder_get_loglikes(kamd_batch_decoder *b, int utt, float *out, int rows_cap, int *rows, int *cols);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ def lib():
     sig("kamd_version", C.c_char_p, [])
     sig("kamd_device_count", C.c_int, [])
     sig("kamd_set_device", C.c_int, [C.c_int])
+    sig("kamd_device_num_cus", C.c_int, [])
     sig("kamd_malloc", vp, [C.c_size_t])
     sig("kamd_free", C.c_int, [vp])
     sig("kamd_memcpy_h2d", C.c_int, [vp, vp, C.c_size_t])
@@ -158,6 +159,16 @@ def lib():
     sig("kamd_decoder_queue_fetch_lattice", C.c_int, [vp, C.c_int32, vp, ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(fp),
                                                       C.POINTER(fp), C.POINTER(vp)])
     sig("kamd_decoder_queue_wait", C.c_int, [vp, fp, ip])
+    sig("kamd_batch_opts_default", None, [C.POINTER(abi.BatchOpts)])
+    sig("kamd_batch_decoder_create", vp, [vp, vp, vp, C.POINTER(abi.BatchOpts), ip, C.c_int32])
+    sig("kamd_batch_decoder_destroy", None, [vp])
+    sig("kamd_batch_decoder_load", C.c_int, [vp, fp, i64p, C.c_int])
+    sig("kamd_batch_decoder_run", C.c_int, [vp, C.POINTER(abi.BatchStats)])
+    sig("kamd_batch_decoder_get_output", C.c_int, [vp, C.c_int, ip, C.c_int, ip, ip, C.c_int, ip, fp, fp, C.POINTER(abi.QueueResult)])
+    sig("kamd_batch_decoder_get_raw_lattice", C.c_int, [vp, C.c_int, ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(fp),
+                                                        C.POINTER(fp), C.POINTER(vp)])
+    sig("kamd_batch_decoder_get_compact_lattice", vp, [vp, C.c_int])
+    sig("kamd_batch_decoder_get_loglikes", C.c_int, [vp, C.c_int, fp, C.c_int, ip, ip])
     sig("kamd_lattice_best_path", C.c_int, [C.c_int32, C.c_int32, fp, vp, C.c_int32, ip, C.c_int, ip, ip, C.c_int, ip, fp, fp])
     sig("kamd_pipeline_create", vp, [vp, vp, vp])
     sig("kamd_pipeline_destroy", None, [vp])
@@ -223,7 +234,8 @@ kamd_decoder_best_path kamd_decoder_partial_best_path kamd_decoder_get_trace kam
 kamd_decoder_partial_best_paths kamd_endpoint_config_default kamd_endpoint_detected kamd_decoder_set_silence_phones kamd_decoder_trailing_silence_frames kamd_decoder_endpoint_detected
 kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch kamd_pipeline_set_ivectors kamd_pipeline_set_online_ivectors
 kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features
-kamd_decoder_queue_configure kamd_decoder_queue_launch kamd_decoder_queue_poll kamd_decoder_queue_result kamd_decoder_queue_fetch_lattice kamd_decoder_queue_wait kamd_lattice_best_path""".split()
+kamd_decoder_queue_configure kamd_decoder_queue_launch kamd_decoder_queue_poll kamd_decoder_queue_result kamd_decoder_queue_fetch_lattice kamd_decoder_queue_wait kamd_lattice_best_path
+kamd_device_num_cus kamd_batch_opts_default kamd_batch_decoder_create kamd_batch_decoder_destroy kamd_batch_decoder_load kamd_batch_decoder_run kamd_batch_decoder_get_output kamd_batch_decoder_get_raw_lattice kamd_batch_decoder_get_compact_lattice kamd_batch_decoder_get_loglikes""".split()
 
 
 def check(rc):

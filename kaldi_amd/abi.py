@@ -181,6 +181,21 @@ class DeterminizeOpts(C.Structure):
                 ("word_determinize", C.c_int32), ("max_loop", C.c_int32), ("retry_cutoff", C.c_float)]
 
 
+class BatchOpts(C.Structure):
+    """kamd_batch_opts."""
+    _fields_ = [("resident_lanes", C.c_int32), ("host_threads", C.c_int32), ("determinize", C.c_int32),
+                ("keep_raw_lattices", C.c_int32), ("nnet_pass_frames", C.c_int64), ("lattice_pool_bytes", C.c_int64),
+                ("lattice_beam", C.c_float), ("det", DeterminizeOpts)]
+
+
+class BatchStats(C.Structure):
+    """kamd_batch_stats."""
+    _fields_ = [("feat_ms", C.c_float), ("nnet_ms", C.c_float), ("decode_ms", C.c_float), ("host_tail_ms", C.c_float),
+                ("first_result_ms", C.c_float), ("total_ms", C.c_float), ("nnet_flops", C.c_double),
+                ("host_thread_ms_sum", C.c_double), ("lanes", C.c_int32), ("nnet_passes", C.c_int32),
+                ("n_failed", C.c_int32), ("pad", C.c_int32)]
+
+
 CLAT_ARC_DTYPE = np.dtype([("src", "<i4"), ("dst", "<i4"), ("label", "<i4"), ("graph_cost", "<f4"),
                            ("acoustic_cost", "<f4"), ("str_begin", "<i4"), ("str_len", "<i4")])
 LAT_ARC_DTYPE = np.dtype([("src", "<i4"), ("dst", "<i4"), ("ilabel", "<i4"),

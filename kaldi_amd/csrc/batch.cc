@@ -1,0 +1,381 @@
+// batch.cc -- a whole test set through the device: NnetBatchDecoder's job.
+//
+// Reference: nnet3/nnet-batch-compute.h:606-833 (NnetBatchDecoder: AcceptInput :665,
+// Finished :690, GetOutput :700; .cc:1007-1343: one compute thread feeding N decoder
+// threads, each of which decodes, determinizes and queues its output) and the binary built
+// on it, nnet3bin/nnet3-latgen-faster-batch.cc:170-214; decode.sh's --nj split
+// (steps/nnet3/decode.sh:96,123) is the same idea across processes.
+//
+// MI355X shape of the same pipeline, per GPU:
+//   1. every waveform of the shard is resident in HBM (288 GB: LibriSpeech test-clean is
+//      1.2 GB of float samples, its log-likelihood matrix 15 GB);
+//   2. features for all utterances in one launch, the acoustic model in a few passes of
+//      ~4e5 input frames (large M for the MFMA GEMMs, bounded activation memory);
+//   3. ONE work-queue launch of the decoder (kamd_decoder_queue_*): a lane per compute unit,
+//      utterances handed out longest first, finalize + lattice hand-off inside the kernel;
+//   4. the host tail -- D2H of each finished lattice on a copy stream, canonical numbering,
+//      GetBestPath, DeterminizeLatticePhonePrunedWrapper -- on a pool of host threads WHILE
+//      the kernel is still decoding the rest (decoder-wrappers.cc:201-296 is the per-utterance
+//      recipe).  Host code only; all device work goes through the C-ABI of the stages.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+
+namespace kamd {
+
+struct UttOut {
+  int done = 0, status = KAMD_OK;     // status: KAMD_OK, or the error of this utterance alone
+  std::string message;
+  kamd_queue_result rec;
+  bool have_path = false;
+  std::vector<int32_t> words, ali;
+  float graph_cost = INFINITY, ac_cost = INFINITY;
+  // raw lattice (canonical), when kept
+  int32_t num_states = 0, num_arcs = 0, start = -1;
+  int32_t *st_frame = NULL, *st_hclg = NULL; float *st_cost = NULL, *st_final = NULL; kamd_lat_arc *arcs = NULL;
+  kamd_compact_lattice *clat = NULL;
+  double host_ms = 0;
+  void Clear() {
+    free(st_frame); free(st_hclg); free(st_cost); free(st_final); free(arcs);
+    st_frame = st_hclg = NULL; st_cost = st_final = NULL; arcs = NULL;
+    if (clat) kamd_compact_lattice_destroy(clat);
+    clat = NULL; done = 0; status = KAMD_OK; have_path = false; words.clear(); ali.clear(); num_states = num_arcs = 0; start = -1;
+    host_ms = 0; message.clear();
+  }
+};
+
+struct BatchDecoder {
+  kamd_feat *feat; kamd_nnet *nnet; kamd_decoder *dec;
+  kamd_batch_opts opts;
+  std::vector<int32_t> tid_phone;
+  int device = 0;
+  int feat_dim = 0, ld_feat = 0, P = 0;
+  int n_utts = 0;
+  std::vector<int64_t> wave_off, feat_off, out_off;
+  float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL;
+  size_t waves_cap = 0, feats_cap = 0, ll_cap = 0;
+  hipStream_t s_main = NULL;
+  hipEvent_t ev[3] = {};
+  std::vector<UttOut> out;
+  // host-tail pool
+  std::vector<std::thread> workers;
+  std::vector<hipStream_t> copy_streams;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::deque<int> jobs;
+  int pending = 0;
+  bool quit = false;
+  kamd_batch_stats last = {};
+};
+
+template <typename T>
+static int GrowDev(T **p, size_t *cap, size_t need) {
+  if (need <= *cap) return KAMD_OK;
+  if (*p) (void)hipFree(*p);
+  *p = NULL; *cap = 0;
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(p), need * sizeof(T)));
+  *cap = need;
+  return KAMD_OK;
+}
+
+// One finished utterance: what DecodeUtteranceLatticeFaster does after Decode()
+// (decoder/decoder-wrappers.cc:217-296): best path -> words / alignment / weight, raw lattice,
+// optional DeterminizeLatticePhonePrunedWrapper.
+static void HostTail(BatchDecoder *b, int u, hipStream_t cs) {
+  const auto t0 = std::chrono::steady_clock::now();
+  UttOut &o = b->out[u];
+  int rc = kamd_decoder_queue_result(b->dec, u, &o.rec);
+  if (rc == KAMD_OK)
+    rc = kamd_decoder_queue_fetch_lattice(b->dec, u, cs, &o.num_states, &o.num_arcs, &o.start, &o.st_frame, &o.st_hclg, &o.st_cost,
+                                          &o.st_final, &o.arcs);
+  if (rc == KAMD_OK && o.num_states > 0) {
+    const int cap = std::max(o.num_arcs, 1);
+    o.words.resize(cap); o.ali.resize(cap);
+    int na = 0, nw = 0;
+    const int brc = kamd_lattice_best_path(o.num_states, o.start, o.st_final, o.arcs, o.num_arcs, o.ali.data(), cap, &na, o.words.data(), cap,
+                                           &nw, &o.graph_cost, &o.ac_cost);
+    if (brc == KAMD_OK) { o.have_path = true; o.ali.resize(na); o.words.resize(nw); }
+    else { o.ali.clear(); o.words.clear(); }
+    if (b->opts.determinize && o.have_path) {
+      std::vector<float> fin2(2 * static_cast<size_t>(o.num_states), INFINITY);
+      for (int s = 0; s < o.num_states; s++)
+        if (o.st_final[s] != INFINITY) { fin2[2 * s] = o.st_final[s]; fin2[2 * s + 1] = 0.0f; }
+      kamd_determinize_opts dopt = b->opts.det;
+      const bool phones = !b->tid_phone.empty();
+      if (!phones) dopt.phone_determinize = 0;
+      o.clat = kamd_lattice_determinize_phone_pruned(o.num_states, o.start, fin2.data(), o.arcs, o.num_arcs,
+                                                     phones ? b->tid_phone.data() : NULL, phones ? static_cast<int>(b->tid_phone.size()) - 1 : 0,
+                                                     b->opts.lattice_beam, &dopt);
+      if (!o.clat) rc = KAMD_ERR_STATE;
+    }
+    if (!b->opts.keep_raw_lattices) {
+      free(o.st_frame); free(o.st_hclg); free(o.st_cost); free(o.st_final); free(o.arcs);
+      o.st_frame = o.st_hclg = NULL; o.st_cost = o.st_final = NULL; o.arcs = NULL;
+    }
+  }
+  if (rc != KAMD_OK) { o.status = rc; o.message = LastError(); }
+  o.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  o.done = 1;
+}
+
+static void WorkerLoop(BatchDecoder *b, int idx) {
+  (void)hipSetDevice(b->device);
+  hipStream_t cs = b->copy_streams[idx];
+  for (;;) {
+    int u;
+    {
+      std::unique_lock<std::mutex> lk(b->mu);
+      b->cv_job.wait(lk, [&] { return b->quit || !b->jobs.empty(); });
+      if (b->jobs.empty()) return;   // quit
+      u = b->jobs.front(); b->jobs.pop_front();
+    }
+    HostTail(b, u, cs);
+    {
+      std::lock_guard<std::mutex> lk(b->mu);
+      b->pending--;
+    }
+    b->cv_done.notify_all();
+  }
+}
+
+}  // namespace kamd
+using kamd::BatchDecoder;
+
+extern "C" {
+
+void kamd_batch_opts_default(kamd_batch_opts *o) {
+  memset(o, 0, sizeof(*o));
+  o->resident_lanes = 0; o->host_threads = 8; o->determinize = 1; o->keep_raw_lattices = 0;
+  o->nnet_pass_frames = 400000; o->lattice_pool_bytes = 1ll << 30; o->lattice_beam = 8.0f;
+  kamd_determinize_opts_default(&o->det);
+}
+
+kamd_batch_decoder *kamd_batch_decoder_create(kamd_feat *feat, kamd_nnet *nnet, kamd_decoder *dec, const kamd_batch_opts *opts,
+                                              const int32_t *tid_phone, int32_t num_tids) {
+  if (!feat || !nnet || !dec) { kamd::SetError(KAMD_ERR_ARG, "batch decoder: null stage handle"); return NULL; }
+  if (!kamd::RequireDevice()) return NULL;
+  BatchDecoder *b = new BatchDecoder();
+  b->feat = feat; b->nnet = nnet; b->dec = dec;
+  if (opts) b->opts = *opts; else kamd_batch_opts_default(&b->opts);
+  if (b->opts.host_threads < 1) b->opts.host_threads = 1;
+  if (b->opts.host_threads > 256) b->opts.host_threads = 256;
+  if (b->opts.nnet_pass_frames <= 0) b->opts.nnet_pass_frames = 400000;
+  if (tid_phone && num_tids > 0) b->tid_phone.assign(tid_phone, tid_phone + num_tids + 1);
+  b->feat_dim = kamd_feat_dim(feat); b->ld_feat = kamd::RoundUp(b->feat_dim, 16); b->P = kamd_nnet_output_dim(nnet);
+  bool ok = hipGetDevice(&b->device) == hipSuccess && hipStreamCreateWithFlags(&b->s_main, hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; ok && i < 3; i++) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+  b->copy_streams.resize(b->opts.host_threads, NULL);
+  for (int i = 0; ok && i < b->opts.host_threads; i++) ok = hipStreamCreateWithFlags(&b->copy_streams[i], hipStreamNonBlocking) == hipSuccess;
+  if (ok && b->opts.lattice_pool_bytes > 0) ok = kamd_decoder_queue_configure(dec, b->opts.lattice_pool_bytes) == KAMD_OK;
+  if (!ok) {
+    kamd::SetError(KAMD_ERR_HIP, "batch decoder: stream / event creation failed");
+    kamd_batch_decoder_destroy(reinterpret_cast<kamd_batch_decoder *>(b));
+    return NULL;
+  }
+  for (int i = 0; i < b->opts.host_threads; i++) b->workers.emplace_back(kamd::WorkerLoop, b, i);
+  return reinterpret_cast<kamd_batch_decoder *>(b);
+}
+
+void kamd_batch_decoder_destroy(kamd_batch_decoder *h) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (!b) return;
+  {
+    std::lock_guard<std::mutex> lk(b->mu);
+    b->quit = true;
+  }
+  b->cv_job.notify_all();
+  for (std::thread &t : b->workers) t.join();
+  for (kamd::UttOut &o : b->out) o.Clear();
+  for (hipStream_t s : b->copy_streams) if (s) (void)hipStreamDestroy(s);
+  for (int i = 0; i < 3; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
+  if (b->s_main) (void)hipStreamDestroy(b->s_main);
+  if (b->d_waves) (void)hipFree(b->d_waves);
+  if (b->d_feats) (void)hipFree(b->d_feats);
+  if (b->d_ll) (void)hipFree(b->d_ll);
+  delete b;
+}
+
+int kamd_batch_decoder_load(kamd_batch_decoder *h, const float *waves, const int64_t *h_wave_off, int n_utts) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (n_utts <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty test set");
+  for (kamd::UttOut &o : b->out) o.Clear();
+  b->n_utts = n_utts;
+  b->wave_off.assign(h_wave_off, h_wave_off + n_utts + 1);
+  b->feat_off.assign(n_utts + 1, 0); b->out_off.assign(n_utts + 1, 0);
+  for (int u = 0; u < n_utts; u++) {
+    const int T = kamd_feat_num_frames(b->feat, h_wave_off[u + 1] - h_wave_off[u]);
+    if (T <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d too short for one frame", u);
+    b->feat_off[u + 1] = b->feat_off[u] + T;
+    b->out_off[u + 1] = b->out_off[u] + kamd_nnet_num_output_frames(b->nnet, T);
+  }
+  const size_t ns = static_cast<size_t>(h_wave_off[n_utts] - h_wave_off[0]);
+  if (kamd::GrowDev(&b->d_waves, &b->waves_cap, ns) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&b->d_feats, &b->feats_cap, static_cast<size_t>(b->feat_off[n_utts]) * b->ld_feat) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&b->d_ll, &b->ll_cap, static_cast<size_t>(b->out_off[n_utts]) * b->P) != KAMD_OK) return KAMD_ERR_HIP;
+  KAMD_HIP(hipMemcpy(b->d_waves, waves + h_wave_off[0], ns * sizeof(float), hipMemcpyHostToDevice));
+  if (h_wave_off[0] != 0) for (int u = 0; u <= n_utts; u++) b->wave_off[u] -= h_wave_off[0];
+  b->out.resize(n_utts);
+  return KAMD_OK;
+}
+
+int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  const int n = b->n_utts;
+  if (n <= 0) return kamd::SetError(KAMD_ERR_STATE, "no test set loaded");
+  for (kamd::UttOut &o : b->out) o.Clear();
+  const auto t0 = std::chrono::steady_clock::now();
+  hipStream_t st = b->s_main;
+  KAMD_HIP(hipEventRecord(b->ev[0], st));
+  int rc = kamd_feat_compute_batch_device(b->feat, b->d_waves, b->wave_off.data(), n, b->d_feats, b->feat_off.data(), b->ld_feat, st);
+  if (rc != KAMD_OK) return rc;
+  KAMD_HIP(hipEventRecord(b->ev[1], st));
+  // ---- acoustic model, a few passes of <= nnet_pass_frames input frames
+  double flops = 0;
+  int passes = 0;
+  for (int u0 = 0; u0 < n;) {
+    int u1 = u0 + 1;
+    while (u1 < n && b->feat_off[u1 + 1] - b->feat_off[u0] <= b->opts.nnet_pass_frames) u1++;
+    rc = kamd_nnet_forward_batch_device(b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat, NULL, u1 - u0, b->d_ll,
+                                        b->out_off.data() + u0, b->P, st);
+    if (rc != KAMD_OK) return rc;
+    flops += kamd_nnet_last_flops(b->nnet);
+    passes++;
+    u0 = u1;
+  }
+  KAMD_HIP(hipEventRecord(b->ev[2], st));
+  // ---- the search: one work-queue launch, longest utterance first
+  std::vector<kamd_queue_task> tasks(n);
+  {
+    std::vector<int> order(n);
+    for (int u = 0; u < n; u++) order[u] = u;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+      return b->out_off[a + 1] - b->out_off[a] > b->out_off[c + 1] - b->out_off[c];
+    });
+    for (int k = 0; k < n; k++) {
+      const int u = order[k];
+      tasks[k].d_loglikes = b->d_ll + static_cast<size_t>(b->out_off[u]) * b->P;
+      tasks[k].ld = b->P; tasks[k].n_frames = static_cast<int32_t>(b->out_off[u + 1] - b->out_off[u]);
+      tasks[k].utt = u; tasks[k].reserved = 0;
+    }
+  }
+  rc = kamd_decoder_queue_launch(b->dec, tasks.data(), n, b->opts.resident_lanes, st);
+  if (rc != KAMD_OK) return rc;
+  // ---- collector: hand finished utterances to the host-tail pool while the kernel runs
+  int collected = 0, idle_after_end = 0;
+  std::vector<int32_t> buf(256);
+  double t_first_done = -1, t_last_done = -1;
+  while (collected < n) {
+    const int k = kamd_decoder_queue_poll(b->dec, buf.data(), static_cast<int>(buf.size()));
+    if (k > 0) {
+      const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (t_first_done < 0) t_first_done = now;
+      t_last_done = now;
+      {
+        std::lock_guard<std::mutex> lk(b->mu);
+        for (int i = 0; i < k; i++) b->jobs.push_back(buf[i]);
+        b->pending += k;
+      }
+      b->cv_job.notify_all();
+      collected += k;
+      idle_after_end = 0;
+      continue;
+    }
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) {
+      if (++idle_after_end > 2) break;      // the kernel has ended and published nothing more
+    } else if (q != hipErrorNotReady) {
+      return kamd::SetError(KAMD_ERR_HIP, "decoder work queue failed: %s", hipGetErrorString(q));
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+  {
+    std::unique_lock<std::mutex> lk(b->mu);
+    b->cv_done.wait(lk, [&] { return b->pending == 0; });
+  }
+  const double total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  float qms = 0; int32_t lanes = 0;
+  rc = kamd_decoder_queue_wait(b->dec, &qms, &lanes);
+  if (rc != KAMD_OK) return rc;
+  if (collected < n) return kamd::SetError(KAMD_ERR_STATE, "work queue ended with %d of %d utterances published", collected, n);
+  kamd_batch_stats s;
+  memset(&s, 0, sizeof(s));
+  (void)hipEventElapsedTime(&s.feat_ms, b->ev[0], b->ev[1]);
+  (void)hipEventElapsedTime(&s.nnet_ms, b->ev[1], b->ev[2]);
+  s.decode_ms = qms; s.total_ms = static_cast<float>(total_ms);
+  s.host_tail_ms = static_cast<float>(total_ms - t_last_done);
+  s.first_result_ms = static_cast<float>(t_first_done);
+  s.nnet_flops = flops; s.lanes = lanes; s.nnet_passes = passes;
+  double host_sum = 0;
+  for (int u = 0; u < n; u++) {
+    if (b->out[u].status != KAMD_OK) s.n_failed++;
+    host_sum += b->out[u].host_ms;
+  }
+  s.host_thread_ms_sum = host_sum;
+  b->last = s;
+  if (stats) *stats = s;
+  return KAMD_OK;
+}
+
+static int UttOk(BatchDecoder *b, int u) {
+  if (u < 0 || u >= b->n_utts) return kamd::SetError(KAMD_ERR_ARG, "utterance %d outside the loaded set", u);
+  if (!b->out[u].done) return kamd::SetError(KAMD_ERR_STATE, "utterance %d has not been decoded", u);
+  return KAMD_OK;
+}
+
+int kamd_batch_decoder_get_output(kamd_batch_decoder *h, int utt, int32_t *words, int words_cap, int *words_len, int32_t *alignment,
+                                  int ali_cap, int *ali_len, float *graph_cost, float *acoustic_cost, kamd_queue_result *record) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (UttOk(b, utt) != KAMD_OK) return KAMD_ERR_ARG;
+  const kamd::UttOut &o = b->out[utt];
+  if (record) *record = o.rec;
+  if (words_len) *words_len = 0;
+  if (ali_len) *ali_len = 0;
+  if (graph_cost) *graph_cost = INFINITY;
+  if (acoustic_cost) *acoustic_cost = INFINITY;
+  if (o.status != KAMD_OK) return kamd::SetError(o.status, "%s", o.message.c_str());
+  if (!o.have_path) return kamd::SetError(KAMD_ERR_STATE, "utterance %d: empty lattice", utt);
+  if (words_len) { *words_len = static_cast<int>(o.words.size()); if (words) memcpy(words, o.words.data(), sizeof(int32_t) * std::min<size_t>(o.words.size(), words_cap)); }
+  if (ali_len) { *ali_len = static_cast<int>(o.ali.size()); if (alignment) memcpy(alignment, o.ali.data(), sizeof(int32_t) * std::min<size_t>(o.ali.size(), ali_cap)); }
+  if (graph_cost) *graph_cost = o.graph_cost;
+  if (acoustic_cost) *acoustic_cost = o.ac_cost;
+  return KAMD_OK;
+}
+
+int kamd_batch_decoder_get_raw_lattice(kamd_batch_decoder *h, int utt, int32_t *num_states, int32_t *num_arcs, int32_t *start,
+                                       const int32_t **state_frame, const int32_t **state_hclg, const float **state_cost,
+                                       const float **state_final, const kamd_lat_arc **arcs) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (UttOk(b, utt) != KAMD_OK) return KAMD_ERR_ARG;
+  const kamd::UttOut &o = b->out[utt];
+  if (o.status != KAMD_OK) return kamd::SetError(o.status, "%s", o.message.c_str());
+  if (!b->opts.keep_raw_lattices) return kamd::SetError(KAMD_ERR_STATE, "raw lattices were not kept (kamd_batch_opts.keep_raw_lattices)");
+  *num_states = o.num_states; *num_arcs = o.num_arcs; *start = o.start;
+  *state_frame = o.st_frame; *state_hclg = o.st_hclg; *state_cost = o.st_cost; *state_final = o.st_final; *arcs = o.arcs;
+  return KAMD_OK;
+}
+
+const kamd_compact_lattice *kamd_batch_decoder_get_compact_lattice(kamd_batch_decoder *h, int utt) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (UttOk(b, utt) != KAMD_OK) return NULL;
+  if (!b->out[utt].clat) kamd::SetError(KAMD_ERR_STATE, "utterance %d has no determinized lattice", utt);
+  return b->out[utt].clat;
+}
+
+int kamd_batch_decoder_get_loglikes(kamd_batch_decoder *h, int utt, float *out, int rows_cap, int *rows, int *cols) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (utt < 0 || utt >= b->n_utts) return kamd::SetError(KAMD_ERR_ARG, "bad utterance index");
+  const int r = static_cast<int>(b->out_off[utt + 1] - b->out_off[utt]);
+  *rows = r; *cols = b->P;
+  if (r > rows_cap) return kamd::SetError(KAMD_ERR_ARG, "buffer too small");
+  KAMD_HIP(hipMemcpy(out, b->d_ll + static_cast<size_t>(b->out_off[utt]) * b->P, static_cast<size_t>(r) * b->P * sizeof(float), hipMemcpyDeviceToHost));
+  return KAMD_OK;
+}
+
+}  // extern "C"

@@ -34,6 +34,12 @@ int kamd_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+int kamd_device_num_cus(void) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  return prop.multiProcessorCount;
+}
 int kamd_set_device(int device) {
   KAMD_HIP(hipSetDevice(device));
   return KAMD_OK;

@@ -103,8 +103,8 @@ class CompactLattice:
     """Determinized word lattice (kaldi::CompactLattice): acceptor on word labels, every arc
     and final weight carries (graph, acoustic) costs and a transition-id string."""
 
-    def __init__(self, handle):
-        self._h = handle
+    def __init__(self, handle, owned=True):
+        self._h, self._owned = handle, owned         # owned=False: borrowed from a batch decoder
         n, m, k, st, ok = (C.c_int32() for _ in range(5))
         check(lib().kamd_compact_lattice_sizes(handle, C.byref(n), C.byref(m), C.byref(k), C.byref(st), C.byref(ok)))
         self.num_states, self.start, self.reached_beam = n.value, st.value, bool(ok.value)
@@ -129,9 +129,9 @@ class CompactLattice:
                                                float(acoustic_scale)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and getattr(self, "_owned", True):
             lib().kamd_compact_lattice_destroy(self._h)
-            self._h = None
+        self._h = None
 
 
 def determinize_opts_default():

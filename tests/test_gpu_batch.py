@@ -1,0 +1,76 @@
+"""kamd_batch_decoder_* (the NnetBatchDecoder mirror): a shard of utterances through features,
+nnet passes, ONE work-queue launch of the search and the threaded host tail.  Per utterance the
+result must be what the oracle gives for the device's own log-likelihoods, bit for bit, and what
+the batch pipeline (three launches) gives for the same waveforms."""
+import numpy as np
+import pytest
+
+from kaldi_amd import abi, batch, io as kio, nnet, pipeline, synth
+from oracle import orc
+from tests.util import lattice_diff, lattices_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n=23, seed=3):
+    g = synth.make_hclg(num_units=32, vocab=120, n_hist=20, seed=8)
+    model = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=4.0)
+    cfg = abi.decoder_config_recipe()
+    rng = np.random.default_rng(seed)
+    waves = [synth.make_wave(float(s), seed=100 + i) for i, s in enumerate(rng.uniform(0.3, 3.0, n))]
+    return g, model, cfg, waves
+
+
+def test_batch_decoder_equals_oracle_and_pipeline():
+    g, model, cfg, waves = _setup()
+    bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=4.0, resident_lanes=4, host_threads=3,
+                                determinize=True, keep_raw_lattices=True, nnet_pass_frames=900)
+    bd.load(waves)
+    st = bd.run()
+    assert st.n_failed == 0 and st.lanes == 4 and st.nnet_passes > 1
+    assert st.total_ms > 0 and st.decode_ms > 0 and st.nnet_flops > 0
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves), max_seconds=4.0)
+    ref = pipe.decode(waves)
+    for u in range(len(waves)):
+        ll = bd.loglikes(u)
+        np.testing.assert_array_equal(ll, pipe.loglikes(u))        # sub-batching the nnet changes nothing (k-ordered chains)
+        o = orc.Decoder(g, cfg, 1)
+        o.Decode(ll)
+        lo = o.GetRawLattice()
+        lat = bd.raw_lattice(u)
+        assert lattices_equal(lat, lo), "utt %d: %s" % (u, lattice_diff(lat, lo))
+        assert lattices_equal(lat, ref[u]["lattice"])
+        out = bd.output(u)
+        bo = lo.best_path()
+        assert out["words"].tolist() == bo["words"].tolist() == ref[u]["words"].tolist()
+        assert out["alignment"].tolist() == bo["alignment"].tolist()
+        assert out["graph_cost"] == bo["graph_cost"] and out["acoustic_cost"] == bo["acoustic_cost"]
+        assert out["record"].n_frames == ll.shape[0] and out["record"].error == 0
+        np.testing.assert_array_equal(np.asarray(out["record"].counters[:7]), o.counters()[:7])
+        cl, cr = bd.compact_lattice(u), kio.determinize_lattice(lat, cfg.lattice_beam)
+        assert cl.num_states == cr.num_states and cl.arcs.tobytes() == cr.arcs.tobytes()
+        assert cl.strings.tobytes() == cr.strings.tobytes() and cl.final.tobytes() == cr.final.tobytes()
+    # a second run of the same shard, and a different shard through the same object
+    st2 = bd.run()
+    assert st2.n_failed == 0
+    for u in (0, 5, len(waves) - 1):
+        assert lattices_equal(bd.raw_lattice(u), ref[u]["lattice"])
+    bd.load(waves[3:9])
+    bd.run()
+    for k, u in enumerate(range(3, 9)):
+        assert lattices_equal(bd.raw_lattice(k), ref[u]["lattice"])
+
+
+def test_batch_decoder_without_raw_lattices_or_determinization():
+    g, model, cfg, waves = _setup(n=7, seed=5)
+    bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=4.0, resident_lanes=2, host_threads=1,
+                                determinize=False, keep_raw_lattices=False)
+    bd.load(waves)
+    bd.run()
+    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves), max_seconds=4.0)
+    ref = pipe.decode(waves)
+    for u in range(len(waves)):
+        assert bd.output(u)["words"].tolist() == ref[u]["words"].tolist()
+        assert bd.compact_lattice(u) is None
+        with pytest.raises(Exception):
+            bd.raw_lattice(u)
