@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- decode RTF (audio-seconds per wall-second) of the MI355X hot path.
 
-One "step" = one pass of the whole hot path over one batch of synthetic utterances that
-is already resident in HBM: MFCC -> TDNN-F log-likelihoods -> LatticeFasterDecoder
-(init + advance + finalize) -> raw lattices / 1-best staged for the host.
-Workload = BASELINE.json configs[1]: mini_librispeech TDNN-F chain topology
-(run_tdnn_1h.sh: 768/96, P=2328), tgsmall-scale synthetic HCLG, batch = 64 utterances
-per GPU, recipe decoder settings (beam 15, max-active 7000, min-active 200,
-lattice-beam 8).  Weak scaling: every rank decodes its own 64-utterance shard.
+Workload (default) = BASELINE.json configs[2]: a LibriSpeech-test-clean-sized synthetic test
+set (2620 utterances, 5.4 h, durations lognormal 1-35 s), the LibriSpeech TDNN-F chain
+topology (run_tdnn_1d.sh:219-249: 1536/160, 17 layers, P = 6000, random init), a
+tglarge-scale synthetic HCLG (31 M states, 69 M arcs), recipe decoder settings (beam 15,
+max-active 7000, min-active 200, lattice-beam 8).
+
+One "step" = one pass of the whole hot path over the test set, waveforms already resident in
+HBM: MFCC -> TDNN-F log-likelihoods -> LatticeFasterDecoder (work queue over one lane per CU:
+init + advance + finalize per utterance) -> pruned raw lattices copied to the host, best path
+and lattice determinization on host threads, overlapped with the search.  The step ends when
+every utterance's 1-best and determinized lattice are on the host.
+
+--gpus N: N ranks, one per GPU, are spawned by this script itself (or by torchrun: RANK /
+LOCAL_RANK / WORLD_SIZE in the environment); the ONE test set is partitioned over the ranks by
+longest-processing-time-first (kaldi_amd/shard.py), so scaling is "strong".
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +33,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+PHASES = ["best", "cutoff", "seed", "expand", "expand_hub", "eps_closure", "compact", "fixup",
+          "eps_links", "clear", "fin_sweep", "fin_compact", "flat_setup"]
 
 
 def algorithmic_bytes(c):
@@ -30,77 +44,121 @@ def algorithmic_bytes(c):
     return 8 * c[0] + 16 * c[1] + 8 * c[2] + 16 * c[3] + 20 * c[4] + 12 * c[5]
 
 
-def build_workload(args, rank):
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="librispeech", choices=["librispeech", "mini_librispeech", "tiny"],
+                    help="librispeech = BASELINE configs[2] (headline); mini_librispeech = configs[1] (use --utts 64)")
+    ap.add_argument("--utts", type=int, default=0, help="utterances of the WHOLE test set (0 = 2620 for librispeech, "
+                    "64 for mini_librispeech, 12 for tiny)")
+    ap.add_argument("--graph", default="", choices=["", "tglarge", "tgsmall"], help="synthetic HCLG scale (default: tglarge "
+                    "for librispeech, tgsmall otherwise)")
+    ap.add_argument("--vocab", type=int, default=0)
+    ap.add_argument("--n-hist", type=int, default=0)
+    ap.add_argument("--output-scale", type=float, default=1.0)
+    ap.add_argument("--lm-scale", type=float, default=-1.0, help="scale on the synthetic LM costs (default per graph)")
+    ap.add_argument("--ll-std", type=float, default=-1.0,
+                    help="per-frame std (nats) of the synthetic log-likelihoods across pdfs after calibration")
+    ap.add_argument("--max-seconds", type=float, default=0.0)
+    ap.add_argument("--lanes", type=int, default=0, help="resident decoder lanes per GPU (0 = one per compute unit)")
+    ap.add_argument("--host-threads", type=int, default=0, help="host-tail threads per rank (0 = min(16, cores / ranks))")
+    ap.add_argument("--no-determinize", action="store_true")
+    ap.add_argument("--hash-capacity", type=int, default=0)
+    ap.add_argument("--tokens-per-frame", type=int, default=0, help="arena budget per frame and lane (0 = from max-active / free HBM)")
+    ap.add_argument("--nnet-pass-frames", type=int, default=400000)
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the cpu_baseline leg (0 = min(cores, 32))")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-wer", action="store_true")
+    ap.add_argument("--wer-utts", type=int, default=64)
+    ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo to "
+                    "exercise the N>1 code path with several ranks sharing one GPU")
+    ap.add_argument("--device", type=int, default=-1, help="override the HIP device of every rank (default LOCAL_RANK)")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------- launcher
+def launch_ranks(args):
+    """--gpus N without a torchrun environment: start N fresh rank processes (this parent never
+    touches the GPU), one per GPU, relay rank 0's JSON line, exit with the worst return code."""
+    n = args.gpus
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
+# ----------------------------------------------------------------------------- workload
+def defaults(args):
+    if args.utts <= 0:
+        args.utts = {"librispeech": 2620, "mini_librispeech": 64, "tiny": 12}[args.workload]
+    if not args.graph:
+        args.graph = "tglarge" if args.workload == "librispeech" else "tgsmall"
+    if args.vocab <= 0:
+        args.vocab = 200000 if args.graph == "tglarge" else 20000
+    if args.n_hist <= 0:
+        args.n_hist = 160000 if args.graph == "tglarge" else 18000
+    # search-load knobs (DESIGN.md section 5): random weights carry no speech information, so the spread of the
+    # log-likelihoods and the flatness of the synthetic LM set how many hypotheses survive the beam
+    if args.lm_scale < 0:
+        args.lm_scale = 0.3 if args.graph == "tglarge" else 0.1
+    if args.ll_std < 0:
+        args.ll_std = 1.9 if args.graph == "tglarge" else 1.3
+    if args.hash_capacity <= 0 and args.graph == "tglarge":
+        args.hash_capacity = 1 << 20     # the unigram tree's second level: > 1e5 tokens on the frames after a word boundary
+    return args
+
+
+def build_workload(args):
     from kaldi_amd import abi, nnet, synth
     t0 = time.time()
     if args.workload == "mini_librispeech":
         g = synth.make_hclg(num_units=1164, vocab=args.vocab, n_hist=args.n_hist, fanout=(12, 64),
                             pron_len=(3, 7), seed=2, self_loop_prob=0.5, lm_scale=args.lm_scale)
-        model = nnet.tdnnf_mini_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale,
-                                            ivector_dim=100 if args.ivectors else 0)
+        model = nnet.tdnnf_mini_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
     elif args.workload == "librispeech":
         g = synth.make_hclg(num_units=3000, vocab=args.vocab, n_hist=args.n_hist, fanout=(12, 64),
                             pron_len=(3, 7), seed=2, self_loop_prob=0.5, lm_scale=args.lm_scale)
-        model = nnet.tdnnf_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale,
-                                       ivector_dim=100 if args.ivectors else 0)
-    else:  # tiny (CI / CPU-less smoke of the script itself)
+        model = nnet.tdnnf_librispeech(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
+    else:  # tiny (CI / smoke of the script itself)
         g = synth.make_hclg(num_units=64, vocab=400, n_hist=60, seed=2)
         model = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=args.output_scale)
-    durs = synth.utterance_durations(args.utts, seed=1000 + rank)
+    # LibriSpeech test-clean: 2620 utterances, 5.4 h (SURVEY 8(d)); lognormal(6.2 s, 0.6) clipped to [1, 35] s sums to that
+    durs = synth.utterance_durations(args.utts, seed=1, mu=6.2 if args.workload != "tiny" else 1.5)
     if args.max_seconds:
         durs = np.minimum(durs, args.max_seconds)
-    waves = [synth.make_wave(d, seed=rank * 100000 + i) for i, d in enumerate(durs)]
     cfg = abi.decoder_config_recipe()
-    return g, model, waves, cfg, time.time() - t0
+    return g, model, durs, cfg, time.time() - t0
 
 
-def calibrate(model, target_std, extractor=None):
+def calibrate(model, target_std):
     """Random weights give arbitrary output scale; rescale the output layer so that the
     per-frame spread of the log-likelihoods across pdfs is `target_std` nats (chain models
     in the wild: a few nats).  Runs on the GPU (this is workload synthesis, not parity)."""
     from kaldi_amd import abi, decoder, feat, synth
-    w = synth.make_wave(3.0, seed=424242)
+    w = synth.make_waves_fast([3.0], seed=424242)[0]
     f = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(w)
-    ivd = model.layers[0].ivector_dim
-    iv = None
-    if ivd:      # a typical i-vector (the last one of the sample), not zeros: it shifts every output
-        iv = extractor.extract_online(f)[-1] if extractor is not None else np.zeros(ivd, np.float32)
-    ll = decoder.Nnet(model).Forward(f, ivector=iv)
+    ll = decoder.Nnet(model).Forward(f)
     spread = float(np.mean(np.std(ll, axis=1)))
     k = target_std / spread
     out = model.layers[-1]
     out.W = (out.W * k).astype(np.float32)
     out.bias = (out.bias * k).astype(np.float32)
     return spread, k
-
-
-PHASES = ["best", "cutoff", "seed", "expand", "expand_hub", "eps_closure", "compact", "fixup",
-          "eps_links", "clear", "fin_sweep", "fin_compact", "flat_setup"]
-
-
-def phase_share(pipe, waves):
-    lane = int(np.argmax([w.size for w in waves]))
-    c = pipe.dec.phase_cycles(lane).astype(np.float64)[:len(PHASES)]
-    tot = max(c.sum(), 1.0)
-    return {k: round(float(v / tot), 3) for k, v in zip(PHASES, c)}
-
-
-def pmc_traffic(args):
-    """HBM bytes per AdvanceKernel launch from the committed rocprofv3 PMC passes
-    (profiles/*_pmc.json), only when they were taken on this exact workload."""
-    key = "%s/%d/%s/%s" % (args.workload, args.utts, args.ll_std, args.lm_scale)
-    best = None
-    pdir = os.path.join(ROOT, "profiles")
-    if os.path.isdir(pdir):
-        for f in sorted(os.listdir(pdir)):
-            if f.endswith("_pmc.json"):
-                try:
-                    d = json.load(open(os.path.join(pdir, f)))
-                except Exception:
-                    continue
-                if d.get("workload_key") == key:
-                    best = d.get("traffic_bytes_per_launch")
-    return best
 
 
 def _edit_distance(a, b):
@@ -114,233 +172,344 @@ def _edit_distance(a, b):
     return prev[-1]
 
 
-def cpu_baseline(g, model, waves, cfg, budget_s, gpu_results=None, cores=0):
-    """The CPU oracle (a port of the reference path: faithful decoder mode 0) timed on this host's cores on a bounded
-    sample of the same workload: one utterance per thread at a time, like nnet3-latgen-faster-parallel (the oracle is C
-    called through ctypes, which releases the interpreter lock)."""
-    import os
-    from concurrent.futures import ThreadPoolExecutor
+def _run_threads(fn, items, threads):
+    """items through fn on `threads` threads pulling from one list (every thread stays busy until the list is
+    empty); returns (results in item order, wall seconds, sum of per-item seconds)."""
+    import threading
+    res = [None] * len(items)
+    busy = [0.0] * len(items)
+    nxt = [0]
+    lock = threading.Lock()
+
+    def work():
+        while True:
+            with lock:
+                k = nxt[0]
+                nxt[0] += 1
+            if k >= len(items):
+                return
+            t = time.time()
+            res[k] = fn(items[k])
+            busy[k] = time.time() - t
+
+    t0 = time.time()
+    ths = [threading.Thread(target=work) for _ in range(max(1, threads))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    return res, time.time() - t0, sum(busy)
+
+
+def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
+    """The CPU oracle (a port of the reference path; decoder in its order-faithful mode 0) on this host's cores, on a
+    bounded sample of the same test set: `cores` threads, each pulling the next utterance (one LatticeFasterDecoder per
+    thread, like nnet3-latgen-faster-parallel; the oracle is C behind ctypes, which releases the interpreter lock), every
+    thread busy for the whole measurement.  Second leg: the CPU decoder alone on the DEVICE's log-likelihoods
+    (latgen-faster-mapped's job), which is also the 1-best parity check of the sampled utterances."""
     from kaldi_amd import abi
     from oracle import orc
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores if cores > 0 else avail, avail, 64))
+    cores = max(1, min(cores if cores > 0 else 32, avail))
+    order = [int(i) for i in np.argsort([w.size for w in waves])]
 
-    def one(idx):
-        w = waves[idx]
-        feats = orc.mfcc(abi.mfcc_opts_hires(), w)
+    def whole(idx):
+        feats = orc.mfcc(abi.mfcc_opts_hires(), waves[idx])
         ll = orc.nnet_forward(model, feats)
         d = orc.Decoder(g, cfg, 0)
         d.Decode(ll)
         lat = d.GetRawLattice()
-        return idx, (lat.best_path() if lat is not None else None)
+        return lat.best_path() if lat is not None else None
 
-    order = [int(i) for i in np.argsort([w.size for w in waves])]
+    # the shortest utterance alone: the single-core rate sizes the sample
     t0 = time.time()
-    first = one(order[0])                  # the shortest utterance, alone: the single-core rate sizes the sample
+    whole(order[0])
     t_first = time.time() - t0
     rate = (waves[order[0]].size / 16000.0) / max(t_first, 1e-6)
-    audio_budget = rate * budget_s * cores * 0.8
+    audio_budget = rate * budget_s * cores * 0.5            # half of the budget for each leg
     sample, audio = [], 0.0
-    for idx in order[1:]:                  # shortest first, until about budget_s of wall time on `cores` threads
+    for idx in order:                                        # shortest first: >= 4 utterances per thread where the set allows
         a = waves[idx].size / 16000.0
-        if sample and audio + a > audio_budget:
+        if len(sample) >= 4 * cores and audio + a > audio_budget:
             break
-        sample.append(idx); audio += a
-    t0 = time.time()
-    if cores == 1 or len(sample) < 2:
-        done = [one(i) for i in sample]
-    else:
-        with ThreadPoolExecutor(max_workers=cores) as ex:
-            done = list(ex.map(one, sorted(sample, key=lambda i: -waves[i].size)))      # longest first: less tail imbalance
-    wall = time.time() - t0
-    errs = ref_words = 0
-    for idx, bp in [first] + done:
-        if gpu_results is not None and bp is not None and gpu_results[idx] is not None:
-            ref = bp["words"].tolist()                         # the CPU path's 1-best is the "reference transcript"
-            errs += _edit_distance(ref, gpu_results[idx]["words"].tolist())
-            ref_words += len(ref)
-    used = min(cores, max(len(sample), 1))
-    out = {"value": audio / max(wall, 1e-9), "unit": "audio-sec/wall-sec", "cores": used, "kind": "port",
-           "single_core_value": rate,
-           "sample": "%d shortest utterance(s) of the batch after the first (%.1f s audio) on %d thread(s), %.1f s wall; the "
-                     "shortest one alone gave the single-core rate (%.1f s CPU): whole path MFCC+nnet+LatticeFasterDecoder"
-                     "(order-faithful oracle)+best path" % (len(sample), audio, used, wall, t_first)}
-    if gpu_results is not None and ref_words > 0:
-        # BASELINE's "WER-equal" clause on synthetic data: word errors of the device 1-best
-        # against the CPU path's 1-best on the same utterances
-        out["wer_vs_cpu_1best"] = {"errors": errs, "ref_words": ref_words, "wer_percent": 100.0 * errs / ref_words}
-    return out
+        sample.append(idx)
+        audio += a
+        if len(sample) >= len(order):
+            break
+    # longest of the sample first, so the tail of the run is made of the short ones
+    sample.sort(key=lambda i: -waves[i].size)
+    ll_cache = {i: bd.loglikes(i) for i in sample}
+    res_w, wall_w, busy_w = _run_threads(whole, sample, cores)
+    bd_like = ll_cache
+
+    def dec_cached(idx):
+        d = orc.Decoder(g, cfg, 0)
+        d.Decode(bd_like[idx])
+        lat = d.GetRawLattice()
+        return lat.best_path() if lat is not None else None
+
+    res_d, wall_d, busy_d = _run_threads(dec_cached, sample, cores)
+    errs_w = errs_d = ref_w = ref_d = cost_diff = 0
+    for k, idx in enumerate(sample):
+        gpu = bd.output(idx)
+        gw = gpu["words"].tolist() if gpu is not None else []
+        if res_w[k] is not None:
+            ref = res_w[k]["words"].tolist()
+            errs_w += _edit_distance(ref, gw)
+            ref_w += len(ref)
+        if res_d[k] is not None:
+            ref = res_d[k]["words"].tolist()
+            errs_d += _edit_distance(ref, gw)
+            ref_d += len(ref)
+            if gpu is None or abs((gpu["graph_cost"] + gpu["acoustic_cost"]) - (res_d[k]["graph_cost"] + res_d[k]["acoustic_cost"])) > 1e-3:
+                cost_diff += 1
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    used = min(cores, len(sample))
+    return {"value": audio / max(wall_w, 1e-9), "unit": "audio-sec/wall-sec", "cores": used, "kind": "port",
+            "cpu_model": cpu_model, "cores_available": avail,
+            "per_core_value": audio / max(busy_w, 1e-9),
+            "thread_busy_fraction": busy_w / max(wall_w * used, 1e-9),
+            "sample": "the %d shortest utterances of the test set (%.1f s audio) on %d threads pulling from one list, %.1f s "
+                      "wall, %.1f core-s: whole path MFCC + nnet + LatticeFasterDecoder (order-faithful oracle, mode 0) + best "
+                      "path; single-utterance probe %.2f s" % (len(sample), audio, used, wall_w, busy_w, t_first),
+            "decoder_only": {"value": audio / max(wall_d, 1e-9), "per_core_value": audio / max(busy_d, 1e-9), "cores": used,
+                             "wall_s": wall_d,
+                             "what": "the CPU decoder alone (mode 0) on the device's log-likelihoods of the same utterances"},
+            "one_best_vs_cpu_whole_path": {"errors": errs_w, "ref_words": ref_w},
+            "one_best_vs_cpu_decoder_same_loglikes": {"errors": errs_d, "ref_words": ref_d, "utterances_with_other_cost": cost_diff}}
 
 
+def wer_leg(g, cfg, n_utts, cores, log):
+    """BASELINE's WER clause on synthetic data with a KNOWN transcript: utterances planted in the bench graph
+    (synth.sample_utterance: a random word sequence through HCLG, log-likelihoods peaked on the true pdfs at a noise level
+    that leaves real errors), decoded by the device (work queue) and by the CPU oracle in its order-faithful mode 0; both
+    lattice sets go through determinization and a best path, and are scored against the transcript."""
+    from kaldi_amd import decoder, io as kio, latbin, pipeline, synth
+    from oracle import orc
+    utts = []
+    for i in range(n_utts):
+        ll, words, _ = synth.sample_utterance(g, n_words=6 + i % 7, seed=7000 + i, peak=2.0, noise=1.0)
+        utts.append((ll, words))
+    T = max(ll.shape[0] for ll, _ in utts)
+    sz = pipeline.default_sizes(cfg, min(n_utts, 64), T + 2, T + 2)
+    bd = decoder.BatchDecoder(decoder.Graph(g), cfg, sz)
+    lats, recs, ms = bd.decode_queue([ll for ll, _ in utts], resident_lanes=min(n_utts, 64))
+    log("wer leg: device decode of %d planted utterances %.1f ms" % (n_utts, ms))
+
+    def cpu(i):
+        o = orc.Decoder(g, cfg, 0)
+        o.Decode(utts[i][0])
+        return o.GetRawLattice()
+
+    cpu_lats, wall, _ = _run_threads(cpu, list(range(n_utts)), cores)
+    log("wer leg: cpu decode %.1f s" % wall)
+
+    def one_best(lat):
+        """determinize, then lattice-best-path's CompactLatticeShortestPath (kaldi_amd/latbin.py)"""
+        if lat is None:
+            return []
+        cl = kio.determinize_lattice(lat, cfg.lattice_beam)
+        L = latbin.Lat(cl.start)
+        for s_ in range(cl.num_states):
+            L.add_state()
+            if np.isfinite(cl.final[2 * s_]):
+                L.final[s_] = (cl.final[2 * s_], cl.final[2 * s_ + 1], cl.final_string(s_).tolist())
+        for k in range(cl.arcs.size):
+            a = cl.arcs[k]
+            L.arcs[int(a["src"])].append((int(a["dst"]), int(a["label"]), a["graph_cost"], a["acoustic_cost"], cl.arc_string(k).tolist()))
+        bp = latbin.best_path(L)
+        return [] if bp is None else list(bp[0])
+
+    from tests.util import lattices_equal
+    ref, hyp_d, hyp_c = {}, {}, {}
+    e_between = lat_diff = 0
+    for i, (ll, words) in enumerate(utts):
+        key = "utt%03d" % i
+        ref[key] = [str(w) for w in words]
+        hyp_d[key] = [str(w) for w in one_best(lats[i])]
+        hyp_c[key] = [str(w) for w in one_best(cpu_lats[i])]
+        e_between += _edit_distance(hyp_c[key], hyp_d[key])
+        lat_diff += 0 if lattices_equal(lats[i], cpu_lats[i]) else 1
+    wd, wc = latbin.compute_wer(ref, hyp_d, "present"), latbin.compute_wer(ref, hyp_c, "present")
+    return {"utterances": n_utts, "wer_line_device": wd[0], "wer_line_cpu_reference_port": wc[0], "identical_wer_lines": wd == wc,
+            "word_errors_device_vs_cpu_hypotheses": e_between,
+            "utterances_whose_raw_lattice_differs_from_mode0": lat_diff,
+            "what": "planted transcripts in the bench HCLG, log-likelihoods peaked on the true pdfs (peak 2.0, noise 1.0); device "
+                    "(work queue, canonical search) vs CPU oracle mode 0 (the reference's order-dependent search); both through "
+                    "DeterminizeLatticePhonePruned + lattice-best-path + compute-wer, scored against the transcript"}
+
+
+# ----------------------------------------------------------------------------- rank
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="mini_librispeech", choices=["mini_librispeech", "librispeech", "tiny"])
-    ap.add_argument("--utts", type=int, default=64)
-    ap.add_argument("--vocab", type=int, default=20000)
-    ap.add_argument("--n-hist", type=int, default=18000)
-    ap.add_argument("--output-scale", type=float, default=1.0)
-    ap.add_argument("--lm-scale", type=float, default=0.1, help="scale on the synthetic LM costs")
-    ap.add_argument("--ll-std", type=float, default=1.3,
-                    help="per-frame std (nats) of the synthetic log-likelihoods across pdfs after calibration")
-    ap.add_argument("--max-seconds", type=float, default=0.0)
-    ap.add_argument("--hash-capacity", type=int, default=0, help="tokens of one frame per lane (power of two); "
-                    "0 = derived from max-active")
-    ap.add_argument("--overlap", default="", help="output-frame indices (e.g. '48') at which the nnet stage is cut in "
-                    "time; each later slice's forward runs while the decoder lanes advance over the slice before it.  Same "
-                    "lattices, but measured SLOWER at batch 64 (DESIGN.md section 5), so off by default")
-    ap.add_argument("--ivectors", action="store_true", help="variant: the model takes 100-dim online i-vectors, estimated "
-                    "on the device from the batch's features (512-Gaussian UBM, period 10) and fed chunk by chunk "
-                    "(frames-per-chunk 50) like nnet3-latgen-faster --online-ivectors; no CPU baseline for this variant")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
-    ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the cpu_baseline leg (0 = every core this process may use)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verbose", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo to "
-                    "exercise the N>1 code path with several ranks sharing one GPU")
-    ap.add_argument("--device", type=int, default=-1, help="override the HIP device (default LOCAL_RANK)")
-    args = ap.parse_args()
-
+    args = defaults(parse_args())
+    world = int(os.environ.get("WORLD_SIZE", "0"))
+    if world == 0 and args.gpus > 1:
+        launch_ranks(args)          # does not return
+    world = max(world, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    T0 = time.time()
+
+    def log(msg):
+        if args.verbose and rank == 0:
+            print("[bench %.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
+
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
         if args.dist_backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(args.dist_backend)   # nccl = RCCL; only barriers + two scalar reductions use it
+            torch.cuda.set_device(local_rank if args.device < 0 else args.device)
+        dist.init_process_group(args.dist_backend)   # nccl = RCCL; only barriers + scalar reductions use it
 
-    from kaldi_amd import abi, pipeline
+    from kaldi_amd import abi, batch, shard, synth
     from kaldi_amd._lib import check, lib, require_gpu
-    require_gpu()
-    check(lib().kamd_set_device(args.device if args.device >= 0 else local_rank))
-    def log(msg):
-        if args.verbose and rank == 0:
-            print("[bench %.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
-    T0 = time.time()
-    g, model, waves, cfg, t_build = build_workload(args, rank)
-    ie = None
-    if args.ivectors:
-        from kaldi_amd import feat, ivector
-        sample = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(waves[0][:16000 * 5])
-        ie = ivector.IvectorExtractor(ivector.make_synthetic(seed=11, feat_mean=sample.mean(0), feat_std=sample.std(0), max_count=100.0))
-        log("i-vector extractor created")
-        # random first-layer weights would let the 100 i-vector inputs swamp the 3 x 40 cepstra (a trained
-        # model sees them through the LDA-like first affine, roughly unit variance in total): damp those
-        # columns so that the synthetic search load stays what --ll-std asks for
-        ivs = ie.extract_online(sample)
-        l0 = model.layers[0]
-        nf = l0.W.shape[1] - l0.ivector_dim
-        ratio = np.std(l0.W[:, :nf] @ np.tile(sample[:50], (1, nf // sample.shape[1])).T) / max(np.std(l0.W[:, nf:] @ ivs.T), 1e-9)
-        l0.W[:, nf:] *= np.float32(0.3 * ratio)
-    spread, k = calibrate(model, args.ll_std, ie)
-    log("workload built: %d states %d arcs, %d utts" % (g.num_states, g.num_arcs, len(waves)))
+    ndev = require_gpu()
+    dev = args.device if args.device >= 0 else local_rank
+    if dev >= ndev:
+        raise SystemExit("rank %d wants device %d but only %d are visible (use --dist-backend gloo --device 0 to share one)" %
+                         (rank, dev, ndev))
+    check(lib().kamd_set_device(dev))
+    g, model, durs, cfg, t_build = build_workload(args)
+    spread, k = calibrate(model, args.ll_std)
+    log("workload built: %d states %d arcs, %d utts (%.2f h)" % (g.num_states, g.num_arcs, durs.size, durs.sum() / 3600))
+    # ONE test set, partitioned over the ranks (steps/nnet3/decode.sh:96,123: split_data + JOB=1:nj)
+    mine = shard.lpt_shards(durs, world)[rank]
+    waves = synth.make_waves_fast(durs[mine], seed=1000 + rank)
     audio = sum(w.size for w in waves) / 16000.0
-    max_s = max(w.size for w in waves) / 16000.0 + 0.5
-    sizes = None
-    if args.hash_capacity:
-        fps = 100.0 / model.subsampling
-        sizes = pipeline.default_sizes(cfg, len(waves), int(max_s * fps) + 2, int(audio / len(waves) * fps) + 2,
-                                       hash_capacity=args.hash_capacity)
-    pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves), max_seconds=max_s,
-                             avg_seconds=audio / len(waves), sizes=sizes)
-    log("pipeline created")
-    if ie is not None:
-        pipe.set_ivector_extractor(ie, 50)
-    pipe.load(waves)                        # inputs resident in HBM before the timed region
-    log("batch loaded")
+    max_s = float(durs.max()) + 0.5
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    host_threads = args.host_threads or max(1, min(16, cores // world))
+    bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=max_s, resident_lanes=args.lanes,
+                                host_threads=host_threads, determinize=not args.no_determinize, keep_raw_lattices=False,
+                                nnet_pass_frames=args.nnet_pass_frames, hash_capacity=args.hash_capacity or None,
+                                tokens_per_frame=args.tokens_per_frame or None,
+                                lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)))
+    log("batch decoder created (%d host threads)" % host_threads)
+    bd.load(waves)                          # inputs resident in HBM before the timed region
+    log("shard loaded: %d utterances, %.0f s audio" % (len(waves), audio))
 
     def sync_all():
         check(lib().kamd_device_synchronize())
         if dist is not None:
             dist.barrier()
 
-    # one unsliced pass first: the stage split and the GEMM rate without any overlap
-    plain_ms = pipe.run()
-    plain_flops = lib().kamd_nnet_last_flops(pipe.nnet._h)
-    log("unsliced pass: stage ms %s" % plain_ms)
-    bounds = [int(x) for x in args.overlap.split(",") if x.strip()]
-    pipe.set_overlap(bounds)
     for _ in range(args.warmup):
-        ms = pipe.run()
-        log("warmup step: stage ms %s" % ms)
+        st = bd.run()
+        log("warmup step: feat %.1f nnet %.1f decode %.1f tail %.1f total %.1f ms, failed %d" %
+            (st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms, st.n_failed))
     sync_all()
     t0 = time.time()
-    stage = np.zeros(4)
-    adv_ms, launches = [], 1
+    acc = np.zeros(7)
     for _ in range(args.steps):
-        stage += np.asarray(pipe.run())
-        adv_ms.append(pipe.dec.last_advance_ms())
-        launches = lib().kamd_decoder_last_advance_launches(pipe.dec._dec)
+        st = bd.run()
+        acc += [st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms, st.first_result_ms, st.host_thread_ms_sum]
     sync_all()
     dt = time.time() - t0
+    my_dt = dt
     log("timed steps done: %.3f s" % dt)
+    rank_walls, total_audio = [dt], audio
     if dist is not None:
         import torch
         tdev = "cuda" if args.dist_backend == "nccl" else "cpu"
-        t = torch.tensor([dt], device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        a = torch.tensor([audio], device=tdev)
+        t = torch.tensor([dt], device=tdev, dtype=torch.float64)
+        allw = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allw, t)
+        rank_walls = [float(x.item()) for x in allw]
+        dt = max(rank_walls)
+        a = torch.tensor([audio], device=tdev, dtype=torch.float64)
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         total_audio = float(a.item())
-    else:
-        total_audio = audio
     if rank != 0:
         return
-    counters = np.sum([pipe.dec.counters(u) for u in range(len(waves))], axis=0)
-    # counters are reset at InitDecoding: per step = per batch, spread over `launches` AdvanceKernel
-    # launches when the nnet stage is sliced (every lane continues where it stopped)
-    alg_bytes = float(algorithmic_bytes(counters)) / launches
-    adv = float(np.mean(adv_ms)) / launches
+    acc /= args.steps
+    n = len(waves)
+    recs = [bd.record(u) for u in range(n)]
+    counters = np.sum([np.asarray(r.counters[:8], np.float64) for r in recs], axis=0)
     frames = int(counters[6])
-    res = pipe.results(lattices=False)
-    log("results fetched")
+    alg_bytes = float(algorithmic_bytes(counters))
+    dec_ms, nnet_ms = float(acc[2]), float(acc[1])
+    longest = int(np.argmax([r.n_frames for r in recs]))
+    ph = np.asarray(recs[longest].phase_cycles[:len(PHASES)], np.float64)
+    n_failed = sum(1 for r in recs if r.error)
+    words = [bd.output(u) for u in range(min(n, 200))]
+    mean_words = float(np.mean([len(w["words"]) for w in words if w is not None])) if any(w is not None for w in words) else 0.0
+    dec_roof = {"bound": "hbm", "kernel": "kamd::DecodeQueueKernel", "achieved": alg_bytes / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": alg_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
+                "traffic_source": "profiles/*_pmc.json of this workload (rocprofv3 --pmc passes), not this run",
+                "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": dec_ms, "lanes": int(st.lanes),
+                "us_per_frame_per_lane": 1e3 * dec_ms * int(st.lanes) / max(frames, 1)}
+    nnet_roof = {"bound": "mfma", "kernel": "kamd::TdnnGemmKernel (all layers of all passes)", "achieved": st.nnet_flops / (nnet_ms * 1e-3) / 1e12,
+                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": st.nnet_flops / (nnet_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                 "traffic": None, "flops_per_step": st.nnet_flops, "stage_ms": nnet_ms, "passes": int(st.nnet_passes)}
+    dominant_is_decoder = dec_ms >= nnet_ms
     out = {
         "metric": "decode RTF (audio-sec/wall-sec)",
         "value": total_audio * args.steps / dt,
         "unit": "audio-sec/wall-sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s TDNN-F chain topology (random init), synthetic %s-scale HCLG "
-                               "(%d states, %d arcs), batch=%d utterances/GPU (%.0f s audio), beam 15 "
-                               "max-active 7000 min-active 200 lattice-beam 8" %
-                               (args.workload, "tglarge" if g.num_states > 2e7 else "tgsmall", g.num_states,
-                                g.num_arcs, len(waves), audio),
-                   "utterances_per_gpu": len(waves), "loglike_std_nats": args.ll_std},
-        "stage_ms": {"features": stage[0] / args.steps, "nnet_before_search": stage[1] / args.steps,
-                     "decode_advance": stage[2] / args.steps, "decode_finalize": stage[3] / args.steps},
-        "stage_ms_unsliced": {"features": plain_ms[0], "nnet": plain_ms[1], "decode_advance": plain_ms[2],
-                              "decode_finalize": plain_ms[3]},
-        "nnet_overlap": {"slice_bounds_output_frames": bounds, "advance_launches_per_step": launches},
+        "config": {"workload": "%s: %d synthetic utterances (%.2f h, lognormal 1-35 s) sharded over %d GPU(s), %s TDNN-F chain "
+                               "topology (random init, P=%d), synthetic %s-scale HCLG (%d states, %d arcs), beam 15 max-active 7000 "
+                               "min-active 200 lattice-beam 8, %s lanes/GPU fed by a device work queue, host tail (D2H, best path, "
+                               "%s) on %d threads/GPU inside the timed region" %
+                               ("LibriSpeech test-clean sized test set" if args.workload == "librispeech" else args.workload + " set",
+                                durs.size, durs.sum() / 3600.0, world, args.workload, g.num_pdfs, args.graph, g.num_states, g.num_arcs,
+                                int(st.lanes), "no determinization" if args.no_determinize else "lattice determinization", host_threads),
+                   "utterances": int(durs.size), "utterances_rank0": n, "loglike_std_nats": args.ll_std, "lm_scale": args.lm_scale,
+                   "baseline_config": "configs[2]" if args.workload == "librispeech" and args.graph == "tglarge" else
+                                      ("configs[1]" if args.workload == "mini_librispeech" else "other")},
+        "device_only_value": audio / ((acc[0] + acc[1] + acc[2]) * 1e-3),
+        "stage_ms": {"features": acc[0], "nnet": acc[1], "decode_queue_kernel": acc[2], "host_tail_after_last_utterance": acc[3],
+                     "total_wall": acc[4], "first_result_at": acc[5], "host_tail_cpu_ms_all_threads": acc[6]},
+        "rank_wall_s": rank_walls, "rank0_wall_s": my_dt,
         "decoder": {"frames": frames, "tokens_per_frame": counters[5] / max(frames, 1),
                     "expanded_per_frame": counters[0] / max(frames, 1),
                     "arcs_per_frame": counters[1] / max(frames, 1),
                     "links_per_frame": counters[4] / max(frames, 1),
-                    "words_lane0": int(res[0]["words"].size)},
-        "roofline": {"bound": "hbm", "kernel": "kamd::AdvanceKernel",
-                     "achieved": alg_bytes / (adv * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg_bytes / (adv * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
-                     "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": adv, "launches_per_step": launches},
-        "phase_share_longest_lane": phase_share(pipe, waves),
-        "nnet_tflops": plain_flops / (plain_ms[1] * 1e-3) / 1e12,
+                    "failed_utterances": n_failed, "mean_words_per_utterance_first_200": mean_words},
+        "roofline": dec_roof if dominant_is_decoder else nnet_roof,
+        "roofline_other_stage": nnet_roof if dominant_is_decoder else dec_roof,
+        "phase_share_longest_utterance": {k2: round(float(v / max(ph.sum(), 1.0)), 3) for k2, v in zip(PHASES, ph)},
         "setup_s": t_build,
     }
-    if args.ivectors:
-        out["config"]["workload"] += ", 100-dim online i-vectors estimated on the device"
-        out["stage_ms"]["features"] = None
-        out["stage_ms"]["features_and_ivectors"] = stage[0] / args.steps
-    if not args.no_cpu_baseline and world == 1 and not args.ivectors:
-        out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, args.cpu_budget, res, args.cpu_cores)
+    if not args.no_cpu_baseline and world == 1:
+        log("cpu baseline ...")
+        out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, bd, args.cpu_budget, args.cpu_cores)
     else:
         out["cpu_baseline"] = None
+    if not args.no_wer and world == 1:
+        log("wer leg ...")
+        del bd
+        out["wer"] = wer_leg(g, cfg, args.wer_utts, min(32, cores), log)
     print(json.dumps(out, default=float))
+
+
+def pmc_traffic(args):
+    """HBM bytes per DecodeQueueKernel launch from the committed rocprofv3 PMC passes
+    (profiles/*_pmc.json), only when they were taken on this exact workload."""
+    key = "%s/%s/%d/%s/%s" % (args.workload, args.graph, args.utts, args.ll_std, args.lm_scale)
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("_pmc.json"):
+                try:
+                    d = json.load(open(os.path.join(pdir, f)))
+                except Exception:
+                    continue
+                if d.get("workload_key") == key:
+                    best = d.get("traffic_bytes_per_launch")
+    return best
 
 
 if __name__ == "__main__":

@@ -418,6 +418,8 @@ __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int stat
       return static_cast<int>(h);
     }
     h = (h + 1) & static_cast<u32>(d.hash_mask);
+    // a table that has overflowed is nearly full: every further insert would scan it end to end
+    if ((probe & 63) == 63 && sh->err) break;
   }
   sh->err = ERR_HASH;
   *improved = false;
@@ -523,6 +525,7 @@ __device__ inline int HashFind(const DecDev &d, const Ctx &c, int state) {
     if (cur == EMPTY64) return -1;
     if (StateOf(cur) == state) return static_cast<int>(h);
     h = (h + 1) & static_cast<u32>(d.hash_mask);
+    if ((probe & 1023) == 1023) return -1;   // only an overflowed table has runs this long
   }
   return -1;
 }

@@ -244,6 +244,25 @@ def make_wave(seconds, seed=0, samp_freq=16000):
     return np.round(x).astype(np.float32)
 
 
+def make_waves_fast(durations, seed=0, samp_freq=16000):
+    """A test set's worth of synthetic utterances in seconds instead of minutes: every utterance
+    is a window of one long make_wave-style signal, with its own gain and one extra tone
+    (the content only has to exercise the feature / nnet kernels; the search load of the bench
+    is set by the calibration of the output layer, not by the audio)."""
+    rng = np.random.default_rng(seed)
+    durations = np.asarray(durations, np.float64)
+    pool = make_wave(min(120.0, float(durations.max()) + 60.0), seed=seed + 1, samp_freq=samp_freq)
+    out = []
+    for d in durations:
+        n = int(d * samp_freq)
+        start = int(rng.integers(0, pool.size - n)) if pool.size > n else 0
+        t = np.arange(n, dtype=np.float32) / np.float32(samp_freq)
+        w = pool[start:start + n] * np.float32(rng.uniform(0.5, 1.0))
+        w = w + np.float32(1500.0) * np.sin(np.float32(2 * np.pi * rng.uniform(150, 3000)) * t, dtype=np.float32)
+        out.append(np.round(w).astype(np.float32))
+    return out
+
+
 def utterance_durations(n, seed=1, mu=7.0, sigma=0.6, lo=1.0, hi=35.0):
     """LibriSpeech-like durations: lognormal(ln 7 s, 0.6) clipped to [1, 35] s."""
     rng = np.random.default_rng(seed)

@@ -31,9 +31,11 @@ def main():
     ap.add_argument("--hash-capacity", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
-    args.ivectors = False
-    g, model, waves, cfg, _ = bench.build_workload(args, 0)
+    args.graph = "tgsmall" if args.vocab < 100000 else "tglarge"
+    from kaldi_amd import synth
+    g, model, durs, cfg, _ = bench.build_workload(args)
     bench.calibrate(model, args.ll_std)
+    waves = synth.make_waves_fast(durs, seed=1000)
     audio = sum(w.size for w in waves) / 16000.0
     max_s = max(w.size for w in waves) / 16000.0 + 0.5
     pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves), max_seconds=max_s,
