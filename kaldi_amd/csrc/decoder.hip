@@ -407,7 +407,7 @@ __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int stat
     const u64 old = atomicCAS(&c.H[h], EMPTY64, mine);
     if (old == EMPTY64) {
       int idx = WaveAlloc(&sh->n_slots);
-      if (idx < d.hash_cap) c.slots[idx] = h + static_cast<u32>(slot_bias); else sh->err = ERR_HASH;
+      if (idx < d.hash_cap) c.slots[idx] = h + static_cast<u32>(slot_bias); else atomicOr(&sh->err, ERR_HASH);
       *improved = true;
       return static_cast<int>(h);
     }
@@ -421,7 +421,7 @@ __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int stat
     // a table that has overflowed is nearly full: every further insert would scan it end to end
     if ((probe & 63) == 63 && sh->err) break;
   }
-  sh->err = ERR_HASH;
+  atomicOr(&sh->err, ERR_HASH);
   *improved = false;
   return -1;
 }
@@ -461,7 +461,7 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
   for (int q = 0; q < W; q++) {
     if (!pass[q]) continue;
     const int li = link_base + WaveAlloc(&sh->n_links);
-    if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
+    if (li >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
     Link L; L.src = src_tok[q]; L.dst = arc[q].nextstate; L.ilabel = arc[q].ilabel; L.olabel = arc[q].olabel;
     L.graph = arc[q].weight; L.ac = ac[q];
     c.links[li] = L;
@@ -599,7 +599,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
     for (int i = tid; i < ns; i += NT) {
       const u32 slot = c.slots[i];
       const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
-      if (e == EMPTY64) { sh->err = ERR_INTERNAL; continue; }
+      if (e == EMPTY64) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
       if (HasEps(StateOf(e)) && CostOf(e) <= cutoff) {
         int p = WaveAlloc(&sh->wl_n[0]);
         c.wl0[p] = slot;
@@ -630,7 +630,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
           if (slot2 >= 0 && improved) {
             if (HasEps(arc.nextstate) && atomicExch(&c.stamp[slot2], round) != round) {
               int p = WaveAlloc(&sh->wl_n[cur ^ 1]);
-              if (p < d.hash_cap) wl_nxt[p] = static_cast<u32>(slot2); else sh->err = ERR_WL;
+              if (p < d.hash_cap) wl_nxt[p] = static_cast<u32>(slot2); else atomicOr(&sh->err, ERR_WL);
             }
           }
         }
@@ -655,7 +655,7 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
   for (int i = tid; i < ns; i += NT) {
     const u32 slot = c.slots[i];
     const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
-    if (e == EMPTY64) sh->err = ERR_INTERNAL;   // a listed slot must hold a token
+    if (e == EMPTY64) atomicOr(&sh->err, ERR_INTERNAL);   // a listed slot must hold a token
     int idx = -1;
     if (e != EMPTY64 && CostOf(e) <= cutoff) {
       idx = tok_base + WaveAlloc(&sh->n_new);
@@ -667,11 +667,11 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
         if (idx - tok_base < cache_cap) cost_cache[idx - tok_base] = CostOf(e);
         if (HasEps(StateOf(e))) {           // dense list of the tokens that own epsilon arcs
           const int p = WaveAlloc(&sh->wl_n[1]);
-          if (p < d.hash_cap) c.wl1[p] = static_cast<u32>(idx); else sh->err = ERR_WL;
+          if (p < d.hash_cap) c.wl1[p] = static_cast<u32>(idx); else atomicOr(&sh->err, ERR_WL);
         }
         const u64 k = (static_cast<u64>(static_cast<u32>(e)) << 32) | static_cast<u32>(st);
         kmin = k < kmin ? k : kmin;
-      } else { sh->err = ERR_TOK; idx = -1; }
+      } else { atomicOr(&sh->err, ERR_TOK); idx = -1; }
     }
     c.slot_tok[slot] = idx;
   }
@@ -705,9 +705,9 @@ __device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tb
         if (tot_cost < cutoff) {
           const int slot2 = TblFind(d, c, tbl, arc.nextstate);
           const int dst = slot2 >= 0 ? c.slot_tok[slot2] : -1;
-          if (dst < 0) { sh->err = ERR_INTERNAL; continue; }
+          if (dst < 0) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
           const int li = eps_link_begin + WaveAlloc(&sh->wl_n[0]);   // worklist 0 is idle here
-          if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
+          if (li >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
           Link L; L.src = t; L.dst = dst; L.ilabel = 0; L.olabel = arc.olabel;
           L.graph = arc.weight; L.ac = 0.0f;
           c.links[li] = L;
@@ -773,7 +773,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
   LdsBarrier();
   const int n2 = min(sh->n_slots, d.hash_cap);      // level-2 entries created by the emitting inserts
   if (n2 > 0) __syncthreads();                      // their slot list lives in HBM
-  auto wl_put = [&](int which, int p, u32 v) { if (p < L.wl_cap) (which ? L.wl1 : L.wl0)[p] = v; else if (p < d.hash_cap) (which ? c.wl1 : c.wl0)[p] = v; else sh->err = ERR_WL; };
+  auto wl_put = [&](int which, int p, u32 v) { if (p < L.wl_cap) (which ? L.wl1 : L.wl0)[p] = v; else if (p < d.hash_cap) (which ? c.wl1 : c.wl0)[p] = v; else atomicOr(&sh->err, ERR_WL); };
   auto wl_get = [&](int which, int p) -> u32 { return p < L.wl_cap ? (which ? L.wl1 : L.wl0)[p] : (which ? c.wl1 : c.wl0)[p]; };
   // ---- epsilon closure: initial worklist = every token with epsilon arcs (:855-859)
   const int n1a = sh->n_slots1;
@@ -785,7 +785,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
   for (int i = tid; i < n2; i += NT) {
     const u32 slot = c.slots[i];
     const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
-    if (e == EMPTY64) { sh->err = ERR_INTERNAL; continue; }
+    if (e == EMPTY64) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
     if (HasEps(StateOf(e)) && CostOf(e) <= cutoff) wl_put(0, WaveAlloc(&sh->wl_n[0]), slot);
   }
   if (tid < 256) sh->hist[tid] = 0;                 // "queued this round" bits of the level-1 slots
@@ -848,7 +848,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
         if (idx - tok_base < cache_cap) cost_cache[idx - tok_base] = CostOf(e);
         const u64 k = (static_cast<u64>(static_cast<u32>(e)) << 32) | static_cast<u32>(st);
         kmin = k < kmin ? k : kmin;
-      } else { sh->err = ERR_TOK; idx = -1; }
+      } else { atomicOr(&sh->err, ERR_TOK); idx = -1; }
     }
     *idx_out = idx;
   };
@@ -856,7 +856,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
     const int p = WaveAlloc(&sh->wl_n[1]);
     if (p < L.owners_cap) L.owners[p] = make_uint2(slot, static_cast<u32>(e));
     else if (p < d.hash_cap) { c.wl1[p] = slot; c.scratch[p] = CostOf(e); }
-    else sh->err = ERR_WL;
+    else atomicOr(&sh->err, ERR_WL);
   };
   const int n1 = sh->n_slots1;                   // level-1 entries (emitting + closure)
   for (int i = tid; i < n1; i += NT) {
@@ -870,7 +870,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
   for (int i = tid; i < ns2; i += NT) {
     const u32 slot = c.slots[i];
     const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
-    if (e == EMPTY64) { sh->err = ERR_INTERNAL; continue; }
+    if (e == EMPTY64) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
     int idx;
     commit_entry(e, &idx);
     if (idx >= 0 && HasEps(StateOf(e))) add_owner(slot, e);
@@ -927,9 +927,9 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
         if (tot_cost < cutoff) {
           const int slot2 = TblFind(d, c, tbl, arc.nextstate);
           const int dst = slot2 >= 0 ? tok_of_slot(slot2) : -1;
-          if (dst < 0) { sh->err = ERR_INTERNAL; continue; }
+          if (dst < 0) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
           const int li = eps_link_begin + WaveAlloc(&sh->wl_n[0]);   // worklist 0 is idle here
-          if (li >= c.lnk_cap) { sh->err = ERR_LINK; continue; }
+          if (li >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
           Link Lk; Lk.src = t; Lk.dst = dst; Lk.ilabel = 0; Lk.olabel = arc.olabel;
           Lk.graph = arc.weight; Lk.ac = 0.0f;
           c.links[li] = Lk;
@@ -1106,7 +1106,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
   }
   ComputeFrameStats(d, c, &sh, frame, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
   for (int it = 0; it < task.n_frames; it++, frame++) {
-    if (frame >= d.max_frames) { if (tid == 0) sh.err = ERR_FRAMES; __syncthreads(); break; }
+    if (frame >= d.max_frames) { if (tid == 0) atomicOr(&sh.err, ERR_FRAMES); __syncthreads(); break; }
     const float *ll = task.d_loglikes + static_cast<size_t>(it) * task.ld;
     const int tb = sh.cur_tb, n = sh.cur_n;   // == c.tok_off[frame], c.tok_off[frame + 1] - tb
     const float *cost = c.tok_cost + tb;
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes)
   int cur = 0;
   for (int f = F; f >= 0; f--) {
     const int tb = c.tok_off[f], nt = c.tok_off[f + 1] - tb;
-    if (nt > d.hash_cap) { if (tid == 0) sh.err = ERR_INTERNAL; __syncthreads(); break; }
+    if (nt > d.hash_cap) { if (tid == 0) atomicOr(&sh.err, ERR_INTERNAL); __syncthreads(); break; }
     float *xcur = c.tok_extra + tb;   // extra_cost of frame f (frame f+1 is final already)
     const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
     const bool in_lds = nt <= FIN_CAP && (f == F || next_in_lds);
@@ -1693,7 +1693,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
   for (int f = F; f >= 0; f--) {
     const int tb = c.tok_off[f], nt = c.tok_off[f + 1] - tb;
     const int tbn = c.tok_off[f + 1], ntn = f < F ? c.tok_off[f + 2] - tbn : 0;
-    if (nt > d.hash_cap) { if (tid == 0) sh.err = ERR_INTERNAL; __syncthreads(); break; }
+    if (nt > d.hash_cap) { if (tid == 0) atomicOr(&sh.err, ERR_INTERNAL); __syncthreads(); break; }
     const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];       // epsilon links inside frame f
     const int le = f < F ? c.lnk_off[2 * (f + 1) + 1] : ee;              // emitting links f -> f+1: [ee, le)
     const float emit_off = c.cost_offsets[f < F ? f : 0];                 // GetRawLattice :173-180 (used for f < F only)
@@ -1807,7 +1807,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
       };
       auto stage_link = [&](Link L, bool is_eps) {
         const int ps2 = lp[L.src - tb], pd = is_eps ? lp[L.dst - tb] : np[L.dst - tbn];
-        if (ps2 < 0 || pd < 0) { sh.err = ERR_INTERNAL; return; }
+        if (ps2 < 0 || pd < 0) { atomicOr(&sh.err, ERR_INTERNAL); return; }
         L.src = ps2; L.dst = pd;
         if (!is_eps) L.ac = L.ac - emit_off;
         c.links[WaveAllocDown(&s_lnk_top)] = L;
@@ -1921,7 +1921,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
           const bool is_eps = li < ee;
           const int ps2 = gp[L.src - tb];
           const int pd = is_eps ? gp[L.dst - tb] : gpn[L.dst - tbn];
-          if (ps2 < 0 || pd < 0) { sh.err = ERR_INTERNAL; }
+          if (ps2 < 0 || pd < 0) { atomicOr(&sh.err, ERR_INTERNAL); }
           else {
             L.src = ps2; L.dst = pd;
             if (!is_eps) L.ac = L.ac - emit_off;

@@ -68,6 +68,12 @@ def lib():
         L.orc_decoder_create.restype = C.c_void_p
         L.orc_decoder_create.argtypes = [C.c_int32, C.c_int32, i64p, C.c_void_p, fp,
                                          C.POINTER(abi.DecoderConfig), ip, C.c_int32, C.c_int]
+        L.orc_graph_create.restype = C.c_void_p
+        L.orc_graph_create.argtypes = [C.c_int32, C.c_int32, i64p, C.c_void_p, fp]
+        L.orc_graph_destroy.argtypes = [C.c_void_p]
+        L.orc_graph_destroy.restype = None
+        L.orc_decoder_create_on.restype = C.c_void_p
+        L.orc_decoder_create_on.argtypes = [C.c_void_p, C.POINTER(abi.DecoderConfig), ip, C.c_int32, C.c_int]
         for f in ("destroy", "init", "finalize"):
             getattr(L, "orc_decoder_" + f).argtypes = [C.c_void_p]
             getattr(L, "orc_decoder_" + f).restype = None
@@ -292,17 +298,44 @@ class Lattice:
                     graph_cost=g.value, acoustic_cost=a.value)
 
 
+class _Graph:
+    """Host copy of a decoding graph in the oracle's layout, shared read-only by its decoders (the reference
+    hands one const fst::Fst& to every decoder object)."""
+
+    def __init__(self, g):
+        arcs = np.ascontiguousarray(g.arcs)
+        self._h = lib().orc_graph_create(g.num_states, g.start, abi.iptr(np.ascontiguousarray(g.arc_off, np.int64), C.c_int64),
+                                         arcs.ctypes.data_as(C.c_void_p), abi.fptr(np.ascontiguousarray(g.final, np.float32)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_graph_destroy(self._h)
+            self._h = None
+
+
+_graph_lock = __import__("threading").Lock()
+
+
+def shared_graph(g):
+    with _graph_lock:
+        sg = getattr(g, "_orc_graph", None)
+        if sg is None:
+            sg = _Graph(g)
+            try:
+                g._orc_graph = sg
+            except AttributeError:           # an object that takes no attributes: a private copy then
+                pass
+        return sg
+
+
 class Decoder:
     """orc_decoder: mode 0 = faithful to the reference's order, 1 = canonical."""
 
     def __init__(self, g, cfg, mode=1):
         self.g, self.cfg, self.mode = g, cfg, mode
-        arcs = np.ascontiguousarray(g.arcs)
-        self._h = lib().orc_decoder_create(
-            g.num_states, g.start, abi.iptr(np.ascontiguousarray(g.arc_off, np.int64), C.c_int64),
-            arcs.ctypes.data_as(C.c_void_p), abi.fptr(np.ascontiguousarray(g.final, np.float32)),
-            C.byref(cfg), abi.iptr(np.ascontiguousarray(g.tid2pdf, np.int32)),
-            g.tid2pdf.size - 1, mode)
+        self._graph = shared_graph(g)          # one host copy per Hclg object, shared by all its decoders
+        self._h = lib().orc_decoder_create_on(self._graph._h, C.byref(cfg), abi.iptr(np.ascontiguousarray(g.tid2pdf, np.int32)),
+                                              g.tid2pdf.size - 1, mode)
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -111,13 +111,24 @@ struct HashList {
   void ResetPoolIfEmpty() { if (list_head == -1) elems.clear(); }
 };
 
-struct Decoder {
-  // graph (OpenFst arc order preserved: the faithful mode depends on it)
+// The decoding graph, shared read-only by every decoder built on it (the reference hands one
+// const fst::Fst& to all decoder objects, nnet-batch-compute.h:610-611).
+struct GraphStore {
   int num_states, start;
   std::vector<int64_t> arc_off;
   std::vector<kamd_arc> arcs;
   std::vector<float> final_cost;
   std::vector<uint8_t> has_eps;  // NumInputEpsilons(state) != 0
+};
+
+struct Decoder {
+  // graph (OpenFst arc order preserved: the faithful mode depends on it)
+  int num_states, start;
+  const int64_t *arc_off;
+  const kamd_arc *arcs;
+  const float *final_cost;
+  const uint8_t *has_eps;
+  GraphStore *own_graph = NULL;   // set when the decoder made its own copy (orc_decoder_create)
   kamd_decoder_config cfg;
   std::vector<int32_t> tid2pdf;
   bool identity_map;
@@ -659,19 +670,27 @@ extern "C" {
 
 typedef struct Decoder orc_decoder;
 
-orc_decoder *orc_decoder_create(int32_t num_states, int32_t start, const int64_t *arc_off,
-                                const kamd_arc *arcs, const float *final_cost,
-                                const kamd_decoder_config *cfg, const int32_t *tid2pdf,
-                                int32_t num_tids, int mode) {
-  Decoder *d = new Decoder();
-  d->num_states = num_states; d->start = start;
-  d->arc_off.assign(arc_off, arc_off + num_states + 1);
-  d->arcs.assign(arcs, arcs + arc_off[num_states]);
-  d->final_cost.assign(final_cost, final_cost + num_states);
-  d->has_eps.assign(num_states, 0);
+typedef struct GraphStore orc_graph;
+orc_graph *orc_graph_create(int32_t num_states, int32_t start, const int64_t *arc_off, const kamd_arc *arcs, const float *final_cost) {
+  GraphStore *g = new GraphStore();
+  g->num_states = num_states; g->start = start;
+  g->arc_off.assign(arc_off, arc_off + num_states + 1);
+  g->arcs.assign(arcs, arcs + arc_off[num_states]);
+  g->final_cost.assign(final_cost, final_cost + num_states);
+  g->has_eps.assign(num_states, 0);
   for (int s = 0; s < num_states; s++)
     for (int64_t a = arc_off[s]; a < arc_off[s + 1]; a++)
-      if (arcs[a].ilabel == 0) { d->has_eps[s] = 1; break; }
+      if (arcs[a].ilabel == 0) { g->has_eps[s] = 1; break; }
+  return g;
+}
+void orc_graph_destroy(orc_graph *g) { delete g; }
+
+// a decoder on a shared graph (the graph must outlive it)
+orc_decoder *orc_decoder_create_on(const orc_graph *g, const kamd_decoder_config *cfg, const int32_t *tid2pdf,
+                                   int32_t num_tids, int mode) {
+  Decoder *d = new Decoder();
+  d->num_states = g->num_states; d->start = g->start;
+  d->arc_off = g->arc_off.data(); d->arcs = g->arcs.data(); d->final_cost = g->final_cost.data(); d->has_eps = g->has_eps.data();
   d->cfg = *cfg;
   d->identity_map = (tid2pdf == NULL);
   if (tid2pdf) d->tid2pdf.assign(tid2pdf, tid2pdf + num_tids + 1);
@@ -682,7 +701,16 @@ orc_decoder *orc_decoder_create(int32_t num_states, int32_t start, const int64_t
   memset(d->counters, 0, sizeof(d->counters));
   return d;
 }
-void orc_decoder_destroy(orc_decoder *d) { delete d; }
+orc_decoder *orc_decoder_create(int32_t num_states, int32_t start, const int64_t *arc_off,
+                                const kamd_arc *arcs, const float *final_cost,
+                                const kamd_decoder_config *cfg, const int32_t *tid2pdf,
+                                int32_t num_tids, int mode) {
+  GraphStore *g = orc_graph_create(num_states, start, arc_off, arcs, final_cost);
+  Decoder *d = orc_decoder_create_on(g, cfg, tid2pdf, num_tids, mode);
+  d->own_graph = g;
+  return d;
+}
+void orc_decoder_destroy(orc_decoder *d) { if (d) { delete d->own_graph; delete d; } }
 void orc_decoder_init(orc_decoder *d) { d->InitDecoding(); }
 void orc_decoder_advance(orc_decoder *d, const float *loglikes, int ld, int n_frames) {
   d->AdvanceDecoding(loglikes, ld, n_frames);
