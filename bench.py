@@ -73,6 +73,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-wer", action="store_true")
     ap.add_argument("--wer-utts", type=int, default=64)
+    ap.add_argument("--search-mode", type=int, default=2, choices=[1, 2], help="kamd_decoder_set_search_mode: 1 canonical (tight), "
+                    "2 canonical-loose (every token the reference's order-dependent pruning can create)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo to "
                     "exercise the N>1 code path with several ranks sharing one GPU")
@@ -286,7 +288,7 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
             "one_best_vs_cpu_decoder_same_loglikes": {"errors": errs_d, "ref_words": ref_d, "utterances_with_other_cost": cost_diff}}
 
 
-def wer_leg(g, cfg, n_utts, cores, log, hash_capacity=0):
+def wer_leg(g, cfg, n_utts, cores, log, hash_capacity=0, search_mode=2):
     """BASELINE's WER clause on synthetic data with a KNOWN transcript: utterances planted in the bench graph
     (synth.sample_utterance: a random word sequence through HCLG, log-likelihoods peaked on the true pdfs at a noise level
     that leaves real errors), decoded by the device (work queue) and by the CPU oracle in its order-faithful mode 0; both
@@ -300,8 +302,12 @@ def wer_leg(g, cfg, n_utts, cores, log, hash_capacity=0):
     T = max(ll.shape[0] for ll, _ in utts)
     sz = pipeline.default_sizes(cfg, min(n_utts, 64), T + 2, T + 2, hash_capacity=hash_capacity or None, tokens_per_frame=80000)   # flat planted scores: a saturated search
     bd = decoder.BatchDecoder(decoder.Graph(g), cfg, sz)
+    bd.SetSearchMode(search_mode)
     lats, recs, ms = bd.decode_queue([ll for ll, _ in utts], resident_lanes=min(n_utts, 64))
-    log("wer leg: device decode of %d planted utterances %.1f ms" % (n_utts, ms))
+    log("wer leg: device decode of %d planted utterances %.1f ms (search mode %d)" % (n_utts, ms, search_mode))
+    bd.SetSearchMode(3 - search_mode)
+    lats_other, _, ms_o = bd.decode_queue([ll for ll, _ in utts], resident_lanes=min(n_utts, 64))
+    log("wer leg: device decode in the other search mode %.1f ms" % ms_o)
 
     def cpu(i):
         o = orc.Decoder(g, cfg, 0)
@@ -328,17 +334,19 @@ def wer_leg(g, cfg, n_utts, cores, log, hash_capacity=0):
         return [] if bp is None else list(bp[0])
 
     from tests.util import lattices_equal
-    ref, hyp_d, hyp_c = {}, {}, {}
+    ref, hyp_d, hyp_c, hyp_o = {}, {}, {}, {}
     e_between = lat_diff = 0
     for i, (ll, words) in enumerate(utts):
         key = "utt%03d" % i
         ref[key] = [str(w) for w in words]
         hyp_d[key] = [str(w) for w in one_best(lats[i])]
+        hyp_o[key] = [str(w) for w in one_best(lats_other[i])]
         hyp_c[key] = [str(w) for w in one_best(cpu_lats[i])]
         e_between += _edit_distance(hyp_c[key], hyp_d[key])
         lat_diff += 0 if lattices_equal(lats[i], cpu_lats[i]) else 1
-    wd, wc = latbin.compute_wer(ref, hyp_d, "present"), latbin.compute_wer(ref, hyp_c, "present")
-    return {"utterances": n_utts, "wer_line_device": wd[0], "wer_line_cpu_reference_port": wc[0], "identical_wer_lines": wd == wc,
+    wd, wc, wo = (latbin.compute_wer(ref, h, "present") for h in (hyp_d, hyp_c, hyp_o))
+    return {"utterances": n_utts, "device_search_mode": search_mode, "wer_line_device": wd[0], "wer_line_cpu_reference_port": wc[0],
+            "identical_wer_lines": wd == wc, "wer_line_device_search_mode_%d" % (3 - search_mode): wo[0],
             "word_errors_device_vs_cpu_hypotheses": e_between,
             "utterances_whose_raw_lattice_differs_from_mode0": lat_diff,
             "what": "planted transcripts in the bench HCLG, log-likelihoods peaked on the true pdfs (peak 3.5, noise 1.5); device "
@@ -390,7 +398,7 @@ def main():
     bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=max_s, resident_lanes=args.lanes,
                                 host_threads=host_threads, determinize=not args.no_determinize, keep_raw_lattices=False,
                                 nnet_pass_frames=args.nnet_pass_frames, hash_capacity=args.hash_capacity or None,
-                                tokens_per_frame=args.tokens_per_frame or None,
+                                tokens_per_frame=args.tokens_per_frame or None, search_mode=args.search_mode,
                                 lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)))
     log("batch decoder created (%d host threads)" % host_threads)
     bd.load(waves)                          # inputs resident in HBM before the timed region
@@ -493,7 +501,7 @@ def main():
         log("wer leg ...")
         del bd
         try:
-            out["wer"] = wer_leg(g, cfg, args.wer_utts, min(32, cores), log, args.hash_capacity)
+            out["wer"] = wer_leg(g, cfg, args.wer_utts, min(32, cores), log, args.hash_capacity, args.search_mode)
         except Exception as e:                      # noqa: BLE001
             out["wer"] = {"error": repr(e)}
     print(json.dumps(out, default=float))

@@ -302,6 +302,16 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *g,
                                   const int32_t *tid2pdf, int32_t num_tids);
 void kamd_decoder_destroy(kamd_decoder *d);
 int kamd_decoder_set_options(kamd_decoder *d, const kamd_decoder_config *cfg);
+/* Which order-independent member of the reference's family of results the lanes compute.  The
+ * reference prunes emitting arcs against a bound that tightens WHILE the tokens are visited in
+ * HashList order (lattice-faster-decoder.cc:798-800), so what it keeps depends on that order.
+ *   1 (default) canonical: an arc is kept iff its cost is within the bound the reference ENDS
+ *     the frame with -- the tightest member; identical lattices whenever the beam alone prunes.
+ *   2 canonical-loose: kept iff within the bound the reference STARTS the frame with (the seed
+ *     from the best token's arcs, :757-772) -- every token the reference can create in any
+ *     visiting order is created; the two differ only when max_active binds (adaptive beam <
+ *     beam), where mode 1 searches less than the reference and mode 2 at least as much. */
+int kamd_decoder_set_search_mode(kamd_decoder *d, int mode);
 /* Optional: split the token / link pools between lanes 0..n-1 in proportion to the
  * number of frames each will decode (utterance lengths differ 1-35 s); lanes >= n get
  * nothing.  Default is a uniform split.  Call before kamd_decoder_init. */

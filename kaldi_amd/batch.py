@@ -17,7 +17,7 @@ from ._lib import KamdError, check, lib
 class NnetBatchDecoder:
     def __init__(self, mfcc_opts, model, hclg, cfg, max_seconds=36.0, resident_lanes=0, host_threads=8, determinize=True,
                  keep_raw_lattices=False, tid_phone=None, sizes=None, nnet_pass_frames=400000, lattice_pool_bytes=1 << 30,
-                 hash_capacity=None, tokens_per_frame=None):
+                 hash_capacity=None, tokens_per_frame=None, search_mode=1):
         featmod = __import__("kaldi_amd.feat", fromlist=["Mfcc"])
         self.feat = featmod.Fbank(mfcc_opts) if isinstance(mfcc_opts, abi.FbankOpts) else featmod.Mfcc(mfcc_opts)
         self.model, self.cfg = model, cfg
@@ -30,6 +30,7 @@ class NnetBatchDecoder:
         self.sizes = sizes or pipeline.default_sizes(cfg, lanes, max_out, max_out, hash_capacity=hash_capacity,
                                                      tokens_per_frame=tokens_per_frame)
         self.dec = decoder.BatchDecoder(self.graph, cfg, self.sizes)
+        self.dec.SetSearchMode(search_mode)
         o = abi.BatchOpts()
         lib().kamd_batch_opts_default(C.byref(o))
         o.resident_lanes, o.host_threads = int(resident_lanes), int(host_threads)

@@ -78,6 +78,7 @@ struct DecDev {
   int num_pdfs_lds;     // log-likelihood row entries staged in LDS per frame (0 = none)
   int lds_table_cap;    // level-1 (LDS) table words, power of two or 0
   kamd_decoder_config cfg;
+  int loose;            // search mode 2: arcs are kept against the seed cutoff (kamd_decoder_set_search_mode)
   int hash_cap, hash_mask, max_frames;
   const long long *lane_tok_base, *lane_lnk_base;  // per lane: offset into the pools
   const int *lane_tok_cap, *lane_lnk_cap;          // per lane: capacity (records)
@@ -440,7 +441,7 @@ template <int W>
 __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, const LlRow &ll,
                                    const kamd_arc (&arc)[W], const int (&pdf)[W], const int (&src_tok)[W],
                                    const float (&cur_cost)[W], const bool (&ok)[W], float cost_offset,
-                                   float adaptive_beam, int link_base) {
+                                   float adaptive_beam, int link_base, bool loose, float seed_cutoff) {
   float ac[W], tot[W];
   bool pass[W];
 #pragma unroll
@@ -448,7 +449,7 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
     ac[q] = cost_offset - LogLikePdf(ll, ok[q] ? pdf[q] : 0);
     tot[q] = cur_cost[q] + ac[q] + arc[q].weight;
     const float nc = OrderedToFloat(sh->next_cutoff_u);   // running bound (conservative)
-    pass[q] = ok[q] && !(tot[q] > nc);
+    pass[q] = ok[q] && !(tot[q] > (loose ? seed_cutoff : nc));
     if (pass[q]) {
       const float cand = tot[q] + adaptive_beam;
       if (cand < nc) atomicMin(&sh->next_cutoff_u, FloatToOrdered(cand));
@@ -837,9 +838,10 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
   const int tok_base = sh->cur_tb + sh->cur_n;   // == c.tok_off[list]
   const int ns2 = min(sh->n_slots, d.hash_cap);  // level-2 entries (emitting + closure)
   u64 kmin = EMPTY64;
+  const bool loose = d.loose != 0;   // mode 2: entries beyond the cutoff are tokens too (they are just not epsilon-expanded, :867)
   auto commit_entry = [&](u64 e, int *idx_out) {
     int idx = -1;
-    if (CostOf(e) <= cutoff) {
+    if (loose || CostOf(e) <= cutoff) {
       idx = tok_base + WaveAlloc(&sh->n_new);
       if (idx < c.tok_cap) {
         const int st = PlainState(StateOf(e));
@@ -864,7 +866,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
     const u64 e = tbl.LH[sl];
     int idx;
     commit_entry(e, &idx);
-    if (idx >= 0 && HasEps(StateOf(e))) add_owner(sl, e);
+    if (idx >= 0 && HasEps(StateOf(e)) && CostOf(e) <= cutoff) add_owner(sl, e);
     tbl.LH[sl] = (e & 0xFFFFFFFF00000000ull) | static_cast<u32>(idx);   // cost half -> token index
   }
   for (int i = tid; i < ns2; i += NT) {
@@ -873,7 +875,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
     if (e == EMPTY64) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
     int idx;
     commit_entry(e, &idx);
-    if (idx >= 0 && HasEps(StateOf(e))) add_owner(slot, e);
+    if (idx >= 0 && HasEps(StateOf(e)) && CostOf(e) <= cutoff) add_owner(slot, e);
     c.slot_tok[slot] = idx;
   }
   // full barrier only when level-2 entries or list overflow put data in HBM that others read
@@ -1181,6 +1183,8 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
     } else if (tid == 0) sh.next_cutoff_u = FloatToOrdered(INFINITY);
     LdsBarrier();
     Stamp(&sh, PH_SEED);
+    const bool loose = d.loose != 0;
+    const float seed_cutoff = OrderedToFloat(sh.next_cutoff_u);   // :757-772, before any other arc tightens it
     const int link_base = sh.lnk_used;
     // ---- ProcessEmitting (:783-815).  Tokens with <= SMALL_DEG arcs are expanded by
     // their own thread; the rest (LM hubs, trie fan-outs) are queued and expanded
@@ -1223,7 +1227,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
               arc[q].ilabel = arc[q].olabel = arc[q].nextstate = 0; arc[q].weight = 0.f;
               if (ok[q]) { arc[q] = d.g.e_arcs[a0 + q]; pdf[q] = d.e_pdf[a0 + q]; }
             }
-            ProcessArcs<SMALL_DEG>(d, c, &sh, tbl, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base);
+            ProcessArcs<SMALL_DEG>(d, c, &sh, tbl, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
           } else {
             const int p = WaveAlloc(&sh.bigcnt);   // < BIGCAP: at most EXPT * NT entries per outer iteration
             big_tok[p] = i; big_a0[p] = a0; big_scan[p] = deg;
@@ -1305,7 +1309,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
             }
 #pragma unroll
             for (int q = 0; q < ARCW; q++) tok[q] += tb;
-            ProcessArcs<ARCW>(d, c, &sh, tbl, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base);
+            ProcessArcs<ARCW>(d, c, &sh, tbl, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
           }
         }
         LdsBarrier();
@@ -1328,7 +1332,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
     const float next_cutoff = OrderedToFloat(sh.next_cutoff_u);
     // ---- FindOrAddToken for the recorded links, against the final cutoff
     int my_slot[COMMIT_KEEP];
-    const int k_surv = InsertEmitted(d, c, &sh, tbl, link_base, sh.n_links, next_cutoff, my_slot);
+    const int k_surv = InsertEmitted(d, c, &sh, tbl, link_base, sh.n_links, loose ? seed_cutoff : next_cutoff, my_slot);
     Stamp(&sh, PH_FIXUP);
     // ---- ProcessNonemitting(next_cutoff) + commit of token list frame+1
     CommitLds cl;
@@ -2499,6 +2503,12 @@ static int ReserveUniform(Decoder *D) {
   KAMD_HIP(hipMemcpy(D->d_tok_cap, D->h_tok_cap.data(), L * 4, hipMemcpyHostToDevice));
   KAMD_HIP(hipMemcpy(D->d_lnk_cap, D->h_lnk_cap.data(), L * 4, hipMemcpyHostToDevice));
   D->split_uniform = true;
+  return KAMD_OK;
+}
+
+int kamd_decoder_set_search_mode(kamd_decoder *h, int mode) {
+  if (mode != 1 && mode != 2) return kamd::SetError(KAMD_ERR_ARG, "search mode must be 1 (canonical) or 2 (canonical-loose)");
+  reinterpret_cast<Decoder *>(h)->dev.loose = mode == 2;
   return KAMD_OK;
 }
 

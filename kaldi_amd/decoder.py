@@ -198,6 +198,10 @@ class LatticeFasterDecoder:
         self.config = config
         check(lib().kamd_decoder_set_options(self._dec, C.byref(config)))
 
+    def SetSearchMode(self, mode):
+        """1 = canonical (default), 2 = canonical-loose (kamd_decoder_set_search_mode)."""
+        check(lib().kamd_decoder_set_search_mode(self._dec, int(mode)))
+
     def InitDecoding(self):
         lanes = np.asarray([self.lane], np.int32)
         check(lib().kamd_decoder_init(self._dec, abi.iptr(lanes), 1, None))
@@ -412,6 +416,9 @@ class BatchDecoder:
         if getattr(self, "_dec", None):
             lib().kamd_decoder_destroy(self._dec)
             self._dec = None
+
+    def SetSearchMode(self, mode):
+        check(lib().kamd_decoder_set_search_mode(self._dec, int(mode)))
 
     def decode(self, matrices):
         """matrices: list of DeviceMatrix / host arrays, one per lane."""

@@ -18,6 +18,11 @@
 //     with (min over all arcs), arcs are kept iff tot <= that final cutoff, no
 //     intermediate pruning (it is provably conservative), final pruning iterated
 //     to the exact fixpoint.  See DESIGN.md "Decoder parity".
+//   mode 2 "canonical-loose": as mode 1, but an arc is kept iff tot <= the SEED
+//     cutoff (best token's arcs + adaptive beam, :757-772), the loosest value the
+//     reference's running bound takes; the frame's tokens are then a superset of
+//     what the reference creates in ANY visiting order.  Differs from mode 1 only
+//     in the tokens between the two bounds, which matter when max_active binds.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -272,7 +277,7 @@ struct Decoder {
   // broken by smallest HCLG state so the choice is order independent.
   bool BetterBest(float w, float best, int key, int best_elem) const {
     if (w < best) return true;
-    if (mode == 1 && w == best && best_elem != -1 && key < hl.elems[best_elem].key)
+    if (mode >= 1 && w == best && best_elem != -1 && key < hl.elems[best_elem].key)
       return true;
     return false;
   }
@@ -322,7 +327,11 @@ struct Decoder {
     trace_cutoff.push_back(cur_cutoff);
     trace_offset.push_back(cost_offset);
 
-    if (mode == 1) {
+    // mode 2 (canonical-loose): an arc is kept iff its cost is within the SEED bound -- the loosest value the
+    // reference's running next_cutoff can have when the arc is visited (it starts there, :757-772, and only
+    // tightens) -- so every token the reference creates, in whatever order it visits them, is created too.
+    const float seed_cutoff = next_cutoff;
+    if (mode >= 1) {
       // canonical: the value the reference's running next_cutoff ends with.
       for (size_t i = 0; i < prev_elems.size(); i++) {
         const Tok &tok = toks[prev_elems[i].val];
@@ -351,12 +360,12 @@ struct Decoder {
           const kamd_arc &arc = arcs[a];
           if (mode == 0) counters[1]++;
           if (arc.ilabel != 0) {
-            if (mode == 1) counters[1]++;
+            if (mode >= 1) counters[1]++;
             counters[2]++;
             float ac_cost = cost_offset - LogLike(loglike_row, arc.ilabel),
                   graph_cost = arc.weight, cur_cost = toks[t].tot_cost,
                   tot_cost = cur_cost + ac_cost + graph_cost;
-            if (tot_cost > next_cutoff) continue;
+            if (tot_cost > (mode == 2 ? seed_cutoff : next_cutoff)) continue;
             else if (tot_cost + adaptive_beam < next_cutoff)
               next_cutoff = tot_cost + adaptive_beam;
             counters[3]++;
@@ -402,7 +411,7 @@ struct Decoder {
         }
       }
     }
-    if (mode == 1) {
+    if (mode >= 1) {
       // canonical work counters (order independent): epsilon arcs of every token
       // that ends the frame within the cutoff, and the epsilon links it keeps.
       for (int e = hl.list_head; e != -1; e = hl.elems[e].tail) {
@@ -521,7 +530,7 @@ struct Decoder {
           }
         }
         if (tok_extra_cost > cfg.lattice_beam) tok_extra_cost = kInf;
-        bool same = (mode == 1) ? (tok.extra_cost == tok_extra_cost)
+        bool same = (mode >= 1) ? (tok.extra_cost == tok_extra_cost)
                                 : ApproxEqual(tok.extra_cost, tok_extra_cost, delta);
         if (!same) changed = true;
         tok.extra_cost = tok_extra_cost;
