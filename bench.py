@@ -528,6 +528,3 @@ def pmc_traffic(args):
 
 if __name__ == "__main__":
     main()
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)      # results are out: skip interpreter finalization (no ordering between ctypes handles and the HIP runtime's own teardown)

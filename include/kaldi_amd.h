@@ -312,6 +312,10 @@ int kamd_decoder_set_options(kamd_decoder *d, const kamd_decoder_config *cfg);
  *     visiting order is created; the two differ only when max_active binds (adaptive beam <
  *     beam), where mode 1 searches less than the reference and mode 2 at least as much. */
 int kamd_decoder_set_search_mode(kamd_decoder *d, int mode);
+/* How a lane's 160 KB of LDS were split: entries of a frame's log-likelihood row staged in LDS
+ * (pdfs beyond that are read from HBM) and words of the level-1 token table (states whose
+ * probe window is full spill to the level-2 table in HBM).  Diagnostic, used by the tests. */
+int kamd_decoder_lds_layout(const kamd_decoder *d, int32_t *num_pdfs_lds, int32_t *table_words);
 /* Optional: split the token / link pools between lanes 0..n-1 in proportion to the
  * number of frames each will decode (utterance lengths differ 1-35 s); lanes >= n get
  * nothing.  Default is a uniform split.  Call before kamd_decoder_init. */

@@ -2506,6 +2506,13 @@ static int ReserveUniform(Decoder *D) {
   return KAMD_OK;
 }
 
+int kamd_decoder_lds_layout(const kamd_decoder *h, int32_t *num_pdfs_lds, int32_t *table_words) {
+  const Decoder *D = reinterpret_cast<const Decoder *>(h);
+  if (num_pdfs_lds) *num_pdfs_lds = D->dev.num_pdfs_lds;
+  if (table_words) *table_words = D->dev.lds_table_cap;
+  return KAMD_OK;
+}
+
 int kamd_decoder_set_search_mode(kamd_decoder *h, int mode) {
   if (mode != 1 && mode != 2) return kamd::SetError(KAMD_ERR_ARG, "search mode must be 1 (canonical) or 2 (canonical-loose)");
   reinterpret_cast<Decoder *>(h)->dev.loose = mode == 2;
