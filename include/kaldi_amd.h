@@ -307,10 +307,12 @@ int kamd_decoder_set_options(kamd_decoder *d, const kamd_decoder_config *cfg);
  * HashList order (lattice-faster-decoder.cc:798-800), so what it keeps depends on that order.
  *   1 (default) canonical: an arc is kept iff its cost is within the bound the reference ENDS
  *     the frame with -- the tightest member; identical lattices whenever the beam alone prunes.
- *   2 canonical-loose: kept iff within the bound the reference STARTS the frame with (the seed
- *     from the best token's arcs, :757-772) -- every token the reference can create in any
- *     visiting order is created; the two differ only when max_active binds (adaptive beam <
- *     beam), where mode 1 searches less than the reference and mode 2 at least as much. */
+ *   2 canonical-loose: on the frames where max_active / min_active made the adaptive beam
+ *     differ from the beam, kept iff within the bound the reference STARTS the frame with (the
+ *     seed from the best token's arcs, :757-772) -- every token the reference can create in any
+ *     visiting order is created; there mode 1 searches less than the reference and mode 2 at
+ *     least as much.  On all other frames the tokens between the two bounds can never be
+ *     expanded (next frame's cutoff = this frame's final bound) and the modes coincide. */
 int kamd_decoder_set_search_mode(kamd_decoder *d, int mode);
 /* How a lane's 160 KB of LDS were split: entries of a frame's log-likelihood row staged in LDS
  * (pdfs beyond that are read from HBM) and words of the level-1 token table (states whose

@@ -767,7 +767,7 @@ struct CommitLds {
 // -1: kept in registers from InsertEmitted so the links are not read back.
 __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
                              int emit_link_begin, float *cost_cache, int cache_cap, int k_surv,
-                             const CommitLds &L, const int (&my_slot)[COMMIT_KEEP]) {
+                             const CommitLds &L, const int (&my_slot)[COMMIT_KEEP], bool loose) {
   const int tid = threadIdx.x;
   LaneState *S = c.st;
   const int lcap = tbl.lcap;
@@ -838,7 +838,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
   const int tok_base = sh->cur_tb + sh->cur_n;   // == c.tok_off[list]
   const int ns2 = min(sh->n_slots, d.hash_cap);  // level-2 entries (emitting + closure)
   u64 kmin = EMPTY64;
-  const bool loose = d.loose != 0;   // mode 2: entries beyond the cutoff are tokens too (they are just not epsilon-expanded, :867)
+  // loose (search mode 2 on this frame): entries beyond the cutoff are tokens too (they are just not epsilon-expanded, :867)
   auto commit_entry = [&](u64 e, int *idx_out) {
     int idx = -1;
     if (loose || CostOf(e) <= cutoff) {
@@ -1183,7 +1183,10 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
     } else if (tid == 0) sh.next_cutoff_u = FloatToOrdered(INFINITY);
     LdsBarrier();
     Stamp(&sh, PH_SEED);
-    const bool loose = d.loose != 0;
+    // search mode 2: the seed bound replaces the final one on the frames where the reference's order-dependent extras
+    // can matter, i.e. where max_active / min_active made the adaptive beam differ from the beam; with adaptive_beam ==
+    // beam the next frame's cutoff (best + beam) equals this frame's final bound and every extra is dead on arrival
+    const bool loose = d.loose != 0 && adaptive_beam != cfg.beam;
     const float seed_cutoff = OrderedToFloat(sh.next_cutoff_u);   // :757-772, before any other arc tightens it
     const int link_base = sh.lnk_used;
     // ---- ProcessEmitting (:783-815).  Tokens with <= SMALL_DEG arcs are expanded by
@@ -1338,7 +1341,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
     CommitLds cl;
     cl.wl0 = reinterpret_cast<u32 *>(dyn_lds); cl.wl1 = cl.wl0 + (3 * BIGCAP) / 2; cl.wl_cap = (3 * BIGCAP) / 2;
     cl.owners = reinterpret_cast<uint2 *>(lh_lds); cl.owners_cap = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP) / 2;
-    CommitFrame2(d, c, &sh, tbl, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP, k_surv, cl, my_slot);
+    CommitFrame2(d, c, &sh, tbl, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP, k_surv, cl, my_slot, loose);
     const int err_now = sh.err;    // CommitFrame ends with a barrier; nobody writes err before the next one
     LdsBarrier();
     if (err_now) { frame++; break; }
@@ -3152,14 +3155,26 @@ int kamd_decoder_queue_fetch_lattice(kamd_decoder *h, int32_t utt, void *copy_st
                           (r.error & 8) ? " max-frames" : "", (r.error & 16) ? " worklist" : "", (r.error & 32) ? " internal" : "",
                           (r.error & 64) ? " lattice-pool" : "", r.n_frames);
   const int F = r.n_frames, nt = r.n_tok, nl = r.n_link, n_last = r.n_last;
-  std::vector<unsigned char> blob(static_cast<size_t>(r.blob_bytes));
-  if (!blob.empty()) {
+  // Page-locked landing buffer, one per calling thread (grow-only): a copy into pinned memory goes to the DMA engines,
+  // which run beside the queue kernel; a copy into pageable memory is a blit KERNEL, and that cannot start while
+  // every CU's register file is held by a decoder lane (measured: all fetches piled up behind the kernel's end).
+  struct Pinned { unsigned char *p = NULL; size_t cap = 0; ~Pinned() { if (p) (void)hipHostFree(p); } };
+  static thread_local Pinned land;
+  const size_t bytes = static_cast<size_t>(r.blob_bytes);
+  if (bytes > land.cap) {
+    if (land.p) (void)hipHostFree(land.p);
+    land.p = NULL; land.cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 20);
+    KAMD_HIP(hipHostMalloc(reinterpret_cast<void **>(&land.p), want, hipHostMallocDefault));
+    land.cap = want;
+  }
+  if (bytes) {
     hipStream_t cs = static_cast<hipStream_t>(copy_stream);
-    KAMD_HIP(hipMemcpyAsync(blob.data(), D->d_pool + r.blob_off, blob.size(), hipMemcpyDeviceToHost, cs));
+    KAMD_HIP(hipMemcpyAsync(land.p, D->d_pool + r.blob_off, bytes, hipMemcpyDeviceToHost, cs));
     KAMD_HIP(hipStreamSynchronize(cs));
   }
-  if (blob.size() < (static_cast<size_t>(F + 2) + 2ull * nt + n_last + 6ull * nl) * 4) return kamd::SetError(KAMD_ERR_STATE, "utterance %d: short lattice blob", utt);
-  const int *toff = reinterpret_cast<const int *>(blob.data());
+  if (bytes < (static_cast<size_t>(F + 2) + 2ull * nt + n_last + 6ull * nl) * 4) return kamd::SetError(KAMD_ERR_STATE, "utterance %d: short lattice blob", utt);
+  const int *toff = reinterpret_cast<const int *>(land.p);
   const int *st = toff + (F + 2);
   const float *co = reinterpret_cast<const float *>(st + nt);
   const float *lf = co + nt;

@@ -18,11 +18,13 @@
 //     with (min over all arcs), arcs are kept iff tot <= that final cutoff, no
 //     intermediate pruning (it is provably conservative), final pruning iterated
 //     to the exact fixpoint.  See DESIGN.md "Decoder parity".
-//   mode 2 "canonical-loose": as mode 1, but an arc is kept iff tot <= the SEED
-//     cutoff (best token's arcs + adaptive beam, :757-772), the loosest value the
-//     reference's running bound takes; the frame's tokens are then a superset of
-//     what the reference creates in ANY visiting order.  Differs from mode 1 only
-//     in the tokens between the two bounds, which matter when max_active binds.
+//   mode 2 "canonical-loose": as mode 1, but on the frames where max_active /
+//     min_active made the adaptive beam differ from the beam an arc is kept iff
+//     tot <= the SEED cutoff (best token's arcs + adaptive beam, :757-772), the
+//     loosest value the reference's running bound takes; such a frame's tokens are
+//     then a superset of what the reference creates in ANY visiting order.  On the
+//     other frames the tokens between the two bounds can never be expanded (the
+//     next frame's cutoff best + beam IS this frame's final bound) and mode 2 = 1.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -331,6 +333,9 @@ struct Decoder {
     // reference's running next_cutoff can have when the arc is visited (it starts there, :757-772, and only
     // tightens) -- so every token the reference creates, in whatever order it visits them, is created too.
     const float seed_cutoff = next_cutoff;
+    // ... on the frames where the extras can matter: max_active / min_active made the adaptive beam differ from the beam.
+    // With adaptive_beam == beam the next frame's cutoff (best + beam) is this frame's final bound: extras are never expanded.
+    const bool loose = mode == 2 && adaptive_beam != cfg.beam;
     if (mode >= 1) {
       // canonical: the value the reference's running next_cutoff ends with.
       for (size_t i = 0; i < prev_elems.size(); i++) {
@@ -365,7 +370,7 @@ struct Decoder {
             float ac_cost = cost_offset - LogLike(loglike_row, arc.ilabel),
                   graph_cost = arc.weight, cur_cost = toks[t].tot_cost,
                   tot_cost = cur_cost + ac_cost + graph_cost;
-            if (tot_cost > (mode == 2 ? seed_cutoff : next_cutoff)) continue;
+            if (tot_cost > (loose ? seed_cutoff : next_cutoff)) continue;
             else if (tot_cost + adaptive_beam < next_cutoff)
               next_cutoff = tot_cost + adaptive_beam;
             counters[3]++;

@@ -38,8 +38,11 @@ def main():
     waves = synth.make_waves_fast(durs, seed=1000)
     audio = sum(w.size for w in waves) / 16000.0
     max_s = max(w.size for w in waves) / 16000.0 + 0.5
+    fps0 = 100.0 / model.subsampling
+    psz = pipeline.default_sizes(cfg, len(waves), int(max_s * fps0) + 2, int(audio / len(waves) * fps0) + 2,
+                                 hash_capacity=args.hash_capacity or None)
     pipe = pipeline.Pipeline(abi.mfcc_opts_hires(), model, g, cfg, max_utts=len(waves), max_seconds=max_s,
-                             avg_seconds=audio / len(waves))
+                             avg_seconds=audio / len(waves), sizes=psz)
     pipe.load(waves)
     ms = pipe.run()
     ms = pipe.run()
