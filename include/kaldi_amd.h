@@ -346,6 +346,10 @@ int kamd_decoder_finalize(kamd_decoder *d, const int32_t *lanes, int n,
 /* Blocks until all queued work of the decoder is done; reports device-side
  * failures (arena/hash overflow) of any lane as KAMD_ERR_CAPACITY. */
 int kamd_decoder_sync(kamd_decoder *d);
+/* The same wait, but a lane's capacity overflow is reported per lane (lane_error[i] = flags of
+ * lanes[i], 0 = fine) instead of failing the call: one stream that outgrows its arena must not
+ * stop the other streams of a server.  Fails only on runtime errors. */
+int kamd_decoder_sync_lanes(kamd_decoder *d, const int32_t *lanes, int n, int32_t *lane_error);
 
 int kamd_decoder_num_frames_decoded(kamd_decoder *d, int lane);
 /* FinalRelativeCost() / ReachedFinal() (lattice-faster-decoder.h:283-300). */
@@ -651,6 +655,11 @@ int kamd_stream_batch_accept_many(kamd_stream_batch *b, const int32_t *streams, 
 /* AdvanceDecoding for all listed streams; frames_decoded[n] may be NULL */
 int kamd_stream_batch_advance(kamd_stream_batch *b, const int32_t *streams, int n, int32_t *frames_decoded);
 int kamd_stream_batch_num_frames_ready(const kamd_stream_batch *b, int stream);
+/* Per-stream health: 0 = fine, otherwise the decoder capacity flags that took this stream out
+ * (its lane's arena / table overflowed).  kamd_stream_batch_advance reports such a failure with
+ * KAMD_ERR_CAPACITY but leaves every OTHER stream of the tick advanced and usable; the failed
+ * stream refuses further ticks until kamd_stream_batch_start restarts it. */
+int kamd_stream_batch_get_status(const kamd_stream_batch *b, const int32_t *streams, int n, int32_t *status);
 /* Online i-vectors in the streaming path (online2-wav-nnet3-latgen-faster with an ivector-extraction config):
  * OnlineIvectorFeature with use_most_recent_ivector feeding DecodableNnetLoopedOnline.  Call before any stream is
  * started.  frames_per_chunk = the looped decodable's --frames-per-chunk (20 in the online recipes; its i-vector

@@ -99,6 +99,8 @@ def lib():
     sig("kamd_stream_batch_accept_many", C.c_int, [vp, ip, C.c_int, fp, i64p, ip])
     sig("kamd_stream_batch_advance", C.c_int, [vp, ip, C.c_int, ip])
     sig("kamd_stream_batch_num_frames_ready", C.c_int, [vp, C.c_int])
+    sig("kamd_stream_batch_get_status", C.c_int, [vp, ip, C.c_int, ip])
+    sig("kamd_decoder_sync_lanes", C.c_int, [vp, ip, C.c_int, ip])
     sig("kamd_stream_batch_set_ivector_extractor", C.c_int, [vp, vp, C.c_int, C.c_int])
     sig("kamd_stream_batch_start_adapted", C.c_int, [vp, ip, C.c_int, C.POINTER(C.c_double)])
     sig("kamd_stream_batch_get_adaptation_state", C.c_int, [vp, C.c_int, C.POINTER(C.c_double)])
@@ -237,7 +239,7 @@ kamd_decoder_partial_best_paths kamd_endpoint_config_default kamd_endpoint_detec
 kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch kamd_pipeline_set_ivectors kamd_pipeline_set_online_ivectors
 kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features
 kamd_decoder_queue_configure kamd_decoder_queue_launch kamd_decoder_queue_poll kamd_decoder_queue_result kamd_decoder_queue_fetch_lattice kamd_decoder_queue_wait kamd_lattice_best_path
-kamd_decoder_set_search_mode kamd_decoder_lds_layout kamd_device_num_cus kamd_batch_opts_default kamd_batch_decoder_create kamd_batch_decoder_destroy kamd_batch_decoder_load kamd_batch_decoder_run kamd_batch_decoder_get_output kamd_batch_decoder_get_raw_lattice kamd_batch_decoder_get_compact_lattice kamd_batch_decoder_get_loglikes""".split()
+kamd_stream_batch_get_status kamd_decoder_sync_lanes kamd_decoder_set_search_mode kamd_decoder_lds_layout kamd_device_num_cus kamd_batch_opts_default kamd_batch_decoder_create kamd_batch_decoder_destroy kamd_batch_decoder_load kamd_batch_decoder_run kamd_batch_decoder_get_output kamd_batch_decoder_get_raw_lattice kamd_batch_decoder_get_compact_lattice kamd_batch_decoder_get_loglikes""".split()
 
 
 def check(rc):

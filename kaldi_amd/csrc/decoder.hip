@@ -2223,6 +2223,7 @@ struct Decoder {
   std::vector<long long> h_tok_base, h_lnk_base; std::vector<int> h_tok_cap, h_lnk_cap;
   hipStream_t last_stream = NULL;
   void *d_path = NULL; int path_cap = 0;   // partial best path: {n, final cost, pad} + arcs
+  void *d_paths = NULL; size_t paths_cap = 0;   // partial best paths of many lanes (kamd_decoder_partial_best_paths)
   unsigned char *d_sil_tid = NULL; int n_sil_tids = 0; int *d_sil_out = NULL; int sil_out_cap = 0;   // endpointing
   // work queue (kamd_decoder_queue_*)
   unsigned char *d_pool = NULL; unsigned long long pool_cap = 0;
@@ -2451,6 +2452,7 @@ void kamd_decoder_destroy(kamd_decoder *h) {
   if (!D) return;
   for (size_t i = 0; i < D->allocs.size(); i++) (void)hipFree(D->allocs[i]);
   if (D->d_path) (void)hipFree(D->d_path);
+  if (D->d_paths) (void)hipFree(D->d_paths);
   if (D->d_sil_tid) (void)hipFree(D->d_sil_tid);
   if (D->d_sil_out) (void)hipFree(D->d_sil_out);
   if (D->d_lanes) (void)hipFree(D->d_lanes);
@@ -2620,6 +2622,26 @@ int kamd_decoder_sync(kamd_decoder *h) {
                             (e & 8) ? " max-frames" : "", (e & 16) ? " worklist" : "", (e & 32) ? " internal" : "",
                             D->h_st[l].frame);
   }
+  return KAMD_OK;
+}
+
+// kamd_decoder_sync restricted to the lanes of interest: blocks, refreshes the host copy of every lane's state, and
+// reports the capacity flags of lanes[i] in lane_error[i] instead of failing the call (a server keeps decoding its
+// other streams when one of them overflows).  Returns KAMD_ERR_HIP only for runtime failures.
+int kamd_decoder_sync_lanes(kamd_decoder *h, const int32_t *lanes, int n, int32_t *lane_error) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (CheckLanes(D, lanes, n) != KAMD_OK) return KAMD_ERR_ARG;
+  KAMD_HIP(hipStreamSynchronize(D->last_stream));
+  if (D->n_timed > 0) {
+    float sum = 0;
+    for (int i = 0; i < D->n_timed; i++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, D->ev[2 * i], D->ev[2 * i + 1]) == hipSuccess) sum += ms;
+    }
+    D->last_ms = sum;
+  }
+  KAMD_HIP(hipMemcpy(D->h_st.data(), D->dev.st, D->h_st.size() * sizeof(kamd::LaneState), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) if (lane_error) lane_error[i] = D->h_st[lanes[i]].error;
   return KAMD_OK;
 }
 
@@ -2795,8 +2817,16 @@ int kamd_decoder_partial_best_paths(kamd_decoder *h, const int32_t *lanes, int n
   }
   const int cap = 4 * (max_frame + 2) + 1024;
   const size_t arcs_bytes = static_cast<size_t>(n) * cap * sizeof(kamd::PathArc), head_bytes = static_cast<size_t>(n) * 8;
-  void *d_buf = NULL;
-  KAMD_HIP(hipMalloc(&d_buf, arcs_bytes + head_bytes));
+  // grow-only buffer owned by the decoder (a server asks for partial results every tick: no hipMalloc / hipFree,
+  // both of which synchronise the device, on that path)
+  if (arcs_bytes + head_bytes > D->paths_cap) {
+    const size_t grow = std::max(arcs_bytes + head_bytes, 2 * D->paths_cap);
+    if (D->d_paths) (void)hipFree(D->d_paths);
+    D->d_paths = NULL; D->paths_cap = 0;
+    KAMD_HIP(hipMalloc(&D->d_paths, grow));
+    D->paths_cap = grow;
+  }
+  void *d_buf = D->d_paths;
   kamd::PathArc *d_arcs = static_cast<kamd::PathArc *>(d_buf);
   int *d_head = reinterpret_cast<int *>(static_cast<char *>(d_buf) + arcs_bytes);
   hipStream_t st = D->last_stream;
@@ -2823,6 +2853,13 @@ int kamd_decoder_partial_best_paths(kamd_decoder *h, const int32_t *lanes, int n
       ali_len[i] = 0; words_len[i] = 0; graph_cost[i] = INFINITY; acoustic_cost[i] = INFINITY;
       const int cnt = head[2 * i];
       if (cnt < 0) { ali_len[i] = -1; words_len[i] = -1; continue; }      // no tokens alive on the newest frame
+      if (cnt > cap) {
+        // the lane advanced since the last sync (the capacity was sized from the host's copy of its frame count): a path
+        // cut to its newest `cap` arcs would come back with wrong costs and words
+        rc = kamd::SetError(KAMD_ERR_STATE, "lane %d: best path of %d arcs exceeds the buffer sized from the last kamd_decoder_sync (%d): sync first",
+                            lanes[i], cnt, cap);
+        break;
+      }
       float fc; memcpy(&fc, &head[2 * i + 1], 4);
       const kamd::PathArc *A = arcs.data() + static_cast<size_t>(i) * longest;
       float gsum = 0.f, asum = 0.f;   // Times() along the path, start -> end
@@ -2834,7 +2871,6 @@ int kamd_decoder_partial_best_paths(kamd_decoder *h, const int32_t *lanes, int n
       graph_cost[i] = gsum + fc; acoustic_cost[i] = asum;
     }
   }
-  (void)hipFree(d_buf);
   return rc;
 }
 

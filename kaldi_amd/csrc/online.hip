@@ -204,6 +204,7 @@ struct StreamBatch {
   std::vector<int64_t> n_samp;
   std::vector<int> n_frames, decoded;
   std::vector<char> finished, live;
+  std::vector<int> status;     // per stream: 0 = fine, else the decoder's capacity flags: the stream is out until restarted
 };
 }  // namespace kamd
 using kamd::StreamBatch;
@@ -218,7 +219,7 @@ kamd_stream_batch *kamd_stream_batch_create(kamd_feat *feat, kamd_nnet *nnet, ka
   b->max_samples = static_cast<int64_t>(max_seconds * samp_freq) + 1;
   b->max_frames = kamd_feat_num_frames_flush(feat, b->max_samples, 1) + 1;
   b->n_samp.assign(max_streams, 0); b->n_frames.assign(max_streams, 0); b->decoded.assign(max_streams, 0);
-  b->finished.assign(max_streams, 0); b->live.assign(max_streams, 0);
+  b->finished.assign(max_streams, 0); b->live.assign(max_streams, 0); b->status.assign(max_streams, 0);
   if (hipMalloc(reinterpret_cast<void **>(&b->d_wave), static_cast<size_t>(max_streams) * b->max_samples * sizeof(float)) != hipSuccess ||
       hipMalloc(reinterpret_cast<void **>(&b->d_frames), static_cast<size_t>(max_streams) * b->max_frames * b->ld * sizeof(float)) != hipSuccess ||
       hipMemset(b->d_frames, 0, static_cast<size_t>(max_streams) * b->max_frames * b->ld * sizeof(float)) != hipSuccess) {
@@ -317,10 +318,11 @@ int kamd_stream_batch_get_adaptation_state(kamd_stream_batch *h, int stream, dou
 // decoder_.InitDecoding() (online-nnet3-decoding.cc:40)
 int kamd_stream_batch_start(kamd_stream_batch *h, const int32_t *streams, int n) {
   StreamBatch *b = reinterpret_cast<StreamBatch *>(h);
+  for (int i = 0; i < n; i++)
+    if (streams[i] < 0 || streams[i] >= b->S) return kamd::SetError(KAMD_ERR_ARG, "stream %d out of range", streams[i]);
   for (int i = 0; i < n; i++) {
     const int s = streams[i];
-    if (s < 0 || s >= b->S) return kamd::SetError(KAMD_ERR_ARG, "stream %d out of range", s);
-    b->n_samp[s] = 0; b->n_frames[s] = 0; b->decoded[s] = 0; b->finished[s] = 0;
+    b->n_samp[s] = 0; b->n_frames[s] = 0; b->decoded[s] = 0; b->finished[s] = 0; b->status[s] = 0;
     if (b->ie) {                  // a fresh adaptation state; kamd_stream_batch_start_adapted replaces it
       std::vector<double> rec(b->rec_size);
       kamd_ivector_stream_record_init(b->ie, NULL, rec.data());
@@ -331,7 +333,13 @@ int kamd_stream_batch_start(kamd_stream_batch *h, const int32_t *streams, int n)
   }
   int rc = kamd_decoder_init(b->dec, streams, n, NULL);
   if (rc != KAMD_OK) return rc;
-  return kamd_decoder_sync(b->dec);
+  // only these lanes matter here: another stream's earlier overflow is that stream's business
+  std::vector<int32_t> err(std::max(n, 1), 0);
+  rc = kamd_decoder_sync_lanes(b->dec, streams, n, err.data());
+  if (rc != KAMD_OK) return rc;
+  for (int i = 0; i < n; i++)
+    if (err[i]) { b->status[streams[i]] = err[i]; return kamd::SetError(KAMD_ERR_CAPACITY, "stream %d: InitDecoding overflowed the lane (flags %d)", streams[i], err[i]); }
+  return KAMD_OK;
 }
 
 // AcceptWaveform / InputFinished (online-nnet3-decoding.h:77-86): samples are appended to the
@@ -414,16 +422,28 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
   // ---- features: the frames that became computable (OnlineGenericBaseFeature::ComputeFeatures)
   std::vector<int64_t> wstart, wlen, frow;
   std::vector<int32_t> f0, fn;
+  // validate everything before anything changes: a bad entry must not leave earlier streams half advanced
+  {
+    std::vector<char> seen(b->S, 0);
+    for (int i = 0; i < n; i++) {
+      const int s = streams[i];
+      if (s < 0 || s >= b->S || !b->live[s]) return kamd::SetError(KAMD_ERR_ARG, "stream %d is not started", s);
+      if (seen[s]) return kamd::SetError(KAMD_ERR_ARG, "stream %d listed twice in one tick", s);
+      seen[s] = 1;
+      if (b->status[s]) return kamd::SetError(KAMD_ERR_STATE, "stream %d failed earlier (flags %d): restart it (kamd_stream_batch_start)", s, b->status[s]);
+      if (kamd_feat_num_frames_flush(b->feat, b->n_samp[s], b->finished[s] ? 1 : 0) > b->max_frames)
+        return kamd::SetError(KAMD_ERR_CAPACITY, "stream %d: more frames than reserved", s);
+    }
+  }
+  std::vector<int> new_frames(n);
   for (int i = 0; i < n; i++) {
     const int s = streams[i];
-    if (s < 0 || s >= b->S || !b->live[s]) return kamd::SetError(KAMD_ERR_ARG, "stream %d is not started", s);
     const int ready = kamd_feat_num_frames_flush(b->feat, b->n_samp[s], b->finished[s] ? 1 : 0);
-    if (ready > b->max_frames) return kamd::SetError(KAMD_ERR_CAPACITY, "stream %d: more frames than reserved", s);
+    new_frames[i] = std::max(ready, b->n_frames[s]);
     if (ready > b->n_frames[s]) {
       wstart.push_back(static_cast<int64_t>(s) * b->max_samples); wlen.push_back(b->n_samp[s]);
       f0.push_back(b->n_frames[s]); fn.push_back(ready - b->n_frames[s]);
       frow.push_back(static_cast<int64_t>(s) * b->max_frames + b->n_frames[s]);
-      b->n_frames[s] = ready;
     }
   }
   if (!wstart.empty()) {
@@ -431,6 +451,7 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
                                              static_cast<int>(wstart.size()), b->d_frames, frow.data(), b->ld, st);
     if (rc != KAMD_OK) return rc;
   }
+  for (int i = 0; i < n; i++) b->n_frames[streams[i]] = new_frames[i];      // the rows exist now
   // ---- online i-vectors: which chunks became computable, one estimate update per stream, new slots
   const int sub = kamd_nnet_frame_subsampling_factor(b->nnet);
   const int L = kamd_nnet_left_context(b->nnet), R = kamd_nnet_right_context(b->nnet);
@@ -438,6 +459,8 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
   if (b->ie) {
     std::vector<int64_t> u_row; std::vector<int32_t> u_base, u_done, u_upto, u_rec;
     std::vector<int> a_src, a_dst, a_cnt;
+    struct Pending { int s, chunks, iv, slots; };
+    std::vector<Pending> pend;                              // state changes, committed once the launches are issued
     for (int i = 0; i < n; i++) {
       const int s = streams[i], F = b->n_frames[s], fin = b->finished[s] ? 1 : 0, C = b->chunk;
       const int n_out_total = kamd_nnet_num_output_frames(b->nnet, F);
@@ -448,11 +471,12 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
       // the estimate the decodable fetches: GetFrame(min(most recent input frame, NumFramesReady() - 1)) (decodable-online-looped.cc:174-183)
       const int iv_ready = fin ? F : std::max(0, F - b->splice_right);
       int src = b->S;                                     // "leave the iVector zero": row S of d_est
+      Pending pd = {s, k, b->iv_done[s], b->slots_assigned[s]};
       if (iv_ready > b->iv_done[s]) {
         src = static_cast<int>(u_row.size());
         u_row.push_back(static_cast<int64_t>(s) * b->max_frames); u_base.push_back(F); u_done.push_back(b->iv_done[s]);
         u_upto.push_back(iv_ready); u_rec.push_back(s);
-        b->iv_done[s] = iv_ready;
+        pd.iv = iv_ready;
       } else if (b->iv_done[s] > 0) src = -1 - s;         // no new frame: the stream's last estimate (kept in its last slot)
       // slots the new chunks' input ranges introduce (nnet-compile-looped.cc:186-207)
       const int hi_t = k * C + R - 1;                     // last input time of chunk k - 1
@@ -461,9 +485,9 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
       if (last_slot + 1 > b->max_slots) return kamd::SetError(KAMD_ERR_CAPACITY, "stream %d: i-vector slots exhausted", s);
       if (last_slot + 1 > have) {
         a_src.push_back(src); a_dst.push_back(s * b->max_slots + have); a_cnt.push_back(last_slot + 1 - have);
-        b->slots_assigned[s] = last_slot + 1;
+        pd.slots = last_slot + 1;
       }
-      b->chunks_done[s] = k;
+      pend.push_back(pd);
     }
     if (!u_row.empty()) {
       int rc = kamd_ivector_stream_update_device(b->ie, b->d_frames, b->ld, static_cast<int64_t>(b->S) * b->max_frames, u_row.data(),
@@ -497,6 +521,7 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
         KAMD_HIP(hipStreamSynchronize(st));           // d_assign is reused by the second pass
       }
     }
+    for (const Pending &pd : pend) { b->chunks_done[pd.s] = pd.chunks; b->iv_done[pd.s] = pd.iv; b->slots_assigned[pd.s] = pd.slots; }
   }
   // ---- nnet: one item per stream with new output frames (DecodableAmNnetLoopedOnline's rows)
   std::vector<int64_t> in_start, out_off;
@@ -545,11 +570,30 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
     }
     rc = kamd_decoder_advance(b->dec, tasks.data(), static_cast<int>(tasks.size()), st);
     if (rc != KAMD_OK) return rc;
-    rc = kamd_decoder_sync(b->dec);
-    if (rc != KAMD_OK) return rc;
+    // the lanes have consumed their rows whatever happens next: account for them first
     for (size_t k = 0; k < sid.size(); k++) b->decoded[sid[k]] += counts[k];
+    std::vector<int32_t> lane_ids(sid.begin(), sid.end()), lane_err(sid.size(), 0);
+    rc = kamd_decoder_sync_lanes(b->dec, lane_ids.data(), static_cast<int>(lane_ids.size()), lane_err.data());
+    if (rc != KAMD_OK) return rc;
+    int n_bad = 0, first_bad = -1;
+    for (size_t k = 0; k < sid.size(); k++)
+      if (lane_err[k]) { b->status[sid[k]] = lane_err[k]; n_bad++; if (first_bad < 0) first_bad = sid[k]; }
+    if (frames_decoded) for (int i = 0; i < n; i++) frames_decoded[i] = b->decoded[streams[i]];
+    if (n_bad)   // the other streams of the tick are fine and stay usable; kamd_stream_batch_get_status names the failed ones
+      return kamd::SetError(KAMD_ERR_CAPACITY, "%d stream(s) of this tick exceeded their lane's capacity (first: stream %d, flags %d); "
+                            "the others advanced normally", n_bad, first_bad, b->status[first_bad]);
+    return KAMD_OK;
   }
   if (frames_decoded) for (int i = 0; i < n; i++) frames_decoded[i] = b->decoded[streams[i]];
+  return KAMD_OK;
+}
+
+int kamd_stream_batch_get_status(const kamd_stream_batch *h, const int32_t *streams, int n, int32_t *status) {
+  const StreamBatch *b = reinterpret_cast<const StreamBatch *>(h);
+  for (int i = 0; i < n; i++) {
+    if (streams[i] < 0 || streams[i] >= b->S) return kamd::SetError(KAMD_ERR_ARG, "stream %d out of range", streams[i]);
+    status[i] = b->status[streams[i]];
+  }
   return KAMD_OK;
 }
 

@@ -287,6 +287,13 @@ class StreamBatch:
         check(lib().kamd_stream_batch_advance(self._h, abi.iptr(s), s.size, abi.iptr(out)))
         return out
 
+    def status(self, streams):
+        """0 = fine; otherwise the capacity flags that took the stream out of service (restart it with start())."""
+        s = np.ascontiguousarray(streams, np.int32)
+        out = np.zeros(s.size, np.int32)
+        check(lib().kamd_stream_batch_get_status(self._h, abi.iptr(s), s.size, abi.iptr(out)))
+        return out
+
     def partial_best_path(self, stream, use_final_probs=False):
         return decoder.partial_best_path(self.dec._dec, int(stream), use_final_probs)
 
@@ -304,7 +311,10 @@ class StreamBatch:
     def finalize(self, streams):
         s = np.ascontiguousarray(streams, np.int32)
         check(lib().kamd_decoder_finalize(self.dec._dec, abi.iptr(s), s.size, None))
-        check(lib().kamd_decoder_sync(self.dec._dec))
+        err = np.zeros(s.size, np.int32)
+        check(lib().kamd_decoder_sync_lanes(self.dec._dec, abi.iptr(s), s.size, abi.iptr(err)))
+        if err.any():
+            raise KamdError("stream(s) %s exceeded their lane's capacity (flags %s)" % (s[err != 0].tolist(), err[err != 0].tolist()))
 
     def raw_lattice(self, stream):
         return decoder.get_raw_lattice(self.dec._dec, int(stream))

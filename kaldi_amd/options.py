@@ -59,6 +59,10 @@ def _register_frame_mel(po, f, m):
 def _frame_mel_from(po, o):
     if po["dither"] != 0.0:
         raise KamdError("--dither=%g: only --dither=0 is supported (dithering is random in the reference)" % po["dither"])
+    if not po.was_given("dither"):
+        import sys
+        print("WARNING --dither not given: this implementation computes with --dither=0 (Kaldi's default is 1.0, random); "
+              "pass --dither=0 to make that explicit", file=sys.stderr)
     if po["window-type"] not in abi.KAMD_WIN:
         raise KamdError("Invalid window type " + po["window-type"])
     f, m = o.frame, o.mel

@@ -442,9 +442,19 @@ class ParseOptions:
             return self.parent[self.prefix + name]
         return self._values[self.normalize(name)]
 
+    def was_given(self, name):
+        """True iff the option appeared on the command line or in a --config file (not in the reference: used to
+        warn where this implementation's default differs from Kaldi's)."""
+        if self.parent is not None:
+            return self.parent.was_given(self.prefix + name)
+        return self.normalize(name) in getattr(self, "_given", ())
+
     def _set(self, key, value, has_eq, where):
         if key not in self._types:
             raise KamdError("Invalid option %s" % where)
+        if not hasattr(self, "_given"):
+            self._given = set()
+        self._given.add(key)
         t = self._types[key]
         if t is bool:
             if has_eq and value == "":

@@ -420,3 +420,61 @@ def test_endpointing_on_the_device_equals_the_oracle():
             assert bool(f) == orc.endpoint_detected(rules, len(bp["alignment"]), want_sil, 0.03, frc)
             checked += 1
     assert checked >= 8
+
+
+def test_one_overflowing_stream_does_not_stop_the_others():
+    """A stream that outgrows its lane's arena fails alone: the tick reports it, the other streams of the tick have
+    advanced and keep decoding to the offline result, the failed stream refuses further ticks until it is restarted,
+    and a bad entry in a tick's stream list changes nothing (validation comes before any state change)."""
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=3.0)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    waves = [synth.make_wave(d, seed=90 + i) for i, d in enumerate((4.0, 0.9, 1.1))]
+    big = abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512)
+
+    def offline(w):
+        d = decoder.LatticeFasterDecoder(G, cfg, big)
+        d.Decode(N.Forward(feat.Mfcc(op).ComputeFeatures(w)))
+        return d.GetRawLattice(), d.counters()
+
+    # an arena that holds the two short utterances but not the long one
+    need = [int(offline(w)[1][5]) for w in waves]
+    cap = max(need[1], need[2]) + 64
+    assert need[0] > 2 * cap
+    S = 3
+    sb = online.StreamBatch(op, N, G, cfg, S, max_seconds=5.0, sizes=abi.DecoderSizes(S, 1 << 14, cap, 4 * cap, 512))
+    sb.start([0, 1, 2])
+    with pytest.raises(Exception):
+        sb.advance([0, 0])                                   # duplicates are rejected ...
+    with pytest.raises(Exception):
+        sb.advance([1, 7])                                   # ... and so is an unknown stream, before anything happens
+    CH = 4000
+    pos, failed_at = [0, 0, 0], None
+    for tick in range(40):
+        live = [s for s in range(S) if pos[s] < waves[s].size and sb.status([s])[0] == 0]
+        if not live:
+            break
+        pieces = []
+        for s in live:
+            pieces.append(waves[s][pos[s]:pos[s] + CH]); pos[s] += pieces[-1].size
+        sb.accept_many(live, pieces, [pos[s] >= waves[s].size for s in live])
+        try:
+            sb.advance(live)
+        except Exception as e:
+            assert "capacity" in str(e)
+            failed_at = tick
+    assert failed_at is not None
+    st = sb.status([0, 1, 2])
+    assert st[0] != 0 and st[1] == 0 and st[2] == 0
+    with pytest.raises(Exception):
+        sb.advance([0])                                      # out of service until restarted
+    sb.finalize([1, 2])
+    for s in (1, 2):
+        assert lattices_equal(sb.raw_lattice(s), offline(waves[s])[0])
+    sb.start([0])                                            # restart the failed slot with an utterance that fits
+    assert sb.status([0])[0] == 0
+    sb.accept(0, waves[1], input_finished=True)
+    sb.advance([0])
+    sb.finalize([0])
+    assert lattices_equal(sb.raw_lattice(0), offline(waves[1])[0])

@@ -54,7 +54,10 @@ def main(argv):
             if glob is not None:
                 st = glob
             else:
-                sk = utt2spk.get(key, key) if utt2spk is not None else key
+                if utt2spk is not None and key not in utt2spk:
+                    # RandomAccessTableReaderMapped::HasKey / Value: KALDI_ERR, not a silent per-utterance fallback
+                    raise KamdError("Attempting to read key %s, which is not present in utt2spk map or its wxfilename" % key)
+                sk = utt2spk[key] if utt2spk is not None else key
                 if sk not in reader:
                     print("WARNING No normalization statistics available for key " + key + ", producing no output for this utterance",
                           file=sys.stderr)

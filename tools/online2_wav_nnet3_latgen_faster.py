@@ -112,7 +112,7 @@ def main(argv):
                     active[s] = dict(key=utt, wave=data[0], pos=0)
             if not active:
                 break
-            chunk = int(po["chunk-length"] * mfcc.frame.samp_freq) if po["chunk-length"] > 0 else 1 << 62
+            chunk = max(1, int(po["chunk-length"] * mfcc.frame.samp_freq)) if po["chunk-length"] > 0 else 1 << 62   # the reference clamps the chunk to one sample
             live = sorted(active)
             pieces = []
             for s in live:
@@ -131,8 +131,8 @@ def main(argv):
                 a = active[s]
                 ended = a["pos"] >= a["wave"].size
                 if s in endpointed:
-                    sb.accept(s, np.zeros(0, np.float32), input_finished=True)
-                    sb.advance([s])
+                    # the reference breaks out of the chunk loop and goes straight to FinalizeDecoding: no InputFinished,
+                    # no further AdvanceDecoding (online2-wav-nnet3-latgen-faster.cc: "if (do_endpointing && ... break;")
                     ended = True
                 if ended:
                     sb.finalize([s])
