@@ -67,16 +67,24 @@ struct Header {
   int64_t start, numstates, numarcs;
 };
 
-bool ReadHeader(Reader *r, Header *h) {
-  if (r->Get<int32_t>() != kFstMagic) return false;
+// The layout is restated from the published format and has never met a file written by OpenFst itself (none exists in
+// this image): every field this reader was not written for is refused by name instead of being guessed at.
+bool ReadHeader(Reader *r, Header *h, std::string *why = NULL) {
+  auto fail = [&](const std::string &m) { if (why) *why = m; return false; };
+  const int32_t magic = r->Get<int32_t>();
+  if (!r->ok || magic != kFstMagic) return fail("magic number " + std::to_string(magic) + ", expected " + std::to_string(kFstMagic));
   h->fsttype = r->Str(); h->arctype = r->Str();
   h->version = r->Get<int32_t>(); h->flags = r->Get<int32_t>();
   h->properties = r->Get<uint64_t>();
   h->start = r->Get<int64_t>(); h->numstates = r->Get<int64_t>(); h->numarcs = r->Get<int64_t>();
-  if (!r->ok) return false;
-  if (h->flags & kHasISymbols) r->SkipSymbolTable();
-  if (h->flags & kHasOSymbols) r->SkipSymbolTable();
-  return r->ok;
+  if (!r->ok) return fail("truncated header");
+  if (h->flags & ~(kHasISymbols | kHasOSymbols | kIsAligned))
+    return fail("header flags " + std::to_string(h->flags) + ": bits other than HAS_ISYMBOLS | HAS_OSYMBOLS | IS_ALIGNED are not understood");
+  // vector-fst.h kFileVersion = 2, const-fst.h kFileVersion = 2 / kAlignedFileVersion = 1 (OpenFst 1.6.x)
+  if (h->version != 1 && h->version != 2) return fail("file version " + std::to_string(h->version) + ", this reader knows 1 and 2 (OpenFst 1.6.x)");
+  if (h->flags & kHasISymbols) { r->SkipSymbolTable(); if (!r->ok) return fail("embedded input symbol table in a layout this reader does not know"); }
+  if (h->flags & kHasOSymbols) { r->SkipSymbolTable(); if (!r->ok) return fail("embedded output symbol table in a layout this reader does not know"); }
+  return true;
 }
 
 struct Writer {
@@ -127,7 +135,8 @@ int kamd_openfst_read(const char *path, int32_t *num_states, int32_t *start, int
   if (!f) return Fail("cannot open", path);
   Reader r(f);
   Header h;
-  if (!ReadHeader(&r, &h)) { fclose(f); return Fail("not an OpenFst binary file (bad magic / header)", path); }
+  std::string why;
+  if (!ReadHeader(&r, &h, &why)) { fclose(f); return kamd::SetError(KAMD_ERR_ARG, "%s: not an OpenFst binary file this reader accepts: %s", path, why.c_str()); }
   if (h.arctype != "standard") { fclose(f); return kamd::SetError(KAMD_ERR_ARG, "%s: arc type '%s', expected 'standard'", path, h.arctype.c_str()); }
   std::vector<int64_t> off;
   std::vector<kamd_arc> a;

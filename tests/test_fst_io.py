@@ -125,3 +125,29 @@ def test_lattice_text_form(tmp_path):
     assert p.read_text() == "k1 \n1\t0\t5\t0\t1.5,-2.25\n0\t2\t0\t7\n2\t2\t3\t3\t0.5,Infinity\n2\t0.25,0\n\n"
     (key, st, f, a), = list(kio.read_lattices(p))
     assert key == "k1" and st == 1 and a.size == 3 and f[4] == np.float32(0.25) and f[5] == 0.0
+
+
+def test_reader_refuses_header_fields_it_was_not_written_for(tmp_path):
+    """The OpenFst layout is restated from the published format and has never met a file OpenFst itself wrote: unknown
+    flag bits, an unknown file version or a wrong magic number are refused BY NAME instead of being read on a guess."""
+    import struct
+    from kaldi_amd import io as kio, synth
+    from kaldi_amd._lib import KamdError
+    g = synth.make_random_graph(num_states=20, num_labels=6, seed=4)
+    p = tmp_path / "g.fst"
+    kio.write_openfst(p, g, "const")
+    raw = bytearray(p.read_bytes())
+    # header: int32 magic | str fsttype | str arctype | int32 version | int32 flags | ...
+    pos = 4
+    for _ in range(2):
+        n = struct.unpack_from("<i", raw, pos)[0]
+        pos += 4 + n
+    ver_pos, flag_pos = pos, pos + 4
+    for patch, what in (((flag_pos, 8), "flags"), ((ver_pos, 7), "version"), ((0, 12345), "magic")):
+        bad = bytearray(raw)
+        struct.pack_into("<i", bad, patch[0], patch[1])
+        q = tmp_path / ("bad_%s.fst" % what)
+        q.write_bytes(bytes(bad))
+        with pytest.raises(KamdError, match=what):
+            kio.read_openfst(q)
+    assert kio.read_openfst(p).num_states == g.num_states
