@@ -67,7 +67,7 @@ def parse_args():
     ap.add_argument("--no-determinize", action="store_true")
     ap.add_argument("--hash-capacity", type=int, default=0)
     ap.add_argument("--tokens-per-frame", type=int, default=0, help="arena budget per frame and lane (0 = from max-active / free HBM)")
-    ap.add_argument("--nnet-pass-frames", type=int, default=400000)
+    ap.add_argument("--nnet-pass-frames", type=int, default=1000000)
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the cpu_baseline leg (0 = min(cores, 32))")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -16,7 +16,7 @@ from ._lib import KamdError, check, lib
 
 class NnetBatchDecoder:
     def __init__(self, mfcc_opts, model, hclg, cfg, max_seconds=36.0, resident_lanes=0, host_threads=8, determinize=True,
-                 keep_raw_lattices=False, tid_phone=None, sizes=None, nnet_pass_frames=400000, lattice_pool_bytes=1 << 30,
+                 keep_raw_lattices=False, tid_phone=None, sizes=None, nnet_pass_frames=1000000, lattice_pool_bytes=1 << 30,
                  hash_capacity=None, tokens_per_frame=None, search_mode=2):
         featmod = __import__("kaldi_amd.feat", fromlist=["Mfcc"])
         self.feat = featmod.Fbank(mfcc_opts) if isinstance(mfcc_opts, abi.FbankOpts) else featmod.Mfcc(mfcc_opts)

@@ -153,7 +153,7 @@ extern "C" {
 void kamd_batch_opts_default(kamd_batch_opts *o) {
   memset(o, 0, sizeof(*o));
   o->resident_lanes = 0; o->host_threads = 8; o->determinize = 1; o->keep_raw_lattices = 0;
-  o->nnet_pass_frames = 400000; o->lattice_pool_bytes = 1ll << 30; o->lattice_beam = 8.0f;
+  o->nnet_pass_frames = 1000000; o->lattice_pool_bytes = 1ll << 30; o->lattice_beam = 8.0f;
   kamd_determinize_opts_default(&o->det);
 }
 
@@ -166,7 +166,7 @@ kamd_batch_decoder *kamd_batch_decoder_create(kamd_feat *feat, kamd_nnet *nnet, 
   if (opts) b->opts = *opts; else kamd_batch_opts_default(&b->opts);
   if (b->opts.host_threads < 1) b->opts.host_threads = 1;
   if (b->opts.host_threads > 256) b->opts.host_threads = 256;
-  if (b->opts.nnet_pass_frames <= 0) b->opts.nnet_pass_frames = 400000;
+  if (b->opts.nnet_pass_frames <= 0) b->opts.nnet_pass_frames = 1000000;
   if (tid_phone && num_tids > 0) b->tid_phone.assign(tid_phone, tid_phone + num_tids + 1);
   b->feat_dim = kamd_feat_dim(feat); b->ld_feat = kamd::RoundUp(b->feat_dim, 16); b->P = kamd_nnet_output_dim(nnet);
   bool ok = hipGetDevice(&b->device) == hipSuccess && hipStreamCreateWithFlags(&b->s_main, hipStreamNonBlocking) == hipSuccess;

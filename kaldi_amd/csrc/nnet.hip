@@ -37,7 +37,77 @@ struct GemmArgs {
   const float *post_offset; float post_scale;
   float *C; int ldC;
   int gx, gy;                       // > 0: 1-D launch, XCD-aware tile order (see the kernel)
+  const float *zeros;               // >= 16 zero floats: the source of A rows that do not exist (rowmap < 0, m >= M)
 };
+
+// Epilogue of one 32x32 accumulator tile of one wavefront (round 2).  The MFMA C/D layout gives a lane 16 values of
+// ONE column; stored from there every global access is a 4-byte one (64 scalar loads + 64 scalar stores per lane and
+// workgroup tile with a bypass): on the K = 320 -> N = 1536 layers, whose main loop is only 20 k-blocks long, that tail
+// was ~40 % of the kernel.  Here the tile goes through a per-wave LDS scratch ([32][36] floats, in the operand buffers
+// the main loop no longer needs) and comes back row-major, so bias / BatchNorm / bypass / store are 16-byte accesses,
+// eight lanes per 128-byte row segment.  Same arithmetic per element, same result bits.
+#define EPI_LD 36
+__device__ inline void EpilogueTile(const GemmArgs &p, const f32x16 &acc, int m_base, int n_base, float *scr /* [32][EPI_LD], this wave's */) {
+  const int lane = threadIdx.x & 63, lr = lane & 31, lk = lane >> 5;
+  const bool vec = (p.N & 3) == 0 && (p.ldC & 3) == 0 && (!p.byp || (p.ld_byp & 3) == 0);
+  if (!vec) {   // unaligned shapes: the scalar path
+    const int n = n_base + lr;
+    if (n >= p.N) return;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const float bs = p.bn_scale ? p.bn_scale[n] : 1.f, bo = p.bn_scale ? p.bn_offset[n] : 0.f;
+    const float po = p.post_offset ? p.post_offset[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (m >= p.M) continue;
+      float v = acc[r] + bias;
+      if (p.ivbias) v += p.ivbias[static_cast<size_t>(p.row2utt[m]) * p.N + n];
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.bn_scale) v = v * bs + bo;
+      if (p.byp) v += p.bypass_scale * p.byp[static_cast<size_t>(p.bypmap[m]) * p.ld_byp + n];
+      if (p.post_offset) v += po;
+      v *= p.post_scale;
+      p.C[static_cast<size_t>(m) * p.ldC + n] = v;
+    }
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r++) scr[((r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_LD + lr] = acc[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the scratch is private to the wave: no barrier
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int c4 = (lane & 7) * 4, n = n_base + c4;
+  if (n < p.N) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 bias = p.bias ? *reinterpret_cast<const float4 *>(p.bias + n) : zero4;
+    const float4 bs = p.bn_scale ? *reinterpret_cast<const float4 *>(p.bn_scale + n) : one4;
+    const float4 bo = p.bn_scale ? *reinterpret_cast<const float4 *>(p.bn_offset + n) : zero4;
+    const float4 po = p.post_offset ? *reinterpret_cast<const float4 *>(p.post_offset + n) : zero4;
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+      const int row = (lane >> 3) + 8 * pass, m = m_base + row;
+      if (m >= p.M) continue;
+      const float4 a = *reinterpret_cast<const float4 *>(scr + row * EPI_LD + c4);
+      float v[4] = {a.x + bias.x, a.y + bias.y, a.z + bias.z, a.w + bias.w};
+      if (p.ivbias) {
+        const float4 iv = *reinterpret_cast<const float4 *>(p.ivbias + static_cast<size_t>(p.row2utt[m]) * p.N + n);
+        v[0] += iv.x; v[1] += iv.y; v[2] += iv.z; v[3] += iv.w;
+      }
+      if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if (p.bn_scale) { v[0] = v[0] * bs.x + bo.x; v[1] = v[1] * bs.y + bo.y; v[2] = v[2] * bs.z + bo.z; v[3] = v[3] * bs.w + bo.w; }
+      if (p.byp) {
+        const float4 z = *reinterpret_cast<const float4 *>(p.byp + static_cast<size_t>(p.bypmap[m]) * p.ld_byp + n);
+        v[0] += p.bypass_scale * z.x; v[1] += p.bypass_scale * z.y; v[2] += p.bypass_scale * z.z; v[3] += p.bypass_scale * z.w;
+      }
+      if (p.post_offset) { v[0] += po.x; v[1] += po.y; v[2] += po.z; v[3] += po.w; }
+      *reinterpret_cast<float4 *>(p.C + static_cast<size_t>(m) * p.ldC + n) =
+          make_float4(v[0] * p.post_scale, v[1] * p.post_scale, v[2] * p.post_scale, v[3] * p.post_scale);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next tile reuses the scratch
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // (256, 4): four workgroups per CU.  The main loop waits for its global prefetch and at a
 // barrier once per k-block; what hides that is other workgroups on the same SIMDs, so the
@@ -51,8 +121,11 @@ __global__ __launch_bounds__(256, 4) void TdnnGemmKernel(GemmArgs p) {
   constexpr int BK = 16;
   constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;
   constexpr int LDA = BM + 2, LDB = BN + 2;
-  __shared__ float As[2][BK][LDA];
-  __shared__ float Bs[2][BK][LDB];
+  constexpr int OPER = 2 * BK * (LDA + LDB);
+  static_assert(OPER >= 4 * 32 * EPI_LD, "the operand buffers double as the epilogue scratch of the four waves");
+  __shared__ __attribute__((aligned(16))) float oper[OPER];
+  float (*As)[BK][LDA] = reinterpret_cast<float (*)[BK][LDA]>(oper);
+  float (*Bs)[BK][LDB] = reinterpret_cast<float (*)[BK][LDB]>(oper + 2 * BK * LDA);
   __shared__ int rm[KAMD_MAX_OFFSETS][BM];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -141,30 +214,143 @@ __global__ __launch_bounds__(256, 4) void TdnnGemmKernel(GemmArgs p) {
     if (kb + 1 < nkb) sstore(buf ^ 1);
     __syncthreads();
   }
-  // epilogue: C/D map of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // epilogue (the loop ended with a barrier: nobody reads the operand buffers any more)
+  asm volatile("" ::: "memory");      // keep the epilogue's vector loads out of the main loop's register budget
+  float *scr = oper + wave * 32 * EPI_LD;
 #pragma unroll
   for (int i = 0; i < TI; i++)
 #pragma unroll
-    for (int j = 0; j < TJ; j++) {
-      const int n = n0 + wn * (BN / WN) + j * 32 + lr;
-      if (n >= p.N) continue;
-      const float bias = p.bias ? p.bias[n] : 0.f;
-      const float bs = p.bn_scale ? p.bn_scale[n] : 1.f, bo = p.bn_scale ? p.bn_offset[n] : 0.f;
-      const float po = p.post_offset ? p.post_offset[n] : 0.f;
+    for (int j = 0; j < TJ; j++)
+      EpilogueTile(p, acc[i][j], m0 + wm * (BM / WM) + i * 32, n0 + wn * (BN / WN) + j * 32, scr);
+}
+
+// Second-generation main loop (round 2): the same tile, the same exact-fp32 MFMA, but the operands go HBM/L2 -> LDS
+// directly (global_load_lds_dwordx4, no staging registers) through a NST-stage ring, two k-blocks ahead of the MFMAs,
+// with counted vmcnt waits and raw barriers.  The first generation (above) prefetches ONE 16-deep k-block through
+// registers: ~1 us of MFMA work to hide a load that takes 2-3 us when every CU streams, and every wave of the workgroup
+// then sits at the barrier (MfmaUtil 53 % at M = 4e5).
+//   * LDS image of a stage: rows of 64 bytes ([m][16 k], A tile then B tile), as the DMA writes them (lane-linear: one
+//     wave instruction = 16 rows x 4 sixteen-byte chunks).  Bank conflicts are avoided on the SOURCE side: the chunk
+//     that lands in slot p of row m is k-chunk p ^ ((m >> 2) & 3), so the four rows that share a 256-byte bank row
+//     and the rows 4, 8, 12 apart hold a given k-chunk in different slots (ds_read_b128 of 16 lanes: conflict free).
+//   * one ds_read_b128 gives a lane 4 consecutive k of its row; lane half lk takes k-chunk 2t + lk, so MFMA step
+//     (t, q) multiplies k = 8t + q (lanes 0-31) and k = 8t + 4 + q (lanes 32-63): every k once, 2 reads per operand
+//     tile and k-block instead of 8.  The summation order inside a k-block differs from the first generation's
+//     (a fixed permutation, the same for every batch composition): results stay exact-fp32 k-chains, bit-equal between
+//     batch / streaming / chunked evaluation, but not bit-equal to generation 1.
+//   * rows that do not exist (rowmap < 0: clamped context is explicit in the map, so this only pads M) read p.zeros.
+template <int BM, int BN, int WM, int WN, int NST>
+__global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
+  constexpr int BK = 16;
+  constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INST = BM / 16, B_INST = BN / 16;                  // wave instructions per stage (1 KB each)
+  constexpr int A_PW = (A_INST + 3) / 4, B_PW = (B_INST + 3) / 4;    // per wave (a clamped duplicate pads the count)
+  constexpr int LOADS = A_PW + B_PW;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + KAMD_MAX_OFFSETS * BM * 4];
+  int *rm = reinterpret_cast<int *>(smem + NST * ST_BYTES);          // [n_off][BM]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.gx > 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    by = xcd + 8 * (slot / p.gx); bx = slot % p.gx;
+    if (by >= p.gy) return;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int K = p.n_off * p.in_pad;
+  for (int i = t; i < p.n_off * BM; i += 256) {
+    const int o = i / BM, r = i % BM, m = m0 + r;
+    rm[o * BM + r] = (m < p.M) ? p.rowmap[static_cast<size_t>(o) * p.M + m] : -1;
+  }
+  __syncthreads();
+  f32x16 acc[TI][TJ];
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bias;
-        if (p.ivbias) v += p.ivbias[static_cast<size_t>(p.row2utt[m]) * p.N + n];
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.bn_scale) v = v * bs + bo;
-        if (p.byp) v += p.bypass_scale * p.byp[static_cast<size_t>(p.bypmap[m]) * p.ld_byp + n];
-        if (p.post_offset) v += po;
-        v *= p.post_scale;
-        p.C[static_cast<size_t>(m) * p.ldC + n] = v;
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  // The DMA is issued through inline asm: hipcc (ROCm 7.2) tracks a __builtin_amdgcn_global_load_lds as a pending LDS
+  // write and puts s_waitcnt vmcnt(0) in front of the next ds_read of the same array, which would drain the two
+  // k-blocks in flight on every iteration.  Invisible to that pass, the loads are ordered by the counted waits below.
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  const unsigned smem_lds = static_cast<unsigned>(reinterpret_cast<size_t>((lds_byte *)smem));
+  auto dma16 = [&](const float *g, unsigned lds_addr) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "memory");
+  };
+  const int lrow = lane >> 2, lslot = lane & 3;
+  auto issue = [&](int kb) {
+    const int k0 = kb * BK;
+    const int off = k0 / p.in_pad, kk = k0 - off * p.in_pad;
+    const unsigned st = smem_lds + (kb % NST) * ST_BYTES;
+#pragma unroll
+    for (int q = 0; q < A_PW; q++) {
+      int I = wave + 4 * q; if (I > A_INST - 1) I = A_INST - 1;
+      const int row = 16 * I + lrow, c = lslot ^ ((row >> 2) & 3);
+      const int src = rm[off * BM + row];
+      const float *g = src >= 0 ? p.A + static_cast<size_t>(src) * p.ldA + kk + 4 * c : p.zeros + 4 * c;
+      dma16(g, st + I * 1024);
+    }
+#pragma unroll
+    for (int q = 0; q < B_PW; q++) {
+      int J = wave + 4 * q; if (J > B_INST - 1) J = B_INST - 1;
+      const int row = 16 * J + lrow, c = lslot ^ ((row >> 2) & 3);
+      const float *g = p.W + static_cast<size_t>(n0 + row) * K + k0 + 4 * c;
+      dma16(g, st + A_BYTES + J * 1024);
+    }
+  };
+  const int nkb = K / BK;
+  issue(0);
+  if (nkb > 1) issue(1);
+  const int lr = lane & 31, lk = lane >> 5;
+  for (int kb = 0; kb < nkb; kb++) {
+    // k-block kb has landed once all but the newest LOADS of this wave's DMAs are done; then everybody's have
+    if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kb + 2 < nkb) issue(kb + 2);     // into the stage everybody finished reading before this barrier
+    const unsigned char *st = smem + (kb % NST) * ST_BYTES;
+    float4 a[TI][2], b[TJ][2];
+#pragma unroll
+    for (int i = 0; i < TI; i++) {
+      const int m = wm * (BM / WM) + i * 32 + lr;
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++)
+        a[i][tt] = *reinterpret_cast<const float4 *>(st + m * 64 + (((2 * tt + lk) ^ ((m >> 2) & 3)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+      const int n = wn * (BN / WN) + j * 32 + lr;
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++)
+        b[j][tt] = *reinterpret_cast<const float4 *>(st + A_BYTES + n * 64 + (((2 * tt + lk) ^ ((n >> 2) & 3)) << 4));
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int i = 0; i < TI; i++) {
+          const float av = q == 0 ? a[i][tt].x : q == 1 ? a[i][tt].y : q == 2 ? a[i][tt].z : a[i][tt].w;
+#pragma unroll
+          for (int j = 0; j < TJ; j++) {
+            const float bv = q == 0 ? b[j][tt].x : q == 1 ? b[j][tt].y : q == 2 ? b[j][tt].z : b[j][tt].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+        }
       }
     }
+  }
+  __builtin_amdgcn_s_barrier();            // every wave has read the last stage: the ring becomes epilogue scratch
+  asm volatile("" ::: "memory");
+  float *scr = reinterpret_cast<float *>(smem) + wave * 32 * EPI_LD;
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++)
+      EpilogueTile(p, acc[i][j], m0 + wm * (BM / WM) + i * 32, n0 + wn * (BN / WN) + j * 32, scr);
 }
 
 // LogSoftmaxComponent::Propagate = ApplyLogSoftMaxPerRow (nnet-simple-component.cc:3599;
@@ -270,6 +456,7 @@ struct Nnet {
   std::vector<int *> maps; std::vector<size_t> maps_cap;
   int64_t *d_meta = NULL; size_t meta_cap = 0;
   float *d_ivb = NULL; size_t ivb_cap = 0;
+  float *d_zero = NULL;      // 64 zero floats (GemmArgs::zeros)
 };
 
 static int Mod(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }
@@ -389,6 +576,8 @@ kamd_nnet *kamd_nnet_create(const kamd_layer_desc *layers, int n_layers, int inp
     if (!ok) { kamd::SetError(KAMD_ERR_HIP, "weight upload failed (layer %d)", i); delete nn; return NULL; }
   }
   if (kamd::PlanGrids(nn) != KAMD_OK) { delete nn; return NULL; }
+  nn->d_zero = kamd::DevAlloc<float>(64);
+  if (!nn->d_zero || hipMemset(nn->d_zero, 0, 64 * sizeof(float)) != hipSuccess) { kamd::SetError(KAMD_ERR_HIP, "nnet: allocation failed"); delete nn; return NULL; }
   nn->act.assign(n_layers, NULL); nn->act_cap.assign(n_layers, 0);
   nn->maps.assign(n_layers, NULL); nn->maps_cap.assign(n_layers, 0);
   return reinterpret_cast<kamd_nnet *>(nn);
@@ -406,6 +595,7 @@ void kamd_nnet_destroy(kamd_nnet *h) {
   }
   if (nn->d_meta) (void)hipFree(nn->d_meta);
   if (nn->d_ivb) (void)hipFree(nn->d_ivb);
+  if (nn->d_zero) (void)hipFree(nn->d_zero);
   delete nn;
 }
 
@@ -557,8 +747,25 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     // tile choice: a narrow layer (bottleneck / prefinal, N <= 160) is ONE column tile as
     // wide as the layer, so the (large) A operand is streamed exactly once; wide layers use
     // the 128x128 tile.
+    g.zeros = nn->d_zero;
+    static const bool gen1 = getenv("KAMD_GEMM_GEN1") != NULL && getenv("KAMD_GEMM_GEN1")[0] == '1';   // A/B against the first generation
     const int nt32 = kamd::CeilDiv(L.out_dim, 32);
-    if (nt32 <= 5) {
+    if (!gen1) {
+      if (nt32 <= 5) {
+        dim3 grid(1, kamd::CeilDiv(Ml, 128));
+        switch (nt32) {
+          case 1: hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 32, 4, 1, 3>), grid, dim3(256), 0, st, g); break;
+          case 2: hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 64, 4, 1, 3>), grid, dim3(256), 0, st, g); break;
+          case 3: hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 96, 4, 1, 3>), grid, dim3(256), 0, st, g); break;
+          case 4: hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 4, 1, 3>), grid, dim3(256), 0, st, g); break;
+          default: hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 160, 4, 1, 3>), grid, dim3(256), 0, st, g); break;
+        }
+      } else {
+        g.gx = kamd::CeilDiv(L.out_dim, 128); g.gy = static_cast<int>(kamd::CeilDiv(Ml, 128));
+        dim3 grid(static_cast<unsigned>(g.gx) * static_cast<unsigned>(kamd::RoundUp(g.gy, 8)));
+        hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, st, g);
+      }
+    } else if (nt32 <= 5) {
       dim3 grid(1, kamd::CeilDiv(Ml, 128));
       switch (nt32) {
         case 1: hipLaunchKernelGGL((kamd::TdnnGemmKernel<128, 32, 4, 1>), grid, dim3(256), 0, st, g); break;
