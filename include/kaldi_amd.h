@@ -755,6 +755,41 @@ int kamd_compact_lattice_get(const kamd_compact_lattice *c, float *state_final /
 int kamd_compact_lattice_write(const char *path, int append, const char *key, int binary,
                                const kamd_compact_lattice *c, float acoustic_scale);
 
+int kamd_compact_lattice_scale_graph(kamd_compact_lattice *c, float scale);
+
+/* ------------------------------------------------ const-ARPA LM rescoring -- */
+/* ConstArpaLm (lm/const-arpa-lm.h:211-352): the compact n-gram LM the recipes rescore lattices
+ * with (decode with tgsmall, then lattice-lmrescore-const-arpa with tglarge / fglarge: this is how
+ * the reference's "tglarge" WERs are produced, egs/librispeech/s5/RESULTS).  The G.carpa on-disk
+ * format is the reference's own (new format with tokens, and the old size-prefixed one). */
+typedef struct kamd_const_arpa kamd_const_arpa;
+/* arpa-to-const-arpa (BuildConstArpaLm, const-arpa-lm.cc:1064-1073) from an ARPA file of integer
+ * word ids, or of words with a "word id" symbol table (words_txt; NULL = integers).  bos / eos
+ * are required, unk = -1 when the LM has no <unk> (ArpaParseOptions). */
+kamd_const_arpa *kamd_const_arpa_build(const char *arpa_path, int32_t bos, int32_t eos, int32_t unk,
+                                       const char *words_txt);
+kamd_const_arpa *kamd_const_arpa_read(const char *path);
+int kamd_const_arpa_write(const kamd_const_arpa *lm, const char *path);
+void kamd_const_arpa_destroy(kamd_const_arpa *lm);
+int kamd_const_arpa_info(const kamd_const_arpa *lm, int32_t *bos, int32_t *eos, int32_t *unk, int32_t *order,
+                         int32_t *num_words, int64_t *lm_states_size);
+/* ConstArpaLm::GetNgramLogprob (const-arpa-lm.cc:741-779), natural log; FLT_MIN for a word the
+ * LM cannot score (no <unk>). */
+float kamd_const_arpa_ngram_logprob(const kamd_const_arpa *lm, int32_t word, const int32_t *hist, int n);
+/* ArpaFileParser::Read alone (lm/arpa-file-parser.cc:41-262): the n-grams in file order with the
+ * line they stand on, log-probabilities converted to natural log. */
+int kamd_arpa_parse(const char *arpa_path, const char *words_txt, int32_t *counts, int counts_cap, int32_t *n_counts,
+                    int32_t *lines, int32_t *orders, int32_t *words /* [cap][8] */, float *logprob, float *backoff,
+                    int cap, int32_t *n);
+/* lattice-lmrescore-const-arpa for one CompactLattice (latbin/lattice-lmrescore-const-arpa.cc:
+ * 76-110): graph costs / lm_scale, ComposeCompactLatticeDeterministic with the LM
+ * (lat/lattice-functions.cc:1529-1650), DeterminizeLattice, graph costs * lm_scale.  Arrays as
+ * kamd_compact_lattice_get returns them.  NULL + "Empty lattice" when nothing composes. */
+kamd_compact_lattice *kamd_compact_lattice_lmrescore_const_arpa(
+    int32_t num_states, int32_t start, const float *state_final, const int32_t *final_str_begin,
+    const int32_t *final_str_len, const kamd_clat_arc *arcs, int32_t num_arcs, const int32_t *strings,
+    const kamd_const_arpa *lm, float lm_scale);
+
 /* Best path of an UN-finalized lane (streaming partial results):
  * LatticeFasterOnlineDecoderTpl::GetBestPath = BestPathEnd + TraceBackBestPath
  * (decoder/lattice-faster-online-decoder.cc:54-165).  Requires a prior kamd_decoder_sync. */

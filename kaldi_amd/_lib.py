@@ -163,6 +163,15 @@ def lib():
     sig("kamd_decoder_queue_fetch_lattice", C.c_int, [vp, C.c_int32, vp, ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(fp),
                                                       C.POINTER(fp), C.POINTER(vp)])
     sig("kamd_decoder_queue_wait", C.c_int, [vp, fp, ip])
+    sig("kamd_compact_lattice_scale_graph", C.c_int, [vp, C.c_float])
+    sig("kamd_const_arpa_build", vp, [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.c_char_p])
+    sig("kamd_const_arpa_read", vp, [C.c_char_p])
+    sig("kamd_const_arpa_write", C.c_int, [vp, C.c_char_p])
+    sig("kamd_const_arpa_destroy", None, [vp])
+    sig("kamd_const_arpa_info", C.c_int, [vp, ip, ip, ip, ip, ip, i64p])
+    sig("kamd_const_arpa_ngram_logprob", C.c_float, [vp, C.c_int32, ip, C.c_int])
+    sig("kamd_arpa_parse", C.c_int, [C.c_char_p, C.c_char_p, ip, C.c_int, ip, ip, ip, ip, fp, fp, C.c_int, ip])
+    sig("kamd_compact_lattice_lmrescore_const_arpa", vp, [C.c_int32, C.c_int32, fp, ip, ip, vp, C.c_int32, ip, vp, C.c_float])
     sig("kamd_batch_opts_default", None, [C.POINTER(abi.BatchOpts)])
     sig("kamd_batch_decoder_create", vp, [vp, vp, vp, C.POINTER(abi.BatchOpts), ip, C.c_int32])
     sig("kamd_batch_decoder_destroy", None, [vp])
@@ -239,7 +248,7 @@ kamd_decoder_partial_best_paths kamd_endpoint_config_default kamd_endpoint_detec
 kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch kamd_pipeline_set_ivectors kamd_pipeline_set_online_ivectors
 kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features
 kamd_decoder_queue_configure kamd_decoder_queue_launch kamd_decoder_queue_poll kamd_decoder_queue_result kamd_decoder_queue_fetch_lattice kamd_decoder_queue_wait kamd_lattice_best_path
-kamd_stream_batch_get_status kamd_decoder_sync_lanes kamd_decoder_set_search_mode kamd_decoder_lds_layout kamd_device_num_cus kamd_batch_opts_default kamd_batch_decoder_create kamd_batch_decoder_destroy kamd_batch_decoder_load kamd_batch_decoder_run kamd_batch_decoder_get_output kamd_batch_decoder_get_raw_lattice kamd_batch_decoder_get_compact_lattice kamd_batch_decoder_get_loglikes""".split()
+kamd_compact_lattice_scale_graph kamd_const_arpa_build kamd_const_arpa_read kamd_const_arpa_write kamd_const_arpa_destroy kamd_const_arpa_info kamd_const_arpa_ngram_logprob kamd_arpa_parse kamd_compact_lattice_lmrescore_const_arpa kamd_stream_batch_get_status kamd_decoder_sync_lanes kamd_decoder_set_search_mode kamd_decoder_lds_layout kamd_device_num_cus kamd_batch_opts_default kamd_batch_decoder_create kamd_batch_decoder_destroy kamd_batch_decoder_load kamd_batch_decoder_run kamd_batch_decoder_get_output kamd_batch_decoder_get_raw_lattice kamd_batch_decoder_get_compact_lattice kamd_batch_decoder_get_loglikes""".split()
 
 
 def check(rc):

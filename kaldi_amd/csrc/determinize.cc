@@ -747,6 +747,15 @@ int kamd_compact_lattice_get(const kamd_compact_lattice *h, float *state_final, 
 // transition-ids; fstext/lattice-weight.h:532-540); text = acceptor lines
 // "src dst label graph,acoustic,tid_tid_..." (:728-740).  acoustic_scale != 1: acoustic costs
 // are divided by it (decoder-wrappers.cc:282-284).
+// ScaleLattice(GraphLatticeScale(s)) (fstext/lattice-utils.h): graph costs of every arc and final weight times s
+int kamd_compact_lattice_scale_graph(kamd_compact_lattice *h, float scale) {
+  CompactLattice *cl = reinterpret_cast<CompactLattice *>(h);
+  for (kamd_clat_arc &a : cl->arcs) a.graph_cost *= scale;
+  for (size_t s = 0; s < cl->fin.size() / 2; s++)
+    if (cl->fin[2 * s] != INFINITY) cl->fin[2 * s] *= scale;
+  return KAMD_OK;
+}
+
 int kamd_compact_lattice_write(const char *path, int append, const char *key, int binary, const kamd_compact_lattice *h,
                                float acoustic_scale) {
   const CompactLattice *cl = reinterpret_cast<const CompactLattice *>(h);
