@@ -281,36 +281,52 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "memory");
   };
   const int lrow = lane >> 2, lslot = lane & 3;
+  // Per-lane source pointers live in registers and advance by one k-block (64 bytes) per issue; only when the k index
+  // crosses into the next time-offset slice of the TDNN operand are the A pointers rebuilt from the row map (the 64-bit
+  // row * ldA arithmetic of every issue was ~60 VALU instructions per k-block beside 32 MFMAs).
+  const float *pa[A_PW], *pb[B_PW];
+  int ainc[A_PW];
+  unsigned a_lds[A_PW], b_lds[B_PW];
+#pragma unroll
+  for (int q = 0; q < B_PW; q++) {
+    int J = wave + 4 * q; if (J > B_INST - 1) J = B_INST - 1;
+    const int row = 16 * J + lrow, c = lslot ^ ((row >> 2) & 3);
+    pb[q] = p.W + static_cast<size_t>(n0 + row) * K + 4 * c;
+    b_lds[q] = A_BYTES + J * 1024;
+  }
+#pragma unroll
+  for (int q = 0; q < A_PW; q++) { int I = wave + 4 * q; if (I > A_INST - 1) I = A_INST - 1; a_lds[q] = I * 1024; pa[q] = p.zeros; ainc[q] = 0; }
+  const int kb_per_off = p.in_pad / BK;
   auto issue = [&](int kb) {
-    const int k0 = kb * BK;
-    const int off = k0 / p.in_pad, kk = k0 - off * p.in_pad;
+    if (kb % kb_per_off == 0) {                      // uniform: a new time-offset slice starts
+      const int off = kb / kb_per_off;
+#pragma unroll
+      for (int q = 0; q < A_PW; q++) {
+        const int row = (a_lds[q] >> 6) + lrow, c = lslot ^ ((row >> 2) & 3);
+        const int src = rm[off * BM + row];
+        pa[q] = src >= 0 ? p.A + static_cast<size_t>(src) * p.ldA + 4 * c : p.zeros + 4 * c;
+        ainc[q] = src >= 0 ? BK : 0;
+      }
+    }
     const unsigned st = smem_lds + (kb % NST) * ST_BYTES;
 #pragma unroll
-    for (int q = 0; q < A_PW; q++) {
-      int I = wave + 4 * q; if (I > A_INST - 1) I = A_INST - 1;
-      const int row = 16 * I + lrow, c = lslot ^ ((row >> 2) & 3);
-      const int src = rm[off * BM + row];
-      const float *g = src >= 0 ? p.A + static_cast<size_t>(src) * p.ldA + kk + 4 * c : p.zeros + 4 * c;
-      dma16(g, st + I * 1024);
-    }
+    for (int q = 0; q < A_PW; q++) { dma16(pa[q], st + a_lds[q]); pa[q] += ainc[q]; }
 #pragma unroll
-    for (int q = 0; q < B_PW; q++) {
-      int J = wave + 4 * q; if (J > B_INST - 1) J = B_INST - 1;
-      const int row = 16 * J + lrow, c = lslot ^ ((row >> 2) & 3);
-      const float *g = p.W + static_cast<size_t>(n0 + row) * K + k0 + 4 * c;
-      dma16(g, st + A_BYTES + J * 1024);
-    }
+    for (int q = 0; q < B_PW; q++) { dma16(pb[q], st + b_lds[q]); pb[q] += BK; }
   };
   const int nkb = K / BK;
-  issue(0);
-  if (nkb > 1) issue(1);
+  constexpr int DIST = NST - 1;          // k-blocks in flight ahead of the MFMAs
+#pragma unroll
+  for (int pkb = 0; pkb < DIST; pkb++) if (pkb < nkb) issue(pkb);
   const int lr = lane & 31, lk = lane >> 5;
   for (int kb = 0; kb < nkb; kb++) {
-    // k-block kb has landed once all but the newest LOADS of this wave's DMAs are done; then everybody's have
-    if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    // k-block kb has landed once all but the newest (DIST - 1) * LOADS of this wave's DMAs are done; then everybody's have
+    const int ahead = min(DIST - 1, nkb - 1 - kb);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (kb + 2 < nkb) issue(kb + 2);     // into the stage everybody finished reading before this barrier
+    if (kb + DIST < nkb) issue(kb + DIST);     // into the stage everybody finished reading before this barrier
     const unsigned char *st = smem + (kb % NST) * ST_BYTES;
     float4 a[TI][2], b[TJ][2];
 #pragma unroll
@@ -763,7 +779,10 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
       } else {
         g.gx = kamd::CeilDiv(L.out_dim, 128); g.gy = static_cast<int>(kamd::CeilDiv(Ml, 128));
         dim3 grid(static_cast<unsigned>(g.gx) * static_cast<unsigned>(kamd::RoundUp(g.gy, 8)));
-        hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, st, g);
+        static const int nst = getenv("KAMD_GEMM_NST") ? atoi(getenv("KAMD_GEMM_NST")) : 3;     // ring depth experiment
+        if (nst == 2) hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, st, g);
+        else if (nst == 4) hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 4>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, st, g);
       }
     } else if (nt32 <= 5) {
       dim3 grid(1, kamd::CeilDiv(Ml, 128));
