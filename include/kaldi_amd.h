@@ -318,6 +318,9 @@ int kamd_decoder_set_search_mode(kamd_decoder *d, int mode);
  * (pdfs beyond that are read from HBM) and words of the level-1 token table (states whose
  * probe window is full spill to the level-2 table in HBM).  Diagnostic, used by the tests. */
 int kamd_decoder_lds_layout(const kamd_decoder *d, int32_t *num_pdfs_lds, int32_t *table_words);
+/* Decoder lanes that share one compute unit in this build (1: 1024-thread lanes, 2: 512-thread lanes):
+ * resident lanes of a work-queue launch default to compute units x this. */
+int kamd_decoder_lanes_per_cu(void);
 /* Optional: split the token / link pools between lanes 0..n-1 in proportion to the
  * number of frames each will decode (utterance lengths differ 1-35 s); lanes >= n get
  * nothing.  Default is a uniform split.  Call before kamd_decoder_init. */

@@ -25,7 +25,7 @@ class NnetBatchDecoder:
         self.graph = hclg if isinstance(hclg, decoder.Graph) else decoder.Graph(hclg)
         fps = 1000.0 / mfcc_opts.frame.frame_shift_ms
         max_out = int(max_seconds * fps / model.subsampling) + 2
-        lanes = resident_lanes or lib().kamd_device_num_cus()
+        lanes = resident_lanes or lib().kamd_device_num_cus() * lib().kamd_decoder_lanes_per_cu()
         # every lane must hold the longest utterance: uniform arenas (avg = max)
         self.sizes = sizes or pipeline.default_sizes(cfg, lanes, max_out, max_out, hash_capacity=hash_capacity,
                                                      tokens_per_frame=tokens_per_frame)

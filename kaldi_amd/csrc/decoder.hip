@@ -33,15 +33,23 @@ namespace kamd {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-#define NT 1024
+// Lane geometry (build-time): KAMD_NT threads per lane.  1024 = one lane per CU with the whole 160 KB of LDS;
+// 512 = two lanes per CU (80 KB each: half the level-1 table, half the queues, a shorter LDS part of the score row):
+// the search is latency-bound per lane, so two independent lanes per CU overlap each other's round trips.
+#ifndef KAMD_NT
+#define KAMD_NT 1024
+#endif
+#define NT KAMD_NT
+#define LANES_PER_CU (1024 / NT)
 #define NWAVES (NT / 64)
-#define BIGCAP 3072     // tokens per flatten batch (deg > SMALL_DEG)
-#define FIN_CAP 6144         // tokens per frame the finalize sweep keeps in LDS (6 arrays)
-#define LDS_TABLE_CAP 8192   // level-1 table words (64 KB of the CU's 160 KB LDS)
-#define SMALL_DEG 4
 #define EXPT 3            // tokens per thread whose records are fetched together (EXPT * NT == BIGCAP)
+#define BIGCAP (EXPT * NT)   // tokens per flatten batch (deg > SMALL_DEG)
+#define FIN_CAP (6 * NT)     // tokens per frame the finalize sweep keeps in LDS (6 arrays)
+#define LDS_TABLE_CAP (8 * NT)   // level-1 table words (64 KB of a 1024-thread lane's LDS)
+#define SMALL_DEG 4
 #define ARCW 4           // arcs in flight per thread in the arc-parallel expansion
-#define CHUNKCAP 5120    // cached chunk owners (16 arcs each) per flatten batch
+#define CHUNKCAP (5 * NT)    // cached chunk owners (16 arcs each) per flatten batch
+static_assert(NT == 1024 || NT == 512, "KAMD_NT: 1024 (one lane per CU) or 512 (two)");
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
 
 enum { ERR_HASH = 1, ERR_TOK = 2, ERR_LINK = 4, ERR_FRAMES = 8, ERR_WL = 16, ERR_INTERNAL = 32 };
@@ -322,8 +330,8 @@ __device__ float BlockSelectKth(SrcPtr cost, int n, int k, Sh *sh) {
 // (monotone bucket map => lower buckets hold smaller costs); the bucket containing rank k
 // is then resolved EXACTLY by ranking its few members against each other.  Falls back to
 // the radix select when the bucket is too crowded.  `src` may point to LDS or global.
-#define LHBINS 4096
-#define LHCAND 1024
+#define LHBINS (4 * NT)     // the bucket scan below takes exactly four buckets per thread
+#define LHCAND NT
 template <typename SrcPtr>
 __device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float beam,
                                    u32 *lh /* [LHBINS] LDS */, float *cand /* [LHCAND] LDS */, Sh *sh) {
@@ -1067,7 +1075,7 @@ __device__ __forceinline__ void InitLane(const DecDev &d, const Ctx &c, Sh *shp)
   CommitFrame(d, c, &sh, tbl, d.cfg.beam, 0, 0, NULL, 0, 0);
   PublishLaneEnd(d, c, &sh, 0);
 }
-__global__ __launch_bounds__(NT) void InitKernel(DecDev d, const int *lanes) {
+__global__ __launch_bounds__(NT, 4) void InitKernel(DecDev d, const int *lanes) {
   __shared__ Sh sh;
   const Ctx c = MakeCtx(d, lanes[blockIdx.x]);
   InitLane(d, c, &sh);
@@ -1098,7 +1106,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
     sh.cur_tb = c.tok_off[frame]; sh.cur_n = c.tok_off[frame + 1] - c.tok_off[frame];
     sh.lnk_used = S->lnk_used; sh.round = S->round;
   }
-  constexpr int LLPF = 3;                         // row entries per thread held in registers
+  constexpr int LLPF = 3072 / NT;                 // row entries per thread held in registers
   const bool ll_pf = d.num_pdfs_lds > 0 && d.num_pdfs_lds <= LLPF * NT;
   float llp[LLPF];
 #pragma unroll
@@ -1348,7 +1356,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
   }
   PublishLaneEnd(d, c, &sh, frame);
 }
-__global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_task *tasks) {
+__global__ __launch_bounds__(NT, 4) void AdvanceKernel(DecDev d, const kamd_decode_task *tasks) {
   __shared__ Sh sh;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   const kamd_decode_task task = tasks[blockIdx.x];
@@ -1360,7 +1368,7 @@ __global__ __launch_bounds__(NT) void AdvanceKernel(DecDev d, const kamd_decode_
 // + PruneForwardLinks(f, delta = 0) for every earlier frame (:312-383), iterated to the
 // exact fixpoint, + PruneTokensForFrame; then in-place, order preserving compaction of
 // the surviving tokens / links so the host copies only the raw lattice.
-__global__ __launch_bounds__(NT) void FinalizeKernel(DecDev d, const int *lanes) {
+__global__ __launch_bounds__(NT, 4) void FinalizeKernel(DecDev d, const int *lanes) {
   __shared__ Sh sh;
   const int lane = lanes[blockIdx.x];
   const Ctx c = MakeCtx(d, lane);
@@ -1959,7 +1967,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
     S->error |= sh.err;
   }
 }
-__global__ __launch_bounds__(NT) void FinalizeKernel2(DecDev d, const int *lanes) {
+__global__ __launch_bounds__(NT, 4) void FinalizeKernel2(DecDev d, const int *lanes) {
   __shared__ Sh sh;
   __shared__ FinSh fs;
   extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
@@ -1991,7 +1999,11 @@ struct QueueDev {
 };
 enum { ERR_POOL = 64 };
 
-__global__ __launch_bounds__(NT) void DecodeQueueKernel(DecDev d, QueueDev q) {
+// The three stages are inlined into one body.  The compiler then spills ~100 VGPRs (uniform pointers, mostly) to
+// scratch in it; the two ways round that which were measured are both slower: the stages behind real calls on an
+// LDS copy of the descriptors (52 spills, decode 194 -> 238 ms on the headline), and the cold per-lane pointers kept
+// in LDS and fetched through v_readfirstlane (45 spills in this kernel, and new ones in the stand-alone kernels).
+__global__ __launch_bounds__(NT, 4) void DecodeQueueKernel(DecDev d, QueueDev q) {
   __shared__ Sh sh;
   __shared__ FinSh fs;
   __shared__ int s_task;
@@ -2130,7 +2142,7 @@ __device__ int WalkBestPath(const DecDev &d, const Ctx &c, Sh *sh, int use_final
   return n_out;
 }
 
-__global__ __launch_bounds__(NT) void TracebackKernel(DecDev d, int lane, int use_final_probs,
+__global__ __launch_bounds__(NT, 4) void TracebackKernel(DecDev d, int lane, int use_final_probs,
                                                       PathArc *out_arcs, int out_cap, int *out_n,
                                                       float *out_final_cost) {
   __shared__ Sh sh;
@@ -2151,7 +2163,7 @@ __global__ __launch_bounds__(NT) void TracebackKernel(DecDev d, int lane, int us
 
 // The same for a batch of lanes in one launch (a server's partial results after a tick): lane lanes[b] writes its
 // arcs at out_arcs + b * out_cap, its count / final cost at head[2b], head[2b+1] (count -1: no token alive).
-__global__ __launch_bounds__(NT) void TracebackBatchKernel(DecDev d, const int *lanes, int use_final_probs, PathArc *out_arcs,
+__global__ __launch_bounds__(NT, 4) void TracebackBatchKernel(DecDev d, const int *lanes, int use_final_probs, PathArc *out_arcs,
                                                            int out_cap, int *head) {
   __shared__ Sh sh;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -2175,7 +2187,7 @@ __global__ __launch_bounds__(NT) void TracebackBatchKernel(DecDev d, const int *
 // TrailingSilenceLength (online2/online-endpoint.cc:71-102) for a batch of un-finalized lanes: the best path
 // without final-probs is walked back from the newest frame, counting transition-ids of silence phones until
 // the first one that is not (sil_tid[tid] = 1 for transition-ids of silence phones).
-__global__ __launch_bounds__(NT) void TrailingSilenceKernel(DecDev d, const int *lanes, const unsigned char *sil_tid,
+__global__ __launch_bounds__(NT, 4) void TrailingSilenceKernel(DecDev d, const int *lanes, const unsigned char *sil_tid,
                                                             int n_tids, int *out) {
   __shared__ Sh sh;
   const Ctx c = MakeCtx(d, lanes[blockIdx.x]);
@@ -2420,7 +2432,7 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   // read from HBM: LogLikePdf)
   d.lds_table_cap = LDS_TABLE_CAP;
   d.num_pdfs_lds = 0;
-  const size_t lds_budget = 160 * 1024 - sizeof(kamd::Sh) - 1024;
+  const size_t lds_budget = 160 * 1024 / LANES_PER_CU - sizeof(kamd::Sh) - 1024;
   const size_t fixed = kamd::AdvanceLdsBytes(0, LDS_TABLE_CAP);
   if (fixed < lds_budget) d.num_pdfs_lds = static_cast<int>(std::min<size_t>(static_cast<size_t>(num_pdfs), (lds_budget - fixed) / 4) & ~static_cast<size_t>(3));
   if (d.num_pdfs_lds + 3 >= num_pdfs && kamd::AdvanceLdsBytes(num_pdfs, LDS_TABLE_CAP) <= lds_budget) d.num_pdfs_lds = num_pdfs;
@@ -2510,6 +2522,8 @@ static int ReserveUniform(Decoder *D) {
   D->split_uniform = true;
   return KAMD_OK;
 }
+
+int kamd_decoder_lanes_per_cu(void) { return LANES_PER_CU; }
 
 int kamd_decoder_lds_layout(const kamd_decoder *h, int32_t *num_pdfs_lds, int32_t *table_words) {
   const Decoder *D = reinterpret_cast<const Decoder *>(h);
@@ -3109,7 +3123,7 @@ int kamd_decoder_queue_launch(kamd_decoder *h, const kamd_queue_task *tasks, int
     KAMD_HIP(hipGetDeviceProperties(&prop, dev));
     cus = prop.multiProcessorCount;
   }
-  int R = resident_lanes > 0 ? resident_lanes : cus;
+  int R = resident_lanes > 0 ? resident_lanes : cus * LANES_PER_CU;
   R = std::min(std::min(R, n), D->sizes.max_lanes);
   if (R < 1) return kamd::SetError(KAMD_ERR_ARG, "no resident lanes");
   if (ReserveUniform(D) != KAMD_OK) return KAMD_ERR_HIP;
