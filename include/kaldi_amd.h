@@ -196,6 +196,8 @@ kamd_nnet *kamd_nnet_create(const kamd_layer_desc *layers, int n_layers,
                             int input_dim, int frame_subsampling_factor);
 void kamd_nnet_destroy(kamd_nnet *n);
 int kamd_nnet_output_dim(const kamd_nnet *n);
+int kamd_nnet_input_dim(const kamd_nnet *n);      /* dim of the "input" node */
+int kamd_nnet_ivector_dim(const kamd_nnet *n);    /* dim of the "ivector" node, 0 without one */
 int kamd_nnet_left_context(const kamd_nnet *n);   /* ComputeSimpleNnetContext */
 int kamd_nnet_right_context(const kamd_nnet *n);
 /* DecodableNnetSimple semantics (nnet-am-decodable-simple.cc:40-47): number of
@@ -759,6 +761,11 @@ int kamd_compact_lattice_write(const char *path, int append, const char *key, in
                                const kamd_compact_lattice *c, float acoustic_scale);
 
 int kamd_compact_lattice_scale_graph(kamd_compact_lattice *c, float scale);
+/* fst::ScaleLattice with a diagonal scale (fstext/lattice-utils-inl.h:250-290): both weight
+ * components of every arc and final weight. */
+int kamd_compact_lattice_scale(kamd_compact_lattice *c, float graph_scale, float acoustic_scale);
+/* A caller-owned copy (of a borrowed lattice, e.g. kamd_batch_decoder_get_compact_lattice's). */
+kamd_compact_lattice *kamd_compact_lattice_copy(const kamd_compact_lattice *c);
 
 /* ------------------------------------------------ const-ARPA LM rescoring -- */
 /* ConstArpaLm (lm/const-arpa-lm.h:211-352): the compact n-gram LM the recipes rescore lattices
@@ -936,6 +943,12 @@ kamd_batch_decoder *kamd_batch_decoder_create(kamd_feat *feat, kamd_nnet *nnet, 
 void kamd_batch_decoder_destroy(kamd_batch_decoder *b);
 /* AcceptInput for the whole shard: utterance u owns samples [wave_off[u], wave_off[u+1]). */
 int kamd_batch_decoder_load(kamd_batch_decoder *b, const float *waves, const int64_t *wave_off, int n_utts);
+/* AcceptInput as the reference declares it (nnet-batch-compute.h:665-669: feature matrices, not
+ * waveforms, plus the optional per-utterance i-vector): rows [row_off[u], row_off[u+1]) of feats
+ * (dim floats per row, dim = the model's input dim) are utterance u; ivectors is [n_utts x
+ * ivector_dim] or NULL.  The run then starts at the acoustic model (feat may be NULL at create). */
+int kamd_batch_decoder_load_features(kamd_batch_decoder *b, const float *feats, const int64_t *row_off, int dim,
+                                     const float *ivectors, int ivector_dim, int n_utts);
 /* Finished(): runs the shard and returns when every utterance's output is on the host.  A
  * per-utterance failure (capacity) does not fail the run: see n_failed and _get_output. */
 int kamd_batch_decoder_run(kamd_batch_decoder *b, kamd_batch_stats *stats);

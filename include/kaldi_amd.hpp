@@ -8,6 +8,8 @@
 //   kaldi_amd::LatticeFasterDecoder       decoder/lattice-faster-decoder.h:226-343
 //   kaldi_amd::DecodableMatrixMapped      decoder/decodable-matrix.h:98-136
 //   kaldi_amd::MfccOptions / Mfcc         feat/feature-mfcc.h:38-56, feature-common.h:111
+//   kaldi_amd::NnetBatchDecoder           nnet3/nnet-batch-compute.h:606-833
+//   kaldi_amd::ConstArpaLm                lm/const-arpa-lm.h:211-352
 // Errors: the reference's KALDI_ERR throws kaldi::KaldiFatalError (std::runtime_error,
 // base/kaldi-error.h:89-140); here every non-zero C-ABI status throws
 // kaldi_amd::KaldiFatalError carrying kamd_last_error().
@@ -828,54 +830,264 @@ class SequentialBaseFloatMatrixReader {
   std::vector<float> data_;
 };
 
-// ---- nnet3-latgen-faster-batch's NnetBatchDecoder flow (nnet3/nnet-batch-compute.h:606-833: AcceptInput per utterance,
-// one compute thread, decoder threads) as ONE device pass per batch: waveforms (or features) -> log-likelihoods ->
-// lattices, nothing crossing PCIe in between (kamd_pipeline_*).
+// ---- nnet3/nnet-batch-compute.h:606-833 NnetBatchDecoder, as nnet3-latgen-faster-batch drives it
+// (nnet3bin/nnet3-latgen-faster-batch.cc:170-214): AcceptInput per utterance, Finished(), GetOutput until false.
+// Here the utterances of the set wait in host memory until Finished(), which runs the whole set through the device
+// (kamd_batch_decoder_*: features -> acoustic model in a few large passes -> ONE work-queue launch of the search ->
+// best path + determinization on num_threads host threads while the search is still running); outputs then come back
+// in input order.  What differs from the reference's signature and why:
+//   * `trans_model` -> the two tables that are read from it: id2pdf (TransitionIdToPdfFast) and tid_phone
+//     (DeterminizeLatticePhonePrunedWrapper's use of it, see that function above; empty = word determinization only);
+//   * `computer` (NnetBatchComputer) -> the acoustic model itself: the device batches whole utterances, there are no
+//     minibatches of chunks to configure; `acoustic_scale` is what NnetSimpleComputationOptions carried;
+//   * word_syms: a vector indexed by word id (fst::SymbolTable is OpenFst's);
+//   * AcceptWaveform: waveform in, features on the device (the reference computes MFCCs in a process upstream).
+struct NnetBatchDecoderOptions {
+  kamd_batch_opts c;            // c.det = config.det_opts of the reference (DeterminizeLatticePhonePrunedOptions)
+  BaseFloat acoustic_scale;     // output lattices get their acoustic costs divided by it (nnet-batch-compute.cc:1265-1267)
+  int32 search_mode;            // kamd_decoder_set_search_mode
+  NnetBatchDecoderOptions() : acoustic_scale(1.0f), search_mode(2) { kamd_batch_opts_default(&c); }
+};
+
 class NnetBatchDecoder {
  public:
-  NnetBatchDecoder(const LatticeFasterDecoderConfig &decoder_opts, const std::vector<int32> &id2pdf, const AmNnetSimple &am_nnet,
-                   const DecodingGraph &fst, const MfccOptions &mfcc_opts, const kamd_decoder_sizes &sizes)
-      : feat_(CheckPtr(kamd_mfcc_create(&mfcc_opts.c, 1.0f))) {
-    decoder_opts.Check();
-    kamd_decoder_config c = decoder_opts.ToC();
-    dec_ = CheckPtr(kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), static_cast<int32>(id2pdf.size())));
-    h_ = CheckPtr(kamd_pipeline_create(feat_, am_nnet.Handle(), dec_));
+  NnetBatchDecoder(const DecodingGraph &fst, const LatticeFasterDecoderConfig &decoder_config, const std::vector<int32> &id2pdf,
+                   const std::vector<int32> &tid_phone, const std::vector<std::string> *word_syms, bool allow_partial, int32 num_threads,
+                   const AmNnetSimple &am_nnet, const MfccOptions *mfcc_opts, const kamd_decoder_sizes &sizes,
+                   NnetBatchDecoderOptions opts = NnetBatchDecoderOptions())
+      : config_(decoder_config), word_syms_(word_syms), allow_partial_(allow_partial), opts_(opts), feat_(NULL), dec_(NULL), h_(NULL),
+        next_out_(0), finished_(false), num_success_(0), num_fail_(0), num_partial_(0), tot_like_(0.0), frame_count_(0) {
+    decoder_config.Check();
+    kamd_decoder_config c = decoder_config.ToC();
+    opts_.c.host_threads = num_threads;
+    opts_.c.determinize = decoder_config.determinize_lattice ? 1 : 0;
+    opts_.c.keep_raw_lattices = decoder_config.determinize_lattice ? 0 : 1;
+    opts_.c.lattice_beam = decoder_config.lattice_beam;
+    if (mfcc_opts) feat_ = CheckPtr(kamd_mfcc_create(&mfcc_opts->c, 1.0f));
+    dec_ = kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), static_cast<int32>(id2pdf.size()));
+    if (dec_ && kamd_decoder_set_search_mode(dec_, opts_.search_mode) == 0)
+      h_ = kamd_batch_decoder_create(feat_, am_nnet.Handle(), dec_, &opts_.c, tid_phone.empty() ? NULL : tid_phone.data(),
+                                     static_cast<int32>(tid_phone.size()) - 1);
+    if (!h_) {
+      const std::string why = kamd_last_error();
+      if (dec_) kamd_decoder_destroy(dec_);
+      if (feat_) kamd_feat_destroy(feat_);
+      throw KaldiFatalError(why);
+    }
+    input_dim_ = kamd_nnet_input_dim(am_nnet.Handle()); ivector_dim_ = kamd_nnet_ivector_dim(am_nnet.Handle());
   }
-  ~NnetBatchDecoder() { kamd_pipeline_destroy(h_); kamd_decoder_destroy(dec_); kamd_feat_destroy(feat_); }
+  ~NnetBatchDecoder() {
+    kamd_batch_decoder_destroy(h_); kamd_decoder_destroy(dec_);
+    if (feat_) kamd_feat_destroy(feat_);
+  }
   NnetBatchDecoder(const NnetBatchDecoder &) = delete;
   NnetBatchDecoder &operator=(const NnetBatchDecoder &) = delete;
-  /// waves: the batch's utterances (int16-range samples); decodes all of them (AcceptInput ... Finished)
-  void Decode(const std::vector<std::vector<float> > &waves) {
-    std::vector<int64_t> off(waves.size() + 1, 0);
-    for (size_t u = 0; u < waves.size(); u++) off[u + 1] = off[u] + static_cast<int64_t>(waves[u].size());
-    std::vector<float> flat(static_cast<size_t>(off.back()));
-    for (size_t u = 0; u < waves.size(); u++) std::copy(waves[u].begin(), waves[u].end(), flat.begin() + off[u]);
-    Check(kamd_pipeline_load_batch(h_, flat.data(), off.data(), static_cast<int>(waves.size())));
-    Check(kamd_pipeline_run(h_, stage_ms_));
+
+  /// input: [num_rows x num_cols] row-major features (Matrix<BaseFloat>); ivector: NULL or [ivector_dim].
+  /// online_ivectors are not taken here: the device estimates them itself (OnlineStreamBatch / kamd_pipeline_set_ivector_extractor).
+  void AcceptInput(const std::string &utterance_id, const float *input, int32 num_rows, int32 num_cols, const float *ivector,
+                   int32 ivector_dim, const float *online_ivectors = NULL, int32 online_ivector_period = 0) {
+    (void)online_ivector_period;
+    if (finished_) throw KaldiFatalError("NnetBatchDecoder: AcceptInput after Finished()");
+    if (online_ivectors) throw KaldiFatalError("NnetBatchDecoder: online i-vectors as input are not supported; the device estimates them");
+    if (!waves_.empty()) throw KaldiFatalError("NnetBatchDecoder: a set is either waveforms or feature matrices");
+    if (num_rows <= 0) throw KaldiFatalError("Zero-length utterance: " + utterance_id);
+    if (num_cols != input_dim_) throw KaldiFatalError("NnetBatchDecoder: feature dim mismatch for " + utterance_id);
+    if ((ivector ? ivector_dim : 0) != ivector_dim_) throw KaldiFatalError("NnetBatchDecoder: i-vector dim mismatch for " + utterance_id);
+    keys_.push_back(utterance_id);
+    feats_.insert(feats_.end(), input, input + static_cast<size_t>(num_rows) * num_cols);
+    row_off_.push_back(row_off_.empty() ? num_rows : row_off_.back() + num_rows);
+    if (ivector) ivectors_.insert(ivectors_.end(), ivector, ivector + ivector_dim);
   }
-  /// online i-vectors estimated on the device from the batch's own features (or NULL to turn that off)
-  void SetIvectorExtractor(kamd_ivector_extractor *extractor, int32 frames_per_chunk = 50) {
-    Check(kamd_pipeline_set_ivector_extractor(h_, extractor, frames_per_chunk));
+  void AcceptWaveform(const std::string &utterance_id, const std::vector<float> &wave) {
+    if (finished_) throw KaldiFatalError("NnetBatchDecoder: AcceptWaveform after Finished()");
+    if (!feat_) throw KaldiFatalError("NnetBatchDecoder: constructed without feature options");
+    if (!feats_.empty()) throw KaldiFatalError("NnetBatchDecoder: a set is either waveforms or feature matrices");
+    keys_.push_back(utterance_id);
+    waves_.insert(waves_.end(), wave.begin(), wave.end());
+    row_off_.push_back(static_cast<int64_t>(waves_.size()));
   }
-  bool GetBestPath(int32 utt, std::vector<int32> *alignment, std::vector<int32> *words, BaseFloat *graph_cost, BaseFloat *acoustic_cost) const {
-    kamd_lattice_size sz;
-    Check(kamd_decoder_lattice_size(dec_, utt, &sz));
-    const int cap = sz.num_arcs + 1;
-    std::vector<int32> ali(cap), wrd(cap);
-    int na = 0, nw = 0;
-    if (kamd_decoder_best_path(dec_, utt, ali.data(), cap, &na, wrd.data(), cap, &nw, graph_cost, acoustic_cost) != 0) return false;
-    alignment->assign(ali.begin(), ali.begin() + na); words->assign(wrd.begin(), wrd.begin() + nw);
+  void UtteranceFailed() { num_fail_++; }
+
+  /// Runs the set; returns the number of utterances successfully decoded (nnet-batch-compute.cc:1310-1343).
+  int32 Finished() {
+    if (finished_) throw KaldiFatalError("NnetBatchDecoder: Finished() called twice");
+    finished_ = true;
+    if (keys_.empty()) return 0;
+    std::vector<int64_t> off(1, 0);
+    off.insert(off.end(), row_off_.begin(), row_off_.end());
+    const int n = static_cast<int>(keys_.size());
+    if (!waves_.empty()) Check(kamd_batch_decoder_load(h_, waves_.data(), off.data(), n));
+    else Check(kamd_batch_decoder_load_features(h_, feats_.data(), off.data(), input_dim_, ivectors_.empty() ? NULL : ivectors_.data(), ivector_dim_, n));
+    std::vector<float>().swap(waves_); std::vector<float>().swap(feats_);
+    Check(kamd_batch_decoder_run(h_, &stats_));
+    // the per-utterance outcome, with the log lines of decoder-wrappers.cc:228-292
+    ok_.assign(n, 0);
+    for (int u = 0; u < n; u++) {
+      kamd_queue_result rec;
+      int nw = 0, na = 0; float g = 0, a = 0;
+      const int rc = kamd_batch_decoder_get_output(h_, u, NULL, 0, &nw, NULL, 0, &na, &g, &a, &rec);
+      if (rc != 0) { fprintf(stderr, "WARNING Decoding failed for utterance %s: %s\n", keys_[u].c_str(), kamd_last_error()); num_fail_++; continue; }
+      const bool reached_final = rec.final_relative_cost != std::numeric_limits<float>::infinity();
+      if (!reached_final) {
+        if (!allow_partial_) {
+          fprintf(stderr, "WARNING Not producing output for utterance %s since no final-state reached and --allow-partial=false.\n", keys_[u].c_str());
+          num_fail_++;
+          continue;
+        }
+        fprintf(stderr, "WARNING Outputting partial output for utterance %s since no final-state reached\n", keys_[u].c_str());
+        num_partial_++;
+      }
+      ok_[u] = 1; num_success_++;
+      tot_like_ += -static_cast<double>(g + a); frame_count_ += rec.n_frames;
+      fprintf(stderr, "LOG Log-like per frame for utterance %s is %g over %d frames.\n", keys_[u].c_str(),
+              rec.n_frames > 0 ? -(g + a) / rec.n_frames : 0.0, rec.n_frames);
+    }
+    return num_success_;
+  }
+
+  /// determinize_lattice == true version: outputs in input order, false when nothing is left.
+  bool GetOutput(std::string *utterance_id, CompactLattice *clat, std::string *sentence) {
+    if (!config_.determinize_lattice) throw KaldiFatalError("Don't call this version of GetOutput if you are not determinizing.");
+    const int u = NextOutput();
+    if (u < 0) return false;
+    const kamd_compact_lattice *c = kamd_batch_decoder_get_compact_lattice(h_, u);
+    if (!c) throw KaldiFatalError(kamd_last_error());
+    kamd_compact_lattice *mine = CheckPtr(kamd_compact_lattice_copy(c));
+    if (opts_.acoustic_scale != 0.0f && opts_.acoustic_scale != 1.0f) kamd_compact_lattice_scale(mine, 1.0f, 1.0f / opts_.acoustic_scale);
+    clat->Reset(mine);
+    *utterance_id = keys_[u];
+    Sentence(u, sentence);
     return true;
   }
-  /// device time of the last batch: features, nnet, AdvanceDecoding, FinalizeDecoding (ms)
-  const float *StageMs() const { return stage_ms_; }
+  /// determinize_lattice == false version.
+  bool GetOutput(std::string *utterance_id, Lattice *lat, std::string *sentence) {
+    if (config_.determinize_lattice) throw KaldiFatalError("Don't call this version of GetOutput if you are determinizing.");
+    const int u = NextOutput();
+    if (u < 0) return false;
+    int32 ns = 0, na = 0, start = -1;
+    const int32 *fr, *hc; const float *cost, *fin; const kamd_lat_arc *arcs;
+    Check(kamd_batch_decoder_get_raw_lattice(h_, u, &ns, &na, &start, &fr, &hc, &cost, &fin, &arcs));
+    const float inv = opts_.acoustic_scale != 0.0f && opts_.acoustic_scale != 1.0f ? 1.0f / opts_.acoustic_scale : 1.0f;
+    lat->start = start;
+    lat->arcs.assign(ns, std::vector<LatticeArc>());
+    lat->final_graph_cost.assign(fin, fin + ns);
+    lat->state_frame.assign(fr, fr + ns); lat->state_hclg.assign(hc, hc + ns);
+    for (int32 i = 0; i < na; i++) {
+      LatticeArc a = {arcs[i].ilabel, arcs[i].olabel, arcs[i].graph_cost, arcs[i].acoustic_cost * inv, arcs[i].dst};
+      lat->arcs[arcs[i].src].push_back(a);
+    }
+    *utterance_id = keys_[u];
+    Sentence(u, sentence);
+    return true;
+  }
+  /// the best path of the utterance LAST returned by GetOutput (DecodeUtteranceLatticeFaster's words / alignment writers)
+  bool GetBestPath(std::vector<int32> *alignment, std::vector<int32> *words, BaseFloat *graph_cost, BaseFloat *acoustic_cost) const {
+    return BestPath(next_out_ - 1, alignment, words, graph_cost, acoustic_cost);
+  }
+  int32 NumSuccess() const { return num_success_; }
+  int32 NumFail() const { return num_fail_; }
+  int32 NumPartial() const { return num_partial_; }
+  double TotLike() const { return tot_like_; }
+  int64_t FrameCount() const { return frame_count_; }
+  const kamd_batch_stats &Stats() const { return stats_; }
   kamd_decoder *DecoderHandle() { return dec_; }
  private:
+  int NextOutput() {
+    if (!finished_) return -1;           // nothing is ready before Finished() here: the set runs as one pass
+    while (next_out_ < static_cast<int>(keys_.size()) && !ok_[next_out_]) next_out_++;
+    if (next_out_ >= static_cast<int>(keys_.size())) return -1;
+    return next_out_++;
+  }
+  bool BestPath(int u, std::vector<int32> *alignment, std::vector<int32> *words, BaseFloat *graph_cost, BaseFloat *acoustic_cost) const {
+    if (u < 0 || u >= static_cast<int>(keys_.size())) return false;
+    int nw = 0, na = 0;
+    if (kamd_batch_decoder_get_output(h_, u, NULL, 0, &nw, NULL, 0, &na, graph_cost, acoustic_cost, NULL) != 0) return false;
+    std::vector<int32> w(std::max(nw, 1)), a(std::max(na, 1));
+    if (kamd_batch_decoder_get_output(h_, u, w.data(), static_cast<int>(w.size()), &nw, a.data(), static_cast<int>(a.size()), &na, graph_cost,
+                                      acoustic_cost, NULL) != 0) return false;
+    words->assign(w.begin(), w.begin() + nw); alignment->assign(a.begin(), a.begin() + na);
+    return true;
+  }
+  void Sentence(int u, std::string *sentence) const {
+    sentence->clear();
+    if (!word_syms_) return;
+    std::vector<int32> ali, words; BaseFloat g, a;
+    if (!BestPath(u, &ali, &words, &g, &a)) return;
+    for (size_t k = 0; k < words.size(); k++) {
+      if (words[k] < 0 || words[k] >= static_cast<int32>(word_syms_->size()) || (*word_syms_)[words[k]].empty())
+        throw KaldiFatalError("Word-id " + std::to_string(words[k]) + " not in symbol table.");
+      if (k) sentence->push_back(' ');
+      sentence->append((*word_syms_)[words[k]]);
+    }
+  }
+  LatticeFasterDecoderConfig config_;
+  const std::vector<std::string> *word_syms_;
+  bool allow_partial_;
+  NnetBatchDecoderOptions opts_;
   kamd_feat *feat_;
   kamd_decoder *dec_;
-  kamd_pipeline *h_;
-  float stage_ms_[4];
+  kamd_batch_decoder *h_;
+  int32 input_dim_, ivector_dim_;
+  std::vector<std::string> keys_;
+  std::vector<float> waves_, feats_, ivectors_;
+  std::vector<int64_t> row_off_;
+  std::vector<char> ok_;
+  int next_out_;
+  bool finished_;
+  int32 num_success_, num_fail_, num_partial_;
+  double tot_like_;
+  int64_t frame_count_;
+  kamd_batch_stats stats_;
 };
+
+// ---- lm/const-arpa-lm.h:211-352 ConstArpaLm + latbin/lattice-lmrescore-const-arpa.cc:76-110
+class ConstArpaLm {
+ public:
+  ConstArpaLm() : lm_(NULL) {}
+  ~ConstArpaLm() { if (lm_) kamd_const_arpa_destroy(lm_); }
+  ConstArpaLm(const ConstArpaLm &) = delete;
+  ConstArpaLm &operator=(const ConstArpaLm &) = delete;
+  /// ReadKaldiObject(lm_rxfilename, &const_arpa): a G.carpa written by arpa-to-const-arpa (either format)
+  void Read(const std::string &rxfilename) { Reset(CheckPtr(kamd_const_arpa_read(rxfilename.c_str()))); }
+  void Write(const std::string &wxfilename) const { Check(kamd_const_arpa_write(lm_, wxfilename.c_str())); }
+  /// BuildConstArpaLm (const-arpa-lm.cc:1064-1073); words_txt empty = the ARPA file holds integer word ids
+  void Build(const std::string &arpa_rxfilename, int32 bos_symbol, int32 eos_symbol, int32 unk_symbol, const std::string &words_txt = "") {
+    Reset(CheckPtr(kamd_const_arpa_build(arpa_rxfilename.c_str(), bos_symbol, eos_symbol, unk_symbol, words_txt.empty() ? NULL : words_txt.c_str())));
+  }
+  /// natural log; hist = the words before `word`, oldest first
+  float GetNgramLogprob(int32 word, const std::vector<int32> &hist) const {
+    return kamd_const_arpa_ngram_logprob(lm_, word, hist.data(), static_cast<int>(hist.size()));
+  }
+  int32 BosSymbol() const { int32 b, e, u, o, n; int64_t sz; Check(kamd_const_arpa_info(lm_, &b, &e, &u, &o, &n, &sz)); return b; }
+  int32 EosSymbol() const { int32 b, e, u, o, n; int64_t sz; Check(kamd_const_arpa_info(lm_, &b, &e, &u, &o, &n, &sz)); return e; }
+  int32 NgramOrder() const { int32 b, e, u, o, n; int64_t sz; Check(kamd_const_arpa_info(lm_, &b, &e, &u, &o, &n, &sz)); return o; }
+  const kamd_const_arpa *Handle() const { return lm_; }
+ private:
+  void Reset(kamd_const_arpa *l) { if (lm_) kamd_const_arpa_destroy(lm_); lm_ = l; }
+  kamd_const_arpa *lm_;
+};
+
+/// The body of lattice-lmrescore-const-arpa's loop for one lattice: ScaleLattice(GraphLatticeScale(1/lm_scale)),
+/// ComposeCompactLatticeDeterministic with ConstArpaLmDeterministicFst, DeterminizeLattice,
+/// ScaleLattice(GraphLatticeScale(lm_scale)).  false = "Empty lattice ... (incompatible LM?)".  lm_scale = 0: copy.
+inline bool LatticeLmrescoreConstArpa(BaseFloat lm_scale, const ConstArpaLm &const_arpa, const CompactLattice &clat, CompactLattice *out) {
+  if (lm_scale == 0.0f) { out->Reset(CheckPtr(kamd_compact_lattice_copy(clat.Handle()))); return true; }
+  int32 ns = 0, na = 0, nl = 0, start = -1, ok = 0;
+  Check(kamd_compact_lattice_sizes(clat.Handle(), &ns, &na, &nl, &start, &ok));
+  std::vector<float> fin(2 * static_cast<size_t>(ns) + 1);
+  std::vector<int32> fb(ns + 1), fl(ns + 1), strings(nl + 1);
+  std::vector<kamd_clat_arc> arcs(na + 1);
+  Check(kamd_compact_lattice_get(clat.Handle(), fin.data(), fb.data(), fl.data(), arcs.data(), strings.data()));
+  kamd_compact_lattice *r = kamd_compact_lattice_lmrescore_const_arpa(ns, start, fin.data(), fb.data(), fl.data(), arcs.data(), na, strings.data(),
+                                                                      const_arpa.Handle(), lm_scale);
+  if (!r) {
+    if (std::string(kamd_last_error()).find("Empty lattice") != std::string::npos) return false;
+    throw KaldiFatalError(kamd_last_error());
+  }
+  out->Reset(r);
+  return true;
+}
 
 // ---- N concurrent SingleUtteranceNnet3Decoder's behind one set of launches (kamd_stream_batch_*): stream s is decoder lane s.
 // With an OnlineIvectorExtractor the streams get online i-vectors as OnlineNnet2FeaturePipeline + DecodableAmNnetLoopedOnline

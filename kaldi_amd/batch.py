@@ -19,11 +19,16 @@ class NnetBatchDecoder:
                  keep_raw_lattices=False, tid_phone=None, sizes=None, nnet_pass_frames=1000000, lattice_pool_bytes=1 << 30,
                  hash_capacity=None, tokens_per_frame=None, search_mode=2):
         featmod = __import__("kaldi_amd.feat", fromlist=["Mfcc"])
-        self.feat = featmod.Fbank(mfcc_opts) if isinstance(mfcc_opts, abi.FbankOpts) else featmod.Mfcc(mfcc_opts)
+        # mfcc_opts = None: no feature stage, the caller hands over feature matrices (load_features), as the
+        # reference's AcceptInput does (nnet-batch-compute.h:665)
+        if mfcc_opts is None:
+            self.feat = None
+        else:
+            self.feat = featmod.Fbank(mfcc_opts) if isinstance(mfcc_opts, abi.FbankOpts) else featmod.Mfcc(mfcc_opts)
         self.model, self.cfg = model, cfg
         self.nnet = decoder.Nnet(model)
         self.graph = hclg if isinstance(hclg, decoder.Graph) else decoder.Graph(hclg)
-        fps = 1000.0 / mfcc_opts.frame.frame_shift_ms
+        fps = 100.0 if mfcc_opts is None else 1000.0 / mfcc_opts.frame.frame_shift_ms
         max_out = int(max_seconds * fps / model.subsampling) + 2
         lanes = resident_lanes or lib().kamd_device_num_cus() * lib().kamd_decoder_lanes_per_cu()
         # every lane must hold the longest utterance: uniform arenas (avg = max)
@@ -39,7 +44,7 @@ class NnetBatchDecoder:
         o.lattice_beam = cfg.lattice_beam
         self.opts = o
         tp = None if tid_phone is None else np.ascontiguousarray(tid_phone, np.int32)
-        self._h = lib().kamd_batch_decoder_create(self.feat._h, self.nnet._h, self.dec._dec, C.byref(o),
+        self._h = lib().kamd_batch_decoder_create(self.feat._h if self.feat is not None else None, self.nnet._h, self.dec._dec, C.byref(o),
                                                   abi.iptr(tp) if tp is not None else None, 0 if tp is None else tp.size - 1)
         if not self._h:
             raise KamdError(lib().kamd_last_error().decode())
@@ -58,6 +63,20 @@ class NnetBatchDecoder:
         check(lib().kamd_batch_decoder_load(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), len(waves)))
         self.n_utts = len(waves)
         self.audio_seconds = float(flat.size) / self.feat.opts.frame.samp_freq
+
+    def load_features(self, feats, ivectors=None):
+        """AcceptInput(utterance_id, input, ivector, ...) for every utterance: feats = list of [T x dim] matrices,
+        ivectors = one row per utterance when the model has an ivector node."""
+        feats = [np.ascontiguousarray(f, np.float32) for f in feats]
+        if not feats:
+            raise KamdError("empty test set")
+        off = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats])]).astype(np.int64)
+        flat = np.ascontiguousarray(np.concatenate(feats, axis=0), np.float32)
+        iv = None if ivectors is None else np.ascontiguousarray(ivectors, np.float32).reshape(len(feats), -1)
+        check(lib().kamd_batch_decoder_load_features(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), flat.shape[1],
+                                                     abi.fptr(iv) if iv is not None else None, 0 if iv is None else iv.shape[1], len(feats)))
+        self.n_utts = len(feats)
+        self.audio_seconds = float(flat.shape[0]) / 100.0
 
     def run(self):
         st = abi.BatchStats()

@@ -59,8 +59,9 @@ struct BatchDecoder {
   int feat_dim = 0, ld_feat = 0, P = 0;
   int n_utts = 0;
   std::vector<int64_t> wave_off, feat_off, out_off;
-  float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL;
-  size_t waves_cap = 0, feats_cap = 0, ll_cap = 0;
+  float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL, *d_iv = NULL;
+  size_t waves_cap = 0, feats_cap = 0, ll_cap = 0, iv_cap = 0;
+  bool from_features = false, have_iv = false;   // the loaded set: feature matrices (+ i-vectors) instead of waveforms
   hipStream_t s_main = NULL;
   hipEvent_t ev[3] = {};
   std::vector<UttOut> out;
@@ -159,7 +160,7 @@ void kamd_batch_opts_default(kamd_batch_opts *o) {
 
 kamd_batch_decoder *kamd_batch_decoder_create(kamd_feat *feat, kamd_nnet *nnet, kamd_decoder *dec, const kamd_batch_opts *opts,
                                               const int32_t *tid_phone, int32_t num_tids) {
-  if (!feat || !nnet || !dec) { kamd::SetError(KAMD_ERR_ARG, "batch decoder: null stage handle"); return NULL; }
+  if (!nnet || !dec) { kamd::SetError(KAMD_ERR_ARG, "batch decoder: null stage handle"); return NULL; }
   if (!kamd::RequireDevice()) return NULL;
   BatchDecoder *b = new BatchDecoder();
   b->feat = feat; b->nnet = nnet; b->dec = dec;
@@ -168,7 +169,13 @@ kamd_batch_decoder *kamd_batch_decoder_create(kamd_feat *feat, kamd_nnet *nnet, 
   if (b->opts.host_threads > 256) b->opts.host_threads = 256;
   if (b->opts.nnet_pass_frames <= 0) b->opts.nnet_pass_frames = 1000000;
   if (tid_phone && num_tids > 0) b->tid_phone.assign(tid_phone, tid_phone + num_tids + 1);
-  b->feat_dim = kamd_feat_dim(feat); b->ld_feat = kamd::RoundUp(b->feat_dim, 16); b->P = kamd_nnet_output_dim(nnet);
+  b->feat_dim = feat ? kamd_feat_dim(feat) : kamd_nnet_input_dim(nnet);
+  if (b->feat_dim != kamd_nnet_input_dim(nnet)) {
+    kamd::SetError(KAMD_ERR_ARG, "batch decoder: features have dim %d, the model's input node %d", b->feat_dim, kamd_nnet_input_dim(nnet));
+    delete b;
+    return NULL;
+  }
+  b->ld_feat = kamd::RoundUp(b->feat_dim, 16); b->P = kamd_nnet_output_dim(nnet);
   bool ok = hipGetDevice(&b->device) == hipSuccess && hipStreamCreateWithFlags(&b->s_main, hipStreamNonBlocking) == hipSuccess;
   for (int i = 0; ok && i < 3; i++) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
   b->copy_streams.resize(b->opts.host_threads, NULL);
@@ -199,14 +206,17 @@ void kamd_batch_decoder_destroy(kamd_batch_decoder *h) {
   if (b->d_waves) (void)hipFree(b->d_waves);
   if (b->d_feats) (void)hipFree(b->d_feats);
   if (b->d_ll) (void)hipFree(b->d_ll);
+  if (b->d_iv) (void)hipFree(b->d_iv);
   delete b;
 }
 
 int kamd_batch_decoder_load(kamd_batch_decoder *h, const float *waves, const int64_t *h_wave_off, int n_utts) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
   if (n_utts <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty test set");
+  if (!b->feat) return kamd::SetError(KAMD_ERR_STATE, "batch decoder was created without a feature stage: use kamd_batch_decoder_load_features");
+  if (kamd_nnet_ivector_dim(b->nnet) > 0) return kamd::SetError(KAMD_ERR_ARG, "the model has an ivector input: use kamd_batch_decoder_load_features");
   for (kamd::UttOut &o : b->out) o.Clear();
-  b->n_utts = n_utts;
+  b->n_utts = 0; b->from_features = false; b->have_iv = false;
   b->wave_off.assign(h_wave_off, h_wave_off + n_utts + 1);
   b->feat_off.assign(n_utts + 1, 0); b->out_off.assign(n_utts + 1, 0);
   for (int u = 0; u < n_utts; u++) {
@@ -222,6 +232,40 @@ int kamd_batch_decoder_load(kamd_batch_decoder *h, const float *waves, const int
   KAMD_HIP(hipMemcpy(b->d_waves, waves + h_wave_off[0], ns * sizeof(float), hipMemcpyHostToDevice));
   if (h_wave_off[0] != 0) for (int u = 0; u <= n_utts; u++) b->wave_off[u] -= h_wave_off[0];
   b->out.resize(n_utts);
+  b->n_utts = n_utts;
+  return KAMD_OK;
+}
+
+int kamd_batch_decoder_load_features(kamd_batch_decoder *h, const float *feats, const int64_t *row_off, int dim, const float *ivectors,
+                                     int ivector_dim, int n_utts) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (n_utts <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty test set");
+  if (dim != b->feat_dim) return kamd::SetError(KAMD_ERR_ARG, "features have dim %d, the model's input node %d", dim, b->feat_dim);
+  const int want_iv = kamd_nnet_ivector_dim(b->nnet);
+  if ((ivectors ? ivector_dim : 0) != want_iv)
+    return kamd::SetError(KAMD_ERR_ARG, "model expects ivector dim %d, got %d", want_iv, ivectors ? ivector_dim : 0);
+  for (kamd::UttOut &o : b->out) o.Clear();
+  b->n_utts = 0;
+  b->feat_off.assign(n_utts + 1, 0); b->out_off.assign(n_utts + 1, 0);
+  for (int u = 0; u < n_utts; u++) {
+    const int64_t T = row_off[u + 1] - row_off[u];
+    if (T <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no feature rows", u);   // "Zero-length utterance", nnet3-latgen-faster-batch.cc:184
+    b->feat_off[u + 1] = b->feat_off[u] + T;
+    b->out_off[u + 1] = b->out_off[u] + kamd_nnet_num_output_frames(b->nnet, static_cast<int>(T));
+  }
+  const size_t rows = static_cast<size_t>(b->feat_off[n_utts]);
+  if (kamd::GrowDev(&b->d_feats, &b->feats_cap, rows * b->ld_feat) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&b->d_ll, &b->ll_cap, static_cast<size_t>(b->out_off[n_utts]) * b->P) != KAMD_OK) return KAMD_ERR_HIP;
+  KAMD_HIP(hipMemset(b->d_feats, 0, rows * b->ld_feat * sizeof(float)));
+  KAMD_HIP(hipMemcpy2D(b->d_feats, b->ld_feat * sizeof(float), feats + static_cast<size_t>(row_off[0]) * dim, dim * sizeof(float),
+                       dim * sizeof(float), rows, hipMemcpyHostToDevice));
+  if (want_iv > 0) {
+    if (kamd::GrowDev(&b->d_iv, &b->iv_cap, static_cast<size_t>(n_utts) * want_iv) != KAMD_OK) return KAMD_ERR_HIP;
+    KAMD_HIP(hipMemcpy(b->d_iv, ivectors, static_cast<size_t>(n_utts) * want_iv * sizeof(float), hipMemcpyHostToDevice));
+  }
+  b->from_features = true; b->have_iv = want_iv > 0;
+  b->out.resize(n_utts);
+  b->n_utts = n_utts;
   return KAMD_OK;
 }
 
@@ -233,7 +277,8 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   const auto t0 = std::chrono::steady_clock::now();
   hipStream_t st = b->s_main;
   KAMD_HIP(hipEventRecord(b->ev[0], st));
-  int rc = kamd_feat_compute_batch_device(b->feat, b->d_waves, b->wave_off.data(), n, b->d_feats, b->feat_off.data(), b->ld_feat, st);
+  int rc = KAMD_OK;
+  if (!b->from_features) rc = kamd_feat_compute_batch_device(b->feat, b->d_waves, b->wave_off.data(), n, b->d_feats, b->feat_off.data(), b->ld_feat, st);
   if (rc != KAMD_OK) return rc;
   KAMD_HIP(hipEventRecord(b->ev[1], st));
   // ---- acoustic model, a few passes of <= nnet_pass_frames input frames
@@ -242,7 +287,8 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   for (int u0 = 0; u0 < n;) {
     int u1 = u0 + 1;
     while (u1 < n && b->feat_off[u1 + 1] - b->feat_off[u0] <= b->opts.nnet_pass_frames) u1++;
-    rc = kamd_nnet_forward_batch_device(b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat, NULL, u1 - u0, b->d_ll,
+    rc = kamd_nnet_forward_batch_device(b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat,
+                                        b->have_iv ? b->d_iv + static_cast<size_t>(u0) * kamd_nnet_ivector_dim(b->nnet) : NULL, u1 - u0, b->d_ll,
                                         b->out_off.data() + u0, b->P, st);
     if (rc != KAMD_OK) return rc;
     flops += kamd_nnet_last_flops(b->nnet);

@@ -756,6 +756,23 @@ int kamd_compact_lattice_scale_graph(kamd_compact_lattice *h, float scale) {
   return KAMD_OK;
 }
 
+// fst::ScaleLattice with a diagonal scale (fstext/lattice-utils-inl.h:250-290; fst::AcousticLatticeScale /
+// GraphLatticeScale): the NnetBatchDecoder hands out lattices whose acoustic costs are already divided by
+// the acoustic scale (nnet-batch-compute.cc:1265-1267)
+int kamd_compact_lattice_scale(kamd_compact_lattice *h, float graph_scale, float acoustic_scale) {
+  CompactLattice *cl = reinterpret_cast<CompactLattice *>(h);
+  if (!cl) return kamd::SetError(KAMD_ERR_ARG, "null compact lattice");
+  for (kamd_clat_arc &a : cl->arcs) { a.graph_cost *= graph_scale; a.acoustic_cost *= acoustic_scale; }
+  for (size_t s = 0; s < cl->fin.size() / 2; s++)
+    if (cl->fin[2 * s] != INFINITY) { cl->fin[2 * s] *= graph_scale; cl->fin[2 * s + 1] *= acoustic_scale; }
+  return KAMD_OK;
+}
+
+kamd_compact_lattice *kamd_compact_lattice_copy(const kamd_compact_lattice *h) {
+  if (!h) { kamd::SetError(KAMD_ERR_ARG, "null compact lattice"); return NULL; }
+  return reinterpret_cast<kamd_compact_lattice *>(new CompactLattice(*reinterpret_cast<const CompactLattice *>(h)));
+}
+
 int kamd_compact_lattice_write(const char *path, int append, const char *key, int binary, const kamd_compact_lattice *h,
                                float acoustic_scale) {
   const CompactLattice *cl = reinterpret_cast<const CompactLattice *>(h);

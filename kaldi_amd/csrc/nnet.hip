@@ -616,6 +616,8 @@ void kamd_nnet_destroy(kamd_nnet *h) {
 }
 
 int kamd_nnet_output_dim(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->L.back().out_dim; }
+int kamd_nnet_input_dim(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->input_dim; }
+int kamd_nnet_ivector_dim(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->L[0].ivector_dim; }
 int kamd_nnet_left_context(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->left; }
 int kamd_nnet_right_context(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->right; }
 int kamd_nnet_frame_subsampling_factor(const kamd_nnet *h) { return reinterpret_cast<const Nnet *>(h)->subsampling; }

@@ -107,6 +107,27 @@ int main(int argc, char **argv) {
                                                      &ali_writer, &words_writer, &clat_writer, &lat_writer, &like);
         printf("wrapper ok=%d like=%.6g\n", ok, like);
       }
+      // lattice-lmrescore-const-arpa on the determinized lattice (G.arpa: integer word ids, <s> = 100001, </s> = 100002)
+      FILE *gf = fopen((dir + "/G.arpa").c_str(), "r");
+      if (gf) {
+        fclose(gf);
+        ConstArpaLm built, lm;
+        built.Build(dir + "/G.arpa", 100001, 100002, -1);
+        built.Write(dir + "/G.carpa");
+        lm.Read(dir + "/G.carpa");
+        DecodableMatrixMapped decodable(id2pdf, ll.data(), T, P);
+        decoder.Decode(&decodable);
+        Lattice raw; CompactLattice clat, rescored, same;
+        decoder.GetRawLattice(&raw);
+        DeterminizeLatticePhonePrunedWrapper(tid_phone, raw, config.lattice_beam, &clat);
+        const bool ok = LatticeLmrescoreConstArpa(1.0f, lm, clat, &rescored) && LatticeLmrescoreConstArpa(0.0f, lm, clat, &same);
+        CompactLatticeWriter in_writer("ark:" + dir + "/carpa_in.ark"), out_writer("ark:" + dir + "/carpa_out.ark");
+        in_writer.Write("utt", clat);
+        out_writer.Write("utt", rescored);
+        std::vector<int32> hist; hist.push_back(100001);
+        printf("carpa ok=%d order=%d bos=%d eos=%d states=%d copy_states=%d p=%.9g\n", ok, lm.NgramOrder(), lm.BosSymbol(), lm.EosSymbol(),
+               rescored.NumStates(), same.NumStates() - clat.NumStates(), lm.GetNgramLogprob(1, hist));
+      }
     }
     // OnlineStreamBatch: two streams (one of them with online i-vectors from the third fixture's extractor, which
     // reads the first 8 cepstra) against the Python mirror driving the same C-ABI (argv[3] model, argv[4] extractor)
@@ -153,18 +174,27 @@ int main(int argc, char **argv) {
       mo.c.use_energy = 0; mo.c.mel.num_bins = 40; mo.c.num_ceps = 40; mo.c.mel.low_freq = 20.0f; mo.c.mel.high_freq = -400.0f;
       kamd_decoder_sizes bs = sz;
       bs.max_lanes = 2;
-      {   // NnetBatchDecoder: both utterances as one batch, offline
-        NnetBatchDecoder bd(config, id2pdf, am, fst, mo, bs);
-        std::vector<std::vector<float> > ws(2);
-        ws[0] = wave; ws[1].assign(wave.begin(), wave.begin() + wave.size() * 2 / 3);
-        bd.Decode(ws);
-        for (int u = 0; u < 2; u++) {
+      {   // NnetBatchDecoder as nnet3-latgen-faster-batch drives it: AcceptInput..., Finished(), GetOutput until false
+        NnetBatchDecoderOptions bo;
+        bo.c.resident_lanes = 2; bo.search_mode = 1;
+        NnetBatchDecoder bd(fst, config, id2pdf, std::vector<int32>(), NULL, true, 2, am, &mo, bs, bo);
+        std::vector<float> w2(wave.begin(), wave.begin() + wave.size() * 2 / 3);
+        bd.AcceptWaveform("utt0", wave);
+        bd.AcceptWaveform("utt1", w2);
+        const int32 n_ok = bd.Finished();
+        std::string key, sentence; CompactLattice clat;
+        int u = 0;
+        while (bd.GetOutput(&key, &clat, &sentence)) {
           std::vector<int32> ali, words; BaseFloat g = 0, a = 0;
-          const bool ok = bd.GetBestPath(u, &ali, &words, &g, &a);
+          const bool ok = bd.GetBestPath(&ali, &words, &g, &a) && n_ok == 2 && key == (u ? "utt1" : "utt0") && clat.NumStates() > 0 && sentence.empty();
           printf("offline utt=%d ok=%d frames=%d cost=%.9g words=", u, ok, static_cast<int>(ali.size()), g + a);
           for (size_t k = 0; k < words.size(); k++) printf("%s%d", k ? "," : "", words[k]);
           printf("\n");
+          u++;
         }
+        bool threw = false;
+        try { Lattice l; bd.GetOutput(&key, &l, &sentence); } catch (const KaldiFatalError &) { threw = true; }
+        if (!threw) throw KaldiFatalError("GetOutput(Lattice) must throw when determinizing");
       }
       OnlineStreamBatch batch(config, id2pdf, am, fst, mo, 2, 4.0f, bs);
       batch.SetIvectorExtractor(extractor.handle(), 20, d.splice_right);

@@ -78,3 +78,48 @@ def test_batch_decoder_without_raw_lattices_or_determinization():
         assert bd.compact_lattice(u) is None
         with pytest.raises(Exception):
             bd.raw_lattice(u)
+
+
+def test_batch_decoder_accepts_feature_matrices_and_ivectors():
+    """AcceptInput as the reference declares it (nnet-batch-compute.h:665): feature matrices in, plus one
+    i-vector per utterance.  Without i-vectors the result equals the waveform-in run; with them, the oracle's
+    DecodableNnetSimple + decoder on the same matrices."""
+    from kaldi_amd import feat
+    g, model, cfg, waves = _setup(n=9, seed=11)
+    mf = feat.Mfcc(abi.mfcc_opts_hires())
+    feats = [mf.ComputeFeatures(w) for w in waves]
+    bw = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=4.0, resident_lanes=3, host_threads=2,
+                                keep_raw_lattices=True)
+    bw.load(waves)
+    bw.run()
+    bf = batch.NnetBatchDecoder(None, model, g, cfg, max_seconds=4.0, resident_lanes=3, host_threads=2, keep_raw_lattices=True)
+    with pytest.raises(Exception):
+        bf.load(waves)                                # no feature stage
+    bf.load_features(feats)
+    st = bf.run()
+    assert st.n_failed == 0
+    for u in range(len(waves)):
+        np.testing.assert_array_equal(bf.loglikes(u), bw.loglikes(u))
+        assert lattices_equal(bf.raw_lattice(u), bw.raw_lattice(u))
+        assert bf.output(u)["words"].tolist() == bw.output(u)["words"].tolist()
+    with pytest.raises(Exception):
+        bf.load_features([f[:, :13] for f in feats])  # wrong feature dim
+    with pytest.raises(Exception):
+        bf.load_features(feats, ivectors=np.zeros((len(feats), 10), np.float32))   # the model has no ivector node
+    # a model with an ivector node
+    mi = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, ivector_dim=10, output_scale=3.0)
+    ivs = np.random.default_rng(4).standard_normal((len(feats), 10)).astype(np.float32)
+    bi = batch.NnetBatchDecoder(None, mi, g, cfg, max_seconds=4.0, resident_lanes=2, host_threads=2, keep_raw_lattices=True,
+                                nnet_pass_frames=700)
+    with pytest.raises(Exception):
+        bi.load_features(feats)                       # missing i-vectors
+    bi.load_features(feats, ivectors=ivs)
+    st = bi.run()
+    assert st.n_failed == 0 and st.nnet_passes > 1
+    for u in range(len(feats)):
+        want = orc.nnet_forward(mi, feats[u], ivector=ivs[u])
+        ll = bi.loglikes(u)
+        np.testing.assert_allclose(ll, want, rtol=2e-4, atol=2e-4)
+        o = orc.Decoder(g, cfg, 2)
+        o.Decode(ll)
+        assert lattices_equal(bi.raw_lattice(u), o.GetRawLattice())

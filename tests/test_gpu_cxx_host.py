@@ -69,6 +69,19 @@ def test_cxx_host_api(tmp_path):
         for a in (info.global_cmvn_stats, info.M, info.sigma_inv, np.asarray([info.prior_offset, info.min_post, info.posterior_scale, info.max_count])):
             vec(f, np.ascontiguousarray(a, np.float64))
         vec(f, f1); vec(f, f2)
+    # an integer-id bigram-less LM over the graph's words for the const-ARPA mirror
+    vocab = int(g.arcs["olabel"].max())
+    lrng = np.random.default_rng(17)
+    lp = -lrng.uniform(0.5, 3.0, vocab + 1)
+    with open(tmp_path / "G.arpa", "w") as f:
+        f.write("\\data\\\nngram 1=%d\nngram 2=%d\n\n\\1-grams:\n" % (vocab + 2, vocab))
+        f.write("-99\t100001\t-0.3\n-1.1\t100002\n")
+        for w in range(1, vocab + 1):
+            f.write("%.4f\t%d\t%.4f\n" % (lp[w], w, -0.1 * (w % 5)))
+        f.write("\n\\2-grams:\n")
+        for w in range(1, vocab + 1):
+            f.write("%.4f\t100001 %d\n" % (lp[w] * 0.5, w))
+        f.write("\n\\end\\\n")
     exe = build_cxx(str(tmp_path))
     out = subprocess.check_output([exe, str(fx), str(tmp_path), str(mfx), str(xfx), "batch"], text=True, stderr=subprocess.DEVNULL).strip().splitlines()
     # OnlineStreamBatch with online i-vectors: the same two streams through the Python mirror
@@ -112,6 +125,19 @@ def test_cxx_host_api(tmp_path):
         assert off_lines[u_] == "offline utt=%d ok=1 frames=%d cost=%.9g words=%s" % (
             u_, len(bp["alignment"]), np.float32(bp["graph_cost"]) + np.float32(bp["acoustic_cost"]), ",".join(str(w) for w in bp["words"]))
     out = [l for l in out if not l.startswith("offline ")]
+    # ConstArpaLm / LatticeLmrescoreConstArpa through the C++ mirror == the Python mirror on the lattice the C++ side wrote
+    from kaldi_amd import constarpa, latbin
+    lm_ = constarpa.ConstArpaLm.read(tmp_path / "G.carpa")
+    (_, lin), = list(latbin.read_lattices("ark:%s" % (tmp_path / "carpa_in.ark")))
+    (_, lout), = list(latbin.read_lattices("ark:%s" % (tmp_path / "carpa_out.ark")))
+    want_l = lm_.rescore(lin, 1.0)
+    crow = [l for l in out if l.startswith("carpa ")][0]
+    assert crow == "carpa ok=1 order=2 bos=100001 eos=100002 states=%d copy_states=0 p=%.9g" % (
+        len(want_l.final), lm_.GetNgramLogprob(1, [100001]))
+    assert latbin.compact_bytes(lout) == latbin.compact_bytes(want_l)
+    bi, bo_ = latbin.best_path(lin), latbin.best_path(lout)
+    assert bo_ is not None and bi is not None
+    out = [l for l in out if not l.startswith("carpa ")]
     ie = ivector.IvectorExtractor(info)
     _, st = ie.extract_online(f1, return_state=True, max_remembered_frames=60.0)
     want_iv = ie.extract_online(f2, state=st)
