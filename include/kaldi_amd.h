@@ -605,6 +605,17 @@ int kamd_ivector_stream_update_device(kamd_ivector_extractor *e, const float *d_
                                       const int64_t *h_feat_row, const int32_t *h_n_base, const int32_t *h_n_done,
                                       const int32_t *h_n_upto, const int32_t *h_record, int n, double *d_records,
                                       float *d_out, void *stream);
+/* The same tick with silence weighting (UpdateStatsUntilFrameWeighted + UpdateStatsForFrames, online2/online-ivector-
+ * feature.cc:191-227, 263-306): frames [h_n_done[i], h_n_upto[i]) are new (their LDA features are computed and stay in
+ * the workspace for later re-weighting); the statistics take item i's entries [h_wl_off[i], h_wl_off[i+1]) of
+ * (h_wl_frame, h_wl_weight) -- kamd_silence_weighting_pop_until's output: increasing frames < h_n_upto[i], non-zero
+ * weights -- each with min_post = GetMinPost(weight) and posteriors scaled by posterior_scale * weight.  An empty
+ * list still runs GetIvector. */
+int kamd_ivector_stream_update_weighted_device(kamd_ivector_extractor *e, const float *d_feats, int ld_feat,
+                                               int64_t ws_rows_total, const int64_t *h_feat_row, const int32_t *h_n_base,
+                                               const int32_t *h_n_done, const int32_t *h_n_upto, const int32_t *h_record,
+                                               const int32_t *h_wl_off, const int32_t *h_wl_frame, const float *h_wl_weight,
+                                               int n, double *d_records, float *d_out, void *stream);
 /* one utterance, host in / host out; returns the number of rows written or < 0 */
 int kamd_ivector_extract_online(kamd_ivector_extractor *e, const float *feats, int num_frames, float *out,
                                 int out_rows_cap);
@@ -675,6 +686,12 @@ int kamd_stream_batch_get_status(const kamd_stream_batch *b, const int32_t *stre
  * (nnet3/nnet-compile-looped.cc:186-207) get that estimate. */
 int kamd_stream_batch_set_ivector_extractor(kamd_stream_batch *b, kamd_ivector_extractor *e, int frames_per_chunk,
                                             int splice_right);
+/* --ivector-silence-weighting.* (online2-wav-nnet3-latgen-faster.cc:214-216, 258-266; OnlineSilenceWeighting):
+ * before every tick's AdvanceDecoding the streams' tracebacks re-decide which frames are silence and the i-vector
+ * statistics are corrected by the difference.  tid_is_silence[tid] = TransitionIdToPhone(tid) is a --silence-phones
+ * phone; silence_weight == 1 = off.  After kamd_stream_batch_set_ivector_extractor, before any stream starts. */
+int kamd_stream_batch_set_silence_weighting(kamd_stream_batch *b, const uint8_t *tid_is_silence, int n_tids,
+                                            float silence_weight, float max_state_duration);
 /* start with the speakers' adaptation states (n x kamd_ivector_state_size() doubles; NULL = fresh) and read a
  * stream's state back after its utterance (before LimitFrames) */
 int kamd_stream_batch_start_adapted(kamd_stream_batch *b, const int32_t *streams, int n, const double *states);
@@ -811,6 +828,32 @@ int kamd_decoder_partial_best_path(kamd_decoder *d, int lane, int use_final_prob
 int kamd_decoder_partial_best_paths(kamd_decoder *d, const int32_t *lanes, int n, int use_final_probs, int32_t *alignments,
                                     int ali_cap, int32_t *ali_len, int32_t *words, int words_cap, int32_t *words_len,
                                     float *graph_cost, float *acoustic_cost);
+/* What OnlineSilenceWeighting::ComputeCurrentTraceback (online2/online-ivector-feature.cc:464-510) reads off the
+ * decoder, for n un-finalized lanes in one launch: the best path without final-probs, NEWEST frame first, one
+ * (transition-id, token) pair per decoded frame; a token is named by its HCLG state (one token per state and
+ * frame).  tids / tokens: [n][cap]; counts[i] = frames on the path, -1 when no token is alive.  Requires a prior
+ * kamd_decoder_sync. */
+int kamd_decoder_frame_tracebacks(kamd_decoder *d, const int32_t *lanes, int n, int32_t *tids, int32_t *tokens,
+                                  int cap, int32_t *counts);
+/* ---- OnlineSilenceWeighting (online2/online-ivector-feature.h:404-535) + the delta-weight queue of
+ * OnlineIvectorFeature (UpdateFrameWeights / UpdateStatsUntilFrameWeighted, .cc:159-174, 263-306), one object per
+ * utterance.  tid_is_silence[tid] = 1 when TransitionIdToPhone(tid) is one of --silence-phones (index 0 unused);
+ * max_state_duration <= 0 turns the duration rule off. */
+typedef struct kamd_silence_weighting kamd_silence_weighting;
+kamd_silence_weighting *kamd_silence_weighting_create(const uint8_t *tid_is_silence, int n_tids, float silence_weight,
+                                                      float max_state_duration, int frame_subsampling_factor);
+void kamd_silence_weighting_destroy(kamd_silence_weighting *w);
+int kamd_silence_weighting_reset(kamd_silence_weighting *w);
+/* ComputeCurrentTraceback: tids[k] / tokens[k] = frame num_frames_decoded - 1 - k (kamd_decoder_frame_tracebacks) */
+int kamd_silence_weighting_compute_traceback(kamd_silence_weighting *w, int num_frames_decoded, const int32_t *tids,
+                                             const int32_t *tokens, int n);
+/* GetDeltaWeights(num_frames_ready_in) + UpdateFrameWeights: the (input frame, delta weight) pairs are queued */
+int kamd_silence_weighting_get_delta_weights(kamd_silence_weighting *w, int num_frames_ready_in, int32_t *n_deltas);
+/* What UpdateStatsUntilFrameWeighted(frame) hands to UpdateStatsForFrames: every queued delta for input frames
+ * <= frame, duplicates summed, zero sums dropped, increasing frame order. */
+int kamd_silence_weighting_pop_until(kamd_silence_weighting *w, int frame, int32_t *frames, float *weights, int cap,
+                                     int32_t *n);
+int kamd_silence_weighting_num_pending(const kamd_silence_weighting *w);
 /* ---- endpointing (online2/online-endpoint.{h,cc}) ----
  * OnlineEndpointRule / OnlineEndpointConfig (online-endpoint.h:113-170); the silence phones are handed to the
  * decoder once (kamd_decoder_set_silence_phones) instead of travelling as a colon-separated string. */

@@ -1113,6 +1113,16 @@ class OnlineStreamBatch {
     Check(kamd_stream_batch_set_ivector_extractor(h_, extractor, frames_per_chunk, splice_right));
     ie_ = extractor;
   }
+  /// OnlineSilenceWeightingConfig (online2/online-ivector-feature.h:404-451) for every stream: tid2phone[tid] =
+  /// TransitionIdToPhone(tid) (index 0 unused), silence_phones as --ivector-silence-weighting.silence-phones lists them.
+  /// After SetIvectorExtractor, before the first Start.  silence_weight == 1 or no phones: off, like Active().
+  void SetSilenceWeighting(const std::vector<int32> &tid2phone, const std::vector<int32> &silence_phones, BaseFloat silence_weight,
+                           BaseFloat max_state_duration = -1.0f) {
+    std::vector<uint8_t> is_sil(tid2phone.size(), 0);
+    for (size_t t = 1; t < tid2phone.size(); t++)
+      is_sil[t] = std::find(silence_phones.begin(), silence_phones.end(), tid2phone[t]) != silence_phones.end();
+    Check(kamd_stream_batch_set_silence_weighting(h_, is_sil.data(), static_cast<int>(is_sil.size()), silence_weight, max_state_duration));
+  }
   /// new utterances; adaptation_states (optional): one state per stream, kamd_ivector_state_size() doubles each
   void Start(const std::vector<int32> &streams, const std::vector<double> *adaptation_states = NULL) {
     if (adaptation_states && ie_) Check(kamd_stream_batch_start_adapted(h_, streams.data(), static_cast<int>(streams.size()), adaptation_states->data()));

@@ -2184,6 +2184,31 @@ __global__ __launch_bounds__(NT, 4) void TracebackBatchKernel(DecDev d, const in
   if (tid == 0) { head[2 * b] = n; head[2 * b + 1] = __float_as_int(fc); }
 }
 
+// What OnlineSilenceWeighting::ComputeCurrentTraceback reads off the decoder (online2/online-ivector-feature.cc:464-510):
+// the best path without final-probs, newest frame first, as one (transition-id, token) pair per decoded frame -- the
+// emitting arc that consumed the frame and the token it left.  A token is named by its HCLG state: a frame holds one
+// token per state and a frame's tokens are only ever deleted, so (frame, state) identifies a token exactly as the
+// reference's pointer comparison does.  out[b][k] = {ilabel, state} for frame (count - 1 - k); head[b] = count or -1.
+__global__ __launch_bounds__(NT, 4) void FrameTraceKernel(DecDev d, const int *lanes, int2 *out, int out_cap, int *head) {
+  __shared__ Sh sh;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const Ctx c = MakeCtx(d, lanes[b]);
+  InitSh(&sh);
+  int2 *o = out + static_cast<size_t>(b) * out_cap;
+  float fc = 0.0f;
+  int n = -1, n_emit = 0;
+  if (!c.st->error && !c.st->finalized) {
+    n = WalkBestPath(d, c, &sh, 0, &fc, [&](int, const Link &L, bool emitting, int) {
+      if (emitting) {
+        if (tid == 0 && n_emit < out_cap) o[n_emit] = make_int2(L.ilabel, c.tok_state[L.src]);
+        n_emit++;
+      }
+      return true;
+    });
+  }
+  if (tid == 0) head[b] = n < 0 ? -1 : n_emit;
+}
+
 // TrailingSilenceLength (online2/online-endpoint.cc:71-102) for a batch of un-finalized lanes: the best path
 // without final-probs is walked back from the newest frame, counting transition-ids of silence phones until
 // the first one that is not (sil_tid[tid] = 1 for transition-ids of silence phones).
@@ -2886,6 +2911,49 @@ int kamd_decoder_partial_best_paths(kamd_decoder *h, const int32_t *lanes, int n
     }
   }
   return rc;
+}
+
+int kamd_decoder_frame_tracebacks(kamd_decoder *h, const int32_t *lanes, int n, int32_t *tids, int32_t *tokens, int cap, int32_t *counts) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0) return KAMD_OK;
+  if (CheckLanes(D, lanes, n) != KAMD_OK || EnsureTaskBuf(D, n) != KAMD_OK) return KAMD_ERR_ARG;
+  int max_frame = 0;
+  for (int i = 0; i < n; i++) {
+    if (D->h_st[lanes[i]].finalized) return kamd::SetError(KAMD_ERR_STATE, "lane %d is finalized", lanes[i]);
+    max_frame = std::max(max_frame, D->h_st[lanes[i]].frame);
+  }
+  const int dcap = max_frame + 1;
+  const size_t pair_bytes = static_cast<size_t>(n) * dcap * sizeof(int2), head_bytes = static_cast<size_t>(n) * 4;
+  if (pair_bytes + head_bytes > D->paths_cap) {
+    const size_t grow = std::max(pair_bytes + head_bytes, 2 * D->paths_cap);
+    if (D->d_paths) (void)hipFree(D->d_paths);
+    D->d_paths = NULL; D->paths_cap = 0;
+    KAMD_HIP(hipMalloc(&D->d_paths, grow));
+    D->paths_cap = grow;
+  }
+  int2 *d_pairs = static_cast<int2 *>(D->d_paths);
+  int *d_head = reinterpret_cast<int *>(static_cast<char *>(D->d_paths) + pair_bytes);
+  hipStream_t st = D->last_stream;
+  KAMD_HIP(hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(kamd::FrameTraceKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes, d_pairs, dcap, d_head);
+  std::vector<int> head(n);
+  std::vector<int2> pairs(static_cast<size_t>(n) * dcap);
+  KAMD_HIP(hipMemcpyAsync(head.data(), d_head, head_bytes, hipMemcpyDeviceToHost, st));
+  KAMD_HIP(hipMemcpyAsync(pairs.data(), d_pairs, pair_bytes, hipMemcpyDeviceToHost, st));
+  if (hipStreamSynchronize(st) != hipSuccess) return kamd::SetError(KAMD_ERR_HIP, "traceback kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  for (int i = 0; i < n; i++) {
+    counts[i] = head[i];
+    if (head[i] > dcap)
+      return kamd::SetError(KAMD_ERR_STATE, "lane %d advanced since the last kamd_decoder_sync (%d frames on the path, %d known): sync first", lanes[i],
+                            head[i], dcap);
+    if (head[i] > cap) return kamd::SetError(KAMD_ERR_ARG, "lane %d: %d frames decoded, room for %d", lanes[i], head[i], cap);
+    for (int k = 0; k < head[i]; k++) {
+      tids[static_cast<size_t>(i) * cap + k] = pairs[static_cast<size_t>(i) * dcap + k].x;
+      tokens[static_cast<size_t>(i) * cap + k] = pairs[static_cast<size_t>(i) * dcap + k].y;
+    }
+  }
+  return KAMD_OK;
 }
 
 int kamd_decoder_get_phase_cycles(kamd_decoder *h, int lane, uint64_t cycles[16]) {

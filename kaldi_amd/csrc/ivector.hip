@@ -56,7 +56,10 @@ struct IvUtt {                    // one per utterance (or stream) of a call
   int stats_first, stats_end;     // mode 1: frames that enter the statistics in this call
   int mode;                       // 0: ivector-extract-online2 stepping (step i = frames (i-1)P+1 .. iP, CG at every step, a row per step)
                                   // 1: streaming GetFrame: steps of P frames from stats_first, CG after the last one only, one row
+                                  // 2: streaming GetFrame with silence weighting (UpdateStatsUntilFrameWeighted): the statistics take the
+                                  //    (frame, delta weight) entries [wl_off, wl_off + wl_n) of the call's list, P entries per step
   int n_steps;
+  int wl_off, wl_n;
   int state_idx;                  // record in the state arrays, or -1
 };
 
@@ -72,6 +75,8 @@ struct IvBatch {
   // 2 x (feat_dim+1) speaker CMVN stats | packed quadratic term | linear term | num_frames [| current estimate]
   const double *state_in; double *state_out; int state_size;
   int x_off;                     // offset of the current estimate inside a record (streaming), or -1
+  // mode 2: frame index within the stream, delta weight, GetMinPost(weight) and its log, per list entry
+  const int *wl_frame; const float *wl_weight, *wl_minpost, *wl_logminpost;
 };
 
 // ---------------------------------------------------------------- running sums
@@ -176,8 +181,16 @@ __global__ __launch_bounds__(256) void PostKernel(IvDev d, IvBatch b) {
   extern __shared__ float plds[];              // per wave: x[D], p[G]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const IvUtt ut = b.utt[blockIdx.y];
-  const int frame = ut.proc_first + blockIdx.x * 4 + w;
-  if (frame >= ut.proc_end) return;
+  int frame = ut.proc_first + blockIdx.x * 4 + w;
+  // posterior of one frame at weight 1, or (mode 2) of one list entry at its delta weight: min_post becomes
+  // GetMinPost(weight), the posteriors are scaled by posterior_scale * weight (online-ivector-feature.cc:176-227)
+  float min_post = d.min_post, log_min_post = d.log_min_post, weight = 1.0f;
+  if (ut.mode == 2) {
+    const int entry = blockIdx.x * 4 + w;
+    if (entry >= ut.wl_n) return;
+    frame = b.wl_frame[ut.wl_off + entry]; weight = b.wl_weight[ut.wl_off + entry];
+    min_post = b.wl_minpost[ut.wl_off + entry]; log_min_post = b.wl_logminpost[ut.wl_off + entry];
+  } else if (frame >= ut.proc_end) return;
   const int64_t row = ut.ws_row + frame;
   float *x = plds + w * (d.D + d.G), *p = x + d.D;
   for (int k = lane; k < d.D; k += 64) x[k] = b.norm_lda[row * d.D + k];
@@ -192,11 +205,11 @@ __global__ __launch_bounds__(256) void PostKernel(IvDev d, IvBatch b) {
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
   // VectorToPosteriorEntry (hmm/posterior.cc:440-508)
-  const float cutoff = mx + d.log_min_post;
+  const float cutoff = mx + log_min_post;
   int n_cand = 0;
   for (int g = lane; g < d.G; g += 64) {
     const float like = p[g];
-    const bool in = d.min_post == 0.0f || like > cutoff;
+    const bool in = min_post == 0.0f || like > cutoff;
     p[g] = in ? expf(like - mx) : -1.0f;
     n_cand += in;
   }
@@ -226,7 +239,7 @@ __global__ __launch_bounds__(256) void PostKernel(IvDev d, IvBatch b) {
   float tot = 0;
 #pragma unroll
   for (int j = 0; j < IV_MAX_NG; j++) if (j < n) tot += sel_p[j];
-  const float cut2 = d.min_post * tot;
+  const float cut2 = min_post * tot;
 #pragma unroll
   for (int j = IV_MAX_NG - 1; j >= 1; j--)      // pop from the back while below min_post of the kept mass
     if (j == n - 1 && sel_p[j] < cut2) { tot -= sel_p[j]; n--; }
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(256) void PostKernel(IvDev d, IvBatch b) {
     float wv = 0.f; int gv = -1;
 #pragma unroll
     for (int j = 0; j < IV_MAX_NG; j++)
-      if (j == lane && j < n) { wv = sel_p[j] * inv; wv *= d.post_scale * 1.0f; gv = sel_g[j]; }
+      if (j == lane && j < n) { wv = sel_p[j] * inv; wv *= d.post_scale * weight; gv = sel_g[j]; }
     b.post_g[row * d.ng + lane] = gv;
     b.post_w[row * d.ng + lane] = wv;
   }
@@ -260,22 +273,31 @@ __global__ __launch_bounds__(256) void StepStatsKernel(IvDev d, IvBatch b) {
   const int64_t r0 = ut.ws_row;
   if (i >= ut.n_steps) return;
   const int I = d.I, Q = d.Q, D = d.D;
-  int f0, f1;
-  if (ut.mode == 0) { f0 = i == 0 ? 0 : (i - 1) * d.period + 1; f1 = i * d.period; }
-  else { f0 = ut.stats_first + i * d.period; f1 = min(ut.stats_end, f0 + d.period) - 1; }
-  const int nf = f1 - f0 + 1;
+  // the step's frames: a contiguous range, or (mode 2) `period` entries of the weighted list
+  int f0 = 0, nf;
+  const int *wl = NULL;
+  if (ut.mode == 0) { f0 = i == 0 ? 0 : (i - 1) * d.period + 1; nf = i * d.period - f0 + 1; }
+  else if (ut.mode == 1) { f0 = ut.stats_first + i * d.period; nf = min(ut.stats_end, f0 + d.period) - f0; }
+  else { wl = b.wl_frame + ut.wl_off + i * d.period; nf = max(0, min(ut.wl_n - i * d.period, d.period)); }
   const int cap = d.period * d.ng;
   double *xf = ss, *pw = xf + d.period * D;
   int *pg = reinterpret_cast<int *>(pw + cap), *pt = pg + cap;
   __shared__ int s_wcnt[4];
   __shared__ double s_half[IV_MAX_DIM];
-  for (int k = tid; k < nf * D; k += 256) xf[k] = static_cast<double>(b.raw_lda[(r0 + f0) * D + k]);
+  for (int k = tid; k < nf * D; k += 256) {
+    const int t = k / D, c = k - t * D;
+    xf[k] = static_cast<double>(b.raw_lda[(r0 + (wl ? wl[t] : f0 + t)) * D + c]);
+  }
   // compact the step's (gaussian, weight, frame) triples, in frame order
   int n_pairs = 0;
   for (int base = 0; base < nf * d.ng; base += 256) {
     const int e = base + tid;
     int g = -1; float wv = 0.f;
-    if (e < nf * d.ng) { g = b.post_g[(r0 + f0) * d.ng + e]; wv = b.post_w[(r0 + f0) * d.ng + e]; }
+    if (e < nf * d.ng) {
+      const int t = e / d.ng, sl = e - t * d.ng;
+      const int64_t pr = (r0 + (wl ? wl[t] : f0 + t)) * d.ng + sl;
+      g = b.post_g[pr]; wv = b.post_w[pr];
+    }
     const unsigned long long m = __ballot(g >= 0);
     if (lane == 0) s_wcnt[wave] = __popcll(m);
     __syncthreads();
@@ -533,6 +555,7 @@ struct IvExtractor {
   double *d_dquad = NULL, *d_dlin = NULL, *d_dtotw = NULL; size_t dq_cap = 0, dl_cap = 0, dt_cap = 0;
   double *d_state_in = NULL, *d_state_out = NULL; size_t si_cap = 0, so_cap = 0;
   IvUtt *d_utt = NULL; size_t utt_cap = 0;
+  int *d_wlf = NULL; float *d_wlw = NULL; size_t wlf_cap = 0, wlw_cap = 0;   // weighted list: frames | weight, min_post, log(min_post)
   int64_t last_rows = 0;
 };
 
@@ -630,7 +653,7 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
 void kamd_ivector_extractor_destroy(kamd_ivector_extractor *h) {
   IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
   if (!e) return;
-  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_S, e->d_nl, e->d_rl, e->d_pg, e->d_pw, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw, e->d_state_in, e->d_state_out, e->d_utt};
+  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_S, e->d_nl, e->d_rl, e->d_pg, e->d_pw, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw, e->d_state_in, e->d_state_out, e->d_utt, e->d_wlf, e->d_wlw};
   for (void *p : ps) if (p) (void)hipFree(p);
   delete e;
 }
@@ -655,9 +678,26 @@ int kamd_ivector_extract_online_device(kamd_ivector_extractor *h, const float *d
 // workspaces for ws_rows feature rows and inc_rows statistic increments; uploads the descriptors; launches
 static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std::vector<kamd::IvUtt> &utts, int64_t ws_rows,
                     int64_t inc_rows, float *d_out, const double *d_state_in, double *d_state_out, int state_size, int x_off,
-                    hipStream_t st) {
+                    hipStream_t st, const std::vector<int> *wl_frame = NULL, const std::vector<float> *wl_weight = NULL) {
   const kamd::IvDev &v = e->dev;
   const int n = static_cast<int>(utts.size());
+  const size_t n_wl = wl_frame ? wl_frame->size() : 0;
+  if (n_wl > 0) {
+    // OnlineIvectorFeature::GetMinPost (online-ivector-feature.cc:176-188), in BaseFloat like the reference
+    std::vector<float> wx(3 * n_wl);
+    for (size_t k = 0; k < n_wl; k++) {
+      const float w = (*wl_weight)[k], aw = fabsf(w);
+      float mp = v.min_post;
+      if (aw == 0.0f) mp = 0.99f;
+      else { mp /= aw; if (mp > 0.99f) mp = 0.99f; }
+      wx[k] = w; wx[n_wl + k] = mp; wx[2 * n_wl + k] = mp > 0 ? logf(mp) : -INFINITY;
+    }
+    if (kamd::GrowDev(&e->d_wlf, &e->wlf_cap, n_wl) != KAMD_OK) return KAMD_ERR_HIP;
+    if (kamd::GrowDev(&e->d_wlw, &e->wlw_cap, 3 * n_wl) != KAMD_OK) return KAMD_ERR_HIP;
+    KAMD_HIP(hipMemcpyAsync(e->d_wlf, wl_frame->data(), n_wl * sizeof(int), hipMemcpyHostToDevice, st));
+    KAMD_HIP(hipMemcpyAsync(e->d_wlw, wx.data(), 3 * n_wl * sizeof(float), hipMemcpyHostToDevice, st));
+    KAMD_HIP(hipStreamSynchronize(st));
+  }
   if (kamd::GrowDev(&e->d_S, &e->S_cap, static_cast<size_t>(ws_rows) * v.feat_dim) != KAMD_OK) return KAMD_ERR_HIP;
   size_t cap2 = e->lda_cap;
   if (kamd::GrowDev(&e->d_nl, &e->lda_cap, static_cast<size_t>(ws_rows) * v.D) != KAMD_OK) return KAMD_ERR_HIP;
@@ -671,21 +711,25 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
   if (kamd::GrowDev(&e->d_utt, &e->utt_cap, static_cast<size_t>(n)) != KAMD_OK) return KAMD_ERR_HIP;
   KAMD_HIP(hipMemcpyAsync(e->d_utt, utts.data(), n * sizeof(kamd::IvUtt), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));          // the descriptors are pageable host memory
-  int max_T = 0, max_proc = 0, max_steps = 0;
+  int max_T = 0, max_proc = 0, max_steps = 0, max_post = 0;
   for (const kamd::IvUtt &u : utts) {
     max_T = std::max(max_T, u.T); max_proc = std::max(max_proc, u.proc_end - u.proc_first); max_steps = std::max(max_steps, u.n_steps);
+    max_post = std::max(max_post, u.mode == 2 ? u.wl_n : u.proc_end - u.proc_first);
   }
   kamd::IvBatch b;
   b.feats = d_feats; b.ld = ld_feat; b.utt = e->d_utt;
   b.S = e->d_S; b.norm_lda = e->d_nl; b.raw_lda = e->d_rl; b.post_g = e->d_pg; b.post_w = e->d_pw; b.out = d_out;
   b.dquad = e->d_dquad; b.dlin = e->d_dlin; b.dtotw = e->d_dtotw;
   b.state_in = d_state_in; b.state_out = d_state_out; b.state_size = state_size; b.x_off = x_off;
+  b.wl_frame = e->d_wlf; b.wl_weight = e->d_wlw; b.wl_minpost = e->d_wlw + n_wl; b.wl_logminpost = e->d_wlw + 2 * n_wl;
   hipLaunchKernelGGL(kamd::PrefixKernel, dim3(n), dim3(256), 0, st, v, b);
   if (max_proc > 0) {
     const size_t lds_front = static_cast<size_t>(2) * (kamd::IV_FT + v.L + v.R) * v.feat_dim * sizeof(float);
     hipLaunchKernelGGL(kamd::FrontKernel, dim3(kamd::CeilDiv(max_proc, kamd::IV_FT), n), dim3(256), lds_front, st, v, b);
+  }
+  if (max_post > 0) {
     const size_t lds_post = static_cast<size_t>(4) * (v.D + v.G) * sizeof(float);
-    hipLaunchKernelGGL(kamd::PostKernel, dim3(kamd::CeilDiv(max_proc, 4), n), dim3(256), lds_post, st, v, b);
+    hipLaunchKernelGGL(kamd::PostKernel, dim3(kamd::CeilDiv(max_post, 4), n), dim3(256), lds_post, st, v, b);
   }
   if (max_steps > 0) {
     const int pair_cap = v.period * v.ng;
@@ -715,7 +759,7 @@ int kamd_ivector_extract_online_adapt_device(kamd_ivector_extractor *h, const fl
       return kamd::SetError(KAMD_ERR_ARG, "utterance %d: output rows too few for %lld frames", u, static_cast<long long>(T));
     kamd::IvUtt &x = utts[u];
     x.feat_row = h_row_off[u]; x.ws_row = h_row_off[u] - h_row_off[0]; x.out_row = h_out_row_off[u]; x.inc_row = h_out_row_off[u] - h_out_row_off[0];
-    x.T = static_cast<int>(T); x.proc_first = 0; x.proc_end = x.T; x.stats_first = 0; x.stats_end = x.T; x.mode = 0; x.n_steps = n_iv;
+    x.T = static_cast<int>(T); x.proc_first = 0; x.proc_end = x.T; x.stats_first = 0; x.stats_end = x.T; x.mode = 0; x.n_steps = n_iv; x.wl_off = 0; x.wl_n = 0;
     x.state_idx = (h_state_in || h_state_out) ? u : -1;
   }
   const int64_t rows = h_row_off[n_utts] - h_row_off[0], iv_rows = h_out_row_off[n_utts] - h_out_row_off[0];
@@ -787,10 +831,49 @@ int kamd_ivector_stream_update_device(kamd_ivector_extractor *h, const float *d_
     x.feat_row = h_feat_row[i]; x.ws_row = h_feat_row[i]; x.out_row = i; x.inc_row = inc;
     x.T = h_n_base[i]; x.proc_first = h_n_done[i]; x.proc_end = h_n_upto[i]; x.stats_first = h_n_done[i]; x.stats_end = h_n_upto[i];
     x.mode = 1; x.n_steps = (h_n_upto[i] - h_n_done[i] + v.period - 1) / v.period; x.state_idx = h_record[i];
+    x.wl_off = 0; x.wl_n = 0;
     inc += x.n_steps;
   }
   const int RS = kamd_ivector_stream_record_size(h);
   return RunBatch(e, d_feats, ld_feat, utts, ws_rows_total, inc, d_out, d_records, d_records, RS, RS - v.I, st);
+}
+
+// The same tick with silence weighting (UpdateStatsUntilFrameWeighted + UpdateStatsForFrames, online2/online-ivector-
+// feature.cc:191-227, 263-306): frames [h_n_done[i], h_n_upto[i]) are new (their LDA features are computed and stay
+// in the workspace rows for later re-weighting); the statistics take item i's entries [h_wl_off[i], h_wl_off[i+1]) of
+// (h_wl_frame, h_wl_weight): frames < h_n_upto[i] in increasing order, no duplicates, no zero weights (the caller has
+// applied MergePairVectorSumming), each with its own min_post = GetMinPost(weight) and its posteriors scaled by
+// posterior_scale * weight (negative when a frame is re-classified as silence).  An empty list still runs GetIvector.
+int kamd_ivector_stream_update_weighted_device(kamd_ivector_extractor *h, const float *d_feats, int ld_feat, int64_t ws_rows_total,
+                                               const int64_t *h_feat_row, const int32_t *h_n_base, const int32_t *h_n_done,
+                                               const int32_t *h_n_upto, const int32_t *h_record, const int32_t *h_wl_off,
+                                               const int32_t *h_wl_frame, const float *h_wl_weight, int n, double *d_records,
+                                               float *d_out, void *stream) {
+  IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n <= 0) return KAMD_OK;
+  const kamd::IvDev &v = e->dev;
+  if (ld_feat < v.feat_dim) return kamd::SetError(KAMD_ERR_ARG, "ld_feat %d < feature dim %d", ld_feat, v.feat_dim);
+  std::vector<kamd::IvUtt> utts(n);
+  std::vector<int> wlf(h_wl_frame, h_wl_frame + h_wl_off[n]);
+  std::vector<float> wlw(h_wl_weight, h_wl_weight + h_wl_off[n]);
+  int64_t inc = 0;
+  for (int i = 0; i < n; i++) {
+    if (h_n_done[i] < 0 || h_n_upto[i] < h_n_done[i] || h_n_upto[i] > h_n_base[i] || h_feat_row[i] < 0 ||
+        h_feat_row[i] + h_n_base[i] > ws_rows_total || h_wl_off[i + 1] < h_wl_off[i])
+      return kamd::SetError(KAMD_ERR_ARG, "stream item %d: bad frame ranges", i);
+    for (int k = h_wl_off[i]; k < h_wl_off[i + 1]; k++)
+      if (wlf[k] < 0 || wlf[k] >= h_n_upto[i] || (k > h_wl_off[i] && wlf[k] <= wlf[k - 1]) || wlw[k] == 0.0f)
+        return kamd::SetError(KAMD_ERR_ARG, "stream item %d: weighted frames must be increasing, below %d and of non-zero weight", i, h_n_upto[i]);
+    kamd::IvUtt &x = utts[i];
+    x.feat_row = h_feat_row[i]; x.ws_row = h_feat_row[i]; x.out_row = i; x.inc_row = inc;
+    x.T = h_n_base[i]; x.proc_first = h_n_done[i]; x.proc_end = h_n_upto[i]; x.stats_first = 0; x.stats_end = 0;
+    x.mode = 2; x.wl_off = h_wl_off[i]; x.wl_n = h_wl_off[i + 1] - h_wl_off[i];
+    x.n_steps = std::max(1, (x.wl_n + v.period - 1) / v.period); x.state_idx = h_record[i];
+    inc += x.n_steps;
+  }
+  const int RS = kamd_ivector_stream_record_size(h);
+  return RunBatch(e, d_feats, ld_feat, utts, ws_rows_total, inc, d_out, d_records, d_records, RS, RS - v.I, st, &wlf, &wlw);
 }
 
 // OnlineIvectorExtractorAdaptationState::LimitFrames (online2/online-ivector-feature.cc:96-117) with

@@ -196,6 +196,8 @@ struct StreamBatch {
   float *d_est = NULL;           // [S][iv_dim]: the tick's estimates (row = position in the update call)
   int *d_assign = NULL;          // 3 x S ints
   std::vector<int> chunks_done, iv_done, slots_assigned;
+  // OnlineSilenceWeighting, one per stream (kamd_stream_batch_set_silence_weighting); empty = off
+  std::vector<kamd_silence_weighting *> sw;
   int S = 0, dim = 0, ld = 0, P = 0, max_frames = 0;
   int64_t max_samples = 0;
   float *d_wave = NULL, *d_frames = NULL, *d_ll = NULL;
@@ -243,6 +245,7 @@ void kamd_stream_batch_destroy(kamd_stream_batch *h) {
   if (b->d_slots) (void)hipFree(b->d_slots);
   if (b->d_est) (void)hipFree(b->d_est);
   if (b->d_assign) (void)hipFree(b->d_assign);
+  for (kamd_silence_weighting *w : b->sw) kamd_silence_weighting_destroy(w);
   delete b;
 }
 
@@ -297,6 +300,28 @@ int kamd_stream_batch_get_ivector_slots(kamd_stream_batch *h, int stream, float 
   return KAMD_OK;
 }
 
+// --ivector-silence-weighting.* (online2-wav-nnet3-latgen-faster.cc:214-216, 258-266): before every AdvanceDecoding
+// the streams' current tracebacks re-decide which frames count as silence, and the i-vector statistics are
+// corrected by the difference.  silence_weight == 1 (or no silence transition-id) is the reference's "not Active".
+int kamd_stream_batch_set_silence_weighting(kamd_stream_batch *h, const uint8_t *tid_is_silence, int n_tids, float silence_weight,
+                                            float max_state_duration) {
+  StreamBatch *b = reinterpret_cast<StreamBatch *>(h);
+  for (int s = 0; s < b->S; s++) if (b->live[s]) return kamd::SetError(KAMD_ERR_STATE, "set the silence weighting before any stream is started");
+  if (!b->ie) return kamd::SetError(KAMD_ERR_STATE, "silence weighting acts on the i-vector statistics: set the i-vector extractor first");
+  for (kamd_silence_weighting *w : b->sw) kamd_silence_weighting_destroy(w);
+  b->sw.clear();
+  bool any = false;
+  for (int t = 0; tid_is_silence && t < n_tids; t++) any = any || tid_is_silence[t];
+  if (!any || silence_weight == 1.0f) return KAMD_OK;
+  for (int s = 0; s < b->S; s++) {
+    kamd_silence_weighting *w = kamd_silence_weighting_create(tid_is_silence, n_tids, silence_weight, max_state_duration,
+                                                              kamd_nnet_frame_subsampling_factor(b->nnet));
+    if (!w) return KAMD_ERR_ARG;
+    b->sw.push_back(w);
+  }
+  return KAMD_OK;
+}
+
 // GetAdaptationState after the utterance (online2-wav-nnet3-latgen-faster.cc:284): the i-vector statistics as they
 // are plus the speaker CMVN statistics advanced by every frame of this utterance; LimitFrames is the caller's
 // (kamd_ivector_state_limit_frames)
@@ -329,6 +354,7 @@ int kamd_stream_batch_start(kamd_stream_batch *h, const int32_t *streams, int n)
       KAMD_HIP(hipMemcpy(b->d_rec + static_cast<size_t>(s) * b->rec_size, rec.data(), b->rec_size * sizeof(double), hipMemcpyHostToDevice));
       b->chunks_done[s] = 0; b->iv_done[s] = 0; b->slots_assigned[s] = 0;
     }
+    if (!b->sw.empty()) kamd_silence_weighting_reset(b->sw[s]);    // "initialize a new copy of this object for each new utterance"
     b->live[s] = 1;
   }
   int rc = kamd_decoder_init(b->dec, streams, n, NULL);
@@ -456,6 +482,33 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
   const int sub = kamd_nnet_frame_subsampling_factor(b->nnet);
   const int L = kamd_nnet_left_context(b->nnet), R = kamd_nnet_right_context(b->nnet);
   std::vector<int> ready_out(n, 0);
+  if (b->ie && !b->sw.empty()) {
+    // silence_weighting.ComputeCurrentTraceback(decoder.Decoder()); GetDeltaWeights(feature_pipeline.NumFramesReady());
+    // IvectorFeature()->UpdateFrameWeights(delta_weights) -- one traceback launch for the tick's streams
+    std::vector<int32_t> tl;
+    int longest = 0;
+    for (int i = 0; i < n; i++)
+      if (b->decoded[streams[i]] > 0) { tl.push_back(streams[i]); longest = std::max(longest, b->decoded[streams[i]]); }
+    std::vector<int32_t> tids(tl.size() * static_cast<size_t>(longest)), toks(tids.size()), cnt(tl.size());
+    if (!tl.empty()) {
+      int rc = kamd_decoder_frame_tracebacks(b->dec, tl.data(), static_cast<int>(tl.size()), tids.data(), toks.data(), longest, cnt.data());
+      if (rc != KAMD_OK) return rc;
+    }
+    size_t k = 0;
+    for (int i = 0; i < n; i++) {
+      const int s = streams[i], F = b->n_frames[s];
+      if (b->decoded[s] > 0) {
+        if (cnt[k] != b->decoded[s])
+          return kamd::SetError(KAMD_ERR_STATE, "stream %d: best path covers %d of %d decoded frames", s, cnt[k], b->decoded[s]);
+        int rc = kamd_silence_weighting_compute_traceback(b->sw[s], b->decoded[s], tids.data() + k * longest, toks.data() + k * longest, cnt[k]);
+        if (rc != KAMD_OK) return rc;
+        k++;
+      }
+      const int iv_ready = b->finished[s] ? F : std::max(0, F - b->splice_right);
+      int rc = kamd_silence_weighting_get_delta_weights(b->sw[s], iv_ready, NULL);
+      if (rc != KAMD_OK) return rc;
+    }
+  }
   if (b->ie) {
     std::vector<int64_t> u_row; std::vector<int32_t> u_base, u_done, u_upto, u_rec;
     std::vector<int> a_src, a_dst, a_cnt;
@@ -489,10 +542,26 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
       }
       pend.push_back(pd);
     }
-    if (!u_row.empty()) {
+    if (!u_row.empty() && b->sw.empty()) {
       int rc = kamd_ivector_stream_update_device(b->ie, b->d_frames, b->ld, static_cast<int64_t>(b->S) * b->max_frames, u_row.data(),
                                                  u_base.data(), u_done.data(), u_upto.data(), u_rec.data(), static_cast<int>(u_row.size()),
                                                  b->d_rec, b->d_est, st);
+      if (rc != KAMD_OK) return rc;
+    } else if (!u_row.empty()) {
+      // UpdateStatsUntilFrameWeighted(upto - 1): the queued deltas up to that frame enter the statistics
+      std::vector<int32_t> wl_off(1, 0), wl_frame; std::vector<float> wl_weight;
+      for (size_t j = 0; j < u_row.size(); j++) {
+        const size_t at = wl_frame.size();
+        wl_frame.resize(at + u_upto[j]); wl_weight.resize(at + u_upto[j]);
+        int32_t got = 0;
+        int rc = kamd_silence_weighting_pop_until(b->sw[u_rec[j]], u_upto[j] - 1, wl_frame.data() + at, wl_weight.data() + at, u_upto[j], &got);
+        if (rc != KAMD_OK) return rc;
+        wl_frame.resize(at + got); wl_weight.resize(at + got);
+        wl_off.push_back(static_cast<int32_t>(wl_frame.size()));
+      }
+      int rc = kamd_ivector_stream_update_weighted_device(b->ie, b->d_frames, b->ld, static_cast<int64_t>(b->S) * b->max_frames, u_row.data(),
+                                                          u_base.data(), u_done.data(), u_upto.data(), u_rec.data(), wl_off.data(),
+                                                          wl_frame.data(), wl_weight.data(), static_cast<int>(u_row.size()), b->d_rec, b->d_est, st);
       if (rc != KAMD_OK) return rc;
     }
     if (!a_src.empty()) {

@@ -354,6 +354,19 @@ def partial_best_paths(dec, lanes, use_final_probs=False):
                                         acoustic_cost=float(a[i])) for i in range(ln.size)]
 
 
+def frame_tracebacks(dec, lanes):
+    """What OnlineSilenceWeighting::ComputeCurrentTraceback reads off the decoder, for several un-finalized lanes in
+    one launch -> per lane (tids, tokens), newest frame first (None: no token alive)"""
+    ln = np.ascontiguousarray(lanes, np.int32)
+    if ln.size == 0:
+        return []
+    cap = max(1, max(lib().kamd_decoder_num_frames_decoded(dec, int(l)) for l in ln))
+    tids, toks = np.zeros((ln.size, cap), np.int32), np.zeros((ln.size, cap), np.int32)
+    cnt = np.zeros(ln.size, np.int32)
+    check(lib().kamd_decoder_frame_tracebacks(dec, abi.iptr(ln), ln.size, abi.iptr(tids), abi.iptr(toks), cap, abi.iptr(cnt)))
+    return [None if cnt[i] < 0 else (tids[i, :cnt[i]].copy(), toks[i, :cnt[i]].copy()) for i in range(ln.size)]
+
+
 def endpoint_config_default():
     """OnlineEndpointConfig() (online2/online-endpoint.h:149-154)"""
     c = abi.EndpointConfig()

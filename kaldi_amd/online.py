@@ -206,6 +206,78 @@ def trailing_silence_length(best_path, tid2phone, silence_phones):
     return n
 
 
+class OnlineSilenceWeightingConfig:
+    """online2/online-ivector-feature.h:404-451; registered with the prefix "ivector-silence-weighting"
+    (online-nnet2-feature-pipeline.h:89-110)."""
+
+    def __init__(self, silence_phones_str="", silence_weight=1.0, max_state_duration=-1.0):
+        self.silence_phones_str, self.silence_weight, self.max_state_duration = silence_phones_str, silence_weight, max_state_duration
+
+    def Active(self):
+        return bool(self.silence_phones_str) and self.silence_weight != 1.0
+
+    def silence_phones(self):
+        """SplitStringToIntegers(silence_phones_str, ":,", false)"""
+        return [int(x) for x in self.silence_phones_str.replace(",", ":").split(":") if x != ""]
+
+    def tid_is_silence(self, tid2phone):
+        sil = np.asarray(self.silence_phones(), np.int64)
+        return np.ascontiguousarray(np.isin(np.asarray(tid2phone), sil), np.uint8)
+
+    @staticmethod
+    def register(po, prefix="ivector-silence-weighting"):
+        po.register(prefix + ".silence-phones", str, "", "(RE weighting in iVector estimation for online decoding) List of integer ids of "
+                    "silence phones, separated by colons (or commas).  Data that (according to the traceback of the decoder) corresponds to "
+                    "these phones will be downweighted by --silence-weight.")
+        po.register(prefix + ".silence-weight", float, 1.0, "(RE weighting in iVector estimation for online decoding) Weighting factor for "
+                    "frames that the decoder trace-back identifies as silence; only relevant if the --silence-phones option is set.")
+        po.register(prefix + ".max-state-duration", float, -1.0, "(RE weighting in iVector estimation for online decoding) Maximum allowed "
+                    "duration of a single transition-id; runs with durations longer than this will be weighted down to the silence-weight.")
+
+    @classmethod
+    def from_options(cls, po, prefix="ivector-silence-weighting"):
+        return cls(po[prefix + ".silence-phones"], po[prefix + ".silence-weight"], po[prefix + ".max-state-duration"])
+
+
+class OnlineSilenceWeighting:
+    """online2/online-ivector-feature.h:453-535 over kamd_silence_weighting_*: one per utterance.  The delta weights are
+    queued inside (OnlineIvectorFeature::UpdateFrameWeights) and come back out through pop_until when the estimate is
+    advanced (UpdateStatsUntilFrameWeighted)."""
+
+    def __init__(self, tid2phone, config, frame_subsampling_factor=1):
+        self.config = config
+        t = config.tid_is_silence(tid2phone)
+        self._h = lib().kamd_silence_weighting_create(t.ctypes.data_as(C.POINTER(C.c_uint8)), t.size, config.silence_weight,
+                                                      config.max_state_duration, int(frame_subsampling_factor))
+        if not self._h:
+            raise KamdError(lib().kamd_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kamd_silence_weighting_destroy(self._h)
+            self._h = None
+
+    def Active(self):
+        return self.config.Active()
+
+    def ComputeCurrentTraceback(self, num_frames_decoded, tids, tokens):
+        """tids / tokens: the decoder's best path without final-probs, newest frame first (decoder.frame_tracebacks)"""
+        t, k = np.ascontiguousarray(tids, np.int32), np.ascontiguousarray(tokens, np.int32)
+        check(lib().kamd_silence_weighting_compute_traceback(self._h, int(num_frames_decoded), abi.iptr(t), abi.iptr(k), t.size))
+
+    def GetDeltaWeights(self, num_frames_ready_in):
+        n = C.c_int32()
+        check(lib().kamd_silence_weighting_get_delta_weights(self._h, int(num_frames_ready_in), C.byref(n)))
+        return n.value
+
+    def pop_until(self, frame):
+        cap = lib().kamd_silence_weighting_num_pending(self._h) + 1
+        fr, wt = np.zeros(cap, np.int32), np.zeros(cap, np.float32)
+        n = C.c_int32()
+        check(lib().kamd_silence_weighting_pop_until(self._h, int(frame), abi.iptr(fr), abi.fptr(wt), cap, C.byref(n)))
+        return [(int(fr[i]), float(wt[i])) for i in range(n.value)]
+
+
 class StreamBatch:
     """N concurrent streams decoded together (kamd_stream_batch_*): stream s = decoder lane s."""
 
@@ -234,6 +306,15 @@ class StreamBatch:
         check(lib().kamd_stream_batch_set_ivector_extractor(self._h, extractor._h, frames_per_chunk, extractor.info.splice_right))
         sub = lib().kamd_nnet_frame_subsampling_factor(self.nnet._h)
         self.extractor, self.frames_per_chunk = extractor, sub * ((frames_per_chunk + sub - 1) // sub)   # GetChunkSize rounding
+
+    def set_silence_weighting(self, config, tid2phone):
+        """--ivector-silence-weighting.* : after set_ivector_extractor, before the first start()"""
+        t = config.tid_is_silence(tid2phone)
+        check(lib().kamd_stream_batch_set_silence_weighting(self._h, t.ctypes.data_as(C.POINTER(C.c_uint8)), t.size,
+                                                            config.silence_weight if config.Active() else 1.0, config.max_state_duration))
+
+    def frame_tracebacks(self, streams):
+        return decoder.frame_tracebacks(self.dec._dec, streams)
 
     def start(self, streams, states=None):
         """states: one adaptation state per stream (the speaker's, after LimitFrames) or None = fresh"""

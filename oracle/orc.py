@@ -206,6 +206,174 @@ def ivector_extract_streaming(info, feats, upto, state=None):
     return out, st_out
 
 
+def ivector_extract_streaming_weighted(info, feats, upto, lists, state=None):
+    """UpdateStatsUntilFrameWeighted(upto[c] - 1) for c = 0, 1, ...; lists[c] = the merged (frame, weight) pairs of call c
+    (DeltaWeightQueue.pop_until): [n_calls x dim], final adaptation state"""
+    f = np.ascontiguousarray(feats, np.float32)
+    u = np.ascontiguousarray(upto, np.int32)
+    off = np.concatenate([[0], np.cumsum([len(l) for l in lists])]).astype(np.int32)
+    fr = np.ascontiguousarray([p[0] for l in lists for p in l] or [0], np.int32)
+    wt = np.ascontiguousarray([p[1] for l in lists for p in l] or [0], np.float32)
+    d = info.desc()
+    out = np.zeros((u.size, info.ivector_dim), np.float32)
+    dp = C.POINTER(C.c_double)
+    st_in = np.ascontiguousarray(state, np.float64) if state is not None else None
+    st_out = np.zeros(info.state_size(), np.float64)
+    r = lib().orc_ivector_extract_streaming_weighted(C.byref(d), abi.fptr(f), f.shape[0], abi.iptr(u), u.size, abi.iptr(off), abi.iptr(fr),
+                                                     abi.fptr(wt), abi.fptr(out), st_in.ctypes.data_as(dp) if st_in is not None else None,
+                                                     st_out.ctypes.data_as(dp))
+    assert r == u.size, r
+    return out, st_out
+
+
+class OnlineSilenceWeighting:
+    """online2/online-ivector-feature.{h:453-535, cc:447-668}, statement by statement.  A token is whatever hashable
+    the caller's traceback names it by (the reference compares Token pointers)."""
+
+    def __init__(self, tid2phone, silence_phones, silence_weight, max_state_duration=-1.0, frame_subsampling_factor=1):
+        self.tid2phone = np.asarray(tid2phone)
+        self.silence_phones = set(int(p) for p in silence_phones)
+        self.silence_weight = np.float32(silence_weight)
+        self.max_state_duration = max_state_duration
+        self.fs = int(frame_subsampling_factor)
+        assert self.fs >= 1
+        self.frame_info = []                     # [token, transition_id, current_weight]
+        self.num_frames_output_and_correct = 0
+
+    def Active(self):
+        return len(self.silence_phones) > 0 and self.silence_weight != 1.0
+
+    def _resize(self, n):
+        while len(self.frame_info) < n:
+            self.frame_info.append([None, -1, np.float32(0.0)])
+
+    def ComputeCurrentTraceback(self, num_frames_decoded, path):
+        """path: (transition_id, token) of frames num_frames_decoded-1, num_frames_decoded-2, ... (BestPathEnd without
+        final-probs + TraceBackBestPath, input-epsilon arcs skipped)  (.cc:464-510)"""
+        num_frames_prev = len(self.frame_info)
+        if num_frames_prev < num_frames_decoded:
+            self._resize(num_frames_decoded)
+        if num_frames_prev > num_frames_decoded and self.frame_info[num_frames_decoded][1] != -1:
+            raise RuntimeError("Number of frames decoded decreased")
+        if num_frames_decoded == 0:
+            return
+        frame = num_frames_decoded - 1
+        it = iter(path)
+        while frame >= 0:
+            tid, tok = next(it)
+            if self.frame_info[frame][0] is not None and self.frame_info[frame][0] == tok:
+                break
+            if self.num_frames_output_and_correct > frame:
+                self.num_frames_output_and_correct = frame
+            self.frame_info[frame][0] = tok
+            self.frame_info[frame][1] = int(tid)
+            frame -= 1
+
+    def GetBeginFrame(self):                    # .cc:521-571
+        max_duration = int(self.max_state_duration)
+        if max_duration <= 0 or self.num_frames_output_and_correct == 0:
+            return self.num_frames_output_and_correct
+        t_last_untouched = self.num_frames_output_and_correct - 1
+        t_end = len(self.frame_info)
+        transition_id = self.frame_info[t_last_untouched][1]
+        lower_search_bound = max(0, t_last_untouched - max_duration)
+        upper_search_bound = min(t_last_untouched + max_duration, t_end - 1)
+        t_lower = t_last_untouched
+        while t_lower > lower_search_bound and self.frame_info[t_lower - 1][1] == transition_id:
+            t_lower -= 1
+        t_upper = t_last_untouched
+        while t_upper < upper_search_bound and self.frame_info[t_upper + 1][1] == transition_id:
+            t_upper += 1
+        run_length = t_upper - t_lower + 1
+        if run_length <= max_duration:
+            return self.num_frames_output_and_correct
+        old_run_length = t_last_untouched - t_lower + 1
+        if old_run_length > max_duration:
+            ans = t_upper - max_duration
+            assert ans >= t_lower
+            return ans
+        return t_lower
+
+    def GetDeltaWeights(self, num_frames_ready_in):
+        """-> [(input frame, delta weight)]  (.cc:573-668).  Note: no statement of the reference raises
+        num_frames_output_and_correct_ (it starts at 0 and ComputeCurrentTraceback only lowers it), so begin_frame is 0."""
+        fs = self.fs
+        num_frames_ready = (num_frames_ready_in + fs - 1) // fs
+        max_state_duration = int(self.max_state_duration)
+        silence_weight = self.silence_weight
+        delta_weights = []
+        if len(self.frame_info) < num_frames_ready:
+            self._resize(num_frames_ready)
+        begin_frame = self.GetBeginFrame()
+        frames_out = len(self.frame_info) - begin_frame
+        assert frames_out >= 0
+        frame_weight = [np.float32(1.0)] * frames_out
+        if frames_out == 0:
+            return delta_weights
+        if self.frame_info[begin_frame][1] == -1:
+            weight = silence_weight if begin_frame == 0 else self.frame_info[begin_frame - 1][2]
+            frame_weight = [weight] * frames_out
+        else:
+            current_run_start_offset = 0
+            for offset in range(frames_out):
+                frame = begin_frame + offset
+                transition_id = self.frame_info[frame][1]
+                if transition_id == -1:
+                    frame_weight[offset] = frame_weight[offset - 1]
+                else:
+                    phone = int(self.tid2phone[transition_id])
+                    if phone in self.silence_phones:
+                        frame_weight[offset] = silence_weight
+                    if max_state_duration > 0 and (offset + 1 == frames_out or transition_id != self.frame_info[frame + 1][1]):
+                        run_length = offset - current_run_start_offset + 1
+                        if run_length >= max_state_duration:
+                            for offset2 in range(current_run_start_offset, offset + 1):
+                                frame_weight[offset2] = silence_weight
+                        if offset + 1 < frames_out:
+                            current_run_start_offset = offset + 1
+        for offset in range(frames_out):
+            frame = begin_frame + offset
+            old_weight = self.frame_info[frame][2]
+            new_weight = np.float32(frame_weight[offset])
+            weight_diff = np.float32(new_weight - old_weight)
+            self.frame_info[frame][2] = new_weight
+            if weight_diff != 0.0 or offset + 1 == frames_out:
+                for i in range(fs):
+                    delta_weights.append((frame * fs + i, weight_diff))
+        return delta_weights
+
+
+class DeltaWeightQueue:
+    """OnlineIvectorFeature's delta_weights_ priority queue: UpdateFrameWeights (.cc:159-174) and what
+    UpdateStatsUntilFrameWeighted(frame) (.cc:263-306) pops and hands to UpdateStatsForFrames, after its
+    MergePairVectorSumming (util/stl-utils.h:290-315)."""
+
+    def __init__(self):
+        import heapq
+        self._hq = heapq
+        self.heap = []
+        self.most_recent_frame_with_weight = -1
+
+    def UpdateFrameWeights(self, delta_weights):
+        for frame, w in delta_weights:
+            assert frame >= 0
+            self._hq.heappush(self.heap, (int(frame), float(np.float32(w))))
+            self.most_recent_frame_with_weight = max(self.most_recent_frame_with_weight, int(frame))
+
+    def pop_until(self, frame):
+        assert frame <= self.most_recent_frame_with_weight
+        popped = []
+        while self.heap and self.heap[0][0] <= frame:
+            popped.append(self._hq.heappop(self.heap))
+        merged = []
+        for fr, w in popped:                     # sorted by frame already
+            if merged and merged[-1][0] == fr:
+                merged[-1][1] = np.float32(merged[-1][1] + np.float32(w))
+            else:
+                merged.append([fr, np.float32(w)])
+        return [(fr, float(w)) for fr, w in merged if w != 0.0]
+
+
 def linear_cgd(A_packed, b, x0, max_iters):
     A = np.ascontiguousarray(A_packed, np.float64)
     bb = np.ascontiguousarray(b, np.float64)
@@ -296,6 +464,26 @@ class Lattice:
             return None
         return dict(alignment=ali[:na.value].copy(), words=words[:nw.value].copy(),
                     graph_cost=g.value, acoustic_cost=a.value)
+
+
+    def best_path_frames(self):
+        """(transition_id, HCLG state of the token the arc leaves) per decoded frame, newest first: what
+        OnlineSilenceWeighting::ComputeCurrentTraceback collects with BestPathEnd + TraceBackBestPath, skipping
+        input-epsilon arcs (online2/online-ivector-feature.cc:478-505).  None when no path exists."""
+        n, m = self.frame.size, self.arcs.size
+        arcs = np.ascontiguousarray(self.arcs)
+        path = np.zeros(max(m, 1), np.int32)
+        k = C.c_int()
+        r = lib().orc_lattice_best_path_arcs(n, self.start, abi.fptr(self.final), m, arcs.ctypes.data_as(C.c_void_p), abi.iptr(path),
+                                             path.size, C.byref(k))
+        if r != 0:
+            return None
+        out = []
+        for i in path[:k.value][::-1]:
+            a = arcs[int(i)]
+            if a["ilabel"] != 0:
+                out.append((int(a["ilabel"]), int(self.hclg[int(a["src"])])))
+        return out
 
 
 class _Graph:

@@ -768,10 +768,10 @@ int orc_decoder_get_raw_lattice(orc_decoder *d, int32_t *state_frame, int32_t *s
 // GetBestPath (lattice-faster-decoder.cc:102-108) + GetLinearSymbolSequence
 // (fstext/fstext-utils-inl.h:178-215).  Forward Viterbi in LatticeWeight
 // (Times = componentwise +, Plus = natural-order min, fstext/lattice-weight.h).
-int orc_lattice_best_path(int num_states, int start, const float *state_final, int num_arcs,
-                          const kamd_lat_arc *arcs, int32_t *alignment, int ali_cap,
-                          int *ali_len, int32_t *words, int words_cap, int *words_len,
-                          float *graph_cost, float *acoustic_cost) {
+static int LatticeBestPath(int num_states, int start, const float *state_final, int num_arcs,
+                           const kamd_lat_arc *arcs, int32_t *alignment, int ali_cap,
+                           int *ali_len, int32_t *words, int words_cap, int *words_len,
+                           float *graph_cost, float *acoustic_cost, std::vector<int> *path_out) {
   *ali_len = 0; *words_len = 0; *graph_cost = kInf; *acoustic_cost = kInf;
   if (num_states == 0) return -1;
   // Kahn topological order
@@ -818,6 +818,30 @@ int orc_lattice_best_path(int num_states, int start, const float *state_final, i
     if (a.olabel != 0) { if (*words_len < words_cap) words[*words_len] = a.olabel; (*words_len)++; }
   }
   *graph_cost = b1; *acoustic_cost = b2;
+  if (path_out) *path_out = path;
+  return 0;
+}
+
+int orc_lattice_best_path(int num_states, int start, const float *state_final, int num_arcs,
+                          const kamd_lat_arc *arcs, int32_t *alignment, int ali_cap,
+                          int *ali_len, int32_t *words, int words_cap, int *words_len,
+                          float *graph_cost, float *acoustic_cost) {
+  return LatticeBestPath(num_states, start, state_final, num_arcs, arcs, alignment, ali_cap, ali_len, words, words_cap, words_len,
+                         graph_cost, acoustic_cost, NULL);
+}
+
+// the arcs of that path, start -> end (indices into arcs): what TraceBackBestPath visits, in the other direction
+int orc_lattice_best_path_arcs(int num_states, int start, const float *state_final, int num_arcs, const kamd_lat_arc *arcs,
+                               int32_t *path, int cap, int *n) {
+  std::vector<int32_t> ali(num_arcs + 1), words(num_arcs + 1);
+  int na = 0, nw = 0; float g = 0, a = 0;
+  std::vector<int> p;
+  const int rc = LatticeBestPath(num_states, start, state_final, num_arcs, arcs, ali.data(), num_arcs + 1, &na, words.data(), num_arcs + 1, &nw,
+                                 &g, &a, &p);
+  *n = static_cast<int>(p.size());
+  if (rc != 0) return rc;
+  if (*n > cap) return -3;
+  for (size_t i = 0; i < p.size(); i++) path[i] = p[i];
   return 0;
 }
 

@@ -430,6 +430,84 @@ int orc_ivector_extract_streaming(const kamd_ivector_desc *desc, const float *fe
   return n_calls;
 }
 
+// The same with silence weighting: call c is UpdateStatsUntilFrameWeighted(upto[c] - 1) (online2/online-ivector-
+// feature.cc:263-306), whose UpdateStatsForFrames (:191-227) takes the merged (frame, weight) pairs
+// [wl_off[c], wl_off[c+1]) -- the caller has popped the delta-weight queue and applied MergePairVectorSumming
+// (orc.py DeltaWeightQueue).  Per pair: posteriors pruned with GetMinPost(weight) (:176-188), scaled by
+// posterior_scale * weight; a zero weight contributes an empty posterior.
+int orc_ivector_extract_streaming_weighted(const kamd_ivector_desc *desc, const float *feats, int T, const int32_t *upto, int n_calls,
+                                           const int32_t *wl_off, const int32_t *wl_frame, const float *wl_weight, float *out,
+                                           const double *state_in, double *state_out) {
+  const Desc &d = *desc;
+  const int I = d.ivector_dim, D = d.lda_rows, sdim = d.feat_dim + 1, Qn = I * (I + 1) / 2;
+  Extractor e(d);
+  std::vector<float> cm, nl, rl;
+  const bool have_spk = state_in != NULL && state_in[d.feat_dim] > 0.0;
+  OnlineCmvn(d, feats, T, &cm, have_spk ? state_in : NULL);
+  SpliceLda(d, cm.data(), T, &nl);
+  SpliceLda(d, feats, T, &rl);
+  Stats st(I, d.prior_offset, d.max_count);
+  if (state_in != NULL) {
+    const double *q = state_in + 2 * sdim;
+    st.quad.assign(q, q + Qn); st.lin.assign(q + Qn, q + Qn + I); st.num_frames = q[Qn + I];
+  }
+  std::vector<double> cur(I, 0.0);
+  cur[0] = d.prior_offset;
+  std::vector<float> ll;
+  int done = 0;
+  for (int c = 0; c < n_calls; c++) {
+    if (upto[c] > T) return -1;
+    if (upto[c] > done) {                        // "for (; num_frames_stats_ <= frame; ...)": nothing happens without a new frame
+      std::vector<const float *> rows;
+      std::vector<std::vector<std::pair<int, float> > > posts;
+      for (int k = wl_off[c]; k < wl_off[c + 1]; k++) {
+        const int t = wl_frame[k];
+        const float weight = wl_weight[k];
+        if (t < 0 || t >= upto[c]) return -2;
+        rows.push_back(&rl[static_cast<size_t>(t) * D]);
+        std::vector<std::pair<int, float> > post;
+        if (weight != 0.0f) {
+          float min_post = d.min_post;           // GetMinPost
+          const float abs_weight = std::fabs(weight);
+          min_post /= abs_weight;
+          if (min_post > 0.99f) min_post = 0.99f;
+          UbmLogLikes(d, &nl[static_cast<size_t>(t) * D], &ll);
+          PosteriorEntry(ll, d.num_gselect, min_post, &post);
+          for (size_t j = 0; j < post.size(); j++) post[j].second *= d.posterior_scale * weight;
+        }
+        posts.push_back(post);
+      }
+      AccStats(e, &st, rows, posts);
+      done = upto[c];
+      if (st.num_frames > 0.0) {
+        if (cur[0] == 0.0) cur[0] = st.prior_offset;
+        LinearCgd(d.num_cg_iters, st.quad, st.lin, &cur, NULL);
+      } else {
+        std::fill(cur.begin(), cur.end(), 0.0);
+        cur[0] = st.prior_offset;
+      }
+    }
+    float *o = out + static_cast<size_t>(c) * I;
+    for (int j = 0; j < I; j++) o[j] = static_cast<float>(cur[j]);
+    o[0] = static_cast<float>(static_cast<double>(o[0]) - d.prior_offset);
+  }
+  if (state_out != NULL) {
+    for (int k = 0; k < 2 * sdim; k++) state_out[k] = state_in != NULL ? state_in[k] : 0.0;
+    for (int t = 0; t < T; t++) {
+      for (int k = 0; k < d.feat_dim; k++) {
+        const double v = feats[static_cast<size_t>(t) * d.feat_dim + k];
+        state_out[k] += v; state_out[sdim + k] += v * v;
+      }
+      state_out[d.feat_dim] += 1.0;
+    }
+    double *q = state_out + 2 * sdim;
+    std::copy(st.quad.begin(), st.quad.end(), q);
+    std::copy(st.lin.begin(), st.lin.end(), q + Qn);
+    q[Qn + I] = st.num_frames;
+  }
+  return n_calls;
+}
+
 // OnlineIvectorExtractorAdaptationState::LimitFrames (online2/online-ivector-feature.cc:96-117) with
 // OnlineIvectorEstimationStats::Scale (ivector/ivector-extractor.cc:671-694), in place
 void orc_ivector_state_limit_frames(const kamd_ivector_desc *desc, double *state, float max_remembered_frames) {

@@ -321,6 +321,19 @@ def test_online2_wav_nnet3_latgen_faster_tool(tmp_path):
         ends.append({k: len(latbin.best_path(l)[1]) for k, l in latbin.read_lattices("ark:%s" % lat)})
     assert ends[0] == ends[1]
     assert all(ends[0][k] <= frames_full[k] for k in frames_full) and any(ends[0][k] < frames_full[k] for k in frames_full), (ends[0], frames_full)
+    # --ivector-silence-weighting.*: per stream again (same archive whatever the batch size); the statistics change, so
+    # the lattices' acoustic costs differ from the unweighted run's
+    sw_outs = []
+    for batch in (1, 3):
+        lat = tmp_path / ("lat_sw%d.ark" % batch)
+        r = subprocess.run(base + ["--batch=%d" % batch, "--ivector-silence-weighting.silence-phones=" + ":".join(str(p) for p in range(1, 26, 2)),
+                                   "--ivector-silence-weighting.silence-weight=0.001", "--ivector-silence-weighting.max-state-duration=5",
+                                   str(tmp_path / "final.mdl"), str(tmp_path / "HCLG.fst"), "ark:%s" % (tmp_path / "spk2utt"),
+                                   "scp:%s" % (tmp_path / "wav.scp"), "ark:%s" % lat], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "Decoded 3 utterances, 0 with errors." in r.stderr
+        sw_outs.append(open(lat, "rb").read())
+    assert sw_outs[0] == sw_outs[1] and sw_outs[0] != outs[0]
     # direct run of the first utterance, same chunking
     g.tid2pdf = np.concatenate([[-1], np.stack([2 * np.arange(25) + 1, 2 * np.arange(25)], 1).reshape(-1)]).astype(np.int32)
     N, G = decoder.Nnet(m), decoder.Graph(g)
@@ -478,3 +491,138 @@ def test_one_overflowing_stream_does_not_stop_the_others():
     sb.advance([0])
     sb.finalize([0])
     assert lattices_equal(sb.raw_lattice(0), offline(waves[1])[0])
+
+
+def test_frame_tracebacks_equal_the_oracle_traceback():
+    """kamd_decoder_frame_tracebacks (what OnlineSilenceWeighting::ComputeCurrentTraceback reads off the decoder): after
+    every chunk, (transition-id, token) per decoded frame == the oracle decoder's best path without final-probs over
+    the same rows, with a token named by its HCLG state."""
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=3.0)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    w = synth.make_wave(2.4, seed=21)
+    s = online.SingleUtteranceNnet3Decoder(op, N, G, cfg, sizes=abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512))
+    s.record_loglikes()
+    prev, rewrites = None, 0
+    for i in range(0, w.size, CHUNK):
+        s.AcceptWaveform(16000, w[i:i + CHUNK])
+        if not s.AdvanceDecoding():
+            continue
+        (tids, toks), = decoder.frame_tracebacks(s.decoder._dec, [s.decoder.lane])
+        o = orc.Decoder(g, cfg, 1)
+        o.InitDecoding()
+        o.AdvanceDecoding(s.loglikes())
+        lat = o.GetRawLattice()
+        lat.final[:] = np.where(lat.frame == lat.num_frames, 0.0, np.inf).astype(np.float32)   # use_final_probs = false
+        want = lat.best_path_frames()
+        assert len(want) == s.NumFramesDecoded() == tids.size
+        assert [(int(a), int(b)) for a, b in zip(tids, toks)] == want
+        if prev is not None:
+            old = prev[::-1]
+            new = want[::-1][:len(old)]
+            rewrites += int(old != new)
+        prev = want
+    assert rewrites > 0                     # the best path did change its mind about earlier frames along the way
+
+
+def test_streams_with_silence_weighting():
+    """--ivector-silence-weighting.* in the streaming batch (online2-wav-nnet3-latgen-faster.cc:214-216, 258-266).  Per tick and
+    stream the device's own traceback (read with frame_tracebacks right before the tick, the data the tick itself uses) drives
+    the ORACLE's OnlineSilenceWeighting + delta-weight queue; the oracle's weighted OnlineIvectorFeature then has to reproduce
+    every i-vector the device put into the network's slots, the lattice has to equal an offline decode with exactly those slots,
+    and the adaptation state the oracle's.  The weighting must really act: negative deltas occur, and the i-vectors differ from
+    the unweighted run's."""
+    from kaldi_amd import ivector
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, ivector_dim=16, seed=12, output_scale=3.0)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    waves = [synth.make_wave(d, seed=60 + i) for i, d in enumerate((3.0, 1.7))]
+    feats = [feat.Mfcc(op).ComputeFeatures(w) for w in waves]
+    allf = np.concatenate(feats)
+    info = ivector.make_synthetic(num_gauss=64, ivector_dim=16, seed=9, feat_mean=allf.mean(0), feat_std=allf.std(0), max_count=10.0)
+    ie = ivector.IvectorExtractor(info)
+    num_tids = len(g.tid2pdf) - 1
+    tid2phone = np.concatenate([[0], (np.arange(num_tids) // 2) + 1]).astype(np.int32)
+    sil = [p for p in range(1, int(tid2phone.max()) + 1) if p % 2 == 0]
+    swc = online.OnlineSilenceWeightingConfig(":".join(map(str, sil)), 0.1, 4.0)
+    assert swc.Active() and swc.silence_phones() == sil
+    S, sub = 2, m.subsampling
+    L, R = N.Context()
+    sizes = abi.DecoderSizes(S, 1 << 14, 1 << 19, 1 << 20, 512)
+
+    def run(weighted):
+        sb = online.StreamBatch(op, N, G, cfg, S, max_seconds=5.0, sizes=sizes)
+        sb.set_ivector_extractor(ie, 20)
+        if weighted:
+            sb.set_silence_weighting(swc, tid2phone)
+        C_ = sb.frames_per_chunk
+        sb.start([0, 1])
+        step = [int(0.18 * 16000), int(0.31 * 16000)]
+        pos, done = [0, 0], [False, False]
+        chunks_done, iv_done = [0, 0], [0, 0]
+        calls, lists, slot_src = [[], []], [[], []], [[], []]
+        osw = [orc.OnlineSilenceWeighting(tid2phone, sil, swc.silence_weight, swc.max_state_duration, sub) for _ in range(S)]
+        oq = [orc.DeltaWeightQueue() for _ in range(S)]
+        n_neg = 0
+        while not all(done):
+            live = [s for s in range(S) if not done[s]]
+            for s in live:
+                chunk = waves[s][pos[s]:pos[s] + step[s]]
+                pos[s] += chunk.size
+                sb.accept(s, chunk, input_finished=pos[s] >= waves[s].size)
+            tb = sb.frame_tracebacks(live)                      # the decoder's state as the tick will find it
+            n_dec_before = {s: (0 if tb[i] is None else tb[i][0].size) for i, s in enumerate(live)}
+            sb.advance(live)
+            for i, s in enumerate(live):
+                fin = pos[s] >= waves[s].size
+                F = sb.num_frames_ready(s)
+                iv_ready = F if fin else max(0, F - info.splice_right)
+                if weighted:
+                    if n_dec_before[s] > 0:
+                        osw[s].ComputeCurrentTraceback(n_dec_before[s], zip(tb[i][0].tolist(), tb[i][1].tolist()))
+                    oq[s].UpdateFrameWeights(osw[s].GetDeltaWeights(iv_ready))
+                n_out_total = (F + sub - 1) // sub
+                k = chunks_done[s]
+                while F > 0 and ((k * C_ < n_out_total * sub) if fin else ((k + 1) * C_ + R <= F)):
+                    k += 1
+                if k > chunks_done[s]:
+                    if iv_ready > iv_done[s]:
+                        calls[s].append(iv_ready); iv_done[s] = iv_ready
+                        if weighted:
+                            lists[s].append(oq[s].pop_until(iv_ready - 1))
+                            n_neg += sum(1 for _, x in lists[s][-1] if x < 0)
+                    src = len(calls[s]) - 1
+                    slot_first = -((L + C_ - 1) // C_)
+                    last = (k * C_ + R - 1) // C_ - slot_first
+                    slot_src[s] += [src] * (last + 1 - len(slot_src[s]))
+                    chunks_done[s] = k
+                if fin:
+                    done[s] = True
+        sb.finalize([0, 1])
+        return sb, C_, calls, lists, slot_src, n_neg
+
+    sb, C_, calls, lists, slot_src, n_neg = run(True)
+    assert n_neg > 0
+    plain, _, calls0, _, slot_src0, _ = run(False)
+    for s in range(S):
+        first, slots = sb.ivector_slots(s)
+        want_iv, want_state = orc.ivector_extract_streaming_weighted(info, feats[s], calls[s], lists[s])
+        assert slots.shape[0] == len(slot_src[s])
+        for j, src in enumerate(slot_src[s]):
+            w = want_iv[src] if src >= 0 else np.zeros(16, np.float32)
+            np.testing.assert_allclose(slots[j], w, rtol=0, atol=1e-4 * max(1.0, np.abs(w).max()), err_msg="stream %d slot %d" % (s, j))
+        ll = N.ForwardSlots(feats[s], slots, first, C_)[0]
+        off = decoder.LatticeFasterDecoder(G, cfg, abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512))
+        off.Decode(ll)
+        assert lattices_equal(sb.raw_lattice(s), off.GetRawLattice())
+        st = sb.adaptation_state(s, max_remembered_frames=1e9)
+        np.testing.assert_allclose(st, want_state, rtol=1e-7, atol=1e-7 * np.abs(want_state).max())
+        _, slots0 = plain.ivector_slots(s)
+        assert calls0[s] == calls[s] and slot_src0[s] == slot_src[s]               # same schedule
+        assert np.abs(slots0 - slots).max() > 1e-2                                 # different statistics
+        # the unweighted run is the weighted machinery with every frame at weight 1, once
+        unit, _ = orc.ivector_extract_streaming_weighted(info, feats[s], calls[s], [[(t, 1.0) for t in range(a, b)]
+                                                                                    for a, b in zip([0] + calls[s][:-1], calls[s])])
+        np.testing.assert_allclose(unit, orc.ivector_extract_streaming(info, feats[s], calls[s])[0], rtol=0, atol=1e-6)

@@ -7,7 +7,7 @@
 online.conf's --feature-type=mfcc, --mfcc-config, --ivector-extraction-config and --endpoint.* options are read as
 they are.  Audio is fed --chunk-length seconds at a time; every tick advances ALL active streams together (one
 stream per speaker, --batch speakers at once; a speaker's utterances follow each other and hand their i-vector
-adaptation state on).  Not supported: plp / fbank / pitch features, silence weighting."""
+adaptation state on) and the --ivector-silence-weighting.* options (OnlineSilenceWeighting).  Not supported: plp / fbank / pitch features."""
 import os
 import sys
 
@@ -32,6 +32,7 @@ def main(argv):
     po.register("feature-type", str, "mfcc", "Base feature type [mfcc]")
     po.register("mfcc-config", str, "", "Configuration file for MFCC features (e.g. conf/mfcc_hires.conf)")
     po.register("ivector-extraction-config", str, "", "Configuration file for online iVector extraction")
+    online.OnlineSilenceWeightingConfig.register(po)
     po.register("endpoint.silence-phones", str, "", "List of phones that are considered to be silence phones by the endpointing code.")
     ep = online.OnlineEndpointConfig()
     for i, r in enumerate((ep.rule1, ep.rule2, ep.rule3, ep.rule4, ep.rule5), 1):
@@ -84,6 +85,9 @@ def main(argv):
         info = ivector.IvectorExtractionInfo.from_config(po["ivector-extraction-config"])
         extractor = ivector.IvectorExtractor(info)
         sb.set_ivector_extractor(extractor, po["frames-per-chunk"])
+        swc = online.OnlineSilenceWeightingConfig.from_options(po)
+        if swc.Active():          # online2-wav-nnet3-latgen-faster.cc:258-259: Active() && IvectorFeature() != NULL
+            sb.set_silence_weighting(swc, model.tid2phone)
     det = kio.determinize_opts_default()
     det.delta, det.phone_determinize, det.word_determinize = po["delta"], int(po["phone-determinize"]), int(po["word-determinize"])
     frame_shift = mfcc.frame.frame_shift_ms * 1e-3 * sub
