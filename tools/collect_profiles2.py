@@ -51,13 +51,13 @@ out = {"round": tag, "device": "MI355X (gfx950), ROCm 7.2",
        "workload": cfg.get("workload")}
 if base:
     out["workload_key"] = "librispeech/tglarge/%d/%s/%s" % (cfg.get("utterances", 0), cfg.get("loglike_std_nats"), cfg.get("lm_scale"))
-for kern, key in (("DecodeQueueKernel", "decode_queue"), ("TdnnGemmKernel", "gemm_all_layers"), ("FeatKernel", "features")):
+for kern, key in (("DecodeQueueKernel", "decode_queue"), ("TdnnGemm", "gemm_all_layers"), ("FeatKernel", "features")):
     fe, wr = per_kernel("pmc_fetch", "FETCH_SIZE", kern), per_kernel("pmc_write", "WRITE_SIZE", kern)
     if fe and wr:
         n = 3.0 if key != "decode_queue" else float(len(fe))     # per bench step: all launches of the kernel family
         out[key] = {"launches_in_pass": len(fe), "FETCH_SIZE_KB_per_step": sum(fe) / n, "WRITE_SIZE_KB_per_step": sum(wr) / n,
                     "traffic_bytes_per_step": 2 * 1024 * sum(fe) / n + 1024 * sum(wr) / n}
-for kern, key in (("DecodeQueueKernel", "decode_queue"), ("TdnnGemmKernel", "gemm_all_layers")):
+for kern, key in (("DecodeQueueKernel", "decode_queue"), ("TdnnGemm", "gemm_all_layers")):
     sq = {}
     for dname in ("pmc_sq1", "pmc_sq3"):
         for r in rows(dname):
@@ -72,7 +72,7 @@ for kern, key in (("DecodeQueueKernel", "decode_queue"), ("TdnnGemmKernel", "gem
             out[key + "_l2_hit_rate"] = s["TCC_HIT_sum"] / (s["TCC_HIT_sum"] + s["TCC_MISS_sum"])
 mf = {}
 for r in rows("pmc_mfma"):
-    if r["Counter_Name"] == "MfmaUtil" and "TdnnGemmKernel" in r["Kernel_Name"]:
+    if r["Counter_Name"] == "MfmaUtil" and "TdnnGemm" in r["Kernel_Name"]:
         dur = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         k = r["Kernel_Name"].split("(")[0].replace("void kamd::", "")
         a = mf.setdefault(k, [0.0, 0.0, 0])

@@ -12,7 +12,7 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o 
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- $B > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- $B > $O/pmc_write.json 2> $O/pmc_write.err
 timeout 300 rocprofv3 --kernel-trace --pmc MfmaUtil --output-format csv -d $O/pmc_mfma -o run -- $B > $O/pmc_mfma.json 2> $O/pmc_mfma.err
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq1 -o run -- $B > $O/pmc_sq1.json 2> $O/pmc_sq1.err
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $O/pmc_sq1 -o run -- $B > $O/pmc_sq1.json 2> $O/pmc_sq1.err
 timeout 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_sq3 -o run -- $B > $O/pmc_sq3.json 2> $O/pmc_sq3.err
 find $O -name "*_kernel_trace.csv" -size +20M -delete
 ls -la $O | head -30
