@@ -22,16 +22,17 @@ def main():
     ap.add_argument("--workload", default="mini_librispeech")
     ap.add_argument("--utts", type=int, default=128)
     ap.add_argument("--lanes", default="32,64,128,256")
-    ap.add_argument("--vocab", type=int, default=20000)
-    ap.add_argument("--n-hist", type=int, default=18000)
-    ap.add_argument("--lm-scale", type=float, default=0.1)
-    ap.add_argument("--ll-std", type=float, default=1.3)
+    ap.add_argument("--graph", default="")
+    ap.add_argument("--vocab", type=int, default=0)
+    ap.add_argument("--n-hist", type=int, default=0)
+    ap.add_argument("--lm-scale", type=float, default=-1.0)
+    ap.add_argument("--ll-std", type=float, default=-1.0)
     ap.add_argument("--output-scale", type=float, default=1.0)
     ap.add_argument("--max-seconds", type=float, default=0.0)
     ap.add_argument("--hash-capacity", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
-    args.graph = "tgsmall" if args.vocab < 100000 else "tglarge"
+    args = bench.defaults(args)
     from kaldi_amd import synth
     g, model, durs, cfg, _ = bench.build_workload(args)
     bench.calibrate(model, args.ll_std)
