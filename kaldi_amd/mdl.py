@@ -199,6 +199,49 @@ def _parse_descriptor(text):
     return parse()
 
 
+# components that are a per-element affine map y = x * scale + offset at test time
+_PER_ELEMENT = ("FixedScaleComponent", "FixedBiasComponent", "PerElementScaleComponent", "NaturalGradientPerElementScaleComponent",
+                "PerElementOffsetComponent", "ScaleAndOffsetComponent")
+
+
+def _per_element_map(typ, f, dim, name):
+    """(scale, offset) of the component, float32 [dim] (nnet-simple-component.cc: FixedScale :3669, FixedBias :3740,
+    PerElementScale :2021, PerElementOffset :2191-2225 and ScaleAndOffset :2400-2440 -- the latter two repeat a shorter
+    parameter vector block-wise over the dimension)."""
+    one, zero = np.ones(dim, np.float32), np.zeros(dim, np.float32)
+
+    def full(v):
+        v = np.asarray(v, np.float32).reshape(-1)
+        if v.size == 0 or dim % v.size:
+            raise MdlError("%s: parameter vector of %d elements for dimension %d" % (name, v.size, dim))
+        return np.tile(v, dim // v.size)
+    if typ == "FixedScaleComponent":
+        return full(f["<Scales>"][0]), zero
+    if typ == "FixedBiasComponent":
+        return one, full(f["<Bias>"][0])
+    if typ in ("PerElementScaleComponent", "NaturalGradientPerElementScaleComponent"):
+        return full(f["<Params>"][0]), zero
+    if typ == "PerElementOffsetComponent":
+        return one, full(f["<Offsets>"][0])
+    return full(f["<Scales>"][0]), full(f["<Offsets>"][0])
+
+
+def _apply_per_element(L, scale, offset, name):
+    """y = layer(x) * scale + offset, folded into the fused layer: into the GEMM's rows while nothing but the affine map
+    has been applied yet, into the post-ReLU per-element map (the BatchNorm slot) afterwards."""
+    if L.bypass_layer != -2 or L.log_softmax:
+        raise MdlError("a per-element map after a bypass / log-softmax is not representable (%s)" % name)
+    if not L.relu and L.bn_scale is None:
+        L.W = np.ascontiguousarray(L.W * scale[:, None], np.float32)
+        b = np.zeros(L.out_dim, np.float32) if L.bias is None else L.bias
+        L.bias = (b * scale + offset).astype(np.float32)
+    elif L.bn_scale is None:
+        L.bn_scale, L.bn_offset = scale.copy(), offset.copy()
+    else:
+        L.bn_offset = (L.bn_offset * scale + offset).astype(np.float32)
+        L.bn_scale = (L.bn_scale * scale).astype(np.float32)
+
+
 def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
     s = _Stream(open(path, "rb").read())
     if s.take(2) != b"\0B":
@@ -257,6 +300,10 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
             if bias is not None and bias.size == 0:
                 bias = None
             ivector_dim = 0
+            col_scales = []                                 # one per appended slice, when a Scale(...) descriptor feeds it
+            whole_scale = 1.0
+            if desc[0] == "Scale":                          # input=Scale(s, x): y = W (s x) + b
+                whole_scale, desc = desc[1], desc[2]
             if typ == "TdnnComponent":
                 offsets = [int(x) for x in f["<TimeOffsets>"][0]]
                 src = resolve(desc)
@@ -266,17 +313,29 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
                     if part[0] == "ReplaceIndex":
                         ivector_dim = inputs[part[1]]
                         continue
+                    part_scale = 1.0
+                    if part[0] == "Scale":                  # Scale(s, Offset(x, t)): folded into that slice's columns below
+                        part_scale, part = part[1], part[2]
                     off, inner = (part[2], part[1]) if part[0] == "Offset" else (0, part)
+                    if inner[0] == "Scale":
+                        part_scale, inner = part_scale * inner[1], inner[2]
+                    col_scales.append(part_scale)
                     idx = resolve(inner)
                     if src is not None and idx != src:
                         raise MdlError("Append over different producers is not supported (%s)" % name)
                     src = idx
                     offsets.append(off)
+            elif desc[0] == "Offset":                       # input=Offset(x, t)
+                offsets, src = [desc[2]], resolve(desc[1])
             else:
                 offsets, src = [0], resolve(desc)
             in_dim = inputs["input"] if src == -1 else layers[src].out_dim
             if W.shape[1] != len(offsets) * in_dim + ivector_dim:
                 raise MdlError("%s: parameter shape %s does not match its input" % (name, W.shape))
+            if whole_scale != 1.0 or (col_scales and any(c != 1.0 for c in col_scales)):
+                W = np.array(W, np.float32)
+                cs = np.full(len(offsets), whole_scale, np.float32) if not col_scales else np.asarray(col_scales, np.float32) * np.float32(whole_scale)
+                W[:, :len(offsets) * in_dim] *= np.repeat(cs, in_dim)[None, :]
             layers.append(Layer(name, in_dim, W.shape[0], offsets, src, np.ascontiguousarray(W, np.float32),
                                 None if bias is None else bias.astype(np.float32), ivector_dim=ivector_dim))
             layer_of[name] = len(layers) - 1
@@ -285,8 +344,9 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
         if typ == "NoOpComponent" and desc[0] == "Sum":      # tdnnf bypass: Sum(Scale(s, prev), this)
             a, b = desc[1], desc[2]
             scaled, plain = (a, b) if a[0] == "Scale" else (b, a)
-            if scaled[0] != "Scale":
-                raise MdlError("unsupported Sum in " + name)
+            if scaled[0] != "Scale":                        # Sum(x, y): a residual connection with scale 1; the later layer is "this"
+                ia, ib = resolve(a), resolve(b)
+                plain, scaled = (a, ("Scale", 1.0, b)) if ia > ib else (b, ("Scale", 1.0, a))
             idx = resolve(plain)
             byp = resolve(scaled[2])
             L = layers[idx]
@@ -314,8 +374,11 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
                 L.bn_scale = L.bn_scale * scale
             else:
                 L.bn_scale, L.bn_offset = scale.astype(np.float32), offset.astype(np.float32)
-        elif typ in ("GeneralDropoutComponent", "DropoutComponent", "NoOpComponent"):
+        elif typ in ("GeneralDropoutComponent", "DropoutComponent", "NoOpComponent", "ClipGradientComponent", "BackpropTruncationComponent"):
             pass                                           # identity at test time
+        elif typ in _PER_ELEMENT:
+            scale, offset = _per_element_map(typ, f, L.out_dim, name)
+            _apply_per_element(L, scale, offset, name)
         elif typ == "LogSoftmaxComponent":
             L.log_softmax = True
         else:

@@ -67,3 +67,104 @@ def test_transition_model_three_state_hmm_topology_old_format():
     # a phone is entered by the forward transition out of ... no: by any non-self-loop transition OF hmm-state 0
     assert tid_phone.tolist() == [0, 0, 1, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0]
     assert mdl.read_transition_model.tid2phone.tolist() == [0, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2]
+
+
+def test_components_outside_the_tdnnf_recipes(tmp_path):
+    """The graph compiler is descriptor-driven, not name-driven: per-element components (FixedScale, FixedBias,
+    PerElementScale, PerElementOffset with a block-repeated vector, ScaleAndOffset), a plain residual Sum(x, y), Scale(...)
+    descriptors feeding an affine (whole input and one appended slice) and a lone Offset(...) input all fold into fused
+    layers.  Checked against a direct float64 evaluation of the component chain as the reference's Propagate functions
+    define it (nnet-simple-component.cc:1234, 2021, 2191-2225, 2400-2440, 3669, 3740, 957)."""
+    from tests import mdl_writer as mw
+    from tests.nnet_ref import forward_f64 as forward_ref
+    rng = np.random.default_rng(5)
+    D, H, P = 40, 24, 19
+    W1, b1 = rng.standard_normal((H, 3 * D)) * 0.1, rng.standard_normal(H) * 0.1
+    s1 = rng.uniform(0.5, 1.5, H)
+    o1 = rng.standard_normal(8) * 0.1                      # block-repeated: 8 values over 24 dims
+    W2, b2 = rng.standard_normal((H, H)) * 0.2, rng.standard_normal(H) * 0.1
+    sc2, of2 = rng.uniform(0.5, 1.5, H), rng.standard_normal(H) * 0.1
+    W3 = rng.standard_normal((H, 2 * H)) * 0.2             # LinearComponent over Append(Scale(2, Offset(l2,-1)), l2)
+    pe3 = rng.uniform(0.5, 1.5, H)
+    W4, b4 = rng.standard_normal((P, H)) * 0.2, rng.standard_normal(P) * 0.1
+    fb4 = rng.standard_normal(P) * 0.1
+
+    def affine(name, W, b):
+        return (name, mw.updatable_common("NaturalGradientAffineComponent") + mw.tok("<LinearParams>") + mw.mat(W) + mw.tok("<BiasParams>") +
+                mw.vec(b) + mw.tok("<RankIn>") + mw.i32(20) + mw.tok("<RankOut>") + mw.i32(80) + mw.tok("<UpdatePeriod>") + mw.i32(4) +
+                mw.tok("<NumSamplesHistory>") + mw.f32(2000.0) + mw.tok("<Alpha>") + mw.f32(4.0) + mw.tok("</NaturalGradientAffineComponent>"))
+
+    def relu(name, dim):
+        z = np.zeros(dim, np.float32)
+        return (name, mw.tok("<RectifiedLinearComponent>") + mw.tok("<Dim>") + mw.i32(dim) + mw.tok("<ValueAvg>") + mw.vec(z) +
+                mw.tok("<DerivAvg>") + mw.vec(z) + mw.tok("<Count>") + mw.f64(0.0) + mw.tok("<OderivRms>") + mw.vec(z) +
+                mw.tok("<OderivCount>") + mw.f64(0.0) + mw.tok("<NumDimsSelfRepaired>") + mw.f64(0.0) + mw.tok("<NumDimsProcessed>") +
+                mw.f64(0.0) + mw.tok("<SelfRepairScale>") + mw.f32(1e-5) + mw.tok("</RectifiedLinearComponent>"))
+    comps = [
+        affine("l1.affine", W1, b1),
+        ("l1.scale", mw.tok("<FixedScaleComponent>") + mw.tok("<Scales>") + mw.vec(s1) + mw.tok("</FixedScaleComponent>")),
+        relu("l1.relu", H),
+        ("l1.offset", mw.updatable_common("PerElementOffsetComponent") + mw.tok("<Offsets>") + mw.vec(o1) + mw.tok("<Dim>") + mw.i32(H) +
+         mw.tok("<UseNaturalGradient>") + mw.boolean(True) + mw.tok("</PerElementOffsetComponent>")),
+        affine("l2.affine", W2, b2),
+        ("l2.so", mw.updatable_common("ScaleAndOffsetComponent") + mw.tok("<Dim>") + mw.i32(H) + mw.tok("<Scales>") + mw.vec(sc2) +
+         mw.tok("<Offsets>") + mw.vec(of2) + mw.tok("<UseNaturalGradient>") + mw.boolean(True) + mw.tok("<Rank>") + mw.i32(20) +
+         mw.tok("</ScaleAndOffsetComponent>")),
+        relu("l2.relu", H),
+        ("l2.res", mw.tok("<NoOpComponent>") + mw.tok("<Dim>") + mw.i32(H) + mw.tok("<BackpropScale>") + mw.f32(1.0) + mw.tok("</NoOpComponent>")),
+        ("l3.linear", mw.updatable_common("LinearComponent") + mw.tok("<Params>") + mw.mat(W3) + mw.tok("<OrthonormalConstraint>") + mw.f32(-1.0) +
+         mw.tok("<UseNaturalGradient>") + mw.boolean(True) + mw.tok("<RankInOut>") + mw.i32(20) + mw.i32(80) + mw.tok("<Alpha>") + mw.f32(4.0) +
+         mw.tok("<NumSamplesHistory>") + mw.f32(2000.0) + mw.tok("<UpdatePeriod>") + mw.i32(4) + mw.tok("</LinearComponent>")),
+        ("l3.pes", mw.updatable_common("PerElementScaleComponent") + mw.tok("<Params>") + mw.vec(pe3) + mw.tok("</PerElementScaleComponent>")),
+        affine("output.affine", W4, b4),
+        ("output.bias", mw.tok("<FixedBiasComponent>") + mw.tok("<Bias>") + mw.vec(fb4) + mw.tok("</FixedBiasComponent>")),
+        ("output.log-softmax", mw.tok("<LogSoftmaxComponent>") + mw.tok("<Dim>") + mw.i32(P) + mw.tok("<ValueAvg>") + mw.vec(np.zeros(0)) +
+         mw.tok("<DerivAvg>") + mw.vec(np.zeros(0)) + mw.tok("<Count>") + mw.f64(0.0) + mw.tok("<NumDimsSelfRepaired>") + mw.f64(0.0) +
+         mw.tok("<NumDimsProcessed>") + mw.f64(0.0) + mw.tok("</LogSoftmaxComponent>")),
+    ]
+    cfg = ["input-node name=input dim=%d" % D,
+           "component-node name=l1.affine component=l1.affine input=Append(Offset(input, -1), input, Offset(input, 1))",
+           "component-node name=l1.scale component=l1.scale input=l1.affine",
+           "component-node name=l1.relu component=l1.relu input=l1.scale",
+           "component-node name=l1.offset component=l1.offset input=l1.relu",
+           "component-node name=l2.affine component=l2.affine input=Scale(0.5, l1.offset)",
+           "component-node name=l2.so component=l2.so input=l2.affine",
+           "component-node name=l2.relu component=l2.relu input=l2.so",
+           "component-node name=l2.res component=l2.res input=Sum(l1.offset, l2.relu)",
+           "component-node name=l3.linear component=l3.linear input=Append(Scale(2.0, Offset(l2.res, -1)), l2.res)",
+           "component-node name=l3.pes component=l3.pes input=l3.linear",
+           "component-node name=output.affine component=output.affine input=Offset(l3.pes, 1)",
+           "component-node name=output.bias component=output.bias input=output.affine",
+           "component-node name=output.log-softmax component=output.log-softmax input=output.bias",
+           "output-node name=output input=output.log-softmax objective=linear"]
+    tm, id2pdf, _ = mw.transition_model(10)
+    blob = b"\0B" + tm + mw.tok("<Nnet3>") + b"\n" + ("\n".join(cfg) + "\n\n").encode() + mw.tok("<NumComponents>") + mw.i32(len(comps))
+    for name, body in comps:
+        blob += mw.tok("<ComponentName>") + mw.tok(name) + body
+    blob += mw.tok("</Nnet3>") + mw.tok("<LeftContext>") + mw.i32(0) + mw.tok("<RightContext>") + mw.i32(0) + mw.tok("<Priors>") + mw.vec(np.zeros(0))
+    (tmp_path / "odd.mdl").write_bytes(blob)
+    model, _, _ = mdl.read_mdl(tmp_path / "odd.mdl", acoustic_scale=1.0, frame_subsampling_factor=1)
+    assert len(model.layers) == 4 and model.layers[1].bypass_layer == 0 and model.layers[1].bypass_scale == 1.0
+    T = 23
+    x = rng.standard_normal((T, D)).astype(np.float32)
+
+    def at(m, t):                                           # nnet3 evaluates out-of-range times by clamping the INPUT (DecodableNnetSimple)
+        return m[np.clip(t, 0, m.shape[0] - 1)]
+    # direct evaluation over an extended time range so that only the network input is clamped, as the decodable does
+    lo, hi = -4, T + 4
+    ts = np.arange(lo, hi)
+    xin = np.stack([x[np.clip(t, 0, T - 1)] for t in ts]).astype(np.float64)
+
+    def shift(m, d):                                        # m[t + d] on the extended range (edges of the extension are never read back)
+        return np.roll(m, -d, axis=0)
+    l1 = np.concatenate([shift(xin, -1), xin, shift(xin, 1)], 1) @ W1.T + b1
+    l1 = np.maximum(l1 * s1, 0.0) + np.tile(o1, H // 8)
+    l2 = (0.5 * l1) @ W2.T + b2
+    l2 = np.maximum(l2 * sc2 + of2, 0.0)
+    res = l1 + l2
+    l3 = (np.concatenate([2.0 * shift(res, -1), res], 1) @ W3.T) * pe3
+    out = shift(l3, 1) @ W4.T + b4 + fb4
+    out = out - np.log(np.exp(out - out.max(1, keepdims=True)).sum(1, keepdims=True)) - out.max(1, keepdims=True)
+    want = out[-lo:-lo + T]
+    got = forward_ref(model, x)
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)
