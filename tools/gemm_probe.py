@@ -34,4 +34,11 @@ for name, din, dout, offs in shapes:
         check(lib().kamd_device_synchronize())
         dt = time.time() - t0
     fl = lib().kamd_nnet_last_flops(N._h)
-    print("%-28s rows %d: %.2f ms  %.1f TFLOP/s" % (name, rows, dt * 1e3, fl / dt / 1e12), flush=True)
+    # numerics of this shape's kernel: rows away from the edges against float64 numpy
+    got = d_o.download()
+    sel = np.asarray([5, 77, rows // 2, rows - 9])
+    want = np.zeros((sel.size, dout))
+    for j, o in enumerate(offs):
+        want += x[sel + o, :din].astype(np.float64) @ W[:, j * din:(j + 1) * din].astype(np.float64).T
+    err = float(np.abs(got[sel] - np.maximum(want, 0.0)).max())
+    print("%-28s rows %d: %.2f ms  %.1f TFLOP/s  max|err| %.2e" % (name, rows, dt * 1e3, fl / dt / 1e12, err), flush=True)
