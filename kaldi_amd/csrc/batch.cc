@@ -58,6 +58,9 @@ struct BatchDecoder {
   int device = 0;
   int feat_dim = 0, ld_feat = 0, P = 0;
   int n_utts = 0;
+  // utterances too short for one frame are not decoded: they fail alone ("Zero-length utterance", nnet3-latgen-faster-
+  // batch.cc:184-188).  kept[k] = the caller's index of the k-th utterance that is; every offset array below is indexed by k
+  std::vector<int> kept, skipped;
   std::vector<int64_t> wave_off, feat_off, out_off;
   float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL, *d_iv = NULL;
   size_t waves_cap = 0, feats_cap = 0, ll_cap = 0, iv_cap = 0;
@@ -89,9 +92,9 @@ static int GrowDev(T **p, size_t *cap, size_t need) {
 // One finished utterance: what DecodeUtteranceLatticeFaster does after Decode()
 // (decoder/decoder-wrappers.cc:217-296): best path -> words / alignment / weight, raw lattice,
 // optional DeterminizeLatticePhonePrunedWrapper.
-static void HostTail(BatchDecoder *b, int u, hipStream_t cs) {
+static void HostTail(BatchDecoder *b, int u, hipStream_t cs) {      // u: the queue's utterance number = position in `kept`
   const auto t0 = std::chrono::steady_clock::now();
-  UttOut &o = b->out[u];
+  UttOut &o = b->out[b->kept[u]];
   int rc = kamd_decoder_queue_result(b->dec, u, &o.rec);
   if (rc == KAMD_OK)
     rc = kamd_decoder_queue_fetch_lattice(b->dec, u, cs, &o.num_states, &o.num_arcs, &o.start, &o.st_frame, &o.st_hclg, &o.st_cost,
@@ -217,20 +220,31 @@ int kamd_batch_decoder_load(kamd_batch_decoder *h, const float *waves, const int
   if (kamd_nnet_ivector_dim(b->nnet) > 0) return kamd::SetError(KAMD_ERR_ARG, "the model has an ivector input: use kamd_batch_decoder_load_features");
   for (kamd::UttOut &o : b->out) o.Clear();
   b->n_utts = 0; b->from_features = false; b->have_iv = false;
-  b->wave_off.assign(h_wave_off, h_wave_off + n_utts + 1);
-  b->feat_off.assign(n_utts + 1, 0); b->out_off.assign(n_utts + 1, 0);
+  b->kept.clear(); b->skipped.clear();
+  b->wave_off.assign(1, 0); b->feat_off.assign(1, 0); b->out_off.assign(1, 0);
   for (int u = 0; u < n_utts; u++) {
-    const int T = kamd_feat_num_frames(b->feat, h_wave_off[u + 1] - h_wave_off[u]);
-    if (T <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d too short for one frame", u);
-    b->feat_off[u + 1] = b->feat_off[u] + T;
-    b->out_off[u + 1] = b->out_off[u] + kamd_nnet_num_output_frames(b->nnet, T);
+    const int64_t len = h_wave_off[u + 1] - h_wave_off[u];
+    const int T = len > 0 ? kamd_feat_num_frames(b->feat, len) : 0;
+    if (len < 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d: negative length", u);
+    if (T <= 0) { b->skipped.push_back(u); continue; }
+    b->kept.push_back(u);
+    b->wave_off.push_back(b->wave_off.back() + len);
+    b->feat_off.push_back(b->feat_off.back() + T);
+    b->out_off.push_back(b->out_off.back() + kamd_nnet_num_output_frames(b->nnet, T));
   }
-  const size_t ns = static_cast<size_t>(h_wave_off[n_utts] - h_wave_off[0]);
-  if (kamd::GrowDev(&b->d_waves, &b->waves_cap, ns) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&b->d_feats, &b->feats_cap, static_cast<size_t>(b->feat_off[n_utts]) * b->ld_feat) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&b->d_ll, &b->ll_cap, static_cast<size_t>(b->out_off[n_utts]) * b->P) != KAMD_OK) return KAMD_ERR_HIP;
-  KAMD_HIP(hipMemcpy(b->d_waves, waves + h_wave_off[0], ns * sizeof(float), hipMemcpyHostToDevice));
-  if (h_wave_off[0] != 0) for (int u = 0; u <= n_utts; u++) b->wave_off[u] -= h_wave_off[0];
+  const size_t ns = static_cast<size_t>(b->wave_off.back());
+  if (kamd::GrowDev(&b->d_waves, &b->waves_cap, std::max<size_t>(ns, 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&b->d_feats, &b->feats_cap, std::max<size_t>(static_cast<size_t>(b->feat_off.back()) * b->ld_feat, 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&b->d_ll, &b->ll_cap, std::max<size_t>(static_cast<size_t>(b->out_off.back()) * b->P, 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (b->skipped.empty()) {
+    if (ns) KAMD_HIP(hipMemcpy(b->d_waves, waves + h_wave_off[0], ns * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    for (size_t k = 0; k < b->kept.size(); k++) {
+      const int u = b->kept[k];
+      KAMD_HIP(hipMemcpy(b->d_waves + b->wave_off[k], waves + h_wave_off[u], static_cast<size_t>(h_wave_off[u + 1] - h_wave_off[u]) * sizeof(float),
+                         hipMemcpyHostToDevice));
+    }
+  }
   b->out.resize(n_utts);
   b->n_utts = n_utts;
   return KAMD_OK;
@@ -246,22 +260,30 @@ int kamd_batch_decoder_load_features(kamd_batch_decoder *h, const float *feats, 
     return kamd::SetError(KAMD_ERR_ARG, "model expects ivector dim %d, got %d", want_iv, ivectors ? ivector_dim : 0);
   for (kamd::UttOut &o : b->out) o.Clear();
   b->n_utts = 0;
-  b->feat_off.assign(n_utts + 1, 0); b->out_off.assign(n_utts + 1, 0);
+  b->kept.clear(); b->skipped.clear();
+  b->feat_off.assign(1, 0); b->out_off.assign(1, 0);
   for (int u = 0; u < n_utts; u++) {
     const int64_t T = row_off[u + 1] - row_off[u];
-    if (T <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no feature rows", u);   // "Zero-length utterance", nnet3-latgen-faster-batch.cc:184
-    b->feat_off[u + 1] = b->feat_off[u] + T;
-    b->out_off[u + 1] = b->out_off[u] + kamd_nnet_num_output_frames(b->nnet, static_cast<int>(T));
+    if (T < 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d: negative length", u);
+    if (T == 0) { b->skipped.push_back(u); continue; }        // "Zero-length utterance", nnet3-latgen-faster-batch.cc:184
+    b->kept.push_back(u);
+    b->feat_off.push_back(b->feat_off.back() + T);
+    b->out_off.push_back(b->out_off.back() + kamd_nnet_num_output_frames(b->nnet, static_cast<int>(T)));
   }
-  const size_t rows = static_cast<size_t>(b->feat_off[n_utts]);
-  if (kamd::GrowDev(&b->d_feats, &b->feats_cap, rows * b->ld_feat) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&b->d_ll, &b->ll_cap, static_cast<size_t>(b->out_off[n_utts]) * b->P) != KAMD_OK) return KAMD_ERR_HIP;
-  KAMD_HIP(hipMemset(b->d_feats, 0, rows * b->ld_feat * sizeof(float)));
-  KAMD_HIP(hipMemcpy2D(b->d_feats, b->ld_feat * sizeof(float), feats + static_cast<size_t>(row_off[0]) * dim, dim * sizeof(float),
-                       dim * sizeof(float), rows, hipMemcpyHostToDevice));
-  if (want_iv > 0) {
-    if (kamd::GrowDev(&b->d_iv, &b->iv_cap, static_cast<size_t>(n_utts) * want_iv) != KAMD_OK) return KAMD_ERR_HIP;
-    KAMD_HIP(hipMemcpy(b->d_iv, ivectors, static_cast<size_t>(n_utts) * want_iv * sizeof(float), hipMemcpyHostToDevice));
+  const size_t rows = static_cast<size_t>(b->feat_off.back());       // rows of empty utterances: none, so the rest stay contiguous
+  if (kamd::GrowDev(&b->d_feats, &b->feats_cap, std::max<size_t>(rows * b->ld_feat, 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&b->d_ll, &b->ll_cap, std::max<size_t>(static_cast<size_t>(b->out_off.back()) * b->P, 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (rows) {
+    KAMD_HIP(hipMemset(b->d_feats, 0, rows * b->ld_feat * sizeof(float)));
+    KAMD_HIP(hipMemcpy2D(b->d_feats, b->ld_feat * sizeof(float), feats + static_cast<size_t>(row_off[0]) * dim, dim * sizeof(float),
+                         dim * sizeof(float), rows, hipMemcpyHostToDevice));
+  }
+  if (want_iv > 0 && !b->kept.empty()) {
+    std::vector<float> iv(b->kept.size() * static_cast<size_t>(want_iv));
+    for (size_t k = 0; k < b->kept.size(); k++)
+      memcpy(&iv[k * want_iv], ivectors + static_cast<size_t>(b->kept[k]) * want_iv, sizeof(float) * want_iv);
+    if (kamd::GrowDev(&b->d_iv, &b->iv_cap, iv.size()) != KAMD_OK) return KAMD_ERR_HIP;
+    KAMD_HIP(hipMemcpy(b->d_iv, iv.data(), iv.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   b->from_features = true; b->have_iv = want_iv > 0;
   b->out.resize(n_utts);
@@ -271,9 +293,22 @@ int kamd_batch_decoder_load_features(kamd_batch_decoder *h, const float *feats, 
 
 int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
-  const int n = b->n_utts;
-  if (n <= 0) return kamd::SetError(KAMD_ERR_STATE, "no test set loaded");
+  if (b->n_utts <= 0) return kamd::SetError(KAMD_ERR_STATE, "no test set loaded");
+  const int n = static_cast<int>(b->kept.size());
   for (kamd::UttOut &o : b->out) o.Clear();
+  for (int u : b->skipped) {
+    kamd::UttOut &o = b->out[u];
+    memset(&o.rec, 0, sizeof(o.rec));
+    o.status = KAMD_ERR_ARG; o.message = "utterance " + std::to_string(u) + ": too short for one frame"; o.done = 1;
+  }
+  if (n == 0) {
+    kamd_batch_stats s;
+    memset(&s, 0, sizeof(s));
+    s.n_failed = static_cast<int32_t>(b->skipped.size());
+    b->last = s;
+    if (stats) *stats = s;
+    return KAMD_OK;
+  }
   const auto t0 = std::chrono::steady_clock::now();
   hipStream_t st = b->s_main;
   KAMD_HIP(hipEventRecord(b->ev[0], st));
@@ -359,7 +394,7 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   s.first_result_ms = static_cast<float>(t_first_done);
   s.nnet_flops = flops; s.lanes = lanes; s.nnet_passes = passes;
   double host_sum = 0;
-  for (int u = 0; u < n; u++) {
+  for (int u = 0; u < b->n_utts; u++) {
     if (b->out[u].status != KAMD_OK) s.n_failed++;
     host_sum += b->out[u].host_ms;
   }
@@ -417,10 +452,14 @@ const kamd_compact_lattice *kamd_batch_decoder_get_compact_lattice(kamd_batch_de
 int kamd_batch_decoder_get_loglikes(kamd_batch_decoder *h, int utt, float *out, int rows_cap, int *rows, int *cols) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
   if (utt < 0 || utt >= b->n_utts) return kamd::SetError(KAMD_ERR_ARG, "bad utterance index");
-  const int r = static_cast<int>(b->out_off[utt + 1] - b->out_off[utt]);
-  *rows = r; *cols = b->P;
+  const std::vector<int>::const_iterator it = std::lower_bound(b->kept.begin(), b->kept.end(), utt);
+  *rows = 0; *cols = b->P;
+  if (it == b->kept.end() || *it != utt) return KAMD_OK;                 // too short for one frame: no rows
+  const size_t k = static_cast<size_t>(it - b->kept.begin());
+  const int r = static_cast<int>(b->out_off[k + 1] - b->out_off[k]);
+  *rows = r;
   if (r > rows_cap) return kamd::SetError(KAMD_ERR_ARG, "buffer too small");
-  KAMD_HIP(hipMemcpy(out, b->d_ll + static_cast<size_t>(b->out_off[utt]) * b->P, static_cast<size_t>(r) * b->P * sizeof(float), hipMemcpyDeviceToHost));
+  KAMD_HIP(hipMemcpy(out, b->d_ll + static_cast<size_t>(b->out_off[k]) * b->P, static_cast<size_t>(r) * b->P * sizeof(float), hipMemcpyDeviceToHost));
   return KAMD_OK;
 }
 

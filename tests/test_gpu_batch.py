@@ -123,3 +123,41 @@ def test_batch_decoder_accepts_feature_matrices_and_ivectors():
         o = orc.Decoder(g, cfg, 2)
         o.Decode(ll)
         assert lattices_equal(bi.raw_lattice(u), o.GetRawLattice())
+
+
+def test_utterances_too_short_for_a_frame_fail_alone():
+    """nnet3-latgen-faster-batch.cc:184-188 warns "Zero-length utterance" and goes on: an utterance with no frame must not
+    take the shard down; the others decode as if it were not there."""
+    from kaldi_amd import feat
+    g, model, cfg, waves = _setup(n=6, seed=13)
+    short = [np.zeros(0, np.float32), waves[0][:100]]                   # no samples at all; 100 samples < one 25 ms window
+    mixed = [waves[0], short[0], waves[1], waves[2], short[1], waves[3], waves[4], waves[5]]
+    bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=4.0, resident_lanes=3, host_threads=2, keep_raw_lattices=True)
+    bd.load(waves)
+    bd.run()
+    want = [bd.raw_lattice(u) for u in range(len(waves))]
+    bd.load(mixed)
+    st = bd.run()
+    assert st.n_failed == 2
+    pos = [0, 2, 3, 5, 6, 7]
+    for k, u in enumerate(pos):
+        assert lattices_equal(bd.raw_lattice(u), want[k])
+        np.testing.assert_array_equal(bd.loglikes(u).shape[1], g.num_pdfs)
+    for u in (1, 4):
+        assert bd.output(u) is None and bd.loglikes(u).shape[0] == 0
+        with pytest.raises(Exception):
+            bd.raw_lattice(u)
+    # the same through the feature-matrix entry
+    mf = feat.Mfcc(abi.mfcc_opts_hires())
+    feats = [mf.ComputeFeatures(w) for w in waves]
+    mixed_f = [feats[0], np.zeros((0, 40), np.float32), feats[1], feats[2], feats[3], np.zeros((0, 40), np.float32), feats[4], feats[5]]
+    bf = batch.NnetBatchDecoder(None, model, g, cfg, max_seconds=4.0, resident_lanes=3, host_threads=2, keep_raw_lattices=True)
+    bf.load_features(mixed_f)
+    st = bf.run()
+    assert st.n_failed == 2
+    for k, u in enumerate([0, 2, 3, 4, 6, 7]):
+        assert lattices_equal(bf.raw_lattice(u), want[k])
+    # nothing but short utterances: a run that decodes nothing and says so
+    bd.load(short)
+    st = bd.run()
+    assert st.n_failed == 2 and bd.output(0) is None
