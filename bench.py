@@ -450,13 +450,15 @@ def main():
     words = [bd.output(u) for u in range(min(n, 200))]
     mean_words = float(np.mean([len(w["words"]) for w in words if w is not None])) if any(w is not None for w in words) else 0.0
     dec_roof = {"bound": "hbm", "kernel": "kamd::DecodeQueueKernel", "achieved": alg_bytes / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": alg_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
+                "unit": "GB/s", "frac": alg_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args, "decode_queue"),
                 "traffic_source": "profiles/*_pmc.json of this workload (rocprofv3 --pmc passes), not this run",
                 "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": dec_ms, "lanes": int(st.lanes),
                 "us_per_frame_per_lane": 1e3 * dec_ms * int(st.lanes) / max(frames, 1)}
-    nnet_roof = {"bound": "mfma", "kernel": "kamd::TdnnGemmKernel (all layers of all passes)", "achieved": st.nnet_flops / (nnet_ms * 1e-3) / 1e12,
+    nnet_roof = {"bound": "mfma", "kernel": "kamd::TdnnGemmDmaKernel (all layers of all passes)", "achieved": st.nnet_flops / (nnet_ms * 1e-3) / 1e12,
                  "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": st.nnet_flops / (nnet_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                 "traffic": None, "flops_per_step": st.nnet_flops, "stage_ms": nnet_ms, "passes": int(st.nnet_passes)}
+                 "traffic": pmc_traffic(args, "gemm_all_layers"),
+                 "traffic_source": "profiles/*_pmc.json of this workload (rocprofv3 --pmc passes), not this run; bytes per step over all GEMM launches",
+                 "flops_per_step": st.nnet_flops, "stage_ms": nnet_ms, "passes": int(st.nnet_passes)}
     dominant_is_decoder = dec_ms >= nnet_ms
     out = {
         "metric": "decode RTF (audio-sec/wall-sec)",
@@ -508,9 +510,9 @@ def main():
     sys.stdout.flush()
 
 
-def pmc_traffic(args):
-    """HBM bytes per DecodeQueueKernel launch from the committed rocprofv3 PMC passes
-    (profiles/*_pmc.json), only when they were taken on this exact workload."""
+def pmc_traffic(args, which):
+    """HBM bytes per step of one kernel family ("decode_queue": one DecodeQueueKernel launch; "gemm_all_layers") from the
+    committed rocprofv3 PMC passes (profiles/*_pmc.json), only when they were taken on this exact workload."""
     key = "%s/%s/%d/%s/%s" % (args.workload, args.graph, args.utts, args.ll_std, args.lm_scale)
     best = None
     pdir = os.path.join(ROOT, "profiles")
@@ -521,8 +523,8 @@ def pmc_traffic(args):
                     d = json.load(open(os.path.join(pdir, f)))
                 except Exception:
                     continue
-                if d.get("workload_key") == key:
-                    best = d.get("traffic_bytes_per_launch")
+                if d.get("workload_key") == key and which in d:
+                    best = d[which].get("traffic_bytes_per_step")
     return best
 
 
