@@ -147,14 +147,18 @@ def build_workload(args):
     return g, model, durs, cfg, time.time() - t0
 
 
-def calibrate(model, target_std):
+def calibrate(model, target_std, extractor=None):
     """Random weights give arbitrary output scale; rescale the output layer so that the
     per-frame spread of the log-likelihoods across pdfs is `target_std` nats (chain models
     in the wild: a few nats).  Runs on the GPU (this is workload synthesis, not parity)."""
     from kaldi_amd import abi, decoder, feat, synth
     w = synth.make_waves_fast([3.0], seed=424242)[0]
     f = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(w)
-    ll = decoder.Nnet(model).Forward(f)
+    ivd = model.layers[0].ivector_dim
+    iv = None
+    if ivd:      # a typical i-vector (the last one of the sample), not zeros: it shifts every output (tools/online_latency.py)
+        iv = extractor.extract_online(f)[-1] if extractor is not None else np.zeros(ivd, np.float32)
+    ll = decoder.Nnet(model).Forward(f, ivector=iv) if ivd else decoder.Nnet(model).Forward(f)
     spread = float(np.mean(np.std(ll, axis=1)))
     k = target_std / spread
     out = model.layers[-1]

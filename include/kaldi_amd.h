@@ -835,6 +835,13 @@ int kamd_decoder_partial_best_paths(kamd_decoder *d, const int32_t *lanes, int n
  * kamd_decoder_sync. */
 int kamd_decoder_frame_tracebacks(kamd_decoder *d, const int32_t *lanes, int n, int32_t *tids, int32_t *tokens,
                                   int cap, int32_t *counts);
+/* The same, incrementally: the decoder remembers (on the device, per lane) the token it reported for every frame, and
+ * a walk stops at the first frame whose token is the remembered one -- the reference's own stopping rule
+ * (online-ivector-feature.cc:489-496), so a tick costs the few frames whose best path changed, not the whole
+ * utterance.  n_decoded[i] = NumFramesDecoded (-1: no token alive); n_entries[i] = pairs written for lane i, newest
+ * frame first, the LAST one being the frame that matched (or frame 0).  kamd_decoder_init forgets a lane's record. */
+int kamd_decoder_frame_tracebacks_incremental(kamd_decoder *d, const int32_t *lanes, int n, int32_t *tids,
+                                              int32_t *tokens, int cap, int32_t *n_decoded, int32_t *n_entries);
 /* ---- OnlineSilenceWeighting (online2/online-ivector-feature.h:404-535) + the delta-weight queue of
  * OnlineIvectorFeature (UpdateFrameWeights / UpdateStatsUntilFrameWeighted, .cc:159-174, 263-306), one object per
  * utterance.  tid_is_silence[tid] = 1 when TransitionIdToPhone(tid) is one of --silence-phones (index 0 unused);

@@ -2189,24 +2189,42 @@ __global__ __launch_bounds__(NT, 4) void TracebackBatchKernel(DecDev d, const in
 // emitting arc that consumed the frame and the token it left.  A token is named by its HCLG state: a frame holds one
 // token per state and a frame's tokens are only ever deleted, so (frame, state) identifies a token exactly as the
 // reference's pointer comparison does.  out[b][k] = {ilabel, state} for frame (count - 1 - k); head[b] = count or -1.
-__global__ __launch_bounds__(NT, 4) void FrameTraceKernel(DecDev d, const int *lanes, int2 *out, int out_cap, int *head) {
+__global__ __launch_bounds__(NT, 4) void FrameTraceKernel(DecDev d, const int *lanes, const int *known, int *prev_tok, int prev_stride,
+                                                       int2 *out, int out_cap, int *head) {
   __shared__ Sh sh;
   const int b = blockIdx.x, tid = threadIdx.x;
   const Ctx c = MakeCtx(d, lanes[b]);
   InitSh(&sh);
   int2 *o = out + static_cast<size_t>(b) * out_cap;
+  // incremental form (prev_tok != NULL): prev[f] = the token recorded for frame f by the previous call, valid for
+  // f < known[b].  The walk stops at the first frame whose token is the recorded one -- from there back the path is
+  // what it was (the reference's own stopping rule, online-ivector-feature.cc:489-496) -- and that entry is the last
+  // one written.  A frame's new token is stored one visit later: by then every thread has passed the barriers of the
+  // next link search, i.e. has made its own comparison against the old value.
+  int *prev = prev_tok ? prev_tok + static_cast<size_t>(lanes[b]) * prev_stride : NULL;
+  const int n_known = prev ? known[b] : 0;
   float fc = 0.0f;
-  int n = -1, n_emit = 0;
+  int n = -1, n_emit = 0, pend_frame = -1, pend_state = 0;
   if (!c.st->error && !c.st->finalized) {
-    n = WalkBestPath(d, c, &sh, 0, &fc, [&](int, const Link &L, bool emitting, int) {
-      if (emitting) {
-        if (tid == 0 && n_emit < out_cap) o[n_emit] = make_int2(L.ilabel, c.tok_state[L.src]);
-        n_emit++;
+    n = WalkBestPath(d, c, &sh, 0, &fc, [&](int, const Link &L, bool emitting, int f) {
+      if (!emitting) return true;
+      const int frame = f - 1, state = c.tok_state[L.src];
+      if (tid == 0 && pend_frame >= 0) prev[pend_frame] = pend_state;
+      pend_frame = -1;
+      if (tid == 0 && n_emit < out_cap) o[n_emit] = make_int2(L.ilabel, state);
+      n_emit++;
+      if (prev) {
+        if (frame < n_known && prev[frame] == state) return false;
+        if (frame < prev_stride) { pend_frame = frame; pend_state = state; }
       }
       return true;
     });
+    if (prev) {
+      __syncthreads();
+      if (tid == 0 && pend_frame >= 0) prev[pend_frame] = pend_state;
+    }
   }
-  if (tid == 0) head[b] = n < 0 ? -1 : n_emit;
+  if (tid == 0) { head[2 * b] = n < 0 ? -1 : c.st->frame; head[2 * b + 1] = n_emit; }
 }
 
 // TrailingSilenceLength (online2/online-endpoint.cc:71-102) for a batch of un-finalized lanes: the best path
@@ -2261,6 +2279,8 @@ struct Decoder {
   hipStream_t last_stream = NULL;
   void *d_path = NULL; int path_cap = 0;   // partial best path: {n, final cost, pad} + arcs
   void *d_paths = NULL; size_t paths_cap = 0;   // partial best paths of many lanes (kamd_decoder_partial_best_paths)
+  int *d_trace_tok = NULL; int trace_stride = 0; // incremental frame tracebacks: the token recorded per lane and frame ...
+  std::vector<int> trace_known;                  // ... and how many frames of it are valid (0 after InitDecoding)
   unsigned char *d_sil_tid = NULL; int n_sil_tids = 0; int *d_sil_out = NULL; int sil_out_cap = 0;   // endpointing
   // work queue (kamd_decoder_queue_*)
   unsigned char *d_pool = NULL; unsigned long long pool_cap = 0;
@@ -2489,6 +2509,7 @@ void kamd_decoder_destroy(kamd_decoder *h) {
   if (!D) return;
   for (size_t i = 0; i < D->allocs.size(); i++) (void)hipFree(D->allocs[i]);
   if (D->d_path) (void)hipFree(D->d_path);
+  if (D->d_trace_tok) (void)hipFree(D->d_trace_tok);
   if (D->d_paths) (void)hipFree(D->d_paths);
   if (D->d_sil_tid) (void)hipFree(D->d_sil_tid);
   if (D->d_sil_out) (void)hipFree(D->d_sil_out);
@@ -2597,6 +2618,7 @@ int kamd_decoder_init(kamd_decoder *h, const int32_t *lanes, int n, void *stream
   hipLaunchKernelGGL(kamd::InitKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes);
   KAMD_HIP(hipGetLastError());
   D->last_stream = st; D->cached_lane = -1; D->n_timed = 0;
+  if (!D->trace_known.empty()) for (int i = 0; i < n; i++) D->trace_known[lanes[i]] = 0;     // a new utterance: nothing recorded
   return KAMD_OK;
 }
 
@@ -2913,8 +2935,8 @@ int kamd_decoder_partial_best_paths(kamd_decoder *h, const int32_t *lanes, int n
   return rc;
 }
 
-int kamd_decoder_frame_tracebacks(kamd_decoder *h, const int32_t *lanes, int n, int32_t *tids, int32_t *tokens, int cap, int32_t *counts) {
-  Decoder *D = reinterpret_cast<Decoder *>(h);
+static int FrameTracebacks(Decoder *D, const int32_t *lanes, int n, int incremental, int32_t *tids, int32_t *tokens, int cap,
+                           int32_t *n_decoded, int32_t *n_entries) {
   if (n <= 0) return KAMD_OK;
   if (CheckLanes(D, lanes, n) != KAMD_OK || EnsureTaskBuf(D, n) != KAMD_OK) return KAMD_ERR_ARG;
   int max_frame = 0;
@@ -2923,9 +2945,9 @@ int kamd_decoder_frame_tracebacks(kamd_decoder *h, const int32_t *lanes, int n, 
     max_frame = std::max(max_frame, D->h_st[lanes[i]].frame);
   }
   const int dcap = max_frame + 1;
-  const size_t pair_bytes = static_cast<size_t>(n) * dcap * sizeof(int2), head_bytes = static_cast<size_t>(n) * 4;
-  if (pair_bytes + head_bytes > D->paths_cap) {
-    const size_t grow = std::max(pair_bytes + head_bytes, 2 * D->paths_cap);
+  const size_t pair_bytes = static_cast<size_t>(n) * dcap * sizeof(int2), head_bytes = static_cast<size_t>(n) * 8, known_bytes = static_cast<size_t>(n) * 4;
+  if (pair_bytes + head_bytes + known_bytes > D->paths_cap) {
+    const size_t grow = std::max(pair_bytes + head_bytes + known_bytes, 2 * D->paths_cap);
     if (D->d_paths) (void)hipFree(D->d_paths);
     D->d_paths = NULL; D->paths_cap = 0;
     KAMD_HIP(hipMalloc(&D->d_paths, grow));
@@ -2933,27 +2955,57 @@ int kamd_decoder_frame_tracebacks(kamd_decoder *h, const int32_t *lanes, int n, 
   }
   int2 *d_pairs = static_cast<int2 *>(D->d_paths);
   int *d_head = reinterpret_cast<int *>(static_cast<char *>(D->d_paths) + pair_bytes);
+  int *d_known = d_head + 2 * n;
   hipStream_t st = D->last_stream;
+  std::vector<int> known(n, 0);
+  if (incremental) {
+    if (!D->d_trace_tok) {
+      D->trace_stride = D->sizes.max_frames + 2;
+      KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_trace_tok), static_cast<size_t>(D->sizes.max_lanes) * D->trace_stride * sizeof(int)));
+      D->trace_known.assign(D->sizes.max_lanes, 0);
+    }
+    for (int i = 0; i < n; i++) known[i] = D->trace_known[lanes[i]];
+    KAMD_HIP(hipMemcpyAsync(d_known, known.data(), known_bytes, hipMemcpyHostToDevice, st));
+  }
   KAMD_HIP(hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
-  hipLaunchKernelGGL(kamd::FrameTraceKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes, d_pairs, dcap, d_head);
-  std::vector<int> head(n);
-  std::vector<int2> pairs(static_cast<size_t>(n) * dcap);
+  hipLaunchKernelGGL(kamd::FrameTraceKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes, d_known, incremental ? D->d_trace_tok : NULL,
+                     D->trace_stride, d_pairs, dcap, d_head);
+  std::vector<int> head(2 * static_cast<size_t>(n));
   KAMD_HIP(hipMemcpyAsync(head.data(), d_head, head_bytes, hipMemcpyDeviceToHost, st));
-  KAMD_HIP(hipMemcpyAsync(pairs.data(), d_pairs, pair_bytes, hipMemcpyDeviceToHost, st));
   if (hipStreamSynchronize(st) != hipSuccess) return kamd::SetError(KAMD_ERR_HIP, "traceback kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  int longest = 0;
   for (int i = 0; i < n; i++) {
-    counts[i] = head[i];
-    if (head[i] > dcap)
+    if (head[2 * i + 1] > dcap)
       return kamd::SetError(KAMD_ERR_STATE, "lane %d advanced since the last kamd_decoder_sync (%d frames on the path, %d known): sync first", lanes[i],
-                            head[i], dcap);
-    if (head[i] > cap) return kamd::SetError(KAMD_ERR_ARG, "lane %d: %d frames decoded, room for %d", lanes[i], head[i], cap);
-    for (int k = 0; k < head[i]; k++) {
-      tids[static_cast<size_t>(i) * cap + k] = pairs[static_cast<size_t>(i) * dcap + k].x;
-      tokens[static_cast<size_t>(i) * cap + k] = pairs[static_cast<size_t>(i) * dcap + k].y;
+                            head[2 * i + 1], dcap);
+    if (head[2 * i + 1] > cap) return kamd::SetError(KAMD_ERR_ARG, "lane %d: %d frames to report, room for %d", lanes[i], head[2 * i + 1], cap);
+    longest = std::max(longest, head[2 * i + 1]);
+  }
+  std::vector<int2> pairs(static_cast<size_t>(n) * std::max(longest, 1));
+  if (longest > 0)      // one strided copy of the used prefix of every lane's segment
+    KAMD_HIP(hipMemcpy2D(pairs.data(), static_cast<size_t>(longest) * sizeof(int2), d_pairs, static_cast<size_t>(dcap) * sizeof(int2),
+                         static_cast<size_t>(longest) * sizeof(int2), n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) {
+    n_decoded[i] = head[2 * i];
+    const int m = head[2 * i] < 0 ? 0 : head[2 * i + 1];
+    if (n_entries) n_entries[i] = m;
+    for (int k = 0; k < m; k++) {
+      tids[static_cast<size_t>(i) * cap + k] = pairs[static_cast<size_t>(i) * longest + k].x;
+      tokens[static_cast<size_t>(i) * cap + k] = pairs[static_cast<size_t>(i) * longest + k].y;
     }
+    if (incremental && head[2 * i] >= 0) D->trace_known[lanes[i]] = std::min(head[2 * i], D->trace_stride);
   }
   return KAMD_OK;
+}
+
+int kamd_decoder_frame_tracebacks(kamd_decoder *h, const int32_t *lanes, int n, int32_t *tids, int32_t *tokens, int cap, int32_t *counts) {
+  return FrameTracebacks(reinterpret_cast<Decoder *>(h), lanes, n, 0, tids, tokens, cap, counts, NULL);
+}
+
+int kamd_decoder_frame_tracebacks_incremental(kamd_decoder *h, const int32_t *lanes, int n, int32_t *tids, int32_t *tokens, int cap,
+                                              int32_t *n_decoded, int32_t *n_entries) {
+  return FrameTracebacks(reinterpret_cast<Decoder *>(h), lanes, n, 1, tids, tokens, cap, n_decoded, n_entries);
 }
 
 int kamd_decoder_get_phase_cycles(kamd_decoder *h, int lane, uint64_t cycles[16]) {

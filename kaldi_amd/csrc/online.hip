@@ -489,9 +489,10 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
     int longest = 0;
     for (int i = 0; i < n; i++)
       if (b->decoded[streams[i]] > 0) { tl.push_back(streams[i]); longest = std::max(longest, b->decoded[streams[i]]); }
-    std::vector<int32_t> tids(tl.size() * static_cast<size_t>(longest)), toks(tids.size()), cnt(tl.size());
+    std::vector<int32_t> tids(tl.size() * static_cast<size_t>(longest)), toks(tids.size()), cnt(tl.size()), n_new(tl.size());
     if (!tl.empty()) {
-      int rc = kamd_decoder_frame_tracebacks(b->dec, tl.data(), static_cast<int>(tl.size()), tids.data(), toks.data(), longest, cnt.data());
+      int rc = kamd_decoder_frame_tracebacks_incremental(b->dec, tl.data(), static_cast<int>(tl.size()), tids.data(), toks.data(), longest,
+                                                         cnt.data(), n_new.data());
       if (rc != KAMD_OK) return rc;
     }
     size_t k = 0;
@@ -500,7 +501,7 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
       if (b->decoded[s] > 0) {
         if (cnt[k] != b->decoded[s])
           return kamd::SetError(KAMD_ERR_STATE, "stream %d: best path covers %d of %d decoded frames", s, cnt[k], b->decoded[s]);
-        int rc = kamd_silence_weighting_compute_traceback(b->sw[s], b->decoded[s], tids.data() + k * longest, toks.data() + k * longest, cnt[k]);
+        int rc = kamd_silence_weighting_compute_traceback(b->sw[s], b->decoded[s], tids.data() + k * longest, toks.data() + k * longest, n_new[k]);
         if (rc != KAMD_OK) return rc;
         k++;
       }

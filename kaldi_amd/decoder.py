@@ -354,15 +354,22 @@ def partial_best_paths(dec, lanes, use_final_probs=False):
                                         acoustic_cost=float(a[i])) for i in range(ln.size)]
 
 
-def frame_tracebacks(dec, lanes):
+def frame_tracebacks(dec, lanes, incremental=False):
     """What OnlineSilenceWeighting::ComputeCurrentTraceback reads off the decoder, for several un-finalized lanes in
-    one launch -> per lane (tids, tokens), newest frame first (None: no token alive)"""
+    one launch -> per lane (tids, tokens), newest frame first (None: no token alive).  incremental: only down to the
+    first frame whose token is the one the previous incremental call reported (that entry included) ->
+    (tids, tokens, frames decoded)."""
     ln = np.ascontiguousarray(lanes, np.int32)
     if ln.size == 0:
         return []
     cap = max(1, max(lib().kamd_decoder_num_frames_decoded(dec, int(l)) for l in ln))
     tids, toks = np.zeros((ln.size, cap), np.int32), np.zeros((ln.size, cap), np.int32)
     cnt = np.zeros(ln.size, np.int32)
+    if incremental:
+        m = np.zeros(ln.size, np.int32)
+        check(lib().kamd_decoder_frame_tracebacks_incremental(dec, abi.iptr(ln), ln.size, abi.iptr(tids), abi.iptr(toks), cap, abi.iptr(cnt),
+                                                              abi.iptr(m)))
+        return [None if cnt[i] < 0 else (tids[i, :m[i]].copy(), toks[i, :m[i]].copy(), int(cnt[i])) for i in range(ln.size)]
     check(lib().kamd_decoder_frame_tracebacks(dec, abi.iptr(ln), ln.size, abi.iptr(tids), abi.iptr(toks), cap, abi.iptr(cnt)))
     return [None if cnt[i] < 0 else (tids[i, :cnt[i]].copy(), toks[i, :cnt[i]].copy()) for i in range(ln.size)]
 

@@ -505,6 +505,7 @@ def test_frame_tracebacks_equal_the_oracle_traceback():
     s = online.SingleUtteranceNnet3Decoder(op, N, G, cfg, sizes=abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512))
     s.record_loglikes()
     prev, rewrites = None, 0
+    remembered, cut = {}, 0
     for i in range(0, w.size, CHUNK):
         s.AcceptWaveform(16000, w[i:i + CHUNK])
         if not s.AdvanceDecoding():
@@ -518,12 +519,26 @@ def test_frame_tracebacks_equal_the_oracle_traceback():
         want = lat.best_path_frames()
         assert len(want) == s.NumFramesDecoded() == tids.size
         assert [(int(a), int(b)) for a, b in zip(tids, toks)] == want
+        # the incremental form: the same walk, cut at the first frame whose token the previous incremental call reported
+        (itids, itoks, n_dec), = decoder.frame_tracebacks(s.decoder._dec, [s.decoder.lane], incremental=True)
+        assert n_dec == len(want)
+        expect = []
+        for k, (t, tok) in enumerate(want):
+            frame = n_dec - 1 - k
+            expect.append((t, tok))
+            if frame in remembered and remembered[frame] == tok:
+                break
+        assert [(int(a), int(b)) for a, b in zip(itids, itoks)] == expect
+        cut += int(len(expect) < len(want))
+        for k, (t, tok) in enumerate(expect):
+            remembered[n_dec - 1 - k] = tok
         if prev is not None:
             old = prev[::-1]
             new = want[::-1][:len(old)]
             rewrites += int(old != new)
         prev = want
     assert rewrites > 0                     # the best path did change its mind about earlier frames along the way
+    assert cut > 0                          # ... and most ticks the incremental walk stopped early
 
 
 def test_streams_with_silence_weighting():

@@ -20,6 +20,8 @@ ap.add_argument("--partials", action="store_true", help="with --streams: partial
 ap.add_argument("--endpointing", action="store_true", help="with --streams: EndpointDetected for all streams after every tick (one traceback launch)")
 ap.add_argument("--ivectors", action="store_true", help="with --streams: the model takes 100-dim online i-vectors, estimated per "
                 "stream on the device (512-Gaussian UBM) and fed on DecodableNnetLoopedOnline's chunk schedule (--frames-per-chunk 20)")
+ap.add_argument("--silence-weighting", action="store_true", help="with --ivectors: --ivector-silence-weighting.* on (every second "
+                "phone counts as silence, weight 0.001, max-state-duration 100): one more traceback launch per tick")
 a = ap.parse_args()
 g = synth.make_hclg(num_units=1164, vocab=20000, n_hist=18000, fanout=(12, 64), pron_len=(3, 7), seed=2,
                     self_loop_prob=0.5, lm_scale=0.1)
@@ -41,6 +43,11 @@ if a.streams > 0:
     sb = online.StreamBatch(abi.mfcc_opts_hires(), N, G, cfg, S, max_seconds=a.seconds + 1)
     if ie is not None:
         sb.set_ivector_extractor(ie, 20)
+        if a.silence_weighting:
+            n_tids = len(g.tid2pdf) - 1
+            tid2phone = np.concatenate([[0], np.arange(n_tids) // 2 + 1]).astype(np.int32)
+            swc = online.OnlineSilenceWeightingConfig(":".join(str(p) for p in range(1, int(tid2phone.max()) + 1, 2)), 0.001, 100.0)
+            sb.set_silence_weighting(swc, tid2phone)
     step = int(a.chunk * 16000)
     ep = online.OnlineEndpointConfig()
     num_tids = len(g.tid2pdf) - 1
