@@ -817,6 +817,15 @@ kamd_compact_lattice *kamd_compact_lattice_lmrescore_const_arpa(
     const int32_t *final_str_len, const kamd_clat_arc *arcs, int32_t num_arcs, const int32_t *strings,
     const kamd_const_arpa *lm, float lm_scale);
 
+/* PruneActiveTokens in the middle of an utterance (decoder/lattice-faster-decoder.cc:519-546; the reference does it
+ * every prune_interval frames): tokens and links the final backward sweep would drop anyway -- extra cost against the
+ * current frontier above lattice_beam -- are dropped now and the survivors move to the bottom of the lane's arenas, so
+ * a long utterance needs room for its PRUNED lattice plus the frames since the last compaction, not for everything
+ * ever created.  Lanes must be un-finalized; decoding continues, the final lattice is the one an uncompacted decode
+ * gives.  kamd_decoder_lane_usage (values of the last kamd_decoder_sync) tells when it is worth it. */
+int kamd_decoder_compact(kamd_decoder *d, const int32_t *lanes, int n, void *stream);
+int kamd_decoder_lane_usage(kamd_decoder *d, int lane, int32_t *tok_used, int32_t *tok_cap, int32_t *lnk_used,
+                            int32_t *lnk_cap);
 /* Best path of an UN-finalized lane (streaming partial results):
  * LatticeFasterOnlineDecoderTpl::GetBestPath = BestPathEnd + TraceBackBestPath
  * (decoder/lattice-faster-online-decoder.cc:54-165).  Requires a prior kamd_decoder_sync. */

@@ -1636,6 +1636,13 @@ __device__ inline LinkLite Lite(const Link &L, int src_base, int dst_base) {
 // Output: tokens in tok_state / tok_map (cost bits) at [out_tok_base, tok_cap), frame by
 // frame; links at [out_lnk_base, lnk_cap) with src/dst = arena positions of the tokens.
 struct FinSh { int tok_top, lnk_top, chg[3]; };
+// MID = true is PruneActiveTokens in the middle of an utterance (lattice-faster-decoder.cc:519-546, with the exact
+// fixpoint instead of the delta tolerance): every token of the newest frame keeps extra cost 0 (PruneForwardLinks
+// :312-383), the survivors are staged exactly as above and then moved back to the bottom of the arenas with the per-frame
+// offsets rebuilt, so that AdvanceDecoding continues on a lane whose dead tokens and links are gone.  Nothing that the
+// final sweep keeps is ever dropped here: a token's extra cost against the current frontier is a lower bound of its
+// final one, and the final sweep's minima are over links this one keeps.
+template <bool MID>
 __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh *shp, FinSh *fs, unsigned char *fin_lds) {
   Sh &sh = *shp;
   int &s_tok_top = fs->tok_top, &s_lnk_top = fs->lnk_top;
@@ -1646,10 +1653,13 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
   if (S->error || S->finalized) return;
   const int F = S->frame;
   const float lattice_beam = d.cfg.lattice_beam;
-  float best_cost, best_with_final;
-  FinalCosts(d, c, &sh, F, &best_cost, &best_with_final);
+  float best_cost = 0.0f, best_with_final = 0.0f;
+  if (!MID) FinalCosts(d, c, &sh, F, &best_cost, &best_with_final);
   const bool finals_empty = best_with_final == INFINITY;                // final_costs_.empty()
   const float final_best = finals_empty ? best_cost : best_with_final;  // :583-588
+  // MID: where the rebuilt link offsets wait until the move (the tail of the lane's scratch, behind bo / xo)
+  int *nlo = reinterpret_cast<int *>(c.scratch) + 2 * d.hash_cap;
+  if (MID && 2 * F + 3 > 2 * LDS_TABLE_CAP) { if (tid == 0) atomicOr(&S->error, ERR_FRAMES); return; }
   const u32 INF_O = FloatToOrdered(INFINITY);
   u32 *bo = reinterpret_cast<u32 *>(c.scratch);                 // HBM mode: base + emitting
   u32 *xo = reinterpret_cast<u32 *>(c.scratch) + d.hash_cap;    // HBM mode: Jacobi target
@@ -1660,7 +1670,10 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
   float *stage_cost = reinterpret_cast<float *>(c.tok_map);
   // LDS: [2] ordered extra costs, [2] forward costs, [2] staged positions (frame f / frame f+1)
   u32 *l_base = reinterpret_cast<u32 *>(fin_lds);
-  if (tid == 0) { s_tok_top = c.tok_cap; s_lnk_top = c.lnk_cap; new_off[F + 1] = c.tok_cap; s_chg[0] = s_chg[1] = s_chg[2] = 0; }
+  if (tid == 0) {
+    s_tok_top = c.tok_cap; s_lnk_top = c.lnk_cap; new_off[F + 1] = c.tok_cap; s_chg[0] = s_chg[1] = s_chg[2] = 0;
+    if (MID) nlo[2 * F + 2] = c.lnk_cap;
+  }
   // registers: frame f (cur) and frame f-1 (nxt)
   LinkLite rl[FIN_PF];     // frame f, packed
   int2 nsd[FIN_PF]; float2 nga[FIN_PF];   // frame f-1 as loaded (nothing may be computed on them before the next iteration: that would wait for the loads)
@@ -1732,7 +1745,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
         if (i < nt) {
           lc[i] = rc[k];
           float b = INFINITY;
-          if (f == F) b = rc[k] + (finals_empty ? 0.0f : d.g.final[rs[k]]) - final_best;   // :430
+          if (f == F) b = MID ? 0.0f : rc[k] + (finals_empty ? 0.0f : d.g.final[rs[k]]) - final_best;   // :430 (MID: :289 extra_cost = 0)
           lx[i] = FloatToOrdered(b);
         }
       }
@@ -1760,7 +1773,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
       for (int li = max(ee, eb + n_reg) + tid; li < le; li += NT) relax_emit(Lite(c.links[li], tb, tbn));
       LdsBarrier();
       if (ee > eb) {
-        const bool last = f == F;
+        const bool last = f == F && !MID;
         auto relax_eps = [&](const LinkLite &L) -> int {
           const int ls = L.sd & 0xFFFFu, ld = L.sd >> 16;
           float lec = xval(lx, ld, last) + ((lc[ls] + L.ac + L.graph) - lc[ld]);
@@ -1787,7 +1800,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
           if (!any_changed) break;
         }
       }
-      if (f == F) {   // store the clamped values: later reads need no special case
+      if (f == F && !MID) {   // store the clamped values: later reads need no special case
         for (int i = tid; i < nt; i += NT) if (OrderedToFloat(lx[i]) > lattice_beam) lx[i] = INF_O;
         LdsBarrier();
       }
@@ -1824,27 +1837,38 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
         const int ps2 = lp[L.src - tb], pd = is_eps ? lp[L.dst - tb] : np[L.dst - tbn];
         if (ps2 < 0 || pd < 0) { atomicOr(&sh.err, ERR_INTERNAL); return; }
         L.src = ps2; L.dst = pd;
-        if (!is_eps) L.ac = L.ac - emit_off;
+        if (!is_eps && !MID) L.ac = L.ac - emit_off;
         c.links[WaveAllocDown(&s_lnk_top)] = L;
       };
-      if (slack_ok) {
-        for (int li = eb + n_reg + tid; li < le; li += NT) {
-          const Link L = c.links[li];
-          if (survives(Lite(L, tb, li < ee ? tb : tbn), li < ee)) stage_link(L, li < ee);
-        }
+      // MID: two passes, the emitting links f -> f+1 first (they end up above the frame's epsilon links: ascending, the
+      // arena then reads eps(0) | emit(1) eps(1) | emit(2) ..., the order lnk_off describes), boundaries recorded
+      for (int pass = 0; pass < (MID ? 2 : 1); pass++) {
+        auto mine = [&](int li) { return !MID || (pass == 0 ? li >= ee : li < ee); };
+        if (slack_ok) {
+          for (int li = eb + n_reg + tid; li < le; li += NT) {
+            const Link L = c.links[li];
+            if (mine(li) && survives(Lite(L, tb, li < ee ? tb : tbn), li < ee)) stage_link(L, li < ee);
+          }
 #pragma unroll
-        for (int k = 0; k < FIN_PF; k++) {
-          const int li = eb + tid + k * NT;
-          if (li < le && survives(rl[k], li < ee)) stage_link(c.links[li], li < ee);
+          for (int k = 0; k < FIN_PF; k++) {
+            const int li = eb + tid + k * NT;
+            if (li < le && mine(li) && survives(rl[k], li < ee)) stage_link(c.links[li], li < ee);
+          }
+        } else {
+          for (int hi = le; hi > eb; hi -= NT) {
+            const int li = hi - NT + tid;
+            Link L; L.src = -1; L.dst = -1; L.ilabel = 0; L.olabel = 0; L.graph = 0.f; L.ac = 0.f;
+            const bool in = li >= eb && li < le && mine(li);
+            if (in) L = c.links[li];
+            __syncthreads();   // full barrier: global reads before global writes
+            if (in && survives(Lite(L, tb, li < ee ? tb : tbn), li < ee)) stage_link(L, li < ee);
+          }
         }
-      } else {
-        for (int hi = le; hi > eb; hi -= NT) {
-          const int li = hi - NT + tid;
-          Link L; L.src = -1; L.dst = -1; L.ilabel = 0; L.olabel = 0; L.graph = 0.f; L.ac = 0.f;
-          const bool in = li >= eb && li < le;
-          if (in) L = c.links[li];
-          __syncthreads();   // full barrier: global reads before global writes
-          if (in && survives(Lite(L, tb, li < ee ? tb : tbn), li < ee)) stage_link(L, li < ee);
+        if (MID) {
+          __syncthreads();
+          const int top = s_lnk_top;       // read by everybody before the next pass allocates again
+          __syncthreads();
+          if (tid == 0) nlo[pass == 0 ? 2 * f + 2 : 2 * f + 1] = top;
         }
       }
       if (next_hbm_mode) __syncthreads(); else LdsBarrier();   // HBM mode reads tok_extra / positions from global
@@ -1859,7 +1883,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
         float b = INFINITY;
         if (f == F) {
           const float fc = finals_empty ? 0.0f : d.g.final[c.tok_state[tb + i]];
-          b = c.tok_cost[tb + i] + fc - final_best;
+          b = MID ? 0.0f : c.tok_cost[tb + i] + fc - final_best;
         }
         __hip_atomic_store(&bo[i], FloatToOrdered(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1877,7 +1901,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
       for (int i = tid; i < nt; i += NT) {
         const u32 b = LoadU32(&bo[i]);
         float v = OrderedToFloat(b);
-        if (f == F && v > lattice_beam) v = INFINITY;
+        if (f == F && !MID && v > lattice_beam) v = INFINITY;
         xcur[i] = v;
         if (ee > eb) __hip_atomic_store(&xo[i], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1896,7 +1920,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
           int changed = 0, dummy = 0;
           for (int i = tid; i < nt; i += NT) {
             float v = OrderedToFloat(LoadU32(&xo[i]));
-            if (f == F && v > lattice_beam) v = INFINITY;
+            if (f == F && !MID && v > lattice_beam) v = INFINITY;
             if (!(v == xcur[i])) changed = 1;
             xcur[i] = v;
             __hip_atomic_store(&xo[i], LoadU32(&bo[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
@@ -1926,23 +1950,27 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
       }
       __syncthreads();
       if (tid == 0) new_off[f] = s_tok_top;
-      for (int hi = le; hi > eb; hi -= NT) {
-        const int li = hi - NT + tid;
-        Link L; L.src = -1; L.dst = -1; L.ilabel = 0; L.olabel = 0; L.graph = 0.f; L.ac = 0.f;
-        const bool in = li >= eb && li < le;
-        if (in) L = c.links[li];
-        __syncthreads();
-        if (in && L.src >= 0 && L.dst >= 0) {
-          const bool is_eps = li < ee;
-          const int ps2 = gp[L.src - tb];
-          const int pd = is_eps ? gp[L.dst - tb] : gpn[L.dst - tbn];
-          if (ps2 < 0 || pd < 0) { atomicOr(&sh.err, ERR_INTERNAL); }
-          else {
-            L.src = ps2; L.dst = pd;
-            if (!is_eps) L.ac = L.ac - emit_off;
-            c.links[WaveAllocDown(&s_lnk_top)] = L;
+      for (int pass = 0; pass < (MID ? 2 : 1); pass++) {
+        for (int hi = le; hi > eb; hi -= NT) {
+          const int li = hi - NT + tid;
+          Link L; L.src = -1; L.dst = -1; L.ilabel = 0; L.olabel = 0; L.graph = 0.f; L.ac = 0.f;
+          const bool in = li >= eb && li < le && (!MID || (pass == 0 ? li >= ee : li < ee));
+          if (in) L = c.links[li];
+          __syncthreads();
+          if (in && L.src >= 0 && L.dst >= 0) {
+            const bool is_eps = li < ee;
+            const int ps2 = gp[L.src - tb];
+            const int pd = is_eps ? gp[L.dst - tb] : gpn[L.dst - tbn];
+            if (ps2 < 0 || pd < 0) { atomicOr(&sh.err, ERR_INTERNAL); }
+            else {
+              L.src = ps2; L.dst = pd;
+              if (!is_eps && !MID) L.ac = L.ac - emit_off;
+              c.links[WaveAllocDown(&s_lnk_top)] = L;
+            }
           }
         }
+        __syncthreads();
+        if (MID && tid == 0) nlo[pass == 0 ? 2 * f + 2 : 2 * f + 1] = s_lnk_top;
       }
       __syncthreads();
       prev_lds = false;
@@ -1956,6 +1984,31 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
   __syncthreads();
   for (int f = tid; f <= F + 1; f += NT) c.tok_off[f] = new_off[f] - tok_base;
   __syncthreads();
+  if (MID) {
+    // ---- move the survivors down to the bottom of the arenas (chunks: read, barrier, write -- a chunk's destination
+    // always lies below the source of every later chunk), costs back into tok_cost, link endpoints and offsets rebased
+    for (int j = tid; j <= 2 * F + 2; j += NT) c.lnk_off[j] = (j == 0 ? nlo[1] : nlo[j]) - lnk_base;
+    for (int b0 = 0; b0 < n_out_tok; b0 += NT) {
+      const int i = b0 + tid;
+      int st = 0; float co = 0.f;
+      if (i < n_out_tok) { st = c.tok_state[tok_base + i]; co = stage_cost[tok_base + i]; }
+      __syncthreads();
+      if (i < n_out_tok) { c.tok_state[i] = st; c.tok_cost[i] = co; }
+    }
+    for (int b0 = 0; b0 < n_out_link; b0 += NT) {
+      const int i = b0 + tid;
+      Link L; L.src = L.dst = L.ilabel = L.olabel = 0; L.graph = L.ac = 0.f;
+      if (i < n_out_link) L = c.links[lnk_base + i];
+      __syncthreads();
+      if (i < n_out_link) { L.src -= tok_base; L.dst -= tok_base; c.links[i] = L; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      S->tok_used = n_out_tok; S->lnk_used = n_out_link;
+      S->error |= sh.err;
+    }
+    return;
+  }
   Stamp(&sh, PH_FIN_COMPACT);
   if (tid == 0) {
     for (int i = 0; i < 16; i++) S->phase_cycles[i] += sh.ph[i];
@@ -1972,7 +2025,15 @@ __global__ __launch_bounds__(NT, 4) void FinalizeKernel2(DecDev d, const int *la
   __shared__ FinSh fs;
   extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
   const Ctx c = MakeCtx(d, lanes[blockIdx.x]);
-  FinalizeLane2(d, c, &sh, &fs, fin_lds);
+  FinalizeLane2<false>(d, c, &sh, &fs, fin_lds);
+}
+// PruneActiveTokens on un-finalized lanes (kamd_decoder_compact)
+__global__ __launch_bounds__(NT, 4) void CompactKernel(DecDev d, const int *lanes) {
+  __shared__ Sh sh;
+  __shared__ FinSh fs;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
+  const Ctx c = MakeCtx(d, lanes[blockIdx.x]);
+  FinalizeLane2<true>(d, c, &sh, &fs, fin_lds);
 }
 
 // ---------------------------------------------------------------- work queue
@@ -2025,7 +2086,7 @@ __global__ __launch_bounds__(NT, 4) void DecodeQueueKernel(DecDev d, QueueDev q)
     __syncthreads();
     AdvanceLane(d, c, &sh, dyn_lds, task);
     __syncthreads();
-    FinalizeLane2(d, c, &sh, &fs, dyn_lds);
+    FinalizeLane2<false>(d, c, &sh, &fs, dyn_lds);
     __syncthreads();
     // ---- hand the lattice out
     const int err = S->error, F = S->frame;
@@ -2484,6 +2545,8 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   if (ok && (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess ||
              hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel2),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess ||
+             hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::CompactKernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess))
     ok = false;
   if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::AdvanceKernel),
@@ -2659,6 +2722,31 @@ int kamd_decoder_finalize(kamd_decoder *h, const int32_t *lanes, int n, void *st
   else hipLaunchKernelGGL(kamd::FinalizeKernel2, dim3(n), dim3(NT), 6 * FIN_CAP * 4, st, D->dev, D->d_lanes);
   KAMD_HIP(hipGetLastError());
   D->last_stream = st; D->cached_lane = -1;
+  return KAMD_OK;
+}
+
+// PruneActiveTokens for un-finalized lanes (lattice-faster-decoder.cc:519-546): what the final sweep would drop anyway
+// is dropped now and the survivors move to the bottom of the lane's arenas; decoding goes on.  The final lattice is
+// the one an uncompacted decode gives.  A stream calls it when its arena fills up (kamd_decoder_lane_usage).
+int kamd_decoder_compact(kamd_decoder *h, const int32_t *lanes, int n, void *stream) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0) return KAMD_OK;
+  if (CheckLanes(D, lanes, n) != KAMD_OK || EnsureTaskBuf(D, n) != KAMD_OK) return KAMD_ERR_ARG;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  KAMD_HIP(hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(kamd::CompactKernel, dim3(n), dim3(NT), 6 * FIN_CAP * 4, st, D->dev, D->d_lanes);
+  KAMD_HIP(hipGetLastError());
+  D->last_stream = st; D->cached_lane = -1;
+  return KAMD_OK;
+}
+
+// as of the last kamd_decoder_sync: records in use and capacity of the lane's token and link arenas
+int kamd_decoder_lane_usage(kamd_decoder *h, int lane, int32_t *tok_used, int32_t *tok_cap, int32_t *lnk_used, int32_t *lnk_cap) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (CheckLanes(D, &lane, 1) != KAMD_OK) return KAMD_ERR_ARG;
+  *tok_used = D->h_st[lane].tok_used; *lnk_used = D->h_st[lane].lnk_used;
+  *tok_cap = D->h_tok_cap[lane]; *lnk_cap = D->h_lnk_cap[lane];
   return KAMD_OK;
 }
 

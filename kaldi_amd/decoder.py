@@ -223,6 +223,16 @@ class LatticeFasterDecoder:
         check(lib().kamd_decoder_finalize(self._dec, abi.iptr(lanes), 1, None))
         check(lib().kamd_decoder_sync(self._dec))
 
+    def PruneActiveTokens(self):
+        """lattice-faster-decoder.cc:519-546 as a compaction of the lane's arenas (kamd_decoder_compact): what the final
+        sweep would drop is dropped now; decoding goes on; the final lattice does not change."""
+        compact(self._dec, [self.lane])
+        check(lib().kamd_decoder_sync(self._dec))
+
+    def usage(self):
+        """(tokens in use, token capacity, links in use, link capacity) of the lane's arenas"""
+        return lane_usage(self._dec, self.lane)
+
     def Decode(self, decodable):
         self.InitDecoding()
         self.AdvanceDecoding(decodable)
@@ -352,6 +362,17 @@ def partial_best_paths(dec, lanes, use_final_probs=False):
                                                 abi.iptr(words), cap, abi.iptr(nw), abi.fptr(g), abi.fptr(a)))
     return [None if na[i] < 0 else dict(alignment=ali[i, :na[i]].copy(), words=words[i, :nw[i]].copy(), graph_cost=float(g[i]),
                                         acoustic_cost=float(a[i])) for i in range(ln.size)]
+
+
+def compact(dec, lanes):
+    ln = np.ascontiguousarray(lanes, np.int32)
+    check(lib().kamd_decoder_compact(dec, abi.iptr(ln), ln.size, None))
+
+
+def lane_usage(dec, lane):
+    v = [C.c_int32() for _ in range(4)]
+    check(lib().kamd_decoder_lane_usage(dec, int(lane), *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
 
 
 def frame_tracebacks(dec, lanes, incremental=False):
