@@ -692,6 +692,11 @@ int kamd_stream_batch_set_ivector_extractor(kamd_stream_batch *b, kamd_ivector_e
  * phone; silence_weight == 1 = off.  After kamd_stream_batch_set_ivector_extractor, before any stream starts. */
 int kamd_stream_batch_set_silence_weighting(kamd_stream_batch *b, const uint8_t *tid_is_silence, int n_tids,
                                             float silence_weight, float max_state_duration);
+/* Arena compaction (kamd_decoder_compact = PruneActiveTokens) for streams: a stream whose token or link arena is fuller
+ * than `fraction` at the start of a tick is compacted before it advances; default 0.5, 0 = never.  Bounds a long
+ * utterance's memory by its pruned lattice; results do not change. */
+int kamd_stream_batch_set_compaction(kamd_stream_batch *b, float fraction);
+int64_t kamd_stream_batch_num_compactions(const kamd_stream_batch *b);
 /* start with the speakers' adaptation states (n x kamd_ivector_state_size() doubles; NULL = fresh) and read a
  * stream's state back after its utterance (before LimitFrames) */
 int kamd_stream_batch_start_adapted(kamd_stream_batch *b, const int32_t *streams, int n, const double *states);

@@ -198,6 +198,10 @@ struct StreamBatch {
   std::vector<int> chunks_done, iv_done, slots_assigned;
   // OnlineSilenceWeighting, one per stream (kamd_stream_batch_set_silence_weighting); empty = off
   std::vector<kamd_silence_weighting *> sw;
+  // PruneActiveTokens as arena compaction: a stream whose token or link arena is fuller than this fraction at the start
+  // of a tick is compacted first (kamd_decoder_compact); 0 = never
+  float compact_at = 0.5f;
+  int64_t n_compactions = 0;
   int S = 0, dim = 0, ld = 0, P = 0, max_frames = 0;
   int64_t max_samples = 0;
   float *d_wave = NULL, *d_frames = NULL, *d_ll = NULL;
@@ -321,6 +325,14 @@ int kamd_stream_batch_set_silence_weighting(kamd_stream_batch *h, const uint8_t 
   }
   return KAMD_OK;
 }
+
+int kamd_stream_batch_set_compaction(kamd_stream_batch *h, float fraction) {
+  StreamBatch *b = reinterpret_cast<StreamBatch *>(h);
+  if (!(fraction >= 0.0f && fraction < 1.0f)) return kamd::SetError(KAMD_ERR_ARG, "compaction threshold must be in [0, 1)");
+  b->compact_at = fraction;
+  return KAMD_OK;
+}
+int64_t kamd_stream_batch_num_compactions(const kamd_stream_batch *h) { return reinterpret_cast<const StreamBatch *>(h)->n_compactions; }
 
 // GetAdaptationState after the utterance (online2-wav-nnet3-latgen-faster.cc:284): the i-vector statistics as they
 // are plus the speaker CMVN statistics advanced by every frame of this utterance; LimitFrames is the caller's
@@ -459,6 +471,28 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
       if (b->status[s]) return kamd::SetError(KAMD_ERR_STATE, "stream %d failed earlier (flags %d): restart it (kamd_stream_batch_start)", s, b->status[s]);
       if (kamd_feat_num_frames_flush(b->feat, b->n_samp[s], b->finished[s] ? 1 : 0) > b->max_frames)
         return kamd::SetError(KAMD_ERR_CAPACITY, "stream %d: more frames than reserved", s);
+    }
+  }
+  if (b->compact_at > 0.0f) {
+    // the usage figures are those of the sync that ended the streams' previous tick
+    std::vector<int32_t> full;
+    for (int i = 0; i < n; i++) {
+      int32_t tu = 0, tc = 1, lu = 0, lc = 1;
+      if (kamd_decoder_lane_usage(b->dec, streams[i], &tu, &tc, &lu, &lc) != KAMD_OK) return KAMD_ERR_ARG;
+      if (b->decoded[streams[i]] > 0 && (tu > b->compact_at * tc || lu > b->compact_at * lc)) full.push_back(streams[i]);
+    }
+    if (!full.empty()) {
+      int rc = kamd_decoder_compact(b->dec, full.data(), static_cast<int>(full.size()), st);
+      if (rc != KAMD_OK) return rc;
+      std::vector<int32_t> err(full.size(), 0);
+      rc = kamd_decoder_sync_lanes(b->dec, full.data(), static_cast<int>(full.size()), err.data());
+      if (rc != KAMD_OK) return rc;
+      for (size_t k = 0; k < full.size(); k++)
+        if (err[k]) {
+          b->status[full[k]] = err[k];
+          return kamd::SetError(KAMD_ERR_CAPACITY, "stream %d: compaction failed (flags %d)", full[k], err[k]);
+        }
+      b->n_compactions += static_cast<int64_t>(full.size());
     }
   }
   std::vector<int> new_frames(n);

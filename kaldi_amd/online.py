@@ -313,6 +313,13 @@ class StreamBatch:
         check(lib().kamd_stream_batch_set_silence_weighting(self._h, t.ctypes.data_as(C.POINTER(C.c_uint8)), t.size,
                                                             config.silence_weight if config.Active() else 1.0, config.max_state_duration))
 
+    def set_compaction(self, fraction):
+        """PruneActiveTokens as arena compaction when a stream's arena is fuller than `fraction` (default 0.5; 0 = never)"""
+        check(lib().kamd_stream_batch_set_compaction(self._h, float(fraction)))
+
+    def num_compactions(self):
+        return int(lib().kamd_stream_batch_num_compactions(self._h))
+
     def frame_tracebacks(self, streams):
         return decoder.frame_tracebacks(self.dec._dec, streams)
 

@@ -107,3 +107,48 @@ def test_compaction_through_both_finalize_modes(step):
     d.FinalizeDecoding()
     got = d.GetRawLattice()
     assert lattices_equal(got, want), lattice_diff(got, want)
+
+
+def test_streams_compact_their_arenas_when_they_fill_up():
+    """kamd_stream_batch: arenas a quarter of what the utterances create; with compaction at 50 % (the default) every
+    stream decodes and its lattice is the offline one; with compaction off the streams overflow."""
+    from kaldi_amd import feat, nnet, online
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=1.2)          # flat scores: many tokens survive
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    waves = [synth.make_wave(d_, seed=70 + i) for i, d_ in enumerate((4.0, 2.5, 3.1))]
+    offline = []
+    for w in waves:
+        off = decoder.LatticeFasterDecoder(G, cfg, abi.DecoderSizes(1, 1 << 14, 1 << 21, 1 << 22, 1024))
+        ll = N.Forward(feat.Mfcc(op).ComputeFeatures(w))
+        off.Decode(ll)
+        offline.append(off.GetRawLattice())
+        off.InitDecoding(); off.AdvanceDecoding(ll)
+        offline[-1].created = off.usage()
+    S = len(waves)
+    tok_cap = max(l.created[0] for l in offline) // 4
+    lnk_cap = max(l.created[2] for l in offline) // 4
+    sizes = abi.DecoderSizes(S, 1 << 14, S * tok_cap, S * lnk_cap, 1024)
+
+    def run(fraction):
+        sb = online.StreamBatch(op, N, G, cfg, S, max_seconds=5.0, sizes=sizes)
+        if fraction is not None:
+            sb.set_compaction(fraction)
+        sb.start(list(range(S)))
+        pos = [0] * S
+        step = int(0.18 * 16000)
+        while any(pos[s] < waves[s].size for s in range(S)):
+            live = [s for s in range(S) if pos[s] < waves[s].size]
+            for s in live:
+                sb.accept(s, waves[s][pos[s]:pos[s] + step], input_finished=pos[s] + step >= waves[s].size)
+                pos[s] += step
+            sb.advance(live)
+        sb.finalize(list(range(S)))
+        return sb
+    sb = run(None)
+    assert sb.num_compactions() >= S
+    for s in range(S):
+        assert lattices_equal(sb.raw_lattice(s), offline[s]), lattice_diff(sb.raw_lattice(s), offline[s])
+    with pytest.raises(KamdError):
+        run(0.0)

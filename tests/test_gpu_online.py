@@ -457,6 +457,7 @@ def test_one_overflowing_stream_does_not_stop_the_others():
     assert need[0] > 2 * cap
     S = 3
     sb = online.StreamBatch(op, N, G, cfg, S, max_seconds=5.0, sizes=abi.DecoderSizes(S, 1 << 14, cap, 4 * cap, 512))
+    sb.set_compaction(0.0)                                   # (with the default compaction the small lane would not overflow)
     sb.start([0, 1, 2])
     with pytest.raises(Exception):
         sb.advance([0, 0])                                   # duplicates are rejected ...
