@@ -230,6 +230,13 @@ class LatticeFasterDecoder {
     Check(kamd_decoder_finalize(dec_, &lane, 1, NULL));
     Check(kamd_decoder_sync(dec_));
   }
+  /// PruneActiveTokens (lattice-faster-decoder.h:455; protected in the reference, which calls it every prune_interval frames
+  /// from AdvanceDecoding): here the caller decides when, e.g. when the lane's arena fills up; results do not change.
+  void PruneActiveTokens() {
+    int32 lane = 0;
+    Check(kamd_decoder_compact(dec_, &lane, 1, NULL));
+    Check(kamd_decoder_sync(dec_));
+  }
   BaseFloat FinalRelativeCost() const { return kamd_decoder_final_relative_cost(dec_, 0); }
   bool ReachedFinal() const { return FinalRelativeCost() != std::numeric_limits<BaseFloat>::infinity(); }
   int32 NumFramesDecoded() const { return kamd_decoder_num_frames_decoded(dec_, 0); }
@@ -1123,6 +1130,8 @@ class OnlineStreamBatch {
       is_sil[t] = std::find(silence_phones.begin(), silence_phones.end(), tid2phone[t]) != silence_phones.end();
     Check(kamd_stream_batch_set_silence_weighting(h_, is_sil.data(), static_cast<int>(is_sil.size()), silence_weight, max_state_duration));
   }
+  /// arena compaction threshold of the streams (PruneActiveTokens when a stream's arena is fuller than this); 0 = never
+  void SetCompaction(BaseFloat fraction) { Check(kamd_stream_batch_set_compaction(h_, fraction)); }
   /// new utterances; adaptation_states (optional): one state per stream, kamd_ivector_state_size() doubles each
   void Start(const std::vector<int32> &streams, const std::vector<double> *adaptation_states = NULL) {
     if (adaptation_states && ie_) Check(kamd_stream_batch_start_adapted(h_, streams.data(), static_cast<int>(streams.size()), adaptation_states->data()));

@@ -78,6 +78,7 @@ int main(int argc, char **argv) {
       for (int32 t = 0; t < T; t += 7) {
         DecodableMatrixMapped part(id2pdf, ll.data(), std::min(T, t + 7), P);
         decoder.AdvanceDecoding(&part);
+        if (t % 14 == 0) decoder.PruneActiveTokens();     // never changes the result
       }
       decoder.FinalizeDecoding();
       Report("chunked", decoder);
