@@ -56,3 +56,32 @@ def test_random_cases(block):
         except AssertionError as e:
             raise AssertionError("block %d case %d (%d states, %d frames, beam %g lattice_beam %g max %d min %d): %s" % (
                 block, i, g.num_states, ll.shape[0], cfg.beam, cfg.lattice_beam, cfg.max_active, cfg.min_active, e))
+
+
+@pytest.mark.parametrize("block", range(int(os.environ.get("KAMD_FUZZ_BLOCKS", "6"))))
+def test_random_cases_chunked_compacted_both_search_modes(block):
+    """the round-2 paths under the same sweep: search mode 1 or 2, AdvanceDecoding in random chunks, PruneActiveTokens
+    (kamd_decoder_compact) after random chunks -- still bit-exact against the oracle's one-shot decode in that mode"""
+    rng = np.random.default_rng(int(os.environ.get("KAMD_FUZZ_SEED", "1234")) + 1000 + block)
+    for i in range(20):
+        g, ll, cfg = random_case(rng)
+        mode = int(rng.integers(1, 3))
+        G = decoder.Graph(g)
+        d = decoder.LatticeFasterDecoder(G, cfg, sizes(hash_cap=1 << 15, toks=1 << 20, links=1 << 21, frames=256))
+        d.SetSearchMode(mode)
+        d.InitDecoding()
+        t, n_compact = 0, 0
+        while t < ll.shape[0]:
+            n = int(rng.integers(1, 12))
+            d.AdvanceDecoding(ll[t:t + n])
+            t += n
+            if rng.random() < 0.5:
+                d.PruneActiveTokens(); n_compact += 1
+        d.FinalizeDecoding()
+        o = orc.Decoder(g, cfg, mode)
+        o.Decode(ll)
+        try:
+            assert_same(d, o)
+        except AssertionError as e:
+            raise AssertionError("block %d case %d mode %d (%d states, %d frames, %d compactions, beam %g lattice_beam %g max %d min %d): %s" % (
+                block, i, mode, g.num_states, ll.shape[0], n_compact, cfg.beam, cfg.lattice_beam, cfg.max_active, cfg.min_active, e))
