@@ -17,7 +17,7 @@ from ._lib import KamdError, check, lib
 class NnetBatchDecoder:
     def __init__(self, mfcc_opts, model, hclg, cfg, max_seconds=36.0, resident_lanes=0, host_threads=8, determinize=True,
                  keep_raw_lattices=False, tid_phone=None, sizes=None, nnet_pass_frames=1000000, lattice_pool_bytes=1 << 30,
-                 hash_capacity=None, tokens_per_frame=None, search_mode=2):
+                 hash_capacity=None, tokens_per_frame=None, search_mode=2, det=None):
         featmod = __import__("kaldi_amd.feat", fromlist=["Mfcc"])
         # mfcc_opts = None: no feature stage, the caller hands over feature matrices (load_features), as the
         # reference's AcceptInput does (nnet-batch-compute.h:665)
@@ -42,6 +42,8 @@ class NnetBatchDecoder:
         o.determinize, o.keep_raw_lattices = int(bool(determinize)), int(bool(keep_raw_lattices))
         o.nnet_pass_frames, o.lattice_pool_bytes = int(nnet_pass_frames), int(lattice_pool_bytes)
         o.lattice_beam = cfg.lattice_beam
+        for k, v in (det or {}).items():        # DeterminizeLatticePhonePrunedOptions: delta, phone_determinize, word_determinize, ...
+            setattr(o.det, k, v)
         self.opts = o
         tp = None if tid_phone is None else np.ascontiguousarray(tid_phone, np.int32)
         self._h = lib().kamd_batch_decoder_create(self.feat._h if self.feat is not None else None, self.nnet._h, self.dec._dec, C.byref(o),

@@ -161,3 +161,63 @@ def test_utterances_too_short_for_a_frame_fail_alone():
     bd.load(short)
     st = bd.run()
     assert st.n_failed == 2 and bd.output(0) is None
+
+
+def test_nnet3_latgen_faster_batch_tool(tmp_path):
+    """tools/nnet3_latgen_faster_batch.py = nnet3-latgen-faster-batch's command line over the work-queue path: the same
+    lattices as tools/nnet3_latgen_faster.py (three launches per batch) writes for the same files, in input order, with a
+    zero-length utterance failing alone, several sets per run, and --wav (features on the device)."""
+    import os
+    import subprocess
+    import sys
+    import wave
+    from kaldi_amd import feat, latbin, table
+    from kaldi_amd import io as kio
+    from tests.mdl_writer import write_mdl
+    g = synth.make_hclg(num_units=25, vocab=60, n_hist=12, seed=6)
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, seed=12, output_scale=3.0)
+    write_mdl(tmp_path / "final.mdl", m, num_units=25)
+    kio.write_openfst(tmp_path / "HCLG.fst", g, "const")
+    waves = [np.round(synth.make_wave(d, seed=50 + i)).astype(np.float32) for i, d in enumerate((1.2, 2.0, 0.8, 1.6, 1.1))]
+    mf = feat.Mfcc(abi.mfcc_opts_hires())
+    with table.TableWriter("ark,scp:%s,%s" % (tmp_path / "feats.ark", tmp_path / "feats.scp"), "matrix") as w:
+        for i, wv in enumerate(waves):
+            w.write("utt%d" % i, mf.ComputeFeatures(wv))
+            if i == 1:
+                w.write("empty", np.zeros((0, 40), np.float32))
+    with open(tmp_path / "wav.scp", "w") as scp:
+        for i, wv in enumerate(waves):
+            with wave.open(str(tmp_path / ("u%d.wav" % i)), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(wv.astype("<i2").tobytes())
+            scp.write("utt%d %s\n" % (i, tmp_path / ("u%d.wav" % i)))
+    (tmp_path / "words.txt").write_text("".join("w%d %d\n" % (k, k) for k in range(0, 61)))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--beam=15", "--max-active=7000", "--lattice-beam=8", "--acoustic-scale=1.0", "--frame-subsampling-factor=3"]
+    mdl_, fst_ = str(tmp_path / "final.mdl"), str(tmp_path / "HCLG.fst")
+    r = subprocess.run([sys.executable, root + "/tools/nnet3_latgen_faster_batch.py"] + common +
+                       ["--num-threads=3", "--set-frames=250", "--search-mode=1", "--word-symbol-table=%s" % (tmp_path / "words.txt"),
+                        mdl_, fst_, "scp:%s" % (tmp_path / "feats.scp"), "ark:%s" % (tmp_path / "batch.lat")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Zero-length utterance: empty" in r.stderr and "Decoded 6 utterances, 1 with errors." in r.stderr
+    r2 = subprocess.run([sys.executable, root + "/tools/nnet3_latgen_faster.py"] + common +
+                        [mdl_, fst_, "scp:%s" % (tmp_path / "feats.scp"), "ark:%s" % (tmp_path / "plain.lat")], capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert open(tmp_path / "batch.lat", "rb").read() == open(tmp_path / "plain.lat", "rb").read()
+    got = [k for k, _ in latbin.read_lattices("ark:%s" % (tmp_path / "batch.lat"))]
+    assert got == ["utt%d" % i for i in range(5)]                  # input order, across three sets
+    assert any(l.startswith("utt0 w") for l in r.stderr.splitlines())      # the sentence of every utterance with --word-symbol-table
+    # waveforms in, raw lattices out
+    r3 = subprocess.run([sys.executable, root + "/tools/nnet3_latgen_faster_batch.py"] + common +
+                        ["--wav", "--determinize-lattice=false", "--search-mode=1", mdl_, fst_, "scp:%s" % (tmp_path / "wav.scp"),
+                         "ark:%s" % (tmp_path / "raw.lat")], capture_output=True, text=True)
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    r4 = subprocess.run([sys.executable, root + "/tools/nnet3_latgen_faster.py"] + common +
+                        ["--wav", "--determinize-lattice=false", mdl_, fst_, "scp:%s" % (tmp_path / "wav.scp"), "ark:%s" % (tmp_path / "raw2.lat")],
+                        capture_output=True, text=True)
+    assert r4.returncode == 0, r4.stderr[-2000:]
+    a = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "raw.lat"), "lattice"))
+    b = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "raw2.lat"), "lattice"))
+    assert list(a) == list(b) and all(a[k][2].size == b[k][2].size for k in a)
+    bad = subprocess.run([sys.executable, root + "/tools/nnet3_latgen_faster_batch.py", "--online-ivectors=ark:x", mdl_, fst_, "scp:a", "ark:b"],
+                         capture_output=True, text=True)
+    assert bad.returncode == 255 and "not supported" in bad.stderr
