@@ -520,14 +520,17 @@ static inline int64_t LayerRows(const LayerDev &l, int n_out, int sub) {
   return (hi - l.lo) / l.step + 1;
 }
 
+// The zero fill is issued on the stream that will use the buffer: a hipMemset on the NULL stream is not ordered with
+// kernels on a non-blocking stream, and a fill that is still running when the first GEMM writes the buffer wipes its
+// output (seen once another kernel kept compute units busy and the fill kernel started late).
 template <typename T>
-static int Grow(T **p, size_t *cap, size_t need) {
+static int Grow(T **p, size_t *cap, size_t need, hipStream_t st) {
   if (need <= *cap) return KAMD_OK;
-  if (*p) (void)hipFree(*p);
+  if (*p) { KAMD_HIP(hipStreamSynchronize(st)); (void)hipFree(*p); }
   *p = NULL;
   size_t n = need + need / 4;
   KAMD_HIP(hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
-  KAMD_HIP(hipMemset(*p, 0, n * sizeof(T)));
+  KAMD_HIP(hipMemsetAsync(*p, 0, n * sizeof(T), st));
   *cap = n;
   return KAMD_OK;
 }
@@ -682,7 +685,7 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
   for (int u = 0; u + 1 < n_utts; u++)
     if (h_out_row_off[u + 1] != h_out_row_off[u] + n_out[u])
       return kamd::SetError(KAMD_ERR_ARG, "h_out_row_off must be the running sum of output frames");
-  if (kamd::Grow(&nn->d_meta, &nn->meta_cap, meta.size()) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::Grow(&nn->d_meta, &nn->meta_cap, meta.size(), st) != KAMD_OK) return KAMD_ERR_HIP;
   KAMD_HIP(hipMemcpyAsync(nn->d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
   const int *d_T = reinterpret_cast<const int *>(nn->d_meta + (nl + 2) * stride);
@@ -695,11 +698,11 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     int64_t row_base = 0;
     if (l == nl - 1) { C = d_out; ldC = ld_out; row_base = h_out_row_off[0]; }
     else {
-      if (kamd::Grow(&nn->act[l], &nn->act_cap[l], static_cast<size_t>(Ml) * L.out_pad) != KAMD_OK) return KAMD_ERR_HIP;
+      if (kamd::Grow(&nn->act[l], &nn->act_cap[l], static_cast<size_t>(Ml) * L.out_pad, st) != KAMD_OK) return KAMD_ERR_HIP;
       C = nn->act[l]; ldC = L.out_pad;
     }
     const size_t map_ints = static_cast<size_t>(L.n_off + 2) * Ml;
-    if (kamd::Grow(&nn->maps[l], &nn->maps_cap[l], map_ints) != KAMD_OK) return KAMD_ERR_HIP;
+    if (kamd::Grow(&nn->maps[l], &nn->maps_cap[l], map_ints, st) != KAMD_OK) return KAMD_ERR_HIP;
     int *rowmap = nn->maps[l], *bypmap = rowmap + static_cast<size_t>(L.n_off) * Ml, *row2utt = bypmap + Ml;
     // the last layer's row offsets are absolute rows of d_out; the map kernel works in
     // layer-local rows, so give it offsets relative to row_base.
@@ -750,7 +753,7 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     if (L.ivector_dim > 0) {
       if (!d_ivectors) return kamd::SetError(KAMD_ERR_ARG, "model needs ivectors");
       const int iv_rows = slots ? slots->table_rows : n_utts;
-      if (kamd::Grow(&nn->d_ivb, &nn->ivb_cap, static_cast<size_t>(iv_rows) * L.out_dim) != KAMD_OK) return KAMD_ERR_HIP;
+      if (kamd::Grow(&nn->d_ivb, &nn->ivb_cap, static_cast<size_t>(iv_rows) * L.out_dim, st) != KAMD_OK) return KAMD_ERR_HIP;
       hipLaunchKernelGGL(kamd::IvecBiasKernel, dim3(kamd::CeilDiv(L.out_dim, 128), iv_rows), dim3(128), 0, st,
                          L.Wiv, d_ivectors, L.out_dim, L.ivector_dim, nn->d_ivb);
       g.ivbias = nn->d_ivb; g.row2utt = row2utt;

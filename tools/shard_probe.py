@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""What ONE rank of an N-GPU run of the headline bench does, measured on this one GPU: the rank's LPT shard of the test
+set (kaldi_amd/shard.py) through the same NnetBatchDecoder step.  The ranks of a real run are independent and their shards
+equal to 0.1 % of audio, so total audio / this step time is what N GPUs would give, minus the barrier.
+
+  python tools/shard_probe.py --worlds 1,2,4,8 [--lanes 0] [--steps 2]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from kaldi_amd import abi, batch, shard, synth  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--utts", type=int, default=0)
+    a = ap.parse_args()
+    sys.argv = [sys.argv[0]] + (["--utts", str(a.utts)] if a.utts else [])
+    args = bench.defaults(bench.parse_args())
+    g, model, durs, cfg, _ = bench.build_workload(args)
+    bench.calibrate(model, args.ll_std)
+    out = []
+    base = None
+    for world in [int(x) for x in a.worlds.split(",")]:
+        mine = shard.lpt_shards(durs, world)[a.rank % world]
+        waves = synth.make_waves_fast(durs[mine], seed=1000 + a.rank)
+        audio = sum(w.size for w in waves) / 16000.0
+        bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=float(durs.max()) + 0.5, resident_lanes=a.lanes,
+                                    host_threads=16, determinize=True, keep_raw_lattices=False, hash_capacity=args.hash_capacity or None,
+                                    search_mode=args.search_mode, lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)))
+        bd.load(waves)
+        bd.run()
+        t0 = time.time()
+        acc = np.zeros(5)
+        for _ in range(a.steps):
+            st = bd.run()
+            acc += [st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms]
+        dt = (time.time() - t0) / a.steps
+        acc /= a.steps
+        total_audio = float(durs.sum())
+        rate = total_audio / dt
+        if base is None:
+            base = rate / world
+        row = {"world": world, "utterances_this_rank": len(waves), "audio_this_rank_s": audio, "longest_s": float(durs[mine].max()),
+               "step_ms": 1e3 * dt, "feat_ms": acc[0], "nnet_ms": acc[1], "decode_ms": acc[2], "tail_ms": acc[3],
+               "implied_x_real_time_all_ranks": rate, "implied_strong_scaling_efficiency": rate / (base * world)}
+        out.append(row)
+        print(json.dumps(row), flush=True)
+        del bd
+    return out
+
+
+if __name__ == "__main__":
+    main()
