@@ -596,7 +596,7 @@ kamd_nnet *kamd_nnet_create(const kamd_layer_desc *layers, int n_layers, int inp
   }
   if (kamd::PlanGrids(nn) != KAMD_OK) { delete nn; return NULL; }
   nn->d_zero = kamd::DevAlloc<float>(64);
-  if (!nn->d_zero || hipMemset(nn->d_zero, 0, 64 * sizeof(float)) != hipSuccess) { kamd::SetError(KAMD_ERR_HIP, "nnet: allocation failed"); delete nn; return NULL; }
+  if (!nn->d_zero || hipMemset(nn->d_zero, 0, 64 * sizeof(float)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { kamd::SetError(KAMD_ERR_HIP, "nnet: allocation failed"); delete nn; return NULL; }
   nn->act.assign(n_layers, NULL); nn->act_cap.assign(n_layers, 0);
   nn->maps.assign(n_layers, NULL); nn->maps_cap.assign(n_layers, 0);
   return reinterpret_cast<kamd_nnet *>(nn);

@@ -112,7 +112,7 @@ int kamd_pipeline_load_features(kamd_pipeline *h, const float *feats, const int6
   const size_t rows = static_cast<size_t>(p->feat_off[n_utts]);
   if (kamd::GrowBuf(&p->d_feats, &p->feats_cap, rows * p->ld_feat) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowBuf(&p->d_ll, &p->ll_cap, static_cast<size_t>(p->out_off[n_utts]) * p->P) != KAMD_OK) return KAMD_ERR_HIP;
-  if (p->ld_feat != dim) KAMD_HIP(hipMemset(p->d_feats, 0, rows * p->ld_feat * sizeof(float)));
+  if (p->ld_feat != dim) { KAMD_HIP(hipMemset(p->d_feats, 0, rows * p->ld_feat * sizeof(float))); KAMD_HIP(hipDeviceSynchronize()); }
   KAMD_HIP(hipMemcpy2D(p->d_feats, p->ld_feat * sizeof(float), feats + h_row_off[0] * dim, dim * sizeof(float),
                        dim * sizeof(float), rows, hipMemcpyHostToDevice));
   return KAMD_OK;
