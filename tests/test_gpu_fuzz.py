@@ -85,3 +85,31 @@ def test_random_cases_chunked_compacted_both_search_modes(block):
         except AssertionError as e:
             raise AssertionError("block %d case %d mode %d (%d states, %d frames, %d compactions, beam %g lattice_beam %g max %d min %d): %s" % (
                 block, i, mode, g.num_states, ll.shape[0], n_compact, cfg.beam, cfg.lattice_beam, cfg.max_active, cfg.min_active, e))
+
+
+@pytest.mark.parametrize("block", range(int(os.environ.get("KAMD_FUZZ_BLOCKS", "6"))))
+def test_random_cases_through_the_work_queue(block):
+    """the fused queue kernel (InitDecoding + AdvanceDecoding + FinalizeDecoding + lattice hand-off per task) under the
+    same sweep: per random (graph, config) a few utterances through 1-3 resident lanes, each bit-exact against the oracle"""
+    rng = np.random.default_rng(int(os.environ.get("KAMD_FUZZ_SEED", "1234")) + 2000 + block)
+    for i in range(10):
+        g, ll0, cfg = random_case(rng)
+        mode = int(rng.integers(1, 3))
+        lls = [ll0] + [synth.random_loglikes(int(rng.integers(1, 40)), g.num_pdfs, seed=int(rng.integers(1 << 30)),
+                                             scale=float(rng.uniform(0.3, 2.5))) for _ in range(int(rng.integers(1, 4)))]
+        bd = decoder.BatchDecoder(decoder.Graph(g), cfg, abi.DecoderSizes(3, 1 << 15, 3 << 19, 3 << 20, 256))
+        bd.SetSearchMode(mode)
+        lats, recs, _ = bd.decode_queue(lls, resident_lanes=int(rng.integers(1, 4)))
+        for u, ll in enumerate(lls):
+            o = orc.Decoder(g, cfg, mode)
+            o.Decode(ll)
+            lo = o.GetRawLattice()
+            what = "block %d case %d utt %d mode %d (%d states, %d frames)" % (block, i, u, mode, g.num_states, ll.shape[0])
+            assert recs[u].status == 1 and recs[u].error == 0 and recs[u].n_frames == ll.shape[0], what
+            if lo is None:
+                assert lats[u] is None, what
+                continue
+            from tests.util import lattice_diff, lattices_equal
+            assert lattices_equal(lats[u], lo), what + ": " + lattice_diff(lats[u], lo)
+            np.testing.assert_array_equal(np.asarray(recs[u].counters[:7]), o.counters()[:7], err_msg=what)
+            assert recs[u].final_relative_cost == o.FinalRelativeCost(), what
