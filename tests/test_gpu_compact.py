@@ -152,3 +152,33 @@ def test_streams_compact_their_arenas_when_they_fill_up():
         assert lattices_equal(sb.raw_lattice(s), offline[s]), lattice_diff(sb.raw_lattice(s), offline[s])
     with pytest.raises(KamdError):
         run(0.0)
+
+
+def test_compaction_at_the_edges():
+    """right after InitDecoding (nothing decoded), after a single frame, twice in a row, and on a finalized lane (a no-op)"""
+    g, ll = _workload(seed=3, n_words=5)
+    cfg = abi.decoder_config_recipe()
+    G = decoder.Graph(g)
+    sz = abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512)
+    ref = decoder.LatticeFasterDecoder(G, cfg, sz)
+    ref.Decode(ll)
+    want = ref.GetRawLattice()
+    d = decoder.LatticeFasterDecoder(G, cfg, sz)
+    d.InitDecoding()
+    d.PruneActiveTokens()
+    assert d.NumFramesDecoded() == 0
+    d.AdvanceDecoding(ll[:1])
+    d.PruneActiveTokens(); d.PruneActiveTokens()
+    d.AdvanceDecoding(ll[1:])
+    d.FinalizeDecoding()
+    got = d.GetRawLattice()
+    assert lattices_equal(got, want), lattice_diff(got, want)
+    d.PruneActiveTokens()                                  # finalized: nothing happens
+    assert lattices_equal(d.GetRawLattice(), want)
+    # an empty utterance: InitDecoding, compaction, FinalizeDecoding
+    e = decoder.LatticeFasterDecoder(G, cfg, sz)
+    e.InitDecoding(); e.PruneActiveTokens(); e.FinalizeDecoding()
+    r = decoder.LatticeFasterDecoder(G, cfg, sz)
+    r.InitDecoding(); r.FinalizeDecoding()
+    a, b = e.GetRawLattice(), r.GetRawLattice()
+    assert (a is None and b is None) or lattices_equal(a, b)
