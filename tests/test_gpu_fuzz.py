@@ -113,3 +113,41 @@ def test_random_cases_through_the_work_queue(block):
             assert lattices_equal(lats[u], lo), what + ": " + lattice_diff(lats[u], lo)
             np.testing.assert_array_equal(np.asarray(recs[u].counters[:7]), o.counters()[:7], err_msg=what)
             assert recs[u].final_relative_cost == o.FinalRelativeCost(), what
+
+
+@pytest.mark.parametrize("block", range(int(os.environ.get("KAMD_FUZZ_STREAM_BLOCKS", "2"))))
+def test_random_streams_with_compaction(block):
+    """kamd_stream_batch_* under random chunkings and compaction thresholds: every stream's lattice equals the offline
+    decode of the same waveform, however often its arena was compacted on the way"""
+    from kaldi_amd import feat, nnet, online
+    rng = np.random.default_rng(int(os.environ.get("KAMD_FUZZ_SEED", "1234")) + 3000 + block)
+    g = synth.make_hclg(num_units=int(rng.integers(10, 30)), vocab=int(rng.integers(20, 80)), n_hist=int(rng.integers(4, 16)),
+                        seed=int(rng.integers(1 << 30)))
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=float(rng.uniform(1.0, 4.0)), seed=int(rng.integers(1 << 20)))
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    cfg.lattice_beam = float(rng.choice([2.0, 6.0, 8.0]))
+    S = int(rng.integers(1, 5))
+    waves = [synth.make_wave(float(rng.uniform(0.4, 3.0)), seed=int(rng.integers(1 << 30))) for _ in range(S)]
+    want = []
+    for w in waves:
+        off = decoder.LatticeFasterDecoder(G, cfg, abi.DecoderSizes(1, 1 << 14, 1 << 21, 1 << 22, 1024))
+        off.Decode(N.Forward(feat.Mfcc(op).ComputeFeatures(w)))
+        want.append(off.GetRawLattice())
+    sb = online.StreamBatch(op, N, G, cfg, S, max_seconds=4.0, sizes=abi.DecoderSizes(S, 1 << 14, S << 19, S << 20, 1024))
+    sb.set_compaction(float(rng.choice([0.0, 0.002, 0.01, 0.05, 0.5])))
+    sb.start(list(range(S)))
+    pos = [0] * S
+    while any(pos[s] < waves[s].size for s in range(S)):
+        live = [s for s in range(S) if pos[s] < waves[s].size and rng.random() < 0.8]
+        for s in live:
+            n = int(rng.integers(400, 8000))
+            sb.accept(s, waves[s][pos[s]:pos[s] + n], input_finished=pos[s] + n >= waves[s].size)
+            pos[s] += n
+        if live:
+            sb.advance(live)
+    sb.finalize(list(range(S)))
+    from tests.util import lattice_diff, lattices_equal
+    for s in range(S):
+        got = sb.raw_lattice(s)
+        assert lattices_equal(got, want[s]), "block %d stream %d (%d compactions): %s" % (block, s, sb.num_compactions(), lattice_diff(got, want[s]))
