@@ -1,16 +1,38 @@
+"""One-line summary of bench.py JSON lines.
+  python bench.py ... | python tools/summarize.py [tag]      or      python tools/summarize.py tag file.json [file2.json ...]
+With file arguments nothing is read from stdin (a call without a pipe must not sit waiting for input)."""
 import json
 import sys
+
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
-for l in sys.stdin:
-    if l.startswith("{"):
-        d = json.loads(l)
-        print("[%s] RTF %.0f  ms/step %.1f  stages %s" % (tag, d["value"], d["ms_per_step"],
-              {k: round(v, 2) for k, v in d["stage_ms"].items()}))
-        print("    decoder %s" % {k: round(v, 1) for k, v in d["decoder"].items()})
-        if "phase_share_longest_lane" in d:
-            print("    phases %s" % d["phase_share_longest_lane"])
-        r = d["roofline"]
-        print("    roofline %.1f GB/s (%.4f of peak), nnet %.1f TFLOP/s, cpu %s" % (
-            r["achieved"], r["frac"], d["nnet_tflops"], d.get("cpu_baseline") and round(d["cpu_baseline"]["value"], 2)))
+files = sys.argv[2:]
+if not files and sys.stdin.isatty():
+    sys.exit("usage: bench.py ... | summarize.py [tag]   or   summarize.py tag file.json ...")
+
+
+def lines():
+    if files:
+        for f in files:
+            for l in open(f):
+                yield l
     else:
+        for l in sys.stdin:
+            yield l
+
+
+for l in lines():
+    if not l.startswith("{"):
         print(l[:300].rstrip())
+        continue
+    d = json.loads(l)
+    print("[%s] x real time %.0f  ms/step %.1f  stages %s" % (tag, d["value"], d["ms_per_step"],
+          {k: round(v, 2) for k, v in d.get("stage_ms", {}).items()}))
+    if "decoder" in d:
+        print("    decoder %s" % {k: round(v, 1) for k, v in d["decoder"].items()})
+    for key in ("roofline", "roofline_other_stage"):
+        r = d.get(key)
+        if r:
+            print("    %s: %s %.1f %s = %.3f of peak" % (key, r.get("kernel", ""), r["achieved"], r["unit"], r["frac"]))
+    c = d.get("cpu_baseline")
+    if c:
+        print("    cpu_baseline %.1f %s on %d threads (%s)" % (c["value"], c["unit"], c["cores"], c["kind"]))
