@@ -13,8 +13,12 @@ if not files and sys.stdin.isatty():
 def lines():
     if files:
         for f in files:
-            for l in open(f):
-                yield l
+            text = open(f).read()
+            try:                                   # a pretty-printed JSON document (profiles/*.json)
+                yield json.dumps(json.loads(text))
+            except ValueError:
+                for l in text.splitlines():
+                    yield l
     else:
         for l in sys.stdin:
             yield l
