@@ -63,7 +63,7 @@ def parse_args():
                     help="per-frame std (nats) of the synthetic log-likelihoods across pdfs after calibration")
     ap.add_argument("--max-seconds", type=float, default=0.0)
     ap.add_argument("--lanes", type=int, default=0, help="resident decoder lanes per GPU (0 = one per compute unit)")
-    ap.add_argument("--host-threads", type=int, default=0, help="host-tail threads per rank (0 = min(16, cores / ranks))")
+    ap.add_argument("--host-threads", type=int, default=0, help="host-tail threads per rank (0 = min(32, cores / ranks))")
     ap.add_argument("--no-determinize", action="store_true")
     ap.add_argument("--hash-capacity", type=int, default=0)
     ap.add_argument("--tokens-per-frame", type=int, default=0, help="arena budget per frame and lane (0 = from max-active / free HBM)")
@@ -398,7 +398,7 @@ def main():
     audio = sum(w.size for w in waves) / 16000.0
     max_s = float(durs.max()) + 0.5
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    host_threads = args.host_threads or max(1, min(16, cores // world))
+    host_threads = args.host_threads or max(1, min(32, cores // world))
     bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=max_s, resident_lanes=args.lanes,
                                 host_threads=host_threads, determinize=not args.no_determinize, keep_raw_lattices=False,
                                 nnet_pass_frames=args.nnet_pass_frames, hash_capacity=args.hash_capacity or None,
