@@ -35,8 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
-PHASES = ["best", "cutoff", "seed", "expand", "expand_hub", "eps_closure", "compact", "fixup",
-          "eps_links", "clear", "fin_sweep", "fin_compact", "flat_setup"]
+PHASES = ["fin_fetch", "cutoff", "seed", "expand", "expand_hub", "eps_closure", "compact", "fixup",
+          "eps_links", "clear", "fin_sweep", "fin_compact", "flat_setup", "fin_emit", "fin_eps", "fin_stage"]
 
 
 def algorithmic_bytes(c):

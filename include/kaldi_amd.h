@@ -416,11 +416,13 @@ typedef struct {
   int32_t n_tok, n_link;     /* raw lattice: states, arcs */
   int32_t n_last, pad;       /* tokens on the last frame (their final costs travel with the lattice) */
   float final_relative_cost, final_best_cost;
-  int64_t blob_off, blob_bytes;   /* the lattice inside the device pool */
+  int64_t blob_off, blob_bytes;   /* the lattice inside the pool */
   int64_t counters[8];       /* the work counters of kamd_decoder_get_counters */
   uint64_t phase_cycles[16];
 } kamd_queue_result;
-/* Lattice pool in HBM (grow-only; default 1 GiB at the first launch). */
+/* Lattice pool (grow-only; default 1 GiB at the first launch): page-locked host memory that the
+ * queue kernel writes every finished utterance's raw lattice into, so that the host reads it
+ * in place. */
 int kamd_decoder_queue_configure(kamd_decoder *d, int64_t pool_bytes);
 /* Asynchronous launch on `stream`: tasks are handed out in the order given (pass the
  * longest first).  resident_lanes <= max_lanes of the decoder; 0 = one per compute unit.
@@ -432,8 +434,8 @@ int kamd_decoder_queue_launch(kamd_decoder *d, const kamd_queue_task *tasks, int
 int kamd_decoder_queue_poll(kamd_decoder *d, int32_t *utts, int cap);
 /* The record of a finished utterance (status == 1), copied out of the shared table. */
 int kamd_decoder_queue_result(kamd_decoder *d, int32_t utt, kamd_queue_result *out);
-/* Raw lattice of a finished utterance: D2H of its blob on `copy_stream` (a stream other
- * than the launch stream: the queue kernel may still be running) + canonical numbering
+/* Raw lattice of a finished utterance: its blob (in the host-resident pool already;
+ * `copy_stream` is unused and may be NULL) + canonical numbering
  * (states by (frame, HCLG state), arcs sorted), as kamd_decoder_get_raw_lattice.  All
  * output arrays are malloc'ed (kamd_host_free); thread-safe for distinct utterances. */
 int kamd_decoder_queue_fetch_lattice(kamd_decoder *d, int32_t utt, void *copy_stream,
@@ -983,7 +985,7 @@ typedef struct {
   int32_t determinize;        /* --determinize-lattice (decoder-wrappers.cc:262-277) */
   int32_t keep_raw_lattices;  /* keep the canonical raw lattice of every utterance on the host */
   int64_t nnet_pass_frames;   /* input frames per acoustic-model pass */
-  int64_t lattice_pool_bytes; /* device pool the finished lattices wait in */
+  int64_t lattice_pool_bytes; /* page-locked host pool the finished lattices wait in */
   float lattice_beam;         /* determinization beam = config.lattice_beam */
   kamd_determinize_opts det;
 } kamd_batch_opts;

@@ -48,7 +48,7 @@ typedef unsigned int u32;
 #define LDS_TABLE_CAP (8 * NT)   // level-1 table words (64 KB of a 1024-thread lane's LDS)
 #define SMALL_DEG 4
 #define ARCW 4           // arcs in flight per thread in the arc-parallel expansion
-#define CHUNKCAP (5 * NT)    // cached chunk owners (16 arcs each) per flatten batch
+#define CHUNKCAP (4 * NT)    // cached chunk owners (16 arcs each) per flatten batch
 static_assert(NT == 1024 || NT == 512, "KAMD_NT: 1024 (one lane per CU) or 512 (two)");
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
 
@@ -153,8 +153,10 @@ struct Sh {  // workgroup-shared state
 };
 
 // phase ids for the diagnostic cycle breakdown
-enum { PH_BEST = 0, PH_CUTOFF, PH_SEED, PH_EXPAND, PH_EXPAND_BIG, PH_EPS_CLOSURE, PH_COMPACT,
-       PH_FIXUP, PH_EPS_LINKS, PH_CLEAR, PH_FIN_SWEEP, PH_FIN_COMPACT, PH_FLAT_SETUP, PH_OTHER };
+// (the finalize sweep, per frame: FIN_FETCH = until the frame's records -- requested one frame ahead -- are in LDS,
+// FIN_EMIT / FIN_EPS = the two relaxations, FIN_STAGE = survivors staged; FIN_SWEEP = what is left: HBM-mode frames, the end)
+enum { PH_FIN_FETCH = 0, PH_CUTOFF, PH_SEED, PH_EXPAND, PH_EXPAND_BIG, PH_EPS_CLOSURE, PH_COMPACT,
+       PH_FIXUP, PH_EPS_LINKS, PH_CLEAR, PH_FIN_SWEEP, PH_FIN_COMPACT, PH_FLAT_SETUP, PH_FIN_EMIT, PH_FIN_EPS, PH_FIN_STAGE };
 __device__ inline void Stamp(Sh *sh, int idx) {   // call right after a barrier
   if (threadIdx.x == 0) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -326,11 +328,12 @@ __device__ float BlockSelectKth(SrcPtr cost, int n, int k, Sh *sh) {
 }
 
 // max-active cutoff: the max_active-th smallest cost, known to lie below beam_cutoff.
-// One pass builds a 4096-bucket LDS histogram over the linear range [best, best+beam)
+// One pass builds a 3072-bucket LDS histogram over the linear range [best, best+beam)
 // (monotone bucket map => lower buckets hold smaller costs); the bucket containing rank k
 // is then resolved EXACTLY by ranking its few members against each other.  Falls back to
 // the radix select when the bucket is too crowded.  `src` may point to LDS or global.
-#define LHBINS (4 * NT)     // the bucket scan below takes exactly four buckets per thread
+#define LHBINS (3 * NT)     // the bucket scan below takes exactly three buckets per thread (a fourth would cost the
+                            // log-likelihood row 4 KB of LDS: 6000 pdfs no longer fit beside the tables)
 #define LHCAND NT
 template <typename SrcPtr>
 __device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float beam,
@@ -343,11 +346,11 @@ __device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float b
     if (b < static_cast<float>(LHBINS)) atomicAdd(&lh[b < 0.f ? 0 : static_cast<int>(b)], 1u);
   }
   __syncthreads();
-  // locate the bucket of rank k: 4 buckets per thread, workgroup scan
+  // locate the bucket of rank k: 3 buckets per thread, workgroup scan
   {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int h0 = lh[4 * t], h1 = lh[4 * t + 1], h2 = lh[4 * t + 2], h3 = lh[4 * t + 3];
-    const int mine = h0 + h1 + h2 + h3;
+    const int h0 = lh[3 * t], h1 = lh[3 * t + 1], h2 = lh[3 * t + 2];
+    const int mine = h0 + h1 + h2;
     int incl = mine;
     for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
     if (lane == 63) sh->redi[w] = incl;
@@ -358,8 +361,8 @@ __device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float b
     if (t == 0) { sh->sel_bin = -1; sh->scan_total = 0; }
     __syncthreads();
     if (k >= excl && k < excl + mine) {
-      int cum = excl, b = 4 * t, cnt = h0;
-      if (cum + h0 <= k) { cum += h0; b++; cnt = h1; if (cum + h1 <= k) { cum += h1; b++; cnt = h2; if (cum + h2 <= k) { cum += h2; b++; cnt = h3; } } }
+      int cum = excl, b = 3 * t, cnt = h0;
+      if (cum + h0 <= k) { cum += h0; b++; cnt = h1; if (cum + h1 <= k) { cum += h1; b++; cnt = h2; } }
       sh->sel_bin = b; sh->sel_below = cum; sh->changed = cnt;
     }
     __syncthreads();
@@ -1106,14 +1109,20 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
     sh.cur_tb = c.tok_off[frame]; sh.cur_n = c.tok_off[frame + 1] - c.tok_off[frame];
     sh.lnk_used = S->lnk_used; sh.round = S->round;
   }
-  constexpr int LLPF = 3072 / NT;                 // row entries per thread held in registers
-  const bool ll_pf = d.num_pdfs_lds > 0 && d.num_pdfs_lds <= LLPF * NT;
-  float llp[LLPF];
-#pragma unroll
-  for (int k = 0; k < LLPF; k++) {
-    const int i = tid + k * NT;
-    llp[k] = (ll_pf && task.n_frames > 0 && i < d.num_pdfs_lds) ? task.d_loglikes[i] : 0.f;
-  }
+  // The frame's log-likelihood row travels HBM -> LDS by DMA (global_load_lds_dword: no registers held), issued one
+  // frame ahead, as soon as the expansion that reads the previous row is over: a cold 24 KB read off the critical path.
+  // Through inline asm, like the GEMM's ring: the compiler's own tracking of the builtin would drain vmcnt before every
+  // later ds_read.  The wave's LDS window goes in M0, the lane's word follows from its id.
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  const unsigned ll_lds_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_byte *)ll_lds));
+  auto row_dma = [&](const float *src) {
+    for (int k0 = 0; k0 < d.num_pdfs_lds; k0 += NT) {
+      const unsigned m0v = __builtin_amdgcn_readfirstlane(ll_lds_addr + static_cast<unsigned>(k0 + (tid & ~63)) * 4u);
+      if (k0 + tid < d.num_pdfs_lds)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(src + k0 + tid) : "memory");
+    }
+  };
+  if (task.n_frames > 0) row_dma(task.d_loglikes);
   ComputeFrameStats(d, c, &sh, frame, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
   for (int it = 0; it < task.n_frames; it++, frame++) {
     if (frame >= d.max_frames) { if (tid == 0) atomicOr(&sh.err, ERR_FRAMES); __syncthreads(); break; }
@@ -1159,23 +1168,12 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
     Stamp(&sh, PH_CUTOFF);
     // ---- cost offset + seed of next_cutoff from the best token's arcs (:757-772)
     const float cost_offset = (n > 0) ? -best : 0.0f;
+    // the frame's log-likelihood row is in LDS once every wavefront's DMA of it has landed (issued a frame ago)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
       c.cost_offsets[frame] = cost_offset;
       c.trace_ntok[frame] = n; c.trace_cutoff[frame] = cur_cutoff;
       c.lnk_off[2 * (frame + 1)] = sh.lnk_used;
-    }
-    // stage the frame's log-likelihood row in LDS: every expanded arc gathers from it.  The
-    // row was loaded into registers one frame ago (a cold 9 KB HBM read off the critical path)
-    if (ll_pf) {
-#pragma unroll
-      for (int k = 0; k < LLPF; k++) { const int i = tid + k * NT; if (i < d.num_pdfs_lds) ll_lds[i] = llp[k]; }
-      if (it + 1 < task.n_frames) {
-        const float *lln = ll + task.ld;
-#pragma unroll
-        for (int k = 0; k < LLPF; k++) { const int i = tid + k * NT; if (i < d.num_pdfs_lds) llp[k] = lln[i]; }
-      }
-    } else {
-      for (int i = tid; i < d.num_pdfs_lds; i += NT) ll_lds[i] = ll[i];
     }
     LlRow row; row.g = ll; row.l = (lds_cfloat *)ll_lds; row.n_lds = d.num_pdfs_lds;
     LdsBarrier();
@@ -1345,6 +1343,10 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
     int my_slot[COMMIT_KEEP];
     const int k_surv = InsertEmitted(d, c, &sh, tbl, link_base, sh.n_links, loose ? seed_cutoff : next_cutoff, my_slot);
     Stamp(&sh, PH_FIXUP);
+    // nobody reads this frame's row any more.  (Issued here and not before the inserts above: those wait for L2 hits,
+    // and loads return in order -- behind a cold 24 KB read they took 2.5 us longer; the closure's first loads are
+    // cold graph reads themselves.)
+    if (it + 1 < task.n_frames) row_dma(ll + task.ld);
     // ---- ProcessNonemitting(next_cutoff) + commit of token list frame+1
     CommitLds cl;
     cl.wl0 = reinterpret_cast<u32 *>(dyn_lds); cl.wl1 = cl.wl0 + (3 * BIGCAP) / 2; cl.wl_cap = (3 * BIGCAP) / 2;
@@ -1623,6 +1625,8 @@ __device__ inline LinkLite Lite(const Link &L, int src_base, int dst_base) {
 }
 #define FIN_PF 4                          // links per thread held in registers (one frame ahead)
 #define FIN_TPT ((FIN_CAP + NT - 1) / NT) // tokens per thread held in registers
+#define FIN_W (NT / 2)                    // frames whose offsets the sweep keeps in LDS
+#define FIN_LDS_BYTES (6 * FIN_CAP * 4 + (4 * FIN_W + 11) * 4)
 
 // FinalizeDecoding, second generation: the same exact backward sweep as FinalizeKernel, with
 //  * the surviving tokens / links of frame f emitted to a staging area as soon as frame f is
@@ -1670,6 +1674,22 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
   float *stage_cost = reinterpret_cast<float *>(c.tok_map);
   // LDS: [2] ordered extra costs, [2] forward costs, [2] staged positions (frame f / frame f+1)
   u32 *l_base = reinterpret_cast<u32 *>(fin_lds);
+  // The per-frame offsets of the next FIN_W frames, in LDS: the sweep is a chain of dependent steps per frame and a frame's
+  // records cannot be requested before its offsets are known -- read from global (written up to a thousand frames ago: L2
+  // misses) they put a second round trip in front of every frame's prefetch.
+  int *l_tok = reinterpret_cast<int *>(fin_lds + 6 * FIN_CAP * 4);      // tok_off[wb .. wb + FIN_W + 3)
+  int *l_lnk = l_tok + FIN_W + 3;                                        // lnk_off[2 wb .. 2 wb + 2 FIN_W + 6)
+  float *l_cof = reinterpret_cast<float *>(l_lnk + 2 * FIN_W + 6);       // cost_offsets[wb .. wb + FIN_W + 2)
+  int wb = F > FIN_W ? F - FIN_W : 0;
+  auto refill = [&]() {
+    for (int i = tid; i < FIN_W + 3; i += NT) l_tok[i] = wb + i <= F + 1 ? c.tok_off[wb + i] : 0;
+    for (int i = tid; i < 2 * FIN_W + 6; i += NT) l_lnk[i] = 2 * wb + i <= 2 * F + 2 ? c.lnk_off[2 * wb + i] : 0;
+    for (int i = tid; i < FIN_W + 2; i += NT) l_cof[i] = wb + i < F ? c.cost_offsets[wb + i] : 0.0f;
+    __syncthreads();
+  };
+  auto TOF = [&](int x) -> int { return l_tok[x - wb]; };
+  auto LOF = [&](int x) -> int { return l_lnk[x - 2 * wb]; };
+  refill();
   if (tid == 0) {
     s_tok_top = c.tok_cap; s_lnk_top = c.lnk_cap; new_off[F + 1] = c.tok_cap; s_chg[0] = s_chg[1] = s_chg[2] = 0;
     if (MID) nlo[2 * F + 2] = c.lnk_cap;
@@ -1681,9 +1701,9 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
   int rs[FIN_TPT], ns_[FIN_TPT];
   auto prefetch = [&](int f, int2 *psd, float2 *pga, float *pc, int *ps) {
     if (f < 0) return;
-    const int tb = c.tok_off[f], nt = c.tok_off[f + 1] - tb;
-    const int eb = c.lnk_off[2 * f + 1];
-    const int le = f < F ? c.lnk_off[2 * (f + 1) + 1] : c.lnk_off[2 * f + 2];
+    const int tb = TOF(f), nt = TOF(f + 1) - tb;
+    const int eb = LOF(2 * f + 1);
+    const int le = f < F ? LOF(2 * (f + 1) + 1) : LOF(2 * f + 2);
 #pragma unroll
     for (int k = 0; k < FIN_TPT; k++) {
       const int i = tid + k * NT;
@@ -1702,8 +1722,8 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
   };
   auto promote = [&](int f) {   // pack the registers loaded for frame f
     if (f < 0) return;
-    const int tb = c.tok_off[f], tbn = c.tok_off[f + 1];
-    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];
+    const int tb = TOF(f), tbn = TOF(f + 1);
+    const int eb = LOF(2 * f + 1), ee = LOF(2 * f + 2);
 #pragma unroll
     for (int k = 0; k < FIN_PF; k++) {
       Link L; L.src = nsd[k].x; L.dst = nsd[k].y; L.graph = nga[k].x; L.ac = nga[k].y; L.ilabel = 0; L.olabel = 0;
@@ -1719,16 +1739,21 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
   int jit = 0;             // epsilon-fixpoint rounds so far (all frames)
   int cur = 0;
   for (int f = F; f >= 0; f--) {
-    const int tb = c.tok_off[f], nt = c.tok_off[f + 1] - tb;
-    const int tbn = c.tok_off[f + 1], ntn = f < F ? c.tok_off[f + 2] - tbn : 0;
+    if (wb > 0 && f - 1 < wb) {      // uniform: slide the window of offsets
+      LdsBarrier();                  // promote() of the previous iteration has read the old one
+      wb = f > FIN_W ? f - FIN_W : 0;
+      refill();
+    }
+    const int tb = TOF(f), nt = TOF(f + 1) - tb;
+    const int tbn = TOF(f + 1), ntn = f < F ? TOF(f + 2) - tbn : 0;
     if (nt > d.hash_cap) { if (tid == 0) atomicOr(&sh.err, ERR_INTERNAL); __syncthreads(); break; }
-    const int eb = c.lnk_off[2 * f + 1], ee = c.lnk_off[2 * f + 2];       // epsilon links inside frame f
-    const int le = f < F ? c.lnk_off[2 * (f + 1) + 1] : ee;              // emitting links f -> f+1: [ee, le)
-    const float emit_off = c.cost_offsets[f < F ? f : 0];                 // GetRawLattice :173-180 (used for f < F only)
+    const int eb = LOF(2 * f + 1), ee = LOF(2 * f + 2);       // epsilon links inside frame f
+    const int le = f < F ? LOF(2 * (f + 1) + 1) : ee;              // emitting links f -> f+1: [ee, le)
+    const float emit_off = f < F ? l_cof[f - wb] : 0.0f;                        // GetRawLattice :173-180 (used for f < F only)
     prefetch(f - 1, nsd, nga, nc_, ns_);
     const int lnk_top0 = s_lnk_top;   // uniform: the previous iteration ended with a barrier
     const bool lds_mode = nt <= FIN_CAP && ntn <= FIN_CAP;
-    const bool next_hbm_mode = f > 0 && ((c.tok_off[f] - c.tok_off[f - 1]) > FIN_CAP || nt > FIN_CAP);
+    const bool next_hbm_mode = f > 0 && ((TOF(f) - TOF(f - 1)) > FIN_CAP || nt > FIN_CAP);
     int *gp = gpos[f & 1], *gpn = gpos[(f + 1) & 1];
     if (lds_mode) {
       u32 *lx = l_base + cur * FIN_CAP, *nx = l_base + (cur ^ 1) * FIN_CAP;
@@ -1750,6 +1775,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
         }
       }
       LdsBarrier();
+      Stamp(&sh, PH_FIN_FETCH);
       // link_extra_cost (:346-350 / :437-441) of a link held as L; x of the last frame reads
       // as +inf above lattice_beam (:462-463)
       auto xval = [&](const u32 *arr, int i, bool last) {
@@ -1772,6 +1798,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
       }
       for (int li = max(ee, eb + n_reg) + tid; li < le; li += NT) relax_emit(Lite(c.links[li], tb, tbn));
       LdsBarrier();
+      Stamp(&sh, PH_FIN_EMIT);
       if (ee > eb) {
         const bool last = f == F && !MID;
         auto relax_eps = [&](const LinkLite &L) -> int {
@@ -1800,6 +1827,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
           if (!any_changed) break;
         }
       }
+      Stamp(&sh, PH_FIN_EPS);
       if (f == F && !MID) {   // store the clamped values: later reads need no special case
         for (int i = tid; i < nt; i += NT) if (OrderedToFloat(lx[i]) > lattice_beam) lx[i] = INF_O;
         LdsBarrier();
@@ -1872,6 +1900,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
         }
       }
       if (next_hbm_mode) __syncthreads(); else LdsBarrier();   // HBM mode reads tok_extra / positions from global
+      Stamp(&sh, PH_FIN_STAGE);
       prev_lds = true;
       cur ^= 1;
     } else {
@@ -2121,7 +2150,7 @@ __global__ __launch_bounds__(NT, 4) void DecodeQueueKernel(DecDev d, QueueDev q)
     DrainStores();
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: L2 write-back, the copy engine reads HBM
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: the blob's stores have reached host memory
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       kamd_queue_result *r = q.results + qt.utt;
       r->error = err | ((bytes && !fits) ? ERR_POOL : 0);
@@ -2344,7 +2373,7 @@ struct Decoder {
   std::vector<int> trace_known;                  // ... and how many frames of it are valid (0 after InitDecoding)
   unsigned char *d_sil_tid = NULL; int n_sil_tids = 0; int *d_sil_out = NULL; int sil_out_cap = 0;   // endpointing
   // work queue (kamd_decoder_queue_*)
-  unsigned char *d_pool = NULL; unsigned long long pool_cap = 0;
+  unsigned char *d_pool = NULL, *h_pool = NULL; unsigned long long pool_cap = 0;   // the lattice pool: page-locked HOST memory, d_pool = its device address
   unsigned long long *d_pool_used = NULL; int *d_qctl = NULL;       // d_qctl[0] = head, [1] = done count
   kamd_queue_task *d_qtasks = NULL; int qtasks_cap = 0;
   kamd_queue_result *h_results = NULL; int *h_ring = NULL; int ring_cap = 0;   // host-visible (hipHostMalloc, coherent)
@@ -2545,16 +2574,16 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   if (ok && (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess ||
              hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel2),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess ||
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS_BYTES) != hipSuccess ||
              hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::CompactKernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess))
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, FIN_LDS_BYTES) != hipSuccess))
     ok = false;
   if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::AdvanceKernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, d.lds_table_cap))) != hipSuccess)
     ok = false;
   if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::DecodeQueueKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(std::max<size_t>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, d.lds_table_cap), 6 * FIN_CAP * 4))) != hipSuccess)
+                                static_cast<int>(std::max<size_t>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, d.lds_table_cap), FIN_LDS_BYTES))) != hipSuccess)
     ok = false;
   for (int i = 0; ok && i < 2 * Decoder::kMaxTimed; i++) if (hipEventCreate(&D->ev[i]) != hipSuccess) ok = false;
   for (int i = 0; ok && i < 2; i++) if (hipEventCreate(&D->qev[i]) != hipSuccess) ok = false;
@@ -2579,7 +2608,7 @@ void kamd_decoder_destroy(kamd_decoder *h) {
   if (D->d_lanes) (void)hipFree(D->d_lanes);
   if (D->d_tasks) (void)hipFree(D->d_tasks);
   for (int i = 0; i < 2 * Decoder::kMaxTimed; i++) if (D->ev[i]) (void)hipEventDestroy(D->ev[i]);
-  if (D->d_pool) (void)hipFree(D->d_pool);
+  if (D->h_pool) (void)hipHostFree(D->h_pool);
   if (D->d_pool_used) (void)hipFree(D->d_pool_used);
   if (D->d_qctl) (void)hipFree(D->d_qctl);
   if (D->d_qtasks) (void)hipFree(D->d_qtasks);
@@ -2719,7 +2748,7 @@ int kamd_decoder_finalize(kamd_decoder *h, const int32_t *lanes, int n, void *st
   // KAMD_FINALIZE_V1=1 selects the first-generation kernel (mark, then compact in place)
   static const bool v1 = getenv("KAMD_FINALIZE_V1") != NULL && getenv("KAMD_FINALIZE_V1")[0] == '1';
   if (v1) hipLaunchKernelGGL(kamd::FinalizeKernel, dim3(n), dim3(NT), 6 * FIN_CAP * 4, st, D->dev, D->d_lanes);
-  else hipLaunchKernelGGL(kamd::FinalizeKernel2, dim3(n), dim3(NT), 6 * FIN_CAP * 4, st, D->dev, D->d_lanes);
+  else hipLaunchKernelGGL(kamd::FinalizeKernel2, dim3(n), dim3(NT), FIN_LDS_BYTES, st, D->dev, D->d_lanes);
   KAMD_HIP(hipGetLastError());
   D->last_stream = st; D->cached_lane = -1;
   return KAMD_OK;
@@ -2735,7 +2764,7 @@ int kamd_decoder_compact(kamd_decoder *h, const int32_t *lanes, int n, void *str
   hipStream_t st = static_cast<hipStream_t>(stream);
   KAMD_HIP(hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
-  hipLaunchKernelGGL(kamd::CompactKernel, dim3(n), dim3(NT), 6 * FIN_CAP * 4, st, D->dev, D->d_lanes);
+  hipLaunchKernelGGL(kamd::CompactKernel, dim3(n), dim3(NT), FIN_LDS_BYTES, st, D->dev, D->d_lanes);
   KAMD_HIP(hipGetLastError());
   D->last_stream = st; D->cached_lane = -1;
   return KAMD_OK;
@@ -3309,9 +3338,16 @@ int kamd_decoder_queue_configure(kamd_decoder *h, int64_t pool_bytes) {
   Decoder *D = reinterpret_cast<Decoder *>(h);
   if (pool_bytes < 4096) return kamd::SetError(KAMD_ERR_ARG, "lattice pool too small");
   if (static_cast<unsigned long long>(pool_bytes) <= D->pool_cap) return KAMD_OK;
-  if (D->d_pool) (void)hipFree(D->d_pool);
-  D->d_pool = NULL; D->pool_cap = 0;
-  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_pool), static_cast<size_t>(pool_bytes)));
+  // The pool lives in page-locked host memory and the kernel writes an utterance's lattice straight into it (~50 KB per
+  // utterance over the host link, posted stores): a host thread that sees the utterance's status reads the blob where it
+  // is.  (A pool in HBM cost one hipMemcpyAsync + hipStreamSynchronize per utterance -- 14 per millisecond at the
+  // headline rate, all through the runtime's locks: the host tail took twice as long per utterance on 64 threads as on 32.)
+  if (D->h_pool) (void)hipHostFree(D->h_pool);
+  D->h_pool = NULL; D->d_pool = NULL; D->pool_cap = 0;
+  KAMD_HIP(hipHostMalloc(reinterpret_cast<void **>(&D->h_pool), static_cast<size_t>(pool_bytes), hipHostMallocDefault));
+  void *dp = NULL;
+  KAMD_HIP(hipHostGetDevicePointer(&dp, D->h_pool, 0));
+  D->d_pool = static_cast<unsigned char *>(dp);
   D->pool_cap = static_cast<unsigned long long>(pool_bytes);
   return KAMD_OK;
 }
@@ -3369,7 +3405,7 @@ int kamd_decoder_queue_launch(kamd_decoder *h, const kamd_queue_task *tasks, int
   q.results = static_cast<kamd_queue_result *>(dp);
   KAMD_HIP(hipHostGetDevicePointer(&dp, D->h_ring, 0));
   q.done_ring = static_cast<int *>(dp);
-  const size_t lds = std::max<size_t>(kamd::AdvanceLdsBytes(D->dev.num_pdfs_lds, D->dev.lds_table_cap), 6 * FIN_CAP * 4);
+  const size_t lds = std::max<size_t>(kamd::AdvanceLdsBytes(D->dev.num_pdfs_lds, D->dev.lds_table_cap), FIN_LDS_BYTES);
   KAMD_HIP(hipEventRecord(D->qev[0], st));
   hipLaunchKernelGGL(kamd::DecodeQueueKernel, dim3(R), dim3(NT), lds, st, D->dev, q);
   KAMD_HIP(hipGetLastError());
@@ -3413,26 +3449,11 @@ int kamd_decoder_queue_fetch_lattice(kamd_decoder *h, int32_t utt, void *copy_st
                           (r.error & 8) ? " max-frames" : "", (r.error & 16) ? " worklist" : "", (r.error & 32) ? " internal" : "",
                           (r.error & 64) ? " lattice-pool" : "", r.n_frames);
   const int F = r.n_frames, nt = r.n_tok, nl = r.n_link, n_last = r.n_last;
-  // Page-locked landing buffer, one per calling thread (grow-only): a copy into pinned memory goes to the DMA engines,
-  // which run beside the queue kernel; a copy into pageable memory is a blit KERNEL, and that cannot start while
-  // every CU's register file is held by a decoder lane (measured: all fetches piled up behind the kernel's end).
-  struct Pinned { unsigned char *p = NULL; size_t cap = 0; ~Pinned() { if (p) (void)hipHostFree(p); } };
-  static thread_local Pinned land;
+  (void)copy_stream;                     // nothing to copy: the blob is in host memory already (kamd_decoder_queue_configure)
   const size_t bytes = static_cast<size_t>(r.blob_bytes);
-  if (bytes > land.cap) {
-    if (land.p) (void)hipHostFree(land.p);
-    land.p = NULL; land.cap = 0;
-    const size_t want = std::max<size_t>(bytes + bytes / 2, 1 << 20);
-    KAMD_HIP(hipHostMalloc(reinterpret_cast<void **>(&land.p), want, hipHostMallocDefault));
-    land.cap = want;
-  }
-  if (bytes) {
-    hipStream_t cs = static_cast<hipStream_t>(copy_stream);
-    KAMD_HIP(hipMemcpyAsync(land.p, D->d_pool + r.blob_off, bytes, hipMemcpyDeviceToHost, cs));
-    KAMD_HIP(hipStreamSynchronize(cs));
-  }
+  const unsigned char *blob = D->h_pool + r.blob_off;
   if (bytes < (static_cast<size_t>(F + 2) + 2ull * nt + n_last + 6ull * nl) * 4) return kamd::SetError(KAMD_ERR_STATE, "utterance %d: short lattice blob", utt);
-  const int *toff = reinterpret_cast<const int *>(land.p);
+  const int *toff = reinterpret_cast<const int *>(blob);
   const int *st = toff + (F + 2);
   const float *co = reinterpret_cast<const float *>(st + nt);
   const float *lf = co + nt;

@@ -2,8 +2,9 @@
 P = 6000) and the tglarge-scale synthetic HCLG (31 M states, 69 M arcs: beyond the Infinity Cache), through the
 test-set decoder (work queue, host tail).  Sampled utterances must equal the oracle bit for bit given the device's
 log-likelihoods (both search modes), the order-faithful mode 0 must give the same 1-best, nnet rows agree to 1e-4 of
-the output scale, and the two paths that only this size exercises must actually have been taken: log-likelihood rows
-wider than the LDS staging area, and frames with more tokens than the level-1 (LDS) table holds."""
+the output scale, and what this size exercises must actually have been taken: a 24 KB log-likelihood row that is DMA'd
+into LDS whole, one frame ahead (rows wider than the staging area: tests/test_gpu_decoder.py, P = 9000), and frames with
+more tokens than the level-1 (LDS) table holds."""
 import ctypes as C
 
 import numpy as np
@@ -41,7 +42,7 @@ def test_configs2_queue_decode_equals_oracle(world, mode):
                                 nnet_pass_frames=1500)
     n_lds, tbl = C.c_int32(), C.c_int32()
     assert lib().kamd_decoder_lds_layout(bd.dec._dec, C.byref(n_lds), C.byref(tbl)) == 0
-    assert 0 < n_lds.value < g.num_pdfs            # P = 6000 does not fit beside the table: the HBM tail of the row is read
+    assert n_lds.value == g.num_pdfs               # the whole row of P = 6000 is staged in LDS beside the tables
     bd.load(waves)
     st = bd.run()
     assert st.n_failed == 0 and st.nnet_passes > 1

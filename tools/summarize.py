@@ -4,8 +4,12 @@ With file arguments nothing is read from stdin (a call without a pipe must not s
 import json
 import sys
 
+import os
+
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 files = sys.argv[2:]
+if not files and os.path.isfile(tag):              # "summarize.py file.json": the tag was left out
+    files, tag = [tag], os.path.basename(tag)
 if not files and sys.stdin.isatty():
     sys.exit("usage: bench.py ... | summarize.py [tag]   or   summarize.py tag file.json ...")
 
