@@ -95,6 +95,7 @@ static int GrowDev(T **p, size_t *cap, size_t need) {
 static void HostTail(BatchDecoder *b, int u, hipStream_t cs) {      // u: the queue's utterance number = position in `kept`
   const auto t0 = std::chrono::steady_clock::now();
   UttOut &o = b->out[b->kept[u]];
+  o.Clear();                             // what the previous run left in this slot
   int rc = kamd_decoder_queue_result(b->dec, u, &o.rec);
   if (rc == KAMD_OK)
     rc = kamd_decoder_queue_fetch_lattice(b->dec, u, cs, &o.num_states, &o.num_arcs, &o.start, &o.st_frame, &o.st_hclg, &o.st_cost,
@@ -295,9 +296,12 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
   if (b->n_utts <= 0) return kamd::SetError(KAMD_ERR_STATE, "no test set loaded");
   const int n = static_cast<int>(b->kept.size());
-  for (kamd::UttOut &o : b->out) o.Clear();
+  // the previous run's lattices are freed by the worker that fills the slot again (HostTail): 2620 compact lattices are
+  // milliseconds of free() that need not sit in front of the first launch
+  for (kamd::UttOut &o : b->out) { o.done = 0; o.status = KAMD_OK; }
   for (int u : b->skipped) {
     kamd::UttOut &o = b->out[u];
+    o.Clear();
     memset(&o.rec, 0, sizeof(o.rec));
     o.status = KAMD_ERR_ARG; o.message = "utterance " + std::to_string(u) + ": too short for one frame"; o.done = 1;
   }

@@ -55,6 +55,15 @@ __device__ inline int FindUtt(const int64_t *off, int n, int64_t g) {
   return lo;
 }
 
+// A wavefront works on its own frame in its own LDS region: ordering its LDS accesses needs no workgroup barrier (the
+// four frames of a workgroup would only wait for each other, a dozen times per frame), just that the compiler keeps the
+// order -- one wavefront's LDS instructions execute in issue order.
+__device__ inline void WaveSync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(256) void FeatKernel(
     FeatDev fd, const float *__restrict__ waves, const int64_t *__restrict__ wave_off,
     const int64_t *__restrict__ frame_off /* [n_utts+1] cumulative frames */,
@@ -67,6 +76,10 @@ __global__ __launch_bounds__(256) void FeatKernel(
   float *re = smem + wave * (2 * N + 128);
   float *im = re + N;
   float *aux = im + N;  // [128]: log-mel energies etc.
+  // twiddles of the whole workgroup, staged once (every butterfly of every stage reads a pair)
+  float *tw_c = smem + 4 * (2 * N + 128), *tw_s = tw_c + (N >> 1);
+  for (int i = threadIdx.x; i < (N >> 1); i += 256) { tw_c[i] = fd.tw_cos[i]; tw_s[i] = fd.tw_sin[i]; }
+  __syncthreads();
   const bool pairs = n_utts < 0;          // wave_off holds (start, end) pairs: items are not adjacent
   if (pairs) n_utts = -n_utts;
   const int64_t total = frame_off[n_utts];
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256) void FeatKernel(
   // stage un-windowed samples in LDS so every lane can read its left neighbour
 #pragma unroll
   for (int j = 0; j < 16; j++) { int s = lane + 64 * j; if (s < N) re[s] = x[j]; }
-  __syncthreads();
+  WaveSync();
   if (fd.preemph != 0.f) {
 #pragma unroll
     for (int j = 0; j < 16; j++) {
@@ -132,7 +145,7 @@ __global__ __launch_bounds__(256) void FeatKernel(
       }
     }
   }
-  __syncthreads();
+  WaveSync();
   float win_energy = 0.f;
 #pragma unroll
   for (int j = 0; j < 16; j++) {
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(256) void FeatKernel(
       im[r] = 0.f;
     }
   }
-  __syncthreads();
+  WaveSync();
   const int half_n = N >> 1;
   for (int st = 0; st < lg; st++) {
     const int half = 1 << st;
@@ -165,14 +178,14 @@ __global__ __launch_bounds__(256) void FeatKernel(
       int i0 = ((b >> st) << (st + 1)) + k;
       int i1 = i0 + half;
       int tw = k << (lg - 1 - st);
-      float wr = fd.tw_cos[tw], wi = fd.tw_sin[tw];
+      float wr = tw_c[tw], wi = tw_s[tw];
       float xr = re[i1], xi = im[i1];
       float tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
       float ar = re[i0], ai = im[i0];
       re[i1] = ar - tr; im[i1] = ai - ti;
       re[i0] = ar + tr; im[i0] = ai + ti;
     }
-    __syncthreads();
+    WaveSync();
   }
   // --- power spectrum bins 0..N/2 (feature-functions.cc:29-51), kept in re[]
   for (int k = lane; k <= half_n; k += 64) {
@@ -180,7 +193,7 @@ __global__ __launch_bounds__(256) void FeatKernel(
     if (!fd.use_power) p = sqrtf(p);   // FbankComputer: ApplyPow(0.5) (feature-fbank.cc:97-98)
     im[k] = p;                         // write to im[] to avoid racing with re[] readers
   }
-  __syncthreads();
+  WaveSync();
   // --- mel filterbank: one lane per bin (mel-computations.cc:226-252)
   for (int b = lane; b < fd.num_bins; b += 64) {
     const float *w = fd.mel_w + fd.mel_off[b];
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(256) void FeatKernel(
     if (fd.use_log) e = logf(fmaxf(e, 1.1920928955078125e-07f));
     aux[b] = e;
   }
-  __syncthreads();
+  WaveSync();
   if (!live) return;
   float *orow = out + (row_off[u] + (f - frame0)) * static_cast<int64_t>(ld_out);
   if (fd.is_mfcc) {
@@ -467,7 +480,7 @@ int kamd_feat_compute_batch_device(kamd_feat *h, const float *d_waves, const int
   KAMD_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));  // 'meta' is a host temporary
   int blocks = kamd::CeilDiv(tot, 4);
-  size_t lds = 4 * (2 * f->dev.N + 128) * sizeof(float);
+  size_t lds = (4 * (2 * f->dev.N + 128) + f->dev.N) * sizeof(float);
   hipLaunchKernelGGL(kamd::FeatKernel, dim3(blocks), dim3(256), lds, st, f->dev, d_waves, d_meta,
                      d_meta + (n_utts + 1), d_meta + 2 * (n_utts + 1), n_utts, d_out, ld_out, 0, NULL);
   KAMD_HIP(hipGetLastError());
@@ -508,7 +521,7 @@ int kamd_feat_compute_ranges_device(kamd_feat *h, const float *d_waves, const in
   int64_t *d_meta = f->d_meta;
   KAMD_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));  // 'meta' is a host temporary
-  const size_t lds = 4 * (2 * f->dev.N + 128) * sizeof(float);
+  const size_t lds = (4 * (2 * f->dev.N + 128) + f->dev.N) * sizeof(float);
   hipLaunchKernelGGL(kamd::FeatKernel, dim3(kamd::CeilDiv(tot, 4)), dim3(256), lds, st, f->dev, d_waves, d_meta,
                      d_meta + 2 * (n + 1), d_meta + 3 * (n + 1), -n, d_out, ld_out, 0,
                      reinterpret_cast<const int *>(d_meta + 4 * (n + 1)));
@@ -545,7 +558,7 @@ int kamd_feat_compute_frames_device(kamd_feat *h, const float *d_wave, int64_t n
   }
   KAMD_HIP(hipMemcpyAsync(f->d_meta, meta, sizeof(meta), hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
-  const size_t lds = 4 * (2 * f->dev.N + 128) * sizeof(float);
+  const size_t lds = (4 * (2 * f->dev.N + 128) + f->dev.N) * sizeof(float);
   hipLaunchKernelGGL(kamd::FeatKernel, dim3(kamd::CeilDiv(num_frames, 4)), dim3(256), lds, st, f->dev, d_wave, f->d_meta,
                      f->d_meta + 2, f->d_meta + 4, 1, d_out, ld_out, first_frame, NULL);
   KAMD_HIP(hipGetLastError());
