@@ -1623,8 +1623,12 @@ __device__ inline LinkLite Lite(const Link &L, int src_base, int dst_base) {
   r.graph = L.graph; r.ac = L.ac;
   return r;
 }
-#define FIN_PF 4                          // links per thread held in registers (one frame ahead)
-#define FIN_TPT ((FIN_CAP + NT - 1) / NT) // tokens per thread held in registers
+#ifndef FIN_PF
+#define FIN_PF 2                          // links per thread held in registers (one frame ahead)
+#endif
+#ifndef FIN_TR
+#define FIN_TR 2                          // tokens per thread held in registers (one frame ahead); the rest of a larger frame is read in place
+#endif
 #define FIN_W (NT / 2)                    // frames whose offsets the sweep keeps in LDS
 #define FIN_LDS_BYTES (6 * FIN_CAP * 4 + (4 * FIN_W + 11) * 4)
 
@@ -1697,15 +1701,15 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
   // registers: frame f (cur) and frame f-1 (nxt)
   LinkLite rl[FIN_PF];     // frame f, packed
   int2 nsd[FIN_PF]; float2 nga[FIN_PF];   // frame f-1 as loaded (nothing may be computed on them before the next iteration: that would wait for the loads)
-  float rc[FIN_TPT], nc_[FIN_TPT];
-  int rs[FIN_TPT], ns_[FIN_TPT];
+  float rc[FIN_TR], nc_[FIN_TR];
+  int rs[FIN_TR], ns_[FIN_TR];
   auto prefetch = [&](int f, int2 *psd, float2 *pga, float *pc, int *ps) {
     if (f < 0) return;
     const int tb = TOF(f), nt = TOF(f + 1) - tb;
     const int eb = LOF(2 * f + 1);
     const int le = f < F ? LOF(2 * (f + 1) + 1) : LOF(2 * f + 2);
 #pragma unroll
-    for (int k = 0; k < FIN_TPT; k++) {
+    for (int k = 0; k < FIN_TR; k++) {
       const int i = tid + k * NT;
       pc[k] = 0.f; ps[k] = 0;
       if (i < nt) { pc[k] = c.tok_cost[tb + i]; ps[k] = c.tok_state[tb + i]; }
@@ -1730,7 +1734,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
       rl[k] = Lite(L, tb, (eb + tid + k * NT) < ee ? tb : tbn);
     }
 #pragma unroll
-    for (int k = 0; k < FIN_TPT; k++) { rc[k] = nc_[k]; rs[k] = ns_[k]; }
+    for (int k = 0; k < FIN_TR; k++) { rc[k] = nc_[k]; rs[k] = ns_[k]; }
   };
   prefetch(F, nsd, nga, nc_, ns_);
   promote(F);
@@ -1765,7 +1769,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
         }
       }
 #pragma unroll
-      for (int k = 0; k < FIN_TPT; k++) {
+      for (int k = 0; k < FIN_TR; k++) {
         const int i = tid + k * NT;
         if (i < nt) {
           lc[i] = rc[k];
@@ -1773,6 +1777,18 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
           if (f == F) b = MID ? 0.0f : rc[k] + (finals_empty ? 0.0f : d.g.final[rs[k]]) - final_best;   // :430 (MID: :289 extra_cost = 0)
           lx[i] = FloatToOrdered(b);
         }
+      }
+      // a frame of more than FIN_TR * NT tokens: the rest is read where it lies (an exposed round trip, on the few
+      // large frames; holding FIN_CAP / NT tokens per thread in registers spilled the whole pipeline to scratch in the
+      // fused kernel -- the records 'prefetched' for the next frame were waited for at once, to be stored).  Their
+      // states wait in lp[], which is free until the staging below fills it.
+      for (int i = FIN_TR * NT + tid; i < nt; i += NT) {
+        const float co = c.tok_cost[tb + i];
+        const int st = c.tok_state[tb + i];
+        lc[i] = co; lp[i] = st;
+        float b = INFINITY;
+        if (f == F) b = MID ? 0.0f : co + (finals_empty ? 0.0f : d.g.final[st]) - final_best;
+        lx[i] = FloatToOrdered(b);
       }
       LdsBarrier();
       Stamp(&sh, PH_FIN_FETCH);
@@ -1836,7 +1852,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
       // [tok_top - survivors, tok_top): frame f's own records are in registers already and
       // everything above them is dead, so no ordering is needed.
 #pragma unroll
-      for (int k = 0; k < FIN_TPT; k++) {
+      for (int k = 0; k < FIN_TR; k++) {
         const int i = tid + k * NT;
         if (i < nt) {
           const bool alive = lx[i] != INF_O;
@@ -1845,6 +1861,13 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
           lp[i] = pos;
           if (next_hbm_mode) { c.tok_extra[tb + i] = OrderedToFloat(lx[i]); gp[i] = pos; }
         }
+      }
+      for (int i = FIN_TR * NT + tid; i < nt; i += NT) {      // the part of a large frame that is not in registers
+        const bool alive = lx[i] != INF_O;
+        int pos = -1;
+        if (alive) { pos = WaveAllocDown(&s_tok_top); c.tok_state[pos] = lp[i]; stage_cost[pos] = lc[i]; }
+        lp[i] = pos;
+        if (next_hbm_mode) { c.tok_extra[tb + i] = OrderedToFloat(lx[i]); gp[i] = pos; }
       }
       LdsBarrier();
       if (tid == 0) new_off[f] = s_tok_top;
