@@ -199,22 +199,67 @@ __device__ inline int PlainState(int flagged) { return flagged & 0x7FFFFFFF; }
 __device__ inline bool HasEps(int flagged) { return (static_cast<u32>(flagged) & EPS_FLAG) != 0; }
 
 // one slot from a workgroup counter for every ACTIVE lane of the wavefront (call under
-// the predicate): wavefront-ballot aggregation => one LDS atomic per wavefront.
+// the predicate): wavefront-ballot aggregation => one LDS atomic per wavefront.  The leader
+// is the first active lane: v_readfirstlane hands its result round (a __shfl would be a
+// ds_bpermute, ~100 cycles through the LDS crossbar, on every call of the inner loops).
 __device__ inline int WaveAlloc(int *counter) {
   const u64 m = __ballot(1);
   const int lane = threadIdx.x & 63;
   const int leader = __ffsll(static_cast<long long>(m)) - 1;
   int base = 0;
   if (lane == leader) base = atomicAdd(counter, __popcll(m));
-  base = __shfl(base, leader, 64);
+  base = __builtin_amdgcn_readfirstlane(base);
   return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
-__device__ inline u64 BlockMin64(u64 v, Sh *sh) {
-  for (int o = 32; o > 0; o >>= 1) {
-    u64 t = __shfl_xor(v, o, 64);
-    v = t < v ? t : v;
+// Full-wavefront reductions on the DPP path (call with every lane active).  Two quad permutes, row_half_mirror and
+// row_mirror leave the total of each row of 16 in all its lanes, four v_readlane combine the rows: ~50 cycles, against
+// ~600 for the six dependent ds_bpermute of a __shfl_xor butterfly (measured on 1024-thread workgroups: a 64-bit
+// workgroup min built on shuffles costs 2.1 us, four or five of those sat in every frame).
+#define KAMD_DPP(x, ctrl) __builtin_amdgcn_update_dpp(0, (x), (ctrl), 0xf, 0xf, false)
+#define KAMD_DPP_STEPS(OP) OP(0xB1) OP(0x4E) OP(0x141) OP(0x140)   /* quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror */
+__device__ inline int WaveSumI(int v) {
+#define KAMD_OP(c) v += KAMD_DPP(v, c);
+  KAMD_DPP_STEPS(KAMD_OP)
+#undef KAMD_OP
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ inline float WaveMinF(float v) {
+#define KAMD_OP(c) v = fminf(v, __int_as_float(KAMD_DPP(__float_as_int(v), c)));
+  KAMD_DPP_STEPS(KAMD_OP)
+#undef KAMD_OP
+  const int i = __float_as_int(v);
+  return fminf(fminf(__int_as_float(__builtin_amdgcn_readlane(i, 0)), __int_as_float(__builtin_amdgcn_readlane(i, 16))),
+               fminf(__int_as_float(__builtin_amdgcn_readlane(i, 32)), __int_as_float(__builtin_amdgcn_readlane(i, 48))));
+}
+// inclusive prefix sum over the wavefront: Hillis-Steele inside the rows of 16 (row_shr, zero fill), then the totals of
+// the rows before
+__device__ inline int WaveInclScanI(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
+  const int row = (threadIdx.x & 63) >> 4;
+  return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
+}
+__device__ inline u64 WaveMin64(u64 v) {
+#define KAMD_OP(c) { const u64 t = (static_cast<u64>(static_cast<u32>(KAMD_DPP(static_cast<int>(v >> 32), c))) << 32) | \
+                                   static_cast<u32>(KAMD_DPP(static_cast<int>(v), c)); v = t < v ? t : v; }
+  KAMD_DPP_STEPS(KAMD_OP)
+#undef KAMD_OP
+  u64 r = ~0ull;
+#pragma unroll
+  for (int l = 0; l < 64; l += 16) {
+    const u64 t = (static_cast<u64>(static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(v >> 32), l))) << 32) |
+                  static_cast<u32>(__builtin_amdgcn_readlane(static_cast<int>(v), l));
+    r = t < r ? t : r;
   }
+  return r;
+}
+
+__device__ inline u64 BlockMin64(u64 v, Sh *sh) {
+  v = WaveMin64(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh->red64[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -225,7 +270,7 @@ __device__ inline u64 BlockMin64(u64 v, Sh *sh) {
 template <bool kLdsOnly = false> __device__ inline void Bar() { if (kLdsOnly) LdsBarrier(); else __syncthreads(); }
 template <bool kLdsOnly = false>
 __device__ inline void BlockSum2(int &a, int &b, Sh *sh) {
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+  a = WaveSumI(a); b = WaveSumI(b);
   Bar<kLdsOnly>();
   if ((threadIdx.x & 63) == 0) { sh->redi[threadIdx.x >> 6] = a; sh->redj[threadIdx.x >> 6] = b; }
   Bar<kLdsOnly>();
@@ -234,9 +279,7 @@ __device__ inline void BlockSum2(int &a, int &b, Sh *sh) {
 }
 template <bool kLdsOnly = false>
 __device__ inline void BlockSum4(int &a, int &b, int &c2, int &d2, Sh *sh) {
-  for (int o = 32; o > 0; o >>= 1) {
-    a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c2 += __shfl_xor(c2, o, 64); d2 += __shfl_xor(d2, o, 64);
-  }
+  a = WaveSumI(a); b = WaveSumI(b); c2 = WaveSumI(c2); d2 = WaveSumI(d2);
   Bar<kLdsOnly>();
   if ((threadIdx.x & 63) == 0) {
     const int w = threadIdx.x >> 6;
@@ -248,7 +291,7 @@ __device__ inline void BlockSum4(int &a, int &b, int &c2, int &d2, Sh *sh) {
 }
 template <bool kLdsOnly = false>
 __device__ inline float BlockMinF(float v, Sh *sh) {
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  v = WaveMinF(v);
   Bar<kLdsOnly>();
   if ((threadIdx.x & 63) == 0) sh->redf[threadIdx.x >> 6] = v;
   Bar<kLdsOnly>();
@@ -351,8 +394,7 @@ __device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float b
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int h0 = lh[3 * t], h1 = lh[3 * t + 1], h2 = lh[3 * t + 2];
     const int mine = h0 + h1 + h2;
-    int incl = mine;
-    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const int incl = WaveInclScanI(mine);
     if (lane == 63) sh->redi[w] = incl;
     __syncthreads();
     int wbase = 0;
@@ -892,7 +934,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
   // full barrier only when level-2 entries or list overflow put data in HBM that others read
   const bool hbm_lists = ns2 > 0;
   if (hbm_lists) kmin = BlockMin64(kmin, sh); else {
-    for (int o = 32; o > 0; o >>= 1) { const u64 t = __shfl_xor(kmin, o, 64); kmin = t < kmin ? t : kmin; }
+    kmin = WaveMin64(kmin);
     LdsBarrier();
     if ((tid & 63) == 0) sh->red64[tid >> 6] = kmin;
     LdsBarrier();
@@ -966,7 +1008,16 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
     }
     DrainStores();   // the next frame's CAS / atomicMin must find the cleared words in L2
   }
-  BlockSum4<true>(k_surv, a_eps, c_lt, c_le, sh);
+  // the two work counters need no workgroup total in this frame: one LDS atomic per wavefront onto the running sums
+  {
+    const int ks = WaveSumI(k_surv), ae = WaveSumI(a_eps);
+    if ((tid & 63) == 0) {
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sh->cnt[1]), static_cast<unsigned long long>(ae));   // A_exp: epsilon arcs of surviving tokens
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sh->cnt[3]), static_cast<unsigned long long>(ks));   // K_surv
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sh->cnt[4]), static_cast<unsigned long long>(ks));   // L_kept (+ the epsilon links below)
+    }
+  }
+  BlockSum2<true>(c_lt, c_le, sh);
   if (tid == 0) {
     const int n_eps_links = min(sh->wl_n[0], c.lnk_cap - eps_link_begin);
     c.tok_off[list + 1] = tok_base + n_new;
@@ -975,9 +1026,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
     S->lnk_used = eps_link_begin + n_eps_links;
     S->round = round;
     sh->round = round; sh->lnk_used = eps_link_begin + n_eps_links; sh->cur_tb = tok_base; sh->cur_n = n_new;
-    sh->cnt[1] += a_eps;                 // A_exp: epsilon arcs of surviving tokens
-    sh->cnt[3] += k_surv;                // K_surv
-    sh->cnt[4] += k_surv + n_eps_links;  // L_kept
+    atomicAdd(reinterpret_cast<unsigned long long *>(&sh->cnt[4]), static_cast<unsigned long long>(n_eps_links));
     sh->cnt[5] += n_new;                 // N_tok
     sh->best_key = kmin; sh->c_lt = c_lt; sh->c_le = c_le;
     sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->n_new = 0;
@@ -1256,9 +1305,8 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
         if (e0 + 1 < nb) v1 = big_scan[e0 + 1];
         if (e0 + 2 < nb) v2 = big_scan[e0 + 2];
         const int mine = v0 + v1 + v2;
-        int incl = mine;
         const int lane = tid & 63, w = tid >> 6;
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        const int incl = WaveInclScanI(mine);
         LdsBarrier();
         if (lane == 63) sh.redi[w] = incl;
         LdsBarrier();
@@ -1330,10 +1378,14 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
     LdsBarrier();
     Stamp(&sh, PH_EXPAND);
     {
-      int ne = n_exp, ae = static_cast<int>(a_emit);
-      BlockSum2<true>(ne, ae, &sh);
+      const int ne = WaveSumI(n_exp), ae = WaveSumI(static_cast<int>(a_emit));
+      if ((tid & 63) == 0) {   // work counters: running sums, nobody needs this frame's total
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sh.cnt[0]), static_cast<unsigned long long>(ne));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sh.cnt[1]), static_cast<unsigned long long>(ae));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sh.cnt[2]), static_cast<unsigned long long>(ae));
+      }
       if (tid == 0) {
-        sh.cnt[0] += ne; sh.cnt[1] += ae; sh.cnt[2] += ae; sh.cnt[6] += 1;
+        sh.cnt[6] += 1;
         c.lnk_off[2 * (frame + 1) + 1] = link_base + min(sh.n_links, c.lnk_cap - link_base);   // for finalize / the host
       }
     }
@@ -1609,7 +1661,7 @@ __device__ inline int WaveAllocDown(int *top) {
   const int leader = __ffsll(static_cast<long long>(m)) - 1;
   int base = 0;
   if (lane == leader) base = atomicSub(top, __popcll(m));
-  base = __shfl(base, leader, 64);
+  base = __builtin_amdgcn_readfirstlane(base);
   return base - 1 - __popcll(m & ((1ull << lane) - 1ull));
 }
 
