@@ -474,7 +474,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s: %d synthetic utterances (%.2f h, lognormal 1-35 s) sharded over %d GPU(s), %s TDNN-F chain "
                                "topology (random init, P=%d), synthetic %s-scale HCLG (%d states, %d arcs), beam 15 max-active 7000 "
-                               "min-active 200 lattice-beam 8, %s lanes/GPU fed by a device work queue, host tail (D2H, best path, "
+                               "min-active 200 lattice-beam 8, %s lanes/GPU fed by a device work queue, host tail (lattice read from the page-locked pool, best path, "
                                "%s) on %d threads/GPU inside the timed region" %
                                ("LibriSpeech test-clean sized test set" if args.workload == "librispeech" else args.workload + " set",
                                 durs.size, durs.sum() / 3600.0, world, args.workload, g.num_pdfs, args.graph, g.num_states, g.num_arcs,
