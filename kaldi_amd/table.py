@@ -245,11 +245,53 @@ class SequentialTableReader:
 
     def __iter__(self):
         last = None
-        for key, val in self._entries():
+        for key, val in (self._background() if self.opts["background"] else self._entries()):
             if self.opts["sorted"] and last is not None and key <= last:
                 raise KamdError("rspecifier %s: keys are not in sorted order (%s after %s)" % (self.rspecifier, key, last))
             last = key
             yield key, val
+
+    def _background(self):
+        """The `bg` option (SequentialTableReaderBackgroundImpl, util/kaldi-table-inl.h:1080-1290): the next object is
+        read by a second thread while the consumer works on the current one -- one object ahead, like the reference;
+        what the reading thread raises is raised where the object would have been delivered."""
+        import queue
+        import threading
+        q = queue.Queue(maxsize=1)
+        stop = threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def produce():
+            try:
+                for kv in self._entries():
+                    if not put(("item", kv)):
+                        return
+                put(("end", None))
+            except BaseException as e:           # delivered to the consumer
+                put(("error", e))
+
+        t = threading.Thread(target=produce, daemon=True)
+        t.start()
+        try:
+            while True:
+                what, v = q.get()
+                if what == "item":
+                    yield v
+                elif what == "error":
+                    raise v
+                else:
+                    return
+        finally:
+            stop.set()                            # a consumer that stops early releases the reader
+            t.join()
 
     def _entries(self):
         if self.type == ARCHIVE:

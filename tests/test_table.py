@@ -256,3 +256,34 @@ def test_double_matrix_tables_round_trip(tmp_path):
     (k, m), = list(T.SequentialTableReader("ark:%s" % (tmp_path / "f.ark"), "dmatrix"))
     assert k == "x" and m.dtype == np.float64
     np.testing.assert_array_equal(m, mats["spk1"].astype(np.float32).astype(np.float64))
+
+
+def test_background_reader_option(tmp_path):
+    """`bg` (SequentialTableReaderBackgroundImpl, util/kaldi-table-inl.h): same objects in the same order, read one ahead
+    by a second thread; its errors surface at the object they belong to; a consumer that stops early does not hang."""
+    import threading
+    rng = np.random.default_rng(3)
+    mats = {"utt%02d" % i: rng.standard_normal((rng.integers(1, 9), 4)).astype(np.float32) for i in range(9)}
+    ark, scp = str(tmp_path / "b.ark"), str(tmp_path / "b.scp")
+    with T.TableWriter("ark,scp:%s,%s" % (ark, scp), "matrix") as w:
+        for k in sorted(mats):
+            w.write(k, mats[k])
+    assert T.classify_rspecifier("ark,bg:" + ark)[2]["background"]
+    n0 = threading.active_count()
+    for spec in ("ark,bg:" + ark, "scp,bg:" + scp, "ark,s,cs,bg:cat %s |" % ark):
+        got = list(T.SequentialTableReader(spec, "matrix"))
+        assert [k for k, _ in got] == sorted(mats)
+        for k, v in got:
+            np.testing.assert_array_equal(v, mats[k])
+    it = iter(T.SequentialTableReader("ark,bg:" + ark, "matrix"))
+    assert next(it)[0] == "utt00"
+    it.close()                                                   # early exit: the reading thread is released and joined
+    assert threading.active_count() == n0
+    lines = open(scp).read().splitlines()
+    open(scp, "w").write("\n".join(lines[:3] + ["bad /no/such/file"] + lines[3:]) + "\n")
+    seen = []
+    with pytest.raises((KamdError, OSError)):
+        for k, _ in T.SequentialTableReader("scp,bg:" + scp, "matrix"):
+            seen.append(k)
+    assert seen == sorted(mats)[:3]                              # everything before the bad entry was delivered
+    assert [k for k, _ in T.SequentialTableReader("scp,bg,p:" + scp, "matrix")] == sorted(mats)
