@@ -2645,7 +2645,11 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   const size_t lds_budget = 160 * 1024 / LANES_PER_CU - sizeof(kamd::Sh) - 1024;
   const size_t fixed = kamd::AdvanceLdsBytes(0, LDS_TABLE_CAP);
   if (fixed < lds_budget) d.num_pdfs_lds = static_cast<int>(std::min<size_t>(static_cast<size_t>(num_pdfs), (lds_budget - fixed) / 4) & ~static_cast<size_t>(3));
-  if (d.num_pdfs_lds + 3 >= num_pdfs && kamd::AdvanceLdsBytes(num_pdfs, LDS_TABLE_CAP) <= lds_budget) d.num_pdfs_lds = num_pdfs;
+  // the row is filled by LDS-DMA, whose LDS base travels in M0[15:0]: keep its end below 64 KB (the row starts behind the
+  // static part, <= 4 KB, and the flatten queue)
+  const size_t dma_reach = (65536 - 4096 - (3 * BIGCAP + 4) * 4) / 4;
+  if (static_cast<size_t>(d.num_pdfs_lds) > dma_reach) d.num_pdfs_lds = static_cast<int>(dma_reach & ~static_cast<size_t>(3));
+  if (d.num_pdfs_lds + 3 >= num_pdfs && static_cast<size_t>(num_pdfs) <= dma_reach && kamd::AdvanceLdsBytes(num_pdfs, LDS_TABLE_CAP) <= lds_budget) d.num_pdfs_lds = num_pdfs;
   if (ok && (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 6 * FIN_CAP * 4) != hipSuccess ||
              hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel2),
