@@ -1675,12 +1675,10 @@ __device__ inline LinkLite Lite(const Link &L, int src_base, int dst_base) {
   r.graph = L.graph; r.ac = L.ac;
   return r;
 }
-#ifndef FIN_PF
-#define FIN_PF 2                          // links per thread held in registers (one frame ahead)
-#endif
-#ifndef FIN_TR
-#define FIN_TR 2                          // tokens per thread held in registers (one frame ahead); the rest of a larger frame is read in place
-#endif
+// FIN_PF / FIN_TR (template parameters of the sweep): links / tokens per thread held in registers one frame ahead; the rest
+// of a larger frame is read in place.  The standalone kernels keep a whole LDS-mode frame (FIN_CAP / NT tokens, 4 links
+// per thread: 52 VGPRs that fit their own 128), the fused work-queue kernel two of each (22 VGPRs: with more, the compiler
+// spilled the pipeline and every "prefetched" record was waited for at once, to be stored to scratch).
 #define FIN_W (NT / 2)                    // frames whose offsets the sweep keeps in LDS
 #define FIN_LDS_BYTES (6 * FIN_CAP * 4 + (4 * FIN_W + 11) * 4)
 
@@ -1702,7 +1700,7 @@ struct FinSh { int tok_top, lnk_top, chg[3]; };
 // offsets rebuilt, so that AdvanceDecoding continues on a lane whose dead tokens and links are gone.  Nothing that the
 // final sweep keeps is ever dropped here: a token's extra cost against the current frontier is a lower bound of its
 // final one, and the final sweep's minima are over links this one keeps.
-template <bool MID>
+template <bool MID, int FIN_TR, int FIN_PF>
 __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh *shp, FinSh *fs, unsigned char *fin_lds) {
   Sh &sh = *shp;
   int &s_tok_top = fs->tok_top, &s_lnk_top = fs->lnk_top;
@@ -2129,7 +2127,7 @@ __global__ __launch_bounds__(NT, 4) void FinalizeKernel2(DecDev d, const int *la
   __shared__ FinSh fs;
   extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
   const Ctx c = MakeCtx(d, lanes[blockIdx.x]);
-  FinalizeLane2<false>(d, c, &sh, &fs, fin_lds);
+  FinalizeLane2<false, FIN_CAP / NT, 4>(d, c, &sh, &fs, fin_lds);
 }
 // PruneActiveTokens on un-finalized lanes (kamd_decoder_compact)
 __global__ __launch_bounds__(NT, 4) void CompactKernel(DecDev d, const int *lanes) {
@@ -2137,7 +2135,7 @@ __global__ __launch_bounds__(NT, 4) void CompactKernel(DecDev d, const int *lane
   __shared__ FinSh fs;
   extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
   const Ctx c = MakeCtx(d, lanes[blockIdx.x]);
-  FinalizeLane2<true>(d, c, &sh, &fs, fin_lds);
+  FinalizeLane2<true, FIN_CAP / NT, 4>(d, c, &sh, &fs, fin_lds);
 }
 
 // ---------------------------------------------------------------- work queue
@@ -2190,7 +2188,7 @@ __global__ __launch_bounds__(NT, 4) void DecodeQueueKernel(DecDev d, QueueDev q)
     __syncthreads();
     AdvanceLane(d, c, &sh, dyn_lds, task);
     __syncthreads();
-    FinalizeLane2<false>(d, c, &sh, &fs, dyn_lds);
+    FinalizeLane2<false, 2, 2>(d, c, &sh, &fs, dyn_lds);
     __syncthreads();
     // ---- hand the lattice out
     const int err = S->error, F = S->frame;
