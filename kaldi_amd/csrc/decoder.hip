@@ -2196,7 +2196,19 @@ __global__ __launch_bounds__(NT, 4) void DecodeQueueKernel(DecDev d, QueueDev q)
     const int tbase = S->out_tok_base, lbase = S->out_lnk_base;
     const int n_last = err ? 0 : c.tok_off[F + 1] - c.tok_off[F];
     const unsigned long long bytes = err ? 0ull : ((static_cast<unsigned long long>(F + 2) + 2ull * nt + n_last + 6ull * nl) * 4ull + 15ull) & ~15ull;
-    if (tid == 0) s_off = bytes ? __hip_atomic_fetch_add(q.pool_used, bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    if (tid == 0) {
+      // bump allocation that takes nothing when the blob does not fit: an utterance too large for what is left fails alone
+      // (flag 64) and the smaller ones behind it still find room
+      unsigned long long off = 0;
+      if (bytes) {
+        unsigned long long cur = __hip_atomic_load(q.pool_used, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+          if (cur + bytes > q.pool_cap) { off = q.pool_cap; break; }      // reads as "does not fit" below
+          if (__hip_atomic_compare_exchange_strong(q.pool_used, &cur, cur + bytes, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { off = cur; break; }
+        }
+      }
+      s_off = off;
+    }
     __syncthreads();
     const unsigned long long off = s_off;
     const bool fits = off + bytes <= q.pool_cap;

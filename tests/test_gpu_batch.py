@@ -163,6 +163,36 @@ def test_utterances_too_short_for_a_frame_fail_alone():
     assert st.n_failed == 2 and bd.output(0) is None
 
 
+def test_lattice_pool_too_small_fails_the_utterances_that_do_not_fit_alone():
+    """The finished lattices wait in a bump-allocated pool of page-locked host memory (kamd_decoder_queue_configure).  When
+    it is exhausted the utterances that no longer fit report flag 64 (lattice pool) and no output; those that did fit are
+    what they are with a pool of the default size; the next run of the same object starts with an empty pool."""
+    g, model, cfg, waves = _setup(n=12, seed=5)
+    ref = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=4.0, resident_lanes=3, host_threads=2, keep_raw_lattices=True)
+    ref.load(waves)
+    assert ref.run().n_failed == 0
+    want = [ref.raw_lattice(u) for u in range(len(waves))]
+    blob = [ref.record(u).blob_bytes for u in range(len(waves))]
+    pool = int(sum(sorted(blob)[:5]) + 64)                       # room for a handful of lattices, not for all twelve
+    bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=4.0, resident_lanes=3, host_threads=2,
+                                keep_raw_lattices=True, lattice_pool_bytes=max(pool, 4096))
+    bd.load(waves)
+    for _ in range(2):                                           # twice: the pool is reset by every launch
+        st = bd.run()
+        assert 0 < st.n_failed < len(waves)
+        n_ok = 0
+        for u in range(len(waves)):
+            rec = bd.record(u)
+            if bd.output(u) is None:
+                assert rec.error & 64 and rec.blob_bytes == 0
+                with pytest.raises(Exception, match="lattice-pool"):
+                    bd.raw_lattice(u)
+            else:
+                assert rec.error == 0 and lattices_equal(bd.raw_lattice(u), want[u])
+                n_ok += 1
+        assert n_ok == len(waves) - st.n_failed and n_ok >= 1, (n_ok, st.n_failed, pool, sorted(blob))
+
+
 def test_nnet3_latgen_faster_batch_tool(tmp_path):
     """tools/nnet3_latgen_faster_batch.py = nnet3-latgen-faster-batch's command line over the work-queue path: the same
     lattices as tools/nnet3_latgen_faster.py (three launches per batch) writes for the same files, in input order, with a
