@@ -1408,6 +1408,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
     LdsBarrier();
     if (err_now) { frame++; break; }
   }
+  DrainStores();     // an early exit leaves the next row's DMA in flight: it must have landed before the LDS changes hands
   PublishLaneEnd(d, c, &sh, frame);
 }
 __global__ __launch_bounds__(NT, 4) void AdvanceKernel(DecDev d, const kamd_decode_task *tasks) {
