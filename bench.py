@@ -403,7 +403,8 @@ def main():
                                 host_threads=host_threads, determinize=not args.no_determinize, keep_raw_lattices=False,
                                 nnet_pass_frames=args.nnet_pass_frames, hash_capacity=args.hash_capacity or None,
                                 tokens_per_frame=args.tokens_per_frame or None, search_mode=args.search_mode,
-                                lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)))
+                                lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)),
+                                long_lanes=16 if world >= 8 else 0)    # small shards: see kamd_batch_decoder_set_long_decoder
     log("batch decoder created (%d host threads)" % host_threads)
     bd.load(waves)                          # inputs resident in HBM before the timed region
     log("shard loaded: %d utterances, %.0f s audio" % (len(waves), audio))

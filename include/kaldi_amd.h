@@ -997,7 +997,8 @@ typedef struct {
   float total_ms;                      /* wall time of the whole run, results on the host */
   double nnet_flops;
   double host_thread_ms_sum;           /* CPU time spent in the host tail, all threads */
-  int32_t lanes, nnet_passes, n_failed, pad;
+  int32_t lanes, nnet_passes, n_failed;
+  int32_t long_utterances;             /* > 0: that many were searched beside the acoustic model (set_long_decoder) */
 } kamd_batch_stats;
 typedef struct kamd_batch_decoder kamd_batch_decoder;
 /* The stages are not owned.  tid_phone as kamd_lattice_determinize_phone_pruned (NULL: word
@@ -1007,6 +1008,16 @@ kamd_batch_decoder *kamd_batch_decoder_create(kamd_feat *feat, kamd_nnet *nnet, 
                                               const kamd_batch_opts *opts, const int32_t *tid_phone,
                                               int32_t num_tids);
 void kamd_batch_decoder_destroy(kamd_batch_decoder *b);
+/* Optional, for shards so small that the search is bound by the longest utterance's own chain of
+ * frames (a rank of an 8-GPU run over test-clean holds ~330 utterances for 256 lanes): `dec_long`
+ * is a second decoder object over the same graph with `lanes` lanes (each sized for the longest
+ * utterance).  run() then scores the `lanes` longest utterances first and searches them on
+ * `dec_long` and a second stream while the acoustic model of the others is still running -- when
+ * 0.55 x the longest utterance's frames exceed 1.5 x the shard's frames per lane; otherwise, and
+ * for models with an i-vector input, nothing changes.  Results are the same either way (the reference's
+ * NnetBatchDecoder likewise leaves the order of computation open, nnet-batch-compute.h:606-660).
+ * NULL / 0 lanes switches it off.  The caller keeps ownership of dec_long. */
+int kamd_batch_decoder_set_long_decoder(kamd_batch_decoder *b, kamd_decoder *dec_long, int lanes);
 /* AcceptInput for the whole shard: utterance u owns samples [wave_off[u], wave_off[u+1]). */
 int kamd_batch_decoder_load(kamd_batch_decoder *b, const float *waves, const int64_t *wave_off, int n_utts);
 /* AcceptInput as the reference declares it (nnet-batch-compute.h:665-669: feature matrices, not

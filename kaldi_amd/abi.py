@@ -193,7 +193,7 @@ class BatchStats(C.Structure):
     _fields_ = [("feat_ms", C.c_float), ("nnet_ms", C.c_float), ("decode_ms", C.c_float), ("host_tail_ms", C.c_float),
                 ("first_result_ms", C.c_float), ("total_ms", C.c_float), ("nnet_flops", C.c_double),
                 ("host_thread_ms_sum", C.c_double), ("lanes", C.c_int32), ("nnet_passes", C.c_int32),
-                ("n_failed", C.c_int32), ("pad", C.c_int32)]
+                ("n_failed", C.c_int32), ("long_utterances", C.c_int32)]
 
 
 CLAT_ARC_DTYPE = np.dtype([("src", "<i4"), ("dst", "<i4"), ("label", "<i4"), ("graph_cost", "<f4"),

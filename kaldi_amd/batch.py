@@ -17,7 +17,7 @@ from ._lib import KamdError, check, lib
 class NnetBatchDecoder:
     def __init__(self, mfcc_opts, model, hclg, cfg, max_seconds=36.0, resident_lanes=0, host_threads=8, determinize=True,
                  keep_raw_lattices=False, tid_phone=None, sizes=None, nnet_pass_frames=1000000, lattice_pool_bytes=1 << 30,
-                 hash_capacity=None, tokens_per_frame=None, search_mode=2, det=None):
+                 hash_capacity=None, tokens_per_frame=None, search_mode=2, det=None, long_lanes=0):
         featmod = __import__("kaldi_amd.feat", fromlist=["Mfcc"])
         # mfcc_opts = None: no feature stage, the caller hands over feature matrices (load_features), as the
         # reference's AcceptInput does (nnet-batch-compute.h:665)
@@ -52,6 +52,15 @@ class NnetBatchDecoder:
             raise KamdError(lib().kamd_last_error().decode())
         self.n_utts = 0
         self.stats = None
+        # long_lanes > 0: a second decoder object of that many lanes, on which run() searches the longest utterances beside
+        # the acoustic model of the rest when the shard is small enough for one utterance's chain of frames to bound it
+        # (kamd_batch_decoder_set_long_decoder)
+        self.dec_long = None
+        if long_lanes > 0:
+            sz = pipeline.default_sizes(cfg, int(long_lanes), max_out, max_out, hash_capacity=hash_capacity, tokens_per_frame=tokens_per_frame)
+            self.dec_long = decoder.BatchDecoder(self.graph, cfg, sz)
+            self.dec_long.SetSearchMode(search_mode)
+            check(lib().kamd_batch_decoder_set_long_decoder(self._h, self.dec_long._dec, int(long_lanes)))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -21,6 +21,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <deque>
 #include <mutex>
 #include <thread>
@@ -67,6 +68,16 @@ struct BatchDecoder {
   bool from_features = false, have_iv = false;   // the loaded set: feature matrices (+ i-vectors) instead of waveforms
   hipStream_t s_main = NULL;
   hipEvent_t ev[3] = {};
+  // A shard so small that its search is the longest utterance's own chain of frames (8 ranks over test-clean): the
+  // `long_lanes` longest utterances are scored first and searched by a second decoder object on its own stream while
+  // the acoustic model of the rest is still running (kamd_batch_decoder_set_long_decoder).
+  kamd_decoder *dec_long = NULL;
+  int long_lanes = 0;
+  hipStream_t s_long = NULL;
+  hipEvent_t ev_long = NULL;
+  std::vector<int64_t> ll_row;          // first row of utterance k's log-likelihoods in d_ll (== out_off unless split)
+  std::vector<int> map_long, map_rest;  // queue-local utterance number -> position in `kept`
+  bool last_split = false;
   std::vector<UttOut> out;
   // host-tail pool
   std::vector<std::thread> workers;
@@ -92,13 +103,18 @@ static int GrowDev(T **p, size_t *cap, size_t need) {
 // One finished utterance: what DecodeUtteranceLatticeFaster does after Decode()
 // (decoder/decoder-wrappers.cc:217-296): best path -> words / alignment / weight, raw lattice,
 // optional DeterminizeLatticePhonePrunedWrapper.
-static void HostTail(BatchDecoder *b, int u, hipStream_t cs) {      // u: the queue's utterance number = position in `kept`
+#define KAMD_JOB_LONG (1 << 30)     // job = queue-local utterance number, | this bit for the long utterances' queue
+static void HostTail(BatchDecoder *b, int job, hipStream_t cs) {
   const auto t0 = std::chrono::steady_clock::now();
-  UttOut &o = b->out[b->kept[u]];
+  const bool lq = (job & KAMD_JOB_LONG) != 0;
+  const int u = job & ~KAMD_JOB_LONG;                                  // the queue's utterance number
+  kamd_decoder *dec = lq ? b->dec_long : b->dec;
+  const int k = lq ? b->map_long[u] : (b->last_split ? b->map_rest[u] : u);   // position in `kept`
+  UttOut &o = b->out[b->kept[k]];
   o.Clear();                             // what the previous run left in this slot
-  int rc = kamd_decoder_queue_result(b->dec, u, &o.rec);
+  int rc = kamd_decoder_queue_result(dec, u, &o.rec);
   if (rc == KAMD_OK)
-    rc = kamd_decoder_queue_fetch_lattice(b->dec, u, cs, &o.num_states, &o.num_arcs, &o.start, &o.st_frame, &o.st_hclg, &o.st_cost,
+    rc = kamd_decoder_queue_fetch_lattice(dec, u, cs, &o.num_states, &o.num_arcs, &o.start, &o.st_frame, &o.st_hclg, &o.st_cost,
                                           &o.st_final, &o.arcs);
   if (rc == KAMD_OK && o.num_states > 0) {
     const int cap = std::max(o.num_arcs, 1);
@@ -207,6 +223,8 @@ void kamd_batch_decoder_destroy(kamd_batch_decoder *h) {
   for (hipStream_t s : b->copy_streams) if (s) (void)hipStreamDestroy(s);
   for (int i = 0; i < 3; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
   if (b->s_main) (void)hipStreamDestroy(b->s_main);
+  if (b->s_long) (void)hipStreamDestroy(b->s_long);
+  if (b->ev_long) (void)hipEventDestroy(b->ev_long);
   if (b->d_waves) (void)hipFree(b->d_waves);
   if (b->d_feats) (void)hipFree(b->d_feats);
   if (b->d_ll) (void)hipFree(b->d_ll);
@@ -292,6 +310,17 @@ int kamd_batch_decoder_load_features(kamd_batch_decoder *h, const float *feats, 
   return KAMD_OK;
 }
 
+int kamd_batch_decoder_set_long_decoder(kamd_batch_decoder *h, kamd_decoder *dec_long, int lanes) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (!dec_long || lanes <= 0) { b->dec_long = NULL; b->long_lanes = 0; return KAMD_OK; }
+  if (!b->s_long) KAMD_HIP(hipStreamCreateWithFlags(&b->s_long, hipStreamNonBlocking));
+  if (!b->ev_long) KAMD_HIP(hipEventCreateWithFlags(&b->ev_long, hipEventDisableTiming));
+  if (b->opts.lattice_pool_bytes > 0 && kamd_decoder_queue_configure(dec_long, std::max<int64_t>(b->opts.lattice_pool_bytes / 8, 1 << 24)) != KAMD_OK)
+    return KAMD_ERR_HIP;
+  b->dec_long = dec_long; b->long_lanes = lanes;
+  return KAMD_OK;
+}
+
 int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
   if (b->n_utts <= 0) return kamd::SetError(KAMD_ERR_STATE, "no test set loaded");
@@ -323,21 +352,34 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   // ---- acoustic model, a few passes of <= nnet_pass_frames input frames
   double flops = 0;
   int passes = 0;
-  for (int u0 = 0; u0 < n;) {
-    int u1 = u0 + 1;
-    while (u1 < n && b->feat_off[u1 + 1] - b->feat_off[u0] <= b->opts.nnet_pass_frames) u1++;
-    rc = kamd_nnet_forward_batch_device(b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat,
-                                        b->have_iv ? b->d_iv + static_cast<size_t>(u0) * kamd_nnet_ivector_dim(b->nnet) : NULL, u1 - u0, b->d_ll,
-                                        b->out_off.data() + u0, b->P, st);
-    if (rc != KAMD_OK) return rc;
-    flops += kamd_nnet_last_flops(b->nnet);
-    passes++;
-    u0 = u1;
-  }
-  KAMD_HIP(hipEventRecord(b->ev[2], st));
-  // ---- the search: one work-queue launch, longest utterance first
-  std::vector<kamd_queue_task> tasks(n);
-  {
+  b->ll_row.assign(b->out_off.begin(), b->out_off.end() - 1);
+  // split?  Only when the longest utterance's chain of frames (at the per-frame cost of a nearly idle device, ~0.55 of
+  // the loaded one) outlasts the balanced share of the whole shard by half (measured: a rank of 8 gains 4 %, a rank of 4,
+  // where the two are equal, loses 3 %: the GEMMs beside the long lanes run 1.25x slower)
+  int64_t longest = 0;
+  for (int k = 0; k < n; k++) longest = std::max(longest, b->out_off[k + 1] - b->out_off[k]);
+  int lanes_main = b->opts.resident_lanes > 0 ? b->opts.resident_lanes : kamd_device_num_cus() * kamd_decoder_lanes_per_cu();
+  bool split = b->dec_long && b->long_lanes > 0 && !b->have_iv && n >= 4 * b->long_lanes &&
+               0.55 * static_cast<double>(longest) > 1.5 * static_cast<double>(b->out_off.back()) / std::max(lanes_main, 1);
+  if (const char *e = getenv("KAMD_BATCH_SPLIT")) split = b->dec_long && b->long_lanes > 0 && !b->have_iv && n > b->long_lanes && atoi(e) != 0;
+  b->last_split = split;
+  int n_main = n;
+  std::vector<kamd_queue_task> tasks;
+  if (!split) {
+    for (int u0 = 0; u0 < n;) {
+      int u1 = u0 + 1;
+      while (u1 < n && b->feat_off[u1 + 1] - b->feat_off[u0] <= b->opts.nnet_pass_frames) u1++;
+      rc = kamd_nnet_forward_batch_device(b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat,
+                                          b->have_iv ? b->d_iv + static_cast<size_t>(u0) * kamd_nnet_ivector_dim(b->nnet) : NULL, u1 - u0, b->d_ll,
+                                          b->out_off.data() + u0, b->P, st);
+      if (rc != KAMD_OK) return rc;
+      flops += kamd_nnet_last_flops(b->nnet);
+      passes++;
+      u0 = u1;
+    }
+    KAMD_HIP(hipEventRecord(b->ev[2], st));
+    // ---- the search: one work-queue launch, longest utterance first
+    tasks.resize(n);
     std::vector<int> order(n);
     for (int u = 0; u < n; u++) order[u] = u;
     std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
@@ -349,15 +391,89 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
       tasks[k].ld = b->P; tasks[k].n_frames = static_cast<int32_t>(b->out_off[u + 1] - b->out_off[u]);
       tasks[k].utt = u; tasks[k].reserved = 0;
     }
+    rc = kamd_decoder_queue_launch(b->dec, tasks.data(), n, b->opts.resident_lanes, st);
+    if (rc != KAMD_OK) return rc;
+  } else {
+    // the K longest utterances, longest first; everybody else in input order.  Log-likelihood rows: the long ones first
+    // (the forward's output rows are a running sum over its items), then the rest.
+    const int K = b->long_lanes;
+    std::vector<int> order(n);
+    for (int u = 0; u < n; u++) order[u] = u;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+      return b->out_off[a + 1] - b->out_off[a] > b->out_off[c + 1] - b->out_off[c];
+    });
+    b->map_long.assign(order.begin(), order.begin() + K);
+    std::vector<char> is_long(n, 0);
+    for (int k : b->map_long) is_long[k] = 1;
+    b->map_rest.clear();
+    for (int k = 0; k < n; k++) if (!is_long[k]) b->map_rest.push_back(k);
+    int64_t row = 0;
+    for (int k : b->map_long) { b->ll_row[k] = row; row += b->out_off[k + 1] - b->out_off[k]; }
+    for (int k : b->map_rest) { b->ll_row[k] = row; row += b->out_off[k + 1] - b->out_off[k]; }
+    auto forward = [&](const std::vector<int> &items, size_t i0, size_t i1) -> int {
+      std::vector<int64_t> in_start(i1 - i0), out_row(i1 - i0 + 1);
+      std::vector<int32_t> in_len(i1 - i0);
+      for (size_t i = i0; i < i1; i++) {
+        const int k = items[i];
+        in_start[i - i0] = b->feat_off[k]; in_len[i - i0] = static_cast<int32_t>(b->feat_off[k + 1] - b->feat_off[k]);
+        out_row[i - i0] = b->ll_row[k];
+      }
+      const int kl = items[i1 - 1];
+      out_row[i1 - i0] = b->ll_row[kl] + (b->out_off[kl + 1] - b->out_off[kl]);
+      const int frc = kamd_nnet_forward_slices_device(b->nnet, b->d_feats, in_start.data(), in_len.data(), b->ld_feat, NULL,
+                                                      static_cast<int>(i1 - i0), b->d_ll, out_row.data(), b->P, st);
+      if (frc == KAMD_OK) { flops += kamd_nnet_last_flops(b->nnet); passes++; }
+      return frc;
+    };
+    auto make_tasks = [&](const std::vector<int> &items, bool longest_first) {
+      std::vector<int> loc(items.size());
+      for (size_t i = 0; i < items.size(); i++) loc[i] = static_cast<int>(i);
+      if (longest_first)
+        std::stable_sort(loc.begin(), loc.end(), [&](int a, int c) {
+          return b->out_off[items[a] + 1] - b->out_off[items[a]] > b->out_off[items[c] + 1] - b->out_off[items[c]];
+        });
+      tasks.resize(items.size());
+      for (size_t i = 0; i < items.size(); i++) {
+        const int k = items[loc[i]];
+        tasks[i].d_loglikes = b->d_ll + static_cast<size_t>(b->ll_row[k]) * b->P;
+        tasks[i].ld = b->P; tasks[i].n_frames = static_cast<int32_t>(b->out_off[k + 1] - b->out_off[k]);
+        tasks[i].utt = loc[i]; tasks[i].reserved = 0;
+      }
+    };
+    rc = forward(b->map_long, 0, b->map_long.size());
+    if (rc != KAMD_OK) return rc;
+    KAMD_HIP(hipEventRecord(b->ev_long, st));
+    KAMD_HIP(hipStreamWaitEvent(b->s_long, b->ev_long, 0));
+    make_tasks(b->map_long, false);
+    rc = kamd_decoder_queue_launch(b->dec_long, tasks.data(), K, K, b->s_long);
+    if (rc != KAMD_OK) return rc;
+    for (size_t i0 = 0; i0 < b->map_rest.size();) {
+      size_t i1 = i0 + 1;
+      int64_t fr = b->feat_off[b->map_rest[i0] + 1] - b->feat_off[b->map_rest[i0]];
+      while (i1 < b->map_rest.size() && fr + (b->feat_off[b->map_rest[i1] + 1] - b->feat_off[b->map_rest[i1]]) <= b->opts.nnet_pass_frames) {
+        fr += b->feat_off[b->map_rest[i1] + 1] - b->feat_off[b->map_rest[i1]];
+        i1++;
+      }
+      rc = forward(b->map_rest, i0, i1);
+      if (rc != KAMD_OK) return rc;
+      i0 = i1;
+    }
+    KAMD_HIP(hipEventRecord(b->ev[2], st));
+    make_tasks(b->map_rest, true);
+    n_main = static_cast<int>(b->map_rest.size());
+    rc = kamd_decoder_queue_launch(b->dec, tasks.data(), n_main, b->opts.resident_lanes, st);
+    if (rc != KAMD_OK) return rc;
   }
-  rc = kamd_decoder_queue_launch(b->dec, tasks.data(), n, b->opts.resident_lanes, st);
-  if (rc != KAMD_OK) return rc;
   // ---- collector: hand finished utterances to the host-tail pool while the kernel runs
   int collected = 0, idle_after_end = 0;
   std::vector<int32_t> buf(256);
   double t_first_done = -1, t_last_done = -1;
   while (collected < n) {
-    const int k = kamd_decoder_queue_poll(b->dec, buf.data(), static_cast<int>(buf.size()));
+    int k = kamd_decoder_queue_poll(b->dec, buf.data(), static_cast<int>(buf.size()));
+    if (k == 0 && split) {
+      k = kamd_decoder_queue_poll(b->dec_long, buf.data(), static_cast<int>(buf.size()));
+      for (int i = 0; i < k; i++) buf[i] |= KAMD_JOB_LONG;
+    }
     if (k > 0) {
       const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (t_first_done < 0) t_first_done = now;
@@ -372,7 +488,8 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
       idle_after_end = 0;
       continue;
     }
-    const hipError_t q = hipStreamQuery(st);
+    hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess && split) q = hipStreamQuery(b->s_long);
     if (q == hipSuccess) {
       if (++idle_after_end > 2) break;      // the kernel has ended and published nothing more
     } else if (q != hipErrorNotReady) {
@@ -388,6 +505,12 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   float qms = 0; int32_t lanes = 0;
   rc = kamd_decoder_queue_wait(b->dec, &qms, &lanes);
   if (rc != KAMD_OK) return rc;
+  if (split) {
+    float qms_long = 0; int32_t lanes_long = 0;
+    rc = kamd_decoder_queue_wait(b->dec_long, &qms_long, &lanes_long);
+    if (rc != KAMD_OK) return rc;
+    lanes += lanes_long;
+  }
   if (collected < n) return kamd::SetError(KAMD_ERR_STATE, "work queue ended with %d of %d utterances published", collected, n);
   kamd_batch_stats s;
   memset(&s, 0, sizeof(s));
@@ -397,6 +520,7 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   s.host_tail_ms = static_cast<float>(total_ms - t_last_done);
   s.first_result_ms = static_cast<float>(t_first_done);
   s.nnet_flops = flops; s.lanes = lanes; s.nnet_passes = passes;
+  s.long_utterances = split ? b->long_lanes : 0;
   double host_sum = 0;
   for (int u = 0; u < b->n_utts; u++) {
     if (b->out[u].status != KAMD_OK) s.n_failed++;
@@ -463,7 +587,8 @@ int kamd_batch_decoder_get_loglikes(kamd_batch_decoder *h, int utt, float *out, 
   const int r = static_cast<int>(b->out_off[k + 1] - b->out_off[k]);
   *rows = r;
   if (r > rows_cap) return kamd::SetError(KAMD_ERR_ARG, "buffer too small");
-  KAMD_HIP(hipMemcpy(out, b->d_ll + static_cast<size_t>(b->out_off[k]) * b->P, static_cast<size_t>(r) * b->P * sizeof(float), hipMemcpyDeviceToHost));
+  const int64_t row0 = b->ll_row.size() == b->kept.size() ? b->ll_row[k] : b->out_off[k];
+  KAMD_HIP(hipMemcpy(out, b->d_ll + static_cast<size_t>(row0) * b->P, static_cast<size_t>(r) * b->P * sizeof(float), hipMemcpyDeviceToHost));
   return KAMD_OK;
 }
 

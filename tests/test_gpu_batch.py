@@ -193,6 +193,49 @@ def test_lattice_pool_too_small_fails_the_utterances_that_do_not_fit_alone():
         assert n_ok == len(waves) - st.n_failed and n_ok >= 1, (n_ok, st.n_failed, pool, sorted(blob))
 
 
+def test_long_utterances_searched_beside_the_acoustic_model_give_the_same_results(monkeypatch):
+    """kamd_batch_decoder_set_long_decoder: a shard whose search is bound by its longest utterance has that utterance (the
+    `long_lanes` longest) scored first and searched on a second decoder object while the model of the others runs.  Nothing
+    an utterance returns may depend on which way it went: log-likelihoods, raw and determinized lattices, best paths and
+    records equal those of the plain run; the split happens by itself for a chain-bound shard and not for a balanced one."""
+    g, model, cfg, _ = _setup(n=1)
+    rng = np.random.default_rng(11)
+    durs = [6.0] + list(rng.uniform(0.3, 0.9, 30))                      # one long utterance over 4 lanes' worth of short ones
+    waves = [synth.make_wave(float(s), seed=300 + i) for i, s in enumerate(durs)]
+    order = rng.permutation(len(waves))
+    waves = [waves[i] for i in order]
+    kw = dict(max_seconds=7.0, resident_lanes=16, host_threads=3, determinize=True, keep_raw_lattices=True, nnet_pass_frames=1200)
+    plain = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, **kw)
+    plain.load(waves)
+    st0 = plain.run()
+    assert st0.n_failed == 0 and st0.long_utterances == 0
+    bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, long_lanes=2, **kw)
+    bd.load(waves)
+    for forced in (None, "1", "0"):
+        if forced is None:
+            monkeypatch.delenv("KAMD_BATCH_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("KAMD_BATCH_SPLIT", forced)
+        st = bd.run()
+        assert st.n_failed == 0
+        assert st.long_utterances == (0 if forced == "0" else 2)        # 0.55 x 200 frames > 1.5 x 31 utterances' frames / 16 lanes
+        for u in range(len(waves)):
+            np.testing.assert_array_equal(bd.loglikes(u), plain.loglikes(u))
+            assert lattices_equal(bd.raw_lattice(u), plain.raw_lattice(u))
+            a, c = bd.output(u), plain.output(u)
+            assert a["words"].tolist() == c["words"].tolist() and a["alignment"].tolist() == c["alignment"].tolist()
+            assert a["graph_cost"] == c["graph_cost"] and a["acoustic_cost"] == c["acoustic_cost"]
+            assert a["record"].n_frames == c["record"].n_frames and list(a["record"].counters[:7]) == list(c["record"].counters[:7])
+            x, y = bd.compact_lattice(u), plain.compact_lattice(u)
+            assert x.num_states == y.num_states and x.arcs.tobytes() == y.arcs.tobytes() and x.strings.tobytes() == y.strings.tobytes()
+    # a balanced shard (many utterances per lane) is left alone
+    monkeypatch.delenv("KAMD_BATCH_SPLIT", raising=False)
+    many = [synth.make_wave(float(s), seed=500 + i) for i, s in enumerate(rng.uniform(0.5, 1.0, 40))]
+    b2 = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, long_lanes=2, max_seconds=7.0, resident_lanes=2, host_threads=2)
+    b2.load(many)
+    assert b2.run().long_utterances == 0
+
+
 def test_nnet3_latgen_faster_batch_tool(tmp_path):
     """tools/nnet3_latgen_faster_batch.py = nnet3-latgen-faster-batch's command line over the work-queue path: the same
     lattices as tools/nnet3_latgen_faster.py (three launches per batch) writes for the same files, in input order, with a

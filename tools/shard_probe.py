@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--utts", type=int, default=0)
+    ap.add_argument("--long-lanes", type=int, default=0, help="kamd_batch_decoder_set_long_decoder: lanes of the second decoder object")
     a = ap.parse_args()
     sys.argv = [sys.argv[0]] + (["--utts", str(a.utts)] if a.utts else [])
     args = bench.defaults(bench.parse_args())
@@ -38,7 +39,7 @@ def main():
         audio = sum(w.size for w in waves) / 16000.0
         bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=float(durs.max()) + 0.5, resident_lanes=a.lanes,
                                     host_threads=16, determinize=True, keep_raw_lattices=False, hash_capacity=args.hash_capacity or None,
-                                    search_mode=args.search_mode, lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)))
+                                    search_mode=args.search_mode, lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), long_lanes=a.long_lanes)
         bd.load(waves)
         bd.run()
         t0 = time.time()
@@ -46,6 +47,7 @@ def main():
         for _ in range(a.steps):
             st = bd.run()
             acc += [st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms]
+            long_utts = st.long_utterances
         dt = (time.time() - t0) / a.steps
         acc /= a.steps
         total_audio = float(durs.sum())
@@ -54,7 +56,7 @@ def main():
             base = rate / world
         row = {"world": world, "utterances_this_rank": len(waves), "audio_this_rank_s": audio, "longest_s": float(durs[mine].max()),
                "step_ms": 1e3 * dt, "feat_ms": acc[0], "nnet_ms": acc[1], "decode_ms": acc[2], "tail_ms": acc[3],
-               "implied_x_real_time_all_ranks": rate, "implied_strong_scaling_efficiency": rate / (base * world)}
+               "implied_x_real_time_all_ranks": rate, "implied_strong_scaling_efficiency": rate / (base * world), "long_utterances": long_utts}
         out.append(row)
         print(json.dumps(row), flush=True)
         del bd
