@@ -1324,7 +1324,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
           // (big_scan[nb] = total is the sentinel).
           const int nchunks = (total + 15) >> 4;
           const int ncached = min(nchunks, CHUNKCAP);
-          if (tid == 0) big_scan[nb] = total;
+          if (tid == 0) { big_scan[nb] = total; big_scan[nb + 1] = 0x7fffffff; big_scan[nb + 2] = 0x7fffffff; }
           for (int cidx = tid; cidx < ncached; cidx += NT) {
             const int j = cidx << 4;
             int lo = 0, hi = nb;
@@ -1337,9 +1337,10 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
             int e;
             if (cidx < ncached) {
               e = chunk_owner[cidx];
-              e += big_scan[e + 1] <= j;
-              e += big_scan[e + 1] <= j;
-              e += big_scan[e + 1] <= j;
+              // the scan is strictly increasing: counting the next three entries <= j is the three dependent steps
+              // e += scan[e + 1] <= j in one LDS round trip (two sentinels behind scan[nb] keep the reads in range)
+              const int s1 = big_scan[e + 1], s2 = big_scan[e + 2], s3 = big_scan[e + 3];
+              e += (s1 <= j) + (s2 <= j) + (s3 <= j);
             } else {
               int lo = 0, hi = nb;
               while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
