@@ -892,10 +892,12 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
   const int ns2 = min(sh->n_slots, d.hash_cap);  // level-2 entries (emitting + closure)
   u64 kmin = EMPTY64;
   // loose (search mode 2 on this frame): entries beyond the cutoff are tokens too (they are just not epsilon-expanded, :867)
-  auto commit_entry = [&](u64 e, int *idx_out) {
+  // Every entry becomes a token (the inserts tested the cutoff; in a loose frame those beyond it count too), so an entry's
+  // place in the slot lists IS its token index: no allocation, no atomic.
+  auto commit_entry = [&](u64 e, int pos, int *idx_out) {
     int idx = -1;
     if (loose || CostOf(e) <= cutoff) {
-      idx = tok_base + WaveAlloc(&sh->n_new);
+      idx = tok_base + pos;
       if (idx < c.tok_cap) {
         const int st = PlainState(StateOf(e));
         c.tok_state[idx] = st;
@@ -904,7 +906,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
         const u64 k = (static_cast<u64>(static_cast<u32>(e)) << 32) | static_cast<u32>(st);
         kmin = k < kmin ? k : kmin;
       } else { atomicOr(&sh->err, ERR_TOK); idx = -1; }
-    }
+    } else atomicOr(&sh->err, ERR_INTERNAL);     // cannot happen: the index space above counts every entry
     *idx_out = idx;
   };
   auto add_owner = [&](u32 slot, u64 e) {
@@ -918,7 +920,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
     const u32 sl = tbl.lslots[i];
     const u64 e = tbl.LH[sl];
     int idx;
-    commit_entry(e, &idx);
+    commit_entry(e, i, &idx);
     if (idx >= 0 && HasEps(StateOf(e)) && CostOf(e) <= cutoff) add_owner(sl, e);
     tbl.LH[sl] = (e & 0xFFFFFFFF00000000ull) | static_cast<u32>(idx);   // cost half -> token index
   }
@@ -927,7 +929,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
     const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
     if (e == EMPTY64) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
     int idx;
-    commit_entry(e, &idx);
+    commit_entry(e, n1 + i, &idx);
     if (idx >= 0 && HasEps(StateOf(e)) && CostOf(e) <= cutoff) add_owner(slot, e);
     c.slot_tok[slot] = idx;
   }
@@ -941,7 +943,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
     kmin = sh->red64[0];
     for (int i = 1; i < NWAVES; i++) kmin = sh->red64[i] < kmin ? sh->red64[i] : kmin;
   }
-  const int n_new = min(sh->n_new, c.tok_cap - tok_base);
+  const int n_new = min(n1 + ns2, c.tok_cap - tok_base);
   const int n_owner = sh->wl_n[1];
   if (n_owner > L.owners_cap && !hbm_lists) __syncthreads();   // overflowed owners went to HBM
   const float next_beam_cutoff = (n_new > 0 ? OrderedToFloat(static_cast<u32>(kmin >> 32)) : INFINITY) + d.cfg.beam;
