@@ -1225,6 +1225,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
       c.cost_offsets[frame] = cost_offset;
       c.trace_ntok[frame] = n; c.trace_cutoff[frame] = cur_cutoff;
       c.lnk_off[2 * (frame + 1)] = sh.lnk_used;
+      sh.next_cutoff_u = FloatToOrdered(INFINITY);       // (the last frame's value was handed on as a parameter)
     }
     LlRow row; row.g = ll; row.l = (lds_cfloat *)ll_lds; row.n_lds = d.num_pdfs_lds;
     LdsBarrier();
@@ -1235,9 +1236,11 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
         const float new_weight = d.g.e_arcs[a].weight + cost_offset - LogLikePdf(row, d.e_pdf[a]) + best;
         seed = fminf(seed, new_weight + adaptive_beam);
       }
-      seed = BlockMinF<true>(seed, &sh);
-      if (tid == 0) sh.next_cutoff_u = FloatToOrdered(seed);
-    } else if (tid == 0) sh.next_cutoff_u = FloatToOrdered(INFINITY);
+      // a minimum is a minimum in any order: the wavefronts that hold an arc of the best token put theirs straight
+      // onto the running bound the expansion tightens further (usually one wavefront: no workgroup reduction)
+      seed = WaveMinF(seed);
+      if ((tid & 63) == 0 && seed < INFINITY) atomicMin(&sh.next_cutoff_u, FloatToOrdered(seed));
+    }
     LdsBarrier();
     Stamp(&sh, PH_SEED);
     // search mode 2: the seed bound replaces the final one on the frames where the reference's order-dependent extras
