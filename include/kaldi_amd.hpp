@@ -885,7 +885,20 @@ class NnetBatchDecoder {
   }
   ~NnetBatchDecoder() {
     kamd_batch_decoder_destroy(h_); kamd_decoder_destroy(dec_);
+    if (dec_long_) kamd_decoder_destroy(dec_long_);
     if (feat_) kamd_feat_destroy(feat_);
+  }
+  /// Not in the reference: for a shard so small that the longest utterance's own chain of frames bounds the search (one
+  /// rank of an 8-GPU run), a second decoder object of `sizes.max_lanes` lanes on which Finished() searches the longest
+  /// utterances while the acoustic model of the others is still running (kamd_batch_decoder_set_long_decoder; outputs do
+  /// not change).  Call before the first AcceptInput.
+  void SetLongUtteranceDecoder(const DecodingGraph &fst, const std::vector<int32> &id2pdf, const kamd_decoder_sizes &sizes) {
+    if (dec_long_) throw KaldiFatalError("NnetBatchDecoder: the long-utterance decoder is set already");
+    kamd_decoder_config c = config_.ToC();
+    dec_long_ = kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), static_cast<int32>(id2pdf.size()));
+    if (!dec_long_ || kamd_decoder_set_search_mode(dec_long_, opts_.search_mode) != 0 ||
+        kamd_batch_decoder_set_long_decoder(h_, dec_long_, sizes.max_lanes) != 0)
+      throw KaldiFatalError(kamd_last_error());
   }
   NnetBatchDecoder(const NnetBatchDecoder &) = delete;
   NnetBatchDecoder &operator=(const NnetBatchDecoder &) = delete;
@@ -1034,6 +1047,7 @@ class NnetBatchDecoder {
   NnetBatchDecoderOptions opts_;
   kamd_feat *feat_;
   kamd_decoder *dec_;
+  kamd_decoder *dec_long_ = NULL;
   kamd_batch_decoder *h_;
   int32 input_dim_, ivector_dim_;
   std::vector<std::string> keys_;
