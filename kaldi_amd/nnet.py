@@ -165,12 +165,15 @@ def make_tdnnf(dim, bottleneck, strides, prefinal_small, num_pdfs, input_dim=40,
 
 
 def tdnnf_mini_librispeech(num_pdfs=2328, **kw):
-    """run_tdnn_1h.sh:163-190: dim 768, bottleneck 96, 12 tdnnf layers, prefinal 192."""
+    """run_tdnn_1h.sh:163-190: dim 768, bottleneck 96, 12 tdnnf layers, prefinal 192, bypass-scale 0.66 (:157).
+    Pinned against the reference's own xconfig generator: tests/test_xconfig_golden.py."""
     return make_tdnnf(768, 96, [1, 1, 1, 0] + [3] * 8, 192, num_pdfs, name="tdnn1h", **kw)
 
 
 def tdnnf_librispeech(num_pdfs=6000, **kw):
-    """run_tdnn_1d.sh:219-249: dim 1536, bottleneck 160, 16 tdnnf layers, prefinal 256."""
+    """run_tdnn_1d.sh:219-249: dim 1536, bottleneck 160, 16 tdnnf layers, prefinal 256, bypass-scale 0.75 (:212).
+    Pinned against the reference's own xconfig generator: tests/test_xconfig_golden.py."""
+    kw.setdefault("bypass_scale", 0.75)
     return make_tdnnf(1536, 160, [1, 1, 1, 0] + [3] * 12, 256, num_pdfs, name="tdnn1d", **kw)
 
 

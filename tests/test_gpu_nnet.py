@@ -200,3 +200,24 @@ def test_looped_ivector_slots():
     part = N.ForwardSlots(x, tab, first, period, slices=[(in_first, in_last - in_first + 1), (0, T)])
     np.testing.assert_array_equal(part[0][k0:k0 + (o1 - o0)], whole[o0:o1])
     np.testing.assert_array_equal(part[1], whole)
+
+
+@pytest.mark.parametrize("name", ["tdnn_1d", "tdnn_1h"])
+def test_xconfig_models(name, tmp_path):
+    """The recipe models as the REFERENCE'S OWN xconfig generator writes them (tests/golden/nnet/*.final.config, see
+    tools/gen_xconfig_golden.py), full width, random parameters, read back through kaldi_amd/mdl.py: the device forward
+    == the CPU oracle == a direct float64 evaluation of the component graph node by node (tests/xconfig_mdl.py)."""
+    from tests import xconfig_mdl
+    from tests.test_xconfig_golden import _load
+    text, params, priors, model = _load(name, tmp_path, seed=5)
+    rng = np.random.default_rng(17)
+    iv = rng.standard_normal(100).astype(np.float32)
+    for T in (40, 133):
+        feats = rng.standard_normal((T, 40)).astype(np.float32)
+        got = decoder.Nnet(model).Forward(feats, iv)
+        want = xconfig_mdl.evaluate(text, params, feats, iv, priors=priors)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 1e-4 * np.abs(want).max()
+        if T == 40:
+            ref = orc.nnet_forward(model, feats, iv)
+            assert np.abs(got - ref).max() < 1e-4 * np.abs(ref).max()
