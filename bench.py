@@ -337,7 +337,7 @@ def wer_leg(g, cfg, n_utts, cores, log, hash_capacity=0, search_mode=2):
         bp = latbin.best_path(L)
         return [] if bp is None else list(bp[0])
 
-    from tests.util import lattices_equal
+    from kaldi_amd.decoder import lattices_equal
     ref, hyp_d, hyp_c, hyp_o = {}, {}, {}, {}
     e_between = lat_diff = 0
     for i, (ll, words) in enumerate(utts):

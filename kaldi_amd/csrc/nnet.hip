@@ -38,7 +38,16 @@ struct GemmArgs {
   float *C; int ldC;
   int gx, gy;                       // > 0: 1-D launch, XCD-aware tile order (see the kernel)
   const float *zeros;               // >= 16 zero floats: the source of A rows that do not exist (rowmap < 0, m >= M)
+  const float *zeros_n, *ones_n;    // >= N zeros / ones: the neutral operands of EpilogueWave
+#ifdef KAMD_GEMM_LAB
+  unsigned long long *stamps;       // tools/microbench/gemm_lab.hip: 8 s_memtime stamps per workgroup
+#endif
 };
+#ifdef KAMD_GEMM_LAB
+#define KAMD_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KAMD_STAMP(i) do { } while (0)
+#endif
 
 // Epilogue of one 32x32 accumulator tile of one wavefront (round 2).  The MFMA C/D layout gives a lane 16 values of
 // ONE column; stored from there every global access is a 4-byte one (64 scalar loads + 64 scalar stores per lane and
@@ -107,6 +116,82 @@ __device__ inline void EpilogueTile(const GemmArgs &p, const f32x16 &acc, int m_
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next tile reuses the scratch
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Epilogue, round 3.  EpilogueTile (above) walks a tile's four row passes one after the other, and in each pass the
+// bypass operand is TWO dependent global loads (bypmap[m], then the row) behind `s_waitcnt vmcnt(0)`: sixteen passes per
+// wave = 32 serialized L2 / HBM round trips per workgroup tile -- on the K = 320 -> N = 1536 layers (20 k-blocks of main
+// loop) longer than the main loop's own MFMA time.  Here everything a tile needs from global memory -- bias, BatchNorm
+// scale / offset, post offset (one float4 each) and the four bypass rows -- is requested up front as independent loads,
+// two tiles ahead of its use (the bypass row numbers sit in LDS since the prologue), so a workgroup tile pays about one
+// round trip instead of 32.  Arithmetic per element, and therefore every result bit, is EpilogueTile's.
+struct EpiLoads { float4 bias, bs, bo, po, z[4]; };
+// Straight-line code: a term a layer does not have is computed with neutral operands (bias / offsets from a vector of
+// zeros, BatchNorm scale from a vector of ones, the bypass from row 0 of the zeros with scale 0, ReLU as max(v, -inf)),
+// which leaves every bit of v as the conditional form would (x + 0, x * 1 + 0 and max(x, -inf) are exact; a -0 sum
+// becomes +0).  With no branches between the requests and their uses hipcc counts the outstanding loads exactly
+// (vmcnt(N)); behind any uniform branch it falls back to vmcnt(0) and the two-tile run-ahead is lost.
+template <int TI, int TJ, int DEPTH, bool IVB>
+__device__ inline void EpilogueWave(const GemmArgs &p, f32x16 (&acc)[TI][TJ], int m_wave, int n_wave, int row_wave /* first row of the wave inside the workgroup tile */,
+                                    float *scr /* [32][EPI_LD], this wave's */, const int *bm /* LDS: bypass row of every tile row */) {
+  constexpr int NT = TI * TJ;
+  const int lane = threadIdx.x & 63, c4 = (lane & 7) * 4, r8 = lane >> 3;
+  const float *bias = p.bias ? p.bias : p.zeros_n, *bsc = p.bn_scale ? p.bn_scale : p.ones_n, *bof = p.bn_scale ? p.bn_offset : p.zeros_n;
+  const float *pof = p.post_offset ? p.post_offset : p.zeros_n, *byp = p.byp ? p.byp : p.zeros_n;
+  const int ld_byp = p.byp ? p.ld_byp : 0;
+  const float byps = p.byp ? p.bypass_scale : 0.f, floor_ = p.relu ? 0.f : -INFINITY, posts = p.post_scale;
+  auto request = [&](int t, EpiLoads &L) {
+    const int i = t / TJ, j = t % TJ;
+    const int n = n_wave + j * 32 + c4, nc = min(n, p.N - 4);          // lanes beyond N read the last float4 and store nothing
+    L.bias = *reinterpret_cast<const float4 *>(bias + nc);
+    L.bs = *reinterpret_cast<const float4 *>(bsc + nc);
+    L.bo = *reinterpret_cast<const float4 *>(bof + nc);
+    L.po = *reinterpret_cast<const float4 *>(pof + nc);
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+      const int row = row_wave + i * 32 + r8 + 8 * pass;                // rows beyond M and layers without a bypass: row 0
+      L.z[pass] = *reinterpret_cast<const float4 *>(byp + static_cast<size_t>(bm[row]) * ld_byp + nc);
+    }
+  };
+  EpiLoads L[DEPTH];
+#pragma unroll
+  for (int t = 0; t < DEPTH && t < NT; t++) request(t, L[t]);
+  const int lr = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int i = t / TJ, j = t % TJ;
+#pragma unroll
+    for (int r = 0; r < 16; r++) scr[((r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_LD + lr] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the scratch is private to the wave: no barrier
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4 a[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) a[pass] = *reinterpret_cast<const float4 *>(scr + (r8 + 8 * pass) * EPI_LD + c4);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next tile reuses the scratch
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const EpiLoads &E = L[t % DEPTH];
+    const int n = n_wave + j * 32 + c4;
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+      const int m = m_wave + i * 32 + r8 + 8 * pass;
+      float v[4] = {a[pass].x + E.bias.x, a[pass].y + E.bias.y, a[pass].z + E.bias.z, a[pass].w + E.bias.w};
+      if (IVB) {                                                   // the first layer of a model with an i-vector input only
+        const int mc = min(m, p.M - 1), nc = min(n, p.N - 4);
+        const float4 iv = *reinterpret_cast<const float4 *>(p.ivbias + static_cast<size_t>(p.row2utt[mc]) * p.N + nc);
+        v[0] += iv.x; v[1] += iv.y; v[2] += iv.z; v[3] += iv.w;
+      }
+      const float4 z = E.z[pass];
+      v[0] = fmaxf(v[0], floor_); v[1] = fmaxf(v[1], floor_); v[2] = fmaxf(v[2], floor_); v[3] = fmaxf(v[3], floor_);
+      v[0] = v[0] * E.bs.x + E.bo.x; v[1] = v[1] * E.bs.y + E.bo.y; v[2] = v[2] * E.bs.z + E.bo.z; v[3] = v[3] * E.bs.w + E.bo.w;
+      v[0] += byps * z.x; v[1] += byps * z.y; v[2] += byps * z.z; v[3] += byps * z.w;
+      v[0] += E.po.x; v[1] += E.po.y; v[2] += E.po.z; v[3] += E.po.w;
+      if (m < p.M && n < p.N)
+        *reinterpret_cast<float4 *>(p.C + static_cast<size_t>(m) * p.ldC + n) = make_float4(v[0] * posts, v[1] * posts, v[2] * posts, v[3] * posts);
+    }
+    if (t + DEPTH < NT) request(t + DEPTH, L[t % DEPTH]);
+  }
 }
 
 // (256, 4): four workgroups per CU.  The main loop waits for its global prefetch and at a
@@ -239,7 +324,7 @@ __global__ __launch_bounds__(256, 4) void TdnnGemmKernel(GemmArgs p) {
 //     (a fixed permutation, the same for every batch composition): results stay exact-fp32 k-chains, bit-equal between
 //     batch / streaming / chunked evaluation, but not bit-equal to generation 1.
 //   * rows that do not exist (rowmap < 0: clamped context is explicit in the map, so this only pads M) read p.zeros.
-template <int BM, int BN, int WM, int WN, int NST>
+template <int BM, int BN, int WM, int WN, int NST, int EPI = 2>       // EPI 1: EpilogueTile (round 2), 2: EpilogueWave, 3: EpilogueWave + per-utterance i-vector bias
 __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
   constexpr int BK = 16;
   constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;
@@ -247,8 +332,10 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
   constexpr int A_INST = BM / 16, B_INST = BN / 16;                  // wave instructions per stage (1 KB each)
   constexpr int A_PW = (A_INST + 3) / 4, B_PW = (B_INST + 3) / 4;    // per wave (a clamped duplicate pads the count)
   constexpr int LOADS = A_PW + B_PW;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + KAMD_MAX_OFFSETS * BM * 4];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + (KAMD_MAX_OFFSETS + 1) * BM * 4];
   int *rm = reinterpret_cast<int *>(smem + NST * ST_BYTES);          // [n_off][BM]
+  int *bm = rm + KAMD_MAX_OFFSETS * BM;                              // [BM] bypass rows (EPI 2)
+  KAMD_STAMP(0);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   int bx = blockIdx.x, by = blockIdx.y;
@@ -263,7 +350,10 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
     const int o = i / BM, r = i % BM, m = m0 + r;
     rm[o * BM + r] = (m < p.M) ? p.rowmap[static_cast<size_t>(o) * p.M + m] : -1;
   }
+  if (EPI >= 2)
+    for (int r = t; r < BM; r += 256) bm[r] = (p.byp && m0 + r < p.M) ? p.bypmap[m0 + r] : 0;
   __syncthreads();
+  KAMD_STAMP(1);
   f32x16 acc[TI][TJ];
 #pragma unroll
   for (int i = 0; i < TI; i++)
@@ -318,6 +408,7 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
   constexpr int DIST = NST - 1;          // k-blocks in flight ahead of the MFMAs
 #pragma unroll
   for (int pkb = 0; pkb < DIST; pkb++) if (pkb < nkb) issue(pkb);
+  KAMD_STAMP(2);
   const int lr = lane & 31, lk = lane >> 5;
   for (int kb = 0; kb < nkb; kb++) {
     // k-block kb has landed once all but the newest (DIST - 1) * LOADS of this wave's DMAs are done; then everybody's have
@@ -326,6 +417,9 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#ifdef KAMD_GEMM_LAB
+    if (kb == 0) KAMD_STAMP(3);
+#endif
     if (kb + DIST < nkb) issue(kb + DIST);     // into the stage everybody finished reading before this barrier
     const unsigned char *st = smem + (kb % NST) * ST_BYTES;
     float4 a[TI][2], b[TJ][2];
@@ -359,14 +453,20 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
       }
     }
   }
+  KAMD_STAMP(4);
   __builtin_amdgcn_s_barrier();            // every wave has read the last stage: the ring becomes epilogue scratch
   asm volatile("" ::: "memory");
   float *scr = reinterpret_cast<float *>(smem) + wave * 32 * EPI_LD;
+  if (EPI >= 2) {        // the host picks EPI 1 for shapes that are not float4-aligned
+    EpilogueWave<TI, TJ, ((TI * TJ * 16 <= 64 && EPI != 3) ? 2 : 1), EPI == 3>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), wm * (BM / WM), scr, bm);
+  } else {
 #pragma unroll
-  for (int i = 0; i < TI; i++)
+    for (int i = 0; i < TI; i++)
 #pragma unroll
-    for (int j = 0; j < TJ; j++)
-      EpilogueTile(p, acc[i][j], m0 + wm * (BM / WM) + i * 32, n0 + wn * (BN / WN) + j * 32, scr);
+      for (int j = 0; j < TJ; j++)
+        EpilogueTile(p, acc[i][j], m0 + wm * (BM / WM) + i * 32, n0 + wn * (BN / WN) + j * 32, scr);
+  }
+  KAMD_STAMP(5);
 }
 
 // LogSoftmaxComponent::Propagate = ApplyLogSoftMaxPerRow (nnet-simple-component.cc:3599;
@@ -472,7 +572,8 @@ struct Nnet {
   std::vector<int *> maps; std::vector<size_t> maps_cap;
   int64_t *d_meta = NULL; size_t meta_cap = 0;
   float *d_ivb = NULL; size_t ivb_cap = 0;
-  float *d_zero = NULL;      // 64 zero floats (GemmArgs::zeros)
+  float *d_zero = NULL;      // n_neutral zero floats (GemmArgs::zeros, zeros_n) followed by n_neutral ones (ones_n)
+  int n_neutral = 0;
 };
 
 static int Mod(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }
@@ -595,8 +696,16 @@ kamd_nnet *kamd_nnet_create(const kamd_layer_desc *layers, int n_layers, int inp
     if (!ok) { kamd::SetError(KAMD_ERR_HIP, "weight upload failed (layer %d)", i); delete nn; return NULL; }
   }
   if (kamd::PlanGrids(nn) != KAMD_OK) { delete nn; return NULL; }
-  nn->d_zero = kamd::DevAlloc<float>(64);
-  if (!nn->d_zero || hipMemset(nn->d_zero, 0, 64 * sizeof(float)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { kamd::SetError(KAMD_ERR_HIP, "nnet: allocation failed"); delete nn; return NULL; }
+  int max_n = 64;
+  for (int i = 0; i < n_layers; i++) max_n = std::max(max_n, nn->L[i].N_pad);
+  nn->n_neutral = max_n;
+  {
+    std::vector<float> neutral(2 * static_cast<size_t>(max_n), 0.0f);
+    std::fill(neutral.begin() + max_n, neutral.end(), 1.0f);
+    nn->d_zero = kamd::DevAlloc<float>(neutral.size());
+    if (!nn->d_zero || hipMemcpy(nn->d_zero, neutral.data(), neutral.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) { kamd::SetError(KAMD_ERR_HIP, "nnet: allocation failed"); delete nn; return NULL; }
+  }
   nn->act.assign(n_layers, NULL); nn->act_cap.assign(n_layers, 0);
   nn->maps.assign(n_layers, NULL); nn->maps_cap.assign(n_layers, 0);
   return reinterpret_cast<kamd_nnet *>(nn);
@@ -768,26 +877,33 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     // tile choice: a narrow layer (bottleneck / prefinal, N <= 160) is ONE column tile as
     // wide as the layer, so the (large) A operand is streamed exactly once; wide layers use
     // the 128x128 tile.
-    g.zeros = nn->d_zero;
+    g.zeros = nn->d_zero; g.zeros_n = nn->d_zero; g.ones_n = nn->d_zero + nn->n_neutral;
+    // epilogue: 2 = EpilogueWave (float4-aligned shapes), 3 = the same + the per-utterance i-vector bias, 1 = round 2's (any shape)
+    const bool vec4 = (L.out_dim & 3) == 0 && (ldC & 3) == 0 && (!g.byp || (g.ld_byp & 3) == 0);
+    static const bool epi1 = getenv("KAMD_GEMM_EPI1") != NULL && getenv("KAMD_GEMM_EPI1")[0] == '1';   // A/B against round 2's epilogue
+    const int epi = (!vec4 || epi1) ? 1 : (g.ivbias ? 3 : 2);
     static const bool gen1 = getenv("KAMD_GEMM_GEN1") != NULL && getenv("KAMD_GEMM_GEN1")[0] == '1';   // A/B against the first generation
     const int nt32 = kamd::CeilDiv(L.out_dim, 32);
     if (!gen1) {
       if (nt32 <= 5) {
         dim3 grid(1, kamd::CeilDiv(Ml, 128));
+        const bool e2 = epi == 2;       // (an i-vector layer this narrow keeps round 2's epilogue)
+#define KAMD_TALL(BN) do { if (e2) hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, BN, 4, 1, 3, 2>), grid, dim3(256), 0, st, g); \
+                           else hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, BN, 4, 1, 3, 1>), grid, dim3(256), 0, st, g); } while (0)
         switch (nt32) {
-          case 1: hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 32, 4, 1, 3>), grid, dim3(256), 0, st, g); break;
-          case 2: hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 64, 4, 1, 3>), grid, dim3(256), 0, st, g); break;
-          case 3: hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 96, 4, 1, 3>), grid, dim3(256), 0, st, g); break;
-          case 4: hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 4, 1, 3>), grid, dim3(256), 0, st, g); break;
-          default: hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 160, 4, 1, 3>), grid, dim3(256), 0, st, g); break;
+          case 1: KAMD_TALL(32); break;
+          case 2: KAMD_TALL(64); break;
+          case 3: KAMD_TALL(96); break;
+          case 4: KAMD_TALL(128); break;
+          default: KAMD_TALL(160); break;
         }
+#undef KAMD_TALL
       } else {
         g.gx = kamd::CeilDiv(L.out_dim, 128); g.gy = static_cast<int>(kamd::CeilDiv(Ml, 128));
         dim3 grid(static_cast<unsigned>(g.gx) * static_cast<unsigned>(kamd::RoundUp(g.gy, 8)));
-        static const int nst = getenv("KAMD_GEMM_NST") ? atoi(getenv("KAMD_GEMM_NST")) : 3;     // ring depth experiment
-        if (nst == 2) hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, st, g);
-        else if (nst == 4) hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 4>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, st, g);
+        if (epi == 2) hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 3, 2>), grid, dim3(256), 0, st, g);
+        else if (epi == 3) hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 3, 3>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 3, 1>), grid, dim3(256), 0, st, g);
       }
     } else if (nt32 <= 5) {
       dim3 grid(1, kamd::CeilDiv(Ml, 128));

@@ -34,30 +34,4 @@ def read_htk(path):
     return np.frombuffer(b[12:12 + n * cols * 4], ">f4").reshape(n, cols).astype(np.float32), kind
 
 
-def lattices_equal(a, b):
-    """Exact (bit-level) equality of two canonical raw lattices."""
-    if a is None or b is None:
-        return a is b
-    ok = (a.start == b.start and a.num_frames == b.num_frames
-          and np.array_equal(a.frame, b.frame) and np.array_equal(a.hclg, b.hclg)
-          and np.array_equal(a.cost.view(np.uint32), b.cost.view(np.uint32))
-          and np.array_equal(a.final.view(np.uint32), b.final.view(np.uint32))
-          and a.arcs.size == b.arcs.size and a.arcs.tobytes() == b.arcs.tobytes())
-    return ok
-
-
-def lattice_diff(a, b):
-    """Human-readable summary of where two canonical lattices differ."""
-    out = ["states %d vs %d, arcs %d vs %d, start %d vs %d" % (
-        a.frame.size, b.frame.size, a.arcs.size, b.arcs.size, a.start, b.start)]
-    ka = set(zip(a.frame.tolist(), a.hclg.tolist()))
-    kb = set(zip(b.frame.tolist(), b.hclg.tolist()))
-    out.append("tokens only in A: %s" % sorted(ka - kb)[:10])
-    out.append("tokens only in B: %s" % sorted(kb - ka)[:10])
-    if ka == kb:
-        bad = np.nonzero(a.cost.view(np.uint32) != b.cost.view(np.uint32))[0]
-        out.append("cost mismatches: %d %s" % (bad.size, [(int(i), float(a.cost[i]), float(b.cost[i])) for i in bad[:5]]))
-        sa = set(map(bytes, a.arcs.view("V24")))
-        sb = set(map(bytes, b.arcs.view("V24")))
-        out.append("arcs only in A: %d, only in B: %d" % (len(sa - sb), len(sb - sa)))
-    return "\n".join(out)
+from kaldi_amd.decoder import lattice_diff, lattices_equal  # noqa: E402,F401  (the package holds them: bench.py uses them too)
