@@ -16,6 +16,7 @@
 // compiler does).  Numerics: exact fp32 products, fp32 accumulate (k-ordered chain
 // per output element => results do not depend on batch composition).
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -40,13 +41,19 @@ struct GemmArgs {
   const float *zeros;               // >= 16 zero floats: the source of A rows that do not exist (rowmap < 0, m >= M)
   const float *zeros_n, *ones_n;    // >= N zeros / ones: the neutral operands of EpilogueWave
 #ifdef KAMD_GEMM_LAB
-  unsigned long long *stamps;       // tools/microbench/gemm_lab.hip: 8 s_memtime stamps per workgroup
+  unsigned long long *stamps;       // tools/microbench/gemm_lab.hip: 32 words per workgroup (phase stamps, per-wave loop segments)
+  int lab_loop;                     // also time the segments of every k-block (perturbs the loop)
+  int lab_valu;                     // experiment: this many extra (useless) vector ALU instructions per k-block and wave
+  int lab_aux;                      // experiment: cache policy of the operand DMAs (1 nt, 2 sc1, 3 sc0 sc1)
+  int lab_prio;                     // experiment: wave priority 3 from the counted wait to the end of the DMA issue, 0 during the MFMAs
 #endif
 };
 #ifdef KAMD_GEMM_LAB
-#define KAMD_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KAMD_STAMP(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define KAMD_STAMP_REAL(i) do { if (p.stamps && threadIdx.x == 0) p.stamps[(static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define KAMD_STAMP(i) do { } while (0)
+#define KAMD_STAMP_REAL(i) do { } while (0)
 #endif
 
 // Epilogue of one 32x32 accumulator tile of one wavefront (round 2).  The MFMA C/D layout gives a lane 16 values of
@@ -324,18 +331,23 @@ __global__ __launch_bounds__(256, 4) void TdnnGemmKernel(GemmArgs p) {
 //     (a fixed permutation, the same for every batch composition): results stay exact-fp32 k-chains, bit-equal between
 //     batch / streaming / chunked evaluation, but not bit-equal to generation 1.
 //   * rows that do not exist (rowmap < 0: clamped context is explicit in the map, so this only pads M) read p.zeros.
-template <int BM, int BN, int WM, int WN, int NST, int EPI = 2>       // EPI 1: EpilogueTile (round 2), 2: EpilogueWave, 3: EpilogueWave + per-utterance i-vector bias
-__global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
-  constexpr int BK = 16;
+// BK = 32 (round 3): rows of 128 bytes, i.e. whole cache lines per request (with BK = 16 every 128-byte line of an operand
+// row is requested twice, half a line at a time, and a workgroup stalls ~570 cycles per DMA instruction in the issue:
+// gemm_lab's per-k-block segments); 8 rows per DMA instruction, 8 sixteen-byte chunks per row, chunk p of row m holds
+// k-chunk p ^ ((m >> 1) & 7) (two rows per 256-byte bank row: conflict free for ds_read_b128 as before).
+template <int BM, int BN, int WM, int WN, int NST, int EPI = 2, int BK = 16, int OCC = 3>       // EPI 1: EpilogueTile (round 2), 2: EpilogueWave, 3: EpilogueWave + per-utterance i-vector bias
+__global__ __launch_bounds__(256, OCC) void TdnnGemmDmaKernel(GemmArgs p) {
+  static_assert(BK == 16 || BK == 32, "k-block depth");
+  constexpr int ROWB = BK * 4, CH = ROWB / 16, RPI = 1024 / ROWB;    // bytes per operand row and stage, 16-byte chunks per row, rows per DMA instruction
   constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, ST_BYTES = A_BYTES + B_BYTES;
-  constexpr int A_INST = BM / 16, B_INST = BN / 16;                  // wave instructions per stage (1 KB each)
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INST = BM / RPI, B_INST = BN / RPI;                // wave instructions per stage (1 KB each)
   constexpr int A_PW = (A_INST + 3) / 4, B_PW = (B_INST + 3) / 4;    // per wave (a clamped duplicate pads the count)
   constexpr int LOADS = A_PW + B_PW;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + (KAMD_MAX_OFFSETS + 1) * BM * 4];
   int *rm = reinterpret_cast<int *>(smem + NST * ST_BYTES);          // [n_off][BM]
   int *bm = rm + KAMD_MAX_OFFSETS * BM;                              // [BM] bypass rows (EPI 2)
-  KAMD_STAMP(0);
+  KAMD_STAMP(0); KAMD_STAMP_REAL(6);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   int bx = blockIdx.x, by = blockIdx.y;
@@ -370,7 +382,8 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "memory");
   };
-  const int lrow = lane >> 2, lslot = lane & 3;
+  const int lrow = lane / CH, lslot = lane % CH;
+  auto swz = [](int row) { return BK == 16 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
   // Per-lane source pointers live in registers and advance by one k-block (64 bytes) per issue; only when the k index
   // crosses into the next time-offset slice of the TDNN operand are the A pointers rebuilt from the row map (the 64-bit
   // row * ldA arithmetic of every issue was ~60 VALU instructions per k-block beside 32 MFMAs).
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
 #pragma unroll
   for (int q = 0; q < B_PW; q++) {
     int J = wave + 4 * q; if (J > B_INST - 1) J = B_INST - 1;
-    const int row = 16 * J + lrow, c = lslot ^ ((row >> 2) & 3);
+    const int row = RPI * J + lrow, c = lslot ^ swz(row);
     pb[q] = p.W + static_cast<size_t>(n0 + row) * K + 4 * c;
     b_lds[q] = A_BYTES + J * 1024;
   }
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
       const int off = kb / kb_per_off;
 #pragma unroll
       for (int q = 0; q < A_PW; q++) {
-        const int row = (a_lds[q] >> 6) + lrow, c = lslot ^ ((row >> 2) & 3);
+        const int row = a_lds[q] / ROWB + lrow, c = lslot ^ swz(row);
         const int src = rm[off * BM + row];
         pa[q] = src >= 0 ? p.A + static_cast<size_t>(src) * p.ldA + 4 * c : p.zeros + 4 * c;
         ainc[q] = src >= 0 ? BK : 0;
@@ -410,17 +423,416 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
   for (int pkb = 0; pkb < DIST; pkb++) if (pkb < nkb) issue(pkb);
   KAMD_STAMP(2);
   const int lr = lane & 31, lk = lane >> 5;
+#ifdef KAMD_GEMM_LAB
+  int lab_dummy = 0;
+  unsigned long long lab_t[4] = {0, 0, 0, 0}, lab_prev = 0;
+#define KAMD_LAB_SEG(i) do { if (p.stamps && p.lab_loop) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); lab_t[i] += now_ - lab_prev; lab_prev = now_; } } while (0)
+  if (p.stamps && p.lab_loop) lab_prev = __builtin_amdgcn_s_memtime();
+#else
+#define KAMD_LAB_SEG(i) do { } while (0)
+#endif
   for (int kb = 0; kb < nkb; kb++) {
     // k-block kb has landed once all but the newest (DIST - 1) * LOADS of this wave's DMAs are done; then everybody's have
     const int ahead = min(DIST - 1, nkb - 1 - kb);
+#ifdef KAMD_GEMM_LAB
+    if (p.lab_prio) __builtin_amdgcn_s_setprio(3);
+#endif
     if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    KAMD_LAB_SEG(0);
+    __builtin_amdgcn_s_barrier();
+    KAMD_LAB_SEG(1);
+#ifdef KAMD_GEMM_LAB
+    if (kb == 0) KAMD_STAMP(3);
+#endif
+    if (kb + DIST < nkb) issue(kb + DIST);     // into the stage everybody finished reading before this barrier
+#ifdef KAMD_GEMM_LAB
+    if (p.lab_prio) __builtin_amdgcn_s_setprio(0);
+    for (int i = 0; i < p.lab_valu; i++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(lab_dummy));
+#endif
+    KAMD_LAB_SEG(2);
+    const unsigned char *st = smem + (kb % NST) * ST_BYTES;
+    constexpr int NTT = BK / 8;
+    float4 a[TI][NTT], b[TJ][NTT];
+#pragma unroll
+    for (int i = 0; i < TI; i++) {
+      const int m = wm * (BM / WM) + i * 32 + lr;
+#pragma unroll
+      for (int tt = 0; tt < NTT; tt++)
+        a[i][tt] = *reinterpret_cast<const float4 *>(st + m * ROWB + (((2 * tt + lk) ^ swz(m)) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+      const int n = wn * (BN / WN) + j * 32 + lr;
+#pragma unroll
+      for (int tt = 0; tt < NTT; tt++)
+        b[j][tt] = *reinterpret_cast<const float4 *>(st + A_BYTES + n * ROWB + (((2 * tt + lk) ^ swz(n)) << 4));
+    }
+#pragma unroll
+    for (int tt = 0; tt < NTT; tt++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int i = 0; i < TI; i++) {
+          const float av = q == 0 ? a[i][tt].x : q == 1 ? a[i][tt].y : q == 2 ? a[i][tt].z : a[i][tt].w;
+#pragma unroll
+          for (int j = 0; j < TJ; j++) {
+            const float bv = q == 0 ? b[j][tt].x : q == 1 ? b[j][tt].y : q == 2 ? b[j][tt].z : b[j][tt].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    KAMD_LAB_SEG(3);
+  }
+#ifdef KAMD_GEMM_LAB
+  if (p.stamps && p.lab_loop && lane == 0)
+    for (int i = 0; i < 4; i++) p.stamps[(static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * 32 + 8 + wave * 4 + i] = lab_t[i];
+#endif
+  KAMD_STAMP(4);
+  __builtin_amdgcn_s_barrier();            // every wave has read the last stage: the ring becomes epilogue scratch
+  asm volatile("" ::: "memory");
+  float *scr = reinterpret_cast<float *>(smem) + wave * 32 * EPI_LD;
+  if (EPI >= 2) {        // the host picks EPI 1 for shapes that are not float4-aligned
+    EpilogueWave<TI, TJ, ((TI * TJ * 16 <= 64 && EPI != 3) ? 2 : 1), EPI == 3>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), wm * (BM / WM), scr, bm);
+  } else {
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++)
+        EpilogueTile(p, acc[i][j], m0 + wm * (BM / WM) + i * 32, n0 + wn * (BN / WN) + j * 32, scr);
+  }
+  KAMD_STAMP(5); KAMD_STAMP_REAL(7);
+}
+
+// Fourth generation (round 3): no vector ALU instructions in the main loop, few in the epilogue.
+// What gemm_lab measured: on gfx950 the fp32 MFMA runs at the vector FMA rate (64 FLOP / clk / SIMD), and every vector
+// ALU instruction a co-resident wave issues takes ~10 cycles away from it -- 16 / 32 / 64 useless v_add per k-block and
+// wave cost the K = 3072 probe 4 / 12 / 26 % -- while the kernels above spend ~30 (per-lane 64-bit source pointers,
+// v_readfirstlane for M0, stage address arithmetic) per k-block and ~130 per epilogue tile (every term of the layer
+// formula as separate multiplies and adds on neutral operands).  Here:
+//   * DMA sources stay per-lane 64-bit pointers, advanced by ONE v_lshl_add_u64 per piece and k-block (4 per wave): the
+//     only vector ALU instructions of a k-block;
+//   * M0 and the ring stage are scalar and compile-time (the k loop is unrolled by the three stages), so the fragment
+//     reads are ds_read_b128 with immediate offsets from four per-lane base addresses;
+//   * the epilogue is compiled per layer form (EF: bias / ReLU / BatchNorm / bypass / post offset / post scale) -- no
+//     neutral operands -- with packed fp32 instructions and fused multiply-adds for the BatchNorm and bypass terms
+//     (one rounding instead of two; within the 1e-4 of the nnet parity tests, and identical for every batch
+//     composition).
+// Same LDS image and k order as the second generation: the GEMM sums are bit-equal to it.
+enum { EF_BIAS = 1, EF_RELU = 2, EF_BN = 4, EF_BYP = 8, EF_PO = 16, EF_SCALE = 32 };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct EpiLoadsS { float4 bias, bs, bo, po, z[4]; };
+template <int TI, int TJ, int EF, bool IVB>
+__device__ inline void EpilogueSpec(const GemmArgs &p, f32x16 (&acc)[TI][TJ], int m_wave, int n_wave, int row_wave, float *scr, const int *bm) {
+  constexpr int NT = TI * TJ;
+  const int lane = threadIdx.x & 63, c4 = (lane & 7) * 4, r8 = lane >> 3;
+  const int lr = lane & 31, lk = lane >> 5;
+  auto request = [&](int t, EpiLoadsS &L) {
+    const int i = t / TJ, j = t % TJ;
+    const int nc = min(n_wave + j * 32 + c4, p.N - 4);
+    if (EF & EF_BIAS) L.bias = *reinterpret_cast<const float4 *>(p.bias + nc);
+    if (EF & EF_BN) { L.bs = *reinterpret_cast<const float4 *>(p.bn_scale + nc); L.bo = *reinterpret_cast<const float4 *>(p.bn_offset + nc); }
+    if (EF & EF_PO) L.po = *reinterpret_cast<const float4 *>(p.post_offset + nc);
+    if (EF & EF_BYP) {
+#pragma unroll
+      for (int pass = 0; pass < 4; pass++)
+        L.z[pass] = *reinterpret_cast<const float4 *>(p.byp + static_cast<size_t>(bm[row_wave + i * 32 + r8 + 8 * pass]) * p.ld_byp + nc);
+    }
+  };
+  EpiLoadsS L;
+  request(0, L);
+  const f32x2 byps = {p.bypass_scale, p.bypass_scale}, posts = {p.post_scale, p.post_scale};
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int i = t / TJ, j = t % TJ;
+#pragma unroll
+    for (int r = 0; r < 16; r++) scr[((r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_LD + lr] = acc[i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float4 a[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) a[pass] = *reinterpret_cast<const float4 *>(scr + (r8 + 8 * pass) * EPI_LD + c4);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int n = n_wave + j * 32 + c4;
+    float4 out[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+      f32x2 v0 = {a[pass].x, a[pass].y}, v1 = {a[pass].z, a[pass].w};
+      if (EF & EF_BIAS) { v0 += f32x2{L.bias.x, L.bias.y}; v1 += f32x2{L.bias.z, L.bias.w}; }
+      if (IVB) {
+        const int mc = min(m_wave + i * 32 + r8 + 8 * pass, p.M - 1), nc = min(n, p.N - 4);
+        const float4 iv = *reinterpret_cast<const float4 *>(p.ivbias + static_cast<size_t>(p.row2utt[mc]) * p.N + nc);
+        v0 += f32x2{iv.x, iv.y}; v1 += f32x2{iv.z, iv.w};
+      }
+      if (EF & EF_RELU) { v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); }
+      if (EF & EF_BN) {
+        v0 = __builtin_elementwise_fma(v0, f32x2{L.bs.x, L.bs.y}, f32x2{L.bo.x, L.bo.y});
+        v1 = __builtin_elementwise_fma(v1, f32x2{L.bs.z, L.bs.w}, f32x2{L.bo.z, L.bo.w});
+      }
+      if (EF & EF_BYP) {
+        v0 = __builtin_elementwise_fma(byps, f32x2{L.z[pass].x, L.z[pass].y}, v0);
+        v1 = __builtin_elementwise_fma(byps, f32x2{L.z[pass].z, L.z[pass].w}, v1);
+      }
+      if (EF & EF_PO) { v0 += f32x2{L.po.x, L.po.y}; v1 += f32x2{L.po.z, L.po.w}; }
+      if (EF & EF_SCALE) { v0 *= posts; v1 *= posts; }
+      out[pass] = make_float4(v0.x, v0.y, v1.x, v1.y);
+    }
+    if (t + 1 < NT) request(t + 1, L);      // (the values of tile t are consumed: the same registers take tile t + 1's)
+    float *crow = p.C + static_cast<size_t>(m_wave + i * 32 + r8) * p.ldC + n;
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+      const int m = m_wave + i * 32 + r8 + 8 * pass;
+      if (m < p.M && n < p.N) *reinterpret_cast<float4 *>(crow + static_cast<size_t>(8 * pass) * p.ldC) = out[pass];
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int EF, bool IVB, int NST = 3, int OCC = 3>
+__global__ __launch_bounds__(256, OCC) void TdnnGemmSaKernel(GemmArgs p) {
+  constexpr int BK = 16, DIST = NST - 1;
+  static_assert(NST == 2 || NST == 3, "ring depth");
+  constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INST = BM / 16, B_INST = BN / 16;
+  constexpr int A_PW = (A_INST + 3) / 4, B_PW = (B_INST + 3) / 4;
+  constexpr int LOADS = A_PW + B_PW;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + (KAMD_MAX_OFFSETS + 1) * BM * 4];
+  int *rm = reinterpret_cast<int *>(smem + NST * ST_BYTES);          // [n_off][BM]
+  int *bm = rm + KAMD_MAX_OFFSETS * BM;                              // [BM]
+  KAMD_STAMP(0); KAMD_STAMP_REAL(6);
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.gx > 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    by = xcd + 8 * (slot / p.gx); bx = slot % p.gx;
+    if (by >= p.gy) return;
+  }
+  bx = __builtin_amdgcn_readfirstlane(bx); by = __builtin_amdgcn_readfirstlane(by);    // (the division runs on the vector ALU: without this every base below lives in VGPRs)
+  const int m0 = by * BM, n0 = bx * BN;
+  const int K = p.n_off * p.in_pad, nkb = K / BK, kb_per_off = p.in_pad / BK;
+  for (int i = t; i < p.n_off * BM; i += 256) {
+    const int o = i / BM, r = i % BM;
+    rm[o * BM + r] = p.rowmap[static_cast<size_t>(o) * p.M + min(m0 + r, p.M - 1)];
+  }
+  if (EF & EF_BYP)
+    for (int r = t; r < BM; r += 256) bm[r] = p.bypmap[min(m0 + r, p.M - 1)];
+  __syncthreads();
+  KAMD_STAMP(1);
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  const unsigned smem_lds = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(reinterpret_cast<size_t>((lds_byte *)smem)));
+  const int lrow = lane >> 2, lslot = lane & 3;
+  // per-lane source pointers (64-bit: one v_lshl_add_u64 per piece and k-block is all the vector ALU work of the loop;
+  // a scalar base + 32-bit per-lane offset would need none, but hipcc keeps loop-carried 64-bit scalars in VGPRs once
+  // the SGPR file is under pressure, and this kernel's argument block alone fills half of it)
+  const float *pa[A_PW], *pb[B_PW];
+  int a_piece[A_PW], b_piece[B_PW];            // uniform
+#pragma unroll
+  for (int q = 0; q < B_PW; q++) {
+    b_piece[q] = min(wave + 4 * q, B_INST - 1);
+    const int row = 16 * b_piece[q] + lrow, c = lslot ^ ((row >> 2) & 3);
+    pb[q] = p.W + static_cast<size_t>(n0 + row) * K + 4 * c;
+  }
+#pragma unroll
+  for (int q = 0; q < A_PW; q++) { a_piece[q] = min(wave + 4 * q, A_INST - 1); pa[q] = p.zeros; }
+  int to_slice = 0, slice = 0;                 // k-blocks until the next time-offset slice starts (uniform)
+  auto issue = [&](unsigned stage_bytes) {
+    if (to_slice == 0) {
+#pragma unroll
+      for (int q = 0; q < A_PW; q++) {
+        const int row = 16 * a_piece[q] + lrow, c = lslot ^ ((row >> 2) & 3);
+        pa[q] = p.A + static_cast<size_t>(rm[slice * BM + row]) * p.ldA + 4 * c;
+      }
+      to_slice = kb_per_off; slice++;
+    }
+    to_slice--;
+#pragma unroll
+    for (int q = 0; q < A_PW; q++) {
+      const unsigned m0v = smem_lds + stage_bytes + a_piece[q] * 1024;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(pa[q]) : "memory");
+      pa[q] += BK;
+    }
+#pragma unroll
+    for (int q = 0; q < B_PW; q++) {
+      const unsigned m0v = smem_lds + stage_bytes + A_BYTES + b_piece[q] * 1024;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(pb[q]) : "memory");
+      pb[q] += BK;
+    }
+  };
+  if (nkb > 0) issue(0);
+  if (DIST > 1 && nkb > 1) issue(ST_BYTES);
+  KAMD_STAMP(2);
+  const int lr = lane & 31, lk = lane >> 5;
+  // per-lane fragment addresses inside a stage: rows lr (+ 32 i, same swizzle), k-chunks lk and 2 + lk
+  const unsigned char *fa[2], *fb[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; tt++) {
+    const int m = wm * (BM / WM) + lr, n = wn * (BN / WN) + lr;
+    fa[tt] = smem + m * 64 + (((2 * tt + lk) ^ ((m >> 2) & 3)) << 4);
+    fb[tt] = smem + A_BYTES + n * 64 + (((2 * tt + lk) ^ ((n >> 2) & 3)) << 4);
+  }
+  int kb = 0;
+  auto step = [&](auto stage_c) {
+    constexpr int S = decltype(stage_c)::value;
+    const int ahead = min(DIST - 1, nkb - 1 - kb);
+    if (DIST > 1 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #ifdef KAMD_GEMM_LAB
     if (kb == 0) KAMD_STAMP(3);
 #endif
-    if (kb + DIST < nkb) issue(kb + DIST);     // into the stage everybody finished reading before this barrier
+    if (kb + DIST < nkb) issue(((S + DIST) % NST) * ST_BYTES);
+    float4 a[TI][2], b[TJ][2];
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) a[i][tt] = *reinterpret_cast<const float4 *>(fa[tt] + S * ST_BYTES + i * 32 * 64);
+#pragma unroll
+    for (int j = 0; j < TJ; j++)
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) b[j][tt] = *reinterpret_cast<const float4 *>(fb[tt] + S * ST_BYTES + j * 32 * 64);
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int i = 0; i < TI; i++) {
+          const float av = q == 0 ? a[i][tt].x : q == 1 ? a[i][tt].y : q == 2 ? a[i][tt].z : a[i][tt].w;
+#pragma unroll
+          for (int j = 0; j < TJ; j++) {
+            const float bv = q == 0 ? b[j][tt].x : q == 1 ? b[j][tt].y : q == 2 ? b[j][tt].z : b[j][tt].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    kb++;
+  };
+  while (kb + NST <= nkb) {
+    step(std::integral_constant<int, 0>());
+    step(std::integral_constant<int, 1>());
+    if (NST == 3) step(std::integral_constant<int, 2>());
+  }
+  if (kb < nkb) step(std::integral_constant<int, 0>());
+  if (NST == 3 && kb < nkb) step(std::integral_constant<int, 1>());
+  KAMD_STAMP(4);
+  __builtin_amdgcn_s_barrier();            // every wave has read the last stage: the ring becomes epilogue scratch
+  asm volatile("" ::: "memory");
+  float *scr = reinterpret_cast<float *>(smem) + wave * 32 * EPI_LD;
+  EpilogueSpec<TI, TJ, EF, IVB>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), wm * (BM / WM), scr, bm);
+  KAMD_STAMP(5); KAMD_STAMP_REAL(7);
+}
+
+// Loader-wave variant (round 3): gemm_lab's per-k-block stamps show a wave of the kernel above spending as long in the
+// ISSUE of its four DMA instructions (~2300 cycles: the vector-memory queue pushes back while the compute unit's other
+// workgroups stream too) as in its 32 MFMAs, and a wave stuck in the issue multiplies nothing.  Here a fifth wave does
+// nothing but request operands -- all (BM + BN) / 16 pieces of a k-block -- and takes the back-pressure; the four MFMA
+// waves execute barrier, fragment reads, MFMAs.  Same ring, same barrier per k-block (the loader waits for its own
+// DMAs with a counted vmcnt in front of it), same LDS image and summation order: results are bit-equal.
+template <int BM, int BN, int WM, int WN, int NST, int OCC, bool IVB>
+__global__ __launch_bounds__(320, OCC) void TdnnGemmLoaderKernel(GemmArgs p) {
+  constexpr int BK = 16;
+  constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INST = BM / 16, B_INST = BN / 16, LOADS = A_INST + B_INST;
+  constexpr int DIST = NST - 1;
+  static_assert((DIST - 1) * LOADS <= 63 || DIST == 1, "vmcnt is a 6-bit counter");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + (KAMD_MAX_OFFSETS + 1) * BM * 4];
+  int *rm = reinterpret_cast<int *>(smem + NST * ST_BYTES);
+  int *bm = rm + KAMD_MAX_OFFSETS * BM;
+  KAMD_STAMP(0); KAMD_STAMP_REAL(6);
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.gx > 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    by = xcd + 8 * (slot / p.gx); bx = slot % p.gx;
+    if (by >= p.gy) return;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int K = p.n_off * p.in_pad, nkb = K / BK;
+  for (int i = t; i < p.n_off * BM; i += 320) {
+    const int o = i / BM, r = i % BM;
+    rm[o * BM + r] = p.rowmap[static_cast<size_t>(o) * p.M + min(m0 + r, p.M - 1)];
+  }
+  for (int r = t; r < BM; r += 320) bm[r] = p.byp ? p.bypmap[min(m0 + r, p.M - 1)] : 0;
+  __syncthreads();
+  KAMD_STAMP(1);
+  if (wave == 4) {
+    // ------------------------------------------------------------------ the loader
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const unsigned smem_lds = static_cast<unsigned>(reinterpret_cast<size_t>((lds_byte *)smem));
+    const int lrow = lane >> 2, lslot = lane & 3;
+    const float *pa[A_INST], *pb[B_INST];
+#pragma unroll
+    for (int J = 0; J < B_INST; J++) {
+      const int row = 16 * J + lrow, c = lslot ^ ((row >> 2) & 3);
+      pb[J] = p.W + static_cast<size_t>(n0 + row) * K + 4 * c;
+    }
+#pragma unroll
+    for (int I = 0; I < A_INST; I++) pa[I] = p.zeros;
+    const int kb_per_off = p.in_pad / BK;
+    auto issue = [&](int kb) {
+      if (kb % kb_per_off == 0) {
+        const int off = kb / kb_per_off;
+#pragma unroll
+        for (int I = 0; I < A_INST; I++) {
+          const int row = 16 * I + lrow, c = lslot ^ ((row >> 2) & 3);
+          pa[I] = p.A + static_cast<size_t>(rm[off * BM + row]) * p.ldA + 4 * c;
+        }
+      }
+      const unsigned st = smem_lds + (kb % NST) * ST_BYTES;
+#pragma unroll
+      for (int I = 0; I < A_INST; I++) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(st + I * 1024), "v"(pa[I]) : "memory");
+        pa[I] += BK;
+      }
+#pragma unroll
+      for (int J = 0; J < B_INST; J++) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(st + A_BYTES + J * 1024), "v"(pb[J]) : "memory");
+        pb[J] += BK;
+      }
+    };
+#pragma unroll
+    for (int pkb = 0; pkb < DIST; pkb++) if (pkb < nkb) issue(pkb);
+    for (int kb = 0; kb < nkb; kb++) {
+      const int ahead = min(DIST - 1, nkb - 1 - kb);
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS > 63 ? 63 : 2 * LOADS) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kb + DIST < nkb) issue(kb + DIST);
+    }
+    __builtin_amdgcn_s_barrier();
+    return;
+  }
+  // -------------------------------------------------------------------- the four MFMA waves
+  const int wm = wave / WN, wn = wave % WN;
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  const int lr = lane & 31, lk = lane >> 5;
+  KAMD_STAMP(2);
+  for (int kb = 0; kb < nkb; kb++) {
+    __builtin_amdgcn_s_barrier();
+#ifdef KAMD_GEMM_LAB
+    if (kb == 0) KAMD_STAMP(3);
+#endif
     const unsigned char *st = smem + (kb % NST) * ST_BYTES;
     float4 a[TI][2], b[TJ][2];
 #pragma unroll
@@ -457,16 +869,270 @@ __global__ __launch_bounds__(256, 3) void TdnnGemmDmaKernel(GemmArgs p) {
   __builtin_amdgcn_s_barrier();            // every wave has read the last stage: the ring becomes epilogue scratch
   asm volatile("" ::: "memory");
   float *scr = reinterpret_cast<float *>(smem) + wave * 32 * EPI_LD;
-  if (EPI >= 2) {        // the host picks EPI 1 for shapes that are not float4-aligned
-    EpilogueWave<TI, TJ, ((TI * TJ * 16 <= 64 && EPI != 3) ? 2 : 1), EPI == 3>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), wm * (BM / WM), scr, bm);
-  } else {
+  EpilogueWave<TI, TJ, 1, IVB>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), wm * (BM / WM), scr, bm);
+  KAMD_STAMP(5); KAMD_STAMP_REAL(7);
+}
+
+// Third generation (round 3): the same tile, ring and MFMA schedule, but a workgroup is PERSISTENT: it walks the tiles
+// blockIdx.x, blockIdx.x + gridDim.x, ... and its DMA stream never stops at a tile boundary -- the first k-blocks of the
+// next tile are requested while the last k-blocks of this one are multiplied, and land while the epilogue runs.  In the
+// one-tile kernel above a workgroup spends ~26 k cycles (of ~150 k on the K = 320 layers) between its launch and its
+// first MFMA: row map global -> LDS, barrier, source pointers, ring fill, DMA latency (tools/microbench/gemm_lab stamps).
+//   * issue stream and compute stream: one step of each per k-block; the issue stream runs DIST k-blocks ahead and
+//     crosses into the next tile on its own (B pointers and the A pointers of the first time-offset slice are rebuilt
+//     there).
+//   * row maps are DMA'd into the SAME LDS arrays, each at the first issue step after its last reader: the next tile's
+//     A row map at step (n_off - 1) * kb_per_off + 1 of a tile (the step before built the last slice's pointers), a
+//     tile's own bypass row map at its step DIST (that step follows the barrier behind the previous tile's epilogue).
+//     Either is complete before the next step's counted wait (it was requested before that step's k-block) and
+//     visible after its barrier.  The host uses this kernel when kb_per_off >= 3 and nkb >= 6.
+//   * epilogue scratch = the ring stage that held the tile's last k-block (free until the next tile's first step issues
+//     into it): 16 KB, so a 32 x 32 accumulator tile goes through it in two halves of 16 rows.
+//   * counted waits: every wait is vmcnt((DIST - 1) * LOADS).  Operations the count does not know about (row-map DMAs,
+//     the epilogue's loads and stores) only ever make it wait longer: they are older than the k-block it leaves in
+//     flight, or they are the stores of the epilogue before, all younger than the k-block it waits for.
+template <int TI, int TJ, int DEPTH, bool IVB>
+__device__ inline void EpilogueWaveHalves(const GemmArgs &p, f32x16 (&acc)[TI][TJ], int m_wave, int n_wave, int row_wave,
+                                          float *scr /* [16][EPI_LD], this wave's */, const int *bm) {
+  constexpr int NT = TI * TJ;
+  const int lane = threadIdx.x & 63, c4 = (lane & 7) * 4, r8 = lane >> 3;
+  const float *bias = p.bias ? p.bias : p.zeros_n, *bsc = p.bn_scale ? p.bn_scale : p.ones_n, *bof = p.bn_scale ? p.bn_offset : p.zeros_n;
+  const float *pof = p.post_offset ? p.post_offset : p.zeros_n, *byp = p.byp ? p.byp : p.zeros_n;
+  const int ld_byp = p.byp ? p.ld_byp : 0;
+  const float byps = p.byp ? p.bypass_scale : 0.f, floor_ = p.relu ? 0.f : -INFINITY, posts = p.post_scale;
+  auto request = [&](int t, EpiLoads &L) {
+    const int i = t / TJ, j = t % TJ;
+    const int n = n_wave + j * 32 + c4, nc = min(n, p.N - 4);
+    L.bias = *reinterpret_cast<const float4 *>(bias + nc);
+    L.bs = *reinterpret_cast<const float4 *>(bsc + nc);
+    L.bo = *reinterpret_cast<const float4 *>(bof + nc);
+    L.po = *reinterpret_cast<const float4 *>(pof + nc);
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+      const int row = row_wave + i * 32 + r8 + 8 * pass;
+      L.z[pass] = *reinterpret_cast<const float4 *>(byp + static_cast<size_t>(bm[row]) * ld_byp + nc);
+    }
+  };
+  EpiLoads L[DEPTH];
+#pragma unroll
+  for (int t = 0; t < DEPTH && t < NT; t++) request(t, L[t]);
+  const int lr = lane & 31, lk = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int i = t / TJ, j = t % TJ;
+    const EpiLoads &E = L[t % DEPTH];
+    const int n = n_wave + j * 32 + c4;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) scr[((r & 3) + 8 * (r >> 2) + 4 * lk) * EPI_LD + lr] = acc[i][j][8 * h + r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the scratch is private to the wave: no barrier
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float4 a[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) a[q] = *reinterpret_cast<const float4 *>(scr + (r8 + 8 * q) * EPI_LD + c4);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the next half reuses the scratch
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int pass = 2 * h + q, m = m_wave + i * 32 + r8 + 8 * pass;
+        float v[4] = {a[q].x + E.bias.x, a[q].y + E.bias.y, a[q].z + E.bias.z, a[q].w + E.bias.w};
+        if (IVB) {
+          const int mc = min(m, p.M - 1), nc = min(n, p.N - 4);
+          const float4 iv = *reinterpret_cast<const float4 *>(p.ivbias + static_cast<size_t>(p.row2utt[mc]) * p.N + nc);
+          v[0] += iv.x; v[1] += iv.y; v[2] += iv.z; v[3] += iv.w;
+        }
+        const float4 z = E.z[pass];
+        v[0] = fmaxf(v[0], floor_); v[1] = fmaxf(v[1], floor_); v[2] = fmaxf(v[2], floor_); v[3] = fmaxf(v[3], floor_);
+        v[0] = v[0] * E.bs.x + E.bo.x; v[1] = v[1] * E.bs.y + E.bo.y; v[2] = v[2] * E.bs.z + E.bo.z; v[3] = v[3] * E.bs.w + E.bo.w;
+        v[0] += byps * z.x; v[1] += byps * z.y; v[2] += byps * z.z; v[3] += byps * z.w;
+        v[0] += E.po.x; v[1] += E.po.y; v[2] += E.po.z; v[3] += E.po.w;
+        if (m < p.M && n < p.N)
+          *reinterpret_cast<float4 *>(p.C + static_cast<size_t>(m) * p.ldC + n) = make_float4(v[0] * posts, v[1] * posts, v[2] * posts, v[3] * posts);
+      }
+    }
+    if (t + DEPTH < NT) request(t + DEPTH, L[t % DEPTH]);
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int NST, bool IVB, int OCC = 3, int DEPTH = 1>     // OCC workgroups per compute unit; DEPTH: tiles the epilogue's loads run ahead
+__global__ __launch_bounds__(256, OCC) void TdnnGemmPersistKernel(GemmArgs p) {
+  constexpr int BK = 16;
+  constexpr int TI = BM / WM / 32, TJ = BN / WN / 32;
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int A_INST = BM / 16, B_INST = BN / 16;
+  constexpr int A_PW = (A_INST + 3) / 4, B_PW = (B_INST + 3) / 4;
+  constexpr int LOADS = A_PW + B_PW;
+  constexpr int DIST = NST - 1;
+  static_assert(ST_BYTES >= 4 * 16 * EPI_LD * 4, "a ring stage doubles as the epilogue scratch of the four waves (half tiles)");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + (KAMD_MAX_OFFSETS + 1) * BM * 4];
+  int *rm = reinterpret_cast<int *>(smem + NST * ST_BYTES);          // [n_off][BM]
+  int *bm = rm + KAMD_MAX_OFFSETS * BM;                              // [BM]
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int gx = p.gx, gy = p.gy;
+  const int n_tiles = gx * ((gy + 7) & ~7);                          // XCD-aware order (see TdnnGemmKernel): some ids fall outside
+  auto tile_by = [&](int id) { return (id & 7) + 8 * ((id >> 3) / gx); };
+  auto tile_bx = [&](int id) { return (id >> 3) % gx; };
+  auto next_tile = [&](int id) {                                     // the next id of this workgroup that is a tile
+    id += gridDim.x;
+    while (id < n_tiles && tile_by(id) >= gy) id += gridDim.x;
+    return id;
+  };
+  int ct = static_cast<int>(blockIdx.x) - static_cast<int>(gridDim.x);
+  ct = next_tile(ct);
+  if (ct >= n_tiles) return;
+  KAMD_STAMP(0); KAMD_STAMP_REAL(6);
+  const int K = p.n_off * p.in_pad, nkb = K / BK, kb_per_off = p.in_pad / BK;
+  // ---- the first tile's row maps the ordinary way
+  {
+    const int m0 = tile_by(ct) * BM;
+    for (int i = t; i < p.n_off * BM; i += 256) {
+      const int o = i / BM, r = i % BM;
+      rm[o * BM + r] = p.rowmap[static_cast<size_t>(o) * p.M + min(m0 + r, p.M - 1)];
+    }
+    for (int r = t; r < BM; r += 256) bm[r] = p.byp ? p.bypmap[min(m0 + r, p.M - 1)] : 0;
+  }
+  __syncthreads();
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  const unsigned smem_lds = static_cast<unsigned>(reinterpret_cast<size_t>((lds_byte *)smem));
+  const unsigned rm_lds = smem_lds + NST * ST_BYTES;
+  auto dma16 = [&](const float *g, unsigned lds_addr) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "memory");
+  };
+  auto dma4 = [&](const int *g, unsigned lds_addr) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(g) : "memory");
+  };
+  const int lrow = lane >> 2, lslot = lane & 3;
+  const float *pa[A_PW], *pb[B_PW];
+  unsigned a_lds[A_PW], b_lds[B_PW];
+#pragma unroll
+  for (int q = 0; q < B_PW; q++) { int J = wave + 4 * q; if (J > B_INST - 1) J = B_INST - 1; b_lds[q] = A_BYTES + J * 1024; pb[q] = p.zeros; }
+#pragma unroll
+  for (int q = 0; q < A_PW; q++) { int I = wave + 4 * q; if (I > A_INST - 1) I = A_INST - 1; a_lds[q] = I * 1024; pa[q] = p.zeros; }
+  // ---- issue stream
+  int it = ct, ikb = 0;                       // tile and k-block the next issue step requests
+  unsigned si = 0;                            // ring stage it goes to
+  int in_flight = 0;                          // k-blocks requested and not yet multiplied
+  const int map_step = (p.n_off - 1) * kb_per_off + 1;
+  auto issue_step = [&]() {
+    if (it >= n_tiles) return;
+    if (ikb == 0) {
+      const int n0 = tile_bx(it) * BN;
+#pragma unroll
+      for (int q = 0; q < B_PW; q++) {
+        const int row = ((b_lds[q] - A_BYTES) >> 6) + lrow, c = lslot ^ ((row >> 2) & 3);
+        pb[q] = p.W + static_cast<size_t>(n0 + row) * K + 4 * c;
+      }
+    }
+    if (ikb % kb_per_off == 0) {              // uniform: a new time-offset slice starts
+      const int off = ikb / kb_per_off;
+#pragma unroll
+      for (int q = 0; q < A_PW; q++) {
+        const int row = (a_lds[q] >> 6) + lrow, c = lslot ^ ((row >> 2) & 3);
+        const int src = rm[off * BM + row];
+        pa[q] = p.A + static_cast<size_t>(src) * p.ldA + 4 * c;
+      }
+    }
+    if (ikb == map_step) {                    // the NEXT tile's row maps, into the array nobody reads any more
+      const int nt = next_tile(it);
+      if (nt < n_tiles) {
+        const int m0n = tile_by(nt) * BM;
+        for (int i = wave; i < 2 * p.n_off; i += 4) {                  // pieces of 64 ints
+          const int o = i >> 1, r = (i & 1) * 64 + lane;
+          dma4(p.rowmap + static_cast<size_t>(o) * p.M + min(m0n + r, p.M - 1), rm_lds + (o * BM + (i & 1) * 64) * 4);
+        }
+      }
+    }
+    if (ikb == DIST && p.byp && wave < 2) {   // THIS tile's bypass rows: the epilogue of the tile before has just ended
+      const int r = wave * 64 + lane;
+      dma4(p.bypmap + min(tile_by(it) * BM + r, p.M - 1), rm_lds + (KAMD_MAX_OFFSETS * BM + wave * 64) * 4);
+    }
+    const unsigned st = smem_lds + si * ST_BYTES;
+#pragma unroll
+    for (int q = 0; q < A_PW; q++) { dma16(pa[q], st + a_lds[q]); pa[q] += BK; }
+#pragma unroll
+    for (int q = 0; q < B_PW; q++) { dma16(pb[q], st + b_lds[q]); pb[q] += BK; }
+    si = si + 1 == NST ? 0 : si + 1;
+    in_flight++;
+    if (++ikb == nkb) { ikb = 0; it = next_tile(it); }
+  };
+#pragma unroll
+  for (int d = 0; d < DIST; d++) issue_step();
+  const int lr = lane & 31, lk = lane >> 5;
+  unsigned sc = 0;                            // ring stage the next compute step reads
+  while (ct < n_tiles) {
+    const int m0 = tile_by(ct) * BM, n0 = tile_bx(ct) * BN;
+    f32x16 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; i++)
 #pragma unroll
       for (int j = 0; j < TJ; j++)
-        EpilogueTile(p, acc[i][j], m0 + wm * (BM / WM) + i * 32, n0 + wn * (BN / WN) + j * 32, scr);
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    for (int kb = 0; kb < nkb; kb++) {
+      // the k-block about to be multiplied has landed once all but the k-blocks requested after it are done
+#ifdef KAMD_GEMM_LAB
+      if (p.lab_prio) __builtin_amdgcn_s_setprio(3);
+#endif
+      if (in_flight >= DIST) {
+        if (DIST >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+        else if (DIST == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else if (DIST >= 3 && in_flight == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      in_flight--;
+      issue_step();                           // into the stage everybody finished reading before this barrier
+#ifdef KAMD_GEMM_LAB
+      if (p.lab_prio) __builtin_amdgcn_s_setprio(0);
+#endif
+      const unsigned char *st = smem + sc * ST_BYTES;
+      sc = sc + 1 == NST ? 0 : sc + 1;
+      float4 a[TI][2], b[TJ][2];
+#pragma unroll
+      for (int i = 0; i < TI; i++) {
+        const int m = wm * (BM / WM) + i * 32 + lr;
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+          a[i][tt] = *reinterpret_cast<const float4 *>(st + m * 64 + (((2 * tt + lk) ^ ((m >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TJ; j++) {
+        const int n = wn * (BN / WN) + j * 32 + lr;
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+          b[j][tt] = *reinterpret_cast<const float4 *>(st + A_BYTES + n * 64 + (((2 * tt + lk) ^ ((n >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+#pragma unroll
+          for (int i = 0; i < TI; i++) {
+            const float av = q == 0 ? a[i][tt].x : q == 1 ? a[i][tt].y : q == 2 ? a[i][tt].z : a[i][tt].w;
+#pragma unroll
+            for (int j = 0; j < TJ; j++) {
+              const float bv = q == 0 ? b[j][tt].x : q == 1 ? b[j][tt].y : q == 2 ? b[j][tt].z : b[j][tt].w;
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();            // every wave has read the tile's last stage: it is the epilogue's scratch now
+    asm volatile("" ::: "memory");
+    const unsigned s_last = sc == 0 ? NST - 1 : sc - 1;
+    float *scr = reinterpret_cast<float *>(smem + s_last * ST_BYTES) + wave * 16 * EPI_LD;
+    EpilogueWaveHalves<TI, TJ, DEPTH, IVB>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), wm * (BM / WM), scr, bm);
+    asm volatile("" ::: "memory");
+    ct = next_tile(ct);
   }
-  KAMD_STAMP(5);
+  KAMD_STAMP(5); KAMD_STAMP_REAL(7);
 }
 
 // LogSoftmaxComponent::Propagate = ApplyLogSoftMaxPerRow (nnet-simple-component.cc:3599;
@@ -884,7 +1550,41 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     const int epi = (!vec4 || epi1) ? 1 : (g.ivbias ? 3 : 2);
     static const bool gen1 = getenv("KAMD_GEMM_GEN1") != NULL && getenv("KAMD_GEMM_GEN1")[0] == '1';   // A/B against the first generation
     const int nt32 = kamd::CeilDiv(L.out_dim, 32);
-    if (!gen1) {
+    // Kernel choice (round 3, measured with tools/microbench/gemm_lab on the layer shapes of the LibriSpeech topology):
+    //   * the bottleneck layers with a long k loop (K >= 1024 into N = 129..160): persistent workgroups, two per CU;
+    //   * layers wider than 160 whose form has a compiled epilogue: the fourth-generation kernel (static ring stages,
+    //     scalar M0, epilogue compiled per layer form);
+    //   * everything else: the second-generation one-tile kernels with the round-3 epilogue (EPI 2 / 3) or, for shapes
+    //     that are not float4-aligned, round 2's (EPI 1).
+    static const int gen_max = getenv("KAMD_GEMM_GEN") ? atoi(getenv("KAMD_GEMM_GEN")) : 4;          // A/B: 2 = second generation only
+    const bool persist = gen_max >= 3 && epi == 2 && nt32 == 5 && L.in_pad / 16 >= 3 && L.n_off * L.in_pad >= 1024;
+    const int ef = (g.bias ? kamd::EF_BIAS : 0) | (g.relu ? kamd::EF_RELU : 0) | (g.bn_scale ? kamd::EF_BN : 0) | (g.byp ? kamd::EF_BYP : 0) |
+                   (g.post_offset ? kamd::EF_PO : 0) | (g.post_scale != 1.0f ? kamd::EF_SCALE : 0);
+    bool gen4 = gen_max >= 4 && epi == 2 && nt32 > 5 && L.n_off * (L.in_pad / 16) >= 2;
+    static const int n_cus = kamd_device_num_cus();
+    if (!gen1 && gen4) {
+      g.gx = kamd::CeilDiv(L.out_dim, 128); g.gy = static_cast<int>(kamd::CeilDiv(Ml, 128));
+      dim3 grid(static_cast<unsigned>(g.gx) * static_cast<unsigned>(kamd::RoundUp(g.gy, 8)));
+#define KAMD_G4(EFV) hipLaunchKernelGGL((kamd::TdnnGemmSaKernel<128, 128, 2, 2, EFV, false>), grid, dim3(256), 0, st, g)
+      switch (ef) {
+        case 0: KAMD_G4(0); break;
+        case kamd::EF_BIAS: KAMD_G4(kamd::EF_BIAS); break;
+        case kamd::EF_BN: KAMD_G4(kamd::EF_BN); break;
+        case kamd::EF_BIAS | kamd::EF_RELU | kamd::EF_BN: KAMD_G4(kamd::EF_BIAS | kamd::EF_RELU | kamd::EF_BN); break;
+        case kamd::EF_BIAS | kamd::EF_RELU | kamd::EF_BN | kamd::EF_BYP: KAMD_G4(kamd::EF_BIAS | kamd::EF_RELU | kamd::EF_BN | kamd::EF_BYP); break;
+        case kamd::EF_BIAS | kamd::EF_PO: KAMD_G4(kamd::EF_BIAS | kamd::EF_PO); break;
+        case kamd::EF_BIAS | kamd::EF_PO | kamd::EF_SCALE: KAMD_G4(kamd::EF_BIAS | kamd::EF_PO | kamd::EF_SCALE); break;
+        default: gen4 = false; break;       // a layer form without a compiled epilogue
+      }
+#undef KAMD_G4
+    }
+    if (gen4 && !gen1) {
+      // launched above
+    } else if (persist && !gen1) {
+      g.gy = static_cast<int>(kamd::CeilDiv(Ml, 128)); g.gx = 1;
+      const int wgs = std::max(8, std::min(kamd::RoundUp(g.gy, 8), 2 * n_cus) & ~7);
+      hipLaunchKernelGGL((kamd::TdnnGemmPersistKernel<128, 160, 4, 1, 3, false, 2, 1>), dim3(wgs), dim3(256), 0, st, g);
+    } else if (!gen1) {
       if (nt32 <= 5) {
         dim3 grid(1, kamd::CeilDiv(Ml, 128));
         const bool e2 = epi == 2;       // (an i-vector layer this narrow keeps round 2's epilogue)
@@ -905,6 +1605,8 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
         else if (epi == 3) hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 3, 3>), grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 128, 2, 2, 3, 1>), grid, dim3(256), 0, st, g);
       }
+    }
+    if (!gen1) {
     } else if (nt32 <= 5) {
       dim3 grid(1, kamd::CeilDiv(Ml, 128));
       switch (nt32) {

@@ -27,7 +27,7 @@ static float *DevRand(size_t n, unsigned seed, float scale) {
   return d;
 }
 
-struct Variant { std::string name; std::function<void(GemmArgs &, int M, int N, hipStream_t)> launch; };
+struct Variant { std::string name; std::function<void(GemmArgs &, int M, int N, hipStream_t)> launch; int prio = 0; int aux = 0; int valu = 0; };
 
 template <int BM, int BN, int WM, int WN, int NST, int EPI>
 static void LaunchTall(GemmArgs &g, int M, int N, hipStream_t st) {      // one column tile as wide as the layer
@@ -40,17 +40,51 @@ static void LaunchGrid(GemmArgs &g, int M, int N, hipStream_t st) {      // XCD-
   hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<BM, BN, WM, WN, NST, EPI>), dim3(static_cast<unsigned>(g.gx) * kamd::RoundUp(g.gy, 8)), dim3(256), 0, st, g);
 }
 
+template <int BM, int BN, int WM, int WN, int NST, int BK, int OCC>
+static void LaunchTallK(GemmArgs &g, int M, int N, hipStream_t st) {
+  g.gx = 0; g.gy = 0;
+  hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<BM, BN, WM, WN, NST, 2, BK, OCC>), dim3(1, kamd::CeilDiv(M, BM)), dim3(256), 0, st, g);
+}
+template <int BM, int BN, int WM, int WN, int NST, int BK, int OCC>
+static void LaunchGridK(GemmArgs &g, int M, int N, hipStream_t st) {
+  g.gx = kamd::CeilDiv(N, BN); g.gy = kamd::CeilDiv(M, BM);
+  hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<BM, BN, WM, WN, NST, 2, BK, OCC>), dim3(static_cast<unsigned>(g.gx) * kamd::RoundUp(g.gy, 8)), dim3(256), 0, st, g);
+}
+template <int BM, int BN, int WM, int WN, int EF, int NST = 3, int OCC = 3>
+static void LaunchSa(GemmArgs &g, int M, int N, hipStream_t st) {
+  if (N <= BN) { g.gx = 0; g.gy = 0; hipLaunchKernelGGL((kamd::TdnnGemmSaKernel<BM, BN, WM, WN, EF, false, NST, OCC>), dim3(1, kamd::CeilDiv(M, BM)), dim3(256), 0, st, g); return; }
+  g.gx = kamd::CeilDiv(N, BN); g.gy = kamd::CeilDiv(M, BM);
+  hipLaunchKernelGGL((kamd::TdnnGemmSaKernel<BM, BN, WM, WN, EF, false, NST, OCC>), dim3(static_cast<unsigned>(g.gx) * kamd::RoundUp(g.gy, 8)), dim3(256), 0, st, g);
+}
+template <int BM, int BN, int WM, int WN, int NST, int OCC>
+static void LaunchLoader(GemmArgs &g, int M, int N, hipStream_t st) {
+  if (N <= BN) { g.gx = 0; g.gy = 0; hipLaunchKernelGGL((kamd::TdnnGemmLoaderKernel<BM, BN, WM, WN, NST, OCC, false>), dim3(1, kamd::CeilDiv(M, BM)), dim3(320), 0, st, g); return; }
+  g.gx = kamd::CeilDiv(N, BN); g.gy = kamd::CeilDiv(M, BM);
+  hipLaunchKernelGGL((kamd::TdnnGemmLoaderKernel<BM, BN, WM, WN, NST, OCC, false>), dim3(static_cast<unsigned>(g.gx) * kamd::RoundUp(g.gy, 8)), dim3(320), 0, st, g);
+}
+template <int BM, int BN, int WM, int WN, int NST, int OCC, int DEPTH>
+static void LaunchPersist(GemmArgs &g, int M, int N, hipStream_t st) {   // persistent workgroups, OCC per compute unit
+  g.gx = kamd::CeilDiv(N, BN); g.gy = kamd::CeilDiv(M, BM);
+  int cus = 0; CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
+  const int wgs = std::max(8, std::min(g.gx * kamd::RoundUp(g.gy, 8), OCC * cus) & ~7);
+  hipLaunchKernelGGL((kamd::TdnnGemmPersistKernel<BM, BN, WM, WN, NST, false, OCC, DEPTH>), dim3(wgs), dim3(256), 0, st, g);
+}
+
 int main(int argc, char **argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 333000;
   const int reps = argc > 2 ? atoi(argv[2]) : 20;
   const Shape shapes[] = {{"affine 2x160 -> 1536 (+bias relu bn bypass)", 160, 2, {0, 1}, 1536, true, true},
                           {"linear 2x1536 -> 160", 1536, 2, {-1, 0}, 160, false, false},
-                          {"output 256 -> 6000 (+bias, post offset)", 256, 1, {0, 0}, 6000, true, false}};
+                          {"output 256 -> 6000 (+bias, post offset)", 256, 1, {0, 0}, 6000, true, false},
+                          {"long-K probe 2x1536 -> 1536 (main loop only matters)", 1536, 2, {-1, 0}, 1536, false, false}};
+  const int only = argc > 3 ? atoi(argv[3]) : -1;
+  int shape_no = -1;
   hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float *zeros;
   { std::vector<float> z(16384, 0.0f); std::fill(z.begin() + 8192, z.end(), 1.0f); CK(hipMalloc(&zeros, z.size() * 4)); CK(hipMemcpy(zeros, z.data(), z.size() * 4, hipMemcpyHostToDevice)); }
   for (const Shape &sh : shapes) {
+    if (only >= 0 && ++shape_no != only) continue;
     const int in_pad = kamd::RoundUp(sh.in_dim, 16), K = sh.n_off * in_pad, N = sh.N, N_pad = kamd::RoundUp(N, 128);
     float *A = DevRand(static_cast<size_t>(M) * in_pad, 1, 1.0f);
     float *W = DevRand(static_cast<size_t>(N_pad) * K, 2, 0.05f);
@@ -63,7 +97,7 @@ int main(int argc, char **argv) {
     int *rowmap; CK(hipMalloc(&rowmap, rmh.size() * 4)); CK(hipMemcpy(rowmap, rmh.data(), rmh.size() * 4, hipMemcpyHostToDevice));
     float *C[2]; for (int i = 0; i < 2; i++) { CK(hipMalloc(&C[i], static_cast<size_t>(M) * N * 4)); CK(hipMemset(C[i], 0, static_cast<size_t>(M) * N * 4)); }
     const int wgs_max = 8 * (kamd::CeilDiv(M, 64) + 8) * kamd::CeilDiv(N, 32);
-    unsigned long long *stamps; CK(hipMalloc(&stamps, static_cast<size_t>(wgs_max) * 64));
+    unsigned long long *stamps; CK(hipMalloc(&stamps, static_cast<size_t>(wgs_max) * 256));
     GemmArgs g; memset(&g, 0, sizeof(g));
     g.A = A; g.ldA = in_pad; g.rowmap = rowmap; g.M = M; g.N = N; g.n_off = sh.n_off; g.in_pad = in_pad; g.W = W;
     if (sh.epi) { g.bias = bias; g.post_offset = po; }
@@ -73,16 +107,24 @@ int main(int argc, char **argv) {
     if (N <= 160) {
       vs.push_back({"128x160 4x1 ring3 epi1 (round 2)", LaunchTall<128, 160, 4, 1, 3, 1>});
       vs.push_back({"128x160 4x1 ring3 epi2", LaunchTall<128, 160, 4, 1, 3, 2>});
-      vs.push_back({"128x160 4x1 ring2 epi2", LaunchTall<128, 160, 4, 1, 2, 2>});
+      vs.push_back({"128x160 4x1 ring3 persistent x2 d1", LaunchPersist<128, 160, 4, 1, 3, 2, 1>});
+      vs.push_back({"128x160 4x1 gen4 (scalar addressing, specialised epilogue)", LaunchSa<128, 160, 4, 1, 0>});
+      vs.push_back({"128x160 4x1 gen4 ring2 x3", LaunchSa<128, 160, 4, 1, 0, 2, 3>});
     } else {
       vs.push_back({"128x128 2x2 ring3 epi1 (round 2)", LaunchGrid<128, 128, 2, 2, 3, 1>});
       vs.push_back({"128x128 2x2 ring3 epi2", LaunchGrid<128, 128, 2, 2, 3, 2>});
-      vs.push_back({"128x128 2x2 ring2 epi2", LaunchGrid<128, 128, 2, 2, 2, 2>});
+      vs.push_back({"128x128 2x2 ring3 persistent x3 d1", LaunchPersist<128, 128, 2, 2, 3, 3, 1>});
+      if (sh.bypass) vs.push_back({"128x128 2x2 gen4 (scalar addressing, specialised epilogue)", LaunchSa<128, 128, 2, 2, kamd::EF_BIAS | kamd::EF_RELU | kamd::EF_BN | kamd::EF_BYP>});
+      else if (sh.epi) vs.push_back({"128x128 2x2 gen4 (scalar addressing, specialised epilogue)", LaunchSa<128, 128, 2, 2, kamd::EF_BIAS | kamd::EF_PO>});
+      else vs.push_back({"128x128 2x2 gen4 (scalar addressing, specialised epilogue)", LaunchSa<128, 128, 2, 2, 0>});
+      if (sh.bypass) vs.push_back({"128x128 2x2 gen4 ring2 x4", LaunchSa<128, 128, 2, 2, kamd::EF_BIAS | kamd::EF_RELU | kamd::EF_BN | kamd::EF_BYP, 2, 4>});
+      else if (sh.epi) vs.push_back({"128x128 2x2 gen4 ring2 x4", LaunchSa<128, 128, 2, 2, kamd::EF_BIAS | kamd::EF_PO, 2, 4>});
+      else vs.push_back({"128x128 2x2 gen4 ring2 x4", LaunchSa<128, 128, 2, 2, 0, 2, 4>});
     }
     const double flops = 2.0 * M * static_cast<double>(N) * sh.n_off * sh.in_dim;
     printf("== %s, %d rows\n", sh.name, M);
     for (size_t v = 0; v < vs.size(); v++) {
-      g.C = C[v == 0 ? 0 : 1]; g.stamps = NULL;
+      g.C = C[v == 0 ? 0 : 1]; g.stamps = NULL; g.lab_prio = vs[v].prio; g.lab_aux = vs[v].aux; g.lab_valu = vs[v].valu;
       for (int r = 0; r < 3; r++) vs[v].launch(g, M, N, st);
       CK(hipStreamSynchronize(st));
       CK(hipEventRecord(e0, st));
@@ -91,16 +133,34 @@ int main(int argc, char **argv) {
       CK(hipStreamSynchronize(st));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
       // stamps
-      CK(hipMemset(stamps, 0, static_cast<size_t>(wgs_max) * 64));
+      CK(hipMemset(stamps, 0, static_cast<size_t>(wgs_max) * 256));
       g.stamps = stamps; vs[v].launch(g, M, N, st); CK(hipStreamSynchronize(st)); g.stamps = NULL;
-      std::vector<unsigned long long> hs(static_cast<size_t>(wgs_max) * 8);
+      std::vector<unsigned long long> hs(static_cast<size_t>(wgs_max) * 32);
       CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
-      double seg[5] = {0, 0, 0, 0, 0}; size_t cnt = 0;
+      double seg[5] = {0, 0, 0, 0, 0}, clk = 0; size_t cnt = 0;
       for (int w = 0; w < wgs_max; w++) {
-        const unsigned long long *q = &hs[static_cast<size_t>(w) * 8];
+        const unsigned long long *q = &hs[static_cast<size_t>(w) * 32];
         if (!q[0] || !q[5]) continue;
-        for (int i = 0; i < 5; i++) seg[i] += static_cast<double>(q[i + 1] - q[i]);
+        if (q[1]) for (int i = 0; i < 5; i++) seg[i] += static_cast<double>(q[i + 1] - q[i]);
+        clk += static_cast<double>(q[5] - q[0]) / static_cast<double>(q[7] - q[6]) * 0.1;     // s_memrealtime: 100 MHz -> GHz
         cnt++;
+      }
+      clk /= cnt ? cnt : 1;
+      // a second stamped launch that also times the segments of every k-block, per wave (perturbs the loop: shares, not totals)
+      double lseg[4] = {0, 0, 0, 0};
+      if (vs[v].name.find("persistent") == std::string::npos && vs[v].name.find("loader") == std::string::npos && vs[v].name.find("gen4") == std::string::npos) {
+        CK(hipMemset(stamps, 0, static_cast<size_t>(wgs_max) * 256));
+        g.stamps = stamps; g.lab_loop = 1; vs[v].launch(g, M, N, st); CK(hipStreamSynchronize(st)); g.stamps = NULL; g.lab_loop = 0;
+        CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+        size_t c2 = 0;
+        for (int w = 0; w < wgs_max; w++) {
+          const unsigned long long *q = &hs[static_cast<size_t>(w) * 32];
+          if (!q[0] || !q[5]) continue;
+          for (int wv = 0; wv < 4; wv++) for (int i = 0; i < 4; i++) lseg[i] += static_cast<double>(q[8 + wv * 4 + i]) / 4;
+          c2++;
+        }
+        const int nkb = K / (vs[v].name.find("BK32") != std::string::npos ? 32 : 16);
+        for (int i = 0; i < 4; i++) lseg[i] /= (c2 ? c2 : 1) * static_cast<double>(nkb);
       }
       for (int i = 0; i < 5; i++) seg[i] /= cnt ? cnt : 1;
       size_t bad = 0;
@@ -110,8 +170,8 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < a.size(); i++) bad += memcmp(&a[i], &b[i], 4) != 0;
         CK(hipMemset(C[1], 0, a.size() * 4));
       }
-      printf("  %-36s %7.3f ms %6.1f TFLOP/s (%.3f of 157.3) | wg cycles: rowmap %.0f ringfill %.0f first-wait %.0f mainloop %.0f epilogue %.0f (%zu wgs)%s\n",
-             vs[v].name.c_str(), ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3, seg[0], seg[1], seg[2], seg[3], seg[4], cnt,
+      printf("  %-36s %7.3f ms %6.1f TFLOP/s (%.3f of 157.3) clock %.2f GHz | wg cycles: rowmap %.0f ringfill %.0f first-wait %.0f mainloop %.0f epilogue %.0f (%zu wgs) | per k-block: dma-wait %.0f barrier %.0f issue %.0f lds+mfma %.0f%s\n",
+             vs[v].name.c_str(), ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3, clk, seg[0], seg[1], seg[2], seg[3], seg[4], cnt, lseg[0], lseg[1], lseg[2], lseg[3],
              v == 0 ? "" : (bad ? "  OUTPUT DIFFERS" : "  bit-equal"));
       fflush(stdout);
     }
