@@ -988,6 +988,8 @@ typedef struct {
   int64_t lattice_pool_bytes; /* page-locked host pool the finished lattices wait in */
   float lattice_beam;         /* determinization beam = config.lattice_beam */
   kamd_determinize_opts det;
+  int64_t first_pass_frames;  /* kamd_batch_decoder_load_host: input frames of the FIRST acoustic-model pass (small, so
+                               * that the model starts behind a short upload); 0 = nnet_pass_frames */
 } kamd_batch_opts;
 void kamd_batch_opts_default(kamd_batch_opts *o);
 typedef struct {
@@ -999,6 +1001,11 @@ typedef struct {
   double host_thread_ms_sum;           /* CPU time spent in the host tail, all threads */
   int32_t lanes, nnet_passes, n_failed;
   int32_t long_utterances;             /* > 0: that many were searched beside the acoustic model (set_long_decoder) */
+  /* kamd_batch_decoder_load_host only (0 otherwise): */
+  float upload_ms;                     /* wall time until the last waveform byte was in HBM */
+  float first_pass_start_ms;           /* wall time until the first pass's features were launched: the exposed part of the upload */
+  float upload_wait_ms;                /* wall time the launching thread spent waiting for a pass's copies to be issued */
+  int32_t upload_passes;
 } kamd_batch_stats;
 typedef struct kamd_batch_decoder kamd_batch_decoder;
 /* The stages are not owned.  tid_phone as kamd_lattice_determinize_phone_pruned (NULL: word
@@ -1020,6 +1027,18 @@ void kamd_batch_decoder_destroy(kamd_batch_decoder *b);
 int kamd_batch_decoder_set_long_decoder(kamd_batch_decoder *b, kamd_decoder *dec_long, int lanes);
 /* AcceptInput for the whole shard: utterance u owns samples [wave_off[u], wave_off[u+1]). */
 int kamd_batch_decoder_load(kamd_batch_decoder *b, const float *waves, const int64_t *wave_off, int n_utts);
+/* AcceptInput with the waveforms left where they are, in the caller's (pageable) host memory: every run() uploads
+ * them itself, inside what it times -- pass by pass through page-locked staging buffers on a copy stream, the
+ * copies of pass k + 1 overlapped with the features and the acoustic model of pass k; the first pass is small
+ * (kamd_batch_opts.first_pass_frames).  `waves` must stay valid until the next load or destroy.  (nnet3-latgen-faster-
+ * batch reads each wave / feature matrix from its table inside the timed loop too: nnet3-latgen-faster-batch.cc:176-214.) */
+int kamd_batch_decoder_load_host(kamd_batch_decoder *b, const float *waves, const int64_t *wave_off, int n_utts);
+/* Workload synthesis for benchmarks: the search reads log-likelihoods from d_loglikes (device, [total output frames x
+ * P], utterances back to back in load order, as kamd_batch_decoder_get_loglikes numbers them) instead of the acoustic
+ * model's output, which is still computed.  NULL switches it off. */
+int kamd_batch_decoder_set_loglike_override(kamd_batch_decoder *b, const float *d_loglikes);
+/* Output frames of every loaded utterance (0 for the ones too short for a frame); total returned. */
+int64_t kamd_batch_decoder_output_frames(kamd_batch_decoder *b, int32_t *frames, int cap);
 /* AcceptInput as the reference declares it (nnet-batch-compute.h:665-669: feature matrices, not
  * waveforms, plus the optional per-utterance i-vector): rows [row_off[u], row_off[u+1]) of feats
  * (dim floats per row, dim = the model's input dim) are utterance u; ivectors is [n_utts x

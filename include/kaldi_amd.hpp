@@ -937,10 +937,12 @@ class NnetBatchDecoder {
     std::vector<int64_t> off(1, 0);
     off.insert(off.end(), row_off_.begin(), row_off_.end());
     const int n = static_cast<int>(keys_.size());
-    if (!waves_.empty()) Check(kamd_batch_decoder_load(h_, waves_.data(), off.data(), n));
+    // waveforms stay in this object's memory: run() uploads them pass by pass behind the features and the model
+    if (!waves_.empty()) Check(kamd_batch_decoder_load_host(h_, waves_.data(), off.data(), n));
     else Check(kamd_batch_decoder_load_features(h_, feats_.data(), off.data(), input_dim_, ivectors_.empty() ? NULL : ivectors_.data(), ivector_dim_, n));
-    std::vector<float>().swap(waves_); std::vector<float>().swap(feats_);
+    std::vector<float>().swap(feats_);
     Check(kamd_batch_decoder_run(h_, &stats_));
+    std::vector<float>().swap(waves_);
     // the per-utterance outcome, with the log lines of decoder-wrappers.cc:228-292
     ok_.assign(n, 0);
     for (int u = 0; u < n; u++) {

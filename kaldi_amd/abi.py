@@ -185,7 +185,7 @@ class BatchOpts(C.Structure):
     """kamd_batch_opts."""
     _fields_ = [("resident_lanes", C.c_int32), ("host_threads", C.c_int32), ("determinize", C.c_int32),
                 ("keep_raw_lattices", C.c_int32), ("nnet_pass_frames", C.c_int64), ("lattice_pool_bytes", C.c_int64),
-                ("lattice_beam", C.c_float), ("det", DeterminizeOpts)]
+                ("lattice_beam", C.c_float), ("det", DeterminizeOpts), ("first_pass_frames", C.c_int64)]
 
 
 class BatchStats(C.Structure):
@@ -193,7 +193,8 @@ class BatchStats(C.Structure):
     _fields_ = [("feat_ms", C.c_float), ("nnet_ms", C.c_float), ("decode_ms", C.c_float), ("host_tail_ms", C.c_float),
                 ("first_result_ms", C.c_float), ("total_ms", C.c_float), ("nnet_flops", C.c_double),
                 ("host_thread_ms_sum", C.c_double), ("lanes", C.c_int32), ("nnet_passes", C.c_int32),
-                ("n_failed", C.c_int32), ("long_utterances", C.c_int32)]
+                ("n_failed", C.c_int32), ("long_utterances", C.c_int32), ("upload_ms", C.c_float),
+                ("first_pass_start_ms", C.c_float), ("upload_wait_ms", C.c_float), ("upload_passes", C.c_int32)]
 
 
 CLAT_ARC_DTYPE = np.dtype([("src", "<i4"), ("dst", "<i4"), ("label", "<i4"), ("graph_cost", "<f4"),

@@ -17,7 +17,7 @@ from ._lib import KamdError, check, lib
 class NnetBatchDecoder:
     def __init__(self, mfcc_opts, model, hclg, cfg, max_seconds=36.0, resident_lanes=0, host_threads=8, determinize=True,
                  keep_raw_lattices=False, tid_phone=None, sizes=None, nnet_pass_frames=1000000, lattice_pool_bytes=1 << 30,
-                 hash_capacity=None, tokens_per_frame=None, search_mode=2, det=None, long_lanes=0):
+                 hash_capacity=None, tokens_per_frame=None, search_mode=2, det=None, long_lanes=0, first_pass_frames=None):
         featmod = __import__("kaldi_amd.feat", fromlist=["Mfcc"])
         # mfcc_opts = None: no feature stage, the caller hands over feature matrices (load_features), as the
         # reference's AcceptInput does (nnet-batch-compute.h:665)
@@ -42,6 +42,8 @@ class NnetBatchDecoder:
         o.determinize, o.keep_raw_lattices = int(bool(determinize)), int(bool(keep_raw_lattices))
         o.nnet_pass_frames, o.lattice_pool_bytes = int(nnet_pass_frames), int(lattice_pool_bytes)
         o.lattice_beam = cfg.lattice_beam
+        if first_pass_frames is not None:
+            o.first_pass_frames = int(first_pass_frames)
         for k, v in (det or {}).items():        # DeterminizeLatticePhonePrunedOptions: delta, phone_determinize, word_determinize, ...
             setattr(o.det, k, v)
         self.opts = o
@@ -74,6 +76,28 @@ class NnetBatchDecoder:
         check(lib().kamd_batch_decoder_load(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), len(waves)))
         self.n_utts = len(waves)
         self.audio_seconds = float(flat.size) / self.feat.opts.frame.samp_freq
+
+    def load_host(self, waves):
+        """AcceptInput with the samples left in host memory: every run() uploads them itself, pass by pass, overlapped
+        with the features and the acoustic model (kamd_batch_decoder_load_host).  The buffer is kept alive here."""
+        waves = [np.asarray(w, np.float32) for w in waves]
+        off = np.concatenate([[0], np.cumsum([w.size for w in waves])]).astype(np.int64)
+        self._host_waves = np.ascontiguousarray(np.concatenate(waves), np.float32)
+        self._host_off = off
+        check(lib().kamd_batch_decoder_load_host(self._h, abi.fptr(self._host_waves), abi.iptr(off, C.c_int64), len(waves)))
+        self.n_utts = len(waves)
+        self.audio_seconds = float(self._host_waves.size) / self.feat.opts.frame.samp_freq
+
+    def output_frames(self):
+        """Output frames of every loaded utterance (0: too short for a frame)."""
+        fr = np.zeros(max(self.n_utts, 1), np.int32)
+        lib().kamd_batch_decoder_output_frames(self._h, abi.iptr(fr), self.n_utts)
+        return fr[:self.n_utts]
+
+    def set_loglike_override(self, device_ptr):
+        """Bench workload synthesis: the search reads this device matrix ([sum of output_frames() x P], load order)
+        instead of the acoustic model's output (still computed).  None switches it off."""
+        check(lib().kamd_batch_decoder_set_loglike_override(self._h, C.c_void_p(device_ptr) if device_ptr else None))
 
     def load_features(self, feats, ivectors=None):
         """AcceptInput(utterance_id, input, ivector, ...) for every utterance: feats = list of [T x dim] matrices,

@@ -66,6 +66,20 @@ struct BatchDecoder {
   float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL, *d_iv = NULL;
   size_t waves_cap = 0, feats_cap = 0, ll_cap = 0, iv_cap = 0;
   bool from_features = false, have_iv = false;   // the loaded set: feature matrices (+ i-vectors) instead of waveforms
+  // kamd_batch_decoder_load_host: the samples stay in the caller's memory and every run() uploads them pass by pass
+  const float *h_waves = NULL;                   // caller's buffer (kept utterance k starts at h_wave_src[k])
+  std::vector<int64_t> h_wave_src;
+  std::vector<int> pass_u0;                      // pass p = kept utterances [pass_u0[p], pass_u0[p + 1])
+  std::vector<int64_t> pass_frames;              // feature frames of pass p
+  int64_t *d_feat_meta = NULL; size_t feat_meta_cap = 0;
+  std::vector<size_t> feat_meta_off;             // first word of pass p's offsets in d_feat_meta
+  static const int kStageBufs = 4;
+  static const size_t kStageFloats = 8u << 20;   // 32 MB each
+  float *h_stage[kStageBufs] = {};
+  hipEvent_t ev_stage[kStageBufs] = {};
+  hipStream_t s_up = NULL;
+  std::vector<hipEvent_t> ev_up, ev_f0, ev_f1, ev_n1;   // per pass: copies done; features start / end; model end
+  const float *d_ll_override = NULL;             // kamd_batch_decoder_set_loglike_override
   hipStream_t s_main = NULL;
   hipEvent_t ev[3] = {};
   // A shard so small that its search is the longest utterance's own chain of frames (8 ranks over test-clean): the
@@ -176,6 +190,7 @@ void kamd_batch_opts_default(kamd_batch_opts *o) {
   o->resident_lanes = 0; o->host_threads = 8; o->determinize = 1; o->keep_raw_lattices = 0;
   o->nnet_pass_frames = 1000000; o->lattice_pool_bytes = 1ll << 30; o->lattice_beam = 8.0f;
   kamd_determinize_opts_default(&o->det);
+  o->first_pass_frames = 60000;
 }
 
 kamd_batch_decoder *kamd_batch_decoder_create(kamd_feat *feat, kamd_nnet *nnet, kamd_decoder *dec, const kamd_batch_opts *opts,
@@ -229,6 +244,14 @@ void kamd_batch_decoder_destroy(kamd_batch_decoder *h) {
   if (b->d_feats) (void)hipFree(b->d_feats);
   if (b->d_ll) (void)hipFree(b->d_ll);
   if (b->d_iv) (void)hipFree(b->d_iv);
+  if (b->d_feat_meta) (void)hipFree(b->d_feat_meta);
+  for (int i = 0; i < BatchDecoder::kStageBufs; i++) {
+    if (b->h_stage[i]) (void)hipHostFree(b->h_stage[i]);
+    if (b->ev_stage[i]) (void)hipEventDestroy(b->ev_stage[i]);
+  }
+  for (std::vector<hipEvent_t> *v : {&b->ev_up, &b->ev_f0, &b->ev_f1, &b->ev_n1})
+    for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
+  if (b->s_up) (void)hipStreamDestroy(b->s_up);
   delete b;
 }
 
@@ -238,7 +261,7 @@ int kamd_batch_decoder_load(kamd_batch_decoder *h, const float *waves, const int
   if (!b->feat) return kamd::SetError(KAMD_ERR_STATE, "batch decoder was created without a feature stage: use kamd_batch_decoder_load_features");
   if (kamd_nnet_ivector_dim(b->nnet) > 0) return kamd::SetError(KAMD_ERR_ARG, "the model has an ivector input: use kamd_batch_decoder_load_features");
   for (kamd::UttOut &o : b->out) o.Clear();
-  b->n_utts = 0; b->from_features = false; b->have_iv = false;
+  b->n_utts = 0; b->from_features = false; b->have_iv = false; b->h_waves = NULL;
   b->kept.clear(); b->skipped.clear();
   b->wave_off.assign(1, 0); b->feat_off.assign(1, 0); b->out_off.assign(1, 0);
   for (int u = 0; u < n_utts; u++) {
@@ -278,7 +301,7 @@ int kamd_batch_decoder_load_features(kamd_batch_decoder *h, const float *feats, 
   if ((ivectors ? ivector_dim : 0) != want_iv)
     return kamd::SetError(KAMD_ERR_ARG, "model expects ivector dim %d, got %d", want_iv, ivectors ? ivector_dim : 0);
   for (kamd::UttOut &o : b->out) o.Clear();
-  b->n_utts = 0;
+  b->n_utts = 0; b->h_waves = NULL;
   b->kept.clear(); b->skipped.clear();
   b->feat_off.assign(1, 0); b->out_off.assign(1, 0);
   for (int u = 0; u < n_utts; u++) {
@@ -308,6 +331,82 @@ int kamd_batch_decoder_load_features(kamd_batch_decoder *h, const float *feats, 
   b->out.resize(n_utts);
   b->n_utts = n_utts;
   return KAMD_OK;
+}
+
+int kamd_batch_decoder_load_host(kamd_batch_decoder *h, const float *waves, const int64_t *h_wave_off, int n_utts) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (n_utts <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty test set");
+  if (!b->feat) return kamd::SetError(KAMD_ERR_STATE, "batch decoder was created without a feature stage: use kamd_batch_decoder_load_features");
+  if (kamd_nnet_ivector_dim(b->nnet) > 0) return kamd::SetError(KAMD_ERR_ARG, "the model has an ivector input: use kamd_batch_decoder_load_features");
+  for (kamd::UttOut &o : b->out) o.Clear();
+  b->n_utts = 0; b->from_features = false; b->have_iv = false; b->h_waves = NULL;
+  b->kept.clear(); b->skipped.clear(); b->h_wave_src.clear();
+  b->wave_off.assign(1, 0); b->feat_off.assign(1, 0); b->out_off.assign(1, 0);
+  for (int u = 0; u < n_utts; u++) {
+    const int64_t len = h_wave_off[u + 1] - h_wave_off[u];
+    if (len < 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d: negative length", u);
+    const int T = len > 0 ? kamd_feat_num_frames(b->feat, len) : 0;
+    if (T <= 0) { b->skipped.push_back(u); continue; }
+    b->kept.push_back(u);
+    b->h_wave_src.push_back(h_wave_off[u]);
+    b->wave_off.push_back(b->wave_off.back() + len);
+    b->feat_off.push_back(b->feat_off.back() + T);
+    b->out_off.push_back(b->out_off.back() + kamd_nnet_num_output_frames(b->nnet, T));
+  }
+  const int n = static_cast<int>(b->kept.size());
+  if (kamd::GrowDev(&b->d_waves, &b->waves_cap, std::max<size_t>(static_cast<size_t>(b->wave_off.back()), 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&b->d_feats, &b->feats_cap, std::max<size_t>(static_cast<size_t>(b->feat_off.back()) * b->ld_feat, 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&b->d_ll, &b->ll_cap, std::max<size_t>(static_cast<size_t>(b->out_off.back()) * b->P, 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  // passes: a small first one, so that the acoustic model starts behind a short upload
+  b->pass_u0.assign(1, 0);
+  for (int u0 = 0; u0 < n;) {
+    const int64_t cap = (b->pass_u0.size() == 1 && b->opts.first_pass_frames > 0) ? b->opts.first_pass_frames : b->opts.nnet_pass_frames;
+    int u1 = u0 + 1;
+    while (u1 < n && b->feat_off[u1 + 1] - b->feat_off[u0] <= cap) u1++;
+    b->pass_u0.push_back(u1);
+    u0 = u1;
+  }
+  const int np = static_cast<int>(b->pass_u0.size()) - 1;
+  // feature offsets of every pass, uploaded once
+  std::vector<int64_t> meta;
+  b->feat_meta_off.assign(np, 0); b->pass_frames.assign(np, 0);
+  for (int p = 0; p < np; p++) {
+    const int u0 = b->pass_u0[p], cnt = b->pass_u0[p + 1] - u0;
+    b->feat_meta_off[p] = meta.size();
+    meta.resize(meta.size() + 3 * static_cast<size_t>(cnt + 1));
+    kamd::FeatBuildMeta(b->feat, b->wave_off.data() + u0, cnt, b->feat_off.data() + u0, meta.data() + b->feat_meta_off[p], &b->pass_frames[p]);
+  }
+  if (kamd::GrowDev(&b->d_feat_meta, &b->feat_meta_cap, std::max<size_t>(meta.size(), 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (!meta.empty()) KAMD_HIP(hipMemcpy(b->d_feat_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice));
+  if (!b->s_up) KAMD_HIP(hipStreamCreateWithFlags(&b->s_up, hipStreamNonBlocking));
+  for (int i = 0; i < BatchDecoder::kStageBufs; i++) {
+    if (!b->h_stage[i]) KAMD_HIP(hipHostMalloc(reinterpret_cast<void **>(&b->h_stage[i]), BatchDecoder::kStageFloats * sizeof(float), hipHostMallocDefault));
+    if (!b->ev_stage[i]) KAMD_HIP(hipEventCreateWithFlags(&b->ev_stage[i], hipEventDisableTiming));
+  }
+  for (std::vector<hipEvent_t> *v : {&b->ev_up, &b->ev_f0, &b->ev_f1, &b->ev_n1})
+    while (static_cast<int>(v->size()) < np) {
+      hipEvent_t e = NULL;
+      KAMD_HIP(hipEventCreate(&e));
+      v->push_back(e);
+    }
+  b->h_waves = waves;
+  b->out.resize(n_utts);
+  b->n_utts = n_utts;
+  return KAMD_OK;
+}
+
+int kamd_batch_decoder_set_loglike_override(kamd_batch_decoder *h, const float *d_loglikes) {
+  reinterpret_cast<BatchDecoder *>(h)->d_ll_override = d_loglikes;
+  return KAMD_OK;
+}
+
+int64_t kamd_batch_decoder_output_frames(kamd_batch_decoder *h, int32_t *frames, int cap) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (frames) for (int u = 0; u < std::min(cap, b->n_utts); u++) frames[u] = 0;
+  if (frames)
+    for (size_t k = 0; k < b->kept.size(); k++)
+      if (b->kept[k] < cap) frames[b->kept[k]] = static_cast<int32_t>(b->out_off[k + 1] - b->out_off[k]);
+  return b->out_off.empty() ? 0 : b->out_off.back();
 }
 
 int kamd_batch_decoder_set_long_decoder(kamd_batch_decoder *h, kamd_decoder *dec_long, int lanes) {
@@ -346,9 +445,70 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   hipStream_t st = b->s_main;
   KAMD_HIP(hipEventRecord(b->ev[0], st));
   int rc = KAMD_OK;
-  if (!b->from_features) rc = kamd_feat_compute_batch_device(b->feat, b->d_waves, b->wave_off.data(), n, b->d_feats, b->feat_off.data(), b->ld_feat, st);
+  const bool host_mode = b->h_waves != NULL;
+  // ---- kamd_batch_decoder_load_host: one thread stages the caller's samples through page-locked buffers and issues the
+  // copies pass by pass on the copy stream; this thread launches a pass's features and model behind its event
+  struct Upload {
+    std::mutex mu; std::condition_variable cv;
+    int issued = 0, rc = KAMD_OK; std::string err; double done_ms = 0;
+  } up;
+  std::thread uploader;
+  if (host_mode) {
+    uploader = std::thread([b, &up, t0]() {
+      (void)hipSetDevice(b->device);
+      const int np = static_cast<int>(b->pass_u0.size()) - 1;
+      int k = 0;
+      auto fail = [&](hipError_t e) {
+        std::lock_guard<std::mutex> lk(up.mu);
+        up.rc = KAMD_ERR_HIP; up.err = std::string("waveform upload failed: ") + hipGetErrorString(e);
+      };
+      for (int p = 0; p < np && up.rc == KAMD_OK; p++) {
+        for (int u = b->pass_u0[p]; u < b->pass_u0[p + 1] && up.rc == KAMD_OK;) {
+          // the longest run of utterances that is contiguous in the caller's buffer (all of them unless some were skipped)
+          int v = u + 1;
+          while (v < b->pass_u0[p + 1] && b->h_wave_src[v] == b->h_wave_src[v - 1] + (b->wave_off[v] - b->wave_off[v - 1])) v++;
+          const float *src = b->h_waves + b->h_wave_src[u];
+          float *dst = b->d_waves + b->wave_off[u];
+          for (int64_t left = b->wave_off[v] - b->wave_off[u]; left > 0;) {
+            const size_t cnt = static_cast<size_t>(std::min<int64_t>(left, BatchDecoder::kStageFloats));
+            const int i = k % BatchDecoder::kStageBufs;
+            hipError_t e = k >= BatchDecoder::kStageBufs ? hipEventSynchronize(b->ev_stage[i]) : hipSuccess;
+            if (e == hipSuccess) {
+              memcpy(b->h_stage[i], src, cnt * sizeof(float));
+              e = hipMemcpyAsync(dst, b->h_stage[i], cnt * sizeof(float), hipMemcpyHostToDevice, b->s_up);
+            }
+            if (e == hipSuccess) e = hipEventRecord(b->ev_stage[i], b->s_up);
+            if (e != hipSuccess) { fail(e); break; }
+            src += cnt; dst += cnt; left -= static_cast<int64_t>(cnt); k++;
+          }
+          u = v;
+        }
+        if (up.rc == KAMD_OK) {
+          const hipError_t e = hipEventRecord(b->ev_up[p], b->s_up);
+          if (e != hipSuccess) fail(e);
+        }
+        {
+          std::lock_guard<std::mutex> lk(up.mu);
+          up.issued = p + 1;
+        }
+        up.cv.notify_all();
+      }
+      if (up.rc == KAMD_OK) {
+        const hipError_t e = hipStreamSynchronize(b->s_up);
+        if (e != hipSuccess) fail(e);
+      }
+      std::lock_guard<std::mutex> lk(up.mu);
+      up.issued = np;
+      up.done_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      up.cv.notify_all();
+    });
+  }
+  // whatever happens below, the uploader is joined before this function returns (it reads the caller's buffer)
+  struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{uploader};
+  if (!b->from_features && !host_mode) rc = kamd_feat_compute_batch_device(b->feat, b->d_waves, b->wave_off.data(), n, b->d_feats, b->feat_off.data(), b->ld_feat, st);
   if (rc != KAMD_OK) return rc;
   KAMD_HIP(hipEventRecord(b->ev[1], st));
+  double upload_wait_ms = 0, first_pass_start_ms = 0;
   // ---- acoustic model, a few passes of <= nnet_pass_frames input frames
   double flops = 0;
   int passes = 0;
@@ -362,17 +522,39 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   bool split = b->dec_long && b->long_lanes > 0 && !b->have_iv && n >= 4 * b->long_lanes &&
                0.55 * static_cast<double>(longest) > 1.5 * static_cast<double>(b->out_off.back()) / std::max(lanes_main, 1);
   if (const char *e = getenv("KAMD_BATCH_SPLIT")) split = b->dec_long && b->long_lanes > 0 && !b->have_iv && n > b->long_lanes && atoi(e) != 0;
+  if (host_mode || b->d_ll_override) split = false;       // (the passes follow the upload; a planted matrix is in load order)
+  const float *ll_base = b->d_ll_override ? b->d_ll_override : b->d_ll;
   b->last_split = split;
   int n_main = n;
   std::vector<kamd_queue_task> tasks;
   if (!split) {
-    for (int u0 = 0; u0 < n;) {
+    int pass = 0;
+    for (int u0 = 0; u0 < n; pass++) {
       int u1 = u0 + 1;
-      while (u1 < n && b->feat_off[u1 + 1] - b->feat_off[u0] <= b->opts.nnet_pass_frames) u1++;
+      if (host_mode) {
+        u1 = b->pass_u0[pass + 1];
+        const auto tw = std::chrono::steady_clock::now();
+        {
+          std::unique_lock<std::mutex> lk(up.mu);
+          up.cv.wait(lk, [&] { return up.issued > pass || up.rc != KAMD_OK; });
+          if (up.rc != KAMD_OK) return kamd::SetError(up.rc, "%s", up.err.c_str());
+        }
+        upload_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+        KAMD_HIP(hipStreamWaitEvent(st, b->ev_up[pass], 0));
+        KAMD_HIP(hipEventRecord(b->ev_f0[pass], st));
+        rc = kamd::FeatLaunchPremeta(b->feat, b->d_waves, b->d_feat_meta + b->feat_meta_off[pass], u1 - u0, b->pass_frames[pass], b->d_feats,
+                                     b->ld_feat, st);
+        if (rc != KAMD_OK) return rc;
+        KAMD_HIP(hipEventRecord(b->ev_f1[pass], st));
+        if (pass == 0) first_pass_start_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      } else {
+        while (u1 < n && b->feat_off[u1 + 1] - b->feat_off[u0] <= b->opts.nnet_pass_frames) u1++;
+      }
       rc = kamd_nnet_forward_batch_device(b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat,
                                           b->have_iv ? b->d_iv + static_cast<size_t>(u0) * kamd_nnet_ivector_dim(b->nnet) : NULL, u1 - u0, b->d_ll,
                                           b->out_off.data() + u0, b->P, st);
       if (rc != KAMD_OK) return rc;
+      if (host_mode) KAMD_HIP(hipEventRecord(b->ev_n1[pass], st));
       flops += kamd_nnet_last_flops(b->nnet);
       passes++;
       u0 = u1;
@@ -387,7 +569,7 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
     });
     for (int k = 0; k < n; k++) {
       const int u = order[k];
-      tasks[k].d_loglikes = b->d_ll + static_cast<size_t>(b->out_off[u]) * b->P;
+      tasks[k].d_loglikes = ll_base + static_cast<size_t>(b->out_off[u]) * b->P;
       tasks[k].ld = b->P; tasks[k].n_frames = static_cast<int32_t>(b->out_off[u + 1] - b->out_off[u]);
       tasks[k].utt = u; tasks[k].reserved = 0;
     }
@@ -516,6 +698,18 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   memset(&s, 0, sizeof(s));
   (void)hipEventElapsedTime(&s.feat_ms, b->ev[0], b->ev[1]);
   (void)hipEventElapsedTime(&s.nnet_ms, b->ev[1], b->ev[2]);
+  if (host_mode) {
+    if (uploader.joinable()) uploader.join();
+    s.feat_ms = 0; s.nnet_ms = 0;
+    for (int p = 0; p < passes; p++) {
+      float f = 0, m = 0;
+      (void)hipEventElapsedTime(&f, b->ev_f0[p], b->ev_f1[p]);
+      (void)hipEventElapsedTime(&m, b->ev_f1[p], b->ev_n1[p]);
+      s.feat_ms += f; s.nnet_ms += m;
+    }
+    s.upload_ms = static_cast<float>(up.done_ms); s.first_pass_start_ms = static_cast<float>(first_pass_start_ms);
+    s.upload_wait_ms = static_cast<float>(upload_wait_ms); s.upload_passes = passes;
+  }
   s.decode_ms = qms; s.total_ms = static_cast<float>(total_ms);
   s.host_tail_ms = static_cast<float>(total_ms - t_last_done);
   s.first_result_ms = static_cast<float>(t_first_done);

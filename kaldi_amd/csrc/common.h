@@ -23,6 +23,12 @@ bool RequireDevice();
 int CopyRowBlocks(const float *src, int ld_src, float *dst, int ld_dst, const int64_t *d_src_row, const int64_t *d_dst_row,
                   const int *d_count, int n_items, int max_count, int cols, hipStream_t st);
 
+// feat.hip: the batch launch of kamd_feat_compute_batch_device in two halves, so that a caller can build and upload the
+// offsets of many launches once (no host synchronisation per launch).  meta = wave_off[n+1] | frame_off[n+1] | row_off[n+1].
+int FeatBuildMeta(kamd_feat *f, const int64_t *h_wave_off, int n_utts, const int64_t *h_row_off, int64_t *meta, int64_t *total_frames);
+int FeatLaunchPremeta(kamd_feat *f, const float *d_waves, const int64_t *d_meta, int n_utts, int64_t total_frames, float *d_out,
+                      int ld_out, hipStream_t st);
+
 #define KAMD_HIP(call)                                                              \
   do {                                                                              \
     hipError_t e_ = (call);                                                         \

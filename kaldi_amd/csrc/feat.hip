@@ -487,6 +487,37 @@ int kamd_feat_compute_batch_device(kamd_feat *h, const float *d_waves, const int
   return KAMD_OK;
 }
 
+}  // extern "C"
+namespace kamd {
+int FeatBuildMeta(kamd_feat *h, const int64_t *h_wave_off, int n_utts, const int64_t *h_row_off, int64_t *meta, int64_t *total_frames) {
+  int64_t tot = 0;
+  for (int u = 0; u < n_utts; u++) {
+    meta[u] = h_wave_off[u];
+    meta[(n_utts + 1) + u] = tot;
+    tot += kamd_feat_num_frames(h, h_wave_off[u + 1] - h_wave_off[u]);
+    meta[2 * (n_utts + 1) + u] = h_row_off[u];
+  }
+  meta[n_utts] = h_wave_off[n_utts];
+  meta[(n_utts + 1) + n_utts] = tot;
+  meta[2 * (n_utts + 1) + n_utts] = 0;
+  *total_frames = tot;
+  return KAMD_OK;
+}
+int FeatLaunchPremeta(kamd_feat *h, const float *d_waves, const int64_t *d_meta, int n_utts, int64_t total_frames, float *d_out,
+                      int ld_out, hipStream_t st) {
+  Feat *f = reinterpret_cast<Feat *>(h);
+  if (n_utts <= 0 || total_frames <= 0) return KAMD_OK;
+  if (ld_out < f->dev.num_out) return SetError(KAMD_ERR_ARG, "ld_out < feature dim");
+  const int blocks = CeilDiv(total_frames, 4);
+  const size_t lds = (4 * (2 * f->dev.N + 128) + f->dev.N) * sizeof(float);
+  hipLaunchKernelGGL(FeatKernel, dim3(blocks), dim3(256), lds, st, f->dev, d_waves, d_meta, d_meta + (n_utts + 1),
+                     d_meta + 2 * (n_utts + 1), n_utts, d_out, ld_out, 0, NULL);
+  KAMD_HIP(hipGetLastError());
+  return KAMD_OK;
+}
+}  // namespace kamd
+extern "C" {
+
 // Frames [first_frame[u], first_frame[u] + num_frames[u]) of n device-resident waveforms in
 // ONE launch (batched streaming: the frames that became computable on every stream).
 int kamd_feat_compute_ranges_device(kamd_feat *h, const float *d_waves, const int64_t *h_wave_start,

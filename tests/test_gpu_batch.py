@@ -294,3 +294,51 @@ def test_nnet3_latgen_faster_batch_tool(tmp_path):
     bad = subprocess.run([sys.executable, root + "/tools/nnet3_latgen_faster_batch.py", "--online-ivectors=ark:x", mdl_, fst_, "scp:a", "ark:b"],
                          capture_output=True, text=True)
     assert bad.returncode == 255 and "not supported" in bad.stderr
+
+
+def test_load_host_uploads_inside_run_and_changes_nothing():
+    """kamd_batch_decoder_load_host: the samples stay in host memory, every run() uploads them pass by pass behind the
+    features and the model of the passes before (small first pass).  Same log-likelihoods and lattices as load(), bit for
+    bit, also with an utterance that is too short for a frame in the middle of the buffer; the loglike override feeds the
+    search a planted matrix while the model still runs."""
+    g, model, cfg, waves = _setup(n=19, seed=11)
+    waves.insert(7, np.zeros(100, np.float32))                 # < one frame: skipped, fails alone
+    kw = dict(max_seconds=4.0, resident_lanes=4, host_threads=3, determinize=True, keep_raw_lattices=True, nnet_pass_frames=700,
+              search_mode=2)
+    ref = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, **kw)
+    ref.load(waves)
+    ref.run()
+    bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, first_pass_frames=150, **kw)
+    bd.load_host(waves)
+    for rep in range(2):
+        st = bd.run()
+        assert st.n_failed == 1 and st.upload_passes == st.nnet_passes > 2 and st.upload_ms > 0 and st.first_pass_start_ms > 0
+        assert st.feat_ms > 0 and st.nnet_ms > 0
+        for u in range(len(waves)):
+            if u == 7:
+                assert bd.output(u) is None and bd.record(u).n_frames == 0
+                continue
+            np.testing.assert_array_equal(bd.loglikes(u), ref.loglikes(u))
+            assert lattices_equal(bd.raw_lattice(u), ref.raw_lattice(u)), lattice_diff(bd.raw_lattice(u), ref.raw_lattice(u))
+            assert bd.output(u)["words"].tolist() == ref.output(u)["words"].tolist()
+    fr = bd.output_frames()
+    assert fr[7] == 0 and all(fr[u] == ref.loglikes(u).shape[0] for u in range(len(waves)))
+    # planted log-likelihoods: the search must see THEM (oracle on the planted matrix), the model's output is untouched
+    from kaldi_amd import decoder
+    P = g.num_pdfs
+    planted = [synth.random_loglikes(int(t), P, seed=50 + u, scale=2.0) for u, t in enumerate(fr) if t > 0]
+    dev = decoder.DeviceMatrix(np.concatenate(planted, axis=0))
+    bd.set_loglike_override(dev.ptr(0))
+    bd.run()
+    k = 0
+    for u in range(len(waves)):
+        if u == 7:
+            continue
+        o = orc.Decoder(g, cfg, 2)
+        o.Decode(planted[k])
+        k += 1
+        assert lattices_equal(bd.raw_lattice(u), o.GetRawLattice())
+        np.testing.assert_array_equal(bd.loglikes(u), ref.loglikes(u))
+    bd.set_loglike_override(None)
+    bd.run()
+    assert lattices_equal(bd.raw_lattice(3), ref.raw_lattice(3))
