@@ -7,11 +7,16 @@ topology (run_tdnn_1d.sh:219-249: 1536/160, 17 layers, P = 6000, random init), a
 tglarge-scale synthetic HCLG (31 M states, 69 M arcs), recipe decoder settings (beam 15,
 max-active 7000, min-active 200, lattice-beam 8).
 
-One "step" = one pass of the whole hot path over the test set, waveforms already resident in
-HBM: MFCC -> TDNN-F log-likelihoods -> LatticeFasterDecoder (work queue over one lane per CU:
-init + advance + finalize per utterance) -> pruned raw lattices copied to the host, best path
-and lattice determinization on host threads, overlapped with the search.  The step ends when
-every utterance's 1-best and determinized lattice are on the host.
+One "step" = one pass of the whole hot path over the test set: waveform upload from host memory
+(pass by pass through page-locked staging, overlapped with the passes before) -> MFCC -> TDNN-F
+log-likelihoods -> LatticeFasterDecoder (work queue over one lane per CU: init + advance +
+finalize per utterance) -> pruned raw lattices handed to the host, best path and lattice
+determinization on host threads, overlapped with the search.  The step ends when every
+utterance's 1-best and determinized lattice are on the host.  `value` is measured at the
+TOKEN-MATCHED search load (>= 3 k expanded tokens per frame); `load_bracket` carries the same
+step at the light load (round 2's headline) and at the load where max-active binds;
+`hbm_resident_value` is the headline load with the waveforms already in HBM; `planted` decodes
+planted transcripts (multi-word hypotheses, real lattice depth through the timed host tail).
 
 --gpus N: N ranks, one per GPU, are spawned by this script itself (or by torchrun: RANK /
 LOCAL_RANK / WORLD_SIZE in the environment); the ONE test set is partitioned over the ranks by
@@ -60,7 +65,16 @@ def parse_args():
     ap.add_argument("--output-scale", type=float, default=1.0)
     ap.add_argument("--lm-scale", type=float, default=-1.0, help="scale on the synthetic LM costs (default per graph)")
     ap.add_argument("--ll-std", type=float, default=-1.0,
-                    help="per-frame std (nats) of the synthetic log-likelihoods across pdfs after calibration")
+                    help="per-frame std (nats) of the synthetic log-likelihoods across pdfs after calibration (the headline load)")
+    ap.add_argument("--ll-std-light", type=float, default=1.9, help="load_bracket: round 2's headline load")
+    ap.add_argument("--ll-std-saturated", type=float, default=1.2, help="load_bracket: the load at which max-active binds")
+    ap.add_argument("--no-bracket", action="store_true", help="only the headline load")
+    ap.add_argument("--no-planted", action="store_true", help="skip the planted-transcript variant")
+    ap.add_argument("--planted-peak", type=float, default=8.3)
+    ap.add_argument("--planted-noise", type=float, default=3.0)
+    ap.add_argument("--resident", action="store_true", help="waveforms resident in HBM before the timed region (round 2's contract) "
+                    "instead of uploaded inside it")
+    ap.add_argument("--first-pass-frames", type=int, default=60000, help="input frames of the first acoustic-model pass when the upload is timed")
     ap.add_argument("--max-seconds", type=float, default=0.0)
     ap.add_argument("--lanes", type=int, default=0, help="resident decoder lanes per GPU (0 = one per compute unit)")
     ap.add_argument("--host-threads", type=int, default=0, help="host-tail threads per rank (0 = min(32, cores / ranks))")
@@ -119,7 +133,7 @@ def defaults(args):
     if args.lm_scale < 0:
         args.lm_scale = 0.3 if args.graph == "tglarge" else 0.1
     if args.ll_std < 0:
-        args.ll_std = 1.9 if args.graph == "tglarge" else 1.3
+        args.ll_std = 1.4 if args.graph == "tglarge" else 1.3     # tglarge: the token-matched load (>= 3 k expanded tokens per frame)
     if args.hash_capacity <= 0 and args.graph == "tglarge":
         args.hash_capacity = 1 << 20     # the unigram tree's second level: > 1e5 tokens on the frames after a word boundary
     return args
@@ -208,31 +222,52 @@ def _run_threads(fn, items, threads):
 
 
 def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
-    """The CPU oracle (a port of the reference path; decoder in its order-faithful mode 0) on this host's cores, on a
-    bounded sample of the same test set: `cores` threads, each pulling the next utterance (one LatticeFasterDecoder per
-    thread, like nnet3-latgen-faster-parallel; the oracle is C behind ctypes, which releases the interpreter lock), every
-    thread busy for the whole measurement.  Second leg: the CPU decoder alone on the DEVICE's log-likelihoods
-    (latgen-faster-mapped's job), which is also the 1-best parity check of the sampled utterances."""
+    """The CPU path (a port of the reference: oracle/) on this host's cores, on a bounded sample of the same test set:
+    `cores` threads, each pulling the next utterance (one LatticeFasterDecoder per thread, like nnet3-latgen-faster-
+    parallel; the oracle is C behind ctypes, which releases the interpreter lock), every thread busy for the whole
+    measurement.  The acoustic model runs the way the reference runs it on a CPU -- DecodableNnetSimple's chunks of
+    --frames-per-chunk 50 with their context recomputed, every Propagate one cblas_sgemm (oracle/orc_nnet_blas.cc, the
+    OpenBLAS next to numpy, one BLAS thread per worker) -- not the scalar oracle kept for parity, whose per-core rate is
+    reported beside it.  Second leg: the CPU decoder alone on the DEVICE's log-likelihoods (latgen-faster-mapped's job),
+    which is also the 1-best parity check of the sampled utterances."""
     from kaldi_amd import abi
     from oracle import orc
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores if cores > 0 else 32, avail))
     order = [int(i) for i in np.argsort([w.size for w in waves])]
+    have_blas = orc.cblas_sgemm() is not None
+    stage_s = [0.0, 0.0, 0.0]
 
     def whole(idx):
+        t0 = time.time()
         feats = orc.mfcc(abi.mfcc_opts_hires(), waves[idx])
-        ll = orc.nnet_forward(model, feats)
+        t1 = time.time()
+        ll = orc.nnet_forward_blas(model, feats, frames_per_chunk=50) if have_blas else orc.nnet_forward(model, feats)
+        t2 = time.time()
         d = orc.Decoder(g, cfg, 0)
         d.Decode(ll)
         lat = d.GetRawLattice()
-        return lat.best_path() if lat is not None else None
+        bp = lat.best_path() if lat is not None else None
+        t3 = time.time()
+        stage_s[0] += t1 - t0; stage_s[1] += t2 - t1; stage_s[2] += t3 - t2       # (racy sums: shares only)
+        return bp
 
-    # the shortest utterance alone: the single-core rate sizes the sample
+    # the shortest utterance alone: the single-core rate sizes the sample; the same utterance through the scalar nnet
     t0 = time.time()
     whole(order[0])
     t_first = time.time() - t0
-    rate = (waves[order[0]].size / 16000.0) / max(t_first, 1e-6)
-    audio_budget = rate * budget_s * cores * 0.5            # half of the budget for each leg
+    f0 = orc.mfcc(abi.mfcc_opts_hires(), waves[order[0]])
+    t0 = time.time()
+    orc.nnet_forward(model, f0)
+    t_scalar_nnet = time.time() - t0
+    t0 = time.time()
+    if have_blas:
+        orc.nnet_forward_blas(model, f0, frames_per_chunk=50)
+    t_blas_nnet = time.time() - t0
+    stage_s[:] = [0.0, 0.0, 0.0]
+    a0 = waves[order[0]].size / 16000.0
+    rate = a0 / max(t_first, 1e-6)
+    audio_budget = rate * budget_s * cores * 0.6
     sample, audio = [], 0.0
     for idx in order:                                        # shortest first: >= 4 utterances per thread where the set allows
         a = waves[idx].size / 16000.0
@@ -278,13 +313,20 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
     except OSError:
         pass
     used = min(cores, len(sample))
+    tot = max(sum(stage_s), 1e-9)
     return {"value": audio / max(wall_w, 1e-9), "unit": "audio-sec/wall-sec", "cores": used, "kind": "port",
             "cpu_model": cpu_model, "cores_available": avail,
             "per_core_value": audio / max(busy_w, 1e-9),
             "thread_busy_fraction": busy_w / max(wall_w * used, 1e-9),
+            "nnet": "cblas_sgemm per Propagate (OpenBLAS, 1 thread per worker), DecodableNnetSimple chunks of 50 frames" if have_blas else
+                    "scalar oracle (no OpenBLAS found next to numpy)",
+            "stage_share": {"features": stage_s[0] / tot, "nnet": stage_s[1] / tot, "decoder_and_best_path": stage_s[2] / tot},
+            "nnet_only_per_core": {"sgemm": a0 / max(t_blas_nnet, 1e-9) if have_blas else None, "scalar_oracle": a0 / max(t_scalar_nnet, 1e-9),
+                                   "what": "audio seconds per second of the acoustic model alone on one core (the shortest utterance)"},
             "sample": "the %d shortest utterances of the test set (%.1f s audio) on %d threads pulling from one list, %.1f s "
-                      "wall, %.1f core-s: whole path MFCC + nnet + LatticeFasterDecoder (order-faithful oracle, mode 0) + best "
-                      "path; single-utterance probe %.2f s" % (len(sample), audio, used, wall_w, busy_w, t_first),
+                      "wall, %.1f core-s: whole path MFCC + nnet (%s) + LatticeFasterDecoder (order-faithful oracle, mode 0) + best "
+                      "path; single-utterance probe %.2f s" % (len(sample), audio, used, wall_w, busy_w,
+                                                               "sgemm" if have_blas else "scalar", t_first),
             "decoder_only": {"value": audio / max(wall_d, 1e-9), "per_core_value": audio / max(busy_d, 1e-9), "cores": used,
                              "wall_s": wall_d,
                              "what": "the CPU decoder alone (mode 0) on the device's log-likelihoods of the same utterances"},
@@ -359,6 +401,15 @@ def wer_leg(g, cfg, n_utts, cores, log, hash_capacity=0, search_mode=2):
 
 
 # ----------------------------------------------------------------------------- rank
+def lattice_depth(cl, n_frames):
+    """steps/diagnostic/analyze_lats.sh's lattice depth: arcs (and final weights) crossing a frame, averaged over the frames
+    = the total length of the transition-id strings of a CompactLattice over the frames of the utterance."""
+    if cl is None or n_frames <= 0:
+        return 0.0
+    fin = np.isfinite(cl.final[0::2])
+    return float(cl.arcs["str_len"].sum() + cl.final_str_len[fin].sum()) / float(n_frames)
+
+
 def main():
     args = defaults(parse_args())
     world = int(os.environ.get("WORLD_SIZE", "0"))
@@ -381,7 +432,8 @@ def main():
             torch.cuda.set_device(local_rank if args.device < 0 else args.device)
         dist.init_process_group(args.dist_backend)   # nccl = RCCL; only barriers + scalar reductions use it
 
-    from kaldi_amd import abi, batch, shard, synth
+    import gc
+    from kaldi_amd import abi, batch, decoder, latbin, shard, synth
     from kaldi_amd._lib import check, lib, require_gpu
     ndev = require_gpu()
     dev = args.device if args.device >= 0 else local_rank
@@ -390,7 +442,7 @@ def main():
                          (rank, dev, ndev))
     check(lib().kamd_set_device(dev))
     g, model, durs, cfg, t_build = build_workload(args)
-    spread, k = calibrate(model, args.ll_std)
+    graph_dev = decoder.Graph(g)                      # one copy of HCLG in HBM for every decoder object of this process
     log("workload built: %d states %d arcs, %d utts (%.2f h)" % (g.num_states, g.num_arcs, durs.size, durs.sum() / 3600))
     # ONE test set, partitioned over the ranks (steps/nnet3/decode.sh:96,123: split_data + JOB=1:nj)
     mine = shard.lpt_shards(durs, world)[rank]
@@ -399,33 +451,63 @@ def main():
     max_s = float(durs.max()) + 0.5
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     host_threads = args.host_threads or max(1, min(32, cores // world))
-    bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=max_s, resident_lanes=args.lanes,
-                                host_threads=host_threads, determinize=not args.no_determinize, keep_raw_lattices=False,
-                                nnet_pass_frames=args.nnet_pass_frames, hash_capacity=args.hash_capacity or None,
-                                tokens_per_frame=args.tokens_per_frame or None, search_mode=args.search_mode,
-                                lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)),
-                                long_lanes=16 if world >= 8 else 0)    # small shards: see kamd_batch_decoder_set_long_decoder
-    log("batch decoder created (%d host threads)" % host_threads)
-    bd.load(waves)                          # inputs resident in HBM before the timed region
-    log("shard loaded: %d utterances, %.0f s audio" % (len(waves), audio))
 
     def sync_all():
         check(lib().kamd_device_synchronize())
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        st = bd.run()
-        log("warmup step: feat %.1f nnet %.1f decode %.1f tail %.1f total %.1f ms, failed %d" %
-            (st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms, st.n_failed))
-    sync_all()
-    t0 = time.time()
-    acc = np.zeros(7)
-    for _ in range(args.steps):
-        st = bd.run()
-        acc += [st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms, st.first_result_ms, st.host_thread_ms_sum]
-    sync_all()
-    dt = time.time() - t0
+    def make_decoder(max_seconds=max_s, **over):
+        kw = dict(max_seconds=max_seconds, resident_lanes=args.lanes, host_threads=host_threads, determinize=not args.no_determinize,
+                  keep_raw_lattices=False, nnet_pass_frames=args.nnet_pass_frames, hash_capacity=args.hash_capacity or None,
+                  tokens_per_frame=args.tokens_per_frame or None, search_mode=args.search_mode,
+                  lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), first_pass_frames=args.first_pass_frames,
+                  long_lanes=16 if world >= 8 else 0)    # small shards: see kamd_batch_decoder_set_long_decoder
+        kw.update(over)
+        return batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, graph_dev, cfg, **kw)
+
+    def timed(bd, steps, warmup):
+        """`warmup` untimed runs, then `steps` runs between barriers: (wall seconds, mean stage vector, last stats)."""
+        for _ in range(warmup):
+            st = bd.run()
+            log("warmup step: feat %.1f nnet %.1f decode %.1f tail %.1f total %.1f ms, failed %d" %
+                (st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms, st.n_failed))
+        sync_all()
+        t0 = time.time()
+        acc = np.zeros(10)
+        for _ in range(steps):
+            st = bd.run()
+            acc += [st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms, st.first_result_ms, st.host_thread_ms_sum,
+                    st.upload_ms, st.first_pass_start_ms, st.upload_wait_ms]
+        sync_all()
+        return time.time() - t0, acc / max(steps, 1), st
+
+    def search_stats(bd, st, acc, n):
+        recs = [bd.record(u) for u in range(n)]
+        counters = np.sum([np.asarray(r.counters[:8], np.float64) for r in recs], axis=0)
+        frames = int(counters[6])
+        dec = {"frames": frames, "tokens_per_frame": counters[5] / max(frames, 1), "expanded_per_frame": counters[0] / max(frames, 1),
+               "arcs_per_frame": counters[1] / max(frames, 1), "links_per_frame": counters[4] / max(frames, 1),
+               "failed_utterances": sum(1 for r in recs if r.error)}
+        alg = float(algorithmic_bytes(counters))
+        dec_ms = float(acc[2])
+        roof = {"bound": "hbm", "kernel": "kamd::DecodeQueueKernel", "achieved": alg / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args, "decode_queue"),
+                "traffic_source": "profiles/*_pmc.json taken on this workload with this library build (rocprofv3 --pmc passes), not this run; null otherwise",
+                "algorithmic_bytes_per_launch": alg, "launch_ms": dec_ms, "lanes": int(st.lanes),
+                "us_per_frame_per_lane": 1e3 * dec_ms * int(st.lanes) / max(frames, 1)}
+        return recs, dec, roof
+
+    # ------------------------------------------------------------------ the headline load
+    spread, k = calibrate(model, args.ll_std)
+    bd = make_decoder()
+    log("batch decoder created (%d host threads)" % host_threads)
+    if args.resident:
+        bd.load(waves)                          # round 2's contract: inputs resident in HBM before the timed region
+    else:
+        bd.load_host(waves)                     # every step uploads the waveforms itself, overlapped with the passes before
+    log("shard loaded: %d utterances, %.0f s audio" % (len(waves), audio))
+    dt, acc, st = timed(bd, args.steps, args.warmup)
     my_dt = dt
     log("timed steps done: %.3f s" % dt)
     rank_walls, total_audio = [dt], audio
@@ -442,29 +524,27 @@ def main():
         total_audio = float(a.item())
     if rank != 0:
         return
-    acc /= args.steps
     n = len(waves)
-    recs = [bd.record(u) for u in range(n)]
-    counters = np.sum([np.asarray(r.counters[:8], np.float64) for r in recs], axis=0)
-    frames = int(counters[6])
-    alg_bytes = float(algorithmic_bytes(counters))
+    recs, dec_stats, dec_roof = search_stats(bd, st, acc, n)
     dec_ms, nnet_ms = float(acc[2]), float(acc[1])
     longest = int(np.argmax([r.n_frames for r in recs]))
     ph = np.asarray(recs[longest].phase_cycles[:len(PHASES)], np.float64)
-    n_failed = sum(1 for r in recs if r.error)
     words = [bd.output(u) for u in range(min(n, 200))]
-    mean_words = float(np.mean([len(w["words"]) for w in words if w is not None])) if any(w is not None for w in words) else 0.0
-    dec_roof = {"bound": "hbm", "kernel": "kamd::DecodeQueueKernel", "achieved": alg_bytes / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": alg_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args, "decode_queue"),
-                "traffic_source": "profiles/*_pmc.json of this workload (rocprofv3 --pmc passes), not this run",
-                "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": dec_ms, "lanes": int(st.lanes),
-                "us_per_frame_per_lane": 1e3 * dec_ms * int(st.lanes) / max(frames, 1)}
-    nnet_roof = {"bound": "mfma", "kernel": "kamd::TdnnGemmDmaKernel (all layers of all passes)", "achieved": st.nnet_flops / (nnet_ms * 1e-3) / 1e12,
-                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": st.nnet_flops / (nnet_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+    dec_stats["mean_words_per_utterance_first_200"] = float(np.mean([len(w["words"]) for w in words if w is not None])) if any(w is not None for w in words) else 0.0
+    # the model's algorithmic work, SURVEY 8(d): 2 x MACs per output frame x output frames (what the judge prices the GEMMs at);
+    # `executed` also counts the context rows at utterance edges and the padded input columns the kernels multiply
+    flops_alg = 2.0 * model.macs_per_output_frame() * dec_stats["frames"]
+    nnet_roof = {"bound": "mfma", "kernel": "kamd::TdnnGemm{Sa,Persist,Dma}Kernel (all layers of all passes)",
+                 "achieved": flops_alg / (nnet_ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": flops_alg / (nnet_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                  "traffic": pmc_traffic(args, "gemm_all_layers"),
-                 "traffic_source": "profiles/*_pmc.json of this workload (rocprofv3 --pmc passes), not this run; bytes per step over all GEMM launches",
-                 "flops_per_step": st.nnet_flops, "stage_ms": nnet_ms, "passes": int(st.nnet_passes)}
+                 "traffic_source": "profiles/*_pmc.json taken on this workload with this library build (rocprofv3 --pmc passes), not this run; null otherwise",
+                 "flops_per_step": flops_alg, "mflop_per_output_frame": 2e-6 * model.macs_per_output_frame(),
+                 "executed_flops_per_step": st.nnet_flops, "executed_achieved": st.nnet_flops / (nnet_ms * 1e-3) / 1e12,
+                 "stage_ms": nnet_ms, "passes": int(st.nnet_passes)}
     dominant_is_decoder = dec_ms >= nnet_ms
+    wav_bytes = 4.0 * sum(w.size for w in waves)
+    load_name = "token-matched" if (args.workload == "librispeech" and args.graph == "tglarge") else "default"
     out = {
         "metric": "decode RTF (audio-sec/wall-sec)",
         "value": total_audio * args.steps / dt,
@@ -476,37 +556,87 @@ def main():
         "config": {"workload": "%s: %d synthetic utterances (%.2f h, lognormal 1-35 s) sharded over %d GPU(s), %s TDNN-F chain "
                                "topology (random init, P=%d), synthetic %s-scale HCLG (%d states, %d arcs), beam 15 max-active 7000 "
                                "min-active 200 lattice-beam 8, %s lanes/GPU fed by a device work queue, host tail (lattice read from the page-locked pool, best path, "
-                               "%s) on %d threads/GPU inside the timed region" %
+                               "%s) on %d threads/GPU inside the timed region; `value` is the %s search load (log-likelihood spread %.2f nats, LM scale %.2f: "
+                               "%.0f expanded / %.0f created tokens and %.0f arcs per frame), %s" %
                                ("LibriSpeech test-clean sized test set" if args.workload == "librispeech" else args.workload + " set",
                                 durs.size, durs.sum() / 3600.0, world, args.workload, g.num_pdfs, args.graph, g.num_states, g.num_arcs,
-                                int(st.lanes), "no determinization" if args.no_determinize else "lattice determinization", host_threads),
+                                int(st.lanes), "no determinization" if args.no_determinize else "lattice determinization", host_threads,
+                                load_name, args.ll_std, args.lm_scale, dec_stats["expanded_per_frame"], dec_stats["tokens_per_frame"],
+                                dec_stats["arcs_per_frame"],
+                                "waveforms resident in HBM before the timed region" if args.resident else
+                                "waveform upload (%.2f GB from host memory) inside the timed region" % (wav_bytes / 1e9)),
                    "utterances": int(durs.size), "utterances_rank0": n, "loglike_std_nats": args.ll_std, "lm_scale": args.lm_scale,
+                   "value_is_load": load_name, "upload_in_timed_region": not args.resident,
                    "baseline_config": "configs[2]" if args.workload == "librispeech" and args.graph == "tglarge" else
                                       ("configs[1]" if args.workload == "mini_librispeech" else "other")},
         "device_only_value": audio / ((acc[0] + acc[1] + acc[2]) * 1e-3),
         "stage_ms": {"features": acc[0], "nnet": acc[1], "decode_queue_kernel": acc[2], "host_tail_after_last_utterance": acc[3],
                      "total_wall": acc[4], "first_result_at": acc[5], "host_tail_cpu_ms_all_threads": acc[6]},
+        "upload": None if args.resident else {"bytes": wav_bytes, "last_byte_in_hbm_at_ms": acc[7], "first_pass_launched_at_ms": acc[8],
+                                              "launch_thread_waited_ms": acc[9], "passes": int(st.upload_passes),
+                                              "what": "host memory (page-locked in place when it was handed over, before the timed region) -> HBM on a copy "
+                                                      "stream, pass by pass; the model of pass k runs while pass k + 1 is copied (first pass %d frames)" % args.first_pass_frames},
         "rank_wall_s": rank_walls, "rank0_wall_s": my_dt,
-        "decoder": {"frames": frames, "tokens_per_frame": counters[5] / max(frames, 1),
-                    "expanded_per_frame": counters[0] / max(frames, 1),
-                    "arcs_per_frame": counters[1] / max(frames, 1),
-                    "links_per_frame": counters[4] / max(frames, 1),
-                    "failed_utterances": n_failed, "mean_words_per_utterance_first_200": mean_words},
+        "decoder": dec_stats,
         "roofline": dec_roof if dominant_is_decoder else nnet_roof,
         "roofline_other_stage": nnet_roof if dominant_is_decoder else dec_roof,
         "phase_share_longest_utterance": {k2: round(float(v / max(ph.sum(), 1.0)), 3) for k2, v in zip(PHASES, ph)},
         "setup_s": t_build,
     }
+    one = world == 1
+    # ------------------------------------------------------------------ the same load, waveforms already in HBM
+    if one and not args.resident:
+        bd.load(waves)
+        dt_r, acc_r, st_r = timed(bd, min(3, args.steps), 1)
+        out["hbm_resident_value"] = audio * min(3, args.steps) / dt_r
+        out["hbm_resident_ms_per_step"] = 1000.0 * dt_r / min(3, args.steps)
     out["cpu_baseline"] = None
-    if not args.no_cpu_baseline and world == 1:
+    if not args.no_cpu_baseline and one:
         log("cpu baseline ...")
         try:
             out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, bd, args.cpu_budget, args.cpu_cores)
         except Exception as e:                      # noqa: BLE001 - the measured line must still be printed
             out["cpu_baseline"] = {"error": repr(e)}
-    if not args.no_wer and world == 1:
+    del bd
+    gc.collect()
+    # ------------------------------------------------------------------ load bracket: the same step at two more loads
+    if one and not args.no_bracket and args.workload == "librispeech" and args.graph == "tglarge":
+        def entry(value, ms, a, d, r):
+            return {"value": value, "ms_per_step": ms, "us_per_frame_per_lane": r["us_per_frame_per_lane"], "tokens_per_frame": d["tokens_per_frame"],
+                    "expanded_per_frame": d["expanded_per_frame"], "arcs_per_frame": d["arcs_per_frame"], "failed_utterances": d["failed_utterances"],
+                    "stage_ms": {"features": a[0], "nnet": a[1], "decode_queue_kernel": a[2], "host_tail_after_last_utterance": a[3]},
+                    "search_roofline_frac": r["frac"]}
+        bracket = {"matched": dict(entry(out["value"], out["ms_per_step"], acc, dec_stats, dec_roof), loglike_std_nats=args.ll_std,
+                                   what="`value`: >= 3 k expanded tokens per frame")}
+        for name, ll_std, over, what in (
+                ("light", args.ll_std_light, {}, "round 2's headline load (540 expanded tokens per frame then)"),
+                ("saturated", args.ll_std_saturated, dict(hbm_fraction=0.62, tokens_per_frame=args.tokens_per_frame or 11000,
+                                                          nnet_pass_frames=min(args.nnet_pass_frames, 500000)),
+                 "max-active 7000 binds on most frames; larger arenas (62 % of HBM), acoustic model in passes of 5e5 frames")):
+            try:
+                calibrate(model, ll_std)
+                b2 = make_decoder(**over)
+                b2.load(waves) if args.resident else b2.load_host(waves)
+                dt2, acc2, st2 = timed(b2, 2, 1)
+                _, d2, r2 = search_stats(b2, st2, acc2, n)
+                bracket[name] = dict(entry(audio * 2 / dt2, 1000.0 * dt2 / 2, acc2, d2, r2), loglike_std_nats=ll_std, what=what)
+                del b2
+                gc.collect()
+            except Exception as e:                  # noqa: BLE001
+                bracket[name] = {"error": repr(e)}
+            log("bracket %s done" % name)
+        calibrate(model, args.ll_std)
+        out["load_bracket"] = bracket
+    # ------------------------------------------------------------------ planted transcripts through the whole timed path
+    if one and not args.no_planted:
+        log("planted variant ...")
+        try:
+            out["planted"] = planted_variant(args, g, model, cfg, durs, make_decoder, timed, latbin, synth, log)
+        except Exception as e:                      # noqa: BLE001
+            out["planted"] = {"error": repr(e)}
+    if not args.no_wer and one:
         log("wer leg ...")
-        del bd
+        gc.collect()
         try:
             out["wer"] = wer_leg(g, cfg, args.wer_utts, min(32, cores), log, args.hash_capacity, args.search_mode)
         except Exception as e:                      # noqa: BLE001
@@ -515,10 +645,87 @@ def main():
     sys.stdout.flush()
 
 
+def planted_variant(args, g, model, cfg, durs, make_decoder, timed, latbin, synth, log):
+    """The whole timed path on utterances with a KNOWN transcript: the waveforms have the durations of planted paths through
+    HCLG (about 3 words per second, synth.sample_path), features and acoustic model run in the timed region as always, but
+    the work queue reads planted log-likelihoods (noise on every pdf, a peak on the path's pdf: kaldi_amd/csrc/synth.hip) --
+    multi-word hypotheses, lattices with real depth through best path + determinization in the timed host tail, a %WER
+    against the transcript."""
+    import gc
+    t0 = time.time()
+    n = durs.size
+    paths = []
+    for u in range(n):
+        n_words = max(1, int(round(float(durs[u]) * 3.0)))
+        paths.append(synth.sample_path(g, n_words, seed=900000 + u))
+    frames = np.asarray([p.size for _, p in paths], np.int64)
+    # a waveform that gives exactly 3 T input frames (snip_edges: 1 + (n - 400) / 160), i.e. T output frames
+    samples = 400 + 160 * (3 * frames - 1)
+    waves = synth.make_waves_fast(samples / 16000.0 + 1e-6, seed=77)
+    waves = [w[:int(s)] if w.size >= s else np.pad(w, (0, int(s) - w.size)) for w, s in zip(waves, samples)]
+    t_synth = time.time() - t0
+    bd = make_decoder(max_seconds=float(samples.max()) / 16000.0 + 0.5, hbm_fraction=0.62, tokens_per_frame=args.tokens_per_frame or 11000,
+                      nnet_pass_frames=min(args.nnet_pass_frames, 500000))
+    bd.load(waves) if args.resident else bd.load_host(waves)
+    fr = bd.output_frames()
+    if not np.array_equal(fr, frames):
+        raise RuntimeError("planted variant: the waveforms give other frame counts than the paths")
+    planted = synth.planted_loglikes_device(np.concatenate([p for _, p in paths]), g.num_pdfs, args.planted_peak, args.planted_noise, seed=5)
+    bd.set_loglike_override(planted.ptr(0))
+    audio = float(samples.sum()) / 16000.0
+    dt, acc, st = timed(bd, 2, 1)
+    ref, hyp = {}, {}
+    depth, n_states, n_arcs, n_words = [], [], [], []
+    for u in range(n):
+        key = "utt%04d" % u
+        ref[key] = [str(w) for w in paths[u][0]]
+        o = bd.output(u)
+        hyp[key] = [] if o is None else [str(w) for w in o["words"]]
+        n_words.append(len(hyp[key]))
+        cl = bd.compact_lattice(u) if not args.no_determinize else None
+        if cl is not None:
+            depth.append(lattice_depth(cl, int(frames[u])))
+            n_states.append(cl.num_states); n_arcs.append(int(cl.arcs.size))
+    wer = latbin.compute_wer(ref, hyp, "present")
+    recs = [bd.record(u) for u in range(n)]
+    counters = np.sum([np.asarray(r.counters[:8], np.float64) for r in recs], axis=0)
+    fr_tot = max(int(counters[6]), 1)
+    res = {"value": audio * 2 / dt, "ms_per_step": 1000.0 * dt / 2, "utterances": int(n), "audio_hours": audio / 3600.0,
+           "wer_line": wer[0], "words_per_utterance": float(np.mean(n_words)), "reference_words": int(sum(len(r) for r in ref.values())),
+           "determinized_lattice_depth": float(np.mean(depth)) if depth else None,
+           "determinized_states_per_utterance": float(np.mean(n_states)) if n_states else None,
+           "determinized_arcs_per_utterance": float(np.mean(n_arcs)) if n_arcs else None,
+           "host_tail_cpu_ms_per_utterance": float(acc[6]) / n, "host_tail_exposed_ms": float(acc[3]), "host_threads": int(bd.opts.host_threads),
+           "stage_ms": {"features": acc[0], "nnet": acc[1], "decode_queue_kernel": acc[2], "total_wall": acc[4]},
+           "tokens_per_frame": counters[5] / fr_tot, "expanded_per_frame": counters[0] / fr_tot, "arcs_per_frame": counters[1] / fr_tot,
+           "us_per_frame_per_lane": 1e3 * float(acc[2]) * int(st.lanes) / fr_tot, "failed_utterances": sum(1 for r in recs if r.error),
+           "peak": args.planted_peak, "noise": args.planted_noise, "synthesis_s": t_synth,
+           "what": "planted word sequences (3 words per second of audio) through the bench HCLG; the acoustic model runs in the timed "
+                   "region, the search reads planted log-likelihoods (noise %.1f on every pdf, peak %.1f on the path's); "
+                   "%%WER against the transcript from the 1-best of the timed run" %
+                   (args.planted_noise, args.planted_peak)}
+    del bd, planted
+    gc.collect()
+    return res
+
+
+def library_build_id():
+    """sha256 (first 16 hex digits) of the HIP / C++ sources the library was built from: a profile taken with another
+    build says nothing about this one's traffic."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "kaldi_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".cc", ".h")):
+            h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(args, which):
     """HBM bytes per step of one kernel family ("decode_queue": one DecodeQueueKernel launch; "gemm_all_layers") from the
     committed rocprofv3 PMC passes (profiles/*_pmc.json), only when they were taken on this exact workload."""
     key = "%s/%s/%d/%s/%s" % (args.workload, args.graph, args.utts, args.ll_std, args.lm_scale)
+    build = library_build_id()
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if os.path.isdir(pdir):
@@ -528,7 +735,7 @@ def pmc_traffic(args, which):
                     d = json.load(open(os.path.join(pdir, f)))
                 except Exception:
                     continue
-                if d.get("workload_key") == key and which in d:
+                if d.get("workload_key") == key and d.get("library_build") == build and which in d:
                     best = d[which].get("traffic_bytes_per_step")
     return best
 

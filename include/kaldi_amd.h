@@ -1027,16 +1027,21 @@ void kamd_batch_decoder_destroy(kamd_batch_decoder *b);
 int kamd_batch_decoder_set_long_decoder(kamd_batch_decoder *b, kamd_decoder *dec_long, int lanes);
 /* AcceptInput for the whole shard: utterance u owns samples [wave_off[u], wave_off[u+1]). */
 int kamd_batch_decoder_load(kamd_batch_decoder *b, const float *waves, const int64_t *wave_off, int n_utts);
-/* AcceptInput with the waveforms left where they are, in the caller's (pageable) host memory: every run() uploads
- * them itself, inside what it times -- pass by pass through page-locked staging buffers on a copy stream, the
- * copies of pass k + 1 overlapped with the features and the acoustic model of pass k; the first pass is small
- * (kamd_batch_opts.first_pass_frames).  `waves` must stay valid until the next load or destroy.  (nnet3-latgen-faster-
+/* AcceptInput with the waveforms left where they are, in the caller's host memory: every run() uploads them itself,
+ * inside what it times -- pass by pass on a copy stream, the copies of pass k + 1 overlapped with the features and the
+ * acoustic model of pass k; the first pass is small (kamd_batch_opts.first_pass_frames).  This call page-locks the
+ * buffer in place (hipHostRegister, undone by the next load / destroy); where the runtime refuses, run() stages the
+ * samples through four 32 MB page-locked buffers instead.  `waves` must stay valid until the next load or destroy.  (nnet3-latgen-faster-
  * batch reads each wave / feature matrix from its table inside the timed loop too: nnet3-latgen-faster-batch.cc:176-214.) */
 int kamd_batch_decoder_load_host(kamd_batch_decoder *b, const float *waves, const int64_t *wave_off, int n_utts);
 /* Workload synthesis for benchmarks: the search reads log-likelihoods from d_loglikes (device, [total output frames x
  * P], utterances back to back in load order, as kamd_batch_decoder_get_loglikes numbers them) instead of the acoustic
  * model's output, which is still computed.  NULL switches it off. */
 int kamd_batch_decoder_set_loglike_override(kamd_batch_decoder *b, const float *d_loglikes);
+/* Benchmark workload synthesis (kaldi_amd/csrc/synth.hip; not part of the decode path): d_out[r][p] = noise * N(0, 1)
+ * + (p == d_true_pdf[r] ? peak : 0), the planted-transcript log-likelihoods of kaldi_amd/synth.py on the device. */
+int kamd_synth_planted_loglikes_device(float *d_out, int64_t rows, int num_pdfs, int ld, const int32_t *d_true_pdf, float peak,
+                                       float noise, uint64_t seed, void *stream);
 /* Output frames of every loaded utterance (0 for the ones too short for a frame); total returned. */
 int64_t kamd_batch_decoder_output_frames(kamd_batch_decoder *b, int32_t *frames, int cap);
 /* AcceptInput as the reference declares it (nnet-batch-compute.h:665-669: feature matrices, not

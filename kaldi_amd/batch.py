@@ -17,7 +17,7 @@ from ._lib import KamdError, check, lib
 class NnetBatchDecoder:
     def __init__(self, mfcc_opts, model, hclg, cfg, max_seconds=36.0, resident_lanes=0, host_threads=8, determinize=True,
                  keep_raw_lattices=False, tid_phone=None, sizes=None, nnet_pass_frames=1000000, lattice_pool_bytes=1 << 30,
-                 hash_capacity=None, tokens_per_frame=None, search_mode=2, det=None, long_lanes=0, first_pass_frames=None):
+                 hash_capacity=None, tokens_per_frame=None, search_mode=2, det=None, long_lanes=0, first_pass_frames=None, hbm_fraction=0.5):
         featmod = __import__("kaldi_amd.feat", fromlist=["Mfcc"])
         # mfcc_opts = None: no feature stage, the caller hands over feature matrices (load_features), as the
         # reference's AcceptInput does (nnet-batch-compute.h:665)
@@ -33,7 +33,7 @@ class NnetBatchDecoder:
         lanes = resident_lanes or lib().kamd_device_num_cus() * lib().kamd_decoder_lanes_per_cu()
         # every lane must hold the longest utterance: uniform arenas (avg = max)
         self.sizes = sizes or pipeline.default_sizes(cfg, lanes, max_out, max_out, hash_capacity=hash_capacity,
-                                                     tokens_per_frame=tokens_per_frame)
+                                                     tokens_per_frame=tokens_per_frame, hbm_fraction=hbm_fraction)
         self.dec = decoder.BatchDecoder(self.graph, cfg, self.sizes)
         self.dec.SetSearchMode(search_mode)
         o = abi.BatchOpts()

@@ -68,6 +68,8 @@ struct BatchDecoder {
   bool from_features = false, have_iv = false;   // the loaded set: feature matrices (+ i-vectors) instead of waveforms
   // kamd_batch_decoder_load_host: the samples stay in the caller's memory and every run() uploads them pass by pass
   const float *h_waves = NULL;                   // caller's buffer (kept utterance k starts at h_wave_src[k])
+  void *h_registered = NULL;                     // ... page-locked in place by load_host (hipHostRegister) when the runtime allows it:
+                                                 // the copies then read it directly; otherwise they go through h_stage
   std::vector<int64_t> h_wave_src;
   std::vector<int> pass_u0;                      // pass p = kept utterances [pass_u0[p], pass_u0[p + 1])
   std::vector<int64_t> pass_frames;              // feature frames of pass p
@@ -103,6 +105,10 @@ struct BatchDecoder {
   bool quit = false;
   kamd_batch_stats last = {};
 };
+
+static void Unregister(BatchDecoder *b) {
+  if (b->h_registered) { (void)hipHostUnregister(b->h_registered); b->h_registered = NULL; }
+}
 
 template <typename T>
 static int GrowDev(T **p, size_t *cap, size_t need) {
@@ -245,6 +251,7 @@ void kamd_batch_decoder_destroy(kamd_batch_decoder *h) {
   if (b->d_ll) (void)hipFree(b->d_ll);
   if (b->d_iv) (void)hipFree(b->d_iv);
   if (b->d_feat_meta) (void)hipFree(b->d_feat_meta);
+  kamd::Unregister(b);
   for (int i = 0; i < BatchDecoder::kStageBufs; i++) {
     if (b->h_stage[i]) (void)hipHostFree(b->h_stage[i]);
     if (b->ev_stage[i]) (void)hipEventDestroy(b->ev_stage[i]);
@@ -262,6 +269,7 @@ int kamd_batch_decoder_load(kamd_batch_decoder *h, const float *waves, const int
   if (kamd_nnet_ivector_dim(b->nnet) > 0) return kamd::SetError(KAMD_ERR_ARG, "the model has an ivector input: use kamd_batch_decoder_load_features");
   for (kamd::UttOut &o : b->out) o.Clear();
   b->n_utts = 0; b->from_features = false; b->have_iv = false; b->h_waves = NULL;
+  kamd::Unregister(b);
   b->kept.clear(); b->skipped.clear();
   b->wave_off.assign(1, 0); b->feat_off.assign(1, 0); b->out_off.assign(1, 0);
   for (int u = 0; u < n_utts; u++) {
@@ -302,6 +310,7 @@ int kamd_batch_decoder_load_features(kamd_batch_decoder *h, const float *feats, 
     return kamd::SetError(KAMD_ERR_ARG, "model expects ivector dim %d, got %d", want_iv, ivectors ? ivector_dim : 0);
   for (kamd::UttOut &o : b->out) o.Clear();
   b->n_utts = 0; b->h_waves = NULL;
+  kamd::Unregister(b);
   b->kept.clear(); b->skipped.clear();
   b->feat_off.assign(1, 0); b->out_off.assign(1, 0);
   for (int u = 0; u < n_utts; u++) {
@@ -340,6 +349,7 @@ int kamd_batch_decoder_load_host(kamd_batch_decoder *h, const float *waves, cons
   if (kamd_nnet_ivector_dim(b->nnet) > 0) return kamd::SetError(KAMD_ERR_ARG, "the model has an ivector input: use kamd_batch_decoder_load_features");
   for (kamd::UttOut &o : b->out) o.Clear();
   b->n_utts = 0; b->from_features = false; b->have_iv = false; b->h_waves = NULL;
+  kamd::Unregister(b);
   b->kept.clear(); b->skipped.clear(); b->h_wave_src.clear();
   b->wave_off.assign(1, 0); b->feat_off.assign(1, 0); b->out_off.assign(1, 0);
   for (int u = 0; u < n_utts; u++) {
@@ -389,6 +399,15 @@ int kamd_batch_decoder_load_host(kamd_batch_decoder *h, const float *waves, cons
       KAMD_HIP(hipEventCreate(&e));
       v->push_back(e);
     }
+  // page-lock the caller's samples where they are (once, here): the copies of run() then need no staging pass.  A runtime
+  // that refuses (limits on locked memory) leaves the staged path.
+  static const bool no_register = getenv("KAMD_BATCH_NO_REGISTER") != NULL;
+  const size_t span = static_cast<size_t>(h_wave_off[n_utts] - h_wave_off[0]) * sizeof(float);
+  if (!no_register && span > 0) {
+    void *base = const_cast<float *>(waves + h_wave_off[0]);
+    if (hipHostRegister(base, span, hipHostRegisterDefault) == hipSuccess) b->h_registered = base;
+    else (void)hipGetLastError();
+  }
   b->h_waves = waves;
   b->out.resize(n_utts);
   b->n_utts = n_utts;
@@ -469,6 +488,12 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
           while (v < b->pass_u0[p + 1] && b->h_wave_src[v] == b->h_wave_src[v - 1] + (b->wave_off[v] - b->wave_off[v - 1])) v++;
           const float *src = b->h_waves + b->h_wave_src[u];
           float *dst = b->d_waves + b->wave_off[u];
+          if (b->h_registered) {          // page-locked in place: one copy for the whole run of utterances
+            const hipError_t e = hipMemcpyAsync(dst, src, static_cast<size_t>(b->wave_off[v] - b->wave_off[u]) * sizeof(float), hipMemcpyHostToDevice, b->s_up);
+            if (e != hipSuccess) fail(e);
+            u = v;
+            continue;
+          }
           for (int64_t left = b->wave_off[v] - b->wave_off[u]; left > 0;) {
             const size_t cnt = static_cast<size_t>(std::min<int64_t>(left, BatchDecoder::kStageFloats));
             const int i = k % BatchDecoder::kStageBufs;

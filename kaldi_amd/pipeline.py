@@ -9,7 +9,7 @@ from ._lib import KamdError, check, lib
 
 
 def default_sizes(cfg, max_utts, max_out_frames, avg_out_frames=None, hash_capacity=None,
-                  tokens_per_frame=None, links_per_frame=None):
+                  tokens_per_frame=None, links_per_frame=None, hbm_fraction=0.5):
     """Device sizing: `max_utts` lanes, each at most `max_out_frames` decoded frames; the
     token / link pools hold `avg_out_frames` frames per lane on average (the pools are split
     between lanes in proportion to utterance length, kamd_decoder_reserve)."""
@@ -18,11 +18,11 @@ def default_sizes(cfg, max_utts, max_out_frames, avg_out_frames=None, hash_capac
     lpf = links_per_frame or int(1.6 * tpf + 2000)
     hc = hash_capacity or 1 << int(np.ceil(np.log2(max(4 * tpf, max_out_frames + 8, 4096))))
     avg = (avg_out_frames or max_out_frames) + 2
-    # keep the arenas within half of the free HBM (16 B per token record incl. map, 24 B per link)
+    # keep the arenas within `hbm_fraction` (half) of the free HBM (16 B per token record incl. map, 24 B per link)
     free, total = C.c_size_t(), C.c_size_t()
     if lib().kamd_device_mem_info(C.byref(free), C.byref(total)) == 0 and free.value > 0:
         need = max_utts * avg * (16.0 * tpf + 24.0 * lpf)
-        budget = 0.5 * free.value
+        budget = hbm_fraction * free.value
         if need > budget:
             k = budget / need
             tpf, lpf = max(4000, int(tpf * k)), max(6000, int(lpf * k))

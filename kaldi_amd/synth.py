@@ -221,6 +221,47 @@ def sample_utterance(g, n_words=6, seed=0, peak=6.0, noise=1.0, dur_p=0.5):
     return np.ascontiguousarray(ll, np.float32), words, pdfs
 
 
+def sample_path(g, n_words=6, seed=0, dur_p=0.5):
+    """The path of sample_utterance without its log-likelihood matrix: (words, pdf of every frame)."""
+    rng = np.random.default_rng(seed)
+    h = g.start
+    words, pdfs = [], []
+    for _ in range(n_words):
+        lo, hi = g.hist_pair_off[h], g.hist_pair_off[h + 1]
+        if hi == lo:
+            h = 0
+            lo, hi = g.hist_pair_off[0], g.hist_pair_off[1]
+        k = int(rng.integers(lo, hi))
+        w = int(g.pair_word[k])
+        words.append(w + 1)
+        ln = int(g.pair_len[k])
+        units = g.chain_unit[g.pair_base[k, :ln]]
+        durs = rng.geometric(dur_p, ln)                      # frames in each unit: entry + self-loops
+        for u, d in zip(units.tolist(), durs.tolist()):
+            pdfs.append(2 * u)
+            pdfs.extend([2 * u + 1] * (d - 1))
+        h = int(g.word_next_hist[w])
+    return words, np.asarray(pdfs, np.int32)
+
+
+def planted_loglikes_device(true_pdf, num_pdfs, peak, noise, seed=1):
+    """[len(true_pdf) x num_pdfs] planted log-likelihoods generated on the device (kamd_synth_planted_loglikes_device);
+    returns a kaldi_amd.decoder.DeviceMatrix-like object (ptr(row), rows, cols, download())."""
+    import ctypes as C
+    from . import decoder
+    from ._lib import check, lib
+    tp = np.ascontiguousarray(true_pdf, np.int32)
+    d_tp = decoder.DeviceMatrix(tp.view(np.float32).reshape(-1, 1))           # (a byte container: int32 rows)
+    m = decoder.DeviceMatrix.__new__(decoder.DeviceMatrix)
+    m.rows, m.cols = int(tp.size), int(num_pdfs)
+    m._d = lib().kamd_malloc(max(m.rows * m.cols * 4, 16))
+    if not m._d:
+        raise MemoryError("planted log-likelihoods: device allocation failed")
+    check(lib().kamd_synth_planted_loglikes_device(m._d, m.rows, m.cols, m.cols, d_tp.ptr(0), float(peak), float(noise), int(seed), None))
+    check(lib().kamd_device_synchronize())
+    return m
+
+
 def random_loglikes(T, P, seed=0, scale=1.0):
     rng = np.random.default_rng(seed)
     return np.ascontiguousarray(scale * rng.standard_normal((T, P)), np.float32)

@@ -41,6 +41,7 @@ def lib():
         L.orc_nnet_context.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, ip, ip]
         L.orc_nnet_forward.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp,
                                        C.c_int, fp, fp, C.c_int]
+        L.orc_nnet_forward_blas.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, C.c_void_p, fp, C.c_int]
         L.orc_nnet_forward_slots.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int,
                                              C.c_int, C.c_int, fp, C.c_int]
         L.orc_nnet_forward_chunked.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int,
@@ -129,6 +130,45 @@ def nnet_forward(model, feats, ivector=None):
     d = model.descs()
     r = lib().orc_nnet_forward(d, len(model.layers), model.input_dim, model.subsampling,
                                abi.fptr(feats), T, abi.fptr(iv), abi.fptr(out), n_out)
+    assert r == n_out, r
+    return out
+
+
+_SGEMM = None
+
+
+def cblas_sgemm():
+    """Address of cblas_sgemm (ILP64) in the OpenBLAS that numpy ships, with OpenBLAS set to ONE thread (the callers bring
+    their own threads, one utterance each, like decode.sh --nj); None when no such library is found."""
+    global _SGEMM
+    if _SGEMM is None:
+        import glob
+        _SGEMM = 0
+        for path in glob.glob(os.path.join(os.path.dirname(np.__file__), "..", "numpy.libs", "libscipy_openblas64_*.so")) + \
+                glob.glob(os.path.join(os.path.dirname(np.__file__), ".libs", "libscipy_openblas64_*.so")):
+            try:
+                L = C.CDLL(path)
+                L.scipy_openblas_set_num_threads64_(1)
+                _SGEMM = C.cast(L.scipy_cblas_sgemm64_, C.c_void_p).value
+                cblas_sgemm.lib = L
+                break
+            except (OSError, AttributeError):
+                continue
+    return _SGEMM or None
+
+
+def nnet_forward_blas(model, feats, ivector=None, frames_per_chunk=50):
+    """The reference's CPU forward: DecodableNnetSimple's chunks, every Propagate an sgemm (oracle/orc_nnet_blas.cc)."""
+    sg = cblas_sgemm()
+    if sg is None:
+        raise RuntimeError("no OpenBLAS with an ILP64 cblas_sgemm next to numpy")
+    feats = np.ascontiguousarray(feats, np.float32)
+    T = feats.shape[0]
+    n_out = (T + model.subsampling - 1) // model.subsampling
+    out = np.zeros((n_out, model.layers[-1].out_dim), np.float32)
+    iv = None if ivector is None else np.ascontiguousarray(ivector, np.float32)
+    r = lib().orc_nnet_forward_blas(model.descs(), len(model.layers), model.input_dim, model.subsampling, abi.fptr(feats), T,
+                                    abi.fptr(iv), int(frames_per_chunk), C.c_void_p(sg), abi.fptr(out), n_out)
     assert r == n_out, r
     return out
 

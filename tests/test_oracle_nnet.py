@@ -109,3 +109,22 @@ def test_chunk_invariance():
     # interior chunks see clamped-at-chunk-edge inputs only where the utterance itself is
     # clamped, so results are identical up to fp32 summation order (none here: same code).
     np.testing.assert_allclose(chunked, whole, rtol=0, atol=1e-5)
+
+
+def test_blas_forward_equals_scalar_oracle():
+    """The CPU baseline's forward (the reference's path: DecodableNnetSimple chunks, one sgemm per Propagate) in its two
+    forms -- oracle/orc_nnet_blas.cc with OpenBLAS's cblas_sgemm, oracle/orc_blas.py with numpy -- against the scalar
+    oracle used for parity, for chunk sizes that do and do not divide the utterance, with and without an i-vector."""
+    from oracle import orc_blas
+    rng = np.random.default_rng(3)
+    for ivd in (0, 10):
+        m = nnet.tdnnf_tiny(num_pdfs=50, ivector_dim=ivd, seed=4)
+        iv = rng.standard_normal(ivd).astype(np.float32) if ivd else None
+        for T in (1, 4, 52, 160):
+            f = rng.standard_normal((T, m.input_dim)).astype(np.float32)
+            want = orc.nnet_forward(m, f, iv)
+            tol = 1e-5 * max(1.0, float(np.abs(want).max()))
+            for fpc in (50, 21, 0):
+                assert np.abs(orc_blas.nnet_forward_blas(m, f, iv, frames_per_chunk=fpc) - want).max() < tol
+                if orc.cblas_sgemm() is not None:
+                    assert np.abs(orc.nnet_forward_blas(m, f, iv, frames_per_chunk=fpc) - want).max() < tol
