@@ -334,70 +334,66 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
             "one_best_vs_cpu_decoder_same_loglikes": {"errors": errs_d, "ref_words": ref_d, "utterances_with_other_cost": cost_diff}}
 
 
-def wer_leg(g, cfg, n_utts, cores, log, hash_capacity=0, search_mode=2):
+def wer_leg(g, cfg, n_utts, cores, log, hash_capacity=0, search_mode=2, second_scale=True):
     """BASELINE's WER clause on synthetic data with a KNOWN transcript: utterances planted in the bench graph
     (synth.sample_utterance: a random word sequence through HCLG, log-likelihoods peaked on the true pdfs at a noise level
     that leaves real errors), decoded by the device (work queue) and by the CPU oracle in its order-faithful mode 0; both
-    lattice sets go through determinization and a best path, and are scored against the transcript."""
-    from kaldi_amd import decoder, io as kio, latbin, pipeline, synth
-    from oracle import orc
-    utts = []
-    for i in range(n_utts):
-        ll, words, _ = synth.sample_utterance(g, n_words=6 + i % 7, seed=7000 + i, peak=3.5, noise=1.5)
-        utts.append((ll, words))
-    T = max(ll.shape[0] for ll, _ in utts)
-    sz = pipeline.default_sizes(cfg, min(n_utts, 64), T + 2, T + 2, hash_capacity=hash_capacity or None, tokens_per_frame=80000)   # flat planted scores: a saturated search
-    bd = decoder.BatchDecoder(decoder.Graph(g), cfg, sz)
-    bd.SetSearchMode(search_mode)
-    lats, recs, ms = bd.decode_queue([ll for ll, _ in utts], resident_lanes=min(n_utts, 64))
-    log("wer leg: device decode of %d planted utterances %.1f ms (search mode %d)" % (n_utts, ms, search_mode))
-    bd.SetSearchMode(3 - search_mode)
-    lats_other, _, ms_o = bd.decode_queue([ll for ll, _ in utts], resident_lanes=min(n_utts, 64))
-    log("wer leg: device decode in the other search mode %.1f ms" % ms_o)
-
-    def cpu(i):
-        o = orc.Decoder(g, cfg, 0)
-        o.Decode(utts[i][0])
-        return o.GetRawLattice()
-
-    cpu_lats, wall, _ = _run_threads(cpu, list(range(n_utts)), cores)
-    log("wer leg: cpu decode %.1f s" % wall)
-
-    def one_best(lat):
-        """determinize, then lattice-best-path's CompactLatticeShortestPath (kaldi_amd/latbin.py)"""
-        if lat is None:
-            return []
-        cl = kio.determinize_lattice(lat, cfg.lattice_beam)
-        L = latbin.Lat(cl.start)
-        for s_ in range(cl.num_states):
-            L.add_state()
-            if np.isfinite(cl.final[2 * s_]):
-                L.final[s_] = (cl.final[2 * s_], cl.final[2 * s_ + 1], cl.final_string(s_).tolist())
-        for k in range(cl.arcs.size):
-            a = cl.arcs[k]
-            L.arcs[int(a["src"])].append((int(a["dst"]), int(a["label"]), a["graph_cost"], a["acoustic_cost"], cl.arc_string(k).tolist()))
-        bp = latbin.best_path(L)
-        return [] if bp is None else list(bp[0])
-
+    lattice sets go through determinization, and are compared at the lattice level (oracle/lattice_parity.py): 1-best, 10
+    best word sequences, lattice-oracle WER, 1-best after rescoring with a second LM -- on the bench graph and, as a second
+    graph scale, on a tgsmall-sized one."""
+    from kaldi_amd import decoder, pipeline, synth
     from kaldi_amd.decoder import lattices_equal
-    ref, hyp_d, hyp_c, hyp_o = {}, {}, {}, {}
-    e_between = lat_diff = 0
-    for i, (ll, words) in enumerate(utts):
-        key = "utt%03d" % i
-        ref[key] = [str(w) for w in words]
-        hyp_d[key] = [str(w) for w in one_best(lats[i])]
-        hyp_o[key] = [str(w) for w in one_best(lats_other[i])]
-        hyp_c[key] = [str(w) for w in one_best(cpu_lats[i])]
-        e_between += _edit_distance(hyp_c[key], hyp_d[key])
-        lat_diff += 0 if lattices_equal(lats[i], cpu_lats[i]) else 1
-    wd, wc, wo = (latbin.compute_wer(ref, h, "present") for h in (hyp_d, hyp_c, hyp_o))
-    return {"utterances": n_utts, "device_search_mode": search_mode, "wer_line_device": wd[0], "wer_line_cpu_reference_port": wc[0],
-            "identical_wer_lines": wd == wc, "wer_line_device_search_mode_%d" % (3 - search_mode): wo[0],
-            "word_errors_device_vs_cpu_hypotheses": e_between,
-            "utterances_whose_raw_lattice_differs_from_mode0": lat_diff,
-            "what": "planted transcripts in the bench HCLG, log-likelihoods peaked on the true pdfs (peak 3.5, noise 1.5); device "
-                    "(work queue, canonical search) vs CPU oracle mode 0 (the reference's order-dependent search); both through "
-                    "DeterminizeLatticePhonePruned + lattice-best-path + compute-wer, scored against the transcript"}
+    from oracle import lattice_parity, orc
+
+    def one_scale(g, hash_capacity, tag):
+        utts = []
+        for i in range(n_utts):
+            ll, words, _ = synth.sample_utterance(g, n_words=6 + i % 7, seed=7000 + i, peak=3.5, noise=1.5)
+            utts.append((ll, words))
+        T = max(ll.shape[0] for ll, _ in utts)
+        sz = pipeline.default_sizes(cfg, min(n_utts, 64), T + 2, T + 2, hash_capacity=hash_capacity or None, tokens_per_frame=80000)   # flat planted scores: a saturated search
+        bd = decoder.BatchDecoder(decoder.Graph(g), cfg, sz)
+        bd.SetSearchMode(search_mode)
+        lats, recs, ms = bd.decode_queue([ll for ll, _ in utts], resident_lanes=min(n_utts, 64))
+        log("wer leg (%s): device decode of %d planted utterances %.1f ms (search mode %d)" % (tag, n_utts, ms, search_mode))
+        bd.SetSearchMode(3 - search_mode)
+        lats_other, _, ms_o = bd.decode_queue([ll for ll, _ in utts], resident_lanes=min(n_utts, 64))
+        del bd
+
+        def cpu(i):
+            o = orc.Decoder(g, cfg, 0)
+            o.Decode(utts[i][0])
+            return o.GetRawLattice()
+
+        cpu_lats, wall, _ = _run_threads(cpu, list(range(n_utts)), cores)
+        log("wer leg (%s): cpu decode %.1f s" % (tag, wall))
+        vocab = int(max(int(g.arcs["olabel"].max()), 1))
+        lm = lattice_parity.second_lm(vocab, n_bigrams=min(200000, 4 * vocab), seed=99)
+        transcripts = [w for _, w in utts]
+        res = lattice_parity.compare(transcripts, lats, cpu_lats, cfg.lattice_beam, lm=lm, lm_scale=1.0)
+        other = lattice_parity.compare(transcripts, lats_other, cpu_lats, cfg.lattice_beam)
+        res["wer_line_device_search_mode_%d" % (3 - search_mode)] = other["wer_line_device"]
+        res["utterances_whose_raw_lattice_differs_from_mode0"] = sum(0 if lattices_equal(a, b) else 1 for a, b in zip(lats, cpu_lats))
+        res["graph"] = "%d states, %d arcs" % (g.num_states, g.num_arcs)
+        log("wer leg (%s): lattice-level comparison done" % tag)
+        return res
+
+    res = one_scale(g, hash_capacity, "bench graph")
+    out = {"utterances": n_utts, "device_search_mode": search_mode, "wer_line_device": res["wer_line_device"],
+           "wer_line_cpu_reference_port": res["wer_line_cpu_mode0"], "identical_wer_lines": res["wer_line_device"] == res["wer_line_cpu_mode0"],
+           "wer_line_device_search_mode_%d" % (3 - search_mode): res["wer_line_device_search_mode_%d" % (3 - search_mode)],
+           "word_errors_device_vs_cpu_hypotheses": n_utts - res["one_best_identical_utterances"],   # (utterances whose 1-best differs)
+           "utterances_whose_raw_lattice_differs_from_mode0": res["utterances_whose_raw_lattice_differs_from_mode0"],
+           "lattice_level": {"bench_graph": res},
+           "what": "planted transcripts in the bench HCLG, log-likelihoods peaked on the true pdfs (peak 3.5, noise 1.5); device "
+                   "(work queue, canonical search) vs CPU oracle mode 0 (the reference's order-dependent search); both through "
+                   "DeterminizeLatticePhonePruned + lattice-best-path + compute-wer, scored against the transcript; lattice_level: "
+                   "10-best overlap, lattice-oracle WER and the 1-best after lattice-lmrescore-const-arpa with a second synthetic LM, "
+                   "on the bench graph and on a tgsmall-scale one"}
+    if second_scale and g.num_states > 5000000:
+        g2 = synth.make_hclg(num_units=1164, vocab=20000, n_hist=18000, fanout=(12, 64), pron_len=(3, 7), seed=2, self_loop_prob=0.5, lm_scale=0.1)
+        out["lattice_level"]["tgsmall_scale_graph"] = one_scale(g2, 0, "tgsmall-scale graph")
+    return out
 
 
 # ----------------------------------------------------------------------------- rank

@@ -592,6 +592,15 @@ int kamd_ivector_extract_online_adapt_device(kamd_ivector_extractor *e, const fl
                                              int ld_feat, int n_utts, float *d_out, const int64_t *h_out_row_off,
                                              const double *h_state_in, double *h_state_out, void *stream);
 int kamd_ivector_state_limit_frames(const kamd_ivector_extractor *e, double *state, float max_remembered_frames);
+/* The extractor's row-indexed workspaces (running sums, LDA outputs, posteriors of every feature row) as an object of
+ * their own.  The silence-weighted update re-reads the LDA rows of frames it processed on EARLIER calls, so a driver of
+ * such a sequence (kamd_stream_batch_* does this) owns one and binds it around its calls; with none bound (NULL) the
+ * extractor's own buffers serve, which is all the stateless entry points need.  Binding is not thread-safe: like every
+ * call on an extractor it belongs to the thread that drives it. */
+typedef struct kamd_ivector_workspace kamd_ivector_workspace;
+kamd_ivector_workspace *kamd_ivector_workspace_create(void);
+void kamd_ivector_workspace_destroy(kamd_ivector_workspace *w);
+int kamd_ivector_extractor_bind_workspace(kamd_ivector_extractor *e, kamd_ivector_workspace *w);
 /* Streaming form: OnlineIvectorFeature::GetFrame with use_most_recent_ivector = true (online2/online-ivector-
  * feature.cc:206-320), for n streams at once.  Stream item i has h_n_base[i] base-feature frames so far at rows
  * h_feat_row[i].. of d_feats (the extractor's workspaces mirror that row space: ws_rows_total rows); frames

@@ -541,6 +541,21 @@ __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
   }
 }
 
+// The row-indexed workspaces: running sums, the two LDA outputs and the posteriors of every feature row.  The silence-
+// weighted update (mode 2) re-reads the LDA rows of frames it processed on EARLIER calls, so whoever drives such a
+// sequence of calls owns one of these (kamd_ivector_workspace_create) and binds it around its calls; the extractor's own
+// one serves the stateless entry points.  Growing keeps the old contents.
+struct IvWorkspace {
+  double *d_S = NULL; size_t S_cap = 0;
+  float *d_nl = NULL, *d_rl = NULL; size_t nl_cap = 0, rl_cap = 0;
+  int32_t *d_pg = NULL; float *d_pw = NULL; size_t pg_cap = 0, pw_cap = 0;
+  void Free() {
+    void *ps[] = {d_S, d_nl, d_rl, d_pg, d_pw};
+    for (void *q : ps) if (q) (void)hipFree(q);
+    d_S = NULL; d_nl = d_rl = NULL; d_pg = NULL; d_pw = NULL; S_cap = nl_cap = rl_cap = pg_cap = pw_cap = 0;
+  }
+};
+
 struct IvExtractor {
   IvDev dev;
   kamd_ivector_desc desc;
@@ -548,9 +563,7 @@ struct IvExtractor {
   float *d_ldaT = NULL, *d_gconsts = NULL, *d_mivT = NULL, *d_ivT = NULL;
   double *d_gsum = NULL, *d_U = NULL, *d_SM = NULL;
   // workspaces
-  double *d_S = NULL; size_t S_cap = 0;
-  float *d_nl = NULL, *d_rl = NULL; size_t lda_cap = 0;
-  int32_t *d_pg = NULL; float *d_pw = NULL; size_t post_cap = 0;
+  IvWorkspace own, *ws = &own;          // ws: the bound one (kamd_ivector_extractor_bind_workspace)
   int64_t *d_off = NULL; size_t off_cap = 0;
   double *d_dquad = NULL, *d_dlin = NULL, *d_dtotw = NULL; size_t dq_cap = 0, dl_cap = 0, dt_cap = 0;
   double *d_state_in = NULL, *d_state_out = NULL; size_t si_cap = 0, so_cap = 0;
@@ -566,6 +579,20 @@ static int GrowDev(T **p, size_t *cap, size_t need) {
   *p = NULL;
   KAMD_HIP(hipMalloc(reinterpret_cast<void **>(p), need * sizeof(T)));
   *cap = need;
+  return KAMD_OK;
+}
+// the same, keeping what the buffer held (the rows of a stream's earlier frames); the copy is ordered on `st`
+template <typename T>
+static int GrowDevKeep(T **p, size_t *cap, size_t need, hipStream_t st) {
+  if (need <= *cap) return KAMD_OK;
+  T *q = NULL;
+  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&q), need * sizeof(T)));
+  if (*p) {
+    KAMD_HIP(hipMemcpyAsync(q, *p, *cap * sizeof(T), hipMemcpyDeviceToDevice, st));
+    KAMD_HIP(hipStreamSynchronize(st));
+    (void)hipFree(*p);
+  }
+  *p = q; *cap = need;
   return KAMD_OK;
 }
 template <typename T>
@@ -653,7 +680,8 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
 void kamd_ivector_extractor_destroy(kamd_ivector_extractor *h) {
   IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
   if (!e) return;
-  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_S, e->d_nl, e->d_rl, e->d_pg, e->d_pw, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw, e->d_state_in, e->d_state_out, e->d_utt, e->d_wlf, e->d_wlw};
+  e->own.Free();
+  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw, e->d_state_in, e->d_state_out, e->d_utt, e->d_wlf, e->d_wlw};
   for (void *p : ps) if (p) (void)hipFree(p);
   delete e;
 }
@@ -663,6 +691,19 @@ int kamd_ivector_period(const kamd_ivector_extractor *h) { return reinterpret_ca
 int kamd_ivector_num_ivectors(const kamd_ivector_extractor *h, int num_frames) {
   const int P = reinterpret_cast<const IvExtractor *>(h)->dev.period;
   return num_frames <= 0 ? 0 : (num_frames + P - 1) / P;
+}
+
+kamd_ivector_workspace *kamd_ivector_workspace_create(void) { return reinterpret_cast<kamd_ivector_workspace *>(new kamd::IvWorkspace()); }
+void kamd_ivector_workspace_destroy(kamd_ivector_workspace *w) {
+  kamd::IvWorkspace *x = reinterpret_cast<kamd::IvWorkspace *>(w);
+  if (!x) return;
+  x->Free();
+  delete x;
+}
+int kamd_ivector_extractor_bind_workspace(kamd_ivector_extractor *h, kamd_ivector_workspace *w) {
+  IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
+  e->ws = w ? reinterpret_cast<kamd::IvWorkspace *>(w) : &e->own;
+  return KAMD_OK;
 }
 
 int kamd_ivector_state_size(const kamd_ivector_extractor *h) {
@@ -698,13 +739,12 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
     KAMD_HIP(hipMemcpyAsync(e->d_wlw, wx.data(), 3 * n_wl * sizeof(float), hipMemcpyHostToDevice, st));
     KAMD_HIP(hipStreamSynchronize(st));
   }
-  if (kamd::GrowDev(&e->d_S, &e->S_cap, static_cast<size_t>(ws_rows) * v.feat_dim) != KAMD_OK) return KAMD_ERR_HIP;
-  size_t cap2 = e->lda_cap;
-  if (kamd::GrowDev(&e->d_nl, &e->lda_cap, static_cast<size_t>(ws_rows) * v.D) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&e->d_rl, &cap2, static_cast<size_t>(ws_rows) * v.D) != KAMD_OK) return KAMD_ERR_HIP;
-  size_t cap3 = e->post_cap;
-  if (kamd::GrowDev(&e->d_pg, &e->post_cap, static_cast<size_t>(ws_rows) * v.ng) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&e->d_pw, &cap3, static_cast<size_t>(ws_rows) * v.ng) != KAMD_OK) return KAMD_ERR_HIP;
+  kamd::IvWorkspace *w = e->ws;
+  if (kamd::GrowDevKeep(&w->d_S, &w->S_cap, static_cast<size_t>(ws_rows) * v.feat_dim, st) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDevKeep(&w->d_nl, &w->nl_cap, static_cast<size_t>(ws_rows) * v.D, st) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDevKeep(&w->d_rl, &w->rl_cap, static_cast<size_t>(ws_rows) * v.D, st) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDevKeep(&w->d_pg, &w->pg_cap, static_cast<size_t>(ws_rows) * v.ng, st) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDevKeep(&w->d_pw, &w->pw_cap, static_cast<size_t>(ws_rows) * v.ng, st) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&e->d_dquad, &e->dq_cap, static_cast<size_t>(inc_rows) * v.Q) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&e->d_dlin, &e->dl_cap, static_cast<size_t>(inc_rows) * v.I) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&e->d_dtotw, &e->dt_cap, static_cast<size_t>(inc_rows)) != KAMD_OK) return KAMD_ERR_HIP;
@@ -718,7 +758,7 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
   }
   kamd::IvBatch b;
   b.feats = d_feats; b.ld = ld_feat; b.utt = e->d_utt;
-  b.S = e->d_S; b.norm_lda = e->d_nl; b.raw_lda = e->d_rl; b.post_g = e->d_pg; b.post_w = e->d_pw; b.out = d_out;
+  b.S = w->d_S; b.norm_lda = w->d_nl; b.raw_lda = w->d_rl; b.post_g = w->d_pg; b.post_w = w->d_pw; b.out = d_out;
   b.dquad = e->d_dquad; b.dlin = e->d_dlin; b.dtotw = e->d_dtotw;
   b.state_in = d_state_in; b.state_out = d_state_out; b.state_size = state_size; b.x_off = x_off;
   b.wl_frame = e->d_wlf; b.wl_weight = e->d_wlw; b.wl_minpost = e->d_wlw + n_wl; b.wl_logminpost = e->d_wlw + 2 * n_wl;
@@ -936,8 +976,8 @@ int kamd_ivector_extract_online_adapt(kamd_ivector_extractor *h, const float *fe
 int kamd_ivector_last_posteriors(kamd_ivector_extractor *h, int32_t *gauss, float *weight, int64_t frames_cap) {
   IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
   if (frames_cap < e->last_rows) return kamd::SetError(KAMD_ERR_ARG, "buffer too small for %lld frames", static_cast<long long>(e->last_rows));
-  KAMD_HIP(hipMemcpy(gauss, e->d_pg, static_cast<size_t>(e->last_rows) * e->dev.ng * 4, hipMemcpyDeviceToHost));
-  KAMD_HIP(hipMemcpy(weight, e->d_pw, static_cast<size_t>(e->last_rows) * e->dev.ng * 4, hipMemcpyDeviceToHost));
+  KAMD_HIP(hipMemcpy(gauss, e->ws->d_pg, static_cast<size_t>(e->last_rows) * e->dev.ng * 4, hipMemcpyDeviceToHost));
+  KAMD_HIP(hipMemcpy(weight, e->ws->d_pw, static_cast<size_t>(e->last_rows) * e->dev.ng * 4, hipMemcpyDeviceToHost));
   return KAMD_OK;
 }
 

@@ -190,6 +190,7 @@ struct StreamBatch {
   // advanced ONCE to the most recent frame (OnlineIvectorFeature::GetFrame, use_most_recent_ivector) and every
   // i-vector slot floor(t / chunk) those chunks' input ranges introduce gets it (nnet-compile-looped.cc:186-207).
   kamd_ivector_extractor *ie = NULL;
+  kamd_ivector_workspace *ie_ws = NULL;   // this batch's LDA / posterior rows (the weighted update re-reads earlier frames' rows)
   int chunk = 0, iv_dim = 0, splice_right = 0, slot_first = 0, max_slots = 0, rec_size = 0;
   double *d_rec = NULL;          // [S][rec_size]
   float *d_slots = NULL;         // [S][max_slots][iv_dim]
@@ -250,6 +251,7 @@ void kamd_stream_batch_destroy(kamd_stream_batch *h) {
   if (b->d_est) (void)hipFree(b->d_est);
   if (b->d_assign) (void)hipFree(b->d_assign);
   for (kamd_silence_weighting *w : b->sw) kamd_silence_weighting_destroy(w);
+  if (b->ie_ws) kamd_ivector_workspace_destroy(b->ie_ws);
   delete b;
 }
 
@@ -577,6 +579,15 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
       }
       pend.push_back(pd);
     }
+    // the extractor may be shared (another stream batch, an offline extraction between ticks): this batch's rows live in
+    // its own workspace, bound for the duration of the call
+    struct Bind {
+      kamd_ivector_extractor *e;
+      Bind(kamd_ivector_extractor *e_, kamd_ivector_workspace *w) : e(e_) { if (e) (void)kamd_ivector_extractor_bind_workspace(e, w); }
+      ~Bind() { if (e) (void)kamd_ivector_extractor_bind_workspace(e, NULL); }
+    };
+    if (!u_row.empty() && !b->ie_ws) b->ie_ws = kamd_ivector_workspace_create();
+    Bind bind(b->ie, u_row.empty() ? NULL : b->ie_ws);
     if (!u_row.empty() && b->sw.empty()) {
       int rc = kamd_ivector_stream_update_device(b->ie, b->d_frames, b->ld, static_cast<int64_t>(b->S) * b->max_frames, u_row.data(),
                                                  u_base.data(), u_done.data(), u_upto.data(), u_rec.data(), static_cast<int>(u_row.size()),

@@ -265,6 +265,100 @@ def best_path(lat):
     return words, ali_parts + ali, g_sum, a_sum
 
 
+def _topo_order(lat):
+    S = len(lat.final)
+    indeg = [0] * S
+    for st in range(S):
+        for d, *_ in lat.arcs[st]:
+            indeg[d] += 1
+    order, stack = [], [st for st in range(S) if indeg[st] == 0]
+    while stack:
+        st = stack.pop(); order.append(st)
+        for d, *_ in lat.arcs[st]:
+            indeg[d] -= 1
+            if indeg[d] == 0:
+                stack.append(d)
+    if len(order) != S:
+        raise KamdError("lattice has cycles")
+    return order
+
+
+def nbest(lat, n):
+    """lattice-to-nbest (latbin/lattice-to-nbest.cc -> fst::ShortestPath with n paths, lat/lattice-functions): the n
+    lowest-cost paths of an acyclic compact lattice as [(words, graph + acoustic cost)], best first.  Best-first search
+    with the exact cost-to-go as the heuristic, so the paths come out in order."""
+    import heapq
+    S = len(lat.final)
+    if S == 0 or lat.start < 0 or n <= 0:
+        return []
+    togo = [INF] * S
+    for st in reversed(_topo_order(lat)):
+        best = INF if lat.final[st] is None else float(lat.final[st][0]) + float(lat.final[st][1])
+        for d, wd, g, a, t in lat.arcs[st]:
+            best = min(best, float(g) + float(a) + togo[d])
+        togo[st] = best
+    if togo[lat.start] == INF:
+        return []
+    out, tie = [], 0
+    heap = [(togo[lat.start], 0, 0.0, lat.start, ())]        # (estimate, tie-break, cost so far, state or -1 = finished, words)
+    while heap and len(out) < n:
+        est, _, cost, st, words = heapq.heappop(heap)
+        if st < 0:
+            out.append((list(words), cost))
+            continue
+        if lat.final[st] is not None:
+            tie += 1
+            c = cost + float(lat.final[st][0]) + float(lat.final[st][1])
+            heapq.heappush(heap, (c, tie, c, -1, words))
+        for d, wd, g, a, t in lat.arcs[st]:
+            if togo[d] == INF:
+                continue
+            tie += 1
+            c = cost + float(g) + float(a)
+            heapq.heappush(heap, (c + togo[d], tie, c, d, words + (wd,) if wd != 0 else words))
+    return out
+
+
+def oracle_errors(lat, ref):
+    """lattice-oracle (latbin/lattice-oracle.cc): the smallest edit distance between `ref` and the word sequence of ANY
+    path through the lattice (the lattice's oracle error count), by dynamic programming over (state, reference position)."""
+    S, R = len(lat.final), len(ref)
+    if S == 0 or lat.start < 0:
+        return R
+    cost = [[INF] * (R + 1) for _ in range(S)]
+    row = cost[lat.start]
+    for j in range(R + 1):
+        row[j] = j                                            # j reference words deleted before the first arc
+    best = INF
+    for st in _topo_order(lat):
+        row = cost[st]
+        for j in range(R):                                    # deletions inside this state
+            if row[j] + 1 < row[j + 1]:
+                row[j + 1] = row[j] + 1
+        if row[0] == INF and min(row) == INF:
+            continue
+        if lat.final[st] is not None:
+            best = min(best, row[R])
+        for d, wd, g, a, t in lat.arcs[st]:
+            nxt = cost[d]
+            if wd == 0:
+                for j in range(R + 1):
+                    if row[j] < nxt[j]:
+                        nxt[j] = row[j]
+            else:
+                for j in range(R + 1):
+                    c = row[j]
+                    if c == INF:
+                        continue
+                    if c + 1 < nxt[j]:
+                        nxt[j] = c + 1                        # the arc's word is an insertion
+                    if j < R:
+                        e = c + (0 if ref[j] == wd else 1)
+                        if e < nxt[j + 1]:
+                            nxt[j + 1] = e
+    return R if best == INF else best
+
+
 def edit_distance(ref, hyp):
     """LevenshteinEditDistance with counts, the reference's recursion and tie-breaking (util/edit-distance-inl.h:79-127)"""
     e = [(i, 0, i, 0) for i in range(len(ref) + 1)]             # (total, ins, del, sub)

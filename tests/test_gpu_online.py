@@ -642,3 +642,63 @@ def test_streams_with_silence_weighting():
         unit, _ = orc.ivector_extract_streaming_weighted(info, feats[s], calls[s], [[(t, 1.0) for t in range(a, b)]
                                                                                     for a, b in zip([0] + calls[s][:-1], calls[s])])
         np.testing.assert_allclose(unit, orc.ivector_extract_streaming(info, feats[s], calls[s])[0], rtol=0, atol=1e-6)
+
+
+def test_shared_extractor_between_stream_batches_and_offline_calls():
+    """Round-2 advisor finding: the silence-weighted update re-reads the LDA rows of frames it processed on EARLIER ticks;
+    those rows lived in workspaces of the EXTRACTOR, which a second stream batch sharing it, or an offline extraction
+    between two ticks, overwrote.  Each stream batch now owns its rows (kamd_ivector_workspace, bound per call): two batches
+    on one extractor, their ticks interleaved with each other and with offline extractions, must give what each gives
+    alone -- i-vector slots, adaptation states and lattices bit for bit."""
+    from kaldi_amd import ivector
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, ivector_dim=16, seed=12, output_scale=3.0)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    waves = [synth.make_wave(d, seed=70 + i) for i, d in enumerate((2.6, 1.9))]
+    feats = [feat.Mfcc(op).ComputeFeatures(w) for w in waves]
+    allf = np.concatenate(feats)
+    info = ivector.make_synthetic(num_gauss=64, ivector_dim=16, seed=9, feat_mean=allf.mean(0), feat_std=allf.std(0), max_count=10.0)
+    ie = ivector.IvectorExtractor(info)
+    num_tids = len(g.tid2pdf) - 1
+    tid2phone = np.concatenate([[0], (np.arange(num_tids) // 2) + 1]).astype(np.int32)
+    sil = [p for p in range(1, int(tid2phone.max()) + 1) if p % 2 == 0]
+    swc = online.OnlineSilenceWeightingConfig(":".join(map(str, sil)), 0.1, 4.0)
+    sizes = abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512)
+    step = [int(0.21 * 16000), int(0.17 * 16000)]
+
+    def make():
+        sb = online.StreamBatch(op, N, G, cfg, 1, max_seconds=4.0, sizes=sizes)
+        sb.set_ivector_extractor(ie, 20)
+        sb.set_silence_weighting(swc, tid2phone)
+        sb.start([0])
+        return sb
+
+    def tick(sb, w, pos):
+        chunk = waves[w][pos:pos + step[w]]
+        sb.accept(0, chunk, input_finished=pos + chunk.size >= waves[w].size)
+        sb.advance([0])
+        return pos + chunk.size
+
+    alone = []
+    for w in range(2):
+        sb, pos = make(), 0
+        while pos < waves[w].size:
+            pos = tick(sb, w, pos)
+        sb.finalize([0])
+        alone.append((sb.ivector_slots(0), sb.adaptation_state(0, max_remembered_frames=1e9), sb.raw_lattice(0)))
+    sbs, pos, k = [make(), make()], [0, 0], 0
+    while any(pos[w] < waves[w].size for w in range(2)):
+        for w in range(2):
+            if pos[w] < waves[w].size:
+                pos[w] = tick(sbs[w], w, pos[w])
+        ie.extract_online(feats[k % 2])                # an offline extraction on the same extractor between the ticks
+        k += 1
+    for w in range(2):
+        sbs[w].finalize([0])
+        (first, slots), state, lat = alone[w]
+        first2, slots2 = sbs[w].ivector_slots(0)
+        assert first2 == first
+        np.testing.assert_array_equal(slots2, slots)
+        np.testing.assert_array_equal(sbs[w].adaptation_state(0, max_remembered_frames=1e9), state)
+        assert lattices_equal(sbs[w].raw_lattice(0), lat)

@@ -147,3 +147,52 @@ def test_edit_distance_reference_known_answers():
     assert edit_distance(hyp, ref) == (3, 2, 0, 1)
     assert edit_distance([1], [1]) == (0, 0, 0, 0)
     assert edit_distance([1, 3], [1, 2]) == (1, 0, 0, 1)
+
+
+def _random_dag(rng, n_states, words):
+    from kaldi_amd import latbin as lb
+    L = lb.Lat(0)
+    for _ in range(n_states):
+        L.add_state()
+    for s in range(n_states - 1):
+        for _ in range(int(rng.integers(1, 4))):
+            d = int(rng.integers(s + 1, n_states))
+            L.arcs[s].append((d, int(rng.choice(words)), float(rng.uniform(0, 3)), float(rng.uniform(0, 3)), [s + 1]))
+    for s in range(n_states):
+        if s == n_states - 1 or rng.random() < 0.2:
+            L.final[s] = (float(rng.uniform(0, 2)), 0.0, [])
+    return L
+
+
+def _all_paths(L):
+    out = []
+
+    def walk(s, words, cost):
+        if L.final[s] is not None:
+            out.append((list(words), cost + L.final[s][0] + L.final[s][1]))
+        for d, w, g, a, t in L.arcs[s]:
+            walk(d, words + [w] if w else words, cost + g + a)
+    walk(L.start, [], 0.0)
+    return out
+
+
+def test_nbest_and_oracle_against_path_enumeration():
+    """lattice-to-nbest's n cheapest paths and lattice-oracle's smallest edit distance, against a brute-force walk over every
+    path of small random acyclic lattices (epsilon arcs included)."""
+    import numpy as np
+    from kaldi_amd import latbin as lb
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        L = _random_dag(rng, int(rng.integers(3, 9)), [0, 1, 2, 3, 4])
+        paths = sorted(_all_paths(L), key=lambda p: p[1])
+        got = lb.nbest(L, 7)
+        assert len(got) == min(7, len(paths))
+        for (w, c), (w2, c2) in zip(got, paths):
+            assert abs(c - c2) < 1e-9
+        assert [round(c, 9) for _, c in got] == sorted(round(c, 9) for _, c in got)
+        # every returned (words, cost) is a path of the lattice
+        want = {(tuple(w), round(c, 6)) for w, c in paths}
+        assert all((tuple(w), round(c, 6)) in want for w, c in got)
+        ref = [int(x) for x in rng.integers(1, 5, int(rng.integers(0, 5)))]
+        brute = min(lb.edit_distance(ref, w)[0] for w, _ in paths)
+        assert lb.oracle_errors(L, ref) == brute
