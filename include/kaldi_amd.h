@@ -385,6 +385,19 @@ int kamd_decoder_lattice_size(kamd_decoder *d, int lane, kamd_lattice_size *sz);
 int kamd_decoder_get_raw_lattice(kamd_decoder *d, int lane, int32_t *state_frame,
                                  int32_t *state_hclg, float *state_cost,
                                  float *state_final, kamd_lat_arc *arcs);
+/* GetRawLattice on a LIVE decoder (decoder/lattice-faster-decoder.cc:113-196 with !decoding_finalized_; what
+ * SingleUtteranceNnet3DecoderTpl::GetLattice(end_of_utterance = false) reads between chunks, online2/online-nnet3-
+ * decoding.cc:66-79): every token and forward link the lane holds, final costs computed on the spot (use_final_probs
+ * = 0: every token of the last frame final with weight One).  A host-side read of the lane's arenas after
+ * kamd_decoder_sync: nothing is launched, the lane decodes on.  Same canonical numbering as kamd_decoder_get_raw_lattice. */
+int kamd_decoder_live_lattice_size(kamd_decoder *d, int lane, int use_final_probs, kamd_lattice_size *sz);
+int kamd_decoder_get_live_raw_lattice(kamd_decoder *d, int lane, int use_final_probs, int32_t *state_frame, int32_t *state_hclg,
+                                      float *state_cost, float *state_final, kamd_lat_arc *arcs);
+/* PruneLattice(beam) on a raw lattice held on the host (lat/lattice-functions.cc; the exact form of what
+ * LatticeFasterOnlineDecoderTpl::GetRawLatticePruned, decoder/lattice-faster-online-decoder.cc:168-265, approximates):
+ * state_map[s] = number of state s in the pruned lattice or -1, arc_keep[i] = 1 for the arcs that stay. */
+int kamd_lattice_prune(int32_t num_states, int32_t start, const float *state_final, const kamd_lat_arc *arcs, int32_t num_arcs,
+                       float beam, int32_t *state_map, uint8_t *arc_keep, int32_t *num_states_out, int32_t *num_arcs_out);
 /* GetBestPath (lattice-faster-decoder.cc:102-108) + GetLinearSymbolSequence
  * (fstext/fstext-utils-inl.h:178): ShortestPath over the raw lattice with
  * LatticeWeight ordering.  Outputs the alignment (transition-ids), words, and the

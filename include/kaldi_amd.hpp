@@ -241,11 +241,14 @@ class LatticeFasterDecoder {
   bool ReachedFinal() const { return FinalRelativeCost() != std::numeric_limits<BaseFloat>::infinity(); }
   int32 NumFramesDecoded() const { return kamd_decoder_num_frames_decoded(dec_, 0); }
 
-  /// Raw state-level lattice; requires FinalizeDecoding() (use_final_probs == true).
+  /// Raw state-level lattice (lattice-faster-decoder.cc:113-196).  After FinalizeDecoding(): the pruned lattice (use_final_probs
+  /// must be true, :117-120).  Before it: every token and link the live decoder holds, final costs computed on the spot;
+  /// use_final_probs == false makes every token of the last frame final with weight One.
   bool GetRawLattice(Lattice *ofst, bool use_final_probs = true) const {
-    if (!use_final_probs) throw KaldiFatalError("You cannot call FinalizeDecoding() and then call GetRawLattice() with use_final_probs == false");
     kamd_lattice_size sz;
-    Check(kamd_decoder_lattice_size(dec_, 0, &sz));
+    const bool finalized = kamd_decoder_lattice_size(dec_, 0, &sz) == 0;
+    if (finalized && !use_final_probs) throw KaldiFatalError("You cannot call FinalizeDecoding() and then call GetRawLattice() with use_final_probs == false");
+    if (!finalized) Check(kamd_decoder_live_lattice_size(dec_, 0, use_final_probs ? 1 : 0, &sz));
     ofst->arcs.assign(sz.num_states, std::vector<LatticeArc>());
     ofst->final_graph_cost.assign(sz.num_states, 0.f);
     ofst->state_frame.assign(sz.num_states, 0); ofst->state_hclg.assign(sz.num_states, 0);
@@ -253,13 +256,50 @@ class LatticeFasterDecoder {
     if (sz.num_states == 0) return false;
     std::vector<float> cost(sz.num_states);
     std::vector<kamd_lat_arc> arcs(sz.num_arcs);
-    Check(kamd_decoder_get_raw_lattice(dec_, 0, ofst->state_frame.data(), ofst->state_hclg.data(), cost.data(),
-                                       ofst->final_graph_cost.data(), arcs.data()));
+    if (finalized) Check(kamd_decoder_get_raw_lattice(dec_, 0, ofst->state_frame.data(), ofst->state_hclg.data(), cost.data(),
+                                                     ofst->final_graph_cost.data(), arcs.data()));
+    else Check(kamd_decoder_get_live_raw_lattice(dec_, 0, use_final_probs ? 1 : 0, ofst->state_frame.data(), ofst->state_hclg.data(),
+                                                cost.data(), ofst->final_graph_cost.data(), arcs.data()));
     for (size_t i = 0; i < arcs.size(); i++) {
       LatticeArc a = {arcs[i].ilabel, arcs[i].olabel, arcs[i].graph_cost, arcs[i].acoustic_cost, arcs[i].dst};
       ofst->arcs[arcs[i].src].push_back(a);
     }
     return true;
+  }
+  /// LatticeFasterOnlineDecoderTpl::GetRawLatticePruned (decoder/lattice-faster-online-decoder.cc:168-265): the raw lattice
+  /// restricted to the paths within `beam` of the best one.  Exact pruning (kamd_lattice_prune); the reference prunes with
+  /// the extra costs its last periodic PruneActiveTokens left behind.
+  bool GetRawLatticePruned(Lattice *ofst, bool use_final_probs, BaseFloat beam) const {
+    Lattice full;
+    if (!GetRawLattice(&full, use_final_probs)) return false;
+    std::vector<float> fin;
+    std::vector<kamd_lat_arc> arcs;
+    const float inf = std::numeric_limits<float>::infinity();
+    fin.assign(full.NumStates(), inf);
+    for (int32 s = 0; s < full.NumStates(); s++) {
+      fin[s] = full.final_graph_cost[s];
+      for (size_t k = 0; k < full.arcs[s].size(); k++) {
+        const LatticeArc &a = full.arcs[s][k];
+        kamd_lat_arc f = {s, a.nextstate, a.ilabel, a.olabel, a.graph_cost, a.acoustic_cost};
+        arcs.push_back(f);
+      }
+    }
+    std::vector<int32> smap(full.NumStates());
+    std::vector<uint8_t> keep(arcs.size() + 1);
+    int32 n_out = 0, m_out = 0;
+    Check(kamd_lattice_prune(full.NumStates(), full.start, fin.data(), arcs.data(), static_cast<int32>(arcs.size()), beam, smap.data(), keep.data(),
+                             &n_out, &m_out));
+    ofst->arcs.assign(n_out, std::vector<LatticeArc>());
+    ofst->final_graph_cost.assign(n_out, inf); ofst->state_frame.assign(n_out, 0); ofst->state_hclg.assign(n_out, 0);
+    ofst->start = n_out > 0 ? smap[full.start] : -1;
+    for (int32 s = 0; s < full.NumStates(); s++)
+      if (smap[s] >= 0) { ofst->final_graph_cost[smap[s]] = fin[s]; ofst->state_frame[smap[s]] = full.state_frame[s]; ofst->state_hclg[smap[s]] = full.state_hclg[s]; }
+    for (size_t i = 0; i < arcs.size(); i++)
+      if (keep[i]) {
+        LatticeArc a = {arcs[i].ilabel, arcs[i].olabel, arcs[i].graph_cost, arcs[i].acoustic_cost, smap[arcs[i].dst]};
+        ofst->arcs[smap[arcs[i].src]].push_back(a);
+      }
+    return n_out > 0;
   }
   /// Single best path: ShortestPath(raw lattice) + GetLinearSymbolSequence.
   bool GetBestPath(std::vector<int32> *alignment, std::vector<int32> *words, BaseFloat *graph_cost,
@@ -640,6 +680,16 @@ class SingleUtteranceNnet3Decoder {
     alignment->assign(ali.begin(), ali.begin() + na);
     words->assign(wrd.begin(), wrd.begin() + nw);
     return true;
+  }
+  /// GetLattice(end_of_utterance, &clat) (online-nnet3-decoding.cc:66-79): the raw lattice -- of the live decoder when
+  /// FinalizeDecoding() has not been called, final-probs only at the end of the utterance -- through
+  /// DeterminizeLatticePhonePrunedWrapper at the decoder's lattice beam.  tid_phone as in that wrapper.
+  void GetLattice(bool end_of_utterance, const std::vector<int32> &tid_phone, CompactLattice *clat,
+                  DeterminizeLatticePhonePrunedOptions det_opts = DeterminizeLatticePhonePrunedOptions()) const {
+    if (NumFramesDecoded() == 0) throw KaldiFatalError("You cannot get a lattice if you decoded no frames.");
+    Lattice raw_lat;
+    decoder_.GetRawLattice(&raw_lat, end_of_utterance);
+    DeterminizeLatticePhonePrunedWrapper(tid_phone, raw_lat, decoder_.GetOptions().lattice_beam, clat, det_opts);
   }
   /// EndpointDetected(config) (online-nnet3-decoding.cc:88-95); the transition model's tid -> phone table is
   /// passed here instead of at construction

@@ -2441,11 +2441,17 @@ struct Graph {
   int64_t num_arcs, num_emit;
   int max_ilabel;
   std::vector<void *> allocs;
+  std::vector<float> h_final;      // host copy of the final costs, made by the first live-lattice read
+};
+
+struct RawLat {
+  std::vector<int32_t> frame, hclg; std::vector<float> cost, fin; std::vector<kamd_lat_arc> arcs;
+  int start = -1, frames = 0;
 };
 
 struct Decoder {
   DecDev dev;
-  const Graph *g;
+  Graph *g;
   kamd_decoder_sizes sizes;
   std::vector<void *> allocs;
   std::vector<LaneState> h_st;
@@ -2475,6 +2481,7 @@ struct Decoder {
   bool split_uniform = true;
   // host copy of one lane's lattice (canonical), cached by lane
   int cached_lane = -1;
+  RawLat live; int live_lane = -1, live_ufp = 1;     // kamd_decoder_live_lattice_size -> kamd_decoder_get_live_raw_lattice
   std::vector<int32_t> lat_frame, lat_hclg; std::vector<float> lat_cost, lat_final;
   std::vector<kamd_lat_arc> lat_arcs; int lat_start = -1, lat_frames = 0;
 };
@@ -2583,7 +2590,7 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
     return NULL;
   }
   Decoder *D = new Decoder();
-  D->g = reinterpret_cast<const Graph *>(gh);
+  D->g = const_cast<Graph *>(reinterpret_cast<const Graph *>(gh));   // (its lazily made host copy of the final costs is the only thing written)
   D->sizes = s;
   kamd::DecDev &d = D->dev;
   memset(&d, 0, sizeof(d));
@@ -3244,10 +3251,7 @@ int kamd_decoder_get_trace(kamd_decoder *h, int lane, int32_t *ntok, float *cuto
 // st / co: [nt] HCLG state and forward cost in arena order (frame by frame, toff[f] = first token of frame f);
 // last_final: final cost of every token of frame F in arena order; lk: links whose endpoints are indices
 // into st (after subtracting link_index_base).
-struct RawLat {
-  std::vector<int32_t> frame, hclg; std::vector<float> cost, fin; std::vector<kamd_lat_arc> arcs;
-  int start = -1, frames = 0;
-};
+using kamd::RawLat;
 static int Canonicalize(int nt, int nl, int F, const int *st, const float *co, const int *toff, const float *last_final,
                         const kamd::Link *lk, int link_index_base, int graph_start, RawLat *out) {
   std::vector<float> fin(nt, INFINITY);
@@ -3334,6 +3338,88 @@ static int FetchLattice(Decoder *D, int lane) {
   return KAMD_OK;
 }
 
+// GetRawLattice on a LIVE decoder (lattice-faster-decoder.cc:113-196 with !decoding_finalized_: every token and forward
+// link the decoder holds, final costs computed on the spot): what SingleUtteranceNnet3Decoder::GetLattice(end_of_utterance
+// = false) reads between two chunks (online2/online-nnet3-decoding.cc:66-79).  The lane's arenas ARE that lattice --
+// frame f's tokens [tok_off[f], tok_off[f + 1]), the emitting links into frame f [lnk_off[2 f], lnk_off[2 f + 1]) with the
+// frame's cost offset still inside their acoustic cost (:173-177), its epsilon links behind them; recorded arcs that did
+// not pass the frame's final cutoff carry a negative endpoint -- so this is a host-side read of the arenas, nothing
+// is launched and the decoder goes on afterwards.  use_final_probs = 0: every token of the last frame is final with
+// weight One (:183-192 with use_final_probs false).
+static int FetchLiveLattice(Decoder *D, int lane, int use_final_probs, RawLat *R) {
+  if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
+  const kamd::LaneState &S = D->h_st[lane];
+  if (S.finalized) return kamd::SetError(KAMD_ERR_STATE, "lane %d is finalized: use kamd_decoder_get_raw_lattice", lane);
+  const int F = S.frame;
+  const size_t mf = D->sizes.max_frames;
+  std::vector<int> toff(F + 2), loff(2 * F + 3);
+  KAMD_HIP(hipMemcpy(toff.data(), D->dev.tok_off + lane * (mf + 2), (F + 2) * 4, hipMemcpyDeviceToHost));
+  KAMD_HIP(hipMemcpy(loff.data(), D->dev.lnk_off + lane * (2 * (mf + 2) + 1), (2 * F + 3) * 4, hipMemcpyDeviceToHost));
+  const int nt = toff[F + 1], nl_all = loff[2 * F + 2];
+  if (nt <= 0) { *R = RawLat(); R->frames = F; return KAMD_OK; }
+  const long long tbase = D->h_tok_base[lane], lbase = D->h_lnk_base[lane];
+  std::vector<int> st(nt);
+  std::vector<float> co(nt), cof(std::max(F, 1));
+  std::vector<kamd::Link> all(std::max(nl_all, 1)), lk;
+  KAMD_HIP(hipMemcpy(st.data(), D->dev.tok_state + tbase, nt * 4, hipMemcpyDeviceToHost));
+  KAMD_HIP(hipMemcpy(co.data(), D->dev.tok_cost + tbase, nt * 4, hipMemcpyDeviceToHost));
+  if (F > 0) KAMD_HIP(hipMemcpy(cof.data(), D->dev.cost_offsets + lane * (mf + 1), F * 4, hipMemcpyDeviceToHost));
+  if (nl_all > 0) KAMD_HIP(hipMemcpy(all.data(), D->dev.links + lbase, static_cast<size_t>(nl_all) * sizeof(kamd::Link), hipMemcpyDeviceToHost));
+  lk.reserve(nl_all);
+  for (int f = 0; f <= F; f++)
+    for (int part = 0; part < 2; part++) {
+      const float off = (part == 0 && f > 0) ? cof[f - 1] : 0.0f;
+      for (int i = loff[2 * f + part]; i < loff[2 * f + part + 1] && i < nl_all; i++) {
+        kamd::Link L = all[i];
+        if (L.src < 0 || L.dst < 0) continue;
+        if (part == 0) L.ac = L.ac - off;
+        lk.push_back(L);
+      }
+    }
+  const int lb = toff[F], le = nt;
+  std::vector<float> fc(std::max(0, le - lb), 0.0f);
+  if (use_final_probs && le > lb) {
+    std::vector<float> &gfin = D->g->h_final;       // (one read of the graph's final costs, kept: partial lattices are asked for tick after tick)
+    if (gfin.empty()) {
+      gfin.resize(D->g->dev.num_states);
+      KAMD_HIP(hipMemcpy(gfin.data(), D->g->dev.final, gfin.size() * 4, hipMemcpyDeviceToHost));
+    }
+    for (int i = lb; i < le; i++) fc[i - lb] = gfin[st[i]];
+  }
+  return Canonicalize(nt, static_cast<int>(lk.size()), F, st.data(), co.data(), toff.data(), fc.data(), lk.data(), 0, D->g->dev.start, R);
+}
+
+int kamd_decoder_live_lattice_size(kamd_decoder *h, int lane, int use_final_probs, kamd_lattice_size *sz) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  RawLat R;
+  const int rc = FetchLiveLattice(D, lane, use_final_probs, &R);
+  if (rc != KAMD_OK) return rc;
+  sz->num_states = static_cast<int32_t>(R.frame.size()); sz->num_arcs = static_cast<int32_t>(R.arcs.size());
+  sz->num_frames = R.frames; sz->start = R.start;
+  D->live.frame.swap(R.frame); D->live.hclg.swap(R.hclg); D->live.cost.swap(R.cost); D->live.fin.swap(R.fin); D->live.arcs.swap(R.arcs);
+  D->live.start = R.start; D->live.frames = R.frames; D->live_lane = lane; D->live_ufp = use_final_probs;
+  return KAMD_OK;
+}
+
+int kamd_decoder_get_live_raw_lattice(kamd_decoder *h, int lane, int use_final_probs, int32_t *state_frame, int32_t *state_hclg,
+                                      float *state_cost, float *state_final, kamd_lat_arc *arcs) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (D->live_lane != lane || D->live_ufp != use_final_probs || D->live.frames != D->h_st[lane].frame) {
+    kamd_lattice_size sz;
+    const int rc = kamd_decoder_live_lattice_size(h, lane, use_final_probs, &sz);
+    if (rc != KAMD_OK) return rc;
+  }
+  const RawLat &R = D->live;
+  const size_t n = R.frame.size();
+  if (n) {
+    memcpy(state_frame, R.frame.data(), n * 4); memcpy(state_hclg, R.hclg.data(), n * 4);
+    memcpy(state_cost, R.cost.data(), n * 4); memcpy(state_final, R.fin.data(), n * 4);
+  }
+  if (!R.arcs.empty()) memcpy(arcs, R.arcs.data(), R.arcs.size() * sizeof(kamd_lat_arc));
+  D->live_lane = -1;
+  return KAMD_OK;
+}
+
 int kamd_decoder_lattice_size(kamd_decoder *h, int lane, kamd_lattice_size *sz) {
   Decoder *D = reinterpret_cast<Decoder *>(h);
   int rc = FetchLattice(D, lane);
@@ -3415,6 +3501,58 @@ int kamd_lattice_best_path(int32_t n, int32_t start, const float *state_final, c
     if (a.olabel != 0) { if (*words_len < words_cap) words[*words_len] = a.olabel; (*words_len)++; }
   }
   *graph_cost = b1; *acoustic_cost = b2;
+  return KAMD_OK;
+}
+
+// fst::Prune on a raw lattice (lat/lattice-functions.cc PruneLattice: total weight = graph + acoustic cost): states and
+// arcs on no path within `beam` of the best path go.  The exact form of what LatticeFasterOnlineDecoderTpl::
+// GetRawLatticePruned (decoder/lattice-faster-online-decoder.cc:168-265) approximates with the extra costs left by the
+// last periodic PruneActiveTokens.  state_map[s] = new number or -1, arc_keep[i] = 0 / 1.
+int kamd_lattice_prune(int32_t n, int32_t start, const float *state_final, const kamd_lat_arc *A, int32_t m, float beam,
+                       int32_t *state_map, uint8_t *arc_keep, int32_t *n_out, int32_t *m_out) {
+  *n_out = 0; *m_out = 0;
+  for (int s = 0; s < n; s++) state_map[s] = -1;
+  for (int i = 0; i < m; i++) arc_keep[i] = 0;
+  if (n <= 0 || start < 0 || start >= n) return KAMD_OK;
+  std::vector<int> first(n + 1, 0), indeg(n, 0), by_src(m), order;
+  for (int i = 0; i < m; i++) {
+    if (A[i].src < 0 || A[i].src >= n || A[i].dst < 0 || A[i].dst >= n) return kamd::SetError(KAMD_ERR_ARG, "lattice arc %d out of range", i);
+    first[A[i].src + 1]++; indeg[A[i].dst]++;
+  }
+  for (int s = 0; s < n; s++) first[s + 1] += first[s];
+  {
+    std::vector<int> fill(first.begin(), first.end() - 1);
+    for (int i = 0; i < m; i++) by_src[fill[A[i].src]++] = i;
+  }
+  order.reserve(n);
+  for (int s = 0; s < n; s++) if (indeg[s] == 0) order.push_back(s);
+  for (size_t k = 0; k < order.size(); k++)
+    for (int j = first[order[k]]; j < first[order[k] + 1]; j++)
+      if (--indeg[A[by_src[j]].dst] == 0) order.push_back(A[by_src[j]].dst);
+  if (order.size() != static_cast<size_t>(n)) return kamd::SetError(KAMD_ERR_STATE, "lattice has a cycle");
+  std::vector<double> fwd(n, INFINITY), bwd(n, INFINITY);
+  fwd[start] = 0.0;
+  for (int s : order)
+    if (fwd[s] != INFINITY)
+      for (int j = first[s]; j < first[s + 1]; j++) {
+        const kamd_lat_arc &a = A[by_src[j]];
+        fwd[a.dst] = std::min(fwd[a.dst], fwd[s] + static_cast<double>(a.graph_cost) + static_cast<double>(a.acoustic_cost));
+      }
+  for (size_t k = order.size(); k-- > 0;) {
+    const int s = order[k];
+    double b = state_final[s];
+    for (int j = first[s]; j < first[s + 1]; j++) {
+      const kamd_lat_arc &a = A[by_src[j]];
+      b = std::min(b, static_cast<double>(a.graph_cost) + static_cast<double>(a.acoustic_cost) + bwd[a.dst]);
+    }
+    bwd[s] = b;
+  }
+  const double best = bwd[start];
+  if (best == INFINITY) return KAMD_OK;
+  const double limit = best + static_cast<double>(beam);
+  for (int s = 0; s < n; s++) if (fwd[s] + bwd[s] <= limit) state_map[s] = (*n_out)++;
+  for (int i = 0; i < m; i++)
+    if (fwd[A[i].src] + static_cast<double>(A[i].graph_cost) + static_cast<double>(A[i].acoustic_cost) + bwd[A[i].dst] <= limit) { arc_keep[i] = 1; (*m_out)++; }
   return KAMD_OK;
 }
 

@@ -277,8 +277,21 @@ class LatticeFasterDecoder:
     def ReachedFinal(self):
         return bool(lib().kamd_decoder_reached_final(self._dec, self.lane))
 
-    def GetRawLattice(self):
-        return get_raw_lattice(self._dec, self.lane)
+    def GetRawLattice(self, use_final_probs=True):
+        """lattice-faster-decoder.cc:113-196.  After FinalizeDecoding: the pruned raw lattice (use_final_probs must be true,
+        as in the reference).  Before it: every token and link the live decoder holds, final costs computed on the spot
+        (use_final_probs False: every token of the last frame is final with weight One)."""
+        if lib().kamd_decoder_lattice_size(self._dec, self.lane, C.byref(abi.LatticeSize())) == 0:
+            if not use_final_probs:
+                raise KamdError("You cannot call FinalizeDecoding() and then call GetRawLattice() with use_final_probs == false")
+            return get_raw_lattice(self._dec, self.lane)
+        return get_live_raw_lattice(self._dec, self.lane, use_final_probs)
+
+    def GetRawLatticePruned(self, use_final_probs, beam):
+        """LatticeFasterOnlineDecoder::GetRawLatticePruned (lattice-faster-online-decoder.cc:168-265): the live raw lattice
+        restricted to the paths within `beam` of the best one (exact pruning; the reference uses the extra costs of its
+        last periodic PruneActiveTokens)."""
+        return prune_lattice(self.GetRawLattice(use_final_probs), beam)
 
     def GetBestPath(self, use_final_probs=True):
         """After FinalizeDecoding: ShortestPath of the raw lattice.  Before it (streaming):
@@ -308,6 +321,38 @@ def get_raw_lattice(dec, lane):
     check(lib().kamd_decoder_get_raw_lattice(dec, lane, abi.iptr(fr), abi.iptr(hc), abi.fptr(co),
                                              abi.fptr(fi), arcs.ctypes.data_as(C.c_void_p)))
     return Lattice(sz.start, fr, hc, co, fi, arcs, sz.num_frames)
+
+
+def get_live_raw_lattice(dec, lane, use_final_probs=True):
+    sz = abi.LatticeSize()
+    check(lib().kamd_decoder_live_lattice_size(dec, lane, int(bool(use_final_probs)), C.byref(sz)))
+    n, m = sz.num_states, sz.num_arcs
+    if n == 0:
+        return None
+    fr, hc = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    co, fi = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    arcs = np.zeros(m, abi.LAT_ARC_DTYPE)
+    check(lib().kamd_decoder_get_live_raw_lattice(dec, lane, int(bool(use_final_probs)), abi.iptr(fr), abi.iptr(hc), abi.fptr(co),
+                                                  abi.fptr(fi), arcs.ctypes.data_as(C.c_void_p)))
+    return Lattice(sz.start, fr, hc, co, fi, arcs, sz.num_frames)
+
+
+def prune_lattice(lat, beam):
+    """PruneLattice(beam, &lat) on a raw Lattice (kamd_lattice_prune); canonical numbering is kept."""
+    if lat is None:
+        return None
+    n, m = lat.frame.size, lat.arcs.size
+    smap, keep = np.zeros(n, np.int32), np.zeros(max(m, 1), np.uint8)
+    n_out, m_out = C.c_int32(), C.c_int32()
+    arcs = np.ascontiguousarray(lat.arcs)
+    check(lib().kamd_lattice_prune(n, lat.start, abi.fptr(np.ascontiguousarray(lat.final, np.float32)), arcs.ctypes.data_as(C.c_void_p), m,
+                                   float(beam), abi.iptr(smap), keep.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(n_out), C.byref(m_out)))
+    if n_out.value == 0:
+        return None
+    ks = smap >= 0
+    a = arcs[keep[:m].astype(bool)].copy()
+    a["src"], a["dst"] = smap[a["src"]], smap[a["dst"]]
+    return Lattice(int(smap[lat.start]), lat.frame[ks], lat.hclg[ks], lat.cost[ks], lat.final[ks], a, lat.num_frames)
 
 
 def queue_fetch_lattice(dec, utt, copy_stream=None):

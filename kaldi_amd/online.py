@@ -124,8 +124,18 @@ class SingleUtteranceNnet3Decoder:
         """online-nnet3-decoding.cc:81-85: use_final_probs = end_of_utterance."""
         return self.decoder.GetBestPath(use_final_probs=end_of_utterance)
 
-    def GetRawLattice(self):
-        return self.decoder.GetRawLattice()
+    def GetRawLattice(self, use_final_probs=True):
+        return self.decoder.GetRawLattice(use_final_probs)
+
+    def GetLattice(self, end_of_utterance, tid_phone=None, det_opts=None):
+        """SingleUtteranceNnet3DecoderTpl::GetLattice (online2/online-nnet3-decoding.cc:66-79): the raw lattice -- of the LIVE
+        decoder when FinalizeDecoding has not been called, final-probs only at the end of the utterance -- through
+        DeterminizeLatticePhonePrunedWrapper at the decoder's lattice beam.  -> kaldi_amd.io.CompactLattice or None."""
+        from . import io as kio
+        raw = self.decoder.GetRawLattice(use_final_probs=bool(end_of_utterance))
+        if raw is None:
+            return None
+        return kio.determinize_lattice(raw, self.decoder.config.lattice_beam, tid_phone, det_opts)
 
     # ---- endpointing (online2/online-nnet3-decoding.cc:88-97, online2/online-endpoint.cc:71-121)
     def TrailingSilenceLength(self, tid2phone, silence_phones):

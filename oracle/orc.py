@@ -88,6 +88,8 @@ def lib():
         L.orc_trailing_silence_length.argtypes = [ip, C.c_int, ip, ip, C.c_int]
         L.orc_decoder_lattice_size.argtypes = [C.c_void_p, C.POINTER(abi.LatticeSize)]
         L.orc_decoder_get_raw_lattice.argtypes = [C.c_void_p, ip, ip, fp, fp, C.c_void_p]
+        L.orc_decoder_lattice_size_ufp.argtypes = [C.c_void_p, C.c_int, C.POINTER(abi.LatticeSize)]
+        L.orc_decoder_get_raw_lattice_ufp.argtypes = [C.c_void_p, C.c_int, ip, ip, fp, fp, C.c_void_p]
         L.orc_lattice_best_path.argtypes = [C.c_int, C.c_int, fp, C.c_int, C.c_void_p, ip, C.c_int,
                                             ip, ip, C.c_int, ip, fp, fp]
         L.orc_decoder_get_trace.argtypes = [C.c_void_p, ip, fp, fp, C.c_int]
@@ -591,16 +593,21 @@ class Decoder:
     def FinalRelativeCost(self):
         return lib().orc_decoder_final_relative_cost(self._h)
 
-    def GetRawLattice(self):
+    def GetRawLattice(self, use_final_probs=True):
+        """lattice-faster-decoder.cc:113-196, also on a live decoder (final costs computed on the spot; use_final_probs
+        False -- legal only before FinalizeDecoding -- makes every token of the last frame final with weight One)."""
         sz = abi.LatticeSize()
-        if lib().orc_decoder_lattice_size(self._h, C.byref(sz)) != 0:
+        rc = lib().orc_decoder_lattice_size_ufp(self._h, int(bool(use_final_probs)), C.byref(sz))
+        if rc == -2:
+            raise ValueError("You cannot call FinalizeDecoding() and then call GetRawLattice() with use_final_probs == false")
+        if rc != 0:
             return None
         n, m = sz.num_states, sz.num_arcs
         fr, hc = np.zeros(n, np.int32), np.zeros(n, np.int32)
         co, fi = np.zeros(n, np.float32), np.zeros(n, np.float32)
         arcs = np.zeros(m, abi.LAT_ARC_DTYPE)
-        lib().orc_decoder_get_raw_lattice(self._h, abi.iptr(fr), abi.iptr(hc), abi.fptr(co),
-                                          abi.fptr(fi), arcs.ctypes.data_as(C.c_void_p))
+        lib().orc_decoder_get_raw_lattice_ufp(self._h, int(bool(use_final_probs)), abi.iptr(fr), abi.iptr(hc), abi.fptr(co),
+                                              abi.fptr(fi), arcs.ctypes.data_as(C.c_void_p))
         return Lattice(sz.start, fr, hc, co, fi, arcs, sz.num_frames)
 
     def trace(self):

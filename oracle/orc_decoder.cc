@@ -609,7 +609,7 @@ struct Decoder {
     std::vector<kamd_lat_arc> arcs;
     int start;
   };
-  bool GetRawLattice(RawLat *out) {
+  bool GetRawLattice(RawLat *out, bool use_final_probs = true) {
     std::vector<std::pair<int, float> > fc_local;
     const std::vector<std::pair<int, float> > *fc = &final_costs;
     if (!decoding_finalized) {
@@ -637,7 +637,7 @@ struct Decoder {
         out->cost.push_back(toks[v[i].second].tot_cost);
         float fin = kInf;
         if (f == num_frames) {  // :183-192
-          if (!fc->empty()) fin = fdense[v[i].second];
+          if (use_final_probs && !fc->empty()) fin = fdense[v[i].second];
           else fin = 0.0f;  // LatticeWeight::One()
         }
         out->final.push_back(fin);
@@ -750,6 +750,28 @@ int orc_decoder_lattice_size(orc_decoder *d, kamd_lattice_size *sz) {
   sz->num_frames = d->NumFramesDecoded();
   sz->start = ok ? g_lat.start : -1;
   return ok ? 0 : -1;
+}
+// the same with GetRawLattice's use_final_probs argument (false is only legal before FinalizeDecoding, :117-120)
+int orc_decoder_lattice_size_ufp(orc_decoder *d, int use_final_probs, kamd_lattice_size *sz) {
+  if (d->decoding_finalized && !use_final_probs) return -2;
+  bool ok = d->GetRawLattice(&g_lat, use_final_probs != 0);
+  sz->num_states = ok ? static_cast<int32_t>(g_lat.frame.size()) : 0;
+  sz->num_arcs = ok ? static_cast<int32_t>(g_lat.arcs.size()) : 0;
+  sz->num_frames = d->NumFramesDecoded();
+  sz->start = ok ? g_lat.start : -1;
+  return ok ? 0 : -1;
+}
+int orc_decoder_get_raw_lattice_ufp(orc_decoder *d, int use_final_probs, int32_t *state_frame, int32_t *state_hclg,
+                                    float *state_cost, float *state_final, kamd_lat_arc *arcs) {
+  Decoder::RawLat lat;
+  if (!d->GetRawLattice(&lat, use_final_probs != 0)) return -1;
+  size_t n = lat.frame.size();
+  memcpy(state_frame, lat.frame.data(), n * 4);
+  memcpy(state_hclg, lat.hclg.data(), n * 4);
+  memcpy(state_cost, lat.cost.data(), n * 4);
+  memcpy(state_final, lat.final.data(), n * 4);
+  if (!lat.arcs.empty()) memcpy(arcs, lat.arcs.data(), lat.arcs.size() * sizeof(kamd_lat_arc));
+  return 0;
 }
 int orc_decoder_get_raw_lattice(orc_decoder *d, int32_t *state_frame, int32_t *state_hclg,
                                 float *state_cost, float *state_final, kamd_lat_arc *arcs) {

@@ -294,7 +294,7 @@ int main(int argc, char **argv) {
       mo.c.frame.dither = 0.0f; mo.c.use_energy = 0; mo.c.mel.num_bins = 40; mo.c.num_ceps = 40; mo.c.mel.low_freq = 20; mo.c.mel.high_freq = -400;
       SingleUtteranceNnet3Decoder sdec(config, id2pdf, am, fst, mo, &sz);
       const size_t chunk = 2880;
-      int partials = 0;
+      int partials = 0, live_lattices = 0;
       // endpointing: options through ParseOptions like online2-wav-nnet3-latgen-faster; every unit counts as silence
       // here (the walk goes all the way back; the stop at the first non-silence frame is covered by test_gpu_online.py)
       OnlineEndpointConfig ep;
@@ -319,6 +319,19 @@ int main(int argc, char **argv) {
         sdec.AdvanceDecoding();
         std::vector<int32> ali, words; BaseFloat g, a;
         if (sdec.NumFramesDecoded() > 0 && sdec.GetBestPath(false, &ali, &words, &g, &a)) partials++;
+        // GetLattice(end_of_utterance = false) on the live decoder (online-nnet3-decoding.cc:66-79) + GetRawLatticePruned
+        if (sdec.NumFramesDecoded() > 0) {
+          CompactLattice partial_clat;
+          sdec.GetLattice(false, std::vector<int32>(), &partial_clat);
+          int32 pn = 0, pm = 0, pk = 0, pst = 0, pok = 0;
+          kamd_compact_lattice_sizes(partial_clat.Handle(), &pn, &pm, &pk, &pst, &pok);
+          Lattice raw, pruned;
+          sdec.Decoder().GetRawLattice(&raw, false);
+          sdec.Decoder().GetRawLatticePruned(&pruned, false, 2.0f);
+          if (pn <= 0 || raw.NumStates() <= 0 || pruned.NumStates() <= 0 || pruned.NumStates() > raw.NumStates())
+            throw KaldiFatalError("partial lattice of the live decoder is empty or the pruned one larger than the full one");
+          live_lattices++;
+        }
         std::vector<int32> det, tsf;
         EndpointDetected(ep, tid2phone, 0.03f, sdec.Decoder().Handle(), std::vector<int32>(1, 0), &det, &tsf);
         if (det[0] != (sdec.EndpointDetected(ep, tid2phone) ? 1 : 0)) throw KaldiFatalError("the two endpointing calls disagree");
@@ -330,6 +343,7 @@ int main(int argc, char **argv) {
       sdec.FinalizeDecoding();
       std::vector<int32> ali, words; BaseFloat g = 0, a = 0;
       const bool ok = sdec.GetBestPath(true, &ali, &words, &g, &a);
+      printf("live lattices=%d\n", live_lattices > 0);
       printf("streaming ok=%d frames=%d partials=%d graph=%.9g acoustic=%.9g words=", ok, sdec.NumFramesDecoded(), partials > 0, g, a);
       for (size_t i = 0; i < words.size(); i++) printf("%d%s", words[i], i + 1 < words.size() ? "," : "");
       printf("\n");

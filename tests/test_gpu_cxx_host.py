@@ -175,6 +175,7 @@ def test_cxx_host_api(tmp_path):
     off = decoder.LatticeFasterDecoder(decoder.Graph(g), abi.decoder_config_recipe())
     off.Decode(decoder.Nnet(m).Forward(feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(wave)))
     ob = off.GetBestPath()
+    assert "live lattices=1" in out           # GetLattice(end_of_utterance = false) / GetRawLattice / GetRawLatticePruned on the live decoder
     srow = [l for l in out if l.startswith("streaming ")][0]
     assert srow.startswith("streaming ok=1 frames=%d partials=1 " % off.NumFramesDecoded())
     assert srow.endswith("words=" + ",".join(str(w) for w in ob["words"]))

@@ -702,3 +702,61 @@ def test_shared_extractor_between_stream_batches_and_offline_calls():
         np.testing.assert_array_equal(slots2, slots)
         np.testing.assert_array_equal(sbs[w].adaptation_state(0, max_remembered_frames=1e9), state)
         assert lattices_equal(sbs[w].raw_lattice(0), lat)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_raw_lattice_of_a_live_decoder_after_every_chunk(mode):
+    """GetRawLattice before FinalizeDecoding (lattice-faster-decoder.cc:113-196 with !decoding_finalized_; what
+    SingleUtteranceNnet3Decoder::GetLattice(end_of_utterance = false) reads, online-nnet3-decoding.cc:66-79): after every
+    chunk of AdvanceDecoding the device's live lattice -- every token and link, final costs computed on the spot, both
+    values of use_final_probs -- equals the oracle's in the same search mode bit for bit; reading it changes nothing
+    (the final lattice equals the uninterrupted decode's); GetRawLatticePruned keeps exactly the states and arcs on paths
+    within the beam (checked against a brute-force forward-backward); GetLattice = its pruned determinization."""
+    g = synth.make_hclg(num_units=24, vocab=60, n_hist=10, seed=6)
+    cfg = abi.decoder_config_recipe()
+    cfg.max_active = 60                                   # binds: the two search modes really differ
+    G = decoder.Graph(g)
+    ll, words, _ = synth.sample_utterance(g, n_words=7, seed=31, peak=2.5, noise=1.2)
+    sizes = abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512)
+    d = decoder.LatticeFasterDecoder(G, cfg, sizes)
+    d.SetSearchMode(mode)
+    o = orc.Decoder(g, cfg, mode)
+    d.InitDecoding(); o.InitDecoding()
+    pos, saw_final_difference = 0, False
+    for n in (1, 2, 5, 3, 9, 4, 1000):
+        chunk = ll[pos:pos + n]
+        if chunk.shape[0] == 0:
+            break
+        pos += chunk.shape[0]
+        d.AdvanceDecoding(decoder.DeviceMatrix(chunk)); o.AdvanceDecoding(chunk)
+        for ufp in (True, False):
+            got, want = d.GetRawLattice(use_final_probs=ufp), o.GetRawLattice(use_final_probs=ufp)
+            assert lattices_equal(got, want), (pos, ufp, lattice_diff(got, want))
+        a, b = d.GetRawLattice(True), d.GetRawLattice(False)
+        saw_final_difference |= not np.array_equal(a.final, b.final)
+        # GetRawLatticePruned: the states / arcs on paths within the beam, by a brute-force forward-backward on the live lattice
+        beam = 3.0
+        pr = d.GetRawLatticePruned(False, beam)
+        n_st = b.frame.size
+        w = b.arcs["graph_cost"].astype(np.float64) + b.arcs["acoustic_cost"].astype(np.float64)
+        fwd, bwd = np.full(n_st, np.inf), np.where(np.isfinite(b.final), b.final.astype(np.float64), np.inf)
+        fwd[b.start] = 0.0
+        for _ in range(n_st):                             # Bellman-Ford sweeps (a small acyclic lattice)
+            f2, b2 = fwd.copy(), bwd.copy()
+            np.minimum.at(f2, b.arcs["dst"], fwd[b.arcs["src"]] + w)
+            np.minimum.at(b2, b.arcs["src"], bwd[b.arcs["dst"]] + w)
+            if np.array_equal(f2, fwd) and np.array_equal(b2, bwd):
+                break
+            fwd, bwd = f2, b2
+        keep = fwd + bwd <= bwd[b.start] + beam
+        assert pr.frame.size == int(keep.sum()) and np.array_equal(pr.hclg, b.hclg[keep]) and np.array_equal(pr.frame, b.frame[keep])
+        assert pr.arcs.size == int((fwd[b.arcs["src"]] + w + bwd[b.arcs["dst"]] <= bwd[b.start] + beam).sum())
+    assert saw_final_difference
+    d.FinalizeDecoding(); o.FinalizeDecoding()
+    assert lattices_equal(d.GetRawLattice(), o.GetRawLattice())
+    with pytest.raises(Exception):
+        d.GetRawLattice(use_final_probs=False)            # :117-120: not after FinalizeDecoding
+    ref = decoder.LatticeFasterDecoder(G, cfg, sizes)
+    ref.SetSearchMode(mode)
+    ref.Decode(decoder.DeviceMatrix(ll))
+    assert lattices_equal(d.GetRawLattice(), ref.GetRawLattice())
