@@ -714,7 +714,7 @@ def test_raw_lattice_of_a_live_decoder_after_every_chunk(mode):
     within the beam (checked against a brute-force forward-backward); GetLattice = its pruned determinization."""
     g = synth.make_hclg(num_units=24, vocab=60, n_hist=10, seed=6)
     cfg = abi.decoder_config_recipe()
-    cfg.max_active = 60                                   # binds: the two search modes really differ
+    cfg.max_active, cfg.min_active = 60, 20               # max-active binds: the two search modes really differ
     G = decoder.Graph(g)
     ll, words, _ = synth.sample_utterance(g, n_words=7, seed=31, peak=2.5, noise=1.2)
     sizes = abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512)
