@@ -229,6 +229,35 @@ int kamd_nnet_forward_range(kamd_nnet *n, const float *d_feats, int ld_in, int f
 /* total multiply-accumulates of the last forward (for the MFMA roofline). */
 double kamd_nnet_last_flops(const kamd_nnet *n);
 
+/* ----------------------------------------------------------------- model -- */
+/* final.mdl -> what the decode path consumes.  Replaces, for this path, what the binary does
+ * before it decodes (nnet3bin/nnet3-latgen-faster.cc:91-104): ReadKaldiObject of the
+ * TransitionModel (hmm/transition-model.cc:394-420) and the AmNnetSimple (nnet3/am-nnet-simple.cc:
+ * 44-54; Nnet::Read nnet3/nnet-nnet.cc:586-628), then SetBatchnormTestMode / SetDropoutTestMode /
+ * CollapseModel (nnet3/nnet-utils.cc:2006), folded into kamd_layer_desc[] together with the
+ * decodable's "-log prior, * acoustic_scale" (nnet-am-decodable-simple.cc:268-271).
+ * Binary models only (text ones: nnet3-am-copy --binary=true).  The graph may use TdnnComponent,
+ * (NaturalGradient|Fixed)AffineComponent, LinearComponent, RectifiedLinear, BatchNorm, the
+ * per-element scale / offset components, dropout / no-op, LogSoftmax, and descriptors Offset,
+ * Append (slices of one producer + ReplaceIndex(ivector, t, 0)), Scale, Sum (one bypass per layer);
+ * anything else is an error (NULL, kamd_last_error() names the node). */
+typedef struct kamd_model kamd_model;
+kamd_model *kamd_model_read(const char *path, float acoustic_scale, int frame_subsampling_factor);
+void kamd_model_destroy(kamd_model *m);
+/* Any out pointer may be NULL.  num_tids = TransitionModel::NumTransitionIds(). */
+int kamd_model_info(const kamd_model *m, int32_t *num_layers, int32_t *input_dim, int32_t *ivector_dim,
+                    int32_t *num_pdfs, int32_t *num_tids, int32_t *frame_subsampling_factor);
+/* The fused layers (num_layers of them); the pointers inside stay valid until kamd_model_destroy. */
+const kamd_layer_desc *kamd_model_layers(const kamd_model *m);
+/* Tables indexed by transition-id, [num_tids + 1] each (index 0 unused), any may be NULL:
+ * id2pdf = TransitionModel::TransitionIdToPdf (the decoder graph's ilabel -> log-likelihood
+ * column), tid_phone = the phone a transition-id ENTERS (hmm-state 0, not a self-loop; 0 elsewhere:
+ * what DeterminizeLatticePhonePruned inserts, lat/determinize-lattice-pruned.cc:1401-1445),
+ * tid2phone = TransitionIdToPhone (endpointing, online2/online-endpoint.cc:72-93). */
+int kamd_model_transition_tables(const kamd_model *m, int32_t *id2pdf, int32_t *tid_phone, int32_t *tid2phone);
+/* = kamd_nnet_create(kamd_model_layers(m), ...): the weights go to HBM. */
+kamd_nnet *kamd_model_create_nnet(const kamd_model *m);
+
 /* ----------------------------------------------------------------- graph -- */
 /* == fst::StdArc memory layout (OpenFst 1.6.7 ArcTpl<TropicalWeight>):
  * {int ilabel; int olabel; float weight; int nextstate}; ilabel is a 1-based

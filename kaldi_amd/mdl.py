@@ -16,6 +16,7 @@ layer, tdnnf-layer, linear-component, prefinal-layer, output-layer); anything el
 PARITY UNPINNED: no model file exists in the reference tree; the layouts are restated from
 the in-tree Read/Write code and exercised by a writer that follows the Write functions
 (tests/mdl_writer.py, tests/test_mdl.py)."""
+import math
 import re
 import struct
 
@@ -336,6 +337,8 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
                 W = np.array(W, np.float32)
                 cs = np.full(len(offsets), whole_scale, np.float32) if not col_scales else np.asarray(col_scales, np.float32) * np.float32(whole_scale)
                 W[:, :len(offsets) * in_dim] *= np.repeat(cs, in_dim)[None, :]
+                if whole_scale != 1.0 and ivector_dim:      # Scale(s, Append(.., ReplaceIndex(ivector, t, 0))) scales the i-vector too
+                    W[:, len(offsets) * in_dim:] *= np.float32(whole_scale)
             layers.append(Layer(name, in_dim, W.shape[0], offsets, src, np.ascontiguousarray(W, np.float32),
                                 None if bias is None else bias.astype(np.float32), ivector_dim=ivector_dim))
             layer_of[name] = len(layers) - 1
@@ -367,7 +370,9 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
             mean, var = f["<StatsMean>"][0].astype(np.float32), f["<StatsVar>"][0].astype(np.float32)
             eps, rms = np.float32(_f(f["<Epsilon>"][0])), np.float32(_f(f["<TargetRms>"][0]))
             # ComputeDerived (nnet-normalize-component.cc:226-245)
-            scale = (np.maximum(var, np.float32(0.0)) + eps) ** np.float32(-0.5) * rms
+            # (the power in double through libm, rounded to float: bit-identical with csrc/mdl.cc; the reference's own
+            # powf differs from it by rounding in at most the rare double-rounding case)
+            scale = np.array([math.pow(float(v), -0.5) for v in np.maximum(var, np.float32(0.0)) + eps], np.float32) * rms
             offset = -mean * scale
             if L.bn_scale is not None:                     # two per-element affine maps compose
                 L.bn_offset = L.bn_offset * scale + offset
@@ -391,9 +396,45 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
         raise MdlError("the output node must be the last layer built")
     out = layers[out_idx]
     if priors.size:
-        out.post_offset = (-np.log(priors)).astype(np.float32)   # nnet-am-decodable-simple.cc:268-269
+        with np.errstate(divide="ignore"):
+            out.post_offset = np.array([-math.log(float(v)) if v > 0 else math.inf for v in priors], np.float32)   # nnet-am-decodable-simple.cc:268-269
     out.post_scale = float(acoustic_scale)
     m = Model(layers, inputs["input"], inputs.get("ivector", 0), frame_subsampling_factor, out.out_dim,
               name=str(path))
     m.tid2phone = tid2phone
     return m, id2pdf, tid_phone
+
+
+def read_mdl_native(path, acoustic_scale=1.0, frame_subsampling_factor=3):
+    """The same three results through the library's own reader (`kamd_model_read`, csrc/mdl.cc: what a C / C++ host
+    uses), copied out of the handle.  Bit-identical with read_mdl (tests/test_mdl.py, tests/test_xconfig_golden.py)."""
+    import ctypes as C
+
+    from . import _lib
+    L = _lib.lib()
+    h = L.kamd_model_read(str(path).encode(), float(acoustic_scale), int(frame_subsampling_factor))
+    if not h:
+        raise MdlError(L.kamd_last_error().decode())
+    try:
+        v = [C.c_int32() for _ in range(6)]
+        L.kamd_model_info(h, *[C.byref(x) for x in v])
+        n_layers, input_dim, ivector_dim, num_pdfs, num_tids, sub = [x.value for x in v]
+        tabs = [np.zeros(num_tids + 1, np.int32) for _ in range(3)]
+        L.kamd_model_transition_tables(h, *[t.ctypes.data_as(C.POINTER(C.c_int32)) for t in tabs])
+        descs = L.kamd_model_layers(h)
+
+        def arr(p, *shape):
+            return None if not p else np.ctypeslib.as_array(p, shape=shape).copy()
+        layers = []
+        for i in range(n_layers):
+            d = descs[i]
+            cols = d.n_offsets * d.in_dim + d.ivector_dim
+            layers.append(Layer("layer%d" % i, d.in_dim, d.out_dim, [int(d.offsets[j]) for j in range(d.n_offsets)], d.input_layer,
+                                arr(d.W, d.out_dim, cols), arr(d.bias, d.out_dim), bool(d.relu), arr(d.bn_scale, d.out_dim),
+                                arr(d.bn_offset, d.out_dim), d.bypass_layer, float(d.bypass_scale), d.ivector_dim,
+                                arr(d.post_offset, d.out_dim), float(d.post_scale), bool(d.log_softmax)))
+    finally:
+        L.kamd_model_destroy(h)
+    m = Model(layers, input_dim, ivector_dim, sub, num_pdfs, name=str(path))
+    m.tid2phone = tabs[2]
+    return m, tabs[0], tabs[1]

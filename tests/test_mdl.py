@@ -7,6 +7,25 @@ from oracle import orc
 from tests.mdl_writer import write_mdl
 
 
+def same_as_native(path, got, id2pdf, tid_phone, acoustic_scale=1.0, sub=3):
+    """kamd_model_read (csrc/mdl.cc, the reader a C / C++ host uses) against the Python reader: every field bit for bit."""
+    nat, id2pdf_n, tid_phone_n = mdl.read_mdl_native(path, acoustic_scale=acoustic_scale, frame_subsampling_factor=sub)
+    np.testing.assert_array_equal(id2pdf, id2pdf_n)
+    np.testing.assert_array_equal(tid_phone, tid_phone_n)
+    np.testing.assert_array_equal(got.tid2phone, nat.tid2phone)
+    assert (nat.input_dim, nat.ivector_dim, nat.subsampling, nat.num_pdfs, len(nat.layers)) == \
+           (got.input_dim, got.ivector_dim, got.subsampling, got.num_pdfs, len(got.layers))
+    for a, b in zip(nat.layers, got.layers):
+        assert (a.in_dim, a.out_dim, list(a.offsets), a.input_layer, a.bypass_layer, bool(a.relu), a.ivector_dim, bool(a.log_softmax)) == \
+               (b.in_dim, b.out_dim, list(b.offsets), b.input_layer, b.bypass_layer, bool(b.relu), b.ivector_dim, bool(b.log_softmax)), b.name
+        assert np.float32(a.bypass_scale) == np.float32(b.bypass_scale) and np.float32(a.post_scale) == np.float32(b.post_scale), b.name
+        for f in ("W", "bias", "bn_scale", "bn_offset", "post_offset"):
+            x, y = getattr(a, f), getattr(b, f)
+            assert (x is None) == (y is None), (b.name, f)
+            if x is not None:
+                np.testing.assert_array_equal(x, np.asarray(y, np.float32).reshape(x.shape), err_msg="%s.%s" % (b.name, f))
+
+
 def test_tdnnf_model_round_trip(tmp_path):
     m = nnet.make_tdnnf(48, 16, [1, 1, 0, 3, 3], 24, 60, input_dim=40, ivector_dim=10, seed=4)
     p = tmp_path / "final.mdl"
@@ -14,6 +33,7 @@ def test_tdnnf_model_round_trip(tmp_path):
     got, id2pdf2, tid_phone2 = mdl.read_mdl(p, acoustic_scale=m.layers[-1].post_scale)
     np.testing.assert_array_equal(id2pdf, id2pdf2)
     np.testing.assert_array_equal(tid_phone, tid_phone2)
+    same_as_native(p, got, id2pdf2, tid_phone2, acoustic_scale=m.layers[-1].post_scale)
     assert len(got.layers) == len(m.layers) and got.input_dim == 40 and got.ivector_dim == 10
     for a, b in zip(got.layers, m.layers):
         assert (a.in_dim, a.out_dim, list(a.offsets), a.input_layer, a.bypass_layer, a.relu, a.ivector_dim) == \
@@ -143,7 +163,8 @@ def test_components_outside_the_tdnnf_recipes(tmp_path):
         blob += mw.tok("<ComponentName>") + mw.tok(name) + body
     blob += mw.tok("</Nnet3>") + mw.tok("<LeftContext>") + mw.i32(0) + mw.tok("<RightContext>") + mw.i32(0) + mw.tok("<Priors>") + mw.vec(np.zeros(0))
     (tmp_path / "odd.mdl").write_bytes(blob)
-    model, _, _ = mdl.read_mdl(tmp_path / "odd.mdl", acoustic_scale=1.0, frame_subsampling_factor=1)
+    model, i2p, tph = mdl.read_mdl(tmp_path / "odd.mdl", acoustic_scale=1.0, frame_subsampling_factor=1)
+    same_as_native(tmp_path / "odd.mdl", model, i2p, tph, sub=1)
     assert len(model.layers) == 4 and model.layers[1].bypass_layer == 0 and model.layers[1].bypass_scale == 1.0
     T = 23
     x = rng.standard_normal((T, D)).astype(np.float32)
@@ -168,3 +189,26 @@ def test_components_outside_the_tdnnf_recipes(tmp_path):
     want = out[-lo:-lo + T]
     got = forward_ref(model, x)
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4)
+
+
+def test_native_reader_errors_name_the_problem(tmp_path):
+    import pytest
+    with pytest.raises(mdl.MdlError, match="cannot open"):
+        mdl.read_mdl_native(tmp_path / "absent.mdl")
+    (tmp_path / "text.mdl").write_bytes(b"<TransitionModel> \n")
+    with pytest.raises(mdl.MdlError, match="binary Kaldi file expected"):
+        mdl.read_mdl_native(tmp_path / "text.mdl")
+    m = nnet.make_tdnnf(48, 16, [1, 0], 24, 60, input_dim=40, seed=4)
+    p = tmp_path / "final.mdl"
+    write_mdl(p, m, num_units=30)
+    blob = p.read_bytes()
+    (tmp_path / "cut.mdl").write_bytes(blob[:len(blob) // 2])
+    with pytest.raises(mdl.MdlError, match="unexpected end of file"):
+        mdl.read_mdl_native(tmp_path / "cut.mdl")
+    bad = blob.replace(b"<RectifiedLinearComponent>", b"<SigmoidBlahBlahComponent>").replace(b"</RectifiedLinearComponent>", b"</SigmoidBlahBlahComponent>")
+    assert bad != blob
+    (tmp_path / "bad.mdl").write_bytes(bad)
+    with pytest.raises(mdl.MdlError, match="unsupported component type SigmoidBlahBlahComponent"):
+        mdl.read_mdl_native(tmp_path / "bad.mdl")
+    with pytest.raises(mdl.MdlError, match="unsupported component type SigmoidBlahBlahComponent"):
+        mdl.read_mdl(tmp_path / "bad.mdl")

@@ -35,6 +35,8 @@ def _load(name, tmp_path, seed=0):
     path = tmp_path / (name + ".mdl")
     xconfig_mdl.write_mdl_from_config(path, text, params, priors, num_units=P // 2)
     model, id2pdf, tid_phone = mdl.read_mdl(path, acoustic_scale=1.0)
+    from tests.test_mdl import same_as_native
+    same_as_native(path, model, id2pdf, tid_phone)          # kamd_model_read (csrc/mdl.cc) reads the same file to the same bits
     return text, params, priors, model
 
 
