@@ -319,6 +319,13 @@ typedef struct {
   int32_t max_frames;         /* frames per lane */
 } kamd_decoder_sizes;
 void kamd_decoder_sizes_default(kamd_decoder_sizes *s);
+/* Sizes for max_lanes lanes of at most max_frames decoded frames each (avg_frames on average, 0 = max_frames:
+ * kamd_decoder_reserve splits the pools by utterance length), scaled down to hbm_fraction (0 = 0.5) of the
+ * HBM that is free at the call.  hash_capacity / tokens_per_frame / links_per_frame: 0 = derived from
+ * cfg->max_active (3 x max_active + 2000 tokens a frame, capped at 62000). */
+int kamd_decoder_sizes_suggest(const kamd_decoder_config *cfg, int max_lanes, int max_frames, int avg_frames,
+                               int hash_capacity, int tokens_per_frame, int links_per_frame, float hbm_fraction,
+                               kamd_decoder_sizes *out);
 
 typedef struct kamd_decoder kamd_decoder;
 /* LatticeFasterDecoderTpl(const FST&, const Config&) (lattice-faster-decoder.cc:
@@ -520,7 +527,8 @@ int kamd_wave_read(const char *path, float *samp_freq, int32_t *num_channels, in
  * (advanced past it; key == NULL: the object itself starts at *offset, as an scp line's
  * "file:offset" points): binary FM / DM, compressed CM / CM2 / CM3 or text
  * (matrix/kaldi-matrix.cc:1378-1512, matrix/compressed-matrix.cc:566-650).  Returns 1 at end of
- * file.  *data row-major [rows x cols], malloc'ed. */
+ * file.  *data row-major [rows x cols], malloc'ed.  A float VECTOR entry (binary FV / DV, text
+ * " [ 1 2 3 ]": BaseFloatVectorHolder, e.g. an --ivectors archive) comes back as one row. */
 int kamd_ark_read_matrix(const char *path, int64_t *offset, char *key, int key_cap, int32_t *rows,
                          int32_t *cols, float **data);
 int kamd_ark_write_matrix(const char *path, int append, const char *key, int binary, int32_t rows,

@@ -9,6 +9,7 @@
 //   kaldi_amd::DecodableMatrixMapped      decoder/decodable-matrix.h:98-136
 //   kaldi_amd::MfccOptions / Mfcc         feat/feature-mfcc.h:38-56, feature-common.h:111
 //   kaldi_amd::NnetBatchDecoder           nnet3/nnet-batch-compute.h:606-833
+//   kaldi_amd::TransitionModelAndNnet     nnet3bin/nnet3-latgen-faster.cc:91-104 (what is read from <nnet-in>)
 //   kaldi_amd::ConstArpaLm                lm/const-arpa-lm.h:211-352
 // Errors: the reference's KALDI_ERR throws kaldi::KaldiFatalError (std::runtime_error,
 // base/kaldi-error.h:89-140); here every non-zero C-ABI status throws
@@ -23,12 +24,15 @@
 #include <cstdint>
 #include <cstdio>
 #include <limits>
+#include <map>
 #include <stdexcept>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
 #include <vector>
+
+#include <unistd.h>
 
 #include "kaldi_amd.h"
 
@@ -392,17 +396,50 @@ inline bool DeterminizeLatticePhonePrunedWrapper(const std::vector<int32> &tid_p
 /// forms "ark:FILE" (binary) and "ark,t:FILE" (text) (util/kaldi-table.h:277-330).
 class TableWriterBase {
  public:
-  explicit TableWriterBase(const std::string &wspecifier) : first_(true) {
-    const size_t colon = wspecifier.find(':');
-    if (colon == std::string::npos || wspecifier.compare(0, 3, "ark") != 0) throw KaldiFatalError("unsupported wspecifier " + wspecifier);
-    binary_ = wspecifier.substr(0, colon).find(",t") == std::string::npos;
-    path_ = wspecifier.substr(colon + 1);
+  /// "ark[,t]:" + a file, "-" or "| command" (ClassifyWspecifier, util/kaldi-table.cc:115-222; WX_PIPE / WX_STDOUT
+  /// of util/kaldi-io.cc:85-130: the entries are spooled to a temporary file that Close() / the destructor streams out)
+  explicit TableWriterBase(const std::string &wspecifier) : first_(true), sink_(0) {
+    char ark[4096], scp[16]; int opts = 0;
+    const int t = kamd_classify_wspecifier(wspecifier.c_str(), ark, sizeof(ark), scp, sizeof(scp), &opts);
+    if (t != 1) throw KaldiFatalError("unsupported wspecifier " + wspecifier + " (an \"ark:\" one is expected)");
+    binary_ = (opts & KAMD_WSPEC_BINARY) != 0;
+    const int wx = kamd_classify_wxfilename(ark);
+    if (wx == KAMD_WX_FILE) { path_ = ark; return; }
+    if (wx != KAMD_WX_STDOUT && wx != KAMD_WX_PIPE) throw KaldiFatalError("invalid output filename " + std::string(ark));
+    sink_ = wx; target_ = ark;
+    char tmpl[] = "/tmp/kamd_table_XXXXXX";
+    const int fd = mkstemp(tmpl);
+    if (fd < 0) throw KaldiFatalError("cannot create a temporary file for " + wspecifier);
+    ::close(fd);
+    path_ = tmpl;
   }
+  virtual ~TableWriterBase() { try { Close(); } catch (...) {} }
   bool IsOpen() const { return !path_.empty(); }
+  /// streams a spooled table to its pipe / stdout; false if the command fails (TableWriter::Close)
+  bool Close() {
+    if (!sink_) return true;
+    const int kind = sink_;
+    sink_ = 0;
+    bool ok = true;
+    if (first_) { FILE *e = fopen(path_.c_str(), "wb"); if (e) fclose(e); }       // nothing written: an empty stream
+    FILE *in = fopen(path_.c_str(), "rb");
+    FILE *out = kind == KAMD_WX_STDOUT ? stdout : popen(target_.substr(target_.find('|') + 1).c_str(), "w");
+    if (!in || !out) ok = false;
+    else {
+      char buf[1 << 16]; size_t n;
+      while ((n = fread(buf, 1, sizeof(buf), in)) > 0) if (fwrite(buf, 1, n, out) != n) { ok = false; break; }
+    }
+    if (in) fclose(in);
+    if (out && kind == KAMD_WX_PIPE) ok = pclose(out) == 0 && ok; else if (out) fflush(out);
+    remove(path_.c_str());
+    if (!ok) throw KaldiFatalError("error closing the table " + target_);
+    return ok;
+  }
  protected:
   int Append() { const int a = first_ ? 0 : 1; first_ = false; return a; }
-  std::string path_;
+  std::string path_, target_;
   bool binary_, first_;
+  int sink_;
 };
 class LatticeWriter : public TableWriterBase {
  public:
@@ -532,10 +569,41 @@ class Fbank {
 
 // ------------------------------------------------ online2/online-nnet3-decoding.h:52-121
 /// The acoustic model handle (nnet3::AmNnetSimple after CollapseModel): kamd_layer_desc list.
+/// What the decode binaries read from <nnet-in> (nnet3bin/nnet3-latgen-faster.cc:91-104: TransitionModel, then
+/// AmNnetSimple, then SetBatchnormTestMode / SetDropoutTestMode / CollapseModel): kamd_model_read.  The tables are the
+/// uses the path makes of the TransitionModel (TransitionIdToPdf, the phone a transition-id enters, TransitionIdToPhone).
+class TransitionModelAndNnet {
+ public:
+  TransitionModelAndNnet(const std::string &filename, BaseFloat acoustic_scale, int32 frame_subsampling_factor)
+      : m_(CheckPtr(kamd_model_read(filename.c_str(), acoustic_scale, frame_subsampling_factor))) {
+    int32 n = 0;
+    kamd_model_info(m_, &num_layers_, &input_dim_, &ivector_dim_, &num_pdfs_, &n, &subsampling_);
+    id2pdf_.resize(n + 1); tid_phone_.resize(n + 1); tid2phone_.resize(n + 1);
+    kamd_model_transition_tables(m_, id2pdf_.data(), tid_phone_.data(), tid2phone_.data());
+  }
+  ~TransitionModelAndNnet() { kamd_model_destroy(m_); }
+  TransitionModelAndNnet(const TransitionModelAndNnet &) = delete;
+  TransitionModelAndNnet &operator=(const TransitionModelAndNnet &) = delete;
+  const kamd_model *Handle() const { return m_; }
+  const std::vector<int32> &Id2Pdf() const { return id2pdf_; }          // index 0 unused
+  const std::vector<int32> &TidPhone() const { return tid_phone_; }
+  const std::vector<int32> &Tid2Phone() const { return tid2phone_; }
+  int32 NumTransitionIds() const { return static_cast<int32>(id2pdf_.size()) - 1; }
+  int32 NumPdfs() const { return num_pdfs_; }
+  int32 InputDim() const { return input_dim_; }
+  int32 IvectorDim() const { return ivector_dim_; }
+  int32 NumLayers() const { return num_layers_; }
+ private:
+  kamd_model *m_;
+  int32 num_layers_ = 0, input_dim_ = 0, ivector_dim_ = 0, num_pdfs_ = 0, subsampling_ = 0;
+  std::vector<int32> id2pdf_, tid_phone_, tid2phone_;
+};
+
 class AmNnetSimple {
  public:
   AmNnetSimple(const std::vector<kamd_layer_desc> &layers, int32 input_dim, int32 frame_subsampling_factor)
       : n_(CheckPtr(kamd_nnet_create(layers.data(), static_cast<int>(layers.size()), input_dim, frame_subsampling_factor))) {}
+  explicit AmNnetSimple(const TransitionModelAndNnet &model) : n_(CheckPtr(kamd_model_create_nnet(model.Handle()))) {}
   ~AmNnetSimple() { kamd_nnet_destroy(n_); }
   kamd_nnet *Handle() const { return n_; }
   int32 OutputDim() const { return kamd_nnet_output_dim(n_); }
@@ -885,6 +953,57 @@ class SequentialBaseFloatMatrixReader {
   bool done_;
   int32 rows_, cols_;
   std::vector<float> data_;
+};
+
+// ---- RandomAccessBaseFloatVectorReader (util/kaldi-table.h:400-470) for the --ivectors option: the table is read
+// once (a vector entry comes back from kamd_ark_read_matrix as one row)
+class RandomAccessBaseFloatVectorReader {
+ public:
+  explicit RandomAccessBaseFloatVectorReader(const std::string &rspecifier) {
+    for (SequentialBaseFloatMatrixReader r(rspecifier); !r.Done(); r.Next()) {
+      if (r.NumRows() > 1) throw KaldiFatalError("a vector table is expected: " + rspecifier + " (key " + r.Key() + ")");
+      map_[r.Key()] = r.Value();
+    }
+  }
+  bool HasKey(const std::string &key) const { return map_.count(key) != 0; }
+  const std::vector<float> &Value(const std::string &key) const {
+    std::map<std::string, std::vector<float> >::const_iterator it = map_.find(key);
+    if (it == map_.end()) throw KaldiFatalError("Value() called for a key that is not in the table: " + key);
+    return it->second;
+  }
+ private:
+  std::map<std::string, std::vector<float> > map_;
+};
+
+// ---- RandomAccessTokenReader (TokenHolder, util/kaldi-holder-inl.h:600-650) for --utt2spk: text lines "key token"
+class RandomAccessTokenReader {
+ public:
+  explicit RandomAccessTokenReader(const std::string &rspecifier) {
+    char rx[4096], buf[4096]; int opts = 0, temp = 0; int64_t off = 0;
+    if (kamd_classify_rspecifier(rspecifier.c_str(), rx, sizeof(rx), &opts) != 1) throw KaldiFatalError("an \"ark:\" rspecifier is expected: " + rspecifier);
+    Check(kamd_rx_materialize(rx, buf, sizeof(buf), &off, &temp));
+    FILE *f = fopen(buf, "r");
+    if (!f) throw KaldiFatalError(std::string("cannot open ") + buf);
+    if (off) fseek(f, static_cast<long>(off), SEEK_SET);
+    char line[8192];
+    while (fgets(line, sizeof(line), f)) {
+      char key[4096], tok[4096];
+      const int n = sscanf(line, "%4095s %4095s", key, tok);
+      if (n <= 0) continue;
+      if (n != 2) { fclose(f); throw KaldiFatalError("bad line in the token table " + rspecifier + ": " + line); }
+      map_[key] = tok;
+    }
+    fclose(f);
+    if (temp) remove(buf);
+  }
+  bool HasKey(const std::string &key) const { return map_.count(key) != 0; }
+  const std::string &Value(const std::string &key) const {
+    std::map<std::string, std::string>::const_iterator it = map_.find(key);
+    if (it == map_.end()) throw KaldiFatalError("Value() called for a key that is not in the table: " + key);
+    return it->second;
+  }
+ private:
+  std::map<std::string, std::string> map_;
 };
 
 // ---- nnet3/nnet-batch-compute.h:606-833 NnetBatchDecoder, as nnet3-latgen-faster-batch drives it

@@ -135,6 +135,8 @@ def lib():
     sig("kamd_graph_num_arcs", C.c_int64, [vp])
     sig("kamd_decoder_config_default", None, [C.POINTER(abi.DecoderConfig)])
     sig("kamd_decoder_sizes_default", None, [C.POINTER(abi.DecoderSizes)])
+    sig("kamd_decoder_sizes_suggest", C.c_int, [C.POINTER(abi.DecoderConfig), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                           C.POINTER(abi.DecoderSizes)])
     sig("kamd_decoder_create", vp, [vp, C.POINTER(abi.DecoderConfig), C.POINTER(abi.DecoderSizes), ip, C.c_int32])
     sig("kamd_decoder_destroy", None, [vp])
     sig("kamd_decoder_set_options", C.c_int, [vp, C.POINTER(abi.DecoderConfig)])
@@ -278,7 +280,7 @@ kamd_wave_read kamd_ark_read_matrix kamd_ark_write_matrix kamd_ark_read_int32_ve
 kamd_classify_rxfilename kamd_classify_wxfilename kamd_classify_rspecifier kamd_classify_wspecifier kamd_rx_materialize kamd_pipeline_load_features kamd_pipeline_set_overlap kamd_decoder_last_advance_launches
 kamd_am_gmm_create kamd_am_gmm_destroy kamd_am_gmm_num_pdfs kamd_am_gmm_dim kamd_am_gmm_loglikes_device kamd_am_gmm_loglikes kamd_feat_splice_transform_device kamd_feat_add_deltas_device kamd_cmvn_acc_stats_device kamd_cmvn_acc_stats_weighted_device kamd_cmvn_apply_device kamd_cmvn_apply_reverse_device kamd_ivector_extractor_create kamd_ivector_extractor_destroy kamd_ivector_dim kamd_ivector_period kamd_ivector_num_ivectors kamd_ivector_extract_online_device kamd_ivector_extract_online kamd_ivector_last_posteriors kamd_pipeline_set_ivector_extractor kamd_ivector_state_size kamd_ivector_extract_online_adapt_device kamd_ivector_state_limit_frames kamd_ivector_extract_online_adapt kamd_ivector_stream_record_size kamd_ivector_stream_record_init kamd_ivector_stream_update_device
 kamd_determinize_opts_default kamd_lattice_determinize_phone_pruned kamd_compact_lattice_destroy kamd_compact_lattice_sizes kamd_compact_lattice_get kamd_compact_lattice_write
-kamd_decoder_config_default kamd_decoder_sizes_default kamd_decoder_create kamd_decoder_destroy
+kamd_decoder_config_default kamd_decoder_sizes_default kamd_decoder_sizes_suggest kamd_decoder_create kamd_decoder_destroy
 kamd_decoder_set_options kamd_decoder_reserve kamd_decoder_init kamd_decoder_advance kamd_decoder_finalize
 kamd_decoder_sync kamd_decoder_num_frames_decoded kamd_decoder_final_relative_cost
 kamd_decoder_reached_final kamd_decoder_lattice_size kamd_decoder_get_raw_lattice

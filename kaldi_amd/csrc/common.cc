@@ -79,4 +79,36 @@ void kamd_decoder_sizes_default(kamd_decoder_sizes *s) {
   s->max_lanes = 64; s->hash_capacity = 1 << 17; s->arena_tokens = 1 << 22;
   s->arena_links = 1 << 23; s->max_frames = 2048;
 }
+// Arenas for `max_lanes` lanes of at most `max_frames` decoded frames each, `avg_frames` (0: max_frames) on average
+// (the pools are split between lanes in proportion to utterance length, kamd_decoder_reserve), kept within
+// `hbm_fraction` of the HBM that is free now (16 B per token record incl. its map entry, 24 B per link).
+int kamd_decoder_sizes_suggest(const kamd_decoder_config *cfg, int max_lanes, int max_frames, int avg_frames, int hash_capacity,
+                               int tokens_per_frame, int links_per_frame, float hbm_fraction, kamd_decoder_sizes *out) {
+  if (!cfg || !out || max_lanes < 1 || max_frames < 1) return kamd::SetError(KAMD_ERR_ARG, "kamd_decoder_sizes_suggest: bad arguments");
+  const double act = cfg->max_active < INT32_MAX ? cfg->max_active : 20000;
+  int64_t tpf = tokens_per_frame > 0 ? tokens_per_frame : static_cast<int64_t>(std::min(3.0 * act, 60000.0) + 2000);
+  int64_t lpf = links_per_frame > 0 ? links_per_frame : static_cast<int64_t>(1.6 * tpf + 2000);
+  int64_t hc = hash_capacity;
+  if (hc <= 0) {
+    const int64_t want = std::max<int64_t>(std::max<int64_t>(4 * tpf, max_frames + 8), 4096);
+    hc = 1;
+    while (hc < want) hc <<= 1;
+  }
+  const int64_t avg = (avg_frames > 0 ? avg_frames : max_frames) + 2;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+    const double need = static_cast<double>(max_lanes) * avg * (16.0 * tpf + 24.0 * lpf);
+    const double budget = static_cast<double>(hbm_fraction > 0 ? hbm_fraction : 0.5f) * free_b;
+    if (need > budget) {
+      const double k = budget / need;
+      tpf = std::max<int64_t>(4000, static_cast<int64_t>(tpf * k));
+      lpf = std::max<int64_t>(6000, static_cast<int64_t>(lpf * k));
+    }
+  } else {
+    (void)hipGetLastError();
+  }
+  out->max_lanes = max_lanes; out->hash_capacity = static_cast<int32_t>(hc);
+  out->arena_tokens = tpf * avg; out->arena_links = lpf * avg; out->max_frames = max_frames + 1;
+  return KAMD_OK;
+}
 }

@@ -61,6 +61,19 @@ bool ReadMatrixBody(File *f, bool binary, std::vector<float> *data, int32_t *row
       }
       return true;
     }
+    if (tok == "FV" || tok == "DV") {                  // Vector<float>::Write (kaldi-vector.cc:1110-1133): one row
+      if (!ReadI32(f, cols) || *cols < 0) { *err = "bad vector size"; return false; }
+      *rows = 1;
+      const size_t n = static_cast<size_t>(*cols);
+      data->resize(n);
+      if (tok == "FV") { if (!f->Bytes(data->data(), n * 4)) { *err = "truncated vector"; return false; } }
+      else {
+        std::vector<double> d(n);
+        if (!f->Bytes(d.data(), n * 8)) { *err = "truncated vector"; return false; }
+        for (size_t i = 0; i < n; i++) (*data)[i] = static_cast<float>(d[i]);
+      }
+      return true;
+    }
     if (tok == "CM" || tok == "CM2" || tok == "CM3") {
       // GlobalHeader without its first field (compressed-matrix.cc:576-584)
       struct { float min_value, range; int32_t num_rows, num_cols; } h;
@@ -97,7 +110,7 @@ bool ReadMatrixBody(File *f, bool binary, std::vector<float> *data, int32_t *row
       }
       return true;
     }
-    *err = "expected token FM, DM or CM*, got " + tok;
+    *err = "expected token FM, DM, CM*, FV or DV, got " + tok;
     return false;
   }
   // text: [ rows separated by newlines ]

@@ -13,20 +13,10 @@ def default_sizes(cfg, max_utts, max_out_frames, avg_out_frames=None, hash_capac
     """Device sizing: `max_utts` lanes, each at most `max_out_frames` decoded frames; the
     token / link pools hold `avg_out_frames` frames per lane on average (the pools are split
     between lanes in proportion to utterance length, kamd_decoder_reserve)."""
-    act = cfg.max_active if cfg.max_active < abi.INT32_MAX else 20000
-    tpf = tokens_per_frame or int(min(3.0 * act, 60000) + 2000)
-    lpf = links_per_frame or int(1.6 * tpf + 2000)
-    hc = hash_capacity or 1 << int(np.ceil(np.log2(max(4 * tpf, max_out_frames + 8, 4096))))
-    avg = (avg_out_frames or max_out_frames) + 2
-    # keep the arenas within `hbm_fraction` (half) of the free HBM (16 B per token record incl. map, 24 B per link)
-    free, total = C.c_size_t(), C.c_size_t()
-    if lib().kamd_device_mem_info(C.byref(free), C.byref(total)) == 0 and free.value > 0:
-        need = max_utts * avg * (16.0 * tpf + 24.0 * lpf)
-        budget = hbm_fraction * free.value
-        if need > budget:
-            k = budget / need
-            tpf, lpf = max(4000, int(tpf * k)), max(6000, int(lpf * k))
-    return abi.DecoderSizes(max_utts, hc, int(tpf) * avg, int(lpf) * avg, max_out_frames + 1)
+    out = abi.DecoderSizes()                      # the arithmetic lives in the library (kamd_decoder_sizes_suggest): C / C++ hosts size the same way
+    check(lib().kamd_decoder_sizes_suggest(C.byref(cfg), int(max_utts), int(max_out_frames), int(avg_out_frames or 0), int(hash_capacity or 0),
+                                           int(tokens_per_frame or 0), int(links_per_frame or 0), float(hbm_fraction), C.byref(out)))
+    return out
 
 
 class Pipeline:

@@ -203,3 +203,82 @@ def test_cxx_host_api(tmp_path):
     clat = open(tmp_path / "clat.ark", "rb").read()
     assert clat.startswith(b"utt-det ") and clat[8] == 214 and b"compactlattice44" in clat[:64]
     assert bp["words"].tolist() == words
+
+
+def test_nnet3_latgen_faster_example_writes_the_python_tools_archive(tmp_path):
+    """examples/nnet3_latgen_faster.cc -- final.mdl read by kamd_model_read, HCLG.fst by kamd_graph_read_openfst, the sets
+    run by the hpp's NnetBatchDecoder -- against tools/nnet3_latgen_faster_batch.py on the same files: the lattice archive
+    byte for byte (features + per-speaker i-vectors, compact lattices through an output pipe; waveforms in, raw lattices
+    out), the reference's warnings for a zero-length utterance and a missing i-vector, words / alignments tables."""
+    import struct
+    import sys
+    import wave
+    from kaldi_amd import feat, latbin, nnet, table
+    from kaldi_amd import io as kio
+    from tests.mdl_writer import write_mdl
+    lib = os.path.join(ROOT, "kaldi_amd", "lib")
+    exe = str(tmp_path / "nnet3-latgen-faster-amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "nnet3_latgen_faster.cc"),
+                           "-o", exe, "-L", lib, "-lkaldi_amd", "-lpthread", "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib"])
+    g = synth.make_hclg(num_units=25, vocab=60, n_hist=12, seed=6)
+    m_iv = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, ivector_dim=10, seed=12, output_scale=3.0)
+    m_plain = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, seed=12, output_scale=3.0)
+    write_mdl(tmp_path / "final_iv.mdl", m_iv, num_units=25)
+    write_mdl(tmp_path / "final.mdl", m_plain, num_units=25)
+    kio.write_openfst(tmp_path / "HCLG.fst", g, "const")
+    waves = [np.round(synth.make_wave(d, seed=50 + i)).astype(np.float32) for i, d in enumerate((1.2, 2.0, 0.8, 1.6, 1.1, 0.9))]
+    mf = feat.Mfcc(abi.mfcc_opts_hires())
+    with table.TableWriter("ark,scp:%s,%s" % (tmp_path / "feats.ark", tmp_path / "feats.scp"), "matrix") as w:
+        for i, wv in enumerate(waves):
+            w.write("utt%d" % i, mf.ComputeFeatures(wv))
+            if i == 1:
+                w.write("empty", np.zeros((0, 40), np.float32))
+    rng = np.random.default_rng(3)
+    with open(tmp_path / "ivectors.ark", "wb") as f:            # BaseFloatVectorWriter entries: key, "\0B", "FV ", size, data
+        for spk in ("spkA", "spkB"):
+            v = rng.standard_normal(10).astype(np.float32)
+            f.write(spk.encode() + b" \0BFV \x04" + struct.pack("<i", 10) + v.tobytes())
+    (tmp_path / "utt2spk").write_text("".join("utt%d %s\n" % (i, ("spkA", "spkB", "spkC")[i % 3]) for i in range(6)) + "empty spkA\n")
+    with open(tmp_path / "wav.scp", "w") as scp:
+        for i, wv in enumerate(waves):
+            with wave.open(str(tmp_path / ("u%d.wav" % i)), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(wv.astype("<i2").tobytes())
+            scp.write("utt%d %s\n" % (i, tmp_path / ("u%d.wav" % i)))
+    (tmp_path / "words.txt").write_text("".join("w%d %d\n" % (k, k) for k in range(0, 61)))
+    common = ["--beam=15", "--max-active=7000", "--lattice-beam=8", "--acoustic-scale=1.0", "--frame-subsampling-factor=3", "--search-mode=1"]
+    fst_ = str(tmp_path / "HCLG.fst")
+    iv = ["--ivectors=ark:%s" % (tmp_path / "ivectors.ark"), "--utt2spk=ark:%s" % (tmp_path / "utt2spk"), "--set-frames=250", "--num-threads=3",
+          "--word-symbol-table=%s" % (tmp_path / "words.txt"), str(tmp_path / "final_iv.mdl"), fst_, "scp:%s" % (tmp_path / "feats.scp")]
+    r = subprocess.run([exe] + common + iv + ["ark:| cat > %s" % (tmp_path / "cxx.lat"), "ark:%s" % (tmp_path / "words.ark"),
+                                              "ark,t:%s" % (tmp_path / "ali.txt")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    p = subprocess.run([sys.executable, ROOT + "/tools/nnet3_latgen_faster_batch.py"] + common + iv + ["ark:%s" % (tmp_path / "py.lat")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert open(tmp_path / "cxx.lat", "rb").read() == open(tmp_path / "py.lat", "rb").read()
+    lats = list(latbin.read_lattices("ark:%s" % (tmp_path / "cxx.lat")))
+    assert [k for k, _ in lats] == ["utt0", "utt1", "utt3", "utt4"]        # utt2 / utt5 are spkC's: no i-vector; input order over sets
+    for text in (r.stderr, p.stderr):
+        assert "Zero-length utterance: empty" in text and "No iVector available for utterance utt2" in text
+        assert "Decoded 7 utterances, 3 with errors." in text
+    assert sorted(l for l in r.stderr.splitlines() if l.startswith("utt")) == sorted(l for l in p.stderr.splitlines() if l.startswith("utt"))
+    assert sorted(l for l in r.stderr.splitlines() if "Log-like per frame" in l) == sorted(l for l in p.stderr.splitlines() if "Log-like per frame" in l)
+    words = dict(table.SequentialTableReader("ark:%s" % (tmp_path / "words.ark"), "int32"))
+    ali = {l.split()[0]: [int(x) for x in l.split()[1:]] for l in open(tmp_path / "ali.txt")}
+    for k, lat in lats:
+        bp_words, bp_ali = latbin.best_path(lat)[:2]
+        assert list(words[k]) == [int(x) for x in bp_words] and ali[k] == [int(x) for x in bp_ali]
+    # waveforms in (features on the device), raw lattices out, one set
+    wv = ["--wav", "--determinize-lattice=false", str(tmp_path / "final.mdl"), fst_, "scp:%s" % (tmp_path / "wav.scp")]
+    r = subprocess.run([exe] + common + wv + ["ark:%s" % (tmp_path / "cxx_raw.lat")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    p = subprocess.run([sys.executable, ROOT + "/tools/nnet3_latgen_faster_batch.py"] + common + wv + ["ark:%s" % (tmp_path / "py_raw.lat")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert open(tmp_path / "cxx_raw.lat", "rb").read() == open(tmp_path / "py_raw.lat", "rb").read()
+    assert "Decoded 6 utterances, 0 with errors." in r.stderr
+    # the reference's exits: usage without arguments, 255 + a message for a model that is not there
+    assert subprocess.run([exe], capture_output=True).returncode == 1
+    bad = subprocess.run([exe] + common + [str(tmp_path / "absent.mdl"), fst_, "scp:%s" % (tmp_path / "feats.scp"), "ark:/dev/null"],
+                         capture_output=True, text=True)
+    assert bad.returncode == 255 and "cannot open" in bad.stderr
