@@ -72,6 +72,14 @@ def parse_args():
     ap.add_argument("--no-planted", action="store_true", help="skip the planted-transcript variant")
     ap.add_argument("--planted-peak", type=float, default=8.3)
     ap.add_argument("--planted-noise", type=float, default=3.0)
+    ap.add_argument("--ivectors", action="store_true", help="the recipe's model input (run_tdnn_1d.sh:220 `input dim=100 name=ivector`): "
+                    "100-dim online i-vectors estimated on the device from every pass's features, the acoustic model evaluated chunk by chunk "
+                    "(--frames-per-chunk 50) like nnet3-latgen-faster --online-ivectors (steps/nnet3/decode.sh:105-107).  Without the flag the "
+                    "default run measures this as the `online_ivectors` leg")
+    ap.add_argument("--no-ivector-leg", action="store_true")
+    ap.add_argument("--ll-std-ivectors", type=float, default=0.96, help="calibration of the i-vector model: the spread at which ITS search load is the "
+                    "token-matched one (>= 3 k expanded tokens per frame; the per-chunk i-vector adds a component that is constant over a chunk, so the "
+                    "same spread prunes harder than without it)")
     ap.add_argument("--resident", action="store_true", help="waveforms resident in HBM before the timed region (round 2's contract) "
                     "instead of uploaded inside it")
     ap.add_argument("--first-pass-frames", type=int, default=60000, help="input frames of the first acoustic-model pass when the upload is timed")
@@ -161,6 +169,18 @@ def build_workload(args):
     return g, model, durs, cfg, time.time() - t0
 
 
+def ivector_variant(args, g):
+    """(model with the recipe's 100-dim ivector input, extractor of the recipe's shape): hires MFCC 40 -> splice +-3 -> LDA 40 ->
+    512-Gaussian UBM -> 100-dim i-vectors, period 10, 15 CG iterations (conf/online_cmvn + ivector_extractor.conf of the recipe)."""
+    from kaldi_amd import abi, feat, ivector, nnet, synth
+    make = {"librispeech": nnet.tdnnf_librispeech, "mini_librispeech": nnet.tdnnf_mini_librispeech}.get(args.workload, nnet.tdnnf_tiny)
+    model = make(num_pdfs=g.num_pdfs, output_scale=args.output_scale, ivector_dim=100)
+    sample = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(synth.make_waves_fast([8.0], seed=31337)[0])
+    ie = ivector.IvectorExtractor(ivector.make_synthetic(seed=11, feat_mean=sample.mean(0), feat_std=sample.std(0), max_count=100.0))
+    calibrate(model, args.ll_std_ivectors if (args.workload == "librispeech" and args.graph == "tglarge") else args.ll_std, ie)
+    return model, ie
+
+
 def calibrate(model, target_std, extractor=None):
     """Random weights give arbitrary output scale; rescale the output layer so that the
     per-frame spread of the log-likelihoods across pdfs is `target_std` nats (chain models
@@ -169,10 +189,12 @@ def calibrate(model, target_std, extractor=None):
     w = synth.make_waves_fast([3.0], seed=424242)[0]
     f = feat.Mfcc(abi.mfcc_opts_hires()).ComputeFeatures(w)
     ivd = model.layers[0].ivector_dim
-    iv = None
-    if ivd:      # a typical i-vector (the last one of the sample), not zeros: it shifts every output (tools/online_latency.py)
-        iv = extractor.extract_online(f)[-1] if extractor is not None else np.zeros(ivd, np.float32)
-    ll = decoder.Nnet(model).Forward(f, ivector=iv) if ivd else decoder.Nnet(model).Forward(f)
+    if ivd and extractor is not None:      # the way the bench runs it: chunk by chunk, every chunk with its own online i-vector
+        ll = decoder.Nnet(model).ForwardChunked([f], [extractor.extract_online(f)], extractor.info.ivector_period, 50)[0]
+    elif ivd:
+        ll = decoder.Nnet(model).Forward(f, ivector=np.zeros(ivd, np.float32))
+    else:
+        ll = decoder.Nnet(model).Forward(f)
     spread = float(np.mean(np.std(ll, axis=1)))
     k = target_std / spread
     out = model.layers[-1]
@@ -439,6 +461,9 @@ def main():
                          (rank, dev, ndev))
     check(lib().kamd_set_device(dev))
     g, model, durs, cfg, t_build = build_workload(args)
+    extractor = None
+    if args.ivectors:
+        model, extractor = ivector_variant(args, g)
     graph_dev = decoder.Graph(g)                      # one copy of HCLG in HBM for every decoder object of this process
     log("workload built: %d states %d arcs, %d utts (%.2f h)" % (g.num_states, g.num_arcs, durs.size, durs.sum() / 3600))
     # ONE test set, partitioned over the ranks (steps/nnet3/decode.sh:96,123: split_data + JOB=1:nj)
@@ -461,7 +486,11 @@ def main():
                   lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), first_pass_frames=args.first_pass_frames,
                   long_lanes=16 if world >= 8 else 0)    # small shards: see kamd_batch_decoder_set_long_decoder
         kw.update(over)
-        return batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, graph_dev, cfg, **kw)
+        m, ie = kw.pop("model", model), kw.pop("extractor", extractor)
+        b = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), m, graph_dev, cfg, **kw)
+        if ie is not None:
+            b.set_ivector_extractor(ie, 50)
+        return b
 
     def timed(bd, steps, warmup):
         """`warmup` untimed runs, then `steps` runs between barriers: (wall seconds, mean stage vector, last stats)."""
@@ -471,11 +500,11 @@ def main():
                 (st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms, st.n_failed))
         sync_all()
         t0 = time.time()
-        acc = np.zeros(10)
+        acc = np.zeros(11)
         for _ in range(steps):
             st = bd.run()
             acc += [st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms, st.first_result_ms, st.host_thread_ms_sum,
-                    st.upload_ms, st.first_pass_start_ms, st.upload_wait_ms]
+                    st.upload_ms, st.first_pass_start_ms, st.upload_wait_ms, st.ivector_ms]
         sync_all()
         return time.time() - t0, acc / max(steps, 1), st
 
@@ -496,8 +525,9 @@ def main():
         return recs, dec, roof
 
     # ------------------------------------------------------------------ the headline load
-    spread, k = calibrate(model, args.ll_std)
-    bd = make_decoder()
+    if not args.ivectors:
+        spread, k = calibrate(model, args.ll_std)
+    bd = make_decoder(**(dict(nnet_pass_frames=min(args.nnet_pass_frames, 400000)) if args.ivectors else {}))
     log("batch decoder created (%d host threads)" % host_threads)
     if args.resident:
         bd.load(waves)                          # round 2's contract: inputs resident in HBM before the timed region
@@ -587,8 +617,14 @@ def main():
         dt_r, acc_r, st_r = timed(bd, min(3, args.steps), 1)
         out["hbm_resident_value"] = audio * min(3, args.steps) / dt_r
         out["hbm_resident_ms_per_step"] = 1000.0 * dt_r / min(3, args.steps)
+    if args.ivectors:
+        out["stage_ms"]["ivector_extraction"] = acc[10]
+        out["config"]["online_ivectors"] = "100-dim, period 10, estimated on the device inside the timed region; model evaluated in chunks of 50 frames"
     out["cpu_baseline"] = None
-    if not args.no_cpu_baseline and one:
+    if args.ivectors:
+        out["cpu_baseline"] = {"skipped": "the CPU leg runs the model without the ivector input (default run); steps/online/nnet2/extract_ivectors_online.sh is a "
+                                          "separate process upstream of nnet3-latgen-faster in the recipe"}
+    elif not args.no_cpu_baseline and one:
         log("cpu baseline ...")
         try:
             out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, bd, args.cpu_budget, args.cpu_cores)
@@ -596,6 +632,36 @@ def main():
             out["cpu_baseline"] = {"error": repr(e)}
     del bd
     gc.collect()
+    # ------------------------------------------------------------------ the recipe's model input: online i-vectors
+    if one and not args.ivectors and not args.no_ivector_leg:
+        log("online i-vector leg ...")
+        try:
+            m_iv, ie = ivector_variant(args, g)
+            b3 = make_decoder(model=m_iv, extractor=ie, nnet_pass_frames=min(args.nnet_pass_frames, 400000))   # (the chunks' context rows: 1.9x the activations)
+            b3.load(waves) if args.resident else b3.load_host(waves)
+            dt3, acc3, st3 = timed(b3, 2, 1)
+            _, d3, r3 = search_stats(b3, st3, acc3, n)
+            fl3 = 2.0 * m_iv.macs_per_output_frame() * d3["frames"]
+            gemm_ms = float(acc3[1])
+            out["online_ivectors"] = {
+                "value": audio * 2 / dt3, "ms_per_step": 1000.0 * dt3 / 2, "ratio_to_value": (audio * 2 / dt3) / out["value"],
+                "stage_ms": {"features": acc3[0], "nnet_chunked": acc3[1], "ivector_extraction": acc3[10],
+                             "decode_queue_kernel": acc3[2], "host_tail_after_last_utterance": acc3[3], "total_wall": acc3[4]},
+                "loglike_std_nats": args.ll_std_ivectors, "tokens_per_frame": d3["tokens_per_frame"], "arcs_per_frame": d3["arcs_per_frame"],
+                "us_per_frame_per_lane": r3["us_per_frame_per_lane"],
+                "nnet_ratio_to_unchunked": gemm_ms / nnet_ms,
+                "mflop_per_output_frame": 2e-6 * m_iv.macs_per_output_frame(), "flops_per_step": fl3, "executed_flops_per_step": st3.nnet_flops,
+                "executed_over_algorithmic": st3.nnet_flops / fl3, "gemm_achieved_tflops": fl3 / (gemm_ms * 1e-3) / 1e12,
+                "gemm_executed_tflops": st3.nnet_flops / (gemm_ms * 1e-3) / 1e12,
+                "expanded_per_frame": d3["expanded_per_frame"], "failed_utterances": d3["failed_utterances"],
+                "what": "run_tdnn_1d.sh:220 `input dim=100 name=ivector` + steps/nnet3/decode.sh:105-107 --online-ivectors: 100-dim online i-vectors "
+                        "(512-Gaussian UBM, period 10, 15 CG iterations) estimated on the device from every pass's features inside the timed region; the "
+                        "model is evaluated like DecodableNnetSimple, in chunks of 50 (51) input frames with the i-vector row of the chunk's middle and "
+                        "the chunk's context recomputed (nnet-am-decodable-simple.cc:93-214): `executed_over_algorithmic` is that recompute"}
+            del b3
+            gc.collect()
+        except Exception as e:                      # noqa: BLE001
+            out["online_ivectors"] = {"error": repr(e)}
     # ------------------------------------------------------------------ load bracket: the same step at two more loads
     if one and not args.no_bracket and args.workload == "librispeech" and args.graph == "tglarge":
         def entry(value, ms, a, d, r):

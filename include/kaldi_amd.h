@@ -1065,6 +1065,7 @@ typedef struct {
   float first_pass_start_ms;           /* wall time until the first pass's features were launched: the exposed part of the upload */
   float upload_wait_ms;                /* wall time the launching thread spent waiting for a pass's copies to be issued */
   int32_t upload_passes;
+  float ivector_ms;                    /* device time of the online i-vector extraction (not part of nnet_ms), 0 without an extractor */
 } kamd_batch_stats;
 typedef struct kamd_batch_decoder kamd_batch_decoder;
 /* The stages are not owned.  tid_phone as kamd_lattice_determinize_phone_pruned (NULL: word
@@ -1103,6 +1104,13 @@ int kamd_synth_planted_loglikes_device(float *d_out, int64_t rows, int num_pdfs,
                                        float noise, uint64_t seed, void *stream);
 /* Output frames of every loaded utterance (0 for the ones too short for a frame); total returned. */
 int64_t kamd_batch_decoder_output_frames(kamd_batch_decoder *b, int32_t *frames, int cap);
+/* The recipe's online i-vectors (steps/nnet3/decode.sh:105-107 passes --online-ivectors=scp:... --online-ivector-period=N,
+ * matrices that steps/online/nnet2/extract_ivectors_online.sh wrote with ivector-extract-online2): estimated HERE from the
+ * features of every pass (kamd_ivector_extract_online_device), and the acoustic model then evaluates chunk by chunk like
+ * DecodableNnetSimple (nnet3/nnet-am-decodable-simple.cc:93-214: frames_per_chunk input frames a chunk, its own context
+ * recomputed, the i-vector row GetCurrentIvector picks; kamd_nnet_forward_chunked_device).  Set before the set is loaded
+ * (kamd_batch_decoder_load / _load_host); NULL removes it.  The extractor is not owned. */
+int kamd_batch_decoder_set_ivector_extractor(kamd_batch_decoder *b, kamd_ivector_extractor *e, int frames_per_chunk);
 /* AcceptInput as the reference declares it (nnet-batch-compute.h:665-669: feature matrices, not
  * waveforms, plus the optional per-utterance i-vector): rows [row_off[u], row_off[u+1]) of feats
  * (dim floats per row, dim = the model's input dim) are utterance u; ivectors is [n_utts x

@@ -69,6 +69,12 @@ class NnetBatchDecoder:
             lib().kamd_batch_decoder_destroy(self._h)
             self._h = None
 
+    def set_ivector_extractor(self, extractor, frames_per_chunk=50):
+        """--online-ivectors of the recipe (steps/nnet3/decode.sh:105-107), estimated on the device from every pass's own
+        features; the model then runs chunk by chunk like DecodableNnetSimple.  Before load() / load_host(); None removes it."""
+        self._ie = extractor
+        check(lib().kamd_batch_decoder_set_ivector_extractor(self._h, None if extractor is None else extractor._h, int(frames_per_chunk)))
+
     def load(self, waves):
         waves = [np.asarray(w, np.float32) for w in waves]
         off = np.concatenate([[0], np.cumsum([w.size for w in waves])]).astype(np.int64)

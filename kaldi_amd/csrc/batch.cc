@@ -66,6 +66,13 @@ struct BatchDecoder {
   float *d_waves = NULL, *d_feats = NULL, *d_ll = NULL, *d_iv = NULL;
   size_t waves_cap = 0, feats_cap = 0, ll_cap = 0, iv_cap = 0;
   bool from_features = false, have_iv = false;   // the loaded set: feature matrices (+ i-vectors) instead of waveforms
+  // online i-vectors estimated from the set's own features (steps/nnet3/decode.sh:105-107 --online-ivectors + --online-
+  // ivector-period; the matrices extract_ivectors_online.sh would have written): kamd_batch_decoder_set_ivector_extractor.
+  // The acoustic model then runs chunk by chunk like DecodableNnetSimple (kamd_nnet_forward_chunked_device).
+  kamd_ivector_extractor *iv_extractor = NULL;
+  int frames_per_chunk = 50;
+  float *d_oiv = NULL; size_t oiv_cap = 0;
+  std::vector<int64_t> oiv_off;
   // kamd_batch_decoder_load_host: the samples stay in the caller's memory and every run() uploads them pass by pass
   const float *h_waves = NULL;                   // caller's buffer (kept utterance k starts at h_wave_src[k])
   void *h_registered = NULL;                     // ... page-locked in place by load_host (hipHostRegister) when the runtime allows it:
@@ -81,6 +88,7 @@ struct BatchDecoder {
   hipEvent_t ev_stage[kStageBufs] = {};
   hipStream_t s_up = NULL;
   std::vector<hipEvent_t> ev_up, ev_f0, ev_f1, ev_n1;   // per pass: copies done; features start / end; model end
+  std::vector<hipEvent_t> ev_iv0, ev_iv1, ev_n0;        // per pass: i-vector extraction start / end; chunked model start
   const float *d_ll_override = NULL;             // kamd_batch_decoder_set_loglike_override
   hipStream_t s_main = NULL;
   hipEvent_t ev[3] = {};
@@ -256,17 +264,46 @@ void kamd_batch_decoder_destroy(kamd_batch_decoder *h) {
     if (b->h_stage[i]) (void)hipHostFree(b->h_stage[i]);
     if (b->ev_stage[i]) (void)hipEventDestroy(b->ev_stage[i]);
   }
-  for (std::vector<hipEvent_t> *v : {&b->ev_up, &b->ev_f0, &b->ev_f1, &b->ev_n1})
+  for (std::vector<hipEvent_t> *v : {&b->ev_up, &b->ev_f0, &b->ev_f1, &b->ev_n1, &b->ev_iv0, &b->ev_iv1, &b->ev_n0})
     for (hipEvent_t e : *v) if (e) (void)hipEventDestroy(e);
+  if (b->d_oiv) (void)hipFree(b->d_oiv);
   if (b->s_up) (void)hipStreamDestroy(b->s_up);
   delete b;
+}
+
+namespace kamd {
+// the model's ivector input: fed by the extractor (rows of d_oiv), or the set must come through load_features
+static int CheckIvectorInput(const BatchDecoder *b) {
+  if (kamd_nnet_ivector_dim(b->nnet) > 0 && !b->iv_extractor)
+    return SetError(KAMD_ERR_ARG, "the model has an ivector input: set an extractor (kamd_batch_decoder_set_ivector_extractor) or use "
+                    "kamd_batch_decoder_load_features");
+  return KAMD_OK;
+}
+static int SizeOnlineIvectors(BatchDecoder *b) {
+  b->oiv_off.assign(1, 0);
+  if (!b->iv_extractor || b->from_features) return KAMD_OK;
+  for (size_t k = 0; k + 1 < b->feat_off.size(); k++)
+    b->oiv_off.push_back(b->oiv_off.back() + kamd_ivector_num_ivectors(b->iv_extractor, static_cast<int>(b->feat_off[k + 1] - b->feat_off[k])));
+  return GrowDev(&b->d_oiv, &b->oiv_cap, std::max<size_t>(static_cast<size_t>(b->oiv_off.back()) * kamd_ivector_dim(b->iv_extractor), 1));
+}
+}  // namespace kamd
+
+int kamd_batch_decoder_set_ivector_extractor(kamd_batch_decoder *h, kamd_ivector_extractor *e, int frames_per_chunk) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (!e) { b->iv_extractor = NULL; return KAMD_OK; }
+  if (frames_per_chunk <= 0) return kamd::SetError(KAMD_ERR_ARG, "bad frames per chunk");
+  if (kamd_ivector_dim(e) != kamd_nnet_ivector_dim(b->nnet))
+    return kamd::SetError(KAMD_ERR_ARG, "the extractor gives %d-dim ivectors, the model takes %d", kamd_ivector_dim(e), kamd_nnet_ivector_dim(b->nnet));
+  if (b->n_utts > 0) return kamd::SetError(KAMD_ERR_STATE, "set the extractor before the test set is loaded");
+  b->iv_extractor = e; b->frames_per_chunk = frames_per_chunk;
+  return KAMD_OK;
 }
 
 int kamd_batch_decoder_load(kamd_batch_decoder *h, const float *waves, const int64_t *h_wave_off, int n_utts) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
   if (n_utts <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty test set");
   if (!b->feat) return kamd::SetError(KAMD_ERR_STATE, "batch decoder was created without a feature stage: use kamd_batch_decoder_load_features");
-  if (kamd_nnet_ivector_dim(b->nnet) > 0) return kamd::SetError(KAMD_ERR_ARG, "the model has an ivector input: use kamd_batch_decoder_load_features");
+  if (kamd::CheckIvectorInput(b) != KAMD_OK) return KAMD_ERR_ARG;
   for (kamd::UttOut &o : b->out) o.Clear();
   b->n_utts = 0; b->from_features = false; b->have_iv = false; b->h_waves = NULL;
   kamd::Unregister(b);
@@ -286,6 +323,7 @@ int kamd_batch_decoder_load(kamd_batch_decoder *h, const float *waves, const int
   if (kamd::GrowDev(&b->d_waves, &b->waves_cap, std::max<size_t>(ns, 1)) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&b->d_feats, &b->feats_cap, std::max<size_t>(static_cast<size_t>(b->feat_off.back()) * b->ld_feat, 1)) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&b->d_ll, &b->ll_cap, std::max<size_t>(static_cast<size_t>(b->out_off.back()) * b->P, 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::SizeOnlineIvectors(b) != KAMD_OK) return KAMD_ERR_HIP;
   if (b->skipped.empty()) {
     if (ns) KAMD_HIP(hipMemcpy(b->d_waves, waves + h_wave_off[0], ns * sizeof(float), hipMemcpyHostToDevice));
   } else {
@@ -346,7 +384,7 @@ int kamd_batch_decoder_load_host(kamd_batch_decoder *h, const float *waves, cons
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
   if (n_utts <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty test set");
   if (!b->feat) return kamd::SetError(KAMD_ERR_STATE, "batch decoder was created without a feature stage: use kamd_batch_decoder_load_features");
-  if (kamd_nnet_ivector_dim(b->nnet) > 0) return kamd::SetError(KAMD_ERR_ARG, "the model has an ivector input: use kamd_batch_decoder_load_features");
+  if (kamd::CheckIvectorInput(b) != KAMD_OK) return KAMD_ERR_ARG;
   for (kamd::UttOut &o : b->out) o.Clear();
   b->n_utts = 0; b->from_features = false; b->have_iv = false; b->h_waves = NULL;
   kamd::Unregister(b);
@@ -367,6 +405,7 @@ int kamd_batch_decoder_load_host(kamd_batch_decoder *h, const float *waves, cons
   if (kamd::GrowDev(&b->d_waves, &b->waves_cap, std::max<size_t>(static_cast<size_t>(b->wave_off.back()), 1)) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&b->d_feats, &b->feats_cap, std::max<size_t>(static_cast<size_t>(b->feat_off.back()) * b->ld_feat, 1)) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&b->d_ll, &b->ll_cap, std::max<size_t>(static_cast<size_t>(b->out_off.back()) * b->P, 1)) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::SizeOnlineIvectors(b) != KAMD_OK) return KAMD_ERR_HIP;
   // passes: a small first one, so that the acoustic model starts behind a short upload
   b->pass_u0.assign(1, 0);
   for (int u0 = 0; u0 < n;) {
@@ -461,6 +500,10 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
     return KAMD_OK;
   }
   const auto t0 = std::chrono::steady_clock::now();
+  static const bool trace = getenv("KAMD_BATCH_TRACE") != NULL;          // host-side timeline of a run on stderr
+  auto mark = [&](const char *what, int k) {
+    if (trace) fprintf(stderr, "[batch %8.2f ms] %s %d\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what, k);
+  };
   hipStream_t st = b->s_main;
   KAMD_HIP(hipEventRecord(b->ev[0], st));
   int rc = KAMD_OK;
@@ -548,41 +591,87 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
                0.55 * static_cast<double>(longest) > 1.5 * static_cast<double>(b->out_off.back()) / std::max(lanes_main, 1);
   if (const char *e = getenv("KAMD_BATCH_SPLIT")) split = b->dec_long && b->long_lanes > 0 && !b->have_iv && n > b->long_lanes && atoi(e) != 0;
   if (host_mode || b->d_ll_override) split = false;       // (the passes follow the upload; a planted matrix is in load order)
+  const bool online_iv = b->iv_extractor != NULL && !b->from_features;
+  if (online_iv) split = false;
   const float *ll_base = b->d_ll_override ? b->d_ll_override : b->d_ll;
   b->last_split = split;
   int n_main = n;
   std::vector<kamd_queue_task> tasks;
   if (!split) {
-    int pass = 0;
-    for (int u0 = 0; u0 < n; pass++) {
-      int u1 = u0 + 1;
-      if (host_mode) {
-        u1 = b->pass_u0[pass + 1];
-        const auto tw = std::chrono::steady_clock::now();
-        {
-          std::unique_lock<std::mutex> lk(up.mu);
-          up.cv.wait(lk, [&] { return up.issued > pass || up.rc != KAMD_OK; });
-          if (up.rc != KAMD_OK) return kamd::SetError(up.rc, "%s", up.err.c_str());
-        }
-        upload_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
-        KAMD_HIP(hipStreamWaitEvent(st, b->ev_up[pass], 0));
-        KAMD_HIP(hipEventRecord(b->ev_f0[pass], st));
-        rc = kamd::FeatLaunchPremeta(b->feat, b->d_waves, b->d_feat_meta + b->feat_meta_off[pass], u1 - u0, b->pass_frames[pass], b->d_feats,
-                                     b->ld_feat, st);
-        if (rc != KAMD_OK) return rc;
-        KAMD_HIP(hipEventRecord(b->ev_f1[pass], st));
-        if (pass == 0) first_pass_start_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      } else {
+    // the passes: load_host fixed them (pass_u0); otherwise <= nnet_pass_frames input frames each
+    std::vector<int> pu(1, 0);
+    if (host_mode) pu = b->pass_u0;
+    else
+      for (int u0 = 0; u0 < n;) {
+        int u1 = u0 + 1;
         while (u1 < n && b->feat_off[u1 + 1] - b->feat_off[u0] <= b->opts.nnet_pass_frames) u1++;
+        pu.push_back(u1);
+        u0 = u1;
       }
-      rc = kamd_nnet_forward_batch_device(b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat,
-                                          b->have_iv ? b->d_iv + static_cast<size_t>(u0) * kamd_nnet_ivector_dim(b->nnet) : NULL, u1 - u0, b->d_ll,
-                                          b->out_off.data() + u0, b->P, st);
+    const int np = static_cast<int>(pu.size()) - 1;
+    // what runs in front of a pass's acoustic model, on stream `ps`: (load_host) the pass's features behind its copies
+    auto features_of = [&](int pass, hipStream_t ps) -> int {
+      if (!host_mode) return KAMD_OK;
+      const auto tw = std::chrono::steady_clock::now();
+      {
+        std::unique_lock<std::mutex> lk(up.mu);
+        up.cv.wait(lk, [&] { return up.issued > pass || up.rc != KAMD_OK; });
+        if (up.rc != KAMD_OK) return kamd::SetError(up.rc, "%s", up.err.c_str());
+      }
+      upload_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+      KAMD_HIP(hipStreamWaitEvent(ps, b->ev_up[pass], 0));
+      KAMD_HIP(hipEventRecord(b->ev_f0[pass], ps));
+      const int frc = kamd::FeatLaunchPremeta(b->feat, b->d_waves, b->d_feat_meta + b->feat_meta_off[pass], pu[pass + 1] - pu[pass],
+                                              b->pass_frames[pass], b->d_feats, b->ld_feat, ps);
+      if (frc != KAMD_OK) return frc;
+      KAMD_HIP(hipEventRecord(b->ev_f1[pass], ps));
+      if (pass == 0) first_pass_start_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      return KAMD_OK;
+    };
+    // online i-vectors: features and OnlineIvectorFeature of pass p + 1 are issued behind the acoustic model of pass p, on
+    // the same stream.  (Measured on a stream of their own beside the model, 2620 utterances: the extraction's 125 ms were
+    // hidden and the GEMMs took 83 ms longer -- both are throughput kernels; the wall time did not move.)
+    auto ivectors_of = [&](int pass) -> int {
+      while (static_cast<int>(b->ev_iv0.size()) <= pass) {
+        hipEvent_t e0 = NULL, e1 = NULL, e2 = NULL;
+        KAMD_HIP(hipEventCreate(&e0)); KAMD_HIP(hipEventCreate(&e1)); KAMD_HIP(hipEventCreate(&e2));
+        b->ev_iv0.push_back(e0); b->ev_iv1.push_back(e1); b->ev_n0.push_back(e2);
+      }
+      int irc = features_of(pass, st);
+      if (irc != KAMD_OK) return irc;
+      KAMD_HIP(hipEventRecord(b->ev_iv0[pass], st));
+      mark("features issued, pass", pass);
+      irc = kamd_ivector_extract_online_device(b->iv_extractor, b->d_feats, b->feat_off.data() + pu[pass], b->ld_feat, pu[pass + 1] - pu[pass],
+                                               b->d_oiv, b->oiv_off.data() + pu[pass], st);
+      if (irc != KAMD_OK) return irc;
+      mark("i-vectors issued, pass", pass);
+      KAMD_HIP(hipEventRecord(b->ev_iv1[pass], st));
+      return KAMD_OK;
+    };
+    if (online_iv) { rc = ivectors_of(0); if (rc != KAMD_OK) return rc; }
+    for (int pass = 0; pass < np; pass++) {
+      const int u0 = pu[pass], u1 = pu[pass + 1];
+      if (online_iv) {
+        KAMD_HIP(hipEventRecord(b->ev_n0[pass], st));
+        rc = kamd_nnet_forward_chunked_device(b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat, b->d_oiv, b->oiv_off.data() + u0,
+                                              kamd_ivector_dim(b->iv_extractor), kamd_ivector_period(b->iv_extractor), b->frames_per_chunk,
+                                              u1 - u0, b->d_ll, b->out_off.data() + u0, b->P, st);
+      } else {
+        rc = features_of(pass, st);
+        if (rc == KAMD_OK)
+          rc = kamd_nnet_forward_batch_device(b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat,
+                                              b->have_iv ? b->d_iv + static_cast<size_t>(u0) * kamd_nnet_ivector_dim(b->nnet) : NULL, u1 - u0, b->d_ll,
+                                              b->out_off.data() + u0, b->P, st);
+      }
       if (rc != KAMD_OK) return rc;
-      if (host_mode) KAMD_HIP(hipEventRecord(b->ev_n1[pass], st));
+      if (host_mode || online_iv) {
+        while (static_cast<int>(b->ev_n1.size()) <= pass) { hipEvent_t e = NULL; KAMD_HIP(hipEventCreate(&e)); b->ev_n1.push_back(e); }
+        KAMD_HIP(hipEventRecord(b->ev_n1[pass], st));
+      }
       flops += kamd_nnet_last_flops(b->nnet);
       passes++;
-      u0 = u1;
+      mark("model issued, pass", pass);
+      if (online_iv && pass + 1 < np) { rc = ivectors_of(pass + 1); if (rc != KAMD_OK) return rc; }
     }
     KAMD_HIP(hipEventRecord(b->ev[2], st));
     // ---- the search: one work-queue launch, longest utterance first
@@ -600,6 +689,7 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
     }
     rc = kamd_decoder_queue_launch(b->dec, tasks.data(), n, b->opts.resident_lanes, st);
     if (rc != KAMD_OK) return rc;
+    mark("search issued, utterances", n);
   } else {
     // the K longest utterances, longest first; everybody else in input order.  Log-likelihood rows: the long ones first
     // (the forward's output rows are a running sum over its items), then the rest.
@@ -729,11 +819,21 @@ int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
     for (int p = 0; p < passes; p++) {
       float f = 0, m = 0;
       (void)hipEventElapsedTime(&f, b->ev_f0[p], b->ev_f1[p]);
-      (void)hipEventElapsedTime(&m, b->ev_f1[p], b->ev_n1[p]);
+      (void)hipEventElapsedTime(&m, online_iv ? b->ev_n0[p] : b->ev_f1[p], b->ev_n1[p]);
       s.feat_ms += f; s.nnet_ms += m;
     }
     s.upload_ms = static_cast<float>(up.done_ms); s.first_pass_start_ms = static_cast<float>(first_pass_start_ms);
     s.upload_wait_ms = static_cast<float>(upload_wait_ms); s.upload_passes = passes;
+  }
+  if (online_iv) {
+    // the model's own time; the extraction is reported on its own
+    if (!host_mode) s.nnet_ms = 0;
+    for (int p = 0; p < passes; p++) {
+      float v = 0, m = 0;
+      (void)hipEventElapsedTime(&v, b->ev_iv0[p], b->ev_iv1[p]);
+      s.ivector_ms += v;
+      if (!host_mode) { (void)hipEventElapsedTime(&m, b->ev_n0[p], b->ev_n1[p]); s.nnet_ms += m; }
+    }
   }
   s.decode_ms = qms; s.total_ms = static_cast<float>(total_ms);
   s.host_tail_ms = static_cast<float>(total_ms - t_last_done);

@@ -1175,6 +1175,9 @@ struct MapArgs {
   // of i-vectors, slot_base[u] + clamp(floor((abs_t0[u] + t) / period) - slot_first[u], 0, slot_count[u] - 1)
   int slot_period;              // 0: one i-vector per item
   const int *slot_base, *slot_first, *slot_count, *abs_t0;
+  // items that are CHUNKS of an utterance (DecodableNnetSimple with online i-vectors): the item's time 0 is input frame
+  // in_t0[u] of the utterance whose rows start at prod_row_off[u] and whose T[u] frames bound the clamp.  NULL: 0.
+  const int *in_t0;
 };
 __global__ void RowMapKernel(MapArgs a) {
   int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1198,6 +1201,7 @@ __global__ void RowMapKernel(MapArgs a) {
     int tin = t + a.offs[i];
     int64_t src;
     if (a.prod_is_input) {
+      if (a.in_t0) tin += a.in_t0[u];
       int c = tin < 0 ? 0 : (tin >= a.T[u] ? a.T[u] - 1 : tin);
       src = a.prod_row_off[u] + c;
     } else {
@@ -1208,11 +1212,13 @@ __global__ void RowMapKernel(MapArgs a) {
 }
 
 // ivbias[u][n] = sum_k W_iv[n][k] * ivec[u][k]   (ReplaceIndex(ivector, t, 0) operand)
-__global__ void IvecBiasKernel(const float *Wiv, const float *ivec, int N, int D, float *out) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x, u = blockIdx.y;
+// (rows != NULL: item u reads row rows[u] of the i-vector table)
+__global__ void IvecBiasKernel(const float *Wiv, const float *ivec, int N, int D, float *out, const int *rows) {
+  int n = blockIdx.y * blockDim.x + threadIdx.x, u = blockIdx.x;     // (items on x: there can be more than 65535)
   if (n >= N) return;
+  const size_t src = rows ? static_cast<size_t>(rows[u]) : static_cast<size_t>(u);
   float s = 0.f;
-  for (int k = 0; k < D; k++) s += Wiv[static_cast<size_t>(n) * D + k] * ivec[static_cast<size_t>(u) * D + k];
+  for (int k = 0; k < D; k++) s += Wiv[static_cast<size_t>(n) * D + k] * ivec[src * D + k];
   out[static_cast<size_t>(u) * N + n] = s;
 }
 
@@ -1411,9 +1417,14 @@ struct SlotSpec {                 // host arrays, one entry per item; table rows
   int period, table_rows;
   const int32_t *slot_base, *slot_first, *slot_count, *abs_t0;
 };
+// Items that are chunks of utterances: item u produces n_out[u] output frames starting at input frame t0[u] (a multiple
+// of the subsampling factor) of the utterance h_in_start[u] / h_in_len[u] describe (the WHOLE utterance: its edges are
+// where the input is clamped); every layer is evaluated at exactly the times the chunk's outputs need.
+struct ChunkSpec { const int32_t *t0, *n_out, *iv_row; };    // iv_row[u]: the row of d_ivectors item u reads
 static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_start, const int32_t *h_in_len,
                         int ld_in, const float *d_ivectors, int n_utts, float *d_out,
-                        const int64_t *h_out_row_off, int ld_out, void *stream, const SlotSpec *slots = NULL) {
+                        const int64_t *h_out_row_off, int ld_out, void *stream, const SlotSpec *slots = NULL,
+                        const ChunkSpec *chunks = NULL) {
   Nnet *nn = reinterpret_cast<Nnet *>(h);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nl = static_cast<int>(nn->L.size()), sub = nn->subsampling;
@@ -1425,9 +1436,11 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
   // layout: [ (nl+2) arrays of (n_utts+1) int64 ] then T as int32
   const size_t stride = n_utts + 1;
   const size_t t_words = (n_utts + 1) / 2 + 1, slot_words = slots ? static_cast<size_t>(2 * n_utts + 2) : 0;
-  std::vector<int64_t> meta((nl + 2) * stride + t_words + slot_words, 0);
+  const size_t chunk_words = chunks ? 2 * t_words : 0;
+  std::vector<int64_t> meta((nl + 2) * stride + t_words + slot_words + chunk_words, 0);
   int *Th = reinterpret_cast<int *>(&meta[(nl + 2) * stride]);
   int *Sh = reinterpret_cast<int *>(&meta[(nl + 2) * stride + t_words]);      // slot_base | slot_first | slot_count | abs_t0
+  int *Ch = reinterpret_cast<int *>(&meta[(nl + 2) * stride + t_words + slot_words]);   // t0 of chunk items
   if (slots)
     for (int u = 0; u < n_utts; u++) {
       Sh[u] = slots->slot_base[u]; Sh[n_utts + u] = slots->slot_first[u];
@@ -1440,6 +1453,11 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     int T = h_in_len[u];
     if (T <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no frames", u);
     Th[u] = T; n_out[u] = (T + sub - 1) / sub;
+    if (chunks) {
+      if (chunks->n_out[u] <= 0 || chunks->t0[u] < 0 || chunks->t0[u] % sub != 0 || chunks->t0[u] / sub + chunks->n_out[u] > n_out[u])
+        return kamd::SetError(KAMD_ERR_ARG, "item %d: bad chunk", u);
+      n_out[u] = chunks->n_out[u]; Ch[u] = chunks->t0[u]; Ch[2 * t_words + u] = chunks->iv_row[u];
+    }
     meta[nl * stride + u] = h_in_start[u];           // feature rows
   }
   meta[nl * stride + n_utts] = h_in_start[n_utts - 1] + h_in_len[n_utts - 1];
@@ -1460,6 +1478,8 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
   for (int u = 0; u + 1 < n_utts; u++)
     if (h_out_row_off[u + 1] != h_out_row_off[u] + n_out[u])
       return kamd::SetError(KAMD_ERR_ARG, "h_out_row_off must be the running sum of output frames");
+  // the last layer's row offsets are absolute rows of d_out; the map kernel works in layer-local rows: a relative copy
+  for (size_t i = 0; i < stride; i++) meta[(nl + 1) * stride + i] = meta[(nl - 1) * stride + i] - h_out_row_off[0];
   if (kamd::Grow(&nn->d_meta, &nn->meta_cap, meta.size(), st) != KAMD_OK) return KAMD_ERR_HIP;
   KAMD_HIP(hipMemcpyAsync(nn->d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, st));
   KAMD_HIP(hipStreamSynchronize(st));
@@ -1487,6 +1507,7 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     ma.T = d_T; ma.lo = L.lo; ma.step = L.step;
     ma.row2utt = L.ivector_dim > 0 ? row2utt : NULL;
     ma.slot_period = 0; ma.slot_base = ma.slot_first = ma.slot_count = ma.abs_t0 = NULL;
+    ma.in_t0 = chunks ? reinterpret_cast<const int *>(nn->d_meta + (nl + 2) * stride + t_words + slot_words) : NULL;
     if (slots && L.ivector_dim > 0) {
       const int *d_S = reinterpret_cast<const int *>(nn->d_meta + (nl + 2) * stride + t_words);
       ma.slot_period = slots->period;
@@ -1498,15 +1519,7 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     };
     // row offsets for the last layer are absolute; shift handled by a local copy
     const int64_t *layer_row_off = d_row_off;
-    int64_t *d_tmp_off = NULL;
-    if (l == nl - 1 && row_base != 0) {
-      std::vector<int64_t> rel(stride);
-      for (size_t i = 0; i < stride; i++) rel[i] = meta[l * stride + i] - row_base;
-      KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_tmp_off), stride * 8));
-      KAMD_HIP(hipMemcpyAsync(d_tmp_off, rel.data(), stride * 8, hipMemcpyHostToDevice, st));
-      KAMD_HIP(hipStreamSynchronize(st));
-      layer_row_off = d_tmp_off;
-    }
+    if (l == nl - 1 && row_base != 0) layer_row_off = nn->d_meta + (nl + 1) * stride;     // (filled with the meta upload)
     ma.row_off = layer_row_off;
     fill_prod(L.input_layer, &ma);
     ma.n_off = L.n_off;
@@ -1529,8 +1542,9 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
       if (!d_ivectors) return kamd::SetError(KAMD_ERR_ARG, "model needs ivectors");
       const int iv_rows = slots ? slots->table_rows : n_utts;
       if (kamd::Grow(&nn->d_ivb, &nn->ivb_cap, static_cast<size_t>(iv_rows) * L.out_dim, st) != KAMD_OK) return KAMD_ERR_HIP;
-      hipLaunchKernelGGL(kamd::IvecBiasKernel, dim3(kamd::CeilDiv(L.out_dim, 128), iv_rows), dim3(128), 0, st,
-                         L.Wiv, d_ivectors, L.out_dim, L.ivector_dim, nn->d_ivb);
+      const int *d_iv_rows = chunks ? reinterpret_cast<const int *>(nn->d_meta + (nl + 2) * stride + t_words + slot_words) + 2 * t_words : NULL;
+      hipLaunchKernelGGL(kamd::IvecBiasKernel, dim3(iv_rows, kamd::CeilDiv(L.out_dim, 128)), dim3(128), 0, st,
+                         L.Wiv, d_ivectors, L.out_dim, L.ivector_dim, nn->d_ivb, d_iv_rows);
       g.ivbias = nn->d_ivb; g.row2utt = row2utt;
     }
     if (L.bypass_layer != -2) {
@@ -1625,7 +1639,6 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
       hipLaunchKernelGGL(kamd::LogSoftmaxRowsKernel, dim3(kamd::CeilDiv(Ml, 4)), dim3(256), 0, st, g.C, g.ldC,
                          static_cast<int>(Ml), L.out_dim, L.post_offset, L.post_scale);
     KAMD_HIP(hipGetLastError());
-    if (d_tmp_off) { KAMD_HIP(hipStreamSynchronize(st)); KAMD_HIP(hipFree(d_tmp_off)); }
     flops += 2.0 * static_cast<double>(Ml) * L.out_dim * (L.n_off * L.in_dim + L.ivector_dim);
   }
   nn->last_flops = flops;
@@ -1693,83 +1706,50 @@ int kamd_nnet_forward_chunked_device(kamd_nnet *h, const float *d_feats, const i
                                      int ivector_period, int frames_per_chunk, int n_utts, float *d_out,
                                      const int64_t *h_out_row_off, int ld_out, void *stream) {
   Nnet *nn = reinterpret_cast<Nnet *>(h);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   if (n_utts <= 0) return KAMD_OK;
-  const int sub = nn->subsampling, P = nn->L.back().out_dim;
+  const int sub = nn->subsampling;
   if (iv_dim != nn->L[0].ivector_dim || iv_dim <= 0) return kamd::SetError(KAMD_ERR_ARG, "model expects ivector dim %d, got %d", nn->L[0].ivector_dim, iv_dim);
   if (ivector_period <= 0 || frames_per_chunk <= 0) return kamd::SetError(KAMD_ERR_ARG, "bad ivector period / frames per chunk");
   if (frames_per_chunk % sub != 0) frames_per_chunk = sub * ((frames_per_chunk + sub - 1) / sub);
   const int C = frames_per_chunk / sub;
-  const int Lc = kamd_nnet_left_context(h), Rc = kamd_nnet_right_context(h);
-  std::vector<int64_t> in_start, tmp_off, iv_row, src_row, dst_row;
-  std::vector<int32_t> in_len, cnt;
-  int64_t tmp_rows = 0;
+  // Every chunk is an item whose layers are evaluated at exactly the times its outputs need (what the compiled
+  // computation of a chunk contains); it writes its rows of d_out in place.  Neighbouring chunks that read the SAME
+  // i-vector row are one item: their computations are identical on the rows they share (at the end of an utterance,
+  // where GetCurrentIvector clamps to the last row, and whenever the period is not shorter than a chunk).
+  static const bool no_merge = getenv("KAMD_CHUNK_NO_MERGE") != NULL && getenv("KAMD_CHUNK_NO_MERGE")[0] == '1';
+  std::vector<int64_t> in_start, out_row;
+  std::vector<int32_t> in_len, t0, nout, iv_row;
+  const int64_t iv_base = h_iv_row_off[0];
+  if (h_iv_row_off[n_utts] - iv_base > 2000000000LL) return kamd::SetError(KAMD_ERR_ARG, "online ivector table too large");
   for (int u = 0; u < n_utts; u++) {
     const int T = static_cast<int>(h_in_row_off[u + 1] - h_in_row_off[u]);
     const int n_iv = static_cast<int>(h_iv_row_off[u + 1] - h_iv_row_off[u]);
     if (T <= 0 || n_iv <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no frames / ivectors", u);
     const int n_out = (T + sub - 1) / sub;
+    bool first = true;
     for (int start = 0; start < n_out; start += C) {
       const int num = std::min(n_out - start, C);
       const int first_out = start * sub, last_out = (start + num - 1) * sub;
-      int ivf = (first_out + (last_out - first_out) / 2) / ivector_period;
+      int ivf = (first_out + (last_out - first_out) / 2) / ivector_period;       // GetCurrentIvector (:181-211)
       if (ivf >= n_iv) {
         if ((ivf - (n_iv - 1)) * ivector_period > 50)
           return kamd::SetError(KAMD_ERR_ARG, "utterance %d: could not get iVector for frame %d (mismatched --online-ivector-period?)", u, first_out);
         ivf = n_iv - 1;
       }
-      const int k0 = std::min(start, (Lc + sub - 1) / sub);          // leading outputs that only carry context
-      const int in_first = sub * (start - k0);
-      const int in_last = std::min(T - 1, last_out + Rc);
-      in_start.push_back(h_in_row_off[u] + in_first); in_len.push_back(in_last - in_first + 1);
-      tmp_off.push_back(tmp_rows);
-      iv_row.push_back(h_iv_row_off[u] + ivf);
-      src_row.push_back(tmp_rows + k0); dst_row.push_back(h_out_row_off[u] + start); cnt.push_back(num);
-      tmp_rows += (in_last - in_first + 1 + sub - 1) / sub;
+      const int32_t row = static_cast<int32_t>(h_iv_row_off[u] - iv_base + ivf);
+      if (!first && !no_merge && iv_row.back() == row) { nout.back() += num; continue; }
+      first = false;
+      in_start.push_back(h_in_row_off[u]); in_len.push_back(T);
+      t0.push_back(first_out); nout.push_back(num);
+      out_row.push_back(h_out_row_off[u] + start);
+      iv_row.push_back(row);
     }
   }
   const int n_items = static_cast<int>(in_start.size());
-  // per-item ivectors (gathered rows), temporary outputs, copy descriptors
-  float *d_iv = NULL, *d_tmp = NULL; int64_t *d_desc = NULL;
-  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_iv), static_cast<size_t>(n_items) * iv_dim * sizeof(float)));
-  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_tmp), static_cast<size_t>(tmp_rows) * P * sizeof(float)));
-  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_desc), static_cast<size_t>(n_items) * (3 * 8 + 4) + 64));
-  int64_t *d_src = d_desc, *d_dst = d_desc + n_items, *d_ivr = d_desc + 2 * n_items;
-  int *d_cnt = reinterpret_cast<int *>(d_desc + 3 * n_items);
-  int rc = KAMD_OK;
-  hipError_t e = hipMemcpyAsync(d_src, src_row.data(), n_items * 8, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst_row.data(), n_items * 8, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_ivr, iv_row.data(), n_items * 8, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_cnt, cnt.data(), n_items * 4, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess) rc = kamd::SetError(KAMD_ERR_HIP, "descriptor upload failed: %s", hipGetErrorString(e));
-  if (rc == KAMD_OK) {
-    // gather the chunk ivectors: reuse the row-block copy (1 row per item)
-    std::vector<int64_t> iota(n_items);
-    std::vector<int> ones(n_items, 1);
-    for (int i = 0; i < n_items; i++) iota[i] = i;
-    int64_t *d_iota = NULL; int *d_ones = NULL;
-    if (hipMalloc(reinterpret_cast<void **>(&d_iota), n_items * 8) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&d_ones), n_items * 4) != hipSuccess ||
-        hipMemcpy(d_iota, iota.data(), n_items * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_ones, ones.data(), n_items * 4, hipMemcpyHostToDevice) != hipSuccess)
-      rc = kamd::SetError(KAMD_ERR_HIP, "allocation failed");
-    if (rc == KAMD_OK) {
-      hipLaunchKernelGGL(kamd::CopyRowBlocksKernel, dim3(1, n_items), dim3(128), 0, st, d_online_ivectors, iv_dim, d_iv, iv_dim,
-                         d_ivr, d_iota, d_ones, iv_dim);
-      rc = ForwardItems(h, d_feats, in_start.data(), in_len.data(), ld_in, d_iv, n_items, d_tmp, tmp_off.data(), P, stream);
-    }
-    if (rc == KAMD_OK) {
-      hipLaunchKernelGGL(kamd::CopyRowBlocksKernel, dim3(std::min(C, 32), n_items), dim3(256), 0, st, d_tmp, P, d_out, ld_out,
-                         d_src, d_dst, d_cnt, P);
-      if (hipStreamSynchronize(st) != hipSuccess) rc = kamd::SetError(KAMD_ERR_HIP, "chunked forward failed");
-    }
-    if (d_iota) (void)hipFree(d_iota);
-    if (d_ones) (void)hipFree(d_ones);
-  }
-  (void)hipFree(d_iv); (void)hipFree(d_tmp); (void)hipFree(d_desc);
-  (void)nn;
-  return rc;
+  out_row.push_back(h_out_row_off[n_utts - 1] + (h_in_row_off[n_utts] - h_in_row_off[n_utts - 1] + sub - 1) / sub);
+  ChunkSpec cs = {t0.data(), nout.data(), iv_row.data()};
+  return ForwardItems(h, d_feats, in_start.data(), in_len.data(), ld_in, d_online_ivectors + iv_base * iv_dim, n_items, d_out, out_row.data(),
+                      ld_out, stream, NULL, &cs);
 }
 
 int kamd_nnet_forward(kamd_nnet *h, const float *feats, int T, const float *ivector, float *out,

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from kaldi_amd import abi, feat, ivector, nnet, pipeline, synth
+from kaldi_amd._lib import KamdError
 from oracle import orc
 
 pytestmark = pytest.mark.gpu
@@ -93,6 +94,85 @@ def test_pipeline_with_the_extractor_equals_precomputed_online_ivectors():
         assert got[u]["words"].tolist() == ref[u]["words"].tolist()
         want = orc.nnet_forward_chunked(m, feats[u], orc.ivector_extract_online(info, feats[u]), info.ivector_period, 50)
         np.testing.assert_allclose(got_ll[u], want, rtol=0, atol=2e-3)
+
+
+def test_batch_decoder_with_the_extractor_equals_the_pipeline_and_the_oracle():
+    """kamd_batch_decoder_set_ivector_extractor (the work-queue path of the bench with the recipe's online i-vectors): per
+    pass features -> i-vectors -> chunked forward, through load() and load_host(), several passes, an utterance too short
+    for a frame in the middle.  Log-likelihoods: the oracle's DecodableNnetSimple with the oracle's own i-vector
+    matrices; lattices: the three-launch pipeline's."""
+    from kaldi_amd import batch
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, ivector_dim=20, seed=12, output_scale=3.0)
+    cfg = abi.decoder_config_recipe()
+    durs = (1.7, 3.2, 0.9, 2.4, 0.6, 1.1, 2.9)
+    waves = [synth.make_wave(d, seed=70 + i) for i, d in enumerate(durs)]
+    op = abi.mfcc_opts_hires()
+    feats = [feat.Mfcc(op).ComputeFeatures(w) for w in waves]
+    allf = np.concatenate(feats)
+    info = ivector.make_synthetic(num_gauss=64, ivector_dim=20, seed=6, feat_mean=allf.mean(0), feat_std=allf.std(0))
+    ie = ivector.IvectorExtractor(info)
+    pipe = pipeline.Pipeline(op, m, g, cfg, max_utts=len(waves), max_seconds=4.0)
+    pipe.load(waves)
+    pipe.set_ivector_extractor(ie, frames_per_chunk=50)
+    pipe.run()
+    ref = pipe.results()
+    ref_ll = [pipe.loglikes(u).copy() for u in range(len(waves))]
+    with_short = waves[:3] + [np.zeros(120, np.float32)] + waves[3:]
+    idx = [0, 1, 2, 4, 5, 6, 7]
+    for loader in ("load", "load_host"):
+        bd = batch.NnetBatchDecoder(op, m, g, cfg, max_seconds=4.0, resident_lanes=3, host_threads=2, determinize=True, keep_raw_lattices=True,
+                                    search_mode=1, nnet_pass_frames=500, first_pass_frames=200)
+        with pytest.raises(KamdError, match="ivector input"):
+            bd.load(waves)
+        bd.set_ivector_extractor(ie, 50)
+        getattr(bd, loader)(with_short)
+        st = bd.run()
+        assert st.nnet_passes >= 3 and st.n_failed == 1 and st.ivector_ms > 0
+        assert bd.output(3) is None
+        for u, k in enumerate(idx):
+            np.testing.assert_array_equal(bd.loglikes(k), ref_ll[u])          # same kernels on the same rows, pass by pass
+            want = orc.nnet_forward_chunked(m, feats[u], orc.ivector_extract_online(info, feats[u]), info.ivector_period, 50)
+            np.testing.assert_allclose(bd.loglikes(k), want, rtol=0, atol=2e-3)
+            assert bd.output(k)["words"].tolist() == ref[u]["words"].tolist()
+            assert bd.raw_lattice(k).arcs.tobytes() == ref[u]["lattice"].arcs.tobytes()
+
+
+def test_recipe_sized_model_with_online_ivectors_through_the_batch_decoder():
+    """BASELINE configs[2] as the recipe runs it (run_tdnn_1d.sh:220 `input dim=100 name=ivector`, steps/nnet3/decode.sh:
+    105-107): the LibriSpeech TDNN-F topology (1536 / 160, 17 layers, P = 6000) with 100-dim online i-vectors from an
+    extractor of the recipe's shape (512 Gaussians), through kamd_batch_decoder_*: log-likelihoods against the oracle's
+    DecodableNnetSimple (chunks of 50 -> 51 frames, context recomputed, GetCurrentIvector's row) fed with the ORACLE's
+    i-vector matrices.  Tolerance: 2e-3 of the largest |log-likelihood| (fp32 GEMMs with K up to 3072 in another
+    summation order, on i-vectors that themselves agree to 1e-4)."""
+    from kaldi_amd import batch
+    g = synth.make_hclg(num_units=3000, vocab=300, n_hist=40, seed=2)
+    m = nnet.tdnnf_librispeech(num_pdfs=g.num_pdfs, ivector_dim=100, output_scale=1.0)
+    assert m.ivector_dim == 100 and len(m.layers) > 30
+    cfg = abi.decoder_config_recipe()
+    waves = [synth.make_wave(d, seed=170 + i) for i, d in enumerate((2.2, 1.1))]
+    op = abi.mfcc_opts_hires()
+    feats = [feat.Mfcc(op).ComputeFeatures(w) for w in waves]
+    allf = np.concatenate(feats)
+    info = ivector.make_synthetic(seed=11, feat_mean=allf.mean(0), feat_std=allf.std(0), max_count=100.0)
+    ie = ivector.IvectorExtractor(info)
+    bd = batch.NnetBatchDecoder(op, m, g, cfg, max_seconds=3.0, resident_lanes=2, host_threads=2, determinize=False, search_mode=1)
+    bd.set_ivector_extractor(ie, 50)
+    bd.load_host(waves)
+    st = bd.run()
+    assert st.ivector_ms > 0
+    # 17 output frames a chunk; what the chunks cost beyond the model's algorithmic work is the recomputed context
+    alg = 2.0 * m.macs_per_output_frame() * sum((f.shape[0] + 2) // 3 for f in feats)
+    assert 1.2 < st.nnet_flops / alg < 3.0
+    for u in range(2):
+        iv = orc.ivector_extract_online(info, feats[u])
+        want = orc.nnet_forward_chunked(m, feats[u], iv, info.ivector_period, 50)
+        got = bd.loglikes(u)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 2e-3 * np.abs(want).max()
+        # and the i-vectors matter: the same model on one constant i-vector gives other numbers
+        assert np.abs(orc.nnet_forward_chunked(m, feats[u], np.repeat(iv[:1], iv.shape[0], 0), info.ivector_period, 50) - want).max() > \
+            20 * np.abs(got - want).max()
 
 
 def test_latgen_tool_with_device_ivectors_and_with_online_ivector_archives(tmp_path):

@@ -184,7 +184,10 @@ def test_matrix_tables_through_ark_scp_offsets_and_pipes(tmp_path):
 
 
 @pytest.mark.parametrize("binary", [True, False])
-def test_int32_and_wave_tables(tmp_path, binary):
+def test_int32_and_wave_tables(tmp_path, binary, monkeypatch):
+    spool = tmp_path / "spool"                       # the spooled pipes of THIS test only (other workers share /tmp)
+    spool.mkdir()
+    monkeypatch.setenv("TMPDIR", str(spool))
     vecs = {"a": np.array([1, 2, 3], np.int32), "b": np.zeros(0, np.int32), "c": np.array([-7, 2**31 - 1], np.int32)}
     ark, scp = str(tmp_path / "v.ark"), str(tmp_path / "v.scp")
     with T.TableWriter("ark%s,scp:%s,%s" % ("" if binary else ",t", ark, scp), "int32") as w:
