@@ -732,6 +732,9 @@ int kamd_stream_batch_accept_many(kamd_stream_batch *b, const int32_t *streams, 
 /* AdvanceDecoding for all listed streams; frames_decoded[n] may be NULL */
 int kamd_stream_batch_advance(kamd_stream_batch *b, const int32_t *streams, int n, int32_t *frames_decoded);
 int kamd_stream_batch_num_frames_ready(const kamd_stream_batch *b, int stream);
+/* (status bit) the silence-weighted i-vector statistics of the stream lost a batch of delta weights when a tick failed
+ * between the traceback and the statistics update: the stream must be restarted. */
+#define KAMD_STREAM_WEIGHTING_LOST (1 << 30)
 /* Per-stream health: 0 = fine, otherwise the decoder capacity flags that took this stream out
  * (its lane's arena / table overflowed).  kamd_stream_batch_advance reports such a failure with
  * KAMD_ERR_CAPACITY but leaves every OTHER stream of the tick advanced and usable; the failed

@@ -478,8 +478,27 @@ int kamd_batch_decoder_set_long_decoder(kamd_batch_decoder *h, kamd_decoder *dec
   return KAMD_OK;
 }
 
+static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats);
+
+// Every error exit of a run leaves through here: jobs may be queued to the host-tail pool and a work-queue kernel may
+// still be running; nothing of this object may be reused (load(), run()) before both have ended.
 int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  const int rc = RunImpl(b, stats);
+  if (rc != KAMD_OK) {
+    {
+      std::unique_lock<std::mutex> lk(b->mu);
+      b->cv_done.wait(lk, [&] { return b->pending == 0; });
+    }
+    if (b->s_main) (void)hipStreamSynchronize(b->s_main);
+    if (b->s_long) (void)hipStreamSynchronize(b->s_long);
+    if (b->s_up) (void)hipStreamSynchronize(b->s_up);
+    (void)hipGetLastError();          // (the error that is reported is the one RunImpl set)
+  }
+  return rc;
+}
+
+static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
   if (b->n_utts <= 0) return kamd::SetError(KAMD_ERR_STATE, "no test set loaded");
   const int n = static_cast<int>(b->kept.size());
   // the previous run's lattices are freed by the worker that fills the slot again (HostTail): 2620 compact lattices are

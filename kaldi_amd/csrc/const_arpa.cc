@@ -294,6 +294,35 @@ static std::string CheckSymbols(const ConstArpa &lm) {      // the asserts at th
   return "";
 }
 
+// A file's <LmStates> block is followed through child offsets at rescoring time: walk it once after reading, so that a
+// truncated or corrupt G.carpa is an error of the read and not an out-of-bounds access later.
+static std::string ValidateStates(const ConstArpa &lm) {
+  const int64_t size = static_cast<int64_t>(lm.lm.size());
+  std::vector<bool> seen(lm.lm.size(), false);
+  std::vector<int64_t> stack;
+  for (int64_t a : lm.unigram) if (a > 0) stack.push_back(a - 1);
+  while (!stack.empty()) {
+    const int64_t p = stack.back();
+    stack.pop_back();
+    if (p < 0 || p + 3 > size) return "LmState offset outside <LmStates>";
+    if (seen[p]) continue;                      // (a corrupt file may point two parents at one state, or in a circle)
+    seen[p] = true;
+    const int64_t n = lm.lm[p + 2];
+    if (n < 0 || p + 3 + 2 * n > size) return "LmState children run past the end of <LmStates>";
+    for (int64_t k = 0; k < n; k++) {
+      const int32_t info = lm.lm[p + 4 + 2 * k];
+      if (info % 2 == 0) continue;              // a leaf: the log-probability itself
+      const int32_t off = info / 2;
+      if (off > 0) stack.push_back(p + off);
+      else {
+        if (static_cast<size_t>(-static_cast<int64_t>(off)) >= lm.overflow.size()) return "overflow index outside <LmOverflow>";
+        stack.push_back(lm.overflow[-off] - 1);
+      }
+    }
+  }
+  return "";
+}
+
 // ---- ConstArpaLmDeterministicFst (:1000-1062): states are word histories, created on demand
 struct LmFst {
   const ConstArpa &lm;
@@ -411,6 +440,10 @@ kamd_const_arpa *kamd_const_arpa_read(const char *path) {
   ConstArpa *lm = new ConstArpa();
   bool ok = true;
   auto fail = [&](const char *why) -> kamd_const_arpa * { kamd::SetError(KAMD_ERR_ARG, "%s: %s", path, why); fclose(f); delete lm; return NULL; };
+  fseek(f, 0, SEEK_END);
+  const int64_t file_size = ftell(f);            // no section can hold more than the file does
+  fseek(f, 0, SEEK_SET);
+  try {
   if (fgetc(f) != '\0' || fgetc(f) != 'B') return fail("not a Kaldi binary file (text-mode reading is not implemented for ConstArpaLm)");
   auto expect = [&](const char *t) {
     char buf[64]; size_t n = 0; int c;
@@ -425,15 +458,15 @@ kamd_const_arpa *kamd_const_arpa_read(const char *path) {
   if (first == 4) {                                   // ReadInternalOldFormat :670-715: every value with its size byte
     lm->bos = i32(); lm->eos = i32(); lm->unk = i32(); lm->order = i32();
     const int32_t n = i32();
-    if (!ok || n < 0) return fail("corrupt old-format header");
+    if (!ok || n < 0 || 5ll * n > file_size) return fail("corrupt old-format header");
     lm->lm.resize(n);
     for (int32_t i = 0; ok && i < n; i++) lm->lm[i] = i32();
     lm->num_words = i32();
-    if (!ok || lm->num_words < 0) return fail("corrupt unigram section");
+    if (!ok || lm->num_words < 0 || 9ll * lm->num_words > file_size) return fail("corrupt unigram section");
     lm->unigram.resize(lm->num_words);
     for (int32_t i = 0; ok && i < lm->num_words; i++) lm->unigram[i] = i64();
     const int32_t no = i32();
-    if (!ok || no < 0) return fail("corrupt overflow section");
+    if (!ok || no < 0 || 9ll * no > file_size) return fail("corrupt overflow section");
     lm->overflow.resize(no);
     for (int32_t i = 0; ok && i < no; i++) lm->overflow[i] = i64();
   } else {
@@ -441,17 +474,17 @@ kamd_const_arpa *kamd_const_arpa_read(const char *path) {
     lm->bos = i32(); lm->eos = i32(); lm->unk = i32(); lm->order = i32();
     expect("</LmInfo>"); expect("<LmStates>");
     const int64_t n = i64();
-    if (!ok || n < 0 || n > (1ll << 40)) return fail("corrupt <LmStates> header");
+    if (!ok || n < 0 || 4 * n > file_size) return fail("corrupt <LmStates> header");
     lm->lm.resize(static_cast<size_t>(n));
     if (n && fread(lm->lm.data(), 4, static_cast<size_t>(n), f) != static_cast<size_t>(n)) return fail("ConstArpaLm <LmStates> section reading failed.");
     expect("</LmStates>"); expect("<LmUnigram>");
     lm->num_words = i32();
-    if (!ok || lm->num_words < 0) return fail("corrupt <LmUnigram> header");
+    if (!ok || lm->num_words < 0 || 8ll * lm->num_words > file_size) return fail("corrupt <LmUnigram> header");
     lm->unigram.resize(lm->num_words);
     if (lm->num_words && fread(lm->unigram.data(), 8, lm->unigram.size(), f) != lm->unigram.size()) return fail("ConstArpaLm <LmUnigram> section reading failed.");
     expect("</LmUnigram>"); expect("<LmOverflow>");
     const int32_t no = i32();
-    if (!ok || no < 0) return fail("corrupt <LmOverflow> header");
+    if (!ok || no < 0 || 8ll * no > file_size) return fail("corrupt <LmOverflow> header");
     lm->overflow.resize(no);
     if (no && fread(lm->overflow.data(), 8, lm->overflow.size(), f) != lm->overflow.size()) return fail("ConstArpaLm <LmOverflow> section reading failed.");
     expect("</LmOverflow>"); expect("</ConstArpaLm>");
@@ -461,6 +494,11 @@ kamd_const_arpa *kamd_const_arpa_read(const char *path) {
   if (!err.empty()) return fail(err.c_str());
   for (int64_t a : lm->unigram) if (a < 0 || a > static_cast<int64_t>(lm->lm.size())) return fail("unigram offset outside <LmStates>");
   for (int64_t a : lm->overflow) if (a <= 0 || a > static_cast<int64_t>(lm->lm.size())) return fail("overflow offset outside <LmStates>");
+  const std::string bad = kamd::ValidateStates(*lm);
+  if (!bad.empty()) return fail(bad.c_str());
+  } catch (const std::bad_alloc &) {
+    return fail("out of memory");
+  }
   fclose(f);
   return reinterpret_cast<kamd_const_arpa *>(lm);
 }

@@ -47,7 +47,7 @@ typedef unsigned int u32;
 #define FIN_CAP (6 * NT)     // tokens per frame the finalize sweep keeps in LDS (6 arrays)
 #define LDS_TABLE_CAP (8 * NT)   // level-1 table words (64 KB of a 1024-thread lane's LDS)
 #define SMALL_DEG 4
-#define ARCW 4           // arcs in flight per thread in the arc-parallel expansion
+#define ARCW 8           // arcs in flight per thread in the arc-parallel expansion
 #define CHUNKCAP (4 * NT)    // cached chunk owners (16 arcs each) per flatten batch
 static_assert(NT == 1024 || NT == 512, "KAMD_NT: 1024 (one lane per CU) or 512 (two)");
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
@@ -82,7 +82,10 @@ struct LaneState {
 struct DecDev {
   GraphDev g;
   const int *tid2pdf;   // NULL => pdf = ilabel - 1
-  const int *e_pdf;     // [emitting arcs] pdf of each emitting arc (tid2pdf applied once)
+  // [emitting arcs] {weight bits, pdf}: what the cutoff test of an expanded arc needs (tid2pdf applied once).  ~90 % of the
+  // expanded arcs fail that test: they cost 8 B of traffic here instead of the 16 B StdArc + 4 B pdf; the survivors'
+  // records (next state, labels) are fetched by arc index in the dense insert sweep
+  const uint2 *e_hot;
   int num_pdfs_lds;     // log-likelihood row entries staged in LDS per frame (0 = none)
   int lds_table_cap;    // level-1 (LDS) table words, power of two or 0
   kamd_decoder_config cfg;
@@ -492,32 +495,34 @@ __device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl
 // all cutoff tests first (the arcs were loaded together), then the inserts and links.
 template <int W>
 __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, const LlRow &ll,
-                                   const kamd_arc (&arc)[W], const int (&pdf)[W], const int (&src_tok)[W],
+                                   const uint2 (&hot)[W], const u32 (&aidx)[W], const int (&src_tok)[W],
                                    const float (&cur_cost)[W], const bool (&ok)[W], float cost_offset,
                                    float adaptive_beam, int link_base, bool loose, float seed_cutoff) {
   float ac[W], tot[W];
   bool pass[W];
+  // the running bound, read once for the W arcs: any value >= the frame's final cutoff is a valid filter here (the dense
+  // sweep applies the final one), and the bound only ever tightens
+  float nc = OrderedToFloat(sh->next_cutoff_u);
 #pragma unroll
   for (int q = 0; q < W; q++) {
-    ac[q] = cost_offset - LogLikePdf(ll, ok[q] ? pdf[q] : 0);
-    tot[q] = cur_cost[q] + ac[q] + arc[q].weight;
-    const float nc = OrderedToFloat(sh->next_cutoff_u);   // running bound (conservative)
+    ac[q] = cost_offset - LogLikePdf(ll, ok[q] ? static_cast<int>(hot[q].y) : 0);
+    tot[q] = cur_cost[q] + ac[q] + __uint_as_float(hot[q].x);
     pass[q] = ok[q] && !(tot[q] > (loose ? seed_cutoff : nc));
     if (pass[q]) {
       const float cand = tot[q] + adaptive_beam;
-      if (cand < nc) atomicMin(&sh->next_cutoff_u, FloatToOrdered(cand));
+      if (cand < nc) { atomicMin(&sh->next_cutoff_u, FloatToOrdered(cand)); nc = cand; }
     }
   }
-  // candidates are only RECORDED here (dst = HCLG state).  The table inserts run later as a
-  // dense sweep over the recorded links (InsertEmitted): with ~10 % of the arcs passing,
-  // inserting in place would run the expensive path at ~10 % lane utilisation.
+  // candidates are only RECORDED here, as (source token, ARC INDEX, costs).  The arc's record (next state, labels) and
+  // the table inserts come later, in a dense sweep over the recorded links (InsertEmitted): with ~10 % of the arcs
+  // passing, fetching and inserting in place would run the expensive path at ~10 % lane utilisation.
 #pragma unroll
   for (int q = 0; q < W; q++) {
     if (!pass[q]) continue;
     const int li = link_base + WaveAlloc(&sh->n_links);
     if (li >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
-    Link L; L.src = src_tok[q]; L.dst = arc[q].nextstate; L.ilabel = arc[q].ilabel; L.olabel = arc[q].olabel;
-    L.graph = arc[q].weight; L.ac = ac[q];
+    Link L; L.src = src_tok[q]; L.dst = static_cast<int>(aidx[q]); L.ilabel = 0; L.olabel = 0;
+    L.graph = __uint_as_float(hot[q].x); L.ac = ac[q];
     c.links[li] = L;
   }
 }
@@ -540,7 +545,7 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
   // INSB links per thread per trip: the records, then the source costs, are loaded for the
   // whole batch before the first insert (two dependent round trips per batch, not per link)
   for (int g0 = 0; link_begin + g0 * NT < le; g0 += INSB) {
-    Link L[INSB]; float cs[INSB];
+    Link L[INSB]; float cs[INSB]; kamd_arc arc[INSB];
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
       const int li = link_begin + threadIdx.x + (g0 + k) * NT;
@@ -551,6 +556,8 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
     for (int k = 0; k < INSB; k++) {
       const int li = link_begin + threadIdx.x + (g0 + k) * NT;
       cs[k] = li < le ? c.tok_cost[L[k].src] : INFINITY;
+      arc[k].ilabel = arc[k].olabel = arc[k].nextstate = 0; arc[k].weight = 0.f;
+      if (li < le) arc[k] = d.g.e_arcs[static_cast<u32>(L[k].dst)];       // the record of the arc ProcessArcs kept by index
     }
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
@@ -560,13 +567,15 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
       int dst = -1;
       if (tot <= cutoff) {                       // :798 with the frame's final cutoff
         bool improved;
-        dst = TblInsert(d, c, sh, tbl, L[k].dst, tot, &improved);
+        dst = TblInsert(d, c, sh, tbl, arc[k].nextstate, tot, &improved);
         k_surv += dst >= 0;
       }
-      // the first COMMIT_KEEP links of a thread: the slot stays in a register until the commit
-      // resolves it to a token (only a rejection is written back now)
-      if (g0 == 0 && k < COMMIT_KEEP) { my_slot[k] = dst; if (dst < 0) c.links[li].dst = -1; }
-      else c.links[li].dst = dst;
+      // the link in its final form but for dst (slot now, token at the commit).  The first COMMIT_KEEP links of a thread:
+      // the slot stays in a register until the commit resolves it to a token (only a rejection is written back now)
+      int dst_now = dst;
+      if (g0 == 0 && k < COMMIT_KEEP) { my_slot[k] = dst; dst_now = dst < 0 ? -1 : L[k].dst; }
+      Link *o = &c.links[li];
+      o->dst = dst_now; o->ilabel = arc[k].ilabel; o->olabel = arc[k].olabel;
     }
   }
   return k_surv;
@@ -1102,9 +1111,9 @@ __device__ inline void InitSh(Sh *sh) {
 
 // pdf of every emitting arc, computed once per decoder (removes the dependent
 // tid -> pdf gather of TransitionIdToPdfFast from the per-arc critical path)
-__global__ void ArcPdfKernel(const kamd_arc *arcs, long long n, const int *tid2pdf, int *e_pdf) {
+__global__ void ArcHotKernel(const kamd_arc *arcs, long long n, const int *tid2pdf, uint2 *e_hot) {
   long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) { const int il = arcs[i].ilabel; e_pdf[i] = tid2pdf ? tid2pdf[il] : il - 1; }
+  if (i < n) { const kamd_arc a = arcs[i]; e_hot[i] = make_uint2(__float_as_uint(a.weight), static_cast<u32>(tid2pdf ? tid2pdf[a.ilabel] : a.ilabel - 1)); }
 }
 
 // ------------------------------------------------------------------ kernels
@@ -1138,9 +1147,8 @@ __global__ __launch_bounds__(NT, 4) void InitKernel(DecDev d, const int *lanes) 
 // AdvanceDecoding (lattice-faster-decoder.cc:593-632): the frame loop of one lane.
 __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *shp, unsigned char *dyn_lds, const kamd_decode_task &task) {
   Sh &sh = *shp;
-  int *big_tok = reinterpret_cast<int *>(dyn_lds);            // [BIGCAP] token (index in list)
-  u32 *big_a0 = reinterpret_cast<u32 *>(big_tok + BIGCAP);     // [BIGCAP] first emitting arc
-  int *big_scan = reinterpret_cast<int *>(big_a0 + BIGCAP);    // [BIGCAP] degree -> exclusive scan
+  int2 *big_ta = reinterpret_cast<int2 *>(dyn_lds);           // [BIGCAP] {token (index in list), first emitting arc - scan}: one ds_read_b64
+  int *big_scan = reinterpret_cast<int *>(big_ta + BIGCAP);    // [BIGCAP] degree -> exclusive scan
   float *ll_lds = reinterpret_cast<float *>(big_scan + BIGCAP + 4);// [num_pdfs_lds]  (+4: sentinel)
   u32 *lh_lds = reinterpret_cast<u32 *>(ll_lds + ((d.num_pdfs_lds + 3) & ~3));   // [LHBINS]
   float *cand_lds = reinterpret_cast<float *>(lh_lds + LHBINS);                  // [LHCAND]
@@ -1233,7 +1241,8 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
       const u32 a0 = d.g.off[best_state].x, a1 = d.g.off[best_state + 1].x;
       float seed = INFINITY;
       for (u32 a = a0 + tid; a < a1; a += NT) {
-        const float new_weight = d.g.e_arcs[a].weight + cost_offset - LogLikePdf(row, d.e_pdf[a]) + best;
+        const uint2 hot = d.e_hot[a];
+        const float new_weight = __uint_as_float(hot.x) + cost_offset - LogLikePdf(row, static_cast<int>(hot.y)) + best;
         seed = fminf(seed, new_weight + adaptive_beam);
       }
       // a minimum is a minimum in any order: the wavefronts that hold an arc of the best token put theirs straight
@@ -1282,18 +1291,18 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
           const u32 deg = a1 - a0;
           a_emit += deg;
           if (deg <= SMALL_DEG) {
-            kamd_arc arc[SMALL_DEG]; int pdf[SMALL_DEG], tok[SMALL_DEG]; float cst[SMALL_DEG]; bool ok[SMALL_DEG];
+            uint2 hot[SMALL_DEG]; u32 aidx[SMALL_DEG]; int tok[SMALL_DEG]; float cst[SMALL_DEG]; bool ok[SMALL_DEG];
 #pragma unroll
             for (int q = 0; q < SMALL_DEG; q++) {
               ok[q] = static_cast<u32>(q) < deg;
-              tok[q] = tb + i; cst[q] = cur_cost; pdf[q] = 0;
-              arc[q].ilabel = arc[q].olabel = arc[q].nextstate = 0; arc[q].weight = 0.f;
-              if (ok[q]) { arc[q] = d.g.e_arcs[a0 + q]; pdf[q] = d.e_pdf[a0 + q]; }
+              tok[q] = tb + i; cst[q] = cur_cost; aidx[q] = a0 + q;
+              hot[q] = make_uint2(0u, 0u);
+              if (ok[q]) hot[q] = d.e_hot[a0 + q];
             }
-            ProcessArcs<SMALL_DEG>(d, c, &sh, tbl, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
+            ProcessArcs<SMALL_DEG>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
           } else {
             const int p = WaveAlloc(&sh.bigcnt);   // < BIGCAP: at most EXPT * NT entries per outer iteration
-            big_tok[p] = i; big_a0[p] = a0; big_scan[p] = deg;
+            big_ta[p] = make_int2(i, static_cast<int>(a0)); big_scan[p] = deg;
           }
         }
       }
@@ -1318,61 +1327,85 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
         int wbase = 0, total = 0;
         for (int k = 0; k < NWAVES; k++) { int cnum = sh.redi[k]; if (k < w) wbase += cnum; total += cnum; }
         const int excl = wbase + incl - mine;
-        if (e0 < nb) big_scan[e0] = excl;
-        if (e0 + 1 < nb) big_scan[e0 + 1] = excl + v0;
-        if (e0 + 2 < nb) big_scan[e0 + 2] = excl + v0 + v1;
+        // (the entry's arc base becomes "first arc - scan": arc j of the flattened range is base + j)
+        if (e0 < nb) { big_scan[e0] = excl; big_ta[e0].y -= excl; }
+        if (e0 + 1 < nb) { big_scan[e0 + 1] = excl + v0; big_ta[e0 + 1].y -= excl + v0; }
+        if (e0 + 2 < nb) { big_scan[e0 + 2] = excl + v0 + v1; big_ta[e0 + 2].y -= excl + v0 + v1; }
         LdsBarrier();
         {
           // owner of the first arc of every 16-arc chunk, computed once per batch.  Queued
           // tokens have >= 5 arcs, so at most 4 of them start inside a chunk: the per-arc
           // owner lookup is the chunk's owner plus three branch-free compare steps
           // (big_scan[nb] = total is the sentinel).
-          const int nchunks = (total + 15) >> 4;
-          const int ncached = min(nchunks, CHUNKCAP);
+          // (a batch with more than 16 * CHUNKCAP arcs -- a frame behind a word boundary, where the LM's hubs are live --
+          // uses chunks of 32, 64, ... arcs, so that every chunk's owner is cached)
+          int shift = 4;
+          while (((total + (1 << shift) - 1) >> shift) > CHUNKCAP) shift++;
+          const int csize = 1 << shift;
+          const int nchunks = (total + csize - 1) >> shift;
           if (tid == 0) { big_scan[nb] = total; big_scan[nb + 1] = 0x7fffffff; big_scan[nb + 2] = 0x7fffffff; }
-          for (int cidx = tid; cidx < ncached; cidx += NT) {
-            const int j = cidx << 4;
+          for (int cidx = tid; cidx < nchunks; cidx += NT) {
+            const int j = cidx << shift;
             int lo = 0, hi = nb;
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
-            chunk_owner[cidx] = lo;
+            // bit 31: the whole chunk belongs to this owner (the rule on frames that hubs dominate): its arcs need no
+            // further look at the scan
+            const int next = lo + 1 < nb ? big_scan[lo + 1] : total;
+            chunk_owner[cidx] = lo | (next >= j + csize ? static_cast<int>(0x80000000u) : 0);
           }
           LdsBarrier();
           auto lookup = [&](int j, u32 *a, int *i2) {
-            const int cidx = j >> 4;
-            int e;
-            if (cidx < ncached) {
-              e = chunk_owner[cidx];
-              // the scan is strictly increasing: counting the next three entries <= j is the three dependent steps
-              // e += scan[e + 1] <= j in one LDS round trip (two sentinels behind scan[nb] keep the reads in range)
-              const int s1 = big_scan[e + 1], s2 = big_scan[e + 2], s3 = big_scan[e + 3];
-              e += (s1 <= j) + (s2 <= j) + (s3 <= j);
-            } else {
-              int lo = 0, hi = nb;
-              while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
-              e = lo;
+            const int co = chunk_owner[j >> shift];
+            int e = co & 0x7fffffff;
+            if (co >= 0) {
+              if (shift == 4) {
+                // the scan is strictly increasing: counting the next three entries <= j is the three dependent steps
+                // e += scan[e + 1] <= j in one LDS round trip (two sentinels behind scan[nb] keep the reads in range)
+                const int s1 = big_scan[e + 1], s2 = big_scan[e + 2], s3 = big_scan[e + 3];
+                e += (s1 <= j) + (s2 <= j) + (s3 <= j);
+              } else {
+                // queued tokens have >= 5 arcs: at most csize / 5 + 1 owners start inside the chunk
+                int lo = e, hi = min(nb, e + csize / 5 + 2);
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
+                e = lo;
+              }
             }
-            *i2 = big_tok[e];
-            *a = big_a0[e] + static_cast<u32>(j - big_scan[e]);
+            const int2 ta = big_ta[e];
+            *i2 = ta.x;
+            *a = static_cast<u32>(ta.y) + static_cast<u32>(j);
           };
           Stamp(&sh, PH_FLAT_SETUP);
           // 4 arcs per thread per trip: all loads are issued before the first is consumed
           // (memory-level parallelism; ~90 % of arcs fail the cutoff test and stop there)
           for (int j0 = tid; j0 < total; j0 += ARCW * NT) {
-            kamd_arc arc[ARCW]; int pdf[ARCW], tok[ARCW]; float cst[ARCW]; bool ok[ARCW];
+            uint2 hot[ARCW]; u32 aidx[ARCW]; int tok[ARCW]; float cst[ARCW]; bool ok[ARCW];
+#ifdef KAMD_HUB_PROF
+            const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
             for (int q = 0; q < ARCW; q++) {
               const int j = j0 + q * NT;
               ok[q] = j < total;
-              tok[q] = 0; pdf[q] = 0; cst[q] = 0.f;
-              arc[q].ilabel = arc[q].olabel = arc[q].nextstate = 0; arc[q].weight = 0.f;
-              if (ok[q]) {
-                u32 a; lookup(j, &a, &tok[q]);
-                arc[q] = d.g.e_arcs[a]; pdf[q] = d.e_pdf[a]; cst[q] = cost[tok[q]];
-              }
+              tok[q] = 0; aidx[q] = 0;
+              if (ok[q]) lookup(j, &aidx[q], &tok[q]);
             }
+#ifdef KAMD_HUB_PROF
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long tp1 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+            for (int q = 0; q < ARCW; q++) {
+              cst[q] = 0.f; hot[q] = make_uint2(0u, 0u);
+              if (ok[q]) { hot[q] = d.e_hot[aidx[q]]; cst[q] = cost[tok[q]]; }
+            }
+#ifdef KAMD_HUB_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long tp2 = __builtin_amdgcn_s_memtime();
+            if (tid == 0) { sh.ph[PH_FIN_SWEEP] += tp1 - tp0; sh.ph[PH_FIN_COMPACT] += tp2 - tp1; }
+#endif
 #pragma unroll
             for (int q = 0; q < ARCW; q++) tok[q] += tb;
-            ProcessArcs<ARCW>(d, c, &sh, tbl, row, arc, pdf, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
+            ProcessArcs<ARCW>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
           }
         }
         LdsBarrier();
@@ -2651,10 +2684,10 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
     for (int t = 1; t <= num_tids; t++) num_pdfs = std::max(num_pdfs, tid2pdf[t] + 1);
   }
   {
-    int *ep = static_cast<int *>(alloc(static_cast<size_t>(std::max<int64_t>(D->g->num_emit, 1)) * 4, 0));
-    d.e_pdf = ep;
+    uint2 *ep = static_cast<uint2 *>(alloc(static_cast<size_t>(std::max<int64_t>(D->g->num_emit, 1)) * 8, 0));
+    d.e_hot = ep;
     if (ok && D->g->num_emit > 0) {
-      hipLaunchKernelGGL(kamd::ArcPdfKernel, dim3(kamd::CeilDiv(D->g->num_emit, 256)), dim3(256), 0, 0, d.g.e_arcs,
+      hipLaunchKernelGGL(kamd::ArcHotKernel, dim3(kamd::CeilDiv(D->g->num_emit, 256)), dim3(256), 0, 0, d.g.e_arcs,
                          static_cast<long long>(D->g->num_emit), d.tid2pdf, ep);
       if (hipDeviceSynchronize() != hipSuccess) ok = false;
     }

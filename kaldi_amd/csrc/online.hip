@@ -518,6 +518,15 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
   const int sub = kamd_nnet_frame_subsampling_factor(b->nnet);
   const int L = kamd_nnet_left_context(b->nnet), R = kamd_nnet_right_context(b->nnet);
   std::vector<int> ready_out(n, 0);
+  // Between the incremental traceback (which advances the device's record of what the host knows) and the weighted
+  // statistics update (which consumes the popped deltas) a failure leaves the two out of step for good: the tick's streams
+  // are then out until restarted, like after a capacity error, instead of silently carrying wrong statistics.
+  bool weighting_in_flight = false;
+  auto lost = [&](int rc) {
+    if (weighting_in_flight)
+      for (int i = 0; i < n; i++) b->status[streams[i]] |= KAMD_STREAM_WEIGHTING_LOST;
+    return rc;
+  };
   if (b->ie && !b->sw.empty()) {
     // silence_weighting.ComputeCurrentTraceback(decoder.Decoder()); GetDeltaWeights(feature_pipeline.NumFramesReady());
     // IvectorFeature()->UpdateFrameWeights(delta_weights) -- one traceback launch for the tick's streams
@@ -530,20 +539,21 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
       int rc = kamd_decoder_frame_tracebacks_incremental(b->dec, tl.data(), static_cast<int>(tl.size()), tids.data(), toks.data(), longest,
                                                          cnt.data(), n_new.data());
       if (rc != KAMD_OK) return rc;
+      weighting_in_flight = true;      // the device's "known" marks have advanced: from here a failure loses deltas
     }
     size_t k = 0;
     for (int i = 0; i < n; i++) {
       const int s = streams[i], F = b->n_frames[s];
       if (b->decoded[s] > 0) {
         if (cnt[k] != b->decoded[s])
-          return kamd::SetError(KAMD_ERR_STATE, "stream %d: best path covers %d of %d decoded frames", s, cnt[k], b->decoded[s]);
+          return lost(kamd::SetError(KAMD_ERR_STATE, "stream %d: best path covers %d of %d decoded frames", s, cnt[k], b->decoded[s]));
         int rc = kamd_silence_weighting_compute_traceback(b->sw[s], b->decoded[s], tids.data() + k * longest, toks.data() + k * longest, n_new[k]);
-        if (rc != KAMD_OK) return rc;
+        if (rc != KAMD_OK) return lost(rc);
         k++;
       }
       const int iv_ready = b->finished[s] ? F : std::max(0, F - b->splice_right);
       int rc = kamd_silence_weighting_get_delta_weights(b->sw[s], iv_ready, NULL);
-      if (rc != KAMD_OK) return rc;
+      if (rc != KAMD_OK) return lost(rc);
     }
   }
   if (b->ie) {
@@ -601,14 +611,16 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
         wl_frame.resize(at + u_upto[j]); wl_weight.resize(at + u_upto[j]);
         int32_t got = 0;
         int rc = kamd_silence_weighting_pop_until(b->sw[u_rec[j]], u_upto[j] - 1, wl_frame.data() + at, wl_weight.data() + at, u_upto[j], &got);
-        if (rc != KAMD_OK) return rc;
+        if (rc != KAMD_OK) return lost(rc);
+        weighting_in_flight = true;    // deltas have left the queue
         wl_frame.resize(at + got); wl_weight.resize(at + got);
         wl_off.push_back(static_cast<int32_t>(wl_frame.size()));
       }
       int rc = kamd_ivector_stream_update_weighted_device(b->ie, b->d_frames, b->ld, static_cast<int64_t>(b->S) * b->max_frames, u_row.data(),
                                                           u_base.data(), u_done.data(), u_upto.data(), u_rec.data(), wl_off.data(),
                                                           wl_frame.data(), wl_weight.data(), static_cast<int>(u_row.size()), b->d_rec, b->d_est, st);
-      if (rc != KAMD_OK) return rc;
+      if (rc != KAMD_OK) return lost(rc);
+      weighting_in_flight = false;     // issued: host and device agree again
     }
     if (!a_src.empty()) {
       const int m = static_cast<int>(a_src.size());

@@ -151,6 +151,29 @@ def test_carpa_file_layout_and_round_trip(words_txt, tmp_path):
     t.write_bytes(raw[:len(raw) // 2])
     with pytest.raises(KamdError):
         constarpa.ConstArpaLm.read(t)
+    # corrupt <LmStates> payloads are errors of the read, not out-of-bounds accesses at rescoring time: a child count that
+    # runs past the block, a child offset that leaves it, an overflow index with no entry, a section larger than the file
+    st = states.copy()
+    roots = [int(a) - 1 for a in uni if a > 0]
+    with_children = [r for r in roots if st[r + 2] > 0]
+    assert with_children
+
+    def rewrite(mutate, header_n=None):
+        s2 = st.copy()
+        mutate(s2)
+        blob = raw[:j + 1] + struct.pack("<q", n if header_n is None else header_n) + s2.tobytes() + raw[j + 9 + 4 * n:]
+        f = tmp_path / "bad.carpa"
+        f.write_bytes(blob)
+        return f
+
+    r0 = with_children[0]
+    for mutate, msg in ((lambda a: a.__setitem__(r0 + 2, 1 << 20), "children run past"),
+                        (lambda a: a.__setitem__(r0 + 4, ((1 << 24) * 2) | 1), "outside <LmStates>"),
+                        (lambda a: a.__setitem__(r0 + 4, -((5 * 2) | 1)), "overflow index")):
+        with pytest.raises(KamdError, match=msg):
+            constarpa.ConstArpaLm.read(rewrite(mutate))
+    with pytest.raises(KamdError, match="corrupt <LmStates> header"):
+        constarpa.ConstArpaLm.read(rewrite(lambda a: None, header_n=1 << 39))
 
 
 def _sausage(paths):
