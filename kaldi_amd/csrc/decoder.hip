@@ -47,7 +47,9 @@ typedef unsigned int u32;
 #define FIN_CAP (6 * NT)     // tokens per frame the finalize sweep keeps in LDS (6 arrays)
 #define LDS_TABLE_CAP (8 * NT)   // level-1 table words (64 KB of a 1024-thread lane's LDS)
 #define SMALL_DEG 4
-#define ARCW 8           // arcs in flight per thread in the arc-parallel expansion
+#define TPG 2            // tokens a 16-lane group expands per trip (their arc records are in flight together)
+#define HUGE_DEG 256      // tokens with more emitting arcs are expanded by the whole lane, one after the other
+#define ARCW 4           // arcs in flight per thread in the arc-parallel expansion
 #define CHUNKCAP (4 * NT)    // cached chunk owners (16 arcs each) per flatten batch
 static_assert(NT == 1024 || NT == 512, "KAMD_NT: 1024 (one lane per CU) or 512 (two)");
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
@@ -142,7 +144,7 @@ struct Sh {  // workgroup-shared state
   float redf[NWAVES];
   u32 hist[256];
   u32 next_cutoff_u;
-  int n_slots, n_slots1, n_links, wl_n[2], err, bigcnt, changed;   // n_slots: level-2 (HBM) entries, n_slots1: level-1 (LDS)
+  int n_slots, n_slots1, n_links, wl_n[2], err, bigcnt, hugecnt, changed;   // n_slots: level-2 (HBM) entries, n_slots1: level-1 (LDS)
   int sel_bin, sel_below;
   int scan_total;
   int big_total;
@@ -498,14 +500,25 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
                                    const uint2 (&hot)[W], const u32 (&aidx)[W], const int (&src_tok)[W],
                                    const float (&cur_cost)[W], const bool (&ok)[W], float cost_offset,
                                    float adaptive_beam, int link_base, bool loose, float seed_cutoff) {
-  float ac[W], tot[W];
+  float ac[W], tot[W], llv[W];
   bool pass[W];
   // the running bound, read once for the W arcs: any value >= the frame's final cutoff is a valid filter here (the dense
   // sweep applies the final one), and the bound only ever tightens
   float nc = OrderedToFloat(sh->next_cutoff_u);
+  // the W scores: LDS reads issued together, no branch in between (hipcc drains vmcnt / lgkmcnt at the end of every
+  // conditional block that loads, which would make the W arcs W sequential round trips); the pdfs beyond the LDS part
+  // of the row -- none at all for the usual chain model -- are patched from HBM afterwards
 #pragma unroll
   for (int q = 0; q < W; q++) {
-    ac[q] = cost_offset - LogLikePdf(ll, ok[q] ? static_cast<int>(hot[q].y) : 0);
+    const int pdf = ok[q] ? static_cast<int>(hot[q].y) : 0;
+    llv[q] = ll.l[max(min(pdf, ll.n_lds - 1), 0)];
+  }
+#pragma unroll
+  for (int q = 0; q < W; q++)
+    if (ok[q] && static_cast<int>(hot[q].y) >= ll.n_lds) llv[q] = ll.g[hot[q].y];
+#pragma unroll
+  for (int q = 0; q < W; q++) {
+    ac[q] = cost_offset - llv[q];
     tot[q] = cur_cost[q] + ac[q] + __uint_as_float(hot[q].x);
     pass[q] = ok[q] && !(tot[q] > (loose ? seed_cutoff : nc));
     if (pass[q]) {
@@ -549,15 +562,14 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
       const int li = link_begin + threadIdx.x + (g0 + k) * NT;
-      L[k].src = 0; L[k].dst = 0; L[k].ilabel = 0; L[k].olabel = 0; L[k].graph = 0.f; L[k].ac = 0.f;
-      if (li < le) L[k] = c.links[li];
+      L[k] = c.links[min(li, le - 1)];          // (unconditional, clamped: see the expansion; le > link_begin here)
     }
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
       const int li = link_begin + threadIdx.x + (g0 + k) * NT;
-      cs[k] = li < le ? c.tok_cost[L[k].src] : INFINITY;
-      arc[k].ilabel = arc[k].olabel = arc[k].nextstate = 0; arc[k].weight = 0.f;
-      if (li < le) arc[k] = d.g.e_arcs[static_cast<u32>(L[k].dst)];       // the record of the arc ProcessArcs kept by index
+      cs[k] = c.tok_cost[L[k].src];
+      // the record of the arc ProcessArcs kept by index (a clamped lane may see a link its owner has rewritten: arc 0)
+      arc[k] = d.g.e_arcs[li < le ? static_cast<u32>(L[k].dst) : 0u];
     }
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
@@ -1100,7 +1112,7 @@ __device__ void PublishLaneEnd(const DecDev &d, const Ctx &c, Sh *sh, int frame)
 __device__ inline void InitSh(Sh *sh) {
   if (threadIdx.x == 0) {
     sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
-    sh->bigcnt = 0; sh->n_new = 0; sh->best_key = EMPTY64; sh->c_lt = 0; sh->c_le = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
+    sh->bigcnt = 0; sh->hugecnt = 0; sh->n_new = 0; sh->best_key = EMPTY64; sh->c_lt = 0; sh->c_le = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
     sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0;
     for (int i = 0; i < 8; i++) sh->cnt[i] = 0;
     for (int i = 0; i < 16; i++) sh->ph[i] = 0;
@@ -1152,7 +1164,6 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
   float *ll_lds = reinterpret_cast<float *>(big_scan + BIGCAP + 4);// [num_pdfs_lds]  (+4: sentinel)
   u32 *lh_lds = reinterpret_cast<u32 *>(ll_lds + ((d.num_pdfs_lds + 3) & ~3));   // [LHBINS]
   float *cand_lds = reinterpret_cast<float *>(lh_lds + LHBINS);                  // [LHCAND]
-  int *chunk_owner = reinterpret_cast<int *>(lh_lds);   // [CHUNKCAP] aliases the select scratch (disjoint phases)
   Tbl tbl;
   tbl.LH = reinterpret_cast<u64 *>(lh_lds + (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP));
   tbl.lcap = d.lds_table_cap;
@@ -1273,13 +1284,17 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
 #pragma unroll
       for (int k = 0; k < EXPT; k++) {
         const int i = base + tid + k * NT;
-        tcost[k] = INFINITY; tstate[k] = 0;
-        if (i < n) { tcost[k] = cost[i]; tstate[k] = state[i]; }
+        // (unconditional loads at a clamped index: a load inside a conditional block is waited for at the block's end,
+        // which would serialize the EXPT fetches)
+        const int ic = min(i, n - 1);
+        tcost[k] = cost[ic]; tstate[k] = state[ic];
+        if (i >= n) tcost[k] = INFINITY;
       }
 #pragma unroll
       for (int k = 0; k < EXPT; k++) {
-        ta0[k] = 0; ta1[k] = 0;
-        if (base + tid + k * NT < n && tcost[k] <= cur_cutoff) { ta0[k] = d.g.off[tstate[k]].x; ta1[k] = d.g.off[tstate[k] + 1].x; }   // :787 (the cutoff may be +inf)
+        const uint2 o0 = d.g.off[tstate[k]], o1 = d.g.off[tstate[k] + 1];
+        const bool live = base + tid + k * NT < n && tcost[k] <= cur_cutoff;      // :787 (the cutoff may be +inf)
+        ta0[k] = live ? o0.x : 0u; ta1[k] = live ? o1.x : 0u;
       }
 #pragma unroll
       for (int k = 0; k < EXPT; k++) {
@@ -1296,120 +1311,79 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
             for (int q = 0; q < SMALL_DEG; q++) {
               ok[q] = static_cast<u32>(q) < deg;
               tok[q] = tb + i; cst[q] = cur_cost; aidx[q] = a0 + q;
-              hot[q] = make_uint2(0u, 0u);
-              if (ok[q]) hot[q] = d.e_hot[a0 + q];
+              hot[q] = d.e_hot[ok[q] ? a0 + q : 0u];
             }
             ProcessArcs<SMALL_DEG>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
           } else {
-            const int p = WaveAlloc(&sh.bigcnt);   // < BIGCAP: at most EXPT * NT entries per outer iteration
+            // one entry per token (at most EXPT * NT = BIGCAP per outer iteration): tokens of up to HUGE_DEG arcs fill the
+            // queue from the bottom, the few with more (the LM's start / backoff hubs) from the top
+            int p;
+            if (deg <= HUGE_DEG) p = WaveAlloc(&sh.bigcnt); else p = BIGCAP - 1 - WaveAlloc(&sh.hugecnt);
             big_ta[p] = make_int2(i, static_cast<int>(a0)); big_scan[p] = deg;
           }
         }
       }
-      const bool last_chunk = true;                // the queue is flushed after every outer iteration
       LdsBarrier();
-      const int nb = sh.bigcnt;                    // uniform: read between two barriers
+      const int nb = sh.bigcnt, nh = sh.hugecnt;   // uniform: read between two barriers
       LdsBarrier();
-      if (nb > 0 && (nb > BIGCAP - NT || last_chunk)) {
+      if (nb + nh > 0) {
         Stamp(&sh, PH_EXPAND);
-        // exclusive scan of the queued degrees (3 entries per thread)
-        int v0 = 0, v1 = 0, v2 = 0;
-        const int e0 = 3 * tid;
-        if (e0 < nb) v0 = big_scan[e0];
-        if (e0 + 1 < nb) v1 = big_scan[e0 + 1];
-        if (e0 + 2 < nb) v2 = big_scan[e0 + 2];
-        const int mine = v0 + v1 + v2;
-        const int lane = tid & 63, w = tid >> 6;
-        const int incl = WaveInclScanI(mine);
-        LdsBarrier();
-        if (lane == 63) sh.redi[w] = incl;
-        LdsBarrier();
-        int wbase = 0, total = 0;
-        for (int k = 0; k < NWAVES; k++) { int cnum = sh.redi[k]; if (k < w) wbase += cnum; total += cnum; }
-        const int excl = wbase + incl - mine;
-        // (the entry's arc base becomes "first arc - scan": arc j of the flattened range is base + j)
-        if (e0 < nb) { big_scan[e0] = excl; big_ta[e0].y -= excl; }
-        if (e0 + 1 < nb) { big_scan[e0 + 1] = excl + v0; big_ta[e0 + 1].y -= excl + v0; }
-        if (e0 + 2 < nb) { big_scan[e0 + 2] = excl + v0 + v1; big_ta[e0 + 2].y -= excl + v0 + v1; }
-        LdsBarrier();
+        // A queued token is expanded by a GROUP of 16 lanes, 64 arcs per trip (4 per lane, all loaded before the first is
+        // used): consecutive lanes read consecutive 8-byte records of one state, the token's index and cost are read once
+        // per token, and no arc needs a search for its owner (the flattened arc-parallel form this replaces spent more
+        // than half of the expansion's issue slots on that search).  Groups take the tokens round robin; the degrees of
+        // the states that matter (LM history states: tens of arcs) make the trips of a wavefront's four groups alike.
         {
-          // owner of the first arc of every 16-arc chunk, computed once per batch.  Queued
-          // tokens have >= 5 arcs, so at most 4 of them start inside a chunk: the per-arc
-          // owner lookup is the chunk's owner plus three branch-free compare steps
-          // (big_scan[nb] = total is the sentinel).
-          // (a batch with more than 16 * CHUNKCAP arcs -- a frame behind a word boundary, where the LM's hubs are live --
-          // uses chunks of 32, 64, ... arcs, so that every chunk's owner is cached)
-          int shift = 4;
-          while (((total + (1 << shift) - 1) >> shift) > CHUNKCAP) shift++;
-          const int csize = 1 << shift;
-          const int nchunks = (total + csize - 1) >> shift;
-          if (tid == 0) { big_scan[nb] = total; big_scan[nb + 1] = 0x7fffffff; big_scan[nb + 2] = 0x7fffffff; }
-          for (int cidx = tid; cidx < nchunks; cidx += NT) {
-            const int j = cidx << shift;
-            int lo = 0, hi = nb;
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
-            // bit 31: the whole chunk belongs to this owner (the rule on frames that hubs dominate): its arcs need no
-            // further look at the scan
-            const int next = lo + 1 < nb ? big_scan[lo + 1] : total;
-            chunk_owner[cidx] = lo | (next >= j + csize ? static_cast<int>(0x80000000u) : 0);
-          }
-          LdsBarrier();
-          auto lookup = [&](int j, u32 *a, int *i2) {
-            const int co = chunk_owner[j >> shift];
-            int e = co & 0x7fffffff;
-            if (co >= 0) {
-              if (shift == 4) {
-                // the scan is strictly increasing: counting the next three entries <= j is the three dependent steps
-                // e += scan[e + 1] <= j in one LDS round trip (two sentinels behind scan[nb] keep the reads in range)
-                const int s1 = big_scan[e + 1], s2 = big_scan[e + 2], s3 = big_scan[e + 3];
-                e += (s1 <= j) + (s2 <= j) + (s3 <= j);
-              } else {
-                // queued tokens have >= 5 arcs: at most csize / 5 + 1 owners start inside the chunk
-                int lo = e, hi = min(nb, e + csize / 5 + 2);
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (big_scan[mid] <= j) lo = mid; else hi = mid; }
-                e = lo;
+          const int grp = tid >> 4, sub = tid & 15;
+          // two tokens per group and trip: the records of both are in flight together (a trip is one HBM round trip; what
+          // bounds the expansion is how many of them a CU has outstanding)
+          for (int e = grp; e < nb; e += TPG * (NT / 16)) {
+            int2 ta[TPG]; int deg[TPG]; float cs[TPG];
+            int dmax = 0;
+#pragma unroll
+            for (int t = 0; t < TPG; t++) {
+              const int et = e + t * (NT / 16);
+              const bool have = et < nb;
+              ta[t] = big_ta[have ? et : e];
+              deg[t] = have ? big_scan[et] : 0;
+              dmax = max(dmax, deg[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < TPG; t++) cs[t] = cost[ta[t].x];
+            for (int k0 = 0; k0 < dmax; k0 += 64) {
+              uint2 hot[4 * TPG]; u32 aidx[4 * TPG]; int tok[4 * TPG]; float cst[4 * TPG]; bool ok[4 * TPG];
+#pragma unroll
+              for (int q = 0; q < 4 * TPG; q++) {
+                const int k = k0 + sub + 16 * (q & 3);
+                ok[q] = k < deg[q >> 2];
+                aidx[q] = static_cast<u32>(ta[q >> 2].y) + static_cast<u32>(k);
+                tok[q] = tb + ta[q >> 2].x; cst[q] = cs[q >> 2];
+                hot[q] = d.e_hot[ok[q] ? aidx[q] : static_cast<u32>(ta[q >> 2].y)];
               }
+              ProcessArcs<4 * TPG>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
             }
-            const int2 ta = big_ta[e];
-            *i2 = ta.x;
-            *a = static_cast<u32>(ta.y) + static_cast<u32>(j);
-          };
-          Stamp(&sh, PH_FLAT_SETUP);
-          // 4 arcs per thread per trip: all loads are issued before the first is consumed
-          // (memory-level parallelism; ~90 % of arcs fail the cutoff test and stop there)
-          for (int j0 = tid; j0 < total; j0 += ARCW * NT) {
+          }
+        }
+        // the hubs: every thread of the lane on one token's arcs, ARCW per thread per trip
+        for (int h = 0; h < nh; h++) {
+          const int2 ta = big_ta[BIGCAP - 1 - h];
+          const int deg = big_scan[BIGCAP - 1 - h];
+          const float cst1 = cost[ta.x];
+          for (int k0 = tid; k0 < deg; k0 += ARCW * NT) {
             uint2 hot[ARCW]; u32 aidx[ARCW]; int tok[ARCW]; float cst[ARCW]; bool ok[ARCW];
-#ifdef KAMD_HUB_PROF
-            const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
-#endif
 #pragma unroll
             for (int q = 0; q < ARCW; q++) {
-              const int j = j0 + q * NT;
-              ok[q] = j < total;
-              tok[q] = 0; aidx[q] = 0;
-              if (ok[q]) lookup(j, &aidx[q], &tok[q]);
+              const int k = k0 + q * NT;
+              ok[q] = k < deg;
+              aidx[q] = static_cast<u32>(ta.y) + static_cast<u32>(k);
+              tok[q] = tb + ta.x; cst[q] = cst1;
+              hot[q] = d.e_hot[ok[q] ? aidx[q] : static_cast<u32>(ta.y)];
             }
-#ifdef KAMD_HUB_PROF
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned long long tp1 = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll
-            for (int q = 0; q < ARCW; q++) {
-              cst[q] = 0.f; hot[q] = make_uint2(0u, 0u);
-              if (ok[q]) { hot[q] = d.e_hot[aidx[q]]; cst[q] = cost[tok[q]]; }
-            }
-#ifdef KAMD_HUB_PROF
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned long long tp2 = __builtin_amdgcn_s_memtime();
-            if (tid == 0) { sh.ph[PH_FIN_SWEEP] += tp1 - tp0; sh.ph[PH_FIN_COMPACT] += tp2 - tp1; }
-#endif
-#pragma unroll
-            for (int q = 0; q < ARCW; q++) tok[q] += tb;
             ProcessArcs<ARCW>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
           }
         }
         LdsBarrier();
-        if (tid == 0) sh.bigcnt = 0;
+        if (tid == 0) { sh.bigcnt = 0; sh.hugecnt = 0; }
         LdsBarrier();
         Stamp(&sh, PH_EXPAND_BIG);
       }
