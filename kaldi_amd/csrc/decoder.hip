@@ -534,7 +534,8 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
     if (!pass[q]) continue;
     const int li = link_base + WaveAlloc(&sh->n_links);
     if (li >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
-    Link L; L.src = src_tok[q]; L.dst = static_cast<int>(aidx[q]); L.ilabel = 0; L.olabel = 0;
+    // (the ilabel field carries the arc's total cost to the insert sweep, which then needs no look at the source token)
+    Link L; L.src = src_tok[q]; L.dst = static_cast<int>(aidx[q]); L.ilabel = __float_as_int(tot[q]); L.olabel = 0;
     L.graph = __uint_as_float(hot[q].x); L.ac = ac[q];
     c.links[li] = L;
   }
@@ -558,7 +559,7 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
   // INSB links per thread per trip: the records, then the source costs, are loaded for the
   // whole batch before the first insert (two dependent round trips per batch, not per link)
   for (int g0 = 0; link_begin + g0 * NT < le; g0 += INSB) {
-    Link L[INSB]; float cs[INSB]; kamd_arc arc[INSB];
+    Link L[INSB]; kamd_arc arc[INSB];
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
       const int li = link_begin + threadIdx.x + (g0 + k) * NT;
@@ -567,7 +568,6 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
       const int li = link_begin + threadIdx.x + (g0 + k) * NT;
-      cs[k] = c.tok_cost[L[k].src];
       // the record of the arc ProcessArcs kept by index (a clamped lane may see a link its owner has rewritten: arc 0)
       arc[k] = d.g.e_arcs[li < le ? static_cast<u32>(L[k].dst) : 0u];
     }
@@ -575,7 +575,7 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
     for (int k = 0; k < INSB; k++) {
       const int li = link_begin + threadIdx.x + (g0 + k) * NT;
       if (li >= le) continue;
-      const float tot = cs[k] + L[k].ac + L[k].graph;
+      const float tot = __int_as_float(L[k].ilabel);      // == source cost + ac + graph, as ProcessArcs summed it
       int dst = -1;
       if (tot <= cutoff) {                       // :798 with the frame's final cutoff
         bool improved;
@@ -878,8 +878,13 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
       if (e == EMPTY64 || cur_cost > cutoff) continue;      // :867
       const int s = PlainState(StateOf(e));
       const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
-      for (u32 a = a0; a < a1; a++) {
-        const kamd_arc arc = d.g.n_arcs[a];
+      // (two records per trip, fetched together: a state with an LM backoff arc and one more is the common case)
+      for (u32 ab = a0; ab < a1; ab += 2) {
+        const kamd_arc x0 = d.g.n_arcs[ab], x1 = d.g.n_arcs[min(ab + 1, a1 - 1)];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+        if (ab + q >= a1) break;
+        const kamd_arc arc = q ? x1 : x0;
         const float tot_cost = cur_cost + arc.weight;
         if (tot_cost < cutoff) {            // :882
           bool improved;
@@ -890,6 +895,7 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
             else first = atomicExch(&c.stamp[slot2], round) != round;
             if (first) wl_put(cur ^ 1, WaveAlloc(&sh->wl_n[cur ^ 1]), static_cast<u32>(slot2));
           }
+        }
         }
       }
     }
@@ -999,18 +1005,23 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
       const int t = tok_of_slot(static_cast<int>(slot));
       const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
       a_eps += static_cast<int>(a1 - a0);
-      for (u32 a = a0; a < a1; a++) {
-        const kamd_arc arc = d.g.n_arcs[a];
-        const float tot_cost = cur_cost + arc.weight;
-        if (tot_cost < cutoff) {
-          const int slot2 = TblFind(d, c, tbl, arc.nextstate);
-          const int dst = slot2 >= 0 ? tok_of_slot(slot2) : -1;
-          if (dst < 0) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
-          const int li = eps_link_begin + WaveAlloc(&sh->wl_n[0]);   // worklist 0 is idle here
-          if (li >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
-          Link Lk; Lk.src = t; Lk.dst = dst; Lk.ilabel = 0; Lk.olabel = arc.olabel;
-          Lk.graph = arc.weight; Lk.ac = 0.0f;
-          c.links[li] = Lk;
+      for (u32 ab = a0; ab < a1; ab += 2) {
+        const kamd_arc x0 = d.g.n_arcs[ab], x1 = d.g.n_arcs[min(ab + 1, a1 - 1)];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          if (ab + q >= a1) break;
+          const kamd_arc arc = q ? x1 : x0;
+          const float tot_cost = cur_cost + arc.weight;
+          if (tot_cost < cutoff) {
+            const int slot2 = TblFind(d, c, tbl, arc.nextstate);
+            const int dst = slot2 >= 0 ? tok_of_slot(slot2) : -1;
+            if (dst < 0) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
+            const int li = eps_link_begin + WaveAlloc(&sh->wl_n[0]);   // worklist 0 is idle here
+            if (li >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
+            Link Lk; Lk.src = t; Lk.dst = dst; Lk.ilabel = 0; Lk.olabel = arc.olabel;
+            Lk.graph = arc.weight; Lk.ac = 0.0f;
+            c.links[li] = Lk;
+          }
         }
       }
     }
