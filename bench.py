@@ -763,6 +763,8 @@ def planted_variant(args, g, model, cfg, durs, make_decoder, timed, latbin, synt
            "tokens_per_frame": counters[5] / fr_tot, "expanded_per_frame": counters[0] / fr_tot, "arcs_per_frame": counters[1] / fr_tot,
            "us_per_frame_per_lane": 1e3 * float(acc[2]) * int(st.lanes) / fr_tot, "failed_utterances": sum(1 for r in recs if r.error),
            "peak": args.planted_peak, "noise": args.planted_noise, "synthesis_s": t_synth,
+           "phase_share_longest_utterance": (lambda ph: {k2: round(float(v / max(ph.sum(), 1.0)), 3) for k2, v in zip(PHASES, ph)})(
+               np.asarray(recs[int(np.argmax([r.n_frames for r in recs]))].phase_cycles[:len(PHASES)], np.float64)),
            "what": "planted word sequences (3 words per second of audio) through the bench HCLG; the acoustic model runs in the timed "
                    "region, the search reads planted log-likelihoods (noise %.1f on every pdf, peak %.1f on the path's); "
                    "%%WER against the transcript from the 1-best of the timed run" %

@@ -542,6 +542,7 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
 }
 
 #define COMMIT_KEEP 2
+#define L2B 2             // level-2 (HBM) table entries / links per thread fetched together in the commit
 #define INSB 4            // links per thread fetched together in InsertEmitted (>= COMMIT_KEEP)
 static_assert(EXPT * NT == BIGCAP, "one outer expansion iteration must fit the flatten queue");
 static_assert(LDS_TABLE_CAP <= 256 * 32, "CommitFrame2 keeps one 'queued' bit per level-1 slot in Sh::hist[256]");
@@ -857,11 +858,21 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
     const u64 e = tbl.LH[sl];
     if (HasEps(StateOf(e)) && CostOf(e) <= cutoff) wl_put(0, WaveAlloc(&sh->wl_n[0]), sl);
   }
-  for (int i = tid; i < n2; i += NT) {
-    const u32 slot = c.slots[i];
-    const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
-    if (e == EMPTY64) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
-    if (HasEps(StateOf(e)) && CostOf(e) <= cutoff) wl_put(0, WaveAlloc(&sh->wl_n[0]), slot);
+  // (level-2 entries: four per thread and trip, slot list then table words, each set of loads issued together and
+  // unconditional -- a load inside a conditional block is waited for at the block's end)
+  for (int i0 = tid; i0 < n2; i0 += L2B * NT) {
+    u32 sl[L2B]; u64 e[L2B];
+#pragma unroll
+    for (int k = 0; k < L2B; k++) sl[k] = c.slots[min(i0 + k * NT, n2 - 1)];
+#pragma unroll
+    for (int k = 0; k < L2B; k++) e[k] = LoadH(&c.H[static_cast<int>(sl[k]) - lcap]);
+#pragma unroll
+    for (int k = 0; k < L2B; k++) {
+      if (i0 + k * NT < n2) {
+        if (e[k] == EMPTY64) atomicOr(&sh->err, ERR_INTERNAL);
+        else if (HasEps(StateOf(e[k])) && CostOf(e[k]) <= cutoff) wl_put(0, WaveAlloc(&sh->wl_n[0]), sl[k]);
+      }
+    }
   }
   if (tid < 256) sh->hist[tid] = 0;                 // "queued this round" bits of the level-1 slots
   LdsBarrier();
@@ -951,14 +962,25 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
     if (idx >= 0 && HasEps(StateOf(e)) && CostOf(e) <= cutoff) add_owner(sl, e);
     tbl.LH[sl] = (e & 0xFFFFFFFF00000000ull) | static_cast<u32>(idx);   // cost half -> token index
   }
-  for (int i = tid; i < ns2; i += NT) {
-    const u32 slot = c.slots[i];
-    const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
-    if (e == EMPTY64) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
-    int idx;
-    commit_entry(e, n1 + i, &idx);
-    if (idx >= 0 && HasEps(StateOf(e)) && CostOf(e) <= cutoff) add_owner(slot, e);
-    c.slot_tok[slot] = idx;
+  for (int i0 = tid; i0 < ns2; i0 += L2B * NT) {
+    u32 sl[L2B]; u64 e[L2B];
+#pragma unroll
+    for (int k = 0; k < L2B; k++) sl[k] = c.slots[min(i0 + k * NT, ns2 - 1)];
+#pragma unroll
+    for (int k = 0; k < L2B; k++) e[k] = LoadH(&c.H[static_cast<int>(sl[k]) - lcap]);
+#pragma unroll
+    for (int k = 0; k < L2B; k++) {
+      const int i = i0 + k * NT;
+      if (i < ns2) {
+        if (e[k] == EMPTY64) atomicOr(&sh->err, ERR_INTERNAL);
+        else {
+          int idx;
+          commit_entry(e[k], n1 + i, &idx);
+          if (idx >= 0 && HasEps(StateOf(e[k])) && CostOf(e[k]) <= cutoff) add_owner(sl[k], e[k]);
+          c.slot_tok[sl[k]] = idx;
+        }
+      }
+    }
   }
   // full barrier only when level-2 entries or list overflow put data in HBM that others read
   const bool hbm_lists = ns2 > 0;
@@ -986,9 +1008,24 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
       const int li = lb + tid + k * NT;
       if (li < le && my_slot[k] >= 0) c.links[li].dst = tok_of_slot(my_slot[k]);
     }
-    for (int li = lb + tid + COMMIT_KEEP * NT; li < le; li += NT) {
-      const int slot = c.links[li].dst;
-      if (slot >= 0) c.links[li].dst = tok_of_slot(slot);
+    for (int l0 = lb + tid + COMMIT_KEEP * NT; l0 < le; l0 += L2B * NT) {
+      int slot[L2B], t1[L2B], t2[L2B];
+#pragma unroll
+      for (int k = 0; k < L2B; k++) {
+        slot[k] = c.links[min(l0 + k * NT, le - 1)].dst;
+        if (l0 + k * NT >= le) slot[k] = -1;        // (a clamped lane may see a link its owner has resolved already)
+      }
+      // both levels are read for every link (level 1: LDS; level 2: HBM, a dummy word for the links that are not there)
+#pragma unroll
+      for (int k = 0; k < L2B; k++) {
+        t1[k] = static_cast<int>(static_cast<u32>(tbl.LH[min(max(slot[k], 0), lcap - 1)]));
+        t2[k] = c.slot_tok[slot[k] >= lcap ? slot[k] : lcap];
+      }
+#pragma unroll
+      for (int k = 0; k < L2B; k++) {
+        const int li = l0 + k * NT;
+        if (li < le && slot[k] >= 0) c.links[li].dst = slot[k] < lcap ? t1[k] : t2[k];
+      }
     }
   }
   // ---- epsilon links of the surviving tokens (final costs), :875-897
