@@ -47,6 +47,7 @@ typedef unsigned int u32;
 #define FIN_CAP (6 * NT)     // tokens per frame the finalize sweep keeps in LDS (6 arrays)
 #define LDS_TABLE_CAP (8 * NT)   // level-1 table words (64 KB of a 1024-thread lane's LDS)
 #define SMALL_DEG 4
+#define GL 8             // lanes of a group (4 * GL arcs of a token per trip)
 #define TPG 2            // tokens a 16-lane group expands per trip (their arc records are in flight together)
 #define HUGE_DEG 256      // tokens with more emitting arcs are expanded by the whole lane, one after the other
 #define ARCW 4           // arcs in flight per thread in the arc-parallel expansion
@@ -1382,15 +1383,15 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
         // than half of the expansion's issue slots on that search).  Groups take the tokens round robin; the degrees of
         // the states that matter (LM history states: tens of arcs) make the trips of a wavefront's four groups alike.
         {
-          const int grp = tid >> 4, sub = tid & 15;
+          const int grp = tid / GL, sub = tid % GL;
           // two tokens per group and trip: the records of both are in flight together (a trip is one HBM round trip; what
           // bounds the expansion is how many of them a CU has outstanding)
-          for (int e = grp; e < nb; e += TPG * (NT / 16)) {
+          for (int e = grp; e < nb; e += TPG * (NT / GL)) {
             int2 ta[TPG]; int deg[TPG]; float cs[TPG];
             int dmax = 0;
 #pragma unroll
             for (int t = 0; t < TPG; t++) {
-              const int et = e + t * (NT / 16);
+              const int et = e + t * (NT / GL);
               const bool have = et < nb;
               ta[t] = big_ta[have ? et : e];
               deg[t] = have ? big_scan[et] : 0;
@@ -1398,11 +1399,11 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
             }
 #pragma unroll
             for (int t = 0; t < TPG; t++) cs[t] = cost[ta[t].x];
-            for (int k0 = 0; k0 < dmax; k0 += 64) {
+            for (int k0 = 0; k0 < dmax; k0 += 4 * GL) {
               uint2 hot[4 * TPG]; u32 aidx[4 * TPG]; int tok[4 * TPG]; float cst[4 * TPG]; bool ok[4 * TPG];
 #pragma unroll
               for (int q = 0; q < 4 * TPG; q++) {
-                const int k = k0 + sub + 16 * (q & 3);
+                const int k = k0 + sub + GL * (q & 3);
                 ok[q] = k < deg[q >> 2];
                 aidx[q] = static_cast<u32>(ta[q >> 2].y) + static_cast<u32>(k);
                 tok[q] = tb + ta[q >> 2].x; cst[q] = cs[q >> 2];
