@@ -229,6 +229,21 @@ int kamd_nnet_forward_range(kamd_nnet *n, const float *d_feats, int ld_in, int f
 /* total multiply-accumulates of the last forward (for the MFMA roofline). */
 double kamd_nnet_last_flops(const kamd_nnet *n);
 
+/* ------------------------------------------------------------- component -- */
+/* nnet3::Component::Propagate (nnet3/nnet-component-itf.h:130-132) for one fused layer -- the compatibility entry for
+ * a host that keeps nnet3's own NnetComputer and hands single components to the device.  The shape of
+ * TdnnComponent::Propagate (nnet3/nnet-tdnn-component.cc:181-212; AffineComponent :1234 is the one-offset case): `in`
+ * holds in_rows consecutive time steps, out row j = sum_i W_i in[j + off_i - off_min] (+ bias, then the layer's ReLU /
+ * BatchNorm / post map), in_rows - (off_max - off_min) rows.  The layer's input_layer / bypass fields are ignored (those
+ * are descriptors of the graph, not of the component); ivector_dim must be 0.  Matrices are device pointers. */
+typedef struct kamd_component kamd_component;
+kamd_component *kamd_component_create(const kamd_layer_desc *layer);
+void kamd_component_destroy(kamd_component *c);
+int kamd_component_output_rows(const kamd_component *c, int in_rows);
+/* returns the number of rows written (kamd_component_output_rows) or a negative status */
+int kamd_component_propagate(kamd_component *c, const float *d_in, int in_rows, int ld_in, float *d_out, int ld_out,
+                             void *stream);
+
 /* ----------------------------------------------------------------- model -- */
 /* final.mdl -> what the decode path consumes.  Replaces, for this path, what the binary does
  * before it decodes (nnet3bin/nnet3-latgen-faster.cc:91-104): ReadKaldiObject of the

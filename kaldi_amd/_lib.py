@@ -66,6 +66,10 @@ def lib():
     sig("kamd_nnet_num_frames_ready", C.c_int, [vp, C.c_int, C.c_int])
     sig("kamd_nnet_forward_range", C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int])
     sig("kamd_nnet_create", vp, [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int])
+    sig("kamd_component_create", vp, [C.POINTER(abi.LayerDesc)])
+    sig("kamd_component_destroy", None, [vp])
+    sig("kamd_component_output_rows", C.c_int, [vp, C.c_int])
+    sig("kamd_component_propagate", C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp])
     sig("kamd_model_read", vp, [C.c_char_p, C.c_float, C.c_int])
     sig("kamd_model_destroy", None, [vp])
     sig("kamd_model_info", C.c_int, [vp, ip, ip, ip, ip, ip, ip])
@@ -271,7 +275,7 @@ def lib():
 
 EXPORTS = """kamd_malloc kamd_free kamd_memcpy_h2d kamd_memcpy_d2h kamd_device_synchronize kamd_device_mem_info kamd_last_error kamd_version kamd_device_count kamd_set_device kamd_mfcc_opts_default
 kamd_fbank_opts_default kamd_mfcc_create kamd_fbank_create kamd_feat_destroy kamd_feat_dim
-kamd_feat_num_frames kamd_feat_compute kamd_feat_compute_batch_device kamd_feat_num_frames_flush kamd_feat_compute_frames_device kamd_online_feat_create kamd_online_feat_destroy kamd_online_feat_accept_waveform kamd_online_feat_input_finished kamd_online_feat_num_frames_ready kamd_online_feat_is_last_frame kamd_online_feat_get_frames kamd_online_feat_device_frames kamd_nnet_num_frames_ready kamd_nnet_forward_range kamd_nnet_create kamd_model_read kamd_model_destroy kamd_model_info kamd_model_layers kamd_model_transition_tables kamd_model_create_nnet
+kamd_feat_num_frames kamd_feat_compute kamd_feat_compute_batch_device kamd_feat_num_frames_flush kamd_feat_compute_frames_device kamd_online_feat_create kamd_online_feat_destroy kamd_online_feat_accept_waveform kamd_online_feat_input_finished kamd_online_feat_num_frames_ready kamd_online_feat_is_last_frame kamd_online_feat_get_frames kamd_online_feat_device_frames kamd_nnet_num_frames_ready kamd_nnet_forward_range kamd_nnet_create kamd_component_create kamd_component_destroy kamd_component_output_rows kamd_component_propagate kamd_model_read kamd_model_destroy kamd_model_info kamd_model_layers kamd_model_transition_tables kamd_model_create_nnet
 kamd_nnet_destroy kamd_nnet_output_dim kamd_nnet_left_context kamd_nnet_right_context
 kamd_nnet_num_output_frames kamd_nnet_frame_subsampling_factor kamd_nnet_forward_batch_device kamd_nnet_forward kamd_nnet_last_flops
 kamd_graph_create kamd_graph_destroy kamd_graph_num_states kamd_graph_num_arcs

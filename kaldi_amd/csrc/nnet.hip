@@ -1752,6 +1752,68 @@ int kamd_nnet_forward_chunked_device(kamd_nnet *h, const float *d_feats, const i
                       ld_out, stream, NULL, &cs);
 }
 
+// ---- nnet3::Component::Propagate (nnet3/nnet-component-itf.h:130-132) for ONE fused layer: SURVEY 8(b)'s option (i),
+// the compatibility entry for a host that keeps nnet3's own computation and hands single components to the device.
+// TdnnComponent::Propagate's shape (nnet-tdnn-component.cc:181-212): `in` holds consecutive time steps, out row j is
+// sum_i W_i in[j + off_i - off_min] (+ bias, ReLU, BatchNorm of the fused layer), so out has in_rows - (off_max - off_min)
+// rows.  Built on the batched forward: the layer as a one-layer network over the in_rows "frames", whose interior rows
+// (the ones no edge clamp touches) are exactly those outputs.
+struct Component {
+  kamd_nnet *net; int in_dim, out_dim, off_min, off_max, ld;
+  float *d_in = NULL, *d_out = NULL; size_t in_cap = 0, out_cap = 0;
+};
+
+kamd_component *kamd_component_create(const kamd_layer_desc *layer) {
+  if (!layer || layer->ivector_dim != 0 || layer->n_offsets < 1) { kamd::SetError(KAMD_ERR_ARG, "kamd_component_create: a plain fused layer is expected"); return NULL; }
+  kamd_layer_desc d = *layer;
+  d.input_layer = -1; d.bypass_layer = -2; d.bypass_scale = 0.0f;      // (a bypass is a Sum descriptor of the graph, not of the component)
+  kamd_nnet *net = kamd_nnet_create(&d, 1, d.in_dim, 1);
+  if (!net) return NULL;
+  Component *c = new Component();
+  c->net = net; c->in_dim = d.in_dim; c->out_dim = d.out_dim; c->ld = kamd::RoundUp(d.in_dim, 16);
+  c->off_min = d.offsets[0]; c->off_max = d.offsets[0];
+  for (int i = 1; i < d.n_offsets; i++) { c->off_min = std::min(c->off_min, d.offsets[i]); c->off_max = std::max(c->off_max, d.offsets[i]); }
+  if (c->off_min > 0 || c->off_max < 0) {   // (every recipe's offsets straddle 0; the interior-row argument below needs it)
+    kamd::SetError(KAMD_ERR_ARG, "kamd_component_create: time offsets must include values <= 0 and >= 0");
+    kamd_nnet_destroy(net); delete c; return NULL;
+  }
+  return reinterpret_cast<kamd_component *>(c);
+}
+void kamd_component_destroy(kamd_component *h) {
+  Component *c = reinterpret_cast<Component *>(h);
+  if (!c) return;
+  kamd_nnet_destroy(c->net);
+  if (c->d_in) (void)hipFree(c->d_in);
+  if (c->d_out) (void)hipFree(c->d_out);
+  delete c;
+}
+int kamd_component_output_rows(const kamd_component *h, int in_rows) {
+  const Component *c = reinterpret_cast<const Component *>(h);
+  return std::max(0, in_rows - (c->off_max - c->off_min));
+}
+int kamd_component_propagate(kamd_component *h, const float *d_in, int in_rows, int ld_in, float *d_out, int ld_out, void *stream) {
+  Component *c = reinterpret_cast<Component *>(h);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int n_out = kamd_component_output_rows(h, in_rows);
+  if (n_out <= 0) return 0;
+  if (ld_in < c->in_dim || ld_out < c->out_dim) return kamd::SetError(KAMD_ERR_ARG, "kamd_component_propagate: leading dimension smaller than the matrix");
+  // staging: the GEMM reads rows of 16-float multiples whose pad columns are zero
+  const size_t need_in = static_cast<size_t>(in_rows) * c->ld, need_out = static_cast<size_t>(in_rows) * c->out_dim;
+  if (need_in > c->in_cap) { if (c->d_in) (void)hipFree(c->d_in); c->d_in = NULL; KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_in), need_in * 4)); c->in_cap = need_in; }
+  if (need_out > c->out_cap) { if (c->d_out) (void)hipFree(c->d_out); c->d_out = NULL; KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&c->d_out), need_out * 4)); c->out_cap = need_out; }
+  KAMD_HIP(hipMemsetAsync(c->d_in, 0, need_in * 4, st));
+  KAMD_HIP(hipMemcpy2DAsync(c->d_in, static_cast<size_t>(c->ld) * 4, d_in, static_cast<size_t>(ld_in) * 4, static_cast<size_t>(c->in_dim) * 4, in_rows,
+                            hipMemcpyDeviceToDevice, st));
+  int64_t in_off[2] = {0, in_rows}, out_off[1] = {0};
+  const int rc = kamd_nnet_forward_batch_device(c->net, c->d_in, in_off, c->ld, NULL, 1, c->d_out, out_off, c->out_dim, st);
+  if (rc != KAMD_OK) return rc;
+  // forward row t uses in[clamp(t + off_i)]: rows t in [-off_min, in_rows - off_max) are clamp-free = Propagate's rows
+  KAMD_HIP(hipMemcpy2DAsync(d_out, static_cast<size_t>(ld_out) * 4, c->d_out + static_cast<size_t>(-c->off_min) * c->out_dim,
+                            static_cast<size_t>(c->out_dim) * 4, static_cast<size_t>(c->out_dim) * 4, n_out, hipMemcpyDeviceToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  return n_out;
+}
+
 int kamd_nnet_forward(kamd_nnet *h, const float *feats, int T, const float *ivector, float *out,
                       int out_rows_cap) {
   Nnet *nn = reinterpret_cast<Nnet *>(h);

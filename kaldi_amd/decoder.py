@@ -164,6 +164,33 @@ def lattice_diff(a, b):
     return "\n".join(out)
 
 
+class Component:
+    """nnet3::Component::Propagate (nnet3/nnet-component-itf.h:130-132) for one fused layer (a `kaldi_amd.nnet.Layer`):
+    the compatibility entry for a host that keeps nnet3's own computation.  TdnnComponent::Propagate's shape: `x` holds
+    consecutive time steps, the result has x.rows - (max offset - min offset) rows."""
+
+    def __init__(self, layer):
+        from .nnet import Model
+        self._m = Model([layer], layer.in_dim, 0, 1, layer.out_dim)
+        self._h = lib().kamd_component_create(self._m.descs())
+        if not self._h:
+            raise KamdError(lib().kamd_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().kamd_component_destroy(self._h)
+            self._h = None
+
+    def Propagate(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        n_out = lib().kamd_component_output_rows(self._h, x.shape[0])
+        d_in, d_out = DeviceMatrix(x), DeviceMatrix(np.zeros((max(n_out, 1), self._m.layers[0].out_dim), np.float32))
+        got = lib().kamd_component_propagate(self._h, d_in.ptr(0), x.shape[0], x.shape[1], d_out.ptr(0), d_out.cols, None)
+        if got < 0:
+            raise KamdError(lib().kamd_last_error().decode())
+        return d_out.download()[:got]
+
+
 class DeviceMatrix:
     """A host float32 matrix uploaded to HBM (DecodableMatrixMapped's 'likes' matrix)."""
 

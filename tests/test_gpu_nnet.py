@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from kaldi_amd import decoder, nnet
+from kaldi_amd._lib import KamdError
 from oracle import orc
 
 pytestmark = pytest.mark.gpu
@@ -221,3 +222,37 @@ def test_xconfig_models(name, tmp_path):
         if T == 40:
             ref = orc.nnet_forward(model, feats, iv)
             assert np.abs(got - ref).max() < 1e-4 * np.abs(ref).max()
+
+
+def test_component_propagate_shaped_entry():
+    """kamd_component_propagate = nnet3::Component::Propagate for one fused layer (TdnnComponent::Propagate's shape,
+    nnet-tdnn-component.cc:181-212: consecutive time steps in, in_rows - span rows out), against the formula in float64:
+    a TDNN layer with three offsets + bias + ReLU + BatchNorm map, a LinearComponent (no bias), an affine with one offset."""
+    from kaldi_amd.nnet import Layer
+    rng = np.random.default_rng(3)
+    for in_dim, out_dim, offs, bias, relu, bn in ((40, 96, [-1, 0, 2], True, True, True), (96, 24, [-3, 0], False, False, False),
+                                                  (24, 150, [0], True, False, False)):
+        W = (rng.standard_normal((out_dim, len(offs) * in_dim)) / np.sqrt(len(offs) * in_dim)).astype(np.float32)
+        b = rng.standard_normal(out_dim).astype(np.float32) * 0.1 if bias else None
+        sc = rng.uniform(0.5, 1.5, out_dim).astype(np.float32) if bn else None
+        of = rng.standard_normal(out_dim).astype(np.float32) * 0.1 if bn else None
+        comp = decoder.Component(Layer("c", in_dim, out_dim, offs, -1, W, b, relu, sc, of))
+        for T in (1, 7, 133):
+            x = rng.standard_normal((T, in_dim)).astype(np.float32)
+            got = comp.Propagate(x)
+            span = max(offs) - min(offs)
+            assert got.shape == (max(0, T - span), out_dim)
+            if T <= span:
+                continue
+            rows = np.arange(T - span)
+            want = sum(x[rows + o - min(offs)].astype(np.float64) @ W[:, k * in_dim:(k + 1) * in_dim].T.astype(np.float64)
+                       for k, o in enumerate(offs))
+            if bias:
+                want = want + b
+            if relu:
+                want = np.maximum(want, 0.0)
+            if bn:
+                want = want * sc + of
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()))
+    with pytest.raises(KamdError, match="offsets must include"):
+        decoder.Component(Layer("c", 8, 8, [1, 2], -1, np.zeros((8, 16), np.float32)))
