@@ -620,7 +620,7 @@ typedef struct kamd_ivector_desc {
   const float *lda;                 /* [lda_rows x lda_cols] row-major */
   const double *global_cmvn_stats;  /* [2 x (feat_dim+1)]: sums, counts; row 1 = sums of squares */
   int32_t cmn_window, speaker_frames, global_frames;   /* OnlineCmvnOptions (feat/online-feature.h:200-230) */
-  int32_t normalize_mean, normalize_variance;          /* variance normalisation is not supported */
+  int32_t normalize_mean, normalize_variance;          /* OnlineCmvnOptions (feat/online-feature.h:170-215); variance needs the mean */
   int32_t num_gauss;                /* diagonal UBM over the lda_rows-dimensional features (final.dubm) */
   const float *ubm_gconsts;         /* [num_gauss] */
   const float *ubm_means_invvars;   /* [num_gauss x lda_rows] */

@@ -34,7 +34,8 @@ constexpr int IV_MAX_DIM = 128;  // ivector_dim (two rows per lane of one wavefr
 struct IvDev {
   int feat_dim, L, R, sd, D, affine;
   const float *ldaT;             // [sd (+1)][D]
-  const double *gsum;            // [feat_dim] global sums
+  const double *gsum;            // [feat_dim] global sums, then [feat_dim] global sums of squares
+  int normalize_variance, sw;    // OnlineCmvn --norm-vars; width of a row of S: feat_dim, or 2 * feat_dim (sums | sums of squares)
   double gcount;
   int cmn_window, speaker_frames, global_frames, normalize_mean;
   int G;
@@ -90,19 +91,21 @@ __global__ __launch_bounds__(256) void PrefixKernel(IvDev d, IvBatch b) {
   while (dpw < d.feat_dim) dpw <<= 1;          // dims padded to a power of two <= 256
   const int chunks = 256 / dpw, k = tid % dpw, c = tid / dpw;
   const int len = (T + chunks - 1) / chunks, t0 = c * len, t1 = min(T, t0 + len);
-  double s = 0;
+  __shared__ double csum2[256];
+  double s = 0, s2c = 0;
   if (k < d.feat_dim)
-    for (int t = t0; t < t1; t++) s += static_cast<double>(b.feats[(r0 + t) * b.ld + k]);
-  csum[tid] = s;
+    for (int t = t0; t < t1; t++) { const double v = static_cast<double>(b.feats[(r0 + t) * b.ld + k]); s += v; s2c += v * v; }
+  csum[tid] = s; csum2[tid] = s2c;
   __syncthreads();
-  double run = 0;
-  for (int c2 = 0; c2 < c; c2++) run += csum[c2 * dpw + k];
+  double run = 0, run2 = 0;
+  for (int c2 = 0; c2 < c; c2++) { run += csum[c2 * dpw + k]; run2 += csum2[c2 * dpw + k]; }
   double sq = 0;
   if (k < d.feat_dim)
     for (int t = t0; t < t1; t++) {
       const double v = static_cast<double>(b.feats[(r0 + t) * b.ld + k]);
       run += v; sq += v * v;
-      b.S[(ut.ws_row + t) * d.feat_dim + k] = run;
+      b.S[(ut.ws_row + t) * d.sw + k] = run;
+      if (d.normalize_variance) { run2 += v * v; b.S[(ut.ws_row + t) * d.sw + d.feat_dim + k] = run2; }
     }
   if (b.state_out && ut.mode == 0 && ut.state_idx >= 0) {
     // OnlineCmvn::GetState(T - 1) (feat/online-feature.cc:455-475): incoming speaker stats + all T frames
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void PrefixKernel(IvDev d, IvBatch b) {
     if (c == 0 && k < d.feat_dim) {
       double s2 = 0, s1 = 0;
       for (int c2 = 0; c2 < chunks; c2++) s2 += csum[c2 * dpw + k];
-      s1 = b.S[(ut.ws_row + T - 1) * d.feat_dim + k];
+      s1 = b.S[(ut.ws_row + T - 1) * d.sw + k];
       const int sd1 = d.feat_dim + 1;
       const double *in = b.state_in ? b.state_in + static_cast<size_t>(ut.state_idx) * b.state_size : NULL;
       double *out = b.state_out + static_cast<size_t>(ut.state_idx) * b.state_size;
@@ -143,24 +146,45 @@ __global__ __launch_bounds__(256) void FrontKernel(IvDev d, IvBatch b) {
     float nv = v;
     if (d.normalize_mean) {
       // OnlineCmvn: window [t2 - W + 1, t2], topped up with the global stats (feat/online-feature.cc:325-407)
-      const double *S = b.S + ut.ws_row * dim;
-      double win = S[static_cast<size_t>(t2) * dim + k];
+      const double *S = b.S + ut.ws_row * d.sw;
+      const bool nvar = d.normalize_variance != 0;
+      double win = S[static_cast<size_t>(t2) * d.sw + k], win2 = nvar ? S[static_cast<size_t>(t2) * d.sw + dim + k] : 0.0;
       double cnt = t2 + 1;
-      if (t2 - d.cmn_window >= 0) { win -= S[static_cast<size_t>(t2 - d.cmn_window) * dim + k]; cnt = d.cmn_window; }
+      if (t2 - d.cmn_window >= 0) {
+        win -= S[static_cast<size_t>(t2 - d.cmn_window) * d.sw + k];
+        if (nvar) win2 -= S[static_cast<size_t>(t2 - d.cmn_window) * d.sw + dim + k];
+        cnt = d.cmn_window;
+      }
       if (cnt < d.cmn_window && b.state_in != NULL && ut.state_idx >= 0) {   // speaker stats of the carried-over state first
         const double *sp = b.state_in + static_cast<size_t>(ut.state_idx) * b.state_size;
         const double speaker_count = sp[dim];
         double from_speaker = d.cmn_window - cnt;
         if (from_speaker > d.speaker_frames) from_speaker = d.speaker_frames;
         if (from_speaker > speaker_count) from_speaker = speaker_count;
-        if (from_speaker > 0.0) { win += from_speaker / speaker_count * sp[k]; cnt += from_speaker / speaker_count * speaker_count; }
+        if (from_speaker > 0.0) {
+          win += from_speaker / speaker_count * sp[k];
+          if (nvar) win2 += from_speaker / speaker_count * sp[dim + 1 + k];
+          cnt += from_speaker / speaker_count * speaker_count;
+        }
       }
       if (cnt < d.cmn_window) {
         double from_global = d.cmn_window - cnt;
         if (from_global > d.global_frames) from_global = d.global_frames;
-        if (from_global > 0.0) { win += from_global / d.gcount * d.gsum[k]; cnt += from_global / d.gcount * d.gcount; }
+        if (from_global > 0.0) {
+          win += from_global / d.gcount * d.gsum[k];
+          if (nvar) win2 += from_global / d.gcount * d.gsum[dim + k];
+          cnt += from_global / d.gcount * d.gcount;
+        }
       }
-      nv = v + static_cast<float>(-1.0 / cnt * win);
+      if (nvar) {
+        // ApplyCmvn with var_norm (transform/cmvn.cc:92-114): a float norm matrix, MulColsVec then AddVecToRows
+        const double mean = win / cnt;
+        double var = (win2 / cnt) - mean * mean;
+        if (var < 1.0e-20) var = 1.0e-20;
+        const double scale = 1.0 / sqrt(var), offset = -(mean * scale);
+        nv = v * static_cast<float>(scale);
+        nv = nv + static_cast<float>(offset);
+      } else nv = v + static_cast<float>(-1.0 / cnt * win);
     }
     nrm[i] = nv;
   }
@@ -615,7 +639,7 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
   if (dim <= 0 || dim > 256 || d.splice_left < 0 || d.splice_right < 0) return bad("bad feature dim / splicing");
   if (d.lda_cols != sd && d.lda_cols != sd + 1) return bad("LDA columns do not match the spliced features");
   if (D <= 0 || G <= 0 || G > 4096 || I <= 0 || I > kamd::IV_MAX_DIM) return bad("dimensions out of range (ivector_dim <= 128, num_gauss <= 4096)");
-  if (d.normalize_variance) return bad("variance normalisation (--norm-vars=true) is not supported");
+  if (d.normalize_variance && !d.normalize_mean) return bad("You cannot normalize the variance but not the mean.");
   if (d.num_gselect <= 0 || d.num_gselect > kamd::IV_MAX_NG) return bad("num_gselect must be 1 .. 8");
   if (d.ivector_period <= 0 || d.min_post < 0 || d.min_post >= 0.5f || d.posterior_scale <= 0 || d.posterior_scale > 1.0f) return bad("bad options");
   if (d.cmn_window <= 0 || d.global_frames > d.cmn_window || d.global_cmvn_stats[dim] <= 0.0) return bad("bad CMVN options / global stats");
@@ -652,6 +676,7 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
     }
   std::vector<float> gc(d.ubm_gconsts, d.ubm_gconsts + G);
   std::vector<double> gsum(d.global_cmvn_stats, d.global_cmvn_stats + dim);
+  gsum.insert(gsum.end(), d.global_cmvn_stats + dim + 1, d.global_cmvn_stats + 2 * dim + 1);     // row 1: sums of squares
   e->d_ldaT = kamd::Upload(ldaT); e->d_gconsts = kamd::Upload(gc); e->d_mivT = kamd::Upload(mivT); e->d_ivT = kamd::Upload(ivT);
   e->d_gsum = kamd::Upload(gsum); e->d_U = kamd::Upload(U); e->d_SM = kamd::Upload(SM);
   if (!e->d_ldaT || !e->d_gconsts || !e->d_mivT || !e->d_ivT || !e->d_gsum || !e->d_U || !e->d_SM) {
@@ -663,6 +688,7 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
   v.feat_dim = dim; v.L = d.splice_left; v.R = d.splice_right; v.sd = sd; v.D = D; v.affine = d.lda_cols == sd + 1;
   v.ldaT = e->d_ldaT; v.gsum = e->d_gsum; v.gcount = d.global_cmvn_stats[dim];
   v.cmn_window = d.cmn_window; v.speaker_frames = d.speaker_frames; v.global_frames = d.global_frames; v.normalize_mean = d.normalize_mean;
+  v.normalize_variance = d.normalize_variance ? 1 : 0; v.sw = dim * (v.normalize_variance ? 2 : 1);
   v.G = G; v.gconsts = e->d_gconsts; v.mivT = e->d_mivT; v.ivT = e->d_ivT;
   v.I = I; v.Q = Q; v.U = e->d_U; v.SM = e->d_SM;
   v.prior_offset = d.prior_offset; v.max_count = d.max_count;
@@ -740,7 +766,7 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
     KAMD_HIP(hipStreamSynchronize(st));
   }
   kamd::IvWorkspace *w = e->ws;
-  if (kamd::GrowDevKeep(&w->d_S, &w->S_cap, static_cast<size_t>(ws_rows) * v.feat_dim, st) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDevKeep(&w->d_S, &w->S_cap, static_cast<size_t>(ws_rows) * v.sw, st) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDevKeep(&w->d_nl, &w->nl_cap, static_cast<size_t>(ws_rows) * v.D, st) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDevKeep(&w->d_rl, &w->rl_cap, static_cast<size_t>(ws_rows) * v.D, st) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDevKeep(&w->d_pg, &w->pg_cap, static_cast<size_t>(ws_rows) * v.ng, st) != KAMD_OK) return KAMD_ERR_HIP;

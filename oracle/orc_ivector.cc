@@ -115,18 +115,28 @@ struct Extractor {
 void OnlineCmvn(const Desc &d, const float *feats, int T, std::vector<float> *out, const double *speaker_stats = NULL) {
   const int dim = d.feat_dim;
   out->assign(static_cast<size_t>(T) * dim, 0.f);
-  std::vector<double> sum(dim, 0.0);
+  std::vector<double> sum(dim, 0.0), sum2(dim, 0.0);
   double count = 0;
   const double *gs = d.global_cmvn_stats;
+  const bool nv = d.normalize_variance != 0;         // the second row of the statistics (ComputeStatsForFrame :339-350)
+  const int sdim = dim + 1;
   for (int t = 0; t < T; t++) {
-    for (int k = 0; k < dim; k++) sum[k] += static_cast<double>(feats[static_cast<size_t>(t) * dim + k]);
+    for (int k = 0; k < dim; k++) {
+      const double v = static_cast<double>(feats[static_cast<size_t>(t) * dim + k]);
+      sum[k] += v;
+      if (nv) sum2[k] += v * v;
+    }
     count += 1.0;
     const int prev = t - d.cmn_window;
     if (prev >= 0) {
-      for (int k = 0; k < dim; k++) sum[k] -= static_cast<double>(feats[static_cast<size_t>(prev) * dim + k]);
+      for (int k = 0; k < dim; k++) {
+        const double v = static_cast<double>(feats[static_cast<size_t>(prev) * dim + k]);
+        sum[k] -= v;
+        if (nv) sum2[k] += -1.0 * (v * v);
+      }
       count -= 1.0;
     }
-    std::vector<double> st(sum);
+    std::vector<double> st(sum), st2(sum2);
     double cnt = count;
     if (cnt < d.cmn_window && speaker_stats != NULL) {      // SmoothOnlineCmvnStats: speaker stats first
       double from_speaker = d.cmn_window - cnt;
@@ -135,6 +145,7 @@ void OnlineCmvn(const Desc &d, const float *feats, int T, std::vector<float> *ou
       if (from_speaker > speaker_count) from_speaker = speaker_count;
       if (from_speaker > 0.0) {
         for (int k = 0; k < dim; k++) st[k] += from_speaker / speaker_count * speaker_stats[k];
+        if (nv) for (int k = 0; k < dim; k++) st2[k] += from_speaker / speaker_count * speaker_stats[sdim + k];
         cnt += from_speaker / speaker_count * speaker_count;
       }
     }
@@ -144,12 +155,21 @@ void OnlineCmvn(const Desc &d, const float *feats, int T, std::vector<float> *ou
       if (from_global > d.global_frames) from_global = d.global_frames;
       if (from_global > 0.0) {
         for (int k = 0; k < dim; k++) st[k] += from_global / gcount * gs[k];
+        if (nv) for (int k = 0; k < dim; k++) st2[k] += from_global / gcount * gs[sdim + k];
         cnt += from_global / gcount * gcount;
       }
     }
     for (int k = 0; k < dim; k++) {
       float v = feats[static_cast<size_t>(t) * dim + k];
-      if (d.normalize_mean) {
+      if (d.normalize_mean && nv) {
+        // ApplyCmvn with var_norm (transform/cmvn.cc:92-114): norm is a float matrix; MulColsVec, then AddVecToRows
+        const double mean = st[k] / cnt;
+        double var = (st2[k] / cnt) - mean * mean;
+        if (var < 1.0e-20) var = 1.0e-20;
+        const double scale = 1.0 / sqrt(var), offset = -(mean * scale);
+        v = v * static_cast<float>(scale);
+        v = v + static_cast<float>(offset);
+      } else if (d.normalize_mean) {
         const float offset = static_cast<float>(-1.0 / cnt * st[k]);   // Vector<float>::AddVec(double alpha, Vector<double>)
         v = v + offset;
       }
@@ -289,7 +309,7 @@ int orc_ivector_extract_online(const kamd_ivector_desc *desc, const float *feats
   if (T <= 0) return 0;
   const int P = d.ivector_period, n_iv = (T + P - 1) / P, I = d.ivector_dim, D = d.lda_rows;
   if (n_iv > out_rows_cap) return -1;
-  if (d.normalize_variance) return -2;
+  if (d.normalize_variance && !d.normalize_mean) return -2;     // OnlineCmvn asserts this combination away (:437)
   Extractor e(d);
   std::vector<float> cm, nl, rl;
   const int sdim = d.feat_dim + 1, Qn = I * (I + 1) / 2;

@@ -25,7 +25,8 @@ def check(info, ie, x):
 
 
 @pytest.mark.parametrize("opts", [dict(), dict(ivector_period=4, max_count=1.5), dict(cmn_window=25, speaker_frames=25, global_frames=10),
-                                  dict(num_gselect=2, min_post=0.2), dict(normalize_mean=False, num_cg_iters=3)])
+                                  dict(num_gselect=2, min_post=0.2), dict(normalize_mean=False, num_cg_iters=3),
+                                  dict(normalize_variance=True, cmn_window=25, speaker_frames=25, global_frames=10)])
 def test_small_extractor_matches_oracle(opts):
     info = ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=70, ivector_dim=10, seed=3, splice_left=2, splice_right=1, **opts)
     ie = ivector.IvectorExtractor(info)
@@ -48,7 +49,8 @@ def test_extractor_shapes_at_the_limits(shape):
     with pytest.raises(Exception):
         ivector.IvectorExtractor(ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=8, ivector_dim=129))
     with pytest.raises(Exception):
-        ivector.IvectorExtractor(ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=8, ivector_dim=10, normalize_variance=True))
+        ivector.IvectorExtractor(ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=8, ivector_dim=10, normalize_variance=True,
+                                                        normalize_mean=False))      # "You cannot normalize the variance but not the mean."
 
 
 def test_recipe_size_extractor_on_mfcc_features():
@@ -243,12 +245,13 @@ def test_latgen_tool_with_device_ivectors_and_with_online_ivector_archives(tmp_p
 
 
 @pytest.mark.parametrize("max_count", [0.0, 3.0])
-def test_speaker_adaptation_state_carried_across_utterances(max_count):
+def test_speaker_adaptation_state_carried_across_utterances(max_count, norm_vars=False):
     """ivector-extract-online2 with a spk2utt that groups utterances: the second and third utterance
     start from the CMVN speaker statistics and the i-vector statistics the earlier ones left
     (LimitFrames applied in between), on the device as in the oracle."""
     info = ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=40, ivector_dim=10, seed=4, splice_left=2, splice_right=1,
-                                  cmn_window=60, speaker_frames=40, global_frames=10, max_count=max_count, ivector_period=5)
+                                  cmn_window=60, speaker_frames=40, global_frames=10, max_count=max_count, ivector_period=5,
+                                  normalize_variance=norm_vars)
     ie = ivector.IvectorExtractor(info)
     rng = np.random.default_rng(7)
     utts = [(rng.standard_normal((T, 8)) * 1.2 + 0.5).astype(np.float32) for T in (90, 31, 140)]
@@ -263,6 +266,11 @@ def test_speaker_adaptation_state_carried_across_utterances(max_count):
             assert np.abs(fresh[0] - got[0]).max() > 1e-3
     # LimitFrames: the speaker's CMVN count is scaled back to max_remembered_frames (float arithmetic, as there)
     assert abs(st_d[8] - 100.0) < 1e-3
+
+
+def test_speaker_adaptation_state_with_variance_normalisation():
+    """OnlineCmvn --norm-vars=true: the speaker statistics' second row (sums of squares) smooths the window as well."""
+    test_speaker_adaptation_state_carried_across_utterances(0.0, norm_vars=True)
 
 
 def test_ivector_extract_online2_tool(tmp_path):

@@ -28,6 +28,28 @@ def test_online_cmvn_window_and_smoothing():
         np.testing.assert_allclose(got[t], x[t] - mean, rtol=0, atol=2e-6)
 
 
+def test_online_cmvn_variance_normalisation():
+    """--norm-vars=true (feat/online-feature.cc:339-350 accumulates the squares in the sliding window, :437 ->
+    transform/cmvn.cc:92-114): x * scale + offset with scale = 1 / sqrt(E[x^2] - mean^2) and offset = -mean * scale over the
+    window, both rows of the statistics topped up with the global ones."""
+    info = small_info(cmn_window=20, speaker_frames=20, global_frames=5, normalize_variance=True)
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((70, 8)) * 3 + 1).astype(np.float32)
+    got = orc.online_cmvn(info, x)
+    g = info.global_cmvn_stats
+    gmean, gsq = g[0, :8] / g[0, 8], g[1, :8] / g[0, 8]
+    for t in (0, 1, 4, 14, 15, 19, 20, 33, 69):
+        lo = max(0, t - 20 + 1)
+        n = t - lo + 1
+        w = x[lo:t + 1].astype(np.float64)
+        extra = min(20 - n, 5) if n < 20 else 0
+        mean = (w.sum(0) + extra * gmean) / (n + extra)
+        var = ((w * w).sum(0) + extra * gsq) / (n + extra) - mean * mean
+        want = x[t] / np.sqrt(var) - mean / np.sqrt(var)
+        np.testing.assert_allclose(got[t], want, rtol=0, atol=5e-6 * max(1.0, np.abs(want).max()))
+    assert np.abs(got - orc.online_cmvn(small_info(cmn_window=20, speaker_frames=20, global_frames=5), x)).max() > 0.1
+
+
 def test_posterior_entry_pruning_and_normalisation():
     ll = np.log(np.array([0.5, 0.3, 0.1, 0.06, 0.03, 0.006, 0.004], np.float32))
     tot_ll, g, p = orc.posterior_entry(ll, 5, 0.025)
