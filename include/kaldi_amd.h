@@ -185,6 +185,14 @@ typedef struct {
   const float *bn_offset;  /* [out_dim] or NULL */
   const float *post_offset;/* [out_dim] or NULL (= -log_priors) */
   float post_scale;        /* acoustic scale on the last layer, else 1 */
+  /* Append over DIFFERENT producers -- descriptors like Append(Offset(tdnn1, -3), tdnn2), which the reference
+   * evaluates with kCopyRows / kAddRows over arbitrary sources (nnet3/nnet-compute.cc:309-383).  multi_input != 0:
+   * slice i of the layer's input reads slice_layer[i] (-1 = the network input) at time offsets[i] and is slice_dim[i]
+   * columns wide; in_dim is the SUM of the slice widths, W's column blocks follow the slices, input_layer is ignored
+   * and ivector_dim must be 0.  Zero-initialised descriptors keep the single-producer meaning. */
+  int32_t multi_input;
+  int32_t slice_layer[KAMD_MAX_OFFSETS];
+  int32_t slice_dim[KAMD_MAX_OFFSETS];
 } kamd_layer_desc;
 
 typedef struct kamd_nnet kamd_nnet;

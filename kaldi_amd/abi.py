@@ -86,7 +86,9 @@ class LayerDesc(C.Structure):
                 ("bypass_scale", C.c_float), ("relu", C.c_int32), ("log_softmax", C.c_int32),
                 ("W", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float)),
                 ("bn_scale", C.POINTER(C.c_float)), ("bn_offset", C.POINTER(C.c_float)),
-                ("post_offset", C.POINTER(C.c_float)), ("post_scale", C.c_float)]
+                ("post_offset", C.POINTER(C.c_float)), ("post_scale", C.c_float),
+                ("multi_input", C.c_int32), ("slice_layer", C.c_int32 * KAMD_MAX_OFFSETS),
+                ("slice_dim", C.c_int32 * KAMD_MAX_OFFSETS)]
 
 
 class Arc(C.Structure):

@@ -169,6 +169,7 @@ struct Layer {
   std::string name;
   int in_dim = 0, out_dim = 0, input_layer = -1, bypass_layer = -2, ivector_dim = 0;
   std::vector<int> offsets;
+  std::vector<int> slice_layers, slice_dims;      // Append over different producers (kamd_layer_desc::multi_input); empty otherwise
   std::vector<float> W, bias, bn_scale, bn_offset, post_offset;
   bool has_bias = false, relu = false, has_bn = false, log_softmax = false, has_post = false;
   float bypass_scale = 0.f, post_scale = 1.f;
@@ -307,7 +308,8 @@ struct Compiler {
       std::vector<double> col_scales;
       double whole_scale = 1.0;
       if (desc.kind == Desc::kScale) { whole_scale = desc.scale; const Desc inner = desc.args[0]; desc = inner; }
-      std::vector<int> offsets;
+      std::vector<int> offsets, producers, slice_dims;
+      bool multi = false;
       int src = -1;
       if (typ == "TdnnComponent") {
         const Value &tv = Field(f, "<TimeOffsets>", cname);
@@ -330,20 +332,31 @@ struct Compiler {
           if (inner.kind == Desc::kScale) { ps *= inner.scale; const Desc in = inner.args[0]; inner = in; }
           col_scales.push_back(ps);
           const int idx = Resolve(inner);
-          if (have_src && idx != src) Fail("Append over different producers is not supported (" + name + ")");
+          if (have_src && idx != src) multi = true;
           src = idx; have_src = true;
+          producers.push_back(idx);
           offsets.push_back(off);
+        }
+        if (multi) {                    // Append over different producers: a multi-input layer
+          if (ivector_dim) Fail("Append over different producers together with an ivector is not supported (" + name + ")");
+          for (int q : producers) slice_dims.push_back(q == -1 ? inputs["input"] : layers[q].out_dim);
+          src = -1;
         }
       } else if (desc.kind == Desc::kOffset) {
         offsets.push_back(desc.offset); src = Resolve(desc.args[0]);
       } else {
         offsets.push_back(0); src = Resolve(desc);
       }
-      const int in_dim = src == -1 ? inputs["input"] : layers[src].out_dim;
+      int in_dim = src == -1 ? inputs["input"] : layers[src].out_dim;
       const int n_off = static_cast<int>(offsets.size());
-      if (Wv.cols != n_off * in_dim + ivector_dim) Fail(name + ": parameter shape does not match its input");
+      std::vector<int> widths(n_off, in_dim), cols(n_off + 1, 0);
+      if (multi) widths = slice_dims;
+      for (int o = 0; o < n_off; o++) cols[o + 1] = cols[o] + widths[o];
+      if (multi) in_dim = cols[n_off];
+      if (Wv.cols != cols[n_off] + ivector_dim) Fail(name + ": parameter shape does not match its input");
       Layer L;
       L.name = name; L.in_dim = in_dim; L.out_dim = Wv.rows; L.offsets = offsets; L.input_layer = src; L.ivector_dim = ivector_dim;
+      if (multi) { L.slice_layers = producers; L.slice_dims = slice_dims; }
       L.W = Wv.data;
       bool scaled = whole_scale != 1.0;
       for (double c : col_scales) scaled = scaled || c != 1.0;
@@ -351,11 +364,11 @@ struct Compiler {
         for (int o = 0; o < n_off; o++) {
           const float cs = static_cast<float>(col_scales.empty() ? whole_scale : col_scales[o]) * (col_scales.empty() ? 1.0f : static_cast<float>(whole_scale));
           for (int n = 0; n < L.out_dim; n++)
-            for (int k = 0; k < in_dim; k++) L.W[static_cast<size_t>(n) * Wv.cols + o * in_dim + k] *= cs;
+            for (int k = 0; k < widths[o]; k++) L.W[static_cast<size_t>(n) * Wv.cols + cols[o] + k] *= cs;
         }
         if (whole_scale != 1.0 && ivector_dim > 0)          // (round-2 advisor: the i-vector columns of a whole-input Scale)
           for (int n = 0; n < L.out_dim; n++)
-            for (int k = 0; k < ivector_dim; k++) L.W[static_cast<size_t>(n) * Wv.cols + n_off * in_dim + k] *= static_cast<float>(whole_scale);
+            for (int k = 0; k < ivector_dim; k++) L.W[static_cast<size_t>(n) * Wv.cols + cols[n_off] + k] *= static_cast<float>(whole_scale);
       }
       if (has_bias) { L.bias = bias; L.has_bias = true; }
       layers.push_back(L);
@@ -522,6 +535,10 @@ void ReadModel(const char *path, float acoustic_scale, int frame_subsampling_fac
     d.W = L.W.data(); d.bias = L.has_bias ? L.bias.data() : NULL;
     d.bn_scale = L.has_bn ? L.bn_scale.data() : NULL; d.bn_offset = L.has_bn ? L.bn_offset.data() : NULL;
     d.post_offset = L.has_post ? L.post_offset.data() : NULL;
+    if (!L.slice_layers.empty()) {
+      d.multi_input = 1;
+      for (size_t o = 0; o < L.slice_layers.size(); o++) { d.slice_layer[o] = L.slice_layers[o]; d.slice_dim[o] = L.slice_dims[o]; }
+    }
   }
 }
 

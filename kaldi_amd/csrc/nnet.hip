@@ -1211,6 +1211,15 @@ __global__ void RowMapKernel(MapArgs a) {
   }
 }
 
+// one slice of a concat layer: dst[r][0 .. dim) = src[map[r]][0 .. dim)
+__global__ void CopySliceKernel(const float *src, int ld_src, const int *map, float *dst, int ld_dst, int dim, int M) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const float *s = src + static_cast<size_t>(map[r]) * ld_src;
+  float *d = dst + static_cast<size_t>(r) * ld_dst;
+  for (int k = threadIdx.x & 63; k < dim; k += 64) d[k] = s[k];
+}
+
 // ivbias[u][n] = sum_k W_iv[n][k] * ivec[u][k]   (ReplaceIndex(ivector, t, 0) operand)
 // (rows != NULL: item u reads row rows[u] of the i-vector table)
 __global__ void IvecBiasKernel(const float *Wiv, const float *ivec, int N, int D, float *out, const int *rows) {
@@ -1232,6 +1241,11 @@ struct LayerDev {
   // time grid (per layer constants): rows for utterance u are t = lo + k*step,
   // k < (hi_const + 3*(n_out_u-1) - lo)/step + 1
   int lo, hi_const, step;
+  // A CONCAT pseudo-layer (no GEMM): the materialised Append over different producers in front of a multi_input layer
+  // (what nnet3 does with kCopyRows, nnet-compute.cc:309-383): slice o = rows of layer sl_layer[o] (-1: the input) at
+  // time offset offs[o], sl_dim[o] columns, written at column sl_col[o] of this layer's rows
+  bool concat = false;
+  int sl_layer[KAMD_MAX_OFFSETS], sl_dim[KAMD_MAX_OFFSETS], sl_col[KAMD_MAX_OFFSETS];
 };
 
 struct Nnet {
@@ -1273,8 +1287,9 @@ static int PlanGrids(Nnet *nn) {
     if (!r.dense) {  // snap lo/hi onto the residue class
       // lo, hi already lie on the residue class by construction
     }
-    int pidx = l.input_layer < 0 ? n : l.input_layer;
     for (int o = 0; o < l.n_off; o++) {
+      const int prod = l.concat ? l.sl_layer[o] : l.input_layer;
+      const int pidx = prod < 0 ? n : prod;
       int off = l.offs[o];
       add(pidx, r.lo + off, r.hi + off, r.dense ? -1 : Mod(r.residue + off, sub), r.dense);
     }
@@ -1321,31 +1336,58 @@ kamd_nnet *kamd_nnet_create(const kamd_layer_desc *layers, int n_layers, int inp
   if (!kamd::RequireDevice()) return NULL;
   Nnet *nn = new Nnet();
   nn->input_dim = input_dim; nn->subsampling = subsampling;
-  nn->L.resize(n_layers);
+  // The device's layer list: the caller's layers, with a CONCAT pseudo-layer in front of every multi_input one (the
+  // caller's indices are mapped through ext2int).
+  nn->L.reserve(2 * static_cast<size_t>(n_layers));
+  std::vector<int> ext2int(n_layers, -1);
+  auto remap = [&](int x) { return x < 0 ? x : ext2int[x]; };
   for (int i = 0; i < n_layers; i++) {
     const kamd_layer_desc &s = layers[i];
-    LayerDev &l = nn->L[i];
     if (s.n_offsets < 1 || s.n_offsets > KAMD_MAX_OFFSETS || s.input_layer >= i || s.bypass_layer >= i ||
-        (s.ivector_dim > 0 && s.input_layer != -1)) {
+        (s.ivector_dim > 0 && (s.input_layer != -1 || s.multi_input))) {
       kamd::SetError(KAMD_ERR_ARG, "layer %d: bad topology", i);
       delete nn; return NULL;
     }
-    int prod_dim = s.input_layer < 0 ? input_dim : layers[s.input_layer].out_dim;
-    if (prod_dim != s.in_dim) { kamd::SetError(KAMD_ERR_ARG, "layer %d: in_dim %d != producer dim %d", i, s.in_dim, prod_dim); delete nn; return NULL; }
+    int n_off_l = s.n_offsets, input_l = remap(s.input_layer);
+    if (s.multi_input) {
+      LayerDev cat;
+      cat.concat = true; cat.n_off = s.n_offsets; cat.in_dim = 0; cat.in_pad = 0; cat.input_layer = -3; cat.bypass_layer = -2; cat.ivector_dim = 0;
+      cat.relu = 0; cat.log_softmax = 0; cat.bypass_scale = 0.0f; cat.post_scale = 1.0f; cat.N_pad = 0;
+      int width = 0;
+      for (int o = 0; o < s.n_offsets; o++) {
+        const int pl = s.slice_layer[o];
+        if (pl >= i || pl < -1 || s.slice_dim[o] != (pl < 0 ? input_dim : layers[pl].out_dim)) {
+          kamd::SetError(KAMD_ERR_ARG, "layer %d: slice %d does not match its producer", i, o);
+          delete nn; return NULL;
+        }
+        cat.offs[o] = s.offsets[o]; cat.sl_layer[o] = remap(pl); cat.sl_dim[o] = s.slice_dim[o]; cat.sl_col[o] = width;
+        width += s.slice_dim[o];
+      }
+      if (width != s.in_dim) { kamd::SetError(KAMD_ERR_ARG, "layer %d: in_dim %d != the sum of its slices %d", i, s.in_dim, width); delete nn; return NULL; }
+      cat.out_dim = width; cat.out_pad = kamd::RoundUp(width, 16);
+      nn->L.push_back(cat);
+      n_off_l = 1; input_l = static_cast<int>(nn->L.size()) - 1;        // the affine part reads the concatenation at offset 0
+    } else {
+      int prod_dim = s.input_layer < 0 ? input_dim : layers[s.input_layer].out_dim;
+      if (prod_dim != s.in_dim) { kamd::SetError(KAMD_ERR_ARG, "layer %d: in_dim %d != producer dim %d", i, s.in_dim, prod_dim); delete nn; return NULL; }
+    }
     if (s.bypass_layer != -2) {
       int bd = s.bypass_layer < 0 ? input_dim : layers[s.bypass_layer].out_dim;
       if (bd != s.out_dim) { kamd::SetError(KAMD_ERR_ARG, "layer %d: bypass dim mismatch", i); delete nn; return NULL; }
     }
+    nn->L.push_back(LayerDev());
+    LayerDev &l = nn->L.back();
+    ext2int[i] = static_cast<int>(nn->L.size()) - 1;
     l.in_dim = s.in_dim; l.out_dim = s.out_dim; l.in_pad = kamd::RoundUp(s.in_dim, 16);
-    l.out_pad = kamd::RoundUp(s.out_dim, 16); l.n_off = s.n_offsets;
-    for (int o = 0; o < s.n_offsets; o++) l.offs[o] = s.offsets[o];
-    l.input_layer = s.input_layer; l.bypass_layer = s.bypass_layer; l.ivector_dim = s.ivector_dim;
+    l.out_pad = kamd::RoundUp(s.out_dim, 16); l.n_off = n_off_l;
+    for (int o = 0; o < n_off_l; o++) l.offs[o] = s.multi_input ? 0 : s.offsets[o];
+    l.input_layer = input_l; l.bypass_layer = s.bypass_layer == -2 ? -2 : remap(s.bypass_layer); l.ivector_dim = s.ivector_dim;
     l.relu = s.relu; l.log_softmax = s.log_softmax; l.bypass_scale = s.bypass_scale; l.post_scale = s.post_scale;
     l.N_pad = kamd::RoundUp(s.out_dim, 128);
-    const int Ksrc = s.n_offsets * s.in_dim + s.ivector_dim, Kp = s.n_offsets * l.in_pad;
+    const int Ksrc = n_off_l * s.in_dim + s.ivector_dim, Kp = n_off_l * l.in_pad;
     std::vector<float> Wp(static_cast<size_t>(l.N_pad) * Kp, 0.0f);
     for (int n = 0; n < s.out_dim; n++)
-      for (int o = 0; o < s.n_offsets; o++)
+      for (int o = 0; o < n_off_l; o++)
         memcpy(&Wp[static_cast<size_t>(n) * Kp + o * l.in_pad], s.W + static_cast<size_t>(n) * Ksrc + o * s.in_dim,
                sizeof(float) * s.in_dim);
     auto up = [&](const float *src, size_t cnt) -> float * {
@@ -1358,7 +1400,7 @@ kamd_nnet *kamd_nnet_create(const kamd_layer_desc *layers, int n_layers, int inp
     if (s.ivector_dim > 0) {
       std::vector<float> wiv(static_cast<size_t>(s.out_dim) * s.ivector_dim);
       for (int n = 0; n < s.out_dim; n++)
-        memcpy(&wiv[static_cast<size_t>(n) * s.ivector_dim], s.W + static_cast<size_t>(n) * Ksrc + s.n_offsets * s.in_dim,
+        memcpy(&wiv[static_cast<size_t>(n) * s.ivector_dim], s.W + static_cast<size_t>(n) * Ksrc + n_off_l * s.in_dim,
                sizeof(float) * s.ivector_dim);
       l.Wiv = up(wiv.data(), wiv.size()); ok = ok && l.Wiv;
     }
@@ -1368,6 +1410,7 @@ kamd_nnet *kamd_nnet_create(const kamd_layer_desc *layers, int n_layers, int inp
     if (!ok) { kamd::SetError(KAMD_ERR_HIP, "weight upload failed (layer %d)", i); delete nn; return NULL; }
   }
   if (kamd::PlanGrids(nn) != KAMD_OK) { delete nn; return NULL; }
+  n_layers = static_cast<int>(nn->L.size());          // from here on: the device's list
   int max_n = 64;
   for (int i = 0; i < n_layers; i++) max_n = std::max(max_n, nn->L[i].N_pad);
   nn->n_neutral = max_n;
@@ -1521,6 +1564,21 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     const int64_t *layer_row_off = d_row_off;
     if (l == nl - 1 && row_base != 0) layer_row_off = nn->d_meta + (nl + 1) * stride;     // (filled with the meta upload)
     ma.row_off = layer_row_off;
+    if (L.concat) {
+      // the materialised Append: per slice a row map into its own producer, then the gather-copy into this layer's rows
+      for (int o = 0; o < L.n_off; o++) {
+        kamd::MapArgs ms = ma;
+        fill_prod(L.sl_layer[o], &ms);
+        ms.n_off = 1; ms.offs[0] = L.offs[o]; ms.rowmap = rowmap + static_cast<size_t>(o) * Ml; ms.row2utt = NULL;
+        hipLaunchKernelGGL(kamd::RowMapKernel, dim3(kamd::CeilDiv(Ml, 256)), dim3(256), 0, st, ms);
+        const float *src = L.sl_layer[o] < 0 ? d_feats : nn->act[L.sl_layer[o]];
+        const int ld_src = L.sl_layer[o] < 0 ? ld_in : nn->L[L.sl_layer[o]].out_pad;
+        hipLaunchKernelGGL(kamd::CopySliceKernel, dim3(kamd::CeilDiv(Ml, 4)), dim3(256), 0, st, src, ld_src, rowmap + static_cast<size_t>(o) * Ml,
+                           C + L.sl_col[o], ldC, L.sl_dim[o], static_cast<int>(Ml));
+      }
+      KAMD_HIP(hipGetLastError());
+      continue;
+    }
     fill_prod(L.input_layer, &ma);
     ma.n_off = L.n_off;
     for (int o = 0; o < L.n_off; o++) ma.offs[o] = L.offs[o];

@@ -301,6 +301,7 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
             if bias is not None and bias.size == 0:
                 bias = None
             ivector_dim = 0
+            slice_layers = slice_dims = None                # Append over different producers
             col_scales = []                                 # one per appended slice, when a Scale(...) descriptor feeds it
             whole_scale = 1.0
             if desc[0] == "Scale":                          # input=Scale(s, x): y = W (s x) + b
@@ -309,7 +310,7 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
                 offsets = [int(x) for x in f["<TimeOffsets>"][0]]
                 src = resolve(desc)
             elif desc[0] == "Append":                       # lda: Append(Offset(input,-1), input, Offset(input,1), ReplaceIndex(ivector,t,0))
-                offsets, src = [], None
+                offsets, src, producers = [], None, []
                 for part in desc[1]:
                     if part[0] == "ReplaceIndex":
                         ivector_dim = inputs[part[1]]
@@ -322,25 +323,34 @@ def read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=3):
                         part_scale, inner = part_scale * inner[1], inner[2]
                     col_scales.append(part_scale)
                     idx = resolve(inner)
-                    if src is not None and idx != src:
-                        raise MdlError("Append over different producers is not supported (%s)" % name)
+                    producers.append(idx)
                     src = idx
                     offsets.append(off)
+                if len(set(producers)) > 1:                 # Append over different producers: a multi-input layer
+                    if ivector_dim:
+                        raise MdlError("Append over different producers together with an ivector is not supported (%s)" % name)
+                    slice_layers = producers
+                    slice_dims = [inputs["input"] if q == -1 else layers[q].out_dim for q in producers]
+                    src = -1
             elif desc[0] == "Offset":                       # input=Offset(x, t)
                 offsets, src = [desc[2]], resolve(desc[1])
             else:
                 offsets, src = [0], resolve(desc)
             in_dim = inputs["input"] if src == -1 else layers[src].out_dim
-            if W.shape[1] != len(offsets) * in_dim + ivector_dim:
+            widths = [in_dim] * len(offsets) if slice_layers is None else slice_dims
+            if slice_layers is not None:
+                in_dim = int(sum(slice_dims))
+            if W.shape[1] != int(sum(widths)) + ivector_dim:
                 raise MdlError("%s: parameter shape %s does not match its input" % (name, W.shape))
             if whole_scale != 1.0 or (col_scales and any(c != 1.0 for c in col_scales)):
                 W = np.array(W, np.float32)
                 cs = np.full(len(offsets), whole_scale, np.float32) if not col_scales else np.asarray(col_scales, np.float32) * np.float32(whole_scale)
-                W[:, :len(offsets) * in_dim] *= np.repeat(cs, in_dim)[None, :]
+                W[:, :int(sum(widths))] *= np.repeat(cs, widths)[None, :]
                 if whole_scale != 1.0 and ivector_dim:      # Scale(s, Append(.., ReplaceIndex(ivector, t, 0))) scales the i-vector too
-                    W[:, len(offsets) * in_dim:] *= np.float32(whole_scale)
+                    W[:, int(sum(widths)):] *= np.float32(whole_scale)
             layers.append(Layer(name, in_dim, W.shape[0], offsets, src, np.ascontiguousarray(W, np.float32),
-                                None if bias is None else bias.astype(np.float32), ivector_dim=ivector_dim))
+                                None if bias is None else bias.astype(np.float32), ivector_dim=ivector_dim,
+                                slice_layers=slice_layers, slice_dims=slice_dims))
             layer_of[name] = len(layers) - 1
             return layer_of[name]
         # components that act on the output of the layer they follow
@@ -428,11 +438,13 @@ def read_mdl_native(path, acoustic_scale=1.0, frame_subsampling_factor=3):
         layers = []
         for i in range(n_layers):
             d = descs[i]
-            cols = d.n_offsets * d.in_dim + d.ivector_dim
+            cols = (d.in_dim if d.multi_input else d.n_offsets * d.in_dim) + d.ivector_dim
             layers.append(Layer("layer%d" % i, d.in_dim, d.out_dim, [int(d.offsets[j]) for j in range(d.n_offsets)], d.input_layer,
                                 arr(d.W, d.out_dim, cols), arr(d.bias, d.out_dim), bool(d.relu), arr(d.bn_scale, d.out_dim),
                                 arr(d.bn_offset, d.out_dim), d.bypass_layer, float(d.bypass_scale), d.ivector_dim,
-                                arr(d.post_offset, d.out_dim), float(d.post_scale), bool(d.log_softmax)))
+                                arr(d.post_offset, d.out_dim), float(d.post_scale), bool(d.log_softmax),
+                                [int(d.slice_layer[j]) for j in range(d.n_offsets)] if d.multi_input else None,
+                                [int(d.slice_dim[j]) for j in range(d.n_offsets)] if d.multi_input else None))
     finally:
         L.kamd_model_destroy(h)
     m = Model(layers, input_dim, ivector_dim, sub, num_pdfs, name=str(path))

@@ -33,6 +33,17 @@ class Layer:
     post_offset: Optional[np.ndarray] = None
     post_scale: float = 1.0
     log_softmax: bool = False     # LogSoftmaxComponent on the output node (non-chain models)
+    # Append over DIFFERENT producers (kamd_layer_desc::multi_input): slice j reads layer slice_layers[j] (-1 = input)
+    # at offsets[j] and is slice_dims[j] wide; in_dim = sum(slice_dims), input_layer is ignored
+    slice_layers: Optional[List[int]] = None
+    slice_dims: Optional[List[int]] = None
+
+    def slices(self):
+        """[(producer, offset, first column of W, width)] of the layer's input."""
+        if self.slice_layers is None:
+            return [(self.input_layer, o, j * self.in_dim, self.in_dim) for j, o in enumerate(self.offsets)]
+        col = np.concatenate([[0], np.cumsum(self.slice_dims)]).astype(int)
+        return [(self.slice_layers[j], o, int(col[j]), int(self.slice_dims[j])) for j, o in enumerate(self.offsets)]
 
 
 @dataclass
@@ -63,17 +74,31 @@ class Model:
                 setattr(d, nm, abi.fptr(a))
             d.post_scale = l.post_scale
             d.log_softmax = int(l.log_softmax)
+            d.multi_input = 0
+            if l.slice_layers is not None:
+                d.multi_input = 1
+                for j in range(len(l.offsets)):
+                    d.slice_layer[j], d.slice_dim[j] = int(l.slice_layers[j]), int(l.slice_dims[j])
         self._keep.append(arr)
         return arr
 
     def context(self):
         """ComputeSimpleNnetContext (nnet3/nnet-utils.cc:146): (left, right)."""
+        memo = {}
+
         def ctx(i):
             if i == -1:
                 return 0, 0
+            if i not in memo:
+                memo[i] = ctx1(i)
+            return memo[i]
+
+        def ctx1(i):
             l = self.layers[i]
-            il, ir = ctx(l.input_layer)
-            left, right = il - min(0, min(l.offsets)), ir + max(0, max(l.offsets))
+            left = right = 0
+            for prod, off, _, _ in l.slices():
+                il, ir = ctx(prod)
+                left, right = max(left, il - min(0, off)), max(right, ir + max(0, off))
             if l.bypass_layer != -2:
                 bl, br = ctx(l.bypass_layer)
                 left, right = max(left, bl), max(right, br)
@@ -90,9 +115,9 @@ class Model:
         period = self.subsampling
         for i in range(n - 1, -1, -1):
             l = self.layers[i]
-            tgt = need[l.input_layer] if l.input_layer >= 0 else need[n]
-            for r in need[i]:
-                for o in l.offsets:
+            for prod, o, _, _ in l.slices():
+                tgt = need[prod] if prod >= 0 else need[n]
+                for r in need[i]:
                     tgt.add((r + o) % period)
             if l.bypass_layer != -2:
                 b = need[l.bypass_layer] if l.bypass_layer >= 0 else need[n]

@@ -21,6 +21,8 @@ import numpy as np
 def _chunk_plan(model, t_out):
     """Times every layer must be evaluated at for the output times t_out (sorted int arrays; index -1 = input)."""
     n = len(model.layers)
+    if any(l.slice_layers is not None for l in model.layers):
+        raise ValueError("the sgemm baseline evaluates single-producer layers only (use orc.nnet_forward)")
     req = {n - 1: np.asarray(t_out, np.int64)}
     for i in range(n - 1, -1, -1):
         l = model.layers[i]

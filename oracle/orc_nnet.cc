@@ -55,23 +55,27 @@ struct Eval {
     std::unordered_map<int, std::vector<float> >::iterator it = m.find(t);
     if (it != m.end()) return it->second.data();
     const kamd_layer_desc &l = L[layer];
-    int K = l.n_offsets * l.in_dim + l.ivector_dim;
+    // slices of the input: all from input_layer, in_dim wide -- or (multi_input: Append over different producers,
+    // nnet-compute.cc:309-383 kCopyRows over arbitrary sources) each from its own layer with its own width
+    std::vector<int> sdim(l.n_offsets), scol(l.n_offsets);
+    int K = l.ivector_dim;
+    for (int i = 0; i < l.n_offsets; i++) { sdim[i] = l.multi_input ? l.slice_dim[i] : l.in_dim; scol[i] = K - l.ivector_dim; K += sdim[i]; }
     std::vector<float> y(l.out_dim);
     std::vector<const float *> xs(l.n_offsets);
-    for (int i = 0; i < l.n_offsets; i++) xs[i] = Get(l.input_layer, t + l.offsets[i]);
+    for (int i = 0; i < l.n_offsets; i++) xs[i] = Get(l.multi_input ? l.slice_layer[i] : l.input_layer, t + l.offsets[i]);
     const float *z = NULL;
     if (l.bypass_layer != -2) z = Get(l.bypass_layer, t);
     for (int o = 0; o < l.out_dim; o++) {
       const float *w = l.W + static_cast<int64_t>(o) * K;
       float acc = l.bias ? l.bias[o] : 0.0f;   // bias first, then AddMatMat (:189-210)
       for (int i = 0; i < l.n_offsets; i++) {
-        const float *x = xs[i], *wi = w + i * l.in_dim;
+        const float *x = xs[i], *wi = w + scol[i];
         float s = 0.0f;
-        for (int k = 0; k < l.in_dim; k++) s += wi[k] * x[k];
+        for (int k = 0; k < sdim[i]; k++) s += wi[k] * x[k];
         acc += s;
       }
       if (l.ivector_dim > 0) {
-        const float *wi = w + l.n_offsets * l.in_dim;
+        const float *wi = w + (K - l.ivector_dim);
         float s = 0.0f;
         const float *iv = IvectorAt(t);
         for (int k = 0; k < l.ivector_dim; k++) s += wi[k] * iv[k];
@@ -105,15 +109,14 @@ void Context(const kamd_layer_desc *L, int layer, int *left, int *right) {
   // ComputeSimpleNnetContext (nnet3/nnet-utils.cc:146) for a layer chain.
   if (layer == -1) { *left = 0; *right = 0; return; }
   const kamd_layer_desc &l = L[layer];
-  int il, ir;
-  Context(L, l.input_layer, &il, &ir);
-  int mn = 0, mx = 0;
+  *left = 0; *right = 0;
+  int il = 0, ir = 0;
+  if (!l.multi_input) Context(L, l.input_layer, &il, &ir);       // (once per layer: the recursion is a chain)
   for (int i = 0; i < l.n_offsets; i++) {
-    mn = std::min(mn, l.offsets[i]);
-    mx = std::max(mx, l.offsets[i]);
+    if (l.multi_input) Context(L, l.slice_layer[i], &il, &ir);
+    *left = std::max(*left, il - std::min(0, l.offsets[i]));
+    *right = std::max(*right, ir + std::max(0, l.offsets[i]));
   }
-  *left = il - mn;
-  *right = ir + mx;
   if (l.bypass_layer != -2) {
     int bl, br;
     Context(L, l.bypass_layer, &bl, &br);

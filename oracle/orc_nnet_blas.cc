@@ -46,6 +46,7 @@ extern "C" int orc_nnet_forward_blas(const kamd_layer_desc *L, int n_layers, int
                                      const float *ivector, int frames_per_chunk, void *sgemm_ptr, float *out, int out_rows_cap) {
   SgemmFn sgemm = reinterpret_cast<SgemmFn>(sgemm_ptr);
   if (T <= 0 || !sgemm) return -1;
+  for (int l = 0; l < n_layers; l++) if (L[l].multi_input) return -3;     // single-producer layers only (the bench models); orc_nnet_forward does the rest
   const int sub = subsampling, n_out = (T + sub - 1) / sub, P = L[n_layers - 1].out_dim;
   if (n_out > out_rows_cap) return -1;
   const int C = frames_per_chunk <= 0 ? n_out : (frames_per_chunk + sub - 1) / sub;

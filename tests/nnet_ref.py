@@ -15,16 +15,15 @@ def forward_f64(model, feats, ivector=None):
     x = feats[np.clip(times, 0, T - 1)].astype(np.float64)
     acts = {-1: x}
     for i, l in enumerate(model.layers):
-        src = acts[l.input_layer]
-        n = src.shape[0]
+        n = x.shape[0]
         W = l.W.astype(np.float64)
         y = np.zeros((n, l.out_dim))
-        for j, off in enumerate(l.offsets):
-            Wj = W[:, j * l.in_dim:(j + 1) * l.in_dim]
-            shifted = np.roll(src, -off, axis=0)        # row r holds src[t_r + off]
+        for prod, off, col, width in l.slices():        # (one producer for all slices, or Append over different ones)
+            Wj = W[:, col:col + width]
+            shifted = np.roll(acts[prod], -off, axis=0)  # row r holds src[t_r + off]
             y += shifted @ Wj.T
         if l.ivector_dim:
-            y += (W[:, len(l.offsets) * l.in_dim:] @ ivector.astype(np.float64))[None, :]
+            y += (W[:, W.shape[1] - l.ivector_dim:] @ ivector.astype(np.float64))[None, :]
         if l.bias is not None:
             y += l.bias.astype(np.float64)
         if l.relu:

@@ -256,3 +256,25 @@ def test_component_propagate_shaped_entry():
             np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * max(1.0, np.abs(want).max()))
     with pytest.raises(KamdError, match="offsets must include"):
         decoder.Component(Layer("c", 8, 8, [1, 2], -1, np.zeros((8, 16), np.float32)))
+
+
+def test_append_over_different_producers_on_the_device(tmp_path):
+    """A graph with Append over different producers and widths (tests/test_mdl.py::append_model; the reference: kCopyRows
+    over arbitrary sources, nnet3/nnet-compute.cc:309-383): the device materialises the Append (a concat pseudo-layer in
+    front of the GEMM) -- whole utterances, a batch with ragged lengths, and subsampled outputs, against the oracle and a
+    direct float64 evaluation of the graph."""
+    from kaldi_amd import mdl
+    from tests.test_mdl import append_model
+    path, direct = append_model(tmp_path)
+    rng = np.random.default_rng(5)
+    for sub in (1, 3):
+        model, _, _ = mdl.read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=sub)
+        N = decoder.Nnet(model)
+        assert N.Context() == (2, 2)
+        for T in (1, 2, 7, 64, 301):
+            x = rng.standard_normal((T, 40)).astype(np.float32)
+            got = N.Forward(x)
+            want = direct(x)[::sub]
+            assert got.shape == want.shape
+            np.testing.assert_allclose(got, want, rtol=0, atol=3e-5 * max(1.0, np.abs(want).max()))
+            np.testing.assert_allclose(got, orc.nnet_forward(model, x), rtol=0, atol=3e-5 * max(1.0, np.abs(want).max()))

@@ -19,6 +19,7 @@ def same_as_native(path, got, id2pdf, tid_phone, acoustic_scale=1.0, sub=3):
         assert (a.in_dim, a.out_dim, list(a.offsets), a.input_layer, a.bypass_layer, bool(a.relu), a.ivector_dim, bool(a.log_softmax)) == \
                (b.in_dim, b.out_dim, list(b.offsets), b.input_layer, b.bypass_layer, bool(b.relu), b.ivector_dim, bool(b.log_softmax)), b.name
         assert np.float32(a.bypass_scale) == np.float32(b.bypass_scale) and np.float32(a.post_scale) == np.float32(b.post_scale), b.name
+        assert a.slice_layers == (None if b.slice_layers is None else [int(q) for q in b.slice_layers]) and a.slice_dims == (None if b.slice_dims is None else [int(q) for q in b.slice_dims]), b.name
         for f in ("W", "bias", "bn_scale", "bn_offset", "post_offset"):
             x, y = getattr(a, f), getattr(b, f)
             assert (x is None) == (y is None), (b.name, f)
@@ -212,3 +213,78 @@ def test_native_reader_errors_name_the_problem(tmp_path):
         mdl.read_mdl_native(tmp_path / "bad.mdl")
     with pytest.raises(mdl.MdlError, match="unsupported component type SigmoidBlahBlahComponent"):
         mdl.read_mdl(tmp_path / "bad.mdl")
+
+
+def append_model(tmp_path, seed=11):
+    """A small graph with an Append over DIFFERENT producers (and widths): l3 reads Append(Offset(l1, -1), l2, Offset(input, 2)),
+    the output layer Append(l3, Scale(0.5, l1)).  -> (path, float64 reference forward as a function of the features)"""
+    from tests import mdl_writer as mw
+    rng = np.random.default_rng(seed)
+    D, H1, H2, H3, P = 40, 24, 16, 32, 21
+    W1, b1 = rng.standard_normal((H1, 2 * D)) * 0.1, rng.standard_normal(H1) * 0.1
+    W2, b2 = rng.standard_normal((H2, H1)) * 0.2, rng.standard_normal(H2) * 0.1
+    W3, b3 = rng.standard_normal((H3, H1 + H2 + D)) * 0.15, rng.standard_normal(H3) * 0.1
+    W4, b4 = rng.standard_normal((P, H3 + H1)) * 0.2, rng.standard_normal(P) * 0.1
+    W1, b1, W2, b2, W3, b3, W4, b4 = [a.astype(np.float32).astype(np.float64) for a in (W1, b1, W2, b2, W3, b3, W4, b4)]   # what the file holds
+
+    def affine(name, W, b):
+        return (name, mw.updatable_common("NaturalGradientAffineComponent") + mw.tok("<LinearParams>") + mw.mat(W) + mw.tok("<BiasParams>") +
+                mw.vec(b) + mw.tok("<RankIn>") + mw.i32(20) + mw.tok("<RankOut>") + mw.i32(80) + mw.tok("<UpdatePeriod>") + mw.i32(4) +
+                mw.tok("<NumSamplesHistory>") + mw.f32(2000.0) + mw.tok("<Alpha>") + mw.f32(4.0) + mw.tok("</NaturalGradientAffineComponent>"))
+
+    def relu(name, dim):
+        z = np.zeros(dim, np.float32)
+        return (name, mw.tok("<RectifiedLinearComponent>") + mw.tok("<Dim>") + mw.i32(dim) + mw.tok("<ValueAvg>") + mw.vec(z) +
+                mw.tok("<DerivAvg>") + mw.vec(z) + mw.tok("<Count>") + mw.f64(0.0) + mw.tok("<OderivRms>") + mw.vec(z) +
+                mw.tok("<OderivCount>") + mw.f64(0.0) + mw.tok("<NumDimsSelfRepaired>") + mw.f64(0.0) + mw.tok("<NumDimsProcessed>") +
+                mw.f64(0.0) + mw.tok("<SelfRepairScale>") + mw.f32(1e-5) + mw.tok("</RectifiedLinearComponent>"))
+    comps = [affine("l1.affine", W1, b1), relu("l1.relu", H1), affine("l2.affine", W2, b2), relu("l2.relu", H2),
+             affine("l3.affine", W3, b3), relu("l3.relu", H3), affine("output.affine", W4, b4)]
+    cfg = ["input-node name=input dim=%d" % D,
+           "component-node name=l1.affine component=l1.affine input=Append(Offset(input, -1), Offset(input, 1))",
+           "component-node name=l1.relu component=l1.relu input=l1.affine",
+           "component-node name=l2.affine component=l2.affine input=l1.relu",
+           "component-node name=l2.relu component=l2.relu input=l2.affine",
+           "component-node name=l3.affine component=l3.affine input=Append(Offset(l1.relu, -1), l2.relu, Offset(input, 2))",
+           "component-node name=l3.relu component=l3.relu input=l3.affine",
+           "component-node name=output.affine component=output.affine input=Append(l3.relu, Scale(0.5, l1.relu))",
+           "output-node name=output input=output.affine objective=linear"]
+    tm, _, _ = mw.transition_model(10)
+    blob = b"\0B" + tm + mw.tok("<Nnet3>") + b"\n" + ("\n".join(cfg) + "\n\n").encode() + mw.tok("<NumComponents>") + mw.i32(len(comps))
+    for name, body in comps:
+        blob += mw.tok("<ComponentName>") + mw.tok(name) + body
+    blob += mw.tok("</Nnet3>") + mw.tok("<LeftContext>") + mw.i32(0) + mw.tok("<RightContext>") + mw.i32(0) + mw.tok("<Priors>") + mw.vec(np.zeros(0))
+    path = tmp_path / "append.mdl"
+    path.write_bytes(blob)
+
+    def direct(x):
+        T = x.shape[0]
+        lo, hi = -6, T + 6
+        ts = np.arange(lo, hi)
+        xin = np.stack([x[np.clip(t, 0, T - 1)] for t in ts]).astype(np.float64)
+        sh = lambda m, d: np.roll(m, -d, axis=0)                     # m[t + d] on the extended range
+        l1 = np.maximum(np.concatenate([sh(xin, -1), sh(xin, 1)], 1) @ W1.T + b1, 0.0)
+        l2 = np.maximum(l1 @ W2.T + b2, 0.0)
+        l3 = np.maximum(np.concatenate([sh(l1, -1), l2, sh(xin, 2)], 1) @ W3.T + b3, 0.0)
+        out = np.concatenate([l3, 0.5 * l1], 1) @ W4.T + b4
+        return out[-lo:-lo + T]
+    return path, direct
+
+
+def test_append_over_different_producers(tmp_path):
+    """Descriptors like Append(Offset(l1, -1), l2, Offset(input, 2)) -- evaluated by the reference with kCopyRows over
+    arbitrary sources (nnet3/nnet-compute.cc:309-383) -- compile into multi-input layers in both readers; the oracle's
+    forward of that model equals a direct float64 evaluation of the graph."""
+    from tests.nnet_ref import forward_f64
+    path, direct = append_model(tmp_path)
+    model, i2p, tph = mdl.read_mdl(path, acoustic_scale=1.0, frame_subsampling_factor=1)
+    same_as_native(path, model, i2p, tph, sub=1)
+    l3, out = model.layers[2], model.layers[3]
+    assert l3.slice_layers == [0, 1, -1] and l3.slice_dims == [24, 16, 40] and list(l3.offsets) == [-1, 0, 2] and l3.in_dim == 80
+    assert out.slice_layers == [2, 0] and out.slice_dims == [32, 24]
+    assert model.context() == (2, 2)                  # l1: +-1; l3: l1 at -1 -> left 2; input at +2 -> right 2
+    x = np.random.default_rng(2).standard_normal((29, 40)).astype(np.float32)
+    want = direct(x)
+    np.testing.assert_allclose(forward_f64(model, x), want, rtol=1e-9, atol=1e-9)
+    got = orc.nnet_forward(model, x)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-5 * np.abs(want).max())
