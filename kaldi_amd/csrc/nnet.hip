@@ -1822,7 +1822,7 @@ struct Component {
 };
 
 kamd_component *kamd_component_create(const kamd_layer_desc *layer) {
-  if (!layer || layer->ivector_dim != 0 || layer->n_offsets < 1) { kamd::SetError(KAMD_ERR_ARG, "kamd_component_create: a plain fused layer is expected"); return NULL; }
+  if (!layer || layer->ivector_dim != 0 || layer->n_offsets < 1 || layer->multi_input) { kamd::SetError(KAMD_ERR_ARG, "kamd_component_create: a plain fused layer is expected"); return NULL; }
   kamd_layer_desc d = *layer;
   d.input_layer = -1; d.bypass_layer = -2; d.bypass_scale = 0.0f;      // (a bypass is a Sum descriptor of the graph, not of the component)
   kamd_nnet *net = kamd_nnet_create(&d, 1, d.in_dim, 1);
