@@ -131,9 +131,10 @@ int main(int argc, char **argv) {
     po.Register("frame-subsampling-factor", &frame_subsampling_factor, "Required if the frame-rate of the output (e.g. in 'chain' models) is "
                 "less than the frame-rate of the original alignment.");
     po.Register("acoustic-scale", &acoustic_scale, "Scaling factor for acoustic log-likelihoods");
-    po.Register("frames-per-chunk", &frames_per_chunk, "(ignored: whole utterances are batched on the device, which gives the same numbers)");
+    po.Register("frames-per-chunk", &frames_per_chunk, "Number of frames in each chunk that is separately evaluated by the neural net (only matters "
+                "with --ivector-extraction-config: without online iVectors whole utterances are batched, which gives the same numbers)");
     po.Register("debug-computation", &debug_computation, "(ignored)");
-    std::string word_syms_filename, ivector_rspecifier, online_ivector_rspecifier, utt2spk_rspecifier, mfcc_config;
+    std::string word_syms_filename, ivector_rspecifier, online_ivector_rspecifier, utt2spk_rspecifier, mfcc_config, ivector_config;
     int32 online_ivector_period = 0, num_threads = 8, set_frames = 2000000, lanes_opt = 0, search_mode = 2, device = -1;
     po.Register("word-symbol-table", &word_syms_filename, "Symbol table for words [for debug output]");
     po.Register("allow-partial", &allow_partial, "If true, produce output even if end state was not reached.");
@@ -143,6 +144,9 @@ int main(int argc, char **argv) {
     po.Register("online-ivectors", &online_ivector_rspecifier, "(not supported here: the device estimates online iVectors itself, see "
                 "OnlineStreamBatch / kamd_pipeline_set_ivector_extractor)");
     po.Register("online-ivector-period", &online_ivector_period, "(not supported here)");
+    po.Register("ivector-extraction-config", &ivector_config, "Configuration file for online iVector extraction (the one of the online2 binaries / "
+                "ivector-extract-online2): the iVectors are estimated on the device from the utterances' own features and the model is evaluated "
+                "in chunks of --frames-per-chunk like nnet3-latgen-faster --online-ivectors (steps/nnet3/decode.sh:105-107)");
     po.Register("num-threads", &num_threads, "Number of host threads for the tail of every utterance (best path, lattice determinization): "
                 "the decoder threads of nnet3-latgen-faster-batch");
     po.Register("wav", &wav, "The third argument is an scp: rspecifier of waveforms; features are computed on the device");
@@ -200,8 +204,14 @@ int main(int argc, char **argv) {
     std::unique_ptr<RandomAccessTokenReader> utt2spk;
     if (!ivector_rspecifier.empty()) ivector_reader.reset(new RandomAccessBaseFloatVectorReader(ivector_rspecifier));
     if (!utt2spk_rspecifier.empty()) utt2spk.reset(new RandomAccessTokenReader(utt2spk_rspecifier));
-    if ((model.IvectorDim() > 0) != (ivector_reader != NULL))
-      throw KaldiFatalError(model.IvectorDim() > 0 ? "the model has an ivector input: give --ivectors" : "the model has no ivector input: drop --ivectors");
+    std::unique_ptr<OnlineIvectorExtractor> ivector_extractor;
+    if (!ivector_config.empty()) {
+      if (ivector_reader) throw KaldiFatalError("--ivectors and --ivector-extraction-config are alternatives");
+      ivector_extractor.reset(new OnlineIvectorExtractor(ivector_config));
+    }
+    if ((model.IvectorDim() > 0) != (ivector_reader != NULL || ivector_extractor != NULL))
+      throw KaldiFatalError(model.IvectorDim() > 0 ? "the model has an ivector input: give --ivectors or --ivector-extraction-config"
+                                                   : "the model has no ivector input: drop --ivectors / --ivector-extraction-config");
     std::vector<std::string> word_syms_storage;
     const std::vector<std::string> *word_syms = NULL;
     if (!word_syms_filename.empty()) { word_syms_storage = ReadSymbolTable(word_syms_filename); word_syms = &word_syms_storage; }
@@ -237,6 +247,7 @@ int main(int argc, char **argv) {
       opts.c.resident_lanes = sized_lanes; opts.c.det = det_opts.c;
       NnetBatchDecoder decoder(decode_fst, config, model.Id2Pdf(), model.TidPhone(), word_syms, allow_partial, num_threads, am_nnet,
                                wav ? &mfcc : NULL, sizes, opts);
+      if (ivector_extractor) decoder.SetIvectorExtractor(ivector_extractor->handle(), frames_per_chunk);
       for (const Utterance &u : *items) {
         if (wav) decoder.AcceptWaveform(u.key, u.data);
         else decoder.AcceptInput(u.key, u.data.data(), u.rows, model.InputDim(), u.ivector.empty() ? NULL : u.ivector.data(),

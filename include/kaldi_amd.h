@@ -641,6 +641,16 @@ typedef struct kamd_ivector_desc {
   float min_post, posterior_scale, max_count;          /* 0.025, 0.1, 0 */
 } kamd_ivector_desc;
 kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *desc);
+/* The files of an i-vector extraction config -- what OnlineIvectorExtractionInfo::Init reads (online2/online-ivector-
+ * feature.cc:30-74) for --ivector-extraction-config of the online2 binaries / --config of ivector-extract-online2:
+ * final.mat, global_cmvn.stats, the OnlineCmvnOptions and splice config files, final.dubm (gconsts recomputed as
+ * DiagGmm::Read does), final.ie.  Binary objects; rxfilenames may be pipes or file:offset.  The descriptor's pointers
+ * stay valid until kamd_ivector_info_destroy.  NULL + kamd_last_error() on a missing option / file / mismatch. */
+typedef struct kamd_ivector_info kamd_ivector_info;
+kamd_ivector_info *kamd_ivector_info_read(const char *config_rxfilename);
+void kamd_ivector_info_destroy(kamd_ivector_info *info);
+const kamd_ivector_desc *kamd_ivector_info_desc(const kamd_ivector_info *info);
+kamd_ivector_extractor *kamd_ivector_info_create_extractor(const kamd_ivector_info *info);
 void kamd_ivector_extractor_destroy(kamd_ivector_extractor *e);
 int kamd_ivector_dim(const kamd_ivector_extractor *e);
 int kamd_ivector_period(const kamd_ivector_extractor *e);

@@ -1040,7 +1040,7 @@ class NnetBatchDecoder {
     opts_.c.keep_raw_lattices = decoder_config.determinize_lattice ? 0 : 1;
     opts_.c.lattice_beam = decoder_config.lattice_beam;
     if (mfcc_opts) feat_ = CheckPtr(kamd_mfcc_create(&mfcc_opts->c, 1.0f));
-    dec_ = kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), static_cast<int32>(id2pdf.size()));
+    dec_ = kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), id2pdf.empty() ? 0 : static_cast<int32>(id2pdf.size()) - 1);
     if (dec_ && kamd_decoder_set_search_mode(dec_, opts_.search_mode) == 0)
       h_ = kamd_batch_decoder_create(feat_, am_nnet.Handle(), dec_, &opts_.c, tid_phone.empty() ? NULL : tid_phone.data(),
                                      static_cast<int32>(tid_phone.size()) - 1);
@@ -1064,10 +1064,18 @@ class NnetBatchDecoder {
   void SetLongUtteranceDecoder(const DecodingGraph &fst, const std::vector<int32> &id2pdf, const kamd_decoder_sizes &sizes) {
     if (dec_long_) throw KaldiFatalError("NnetBatchDecoder: the long-utterance decoder is set already");
     kamd_decoder_config c = config_.ToC();
-    dec_long_ = kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), static_cast<int32>(id2pdf.size()));
+    dec_long_ = kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), id2pdf.empty() ? 0 : static_cast<int32>(id2pdf.size()) - 1);
     if (!dec_long_ || kamd_decoder_set_search_mode(dec_long_, opts_.search_mode) != 0 ||
         kamd_batch_decoder_set_long_decoder(h_, dec_long_, sizes.max_lanes) != 0)
       throw KaldiFatalError(kamd_last_error());
+  }
+  /// Not in the reference's class (there, online i-vectors arrive as matrices extract_ivectors_online.sh wrote):
+  /// i-vectors estimated on the device from every pass's features, the model evaluated chunk by chunk like
+  /// DecodableNnetSimple with --online-ivectors (kamd_batch_decoder_set_ivector_extractor).  Before the first AcceptInput /
+  /// AcceptWaveform; utterances then come without an i-vector of their own.
+  void SetIvectorExtractor(kamd_ivector_extractor *extractor, int32 frames_per_chunk = 50) {
+    Check(kamd_batch_decoder_set_ivector_extractor(h_, extractor, frames_per_chunk));
+    online_ivectors_ = extractor != NULL;
   }
   NnetBatchDecoder(const NnetBatchDecoder &) = delete;
   NnetBatchDecoder &operator=(const NnetBatchDecoder &) = delete;
@@ -1082,7 +1090,8 @@ class NnetBatchDecoder {
     if (!waves_.empty()) throw KaldiFatalError("NnetBatchDecoder: a set is either waveforms or feature matrices");
     if (num_rows <= 0) throw KaldiFatalError("Zero-length utterance: " + utterance_id);
     if (num_cols != input_dim_) throw KaldiFatalError("NnetBatchDecoder: feature dim mismatch for " + utterance_id);
-    if ((ivector ? ivector_dim : 0) != ivector_dim_) throw KaldiFatalError("NnetBatchDecoder: i-vector dim mismatch for " + utterance_id);
+    if (!(online_ivectors_ && !ivector) && (ivector ? ivector_dim : 0) != ivector_dim_)
+      throw KaldiFatalError("NnetBatchDecoder: i-vector dim mismatch for " + utterance_id);
     keys_.push_back(utterance_id);
     feats_.insert(feats_.end(), input, input + static_cast<size_t>(num_rows) * num_cols);
     row_off_.push_back(row_off_.empty() ? num_rows : row_off_.back() + num_rows);
@@ -1221,6 +1230,7 @@ class NnetBatchDecoder {
   kamd_decoder *dec_long_ = NULL;
   kamd_batch_decoder *h_;
   int32 input_dim_, ivector_dim_;
+  bool online_ivectors_ = false;
   std::vector<std::string> keys_;
   std::vector<float> waves_, feats_, ivectors_;
   std::vector<int64_t> row_off_;
@@ -1293,7 +1303,7 @@ class OnlineStreamBatch {
       : feat_(CheckPtr(kamd_mfcc_create(&mfcc_opts.c, 1.0f))), ie_(NULL) {
     decoder_opts.Check();
     kamd_decoder_config c = decoder_opts.ToC();
-    dec_ = CheckPtr(kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), static_cast<int32>(id2pdf.size())));
+    dec_ = CheckPtr(kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), id2pdf.empty() ? 0 : static_cast<int32>(id2pdf.size()) - 1));
     h_ = CheckPtr(kamd_stream_batch_create(feat_, am_nnet.Handle(), dec_, max_streams, max_seconds, mfcc_opts.c.frame.samp_freq));
     frame_shift_ = mfcc_opts.c.frame.frame_shift_ms * 1.0e-3f * kamd_nnet_frame_subsampling_factor(am_nnet.Handle());
   }
@@ -1404,6 +1414,15 @@ class OnlineIvectorExtractor {
   // desc: the fields of OnlineIvectorExtractionInfo (lda_mat, global_cmvn_stats, diag_ubm, extractor M_ / Sigma_inv_, options)
   explicit OnlineIvectorExtractor(const kamd_ivector_desc &desc, BaseFloat max_remembered_frames = 1000.0)
       : h_(kamd_ivector_extractor_create(&desc)), max_remembered_frames_(max_remembered_frames) {
+    if (!h_) throw KaldiFatalError(kamd_last_error());
+  }
+  /// OnlineIvectorExtractionInfo::Init from the files of an extraction config (--ivector-extraction-config of the online2
+  /// binaries, --config of ivector-extract-online2; online2/online-ivector-feature.cc:30-74): kamd_ivector_info_read
+  explicit OnlineIvectorExtractor(const std::string &config_rxfilename, BaseFloat max_remembered_frames = 1000.0)
+      : h_(NULL), max_remembered_frames_(max_remembered_frames) {
+    kamd_ivector_info *info = CheckPtr(kamd_ivector_info_read(config_rxfilename.c_str()));
+    h_ = kamd_ivector_info_create_extractor(info);
+    kamd_ivector_info_destroy(info);
     if (!h_) throw KaldiFatalError(kamd_last_error());
   }
   ~OnlineIvectorExtractor() { kamd_ivector_extractor_destroy(h_); }

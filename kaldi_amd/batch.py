@@ -17,7 +17,8 @@ from ._lib import KamdError, check, lib
 class NnetBatchDecoder:
     def __init__(self, mfcc_opts, model, hclg, cfg, max_seconds=36.0, resident_lanes=0, host_threads=8, determinize=True,
                  keep_raw_lattices=False, tid_phone=None, sizes=None, nnet_pass_frames=1000000, lattice_pool_bytes=1 << 30,
-                 hash_capacity=None, tokens_per_frame=None, search_mode=2, det=None, long_lanes=0, first_pass_frames=None, hbm_fraction=0.5):
+                 hash_capacity=None, tokens_per_frame=None, search_mode=2, det=None, long_lanes=0, first_pass_frames=None, hbm_fraction=0.5,
+                 nnet=None):
         featmod = __import__("kaldi_amd.feat", fromlist=["Mfcc"])
         # mfcc_opts = None: no feature stage, the caller hands over feature matrices (load_features), as the
         # reference's AcceptInput does (nnet-batch-compute.h:665)
@@ -26,7 +27,7 @@ class NnetBatchDecoder:
         else:
             self.feat = featmod.Fbank(mfcc_opts) if isinstance(mfcc_opts, abi.FbankOpts) else featmod.Mfcc(mfcc_opts)
         self.model, self.cfg = model, cfg
-        self.nnet = decoder.Nnet(model)
+        self.nnet = nnet if nnet is not None else decoder.Nnet(model)      # (one set of weights in HBM can serve several decoders)
         self.graph = hclg if isinstance(hclg, decoder.Graph) else decoder.Graph(hclg)
         fps = 100.0 if mfcc_opts is None else 1000.0 / mfcc_opts.frame.frame_shift_ms
         max_out = int(max_seconds * fps / model.subsampling) + 2

@@ -281,7 +281,7 @@ static int CheckIvectorInput(const BatchDecoder *b) {
 }
 static int SizeOnlineIvectors(BatchDecoder *b) {
   b->oiv_off.assign(1, 0);
-  if (!b->iv_extractor || b->from_features) return KAMD_OK;
+  if (!b->iv_extractor || b->have_iv) return KAMD_OK;
   for (size_t k = 0; k + 1 < b->feat_off.size(); k++)
     b->oiv_off.push_back(b->oiv_off.back() + kamd_ivector_num_ivectors(b->iv_extractor, static_cast<int>(b->feat_off[k + 1] - b->feat_off[k])));
   return GrowDev(&b->d_oiv, &b->oiv_cap, std::max<size_t>(static_cast<size_t>(b->oiv_off.back()) * kamd_ivector_dim(b->iv_extractor), 1));
@@ -343,8 +343,11 @@ int kamd_batch_decoder_load_features(kamd_batch_decoder *h, const float *feats, 
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
   if (n_utts <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty test set");
   if (dim != b->feat_dim) return kamd::SetError(KAMD_ERR_ARG, "features have dim %d, the model's input node %d", dim, b->feat_dim);
-  const int want_iv = kamd_nnet_ivector_dim(b->nnet);
-  if ((ivectors ? ivector_dim : 0) != want_iv)
+  // the model's ivector input: one vector per utterance (--ivectors), or -- with an extractor set and none given -- online
+  // i-vectors estimated from these very features (--online-ivectors of the recipe)
+  const bool online = b->iv_extractor != NULL && ivectors == NULL;
+  const int want_iv = online ? 0 : kamd_nnet_ivector_dim(b->nnet);
+  if (!online && (ivectors ? ivector_dim : 0) != want_iv)
     return kamd::SetError(KAMD_ERR_ARG, "model expects ivector dim %d, got %d", want_iv, ivectors ? ivector_dim : 0);
   for (kamd::UttOut &o : b->out) o.Clear();
   b->n_utts = 0; b->h_waves = NULL;
@@ -375,6 +378,7 @@ int kamd_batch_decoder_load_features(kamd_batch_decoder *h, const float *feats, 
     KAMD_HIP(hipMemcpy(b->d_iv, iv.data(), iv.size() * sizeof(float), hipMemcpyHostToDevice));
   }
   b->from_features = true; b->have_iv = want_iv > 0;
+  if (kamd::SizeOnlineIvectors(b) != KAMD_OK) return KAMD_ERR_HIP;
   b->out.resize(n_utts);
   b->n_utts = n_utts;
   return KAMD_OK;
@@ -610,7 +614,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
                0.55 * static_cast<double>(longest) > 1.5 * static_cast<double>(b->out_off.back()) / std::max(lanes_main, 1);
   if (const char *e = getenv("KAMD_BATCH_SPLIT")) split = b->dec_long && b->long_lanes > 0 && !b->have_iv && n > b->long_lanes && atoi(e) != 0;
   if (host_mode || b->d_ll_override) split = false;       // (the passes follow the upload; a planted matrix is in load order)
-  const bool online_iv = b->iv_extractor != NULL && !b->from_features;
+  const bool online_iv = b->iv_extractor != NULL && !b->have_iv;
   if (online_iv) split = false;
   const float *ll_base = b->d_ll_override ? b->d_ll_override : b->d_ll;
   b->last_split = split;

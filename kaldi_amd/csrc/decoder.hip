@@ -2508,6 +2508,7 @@ struct RawLat {
 struct Decoder {
   DecDev dev;
   Graph *g;
+  int num_pdfs = 0;          // 1 + the largest pdf an arc of the graph maps to: every log-likelihood row must be this wide
   kamd_decoder_sizes sizes;
   std::vector<void *> allocs;
   std::vector<LaneState> h_st;
@@ -2706,6 +2707,7 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
     num_pdfs = 0;
     for (int t = 1; t <= num_tids; t++) num_pdfs = std::max(num_pdfs, tid2pdf[t] + 1);
   }
+  D->num_pdfs = num_pdfs;
   {
     uint2 *ep = static_cast<uint2 *>(alloc(static_cast<size_t>(std::max<int64_t>(D->g->num_emit, 1)) * 8, 0));
     d.e_hot = ep;
@@ -2880,6 +2882,9 @@ int kamd_decoder_advance(kamd_decoder *h, const kamd_decode_task *tasks, int n, 
   for (int i = 0; i < n; i++)
     if (tasks[i].lane < 0 || tasks[i].lane >= D->sizes.max_lanes || tasks[i].n_frames < 0)
       return kamd::SetError(KAMD_ERR_ARG, "task %d: bad lane / frame count", i);
+  for (int i = 0; i < n; i++)
+    if (tasks[i].n_frames > 0 && tasks[i].ld < D->num_pdfs)
+      return kamd::SetError(KAMD_ERR_ARG, "task %d: log-likelihood rows of %d columns, the graph's arcs map to pdfs up to %d", i, tasks[i].ld, D->num_pdfs - 1);
   hipStream_t st = static_cast<hipStream_t>(stream);
   // longest first: the tail of the launch is the longest utterance, start it early
   std::vector<kamd_decode_task> sorted(tasks, tasks + n);
@@ -3649,6 +3654,8 @@ int kamd_decoder_queue_launch(kamd_decoder *h, const kamd_queue_task *tasks, int
     if (tasks[i].n_frames < 0 || tasks[i].n_frames > D->sizes.max_frames)
       return kamd::SetError(KAMD_ERR_ARG, "task %d: %d frames (max_frames %d)", i, tasks[i].n_frames, D->sizes.max_frames);
     if (tasks[i].utt < 0 || tasks[i].utt >= n) return kamd::SetError(KAMD_ERR_ARG, "task %d: utterance index %d outside [0, %d)", i, tasks[i].utt, n);
+    if (tasks[i].n_frames > 0 && tasks[i].ld < D->num_pdfs)
+      return kamd::SetError(KAMD_ERR_ARG, "task %d: log-likelihood rows of %d columns, the graph's arcs map to pdfs up to %d", i, tasks[i].ld, D->num_pdfs - 1);
   }
   int cus = 0;
   {

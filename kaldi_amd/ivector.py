@@ -9,6 +9,7 @@ The file readers follow IvectorExtractor::Write (ivector/ivector-extractor.cc:80
 (gmm/diag-gmm.cc:690-726), PackedMatrix::Write (matrix/packed-matrix.cc:236-271) and the Matrix /
 Vector writers; write_* are their inverse, used by the tests (no extractor is available offline)."""
 import ctypes as C
+import math
 import os
 import struct
 
@@ -47,10 +48,11 @@ class IvectorExtractionInfo:
         out = np.zeros(self.ubm_weights.size, np.float32)
         offset = np.float32(-0.5 * 1.8378770664093453 * D)
         for g in range(out.size):
-            gc = np.float32(np.log(self.ubm_weights[g])) + offset
+            # (logs through libm in double, rounded to float: bit-identical with csrc/ivector_io.cc)
+            gc = np.float32(math.log(float(self.ubm_weights[g])) if self.ubm_weights[g] > 0 else -np.inf) + offset
             for k in range(D):
                 iv, mi = self.ubm_inv_vars[g, k], self.ubm_means_invvars[g, k]
-                gc = np.float32(gc + np.float32(np.float32(0.5) * np.float32(np.log(iv))) - np.float32(np.float32(0.5) * mi * mi / iv))
+                gc = np.float32(gc + np.float32(np.float32(0.5) * np.float32(math.log(float(iv)))) - np.float32(np.float32(0.5) * mi * mi / iv))
             if np.isinf(gc) and gc > 0:
                 gc = -gc
             out[g] = gc
@@ -130,6 +132,28 @@ class IvectorExtractionInfo:
                    off, sp["left-context"], sp["right-context"], cm["cmn-window"], cm["speaker-frames"], cm["global-frames"],
                    cm["norm-means"], cm["norm-vars"], po["ivector-period"], po["num-gselect"], po["min-post"],
                    po["posterior-scale"], po["max-count"])
+
+
+def read_config_native(config_rxfilename):
+    """The same files through the library's own reader (kamd_ivector_info_read, csrc/ivector_io.cc: what a C / C++ host
+    uses) -> IvectorExtractionInfo; every field bit-identical with from_config (tests/test_ivector_io.py)."""
+    L = lib()
+    h = L.kamd_ivector_info_read(str(config_rxfilename).encode())
+    if not h:
+        raise KamdError(L.kamd_last_error().decode())
+    try:
+        d = L.kamd_ivector_info_desc(h).contents
+        G, D, I, sdim = d.num_gauss, d.lda_rows, d.ivector_dim, d.feat_dim + 1
+        arr = lambda p, *shape: np.ctypeslib.as_array(p, shape=shape).copy()
+        info = IvectorExtractionInfo(arr(d.lda, D, d.lda_cols), arr(d.global_cmvn_stats, 2, sdim), np.ones(G, np.float32),
+                                     arr(d.ubm_means_invvars, G, D), arr(d.ubm_inv_vars, G, D), arr(d.M, G, D, I),
+                                     arr(d.sigma_inv, G, D * (D + 1) // 2), d.prior_offset, d.splice_left, d.splice_right, d.cmn_window,
+                                     d.speaker_frames, d.global_frames, bool(d.normalize_mean), bool(d.normalize_variance), d.ivector_period,
+                                     d.num_gselect, d.min_post, d.posterior_scale, d.max_count, d.num_cg_iters)
+        info.ubm_gconsts = arr(d.ubm_gconsts, G)          # (the weights themselves are not part of the descriptor)
+        return info
+    finally:
+        L.kamd_ivector_info_destroy(h)
 
 
 # ---- Kaldi object files ---------------------------------------------------------------------

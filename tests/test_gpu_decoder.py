@@ -527,3 +527,18 @@ def test_no_device_memory_leak_over_create_destroy_cycles():
     for _ in range(10):
         cycle()
     assert abs(free_bytes() - base) < (8 << 20), (base, free_bytes())
+
+
+def test_loglike_rows_narrower_than_the_graphs_pdfs_are_refused():
+    """A log-likelihood matrix with fewer columns than the pdfs the graph's arcs map to would be read out of bounds (the
+    frame's row is DMA'd into LDS): the launch is refused by name instead.  (Found through the C++ mirror passing one
+    entry too many of the transition-id table, whose garbage tail entry raised the pdf count.)"""
+    from kaldi_amd._lib import KamdError
+    g = synth.make_hclg(num_units=16, vocab=50, n_hist=8, seed=4)
+    ll = synth.random_loglikes(12, g.num_pdfs, seed=1)
+    d = decoder.LatticeFasterDecoder(decoder.Graph(g), abi.decoder_config_recipe(), sizes())
+    with pytest.raises(KamdError, match="log-likelihood rows of %d columns" % (g.num_pdfs - 3)):
+        d.Decode(np.ascontiguousarray(ll[:, :g.num_pdfs - 3]))
+    d2 = decoder.LatticeFasterDecoder(decoder.Graph(g), abi.decoder_config_recipe(), sizes())
+    d2.Decode(ll)                      # the right width decodes
+    assert d2.GetRawLattice() is not None

@@ -36,6 +36,9 @@ def main(argv):
     po.register("utt2spk", str, "", "Rspecifier for utt2spk option used to get ivectors per speaker")
     po.register("online-ivectors", str, "", "(not supported by this tool)")
     po.register("online-ivector-period", int, 0, "(not supported by this tool)")
+    po.register("ivector-extraction-config", str, "", "Configuration file for online iVector extraction (the one of the online2 binaries): the "
+                "iVectors are estimated on the device from the utterances' own features, the model is evaluated in chunks of "
+                "--frames-per-chunk like nnet3-latgen-faster --online-ivectors")
     po.register("num-threads", int, max(1, min(16, (os.cpu_count() or 2) - 1)), "Number of host threads for the tail of every "
                 "utterance (best path, lattice determinization); the reference's decoder threads")
     po.register("use-gpu", str, "yes", "(ignored: there is no CPU path)")
@@ -75,8 +78,15 @@ def main(argv):
     G = decoder.Graph(g)
     const_ivecs = table.RandomAccessTableReader(po["ivectors"], "vector") if po["ivectors"] else None
     utt2spk = {k: v[0] for k, v in table.SequentialTableReader(po["utt2spk"], "tokens")} if po["utt2spk"] else None
-    if (model.ivector_dim > 0) != (const_ivecs is not None):
-        raise KamdError("the model %s an ivector input: %s --ivectors" % (("has", "give") if model.ivector_dim else ("has no", "drop")))
+    extractor = None
+    if po["ivector-extraction-config"]:
+        from kaldi_amd import ivector
+        if const_ivecs is not None:
+            raise KamdError("--ivectors and --ivector-extraction-config are alternatives")
+        extractor = ivector.IvectorExtractor(ivector.IvectorExtractionInfo.from_config(po["ivector-extraction-config"]))
+    if (model.ivector_dim > 0) != (const_ivecs is not None or extractor is not None):
+        raise KamdError("the model %s an ivector input: %s --ivectors / --ivector-extraction-config" %
+                        (("has", "give") if model.ivector_dim else ("has no", "drop")))
     words = None
     if po["word-symbol-table"]:
         words = {}
@@ -109,6 +119,8 @@ def main(argv):
                                                  tid_phone=tid_phone, search_mode=po["search-mode"],
                                                  det=dict(delta=po["delta"], phone_determinize=int(po["phone-determinize"]),
                                                           word_determinize=int(po["word-determinize"])))
+            if extractor is not None:
+                state["bd"].set_ivector_extractor(extractor, po["frames-per-chunk"])
         bd = state["bd"]
         if po["wav"]:
             bd.load(vals)
