@@ -574,8 +574,12 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
           }
           u = v;
         }
+        // the pass is handed to the launch thread once its last byte is in HBM, by this thread's own wait: a
+        // hipStreamWaitEvent on the main stream against an event of the copy stream held the kernels back until EVERY copy
+        // queued by then had finished (seen in the rocprofv3 timeline: pass 0's features started behind the last pass's
+        // copy, 21 ms late)
         if (up.rc == KAMD_OK) {
-          const hipError_t e = hipEventRecord(b->ev_up[p], b->s_up);
+          const hipError_t e = hipStreamSynchronize(b->s_up);
           if (e != hipSuccess) fail(e);
         }
         {
@@ -642,13 +646,13 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
         if (up.rc != KAMD_OK) return kamd::SetError(up.rc, "%s", up.err.c_str());
       }
       upload_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
-      KAMD_HIP(hipStreamWaitEvent(ps, b->ev_up[pass], 0));
-      KAMD_HIP(hipEventRecord(b->ev_f0[pass], ps));
+      KAMD_HIP(hipEventRecord(b->ev_f0[pass], ps));       // (the pass's samples are in HBM: the uploader waited for them)
       const int frc = kamd::FeatLaunchPremeta(b->feat, b->d_waves, b->d_feat_meta + b->feat_meta_off[pass], pu[pass + 1] - pu[pass],
                                               b->pass_frames[pass], b->d_feats, b->ld_feat, ps);
       if (frc != KAMD_OK) return frc;
       KAMD_HIP(hipEventRecord(b->ev_f1[pass], ps));
       if (pass == 0) first_pass_start_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      mark("features issued, pass", pass);
       return KAMD_OK;
     };
     // online i-vectors: features and OnlineIvectorFeature of pass p + 1 are issued behind the acoustic model of pass p, on
@@ -663,7 +667,6 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
       int irc = features_of(pass, st);
       if (irc != KAMD_OK) return irc;
       KAMD_HIP(hipEventRecord(b->ev_iv0[pass], st));
-      mark("features issued, pass", pass);
       irc = kamd_ivector_extract_online_device(b->iv_extractor, b->d_feats, b->feat_off.data() + pu[pass], b->ld_feat, pu[pass + 1] - pu[pass],
                                                b->d_oiv, b->oiv_off.data() + pu[pass], st);
       if (irc != KAMD_OK) return irc;

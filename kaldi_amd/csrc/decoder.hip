@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "common.h"
+#include "meta_ring.h"
 
 namespace kamd {
 
@@ -2530,7 +2531,7 @@ struct Decoder {
   // work queue (kamd_decoder_queue_*)
   unsigned char *d_pool = NULL, *h_pool = NULL; unsigned long long pool_cap = 0;   // the lattice pool: page-locked HOST memory, d_pool = its device address
   unsigned long long *d_pool_used = NULL; int *d_qctl = NULL;       // d_qctl[0] = head, [1] = done count
-  kamd_queue_task *d_qtasks = NULL; int qtasks_cap = 0;
+  kamd::MetaRing qtasks;      // the task list of a work-queue launch (meta_ring.h)
   kamd_queue_result *h_results = NULL; int *h_ring = NULL; int ring_cap = 0;   // host-visible (hipHostMalloc, coherent)
   int q_n = 0, q_next = 0, q_lanes = 0;
   hipEvent_t qev[2] = {};
@@ -2772,7 +2773,6 @@ void kamd_decoder_destroy(kamd_decoder *h) {
   if (D->h_pool) (void)hipHostFree(D->h_pool);
   if (D->d_pool_used) (void)hipFree(D->d_pool_used);
   if (D->d_qctl) (void)hipFree(D->d_qctl);
-  if (D->d_qtasks) (void)hipFree(D->d_qtasks);
   if (D->h_results) (void)hipHostFree(D->h_results);
   if (D->h_ring) (void)hipHostFree(D->h_ring);
   for (int i = 0; i < 2; i++) if (D->qev[i]) (void)hipEventDestroy(D->qev[i]);
@@ -3673,12 +3673,6 @@ int kamd_decoder_queue_launch(kamd_decoder *h, const kamd_queue_task *tasks, int
     KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_pool_used), 8));
     KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_qctl), 2 * sizeof(int)));
   }
-  if (n > D->qtasks_cap) {
-    if (D->d_qtasks) (void)hipFree(D->d_qtasks);
-    D->d_qtasks = NULL; D->qtasks_cap = 0;
-    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_qtasks), static_cast<size_t>(n) * sizeof(kamd_queue_task)));
-    D->qtasks_cap = n;
-  }
   if (n > D->ring_cap) {
     if (D->h_results) (void)hipHostFree(D->h_results);
     if (D->h_ring) (void)hipHostFree(D->h_ring);
@@ -3692,10 +3686,12 @@ int kamd_decoder_queue_launch(kamd_decoder *h, const kamd_queue_task *tasks, int
   hipStream_t st = static_cast<hipStream_t>(stream);
   KAMD_HIP(hipMemsetAsync(D->d_pool_used, 0, 8, st));
   KAMD_HIP(hipMemsetAsync(D->d_qctl, 0, 2 * sizeof(int), st));
-  KAMD_HIP(hipMemcpyAsync(D->d_qtasks, tasks, static_cast<size_t>(n) * sizeof(kamd_queue_task), hipMemcpyHostToDevice, st));
-  KAMD_HIP(hipStreamSynchronize(st));      // `tasks` is the caller's (pageable) memory
+  // the task list is pulled in by a kernel on `st`: the launch is issued while the acoustic model still runs (no host wait)
+  void *d_tasks = NULL;
+  if (D->qtasks.Acquire(tasks, static_cast<size_t>(n) * sizeof(kamd_queue_task), &d_tasks, st) != KAMD_OK) return KAMD_ERR_HIP;
+  struct Releaser { kamd::MetaRing &m; hipStream_t s; ~Releaser() { (void)m.Release(s); } } releaser{D->qtasks, st};
   kamd::QueueDev q;
-  q.tasks = D->d_qtasks; q.n_tasks = n; q.head = D->d_qctl; q.done_count = D->d_qctl + 1;
+  q.tasks = static_cast<const kamd_queue_task *>(d_tasks); q.n_tasks = n; q.head = D->d_qctl; q.done_count = D->d_qctl + 1;
   q.pool = D->d_pool; q.pool_cap = D->pool_cap; q.pool_used = D->d_pool_used;
   void *dp = NULL;
   KAMD_HIP(hipHostGetDevicePointer(&dp, D->h_results, 0));

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "common.h"
+#include "meta_ring.h"
 
 namespace kamd {
 
@@ -591,7 +592,7 @@ struct IvExtractor {
   int64_t *d_off = NULL; size_t off_cap = 0;
   double *d_dquad = NULL, *d_dlin = NULL, *d_dtotw = NULL; size_t dq_cap = 0, dl_cap = 0, dt_cap = 0;
   double *d_state_in = NULL, *d_state_out = NULL; size_t si_cap = 0, so_cap = 0;
-  IvUtt *d_utt = NULL; size_t utt_cap = 0;
+  MetaRing utt_ring;              // the utterance records of a call (meta_ring.h: no copy engine, no host wait)
   int *d_wlf = NULL; float *d_wlw = NULL; size_t wlf_cap = 0, wlw_cap = 0;   // weighted list: frames | weight, min_post, log(min_post)
   int64_t last_rows = 0;
 };
@@ -707,7 +708,7 @@ void kamd_ivector_extractor_destroy(kamd_ivector_extractor *h) {
   IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
   if (!e) return;
   e->own.Free();
-  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw, e->d_state_in, e->d_state_out, e->d_utt, e->d_wlf, e->d_wlw};
+  void *ps[] = {e->d_ldaT, e->d_gconsts, e->d_mivT, e->d_ivT, e->d_gsum, e->d_U, e->d_SM, e->d_off, e->d_dquad, e->d_dlin, e->d_dtotw, e->d_state_in, e->d_state_out, e->d_wlf, e->d_wlw};
   for (void *p : ps) if (p) (void)hipFree(p);
   delete e;
 }
@@ -774,16 +775,16 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
   if (kamd::GrowDev(&e->d_dquad, &e->dq_cap, static_cast<size_t>(inc_rows) * v.Q) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&e->d_dlin, &e->dl_cap, static_cast<size_t>(inc_rows) * v.I) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDev(&e->d_dtotw, &e->dt_cap, static_cast<size_t>(inc_rows)) != KAMD_OK) return KAMD_ERR_HIP;
-  if (kamd::GrowDev(&e->d_utt, &e->utt_cap, static_cast<size_t>(n)) != KAMD_OK) return KAMD_ERR_HIP;
-  KAMD_HIP(hipMemcpyAsync(e->d_utt, utts.data(), n * sizeof(kamd::IvUtt), hipMemcpyHostToDevice, st));
-  KAMD_HIP(hipStreamSynchronize(st));          // the descriptors are pageable host memory
+  void *d_utt = NULL;
+  if (e->utt_ring.Acquire(utts.data(), n * sizeof(kamd::IvUtt), &d_utt, st) != KAMD_OK) return KAMD_ERR_HIP;
+  struct Releaser { kamd::MetaRing &m; hipStream_t s; ~Releaser() { (void)m.Release(s); } } releaser{e->utt_ring, st};
   int max_T = 0, max_proc = 0, max_steps = 0, max_post = 0;
   for (const kamd::IvUtt &u : utts) {
     max_T = std::max(max_T, u.T); max_proc = std::max(max_proc, u.proc_end - u.proc_first); max_steps = std::max(max_steps, u.n_steps);
     max_post = std::max(max_post, u.mode == 2 ? u.wl_n : u.proc_end - u.proc_first);
   }
   kamd::IvBatch b;
-  b.feats = d_feats; b.ld = ld_feat; b.utt = e->d_utt;
+  b.feats = d_feats; b.ld = ld_feat; b.utt = static_cast<const kamd::IvUtt *>(d_utt);
   b.S = w->d_S; b.norm_lda = w->d_nl; b.raw_lda = w->d_rl; b.post_g = w->d_pg; b.post_w = w->d_pw; b.out = d_out;
   b.dquad = e->d_dquad; b.dlin = e->d_dlin; b.dtotw = e->d_dtotw;
   b.state_in = d_state_in; b.state_out = d_state_out; b.state_size = state_size; b.x_off = x_off;

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include "meta_ring.h"
 
 namespace kamd {
 
@@ -1256,7 +1257,7 @@ struct Nnet {
   // batch workspace (grown on demand)
   std::vector<float *> act; std::vector<size_t> act_cap;
   std::vector<int *> maps; std::vector<size_t> maps_cap;
-  int64_t *d_meta = NULL; size_t meta_cap = 0;
+  kamd::MetaRing meta;       // per-pass descriptors (row offsets of every layer, item lengths ...): meta_ring.h
   float *d_ivb = NULL; size_t ivb_cap = 0;
   float *d_zero = NULL;      // n_neutral zero floats (GemmArgs::zeros, zeros_n) followed by n_neutral ones (ones_n)
   int n_neutral = 0;
@@ -1436,7 +1437,6 @@ void kamd_nnet_destroy(kamd_nnet *h) {
     if (nn->act[i]) (void)hipFree(nn->act[i]);
     if (nn->maps[i]) (void)hipFree(nn->maps[i]);
   }
-  if (nn->d_meta) (void)hipFree(nn->d_meta);
   if (nn->d_ivb) (void)hipFree(nn->d_ivb);
   if (nn->d_zero) (void)hipFree(nn->d_zero);
   delete nn;
@@ -1523,10 +1523,12 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
       return kamd::SetError(KAMD_ERR_ARG, "h_out_row_off must be the running sum of output frames");
   // the last layer's row offsets are absolute rows of d_out; the map kernel works in layer-local rows: a relative copy
   for (size_t i = 0; i < stride; i++) meta[(nl + 1) * stride + i] = meta[(nl - 1) * stride + i] - h_out_row_off[0];
-  if (kamd::Grow(&nn->d_meta, &nn->meta_cap, meta.size(), st) != KAMD_OK) return KAMD_ERR_HIP;
-  KAMD_HIP(hipMemcpyAsync(nn->d_meta, meta.data(), meta.size() * 8, hipMemcpyHostToDevice, st));
-  KAMD_HIP(hipStreamSynchronize(st));
-  const int *d_T = reinterpret_cast<const int *>(nn->d_meta + (nl + 2) * stride);
+  // (no host wait here: the passes of a test set are issued back to back, meta_ring.h)
+  void *d_meta_v = NULL;
+  if (nn->meta.Acquire(meta.data(), meta.size() * 8, &d_meta_v, st) != KAMD_OK) return KAMD_ERR_HIP;
+  struct Releaser { kamd::MetaRing &m; hipStream_t s; ~Releaser() { (void)m.Release(s); } } releaser{nn->meta, st};
+  const int64_t *const d_meta = static_cast<const int64_t *>(d_meta_v);
+  const int *d_T = reinterpret_cast<const int *>(d_meta + (nl + 2) * stride);
   double flops = 0;
   for (int l = 0; l < nl; l++) {
     LayerDev &L = nn->L[l];
@@ -1544,25 +1546,25 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     int *rowmap = nn->maps[l], *bypmap = rowmap + static_cast<size_t>(L.n_off) * Ml, *row2utt = bypmap + Ml;
     // the last layer's row offsets are absolute rows of d_out; the map kernel works in
     // layer-local rows, so give it offsets relative to row_base.
-    const int64_t *d_row_off = nn->d_meta + l * stride;
+    const int64_t *d_row_off = d_meta + l * stride;
     kamd::MapArgs ma;
     ma.n_utts = n_utts; ma.M = static_cast<int>(Ml);
     ma.T = d_T; ma.lo = L.lo; ma.step = L.step;
     ma.row2utt = L.ivector_dim > 0 ? row2utt : NULL;
     ma.slot_period = 0; ma.slot_base = ma.slot_first = ma.slot_count = ma.abs_t0 = NULL;
-    ma.in_t0 = chunks ? reinterpret_cast<const int *>(nn->d_meta + (nl + 2) * stride + t_words + slot_words) : NULL;
+    ma.in_t0 = chunks ? reinterpret_cast<const int *>(d_meta + (nl + 2) * stride + t_words + slot_words) : NULL;
     if (slots && L.ivector_dim > 0) {
-      const int *d_S = reinterpret_cast<const int *>(nn->d_meta + (nl + 2) * stride + t_words);
+      const int *d_S = reinterpret_cast<const int *>(d_meta + (nl + 2) * stride + t_words);
       ma.slot_period = slots->period;
       ma.slot_base = d_S; ma.slot_first = d_S + n_utts; ma.slot_count = d_S + 2 * n_utts; ma.abs_t0 = d_S + 3 * n_utts;
     }
     auto fill_prod = [&](int prod, kamd::MapArgs *a) {
-      if (prod < 0) { a->prod_row_off = nn->d_meta + nl * stride; a->prod_is_input = 1; a->prod_lo = 0; a->prod_step = 1; }
-      else { a->prod_row_off = nn->d_meta + prod * stride; a->prod_is_input = 0; a->prod_lo = nn->L[prod].lo; a->prod_step = nn->L[prod].step; }
+      if (prod < 0) { a->prod_row_off = d_meta + nl * stride; a->prod_is_input = 1; a->prod_lo = 0; a->prod_step = 1; }
+      else { a->prod_row_off = d_meta + prod * stride; a->prod_is_input = 0; a->prod_lo = nn->L[prod].lo; a->prod_step = nn->L[prod].step; }
     };
     // row offsets for the last layer are absolute; shift handled by a local copy
     const int64_t *layer_row_off = d_row_off;
-    if (l == nl - 1 && row_base != 0) layer_row_off = nn->d_meta + (nl + 1) * stride;     // (filled with the meta upload)
+    if (l == nl - 1 && row_base != 0) layer_row_off = d_meta + (nl + 1) * stride;     // (filled with the meta upload)
     ma.row_off = layer_row_off;
     if (L.concat) {
       // the materialised Append: per slice a row map into its own producer, then the gather-copy into this layer's rows
@@ -1600,7 +1602,7 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
       if (!d_ivectors) return kamd::SetError(KAMD_ERR_ARG, "model needs ivectors");
       const int iv_rows = slots ? slots->table_rows : n_utts;
       if (kamd::Grow(&nn->d_ivb, &nn->ivb_cap, static_cast<size_t>(iv_rows) * L.out_dim, st) != KAMD_OK) return KAMD_ERR_HIP;
-      const int *d_iv_rows = chunks ? reinterpret_cast<const int *>(nn->d_meta + (nl + 2) * stride + t_words + slot_words) + 2 * t_words : NULL;
+      const int *d_iv_rows = chunks ? reinterpret_cast<const int *>(d_meta + (nl + 2) * stride + t_words + slot_words) + 2 * t_words : NULL;
       hipLaunchKernelGGL(kamd::IvecBiasKernel, dim3(iv_rows, kamd::CeilDiv(L.out_dim, 128)), dim3(128), 0, st,
                          L.Wiv, d_ivectors, L.out_dim, L.ivector_dim, nn->d_ivb, d_iv_rows);
       g.ivbias = nn->d_ivb; g.row2utt = row2utt;
