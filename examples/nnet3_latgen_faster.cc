@@ -42,41 +42,6 @@ struct Totals {
   int64_t frame_count = 0;
 };
 
-// "key rxfilename" lines of a wav.scp (a `scp:` rspecifier; the rxfilename may be a pipe)
-struct WaveScp {
-  std::vector<std::pair<std::string, std::string> > entries;
-  explicit WaveScp(const std::string &rspecifier) {
-    char rx[4096], path[4096]; int opts = 0, temp = 0; int64_t off = 0;
-    if (kamd_classify_rspecifier(rspecifier.c_str(), rx, sizeof(rx), &opts) != 2)
-      throw KaldiFatalError("--wav expects an scp: rspecifier of \"key file\" lines, got " + rspecifier);
-    Check(kamd_rx_materialize(rx, path, sizeof(path), &off, &temp));
-    FILE *f = fopen(path, "r");
-    if (!f) throw KaldiFatalError(std::string("cannot open ") + path);
-    char line[8192];
-    while (fgets(line, sizeof(line), f)) {
-      std::string l(line);
-      while (!l.empty() && (l.back() == '\n' || l.back() == '\r' || l.back() == ' ')) l.pop_back();
-      const size_t sp = l.find_first_of(" \t");
-      if (l.empty()) continue;
-      if (sp == std::string::npos) { fclose(f); throw KaldiFatalError("Invalid line in script file: \"" + l + "\""); }
-      entries.push_back(std::make_pair(l.substr(0, sp), l.substr(l.find_first_not_of(" \t", sp))));
-    }
-    fclose(f);
-    if (temp) remove(path);
-  }
-  static void Read(const std::string &rxfilename, float expect_freq, std::vector<float> *samples) {
-    char path[4096]; int temp = 0; int64_t off = 0;
-    Check(kamd_rx_materialize(rxfilename.c_str(), path, sizeof(path), &off, &temp));
-    float sf = 0; int32_t nch = 0; int64_t n = 0; float *p = NULL;
-    const int rc = kamd_wave_read(path, &sf, &nch, &n, &p);
-    if (temp) remove(path);
-    Check(rc);
-    if (sf != expect_freq) { kamd_host_free(p); throw KaldiFatalError(rxfilename + ": sampling rate " + std::to_string(sf) + ", the feature config expects " + std::to_string(expect_freq)); }
-    samples->assign(p, p + n);                             // channel 0
-    kamd_host_free(p);
-  }
-};
-
 std::vector<std::string> ReadSymbolTable(const std::string &filename) {       // fst::SymbolTable::ReadText: "symbol id" lines
   std::vector<std::string> syms;
   FILE *f = fopen(filename.c_str(), "r");
@@ -170,29 +135,10 @@ int main(int argc, char **argv) {
     if (wav && !mfcc_config.empty()) {
       kamd_mfcc_opts_default(&mfcc.c);
       ParseOptions mpo("compute-mfcc-feats options");
-      bool use_energy = mfcc.c.use_energy != 0, raw_energy = mfcc.c.raw_energy != 0, htk_compat = mfcc.c.htk_compat != 0,
-           remove_dc = mfcc.c.frame.remove_dc_offset != 0, snip_edges = mfcc.c.frame.snip_edges != 0;
-      BaseFloat dither = 0.0f;
-      mpo.Register("sample-frequency", &mfcc.c.frame.samp_freq, "Waveform data sample frequency");
-      mpo.Register("frame-length", &mfcc.c.frame.frame_length_ms, "Frame length in milliseconds");
-      mpo.Register("frame-shift", &mfcc.c.frame.frame_shift_ms, "Frame shift in milliseconds");
-      mpo.Register("preemphasis-coefficient", &mfcc.c.frame.preemph_coeff, "Coefficient for use in signal preemphasis");
-      mpo.Register("remove-dc-offset", &remove_dc, "Subtract mean from waveform on each frame");
-      mpo.Register("dither", &dither, "Dithering constant; only 0 is supported");
-      mpo.Register("snip-edges", &snip_edges, "Only output frames that completely fit in the file");
-      mpo.Register("num-mel-bins", &mfcc.c.mel.num_bins, "Number of triangular mel-frequency bins");
-      mpo.Register("low-freq", &mfcc.c.mel.low_freq, "Low cutoff frequency for mel bins");
-      mpo.Register("high-freq", &mfcc.c.mel.high_freq, "High cutoff frequency for mel bins (if <= 0, offset from Nyquist)");
-      mpo.Register("num-ceps", &mfcc.c.num_ceps, "Number of cepstra in MFCC computation (including C0)");
-      mpo.Register("use-energy", &use_energy, "Use energy (not C0) in MFCC computation");
-      mpo.Register("energy-floor", &mfcc.c.energy_floor, "Floor on energy (absolute, not relative) in MFCC computation");
-      mpo.Register("raw-energy", &raw_energy, "If true, compute energy before preemphasis and windowing");
-      mpo.Register("cepstral-lifter", &mfcc.c.cepstral_lifter, "Constant that controls scaling of MFCCs");
-      mpo.Register("htk-compat", &htk_compat, "If true, put energy or C0 last");
+      MfccOptionsParser mp(&mfcc);
+      mp.Register(&mpo);
       mpo.ReadConfigFile(mfcc_config);
-      if (dither != 0.0f) throw KaldiFatalError("--dither: only 0 is supported");
-      mfcc.c.use_energy = use_energy; mfcc.c.raw_energy = raw_energy; mfcc.c.htk_compat = htk_compat;
-      mfcc.c.frame.remove_dc_offset = remove_dc; mfcc.c.frame.snip_edges = snip_edges;
+      mp.Finish();
     }
     const double samp = wav ? mfcc.c.frame.samp_freq : 16000.0, shift = (wav ? mfcc.c.frame.frame_shift_ms : 10.0) * 1e-3;
 

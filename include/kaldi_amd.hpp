@@ -1361,6 +1361,24 @@ class OnlineStreamBatch {
     alignment->assign(ali.begin(), ali.begin() + na); words->assign(wrd.begin(), wrd.begin() + nw);
     return true;
   }
+  /// GetRawLattice of a finalized stream (LatticeFasterDecoder::GetRawLattice, lane `stream` of the shared decoder)
+  bool GetRawLattice(int32 stream, Lattice *ofst) const {
+    kamd_lattice_size sz;
+    Check(kamd_decoder_lattice_size(dec_, stream, &sz));
+    ofst->arcs.assign(sz.num_states, std::vector<LatticeArc>());
+    ofst->final_graph_cost.assign(sz.num_states, 0.f);
+    ofst->state_frame.assign(sz.num_states, 0); ofst->state_hclg.assign(sz.num_states, 0);
+    ofst->start = sz.start;
+    if (sz.num_states == 0) return false;
+    std::vector<float> cost(sz.num_states);
+    std::vector<kamd_lat_arc> arcs(sz.num_arcs);
+    Check(kamd_decoder_get_raw_lattice(dec_, stream, ofst->state_frame.data(), ofst->state_hclg.data(), cost.data(), ofst->final_graph_cost.data(), arcs.data()));
+    for (size_t i = 0; i < arcs.size(); i++) {
+      LatticeArc a = {arcs[i].ilabel, arcs[i].olabel, arcs[i].graph_cost, arcs[i].acoustic_cost, arcs[i].dst};
+      ofst->arcs[arcs[i].src].push_back(a);
+    }
+    return true;
+  }
   /// GetAdaptationState + LimitFrames: what the speaker's next utterance starts from
   void GetAdaptationState(int32 stream, BaseFloat max_remembered_frames, std::vector<double> *state) const {
     state->resize(kamd_ivector_state_size(ie_));
@@ -1413,14 +1431,15 @@ class OnlineIvectorExtractor {
  public:
   // desc: the fields of OnlineIvectorExtractionInfo (lda_mat, global_cmvn_stats, diag_ubm, extractor M_ / Sigma_inv_, options)
   explicit OnlineIvectorExtractor(const kamd_ivector_desc &desc, BaseFloat max_remembered_frames = 1000.0)
-      : h_(kamd_ivector_extractor_create(&desc)), max_remembered_frames_(max_remembered_frames) {
+      : h_(kamd_ivector_extractor_create(&desc)), max_remembered_frames_(max_remembered_frames), splice_right_(desc.splice_right) {
     if (!h_) throw KaldiFatalError(kamd_last_error());
   }
   /// OnlineIvectorExtractionInfo::Init from the files of an extraction config (--ivector-extraction-config of the online2
   /// binaries, --config of ivector-extract-online2; online2/online-ivector-feature.cc:30-74): kamd_ivector_info_read
   explicit OnlineIvectorExtractor(const std::string &config_rxfilename, BaseFloat max_remembered_frames = 1000.0)
-      : h_(NULL), max_remembered_frames_(max_remembered_frames) {
+      : h_(NULL), max_remembered_frames_(max_remembered_frames), splice_right_(0) {
     kamd_ivector_info *info = CheckPtr(kamd_ivector_info_read(config_rxfilename.c_str()));
+    splice_right_ = kamd_ivector_info_desc(info)->splice_right;
     h_ = kamd_ivector_info_create_extractor(info);
     kamd_ivector_info_destroy(info);
     if (!h_) throw KaldiFatalError(kamd_last_error());
@@ -1446,9 +1465,123 @@ class OnlineIvectorExtractor {
     }
   }
   kamd_ivector_extractor *handle() { return h_; }
+  /// right context of the splicing in front of the LDA (OnlineSpliceOptions): what OnlineStreamBatch::SetIvectorExtractor asks for
+  int32 SpliceRight() const { return splice_right_; }
  private:
   kamd_ivector_extractor *h_;
   BaseFloat max_remembered_frames_;
+  int32 splice_right_;
+};
+
+// ---- OnlineSilenceWeightingConfig (online2/online-ivector-feature.h:404-451), registered with the prefix
+// "ivector-silence-weighting" by OnlineNnet2FeaturePipelineConfig (online-nnet2-feature-pipeline.h:89-110)
+struct OnlineSilenceWeightingConfig {
+  std::string silence_phones_str;
+  BaseFloat silence_weight, max_state_duration;
+  OnlineSilenceWeightingConfig() : silence_weight(1.0f), max_state_duration(-1.0f) {}
+  bool Active() const { return !silence_phones_str.empty() && silence_weight != 1.0f; }
+  template <typename Opts> void RegisterWithPrefix(const std::string &prefix, Opts *opts) {
+    opts->Register(prefix + ".silence-phones", &silence_phones_str, "(RE weighting in iVector estimation for online decoding) List of integer ids of "
+                   "silence phones, separated by colons (or commas).  Data that (according to the traceback of the decoder) corresponds to "
+                   "these phones will be downweighted by --silence-weight.");
+    opts->Register(prefix + ".silence-weight", &silence_weight, "(RE weighting in iVector estimation for online decoding) Weighting factor for "
+                   "frames that the decoder trace-back identifies as silence; only relevant if the --silence-phones option is set.");
+    opts->Register(prefix + ".max-state-duration", &max_state_duration, "(RE weighting in iVector estimation for online decoding) Maximum allowed "
+                   "duration of a single transition-id; runs with durations longer than this will be weighted down to the silence-weight.");
+  }
+  /// SplitStringToIntegers(silence_phones_str, ":,", false, ...)
+  std::vector<int32> SilencePhones() const {
+    std::vector<int32> out;
+    std::string tok;
+    for (size_t i = 0; i <= silence_phones_str.size(); i++) {
+      const char ch = i < silence_phones_str.size() ? silence_phones_str[i] : ':';
+      if (ch != ':' && ch != ',') { tok += ch; continue; }
+      if (tok.empty()) continue;
+      char *end = NULL;
+      const long v = strtol(tok.c_str(), &end, 10);
+      if (*end != 0) throw KaldiFatalError("Bad --silence-phones option in silence-weighting config: " + silence_phones_str);
+      out.push_back(static_cast<int32>(v));
+      tok.clear();
+    }
+    return out;
+  }
+};
+
+// ---- compute-mfcc-feats options (MfccOptions::Register, feat/feature-mfcc.h:58-88, with FrameExtractionOptions and
+// MelBanksOptions) for a ParseOptions: Register, read, then Finish() copies the flags into the C struct
+struct MfccOptionsParser {
+  MfccOptions *opts;
+  bool use_energy, raw_energy, htk_compat, remove_dc_offset, snip_edges;
+  BaseFloat dither;
+  explicit MfccOptionsParser(MfccOptions *o)
+      : opts(o), use_energy(o->c.use_energy != 0), raw_energy(o->c.raw_energy != 0), htk_compat(o->c.htk_compat != 0),
+        remove_dc_offset(o->c.frame.remove_dc_offset != 0), snip_edges(o->c.frame.snip_edges != 0), dither(0.0f) {}
+  void Register(ParseOptions *po) {
+    kamd_mfcc_opts &c = opts->c;
+    po->Register("sample-frequency", &c.frame.samp_freq, "Waveform data sample frequency");
+    po->Register("frame-length", &c.frame.frame_length_ms, "Frame length in milliseconds");
+    po->Register("frame-shift", &c.frame.frame_shift_ms, "Frame shift in milliseconds");
+    po->Register("preemphasis-coefficient", &c.frame.preemph_coeff, "Coefficient for use in signal preemphasis");
+    po->Register("remove-dc-offset", &remove_dc_offset, "Subtract mean from waveform on each frame");
+    po->Register("dither", &dither, "Dithering constant; only 0 is supported");
+    po->Register("snip-edges", &snip_edges, "Only output frames that completely fit in the file");
+    po->Register("num-mel-bins", &c.mel.num_bins, "Number of triangular mel-frequency bins");
+    po->Register("low-freq", &c.mel.low_freq, "Low cutoff frequency for mel bins");
+    po->Register("high-freq", &c.mel.high_freq, "High cutoff frequency for mel bins (if <= 0, offset from Nyquist)");
+    po->Register("num-ceps", &c.num_ceps, "Number of cepstra in MFCC computation (including C0)");
+    po->Register("use-energy", &use_energy, "Use energy (not C0) in MFCC computation");
+    po->Register("energy-floor", &c.energy_floor, "Floor on energy (absolute, not relative) in MFCC computation");
+    po->Register("raw-energy", &raw_energy, "If true, compute energy before preemphasis and windowing");
+    po->Register("cepstral-lifter", &c.cepstral_lifter, "Constant that controls scaling of MFCCs");
+    po->Register("htk-compat", &htk_compat, "If true, put energy or C0 last");
+  }
+  void Finish() {
+    if (dither != 0.0f) throw KaldiFatalError("--dither: only 0 is supported");
+    kamd_mfcc_opts &c = opts->c;
+    c.use_energy = use_energy; c.raw_energy = raw_energy; c.htk_compat = htk_compat;
+    c.frame.remove_dc_offset = remove_dc_offset; c.frame.snip_edges = snip_edges;
+  }
+};
+
+// ---- "key rxfilename" lines of a wav.scp (an `scp:` rspecifier; the rxfilename may be an input pipe) and
+// WaveHolder::Read of one entry (feat/wave-reader.h:150-200), channel 0
+struct WaveScp {
+  std::vector<std::pair<std::string, std::string> > entries;
+  explicit WaveScp(const std::string &rspecifier) {
+    char rx[4096], path[4096]; int opts = 0, temp = 0; int64_t off = 0;
+    if (kamd_classify_rspecifier(rspecifier.c_str(), rx, sizeof(rx), &opts) != 2)
+      throw KaldiFatalError("expected an scp: rspecifier of \"key wav-rxfilename\" lines, got " + rspecifier);
+    Check(kamd_rx_materialize(rx, path, sizeof(path), &off, &temp));
+    FILE *f = fopen(path, "r");
+    if (!f) throw KaldiFatalError(std::string("cannot open ") + path);
+    char line[8192];
+    while (fgets(line, sizeof(line), f)) {
+      std::string l(line);
+      while (!l.empty() && (l.back() == '\n' || l.back() == '\r' || l.back() == ' ')) l.pop_back();
+      const size_t sp = l.find_first_of(" \t");
+      if (l.empty()) continue;
+      if (sp == std::string::npos) { fclose(f); throw KaldiFatalError("Invalid line in script file: \"" + l + "\""); }
+      entries.push_back(std::make_pair(l.substr(0, sp), l.substr(l.find_first_not_of(" \t", sp))));
+    }
+    fclose(f);
+    if (temp) remove(path);
+  }
+  /// the rxfilename of `key`, or NULL
+  const std::string *Find(const std::string &key) const {
+    for (size_t i = 0; i < entries.size(); i++) if (entries[i].first == key) return &entries[i].second;
+    return NULL;
+  }
+  static void Read(const std::string &rxfilename, float expect_freq, std::vector<float> *samples) {
+    char path[4096]; int temp = 0; int64_t off = 0;
+    Check(kamd_rx_materialize(rxfilename.c_str(), path, sizeof(path), &off, &temp));
+    float sf = 0; int32_t nch = 0; int64_t n = 0; float *p = NULL;
+    const int rc = kamd_wave_read(path, &sf, &nch, &n, &p);
+    if (temp) remove(path);
+    Check(rc);
+    if (sf != expect_freq) { kamd_host_free(p); throw KaldiFatalError(rxfilename + ": sampling rate " + std::to_string(sf) + ", the feature config expects " + std::to_string(expect_freq)); }
+    samples->assign(p, p + n);                             // channel 0
+    kamd_host_free(p);
+  }
 };
 
 }  // namespace kaldi_amd

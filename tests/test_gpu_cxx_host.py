@@ -300,3 +300,73 @@ def test_nnet3_latgen_faster_example_writes_the_python_tools_archive(tmp_path):
     bad = subprocess.run([exe] + common + [str(tmp_path / "absent.mdl"), fst_, "scp:%s" % (tmp_path / "feats.scp"), "ark:/dev/null"],
                          capture_output=True, text=True)
     assert bad.returncode == 255 and "cannot open" in bad.stderr
+
+
+def test_online2_wav_nnet3_latgen_faster_example_writes_the_python_tools_archive(tmp_path):
+    """examples/online2_wav_nnet3_latgen_faster.cc (BASELINE configs[4] as a C++ host program: online.conf, spk2utt, wav.scp,
+    a model with an i-vector input, the extraction config read by the library) against tools/online2_wav_nnet3_latgen_faster.py
+    on the same files: the CompactLattice archive byte for byte -- plain, with --do-endpointing and with
+    --ivector-silence-weighting.* -- whatever the --batch; a speaker's second utterance starts from the first one's
+    adaptation state in both."""
+    import sys
+    import wave
+    from kaldi_amd import feat, ivector, latbin, nnet
+    from kaldi_amd import io as kio
+    from tests.mdl_writer import write_mdl
+    lib = os.path.join(ROOT, "kaldi_amd", "lib")
+    exe = str(tmp_path / "online2-wav-nnet3-latgen-faster-amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "online2_wav_nnet3_latgen_faster.cc"),
+                           "-o", exe, "-L", lib, "-lkaldi_amd", "-lpthread", "-Wl,-rpath," + lib, "-Wl,-rpath-link,/opt/rocm/lib"])
+    g = synth.make_hclg(num_units=25, vocab=60, n_hist=12, seed=6)
+    m = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, ivector_dim=16, seed=12, output_scale=3.0)
+    write_mdl(tmp_path / "final.mdl", m, num_units=25)
+    kio.write_openfst(tmp_path / "HCLG.fst", g, "const")
+    waves = {"a1": 2.1, "a2": 1.4, "b1": 1.8, "c1": 0.9}
+    waves = {k: np.round(synth.make_wave(d, seed=90 + i)).astype(np.float32) for i, (k, d) in enumerate(waves.items())}
+    op = abi.mfcc_opts_hires()
+    allf = np.concatenate([feat.Mfcc(op).ComputeFeatures(w) for w in waves.values()])
+    info = ivector.make_synthetic(num_gauss=64, ivector_dim=16, seed=9, feat_mean=allf.mean(0), feat_std=allf.std(0), max_count=10.0)
+    iconf = ivector.write_config_dir(tmp_path / "ivector_extractor", info)
+    (tmp_path / "mfcc.conf").write_text("--use-energy=false   # hires\n--num-mel-bins=40\n--num-ceps=40\n--low-freq=20\n--high-freq=-400\n")
+    (tmp_path / "online.conf").write_text("--feature-type=mfcc\n--mfcc-config=%s\n--ivector-extraction-config=%s\n--endpoint.silence-phones=1:2\n" %
+                                          (tmp_path / "mfcc.conf", iconf))
+    with open(tmp_path / "wav.scp", "w") as scp:
+        for k, w in waves.items():
+            if k == "c1":
+                continue                                     # spkC's audio is missing: the reference's warning
+            with wave.open(str(tmp_path / (k + ".wav")), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000); f.writeframes(w.astype("<i2").tobytes())
+            scp.write("%s %s\n" % (k, tmp_path / (k + ".wav")))
+    (tmp_path / "spk2utt").write_text("spkA a1 a2\nspkB b1\nspkC c1\n")
+    common = ["--config=%s" % (tmp_path / "online.conf"), "--beam=15", "--max-active=7000", "--lattice-beam=8", "--acoustic-scale=1.0",
+              "--frame-subsampling-factor=3", "--max-seconds=3", "--chunk-length=0.18"]
+    files = [str(tmp_path / "final.mdl"), str(tmp_path / "HCLG.fst"), "ark:%s" % (tmp_path / "spk2utt"), "scp:%s" % (tmp_path / "wav.scp")]
+    variants = {
+        "plain": [],
+        "endpoint": ["--do-endpointing=true", "--endpoint.silence-phones=" + ":".join(str(p) for p in range(1, 21)),
+                     "--endpoint.rule3.min-trailing-silence=0.06", "--endpoint.rule3.max-relative-cost=inf"],
+        "weighted": ["--ivector-silence-weighting.silence-phones=" + ":".join(str(p) for p in range(1, 26, 2)),
+                     "--ivector-silence-weighting.silence-weight=0.001", "--ivector-silence-weighting.max-state-duration=5"],
+    }
+    got = {}
+    for tag, extra in variants.items():
+        p = subprocess.run([sys.executable, ROOT + "/tools/online2_wav_nnet3_latgen_faster.py"] + common + extra + ["--batch=3"] + files +
+                           ["ark:%s" % (tmp_path / ("py_%s.lat" % tag))], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr[-3000:]
+        want = open(tmp_path / ("py_%s.lat" % tag), "rb").read()
+        for batch in (1, 3):
+            r = subprocess.run([exe] + common + extra + ["--batch=%d" % batch] + files + ["ark:%s" % (tmp_path / ("cxx_%s_%d.lat" % (tag, batch)))],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-3000:]
+            assert open(tmp_path / ("cxx_%s_%d.lat" % (tag, batch)), "rb").read() == want, (tag, batch)
+            for text in (r.stderr, p.stderr):
+                assert "Did not find audio for utterance c1" in text and "Decoded 3 utterances, 1 with errors." in text
+            assert sorted(l for l in r.stderr.splitlines() if "log-like per frame" in l) == sorted(l for l in p.stderr.splitlines() if "log-like per frame" in l)
+        got[tag] = want
+    assert got["plain"] != got["endpoint"] and got["plain"] != got["weighted"]
+    assert [k for k, _ in latbin.read_lattices("ark:%s" % (tmp_path / "cxx_plain_1.lat"))] == ["a1", "a2", "b1"]
+    # the reference's exits: usage without arguments; 255 + a message for a model without the i-vector config
+    assert subprocess.run([exe], capture_output=True).returncode == 1
+    (tmp_path / "plain.conf").write_text("--feature-type=mfcc\n--mfcc-config=%s\n" % (tmp_path / "mfcc.conf"))
+    bad = subprocess.run([exe, "--config=%s" % (tmp_path / "plain.conf")] + files + ["ark:/dev/null"], capture_output=True, text=True)
+    assert bad.returncode == 255 and "ivector" in bad.stderr
