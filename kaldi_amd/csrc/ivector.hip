@@ -292,7 +292,7 @@ __device__ inline double WaveSum(double v) {
 // are the bulk of the traffic (L2 / Infinity-Cache resident: 37 MB for the recipe's extractor) and
 // must not sit on the per-utterance sequential chain.  grid (max steps, utterances).
 __global__ __launch_bounds__(256) void StepStatsKernel(IvDev d, IvBatch b) {
-  extern __shared__ double ss[];               // xf[period][D], pw[cap], then int pg[cap], pt[cap]
+  extern __shared__ double ss[];               // xf[period][D], pw[cap], uw[cap], yk[cap][D], then int pg[cap], pt[cap], ug[cap]
   const int u = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const IvUtt ut = b.utt[u];
   const int64_t r0 = ut.ws_row;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void StepStatsKernel(IvDev d, IvBatch b) {
   else { wl = b.wl_frame + ut.wl_off + i * d.period; nf = max(0, min(ut.wl_n - i * d.period, d.period)); }
   const int cap = d.period * d.ng;
   double *xf = ss, *pw = xf + d.period * D;
-  int *pg = reinterpret_cast<int *>(pw + cap), *pt = pg + cap;
+  int *pg = reinterpret_cast<int *>(pw + 2 * cap + cap * D), *pt = pg + cap;
   __shared__ int s_wcnt[4];
   __shared__ double s_half[IV_MAX_DIM];
   for (int k = tid; k < nf * D; k += 256) {
@@ -335,24 +335,60 @@ __global__ __launch_bounds__(256) void StepStatsKernel(IvDev d, IvBatch b) {
     n_pairs += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
     __syncthreads();
   }
+  // ---- the pairs of one Gaussian merged (neighbouring frames share most of their selected Gaussians: 40 pairs of a
+  // step are ~26 Gaussians on the bench's features): U_g and Sigma_inv_M_g are read once per Gaussian of the step, with
+  // the summed weight and the weight-summed feature vector.  uw[k], ug[k], yk[k][D]: Gaussian k of the step.
+  double *uw = pw + cap, *yk = uw + cap;
+  int *ug = pt + cap;
+  __shared__ int s_nu;
+  int n_u = 0;
+  for (int base = 0; base < n_pairs; base += 256) {
+    const int e = base + tid;
+    bool lead = false;
+    double wsum = 0;
+    if (e < n_pairs) {
+      const int g = pg[e];
+      lead = true;
+      for (int e2 = 0; e2 < e; e2++) if (pg[e2] == g) { lead = false; break; }
+      if (lead) for (int e2 = e; e2 < n_pairs; e2++) if (pg[e2] == g) wsum += pw[e2];
+    }
+    const unsigned long long m = __ballot(lead);
+    if (lane == 0) s_wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = n_u;
+    for (int w2 = 0; w2 < wave; w2++) off += s_wcnt[w2];
+    if (lead) {
+      const int pos = off + __popcll(m & ((1ull << lane) - 1));
+      ug[pos] = pg[e]; uw[pos] = wsum;
+    }
+    n_u += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
+  }
+  for (int k = tid; k < n_u * D; k += 256) {
+    const int u = k / D, a = k - u * D, g = ug[u];
+    double y = 0;
+    for (int e = 0; e < n_pairs; e++) if (pg[e] == g) y += pw[e] * xf[pt[e] * D + a];
+    yk[k] = y;
+  }
+  if (tid == 0) s_nu = n_u;
+  __syncthreads();
+  n_u = s_nu;
   const int64_t row = ut.inc_row + i;
   for (int q = tid; q < Q; q += 256) {
     double acc = 0;
 #pragma unroll 8
-    for (int e = 0; e < n_pairs; e++) acc += pw[e] * d.U[static_cast<size_t>(pg[e]) * Q + q];
+    for (int k = 0; k < n_u; k++) acc += uw[k] * d.U[static_cast<size_t>(ug[k]) * Q + q];
     b.dquad[row * Q + q] = acc;
   }
   {
     const int j = tid & 127, half = tid >> 7;
     double acc = 0;
     if (j < I)
-      for (int e = 0; e < n_pairs; e++) {
-        const double *SM = d.SM + static_cast<size_t>(pg[e]) * D * I;
-        const double *xr = xf + pt[e] * D;
-        double a2 = 0;
+      for (int k = 0; k < n_u; k++) {
+        const double *SM = d.SM + static_cast<size_t>(ug[k]) * D * I;
+        const double *yr = yk + k * D;
 #pragma unroll 8
-        for (int a = half; a < D; a += 2) a2 += SM[static_cast<size_t>(a) * I + j] * xr[a];
-        acc += pw[e] * a2;
+        for (int a = half; a < D; a += 2) acc += SM[static_cast<size_t>(a) * I + j] * yr[a];
       }
     if (half == 1 && j < I) s_half[j] = acc;
     __syncthreads();
@@ -800,7 +836,8 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
   }
   if (max_steps > 0) {
     const int pair_cap = v.period * v.ng;
-    const size_t lds_step = (static_cast<size_t>(v.period) * v.D + pair_cap) * sizeof(double) + static_cast<size_t>(2) * pair_cap * sizeof(int);
+    const size_t lds_step = (static_cast<size_t>(v.period) * v.D + 2 * pair_cap + static_cast<size_t>(pair_cap) * v.D) * sizeof(double) +
+                            static_cast<size_t>(3) * pair_cap * sizeof(int);
     hipLaunchKernelGGL(kamd::StepStatsKernel, dim3(max_steps, n), dim3(256), lds_step, st, v, b);
     const size_t lds_solve = (static_cast<size_t>(v.Q) + 6 * kamd::IV_MAX_DIM) * sizeof(double);
     hipLaunchKernelGGL(kamd::SolveKernel, dim3(n), dim3(256), lds_solve, st, v, b);
