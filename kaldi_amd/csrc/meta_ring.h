@@ -26,6 +26,10 @@ class MetaRing {
   // Copies `bytes` (rounded up to 8) from `src` to a device buffer, on stream `st`; kernels launched on `st` after this
   // call see the data at *d.  Returns a KAMD status.  Every Acquire is followed by one Release.
   int Acquire(const void *src, size_t bytes, void **d, hipStream_t st);
+  // The same in two steps, for descriptors that hold pointers INTO the device buffer: Reserve hands out the slot's host
+  // buffer (*h, to be filled by the caller) and the device address the bytes will have (*d); Commit sends them.
+  int Reserve(size_t bytes, void **h, void **d);
+  int Commit(hipStream_t st);
   // The kernels issued on `st` so far are the slot's last readers.
   int Release(hipStream_t st);
 
@@ -38,6 +42,8 @@ class MetaRing {
   bool busy_[kSlots] = {false, false, false, false};
   unsigned next_ = 0;
   int cur_ = -1;
+  size_t cur_words_ = 0;
+  bool committed_ = false;
 };
 
 }  // namespace kamd

@@ -24,8 +24,8 @@ MetaRing::~MetaRing() {
   }
 }
 
-int MetaRing::Acquire(const void *src, size_t bytes, void **d, hipStream_t st) {
-  if (cur_ >= 0) return SetError(KAMD_ERR_STATE, "MetaRing: Acquire without Release");
+int MetaRing::Reserve(size_t bytes, void **h, void **d) {
+  if (cur_ >= 0) return SetError(KAMD_ERR_STATE, "MetaRing: Reserve without Release");
   const int r = static_cast<int>(next_++ % kSlots);
   const size_t words = std::max<size_t>(1, (bytes + 7) / 8);
   if (words > cap_) {
@@ -49,19 +49,34 @@ int MetaRing::Acquire(const void *src, size_t bytes, void **d, hipStream_t st) {
   }
   if (busy_[r]) { KAMD_HIP(hipEventSynchronize(ev_[r])); busy_[r] = false; }      // the launch that used this slot has run
   static_cast<uint64_t *>(h_[r])[words - 1] = 0;
-  memcpy(h_[r], src, bytes);
-  hipLaunchKernelGGL(MetaPullKernel, dim3(std::min(256, CeilDiv(static_cast<int64_t>(words), 256))), dim3(256), 0, st,
-                     static_cast<uint64_t *>(d_[r]), static_cast<const uint64_t *>(h_dev_[r]), words);
-  KAMD_HIP(hipGetLastError());
-  cur_ = r;
-  *d = d_[r];
+  cur_ = r; cur_words_ = words; committed_ = false;
+  *h = h_[r]; *d = d_[r];
   return KAMD_OK;
+}
+
+int MetaRing::Commit(hipStream_t st) {
+  if (cur_ < 0 || committed_) return SetError(KAMD_ERR_STATE, "MetaRing: Commit without Reserve");
+  const int r = cur_;
+  hipLaunchKernelGGL(MetaPullKernel, dim3(std::min(256, CeilDiv(static_cast<int64_t>(cur_words_), 256))), dim3(256), 0, st,
+                     static_cast<uint64_t *>(d_[r]), static_cast<const uint64_t *>(h_dev_[r]), cur_words_);
+  KAMD_HIP(hipGetLastError());
+  committed_ = true;
+  return KAMD_OK;
+}
+
+int MetaRing::Acquire(const void *src, size_t bytes, void **d, hipStream_t st) {
+  void *h = NULL;
+  const int rc = Reserve(bytes, &h, d);
+  if (rc != KAMD_OK) return rc;
+  memcpy(h, src, bytes);
+  return Commit(st);
 }
 
 int MetaRing::Release(hipStream_t st) {
   if (cur_ < 0) return KAMD_OK;
   const int r = cur_;
   cur_ = -1;
+  if (!committed_) return KAMD_OK;            // reserved, never sent: nothing on the device reads the slot
   KAMD_HIP(hipEventRecord(ev_[r], st));
   busy_[r] = true;
   return KAMD_OK;

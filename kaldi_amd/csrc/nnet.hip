@@ -1180,8 +1180,7 @@ struct MapArgs {
   // in_t0[u] of the utterance whose rows start at prod_row_off[u] and whose T[u] frames bound the clamp.  NULL: 0.
   const int *in_t0;
 };
-__global__ void RowMapKernel(MapArgs a) {
-  int r = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ inline void RowMapRow(const MapArgs &a, int r) {
   if (r >= a.M) return;
   int lo = 0, hi = a.n_utts;
   while (hi - lo > 1) {
@@ -1210,6 +1209,19 @@ __global__ void RowMapKernel(MapArgs a) {
     }
     a.rowmap[static_cast<size_t>(i) * a.M + r] = static_cast<int>(src);
   }
+}
+// Every row map of a pass in ONE launch (the maps depend on the pass's descriptors only, not on activations): map k owns
+// the blocks [block_start[k], block_start[k + 1]).  89 GEMMs of a pass used to come with 144 map launches, which is what a
+// streaming tick of a few hundred rows spends its time on.
+__global__ __launch_bounds__(256) void RowMapAllKernel(const MapArgs *maps, const int *block_start, int n_maps) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = n_maps;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (block_start[mid] <= b) lo = mid; else hi = mid;
+  }
+  const MapArgs a = maps[lo];
+  RowMapRow(a, (b - block_start[lo]) * 256 + static_cast<int>(threadIdx.x));
 }
 
 // one slice of a concat layer: dst[r][0 .. dim) = src[map[r]][0 .. dim)
@@ -1523,34 +1535,49 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
       return kamd::SetError(KAMD_ERR_ARG, "h_out_row_off must be the running sum of output frames");
   // the last layer's row offsets are absolute rows of d_out; the map kernel works in layer-local rows: a relative copy
   for (size_t i = 0; i < stride; i++) meta[(nl + 1) * stride + i] = meta[(nl - 1) * stride + i] - h_out_row_off[0];
-  // (no host wait here: the passes of a test set are issued back to back, meta_ring.h)
-  void *d_meta_v = NULL;
-  if (nn->meta.Acquire(meta.data(), meta.size() * 8, &d_meta_v, st) != KAMD_OK) return KAMD_ERR_HIP;
-  struct Releaser { kamd::MetaRing &m; hipStream_t s; ~Releaser() { (void)m.Release(s); } } releaser{nn->meta, st};
-  const int64_t *const d_meta = static_cast<const int64_t *>(d_meta_v);
-  const int *d_T = reinterpret_cast<const int *>(d_meta + (nl + 2) * stride);
-  double flops = 0;
+  // ---- workspaces of every layer
+  struct LayerBufs { float *C; int ldC; int64_t row_base; int *rowmap, *bypmap, *row2utt; };
+  std::vector<LayerBufs> bufs(nl);
+  int n_maps = 0;
   for (int l = 0; l < nl; l++) {
     LayerDev &L = nn->L[l];
-    const int64_t Ml = M[l];
-    // workspace
-    float *C; int ldC;
-    int64_t row_base = 0;
-    if (l == nl - 1) { C = d_out; ldC = ld_out; row_base = h_out_row_off[0]; }
+    LayerBufs &B = bufs[l];
+    B.row_base = 0;
+    if (l == nl - 1) { B.C = d_out; B.ldC = ld_out; B.row_base = h_out_row_off[0]; }
     else {
-      if (kamd::Grow(&nn->act[l], &nn->act_cap[l], static_cast<size_t>(Ml) * L.out_pad, st) != KAMD_OK) return KAMD_ERR_HIP;
-      C = nn->act[l]; ldC = L.out_pad;
+      if (kamd::Grow(&nn->act[l], &nn->act_cap[l], static_cast<size_t>(M[l]) * L.out_pad, st) != KAMD_OK) return KAMD_ERR_HIP;
+      B.C = nn->act[l]; B.ldC = L.out_pad;
     }
-    const size_t map_ints = static_cast<size_t>(L.n_off + 2) * Ml;
-    if (kamd::Grow(&nn->maps[l], &nn->maps_cap[l], map_ints, st) != KAMD_OK) return KAMD_ERR_HIP;
-    int *rowmap = nn->maps[l], *bypmap = rowmap + static_cast<size_t>(L.n_off) * Ml, *row2utt = bypmap + Ml;
-    // the last layer's row offsets are absolute rows of d_out; the map kernel works in
-    // layer-local rows, so give it offsets relative to row_base.
-    const int64_t *d_row_off = d_meta + l * stride;
+    if (kamd::Grow(&nn->maps[l], &nn->maps_cap[l], static_cast<size_t>(L.n_off + 2) * M[l], st) != KAMD_OK) return KAMD_ERR_HIP;
+    B.rowmap = nn->maps[l]; B.bypmap = B.rowmap + static_cast<size_t>(L.n_off) * M[l]; B.row2utt = B.bypmap + M[l];
+    n_maps += L.concat ? L.n_off : 1 + (L.bypass_layer != -2 ? 1 : 0);
+  }
+  // ---- the descriptors go to the device behind this stream's work, with no host wait (meta_ring.h): the int64 words
+  // above, then one MapArgs per row map (they point into the same buffer), then the maps' first blocks
+  const size_t maps_at = meta.size() * 8, starts_at = maps_at + static_cast<size_t>(n_maps) * sizeof(kamd::MapArgs);
+  void *h_meta_v = NULL, *d_meta_v = NULL;
+  if (nn->meta.Reserve(starts_at + static_cast<size_t>(n_maps + 1) * sizeof(int), &h_meta_v, &d_meta_v) != KAMD_OK) return KAMD_ERR_HIP;
+  struct Releaser { kamd::MetaRing &m; hipStream_t s; ~Releaser() { (void)m.Release(s); } } releaser{nn->meta, st};
+  memcpy(h_meta_v, meta.data(), maps_at);
+  kamd::MapArgs *h_maps = reinterpret_cast<kamd::MapArgs *>(static_cast<char *>(h_meta_v) + maps_at);
+  int *h_starts = reinterpret_cast<int *>(static_cast<char *>(h_meta_v) + starts_at);
+  const int64_t *const d_meta = static_cast<const int64_t *>(d_meta_v);
+  const int *d_T = reinterpret_cast<const int *>(d_meta + (nl + 2) * stride);
+  int km = 0;
+  int64_t map_blocks = 0;
+  auto add_map = [&](const kamd::MapArgs &a) {
+    h_maps[km] = a; h_starts[km] = static_cast<int>(map_blocks); km++;
+    map_blocks += kamd::CeilDiv(a.M, 256);
+  };
+  for (int l = 0; l < nl; l++) {
+    LayerDev &L = nn->L[l];
+    const LayerBufs &B = bufs[l];
+    const int64_t Ml = M[l];
     kamd::MapArgs ma;
+    memset(&ma, 0, sizeof(ma));
     ma.n_utts = n_utts; ma.M = static_cast<int>(Ml);
     ma.T = d_T; ma.lo = L.lo; ma.step = L.step;
-    ma.row2utt = L.ivector_dim > 0 ? row2utt : NULL;
+    ma.row2utt = L.ivector_dim > 0 ? B.row2utt : NULL;
     ma.slot_period = 0; ma.slot_base = ma.slot_first = ma.slot_count = ma.abs_t0 = NULL;
     ma.in_t0 = chunks ? reinterpret_cast<const int *>(d_meta + (nl + 2) * stride + t_words + slot_words) : NULL;
     if (slots && L.ivector_dim > 0) {
@@ -1562,17 +1589,47 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
       if (prod < 0) { a->prod_row_off = d_meta + nl * stride; a->prod_is_input = 1; a->prod_lo = 0; a->prod_step = 1; }
       else { a->prod_row_off = d_meta + prod * stride; a->prod_is_input = 0; a->prod_lo = nn->L[prod].lo; a->prod_step = nn->L[prod].step; }
     };
-    // row offsets for the last layer are absolute; shift handled by a local copy
-    const int64_t *layer_row_off = d_row_off;
-    if (l == nl - 1 && row_base != 0) layer_row_off = d_meta + (nl + 1) * stride;     // (filled with the meta upload)
-    ma.row_off = layer_row_off;
+    // the last layer's row offsets are absolute rows of d_out; the map kernel works in layer-local rows: the relative copy
+    ma.row_off = (l == nl - 1 && B.row_base != 0) ? d_meta + (nl + 1) * stride : d_meta + l * stride;
     if (L.concat) {
-      // the materialised Append: per slice a row map into its own producer, then the gather-copy into this layer's rows
+      // the materialised Append: per slice a row map into its own producer (the gather-copy follows in the layer loop)
       for (int o = 0; o < L.n_off; o++) {
         kamd::MapArgs ms = ma;
         fill_prod(L.sl_layer[o], &ms);
-        ms.n_off = 1; ms.offs[0] = L.offs[o]; ms.rowmap = rowmap + static_cast<size_t>(o) * Ml; ms.row2utt = NULL;
-        hipLaunchKernelGGL(kamd::RowMapKernel, dim3(kamd::CeilDiv(Ml, 256)), dim3(256), 0, st, ms);
+        ms.n_off = 1; ms.offs[0] = L.offs[o]; ms.rowmap = B.rowmap + static_cast<size_t>(o) * Ml; ms.row2utt = NULL;
+        add_map(ms);
+      }
+      continue;
+    }
+    fill_prod(L.input_layer, &ma);
+    ma.n_off = L.n_off;
+    for (int o = 0; o < L.n_off; o++) ma.offs[o] = L.offs[o];
+    ma.rowmap = B.rowmap;
+    add_map(ma);
+    if (L.bypass_layer != -2) {
+      kamd::MapArgs mb = ma;
+      fill_prod(L.bypass_layer, &mb);
+      mb.n_off = 1; mb.offs[0] = 0; mb.rowmap = B.bypmap; mb.row2utt = NULL;
+      add_map(mb);
+    }
+  }
+  h_starts[km] = static_cast<int>(map_blocks);
+  if (km != n_maps || map_blocks > 2000000000LL) return kamd::SetError(KAMD_ERR_STATE, "row map plan");
+  if (nn->meta.Commit(st) != KAMD_OK) return KAMD_ERR_HIP;
+  if (map_blocks > 0)
+    hipLaunchKernelGGL(kamd::RowMapAllKernel, dim3(static_cast<unsigned>(map_blocks)), dim3(256), 0, st,
+                       reinterpret_cast<const kamd::MapArgs *>(static_cast<const char *>(d_meta_v) + maps_at),
+                       reinterpret_cast<const int *>(static_cast<const char *>(d_meta_v) + starts_at), n_maps);
+  KAMD_HIP(hipGetLastError());
+  double flops = 0;
+  for (int l = 0; l < nl; l++) {
+    LayerDev &L = nn->L[l];
+    const int64_t Ml = M[l];
+    float *const C = bufs[l].C; const int ldC = bufs[l].ldC;
+    const int64_t row_base = bufs[l].row_base;
+    int *const rowmap = bufs[l].rowmap, *const bypmap = bufs[l].bypmap, *const row2utt = bufs[l].row2utt;
+    if (L.concat) {
+      for (int o = 0; o < L.n_off; o++) {
         const float *src = L.sl_layer[o] < 0 ? d_feats : nn->act[L.sl_layer[o]];
         const int ld_src = L.sl_layer[o] < 0 ? ld_in : nn->L[L.sl_layer[o]].out_pad;
         hipLaunchKernelGGL(kamd::CopySliceKernel, dim3(kamd::CeilDiv(Ml, 4)), dim3(256), 0, st, src, ld_src, rowmap + static_cast<size_t>(o) * Ml,
@@ -1580,17 +1637,6 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
       }
       KAMD_HIP(hipGetLastError());
       continue;
-    }
-    fill_prod(L.input_layer, &ma);
-    ma.n_off = L.n_off;
-    for (int o = 0; o < L.n_off; o++) ma.offs[o] = L.offs[o];
-    ma.rowmap = rowmap;
-    hipLaunchKernelGGL(kamd::RowMapKernel, dim3(kamd::CeilDiv(Ml, 256)), dim3(256), 0, st, ma);
-    if (L.bypass_layer != -2) {
-      kamd::MapArgs mb = ma;
-      fill_prod(L.bypass_layer, &mb);
-      mb.n_off = 1; mb.offs[0] = 0; mb.rowmap = bypmap; mb.row2utt = NULL;
-      hipLaunchKernelGGL(kamd::RowMapKernel, dim3(kamd::CeilDiv(Ml, 256)), dim3(256), 0, st, mb);
     }
     kamd::GemmArgs g;
     memset(&g, 0, sizeof(g));
