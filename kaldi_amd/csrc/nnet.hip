@@ -336,6 +336,18 @@ __global__ __launch_bounds__(256, 4) void TdnnGemmKernel(GemmArgs p) {
 // row is requested twice, half a line at a time, and a workgroup stalls ~570 cycles per DMA instruction in the issue:
 // gemm_lab's per-k-block segments); 8 rows per DMA instruction, 8 sixteen-byte chunks per row, chunk p of row m holds
 // k-chunk p ^ ((m >> 1) & 7) (two rows per 256-byte bank row: conflict free for ds_read_b128 as before).
+// s_waitcnt vmcnt(ahead * LOADS): all but the newest `ahead` k-blocks of this wave's DMAs have landed (ahead <= MAXA)
+template <int LOADS, int MAXA>
+__device__ inline void WaitAhead(int ahead) {
+  static_assert(MAXA * LOADS <= 63, "vmcnt is a 6-bit counter");
+  if constexpr (MAXA > 0) {
+    if (ahead >= MAXA) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MAXA * LOADS) : "memory"); return; }
+    WaitAhead<LOADS, MAXA - 1>(ahead);
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int NST, int EPI = 2, int BK = 16, int OCC = 3>       // EPI 1: EpilogueTile (round 2), 2: EpilogueWave, 3: EpilogueWave + per-utterance i-vector bias
 __global__ __launch_bounds__(256, OCC) void TdnnGemmDmaKernel(GemmArgs p) {
   static_assert(BK == 16 || BK == 32, "k-block depth");
@@ -438,9 +450,7 @@ __global__ __launch_bounds__(256, OCC) void TdnnGemmDmaKernel(GemmArgs p) {
 #ifdef KAMD_GEMM_LAB
     if (p.lab_prio) __builtin_amdgcn_s_setprio(3);
 #endif
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WaitAhead<LOADS, DIST - 1>(ahead);
     KAMD_LAB_SEG(0);
     __builtin_amdgcn_s_barrier();
     KAMD_LAB_SEG(1);
@@ -1700,6 +1710,13 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     }
     if (gen4 && !gen1) {
       // launched above
+    } else if (!gen1 && gen_max >= 4 && epi == 2 && nt32 <= 5 && kamd::CeilDiv(Ml, 128) <= 96) {
+      // A narrow layer over few rows (a streaming tick: 24 rows per stream): one 128 x N workgroup per row tile walks the
+      // whole k range alone and its time is k-blocks x DMA latency / blocks in flight (85 us for K = 1536 with a ring of
+      // three, twelve such layers a tick).  Here: 128 x 32 tiles, so that the N / 32 column tiles run on CUs of their
+      // own, and a ring of six stages (10 KB each), five k-blocks in flight.  Same k order, same sums.
+      dim3 grid(nt32, kamd::CeilDiv(Ml, 128));
+      hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 32, 4, 1, 6, 2>), grid, dim3(256), 0, st, g);
     } else if (persist && !gen1) {
       g.gy = static_cast<int>(kamd::CeilDiv(Ml, 128)); g.gx = 1;
       const int wgs = std::max(8, std::min(kamd::RoundUp(g.gy, 8), 2 * n_cus) & ~7);
