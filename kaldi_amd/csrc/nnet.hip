@@ -1710,11 +1710,12 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     }
     if (gen4 && !gen1) {
       // launched above
-    } else if (!gen1 && gen_max >= 4 && epi == 2 && nt32 <= 5 && kamd::CeilDiv(Ml, 128) <= 96) {
+    } else if (!gen1 && gen_max >= 4 && epi == 2 && nt32 <= 5 && static_cast<int64_t>(kamd::CeilDiv(Ml, 128)) * nt32 <= 2 * n_cus) {
       // A narrow layer over few rows (a streaming tick: 24 rows per stream): one 128 x N workgroup per row tile walks the
       // whole k range alone and its time is k-blocks x DMA latency / blocks in flight (85 us for K = 1536 with a ring of
-      // three, twelve such layers a tick).  Here: 128 x 32 tiles, so that the N / 32 column tiles run on CUs of their
-      // own, and a ring of six stages (10 KB each), five k-blocks in flight.  Same k order, same sums.
+      // three, twelve such layers a tick).  Here, while all tiles fit on the chip at once (two workgroups per CU): 128 x 32
+      // tiles, so that the N / 32 column tiles run on CUs of their own, and a ring of six stages (10 KB each), five
+      // k-blocks in flight.  Same k order, same sums.
       dim3 grid(nt32, kamd::CeilDiv(Ml, 128));
       hipLaunchKernelGGL((kamd::TdnnGemmDmaKernel<128, 32, 4, 1, 6, 2>), grid, dim3(256), 0, st, g);
     } else if (persist && !gen1) {
