@@ -1692,6 +1692,7 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
                    (g.post_offset ? kamd::EF_PO : 0) | (g.post_scale != 1.0f ? kamd::EF_SCALE : 0);
     bool gen4 = gen_max >= 4 && epi == 2 && nt32 > 5 && L.n_off * (L.in_pad / 16) >= 2;
     static const int n_cus = kamd_device_num_cus();
+    static const bool no_lat = getenv("KAMD_GEMM_NO_LAT") != NULL;      // A/B: without the latency tiles of narrow layers over few rows
     if (!gen1 && gen4) {
       g.gx = kamd::CeilDiv(L.out_dim, 128); g.gy = static_cast<int>(kamd::CeilDiv(Ml, 128));
       dim3 grid(static_cast<unsigned>(g.gx) * static_cast<unsigned>(kamd::RoundUp(g.gy, 8)));
@@ -1710,7 +1711,7 @@ static int ForwardItems(kamd_nnet *h, const float *d_feats, const int64_t *h_in_
     }
     if (gen4 && !gen1) {
       // launched above
-    } else if (!gen1 && gen_max >= 4 && epi == 2 && nt32 <= 5 && static_cast<int64_t>(kamd::CeilDiv(Ml, 128)) * nt32 <= 2 * n_cus) {
+    } else if (!gen1 && gen_max >= 4 && !no_lat && epi == 2 && nt32 <= 5 && static_cast<int64_t>(kamd::CeilDiv(Ml, 128)) * nt32 <= 2 * n_cus) {
       // A narrow layer over few rows (a streaming tick: 24 rows per stream): one 128 x N workgroup per row tile walks the
       // whole k range alone and its time is k-blocks x DMA latency / blocks in flight (85 us for K = 1536 with a ring of
       // three, twelve such layers a tick).  Here, while all tiles fit on the chip at once (two workgroups per CU): 128 x 32
