@@ -484,7 +484,7 @@ def main():
                   keep_raw_lattices=False, nnet_pass_frames=args.nnet_pass_frames, hash_capacity=args.hash_capacity or None,
                   tokens_per_frame=args.tokens_per_frame or None, search_mode=args.search_mode,
                   lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), first_pass_frames=args.first_pass_frames,
-                  long_lanes=16 if world >= 8 else 0)    # small shards: see kamd_batch_decoder_set_long_decoder
+                  long_lanes=32 if world >= 4 else 0)    # small shards: see kamd_batch_decoder_set_long_decoder
         kw.update(over)
         m, ie = kw.pop("model", model), kw.pop("extractor", extractor)
         b = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), m, graph_dev, cfg, **kw)

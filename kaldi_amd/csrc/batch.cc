@@ -102,6 +102,8 @@ struct BatchDecoder {
   std::vector<int64_t> ll_row;          // first row of utterance k's log-likelihoods in d_ll (== out_off unless split)
   std::vector<int> map_long, map_rest;  // queue-local utterance number -> position in `kept`
   bool last_split = false;
+  std::vector<int64_t> load_row;        // load_host: utterance k's first row in a matrix whose rows follow the LOAD order (kamd_batch_decoder_set_loglike_override)
+  int host_split = 0;                   // load_host put this many of the longest utterances first (pass 0): they go to dec_long
   std::vector<UttOut> out;
   // host-tail pool
   std::vector<std::thread> workers;
@@ -196,6 +198,18 @@ static void WorkerLoop(BatchDecoder *b, int idx) {
 
 }  // namespace kamd
 using kamd::BatchDecoder;
+
+// Do the longest utterances go to the second decoder object?  Only when the longest utterance's chain of frames, at the
+// per-frame cost of a lane on an otherwise idle device (~0.63 of a loaded lane's: 79 against 125 us at the matched load),
+// is about as long as the balanced share of the whole shard or longer.  Measured on the 2620-utterance set: a shard of 8
+// goes 132.8 -> 109 ms (32 lanes), a shard of 4 182.3 -> 174.0 ms, a shard of 2 loses (308 -> 333 ms: the model beside
+// the long lanes runs 1.2x slower and there is no chain to hide).  KAMD_BATCH_SPLIT=0/1 overrides.
+static bool WantSplit(const BatchDecoder *b, int n, int64_t longest_out, int64_t total_out) {
+  if (!b->dec_long || b->long_lanes <= 0) return false;
+  if (const char *e = getenv("KAMD_BATCH_SPLIT")) return n > b->long_lanes && atoi(e) != 0;
+  const int lanes_main = b->opts.resident_lanes > 0 ? b->opts.resident_lanes : kamd_device_num_cus() * kamd_decoder_lanes_per_cu();
+  return n >= 4 * b->long_lanes && 0.7 * static_cast<double>(longest_out) > static_cast<double>(total_out) / std::max(lanes_main, 1);
+}
 
 extern "C" {
 
@@ -394,11 +408,44 @@ int kamd_batch_decoder_load_host(kamd_batch_decoder *h, const float *waves, cons
   kamd::Unregister(b);
   b->kept.clear(); b->skipped.clear(); b->h_wave_src.clear();
   b->wave_off.assign(1, 0); b->feat_off.assign(1, 0); b->out_off.assign(1, 0);
+  b->host_split = 0;
+  std::vector<int> order;                      // the utterances that have frames, in the order they are stored and scored
+  std::vector<int> frames_of(n_utts, 0);
+  int64_t longest_out = 0, total_out = 0;
   for (int u = 0; u < n_utts; u++) {
     const int64_t len = h_wave_off[u + 1] - h_wave_off[u];
     if (len < 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d: negative length", u);
     const int T = len > 0 ? kamd_feat_num_frames(b->feat, len) : 0;
     if (T <= 0) { b->skipped.push_back(u); continue; }
+    frames_of[u] = T;
+    order.push_back(u);
+    const int64_t no = kamd_nnet_num_output_frames(b->nnet, T);
+    longest_out = std::max(longest_out, no); total_out += no;
+  }
+  // kamd_batch_decoder_set_long_decoder: the longest utterances first, as a pass of their own -- their search starts on
+  // the second decoder object as soon as that pass is scored, beside the model of the others (RunImpl)
+  if (!b->iv_extractor && kamd_nnet_ivector_dim(b->nnet) == 0 && WantSplit(b, static_cast<int>(order.size()), longest_out, total_out)) {
+    std::vector<int> by_len(order);
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int c) { return frames_of[a] > frames_of[c]; });
+    by_len.resize(b->long_lanes);
+    std::vector<char> is_long(n_utts, 0);
+    for (int u : by_len) is_long[u] = 1;
+    std::vector<int> rest;
+    for (int u : order) if (!is_long[u]) rest.push_back(u);
+    order = by_len;
+    order.insert(order.end(), rest.begin(), rest.end());
+    b->host_split = b->long_lanes;
+  }
+  {
+    std::vector<int64_t> row_of_utt(n_utts, 0);
+    int64_t row = 0;
+    for (int u = 0; u < n_utts; u++) { row_of_utt[u] = row; if (frames_of[u] > 0) row += kamd_nnet_num_output_frames(b->nnet, frames_of[u]); }
+    b->load_row.clear();
+    for (int u : order) b->load_row.push_back(row_of_utt[u]);
+  }
+  for (int u : order) {
+    const int64_t len = h_wave_off[u + 1] - h_wave_off[u];
+    const int T = frames_of[u];
     b->kept.push_back(u);
     b->h_wave_src.push_back(h_wave_off[u]);
     b->wave_off.push_back(b->wave_off.back() + len);
@@ -412,7 +459,8 @@ int kamd_batch_decoder_load_host(kamd_batch_decoder *h, const float *waves, cons
   if (kamd::SizeOnlineIvectors(b) != KAMD_OK) return KAMD_ERR_HIP;
   // passes: a small first one, so that the acoustic model starts behind a short upload
   b->pass_u0.assign(1, 0);
-  for (int u0 = 0; u0 < n;) {
+  if (b->host_split > 0) b->pass_u0.push_back(b->host_split);        // (the long utterances ARE the small first pass)
+  for (int u0 = b->pass_u0.back(); u0 < n;) {
     const int64_t cap = (b->pass_u0.size() == 1 && b->opts.first_pass_frames > 0) ? b->opts.first_pass_frames : b->opts.nnet_pass_frames;
     int u1 = u0 + 1;
     while (u1 < n && b->feat_off[u1 + 1] - b->feat_off[u0] <= cap) u1++;
@@ -474,7 +522,15 @@ int64_t kamd_batch_decoder_output_frames(kamd_batch_decoder *h, int32_t *frames,
 int kamd_batch_decoder_set_long_decoder(kamd_batch_decoder *h, kamd_decoder *dec_long, int lanes) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
   if (!dec_long || lanes <= 0) { b->dec_long = NULL; b->long_lanes = 0; return KAMD_OK; }
-  if (!b->s_long) KAMD_HIP(hipStreamCreateWithFlags(&b->s_long, hipStreamNonBlocking));
+  if (!b->s_long) {
+    // a stream of the highest priority: HIP shares a few hardware queues between the streams of one priority, and two
+    // streams on one queue run their kernels in submission order -- seen in a rocprofv3 trace: the model's GEMMs started
+    // only when the long utterances' search, issued before them on "another" stream, had ended.  Priorities have queues
+    // of their own.  (And the chain of the longest utterance IS the critical path of a small shard.)
+    int least = 0, greatest = 0;
+    KAMD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    KAMD_HIP(hipStreamCreateWithPriority(&b->s_long, hipStreamNonBlocking, greatest));
+  }
   if (!b->ev_long) KAMD_HIP(hipEventCreateWithFlags(&b->ev_long, hipEventDisableTiming));
   if (b->opts.lattice_pool_bytes > 0 && kamd_decoder_queue_configure(dec_long, std::max<int64_t>(b->opts.lattice_pool_bytes / 8, 1 << 24)) != KAMD_OK)
     return KAMD_ERR_HIP;
@@ -483,6 +539,7 @@ int kamd_batch_decoder_set_long_decoder(kamd_batch_decoder *h, kamd_decoder *dec
 }
 
 static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats);
+
 
 // Every error exit of a run leaves through here: jobs may be queued to the host-tail pool and a work-queue kernel may
 // still be running; nothing of this object may be reused (load(), run()) before both have ended.
@@ -608,20 +665,17 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
   double flops = 0;
   int passes = 0;
   b->ll_row.assign(b->out_off.begin(), b->out_off.end() - 1);
-  // split?  Only when the longest utterance's chain of frames (at the per-frame cost of a nearly idle device, ~0.55 of
-  // the loaded one) outlasts the balanced share of the whole shard by half (measured: a rank of 8 gains 4 %, a rank of 4,
-  // where the two are equal, loses 3 %: the GEMMs beside the long lanes run 1.25x slower)
   int64_t longest = 0;
   for (int k = 0; k < n; k++) longest = std::max(longest, b->out_off[k + 1] - b->out_off[k]);
-  int lanes_main = b->opts.resident_lanes > 0 ? b->opts.resident_lanes : kamd_device_num_cus() * kamd_decoder_lanes_per_cu();
-  bool split = b->dec_long && b->long_lanes > 0 && !b->have_iv && n >= 4 * b->long_lanes &&
-               0.55 * static_cast<double>(longest) > 1.5 * static_cast<double>(b->out_off.back()) / std::max(lanes_main, 1);
-  if (const char *e = getenv("KAMD_BATCH_SPLIT")) split = b->dec_long && b->long_lanes > 0 && !b->have_iv && n > b->long_lanes && atoi(e) != 0;
-  if (host_mode || b->d_ll_override) split = false;       // (the passes follow the upload; a planted matrix is in load order)
+  bool split = !b->have_iv && WantSplit(b, n, longest, b->out_off.back());
+  if (host_mode || b->d_ll_override) split = false;       // (the passes follow the upload -- see host_split below; a planted matrix is in load order)
   const bool online_iv = b->iv_extractor != NULL && !b->have_iv;
   if (online_iv) split = false;
   const float *ll_base = b->d_ll_override ? b->d_ll_override : b->d_ll;
-  b->last_split = split;
+  // load_host stored the long utterances first: pass 0 is theirs, the second decoder object takes them from there
+  const int Kh = (host_mode && !online_iv && !b->d_ll_override && b->dec_long && b->host_split < n) ? b->host_split : 0;
+  const bool two_queues = split || Kh > 0;
+  b->last_split = two_queues;
   int n_main = n;
   std::vector<kamd_queue_task> tasks;
   if (!split) {
@@ -697,23 +751,42 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
       flops += kamd_nnet_last_flops(b->nnet);
       passes++;
       mark("model issued, pass", pass);
+      if (pass == 0 && Kh > 0) {
+        if (pu[1] != Kh) return kamd::SetError(KAMD_ERR_STATE, "the first pass is not the long utterances'");
+        KAMD_HIP(hipEventRecord(b->ev_long, st));
+        KAMD_HIP(hipStreamWaitEvent(b->s_long, b->ev_long, 0));
+        b->map_long.resize(Kh); b->map_rest.resize(n - Kh);
+        for (int k = 0; k < Kh; k++) b->map_long[k] = k;
+        for (int k = Kh; k < n; k++) b->map_rest[k - Kh] = k;
+        tasks.resize(Kh);
+        for (int k = 0; k < Kh; k++) {                     // (stored longest first)
+          tasks[k].d_loglikes = ll_base + static_cast<size_t>(b->out_off[k]) * b->P;
+          tasks[k].ld = b->P; tasks[k].n_frames = static_cast<int32_t>(b->out_off[k + 1] - b->out_off[k]);
+          tasks[k].utt = k; tasks[k].reserved = 0;
+        }
+        rc = kamd_decoder_queue_launch(b->dec_long, tasks.data(), Kh, Kh, b->s_long);
+        if (rc != KAMD_OK) return rc;
+        mark("long utterances' search issued", Kh);
+      }
       if (online_iv && pass + 1 < np) { rc = ivectors_of(pass + 1); if (rc != KAMD_OK) return rc; }
     }
     KAMD_HIP(hipEventRecord(b->ev[2], st));
     // ---- the search: one work-queue launch, longest utterance first
-    tasks.resize(n);
-    std::vector<int> order(n);
-    for (int u = 0; u < n; u++) order[u] = u;
+    n_main = n - Kh;
+    tasks.resize(n_main);
+    std::vector<int> order(n_main);
+    for (int u = 0; u < n_main; u++) order[u] = Kh + u;
     std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
       return b->out_off[a + 1] - b->out_off[a] > b->out_off[c + 1] - b->out_off[c];
     });
-    for (int k = 0; k < n; k++) {
+    for (int k = 0; k < n_main; k++) {
       const int u = order[k];
-      tasks[k].d_loglikes = ll_base + static_cast<size_t>(b->out_off[u]) * b->P;
+      const int64_t row = (b->d_ll_override && host_mode && b->load_row.size() == static_cast<size_t>(n)) ? b->load_row[u] : b->out_off[u];
+      tasks[k].d_loglikes = ll_base + static_cast<size_t>(row) * b->P;
       tasks[k].ld = b->P; tasks[k].n_frames = static_cast<int32_t>(b->out_off[u + 1] - b->out_off[u]);
-      tasks[k].utt = u; tasks[k].reserved = 0;
+      tasks[k].utt = u - Kh; tasks[k].reserved = 0;       // queue-local number (map_rest when the long ones went elsewhere)
     }
-    rc = kamd_decoder_queue_launch(b->dec, tasks.data(), n, b->opts.resident_lanes, st);
+    rc = kamd_decoder_queue_launch(b->dec, tasks.data(), n_main, b->opts.resident_lanes, st);
     if (rc != KAMD_OK) return rc;
     mark("search issued, utterances", n);
   } else {
@@ -793,7 +866,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
   double t_first_done = -1, t_last_done = -1;
   while (collected < n) {
     int k = kamd_decoder_queue_poll(b->dec, buf.data(), static_cast<int>(buf.size()));
-    if (k == 0 && split) {
+    if (k == 0 && two_queues) {
       k = kamd_decoder_queue_poll(b->dec_long, buf.data(), static_cast<int>(buf.size()));
       for (int i = 0; i < k; i++) buf[i] |= KAMD_JOB_LONG;
     }
@@ -812,7 +885,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
       continue;
     }
     hipError_t q = hipStreamQuery(st);
-    if (q == hipSuccess && split) q = hipStreamQuery(b->s_long);
+    if (q == hipSuccess && two_queues) q = hipStreamQuery(b->s_long);
     if (q == hipSuccess) {
       if (++idle_after_end > 2) break;      // the kernel has ended and published nothing more
     } else if (q != hipErrorNotReady) {
@@ -828,7 +901,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
   float qms = 0; int32_t lanes = 0;
   rc = kamd_decoder_queue_wait(b->dec, &qms, &lanes);
   if (rc != KAMD_OK) return rc;
-  if (split) {
+  if (two_queues) {
     float qms_long = 0; int32_t lanes_long = 0;
     rc = kamd_decoder_queue_wait(b->dec_long, &qms_long, &lanes_long);
     if (rc != KAMD_OK) return rc;
@@ -865,7 +938,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
   s.host_tail_ms = static_cast<float>(total_ms - t_last_done);
   s.first_result_ms = static_cast<float>(t_first_done);
   s.nnet_flops = flops; s.lanes = lanes; s.nnet_passes = passes;
-  s.long_utterances = split ? b->long_lanes : 0;
+  s.long_utterances = two_queues ? b->long_lanes : 0;
   double host_sum = 0;
   for (int u = 0; u < b->n_utts; u++) {
     if (b->out[u].status != KAMD_OK) s.n_failed++;
@@ -925,7 +998,7 @@ const kamd_compact_lattice *kamd_batch_decoder_get_compact_lattice(kamd_batch_de
 int kamd_batch_decoder_get_loglikes(kamd_batch_decoder *h, int utt, float *out, int rows_cap, int *rows, int *cols) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
   if (utt < 0 || utt >= b->n_utts) return kamd::SetError(KAMD_ERR_ARG, "bad utterance index");
-  const std::vector<int>::const_iterator it = std::lower_bound(b->kept.begin(), b->kept.end(), utt);
+  const std::vector<int>::const_iterator it = std::find(b->kept.begin(), b->kept.end(), utt);     // (load_host may store the longest utterances first)
   *rows = 0; *cols = b->P;
   if (it == b->kept.end() || *it != utt) return KAMD_OK;                 // too short for one frame: no rows
   const size_t k = static_cast<size_t>(it - b->kept.begin());

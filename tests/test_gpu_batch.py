@@ -204,7 +204,7 @@ def test_long_utterances_searched_beside_the_acoustic_model_give_the_same_result
     waves = [synth.make_wave(float(s), seed=300 + i) for i, s in enumerate(durs)]
     order = rng.permutation(len(waves))
     waves = [waves[i] for i in order]
-    kw = dict(max_seconds=7.0, resident_lanes=16, host_threads=3, determinize=True, keep_raw_lattices=True, nnet_pass_frames=1200)
+    kw = dict(max_seconds=7.0, resident_lanes=16, host_threads=3, determinize=True, keep_raw_lattices=True, nnet_pass_frames=1200, search_mode=2)
     plain = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, **kw)
     plain.load(waves)
     st0 = plain.run()
@@ -218,7 +218,7 @@ def test_long_utterances_searched_beside_the_acoustic_model_give_the_same_result
             monkeypatch.setenv("KAMD_BATCH_SPLIT", forced)
         st = bd.run()
         assert st.n_failed == 0
-        assert st.long_utterances == (0 if forced == "0" else 2)        # 0.55 x 200 frames > 1.5 x 31 utterances' frames / 16 lanes
+        assert st.long_utterances == (0 if forced == "0" else 2)        # 0.7 x 200 frames > 31 utterances' frames / 16 lanes
         for u in range(len(waves)):
             np.testing.assert_array_equal(bd.loglikes(u), plain.loglikes(u))
             assert lattices_equal(bd.raw_lattice(u), plain.raw_lattice(u))
@@ -228,6 +228,33 @@ def test_long_utterances_searched_beside_the_acoustic_model_give_the_same_result
             assert a["record"].n_frames == c["record"].n_frames and list(a["record"].counters[:7]) == list(c["record"].counters[:7])
             x, y = bd.compact_lattice(u), plain.compact_lattice(u)
             assert x.num_states == y.num_states and x.arcs.tobytes() == y.arcs.tobytes() and x.strings.tobytes() == y.strings.tobytes()
+    # the same with the waveforms uploaded inside run() (load_host stores the long utterances first, as a pass of their own)
+    monkeypatch.delenv("KAMD_BATCH_SPLIT", raising=False)
+    bh = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, long_lanes=2, **kw)
+    bh.load_host(waves)
+    for rep in range(2):
+        st = bh.run()
+        assert st.n_failed == 0 and st.long_utterances == 2 and st.upload_passes == st.nnet_passes > 2
+        for u in range(len(waves)):
+            np.testing.assert_array_equal(bh.loglikes(u), plain.loglikes(u))
+            assert lattices_equal(bh.raw_lattice(u), plain.raw_lattice(u))
+            a, c = bh.output(u), plain.output(u)
+            assert a["words"].tolist() == c["words"].tolist() and a["graph_cost"] == c["graph_cost"] and a["acoustic_cost"] == c["acoustic_cost"]
+            x, y = bh.compact_lattice(u), plain.compact_lattice(u)
+            assert x.num_states == y.num_states and x.arcs.tobytes() == y.arcs.tobytes()
+    # ... and a planted matrix in LOAD order still reaches the right utterances (one queue then: the override's rows
+    # follow the caller's order, the stored order has the long ones first)
+    fr = bh.output_frames()
+    planted = [synth.random_loglikes(int(t), g.num_pdfs, seed=70 + u, scale=2.0) for u, t in enumerate(fr)]
+    from kaldi_amd import decoder
+    dev = decoder.DeviceMatrix(np.concatenate(planted, axis=0))
+    bh.set_loglike_override(dev.ptr(0))
+    assert bh.run().long_utterances == 0
+    for u in (0, int(np.argmax(fr)), len(waves) - 1):
+        o = orc.Decoder(g, cfg, 2)
+        o.Decode(planted[u])
+        assert lattices_equal(bh.raw_lattice(u), o.GetRawLattice())
+    bh.set_loglike_override(None)
     # a balanced shard (many utterances per lane) is left alone
     monkeypatch.delenv("KAMD_BATCH_SPLIT", raising=False)
     many = [synth.make_wave(float(s), seed=500 + i) for i, s in enumerate(rng.uniform(0.5, 1.0, 40))]
