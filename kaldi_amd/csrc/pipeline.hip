@@ -162,8 +162,12 @@ int kamd_pipeline_set_overlap(kamd_pipeline *h, const int32_t *bounds, int n_bou
     if (bounds[i] <= (i ? bounds[i - 1] : 0)) return kamd::SetError(KAMD_ERR_ARG, "slice boundaries must be positive and increasing");
   p->bounds.assign(bounds, bounds + n_bounds);
   if (n_bounds > 0 && !p->s_nnet) {
+    // streams of different priorities: two streams of ONE priority can share a hardware queue, on which their kernels run
+    // in submission order (seen in batch.cc's long-utterance decoder: kamd_batch_decoder_set_long_decoder)
+    int least = 0, greatest = 0;
+    KAMD_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     KAMD_HIP(hipStreamCreateWithFlags(&p->s_nnet, hipStreamNonBlocking));
-    KAMD_HIP(hipStreamCreateWithFlags(&p->s_dec, hipStreamNonBlocking));
+    KAMD_HIP(hipStreamCreateWithPriority(&p->s_dec, hipStreamNonBlocking, greatest));
   }
   while (static_cast<int>(p->slice_done.size()) < n_bounds + 1) {
     hipEvent_t e;
