@@ -673,7 +673,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
   if (online_iv) split = false;
   const float *ll_base = b->d_ll_override ? b->d_ll_override : b->d_ll;
   // load_host stored the long utterances first: pass 0 is theirs, the second decoder object takes them from there
-  const int Kh = (host_mode && !online_iv && !b->d_ll_override && b->dec_long && b->host_split < n) ? b->host_split : 0;
+  const int Kh = (host_mode && !online_iv && !b->d_ll_override && b->dec_long && b->host_split == b->long_lanes && b->host_split < n) ? b->host_split : 0;
   const bool two_queues = split || Kh > 0;
   b->last_split = two_queues;
   int n_main = n;
