@@ -592,7 +592,8 @@ def main():
                                 dec_stats["arcs_per_frame"],
                                 "waveforms resident in HBM before the timed region" if args.resident else
                                 "waveform upload (%.2f GB from host memory) inside the timed region" % (wav_bytes / 1e9)),
-                   "utterances": int(durs.size), "utterances_rank0": n, "loglike_std_nats": args.ll_std, "lm_scale": args.lm_scale,
+                   "utterances": int(durs.size), "utterances_rank0": n, "long_utterances_rank0": int(st.long_utterances),
+                   "loglike_std_nats": args.ll_std, "lm_scale": args.lm_scale,
                    "value_is_load": load_name, "upload_in_timed_region": not args.resident,
                    "baseline_config": "configs[2]" if args.workload == "librispeech" and args.graph == "tglarge" else
                                       ("configs[1]" if args.workload == "mini_librispeech" else "other")},

@@ -28,6 +28,18 @@ def test_two_ranks_are_launched_and_share_one_test_set():
     assert d["cpu_baseline"] is None                                                       # rank 0 at N = 1 only
 
 
+def test_four_ranks_search_their_longest_utterances_beside_the_model():
+    """Ranks of 4 and more get the long-utterance decoder (kamd_batch_decoder_set_long_decoder, 32 lanes): with the upload
+    inside the timed region the 32 longest utterances of a rank's shard are stored first and searched beside the model of the
+    others; no utterance may fail and the line keeps its shape."""
+    d = run_bench("--workload", "tiny", "--utts", "640", "--gpus", "4", "--dist-backend", "gloo", "--device", "0", "--steps", "2", "--warmup", "1",
+                  "--host-threads", "2", "--tokens-per-frame", "4000")        # (four ranks' arenas on ONE device here)
+    assert d["n_gpus"] == 4 and len(d["rank_wall_s"]) == 4 and d["value"] > 0
+    assert d["config"]["utterances"] == 640 and d["config"]["utterances_rank0"] == 160
+    assert d["config"]["long_utterances_rank0"] == 32 and d["config"]["upload_in_timed_region"] is True
+    assert d["decoder"]["failed_utterances"] == 0
+
+
 def test_single_rank_line_has_roofline_cpu_baseline_and_wer():
     d = run_bench("--workload", "tiny", "--steps", "2", "--warmup", "1", "--cpu-budget", "2", "--wer-utts", "8")
     assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
