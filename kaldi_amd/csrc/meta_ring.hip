@@ -69,7 +69,9 @@ int MetaRing::Acquire(const void *src, size_t bytes, void **d, hipStream_t st) {
   const int rc = Reserve(bytes, &h, d);
   if (rc != KAMD_OK) return rc;
   memcpy(h, src, bytes);
-  return Commit(st);
+  const int crc = Commit(st);
+  if (crc != KAMD_OK) cur_ = -1;        // (nothing was sent: the slot is free again, the caller has no Release to make)
+  return crc;
 }
 
 int MetaRing::Release(hipStream_t st) {
