@@ -1,6 +1,6 @@
 // online2-wav-nnet3-latgen-faster (online2bin/online2-wav-nnet3-latgen-faster.cc:60-300) as a C++ host program over the
 // C-ABI and the kaldi_amd.hpp mirror (BASELINE configs[4]): the reference's usage line, option names (online.conf with
-// --feature-type=mfcc, --mfcc-config, --ivector-extraction-config, --endpoint.*, --ivector-silence-weighting.*) and log
+// --feature-type, --mfcc-config / --fbank-config, --ivector-extraction-config, --endpoint.*, --ivector-silence-weighting.*) and log
 // lines; chunked features, online i-vectors, the acoustic model and the lattice-generating search run on the MI355X.
 //
 //   online2-wav-nnet3-latgen-faster-amd [options] <nnet3-in> <fst-in> <spk2utt-rspecifier> <wav-rspecifier> <lattice-wspecifier>
@@ -11,7 +11,7 @@
 // fed --chunk-length seconds at a time; every tick uploads the chunks of ALL active streams with one copy and advances them
 // together (features, i-vectors, the model on the frames that became computable, the search).  A speaker's utterances
 // follow each other and hand their i-vector adaptation state on (:183-191, :285-286).  The same archive, byte for byte,
-// as tools/online2_wav_nnet3_latgen_faster.py (tests/test_gpu_cxx_host.py).  Not supported: plp / fbank / pitch features.
+// as tools/online2_wav_nnet3_latgen_faster.py (tests/test_gpu_cxx_host.py).  --feature-type=mfcc or fbank; not supported: plp and pitch features.
 // Build: g++ -std=c++14 -O2 -I include examples/online2_wav_nnet3_latgen_faster.cc -L kaldi_amd/lib -lkaldi_amd -lpthread
 #include <algorithm>
 #include <cstdio>
@@ -105,15 +105,16 @@ int main(int argc, char **argv) {
     BaseFloat chunk_length_secs = 0.18f, max_seconds = 60.0f;
     bool do_endpointing = false, online = true;
     int32 num_threads_startup = 8, batch = 64, device = -1;
-    std::string word_syms_rxfilename, feature_type = "mfcc", mfcc_config, ivector_config;
+    std::string word_syms_rxfilename, feature_type = "mfcc", mfcc_config, fbank_config, ivector_config;
     po.Register("chunk-length", &chunk_length_secs, "Length of chunk size in seconds, that we process.  Set to <= 0 to use all input in one chunk.");
     po.Register("word-symbol-table", &word_syms_rxfilename, "Symbol table for words [for debug output]");
     po.Register("do-endpointing", &do_endpointing, "If true, apply endpoint detection");
     po.Register("online", &online, "(ignored: decoding is always chunk by chunk)");
     po.Register("num-threads-startup", &num_threads_startup, "(ignored)");
     // OnlineNnet2FeaturePipelineConfig::Register (online2/online-nnet2-feature-pipeline.h:89-110)
-    po.Register("feature-type", &feature_type, "Base feature type [mfcc]");
+    po.Register("feature-type", &feature_type, "Base feature type [mfcc, fbank]");
     po.Register("mfcc-config", &mfcc_config, "Configuration file for MFCC features (e.g. conf/mfcc_hires.conf)");
+    po.Register("fbank-config", &fbank_config, "Configuration file for filterbank features (e.g. conf/fbank.conf)");
     po.Register("ivector-extraction-config", &ivector_config, "Configuration file for online iVector extraction");
     OnlineSilenceWeightingConfig silence_weighting_config;
     silence_weighting_config.RegisterWithPrefix("ivector-silence-weighting", &po);
@@ -126,14 +127,25 @@ int main(int argc, char **argv) {
     if (po.NumArgs() != 5) { po.PrintUsage(); return 1; }
     const std::string nnet3_rxfilename = po.GetArg(1), fst_rxfilename = po.GetArg(2), spk2utt_rspecifier = po.GetArg(3),
                       wav_rspecifier = po.GetArg(4), clat_wspecifier = po.GetArg(5);
-    if (feature_type != "mfcc") throw KaldiFatalError("only --feature-type=mfcc is supported");
+    if (feature_type != "mfcc" && feature_type != "fbank")       // online-nnet2-feature-pipeline.cc:36-58 (plp and pitch: not on this path)
+      throw KaldiFatalError("Invalid feature type: " + feature_type + " (supported: mfcc, fbank)");
     if (do_endpointing && endpoint_opts.SilencePhones().empty()) throw KaldiFatalError("--do-endpointing needs --endpoint.silence-phones");
     config.Check();
     if (device >= 0) Check(kamd_set_device(device));
     det_opts.c.max_mem = max_mem; det_opts.c.phone_determinize = phone_determinize; det_opts.c.word_determinize = word_determinize;
 
     MfccOptions mfcc;
-    if (!mfcc_config.empty()) {
+    FbankOptions fbank;
+    const bool use_fbank = feature_type == "fbank";
+    if (use_fbank) {
+      if (!fbank_config.empty()) {
+        ParseOptions fpo("fbank config");
+        FbankOptionsParser fp(&fbank);
+        fp.Register(&fpo);
+        fpo.ReadConfigFile(fbank_config);
+        fp.Finish();
+      }
+    } else if (!mfcc_config.empty()) {
       ParseOptions mpo("mfcc config");
       MfccOptionsParser mp(&mfcc);
       mp.Register(&mpo);
@@ -142,7 +154,8 @@ int main(int argc, char **argv) {
     } else {                                                // conf/mfcc_hires.conf
       mfcc.c.use_energy = 0; mfcc.c.mel.num_bins = 40; mfcc.c.num_ceps = 40; mfcc.c.mel.low_freq = 20.0f; mfcc.c.mel.high_freq = -400.0f;
     }
-    const float samp_freq = mfcc.c.frame.samp_freq;
+    const kamd_frame_opts &frame_opts = use_fbank ? fbank.c.frame : mfcc.c.frame;
+    const float samp_freq = frame_opts.samp_freq;
 
     // TransitionModel + AmNnetSimple, batch-norm / dropout in test mode, collapsed (:160-170)
     TransitionModelAndNnet model(nnet3_rxfilename, acoustic_scale, frame_subsampling_factor);
@@ -156,8 +169,10 @@ int main(int argc, char **argv) {
     const int32 sub = frame_subsampling_factor;
     kamd_decoder_config cfg = config.ToC();
     kamd_decoder_sizes sizes;
-    Check(kamd_decoder_sizes_suggest(&cfg, S, static_cast<int32>(max_seconds * 1000.0 / mfcc.c.frame.frame_shift_ms / sub) + 2, 0, 0, 0, 0, 0.5f, &sizes));
-    OnlineStreamBatch sb(config, model.Id2Pdf(), am_nnet, decode_fst, mfcc, S, max_seconds, sizes);
+    Check(kamd_decoder_sizes_suggest(&cfg, S, static_cast<int32>(max_seconds * 1000.0 / frame_opts.frame_shift_ms / sub) + 2, 0, 0, 0, 0, 0.5f, &sizes));
+    std::unique_ptr<OnlineStreamBatch> sb_owner(use_fbank ? new OnlineStreamBatch(config, model.Id2Pdf(), am_nnet, decode_fst, fbank, S, max_seconds, sizes)
+                                                          : new OnlineStreamBatch(config, model.Id2Pdf(), am_nnet, decode_fst, mfcc, S, max_seconds, sizes));
+    OnlineStreamBatch &sb = *sb_owner;
     std::unique_ptr<OnlineIvectorExtractor> extractor;
     if (!ivector_config.empty()) {
       extractor.reset(new OnlineIvectorExtractor(ivector_config));

@@ -1301,11 +1301,14 @@ class OnlineStreamBatch {
                     const DecodingGraph &fst, const MfccOptions &mfcc_opts, int32 max_streams, BaseFloat max_seconds,
                     const kamd_decoder_sizes &sizes)
       : feat_(CheckPtr(kamd_mfcc_create(&mfcc_opts.c, 1.0f))), ie_(NULL) {
-    decoder_opts.Check();
-    kamd_decoder_config c = decoder_opts.ToC();
-    dec_ = CheckPtr(kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), id2pdf.empty() ? 0 : static_cast<int32>(id2pdf.size()) - 1));
-    h_ = CheckPtr(kamd_stream_batch_create(feat_, am_nnet.Handle(), dec_, max_streams, max_seconds, mfcc_opts.c.frame.samp_freq));
-    frame_shift_ = mfcc_opts.c.frame.frame_shift_ms * 1.0e-3f * kamd_nnet_frame_subsampling_factor(am_nnet.Handle());
+    Init(decoder_opts, id2pdf, am_nnet, fst, mfcc_opts.c.frame, max_streams, max_seconds, sizes);
+  }
+  /// --feature-type=fbank (OnlineFbank as the base feature, online2/online-nnet2-feature-pipeline.cc:84-85)
+  OnlineStreamBatch(const LatticeFasterDecoderConfig &decoder_opts, const std::vector<int32> &id2pdf, const AmNnetSimple &am_nnet,
+                    const DecodingGraph &fst, const FbankOptions &fbank_opts, int32 max_streams, BaseFloat max_seconds,
+                    const kamd_decoder_sizes &sizes)
+      : feat_(CheckPtr(kamd_fbank_create(&fbank_opts.c, 1.0f))), ie_(NULL) {
+    Init(decoder_opts, id2pdf, am_nnet, fst, fbank_opts.c.frame, max_streams, max_seconds, sizes);
   }
   ~OnlineStreamBatch() { kamd_stream_batch_destroy(h_); kamd_decoder_destroy(dec_); kamd_feat_destroy(feat_); }
   OnlineStreamBatch(const OnlineStreamBatch &) = delete;
@@ -1413,6 +1416,21 @@ class OnlineStreamBatch {
   }
   kamd_decoder *DecoderHandle() { return dec_; }
  private:
+  void Init(const LatticeFasterDecoderConfig &decoder_opts, const std::vector<int32> &id2pdf, const AmNnetSimple &am_nnet,
+            const DecodingGraph &fst, const kamd_frame_opts &frame, int32 max_streams, BaseFloat max_seconds, const kamd_decoder_sizes &sizes) {
+    dec_ = NULL; h_ = NULL;
+    decoder_opts.Check();
+    kamd_decoder_config c = decoder_opts.ToC();
+    dec_ = kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), id2pdf.empty() ? 0 : static_cast<int32>(id2pdf.size()) - 1);
+    if (dec_) h_ = kamd_stream_batch_create(feat_, am_nnet.Handle(), dec_, max_streams, max_seconds, frame.samp_freq);
+    if (!h_) {
+      const std::string msg = kamd_last_error();
+      if (dec_) kamd_decoder_destroy(dec_);
+      kamd_feat_destroy(feat_);
+      throw KaldiFatalError(msg);
+    }
+    frame_shift_ = frame.frame_shift_ms * 1.0e-3f * kamd_nnet_frame_subsampling_factor(am_nnet.Handle());
+  }
   BaseFloat frame_shift_;
   kamd_feat *feat_;
   kamd_decoder *dec_;
@@ -1507,39 +1525,92 @@ struct OnlineSilenceWeightingConfig {
   }
 };
 
-// ---- compute-mfcc-feats options (MfccOptions::Register, feat/feature-mfcc.h:58-88, with FrameExtractionOptions and
-// MelBanksOptions) for a ParseOptions: Register, read, then Finish() copies the flags into the C struct
+// ---- compute-mfcc-feats / compute-fbank-feats options for a ParseOptions: FrameExtractionOptions::Register
+// (feat/feature-window.h:60-86), MelBanksOptions::Register (feat/mel-computations.h:58-76), MfccOptions::Register
+// (feat/feature-mfcc.h:58-88), FbankOptions::Register (feat/feature-fbank.h:60-80).  Register, read, then Finish() copies
+// the flags into the C struct.
+struct FrameMelOptionsParser {
+  kamd_frame_opts *frame;
+  kamd_mel_opts *mel;
+  bool remove_dc_offset, snip_edges, round_to_power_of_two;
+  BaseFloat dither;
+  std::string window_type;
+  FrameMelOptionsParser(kamd_frame_opts *f, kamd_mel_opts *m)
+      : frame(f), mel(m), remove_dc_offset(f->remove_dc_offset != 0), snip_edges(f->snip_edges != 0),
+        round_to_power_of_two(f->round_to_power_of_two != 0), dither(0.0f) {
+    static const char *const names[] = {"hanning", "hamming", "povey", "rectangular", "blackman"};
+    window_type = names[f->window_type >= 0 && f->window_type < 5 ? f->window_type : 2];
+  }
+  void Register(ParseOptions *po) {
+    po->Register("sample-frequency", &frame->samp_freq, "Waveform data sample frequency (must match the waveform file, if specified there)");
+    po->Register("frame-length", &frame->frame_length_ms, "Frame length in milliseconds");
+    po->Register("frame-shift", &frame->frame_shift_ms, "Frame shift in milliseconds");
+    po->Register("preemphasis-coefficient", &frame->preemph_coeff, "Coefficient for use in signal preemphasis");
+    po->Register("remove-dc-offset", &remove_dc_offset, "Subtract mean from waveform on each frame");
+    po->Register("dither", &dither, "Dithering constant (0.0 means no dither); only 0 is supported here (dithering is random in the reference)");
+    po->Register("window-type", &window_type, "Type of window (\"hamming\"|\"hanning\"|\"povey\"|\"rectangular\"|\"blackmann\")");
+    po->Register("blackman-coeff", &frame->blackman_coeff, "Constant coefficient for generalized Blackman window.");
+    po->Register("round-to-power-of-two", &round_to_power_of_two, "If true, round window size to power of two by zero-padding input to FFT.");
+    po->Register("snip-edges", &snip_edges, "If true, end effects will be handled by outputting only frames that completely fit in the file");
+    po->Register("num-mel-bins", &mel->num_bins, "Number of triangular mel-frequency bins");
+    po->Register("low-freq", &mel->low_freq, "Low cutoff frequency for mel bins");
+    po->Register("high-freq", &mel->high_freq, "High cutoff frequency for mel bins (if <= 0, offset from Nyquist)");
+    po->Register("vtln-low", &mel->vtln_low, "Low inflection point in piecewise linear VTLN warping function");
+    po->Register("vtln-high", &mel->vtln_high, "High inflection point in piecewise linear VTLN warping function (if negative, offset from high-mel-freq");
+  }
+  void Finish() {
+    if (dither != 0.0f) throw KaldiFatalError("--dither: only 0 is supported");
+    static const char *const names[] = {"hanning", "hamming", "povey", "rectangular", "blackman"};
+    int w = -1;
+    for (int i = 0; i < 5; i++) if (window_type == names[i]) w = i;
+    if (w < 0) throw KaldiFatalError("Invalid window type " + window_type);
+    frame->window_type = w; frame->dither = 0.0f;
+    frame->remove_dc_offset = remove_dc_offset; frame->snip_edges = snip_edges; frame->round_to_power_of_two = round_to_power_of_two;
+  }
+};
 struct MfccOptionsParser {
   MfccOptions *opts;
-  bool use_energy, raw_energy, htk_compat, remove_dc_offset, snip_edges;
-  BaseFloat dither;
+  FrameMelOptionsParser fm;
+  bool use_energy, raw_energy, htk_compat;
   explicit MfccOptionsParser(MfccOptions *o)
-      : opts(o), use_energy(o->c.use_energy != 0), raw_energy(o->c.raw_energy != 0), htk_compat(o->c.htk_compat != 0),
-        remove_dc_offset(o->c.frame.remove_dc_offset != 0), snip_edges(o->c.frame.snip_edges != 0), dither(0.0f) {}
+      : opts(o), fm(&o->c.frame, &o->c.mel), use_energy(o->c.use_energy != 0), raw_energy(o->c.raw_energy != 0), htk_compat(o->c.htk_compat != 0) {}
   void Register(ParseOptions *po) {
     kamd_mfcc_opts &c = opts->c;
-    po->Register("sample-frequency", &c.frame.samp_freq, "Waveform data sample frequency");
-    po->Register("frame-length", &c.frame.frame_length_ms, "Frame length in milliseconds");
-    po->Register("frame-shift", &c.frame.frame_shift_ms, "Frame shift in milliseconds");
-    po->Register("preemphasis-coefficient", &c.frame.preemph_coeff, "Coefficient for use in signal preemphasis");
-    po->Register("remove-dc-offset", &remove_dc_offset, "Subtract mean from waveform on each frame");
-    po->Register("dither", &dither, "Dithering constant; only 0 is supported");
-    po->Register("snip-edges", &snip_edges, "Only output frames that completely fit in the file");
-    po->Register("num-mel-bins", &c.mel.num_bins, "Number of triangular mel-frequency bins");
-    po->Register("low-freq", &c.mel.low_freq, "Low cutoff frequency for mel bins");
-    po->Register("high-freq", &c.mel.high_freq, "High cutoff frequency for mel bins (if <= 0, offset from Nyquist)");
+    fm.Register(po);
     po->Register("num-ceps", &c.num_ceps, "Number of cepstra in MFCC computation (including C0)");
     po->Register("use-energy", &use_energy, "Use energy (not C0) in MFCC computation");
     po->Register("energy-floor", &c.energy_floor, "Floor on energy (absolute, not relative) in MFCC computation");
     po->Register("raw-energy", &raw_energy, "If true, compute energy before preemphasis and windowing");
     po->Register("cepstral-lifter", &c.cepstral_lifter, "Constant that controls scaling of MFCCs");
-    po->Register("htk-compat", &htk_compat, "If true, put energy or C0 last");
+    po->Register("htk-compat", &htk_compat, "If true, put energy or C0 last and use a factor of sqrt(2) on C0.");
   }
   void Finish() {
-    if (dither != 0.0f) throw KaldiFatalError("--dither: only 0 is supported");
+    fm.Finish();
     kamd_mfcc_opts &c = opts->c;
     c.use_energy = use_energy; c.raw_energy = raw_energy; c.htk_compat = htk_compat;
-    c.frame.remove_dc_offset = remove_dc_offset; c.frame.snip_edges = snip_edges;
+  }
+};
+struct FbankOptionsParser {
+  FbankOptions *opts;
+  FrameMelOptionsParser fm;
+  bool use_energy, raw_energy, htk_compat, use_log_fbank, use_power;
+  explicit FbankOptionsParser(FbankOptions *o)
+      : opts(o), fm(&o->c.frame, &o->c.mel), use_energy(o->c.use_energy != 0), raw_energy(o->c.raw_energy != 0), htk_compat(o->c.htk_compat != 0),
+        use_log_fbank(o->c.use_log_fbank != 0), use_power(o->c.use_power != 0) {}
+  void Register(ParseOptions *po) {
+    kamd_fbank_opts &c = opts->c;
+    fm.Register(po);
+    po->Register("use-energy", &use_energy, "Add an extra dimension with energy to the FBANK output.");
+    po->Register("energy-floor", &c.energy_floor, "Floor on energy (absolute, not relative) in FBANK computation");
+    po->Register("raw-energy", &raw_energy, "If true, compute energy before preemphasis and windowing");
+    po->Register("htk-compat", &htk_compat, "If true, put energy last.");
+    po->Register("use-log-fbank", &use_log_fbank, "If true, produce log-filterbank, else produce linear.");
+    po->Register("use-power", &use_power, "If true, use power, else use magnitude.");
+  }
+  void Finish() {
+    fm.Finish();
+    kamd_fbank_opts &c = opts->c;
+    c.use_energy = use_energy; c.raw_energy = raw_energy; c.htk_compat = htk_compat; c.use_log_fbank = use_log_fbank; c.use_power = use_power;
   }
 };
 

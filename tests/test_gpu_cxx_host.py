@@ -365,6 +365,20 @@ def test_online2_wav_nnet3_latgen_faster_example_writes_the_python_tools_archive
         got[tag] = want
     assert got["plain"] != got["endpoint"] and got["plain"] != got["weighted"]
     assert [k for k, _ in latbin.read_lattices("ark:%s" % (tmp_path / "cxx_plain_1.lat"))] == ["a1", "a2", "b1"]
+    # --feature-type=fbank (OnlineFbank as the base feature): a model without an i-vector input over 40 log-mel bins
+    m_fb = nnet.make_tdnnf(64, 16, [1, 0, 3], 32, g.num_pdfs, input_dim=40, seed=13, output_scale=3.0)
+    write_mdl(tmp_path / "final_fbank.mdl", m_fb, num_units=25)
+    (tmp_path / "fbank.conf").write_text("--num-mel-bins=40\n--dither=0\n--window-type=hamming\n--use-energy=false\n")
+    (tmp_path / "fbank_online.conf").write_text("--feature-type=fbank\n--fbank-config=%s\n" % (tmp_path / "fbank.conf"))
+    fb_common = ["--config=%s" % (tmp_path / "fbank_online.conf")] + common[1:]
+    fb_files = [str(tmp_path / "final_fbank.mdl")] + files[1:]
+    p = subprocess.run([sys.executable, ROOT + "/tools/online2_wav_nnet3_latgen_faster.py"] + fb_common + ["--batch=2"] + fb_files +
+                       ["ark:%s" % (tmp_path / "py_fbank.lat")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = subprocess.run([exe] + fb_common + ["--batch=3"] + fb_files + ["ark:%s" % (tmp_path / "cxx_fbank.lat")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert open(tmp_path / "cxx_fbank.lat", "rb").read() == open(tmp_path / "py_fbank.lat", "rb").read()
+    assert [k for k, _ in latbin.read_lattices("ark:%s" % (tmp_path / "cxx_fbank.lat"))] == ["a1", "a2", "b1"]
     # the reference's exits: usage without arguments; 255 + a message for a model without the i-vector config
     assert subprocess.run([exe], capture_output=True).returncode == 1
     (tmp_path / "plain.conf").write_text("--feature-type=mfcc\n--mfcc-config=%s\n" % (tmp_path / "mfcc.conf"))

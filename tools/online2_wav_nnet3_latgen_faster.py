@@ -4,10 +4,10 @@
   e.g.  online2_wav_nnet3_latgen_faster.py --config=conf/online.conf --do-endpointing=false --frames-per-chunk=20 \\
             --acoustic-scale=1.0 --frame-subsampling-factor=3 final.mdl HCLG.fst ark:spk2utt scp:wav.scp "ark:|gzip -c > lat.1.gz"
 
-online.conf's --feature-type=mfcc, --mfcc-config, --ivector-extraction-config and --endpoint.* options are read as
+online.conf's --feature-type, --mfcc-config / --fbank-config, --ivector-extraction-config and --endpoint.* options are read as
 they are.  Audio is fed --chunk-length seconds at a time; every tick advances ALL active streams together (one
 stream per speaker, --batch speakers at once; a speaker's utterances follow each other and hand their i-vector
-adaptation state on) and the --ivector-silence-weighting.* options (OnlineSilenceWeighting).  Not supported: plp / fbank / pitch features."""
+adaptation state on) and the --ivector-silence-weighting.* options (OnlineSilenceWeighting).  --feature-type=mfcc or fbank; not supported: plp and pitch features."""
 import os
 import sys
 
@@ -29,8 +29,9 @@ def main(argv):
     po.register("do-endpointing", bool, False, "If true, apply endpoint detection")
     po.register("online", bool, True, "(ignored: decoding is always chunk by chunk)")
     po.register("num-threads-startup", int, 8, "(ignored)")
-    po.register("feature-type", str, "mfcc", "Base feature type [mfcc]")
+    po.register("feature-type", str, "mfcc", "Base feature type [mfcc, fbank]")
     po.register("mfcc-config", str, "", "Configuration file for MFCC features (e.g. conf/mfcc_hires.conf)")
+    po.register("fbank-config", str, "", "Configuration file for filterbank features (e.g. conf/fbank.conf)")
     po.register("ivector-extraction-config", str, "", "Configuration file for online iVector extraction")
     online.OnlineSilenceWeightingConfig.register(po)
     po.register("endpoint.silence-phones", str, "", "List of phones that are considered to be silence phones by the endpointing code.")
@@ -45,8 +46,8 @@ def main(argv):
     if len(args) != 5:
         po.print_usage()
         return 1
-    if po["feature-type"] != "mfcc":
-        raise KamdError("only --feature-type=mfcc is supported")
+    if po["feature-type"] not in ("mfcc", "fbank"):        # online-nnet2-feature-pipeline.cc:36-58 (plp and pitch: not on this path)
+        raise KamdError("Invalid feature type: %s (supported: mfcc, fbank)" % po["feature-type"])
     for i, r in enumerate((ep.rule1, ep.rule2, ep.rule3, ep.rule4, ep.rule5), 1):
         pre = "endpoint.rule%d." % i
         r.must_contain_nonsilence, r.min_trailing_silence = po[pre + "must-contain-nonsilence"], po[pre + "min-trailing-silence"]
@@ -54,13 +55,20 @@ def main(argv):
     sil = [int(x) for x in po["endpoint.silence-phones"].split(":") if x]
     if po["do-endpointing"] and not sil:
         raise KamdError("--do-endpointing needs --endpoint.silence-phones")
-    mpo = table.ParseOptions("mfcc config")
-    options.register_mfcc(mpo)
-    if po["mfcc-config"]:
-        mpo.read_config_file(po["mfcc-config"])
-        mfcc = options.mfcc_opts(mpo)
+    if po["feature-type"] == "fbank":
+        fpo = table.ParseOptions("fbank config")
+        options.register_fbank(fpo)
+        if po["fbank-config"]:
+            fpo.read_config_file(po["fbank-config"])
+        mfcc = options.fbank_opts(fpo) if po["fbank-config"] else abi.fbank_opts_default()       # (the base feature's options, whichever type)
     else:
-        mfcc = abi.mfcc_opts_hires()
+        mpo = table.ParseOptions("mfcc config")
+        options.register_mfcc(mpo)
+        if po["mfcc-config"]:
+            mpo.read_config_file(po["mfcc-config"])
+            mfcc = options.mfcc_opts(mpo)
+        else:
+            mfcc = abi.mfcc_opts_hires()
     cfg = options.decoder_config(po)
     acwt = po["acoustic-scale"]
     model, id2pdf, tid_phone = mdl.read_mdl(args[0], acwt, po["frame-subsampling-factor"])
