@@ -1419,7 +1419,7 @@ class OnlineStreamBatch {
   void Init(const LatticeFasterDecoderConfig &decoder_opts, const std::vector<int32> &id2pdf, const AmNnetSimple &am_nnet,
             const DecodingGraph &fst, const kamd_frame_opts &frame, int32 max_streams, BaseFloat max_seconds, const kamd_decoder_sizes &sizes) {
     dec_ = NULL; h_ = NULL;
-    decoder_opts.Check();
+    try { decoder_opts.Check(); } catch (...) { kamd_feat_destroy(feat_); throw; }
     kamd_decoder_config c = decoder_opts.ToC();
     dec_ = kamd_decoder_create(fst.Handle(), &c, &sizes, id2pdf.empty() ? NULL : id2pdf.data(), id2pdf.empty() ? 0 : static_cast<int32>(id2pdf.size()) - 1);
     if (dec_) h_ = kamd_stream_batch_create(feat_, am_nnet.Handle(), dec_, max_streams, max_seconds, frame.samp_freq);
