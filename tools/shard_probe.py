@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--utts", type=int, default=0)
     ap.add_argument("--long-lanes", type=int, default=0, help="kamd_batch_decoder_set_long_decoder: lanes of the second decoder object")
+    ap.add_argument("--tokens-per-frame", type=int, default=0, help="arena budget per frame and lane of both decoder objects (0 = from max-active / free HBM)")
     ap.add_argument("--host", action="store_true", help="the waveforms are uploaded inside run() (bench.py's default contract) instead of resident")
     a = ap.parse_args()
     sys.argv = [sys.argv[0]] + (["--utts", str(a.utts)] if a.utts else [])
@@ -40,7 +41,8 @@ def main():
         audio = sum(w.size for w in waves) / 16000.0
         bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=float(durs.max()) + 0.5, resident_lanes=a.lanes,
                                     host_threads=16, determinize=True, keep_raw_lattices=False, hash_capacity=args.hash_capacity or None,
-                                    search_mode=args.search_mode, lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), long_lanes=a.long_lanes)
+                                    search_mode=args.search_mode, lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), long_lanes=a.long_lanes,
+                                    tokens_per_frame=a.tokens_per_frame or None)
         (bd.load_host if a.host else bd.load)(waves)
         bd.run()
         t0 = time.time()
