@@ -939,6 +939,12 @@ int kamd_decoder_partial_best_path(kamd_decoder *d, int lane, int use_final_prob
 int kamd_decoder_partial_best_paths(kamd_decoder *d, const int32_t *lanes, int n, int use_final_probs, int32_t *alignments,
                                     int ali_cap, int32_t *ali_len, int32_t *words, int words_cap, int32_t *words_len,
                                     float *graph_cost, float *acoustic_cost);
+/* The same with use_final_probs = 0 for a host that asks after EVERY tick: the decoder keeps each lane's previous answer
+ * on the device and walks back only to the first frame whose token is the one recorded then (typically the newest few dozen
+ * frames); identical results.  InitDecoding of a lane forgets its record. */
+int kamd_decoder_partial_best_paths_incremental(kamd_decoder *d, const int32_t *lanes, int n, int32_t *alignments, int ali_cap,
+                                                int32_t *ali_len, int32_t *words, int words_cap, int32_t *words_len,
+                                                float *graph_cost, float *acoustic_cost);
 /* What OnlineSilenceWeighting::ComputeCurrentTraceback (online2/online-ivector-feature.cc:464-510) reads off the
  * decoder, for n un-finalized lanes in one launch: the best path without final-probs, NEWEST frame first, one
  * (transition-id, token) pair per decoded frame; a token is named by its HCLG state (one token per state and

@@ -1390,15 +1390,18 @@ class OnlineStreamBatch {
   }
   /// partial results (GetBestPath(end_of_utterance = false)) of these streams after a tick, one launch; words[i] is empty and
   /// ok[i] false for a stream with no token alive
+  /// incremental: kamd_decoder_partial_best_paths_incremental (the decoder keeps every stream's previous answer and walks
+  /// back only to the first frame whose best-path token is unchanged: what a server calls after every tick)
   void GetPartialBestPaths(const std::vector<int32> &streams, std::vector<std::vector<int32> > *words,
-                           std::vector<std::vector<int32> > *alignments = NULL, std::vector<char> *ok = NULL) {
+                           std::vector<std::vector<int32> > *alignments = NULL, std::vector<char> *ok = NULL, bool incremental = false) {
     const int n = static_cast<int>(streams.size());
     int32 frames = 0;
     for (int i = 0; i < n; i++) frames = std::max(frames, kamd_decoder_num_frames_decoded(dec_, streams[i]));
     const int cap = 4 * (frames + 2) + 1024;
     std::vector<int32> ali(static_cast<size_t>(n) * cap), wrd(static_cast<size_t>(n) * cap), na(n), nw(n);
     std::vector<float> g(n), a(n);
-    Check(kamd_decoder_partial_best_paths(dec_, streams.data(), n, 0, ali.data(), cap, na.data(), wrd.data(), cap, nw.data(), g.data(), a.data()));
+    if (incremental) Check(kamd_decoder_partial_best_paths_incremental(dec_, streams.data(), n, ali.data(), cap, na.data(), wrd.data(), cap, nw.data(), g.data(), a.data()));
+    else Check(kamd_decoder_partial_best_paths(dec_, streams.data(), n, 0, ali.data(), cap, na.data(), wrd.data(), cap, nw.data(), g.data(), a.data()));
     words->assign(n, std::vector<int32>());
     if (alignments) alignments->assign(n, std::vector<int32>());
     if (ok) ok->assign(n, 0);

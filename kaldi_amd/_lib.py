@@ -160,6 +160,7 @@ def lib():
     sig("kamd_decoder_best_path", C.c_int, [vp, C.c_int, ip, C.c_int, ip, ip, C.c_int, ip, fp, fp])
     sig("kamd_decoder_partial_best_path", C.c_int, [vp, C.c_int, C.c_int, ip, C.c_int, ip, ip, C.c_int, ip, fp, fp])
     sig("kamd_decoder_partial_best_paths", C.c_int, [vp, ip, C.c_int, C.c_int, ip, C.c_int, ip, ip, C.c_int, ip, fp, fp])
+    sig("kamd_decoder_partial_best_paths_incremental", C.c_int, [vp, ip, C.c_int, ip, C.c_int, ip, ip, C.c_int, ip, fp, fp])
     sig("kamd_endpoint_config_default", None, [C.POINTER(abi.EndpointConfig)])
     sig("kamd_endpoint_detected", C.c_int, [C.POINTER(abi.EndpointConfig), C.c_int, C.c_int, C.c_float, C.c_float])
     sig("kamd_decoder_set_silence_phones", C.c_int, [vp, ip, C.c_int, ip, C.c_int])
@@ -294,7 +295,7 @@ kamd_decoder_set_options kamd_decoder_reserve kamd_decoder_init kamd_decoder_adv
 kamd_decoder_sync kamd_decoder_num_frames_decoded kamd_decoder_final_relative_cost
 kamd_decoder_reached_final kamd_decoder_lattice_size kamd_decoder_get_raw_lattice
 kamd_decoder_best_path kamd_decoder_partial_best_path kamd_decoder_get_trace kamd_decoder_get_counters
-kamd_decoder_partial_best_paths kamd_endpoint_config_default kamd_endpoint_detected kamd_decoder_set_silence_phones kamd_decoder_trailing_silence_frames kamd_decoder_endpoint_detected
+kamd_decoder_partial_best_paths kamd_decoder_partial_best_paths_incremental kamd_endpoint_config_default kamd_endpoint_detected kamd_decoder_set_silence_phones kamd_decoder_trailing_silence_frames kamd_decoder_endpoint_detected
 kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch kamd_pipeline_set_ivectors kamd_pipeline_set_online_ivectors
 kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features
 kamd_decoder_queue_configure kamd_decoder_queue_launch kamd_decoder_queue_poll kamd_decoder_queue_result kamd_decoder_queue_fetch_lattice kamd_decoder_queue_wait kamd_lattice_best_path

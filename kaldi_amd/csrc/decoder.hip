@@ -2423,6 +2423,57 @@ __global__ __launch_bounds__(NT, 4) void TracebackBatchKernel(DecDev d, const in
   if (tid == 0) { head[2 * b] = n; head[2 * b + 1] = __float_as_int(fc); }
 }
 
+// TracebackBatchKernel for a server that asks for partial results after EVERY tick: the walk costs a block-wide link
+// search per arc (two barriers and a dependent round trip: 0.6-1.2 ms for a 12 s utterance, growing with it), and from
+// one tick to the next only the newest few dozen frames of the best path change.  Per lane the previous answer is kept
+// on the device -- its arcs OLDEST first in cache[lane][0 .. cache_cap / 2), and for every frame the token (named by its
+// HCLG state, as in FrameTraceKernel) that the emitting arc consuming the frame LEFT, with the number of arcs older than
+// that arc -- and the walk stops at the first frame whose token is the recorded one: from that token back the path is what
+// it was (a token's best incoming link never changes once its frame is closed; pruning keeps the best path's links).
+// The new arcs are collected newest first in the upper half of the cache row, moved behind the unchanged prefix, and the
+// whole path is copied to out[b] for the host.  head[3b] = arcs on the path (-1: no token alive, -2: the row is too
+// small), head[3b + 1] = final cost bits (0: no final-probs), head[3b + 2] = frames now recorded.
+__global__ __launch_bounds__(NT, 4) void TracebackIncKernel(DecDev d, const int *lanes, const int *known, PathArc *cache, int cache_cap,
+                                                         int *rec, int stride, PathArc *out_arcs, int out_cap, int *head) {
+  __shared__ Sh sh;
+  const int b = blockIdx.x, tid = threadIdx.x, lane_id = lanes[b];
+  const Ctx c = MakeCtx(d, lane_id);
+  InitSh(&sh);
+  PathArc *P = cache + static_cast<size_t>(lane_id) * cache_cap;
+  int *tok = rec + static_cast<size_t>(lane_id) * 4 * stride, *idx = tok + stride, *tstate = idx + stride, *tk = tstate + stride;
+  PathArc *out = out_arcs + static_cast<size_t>(b) * out_cap;
+  const int n_known = known[b], half = cache_cap / 2;
+  float fc = 0.0f;
+  int n = -1, matched = -1, newest = -1, oldest = 0;
+  if (!c.st->error && !c.st->finalized)
+    n = WalkBestPath(d, c, &sh, 0, &fc, [&](int k, const Link &L, bool emitting, int f) {
+      if (tid == 0 && k < half) {
+        PathArc a; a.ilabel = L.ilabel; a.olabel = L.olabel; a.graph = L.graph;
+        a.ac = emitting ? L.ac - c.cost_offsets[f - 1] : L.ac;
+        P[cache_cap - 1 - k] = a;
+      }
+      if (!emitting) return true;
+      const int frame = f - 1, state = c.tok_state[L.src];
+      if (frame >= stride) return true;
+      if (tid == 0) { tstate[frame] = state; tk[frame] = k; }
+      if (newest < 0) newest = frame;
+      oldest = frame;
+      if (frame < n_known && tok[frame] == state) { matched = frame; return false; }
+      return true;
+    });
+  __syncthreads();
+  if (n < 0) { if (tid == 0) { head[3 * b] = -1; head[3 * b + 1] = 0; head[3 * b + 2] = 0; } return; }
+  const int prefix = matched >= 0 ? idx[matched] : 0;
+  const int total = prefix + n;
+  if (n > half || total > half || total > out_cap) { if (tid == 0) { head[3 * b] = -2; head[3 * b + 1] = 0; head[3 * b + 2] = 0; } return; }
+  for (int k = tid; k < n; k += NT) P[prefix + (n - 1 - k)] = P[cache_cap - 1 - k];        // (lower half <- upper half: disjoint)
+  if (newest >= 0)
+    for (int fr = oldest + tid; fr <= newest; fr += NT) { tok[fr] = tstate[fr]; idx[fr] = prefix + (n - 1 - tk[fr]); }
+  __syncthreads();
+  for (int k = tid; k < total; k += NT) out[k] = P[k];
+  if (tid == 0) { head[3 * b] = total; head[3 * b + 1] = __float_as_int(fc); head[3 * b + 2] = min(newest + 1, stride); }
+}
+
 // What OnlineSilenceWeighting::ComputeCurrentTraceback reads off the decoder (online2/online-ivector-feature.cc:464-510):
 // the best path without final-probs, newest frame first, as one (transition-id, token) pair per decoded frame -- the
 // emitting arc that consumed the frame and the token it left.  A token is named by its HCLG state: a frame holds one
@@ -2527,6 +2578,8 @@ struct Decoder {
   void *d_paths = NULL; size_t paths_cap = 0;   // partial best paths of many lanes (kamd_decoder_partial_best_paths)
   int *d_trace_tok = NULL; int trace_stride = 0; // incremental frame tracebacks: the token recorded per lane and frame ...
   std::vector<int> trace_known;                  // ... and how many frames of it are valid (0 after InitDecoding)
+  kamd::PathArc *d_pp_arcs = NULL; int *d_pp_rec = NULL; int pp_cap = 0, pp_stride = 0;   // kamd_decoder_partial_best_paths_incremental: the previous answers
+  std::vector<int> pp_known;                     // ... frames recorded per lane (0 after InitDecoding)
   unsigned char *d_sil_tid = NULL; int n_sil_tids = 0; int *d_sil_out = NULL; int sil_out_cap = 0;   // endpointing
   // work queue (kamd_decoder_queue_*)
   unsigned char *d_pool = NULL, *h_pool = NULL; unsigned long long pool_cap = 0;   // the lattice pool: page-locked HOST memory, d_pool = its device address
@@ -2764,6 +2817,8 @@ void kamd_decoder_destroy(kamd_decoder *h) {
   for (size_t i = 0; i < D->allocs.size(); i++) (void)hipFree(D->allocs[i]);
   if (D->d_path) (void)hipFree(D->d_path);
   if (D->d_trace_tok) (void)hipFree(D->d_trace_tok);
+  if (D->d_pp_arcs) (void)hipFree(D->d_pp_arcs);
+  if (D->d_pp_rec) (void)hipFree(D->d_pp_rec);
   if (D->d_paths) (void)hipFree(D->d_paths);
   if (D->d_sil_tid) (void)hipFree(D->d_sil_tid);
   if (D->d_sil_out) (void)hipFree(D->d_sil_out);
@@ -2872,6 +2927,7 @@ int kamd_decoder_init(kamd_decoder *h, const int32_t *lanes, int n, void *stream
   KAMD_HIP(hipGetLastError());
   D->last_stream = st; D->cached_lane = -1; D->n_timed = 0;
   if (!D->trace_known.empty()) for (int i = 0; i < n; i++) D->trace_known[lanes[i]] = 0;     // a new utterance: nothing recorded
+  if (!D->pp_known.empty()) for (int i = 0; i < n; i++) D->pp_known[lanes[i]] = 0;
   return KAMD_OK;
 }
 
@@ -3214,6 +3270,74 @@ int kamd_decoder_partial_best_paths(kamd_decoder *h, const int32_t *lanes, int n
     }
   }
   return rc;
+}
+
+int kamd_decoder_partial_best_paths_incremental(kamd_decoder *h, const int32_t *lanes, int n, int32_t *alignments, int ali_cap, int32_t *ali_len,
+                                                int32_t *words, int words_cap, int32_t *words_len, float *graph_cost, float *acoustic_cost) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0) return KAMD_OK;
+  if (CheckLanes(D, lanes, n) != KAMD_OK || EnsureTaskBuf(D, n) != KAMD_OK) return KAMD_ERR_ARG;
+  int max_frame = 0;
+  for (int i = 0; i < n; i++) {
+    if (D->h_st[lanes[i]].finalized) return kamd::SetError(KAMD_ERR_STATE, "lane %d is finalized: use kamd_decoder_best_path", lanes[i]);
+    max_frame = std::max(max_frame, D->h_st[lanes[i]].frame);
+  }
+  if (!D->d_pp_arcs) {
+    D->pp_stride = D->sizes.max_frames + 2;
+    D->pp_cap = 2 * (4 * (D->sizes.max_frames + 2) + 1024);
+    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_pp_arcs), static_cast<size_t>(D->sizes.max_lanes) * D->pp_cap * sizeof(kamd::PathArc)));
+    KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_pp_rec), static_cast<size_t>(D->sizes.max_lanes) * 4 * D->pp_stride * sizeof(int)));
+    D->pp_known.assign(D->sizes.max_lanes, 0);
+  }
+  const int cap = 4 * (max_frame + 2) + 1024;
+  const size_t arcs_bytes = static_cast<size_t>(n) * cap * sizeof(kamd::PathArc), head_bytes = static_cast<size_t>(n) * 12, known_bytes = static_cast<size_t>(n) * 4;
+  if (arcs_bytes + head_bytes + known_bytes > D->paths_cap) {
+    const size_t grow = std::max(arcs_bytes + head_bytes + known_bytes, 2 * D->paths_cap);
+    if (D->d_paths) (void)hipFree(D->d_paths);
+    D->d_paths = NULL; D->paths_cap = 0;
+    KAMD_HIP(hipMalloc(&D->d_paths, grow));
+    D->paths_cap = grow;
+  }
+  kamd::PathArc *d_arcs = static_cast<kamd::PathArc *>(D->d_paths);
+  int *d_head = reinterpret_cast<int *>(static_cast<char *>(D->d_paths) + arcs_bytes);
+  int *d_known = d_head + 3 * n;
+  hipStream_t st = D->last_stream;
+  std::vector<int> known(n), head(3 * static_cast<size_t>(n));
+  for (int i = 0; i < n; i++) known[i] = D->pp_known[lanes[i]];
+  KAMD_HIP(hipMemcpyAsync(d_known, known.data(), known_bytes, hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipMemcpyAsync(D->d_lanes, lanes, n * sizeof(int), hipMemcpyHostToDevice, st));
+  KAMD_HIP(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(kamd::TracebackIncKernel, dim3(n), dim3(NT), 0, st, D->dev, D->d_lanes, d_known, D->d_pp_arcs, D->pp_cap, D->d_pp_rec, D->pp_stride,
+                     d_arcs, cap, d_head);
+  KAMD_HIP(hipMemcpyAsync(head.data(), d_head, head_bytes, hipMemcpyDeviceToHost, st));
+  if (hipStreamSynchronize(st) != hipSuccess) return kamd::SetError(KAMD_ERR_HIP, "traceback kernel failed: %s", hipGetErrorString(hipGetLastError()));
+  int longest = 0;
+  for (int i = 0; i < n; i++) {
+    if (head[3 * i] == -2)
+      return kamd::SetError(KAMD_ERR_STATE, "lane %d: the best path exceeds the buffer sized from the last kamd_decoder_sync (%d arcs): sync first", lanes[i], cap);
+    longest = std::max(longest, head[3 * i]);
+  }
+  std::vector<kamd::PathArc> arcs(static_cast<size_t>(n) * std::max(longest, 1));
+  if (longest > 0)      // one strided copy of the used prefix of every lane's segment
+    KAMD_HIP(hipMemcpy2D(arcs.data(), static_cast<size_t>(longest) * sizeof(kamd::PathArc), d_arcs, static_cast<size_t>(cap) * sizeof(kamd::PathArc),
+                         static_cast<size_t>(longest) * sizeof(kamd::PathArc), n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) {
+    int32_t *ali = alignments + static_cast<size_t>(i) * ali_cap, *wrd = words + static_cast<size_t>(i) * words_cap;
+    ali_len[i] = 0; words_len[i] = 0; graph_cost[i] = INFINITY; acoustic_cost[i] = INFINITY;
+    const int cnt = head[3 * i];
+    if (cnt < 0) { ali_len[i] = -1; words_len[i] = -1; D->pp_known[lanes[i]] = 0; continue; }      // no tokens alive on the newest frame
+    float fc; memcpy(&fc, &head[3 * i + 1], 4);
+    const kamd::PathArc *A = arcs.data() + static_cast<size_t>(i) * longest;
+    float gsum = 0.f, asum = 0.f;   // Times() along the path, start -> end (the arcs come oldest first here)
+    for (int k = 0; k < cnt; k++) {
+      if (A[k].ilabel != 0) { if (ali_len[i] < ali_cap) ali[ali_len[i]] = A[k].ilabel; ali_len[i]++; }
+      if (A[k].olabel != 0) { if (words_len[i] < words_cap) wrd[words_len[i]] = A[k].olabel; words_len[i]++; }
+      gsum += A[k].graph; asum += A[k].ac;
+    }
+    graph_cost[i] = gsum + fc; acoustic_cost[i] = asum;
+    D->pp_known[lanes[i]] = head[3 * i + 2];
+  }
+  return KAMD_OK;
 }
 
 static int FrameTracebacks(Decoder *D, const int32_t *lanes, int n, int incremental, int32_t *tids, int32_t *tokens, int cap,

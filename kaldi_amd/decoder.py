@@ -449,8 +449,10 @@ def partial_best_path(dec, lane, use_final_probs=True):
                 acoustic_cost=a.value)
 
 
-def partial_best_paths(dec, lanes, use_final_probs=False):
-    """partial_best_path of several un-finalized lanes in one launch -> list of dicts (None: no token alive)"""
+def partial_best_paths(dec, lanes, use_final_probs=False, incremental=False):
+    """partial_best_path of several un-finalized lanes in one launch -> list of dicts (None: no token alive).
+    incremental: kamd_decoder_partial_best_paths_incremental -- the decoder keeps every lane's previous answer and walks
+    back only to the first frame whose token is unchanged (for a host that asks after every tick; no final-probs)."""
     ln = np.ascontiguousarray(lanes, np.int32)
     if ln.size == 0:
         return []
@@ -459,8 +461,14 @@ def partial_best_paths(dec, lanes, use_final_probs=False):
     ali, words = np.zeros((ln.size, cap), np.int32), np.zeros((ln.size, cap), np.int32)
     na, nw = np.zeros(ln.size, np.int32), np.zeros(ln.size, np.int32)
     g, a = np.zeros(ln.size, np.float32), np.zeros(ln.size, np.float32)
-    check(lib().kamd_decoder_partial_best_paths(dec, abi.iptr(ln), ln.size, int(use_final_probs), abi.iptr(ali), cap, abi.iptr(na),
-                                                abi.iptr(words), cap, abi.iptr(nw), abi.fptr(g), abi.fptr(a)))
+    if incremental:
+        if use_final_probs:
+            raise KamdError("incremental partial best paths are without final-probs")
+        check(lib().kamd_decoder_partial_best_paths_incremental(dec, abi.iptr(ln), ln.size, abi.iptr(ali), cap, abi.iptr(na),
+                                                                abi.iptr(words), cap, abi.iptr(nw), abi.fptr(g), abi.fptr(a)))
+    else:
+        check(lib().kamd_decoder_partial_best_paths(dec, abi.iptr(ln), ln.size, int(use_final_probs), abi.iptr(ali), cap, abi.iptr(na),
+                                                    abi.iptr(words), cap, abi.iptr(nw), abi.fptr(g), abi.fptr(a)))
     return [None if na[i] < 0 else dict(alignment=ali[i, :na[i]].copy(), words=words[i, :nw[i]].copy(), graph_cost=float(g[i]),
                                         acoustic_cost=float(a[i])) for i in range(ln.size)]
 

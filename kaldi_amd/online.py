@@ -395,9 +395,10 @@ class StreamBatch:
     def partial_best_path(self, stream, use_final_probs=False):
         return decoder.partial_best_path(self.dec._dec, int(stream), use_final_probs)
 
-    def partial_best_paths(self, streams, use_final_probs=False):
-        """partial results of these streams in one launch"""
-        return decoder.partial_best_paths(self.dec._dec, streams, use_final_probs)
+    def partial_best_paths(self, streams, use_final_probs=False, incremental=False):
+        """partial results of these streams in one launch; incremental: only the frames whose best-path token changed since
+        the last call are walked (kamd_decoder_partial_best_paths_incremental)"""
+        return decoder.partial_best_paths(self.dec._dec, streams, use_final_probs, incremental)
 
     def endpoint_detected(self, config, streams, tid2phone, silence_phones, frame_shift_in_seconds=None):
         """EndpointDetected for these streams in one launch -> (flags, trailing silence frames)"""

@@ -435,6 +435,52 @@ def test_endpointing_on_the_device_equals_the_oracle():
     assert checked >= 8
 
 
+def test_incremental_partial_best_paths_equal_the_full_walk():
+    """kamd_decoder_partial_best_paths_incremental keeps every stream's previous answer on the device and walks back only
+    to the first frame whose best-path token is unchanged.  After every tick -- also when a stream was not asked for a
+    while, with arena compaction at a low threshold, and across a restart of a stream with another utterance -- it
+    returns what the full walk returns: alignment, words and both costs, bit for bit."""
+    g = synth.make_hclg(num_units=25, vocab=60, n_hist=12, seed=6)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=3.0)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    S = 5
+    sb = online.StreamBatch(op, N, G, cfg, S, max_seconds=8.0, sizes=abi.DecoderSizes(S, 1 << 14, S * 60000, S * 120000, 512))
+    sb.set_compaction(0.05)                                   # (3000 tokens: a stream compacts every few ticks)
+    rng = np.random.default_rng(17)
+    waves = [synth.make_wave(d, seed=70 + k) for k, d in enumerate([3.1, 1.4, 4.2, 2.0, 0.8])]
+    again = [synth.make_wave(d, seed=170 + k) for k, d in enumerate([1.1, 2.3, 0.9, 1.7, 2.9])]
+    sb.start(np.arange(S))
+    pos, second = [0] * S, [False] * S
+    compared = shorter_walks = 0
+    for tick in range(400):
+        live = [k for k in range(S) if pos[k] < waves[k].size]
+        if not live:
+            break
+        for k in live:
+            n = int(rng.integers(1200, 6000))
+            sb.accept(k, waves[k][pos[k]:pos[k] + n], input_finished=False)
+            pos[k] += n
+        nd = sb.advance(live)
+        cand = [k for k, d in zip(live, nd) if d > 0 and rng.random() < 0.8]       # (a stream is skipped now and then)
+        if cand:
+            inc = sb.partial_best_paths(cand, incremental=True)
+            full = sb.partial_best_paths(cand)
+            for k, a, b in zip(cand, inc, full):
+                assert (a is None) == (b is None)
+                if a is None:
+                    continue
+                assert a["alignment"].tolist() == b["alignment"].tolist() and a["words"].tolist() == b["words"].tolist(), (tick, k)
+                assert a["graph_cost"] == b["graph_cost"] and a["acoustic_cost"] == b["acoustic_cost"], (tick, k)
+                compared += 1
+        for k in live:                                                            # a finished stream starts another utterance once
+            if pos[k] >= waves[k].size and not second[k]:
+                sb.finalize([k])
+                sb.start([k])
+                waves[k], pos[k], second[k] = again[k], 0, True
+    assert compared >= 40 and sb.num_compactions() > 0
+
+
 def test_one_overflowing_stream_does_not_stop_the_others():
     """A stream that outgrows its lane's arena fails alone: the tick reports it, the other streams of the tick have
     advanced and keep decoding to the offline result, the failed stream refuses further ticks until it is restarted,

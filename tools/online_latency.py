@@ -17,6 +17,8 @@ ap.add_argument("--ll-std", type=float, default=1.3)
 ap.add_argument("--streams", type=int, default=0, help="> 0: that many concurrent streams through kamd_stream_batch")
 ap.add_argument("--accept-each", action="store_true", help="with --streams: one AcceptWaveform (one upload) per stream instead of accept_many")
 ap.add_argument("--partials", action="store_true", help="with --streams: partial best paths of all streams after every tick (one launch)")
+ap.add_argument("--partials-incremental", action="store_true", help="with --partials: kamd_decoder_partial_best_paths_incremental (only the frames whose "
+                "best-path token changed since the last tick are walked)")
 ap.add_argument("--endpointing", action="store_true", help="with --streams: EndpointDetected for all streams after every tick (one traceback launch)")
 ap.add_argument("--ivectors", action="store_true", help="with --streams: the model takes 100-dim online i-vectors, estimated per "
                 "stream on the device (512-Gaussian UBM) and fed on DecodableNnetLoopedOnline's chunk schedule (--frames-per-chunk 20)")
@@ -71,7 +73,7 @@ if a.streams > 0:
                 ep_ms.append((time.perf_counter() - t2) * 1e3); ep_sil.append(float(np.mean(sil_fr)))
             if a.partials and nd[0] > 0 and i + step < waves[0].size:
                 t3 = time.perf_counter()
-                pb = sb.partial_best_paths(np.arange(S))
+                pb = sb.partial_best_paths(np.arange(S), incremental=a.partials_incremental)
                 pb_ms.append((time.perf_counter() - t3) * 1e3)
             lat.append((t2 - t1, t1 - t0))
         t0 = time.perf_counter()
