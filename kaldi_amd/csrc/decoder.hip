@@ -3077,6 +3077,17 @@ int kamd_decoder_partial_best_path(kamd_decoder *h, int lane, int use_final_prob
   Decoder *D = reinterpret_cast<Decoder *>(h);
   if (LaneOk(D, lane) != KAMD_OK) return KAMD_ERR_ARG;
   if (D->h_st[lane].finalized) return kamd::SetError(KAMD_ERR_STATE, "lane %d is finalized: use kamd_decoder_best_path", lane);
+  if (!use_final_probs) {
+    // GetBestPath(end_of_utterance = false) after every chunk: the incremental walk (only the frames whose token changed)
+    int32_t al = 0, wl = 0;
+    const int32_t one = lane;
+    const int rc = kamd_decoder_partial_best_paths_incremental(h, &one, 1, alignment, ali_cap, &al, words, words_cap, &wl, graph_cost, acoustic_cost);
+    *ali_len = 0; *words_len = 0;
+    if (rc != KAMD_OK) return rc;
+    if (al < 0) { *graph_cost = INFINITY; *acoustic_cost = INFINITY; return kamd::SetError(KAMD_ERR_STATE, "no tokens alive on the newest frame"); }
+    *ali_len = al; *words_len = wl;
+    return KAMD_OK;
+  }
   const int cap = 4 * (D->h_st[lane].frame + 2) + 1024;
   if (cap > D->path_cap) {         // one buffer for the decoder's lifetime (a server asks for partial results every tick)
     const int grow = std::max(cap, 2 * D->path_cap);

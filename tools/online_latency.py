@@ -118,5 +118,5 @@ lat, part = np.asarray(lat) * 1e3, np.asarray(part) * 1e3
 print("stream of %.1f s in %.0f ms chunks: %d chunks, %d frames decoded" % (a.seconds, a.chunk * 1e3, lat.size, d.NumFramesDecoded()))
 print("per chunk (features + nnet + AdvanceDecoding, incl. host sync): median %.2f ms, p95 %.2f ms, max %.2f ms  => %.0f x real time"
       % (np.median(lat), np.percentile(lat, 95), lat.max(), a.seconds * 1e3 / lat.sum()))
-print("partial best path (BestPathEnd + traceback): median %.2f ms, max %.2f ms (grows with the utterance)" % (np.median(part), part.max()))
+print("partial best path (BestPathEnd + incremental traceback): median %.2f ms, max %.2f ms" % (np.median(part), part.max()))
 print("FinalizeDecoding + GetBestPath at the end: %.2f ms" % (fin * 1e3))
