@@ -706,7 +706,7 @@ class SingleUtteranceNnet3Decoder {
     frame_shift_ = mfcc_opts.c.frame.frame_shift_ms * 1.0e-3f;
     decoder_.InitDecoding();                          // online-nnet3-decoding.cc:40
   }
-  ~SingleUtteranceNnet3Decoder() { kamd_online_feat_destroy(online_); kamd_feat_destroy(feat_); }
+  ~SingleUtteranceNnet3Decoder() { if (d_ll_) kamd_free(d_ll_); kamd_online_feat_destroy(online_); kamd_feat_destroy(feat_); }
   void AcceptWaveform(BaseFloat sampling_rate, const std::vector<float> &waveform) {
     Check(kamd_online_feat_accept_waveform(online_, sampling_rate, waveform.data(), static_cast<int64_t>(waveform.size())));
   }
@@ -718,16 +718,21 @@ class SingleUtteranceNnet3Decoder {
     const int32 n = kamd_nnet_num_frames_ready(nnet_, feat_ready, finished_) - done;
     if (n <= 0) return;
     const int32 P = kamd_nnet_output_dim(nnet_);
-    float *d_ll = static_cast<float *>(CheckPtr(kamd_malloc(static_cast<size_t>(n) * P * sizeof(float))));
+    const size_t need = static_cast<size_t>(n) * P * sizeof(float);
+    if (need > ll_bytes_) {            // grow-only: hipMalloc / hipFree synchronise the device, not something for every chunk
+      if (d_ll_) kamd_free(d_ll_);
+      d_ll_ = NULL; ll_bytes_ = 0;
+      d_ll_ = static_cast<float *>(CheckPtr(kamd_malloc(need + need / 2)));
+      ll_bytes_ = need + need / 2;
+    }
     int ld = 0;
     const float *d_feats = kamd_online_feat_device_frames(online_, &ld);
-    int rc = kamd_nnet_forward_range(nnet_, d_feats, ld, feat_ready, finished_, done, n, d_ll, P);
+    int rc = kamd_nnet_forward_range(nnet_, d_feats, ld, feat_ready, finished_, done, n, d_ll_, P);
     if (rc == 0) {
-      kamd_decode_task t = {0, n, d_ll, P, 0};
+      kamd_decode_task t = {0, n, d_ll_, P, 0};
       rc = kamd_decoder_advance(decoder_.Handle(), &t, 1, NULL);
       if (rc == 0) rc = kamd_decoder_sync(decoder_.Handle());
     }
-    kamd_free(d_ll);
     Check(rc);
   }
   void FinalizeDecoding() { decoder_.FinalizeDecoding(); }
@@ -776,6 +781,8 @@ class SingleUtteranceNnet3Decoder {
   kamd_online_feat *online_;
   LatticeFasterDecoder decoder_;
   bool finished_;
+  float *d_ll_ = NULL;        // the chunk's log-likelihood rows (device)
+  size_t ll_bytes_ = 0;
 };
 
 // ---- util/parse-options.h:36-260: the subset the decode binaries use (typed --name=value options, bare --flag
