@@ -1282,6 +1282,7 @@ struct Nnet {
   kamd::MetaRing meta;       // per-pass descriptors (row offsets of every layer, item lengths ...): meta_ring.h
   float *d_ivb = NULL; size_t ivb_cap = 0;
   float *d_zero = NULL;      // n_neutral zero floats (GemmArgs::zeros, zeros_n) followed by n_neutral ones (ones_n)
+  float *d_scratch = NULL; size_t scratch_cap = 0;     // kamd::NnetScratch: the streaming entry's temporary rows
   int n_neutral = 0;
 };
 
@@ -1344,6 +1345,20 @@ static int Grow(T **p, size_t *cap, size_t need, hipStream_t st) {
   KAMD_HIP(hipMemsetAsync(*p, 0, n * sizeof(T), st));
   *cap = n;
   return KAMD_OK;
+}
+
+// A grow-only device buffer owned by the model, for callers that need a few temporary rows per call (kamd_nnet_forward_range
+// after every chunk of a stream: hipMalloc / hipFree synchronise the device).  Not thread-safe, like the model's workspaces.
+float *NnetScratch(kamd_nnet *h, size_t floats) {
+  Nnet *nn = reinterpret_cast<Nnet *>(h);
+  if (floats > nn->scratch_cap) {
+    if (nn->d_scratch) (void)hipFree(nn->d_scratch);
+    nn->d_scratch = NULL; nn->scratch_cap = 0;
+    const size_t cap = floats + floats / 2;
+    if (hipMalloc(reinterpret_cast<void **>(&nn->d_scratch), cap * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return NULL; }
+    nn->scratch_cap = cap;
+  }
+  return nn->d_scratch;
 }
 
 }  // namespace kamd
@@ -1461,6 +1476,7 @@ void kamd_nnet_destroy(kamd_nnet *h) {
   }
   if (nn->d_ivb) (void)hipFree(nn->d_ivb);
   if (nn->d_zero) (void)hipFree(nn->d_zero);
+  if (nn->d_scratch) (void)hipFree(nn->d_scratch);
   delete nn;
 }
 

@@ -12,6 +12,8 @@
 
 #include "common.h"
 
+namespace kamd { float *NnetScratch(kamd_nnet *h, size_t floats); }   // nnet.hip
+
 extern "C" int kamd_feat_compute_frames_device(kamd_feat *f, const float *d_wave, int64_t num_samples,
                                                int first_frame, int num_frames, float *d_out, int ld_out,
                                                void *stream);
@@ -139,17 +141,18 @@ int kamd_nnet_forward_range(kamd_nnet *n, const float *d_feats, int ld_in, int f
   const int T = in_last - in_first + 1;
   const int n_out = kamd_nnet_num_output_frames(n, T);
   const int P = kamd_nnet_output_dim(n);
-  float *d_tmp = NULL;
-  KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&d_tmp), static_cast<size_t>(n_out) * P * sizeof(float)));
+  // (the model's own grow-only scratch: a stream calls this after every chunk, and hipMalloc / hipFree wait for the device)
+  float *d_tmp = kamd::NnetScratch(n, static_cast<size_t>(n_out) * P);
+  if (!d_tmp) return kamd::SetError(KAMD_ERR_HIP, "kamd_nnet_forward_range: out of device memory");
   int64_t in_off[2] = {0, T}, out_off[1] = {0};
   int rc = kamd_nnet_forward_batch_device(n, d_feats + static_cast<size_t>(in_first) * ld_in, in_off, ld_in, NULL, 1,
                                           d_tmp, out_off, P, NULL);
   if (rc == KAMD_OK) {
-    hipError_t e = hipMemcpy2D(d_out, ld_out * sizeof(float), d_tmp + static_cast<size_t>(k0) * P, P * sizeof(float),
-                               P * sizeof(float), out_count, hipMemcpyDeviceToDevice);
+    hipError_t e = hipMemcpy2DAsync(d_out, ld_out * sizeof(float), d_tmp + static_cast<size_t>(k0) * P, P * sizeof(float),
+                                    P * sizeof(float), out_count, hipMemcpyDeviceToDevice, NULL);
+    if (e == hipSuccess) e = hipStreamSynchronize(NULL);      // (as before: the rows are there when the call returns)
     if (e != hipSuccess) rc = kamd::SetError(KAMD_ERR_HIP, "copy failed: %s", hipGetErrorString(e));
   }
-  (void)hipFree(d_tmp);
   return rc;
 }
 
