@@ -1136,6 +1136,10 @@ int kamd_batch_decoder_load(kamd_batch_decoder *b, const float *waves, const int
  * samples through four 32 MB page-locked buffers instead.  `waves` must stay valid until the next load or destroy.  (nnet3-latgen-faster-
  * batch reads each wave / feature matrix from its table inside the timed loop too: nnet3-latgen-faster-batch.cc:176-214.) */
 int kamd_batch_decoder_load_host(kamd_batch_decoder *b, const float *waves, const int64_t *wave_off, int n_utts);
+/* Releases the buffer of kamd_batch_decoder_load_host: undoes the page lock and forgets the pointer, so that the caller may
+ * free `waves` while the decoder object lives on (outputs of the last run() stay readable; another run() needs a new load).
+ * A no-op when nothing is held. */
+int kamd_batch_decoder_unload_host(kamd_batch_decoder *b);
 /* Workload synthesis for benchmarks: the search reads log-likelihoods from d_loglikes (device, [total output frames x
  * P], utterances back to back in load order, as kamd_batch_decoder_get_loglikes numbers them) instead of the acoustic
  * model's output, which is still computed.  NULL switches it off. */

@@ -1127,6 +1127,8 @@ class NnetBatchDecoder {
     else Check(kamd_batch_decoder_load_features(h_, feats_.data(), off.data(), input_dim_, ivectors_.empty() ? NULL : ivectors_.data(), ivector_dim_, n));
     std::vector<float>().swap(feats_);
     Check(kamd_batch_decoder_run(h_, &stats_));
+    // the library page-locked waves_ in place: the lock must be gone before the memory is
+    Check(kamd_batch_decoder_unload_host(h_));
     std::vector<float>().swap(waves_);
     // the per-utterance outcome, with the log lines of decoder-wrappers.cc:228-292
     ok_.assign(n, 0);

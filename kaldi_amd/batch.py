@@ -89,11 +89,20 @@ class NnetBatchDecoder:
         with the features and the acoustic model (kamd_batch_decoder_load_host).  The buffer is kept alive here."""
         waves = [np.asarray(w, np.float32) for w in waves]
         off = np.concatenate([[0], np.cumsum([w.size for w in waves])]).astype(np.int64)
-        self._host_waves = np.ascontiguousarray(np.concatenate(waves), np.float32)
-        self._host_off = off
-        check(lib().kamd_batch_decoder_load_host(self._h, abi.fptr(self._host_waves), abi.iptr(off, C.c_int64), len(waves)))
+        flat = np.ascontiguousarray(np.concatenate(waves), np.float32)
+        # the library page-locks `flat` in place and unlocks the PREVIOUS buffer inside this call: the previous array must
+        # outlive it (rebinding self._host_waves first would free memory that is still registered)
+        previous = getattr(self, "_host_waves", None)
+        check(lib().kamd_batch_decoder_load_host(self._h, abi.fptr(flat), abi.iptr(off, C.c_int64), len(waves)))
+        self._host_waves, self._host_off = flat, off
+        del previous
         self.n_utts = len(waves)
         self.audio_seconds = float(self._host_waves.size) / self.feat.opts.frame.samp_freq
+
+    def unload_host(self):
+        """Releases the buffer of load_host() (page lock undone first, then the array); outputs stay readable."""
+        check(lib().kamd_batch_decoder_unload_host(self._h))
+        self._host_waves = None
 
     def output_frames(self):
         """Output frames of every loaded utterance (0: too short for a frame)."""

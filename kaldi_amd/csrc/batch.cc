@@ -75,6 +75,7 @@ struct BatchDecoder {
   std::vector<int64_t> oiv_off;
   // kamd_batch_decoder_load_host: the samples stay in the caller's memory and every run() uploads them pass by pass
   const float *h_waves = NULL;                   // caller's buffer (kept utterance k starts at h_wave_src[k])
+  bool host_unloaded = false;                    // kamd_batch_decoder_unload_host: the samples are gone, run() needs a new load
   void *h_registered = NULL;                     // ... page-locked in place by load_host (hipHostRegister) when the runtime allows it:
                                                  // the copies then read it directly; otherwise they go through h_stage
   std::vector<int64_t> h_wave_src;
@@ -117,6 +118,7 @@ struct BatchDecoder {
 };
 
 static void Unregister(BatchDecoder *b) {
+  b->host_unloaded = false;
   if (b->h_registered) { (void)hipHostUnregister(b->h_registered); b->h_registered = NULL; }
 }
 
@@ -398,6 +400,14 @@ int kamd_batch_decoder_load_features(kamd_batch_decoder *h, const float *feats, 
   return KAMD_OK;
 }
 
+int kamd_batch_decoder_unload_host(kamd_batch_decoder *h) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (!b) return kamd::SetError(KAMD_ERR_ARG, "null batch decoder");
+  kamd::Unregister(b);
+  if (b->h_waves) { b->h_waves = NULL; b->host_unloaded = true; }
+  return KAMD_OK;
+}
+
 int kamd_batch_decoder_load_host(kamd_batch_decoder *h, const float *waves, const int64_t *h_wave_off, int n_utts) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
   if (n_utts <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty test set");
@@ -545,6 +555,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats);
 // still be running; nothing of this object may be reused (load(), run()) before both have ended.
 int kamd_batch_decoder_run(kamd_batch_decoder *h, kamd_batch_stats *stats) {
   BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (b->host_unloaded) return kamd::SetError(KAMD_ERR_STATE, "kamd_batch_decoder_run: the waveforms were released (kamd_batch_decoder_unload_host); load again");
   const int rc = RunImpl(b, stats);
   if (rc != KAMD_OK) {
     {

@@ -41,6 +41,11 @@ typedef unsigned int u32;
 #define KAMD_NT 1024
 #endif
 #define NT KAMD_NT
+// Minimum wavefronts per SIMD the search kernels are compiled for: 4 = a 1024-thread lane with 128 VGPRs per thread.
+// tools/regime_probe.py builds with 5 (96 VGPRs) to force register spills on purpose.
+#ifndef KAMD_SEARCH_WAVES_PER_EU
+#define KAMD_SEARCH_WAVES_PER_EU 4
+#endif
 #define LANES_PER_CU (1024 / NT)
 #define NWAVES (NT / 64)
 #define EXPT 3            // tokens per thread whose records are fetched together (EXPT * NT == BIGCAP)
@@ -1474,7 +1479,7 @@ __device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *s
   DrainStores();     // an early exit leaves the next row's DMA in flight: it must have landed before the LDS changes hands
   PublishLaneEnd(d, c, &sh, frame);
 }
-__global__ __launch_bounds__(NT, 4) void AdvanceKernel(DecDev d, const kamd_decode_task *tasks) {
+__global__ __launch_bounds__(NT, KAMD_SEARCH_WAVES_PER_EU) void AdvanceKernel(DecDev d, const kamd_decode_task *tasks) {
   __shared__ Sh sh;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   const kamd_decode_task task = tasks[blockIdx.x];
@@ -2230,7 +2235,7 @@ enum { ERR_POOL = 64 };
 // scratch in it; the two ways round that which were measured are both slower: the stages behind real calls on an
 // LDS copy of the descriptors (52 spills, decode 194 -> 238 ms on the headline), and the cold per-lane pointers kept
 // in LDS and fetched through v_readfirstlane (45 spills in this kernel, and new ones in the stand-alone kernels).
-__global__ __launch_bounds__(NT, 4) void DecodeQueueKernel(DecDev d, QueueDev q) {
+__global__ __launch_bounds__(NT, KAMD_SEARCH_WAVES_PER_EU) void DecodeQueueKernel(DecDev d, QueueDev q) {
   __shared__ Sh sh;
   __shared__ FinSh fs;
   __shared__ int s_task;
@@ -2549,7 +2554,7 @@ struct Graph {
   int64_t num_arcs, num_emit;
   int max_ilabel;
   std::vector<void *> allocs;
-  std::vector<float> h_final;      // host copy of the final costs, made by the first live-lattice read
+  std::vector<float> h_final;      // host copy of the final costs (kamd_graph_create): live lattices with final-probs read it
 };
 
 struct RawLat {
@@ -2658,6 +2663,7 @@ kamd_graph *kamd_graph_create(int32_t num_states, int32_t start, const int64_t *
     if (bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return NULL;
     return p;
   };
+  g->h_final.assign(final_cost, final_cost + num_states);
   g->dev.num_states = num_states; g->dev.start = start;
   g->dev.start_flagged = (off[start + 1].y > off[start].y) ? static_cast<int>(static_cast<unsigned>(start) | EPS_FLAG) : start;
   g->dev.off = static_cast<const uint2 *>(up(off.data(), off.size() * sizeof(uint2)));
@@ -2701,7 +2707,7 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
     return NULL;
   }
   Decoder *D = new Decoder();
-  D->g = const_cast<Graph *>(reinterpret_cast<const Graph *>(gh));   // (its lazily made host copy of the final costs is the only thing written)
+  D->g = const_cast<Graph *>(reinterpret_cast<const Graph *>(gh));   // (never written through: one graph serves many decoder objects and threads)
   D->sizes = s;
   kamd::DecDev &d = D->dev;
   memset(&d, 0, sizeof(d));
@@ -3575,11 +3581,7 @@ static int FetchLiveLattice(Decoder *D, int lane, int use_final_probs, RawLat *R
   const int lb = toff[F], le = nt;
   std::vector<float> fc(std::max(0, le - lb), 0.0f);
   if (use_final_probs && le > lb) {
-    std::vector<float> &gfin = D->g->h_final;       // (one read of the graph's final costs, kept: partial lattices are asked for tick after tick)
-    if (gfin.empty()) {
-      gfin.resize(D->g->dev.num_states);
-      KAMD_HIP(hipMemcpy(gfin.data(), D->g->dev.final, gfin.size() * 4, hipMemcpyDeviceToHost));
-    }
+    const std::vector<float> &gfin = D->g->h_final;   // host copy made by kamd_graph_create: the graph is shared, read-only from here on
     for (int i = lb; i < le; i++) fc[i - lb] = gfin[st[i]];
   }
   return Canonicalize(nt, static_cast<int>(lk.size()), F, st.data(), co.data(), toff.data(), fc.data(), lk.data(), 0, D->g->dev.start, R);

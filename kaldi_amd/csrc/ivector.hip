@@ -291,6 +291,12 @@ __device__ inline double WaveSum(double v) {
 // utterance in parallel: the 40 KB rows of U_g and the 32 KB of Sigma_inv_M_g per selected Gaussian
 // are the bulk of the traffic (L2 / Infinity-Cache resident: 37 MB for the recipe's extractor) and
 // must not sit on the per-utterance sequential chain.  grid (max steps, utterances).
+// dynamic LDS of StepStatsKernel: the period's frames, {weight, quadratic-term weight} per (frame, Gaussian) pair, the pairs'
+// y_k vectors (doubles), and three ints per pair
+static inline size_t StepStatsLdsBytes(const IvDev &d) {
+  const size_t pair_cap = static_cast<size_t>(d.period) * d.ng;
+  return (static_cast<size_t>(d.period) * d.D + 2 * pair_cap + pair_cap * d.D) * sizeof(double) + 3 * pair_cap * sizeof(int);
+}
 __global__ __launch_bounds__(256) void StepStatsKernel(IvDev d, IvBatch b) {
   extern __shared__ double ss[];               // xf[period][D], pw[cap], uw[cap], yk[cap][D], then int pg[cap], pt[cap], ug[cap]
   const int u = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -736,6 +742,23 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
     kamd_ivector_extractor_destroy(reinterpret_cast<kamd_ivector_extractor *>(e));
     return NULL;
   }
+  {
+    // StepStatsKernel's dynamic LDS grows with period * num_gselect * lda_rows: beyond the default 64 KB the launch needs the
+    // attribute, beyond a CU's 160 KB the configuration cannot run at all -- say so here, not at the first extraction
+    const size_t lds_step = kamd::StepStatsLdsBytes(v);
+    if (lds_step > 150 * 1024) {
+      kamd::SetError(KAMD_ERR_ARG, "i-vector extractor: ivector_period %d x num_gselect %d x feature dim %d needs %zu bytes of LDS per step (limit %d)",
+                     v.period, v.ng, v.D, lds_step, 150 * 1024);
+      kamd_ivector_extractor_destroy(reinterpret_cast<kamd_ivector_extractor *>(e));
+      return NULL;
+    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::StepStatsKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            static_cast<int>(lds_step)) != hipSuccess) {
+      kamd::SetError(KAMD_ERR_HIP, "i-vector extractor: cannot reserve LDS for the statistics step");
+      kamd_ivector_extractor_destroy(reinterpret_cast<kamd_ivector_extractor *>(e));
+      return NULL;
+    }
+  }
   v.min_post = d.min_post; v.log_min_post = d.min_post > 0 ? logf(d.min_post) : -INFINITY; v.post_scale = d.posterior_scale;
   return reinterpret_cast<kamd_ivector_extractor *>(e);
 }
@@ -835,9 +858,7 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
     hipLaunchKernelGGL(kamd::PostKernel, dim3(kamd::CeilDiv(max_post, 4), n), dim3(256), lds_post, st, v, b);
   }
   if (max_steps > 0) {
-    const int pair_cap = v.period * v.ng;
-    const size_t lds_step = (static_cast<size_t>(v.period) * v.D + 2 * pair_cap + static_cast<size_t>(pair_cap) * v.D) * sizeof(double) +
-                            static_cast<size_t>(3) * pair_cap * sizeof(int);
+    const size_t lds_step = kamd::StepStatsLdsBytes(v);
     hipLaunchKernelGGL(kamd::StepStatsKernel, dim3(max_steps, n), dim3(256), lds_step, st, v, b);
     const size_t lds_solve = (static_cast<size_t>(v.Q) + 6 * kamd::IV_MAX_DIM) * sizeof(double);
     hipLaunchKernelGGL(kamd::SolveKernel, dim3(n), dim3(256), lds_solve, st, v, b);

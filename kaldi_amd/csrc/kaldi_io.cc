@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include <new>
+
 #include "common.h"
 
 namespace {
@@ -28,6 +30,15 @@ struct File {
   bool Bytes(void *p, size_t n) { return n == 0 || fread(p, 1, n, f) == n; }
   int Get() { return fgetc(f); }
   int Peek() { int c = fgetc(f); if (c != EOF) ungetc(c, f); return c; }
+  // can the file still hold `bytes`?  Asked BEFORE allocating for a count read from a header, so that a corrupt one
+  // fails here and not in a multi-gigabyte resize (a stream that cannot seek gets the benefit of the doubt up to 2 GB)
+  bool Holds(uint64_t bytes) {
+    const long here = ftell(f);
+    if (here < 0 || fseek(f, 0, SEEK_END) != 0) return bytes <= (1ull << 31);
+    const long end = ftell(f);
+    (void)fseek(f, here, SEEK_SET);
+    return end >= here && bytes <= static_cast<uint64_t>(end - here);
+  }
 };
 
 int Fail(const char *what, const char *path) { return kamd::SetError(KAMD_ERR_ARG, "%s: %s", what, path ? path : ""); }
@@ -52,6 +63,7 @@ bool ReadMatrixBody(File *f, bool binary, std::vector<float> *data, int32_t *row
     if (tok == "FM" || tok == "DM") {
       if (!ReadI32(f, rows) || !ReadI32(f, cols) || *rows < 0 || *cols < 0) { *err = "bad matrix size"; return false; }
       const size_t n = static_cast<size_t>(*rows) * *cols;
+      if (!f->Holds(static_cast<uint64_t>(n) * (tok == "FM" ? 4 : 8))) { *err = "matrix size exceeds the file size"; return false; }
       data->resize(n);
       if (tok == "FM") { if (!f->Bytes(data->data(), n * 4)) { *err = "truncated matrix"; return false; } }
       else {
@@ -65,6 +77,7 @@ bool ReadMatrixBody(File *f, bool binary, std::vector<float> *data, int32_t *row
       if (!ReadI32(f, cols) || *cols < 0) { *err = "bad vector size"; return false; }
       *rows = 1;
       const size_t n = static_cast<size_t>(*cols);
+      if (!f->Holds(static_cast<uint64_t>(n) * (tok == "FV" ? 4 : 8))) { *err = "vector size exceeds the file size"; return false; }
       data->resize(n);
       if (tok == "FV") { if (!f->Bytes(data->data(), n * 4)) { *err = "truncated vector"; return false; } }
       else {
@@ -80,6 +93,7 @@ bool ReadMatrixBody(File *f, bool binary, std::vector<float> *data, int32_t *row
       if (!f->Bytes(&h, sizeof(h)) || h.num_rows < 0 || h.num_cols < 0) { *err = "bad compressed header"; return false; }
       *rows = h.num_rows; *cols = h.num_cols;
       const size_t R = h.num_rows, C = h.num_cols;
+      if (!f->Holds(static_cast<uint64_t>(R) * C * (tok == "CM2" ? 2 : 1))) { *err = "compressed matrix size exceeds the file size"; return false; }
       data->assign(R * C, 0.0f);
       if (C == 0) return true;
       auto u16 = [&](uint16_t v) { return h.min_value + h.range * 1.52590218966964e-05F * v; };   // :371-377
@@ -250,7 +264,11 @@ int kamd_ark_read_matrix(const char *path, int64_t *offset, char *key, int key_c
   if (f.Peek() == '\0') { f.Get(); if (f.Get() != 'B') return Fail("bad binary marker", path); binary = true; }
   std::vector<float> m;
   std::string err;
-  if (!ReadMatrixBody(&f, binary, &m, rows, cols, &err)) return kamd::SetError(KAMD_ERR_ARG, "%s: key %s: %s", path, shown, err.c_str());
+  try {
+    if (!ReadMatrixBody(&f, binary, &m, rows, cols, &err)) return kamd::SetError(KAMD_ERR_ARG, "%s: key %s: %s", path, shown, err.c_str());
+  } catch (const std::bad_alloc &) {      // no exception may cross the C ABI
+    return kamd::SetError(KAMD_ERR_ARG, "%s: key %s: out of host memory reading a %d x %d matrix", path, shown, *rows, *cols);
+  }
   *offset = ftell(f.f);
   *data = static_cast<float *>(malloc(sizeof(float) * (m.size() + 1)));
   if (!*data) return kamd::SetError(KAMD_ERR_ARG, "out of host memory");
@@ -308,6 +326,7 @@ int kamd_ark_read_int32_vector(const char *path, int64_t *offset, char *key, int
     // WriteBasicType of every element (each with its own size byte)
     int32_t cnt;
     if (f.Get() != 'B' || !ReadI32(&f, &cnt) || cnt < 0) return Fail("bad binary int32 vector", path);
+    if (!f.Holds(static_cast<uint64_t>(cnt) * 5)) return Fail("int32 vector size exceeds the file size", path);
     v.resize(cnt);
     for (int32_t i = 0; i < cnt; i++) if (!ReadI32(&f, &v[i])) return Fail("truncated int32 vector", path);
   } else if (c == ' ') {

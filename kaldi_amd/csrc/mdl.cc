@@ -60,15 +60,23 @@ struct Stream {
   void Expect(const char *tok) { const std::string t = Token(); if (t != tok) Fail(std::string("expected ") + tok + ", got " + t); }
   int32_t I32() { if (*Take(1) != 4) Fail("int32 expected"); int32_t v; memcpy(&v, Take(4), 4); return v; }
   float F32() { if (*Take(1) != 4) Fail("float expected"); float v; memcpy(&v, Take(4), 4); return v; }
+  // a count read from the file, checked against what the file can still hold (min_bytes per element) BEFORE anything is
+  // allocated for it: a corrupt header must fail here, not in a multi-gigabyte resize
+  size_t Count(int64_t n, size_t min_bytes, const char *what) {
+    if (n < 0) Fail(std::string("negative ") + what);
+    if (static_cast<uint64_t>(n) > (b.size() - p) / (min_bytes ? min_bytes : 1)) Fail(std::string("unexpected end of file: ") + what + " exceeds what is left of it");
+    return static_cast<size_t>(n);
+  }
   std::vector<int32_t> IntVector() {              // WriteIntegerVector (base/io-funcs-inl.h:198-229)
     if (*Take(1) != 4) Fail("integer vector expected");
     int32_t n; memcpy(&n, Take(4), 4);
-    if (n < 0) Fail("negative vector size");
+    Count(n, 4, "integer vector size");
     std::vector<int32_t> v(n);
     if (n) memcpy(v.data(), Take(4 * static_cast<size_t>(n)), 4 * static_cast<size_t>(n));
     return v;
   }
   void Floats(bool dbl, size_t n, std::vector<float> *out) {
+    Count(static_cast<int64_t>(n), dbl ? 8 : 4, "matrix / vector size");
     out->resize(n);
     if (!dbl) { if (n) memcpy(out->data(), Take(4 * n), 4 * n); return; }
     const unsigned char *q = Take(8 * n);
@@ -90,6 +98,7 @@ struct Stream {
     Value v; v.kind = Value::kMatrix;
     v.rows = I32(); v.cols = I32();
     if (v.rows < 0 || v.cols < 0) Fail("negative matrix size");
+    if (v.cols > 0 && static_cast<uint64_t>(v.rows) > b.size() / static_cast<uint64_t>(v.cols)) Fail("unexpected end of file: matrix size exceeds what is left of it");
     Floats(t == "DM", static_cast<size_t>(v.rows) * v.cols, &v.data);
     return v;
   }
@@ -196,15 +205,15 @@ void ReadTransitionModel(Stream *s, Model *m) {
   bool is_hmm = true;
   if (n == -1) { is_hmm = false; n = s->I32(); }
   struct St { int fwd, slf; std::vector<std::pair<int, float> > trans; };
-  std::vector<std::vector<St> > entries(n);
+  std::vector<std::vector<St> > entries(s->Count(n, 5, "topology entry count"));      // (an entry is at least its state count: 5 bytes)
   for (int e = 0; e < n; e++) {
     const int ns = s->I32();
-    entries[e].resize(ns);
+    entries[e].resize(s->Count(ns, 10, "HMM state count"));                             // (a state: pdf class + transition count)
     for (int k = 0; k < ns; k++) {
       St &st = entries[e][k];
       st.fwd = s->I32();
       st.slf = is_hmm ? st.fwd : s->I32();
-      const int nt = s->I32();
+      const int nt = static_cast<int>(s->Count(s->I32(), 10, "transition count"));
       for (int t = 0; t < nt; t++) { const int dst = s->I32(); const float pr = s->F32(); st.trans.push_back(std::make_pair(dst, pr)); }
     }
   }
@@ -212,7 +221,7 @@ void ReadTransitionModel(Stream *s, Model *m) {
   const std::string tok = s->Token();
   if (tok != "<Triples>" && tok != "<Tuples>") Fail("expected <Triples> or <Tuples>, got " + tok);
   struct Tup { int ph, hs, fp, sp; };
-  std::vector<Tup> tuples(s->I32());
+  std::vector<Tup> tuples(s->Count(s->I32(), 15, "tuple count"));
   for (Tup &t : tuples) { t.ph = s->I32(); t.hs = s->I32(); t.fp = s->I32(); t.sp = tok == "<Triples>" ? t.fp : s->I32(); }
   s->Expect(tok == "<Triples>" ? "</Triples>" : "</Tuples>");
   s->Expect("<LogProbs>"); s->Vector(); s->Expect("</LogProbs>");

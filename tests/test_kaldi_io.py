@@ -155,3 +155,21 @@ def test_wave_reader_reference_known_answers(tmp_path, name, args, hz, want):
     assert sf == hz
     np.testing.assert_array_equal(data, np.asarray(want, np.float32))
     assert abs(data.shape[1] / sf - len(want[0]) / hz) < 1e-6           # Duration()
+
+
+def test_corrupt_counts_fail_before_anything_is_allocated(tmp_path):
+    """A header that announces more data than the file holds is an error message, not a multi-gigabyte allocation (and
+    no exception crosses the C ABI)."""
+    p = tmp_path / "huge.ark"
+    p.write_bytes(b"utt \0BFM \x04" + struct.pack("<i", 2000000000) + b"\x04" + struct.pack("<i", 2000000000) + b"\0" * 64)
+    with pytest.raises(KamdError, match="exceeds the file size"):
+        list(kio.read_matrix_ark(p))
+    p.write_bytes(b"utt \0BDV \x04" + struct.pack("<i", 2000000000) + b"\0" * 64)
+    with pytest.raises(KamdError, match="exceeds the file size"):
+        list(kio.read_matrix_ark(p))
+    p.write_bytes(b"utt \0BCM2 " + struct.pack("<ffii", 0.0, 1.0, 1000000, 1000000) + b"\0" * 64)
+    with pytest.raises(KamdError, match="exceeds the file size"):
+        list(kio.read_matrix_ark(p))
+    p.write_bytes(b"utt \0B\x04" + struct.pack("<i", 2000000000) + b"\x04" + struct.pack("<i", 7))
+    with pytest.raises(KamdError, match="exceeds the file size"):
+        list(kio.read_int32_vector_ark(p))

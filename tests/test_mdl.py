@@ -206,6 +206,13 @@ def test_native_reader_errors_name_the_problem(tmp_path):
     (tmp_path / "cut.mdl").write_bytes(blob[:len(blob) // 2])
     with pytest.raises(mdl.MdlError, match="unexpected end of file"):
         mdl.read_mdl_native(tmp_path / "cut.mdl")
+    # a count that the file cannot hold is refused before anything is sized by it: the <Tuples> count patched to 2^31 - 1
+    at = blob.index(b"<Tuples> ") if b"<Tuples> " in blob else blob.index(b"<Triples> ")
+    at = blob.index(b" ", at) + 1
+    assert blob[at] == 4
+    (tmp_path / "count.mdl").write_bytes(blob[:at + 1] + (2 ** 31 - 1).to_bytes(4, "little") + blob[at + 5:])
+    with pytest.raises(mdl.MdlError, match="tuple count exceeds"):
+        mdl.read_mdl_native(tmp_path / "count.mdl")
     bad = blob.replace(b"<RectifiedLinearComponent>", b"<SigmoidBlahBlahComponent>").replace(b"</RectifiedLinearComponent>", b"</SigmoidBlahBlahComponent>")
     assert bad != blob
     (tmp_path / "bad.mdl").write_bytes(bad)
