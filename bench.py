@@ -94,6 +94,7 @@ def parse_args():
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the cpu_baseline leg (0 = min(cores, 32))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-wer", action="store_true")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the configs[4] streaming leg")
     ap.add_argument("--wer-utts", type=int, default=64)
     ap.add_argument("--search-mode", type=int, default=2, choices=[1, 2], help="kamd_decoder_set_search_mode: 1 canonical (tight), "
                     "2 canonical-loose (every token the reference's order-dependent pruning can create)")
@@ -290,15 +291,24 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
     a0 = waves[order[0]].size / 16000.0
     rate = a0 / max(t_first, 1e-6)
     audio_budget = rate * budget_s * cores * 0.6
-    sample, audio = [], 0.0
-    for idx in order:                                        # shortest first: >= 4 utterances per thread where the set allows
-        a = waves[idx].size / 16000.0
-        if len(sample) >= 4 * cores and audio + a > audio_budget:
-            break
-        sample.append(idx)
-        audio += a
-        if len(sample) >= len(order):
-            break
+    # duration-stratified sample: every k-th utterance of the duration-sorted set, k sized to the budget -- short and long
+    # utterances in the set's own proportions (the shortest-400 sample of round 3 had another edge-frame / search mix)
+    total_audio = sum(w.size for w in waves) / 16000.0
+    k_strat = max(1, int(np.ceil(total_audio / max(audio_budget, 1e-9))))
+    if len(order) // k_strat < cores:                        # never fewer utterances than threads
+        k_strat = max(1, len(order) // cores)
+    sample = order[k_strat // 2::k_strat]
+    audio = sum(waves[i].size for i in sample) / 16000.0
+    # the single-threaded whole path (= nnet3-latgen-faster, src/nnet3bin/nnet3-latgen-faster.cc:140,255-263) on a sparser
+    # stratified sample worth ~8 s of one core
+    k_one = max(k_strat, int(np.ceil(total_audio / max(rate * 8.0, 1e-9))))
+    sample_one = order[k_one // 2::k_one]
+    audio_one = sum(waves[i].size for i in sample_one) / 16000.0
+    t0 = time.time()
+    for idx in sample_one:
+        whole(idx)
+    t_one = time.time() - t0
+    stage_s[:] = [0.0, 0.0, 0.0]
     # longest of the sample first, so the tail of the run is made of the short ones
     sample.sort(key=lambda i: -waves[i].size)
     ll_cache = {i: bd.loglikes(i) for i in sample}
@@ -345,10 +355,14 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
             "stage_share": {"features": stage_s[0] / tot, "nnet": stage_s[1] / tot, "decoder_and_best_path": stage_s[2] / tot},
             "nnet_only_per_core": {"sgemm": a0 / max(t_blas_nnet, 1e-9) if have_blas else None, "scalar_oracle": a0 / max(t_scalar_nnet, 1e-9),
                                    "what": "audio seconds per second of the acoustic model alone on one core (the shortest utterance)"},
-            "sample": "the %d shortest utterances of the test set (%.1f s audio) on %d threads pulling from one list, %.1f s "
-                      "wall, %.1f core-s: whole path MFCC + nnet (%s) + LatticeFasterDecoder (order-faithful oracle, mode 0) + best "
-                      "path; single-utterance probe %.2f s" % (len(sample), audio, used, wall_w, busy_w,
-                                                               "sgemm" if have_blas else "scalar", t_first),
+            "sample": "duration-stratified: every %d-th utterance of the duration-sorted test set, %d utterances (%.1f s audio, %.1f-%.1f s "
+                      "each) on %d threads pulling from one list (longest first), %.1f s wall, %.1f core-s: whole path MFCC + nnet (%s) + "
+                      "LatticeFasterDecoder (order-faithful oracle, mode 0) + best path; single-utterance probe %.2f s" %
+                      (k_strat, len(sample), audio, min(waves[i].size for i in sample) / 16000.0, max(waves[i].size for i in sample) / 16000.0,
+                       used, wall_w, busy_w, "sgemm" if have_blas else "scalar", t_first),
+            "single_thread": {"value": audio_one / max(t_one, 1e-9), "cores": 1, "utterances": len(sample_one), "audio_s": audio_one, "wall_s": t_one,
+                              "what": "the same whole path, one utterance after the other on ONE thread (nnet3-latgen-faster's own shape), "
+                                      "every %d-th utterance of the duration-sorted set" % k_one},
             "decoder_only": {"value": audio / max(wall_d, 1e-9), "per_core_value": audio / max(busy_d, 1e-9), "cores": used,
                              "wall_s": wall_d,
                              "what": "the CPU decoder alone (mode 0) on the device's log-likelihoods of the same utterances"},
@@ -514,7 +528,7 @@ def main():
         frames = int(counters[6])
         dec = {"frames": frames, "tokens_per_frame": counters[5] / max(frames, 1), "expanded_per_frame": counters[0] / max(frames, 1),
                "arcs_per_frame": counters[1] / max(frames, 1), "links_per_frame": counters[4] / max(frames, 1),
-               "failed_utterances": sum(1 for r in recs if r.error)}
+               "failed_utterances": sum(1 for r in recs if r.error), "failures": failure_report(recs)}
         alg = float(algorithmic_bytes(counters))
         dec_ms = float(acc[2])
         roof = {"bound": "hbm", "kernel": "kamd::DecodeQueueKernel", "achieved": alg / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
@@ -522,6 +536,10 @@ def main():
                 "traffic_source": "profiles/*_pmc.json taken on this workload with this library build (rocprofv3 --pmc passes), not this run; null otherwise",
                 "algorithmic_bytes_per_launch": alg, "launch_ms": dec_ms, "lanes": int(st.lanes),
                 "us_per_frame_per_lane": 1e3 * dec_ms * int(st.lanes) / max(frames, 1)}
+        roof.update(search_counter_view(args, counters, dec_ms))
+        roof["reading"] = ("`frac` is the contract figure: SURVEY 8(d)'s algorithmic bytes over the launch time.  The kernel moves fewer bytes than "
+                           "that formula prices and is bound by dependent memory round trips, not bandwidth: see counter_frac (PMC bytes / launch / "
+                           "peak), wait_fraction (SQ_WAIT_ANY / SQ_WAVE_CYCLES) and write_amplification (WRITE_SIZE / algorithmic writes)")
         return recs, dec, roof
 
     # ------------------------------------------------------------------ the headline load
@@ -698,6 +716,13 @@ def main():
             out["planted"] = planted_variant(args, g, model, cfg, durs, make_decoder, timed, latbin, synth, log)
         except Exception as e:                      # noqa: BLE001
             out["planted"] = {"error": repr(e)}
+    if one and not args.no_streaming:
+        log("streaming leg ...")
+        gc.collect()
+        try:
+            out["streaming"] = streaming_leg(log)
+        except Exception as e:                      # noqa: BLE001
+            out["streaming"] = {"error": repr(e)}
     if not args.no_wer and one:
         log("wer leg ...")
         gc.collect()
@@ -707,6 +732,32 @@ def main():
             out["wer"] = {"error": repr(e)}
     print(json.dumps(out, default=float))
     sys.stdout.flush()
+
+
+def streaming_leg(log, streams=256, seconds=12.0, chunk=0.24):
+    """BASELINE configs[4]: online2-wav-nnet3-latgen-faster (src/online2bin/online2-wav-nnet3-latgen-faster.cc:107,211-285) --
+    audio arrives in 240 ms chunks, features, looped acoustic model and AdvanceDecoding run on the device per chunk.  Two passes
+    of tools/online_latency.py: one stream (latency per chunk, a partial best path after each), and `streams` concurrent streams
+    through kamd_stream_batch with the recipe's online i-vectors, silence weighting and incremental partial results on."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import gc
+    import online_latency as ol
+    t0 = time.time()
+    g, _, N, G, cfg, _ = ol.build(1.3, False, seconds)
+    one = ol.single_stream(N, G, cfg, seconds, chunk)
+    del N, G
+    gc.collect()
+    log("streaming: one stream done")
+    g, _, N, G, cfg, ie = ol.build(1.3, True, seconds)
+    many = ol.many_streams(g, N, G, cfg, ie, streams, seconds, chunk, partials=True, partials_incremental=True, silence_weighting=True)
+    del N, G, ie
+    gc.collect()
+    return {"ms_per_chunk": one["ms_per_chunk"], "x_rt": one["x_rt"], "partial_ms": one["partial_ms"],
+            "ms_per_tick_%d" % streams: many["ms_per_tick"], "aggregate_x_rt": many["aggregate_x_rt"], "finalize_ms": many["finalize_ms"],
+            "one_stream": one, "streams_%d" % streams: many, "leg_wall_s": time.time() - t0,
+            "what": "mini_librispeech-sized TDNN-F, 20 k-word synthetic HCLG, %.0f s of audio per stream in %.0f ms chunks; host wall clock around "
+                    "AcceptWaveform + AdvanceDecoding (device sync included); the %d-stream pass runs online i-vector estimation, silence weighting and "
+                    "incremental partial best paths of every stream per tick" % (seconds, chunk * 1e3, streams)}
 
 
 def planted_variant(args, g, model, cfg, durs, make_decoder, timed, latbin, synth, log):
@@ -763,6 +814,7 @@ def planted_variant(args, g, model, cfg, durs, make_decoder, timed, latbin, synt
            "stage_ms": {"features": acc[0], "nnet": acc[1], "decode_queue_kernel": acc[2], "total_wall": acc[4]},
            "tokens_per_frame": counters[5] / fr_tot, "expanded_per_frame": counters[0] / fr_tot, "arcs_per_frame": counters[1] / fr_tot,
            "us_per_frame_per_lane": 1e3 * float(acc[2]) * int(st.lanes) / fr_tot, "failed_utterances": sum(1 for r in recs if r.error),
+           "failures": failure_report(recs),
            "peak": args.planted_peak, "noise": args.planted_noise, "synthesis_s": t_synth,
            "phase_share_longest_utterance": (lambda ph: {k2: round(float(v / max(ph.sum(), 1.0)), 3) for k2, v in zip(PHASES, ph)})(
                np.asarray(recs[int(np.argmax([r.n_frames for r in recs]))].phase_cycles[:len(PHASES)], np.float64)),
@@ -773,6 +825,20 @@ def planted_variant(args, g, model, cfg, durs, make_decoder, timed, latbin, synt
     del bd, planted
     gc.collect()
     return res
+
+
+ERROR_FLAGS = ((1, "level-2 table full"), (2, "token arena full"), (4, "link arena full"), (8, "more frames than max_frames"),
+               (16, "worklist full"), (32, "internal"), (64, "lattice pool full"))
+
+
+def failure_report(recs, limit=16):
+    """Per failed utterance: index, frames and the reasons (the lane's error flags, kaldi_amd/csrc/decoder.hip ERR_*)."""
+    out = []
+    for u, r in enumerate(recs):
+        if r.error:
+            out.append({"utt": u, "frames": int(r.n_frames), "flags": int(r.error),
+                        "why": [name for bit, name in ERROR_FLAGS if r.error & bit] or ["host tail"]})
+    return out[:limit]
 
 
 def library_build_id():
@@ -787,9 +853,9 @@ def library_build_id():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(args, which):
-    """HBM bytes per step of one kernel family ("decode_queue": one DecodeQueueKernel launch; "gemm_all_layers") from the
-    committed rocprofv3 PMC passes (profiles/*_pmc.json), only when they were taken on this exact workload."""
+def pmc_entry(args):
+    """The committed rocprofv3 PMC passes (profiles/*_pmc.json) of this exact workload AND this exact library build, or None:
+    counters are collected in separate profiler runs (tools/profile_round*.sh), never inside a bench run."""
     key = "%s/%s/%d/%s/%s" % (args.workload, args.graph, args.utts, args.ll_std, args.lm_scale)
     build = library_build_id()
     best = None
@@ -801,9 +867,33 @@ def pmc_traffic(args, which):
                     d = json.load(open(os.path.join(pdir, f)))
                 except Exception:
                     continue
-                if d.get("workload_key") == key and d.get("library_build") == build and which in d:
-                    best = d[which].get("traffic_bytes_per_step")
+                if d.get("workload_key") == key and d.get("library_build") == build:
+                    best = dict(d, file=f)
     return best
+
+
+def pmc_traffic(args, which):
+    """HBM bytes per step of one kernel family ("decode_queue": one DecodeQueueKernel launch; "gemm_all_layers")."""
+    d = pmc_entry(args)
+    return d[which].get("traffic_bytes_per_step") if d and which in d else None
+
+
+def search_counter_view(args, counters, dec_ms):
+    """What the PMC passes say about the search kernel, in the terms of the roofline object: the
+    algorithmic `frac` prices bytes the kernel no longer moves (8-byte hot arc records instead of 16 + 4), so the line also
+    carries the measured traffic as a fraction of peak, the wait fraction of the wavefront cycles and the write amplification.
+    Everything but arcs_per_expanded_token is None unless profiles/ holds passes of this workload taken on this build."""
+    out = {"arcs_per_expanded_token": float(counters[1] / max(counters[0], 1.0)), "counter_frac": None, "wait_fraction": None,
+           "l2_hit_rate": None, "write_amplification": None, "read_bytes_upper_bound": None, "written_bytes": None, "pmc_file": None}
+    d = pmc_entry(args)
+    if d and "decode_queue" in d:
+        q = d["decode_queue"]
+        alg_writes = 20.0 * counters[4] + 12.0 * counters[5]            # SURVEY 8(d): links kept + tokens
+        out.update({"counter_frac": q["traffic_bytes_per_step"] / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "wait_fraction": d.get("decode_queue_wait_fraction"), "l2_hit_rate": d.get("decode_queue_l2_hit_rate"),
+                    "read_bytes_upper_bound": 2.0 * 1024.0 * q["FETCH_SIZE_KB_per_step"], "written_bytes": 1024.0 * q["WRITE_SIZE_KB_per_step"],
+                    "write_amplification": 1024.0 * q["WRITE_SIZE_KB_per_step"] / max(alg_writes, 1.0), "pmc_file": "profiles/" + d["file"]})
+    return out
 
 
 if __name__ == "__main__":

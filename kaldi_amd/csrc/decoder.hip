@@ -46,6 +46,14 @@ typedef unsigned int u32;
 #ifndef KAMD_SEARCH_WAVES_PER_EU
 #define KAMD_SEARCH_WAVES_PER_EU 4
 #endif
+// ... and the VGPR budget the register allocator gets for them.  A 1024-thread lane may use 128; the product is built for
+// KAMD_SEARCH_VGPRS = 120 and must not touch scratch memory at that (tests/test_kernel_resources.py), i.e. the kernels
+// carry 8 registers of head-room against the next compiler release or source edit.  ("amdgpu_num_vgpr" counts the unified
+// VGPR + AGPR file of gfx90a and later in halves: the attribute's argument is the budget divided by two.)
+#ifndef KAMD_SEARCH_VGPRS
+#define KAMD_SEARCH_VGPRS 120
+#endif
+#define KAMD_SEARCH_KERNEL __global__ __launch_bounds__(NT, KAMD_SEARCH_WAVES_PER_EU) __attribute__((amdgpu_num_vgpr(KAMD_SEARCH_VGPRS / 2)))
 #define LANES_PER_CU (1024 / NT)
 #define NWAVES (NT / 64)
 #define EXPT 3            // tokens per thread whose records are fetched together (EXPT * NT == BIGCAP)
@@ -60,6 +68,18 @@ typedef unsigned int u32;
 #define CHUNKCAP (4 * NT)    // cached chunk owners (16 arcs each) per flatten batch
 static_assert(NT == 1024 || NT == 512, "KAMD_NT: 1024 (one lane per CU) or 512 (two)");
 #define EMPTY64 0xFFFFFFFFFFFFFFFFull
+
+// threadIdx.x through a pointer-free barrier the optimiser cannot see through.  Inside a lane's frame loop everything
+// that depends only on the thread id -- lane masks (tid < 256, tid < 64, ...: an SGPR pair each), tid * 12, tid & 7,
+// addresses into the static LDS -- is loop invariant, and LICM hoists all of it in front of the loop: dozens of values
+// live across every phase of every frame, which is what filled the register files.  Read this
+// way the id is a new value at every call: what is derived from it lives where it is used.
+__device__ __forceinline__ int Tid() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  __builtin_assume(t >= 0 && t < KAMD_NT);
+  return t;
+}
 
 enum { ERR_HASH = 1, ERR_TOK = 2, ERR_LINK = 4, ERR_FRAMES = 8, ERR_WL = 16, ERR_INTERNAL = 32 };
 
@@ -139,6 +159,35 @@ __device__ inline Ctx MakeCtx(const DecDev &d, int lane) {
   return c;
 }
 
+// ---- phase-scoped views of the launch descriptors -------------------------------------------------------------
+// A search lane keeps ~100 uniform values alive (the DecDev fields, the lane's Ctx pointers, LDS regions) and hipcc
+// hoists every  base + tid * size  it can out of the loops.  Taken from the by-value kernel argument they are all live
+// from the kernel's entry to its end: 105-148 SGPR spills and a VGPR file full of loop-invariant 64-bit addresses,
+// i.e. a kernel one source edit away from spilling to scratch memory.  Instead every PHASE of
+// a frame (cutoff, expansion, inserts, commit) and every stage of an utterance (init, finalize, hand-over) re-reads
+// what it needs from the kernarg segment through a pointer the optimiser cannot see through: the s_load's (scalar
+// cache hits, a few hundred cycles per phase against ~10^5 per frame) cannot be hoisted above the phase's start, so
+// the descriptors -- and everything derived from them -- are live inside one phase only.
+// Every kernel that uses this has the DecDev as its FIRST parameter (kernarg offset 0).
+template <typename T> using KPtr = const T __attribute__((address_space(4))) *;
+__device__ __forceinline__ DecDev LoadDecDev() {
+  KPtr<DecDev> p = (KPtr<DecDev>)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const DecDev *)p;
+}
+// a second by-value parameter that directly follows the DecDev
+template <typename T>
+__device__ __forceinline__ T LoadSecondArg() {
+  typedef const unsigned char __attribute__((address_space(4))) *KBytes;
+  KBytes b = (KBytes)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DecDev) + alignof(T) - 1) / alignof(T)) * alignof(T);
+  KPtr<T> p = (KPtr<T>)b;
+  asm volatile("" : "+s"(p));
+  return *(const T *)p;
+}
+// the same for a value the kernel already holds in SGPRs (a lane number, a task): what is derived from it after this
+// point cannot be computed before it
+__device__ __forceinline__ int Opaque(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
+
 struct Sh {  // workgroup-shared state
   u64 red64[NWAVES];
   int redi[NWAVES];
@@ -170,7 +219,7 @@ struct Sh {  // workgroup-shared state
 enum { PH_FIN_FETCH = 0, PH_CUTOFF, PH_SEED, PH_EXPAND, PH_EXPAND_BIG, PH_EPS_CLOSURE, PH_COMPACT,
        PH_FIXUP, PH_EPS_LINKS, PH_CLEAR, PH_FIN_SWEEP, PH_FIN_COMPACT, PH_FLAT_SETUP, PH_FIN_EMIT, PH_FIN_EPS, PH_FIN_STAGE };
 __device__ inline void Stamp(Sh *sh, int idx) {   // call right after a barrier
-  if (threadIdx.x == 0) {
+  if (Tid() == 0) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
     sh->ph[idx] += now - sh->t_prev;
     sh->t_prev = now;
@@ -216,7 +265,7 @@ __device__ inline bool HasEps(int flagged) { return (static_cast<u32>(flagged) &
 // ds_bpermute, ~100 cycles through the LDS crossbar, on every call of the inner loops).
 __device__ inline int WaveAlloc(int *counter) {
   const u64 m = __ballot(1);
-  const int lane = threadIdx.x & 63;
+  const int lane = Tid() & 63;
   const int leader = __ffsll(static_cast<long long>(m)) - 1;
   int base = 0;
   if (lane == leader) base = atomicAdd(counter, __popcll(m));
@@ -252,7 +301,7 @@ __device__ inline int WaveInclScanI(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
   const int t0 = __builtin_amdgcn_readlane(v, 15), t1 = __builtin_amdgcn_readlane(v, 31), t2 = __builtin_amdgcn_readlane(v, 47);
-  const int row = (threadIdx.x & 63) >> 4;
+  const int row = (Tid() & 63) >> 4;
   return v + (row > 0 ? t0 : 0) + (row > 1 ? t1 : 0) + (row > 2 ? t2 : 0);
 }
 __device__ inline u64 WaveMin64(u64 v) {
@@ -273,7 +322,7 @@ __device__ inline u64 WaveMin64(u64 v) {
 __device__ inline u64 BlockMin64(u64 v, Sh *sh) {
   v = WaveMin64(v);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh->red64[threadIdx.x >> 6] = v;
+  if ((Tid() & 63) == 0) sh->red64[Tid() >> 6] = v;
   __syncthreads();
   u64 r = sh->red64[0];
   for (int i = 1; i < NWAVES; i++) r = sh->red64[i] < r ? sh->red64[i] : r;
@@ -284,7 +333,7 @@ template <bool kLdsOnly = false>
 __device__ inline void BlockSum2(int &a, int &b, Sh *sh) {
   a = WaveSumI(a); b = WaveSumI(b);
   Bar<kLdsOnly>();
-  if ((threadIdx.x & 63) == 0) { sh->redi[threadIdx.x >> 6] = a; sh->redj[threadIdx.x >> 6] = b; }
+  if ((Tid() & 63) == 0) { sh->redi[Tid() >> 6] = a; sh->redj[Tid() >> 6] = b; }
   Bar<kLdsOnly>();
   a = 0; b = 0;
   for (int i = 0; i < NWAVES; i++) { a += sh->redi[i]; b += sh->redj[i]; }
@@ -293,8 +342,8 @@ template <bool kLdsOnly = false>
 __device__ inline void BlockSum4(int &a, int &b, int &c2, int &d2, Sh *sh) {
   a = WaveSumI(a); b = WaveSumI(b); c2 = WaveSumI(c2); d2 = WaveSumI(d2);
   Bar<kLdsOnly>();
-  if ((threadIdx.x & 63) == 0) {
-    const int w = threadIdx.x >> 6;
+  if ((Tid() & 63) == 0) {
+    const int w = Tid() >> 6;
     sh->redi[w] = a; sh->redj[w] = b; sh->redk[w] = c2; sh->redl[w] = d2;
   }
   Bar<kLdsOnly>();
@@ -305,7 +354,7 @@ template <bool kLdsOnly = false>
 __device__ inline float BlockMinF(float v, Sh *sh) {
   v = WaveMinF(v);
   Bar<kLdsOnly>();
-  if ((threadIdx.x & 63) == 0) sh->redf[threadIdx.x >> 6] = v;
+  if ((Tid() & 63) == 0) sh->redf[Tid() >> 6] = v;
   Bar<kLdsOnly>();
   float r = sh->redf[0];
   for (int i = 1; i < NWAVES; i++) r = fminf(r, sh->redf[i]);
@@ -314,7 +363,7 @@ __device__ inline float BlockMinF(float v, Sh *sh) {
 // deterministic (index ordered) exclusive scan of a 0/1 flag over the workgroup
 __device__ inline int BlockScanFlag(bool f, int *total, Sh *sh) {
   const u64 m = __ballot(f);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = Tid() & 63, w = Tid() >> 6;
   __syncthreads();
   if (lane == 0) sh->redi[w] = __popcll(m);
   __syncthreads();
@@ -327,7 +376,7 @@ __device__ inline int BlockScanFlag(bool f, int *total, Sh *sh) {
 // wavefront-aggregated histogram add (costs of one frame cluster in few digits)
 __device__ inline void WaveHistAdd(u32 *hist, int bin, bool active) {
   u64 todo = __ballot(active);
-  const int lane = threadIdx.x & 63;
+  const int lane = Tid() & 63;
   while (todo) {
     const int leader = __ffsll(static_cast<long long>(todo)) - 1;
     const int lb = __shfl(bin, leader, 64);
@@ -344,14 +393,14 @@ typedef __attribute__((address_space(3))) const float lds_cfloat;
 // position k (lattice-faster-decoder.cc:693-697, 707-712).  4-pass 8-bit radix select
 // on order-preserving keys with an LDS histogram.
 template <typename SrcPtr>
-__device__ float BlockSelectKth(SrcPtr cost, int n, int k, Sh *sh) {
+__device__ __forceinline__ float BlockSelectKth(SrcPtr cost, int n, int k, Sh *sh) {
   u32 prefix = 0, mask = 0;
   for (int shift = 24; shift >= 0; shift -= 8) {
     __syncthreads();
-    if (threadIdx.x < 256) sh->hist[threadIdx.x] = 0;
+    if (Tid() < 256) sh->hist[Tid()] = 0;
     __syncthreads();
     for (int base = 0; base < n; base += NT) {
-      int i = base + threadIdx.x;
+      int i = base + Tid();
       bool act = false; int bin = 0;
       if (i < n) {
         u32 key = FloatToOrdered(cost[i]);
@@ -361,8 +410,8 @@ __device__ float BlockSelectKth(SrcPtr cost, int n, int k, Sh *sh) {
       WaveHistAdd(sh->hist, bin, act);
     }
     __syncthreads();
-    if (threadIdx.x < 64) {   // one wavefront: 4 bins per lane, shuffle scan, locate rank k
-      const int l = threadIdx.x;
+    if (Tid() < 64) {   // one wavefront: 4 bins per lane, shuffle scan, locate rank k
+      const int l = Tid();
       const int h0 = sh->hist[4 * l], h1 = sh->hist[4 * l + 1], h2 = sh->hist[4 * l + 2], h3 = sh->hist[4 * l + 3];
       const int mine = h0 + h1 + h2 + h3;
       int incl = mine;
@@ -391,19 +440,19 @@ __device__ float BlockSelectKth(SrcPtr cost, int n, int k, Sh *sh) {
                             // log-likelihood row 4 KB of LDS: 6000 pdfs no longer fit beside the tables)
 #define LHCAND NT
 template <typename SrcPtr>
-__device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float beam,
+__device__ __forceinline__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float beam,
                                    u32 *lh /* [LHBINS] LDS */, float *cand /* [LHCAND] LDS */, Sh *sh) {
   const float scale = static_cast<float>(LHBINS) / beam;
-  for (int i = threadIdx.x; i < LHBINS; i += NT) lh[i] = 0;
+  for (int i = Tid(); i < LHBINS; i += NT) lh[i] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += NT) {
+  for (int i = Tid(); i < n; i += NT) {
     const float b = (src[i] - best) * scale;
     if (b < static_cast<float>(LHBINS)) atomicAdd(&lh[b < 0.f ? 0 : static_cast<int>(b)], 1u);
   }
   __syncthreads();
   // locate the bucket of rank k: 3 buckets per thread, workgroup scan
   {
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = Tid(), lane = t & 63, w = t >> 6;
     const int h0 = lh[3 * t], h1 = lh[3 * t + 1], h2 = lh[3 * t + 2];
     const int mine = h0 + h1 + h2;
     const int incl = WaveInclScanI(mine);
@@ -424,7 +473,7 @@ __device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float b
   const int bin = sh->sel_bin, below = sh->sel_below, members = sh->changed;
   if (bin < 0 || members > LHCAND) return BlockSelectKth(src, n, k, sh);   // uniform decision
   // gather the bucket's members
-  for (int i = threadIdx.x; i < n; i += NT) {
+  for (int i = Tid(); i < n; i += NT) {
     const float v = src[i];
     const float b = (v - best) * scale;
     if (b < static_cast<float>(LHBINS) && (b < 0.f ? 0 : static_cast<int>(b)) == bin) {
@@ -435,9 +484,9 @@ __device__ float BlockSelectLinear(SrcPtr src, int n, int k, float best, float b
   __syncthreads();
   const int m = sh->scan_total, kk = k - below;     // kk-th smallest of the m members
   __syncthreads();
-  if (threadIdx.x == 0) sh->sel_below = 0;
+  if (Tid() == 0) sh->sel_below = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < m; i += NT) {
+  for (int i = Tid(); i < m; i += NT) {
     const float v = cand[i];
     int less = 0, eq = 0;
     for (int j = 0; j < m; j++) { const float u = cand[j]; less += u < v; eq += u == v; }
@@ -570,18 +619,18 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
     Link L[INSB]; kamd_arc arc[INSB];
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
-      const int li = link_begin + threadIdx.x + (g0 + k) * NT;
+      const int li = link_begin + Tid() + (g0 + k) * NT;
       L[k] = c.links[min(li, le - 1)];          // (unconditional, clamped: see the expansion; le > link_begin here)
     }
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
-      const int li = link_begin + threadIdx.x + (g0 + k) * NT;
+      const int li = link_begin + Tid() + (g0 + k) * NT;
       // the record of the arc ProcessArcs kept by index (a clamped lane may see a link its owner has rewritten: arc 0)
       arc[k] = d.g.e_arcs[li < le ? static_cast<u32>(L[k].dst) : 0u];
     }
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
-      const int li = link_begin + threadIdx.x + (g0 + k) * NT;
+      const int li = link_begin + Tid() + (g0 + k) * NT;
       if (li >= le) continue;
       const float tot = __int_as_float(L[k].ilabel);      // == source cost + ac + graph, as ProcessArcs summed it
       int dst = -1;
@@ -671,9 +720,9 @@ __device__ inline float LogLike(const DecDev &d, const float *ll, int ilabel) {
 // ProcessNonemitting (lattice-faster-decoder.cc:833-899) as a fixpoint relaxation, then
 // commit the frame: compact surviving tokens into the arena, resolve emitting links,
 // emit epsilon links, clear the table.  'list' is the token-list index being created.
-__device__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
+__device__ __forceinline__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
                             int emit_link_begin, float *cost_cache, int cache_cap, int k_surv) {
-  const int tid = threadIdx.x;
+  const int tid = Tid();
   LaneState *S = c.st;
   __syncthreads();
   // ---- epsilon closure: initial worklist = every token with epsilon arcs (:855-859)
@@ -847,10 +896,10 @@ struct CommitLds {
 // barrier of the commit has to wait for global memory.
 // my_slot[k] = table slot of this thread's k-th recorded link (link_begin + tid + k*NT), or
 // -1: kept in registers from InsertEmitted so the links are not read back.
-__device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
+__device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
                              int emit_link_begin, float *cost_cache, int cache_cap, int k_surv,
                              const CommitLds &L, const int (&my_slot)[COMMIT_KEEP], bool loose) {
-  const int tid = threadIdx.x;
+  const int tid = Tid();
   LaneState *S = c.st;
   const int lcap = tbl.lcap;
   LdsBarrier();
@@ -1115,33 +1164,33 @@ __device__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t
 
 // best token and beam counts of token list 'list' (what CommitFrame leaves behind), for
 // the first frame of a launch
-__device__ void ComputeFrameStats(const DecDev &d, const Ctx &c, Sh *sh, int list, float *cost_cache,
+__device__ __forceinline__ void ComputeFrameStats(const DecDev &d, const Ctx &c, Sh *sh, int list, float *cost_cache,
                                   int cache_cap) {
   const int tb = c.tok_off[list], n = c.tok_off[list + 1] - tb;
   u64 key = EMPTY64;
-  for (int i = threadIdx.x; i < n; i += NT) {
+  for (int i = Tid(); i < n; i += NT) {
     const u64 k = (static_cast<u64>(FloatToOrdered(c.tok_cost[tb + i])) << 32) | static_cast<u32>(c.tok_state[tb + i]);
     key = k < key ? k : key;
   }
   key = BlockMin64(key, sh);
   const float bc = (n > 0 ? OrderedToFloat(static_cast<u32>(key >> 32)) : INFINITY) + d.cfg.beam;
   int c_lt = 0, c_le = 0;
-  for (int i = threadIdx.x; i < n; i += NT) {
+  for (int i = Tid(); i < n; i += NT) {
     const float w = c.tok_cost[tb + i];
     if (i < cache_cap) cost_cache[i] = w;
     c_lt += w < bc; c_le += w <= bc;
   }
   BlockSum2(c_lt, c_le, sh);
-  if (threadIdx.x == 0) { sh->best_key = key; sh->c_lt = c_lt; sh->c_le = c_le; }
+  if (Tid() == 0) { sh->best_key = key; sh->c_lt = c_lt; sh->c_le = c_le; }
   __syncthreads();
 }
 
 // ComputeFinalCosts (lattice-faster-decoder.cc:549-590) over token list 'list'
-__device__ void FinalCosts(const DecDev &d, const Ctx &c, Sh *sh, int list, float *best_cost,
+__device__ __forceinline__ void FinalCosts(const DecDev &d, const Ctx &c, Sh *sh, int list, float *best_cost,
                            float *best_with_final) {
   const int tb = c.tok_off[list], te = c.tok_off[list + 1];
   float b = INFINITY, bf = INFINITY;
-  for (int t = tb + threadIdx.x; t < te; t += NT) {
+  for (int t = tb + Tid(); t < te; t += NT) {
     const float cost = c.tok_cost[t];
     const float fc = d.g.final[c.tok_state[t]];
     b = fminf(b, cost);
@@ -1151,21 +1200,23 @@ __device__ void FinalCosts(const DecDev &d, const Ctx &c, Sh *sh, int list, floa
   *best_with_final = BlockMinF(bf, sh);
 }
 
-__device__ void PublishLaneEnd(const DecDev &d, const Ctx &c, Sh *sh, int frame) {
+__device__ __forceinline__ void PublishLaneEnd(const DecDev &d, const Ctx &c, Sh *sh, int frame) {
   float b, bf;
   FinalCosts(d, c, sh, frame, &b, &bf);
-  if (threadIdx.x == 0) {
-    LaneState *S = c.st;
+  LaneState *S = c.st;
+  const int tid = Tid();
+  if (tid == 0) {
     S->frame = frame;
     S->final_relative_cost = (b == INFINITY && bf == INFINITY) ? INFINITY : bf - b;  // :574-582
     S->error |= sh->err;
-    for (int i = 0; i < 8; i++) S->counters[i] += sh->cnt[i];
-    for (int i = 0; i < 16; i++) S->phase_cycles[i] += sh->ph[i];
   }
+  // (one counter per thread: unrolled on thread 0 the 24 read-modify-writes were all in flight together, 50 VGPRs)
+  if (tid < 8) S->counters[tid] += sh->cnt[tid];
+  if (tid < 16) S->phase_cycles[tid] += sh->ph[tid];
 }
 
 __device__ inline void InitSh(Sh *sh) {
-  if (threadIdx.x == 0) {
+  if (Tid() == 0) {
     sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
     sh->bigcnt = 0; sh->hugecnt = 0; sh->n_new = 0; sh->best_key = EMPTY64; sh->c_lt = 0; sh->c_le = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
     sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0;
@@ -1179,7 +1230,7 @@ __device__ inline void InitSh(Sh *sh) {
 // pdf of every emitting arc, computed once per decoder (removes the dependent
 // tid -> pdf gather of TransitionIdToPdfFast from the per-arc critical path)
 __global__ void ArcHotKernel(const kamd_arc *arcs, long long n, const int *tid2pdf, uint2 *e_hot) {
-  long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+  long long i = static_cast<long long>(blockIdx.x) * blockDim.x + Tid();
   if (i < n) { const kamd_arc a = arcs[i]; e_hot[i] = make_uint2(__float_as_uint(a.weight), static_cast<u32>(tid2pdf ? tid2pdf[a.ilabel] : a.ilabel - 1)); }
 }
 
@@ -1189,7 +1240,7 @@ __device__ __forceinline__ void InitLane(const DecDev &d, const Ctx &c, Sh *shp)
   Sh &sh = *shp;
   InitSh(&sh);
   LaneState *S = c.st;
-  if (threadIdx.x == 0) {
+  if (Tid() == 0) {
     S->frame = 0; S->tok_used = 0; S->lnk_used = 0; S->error = 0; S->finalized = 0;
     S->final_relative_cost = INFINITY; S->final_best_cost = INFINITY;
     S->out_ntok = 0; S->out_nlink = 0; S->out_tok_base = 0; S->out_lnk_base = 0;
@@ -1211,280 +1262,358 @@ __global__ __launch_bounds__(NT, 4) void InitKernel(DecDev d, const int *lanes) 
   InitLane(d, c, &sh);
 }
 
-// AdvanceDecoding (lattice-faster-decoder.cc:593-632): the frame loop of one lane.
-__device__ __forceinline__ void AdvanceLane(const DecDev &d, const Ctx &c, Sh *shp, unsigned char *dyn_lds, const kamd_decode_task &task) {
-  Sh &sh = *shp;
-  int2 *big_ta = reinterpret_cast<int2 *>(dyn_lds);           // [BIGCAP] {token (index in list), first emitting arc - scan}: one ds_read_b64
-  int *big_scan = reinterpret_cast<int *>(big_ta + BIGCAP);    // [BIGCAP] degree -> exclusive scan
-  float *ll_lds = reinterpret_cast<float *>(big_scan + BIGCAP + 4);// [num_pdfs_lds]  (+4: sentinel)
-  u32 *lh_lds = reinterpret_cast<u32 *>(ll_lds + ((d.num_pdfs_lds + 3) & ~3));   // [LHBINS]
-  float *cand_lds = reinterpret_cast<float *>(lh_lds + LHBINS);                  // [LHCAND]
-  Tbl tbl;
-  tbl.LH = reinterpret_cast<u64 *>(lh_lds + (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP));
-  tbl.lcap = d.lds_table_cap;
-  tbl.lslots = reinterpret_cast<unsigned short *>(tbl.LH + tbl.lcap);
-  for (int i = threadIdx.x; i < tbl.lcap; i += NT) tbl.LH[i] = EMPTY64;
-  const int tid = threadIdx.x;
-  InitSh(&sh);
-  LaneState *S = c.st;
-  int frame = S->frame;
-  if (S->error || S->finalized) return;
-  const kamd_decoder_config cfg = d.cfg;
-  if (tid == 0) {
-    sh.cur_tb = c.tok_off[frame]; sh.cur_n = c.tok_off[frame + 1] - c.tok_off[frame];
-    sh.lnk_used = S->lnk_used; sh.round = S->round;
-  }
-  // The frame's log-likelihood row travels HBM -> LDS by DMA (global_load_lds_dword: no registers held), issued one
-  // frame ahead, as soon as the expansion that reads the previous row is over: a cold 24 KB read off the critical path.
-  // Through inline asm, like the GEMM's ring: the compiler's own tracking of the builtin would drain vmcnt before every
-  // later ds_read.  The wave's LDS window goes in M0, the lane's word follows from its id.
+// The lane's regions of the dynamic LDS (a function of two DecDev fields: recomputed by every phase from its own view)
+struct AdvLds {
+  int2 *big_ta;      // [BIGCAP] {token (index in list), first emitting arc}: one ds_read_b64
+  int *big_scan;     // [BIGCAP] degree
+  float *ll;         // [num_pdfs_lds] the frame's log-likelihood row (+4: sentinel in front)
+  u32 *lh;           // [LHBINS] select histogram / commit scratch
+  float *cand;       // [LHCAND]
+  Tbl tbl;           // level-1 table + its dense slot list
+};
+__device__ __forceinline__ AdvLds MakeAdvLds(unsigned char *dyn_lds, int num_pdfs_lds, int lds_table_cap) {
+  AdvLds a;
+  a.big_ta = reinterpret_cast<int2 *>(dyn_lds);
+  a.big_scan = reinterpret_cast<int *>(a.big_ta + BIGCAP);
+  a.ll = reinterpret_cast<float *>(a.big_scan + BIGCAP + 4);
+  a.lh = reinterpret_cast<u32 *>(a.ll + ((num_pdfs_lds + 3) & ~3));
+  a.cand = reinterpret_cast<float *>(a.lh + LHBINS);
+  a.tbl.LH = reinterpret_cast<u64 *>(a.lh + (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP));
+  a.tbl.lcap = lds_table_cap;
+  a.tbl.lslots = reinterpret_cast<unsigned short *>(a.tbl.LH + lds_table_cap);
+  return a;
+}
+// The frame's log-likelihood row travels HBM -> LDS by DMA (global_load_lds_dword: no registers held), issued one
+// frame ahead, as soon as the expansion that reads the previous row is over: a cold 24 KB read off the critical path.
+// Through inline asm, like the GEMM's ring: the compiler's own tracking of the builtin would drain vmcnt before every
+// later ds_read.  The wave's LDS window goes in M0, the lane's word follows from its id.
+__device__ __forceinline__ void RowDma(float *ll_lds, int num_pdfs_lds, const float *src) {
   typedef __attribute__((address_space(3))) unsigned char lds_byte;
   const unsigned ll_lds_addr = static_cast<unsigned>(reinterpret_cast<size_t>((lds_byte *)ll_lds));
-  auto row_dma = [&](const float *src) {
-    for (int k0 = 0; k0 < d.num_pdfs_lds; k0 += NT) {
-      const unsigned m0v = __builtin_amdgcn_readfirstlane(ll_lds_addr + static_cast<unsigned>(k0 + (tid & ~63)) * 4u);
-      if (k0 + tid < d.num_pdfs_lds)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(src + k0 + tid) : "memory");
-    }
-  };
-  if (task.n_frames > 0) row_dma(task.d_loglikes);
-  ComputeFrameStats(d, c, &sh, frame, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
-  for (int it = 0; it < task.n_frames; it++, frame++) {
-    if (frame >= d.max_frames) { if (tid == 0) atomicOr(&sh.err, ERR_FRAMES); __syncthreads(); break; }
-    const float *ll = task.d_loglikes + static_cast<size_t>(it) * task.ld;
-    const int tb = sh.cur_tb, n = sh.cur_n;   // == c.tok_off[frame], c.tok_off[frame + 1] - tb
-    const float *cost = c.tok_cost + tb;
-    const int *state = c.tok_state + tb;
-    // ---- GetCutoff (:657-724).  The best token (ties -> smallest state, as oracle mode 1)
-    // and the two beam counts were left behind by the sweep that created this token list
-    // (CommitFrame / ComputeFrameStats), together with an LDS copy of the costs.
-    const u64 key = sh.best_key;
-    const int c_lt = sh.c_lt, c_le = sh.c_le;
-    float *cost_cache = reinterpret_cast<float *>(dyn_lds);
-    const bool cached = n <= 3 * BIGCAP;
-    LdsBarrier();   // everyone has read the stats before a select may reuse Sh scratch
-    float best = INFINITY; int best_state = -1;
-    if (n > 0) { best = OrderedToFloat(static_cast<u32>(key >> 32)); best_state = static_cast<int>(key & 0xFFFFFFFFu); }
-    float cur_cutoff, adaptive_beam;
-    const float beam_cutoff = best + cfg.beam;
-    if (cfg.max_active == 2147483647 && cfg.min_active == 0) {
-      cur_cutoff = beam_cutoff; adaptive_beam = cfg.beam;
+  const int tid = Tid();
+  for (int k0 = 0; k0 < num_pdfs_lds; k0 += NT) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(ll_lds_addr + static_cast<unsigned>(k0 + (tid & ~63)) * 4u);
+    if (k0 + tid < num_pdfs_lds)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(src + k0 + tid) : "memory");
+  }
+}
+
+// what one phase of a frame hands to the next (registers; everything else is re-read from the descriptors)
+struct FrameCtl {
+  int tb, n;                       // the newest token list: first token, count
+  float best; int best_state;      // its best token
+  float cur_cutoff, adaptive_beam; // GetCutoff
+  float cost_offset, seed_cutoff, next_cutoff;
+  bool loose;
+  int link_base, k_surv;
+  int my_slot[COMMIT_KEEP];
+};
+
+// ---- GetCutoff (:657-724).  The best token (ties -> smallest state, as oracle mode 1) and the two beam counts were
+// left behind by the sweep that created this token list (CommitFrame / ComputeFrameStats), together with an LDS copy
+// of the costs.
+__device__ __forceinline__ void PhaseCutoff(int lane, Sh &sh, unsigned char *dyn_lds, FrameCtl &fc) {
+  const DecDev d = LoadDecDev();
+  const kamd_decoder_config cfg = d.cfg;
+  const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
+  const int tb = sh.cur_tb, n = sh.cur_n;   // == c.tok_off[frame], c.tok_off[frame + 1] - tb
+  const u64 key = sh.best_key;
+  const int c_lt = sh.c_lt, c_le = sh.c_le;
+  float *cost_cache = reinterpret_cast<float *>(dyn_lds);
+  const bool cached = n <= 3 * BIGCAP;
+  LdsBarrier();   // everyone has read the stats before a select may reuse Sh scratch
+  float best = INFINITY; int best_state = -1;
+  if (n > 0) { best = OrderedToFloat(static_cast<u32>(key >> 32)); best_state = static_cast<int>(key & 0xFFFFFFFFu); }
+  float cur_cutoff, adaptive_beam;
+  const float beam_cutoff = best + cfg.beam;
+  if (cfg.max_active == 2147483647 && cfg.min_active == 0) {
+    cur_cutoff = beam_cutoff; adaptive_beam = cfg.beam;
+  } else {
+    lds_cfloat *cache_l = (lds_cfloat *)cost_cache;
+    // the costs of a list too long for the LDS copy are read where they lie (the lane's arena: one pointer of the view)
+    const float *cost = d.tok_cost + d.lane_tok_base[Opaque(lane)] + tb;
+    // nth_element(max_active) < beam_cutoff  <=>  more than max_active costs < beam_cutoff
+    if (n > cfg.max_active && c_lt > cfg.max_active) {
+      const float mac = cached ? BlockSelectLinear(cache_l, n, cfg.max_active, best, cfg.beam, L.lh, L.cand, &sh)
+                               : BlockSelectLinear(cost, n, cfg.max_active, best, cfg.beam, L.lh, L.cand, &sh);
+      adaptive_beam = mac - best + cfg.beam_delta;   // :700-702
+      cur_cutoff = mac;
     } else {
-      lds_cfloat *cache_l = (lds_cfloat *)cost_cache;
-      // nth_element(max_active) < beam_cutoff  <=>  more than max_active costs < beam_cutoff
-      if (n > cfg.max_active && c_lt > cfg.max_active) {
-        const float mac = cached ? BlockSelectLinear(cache_l, n, cfg.max_active, best, cfg.beam, lh_lds, cand_lds, &sh)
-                                 : BlockSelectLinear(cost, n, cfg.max_active, best, cfg.beam, lh_lds, cand_lds, &sh);
-        adaptive_beam = mac - best + cfg.beam_delta;   // :700-702
-        cur_cutoff = mac;
-      } else {
-        float mic = INFINITY;
-        if (n > cfg.min_active) {
-          if (cfg.min_active == 0) mic = best;
-          else if (c_le <= cfg.min_active)
-            mic = cached ? BlockSelectKth(cache_l, n, cfg.min_active, &sh) : BlockSelectKth(cost, n, cfg.min_active, &sh);
-          else mic = -INFINITY;  // nth_element(min_active) <= beam_cutoff: not looser than the beam
+      float mic = INFINITY;
+      if (n > cfg.min_active) {
+        if (cfg.min_active == 0) mic = best;
+        else if (c_le <= cfg.min_active)
+          mic = cached ? BlockSelectKth(cache_l, n, cfg.min_active, &sh) : BlockSelectKth(cost, n, cfg.min_active, &sh);
+        else mic = -INFINITY;  // nth_element(min_active) <= beam_cutoff: not looser than the beam
+      }
+      if (mic > beam_cutoff) { adaptive_beam = mic - best + cfg.beam_delta; cur_cutoff = mic; }  // :715-718
+      else { adaptive_beam = cfg.beam; cur_cutoff = beam_cutoff; }
+    }
+  }
+  LdsBarrier();
+  Stamp(&sh, PH_CUTOFF);
+  fc.tb = tb; fc.n = n; fc.best = best; fc.best_state = best_state; fc.cur_cutoff = cur_cutoff; fc.adaptive_beam = adaptive_beam;
+  // search mode 2: the seed bound replaces the final one on the frames where the reference's order-dependent extras
+  // can matter, i.e. where max_active / min_active made the adaptive beam differ from the beam; with adaptive_beam ==
+  // beam the next frame's cutoff (best + beam) equals this frame's final bound and every extra is dead on arrival
+  fc.loose = d.loose != 0 && adaptive_beam != cfg.beam;
+}
+
+// ---- cost offset + seed of next_cutoff from the best token's arcs (:757-772), then ProcessEmitting (:783-815).
+// Tokens with <= SMALL_DEG arcs are expanded by their own thread; the rest (LM hubs, trie fan-outs) are queued and
+// expanded by groups of lanes / by the whole workgroup.
+__device__ __forceinline__ void PhaseExpand(int lane, Sh &sh, unsigned char *dyn_lds, int frame, const float *ll, FrameCtl &fc) {
+  const DecDev d = LoadDecDev();
+  const Ctx c = MakeCtx(d, Opaque(lane));
+  const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
+  const Tbl &tbl = L.tbl;
+  int2 *big_ta = L.big_ta; int *big_scan = L.big_scan;
+  const int tid = Tid();
+  const int tb = fc.tb, n = fc.n;
+  const float best = fc.best; const int best_state = fc.best_state;
+  const float cur_cutoff = fc.cur_cutoff, adaptive_beam = fc.adaptive_beam;
+  const bool loose = fc.loose;
+  const float *cost = c.tok_cost + tb;
+  const int *state = c.tok_state + tb;
+  const float cost_offset = (n > 0) ? -best : 0.0f;
+  // the frame's log-likelihood row is in LDS once every wavefront's DMA of it has landed (issued a frame ago)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid == 0) {
+    c.cost_offsets[frame] = cost_offset;
+    c.trace_ntok[frame] = n; c.trace_cutoff[frame] = cur_cutoff;
+    c.lnk_off[2 * (frame + 1)] = sh.lnk_used;
+    sh.next_cutoff_u = FloatToOrdered(INFINITY);       // (the last frame's value was handed on as a parameter)
+  }
+  LlRow row; row.g = ll; row.l = (lds_cfloat *)L.ll; row.n_lds = d.num_pdfs_lds;
+  LdsBarrier();
+  if (n > 0) {
+    const u32 a0 = d.g.off[best_state].x, a1 = d.g.off[best_state + 1].x;
+    float seed = INFINITY;
+    for (u32 a = a0 + tid; a < a1; a += NT) {
+      const uint2 hot = d.e_hot[a];
+      const float new_weight = __uint_as_float(hot.x) + cost_offset - LogLikePdf(row, static_cast<int>(hot.y)) + best;
+      seed = fminf(seed, new_weight + adaptive_beam);
+    }
+    // a minimum is a minimum in any order: the wavefronts that hold an arc of the best token put theirs straight
+    // onto the running bound the expansion tightens further (usually one wavefront: no workgroup reduction)
+    seed = WaveMinF(seed);
+    if ((tid & 63) == 0 && seed < INFINITY) atomicMin(&sh.next_cutoff_u, FloatToOrdered(seed));
+  }
+  LdsBarrier();
+  Stamp(&sh, PH_SEED);
+  const float seed_cutoff = OrderedToFloat(sh.next_cutoff_u);   // :757-772, before any other arc tightens it
+  const int link_base = sh.lnk_used;
+  int n_exp = 0; long long a_emit = 0;
+  // EXPT tokens per thread per outer iteration: their costs, states and arc ranges are all
+  // loaded before the first one is expanded (three dependent round trips per BATCH of
+  // tokens instead of per token).  EXPT * NT = BIGCAP tokens are queued at most, so the
+  // queue is flushed after every outer iteration and cannot overflow.
+  for (int base = 0; base < n; base += EXPT * NT) {
+    float tcost[EXPT]; int tstate[EXPT]; u32 ta0[EXPT], ta1[EXPT];
+#pragma unroll
+    for (int k = 0; k < EXPT; k++) {
+      const int i = base + tid + k * NT;
+      // (unconditional loads at a clamped index: a load inside a conditional block is waited for at the block's end,
+      // which would serialize the EXPT fetches)
+      const int ic = min(i, n - 1);
+      tcost[k] = cost[ic]; tstate[k] = state[ic];
+      if (i >= n) tcost[k] = INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < EXPT; k++) {
+      const uint2 o0 = d.g.off[tstate[k]], o1 = d.g.off[tstate[k] + 1];
+      const bool live = base + tid + k * NT < n && tcost[k] <= cur_cutoff;      // :787 (the cutoff may be +inf)
+      ta0[k] = live ? o0.x : 0u; ta1[k] = live ? o1.x : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < EXPT; k++) {
+      const int i = base + tid + k * NT;
+      if (i < n && tcost[k] <= cur_cutoff) {
+        const float cur_cost = tcost[k];
+        n_exp++;
+        const u32 a0 = ta0[k], a1 = ta1[k];
+        const u32 deg = a1 - a0;
+        a_emit += deg;
+        if (deg <= SMALL_DEG) {
+          uint2 hot[SMALL_DEG]; u32 aidx[SMALL_DEG]; int tok[SMALL_DEG]; float cst[SMALL_DEG]; bool ok[SMALL_DEG];
+#pragma unroll
+          for (int q = 0; q < SMALL_DEG; q++) {
+            ok[q] = static_cast<u32>(q) < deg;
+            tok[q] = tb + i; cst[q] = cur_cost; aidx[q] = a0 + q;
+            hot[q] = d.e_hot[ok[q] ? a0 + q : 0u];
+          }
+          ProcessArcs<SMALL_DEG>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
+        } else {
+          // one entry per token (at most EXPT * NT = BIGCAP per outer iteration): tokens of up to HUGE_DEG arcs fill the
+          // queue from the bottom, the few with more (the LM's start / backoff hubs) from the top
+          int p;
+          if (deg <= HUGE_DEG) p = WaveAlloc(&sh.bigcnt); else p = BIGCAP - 1 - WaveAlloc(&sh.hugecnt);
+          big_ta[p] = make_int2(i, static_cast<int>(a0)); big_scan[p] = deg;
         }
-        if (mic > beam_cutoff) { adaptive_beam = mic - best + cfg.beam_delta; cur_cutoff = mic; }  // :715-718
-        else { adaptive_beam = cfg.beam; cur_cutoff = beam_cutoff; }
       }
     }
     LdsBarrier();
-    Stamp(&sh, PH_CUTOFF);
-    // ---- cost offset + seed of next_cutoff from the best token's arcs (:757-772)
-    const float cost_offset = (n > 0) ? -best : 0.0f;
-    // the frame's log-likelihood row is in LDS once every wavefront's DMA of it has landed (issued a frame ago)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int nb = sh.bigcnt, nh = sh.hugecnt;   // uniform: read between two barriers
+    LdsBarrier();
+    if (nb + nh > 0) {
+      Stamp(&sh, PH_EXPAND);
+      // A queued token is expanded by a GROUP of lanes, 4 arcs per lane and trip (all loaded before the first is
+      // used): consecutive lanes read consecutive 8-byte records of one state, the token's index and cost are read once
+      // per token, and no arc needs a search for its owner (the flattened arc-parallel form this replaces spent more
+      // than half of the expansion's issue slots on that search).  Groups take the tokens round robin; the degrees of
+      // the states that matter (LM history states: tens of arcs) make the trips of a wavefront's groups alike.
+      {
+        const int grp = tid / GL, sub = tid % GL;
+        // two tokens per group and trip: the records of both are in flight together (a trip is one HBM round trip; what
+        // bounds the expansion is how many of them a CU has outstanding)
+        for (int e = grp; e < nb; e += TPG * (NT / GL)) {
+          int2 ta[TPG]; int deg[TPG]; float cs[TPG];
+          int dmax = 0;
+#pragma unroll
+          for (int t = 0; t < TPG; t++) {
+            const int et = e + t * (NT / GL);
+            const bool have = et < nb;
+            ta[t] = big_ta[have ? et : e];
+            deg[t] = have ? big_scan[et] : 0;
+            dmax = max(dmax, deg[t]);
+          }
+#pragma unroll
+          for (int t = 0; t < TPG; t++) cs[t] = cost[ta[t].x];
+          for (int k0 = 0; k0 < dmax; k0 += 4 * GL) {
+            uint2 hot[4 * TPG]; u32 aidx[4 * TPG]; int tok[4 * TPG]; float cst[4 * TPG]; bool ok[4 * TPG];
+#pragma unroll
+            for (int q = 0; q < 4 * TPG; q++) {
+              const int k = k0 + sub + GL * (q & 3);
+              ok[q] = k < deg[q >> 2];
+              aidx[q] = static_cast<u32>(ta[q >> 2].y) + static_cast<u32>(k);
+              tok[q] = tb + ta[q >> 2].x; cst[q] = cs[q >> 2];
+              hot[q] = d.e_hot[ok[q] ? aidx[q] : static_cast<u32>(ta[q >> 2].y)];
+            }
+            ProcessArcs<4 * TPG>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
+          }
+        }
+      }
+      // the hubs: every thread of the lane on one token's arcs, ARCW per thread per trip
+      for (int h = 0; h < nh; h++) {
+        const int2 ta = big_ta[BIGCAP - 1 - h];
+        const int deg = big_scan[BIGCAP - 1 - h];
+        const float cst1 = cost[ta.x];
+        for (int k0 = tid; k0 < deg; k0 += ARCW * NT) {
+          uint2 hot[ARCW]; u32 aidx[ARCW]; int tok[ARCW]; float cst[ARCW]; bool ok[ARCW];
+#pragma unroll
+          for (int q = 0; q < ARCW; q++) {
+            const int k = k0 + q * NT;
+            ok[q] = k < deg;
+            aidx[q] = static_cast<u32>(ta.y) + static_cast<u32>(k);
+            tok[q] = tb + ta.x; cst[q] = cst1;
+            hot[q] = d.e_hot[ok[q] ? aidx[q] : static_cast<u32>(ta.y)];
+          }
+          ProcessArcs<ARCW>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
+        }
+      }
+      LdsBarrier();
+      if (tid == 0) { sh.bigcnt = 0; sh.hugecnt = 0; }
+      LdsBarrier();
+      Stamp(&sh, PH_EXPAND_BIG);
+    }
+  }
+  LdsBarrier();
+  Stamp(&sh, PH_EXPAND);
+  {
+    const int ne = WaveSumI(n_exp), ae = WaveSumI(static_cast<int>(a_emit));
+    if ((tid & 63) == 0) {   // work counters: running sums, nobody needs this frame's total
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sh.cnt[0]), static_cast<unsigned long long>(ne));
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sh.cnt[1]), static_cast<unsigned long long>(ae));
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sh.cnt[2]), static_cast<unsigned long long>(ae));
+    }
     if (tid == 0) {
-      c.cost_offsets[frame] = cost_offset;
-      c.trace_ntok[frame] = n; c.trace_cutoff[frame] = cur_cutoff;
-      c.lnk_off[2 * (frame + 1)] = sh.lnk_used;
-      sh.next_cutoff_u = FloatToOrdered(INFINITY);       // (the last frame's value was handed on as a parameter)
+      sh.cnt[6] += 1;
+      c.lnk_off[2 * (frame + 1) + 1] = link_base + min(sh.n_links, c.lnk_cap - link_base);   // for finalize / the host
     }
-    LlRow row; row.g = ll; row.l = (lds_cfloat *)ll_lds; row.n_lds = d.num_pdfs_lds;
-    LdsBarrier();
-    if (n > 0) {
-      const u32 a0 = d.g.off[best_state].x, a1 = d.g.off[best_state + 1].x;
-      float seed = INFINITY;
-      for (u32 a = a0 + tid; a < a1; a += NT) {
-        const uint2 hot = d.e_hot[a];
-        const float new_weight = __uint_as_float(hot.x) + cost_offset - LogLikePdf(row, static_cast<int>(hot.y)) + best;
-        seed = fminf(seed, new_weight + adaptive_beam);
-      }
-      // a minimum is a minimum in any order: the wavefronts that hold an arc of the best token put theirs straight
-      // onto the running bound the expansion tightens further (usually one wavefront: no workgroup reduction)
-      seed = WaveMinF(seed);
-      if ((tid & 63) == 0 && seed < INFINITY) atomicMin(&sh.next_cutoff_u, FloatToOrdered(seed));
+  }
+  fc.cost_offset = cost_offset; fc.seed_cutoff = seed_cutoff; fc.link_base = link_base;
+  __syncthreads();   // FULL barrier: InsertEmitted reads the links other threads recorded (global)
+  fc.next_cutoff = OrderedToFloat(sh.next_cutoff_u);
+}
+
+// ---- FindOrAddToken for the recorded links, against the final cutoff
+__device__ __forceinline__ void PhaseInsert(int lane, Sh &sh, unsigned char *dyn_lds, FrameCtl &fc) {
+  const DecDev d = LoadDecDev();
+  const Ctx c = MakeCtx(d, Opaque(lane));
+  const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
+  fc.k_surv = InsertEmitted(d, c, &sh, L.tbl, fc.link_base, sh.n_links, fc.loose ? fc.seed_cutoff : fc.next_cutoff, fc.my_slot);
+  Stamp(&sh, PH_FIXUP);
+}
+
+// ---- ProcessNonemitting(next_cutoff) + commit of token list frame + 1
+__device__ __forceinline__ void PhaseCommit(int lane, Sh &sh, unsigned char *dyn_lds, int frame, const FrameCtl &fc) {
+  const DecDev d = LoadDecDev();
+  const Ctx c = MakeCtx(d, Opaque(lane));
+  const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
+  CommitLds cl;
+  cl.wl0 = reinterpret_cast<u32 *>(dyn_lds); cl.wl1 = cl.wl0 + (3 * BIGCAP) / 2; cl.wl_cap = (3 * BIGCAP) / 2;
+  cl.owners = reinterpret_cast<uint2 *>(L.lh); cl.owners_cap = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP) / 2;
+  CommitFrame2(d, c, &sh, L.tbl, fc.next_cutoff, frame + 1, fc.link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP, fc.k_surv, cl, fc.my_slot, fc.loose);
+}
+
+// AdvanceDecoding (lattice-faster-decoder.cc:593-632): the frame loop of one lane.  Every phase takes its own view of
+// the descriptors (LoadDecDev above); what the phases hand to each other is the FrameCtl.
+__device__ __forceinline__ void AdvanceLane(int lane_in, Sh *shp, unsigned char *dyn_lds, const kamd_decode_task &task) {
+  Sh &sh = *shp;
+  const int lane = Opaque(lane_in);
+  const int tid = Tid();
+  int frame;
+  {
+    const DecDev d = LoadDecDev();
+    const Ctx c = MakeCtx(d, Opaque(lane));
+    const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
+    for (int i = Tid(); i < L.tbl.lcap; i += NT) L.tbl.LH[i] = EMPTY64;
+    InitSh(&sh);
+    LaneState *S = c.st;
+    frame = S->frame;
+    if (S->error || S->finalized) return;
+    if (tid == 0) {
+      sh.cur_tb = c.tok_off[frame]; sh.cur_n = c.tok_off[frame + 1] - c.tok_off[frame];
+      sh.lnk_used = S->lnk_used; sh.round = S->round;
     }
-    LdsBarrier();
-    Stamp(&sh, PH_SEED);
-    // search mode 2: the seed bound replaces the final one on the frames where the reference's order-dependent extras
-    // can matter, i.e. where max_active / min_active made the adaptive beam differ from the beam; with adaptive_beam ==
-    // beam the next frame's cutoff (best + beam) equals this frame's final bound and every extra is dead on arrival
-    const bool loose = d.loose != 0 && adaptive_beam != cfg.beam;
-    const float seed_cutoff = OrderedToFloat(sh.next_cutoff_u);   // :757-772, before any other arc tightens it
-    const int link_base = sh.lnk_used;
-    // ---- ProcessEmitting (:783-815).  Tokens with <= SMALL_DEG arcs are expanded by
-    // their own thread; the rest (LM hubs, trie fan-outs) are queued and expanded
-    // ARC-parallel: a workgroup scan of the degrees flattens the queue so that thread j
-    // takes arc j (consecutive lanes read consecutive 16-B arcs of one state), whatever
-    // the degree distribution is.
-    int n_exp = 0; long long a_emit = 0;
-    // EXPT tokens per thread per outer iteration: their costs, states and arc ranges are all
-    // loaded before the first one is expanded (three dependent round trips per BATCH of
-    // tokens instead of per token).  EXPT * NT = BIGCAP tokens are queued at most, so the
-    // queue is flushed after every outer iteration and cannot overflow.
-    for (int base = 0; base < n; base += EXPT * NT) {
-      float tcost[EXPT]; int tstate[EXPT]; u32 ta0[EXPT], ta1[EXPT];
-#pragma unroll
-      for (int k = 0; k < EXPT; k++) {
-        const int i = base + tid + k * NT;
-        // (unconditional loads at a clamped index: a load inside a conditional block is waited for at the block's end,
-        // which would serialize the EXPT fetches)
-        const int ic = min(i, n - 1);
-        tcost[k] = cost[ic]; tstate[k] = state[ic];
-        if (i >= n) tcost[k] = INFINITY;
-      }
-#pragma unroll
-      for (int k = 0; k < EXPT; k++) {
-        const uint2 o0 = d.g.off[tstate[k]], o1 = d.g.off[tstate[k] + 1];
-        const bool live = base + tid + k * NT < n && tcost[k] <= cur_cutoff;      // :787 (the cutoff may be +inf)
-        ta0[k] = live ? o0.x : 0u; ta1[k] = live ? o1.x : 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < EXPT; k++) {
-        const int i = base + tid + k * NT;
-        if (i < n && tcost[k] <= cur_cutoff) {
-          const float cur_cost = tcost[k];
-          n_exp++;
-          const u32 a0 = ta0[k], a1 = ta1[k];
-          const u32 deg = a1 - a0;
-          a_emit += deg;
-          if (deg <= SMALL_DEG) {
-            uint2 hot[SMALL_DEG]; u32 aidx[SMALL_DEG]; int tok[SMALL_DEG]; float cst[SMALL_DEG]; bool ok[SMALL_DEG];
-#pragma unroll
-            for (int q = 0; q < SMALL_DEG; q++) {
-              ok[q] = static_cast<u32>(q) < deg;
-              tok[q] = tb + i; cst[q] = cur_cost; aidx[q] = a0 + q;
-              hot[q] = d.e_hot[ok[q] ? a0 + q : 0u];
-            }
-            ProcessArcs<SMALL_DEG>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
-          } else {
-            // one entry per token (at most EXPT * NT = BIGCAP per outer iteration): tokens of up to HUGE_DEG arcs fill the
-            // queue from the bottom, the few with more (the LM's start / backoff hubs) from the top
-            int p;
-            if (deg <= HUGE_DEG) p = WaveAlloc(&sh.bigcnt); else p = BIGCAP - 1 - WaveAlloc(&sh.hugecnt);
-            big_ta[p] = make_int2(i, static_cast<int>(a0)); big_scan[p] = deg;
-          }
-        }
-      }
-      LdsBarrier();
-      const int nb = sh.bigcnt, nh = sh.hugecnt;   // uniform: read between two barriers
-      LdsBarrier();
-      if (nb + nh > 0) {
-        Stamp(&sh, PH_EXPAND);
-        // A queued token is expanded by a GROUP of 16 lanes, 64 arcs per trip (4 per lane, all loaded before the first is
-        // used): consecutive lanes read consecutive 8-byte records of one state, the token's index and cost are read once
-        // per token, and no arc needs a search for its owner (the flattened arc-parallel form this replaces spent more
-        // than half of the expansion's issue slots on that search).  Groups take the tokens round robin; the degrees of
-        // the states that matter (LM history states: tens of arcs) make the trips of a wavefront's four groups alike.
-        {
-          const int grp = tid / GL, sub = tid % GL;
-          // two tokens per group and trip: the records of both are in flight together (a trip is one HBM round trip; what
-          // bounds the expansion is how many of them a CU has outstanding)
-          for (int e = grp; e < nb; e += TPG * (NT / GL)) {
-            int2 ta[TPG]; int deg[TPG]; float cs[TPG];
-            int dmax = 0;
-#pragma unroll
-            for (int t = 0; t < TPG; t++) {
-              const int et = e + t * (NT / GL);
-              const bool have = et < nb;
-              ta[t] = big_ta[have ? et : e];
-              deg[t] = have ? big_scan[et] : 0;
-              dmax = max(dmax, deg[t]);
-            }
-#pragma unroll
-            for (int t = 0; t < TPG; t++) cs[t] = cost[ta[t].x];
-            for (int k0 = 0; k0 < dmax; k0 += 4 * GL) {
-              uint2 hot[4 * TPG]; u32 aidx[4 * TPG]; int tok[4 * TPG]; float cst[4 * TPG]; bool ok[4 * TPG];
-#pragma unroll
-              for (int q = 0; q < 4 * TPG; q++) {
-                const int k = k0 + sub + GL * (q & 3);
-                ok[q] = k < deg[q >> 2];
-                aidx[q] = static_cast<u32>(ta[q >> 2].y) + static_cast<u32>(k);
-                tok[q] = tb + ta[q >> 2].x; cst[q] = cs[q >> 2];
-                hot[q] = d.e_hot[ok[q] ? aidx[q] : static_cast<u32>(ta[q >> 2].y)];
-              }
-              ProcessArcs<4 * TPG>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
-            }
-          }
-        }
-        // the hubs: every thread of the lane on one token's arcs, ARCW per thread per trip
-        for (int h = 0; h < nh; h++) {
-          const int2 ta = big_ta[BIGCAP - 1 - h];
-          const int deg = big_scan[BIGCAP - 1 - h];
-          const float cst1 = cost[ta.x];
-          for (int k0 = tid; k0 < deg; k0 += ARCW * NT) {
-            uint2 hot[ARCW]; u32 aidx[ARCW]; int tok[ARCW]; float cst[ARCW]; bool ok[ARCW];
-#pragma unroll
-            for (int q = 0; q < ARCW; q++) {
-              const int k = k0 + q * NT;
-              ok[q] = k < deg;
-              aidx[q] = static_cast<u32>(ta.y) + static_cast<u32>(k);
-              tok[q] = tb + ta.x; cst[q] = cst1;
-              hot[q] = d.e_hot[ok[q] ? aidx[q] : static_cast<u32>(ta.y)];
-            }
-            ProcessArcs<ARCW>(d, c, &sh, tbl, row, hot, aidx, tok, cst, ok, cost_offset, adaptive_beam, link_base, loose, seed_cutoff);
-          }
-        }
-        LdsBarrier();
-        if (tid == 0) { sh.bigcnt = 0; sh.hugecnt = 0; }
-        LdsBarrier();
-        Stamp(&sh, PH_EXPAND_BIG);
-      }
-    }
-    LdsBarrier();
-    Stamp(&sh, PH_EXPAND);
+    if (task.n_frames > 0) RowDma(L.ll, d.num_pdfs_lds, task.d_loglikes);
+    ComputeFrameStats(d, c, &sh, frame, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
+  }
+  for (int it = 0; it < task.n_frames; it++, frame++) {
+    const float *ll = task.d_loglikes + static_cast<size_t>(it) * task.ld;
     {
-      const int ne = WaveSumI(n_exp), ae = WaveSumI(static_cast<int>(a_emit));
-      if ((tid & 63) == 0) {   // work counters: running sums, nobody needs this frame's total
-        atomicAdd(reinterpret_cast<unsigned long long *>(&sh.cnt[0]), static_cast<unsigned long long>(ne));
-        atomicAdd(reinterpret_cast<unsigned long long *>(&sh.cnt[1]), static_cast<unsigned long long>(ae));
-        atomicAdd(reinterpret_cast<unsigned long long *>(&sh.cnt[2]), static_cast<unsigned long long>(ae));
-      }
-      if (tid == 0) {
-        sh.cnt[6] += 1;
-        c.lnk_off[2 * (frame + 1) + 1] = link_base + min(sh.n_links, c.lnk_cap - link_base);   // for finalize / the host
-      }
+      const DecDev d = LoadDecDev();
+      if (frame >= d.max_frames) { if (tid == 0) atomicOr(&sh.err, ERR_FRAMES); __syncthreads(); break; }
     }
-    __syncthreads();   // FULL barrier: InsertEmitted reads the links other threads recorded (global)
-    const float next_cutoff = OrderedToFloat(sh.next_cutoff_u);
-    // ---- FindOrAddToken for the recorded links, against the final cutoff
-    int my_slot[COMMIT_KEEP];
-    const int k_surv = InsertEmitted(d, c, &sh, tbl, link_base, sh.n_links, loose ? seed_cutoff : next_cutoff, my_slot);
-    Stamp(&sh, PH_FIXUP);
+    FrameCtl fc;
+    PhaseCutoff(lane, sh, dyn_lds, fc);
+    PhaseExpand(lane, sh, dyn_lds, frame, ll, fc);
+    PhaseInsert(lane, sh, dyn_lds, fc);
     // nobody reads this frame's row any more.  (Issued here and not before the inserts above: those wait for L2 hits,
     // and loads return in order -- behind a cold 24 KB read they took 2.5 us longer; the closure's first loads are
     // cold graph reads themselves.)
-    if (it + 1 < task.n_frames) row_dma(ll + task.ld);
-    // ---- ProcessNonemitting(next_cutoff) + commit of token list frame+1
-    CommitLds cl;
-    cl.wl0 = reinterpret_cast<u32 *>(dyn_lds); cl.wl1 = cl.wl0 + (3 * BIGCAP) / 2; cl.wl_cap = (3 * BIGCAP) / 2;
-    cl.owners = reinterpret_cast<uint2 *>(lh_lds); cl.owners_cap = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP) / 2;
-    CommitFrame2(d, c, &sh, tbl, next_cutoff, frame + 1, link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP, k_surv, cl, my_slot, loose);
+    if (it + 1 < task.n_frames) {
+      const DecDev d = LoadDecDev();
+      const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
+      RowDma(L.ll, d.num_pdfs_lds, ll + task.ld);
+    }
+    PhaseCommit(lane, sh, dyn_lds, frame, fc);
     const int err_now = sh.err;    // CommitFrame ends with a barrier; nobody writes err before the next one
     LdsBarrier();
     if (err_now) { frame++; break; }
   }
   DrainStores();     // an early exit leaves the next row's DMA in flight: it must have landed before the LDS changes hands
-  PublishLaneEnd(d, c, &sh, frame);
+  {
+    const DecDev d = LoadDecDev();
+    const Ctx c = MakeCtx(d, Opaque(lane));
+    PublishLaneEnd(d, c, &sh, frame);
+  }
 }
-__global__ __launch_bounds__(NT, KAMD_SEARCH_WAVES_PER_EU) void AdvanceKernel(DecDev d, const kamd_decode_task *tasks) {
+KAMD_SEARCH_KERNEL void AdvanceKernel(DecDev d_unused, const kamd_decode_task *tasks) {
   __shared__ Sh sh;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   const kamd_decode_task task = tasks[blockIdx.x];
-  const Ctx c = MakeCtx(d, task.lane);
-  AdvanceLane(d, c, &sh, dyn_lds, task);
+  AdvanceLane(task.lane, &sh, dyn_lds, task);
 }
 
 // FinalizeDecoding (lattice-faster-decoder.cc:638-653) = PruneForwardLinksFinal (:389-471)
@@ -1495,7 +1624,7 @@ __global__ __launch_bounds__(NT, 4) void FinalizeKernel(DecDev d, const int *lan
   __shared__ Sh sh;
   const int lane = lanes[blockIdx.x];
   const Ctx c = MakeCtx(d, lane);
-  const int tid = threadIdx.x;
+  const int tid = Tid();
   InitSh(&sh);
   LaneState *S = c.st;
   if (S->error || S->finalized) return;
@@ -1726,7 +1855,7 @@ __global__ __launch_bounds__(NT, 4) void FinalizeKernel(DecDev d, const int *lan
 // arena toward the data still to be swept); call under the predicate.
 __device__ inline int WaveAllocDown(int *top) {
   const u64 m = __ballot(1);
-  const int lane = threadIdx.x & 63;
+  const int lane = Tid() & 63;
   const int leader = __ffsll(static_cast<long long>(m)) - 1;
   int base = 0;
   if (lane == leader) base = atomicSub(top, __popcll(m));
@@ -1774,7 +1903,7 @@ __device__ __forceinline__ void FinalizeLane2(const DecDev &d, const Ctx &c, Sh 
   Sh &sh = *shp;
   int &s_tok_top = fs->tok_top, &s_lnk_top = fs->lnk_top;
   int *s_chg = fs->chg;
-  const int tid = threadIdx.x;
+  const int tid = Tid();
   InitSh(&sh);
   LaneState *S = c.st;
   if (S->error || S->finalized) return;
@@ -2231,35 +2360,49 @@ struct QueueDev {
 };
 enum { ERR_POOL = 64 };
 
-// The three stages are inlined into one body.  The compiler then spills ~100 VGPRs (uniform pointers, mostly) to
-// scratch in it; the two ways round that which were measured are both slower: the stages behind real calls on an
-// LDS copy of the descriptors (52 spills, decode 194 -> 238 ms on the headline), and the cold per-lane pointers kept
-// in LDS and fetched through v_readfirstlane (45 spills in this kernel, and new ones in the stand-alone kernels).
-__global__ __launch_bounds__(NT, KAMD_SEARCH_WAVES_PER_EU) void DecodeQueueKernel(DecDev d, QueueDev q) {
+// The three stages are inlined into one body; each of them, and each phase of a frame inside AdvanceLane, takes its own
+// view of the two kernel arguments (LoadDecDev / LoadSecondArg), so that nothing but the lane number, the task and the
+// utterance id is live from one stage to the next.
+KAMD_SEARCH_KERNEL void DecodeQueueKernel(DecDev d_unused, QueueDev q_unused) {
   __shared__ Sh sh;
   __shared__ FinSh fs;
   __shared__ int s_task;
   __shared__ unsigned long long s_off;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  const int tid = threadIdx.x;
   const int lane = blockIdx.x;
-  const Ctx c = MakeCtx(d, lane);
-  LaneState *S = c.st;
   for (;;) {
-    if (tid == 0) s_task = __hip_atomic_fetch_add(q.head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const int ti = s_task;
-    if (ti >= q.n_tasks) break;
-    const kamd_queue_task qt = q.tasks[ti];
     kamd_decode_task task;
-    task.lane = lane; task.n_frames = qt.n_frames; task.d_loglikes = qt.d_loglikes; task.ld = qt.ld; task.reserved = 0;
-    InitLane(d, c, &sh);
+    int utt;
+    {
+      const QueueDev q = LoadSecondArg<QueueDev>();
+      if (Tid() == 0) s_task = __hip_atomic_fetch_add(q.head, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int ti = s_task;
+      if (ti >= q.n_tasks) break;
+      const kamd_queue_task qt = q.tasks[ti];
+      task.lane = lane; task.n_frames = qt.n_frames; task.d_loglikes = qt.d_loglikes; task.ld = qt.ld; task.reserved = 0;
+      utt = qt.utt;
+    }
+    {
+      const DecDev d = LoadDecDev();
+      const Ctx c = MakeCtx(d, Opaque(lane));
+      InitLane(d, c, &sh);
+    }
     __syncthreads();
-    AdvanceLane(d, c, &sh, dyn_lds, task);
+    AdvanceLane(lane, &sh, dyn_lds, task);
     __syncthreads();
-    FinalizeLane2<false, 2, 2>(d, c, &sh, &fs, dyn_lds);
+    {
+      const DecDev d = LoadDecDev();
+      const Ctx c = MakeCtx(d, Opaque(lane));
+      FinalizeLane2<false, 2, 2>(d, c, &sh, &fs, dyn_lds);
+    }
     __syncthreads();
     // ---- hand the lattice out
+    const int tid = Tid();
+    const DecDev d = LoadDecDev();
+    const Ctx c = MakeCtx(d, Opaque(lane));
+    const QueueDev q = LoadSecondArg<QueueDev>();
+    LaneState *S = c.st;
     const int err = S->error, F = S->frame;
     const int nt = err ? 0 : S->out_ntok, nl = err ? 0 : S->out_nlink;
     const int tbase = S->out_tok_base, lbase = S->out_lnk_base;
@@ -2306,7 +2449,7 @@ __global__ __launch_bounds__(NT, KAMD_SEARCH_WAVES_PER_EU) void DecodeQueueKerne
     if (tid == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: the blob's stores have reached host memory
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      kamd_queue_result *r = q.results + qt.utt;
+      kamd_queue_result *r = q.results + utt;
       r->error = err | ((bytes && !fits) ? ERR_POOL : 0);
       r->lane = lane; r->n_frames = F; r->n_tok = fits ? nt : 0; r->n_link = fits ? nl : 0; r->n_last = fits ? n_last : 0;
       r->final_relative_cost = S->final_relative_cost; r->final_best_cost = S->final_best_cost;
@@ -2317,7 +2460,7 @@ __global__ __launch_bounds__(NT, KAMD_SEARCH_WAVES_PER_EU) void DecodeQueueKerne
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const int k = __hip_atomic_fetch_add(q.done_count, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&r->status, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(&q.done_ring[k], qt.utt + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&q.done_ring[k], utt + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (err) {
       // an overflow can leave level-2 table words behind that no slot list names: wipe the lane's table
@@ -2340,8 +2483,8 @@ struct PathArc { int ilabel, olabel; float graph, ac; };
 // by every thread (uniformly) for the k-th arc from the end; returning false stops the walk.  Returns the number
 // of arcs visited, or -1 when no token is alive on the newest frame.
 template <typename Visit>
-__device__ int WalkBestPath(const DecDev &d, const Ctx &c, Sh *sh, int use_final_probs, float *final_cost, Visit visit) {
-  const int tid = threadIdx.x;
+__device__ __forceinline__ int WalkBestPath(const DecDev &d, const Ctx &c, Sh *sh, int use_final_probs, float *final_cost, Visit visit) {
+  const int tid = Tid();
   const int F = c.st->frame;
   bool use_final = false;
   if (use_final_probs) {
@@ -2391,7 +2534,7 @@ __global__ __launch_bounds__(NT, 4) void TracebackKernel(DecDev d, int lane, int
                                                       float *out_final_cost) {
   __shared__ Sh sh;
   const Ctx c = MakeCtx(d, lane);
-  const int tid = threadIdx.x;
+  const int tid = Tid();
   InitSh(&sh);
   float fc = 0.0f;
   const int n = WalkBestPath(d, c, &sh, use_final_probs, &fc, [&](int k, const Link &L, bool emitting, int f) {
@@ -2410,7 +2553,7 @@ __global__ __launch_bounds__(NT, 4) void TracebackKernel(DecDev d, int lane, int
 __global__ __launch_bounds__(NT, 4) void TracebackBatchKernel(DecDev d, const int *lanes, int use_final_probs, PathArc *out_arcs,
                                                            int out_cap, int *head) {
   __shared__ Sh sh;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = Tid();
   const Ctx c = MakeCtx(d, lanes[b]);
   InitSh(&sh);
   PathArc *out = out_arcs + static_cast<size_t>(b) * out_cap;
@@ -2441,7 +2584,7 @@ __global__ __launch_bounds__(NT, 4) void TracebackBatchKernel(DecDev d, const in
 __global__ __launch_bounds__(NT, 4) void TracebackIncKernel(DecDev d, const int *lanes, const int *known, PathArc *cache, int cache_cap,
                                                          int *rec, int stride, PathArc *out_arcs, int out_cap, int *head) {
   __shared__ Sh sh;
-  const int b = blockIdx.x, tid = threadIdx.x, lane_id = lanes[b];
+  const int b = blockIdx.x, tid = Tid(), lane_id = lanes[b];
   const Ctx c = MakeCtx(d, lane_id);
   InitSh(&sh);
   PathArc *P = cache + static_cast<size_t>(lane_id) * cache_cap;
@@ -2487,7 +2630,7 @@ __global__ __launch_bounds__(NT, 4) void TracebackIncKernel(DecDev d, const int 
 __global__ __launch_bounds__(NT, 4) void FrameTraceKernel(DecDev d, const int *lanes, const int *known, int *prev_tok, int prev_stride,
                                                        int2 *out, int out_cap, int *head) {
   __shared__ Sh sh;
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = Tid();
   const Ctx c = MakeCtx(d, lanes[b]);
   InitSh(&sh);
   int2 *o = out + static_cast<size_t>(b) * out_cap;
@@ -2539,7 +2682,7 @@ __global__ __launch_bounds__(NT, 4) void TrailingSilenceKernel(DecDev d, const i
       return false;
     });
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = n_sil;
+  if (Tid() == 0) out[blockIdx.x] = n_sil;
 }
 
 static inline size_t AdvanceLdsBytes(int num_pdfs_lds, int lds_table_cap) {

@@ -7,9 +7,11 @@ of spill on purpose, and runs the bit-exact decoder tests against every build, s
 the result" is an experiment and not a guess:
 
   base     the product flags (control)
+  mlicm    machine LICM left on (round 3's flags)
   s2m      -mllvm -amdgpu-spill-sgpr-to-vgpr=0: every SGPR spill goes to scratch MEMORY instead of VGPR lanes
-  v96      search kernels compiled for 5 wavefronts per SIMD: 96 VGPRs, i.e. forced VGPR spills (SGPR spills stay in lanes)
-  s2m_v96  both: the closest synthetic stand-in for round 3's bad regime (VGPR spills + SGPR spills to memory)
+  v64      search kernels compiled for a 64-VGPR budget: forced VGPR spills (SGPR spills stay in lanes)
+  s2m_v64  both: the closest synthetic stand-in for round 3's bad regime (VGPR spills + SGPR spills to memory)
+  mlicm_s2m_v96  the same with machine LICM on
 
     python tools/regime_probe.py build            # here (no GPU): build/regime/libkaldi_amd_<variant>.so + resources.json
     python tools/regime_probe.py run [tests...]   # on the GPU box: pytest per variant -> gpurun_out/regime/<variant>.log
@@ -28,15 +30,20 @@ OUT = os.path.join(ROOT, "build", "regime")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 BASE = ["--offload-arch=gfx950", "-DKAMD_NT=1024", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
         "-Wno-unused-result", "-Wno-pass-failed"]
+NO_MLICM = ["-mllvm", "-disable-machine-licm"]          # kaldi_amd/csrc/Makefile: DECODER_FLAGS
+S2M = ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0"]
 VARIANTS = {
-    "base": [],
-    "s2m": ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0"],
-    "v96": ["-DKAMD_SEARCH_WAVES_PER_EU=5"],
-    "s2m_v96": ["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=0", "-DKAMD_SEARCH_WAVES_PER_EU=5"],
+    "base": NO_MLICM,                                        # the product flags (control)
+    "mlicm": [],                                             # machine LICM left on (round 3's flags)
+    "s2m": NO_MLICM + S2M,                                   # every SGPR spill to scratch memory
+    "v64": NO_MLICM + ["-DKAMD_SEARCH_VGPRS=64"],            # half the VGPR budget: forced VGPR spills
+    "s2m_v64": NO_MLICM + S2M + ["-DKAMD_SEARCH_VGPRS=64"],  # both
+    "mlicm_s2m_v96": S2M + ["-DKAMD_SEARCH_VGPRS=96"],       # round 3's flags, spilling both ways
 }
 for item in filter(None, os.environ.get("KAMD_REGIME_EXTRA", "").split(";")):
     name, flags = item.split(":", 1)
     VARIANTS[name] = flags.split()
+PER_VARIANT_S = int(os.environ.get("KAMD_REGIME_TIMEOUT", "420"))
 DEFAULT_TESTS = ["tests/test_gpu_decoder.py", "tests/test_gpu_queue.py", "tests/test_gpu_search_mode.py"]
 
 
@@ -87,8 +94,15 @@ def run(tests):
         if not os.path.exists(lib):
             continue
         env = dict(os.environ, KAMD_LIB=lib)
-        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-rf", "--tb=line", "-p", "no:cacheprovider"] + tests,
-                           cwd=ROOT, env=env, capture_output=True, text=True)
+        # a build that decodes wrongly may also spin (a fixpoint loop fed garbage): every test and the whole run are bounded,
+        # so that a variant can fail without taking the GPU box with it
+        try:
+            r = subprocess.run(["timeout", "-k", "10", str(PER_VARIANT_S), sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-rf", "--tb=line",
+                                "-p", "no:cacheprovider", "--timeout=90", "--timeout-method=thread"] + tests,
+                               cwd=ROOT, env=env, capture_output=True, text=True)
+        except Exception as e:                      # noqa: BLE001
+            summary[name] = {"rc": -1, "tail": repr(e), "failed": []}
+            continue
         with open(os.path.join(out, name + ".log"), "w") as f:
             f.write(r.stdout[-20000:] + "\n" + r.stderr[-4000:])
         tail = [l for l in r.stdout.splitlines() if l.strip()][-1:] or ["?"]
