@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 PHASES = ["fin_fetch", "cutoff", "seed", "expand", "expand_hub", "eps_closure", "compact", "fixup",
-          "eps_links", "clear", "fin_sweep", "fin_compact", "flat_setup", "fin_emit", "fin_eps", "fin_stage"]
+          "eps_links", "clear", "fin_sweep", "fin_compact", "commit_scan", "fin_emit", "fin_eps", "fin_stage"]
 
 
 def algorithmic_bytes(c):
@@ -69,7 +69,14 @@ def parse_args():
     ap.add_argument("--ll-std-light", type=float, default=1.9, help="load_bracket: round 2's headline load")
     ap.add_argument("--ll-std-saturated", type=float, default=1.2, help="load_bracket: the load at which max-active binds")
     ap.add_argument("--no-bracket", action="store_true", help="only the headline load")
-    ap.add_argument("--no-planted", action="store_true", help="skip the planted-transcript variant")
+    ap.add_argument("--headline", default="faithful", choices=["faithful", "random"],
+                    help="what `value` measures.  faithful (default): the recipe's configuration -- the model WITH its 100-dim i-vector input "
+                         "(run_tdnn_1d.sh:220), online i-vectors estimated on the device and the model evaluated chunk by chunk (decode.sh:105-107), "
+                         "on utterances with planted multi-word transcripts (speech-like search: ~23 words per utterance, lattices with real depth, "
+                         "a %%WER).  random: round 3's headline -- the model without the i-vector input on random-weight log-likelihoods "
+                         "calibrated to the token-matched search load (one word per utterance); reported as the `random_loglikes` leg otherwise")
+    ap.add_argument("--no-planted", action="store_true", help="skip the planted-transcript leg of --headline random")
+    ap.add_argument("--no-random-leg", action="store_true", help="--headline faithful: skip the random-log-likelihood leg (round 3's headline)")
     ap.add_argument("--planted-peak", type=float, default=8.3)
     ap.add_argument("--planted-noise", type=float, default=3.0)
     ap.add_argument("--ivectors", action="store_true", help="the recipe's model input (run_tdnn_1d.sh:220 `input dim=100 name=ivector`): "
@@ -244,7 +251,7 @@ def _run_threads(fn, items, threads):
     return res, time.time() - t0, sum(busy)
 
 
-def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
+def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
     """The CPU path (a port of the reference: oracle/) on this host's cores, on a bounded sample of the same test set:
     `cores` threads, each pulling the next utterance (one LatticeFasterDecoder per thread, like nnet3-latgen-faster-
     parallel; the oracle is C behind ctypes, which releases the interpreter lock), every thread busy for the whole
@@ -252,7 +259,9 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
     --frames-per-chunk 50 with their context recomputed, every Propagate one cblas_sgemm (oracle/orc_nnet_blas.cc, the
     OpenBLAS next to numpy, one BLAS thread per worker) -- not the scalar oracle kept for parity, whose per-core rate is
     reported beside it.  Second leg: the CPU decoder alone on the DEVICE's log-likelihoods (latgen-faster-mapped's job),
-    which is also the 1-best parity check of the sampled utterances."""
+    which is also the 1-best parity check of the sampled utterances.  ll_of (the faithful headline): the decoder searches
+    ll_of(idx) -- the planted log-likelihoods the device searched -- instead of the model's output, which is still computed
+    (the model here is the topology WITHOUT the i-vector input: the scalar / sgemm port has no extractor)."""
     from kaldi_amd import abi
     from oracle import orc
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -260,6 +269,7 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
     order = [int(i) for i in np.argsort([w.size for w in waves])]
     have_blas = orc.cblas_sgemm() is not None
     stage_s = [0.0, 0.0, 0.0]
+    ll_cache = {}
 
     def whole(idx):
         t0 = time.time()
@@ -267,6 +277,8 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
         t1 = time.time()
         ll = orc.nnet_forward_blas(model, feats, frames_per_chunk=50) if have_blas else orc.nnet_forward(model, feats)
         t2 = time.time()
+        if ll_of is not None:
+            ll = ll_cache[idx] if idx in ll_cache else ll_of(idx)       # (fetched before the timed part for the sampled utterances)
         d = orc.Decoder(g, cfg, 0)
         d.Decode(ll)
         lat = d.GetRawLattice()
@@ -301,7 +313,7 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
     audio = sum(waves[i].size for i in sample) / 16000.0
     # the single-threaded whole path (= nnet3-latgen-faster, src/nnet3bin/nnet3-latgen-faster.cc:140,255-263) on a sparser
     # stratified sample worth ~8 s of one core
-    k_one = max(k_strat, int(np.ceil(total_audio / max(rate * 8.0, 1e-9))))
+    k_one = min(max(k_strat, int(np.ceil(total_audio / max(rate * 8.0, 1e-9)))), max(1, len(order) // 8))
     sample_one = order[k_one // 2::k_one]
     audio_one = sum(waves[i].size for i in sample_one) / 16000.0
     t0 = time.time()
@@ -311,7 +323,7 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores):
     stage_s[:] = [0.0, 0.0, 0.0]
     # longest of the sample first, so the tail of the run is made of the short ones
     sample.sort(key=lambda i: -waves[i].size)
-    ll_cache = {i: bd.loglikes(i) for i in sample}
+    ll_cache.update({i: (ll_of(i) if ll_of is not None else bd.loglikes(i)) for i in sample})
     res_w, wall_w, busy_w = _run_threads(whole, sample, cores)
     bd_like = ll_cache
 
@@ -475,16 +487,27 @@ def main():
                          (rank, dev, ndev))
     check(lib().kamd_set_device(dev))
     g, model, durs, cfg, t_build = build_workload(args)
+    faithful = args.headline == "faithful"
+    model_plain = model                               # the topology without the i-vector input (round 3's headline, the CPU leg)
     extractor = None
-    if args.ivectors:
+    if args.ivectors or faithful:
         model, extractor = ivector_variant(args, g)
     graph_dev = decoder.Graph(g)                      # one copy of HCLG in HBM for every decoder object of this process
     log("workload built: %d states %d arcs, %d utts (%.2f h)" % (g.num_states, g.num_arcs, durs.size, durs.sum() / 3600))
     # ONE test set, partitioned over the ranks (steps/nnet3/decode.sh:96,123: split_data + JOB=1:nj)
     mine = shard.lpt_shards(durs, world)[rank]
-    waves = synth.make_waves_fast(durs[mine], seed=1000 + rank)
+    planted_set = None
+    if faithful:
+        # utterances with a KNOWN transcript: word sequences sampled through HCLG (about 3 words per second), waveforms of
+        # exactly the paths' lengths; the search reads planted log-likelihoods (kaldi_amd/csrc/synth.hip) while features,
+        # i-vectors and the acoustic model run in the timed region as always
+        planted_set = planted_testset(g, durs, mine, synth)
+        waves = planted_set["waves"]
+        max_s = planted_set["max_seconds"]
+    else:
+        waves = synth.make_waves_fast(durs[mine], seed=1000 + rank)
+        max_s = float(durs.max()) + 0.5
     audio = sum(w.size for w in waves) / 16000.0
-    max_s = float(durs.max()) + 0.5
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     host_threads = args.host_threads or max(1, min(32, cores // world))
 
@@ -522,35 +545,48 @@ def main():
         sync_all()
         return time.time() - t0, acc / max(steps, 1), st
 
-    def search_stats(bd, st, acc, n):
+    def search_stats(bd, st, acc, n, use_pmc=True):
         recs = [bd.record(u) for u in range(n)]
         counters = np.sum([np.asarray(r.counters[:8], np.float64) for r in recs], axis=0)
         frames = int(counters[6])
         dec = {"frames": frames, "tokens_per_frame": counters[5] / max(frames, 1), "expanded_per_frame": counters[0] / max(frames, 1),
                "arcs_per_frame": counters[1] / max(frames, 1), "links_per_frame": counters[4] / max(frames, 1),
+               "level2_tokens_per_frame": counters[7] / max(frames, 1),
                "failed_utterances": sum(1 for r in recs if r.error), "failures": failure_report(recs)}
         alg = float(algorithmic_bytes(counters))
         dec_ms = float(acc[2])
         roof = {"bound": "hbm", "kernel": "kamd::DecodeQueueKernel", "achieved": alg / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args, "decode_queue"),
+                "unit": "GB/s", "frac": alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(args, "decode_queue") if use_pmc else None,
                 "traffic_source": "profiles/*_pmc.json taken on this workload with this library build (rocprofv3 --pmc passes), not this run; null otherwise",
                 "algorithmic_bytes_per_launch": alg, "launch_ms": dec_ms, "lanes": int(st.lanes),
                 "us_per_frame_per_lane": 1e3 * dec_ms * int(st.lanes) / max(frames, 1)}
-        roof.update(search_counter_view(args, counters, dec_ms))
+        roof.update(search_counter_view(args if use_pmc else None, counters, dec_ms))
         roof["reading"] = ("`frac` is the contract figure: SURVEY 8(d)'s algorithmic bytes over the launch time.  The kernel moves fewer bytes than "
                            "that formula prices and is bound by dependent memory round trips, not bandwidth: see counter_frac (PMC bytes / launch / "
                            "peak), wait_fraction (SQ_WAIT_ANY / SQ_WAVE_CYCLES) and write_amplification (WRITE_SIZE / algorithmic writes)")
         return recs, dec, roof
 
     # ------------------------------------------------------------------ the headline load
-    if not args.ivectors:
+    if not (args.ivectors or faithful):
         spread, k = calibrate(model, args.ll_std)
-    bd = make_decoder(**(dict(nnet_pass_frames=min(args.nnet_pass_frames, 400000)) if args.ivectors else {}))
+    head_kw = {}
+    if args.ivectors or faithful:
+        head_kw["nnet_pass_frames"] = min(args.nnet_pass_frames, 400000)      # (the chunks' context rows: 1.9x the activations)
+    if faithful:
+        head_kw.update(hbm_fraction=0.62, tokens_per_frame=args.tokens_per_frame or 11000)
+    bd = make_decoder(**head_kw)
     log("batch decoder created (%d host threads)" % host_threads)
     if args.resident:
         bd.load(waves)                          # round 2's contract: inputs resident in HBM before the timed region
     else:
         bd.load_host(waves)                     # every step uploads the waveforms itself, overlapped with the passes before
+    planted = None
+    if faithful:
+        if not np.array_equal(bd.output_frames(), planted_set["frames"]):
+            raise RuntimeError("planted test set: the waveforms give other frame counts than the paths")
+        planted = synth.planted_loglikes_device(np.concatenate([p for _, p in planted_set["paths"]]), g.num_pdfs, args.planted_peak,
+                                                args.planted_noise, seed=5 + rank)
+        bd.set_loglike_override(planted.ptr(0))
     log("shard loaded: %d utterances, %.0f s audio" % (len(waves), audio))
     dt, acc, st = timed(bd, args.steps, args.warmup)
     my_dt = dt
@@ -590,6 +626,8 @@ def main():
     dominant_is_decoder = dec_ms >= nnet_ms
     wav_bytes = 4.0 * sum(w.size for w in waves)
     load_name = "token-matched" if (args.workload == "librispeech" and args.graph == "tglarge") else "default"
+    if faithful:
+        load_name = "planted transcripts, the recipe's i-vector model"
     out = {
         "metric": "decode RTF (audio-sec/wall-sec)",
         "value": total_audio * args.steps / dt,
@@ -601,17 +639,22 @@ def main():
         "config": {"workload": "%s: %d synthetic utterances (%.2f h, lognormal 1-35 s) sharded over %d GPU(s), %s TDNN-F chain "
                                "topology (random init, P=%d), synthetic %s-scale HCLG (%d states, %d arcs), beam 15 max-active 7000 "
                                "min-active 200 lattice-beam 8, %s lanes/GPU fed by a device work queue, host tail (lattice read from the page-locked pool, best path, "
-                               "%s) on %d threads/GPU inside the timed region; `value` is the %s search load (log-likelihood spread %.2f nats, LM scale %.2f: "
+                               "%s) on %d threads/GPU inside the timed region; `value` is the %s search load (%s, LM scale %.2f: "
                                "%.0f expanded / %.0f created tokens and %.0f arcs per frame), %s" %
                                ("LibriSpeech test-clean sized test set" if args.workload == "librispeech" else args.workload + " set",
-                                durs.size, durs.sum() / 3600.0, world, args.workload, g.num_pdfs, args.graph, g.num_states, g.num_arcs,
+                                durs.size, total_audio / 3600.0, world, args.workload, g.num_pdfs, args.graph, g.num_states, g.num_arcs,
                                 int(st.lanes), "no determinization" if args.no_determinize else "lattice determinization", host_threads,
-                                load_name, args.ll_std, args.lm_scale, dec_stats["expanded_per_frame"], dec_stats["tokens_per_frame"],
+                                load_name,
+                                ("utterances with planted word sequences, 3 words per second: the search reads planted log-likelihoods, noise %.1f on every "
+                                 "pdf and a peak of %.1f on the path's, while MFCC, the online i-vector extraction (100-dim, period 10) and the model with "
+                                 "its i-vector input, evaluated in chunks of 50 frames like DecodableNnetSimple, run in the timed region" %
+                                 (args.planted_noise, args.planted_peak)) if faithful else ("log-likelihood spread %.2f nats" % args.ll_std),
+                                args.lm_scale, dec_stats["expanded_per_frame"], dec_stats["tokens_per_frame"],
                                 dec_stats["arcs_per_frame"],
                                 "waveforms resident in HBM before the timed region" if args.resident else
                                 "waveform upload (%.2f GB from host memory) inside the timed region" % (wav_bytes / 1e9)),
                    "utterances": int(durs.size), "utterances_rank0": n, "long_utterances_rank0": int(st.long_utterances),
-                   "loglike_std_nats": args.ll_std, "lm_scale": args.lm_scale,
+                   "loglike_std_nats": None if faithful else args.ll_std, "lm_scale": args.lm_scale, "headline": args.headline,
                    "value_is_load": load_name, "upload_in_timed_region": not args.resident,
                    "baseline_config": "configs[2]" if args.workload == "librispeech" and args.graph == "tglarge" else
                                       ("configs[1]" if args.workload == "mini_librispeech" else "other")},
@@ -631,14 +674,27 @@ def main():
     }
     one = world == 1
     # ------------------------------------------------------------------ the same load, waveforms already in HBM
+    if args.ivectors or faithful:
+        out["stage_ms"]["ivector_extraction"] = acc[10]
+        out["config"]["online_ivectors"] = "100-dim, period 10, estimated on the device inside the timed region; model evaluated in chunks of 50 frames"
+        out["nnet_chunked"] = {"executed_over_algorithmic": st.nnet_flops / max(flops_alg, 1.0), "gemm_achieved_tflops": flops_alg / (nnet_ms * 1e-3) / 1e12,
+                               "gemm_executed_tflops": st.nnet_flops / (nnet_ms * 1e-3) / 1e12,
+                               "what": "DecodableNnetSimple's chunks (nnet-am-decodable-simple.cc:93-214): every chunk of 50 frames recomputes its "
+                                       "context rows and takes the i-vector row of its middle; executed / algorithmic is that recompute"}
+    if faithful:
+        out["n_retried"] = int(st.n_retried)
+        try:
+            out["transcripts"] = transcript_quality(planted_set, bd, latbin, not args.no_determinize, planted_set["frames"])
+        except Exception as e:                      # noqa: BLE001
+            out["transcripts"] = {"error": repr(e)}
+    # ------------------------------------------------------------------ the same load, waveforms already in HBM
     if one and not args.resident:
         bd.load(waves)
+        if faithful:
+            bd.set_loglike_override(planted.ptr(0))
         dt_r, acc_r, st_r = timed(bd, min(3, args.steps), 1)
         out["hbm_resident_value"] = audio * min(3, args.steps) / dt_r
         out["hbm_resident_ms_per_step"] = 1000.0 * dt_r / min(3, args.steps)
-    if args.ivectors:
-        out["stage_ms"]["ivector_extraction"] = acc[10]
-        out["config"]["online_ivectors"] = "100-dim, period 10, estimated on the device inside the timed region; model evaluated in chunks of 50 frames"
     out["cpu_baseline"] = None
     if args.ivectors:
         out["cpu_baseline"] = {"skipped": "the CPU leg runs the model without the ivector input (default run); steps/online/nnet2/extract_ivectors_online.sh is a "
@@ -646,13 +702,41 @@ def main():
     elif not args.no_cpu_baseline and one:
         log("cpu baseline ...")
         try:
-            out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, bd, args.cpu_budget, args.cpu_cores)
+            if faithful:
+                ro = planted_set["row_off"]
+                out["cpu_baseline"] = cpu_baseline(g, model_plain, waves, cfg, bd, args.cpu_budget, args.cpu_cores,
+                                                   ll_of=lambda i: planted_rows(planted, ro[i], ro[i + 1] - ro[i], g.num_pdfs))
+            else:
+                out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, bd, args.cpu_budget, args.cpu_cores)
         except Exception as e:                      # noqa: BLE001 - the measured line must still be printed
             out["cpu_baseline"] = {"error": repr(e)}
-    del bd
+    del bd, planted
     gc.collect()
+    # ------------------------------------------------------------------ round 3's headline as a leg: the model without the i-vector input on random-weight scores
+    if one and faithful and not args.no_random_leg:
+        log("random log-likelihood leg ...")
+        try:
+            calibrate(model_plain, args.ll_std)
+            w4 = synth.make_waves_fast(durs[mine], seed=1000 + rank)
+            a4 = sum(w.size for w in w4) / 16000.0
+            b4 = make_decoder(model=model_plain, extractor=None, max_seconds=float(durs.max()) + 0.5)
+            b4.load(w4) if args.resident else b4.load_host(w4)
+            dt4, acc4, st4 = timed(b4, 2, 1)
+            _, d4, r4 = search_stats(b4, st4, acc4, len(w4), use_pmc=False)
+            fl4 = 2.0 * model_plain.macs_per_output_frame() * d4["frames"]
+            out["random_loglikes"] = {
+                "value": a4 * 2 / dt4, "ms_per_step": 1000.0 * dt4 / 2, "ratio_to_value": (a4 * 2 / dt4) / out["value"],
+                "stage_ms": {"features": acc4[0], "nnet": acc4[1], "decode_queue_kernel": acc4[2], "host_tail_after_last_utterance": acc4[3], "total_wall": acc4[4]},
+                "loglike_std_nats": args.ll_std, "decoder": d4, "roofline": r4,
+                "gemm_achieved_tflops": fl4 / (float(acc4[1]) * 1e-3) / 1e12, "gemm_frac_of_fp32_mfma_peak": fl4 / (float(acc4[1]) * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                "what": "round 3's headline: the same topology WITHOUT the i-vector input, whole utterances per pass, random-weight log-likelihoods "
+                        "calibrated to a spread of %.2f nats (the token-matched search load: one word per utterance)" % args.ll_std}
+            del b4, w4
+            gc.collect()
+        except Exception as e:                      # noqa: BLE001
+            out["random_loglikes"] = {"error": repr(e)}
     # ------------------------------------------------------------------ the recipe's model input: online i-vectors
-    if one and not args.ivectors and not args.no_ivector_leg:
+    if one and not faithful and not args.ivectors and not args.no_ivector_leg:
         log("online i-vector leg ...")
         try:
             m_iv, ie = ivector_variant(args, g)
@@ -682,7 +766,7 @@ def main():
         except Exception as e:                      # noqa: BLE001
             out["online_ivectors"] = {"error": repr(e)}
     # ------------------------------------------------------------------ load bracket: the same step at two more loads
-    if one and not args.no_bracket and args.workload == "librispeech" and args.graph == "tglarge":
+    if one and not faithful and not args.no_bracket and args.workload == "librispeech" and args.graph == "tglarge":
         def entry(value, ms, a, d, r):
             return {"value": value, "ms_per_step": ms, "us_per_frame_per_lane": r["us_per_frame_per_lane"], "tokens_per_frame": d["tokens_per_frame"],
                     "expanded_per_frame": d["expanded_per_frame"], "arcs_per_frame": d["arcs_per_frame"], "failed_utterances": d["failed_utterances"],
@@ -710,7 +794,7 @@ def main():
         calibrate(model, args.ll_std)
         out["load_bracket"] = bracket
     # ------------------------------------------------------------------ planted transcripts through the whole timed path
-    if one and not args.no_planted:
+    if one and not faithful and not args.no_planted:
         log("planted variant ...")
         try:
             out["planted"] = planted_variant(args, g, model, cfg, durs, make_decoder, timed, latbin, synth, log)
@@ -758,6 +842,50 @@ def streaming_leg(log, streams=256, seconds=12.0, chunk=0.24):
             "what": "mini_librispeech-sized TDNN-F, 20 k-word synthetic HCLG, %.0f s of audio per stream in %.0f ms chunks; host wall clock around "
                     "AcceptWaveform + AdvanceDecoding (device sync included); the %d-stream pass runs online i-vector estimation, silence weighting and "
                     "incremental partial best paths of every stream per tick" % (seconds, chunk * 1e3, streams)}
+
+
+def planted_testset(g, durs, mine, synth):
+    """The shard `mine` of the test set as utterances with known transcripts: utterance u (global index) gets
+    round(3 x seconds) words sampled through the graph (synth.sample_path, seed 900000 + u), and a waveform that gives
+    exactly the path's number of output frames (3 T input frames at snip_edges: 400 + 160 (3 T - 1) samples)."""
+    paths = []
+    for u in mine:
+        n_words = max(1, int(round(float(durs[u]) * 3.0)))
+        paths.append(synth.sample_path(g, n_words, seed=900000 + int(u)))
+    frames = np.asarray([p.size for _, p in paths], np.int64)
+    samples = 400 + 160 * (3 * frames - 1)
+    waves = synth.make_waves_fast(samples / 16000.0 + 1e-6, seed=77)
+    waves = [w[:int(n)] if w.size >= n else np.pad(w, (0, int(n) - w.size)) for w, n in zip(waves, samples)]
+    return {"paths": paths, "frames": frames, "waves": waves, "samples": samples, "max_seconds": float(samples.max()) / 16000.0 + 0.5,
+            "row_off": np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)}
+
+
+def planted_rows(planted, row0, rows, num_pdfs):
+    """Rows [row0, row0 + rows) of the planted device matrix, on the host (the CPU leg decodes what the device searched)."""
+    import ctypes as C
+    from kaldi_amd._lib import check, lib
+    out = np.empty((int(rows), int(num_pdfs)), np.float32)
+    if rows:
+        check(lib().kamd_memcpy_d2h(out.ctypes.data_as(C.c_void_p), C.c_void_p(planted.ptr(int(row0))), out.nbytes))
+    return out
+
+
+def transcript_quality(planted_set, bd, latbin, determinize, frames_of):
+    """%WER of the timed run's 1-best against the planted transcripts, words per utterance, determinized lattice depth."""
+    ref, hyp, depth, n_words = {}, {}, [], []
+    for k, (words, _) in enumerate(planted_set["paths"]):
+        key = "utt%05d" % k
+        ref[key] = [str(w) for w in words]
+        o = bd.output(k)
+        hyp[key] = [] if o is None else [str(w) for w in o["words"]]
+        n_words.append(len(hyp[key]))
+        if determinize and k < 400:
+            cl = bd.compact_lattice(k)
+            if cl is not None:
+                depth.append(lattice_depth(cl, int(frames_of[k])))
+    wer = latbin.compute_wer(ref, hyp, "present")
+    return {"wer_line": wer[0], "words_per_utterance": float(np.mean(n_words)), "reference_words": int(sum(len(r) for r in ref.values())),
+            "determinized_lattice_depth_first_400": float(np.mean(depth)) if depth else None}
 
 
 def planted_variant(args, g, model, cfg, durs, make_decoder, timed, latbin, synth, log):
@@ -813,6 +941,7 @@ def planted_variant(args, g, model, cfg, durs, make_decoder, timed, latbin, synt
            "host_tail_cpu_ms_per_utterance": float(acc[6]) / n, "host_tail_exposed_ms": float(acc[3]), "host_threads": int(bd.opts.host_threads),
            "stage_ms": {"features": acc[0], "nnet": acc[1], "decode_queue_kernel": acc[2], "total_wall": acc[4]},
            "tokens_per_frame": counters[5] / fr_tot, "expanded_per_frame": counters[0] / fr_tot, "arcs_per_frame": counters[1] / fr_tot,
+           "links_per_frame": counters[4] / fr_tot, "level2_tokens_per_frame": counters[7] / fr_tot,
            "us_per_frame_per_lane": 1e3 * float(acc[2]) * int(st.lanes) / fr_tot, "failed_utterances": sum(1 for r in recs if r.error),
            "failures": failure_report(recs),
            "peak": args.planted_peak, "noise": args.planted_noise, "synthesis_s": t_synth,
@@ -857,6 +986,8 @@ def pmc_entry(args):
     """The committed rocprofv3 PMC passes (profiles/*_pmc.json) of this exact workload AND this exact library build, or None:
     counters are collected in separate profiler runs (tools/profile_round*.sh), never inside a bench run."""
     key = "%s/%s/%d/%s/%s" % (args.workload, args.graph, args.utts, args.ll_std, args.lm_scale)
+    if getattr(args, "headline", "random") == "faithful":
+        key = "%s/%s/%d/faithful/%s/%s/%s" % (args.workload, args.graph, args.utts, args.planted_peak, args.planted_noise, args.lm_scale)
     build = library_build_id()
     best = None
     pdir = os.path.join(ROOT, "profiles")
@@ -885,7 +1016,7 @@ def search_counter_view(args, counters, dec_ms):
     Everything but arcs_per_expanded_token is None unless profiles/ holds passes of this workload taken on this build."""
     out = {"arcs_per_expanded_token": float(counters[1] / max(counters[0], 1.0)), "counter_frac": None, "wait_fraction": None,
            "l2_hit_rate": None, "write_amplification": None, "read_bytes_upper_bound": None, "written_bytes": None, "pmc_file": None}
-    d = pmc_entry(args)
+    d = pmc_entry(args) if args is not None else None
     if d and "decode_queue" in d:
         q = d["decode_queue"]
         alg_writes = 20.0 * counters[4] + 12.0 * counters[5]            # SURVEY 8(d): links kept + tokens

@@ -379,6 +379,11 @@ int kamd_decoder_set_search_mode(kamd_decoder *d, int mode);
  * (pdfs beyond that are read from HBM) and words of the level-1 token table (states whose
  * probe window is full spill to the level-2 table in HBM).  Diagnostic, used by the tests. */
 int kamd_decoder_lds_layout(const kamd_decoder *d, int32_t *num_pdfs_lds, int32_t *table_words);
+/* Words of the level-1 (LDS) token table region: a power of two up to what kamd_decoder_lds_layout reports at creation
+ * (the default), or 0 for none.  A frame uses half of the region, or -- after a frame that created many tokens -- all of
+ * it; states that find their probe window full go to the level-2 table in HBM.  Results do not depend on it: the tests
+ * shrink the region to drive ordinary test cases through the level-2 and large-frame paths. */
+int kamd_decoder_set_level1_table(kamd_decoder *d, int32_t table_words);
 /* Decoder lanes that share one compute unit in this build (1: 1024-thread lanes, 2: 512-thread lanes):
  * resident lanes of a work-queue launch default to compute units x this. */
 int kamd_decoder_lanes_per_cu(void);
@@ -516,6 +521,13 @@ int kamd_decoder_queue_fetch_lattice(kamd_decoder *d, int32_t utt, void *copy_st
                                      float **state_cost, float **state_final, kamd_lat_arc **arcs);
 /* Blocks until the queue kernel has ended; *ms = its duration (HIP events on the launch
  * stream), *lanes = resident lanes used. */
+/* The same for FEW utterances that need MUCH room: n <= max_lanes tasks on n lanes, the token and link pools split between
+ * just these n (each lane's arenas are max_lanes / n times the usual ones) -- the second chance NnetBatchDecoder gives an
+ * utterance whose lane ran out of arena space.  Nothing of this decoder may be in flight; the next ordinary launch
+ * restores the uniform split.  Poll / result / fetch / wait as above. */
+int kamd_decoder_queue_launch_wide(kamd_decoder *d, const kamd_queue_task *tasks, int n, void *stream);
+/* kamd_decoder_sizes.max_lanes of the object. */
+int kamd_decoder_max_lanes(const kamd_decoder *d);
 int kamd_decoder_queue_wait(kamd_decoder *d, float *ms, int32_t *lanes);
 /* GetBestPath over a raw lattice given as arrays (the same ShortestPath as
  * kamd_decoder_best_path; no decoder state, thread-safe). */
@@ -1108,6 +1120,8 @@ typedef struct {
   float upload_wait_ms;                /* wall time the launching thread spent waiting for a pass's copies to be issued */
   int32_t upload_passes;
   float ivector_ms;                    /* device time of the online i-vector extraction (not part of nnet_ms), 0 without an extractor */
+  int32_t n_retried;                   /* utterances searched a second time on a lane with larger arenas (their first search ran
+                                        * out of token / link arena or lattice pool): inside decode_ms and total_ms */
 } kamd_batch_stats;
 typedef struct kamd_batch_decoder kamd_batch_decoder;
 /* The stages are not owned.  tid_phone as kamd_lattice_determinize_phone_pruned (NULL: word

@@ -102,6 +102,8 @@ struct BatchDecoder {
   hipEvent_t ev_long = NULL;
   std::vector<int64_t> ll_row;          // first row of utterance k's log-likelihoods in d_ll (== out_off unless split)
   std::vector<int> map_long, map_rest;  // queue-local utterance number -> position in `kept`
+  std::vector<int> map_retry;           // ... of a second-chance launch (kamd_decoder_queue_launch_wide)
+  std::vector<const float *> task_ll;   // per position in `kept`: the first log-likelihood row its task was given
   bool last_split = false;
   std::vector<int64_t> load_row;        // load_host: utterance k's first row in a matrix whose rows follow the LOAD order (kamd_batch_decoder_set_loglike_override)
   int host_split = 0;                   // load_host put this many of the longest utterances first (pass 0): they go to dec_long
@@ -136,12 +138,13 @@ static int GrowDev(T **p, size_t *cap, size_t need) {
 // (decoder/decoder-wrappers.cc:217-296): best path -> words / alignment / weight, raw lattice,
 // optional DeterminizeLatticePhonePrunedWrapper.
 #define KAMD_JOB_LONG (1 << 30)     // job = queue-local utterance number, | this bit for the long utterances' queue
+#define KAMD_JOB_RETRY (1 << 29)    // ... | this bit for a second-chance launch on the main decoder (map_retry)
 static void HostTail(BatchDecoder *b, int job, hipStream_t cs) {
   const auto t0 = std::chrono::steady_clock::now();
-  const bool lq = (job & KAMD_JOB_LONG) != 0;
-  const int u = job & ~KAMD_JOB_LONG;                                  // the queue's utterance number
+  const bool lq = (job & KAMD_JOB_LONG) != 0, rq = (job & KAMD_JOB_RETRY) != 0;
+  const int u = job & ~(KAMD_JOB_LONG | KAMD_JOB_RETRY);               // the queue's utterance number
   kamd_decoder *dec = lq ? b->dec_long : b->dec;
-  const int k = lq ? b->map_long[u] : (b->last_split ? b->map_rest[u] : u);   // position in `kept`
+  const int k = rq ? b->map_retry[u] : lq ? b->map_long[u] : (b->last_split ? b->map_rest[u] : u);   // position in `kept`
   UttOut &o = b->out[b->kept[k]];
   o.Clear();                             // what the previous run left in this slot
   int rc = kamd_decoder_queue_result(dec, u, &o.rec);
@@ -678,6 +681,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
   b->ll_row.assign(b->out_off.begin(), b->out_off.end() - 1);
   int64_t longest = 0;
   for (int k = 0; k < n; k++) longest = std::max(longest, b->out_off[k + 1] - b->out_off[k]);
+  b->task_ll.assign(n, NULL);
   bool split = !b->have_iv && WantSplit(b, n, longest, b->out_off.back());
   if (host_mode || b->d_ll_override) split = false;       // (the passes follow the upload -- see host_split below; a planted matrix is in load order)
   const bool online_iv = b->iv_extractor != NULL && !b->have_iv;
@@ -774,6 +778,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
           tasks[k].d_loglikes = ll_base + static_cast<size_t>(b->out_off[k]) * b->P;
           tasks[k].ld = b->P; tasks[k].n_frames = static_cast<int32_t>(b->out_off[k + 1] - b->out_off[k]);
           tasks[k].utt = k; tasks[k].reserved = 0;
+          b->task_ll[k] = tasks[k].d_loglikes;
         }
         rc = kamd_decoder_queue_launch(b->dec_long, tasks.data(), Kh, Kh, b->s_long);
         if (rc != KAMD_OK) return rc;
@@ -796,6 +801,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
       tasks[k].d_loglikes = ll_base + static_cast<size_t>(row) * b->P;
       tasks[k].ld = b->P; tasks[k].n_frames = static_cast<int32_t>(b->out_off[u + 1] - b->out_off[u]);
       tasks[k].utt = u - Kh; tasks[k].reserved = 0;       // queue-local number (map_rest when the long ones went elsewhere)
+      b->task_ll[u] = tasks[k].d_loglikes;
     }
     rc = kamd_decoder_queue_launch(b->dec, tasks.data(), n_main, b->opts.resident_lanes, st);
     if (rc != KAMD_OK) return rc;
@@ -845,6 +851,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
         tasks[i].d_loglikes = b->d_ll + static_cast<size_t>(b->ll_row[k]) * b->P;
         tasks[i].ld = b->P; tasks[i].n_frames = static_cast<int32_t>(b->out_off[k + 1] - b->out_off[k]);
         tasks[i].utt = loc[i]; tasks[i].reserved = 0;
+        b->task_ll[k] = tasks[i].d_loglikes;
       }
     };
     rc = forward(b->map_long, 0, b->map_long.size());
@@ -919,6 +926,65 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
     lanes += lanes_long;
   }
   if (collected < n) return kamd::SetError(KAMD_ERR_STATE, "work queue ended with %d of %d utterances published", collected, n);
+  // ---- second chance: an utterance whose lane ran out of token / link arena (or that found the lattice pool full) is
+  // searched again on a lane that owns a larger share of the pools -- a launch for the few of them, the pools split
+  // between 1/8 of the lanes first, then 1/64 (kamd_decoder_queue_launch_wide).  The reference has no capacities to run out
+  // of; here an unusually dense utterance costs a second search instead of a failure (KAMD_BATCH_RETRY=0 switches it off).
+  int n_retried = 0;
+  const char *retry_env = getenv("KAMD_BATCH_RETRY");        // (read per run: the tests switch it)
+  const bool retry_on = !(retry_env && retry_env[0] == '0');
+  for (int round = 0; retry_on && round < 2; round++) {
+    std::vector<int> again;
+    for (int k = 0; k < n; k++) {
+      const kamd::UttOut &o = b->out[b->kept[k]];
+      if (o.status == KAMD_ERR_CAPACITY && (o.rec.error & (2 | 4 | 64)) != 0 && (o.rec.error & 8) == 0 && b->task_ll[k]) again.push_back(k);
+    }
+    if (again.empty()) break;
+    const int max_lanes = kamd_decoder_max_lanes(b->dec);
+    const int group = std::max(1, max_lanes / (round == 0 ? 8 : 64));
+    for (size_t g0 = 0; g0 < again.size(); g0 += group) {
+      const int m = static_cast<int>(std::min(again.size() - g0, static_cast<size_t>(group)));
+      std::vector<kamd_queue_task> rt(m);
+      b->map_retry.assign(again.begin() + g0, again.begin() + g0 + m);
+      for (int i = 0; i < m; i++) {
+        const int k = b->map_retry[i];
+        rt[i].d_loglikes = b->task_ll[k]; rt[i].ld = b->P;
+        rt[i].n_frames = static_cast<int32_t>(b->out_off[k + 1] - b->out_off[k]); rt[i].utt = i; rt[i].reserved = 0;
+      }
+      rc = kamd_decoder_queue_launch_wide(b->dec, rt.data(), m, st);
+      if (rc != KAMD_OK) return rc;
+      int got = 0;
+      while (got < m) {
+        int k = kamd_decoder_queue_poll(b->dec, buf.data(), static_cast<int>(buf.size()));
+        if (k > 0) {
+          {
+            std::lock_guard<std::mutex> lk(b->mu);
+            for (int i = 0; i < k; i++) b->jobs.push_back(buf[i] | KAMD_JOB_RETRY);
+            b->pending += k;
+          }
+          b->cv_job.notify_all();
+          got += k;
+          continue;
+        }
+        const hipError_t q = hipStreamQuery(st);
+        if (q == hipSuccess) { if (kamd_decoder_queue_poll(b->dec, buf.data(), 0) == 0 && ++idle_after_end > 4) break; }
+        else if (q != hipErrorNotReady) return kamd::SetError(KAMD_ERR_HIP, "decoder work queue (second chance) failed: %s", hipGetErrorString(q));
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+      }
+      {
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->cv_done.wait(lk, [&] { return b->pending == 0; });      // (map_retry is reused by the next group)
+      }
+      float qms2 = 0; int32_t l2 = 0;
+      rc = kamd_decoder_queue_wait(b->dec, &qms2, &l2);
+      if (rc != KAMD_OK) return rc;
+      if (got < m) return kamd::SetError(KAMD_ERR_STATE, "second-chance queue ended with %d of %d utterances published", got, m);
+      qms += qms2;
+      n_retried += m;
+      idle_after_end = 0;
+    }
+  }
+  const double total_ms_all = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   kamd_batch_stats s;
   memset(&s, 0, sizeof(s));
   (void)hipEventElapsedTime(&s.feat_ms, b->ev[0], b->ev[1]);
@@ -945,8 +1011,9 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
       if (!host_mode) { (void)hipEventElapsedTime(&m, b->ev_n0[p], b->ev_n1[p]); s.nnet_ms += m; }
     }
   }
-  s.decode_ms = qms; s.total_ms = static_cast<float>(total_ms);
+  s.decode_ms = qms; s.total_ms = static_cast<float>(n_retried ? total_ms_all : total_ms);
   s.host_tail_ms = static_cast<float>(total_ms - t_last_done);
+  s.n_retried = n_retried;
   s.first_result_ms = static_cast<float>(t_first_done);
   s.nnet_flops = flops; s.lanes = lanes; s.nnet_passes = passes;
   s.long_utterances = two_queues ? b->long_lanes : 0;

@@ -59,7 +59,10 @@ typedef unsigned int u32;
 #define EXPT 3            // tokens per thread whose records are fetched together (EXPT * NT == BIGCAP)
 #define BIGCAP (EXPT * NT)   // tokens per flatten batch (deg > SMALL_DEG)
 #define FIN_CAP (6 * NT)     // tokens per frame the finalize sweep keeps in LDS (6 arrays)
-#define LDS_TABLE_CAP (8 * NT)   // level-1 table words (64 KB of a 1024-thread lane's LDS)
+#define LDS_TABLE_CAP (16 * NT)  // level-1 table region, words: 128 KB of a 1024-thread lane's LDS.  A frame uses the lower half
+                                 // (LDS_TABLE_SMALL words; the upper half is the commit's scratch) or, when the last frame was a
+                                 // large one, all of it (the commit's lists then live in HBM): AdvanceLane
+#define LDS_TABLE_SMALL (8 * NT)
 #define SMALL_DEG 4
 #define GL 8             // lanes of a group (4 * GL arcs of a token per trip)
 #define TPG 2            // tokens a 16-lane group expands per trip (their arc records are in flight together)
@@ -117,12 +120,14 @@ struct DecDev {
   const uint2 *e_hot;
   int num_pdfs_lds;     // log-likelihood row entries staged in LDS per frame (0 = none)
   int lds_table_cap;    // level-1 (LDS) table words, power of two or 0
+  int big_frame_tokens; // a frame after one that created more tokens than this inserts into the whole table region
   kamd_decoder_config cfg;
   int loose;            // search mode 2: arcs are kept against the seed cutoff (kamd_decoder_set_search_mode)
   int hash_cap, hash_mask, max_frames;
   const long long *lane_tok_base, *lane_lnk_base;  // per lane: offset into the pools
   const int *lane_tok_cap, *lane_lnk_cap;          // per lane: capacity (records)
   u64 *H; u32 *slots; int *slot_tok; u32 *stamp; u32 *wl;  // per lane: hash_cap (wl: 2x)
+  u64 *e2;              // per lane: hash_cap -- the frame's level-2 entries, dense, in slot-list order (CommitFrame2)
   int *tok_state; float *tok_cost; float *tok_extra; int *tok_map;  // per lane: arena_tokens
   Link *links;                                                      // per lane: arena_links
   int *tok_off;        // per lane: max_frames + 2
@@ -135,7 +140,7 @@ struct DecDev {
 
 // per-lane view
 struct Ctx {
-  u64 *H; u32 *slots; int *slot_tok; u32 *stamp; u32 *wl0, *wl1;
+  u64 *H; u64 *e2; u32 *slots; int *slot_tok; u32 *stamp; u32 *wl0, *wl1;
   int *tok_state; float *tok_cost; float *tok_extra; int *tok_map;
   Link *links; int *tok_off; int *lnk_off; float *cost_offsets; int *trace_ntok;
   float *trace_cutoff; float *scratch; LaneState *st;
@@ -147,7 +152,7 @@ __device__ inline Ctx MakeCtx(const DecDev &d, int lane) {
   size_t hc = static_cast<size_t>(d.hash_cap) + LDS_TABLE_CAP, mf = d.max_frames;
   const long long tbase = d.lane_tok_base[lane], lbase = d.lane_lnk_base[lane];
   c.tok_cap = d.lane_tok_cap[lane]; c.lnk_cap = d.lane_lnk_cap[lane];
-  c.H = d.H + lane * static_cast<size_t>(d.hash_cap); c.slots = d.slots + lane * hc; c.slot_tok = d.slot_tok + lane * hc;
+  c.H = d.H + lane * static_cast<size_t>(d.hash_cap); c.e2 = d.e2 + lane * static_cast<size_t>(d.hash_cap); c.slots = d.slots + lane * hc; c.slot_tok = d.slot_tok + lane * hc;
   c.stamp = d.stamp + lane * hc; c.wl0 = d.wl + lane * 2 * hc; c.wl1 = c.wl0 + hc;
   c.tok_state = d.tok_state + tbase; c.tok_cost = d.tok_cost + tbase;
   c.tok_extra = d.tok_extra + tbase; c.tok_map = d.tok_map + tbase;
@@ -188,6 +193,8 @@ __device__ __forceinline__ T LoadSecondArg() {
 // point cannot be computed before it
 __device__ __forceinline__ int Opaque(int v) { v = __builtin_amdgcn_readfirstlane(v); asm volatile("" : "+s"(v)); return v; }
 
+#define SH_HIST (LDS_TABLE_CAP / 32 > NT ? LDS_TABLE_CAP / 32 : NT)
+#define SH_CAND (NT / 2)
 struct Sh {  // workgroup-shared state
   u64 red64[NWAVES];
   int redi[NWAVES];
@@ -198,9 +205,15 @@ struct Sh {  // workgroup-shared state
   int c_lt, c_le;        // #costs < / <= best+beam of the newest token list
   int n_new;
   float redf[NWAVES];
-  u32 hist[256];
+  u32 hist[SH_HIST];     // radix-select bins / one "queued" bit per level-1 slot / the commit's linear cost histogram (TblSelectLinear)
+  float sel_cand[SH_CAND];   // TblSelectLinear: the members of the bucket that holds the wanted rank
   u32 next_cutoff_u;
-  int n_slots, n_slots1, n_links, wl_n[2], err, bigcnt, hugecnt, changed;   // n_slots: level-2 (HBM) entries, n_slots1: level-1 (LDS)
+  int n_slots, n_slots1, n_links, wl_n[2], err, bigcnt, hugecnt, changed;   // n_slots: level-2 (HBM) entries, n_slots1: level-1 (LDS), counted by the commit
+  int cache_valid;       // the newest token list's costs are in the LDS cost cache (small-table frames)
+  // the work-queue lane drops tokens that can never be expanded when it commits a list (CommitFrame2, `drop`): the list
+  // then holds cur_n of the cur_n_all tokens created, and its GetCutoff has been evaluated already (on all of them)
+  int cur_n_all, cutoff_ready;
+  float nx_cur_cutoff, nx_adaptive_beam;
   int sel_bin, sel_below;
   int scan_total;
   int big_total;
@@ -215,9 +228,10 @@ struct Sh {  // workgroup-shared state
 
 // phase ids for the diagnostic cycle breakdown
 // (the finalize sweep, per frame: FIN_FETCH = until the frame's records -- requested one frame ahead -- are in LDS,
-// FIN_EMIT / FIN_EPS = the two relaxations, FIN_STAGE = survivors staged; FIN_SWEEP = what is left: HBM-mode frames, the end)
+// FIN_EMIT / FIN_EPS = the two relaxations, FIN_STAGE = survivors staged; FIN_SWEEP = what is left: HBM-mode frames, the end;
+// COMMIT_SCAN = the commit's counting sweeps over the table: entries, best token, and -- `drop` -- the next frame's GetCutoff)
 enum { PH_FIN_FETCH = 0, PH_CUTOFF, PH_SEED, PH_EXPAND, PH_EXPAND_BIG, PH_EPS_CLOSURE, PH_COMPACT,
-       PH_FIXUP, PH_EPS_LINKS, PH_CLEAR, PH_FIN_SWEEP, PH_FIN_COMPACT, PH_FLAT_SETUP, PH_FIN_EMIT, PH_FIN_EPS, PH_FIN_STAGE };
+       PH_FIXUP, PH_EPS_LINKS, PH_CLEAR, PH_FIN_SWEEP, PH_FIN_COMPACT, PH_COMMIT_SCAN, PH_FIN_EMIT, PH_FIN_EPS, PH_FIN_STAGE };
 __device__ inline void Stamp(Sh *sh, int idx) {   // call right after a barrier
   if (Tid() == 0) {
     const unsigned long long now = __builtin_amdgcn_s_memtime();
@@ -503,8 +517,8 @@ __device__ __forceinline__ float BlockSelectLinear(SrcPtr src, int n, int k, flo
 // trip (~1-2k cycles).  A state whose window is full goes to the HBM table (level 2).
 // Entries are never removed inside a frame, so "window full / EMPTY seen" decide
 // membership consistently.  Slot ids: [0, lcap) = LDS, lcap + g = global slot g.
-#define LWIN 8
-struct Tbl { u64 *LH; int lcap; unsigned short *lslots; };   // lslots: level-1 slots in use (dense list, LDS)
+#define LWIN 8      // words of a window scanned together; a table probes lwin = LWIN or 2 * LWIN words (the large table, which runs fuller)
+struct Tbl { u64 *LH; int lcap; int lwin; int hmask; };   // hmask: this frame's level-2 (HBM) table size - 1, a power of two <= hash_cap
 __device__ inline u32 HashL(int s, int lcap) { return (static_cast<u32>(s) * 2654435761u >> 9) & static_cast<u32>(lcap - 1); }
 __device__ inline u64 TblLoad(const Ctx &c, const Tbl &t, int slot) {
   return slot < t.lcap ? t.LH[slot] : LoadH(&c.H[slot - t.lcap]);
@@ -513,10 +527,10 @@ __device__ inline u64 TblLoad(const Ctx &c, const Tbl &t, int slot) {
 // FindOrAddToken (lattice-faster-decoder.cc:266-306) on the frame's table.
 // returns slot (or -1 on overflow); *improved = created, or strictly lowered the cost.
 __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int state, float cost,
-                                 bool *improved, int slot_bias) {
+                                 bool *improved, int slot_bias, int hmask) {
   const u64 mine = Pack(state, cost);
-  u32 h = HashState(state, d.hash_mask);
-  for (int probe = 0; probe < d.hash_cap; probe++) {
+  u32 h = HashState(state, hmask);
+  for (int probe = 0; probe <= hmask; probe++) {
     // optimistic claim: one L2 round trip for a new token, and the returned word tells
     // whether an existing token of this state already has a cost <= ours.
     const u64 old = atomicCAS(&c.H[h], EMPTY64, mine);
@@ -532,7 +546,7 @@ __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int stat
       *improved = prev > mine;
       return static_cast<int>(h);
     }
-    h = (h + 1) & static_cast<u32>(d.hash_mask);
+    h = (h + 1) & static_cast<u32>(hmask);
     // a table that has overflowed is nearly full: every further insert would scan it end to end
     if ((probe & 63) == 63 && sh->err) break;
   }
@@ -598,11 +612,9 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
 }
 
 #define COMMIT_KEEP 2
-#define L2B 2             // level-2 (HBM) table entries / links per thread fetched together in the commit
+#define L2B 4             // level-2 (HBM) table entries / links per thread fetched together in the commit
 #define INSB 4            // links per thread fetched together in InsertEmitted (>= COMMIT_KEEP)
 static_assert(EXPT * NT == BIGCAP, "one outer expansion iteration must fit the flatten queue");
-static_assert(LDS_TABLE_CAP <= 256 * 32, "CommitFrame2 keeps one 'queued' bit per level-1 slot in Sh::hist[256]");
-static_assert(LDS_TABLE_CAP <= 65536, "level-1 slots are listed as 16-bit values");
 // Dense sweep over the frame's recorded emitting links (lattice-faster-decoder.cc:803-809):
 // FindOrAddToken for every link whose own tot passes the FINAL next_cutoff; the link's dst
 // becomes the table slot, or -1 when the arc is outside the final cutoff (the canonical
@@ -625,8 +637,10 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
       const int li = link_begin + Tid() + (g0 + k) * NT;
-      // the record of the arc ProcessArcs kept by index (a clamped lane may see a link its owner has rewritten: arc 0)
-      arc[k] = d.g.e_arcs[li < le ? static_cast<u32>(L[k].dst) : 0u];
+      // the record of the arc ProcessArcs kept by index -- only for the candidates that pass the final cutoff (2.5 were
+      // recorded per survivor at the matched load: the others all read arc 0, one cached line instead of a random 16-byte
+      // fetch each; a clamped lane may see a link its owner has rewritten: arc 0 as well)
+      arc[k] = d.g.e_arcs[(li < le && __int_as_float(L[k].ilabel) <= cutoff) ? static_cast<u32>(L[k].dst) : 0u];
     }
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
@@ -650,13 +664,13 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
   return k_surv;
 }
 
-__device__ inline int HashFind(const DecDev &d, const Ctx &c, int state) {
-  u32 h = HashState(state, d.hash_mask);
-  for (int probe = 0; probe < d.hash_cap; probe++) {
+__device__ inline int HashFind(const DecDev &d, const Ctx &c, int state, int hmask) {
+  u32 h = HashState(state, hmask);
+  for (int probe = 0; probe <= hmask; probe++) {
     u64 cur = LoadH(&c.H[h]);
     if (cur == EMPTY64) return -1;
     if (StateOf(cur) == state) return static_cast<int>(h);
-    h = (h + 1) & static_cast<u32>(d.hash_mask);
+    h = (h + 1) & static_cast<u32>(hmask);
     if ((probe & 1023) == 1023) return -1;   // only an overflowed table has runs this long
   }
   return -1;
@@ -667,48 +681,47 @@ __device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl
   if (t.lcap > 0) {
     const u64 mine = Pack(state, cost);
     const u32 h0 = HashL(state, t.lcap), m = static_cast<u32>(t.lcap - 1);
-    // scan the window with plain LDS reads (pipelined), then one atomic on the chosen word
-    int w_empty = -1, w_match = -1;
+    // scan the window LWIN words at a time with plain LDS reads (pipelined), then one atomic on the chosen word
+    for (int w0 = 0; w0 < t.lwin; w0 += LWIN) {
+      int w_empty = -1, w_match = -1;
 #pragma unroll
-    for (int w = 0; w < LWIN; w++) {
-      const u64 e = t.LH[(h0 + w) & m];
-      if (w_match < 0 && w_empty < 0) {
-        if (e == EMPTY64) w_empty = w;
-        else if (StateOf(e) == state) w_match = w;
+      for (int w = 0; w < LWIN; w++) {
+        const u64 e = t.LH[(h0 + w0 + w) & m];
+        if (w_match < 0 && w_empty < 0) {
+          if (e == EMPTY64) w_empty = w;
+          else if (StateOf(e) == state) w_match = w;
+        }
       }
-    }
-    int w = w_match >= 0 ? w_match : w_empty;
-    while (w >= 0 && w < LWIN) {
-      const u32 sl = (h0 + w) & m;
-      const u64 old = atomicCAS(&t.LH[sl], EMPTY64, mine);
-      if (old == EMPTY64) {
-        t.lslots[WaveAlloc(&sh->n_slots1)] = static_cast<unsigned short>(sl);   // cannot overflow: one entry per table word
-        *improved = true;
-        return static_cast<int>(sl);
+      int w = w_match >= 0 ? w_match : w_empty;
+      while (w >= 0 && w < LWIN) {
+        const u32 sl = (h0 + w0 + w) & m;
+        const u64 old = atomicCAS(&t.LH[sl], EMPTY64, mine);
+        if (old == EMPTY64) { *improved = true; return static_cast<int>(sl); }
+        if (StateOf(old) == state) {
+          if (old <= mine) { *improved = false; return static_cast<int>(sl); }
+          const u64 prev = atomicMin(&t.LH[sl], mine);
+          *improved = prev > mine;
+          return static_cast<int>(sl);
+        }
+        w++;   // lost the word to another state: keep probing
       }
-      if (StateOf(old) == state) {
-        if (old <= mine) { *improved = false; return static_cast<int>(sl); }
-        const u64 prev = atomicMin(&t.LH[sl], mine);
-        *improved = prev > mine;
-        return static_cast<int>(sl);
-      }
-      w++;   // lost the word to another state: keep probing
+      // (these LWIN words hold other states: the next LWIN, or level 2 once the whole window is full)
     }
   }
-  const int g = HashInsert(d, c, sh, state, cost, improved, t.lcap);
+  const int g = HashInsert(d, c, sh, state, cost, improved, t.lcap, t.hmask);
   return g < 0 ? g : g + t.lcap;
 }
 __device__ inline int TblFind(const DecDev &d, const Ctx &c, const Tbl &t, int state) {
   if (t.lcap > 0) {
     const u32 h0 = HashL(state, t.lcap);
-    for (int w = 0; w < LWIN; w++) {
+    for (int w = 0; w < t.lwin; w++) {
       const u32 sl = (h0 + w) & static_cast<u32>(t.lcap - 1);
       const u64 cur = t.LH[sl];
       if (cur == EMPTY64) return -1;
       if (StateOf(cur) == state) return static_cast<int>(sl);
     }
   }
-  const int g = HashFind(d, c, state);
+  const int g = HashFind(d, c, state, t.hmask);
   return g < 0 ? g : g + t.lcap;
 }
 
@@ -870,6 +883,7 @@ __device__ __forceinline__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *s
     S->lnk_used = eps_link_begin + n_eps_links;
     S->round = round;
     sh->round = round; sh->lnk_used = eps_link_begin + n_eps_links; sh->cur_tb = tok_base; sh->cur_n = n_new;
+    sh->cur_n_all = n_new; sh->cutoff_ready = 0;
     sh->cnt[1] += a_eps;                 // A_exp: epsilon arcs of surviving tokens
     sh->cnt[3] += k_surv;                // K_surv
     sh->cnt[4] += k_surv + n_eps_links;  // L_kept
@@ -881,24 +895,187 @@ __device__ __forceinline__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *s
   Stamp(sh, PH_CLEAR);
 }
 
-// LDS scratch of CommitFrame2 (regions of the dynamic LDS that are idle while a frame commits)
+// The frame's level-2 entries as the commit sees them: copied once, after the epsilon closure, from where the slot list
+// points (a dependent pair of loads per entry) into a dense per-lane array.  A frame behind a word boundary can hold 10^5
+// of them and the commit sweeps them several times: every later sweep is a coalesced read, E2B entries per thread in
+// flight, of words this very thread wrote (entry i belongs to thread i mod NT in every sweep: no barrier in between).
+#define E2B 4
+template <typename F>
+__device__ __forceinline__ void ForLevel2(const u64 *e2, int n, F f) {
+  for (int i0 = Tid(); i0 < n; i0 += E2B * NT) {
+    u64 e[E2B];
+#pragma unroll
+    for (int k = 0; k < E2B; k++) e[k] = e2[min(i0 + k * NT, n - 1)];
+#pragma unroll
+    for (int k = 0; k < E2B; k++) if (i0 + k * NT < n) f(i0 + k * NT, e[k]);
+  }
+}
+
+// GetCutoff (lattice-faster-decoder.cc:657-724) on a token list of n costs, given its best cost and the two counts
+// c_lt / c_le = #costs < / <= best + beam.  sel_max() / sel_min() return the max_active-th / min_active-th smallest cost
+// (0-based rank: what std::nth_element leaves there) and are only called when that value decides -- uniformly.
+template <typename SelMax, typename SelMin>
+__device__ __forceinline__ void GetCutoff(const kamd_decoder_config &cfg, int n, float best, int c_lt, int c_le, SelMax sel_max, SelMin sel_min,
+                                          float *cur_cutoff, float *adaptive_beam) {
+  const float beam_cutoff = best + cfg.beam;
+  if (cfg.max_active == 2147483647 && cfg.min_active == 0) { *cur_cutoff = beam_cutoff; *adaptive_beam = cfg.beam; return; }
+  // nth_element(max_active) < beam_cutoff  <=>  more than max_active costs < beam_cutoff
+  if (n > cfg.max_active && c_lt > cfg.max_active) {
+    const float mac = sel_max();
+    *adaptive_beam = mac - best + cfg.beam_delta;   // :700-702
+    *cur_cutoff = mac;
+    return;
+  }
+  float mic = INFINITY;
+  if (n > cfg.min_active) {
+    if (cfg.min_active == 0) mic = best;
+    else if (c_le <= cfg.min_active) mic = sel_min();
+    else mic = -INFINITY;  // nth_element(min_active) <= beam_cutoff: not looser than the beam
+  }
+  if (mic > beam_cutoff) { *adaptive_beam = mic - best + cfg.beam_delta; *cur_cutoff = mic; }  // :715-718
+  else { *adaptive_beam = cfg.beam; *cur_cutoff = beam_cutoff; }
+}
+
+// BlockSelectKth over the costs of a frame's table entries where they lie: level 1 swept in LDS, the n2 level-2 entries
+// through their slot list in HBM.  The same 4-pass radix select on the order-preserving cost words; no scratch but Sh.
+__device__ inline float TblSelectKth(const Ctx &c, const Tbl &tbl, int n2, int k, Sh *sh) {
+  const int tid = Tid();
+  u32 prefix = 0, mask = 0;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    __syncthreads();
+    if (tid < 256) sh->hist[tid] = 0;
+    __syncthreads();
+    // (the costs of a frame share their top bytes -- a few bins per wavefront, added by ballot -- and are uniformly spread in
+    // the low ones, where the ballot loop would run once per lane: plain LDS atomics there)
+    auto add = [&](u64 e) {
+      const u32 key = static_cast<u32>(e);
+      const bool act = e != EMPTY64 && (key & mask) == prefix;
+      if (shift >= 16) WaveHistAdd(sh->hist, (key >> shift) & 255, act);
+      else if (act) atomicAdd(&sh->hist[(key >> shift) & 255], 1u);
+    };
+    for (int sl = tid; sl < tbl.lcap; sl += NT) add(tbl.LH[sl]);
+    ForLevel2(c.e2, n2, [&](int, u64 e) { add(e); });
+    __syncthreads();
+    if (tid < 64) {   // one wavefront: 4 bins per lane, shuffle scan, locate rank k
+      const int l = tid;
+      const int h0 = sh->hist[4 * l], h1 = sh->hist[4 * l + 1], h2 = sh->hist[4 * l + 2], h3 = sh->hist[4 * l + 3];
+      const int mine = h0 + h1 + h2 + h3;
+      int incl = mine;
+      for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (l >= o) incl += t; }
+      const int excl = incl - mine;
+      if (k >= excl && k < incl) {
+        int cum = excl, b = 4 * l;
+        if (cum + h0 > k) { } else { cum += h0; b++; if (cum + h1 > k) { } else { cum += h1; b++; if (cum + h2 > k) { } else { cum += h2; b++; } } }
+        sh->sel_bin = b; sh->sel_below = cum;
+      }
+    }
+    __syncthreads();
+    prefix |= static_cast<u32>(sh->sel_bin) << shift;
+    mask |= 255u << shift;
+    k -= sh->sel_below;
+  }
+  __syncthreads();
+  return OrderedToFloat(prefix);
+}
+
+// The max_active-th smallest cost of a frame's table entries (known to lie below best + beam), the way BlockSelectLinear
+// finds it in a dense array: ONE pass builds a histogram of SH_HIST buckets over the linear range [best, best + beam)
+// (monotone bucket map), the bucket that holds rank k is located by a workgroup scan, ONE more pass collects that bucket's
+// members (a few dozen of 10^5) and their exact ranks decide.  Falls back to the radix select when the bucket is too
+// crowded.  Level 1 swept in LDS, level 2 from its dense copy (ForLevel2): a frame of 10^5 tokens is read twice, not five
+// times.  `count` is called for every entry as well (the caller's c_lt / c_le ride on the first pass).
+__device__ __forceinline__ int TblBucket(float v, float best, float scale) {
+  const float b = (v - best) * scale;
+  return b < static_cast<float>(SH_HIST) ? (b < 0.f ? 0 : static_cast<int>(b)) : -1;
+}
+// pass 1: the histogram (Sh::hist), count(cost) called for every entry on the way
+template <typename Count>
+__device__ __forceinline__ void TblLinearHist(const Ctx &c, const Tbl &tbl, int n2, float best, float beam, Sh *sh, Count count) {
+  const int tid = Tid();
+  const float scale = static_cast<float>(SH_HIST) / beam;
+  for (int i = tid; i < SH_HIST; i += NT) sh->hist[i] = 0;
+  LdsBarrier();
+  auto pass1 = [&](u64 e) {
+    if (e == EMPTY64) return;
+    const float v = CostOf(e);
+    count(v);
+    const int b = TblBucket(v, best, scale);
+    if (b >= 0) atomicAdd(&sh->hist[b], 1u);
+  };
+  for (int sl = tid; sl < tbl.lcap; sl += NT) pass1(tbl.LH[sl]);
+  ForLevel2(c.e2, n2, [&](int, u64 e) { pass1(e); });
+  LdsBarrier();
+}
+// the rest, on the histogram TblLinearHist left in Sh::hist
+__device__ inline float TblSelectLinear(const Ctx &c, const Tbl &tbl, int n2, int k, float best, float beam, Sh *sh) {
+  const int tid = Tid();
+  const float scale = static_cast<float>(SH_HIST) / beam;
+  // locate the bucket of rank k: SH_HIST / NT buckets per thread, workgroup scan
+  constexpr int PER = SH_HIST / NT;
+  static_assert(SH_HIST % NT == 0, "TblSelectLinear: whole buckets per thread");
+  int h[PER], mine = 0;
+#pragma unroll
+  for (int q = 0; q < PER; q++) { h[q] = static_cast<int>(sh->hist[PER * tid + q]); mine += h[q]; }
+  const int incl = WaveInclScanI(mine);
+  if ((tid & 63) == 63) sh->redi[tid >> 6] = incl;
+  if (tid == 0) { sh->sel_bin = -1; sh->scan_total = 0; }
+  LdsBarrier();
+  int wbase = 0;
+  for (int q = 0; q < (tid >> 6); q++) wbase += sh->redi[q];
+  const int excl = wbase + incl - mine;
+  if (k >= excl && k < excl + mine) {
+    int cum = excl, b = PER * tid;
+#pragma unroll
+    for (int q = 0; q < PER; q++) { if (cum + h[q] > k) break; cum += h[q]; b++; }
+    sh->sel_bin = b; sh->sel_below = cum; sh->changed = static_cast<int>(sh->hist[b]);
+  }
+  LdsBarrier();
+  const int bin = sh->sel_bin, below = sh->sel_below, members = sh->changed;
+  if (bin < 0 || members > SH_CAND) return TblSelectKth(c, tbl, n2, k, sh);   // uniform decision
+  auto pass2 = [&](u64 e) {
+    if (e == EMPTY64) return;
+    const float v = CostOf(e);
+    if (TblBucket(v, best, scale) == bin) { const int p = WaveAlloc(&sh->scan_total); if (p < SH_CAND) sh->sel_cand[p] = v; }
+  };
+  for (int sl = tid; sl < tbl.lcap; sl += NT) pass2(tbl.LH[sl]);
+  ForLevel2(c.e2, n2, [&](int, u64 e) { pass2(e); });
+  LdsBarrier();
+  const int m = min(sh->scan_total, SH_CAND), kk = k - below;     // kk-th smallest of the m members
+  if (tid == 0) sh->sel_below = 0;
+  LdsBarrier();
+  for (int i = tid; i < m; i += NT) {
+    const float v = sh->sel_cand[i];
+    int less = 0, eq = 0;
+    for (int j = 0; j < m; j++) { const float u = sh->sel_cand[j]; less += u < v; eq += u == v; }
+    if (kk >= less && kk < less + eq) sh->sel_below = static_cast<int>(FloatToOrdered(v));  // all writers agree
+  }
+  LdsBarrier();
+  const float ans = OrderedToFloat(static_cast<u32>(sh->sel_below));
+  LdsBarrier();
+  return ans;
+}
+
+// LDS scratch of CommitFrame2: the upper half of the table region when the frame runs on the small table; nothing
+// (every cap 0: the lists then live in the lane's HBM areas) when the table takes the whole region
 struct CommitLds {
-  u32 *wl0, *wl1; int wl_cap;    // epsilon-closure worklists (table slots): the flatten-queue region
-  uint2 *owners; int owners_cap; // {slot, cost bits} of the tokens that own epsilon arcs: select/chunk scratch
+  u32 *wl0, *wl1; int wl_cap;    // epsilon-closure worklists (table slots)
+  uint2 *owners; int owners_cap; // {slot, cost bits} of the tokens that own epsilon arcs
+  float *cost_cache; int cache_cap;   // the new token list's costs, for the next frame's GetCutoff
 };
 
 // CommitFrame for a lane with a level-1 (LDS) table: the same steps, but everything that
-// concerns level-1 entries stays in LDS — the entries are found by scanning the 8192-word
-// table instead of through a slot list in HBM, a committed entry's cost half is overwritten
-// with its token index (so links resolve slot -> token with one ds_read), worklists and the
-// epsilon-owner list live in idle LDS regions, and the per-round "already queued" test is a
-// bit per slot.  Level-2 (HBM) entries keep the global lists; when a frame has none, no
-// barrier of the commit has to wait for global memory.
+// concerns level-1 entries stays in LDS -- the entries are found by sweeping the table (8 or 16
+// words per thread: no list of used slots is kept, an insert is one LDS atomic and nothing else),
+// an entry's token index is its rank in that sweep (ballots inside a wavefront, a prefix over the
+// wavefronts' counts), a committed entry's cost half is overwritten with its token index (so links resolve
+// slot -> token with one ds_read), worklists and the epsilon-owner list live in idle LDS and the
+// per-round "already queued" test is a bit per slot.  Level-2 (HBM) entries keep the global
+// lists; when a frame has none, no barrier of the commit has to wait for global memory.
 // my_slot[k] = table slot of this thread's k-th recorded link (link_begin + tid + k*NT), or
 // -1: kept in registers from InsertEmitted so the links are not read back.
 __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
-                             int emit_link_begin, float *cost_cache, int cache_cap, int k_surv,
-                             const CommitLds &L, const int (&my_slot)[COMMIT_KEEP], bool loose) {
+                                             int emit_link_begin, int k_surv,
+                                             const CommitLds &L, const int (&my_slot)[COMMIT_KEEP], bool loose, bool drop) {
   const int tid = Tid();
   LaneState *S = c.st;
   const int lcap = tbl.lcap;
@@ -908,13 +1085,11 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
   auto wl_put = [&](int which, int p, u32 v) { if (p < L.wl_cap) (which ? L.wl1 : L.wl0)[p] = v; else if (p < d.hash_cap) (which ? c.wl1 : c.wl0)[p] = v; else atomicOr(&sh->err, ERR_WL); };
   auto wl_get = [&](int which, int p) -> u32 { return p < L.wl_cap ? (which ? L.wl1 : L.wl0)[p] : (which ? c.wl1 : c.wl0)[p]; };
   // ---- epsilon closure: initial worklist = every token with epsilon arcs (:855-859)
-  const int n1a = sh->n_slots1;
-  for (int i = tid; i < n1a; i += NT) {
-    const u32 sl = tbl.lslots[i];
+  for (int sl = tid; sl < lcap; sl += NT) {
     const u64 e = tbl.LH[sl];
-    if (HasEps(StateOf(e)) && CostOf(e) <= cutoff) wl_put(0, WaveAlloc(&sh->wl_n[0]), sl);
+    if (e != EMPTY64 && HasEps(StateOf(e)) && CostOf(e) <= cutoff) wl_put(0, WaveAlloc(&sh->wl_n[0]), static_cast<u32>(sl));
   }
-  // (level-2 entries: four per thread and trip, slot list then table words, each set of loads issued together and
+  // (level-2 entries: two per thread and trip, slot list then table words, each set of loads issued together and
   // unconditional -- a load inside a conditional block is waited for at the block's end)
   for (int i0 = tid; i0 < n2; i0 += L2B * NT) {
     u32 sl[L2B]; u64 e[L2B];
@@ -930,7 +1105,7 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
       }
     }
   }
-  if (tid < 256) sh->hist[tid] = 0;                 // "queued this round" bits of the level-1 slots
+  for (int i = tid; i < lcap / 32; i += NT) sh->hist[i] = 0;   // "queued this round" bits of the level-1 slots
   LdsBarrier();
   if (sh->wl_n[0] > L.wl_cap) __syncthreads();
   int cur = 0;
@@ -970,7 +1145,7 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
     if (sh->wl_n[cur ^ 1] > L.wl_cap) __syncthreads();   // uniform: the overflow of the next worklist is in HBM
     const int err_now = sh->err;     // read between two barriers: uniform
     if (tid == 0) sh->wl_n[cur] = 0;
-    if (tid < 256) sh->hist[tid] = 0;
+    for (int i = tid; i < lcap / 32; i += NT) sh->hist[i] = 0;
     cur ^= 1;
     LdsBarrier();
     if (err_now) break;
@@ -980,25 +1155,92 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
   if (sh->n_slots > 0) __syncthreads();   // uniform: level-2 slot list (HBM) complete before it is read
   Stamp(sh, PH_EPS_CLOSURE);
   // ---- compaction: every table entry becomes a token of list 'list' (all of them are within
-  // the cutoff: the inserts tested it).  The same sweep finds the list's best token for the
-  // NEXT frame's GetCutoff and collects the owners of epsilon arcs.
+  // the cutoff: the inserts tested it; in a loose frame -- search mode 2 -- those beyond it count too: they are just not
+  // epsilon-expanded, :867).  First sweep: how many entries each thread owns and the list's best token (for the NEXT
+  // frame's GetCutoff); a prefix sum turns the counts into token indices; second sweep: the records.
   const int tok_base = sh->cur_tb + sh->cur_n;   // == c.tok_off[list]
   const int ns2 = min(sh->n_slots, d.hash_cap);  // level-2 entries (emitting + closure)
   u64 kmin = EMPTY64;
-  // loose (search mode 2 on this frame): entries beyond the cutoff are tokens too (they are just not epsilon-expanded, :867)
-  // Every entry becomes a token (the inserts tested the cutoff; in a loose frame those beyond it count too), so an entry's
-  // place in the slot lists IS its token index: no allocation, no atomic.
+  auto key_of = [&](u64 e) -> u64 { return (static_cast<u64>(static_cast<u32>(e)) << 32) | static_cast<u32>(PlainState(StateOf(e))); };
+  // (token indices go to the entries in sweep order, wavefront by wavefront: within one step of a wavefront's sweep the
+  // occupied lanes get consecutive indices -- a ballot -- so that the records below are written coalesced; the wavefront's
+  // first index is the number of entries the wavefronts before it own)
+  int wave_cnt = 0;
+  for (int sl = tid; sl < lcap; sl += NT) {          // lcap is a multiple of NT: every lane of a wavefront makes the same trips
+    const u64 e = tbl.LH[sl];
+    const bool occ = e != EMPTY64;
+    wave_cnt += __popcll(__ballot(occ));
+    if (occ) { const u64 k = key_of(e); kmin = k < kmin ? k : kmin; }
+  }
+  // (level 2: the one sweep through the slot list -- E2B dependent pairs of loads in flight -- that leaves the entries dense)
+  for (int i0 = tid; i0 < ns2; i0 += E2B * NT) {
+    u32 sl[E2B]; u64 e[E2B];
+#pragma unroll
+    for (int k = 0; k < E2B; k++) sl[k] = c.slots[min(i0 + k * NT, ns2 - 1)];
+#pragma unroll
+    for (int k = 0; k < E2B; k++) e[k] = LoadH(&c.H[static_cast<int>(sl[k]) - lcap]);
+#pragma unroll
+    for (int k = 0; k < E2B; k++)
+      if (i0 + k * NT < ns2) {
+        c.e2[i0 + k * NT] = e[k];
+        if (e[k] != EMPTY64) { const u64 kk = key_of(e[k]); kmin = kk < kmin ? kk : kmin; }
+      }
+  }
+  kmin = WaveMin64(kmin);
+  LdsBarrier();
+  if ((tid & 63) == 0) { sh->red64[tid >> 6] = kmin; sh->redi[tid >> 6] = wave_cnt; }
+  LdsBarrier();
+  kmin = sh->red64[0];
+  int n1 = 0, my_base = 0;                                      // level-1 entries (emitting + closure); those of the wavefronts before mine
+  for (int i = 0; i < NWAVES; i++) {
+    if (i > 0) kmin = sh->red64[i] < kmin ? sh->red64[i] : kmin;
+    const int cw = sh->redi[i];
+    if (i < (tid >> 6)) my_base += cw;
+    n1 += cw;
+  }
+  const int n_all = n1 + ns2;
+  const float best_next = n_all > 0 ? OrderedToFloat(static_cast<u32>(kmin >> 32)) : INFINITY;
+  const float next_beam_cutoff = best_next + d.cfg.beam;
+  // ---- `drop` (the work-queue lane, when another frame follows): a token that the NEXT frame will not expand -- its cost is
+  // beyond that frame's GetCutoff, which depends on nothing but the costs in this table -- and whose state has no epsilon
+  // arc has no forward link and never will have: PruneForwardLinks gives it extra cost +inf and PruneTokensForFrame deletes
+  // it (lattice-faster-decoder.cc:312-383, 492-511), whatever comes later.  Such tokens get no record here and the links
+  // into them are dropped like the arcs outside the final cutoff: the lane writes, keeps and finalizes what can reach the
+  // lattice.  They still count (trace, counters, the next frame's max-active / min-active logic: all of that is evaluated
+  // right here, on the whole table).  Not on a call's last frame, whose tokens all stay (final costs / the next call).
+  const bool do_drop = drop && n_all > 0;
+  float nx_cutoff = INFINITY, nx_abeam = d.cfg.beam;
+  int live_base = my_base, n_live1 = n1;
+  auto is_live = [&](u64 e) -> bool { return CostOf(e) <= nx_cutoff || HasEps(StateOf(e)); };
+  if (do_drop) {
+    int cl = 0, ce = 0;
+    TblLinearHist(c, tbl, ns2, best_next, d.cfg.beam, sh, [&](float w) { cl += w < next_beam_cutoff; ce += w <= next_beam_cutoff; });
+    BlockSum2<true>(cl, ce, sh);
+    GetCutoff(d.cfg, n_all, best_next, cl, ce, [&]() { return TblSelectLinear(c, tbl, ns2, d.cfg.max_active, best_next, d.cfg.beam, sh); },
+              [&]() { return TblSelectKth(c, tbl, ns2, d.cfg.min_active, sh); }, &nx_cutoff, &nx_abeam);
+    int wave_live = 0;
+    for (int sl = tid; sl < lcap; sl += NT) {
+      const u64 e = tbl.LH[sl];
+      wave_live += __popcll(__ballot(e != EMPTY64 && is_live(e)));
+    }
+    LdsBarrier();
+    if ((tid & 63) == 0) sh->redi[tid >> 6] = wave_live;
+    LdsBarrier();
+    live_base = 0; n_live1 = 0;
+    for (int i = 0; i < NWAVES; i++) { const int cw = sh->redi[i]; if (i < (tid >> 6)) live_base += cw; n_live1 += cw; }
+  }
+  Stamp(sh, PH_COMMIT_SCAN);      // (every path above ends on a barrier)
+  int a_eps = 0, c_lt = 0, c_le = 0, eps_dropped = 0;
   auto commit_entry = [&](u64 e, int pos, int *idx_out) {
     int idx = -1;
     if (loose || CostOf(e) <= cutoff) {
       idx = tok_base + pos;
       if (idx < c.tok_cap) {
-        const int st = PlainState(StateOf(e));
-        c.tok_state[idx] = st;
-        c.tok_cost[idx] = CostOf(e);
-        if (idx - tok_base < cache_cap) cost_cache[idx - tok_base] = CostOf(e);
-        const u64 k = (static_cast<u64>(static_cast<u32>(e)) << 32) | static_cast<u32>(st);
-        kmin = k < kmin ? k : kmin;
+        const float w = CostOf(e);
+        c.tok_state[idx] = PlainState(StateOf(e));
+        c.tok_cost[idx] = w;
+        if (!do_drop && pos < L.cache_cap) L.cost_cache[pos] = w;          // (`drop`: that GetCutoff is done)
+        c_lt += w < next_beam_cutoff; c_le += w <= next_beam_cutoff;      // the next frame's GetCutoff counts
       } else { atomicOr(&sh->err, ERR_TOK); idx = -1; }
     } else atomicOr(&sh->err, ERR_INTERNAL);     // cannot happen: the index space above counts every entry
     *idx_out = idx;
@@ -1009,49 +1251,51 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
     else if (p < d.hash_cap) { c.wl1[p] = slot; c.scratch[p] = CostOf(e); }
     else atomicOr(&sh->err, ERR_WL);
   };
-  const int n1 = sh->n_slots1;                   // level-1 entries (emitting + closure)
-  for (int i = tid; i < n1; i += NT) {
-    const u32 sl = tbl.lslots[i];
-    const u64 e = tbl.LH[sl];
-    int idx;
-    commit_entry(e, i, &idx);
-    if (idx >= 0 && HasEps(StateOf(e)) && CostOf(e) <= cutoff) add_owner(sl, e);
-    tbl.LH[sl] = (e & 0xFFFFFFFF00000000ull) | static_cast<u32>(idx);   // cost half -> token index
+  {
+    int run = live_base;
+    const u64 lt = (1ull << (tid & 63)) - 1ull;
+    for (int sl = tid; sl < lcap; sl += NT) {
+      const u64 e = tbl.LH[sl];
+      const bool occ = e != EMPTY64;
+      const bool lv = occ && (!do_drop || is_live(e));
+      const u64 m = __ballot(lv);
+      const int pos = run + __popcll(m & lt);
+      run += __popcll(m);
+      if (!occ) continue;
+      int idx = -1;
+      if (lv) {
+        commit_entry(e, pos, &idx);
+        if (idx >= 0 && HasEps(StateOf(e)) && CostOf(e) <= cutoff) add_owner(static_cast<u32>(sl), e);
+      }
+      tbl.LH[sl] = (e & 0xFFFFFFFF00000000ull) | static_cast<u32>(idx);   // cost half -> token index (all ones: no token)
+    }
   }
-  for (int i0 = tid; i0 < ns2; i0 += L2B * NT) {
-    u32 sl[L2B]; u64 e[L2B];
+  for (int i0 = tid; i0 < ns2; i0 += E2B * NT) {
+    u32 sl[E2B]; u64 e[E2B];
 #pragma unroll
-    for (int k = 0; k < L2B; k++) sl[k] = c.slots[min(i0 + k * NT, ns2 - 1)];
+    for (int k = 0; k < E2B; k++) { sl[k] = c.slots[min(i0 + k * NT, ns2 - 1)]; e[k] = c.e2[min(i0 + k * NT, ns2 - 1)]; }
 #pragma unroll
-    for (int k = 0; k < L2B; k++) e[k] = LoadH(&c.H[static_cast<int>(sl[k]) - lcap]);
-#pragma unroll
-    for (int k = 0; k < L2B; k++) {
+    for (int k = 0; k < E2B; k++) {
       const int i = i0 + k * NT;
       if (i < ns2) {
         if (e[k] == EMPTY64) atomicOr(&sh->err, ERR_INTERNAL);
         else {
-          int idx;
-          commit_entry(e[k], n1 + i, &idx);
+          int idx = -1;
+          if (!do_drop) commit_entry(e[k], n1 + i, &idx);
+          else if (is_live(e[k])) commit_entry(e[k], n_live1 + WaveAlloc(&sh->n_new), &idx);   // (n_new: idle since InitSh / the last commit)
           if (idx >= 0 && HasEps(StateOf(e[k])) && CostOf(e[k]) <= cutoff) add_owner(sl[k], e[k]);
           c.slot_tok[sl[k]] = idx;
         }
       }
     }
   }
-  // full barrier only when level-2 entries or list overflow put data in HBM that others read
-  const bool hbm_lists = ns2 > 0;
-  if (hbm_lists) kmin = BlockMin64(kmin, sh); else {
-    kmin = WaveMin64(kmin);
-    LdsBarrier();
-    if ((tid & 63) == 0) sh->red64[tid >> 6] = kmin;
-    LdsBarrier();
-    kmin = sh->red64[0];
-    for (int i = 1; i < NWAVES; i++) kmin = sh->red64[i] < kmin ? sh->red64[i] : kmin;
-  }
-  const int n_new = min(n1 + ns2, c.tok_cap - tok_base);
+  // the links below read the token indices other threads have just written: LDS only, unless level-2 entries or an
+  // overflowing owner list put data in HBM that others read
+  LdsBarrier();
   const int n_owner = sh->wl_n[1];
-  if (n_owner > L.owners_cap && !hbm_lists) __syncthreads();   // overflowed owners went to HBM
-  const float next_beam_cutoff = (n_new > 0 ? OrderedToFloat(static_cast<u32>(kmin >> 32)) : INFINITY) + d.cfg.beam;
+  const int n_new = min(do_drop ? n_live1 + sh->n_new : n_all, c.tok_cap - tok_base);     // the records of list 'list'
+  const bool hbm_lists = ns2 > 0 || n_owner > L.owners_cap;
+  if (hbm_lists) __syncthreads();
   Stamp(sh, PH_COMPACT);
   auto tok_of_slot = [&](int slot) -> int {
     return slot < lcap ? static_cast<int>(static_cast<u32>(tbl.LH[slot])) : c.slot_tok[slot];
@@ -1086,7 +1330,6 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
   }
   // ---- epsilon links of the surviving tokens (final costs), :875-897
   const int eps_link_begin = emit_link_begin + min(sh->n_links, c.lnk_cap - emit_link_begin);   // == c.lnk_off[2 * list + 1]
-  int a_eps = 0, c_lt = 0, c_le = 0;
   {
     const int ne = min(n_owner, d.hash_cap);
     for (int i = tid; i < ne; i += NT) {
@@ -1108,7 +1351,10 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
           if (tot_cost < cutoff) {
             const int slot2 = TblFind(d, c, tbl, arc.nextstate);
             const int dst = slot2 >= 0 ? tok_of_slot(slot2) : -1;
-            if (dst < 0) { atomicOr(&sh->err, ERR_INTERNAL); continue; }
+            if (dst < 0) {           // `drop`: a link into a token without a record is a link the final sweep would excise
+              if (do_drop && slot2 >= 0) eps_dropped++; else atomicOr(&sh->err, ERR_INTERNAL);
+              continue;
+            }
             const int li = eps_link_begin + WaveAlloc(&sh->wl_n[0]);   // worklist 0 is idle here
             if (li >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
             Link Lk; Lk.src = t; Lk.dst = dst; Lk.ilabel = 0; Lk.olabel = arc.olabel;
@@ -1119,29 +1365,28 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
       }
     }
   }
-  // ---- the next frame's GetCutoff counts, from the LDS copy of the costs
-  for (int i = tid; i < n_new; i += NT) {
-    const float w = i < cache_cap ? cost_cache[i] : c.tok_cost[tok_base + i];
-    c_lt += w < next_beam_cutoff; c_le += w <= next_beam_cutoff;
-  }
   LdsBarrier();
   Stamp(sh, PH_EPS_LINKS);
   // ---- clear the table, publish offsets and counters
-  for (int i = tid; i < n1; i += NT) tbl.LH[tbl.lslots[i]] = EMPTY64;
+  for (int sl = tid; sl < lcap; sl += NT) tbl.LH[sl] = EMPTY64;
   if (ns2 > 0) {
-    for (int i = tid; i < ns2; i += NT) {
-      const int sl = static_cast<int>(c.slots[i]);
-      __hip_atomic_store(&c.H[sl - lcap], EMPTY64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i0 = tid; i0 < ns2; i0 += E2B * NT) {
+      int sl[E2B];
+#pragma unroll
+      for (int k = 0; k < E2B; k++) sl[k] = static_cast<int>(c.slots[min(i0 + k * NT, ns2 - 1)]);
+#pragma unroll
+      for (int k = 0; k < E2B; k++)
+        if (i0 + k * NT < ns2) __hip_atomic_store(&c.H[sl[k] - lcap], EMPTY64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     DrainStores();   // the next frame's CAS / atomicMin must find the cleared words in L2
   }
   // the two work counters need no workgroup total in this frame: one LDS atomic per wavefront onto the running sums
   {
-    const int ks = WaveSumI(k_surv), ae = WaveSumI(a_eps);
+    const int ks = WaveSumI(k_surv), ae = WaveSumI(a_eps), ed = WaveSumI(eps_dropped);
     if ((tid & 63) == 0) {
       atomicAdd(reinterpret_cast<unsigned long long *>(&sh->cnt[1]), static_cast<unsigned long long>(ae));   // A_exp: epsilon arcs of surviving tokens
       atomicAdd(reinterpret_cast<unsigned long long *>(&sh->cnt[3]), static_cast<unsigned long long>(ks));   // K_surv
-      atomicAdd(reinterpret_cast<unsigned long long *>(&sh->cnt[4]), static_cast<unsigned long long>(ks));   // L_kept (+ the epsilon links below)
+      atomicAdd(reinterpret_cast<unsigned long long *>(&sh->cnt[4]), static_cast<unsigned long long>(ks + ed));   // L_kept (+ the epsilon links below; `drop`: the unwritten ones count)
     }
   }
   BlockSum2<true>(c_lt, c_le, sh);
@@ -1153,12 +1398,16 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
     S->lnk_used = eps_link_begin + n_eps_links;
     S->round = round;
     sh->round = round; sh->lnk_used = eps_link_begin + n_eps_links; sh->cur_tb = tok_base; sh->cur_n = n_new;
+    sh->cur_n_all = do_drop ? n_all : n_new; sh->cutoff_ready = do_drop; sh->nx_cur_cutoff = nx_cutoff; sh->nx_adaptive_beam = nx_abeam;
     atomicAdd(reinterpret_cast<unsigned long long *>(&sh->cnt[4]), static_cast<unsigned long long>(n_eps_links));
-    sh->cnt[5] += n_new;                 // N_tok
+    sh->cnt[5] += do_drop ? n_all : n_new;   // N_tok: tokens created
+    sh->cnt[7] += ns2;                   // (diagnostic, not part of the parity contract) tokens that went to the level-2 table
     sh->best_key = kmin; sh->c_lt = c_lt; sh->c_le = c_le;
+    sh->cache_valid = !do_drop && n_new <= L.cache_cap;
     sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->n_new = 0;
   }
-  LdsBarrier();
+  // the next frame's GetCutoff may read the list's costs where they lie (no LDS copy): a full barrier then
+  if (!do_drop && n_new > L.cache_cap) { DrainStores(); __syncthreads(); } else LdsBarrier();
   Stamp(sh, PH_CLEAR);
 }
 
@@ -1181,7 +1430,7 @@ __device__ __forceinline__ void ComputeFrameStats(const DecDev &d, const Ctx &c,
     c_lt += w < bc; c_le += w <= bc;
   }
   BlockSum2(c_lt, c_le, sh);
-  if (Tid() == 0) { sh->best_key = key; sh->c_lt = c_lt; sh->c_le = c_le; }
+  if (Tid() == 0) { sh->best_key = key; sh->c_lt = c_lt; sh->c_le = c_le; sh->cache_valid = n <= cache_cap; sh->cur_n_all = n; sh->cutoff_ready = 0; }
   __syncthreads();
 }
 
@@ -1219,7 +1468,7 @@ __device__ inline void InitSh(Sh *sh) {
   if (Tid() == 0) {
     sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
     sh->bigcnt = 0; sh->hugecnt = 0; sh->n_new = 0; sh->best_key = EMPTY64; sh->c_lt = 0; sh->c_le = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
-    sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0;
+    sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0; sh->cur_n_all = 0; sh->cutoff_ready = 0; sh->cache_valid = 0;
     for (int i = 0; i < 8; i++) sh->cnt[i] = 0;
     for (int i = 0; i < 16; i++) sh->ph[i] = 0;
     sh->t_prev = __builtin_amdgcn_s_memtime();
@@ -1249,10 +1498,10 @@ __device__ __forceinline__ void InitLane(const DecDev &d, const Ctx &c, Sh *shp)
     c.tok_off[0] = 0; c.lnk_off[0] = 0; c.lnk_off[1] = 0;
     sh.round = S->round;   // stamps persist across utterances: never reset
     bool imp;
-    HashInsert(d, c, &sh, d.g.start_flagged, 0.0f, &imp, 0);
+    HashInsert(d, c, &sh, d.g.start_flagged, 0.0f, &imp, 0, d.hash_mask);
   }
   __syncthreads();
-  Tbl tbl; tbl.LH = NULL; tbl.lcap = 0; tbl.lslots = NULL;     // InitDecoding has no LDS table: level 2 only
+  Tbl tbl; tbl.LH = NULL; tbl.lcap = 0; tbl.lwin = 0; tbl.hmask = d.hash_mask;     // InitDecoding has no LDS table: level 2 only
   CommitFrame(d, c, &sh, tbl, d.cfg.beam, 0, 0, NULL, 0, 0);
   PublishLaneEnd(d, c, &sh, 0);
 }
@@ -1264,24 +1513,49 @@ __global__ __launch_bounds__(NT, 4) void InitKernel(DecDev d, const int *lanes) 
 
 // The lane's regions of the dynamic LDS (a function of two DecDev fields: recomputed by every phase from its own view)
 struct AdvLds {
-  int2 *big_ta;      // [BIGCAP] {token (index in list), first emitting arc}: one ds_read_b64
-  int *big_scan;     // [BIGCAP] degree
-  float *ll;         // [num_pdfs_lds] the frame's log-likelihood row (+4: sentinel in front)
-  u32 *lh;           // [LHBINS] select histogram / commit scratch
-  float *cand;       // [LHCAND]
-  Tbl tbl;           // level-1 table + its dense slot list
+  float *ll;         // [num_pdfs_lds] the frame's log-likelihood row (first: the DMA's LDS base must stay below 64 KB)
+  u64 *T;            // [lds_table_cap] the table region; its upper half doubles as scratch:
+  int2 *big_ta;      //   expansion: [BIGCAP] {token (index in list), first emitting arc}: one ds_read_b64
+  int *big_scan;     //   expansion: [BIGCAP] degree
+  float *cost_cache; //   GetCutoff / commit (small table): [3 * BIGCAP] the newest token list's costs (same words as the queue)
+  u32 *lh;           //   GetCutoff: [LHBINS] select histogram; commit (small table): the epsilon owners
+  float *cand;       //   GetCutoff: [LHCAND]
+  int cap_small, cap_big;
 };
+// dyn_lds = [16 B][row][table region]; scratch inside the region's upper half: [A: 3 * BIGCAP words][C: LHBINS + LHCAND words]
+#define ADV_SCRATCH_WORDS (3 * BIGCAP + (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP))
+static_assert(ADV_SCRATCH_WORDS * 4 <= (LDS_TABLE_CAP - LDS_TABLE_SMALL) * 8, "the phases' scratch must fit the upper half of the table region");
 __device__ __forceinline__ AdvLds MakeAdvLds(unsigned char *dyn_lds, int num_pdfs_lds, int lds_table_cap) {
   AdvLds a;
-  a.big_ta = reinterpret_cast<int2 *>(dyn_lds);
+  a.ll = reinterpret_cast<float *>(dyn_lds + 16);
+  a.T = reinterpret_cast<u64 *>(a.ll + ((num_pdfs_lds + 3) & ~3));
+  a.cap_big = lds_table_cap; a.cap_small = lds_table_cap / 2;
+  unsigned char *up = reinterpret_cast<unsigned char *>(a.T + a.cap_small);
+  a.big_ta = reinterpret_cast<int2 *>(up);
   a.big_scan = reinterpret_cast<int *>(a.big_ta + BIGCAP);
-  a.ll = reinterpret_cast<float *>(a.big_scan + BIGCAP + 4);
-  a.lh = reinterpret_cast<u32 *>(a.ll + ((num_pdfs_lds + 3) & ~3));
+  a.cost_cache = reinterpret_cast<float *>(up);
+  a.lh = reinterpret_cast<u32 *>(up) + 3 * BIGCAP;
   a.cand = reinterpret_cast<float *>(a.lh + LHBINS);
-  a.tbl.LH = reinterpret_cast<u64 *>(a.lh + (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP));
-  a.tbl.lcap = lds_table_cap;
-  a.tbl.lslots = reinterpret_cast<unsigned short *>(a.tbl.LH + lds_table_cap);
   return a;
+}
+// this frame's table: all of the region after a frame that created many tokens (the level-1 table then runs at the
+// load the small one has on ordinary frames, probing a window twice as long), else the lower half
+#define BIG_FRAME_TOKENS (6 * NT)
+__device__ __forceinline__ Tbl FrameTable(const AdvLds &a, bool big, int hmask) {
+  Tbl t; t.LH = a.T; t.lcap = big ? a.cap_big : a.cap_small; t.lwin = big ? 2 * LWIN : LWIN; t.hmask = hmask;
+  return t;
+}
+// This frame's level-2 table: the lane's HBM table addressed through a mask sized for the frame -- four slots per recorded
+// candidate (every token of the frame comes from one, the epsilon closure adds a few), at least L2_MIN_SLOTS, at most all of
+// it.  An ordinary frame's overflow then lives in 512 KB per lane (Infinity-Cache resident for all lanes together) instead
+// of being scattered over the 8 MB that the frames behind a word boundary need; the table is empty between frames, so
+// every frame may pick its own size.
+#define L2_MIN_SLOTS (1 << 16)
+__device__ __forceinline__ int FrameLevel2Mask(int n_candidates, int hash_cap) {
+  int cap = L2_MIN_SLOTS;
+  const long long want = 4ll * (static_cast<long long>(n_candidates) + 4096);
+  while (cap < want && cap < hash_cap) cap <<= 1;
+  return min(cap, hash_cap) - 1;
 }
 // The frame's log-likelihood row travels HBM -> LDS by DMA (global_load_lds_dword: no registers held), issued one
 // frame ahead, as soon as the expansion that reads the previous row is over: a cold 24 KB read off the critical path.
@@ -1300,11 +1574,13 @@ __device__ __forceinline__ void RowDma(float *ll_lds, int num_pdfs_lds, const fl
 
 // what one phase of a frame hands to the next (registers; everything else is re-read from the descriptors)
 struct FrameCtl {
-  int tb, n;                       // the newest token list: first token, count
+  int tb, n, n_all;                // the newest token list: first token, records, tokens created (>= records: CommitFrame2's `drop`)
   float best; int best_state;      // its best token
   float cur_cutoff, adaptive_beam; // GetCutoff
   float cost_offset, seed_cutoff, next_cutoff;
   bool loose;
+  bool big;                        // the frame inserts into the whole table region (FrameTable)
+  int hmask;                       // ... and into a level-2 table of hmask + 1 slots (FrameLevel2Mask)
   int link_base, k_surv;
   int my_slot[COMMIT_KEEP];
 };
@@ -1317,46 +1593,37 @@ __device__ __forceinline__ void PhaseCutoff(int lane, Sh &sh, unsigned char *dyn
   const kamd_decoder_config cfg = d.cfg;
   const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
   const int tb = sh.cur_tb, n = sh.cur_n;   // == c.tok_off[frame], c.tok_off[frame + 1] - tb
+  const int n_all = sh.cur_n_all;           // tokens created (> n when the commit dropped those that cannot be expanded)
   const u64 key = sh.best_key;
   const int c_lt = sh.c_lt, c_le = sh.c_le;
-  float *cost_cache = reinterpret_cast<float *>(dyn_lds);
-  const bool cached = n <= 3 * BIGCAP;
+  const bool ready = sh.cutoff_ready != 0;
+  const float rd_cutoff = sh.nx_cur_cutoff, rd_abeam = sh.nx_adaptive_beam;
+  float *cost_cache = L.cost_cache;
+  const bool cached = sh.cache_valid != 0 && n <= 3 * BIGCAP;
   LdsBarrier();   // everyone has read the stats before a select may reuse Sh scratch
   float best = INFINITY; int best_state = -1;
   if (n > 0) { best = OrderedToFloat(static_cast<u32>(key >> 32)); best_state = static_cast<int>(key & 0xFFFFFFFFu); }
   float cur_cutoff, adaptive_beam;
-  const float beam_cutoff = best + cfg.beam;
-  if (cfg.max_active == 2147483647 && cfg.min_active == 0) {
-    cur_cutoff = beam_cutoff; adaptive_beam = cfg.beam;
+  if (ready) {                 // evaluated by the commit that made this list, on every token it created
+    cur_cutoff = rd_cutoff; adaptive_beam = rd_abeam;
   } else {
     lds_cfloat *cache_l = (lds_cfloat *)cost_cache;
     // the costs of a list too long for the LDS copy are read where they lie (the lane's arena: one pointer of the view)
     const float *cost = d.tok_cost + d.lane_tok_base[Opaque(lane)] + tb;
-    // nth_element(max_active) < beam_cutoff  <=>  more than max_active costs < beam_cutoff
-    if (n > cfg.max_active && c_lt > cfg.max_active) {
-      const float mac = cached ? BlockSelectLinear(cache_l, n, cfg.max_active, best, cfg.beam, L.lh, L.cand, &sh)
-                               : BlockSelectLinear(cost, n, cfg.max_active, best, cfg.beam, L.lh, L.cand, &sh);
-      adaptive_beam = mac - best + cfg.beam_delta;   // :700-702
-      cur_cutoff = mac;
-    } else {
-      float mic = INFINITY;
-      if (n > cfg.min_active) {
-        if (cfg.min_active == 0) mic = best;
-        else if (c_le <= cfg.min_active)
-          mic = cached ? BlockSelectKth(cache_l, n, cfg.min_active, &sh) : BlockSelectKth(cost, n, cfg.min_active, &sh);
-        else mic = -INFINITY;  // nth_element(min_active) <= beam_cutoff: not looser than the beam
-      }
-      if (mic > beam_cutoff) { adaptive_beam = mic - best + cfg.beam_delta; cur_cutoff = mic; }  // :715-718
-      else { adaptive_beam = cfg.beam; cur_cutoff = beam_cutoff; }
-    }
+    GetCutoff(cfg, n, best, c_lt, c_le,
+              [&]() { return cached ? BlockSelectLinear(cache_l, n, cfg.max_active, best, cfg.beam, L.lh, L.cand, &sh)
+                                    : BlockSelectLinear(cost, n, cfg.max_active, best, cfg.beam, L.lh, L.cand, &sh); },
+              [&]() { return cached ? BlockSelectKth(cache_l, n, cfg.min_active, &sh) : BlockSelectKth(cost, n, cfg.min_active, &sh); },
+              &cur_cutoff, &adaptive_beam);
   }
   LdsBarrier();
   Stamp(&sh, PH_CUTOFF);
-  fc.tb = tb; fc.n = n; fc.best = best; fc.best_state = best_state; fc.cur_cutoff = cur_cutoff; fc.adaptive_beam = adaptive_beam;
+  fc.tb = tb; fc.n = n; fc.n_all = n_all; fc.best = best; fc.best_state = best_state; fc.cur_cutoff = cur_cutoff; fc.adaptive_beam = adaptive_beam;
   // search mode 2: the seed bound replaces the final one on the frames where the reference's order-dependent extras
   // can matter, i.e. where max_active / min_active made the adaptive beam differ from the beam; with adaptive_beam ==
   // beam the next frame's cutoff (best + beam) equals this frame's final bound and every extra is dead on arrival
   fc.loose = d.loose != 0 && adaptive_beam != cfg.beam;
+  fc.big = L.cap_big > L.cap_small && n_all > d.big_frame_tokens;      // (token counts move slowly from frame to frame)
 }
 
 // ---- cost offset + seed of next_cutoff from the best token's arcs (:757-772), then ProcessEmitting (:783-815).
@@ -1366,7 +1633,7 @@ __device__ __forceinline__ void PhaseExpand(int lane, Sh &sh, unsigned char *dyn
   const DecDev d = LoadDecDev();
   const Ctx c = MakeCtx(d, Opaque(lane));
   const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
-  const Tbl &tbl = L.tbl;
+  const Tbl tbl = FrameTable(L, fc.big, d.hash_mask);       // (the expansion only records candidates: no table access)
   int2 *big_ta = L.big_ta; int *big_scan = L.big_scan;
   const int tid = Tid();
   const int tb = fc.tb, n = fc.n;
@@ -1380,7 +1647,7 @@ __device__ __forceinline__ void PhaseExpand(int lane, Sh &sh, unsigned char *dyn
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (tid == 0) {
     c.cost_offsets[frame] = cost_offset;
-    c.trace_ntok[frame] = n; c.trace_cutoff[frame] = cur_cutoff;
+    c.trace_ntok[frame] = fc.n_all; c.trace_cutoff[frame] = cur_cutoff;
     c.lnk_off[2 * (frame + 1)] = sh.lnk_used;
     sh.next_cutoff_u = FloatToOrdered(INFINITY);       // (the last frame's value was handed on as a parameter)
   }
@@ -1541,23 +1808,36 @@ __device__ __forceinline__ void PhaseInsert(int lane, Sh &sh, unsigned char *dyn
   const DecDev d = LoadDecDev();
   const Ctx c = MakeCtx(d, Opaque(lane));
   const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
-  fc.k_surv = InsertEmitted(d, c, &sh, L.tbl, fc.link_base, sh.n_links, fc.loose ? fc.seed_cutoff : fc.next_cutoff, fc.my_slot);
+  fc.hmask = FrameLevel2Mask(sh.n_links, d.hash_cap);
+  const Tbl tbl = FrameTable(L, fc.big, fc.hmask);
+  if (fc.big) {   // the upper half of the region was the expansion's queue: make it table
+    for (int sl = L.cap_small + Tid(); sl < L.cap_big; sl += NT) L.T[sl] = EMPTY64;
+    LdsBarrier();
+  }
+  fc.k_surv = InsertEmitted(d, c, &sh, tbl, fc.link_base, sh.n_links, fc.loose ? fc.seed_cutoff : fc.next_cutoff, fc.my_slot);
   Stamp(&sh, PH_FIXUP);
 }
 
 // ---- ProcessNonemitting(next_cutoff) + commit of token list frame + 1
-__device__ __forceinline__ void PhaseCommit(int lane, Sh &sh, unsigned char *dyn_lds, int frame, const FrameCtl &fc) {
+__device__ __forceinline__ void PhaseCommit(int lane, Sh &sh, unsigned char *dyn_lds, int frame, const FrameCtl &fc, bool drop) {
   const DecDev d = LoadDecDev();
   const Ctx c = MakeCtx(d, Opaque(lane));
   const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
+  const Tbl tbl = FrameTable(L, fc.big, fc.hmask);
   CommitLds cl;
-  cl.wl0 = reinterpret_cast<u32 *>(dyn_lds); cl.wl1 = cl.wl0 + (3 * BIGCAP) / 2; cl.wl_cap = (3 * BIGCAP) / 2;
-  cl.owners = reinterpret_cast<uint2 *>(L.lh); cl.owners_cap = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP) / 2;
-  CommitFrame2(d, c, &sh, L.tbl, fc.next_cutoff, frame + 1, fc.link_base, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP, fc.k_surv, cl, fc.my_slot, fc.loose);
+  if (fc.big) {        // no idle LDS: the worklists, the owner list and the costs stay in the lane's HBM areas
+    cl.wl0 = cl.wl1 = NULL; cl.wl_cap = 0; cl.owners = NULL; cl.owners_cap = 0; cl.cost_cache = NULL; cl.cache_cap = 0;
+  } else {
+    cl.wl0 = reinterpret_cast<u32 *>(L.cost_cache); cl.wl1 = cl.wl0 + (3 * BIGCAP) / 2; cl.wl_cap = (3 * BIGCAP) / 2;
+    cl.owners = reinterpret_cast<uint2 *>(L.lh); cl.owners_cap = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP) / 2;
+    cl.cost_cache = L.cost_cache; cl.cache_cap = 3 * BIGCAP;
+  }
+  CommitFrame2(d, c, &sh, tbl, fc.next_cutoff, frame + 1, fc.link_base, fc.k_surv, cl, fc.my_slot, fc.loose, drop);
 }
 
 // AdvanceDecoding (lattice-faster-decoder.cc:593-632): the frame loop of one lane.  Every phase takes its own view of
 // the descriptors (LoadDecDev above); what the phases hand to each other is the FrameCtl.
+template <bool kDropDead>
 __device__ __forceinline__ void AdvanceLane(int lane_in, Sh *shp, unsigned char *dyn_lds, const kamd_decode_task &task) {
   Sh &sh = *shp;
   const int lane = Opaque(lane_in);
@@ -1567,7 +1847,7 @@ __device__ __forceinline__ void AdvanceLane(int lane_in, Sh *shp, unsigned char 
     const DecDev d = LoadDecDev();
     const Ctx c = MakeCtx(d, Opaque(lane));
     const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
-    for (int i = Tid(); i < L.tbl.lcap; i += NT) L.tbl.LH[i] = EMPTY64;
+    for (int i = Tid(); i < L.cap_small; i += NT) L.T[i] = EMPTY64;     // (the upper half is cleared by the frames that use it)
     InitSh(&sh);
     LaneState *S = c.st;
     frame = S->frame;
@@ -1577,7 +1857,7 @@ __device__ __forceinline__ void AdvanceLane(int lane_in, Sh *shp, unsigned char 
       sh.lnk_used = S->lnk_used; sh.round = S->round;
     }
     if (task.n_frames > 0) RowDma(L.ll, d.num_pdfs_lds, task.d_loglikes);
-    ComputeFrameStats(d, c, &sh, frame, reinterpret_cast<float *>(dyn_lds), 3 * BIGCAP);
+    ComputeFrameStats(d, c, &sh, frame, L.cost_cache, 3 * BIGCAP);
   }
   for (int it = 0; it < task.n_frames; it++, frame++) {
     const float *ll = task.d_loglikes + static_cast<size_t>(it) * task.ld;
@@ -1597,7 +1877,9 @@ __device__ __forceinline__ void AdvanceLane(int lane_in, Sh *shp, unsigned char 
       const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
       RowDma(L.ll, d.num_pdfs_lds, ll + task.ld);
     }
-    PhaseCommit(lane, sh, dyn_lds, frame, fc);
+    // kDropDead (the work-queue lane: nothing reads its token lists before FinalizeDecoding): tokens that cannot be expanded
+    // get no record -- never on the call's last frame, whose tokens all stay
+    PhaseCommit(lane, sh, dyn_lds, frame, fc, kDropDead && it + 1 < task.n_frames);
     const int err_now = sh.err;    // CommitFrame ends with a barrier; nobody writes err before the next one
     LdsBarrier();
     if (err_now) { frame++; break; }
@@ -1613,7 +1895,7 @@ KAMD_SEARCH_KERNEL void AdvanceKernel(DecDev d_unused, const kamd_decode_task *t
   __shared__ Sh sh;
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
   const kamd_decode_task task = tasks[blockIdx.x];
-  AdvanceLane(task.lane, &sh, dyn_lds, task);
+  AdvanceLane<false>(task.lane, &sh, dyn_lds, task);     // (its token lists can be read between calls: GetRawLattice of a live decoder)
 }
 
 // FinalizeDecoding (lattice-faster-decoder.cc:638-653) = PruneForwardLinksFinal (:389-471)
@@ -2389,7 +2671,7 @@ KAMD_SEARCH_KERNEL void DecodeQueueKernel(DecDev d_unused, QueueDev q_unused) {
       InitLane(d, c, &sh);
     }
     __syncthreads();
-    AdvanceLane(lane, &sh, dyn_lds, task);
+    AdvanceLane<true>(lane, &sh, dyn_lds, task);
     __syncthreads();
     {
       const DecDev d = LoadDecDev();
@@ -2686,9 +2968,7 @@ __global__ __launch_bounds__(NT, 4) void TrailingSilenceKernel(DecDev d, const i
 }
 
 static inline size_t AdvanceLdsBytes(int num_pdfs_lds, int lds_table_cap) {
-  const size_t scratch = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP);
-  return (3 * BIGCAP + 4) * 4 + static_cast<size_t>((num_pdfs_lds + 3) & ~3) * 4 + scratch * 4 +
-         static_cast<size_t>(lds_table_cap) * (8 + 2);   // table words + the dense list of used slots
+  return 16 + static_cast<size_t>((num_pdfs_lds + 3) & ~3) * 4 + static_cast<size_t>(lds_table_cap) * 8;   // MakeAdvLds
 }
 
 // ------------------------------------------------------------------ host
@@ -2866,6 +3146,7 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
     return p;
   };
   d.H = static_cast<kamd::u64 *>(alloc(L * static_cast<size_t>(s.hash_capacity) * 8, 0xFF));
+  d.e2 = static_cast<kamd::u64 *>(alloc(L * static_cast<size_t>(s.hash_capacity) * 8, -1));
   d.slots = static_cast<kamd::u32 *>(alloc(L * hc * 4, 0));
   d.slot_tok = static_cast<int *>(alloc(L * hc * 4, 0));
   d.stamp = static_cast<kamd::u32 *>(alloc(L * hc * 4, 0));
@@ -2920,19 +3201,18 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
       if (hipDeviceSynchronize() != hipSuccess) ok = false;
     }
   }
-  // LDS budget (160 KB per CU): static Sh + flatten queue + select/chunk scratch + level-1 table
-  // + the log-likelihood row when it still fits
-  // LDS budget (160 KB per CU): static Sh + flatten queue + select/chunk scratch + level-1 table
-  // and its slot list + as much of the log-likelihood row as still fits (pdfs beyond that are
-  // read from HBM: LogLikePdf)
+  // LDS budget (160 KB per CU): static Sh + the level-1 table region (whose upper half doubles as the phases' scratch:
+  // MakeAdvLds) + as much of the log-likelihood row as still fits (pdfs beyond that are read from HBM: LogLikePdf)
   d.lds_table_cap = LDS_TABLE_CAP;
+  d.big_frame_tokens = BIG_FRAME_TOKENS;
+  if (const char *e = getenv("KAMD_BIG_FRAME_TOKENS")) d.big_frame_tokens = atoi(e);      // (experiments: tools/ab_bench.py)
   d.num_pdfs_lds = 0;
   const size_t lds_budget = 160 * 1024 / LANES_PER_CU - sizeof(kamd::Sh) - 1024;
   const size_t fixed = kamd::AdvanceLdsBytes(0, LDS_TABLE_CAP);
   if (fixed < lds_budget) d.num_pdfs_lds = static_cast<int>(std::min<size_t>(static_cast<size_t>(num_pdfs), (lds_budget - fixed) / 4) & ~static_cast<size_t>(3));
-  // the row is filled by LDS-DMA, whose LDS base travels in M0[15:0]: keep its end below 64 KB (the row starts behind the
-  // static part, <= 4 KB, and the flatten queue)
-  const size_t dma_reach = (65536 - 4096 - (3 * BIGCAP + 4) * 4) / 4;
+  // the row is filled by LDS-DMA, whose LDS base travels in M0[15:0]: keep its end below 64 KB (the row starts right behind
+  // the static part, <= 4 KB)
+  const size_t dma_reach = (65536 - 4096 - 16) / 4;
   if (static_cast<size_t>(d.num_pdfs_lds) > dma_reach) d.num_pdfs_lds = static_cast<int>(dma_reach & ~static_cast<size_t>(3));
   if (d.num_pdfs_lds + 3 >= num_pdfs && static_cast<size_t>(num_pdfs) <= dma_reach && kamd::AdvanceLdsBytes(num_pdfs, LDS_TABLE_CAP) <= lds_budget) d.num_pdfs_lds = num_pdfs;
   if (ok && (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel),
@@ -2944,10 +3224,10 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
     ok = false;
   if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::AdvanceKernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, d.lds_table_cap))) != hipSuccess)
+                                static_cast<int>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, LDS_TABLE_CAP))) != hipSuccess)
     ok = false;
   if (ok && hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::DecodeQueueKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                static_cast<int>(std::max<size_t>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, d.lds_table_cap), FIN_LDS_BYTES))) != hipSuccess)
+                                static_cast<int>(std::max<size_t>(kamd::AdvanceLdsBytes(d.num_pdfs_lds, LDS_TABLE_CAP), FIN_LDS_BYTES))) != hipSuccess)
     ok = false;
   for (int i = 0; ok && i < 2 * Decoder::kMaxTimed; i++) if (hipEventCreate(&D->ev[i]) != hipSuccess) ok = false;
   for (int i = 0; ok && i < 2; i++) if (hipEventCreate(&D->qev[i]) != hipSuccess) ok = false;
@@ -3035,6 +3315,15 @@ int kamd_decoder_lds_layout(const kamd_decoder *h, int32_t *num_pdfs_lds, int32_
   return KAMD_OK;
 }
 
+int kamd_decoder_set_level1_table(kamd_decoder *h, int32_t words) {
+  if (words < 0 || words > LDS_TABLE_CAP || (words & (words - 1)) != 0 || (words > 0 && words < 64))
+    return kamd::SetError(KAMD_ERR_ARG, "level-1 table region: 0 or a power of two in [64, %d] words", LDS_TABLE_CAP);
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  D->dev.lds_table_cap = words;       // (the LDS reservation stays what it was: the region is only used less)
+  D->dev.big_frame_tokens = words >= LDS_TABLE_CAP ? BIG_FRAME_TOKENS : (words / 2) * 3 / 4;      // three quarters of the half-region table
+  return KAMD_OK;
+}
+
 int kamd_decoder_set_search_mode(kamd_decoder *h, int mode) {
   if (mode != 1 && mode != 2) return kamd::SetError(KAMD_ERR_ARG, "search mode must be 1 (canonical) or 2 (canonical-loose)");
   reinterpret_cast<Decoder *>(h)->dev.loose = mode == 2;
@@ -3099,7 +3388,7 @@ int kamd_decoder_advance(kamd_decoder *h, const kamd_decode_task *tasks, int n, 
   KAMD_HIP(hipStreamSynchronize(st));
   const int slot = D->n_timed < Decoder::kMaxTimed ? D->n_timed : Decoder::kMaxTimed - 1;   // streaming: the last pair is reused
   KAMD_HIP(hipEventRecord(D->ev[2 * slot], st));
-  const size_t lds = kamd::AdvanceLdsBytes(D->dev.num_pdfs_lds, D->dev.lds_table_cap);
+  const size_t lds = kamd::AdvanceLdsBytes(D->dev.num_pdfs_lds, LDS_TABLE_CAP);
   hipLaunchKernelGGL(kamd::AdvanceKernel, dim3(n), dim3(NT), lds, st, D->dev, D->d_tasks);
   KAMD_HIP(hipGetLastError());
   KAMD_HIP(hipEventRecord(D->ev[2 * slot + 1], st));
@@ -3927,7 +4216,27 @@ int kamd_decoder_queue_configure(kamd_decoder *h, int64_t pool_bytes) {
   return KAMD_OK;
 }
 
+static int QueueLaunch(kamd_decoder *h, const kamd_queue_task *tasks, int n, int resident_lanes, void *stream, bool wide);
+
 int kamd_decoder_queue_launch(kamd_decoder *h, const kamd_queue_task *tasks, int n, int resident_lanes, void *stream) {
+  return QueueLaunch(h, tasks, n, resident_lanes, stream, false);
+}
+
+// A launch for few utterances that need much room (the second chance of utterances whose lane ran out of token / link
+// arena, NnetBatchDecoder): n lanes, one per task, the whole token and link pools split between just these n -- each
+// lane's arenas are max_lanes / n times the usual ones.  Nothing of this decoder may be in flight (the split is
+// uploaded synchronously); the next ordinary launch restores the uniform split.
+int kamd_decoder_queue_launch_wide(kamd_decoder *h, const kamd_queue_task *tasks, int n, void *stream) {
+  Decoder *D = reinterpret_cast<Decoder *>(h);
+  if (n <= 0 || n > D->sizes.max_lanes) return kamd::SetError(KAMD_ERR_ARG, "wide queue launch: %d tasks, the decoder has %d lanes", n, D->sizes.max_lanes);
+  std::vector<int32_t> share(n, 1);
+  if (kamd_decoder_reserve(h, share.data(), n) != KAMD_OK) return KAMD_ERR_HIP;
+  return QueueLaunch(h, tasks, n, n, stream, true);
+}
+
+int kamd_decoder_max_lanes(const kamd_decoder *h) { return reinterpret_cast<const Decoder *>(h)->sizes.max_lanes; }
+
+static int QueueLaunch(kamd_decoder *h, const kamd_queue_task *tasks, int n, int resident_lanes, void *stream, bool wide) {
   Decoder *D = reinterpret_cast<Decoder *>(h);
   if (n <= 0) return kamd::SetError(KAMD_ERR_ARG, "empty queue");
   for (int i = 0; i < n; i++) {
@@ -3947,7 +4256,7 @@ int kamd_decoder_queue_launch(kamd_decoder *h, const kamd_queue_task *tasks, int
   int R = resident_lanes > 0 ? resident_lanes : cus * LANES_PER_CU;
   R = std::min(std::min(R, n), D->sizes.max_lanes);
   if (R < 1) return kamd::SetError(KAMD_ERR_ARG, "no resident lanes");
-  if (ReserveUniform(D) != KAMD_OK) return KAMD_ERR_HIP;
+  if (!wide && ReserveUniform(D) != KAMD_OK) return KAMD_ERR_HIP;
   if (!D->d_pool && kamd_decoder_queue_configure(h, 1ll << 30) != KAMD_OK) return KAMD_ERR_HIP;
   if (!D->d_pool_used) {
     KAMD_HIP(hipMalloc(reinterpret_cast<void **>(&D->d_pool_used), 8));
@@ -3978,7 +4287,7 @@ int kamd_decoder_queue_launch(kamd_decoder *h, const kamd_queue_task *tasks, int
   q.results = static_cast<kamd_queue_result *>(dp);
   KAMD_HIP(hipHostGetDevicePointer(&dp, D->h_ring, 0));
   q.done_ring = static_cast<int *>(dp);
-  const size_t lds = std::max<size_t>(kamd::AdvanceLdsBytes(D->dev.num_pdfs_lds, D->dev.lds_table_cap), FIN_LDS_BYTES);
+  const size_t lds = std::max<size_t>(kamd::AdvanceLdsBytes(D->dev.num_pdfs_lds, LDS_TABLE_CAP), FIN_LDS_BYTES);
   KAMD_HIP(hipEventRecord(D->qev[0], st));
   hipLaunchKernelGGL(kamd::DecodeQueueKernel, dim3(R), dim3(NT), lds, st, D->dev, q);
   KAMD_HIP(hipGetLastError());

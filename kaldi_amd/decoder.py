@@ -258,6 +258,10 @@ class LatticeFasterDecoder:
         """1 = canonical (default), 2 = canonical-loose (kamd_decoder_set_search_mode)."""
         check(lib().kamd_decoder_set_search_mode(self._dec, int(mode)))
 
+    def SetLevel1Table(self, words):
+        """Words of the level-1 (LDS) table region, 0 = none (kamd_decoder_set_level1_table): a test knob, results do not depend on it."""
+        check(lib().kamd_decoder_set_level1_table(self._dec, int(words)))
+
     def InitDecoding(self):
         lanes = np.asarray([self.lane], np.int32)
         check(lib().kamd_decoder_init(self._dec, abi.iptr(lanes), 1, None))
@@ -569,6 +573,9 @@ class BatchDecoder:
 
     def SetSearchMode(self, mode):
         check(lib().kamd_decoder_set_search_mode(self._dec, int(mode)))
+
+    def SetLevel1Table(self, words):
+        check(lib().kamd_decoder_set_level1_table(self._dec, int(words)))
 
     def decode(self, matrices):
         """matrices: list of DeviceMatrix / host arrays, one per lane."""

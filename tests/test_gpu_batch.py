@@ -163,17 +163,19 @@ def test_utterances_too_short_for_a_frame_fail_alone():
     assert st.n_failed == 2 and bd.output(0) is None
 
 
-def test_lattice_pool_too_small_fails_the_utterances_that_do_not_fit_alone():
+def test_lattice_pool_too_small_fails_the_utterances_that_do_not_fit_alone(monkeypatch):
     """The finished lattices wait in a bump-allocated pool of page-locked host memory (kamd_decoder_queue_configure).  When
     it is exhausted the utterances that no longer fit report flag 64 (lattice pool) and no output; those that did fit are
-    what they are with a pool of the default size; the next run of the same object starts with an empty pool."""
+    what they are with a pool of the default size; the next run of the same object starts with an empty pool.  That is the
+    first search; by default run() then gives the failed ones a second chance (fewer utterances per launch: each finds room)."""
+    monkeypatch.setenv("KAMD_BATCH_RETRY", "0")
     g, model, cfg, waves = _setup(n=12, seed=5)
     ref = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=4.0, resident_lanes=3, host_threads=2, keep_raw_lattices=True)
     ref.load(waves)
     assert ref.run().n_failed == 0
     want = [ref.raw_lattice(u) for u in range(len(waves))]
     blob = [ref.record(u).blob_bytes for u in range(len(waves))]
-    pool = int(sum(sorted(blob)[:5]) + 64)                       # room for a handful of lattices, not for all twelve
+    pool = int(max(sum(sorted(blob)[:5]), max(blob)) + 64)       # room for a handful of lattices (and for any single one), not for all twelve
     bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=4.0, resident_lanes=3, host_threads=2,
                                 keep_raw_lattices=True, lattice_pool_bytes=max(pool, 4096))
     bd.load(waves)
@@ -191,6 +193,34 @@ def test_lattice_pool_too_small_fails_the_utterances_that_do_not_fit_alone():
                 assert rec.error == 0 and lattices_equal(bd.raw_lattice(u), want[u])
                 n_ok += 1
         assert n_ok == len(waves) - st.n_failed and n_ok >= 1, (n_ok, st.n_failed, pool, sorted(blob))
+    monkeypatch.delenv("KAMD_BATCH_RETRY")
+    st = bd.run()                                                # second chance on: nobody fails, and nothing changes for anybody
+    assert st.n_failed == 0 and st.n_retried > 0
+    for u in range(len(waves)):
+        assert bd.record(u).error == 0 and lattices_equal(bd.raw_lattice(u), want[u])
+
+
+def test_token_arena_too_small_gets_a_second_chance_on_a_wider_lane(monkeypatch):
+    """An utterance whose lane runs out of token / link arena fails alone (flags 2 / 4) in the first search; the second
+    chance searches it on a lane that owns 8x (then 64x) the arena.  Same lattices as a run with ample arenas."""
+    g, model, cfg, waves = _setup(n=10, seed=21)
+    kw = dict(max_seconds=4.0, resident_lanes=8, host_threads=2, keep_raw_lattices=True)
+    ref = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, **kw)
+    ref.load(waves)
+    assert ref.run().n_failed == 0
+    want = [ref.raw_lattice(u) for u in range(len(waves))]
+    tpf = max(4, int(max(ref.record(u).counters[5] / max(ref.record(u).n_frames, 1) for u in range(len(waves))) / 3))
+    bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, tokens_per_frame=tpf, **kw)      # a third of what the densest needs
+    bd.load(waves)
+    monkeypatch.setenv("KAMD_BATCH_RETRY", "0")
+    st = bd.run()
+    assert st.n_failed > 0 and st.n_retried == 0
+    assert all(bd.record(u).error & (2 | 4) for u in range(len(waves)) if bd.output(u) is None)
+    monkeypatch.delenv("KAMD_BATCH_RETRY")
+    st = bd.run()
+    assert st.n_failed == 0 and st.n_retried > 0
+    for u in range(len(waves)):
+        assert lattices_equal(bd.raw_lattice(u), want[u])
 
 
 def test_long_utterances_searched_beside_the_acoustic_model_give_the_same_results(monkeypatch):

@@ -33,7 +33,7 @@ def test_four_ranks_search_their_longest_utterances_beside_the_model():
     inside the timed region the 32 longest utterances of a rank's shard are stored first and searched beside the model of the
     others; no utterance may fail and the line keeps its shape."""
     d = run_bench("--workload", "tiny", "--utts", "640", "--gpus", "4", "--dist-backend", "gloo", "--device", "0", "--steps", "2", "--warmup", "1",
-                  "--host-threads", "2", "--tokens-per-frame", "4000")        # (four ranks' arenas on ONE device here)
+                  "--host-threads", "2", "--tokens-per-frame", "4000", "--headline", "random")        # (four ranks' arenas on ONE device here)
     assert d["n_gpus"] == 4 and len(d["rank_wall_s"]) == 4 and d["value"] > 0
     assert d["config"]["utterances"] == 640 and d["config"]["utterances_rank0"] == 160
     assert d["config"]["long_utterances_rank0"] == 32 and d["config"]["upload_in_timed_region"] is True
@@ -41,30 +41,45 @@ def test_four_ranks_search_their_longest_utterances_beside_the_model():
 
 
 def test_single_rank_line_has_roofline_cpu_baseline_and_wer():
+    """The default line: `value` is the recipe-faithful configuration (i-vector model, planted transcripts)."""
     d = run_bench("--workload", "tiny", "--steps", "2", "--warmup", "1", "--cpu-budget", "2", "--wer-utts", "8")
     assert d["n_gpus"] == 1 and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["config"]["headline"] == "faithful" and "online_ivectors" in d["config"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"] and k in d["roofline_other_stage"]
     assert {d["roofline"]["bound"], d["roofline_other_stage"]["bound"]} == {"hbm", "mfma"}
+    hbm = d["roofline"] if d["roofline"]["bound"] == "hbm" else d["roofline_other_stage"]
+    for k in ("counter_frac", "wait_fraction", "write_amplification", "arcs_per_expanded_token"):
+        assert k in hbm
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
-    assert cb["one_best_vs_cpu_decoder_same_loglikes"]["errors"] == 0
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["single_thread"]["value"] > 0
+    assert cb["one_best_vs_cpu_decoder_same_loglikes"]["errors"] == 0 and cb["one_best_vs_cpu_decoder_same_loglikes"]["ref_words"] > 0
     assert d["wer"]["identical_wer_lines"] is True and d["wer"]["wer_line_device"].startswith("%WER")
-    assert d["stage_ms"]["total_wall"] >= d["stage_ms"]["decode_queue_kernel"]
-    assert d["decoder"]["failed_utterances"] == 0
-    # round 3: the waveform upload is inside the timed region, the resident figure beside it; the CPU baseline's acoustic
-    # model is the reference's sgemm path; the planted variant decodes multi-word transcripts through the timed host tail
+    assert d["stage_ms"]["total_wall"] >= d["stage_ms"]["decode_queue_kernel"] and d["stage_ms"]["ivector_extraction"] > 0
+    assert d["decoder"]["failed_utterances"] == 0 and d["decoder"]["failures"] == []
+    t = d["transcripts"]
+    assert "error" not in t and t["wer_line"].startswith("%WER") and t["words_per_utterance"] > 1.5
     assert d["config"]["upload_in_timed_region"] is True and d["upload"]["bytes"] > 0 and d["upload"]["passes"] >= 1
     assert d["hbm_resident_value"] > 0
     assert "sgemm" in cb["nnet"] and cb["nnet_only_per_core"]["scalar_oracle"] > 0
     assert d["roofline_other_stage"]["flops_per_step"] > 0 or d["roofline"].get("flops_per_step", 0) > 0
+    r = d["random_loglikes"]
+    assert "error" not in r and r["value"] > 0 and r["roofline"]["bound"] == "hbm" and r["decoder"]["failed_utterances"] == 0
+    sl = d["streaming"]
+    assert "error" not in sl and sl["ms_per_chunk"] > 0 and sl["aggregate_x_rt"] > 0 and sl["finalize_ms"] > 0 and sl["ms_per_tick_256"] > 0
+
+
+def test_random_headline_keeps_round_3_legs():
+    d = run_bench("--workload", "tiny", "--steps", "2", "--warmup", "1", "--headline", "random", "--no-cpu-baseline", "--no-wer", "--no-streaming")
+    assert d["config"]["headline"] == "random" and d["decoder"]["failed_utterances"] == 0
     p = d["planted"]
     assert "error" not in p and p["wer_line"].startswith("%WER") and p["words_per_utterance"] > 1.5
     assert p["determinized_lattice_depth"] >= 1.0 and p["host_tail_cpu_ms_per_utterance"] > 0
+    assert "error" not in d["online_ivectors"] and d["online_ivectors"]["value"] > 0
 
 
 def test_resident_flag_keeps_round_2_contract():
-    d = run_bench("--workload", "tiny", "--steps", "1", "--warmup", "1", "--resident", "--no-cpu-baseline", "--no-wer", "--no-planted")
+    d = run_bench("--workload", "tiny", "--steps", "1", "--warmup", "1", "--resident", "--no-cpu-baseline", "--no-wer", "--no-random-leg", "--no-streaming")
     assert d["config"]["upload_in_timed_region"] is False and d["upload"] is None and "hbm_resident_value" not in d
 
 

@@ -168,6 +168,27 @@ def test_midsize_graph_saturated(seed):
     assert (o.trace()[0] > 2000).any()
 
 
+@pytest.mark.parametrize("words", [0, 64, 1024, 8192])
+def test_small_level1_tables_take_the_level2_and_large_frame_paths(words):
+    """The level-1 (LDS) table region shrunk (kamd_decoder_set_level1_table): frames of thousands of tokens then overflow into
+    the level-2 table in HBM, switch between the half-region and the whole-region table from frame to frame and keep the
+    commit's worklists in HBM -- the paths a full-size region only takes on frames of > 5 k / > 10 k tokens.  Same results."""
+    g = synth.make_hclg(num_units=200, vocab=3000, n_hist=300, fanout=(10, 60), seed=0)
+    ll = _mixed_load(g)[:40]
+    cfg = abi.decoder_config_recipe()
+    cfg.max_active = 3000
+    G = decoder.Graph(g)
+    d = decoder.LatticeFasterDecoder(G, cfg, sizes(hash_cap=1 << 16, toks=1 << 21, links=1 << 22))
+    d.SetLevel1Table(words)
+    d.Decode(ll)
+    o = orc.Decoder(g, cfg, 1)
+    o.Decode(ll)
+    assert_same(d, o)
+    assert (o.trace()[0] > 6000).any() and (o.trace()[0] < 200).any()
+    if words < 8192:
+        assert int(d.counters()[7]) > 0          # tokens did go to the level-2 table
+
+
 def _mixed_load(g):
     """frames of tens of thousands of tokens (flat scores) alternating with frames of a few
     tokens (sharply peaked scores): both finalize modes and both transitions between them"""
