@@ -655,6 +655,7 @@ def main():
                                 "waveform upload (%.2f GB from host memory) inside the timed region" % (wav_bytes / 1e9)),
                    "utterances": int(durs.size), "utterances_rank0": n, "long_utterances_rank0": int(st.long_utterances),
                    "loglike_std_nats": None if faithful else args.ll_std, "lm_scale": args.lm_scale, "headline": args.headline,
+                   "planted_peak": args.planted_peak if faithful else None, "planted_noise": args.planted_noise if faithful else None,
                    "value_is_load": load_name, "upload_in_timed_region": not args.resident,
                    "baseline_config": "configs[2]" if args.workload == "librispeech" and args.graph == "tglarge" else
                                       ("configs[1]" if args.workload == "mini_librispeech" else "other")},

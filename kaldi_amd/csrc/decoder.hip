@@ -121,6 +121,7 @@ struct DecDev {
   int num_pdfs_lds;     // log-likelihood row entries staged in LDS per frame (0 = none)
   int lds_table_cap;    // level-1 (LDS) table words, power of two or 0
   int big_frame_tokens; // a frame after one that created more tokens than this inserts into the whole table region
+  float good_first;     // > 0 (experiment, KAMD_GOOD_FIRST): tokens within this of the best are expanded in a pass of their own, first
   kamd_decoder_config cfg;
   int loose;            // search mode 2: arcs are kept against the seed cutoff (kamd_decoder_set_search_mode)
   int hash_cap, hash_mask, max_frames;
@@ -208,7 +209,8 @@ struct Sh {  // workgroup-shared state
   u32 hist[SH_HIST];     // radix-select bins / one "queued" bit per level-1 slot / the commit's linear cost histogram (TblSelectLinear)
   float sel_cand[SH_CAND];   // TblSelectLinear: the members of the bucket that holds the wanted rank
   u32 next_cutoff_u;
-  int n_slots, n_slots1, n_links, wl_n[2], err, bigcnt, hugecnt, changed;   // n_slots: level-2 (HBM) entries, n_slots1: level-1 (LDS), counted by the commit
+  int n_slots, n_slots1, n_links, n_surv, n_final, wl_n[2], err, bigcnt, hugecnt, changed;   // n_links: candidates recorded; n_surv: those the insert sweep carried on
+    // n_slots: level-2 (HBM) entries, n_slots1: level-1 (LDS), counted by the commit
   int cache_valid;       // the newest token list's costs are in the LDS cost cache (small-table frames)
   // the work-queue lane drops tokens that can never be expanded when it commits a list (CommitFrame2, `drop`): the list
   // then holds cur_n of the cur_n_all tokens created, and its GetCutoff has been evaluated already (on all of them)
@@ -518,7 +520,13 @@ __device__ __forceinline__ float BlockSelectLinear(SrcPtr src, int n, int k, flo
 // Entries are never removed inside a frame, so "window full / EMPTY seen" decide
 // membership consistently.  Slot ids: [0, lcap) = LDS, lcap + g = global slot g.
 #define LWIN 8      // words of a window scanned together; a table probes lwin = LWIN or 2 * LWIN words (the large table, which runs fuller)
-struct Tbl { u64 *LH; int lcap; int lwin; int hmask; };   // hmask: this frame's level-2 (HBM) table size - 1, a power of two <= hash_cap
+struct Tbl {
+  u64 *LH; int lcap; int lwin;
+  int hmask;            // this frame's level-2 (HBM) table size - 1, a power of two <= hash_cap
+  // the insert sweep queues every level-2 token it CREATES with the epsilon flag straight onto the closure's first worklist
+  // (q_on): the closure then starts without a sweep through the level-2 slot list (a dependent pair of loads per entry)
+  bool q_on; u32 *q_lds; int q_cap;
+};
 __device__ inline u32 HashL(int s, int lcap) { return (static_cast<u32>(s) * 2654435761u >> 9) & static_cast<u32>(lcap - 1); }
 __device__ inline u64 TblLoad(const Ctx &c, const Tbl &t, int slot) {
   return slot < t.lcap ? t.LH[slot] : LoadH(&c.H[slot - t.lcap]);
@@ -527,7 +535,8 @@ __device__ inline u64 TblLoad(const Ctx &c, const Tbl &t, int slot) {
 // FindOrAddToken (lattice-faster-decoder.cc:266-306) on the frame's table.
 // returns slot (or -1 on overflow); *improved = created, or strictly lowered the cost.
 __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int state, float cost,
-                                 bool *improved, int slot_bias, int hmask) {
+                                 bool *improved, const Tbl &t) {
+  const int slot_bias = t.lcap, hmask = t.hmask;
   const u64 mine = Pack(state, cost);
   u32 h = HashState(state, hmask);
   for (int probe = 0; probe <= hmask; probe++) {
@@ -537,6 +546,12 @@ __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int stat
     if (old == EMPTY64) {
       int idx = WaveAlloc(&sh->n_slots);
       if (idx < d.hash_cap) c.slots[idx] = h + static_cast<u32>(slot_bias); else atomicOr(&sh->err, ERR_HASH);
+      if (t.q_on && HasEps(state)) {
+        const int p = WaveAlloc(&sh->wl_n[0]);
+        if (p < t.q_cap) t.q_lds[p] = h + static_cast<u32>(slot_bias);
+        else if (p < d.hash_cap) c.wl0[p] = h + static_cast<u32>(slot_bias);
+        else atomicOr(&sh->err, ERR_WL);
+      }
       *improved = true;
       return static_cast<int>(h);
     }
@@ -611,21 +626,26 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
   }
 }
 
-#define COMMIT_KEEP 2
 #define L2B 4             // level-2 (HBM) table entries / links per thread fetched together in the commit
-#define INSB 4            // links per thread fetched together in InsertEmitted (>= COMMIT_KEEP)
+#define INSB 4            // links per thread fetched together in InsertEmitted
 static_assert(EXPT * NT == BIGCAP, "one outer expansion iteration must fit the flatten queue");
 // Dense sweep over the frame's recorded emitting links (lattice-faster-decoder.cc:803-809):
 // FindOrAddToken for every link whose own tot passes the FINAL next_cutoff; the link's dst
 // becomes the table slot, or -1 when the arc is outside the final cutoff (the canonical
 // rule: no order-dependent extras ever enter the table).
+// Where a frame's links live while it is being built (round 4: every link record is written ONCE in its final form, and
+// only when it is kept): the expansion records CANDIDATES {src, arc index, tot, graph, ac} at [link_begin, + n_cand); the
+// insert sweep below reads them once and appends the SURVIVORS -- final form but for dst, which is the table slot --
+// behind them, at [link_begin + n_cand, + n_surv); the commit reads those, resolves slot -> token and writes the FINAL
+// links, dense from link_begin again (over the dead candidates: a final link's index is never beyond its survivor's,
+// which lies behind every candidate), leaving out the ones whose destination token got no record (CommitFrame2, `drop`).
+// The arena needs room for n_cand + n_surv records beyond the links in use; the records behind the final links are scratch.
 __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, int link_begin,
-                                    int n_links, float cutoff, int (&my_slot)[COMMIT_KEEP]) {
+                                    int n_links, float cutoff) {
   int k_surv = 0;
   const int le = min(link_begin + n_links, c.lnk_cap);
-#pragma unroll
-  for (int k = 0; k < COMMIT_KEEP; k++) my_slot[k] = -1;
-  // INSB links per thread per trip: the records, then the source costs, are loaded for the
+  const int surv_begin = le;
+  // INSB links per thread per trip: the records, then the arcs, are loaded for the
   // whole batch before the first insert (two dependent round trips per batch, not per link)
   for (int g0 = 0; link_begin + g0 * NT < le; g0 += INSB) {
     Link L[INSB]; kamd_arc arc[INSB];
@@ -639,7 +659,7 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
       const int li = link_begin + Tid() + (g0 + k) * NT;
       // the record of the arc ProcessArcs kept by index -- only for the candidates that pass the final cutoff (2.5 were
       // recorded per survivor at the matched load: the others all read arc 0, one cached line instead of a random 16-byte
-      // fetch each; a clamped lane may see a link its owner has rewritten: arc 0 as well)
+      // fetch each)
       arc[k] = d.g.e_arcs[(li < le && __int_as_float(L[k].ilabel) <= cutoff) ? static_cast<u32>(L[k].dst) : 0u];
     }
 #pragma unroll
@@ -647,18 +667,15 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
       const int li = link_begin + Tid() + (g0 + k) * NT;
       if (li >= le) continue;
       const float tot = __int_as_float(L[k].ilabel);      // == source cost + ac + graph, as ProcessArcs summed it
-      int dst = -1;
-      if (tot <= cutoff) {                       // :798 with the frame's final cutoff
-        bool improved;
-        dst = TblInsert(d, c, sh, tbl, arc[k].nextstate, tot, &improved);
-        k_surv += dst >= 0;
-      }
-      // the link in its final form but for dst (slot now, token at the commit).  The first COMMIT_KEEP links of a thread:
-      // the slot stays in a register until the commit resolves it to a token (only a rejection is written back now)
-      int dst_now = dst;
-      if (g0 == 0 && k < COMMIT_KEEP) { my_slot[k] = dst; dst_now = dst < 0 ? -1 : L[k].dst; }
-      Link *o = &c.links[li];
-      o->dst = dst_now; o->ilabel = arc[k].ilabel; o->olabel = arc[k].olabel;
+      if (!(tot <= cutoff)) continue;            // :798 with the frame's final cutoff: the candidate is simply not carried on
+      bool improved;
+      const int dst = TblInsert(d, c, sh, tbl, arc[k].nextstate, tot, &improved);
+      if (dst < 0) continue;                     // (table overflow: flagged)
+      k_surv++;
+      const int so = surv_begin + WaveAlloc(&sh->n_surv);
+      if (so >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
+      Link o; o.src = L[k].src; o.dst = dst; o.ilabel = arc[k].ilabel; o.olabel = arc[k].olabel; o.graph = L[k].graph; o.ac = L[k].ac;
+      c.links[so] = o;
     }
   }
   return k_surv;
@@ -708,7 +725,7 @@ __device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl
       // (these LWIN words hold other states: the next LWIN, or level 2 once the whole window is full)
     }
   }
-  const int g = HashInsert(d, c, sh, state, cost, improved, t.lcap, t.hmask);
+  const int g = HashInsert(d, c, sh, state, cost, improved, t);
   return g < 0 ? g : g + t.lcap;
 }
 __device__ inline int TblFind(const DecDev &d, const Ctx &c, const Tbl &t, int state) {
@@ -1071,11 +1088,9 @@ struct CommitLds {
 // slot -> token with one ds_read), worklists and the epsilon-owner list live in idle LDS and the
 // per-round "already queued" test is a bit per slot.  Level-2 (HBM) entries keep the global
 // lists; when a frame has none, no barrier of the commit has to wait for global memory.
-// my_slot[k] = table slot of this thread's k-th recorded link (link_begin + tid + k*NT), or
-// -1: kept in registers from InsertEmitted so the links are not read back.
 __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
                                              int emit_link_begin, int k_surv,
-                                             const CommitLds &L, const int (&my_slot)[COMMIT_KEEP], bool loose, bool drop) {
+                                             const CommitLds &L, bool loose, bool drop) {
   const int tid = Tid();
   LaneState *S = c.st;
   const int lcap = tbl.lcap;
@@ -1089,22 +1104,7 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
     const u64 e = tbl.LH[sl];
     if (e != EMPTY64 && HasEps(StateOf(e)) && CostOf(e) <= cutoff) wl_put(0, WaveAlloc(&sh->wl_n[0]), static_cast<u32>(sl));
   }
-  // (level-2 entries: two per thread and trip, slot list then table words, each set of loads issued together and
-  // unconditional -- a load inside a conditional block is waited for at the block's end)
-  for (int i0 = tid; i0 < n2; i0 += L2B * NT) {
-    u32 sl[L2B]; u64 e[L2B];
-#pragma unroll
-    for (int k = 0; k < L2B; k++) sl[k] = c.slots[min(i0 + k * NT, n2 - 1)];
-#pragma unroll
-    for (int k = 0; k < L2B; k++) e[k] = LoadH(&c.H[static_cast<int>(sl[k]) - lcap]);
-#pragma unroll
-    for (int k = 0; k < L2B; k++) {
-      if (i0 + k * NT < n2) {
-        if (e[k] == EMPTY64) atomicOr(&sh->err, ERR_INTERNAL);
-        else if (HasEps(StateOf(e[k])) && CostOf(e[k]) <= cutoff) wl_put(0, WaveAlloc(&sh->wl_n[0]), sl[k]);
-      }
-    }
-  }
+  // (the level-2 entries that own epsilon arcs queued themselves when the insert sweep created them: HashInsert, q_on)
   for (int i = tid; i < lcap / 32; i += NT) sh->hist[i] = 0;   // "queued this round" bits of the level-1 slots
   LdsBarrier();
   if (sh->wl_n[0] > L.wl_cap) __syncthreads();
@@ -1300,36 +1300,36 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
   auto tok_of_slot = [&](int slot) -> int {
     return slot < lcap ? static_cast<int>(static_cast<u32>(tbl.LH[slot])) : c.slot_tok[slot];
   };
-  // ---- emitting links: slot -> token (the first COMMIT_KEEP per thread from registers)
+  // ---- emitting links: the survivors the insert sweep left behind the candidates become the frame's final links, dense from
+  // emit_link_begin, slot -> token; a link into a token without a record (`drop`) is not written at all
   {
-    const int lb = emit_link_begin, le = min(emit_link_begin + sh->n_links, c.lnk_cap);
+    const int n_cand = min(sh->n_links, c.lnk_cap - emit_link_begin);
+    const int surv_begin = emit_link_begin + n_cand;
+    const int n_surv = min(sh->n_surv, c.lnk_cap - surv_begin);
+    for (int i0 = tid; i0 < n_surv; i0 += L2B * NT) {
+      Link Lk[L2B]; int t1[L2B], t2[L2B];
 #pragma unroll
-    for (int k = 0; k < COMMIT_KEEP; k++) {
-      const int li = lb + tid + k * NT;
-      if (li < le && my_slot[k] >= 0) c.links[li].dst = tok_of_slot(my_slot[k]);
-    }
-    for (int l0 = lb + tid + COMMIT_KEEP * NT; l0 < le; l0 += L2B * NT) {
-      int slot[L2B], t1[L2B], t2[L2B];
-#pragma unroll
-      for (int k = 0; k < L2B; k++) {
-        slot[k] = c.links[min(l0 + k * NT, le - 1)].dst;
-        if (l0 + k * NT >= le) slot[k] = -1;        // (a clamped lane may see a link its owner has resolved already)
-      }
+      for (int k = 0; k < L2B; k++) Lk[k] = c.links[surv_begin + min(i0 + k * NT, n_surv - 1)];
       // both levels are read for every link (level 1: LDS; level 2: HBM, a dummy word for the links that are not there)
 #pragma unroll
       for (int k = 0; k < L2B; k++) {
-        t1[k] = static_cast<int>(static_cast<u32>(tbl.LH[min(max(slot[k], 0), lcap - 1)]));
-        t2[k] = c.slot_tok[slot[k] >= lcap ? slot[k] : lcap];
+        const int slot = Lk[k].dst;
+        t1[k] = lcap > 0 ? static_cast<int>(static_cast<u32>(tbl.LH[min(max(slot, 0), lcap - 1)])) : -1;
+        t2[k] = c.slot_tok[slot >= lcap ? slot : lcap];
       }
 #pragma unroll
       for (int k = 0; k < L2B; k++) {
-        const int li = l0 + k * NT;
-        if (li < le && slot[k] >= 0) c.links[li].dst = slot[k] < lcap ? t1[k] : t2[k];
+        const int tok = Lk[k].dst < lcap ? t1[k] : t2[k];
+        if (i0 + k * NT < n_surv && tok >= 0) {
+          Link o; o.src = Lk[k].src; o.dst = tok; o.ilabel = Lk[k].ilabel; o.olabel = Lk[k].olabel; o.graph = Lk[k].graph; o.ac = Lk[k].ac;
+          c.links[emit_link_begin + WaveAlloc(&sh->n_final)] = o;     // (never beyond the survivor's own index: behind no candidate)
+        }
       }
     }
   }
+  LdsBarrier();      // every survivor has been read (the epsilon links may land on them), the count is final
   // ---- epsilon links of the surviving tokens (final costs), :875-897
-  const int eps_link_begin = emit_link_begin + min(sh->n_links, c.lnk_cap - emit_link_begin);   // == c.lnk_off[2 * list + 1]
+  const int eps_link_begin = emit_link_begin + sh->n_final;   // == c.lnk_off[2 * list + 1]
   {
     const int ne = min(n_owner, d.hash_cap);
     for (int i = tid; i < ne; i += NT) {
@@ -1393,6 +1393,7 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
   if (tid == 0) {
     const int n_eps_links = min(sh->wl_n[0], c.lnk_cap - eps_link_begin);
     c.tok_off[list + 1] = tok_base + n_new;
+    c.lnk_off[2 * list + 1] = eps_link_begin;              // the emitting links into list 'list' end here (only the kept ones are there)
     c.lnk_off[2 * list + 2] = eps_link_begin + n_eps_links;
     S->tok_used = tok_base + n_new;
     S->lnk_used = eps_link_begin + n_eps_links;
@@ -1404,7 +1405,7 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
     sh->cnt[7] += ns2;                   // (diagnostic, not part of the parity contract) tokens that went to the level-2 table
     sh->best_key = kmin; sh->c_lt = c_lt; sh->c_le = c_le;
     sh->cache_valid = !do_drop && n_new <= L.cache_cap;
-    sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->n_new = 0;
+    sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->n_surv = 0; sh->n_final = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->n_new = 0;
   }
   // the next frame's GetCutoff may read the list's costs where they lie (no LDS copy): a full barrier then
   if (!do_drop && n_new > L.cache_cap) { DrainStores(); __syncthreads(); } else LdsBarrier();
@@ -1466,7 +1467,7 @@ __device__ __forceinline__ void PublishLaneEnd(const DecDev &d, const Ctx &c, Sh
 
 __device__ inline void InitSh(Sh *sh) {
   if (Tid() == 0) {
-    sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
+    sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->n_surv = 0; sh->n_final = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
     sh->bigcnt = 0; sh->hugecnt = 0; sh->n_new = 0; sh->best_key = EMPTY64; sh->c_lt = 0; sh->c_le = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
     sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0; sh->cur_n_all = 0; sh->cutoff_ready = 0; sh->cache_valid = 0;
     for (int i = 0; i < 8; i++) sh->cnt[i] = 0;
@@ -1498,10 +1499,11 @@ __device__ __forceinline__ void InitLane(const DecDev &d, const Ctx &c, Sh *shp)
     c.tok_off[0] = 0; c.lnk_off[0] = 0; c.lnk_off[1] = 0;
     sh.round = S->round;   // stamps persist across utterances: never reset
     bool imp;
-    HashInsert(d, c, &sh, d.g.start_flagged, 0.0f, &imp, 0, d.hash_mask);
+    Tbl t0; t0.LH = NULL; t0.lcap = 0; t0.lwin = 0; t0.hmask = d.hash_mask; t0.q_on = false; t0.q_lds = NULL; t0.q_cap = 0;
+    HashInsert(d, c, &sh, d.g.start_flagged, 0.0f, &imp, t0);
   }
   __syncthreads();
-  Tbl tbl; tbl.LH = NULL; tbl.lcap = 0; tbl.lwin = 0; tbl.hmask = d.hash_mask;     // InitDecoding has no LDS table: level 2 only
+  Tbl tbl; tbl.LH = NULL; tbl.lcap = 0; tbl.lwin = 0; tbl.hmask = d.hash_mask; tbl.q_on = false; tbl.q_lds = NULL; tbl.q_cap = 0;     // InitDecoding has no LDS table: level 2 only
   CommitFrame(d, c, &sh, tbl, d.cfg.beam, 0, 0, NULL, 0, 0);
   PublishLaneEnd(d, c, &sh, 0);
 }
@@ -1543,6 +1545,7 @@ __device__ __forceinline__ AdvLds MakeAdvLds(unsigned char *dyn_lds, int num_pdf
 #define BIG_FRAME_TOKENS (6 * NT)
 __device__ __forceinline__ Tbl FrameTable(const AdvLds &a, bool big, int hmask) {
   Tbl t; t.LH = a.T; t.lcap = big ? a.cap_big : a.cap_small; t.lwin = big ? 2 * LWIN : LWIN; t.hmask = hmask;
+  t.q_on = false; t.q_lds = NULL; t.q_cap = 0;
   return t;
 }
 // This frame's level-2 table: the lane's HBM table addressed through a mask sized for the frame -- four slots per recorded
@@ -1582,7 +1585,6 @@ struct FrameCtl {
   bool big;                        // the frame inserts into the whole table region (FrameTable)
   int hmask;                       // ... and into a level-2 table of hmask + 1 slots (FrameLevel2Mask)
   int link_base, k_surv;
-  int my_slot[COMMIT_KEEP];
 };
 
 // ---- GetCutoff (:657-724).  The best token (ties -> smallest state, as oracle mode 1) and the two beam counts were
@@ -1675,6 +1677,12 @@ __device__ __forceinline__ void PhaseExpand(int lane, Sh &sh, unsigned char *dyn
   // loaded before the first one is expanded (three dependent round trips per BATCH of
   // tokens instead of per token).  EXPT * NT = BIGCAP tokens are queued at most, so the
   // queue is flushed after every outer iteration and cannot overflow.
+  // "good tokens first" (measured and left off): with d.good_first > 0 the tokens within that
+  // distance of the best one are expanded in a pass of their own before everybody else, so that the running bound the
+  // others are filtered with is close to its final value (fewer candidates recorded); costs the token list a second read.
+  const int n_pass = d.good_first > 0.0f ? 2 : 1;
+  const float good_cut = best + d.good_first;
+  for (int pass = 0; pass < n_pass; pass++)
   for (int base = 0; base < n; base += EXPT * NT) {
     float tcost[EXPT]; int tstate[EXPT]; u32 ta0[EXPT], ta1[EXPT];
 #pragma unroll
@@ -1689,13 +1697,14 @@ __device__ __forceinline__ void PhaseExpand(int lane, Sh &sh, unsigned char *dyn
 #pragma unroll
     for (int k = 0; k < EXPT; k++) {
       const uint2 o0 = d.g.off[tstate[k]], o1 = d.g.off[tstate[k] + 1];
-      const bool live = base + tid + k * NT < n && tcost[k] <= cur_cutoff;      // :787 (the cutoff may be +inf)
+      const bool mine = n_pass == 1 || (pass == 0) == (tcost[k] <= good_cut);
+      const bool live = base + tid + k * NT < n && tcost[k] <= cur_cutoff && mine;      // :787 (the cutoff may be +inf)
       ta0[k] = live ? o0.x : 0u; ta1[k] = live ? o1.x : 0u;
     }
 #pragma unroll
     for (int k = 0; k < EXPT; k++) {
       const int i = base + tid + k * NT;
-      if (i < n && tcost[k] <= cur_cutoff) {
+      if (i < n && tcost[k] <= cur_cutoff && (n_pass == 1 || (pass == 0) == (tcost[k] <= good_cut))) {
         const float cur_cost = tcost[k];
         n_exp++;
         const u32 a0 = ta0[k], a1 = ta1[k];
@@ -1809,12 +1818,13 @@ __device__ __forceinline__ void PhaseInsert(int lane, Sh &sh, unsigned char *dyn
   const Ctx c = MakeCtx(d, Opaque(lane));
   const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
   fc.hmask = FrameLevel2Mask(sh.n_links, d.hash_cap);
-  const Tbl tbl = FrameTable(L, fc.big, fc.hmask);
+  Tbl tbl = FrameTable(L, fc.big, fc.hmask);
+  tbl.q_on = true; tbl.q_lds = reinterpret_cast<u32 *>(L.cost_cache); tbl.q_cap = fc.big ? 0 : (3 * BIGCAP) / 2;    // = PhaseCommit's wl0
   if (fc.big) {   // the upper half of the region was the expansion's queue: make it table
     for (int sl = L.cap_small + Tid(); sl < L.cap_big; sl += NT) L.T[sl] = EMPTY64;
     LdsBarrier();
   }
-  fc.k_surv = InsertEmitted(d, c, &sh, tbl, fc.link_base, sh.n_links, fc.loose ? fc.seed_cutoff : fc.next_cutoff, fc.my_slot);
+  fc.k_surv = InsertEmitted(d, c, &sh, tbl, fc.link_base, sh.n_links, fc.loose ? fc.seed_cutoff : fc.next_cutoff);
   Stamp(&sh, PH_FIXUP);
 }
 
@@ -1832,7 +1842,7 @@ __device__ __forceinline__ void PhaseCommit(int lane, Sh &sh, unsigned char *dyn
     cl.owners = reinterpret_cast<uint2 *>(L.lh); cl.owners_cap = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP) / 2;
     cl.cost_cache = L.cost_cache; cl.cache_cap = 3 * BIGCAP;
   }
-  CommitFrame2(d, c, &sh, tbl, fc.next_cutoff, frame + 1, fc.link_base, fc.k_surv, cl, fc.my_slot, fc.loose, drop);
+  CommitFrame2(d, c, &sh, tbl, fc.next_cutoff, frame + 1, fc.link_base, fc.k_surv, cl, fc.loose, drop);
 }
 
 // AdvanceDecoding (lattice-faster-decoder.cc:593-632): the frame loop of one lane.  Every phase takes its own view of
@@ -3206,6 +3216,7 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   d.lds_table_cap = LDS_TABLE_CAP;
   d.big_frame_tokens = BIG_FRAME_TOKENS;
   if (const char *e = getenv("KAMD_BIG_FRAME_TOKENS")) d.big_frame_tokens = atoi(e);      // (experiments: tools/ab_bench.py)
+  if (const char *e = getenv("KAMD_GOOD_FIRST")) d.good_first = static_cast<float>(atof(e));
   d.num_pdfs_lds = 0;
   const size_t lds_budget = 160 * 1024 / LANES_PER_CU - sizeof(kamd::Sh) - 1024;
   const size_t fixed = kamd::AdvanceLdsBytes(0, LDS_TABLE_CAP);
