@@ -576,6 +576,11 @@ __device__ inline float LogLikePdf(const LlRow &r, int pdf) {
   return r.g[pdf];
 }
 
+// the frame's candidate records: 16-byte words in the part of the link arena that starts at link `link_base` (n candidates
+// never reach beyond link_base + n: 16 n + 8 <= 24 n)
+__device__ __forceinline__ uint4 *CandBase(const Ctx &c, int link_base) {
+  return reinterpret_cast<uint4 *>((reinterpret_cast<size_t>(c.links + link_base) + 15) & ~static_cast<size_t>(15));
+}
 __device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t, int state, float cost,
                                 bool *improved);
 // W emitting arcs of one thread (lattice-faster-decoder.cc:791-809), evaluated together:
@@ -617,12 +622,11 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
 #pragma unroll
   for (int q = 0; q < W; q++) {
     if (!pass[q]) continue;
-    const int li = link_base + WaveAlloc(&sh->n_links);
-    if (li >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
-    // (the ilabel field carries the arc's total cost to the insert sweep, which then needs no look at the source token)
-    Link L; L.src = src_tok[q]; L.dst = static_cast<int>(aidx[q]); L.ilabel = __float_as_int(tot[q]); L.olabel = 0;
-    L.graph = __uint_as_float(hot[q].x); L.ac = ac[q];
-    c.links[li] = L;
+    const int k = WaveAlloc(&sh->n_links);
+    if (link_base + k >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
+    // a candidate is 16 bytes: source token, arc index, the arc's total cost (the insert sweep then needs no look at the
+    // source token) and its acoustic part; labels, target and graph weight come from the arc record, for the survivors only
+    CandBase(c, link_base)[k] = make_uint4(static_cast<u32>(src_tok[q]), aidx[q], __float_as_uint(tot[q]), __float_as_uint(ac[q]));
   }
 }
 
@@ -635,7 +639,7 @@ static_assert(EXPT * NT == BIGCAP, "one outer expansion iteration must fit the f
 // rule: no order-dependent extras ever enter the table).
 // Where a frame's links live while it is being built (round 4: every link record is written ONCE in its final form, and
 // only when it is kept): the expansion records CANDIDATES {src, arc index, tot, graph, ac} at [link_begin, + n_cand); the
-// insert sweep below reads them once and appends the SURVIVORS -- final form but for dst, which is the table slot --
+// (16 bytes each: CandBase); the insert sweep below reads them once and appends the SURVIVORS -- final form but for dst, which is the table slot --
 // behind them, at [link_begin + n_cand, + n_surv); the commit reads those, resolves slot -> token and writes the FINAL
 // links, dense from link_begin again (over the dead candidates: a final link's index is never beyond its survivor's,
 // which lies behind every candidate), leaving out the ones whose destination token got no record (CommitFrame2, `drop`).
@@ -647,26 +651,28 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
   const int surv_begin = le;
   // INSB links per thread per trip: the records, then the arcs, are loaded for the
   // whole batch before the first insert (two dependent round trips per batch, not per link)
-  for (int g0 = 0; link_begin + g0 * NT < le; g0 += INSB) {
-    Link L[INSB]; kamd_arc arc[INSB];
+  const uint4 *cand = CandBase(c, link_begin);
+  const int n_cand = le - link_begin;
+  for (int g0 = 0; g0 * NT < n_cand; g0 += INSB) {
+    uint4 L[INSB]; kamd_arc arc[INSB];      // L: {source token, arc index, tot, acoustic cost}
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
-      const int li = link_begin + Tid() + (g0 + k) * NT;
-      L[k] = c.links[min(li, le - 1)];          // (unconditional, clamped: see the expansion; le > link_begin here)
+      const int ci = Tid() + (g0 + k) * NT;
+      L[k] = cand[min(ci, n_cand - 1)];          // (unconditional, clamped: see the expansion; n_cand > 0 here)
     }
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
-      const int li = link_begin + Tid() + (g0 + k) * NT;
+      const int ci = Tid() + (g0 + k) * NT;
       // the record of the arc ProcessArcs kept by index -- only for the candidates that pass the final cutoff (2.5 were
       // recorded per survivor at the matched load: the others all read arc 0, one cached line instead of a random 16-byte
       // fetch each)
-      arc[k] = d.g.e_arcs[(li < le && __int_as_float(L[k].ilabel) <= cutoff) ? static_cast<u32>(L[k].dst) : 0u];
+      arc[k] = d.g.e_arcs[(ci < n_cand && __uint_as_float(L[k].z) <= cutoff) ? L[k].y : 0u];
     }
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
-      const int li = link_begin + Tid() + (g0 + k) * NT;
-      if (li >= le) continue;
-      const float tot = __int_as_float(L[k].ilabel);      // == source cost + ac + graph, as ProcessArcs summed it
+      const int ci = Tid() + (g0 + k) * NT;
+      if (ci >= n_cand) continue;
+      const float tot = __uint_as_float(L[k].z);      // == source cost + ac + graph, as ProcessArcs summed it
       if (!(tot <= cutoff)) continue;            // :798 with the frame's final cutoff: the candidate is simply not carried on
       bool improved;
       const int dst = TblInsert(d, c, sh, tbl, arc[k].nextstate, tot, &improved);
@@ -674,7 +680,8 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
       k_surv++;
       const int so = surv_begin + WaveAlloc(&sh->n_surv);
       if (so >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
-      Link o; o.src = L[k].src; o.dst = dst; o.ilabel = arc[k].ilabel; o.olabel = arc[k].olabel; o.graph = L[k].graph; o.ac = L[k].ac;
+      Link o; o.src = static_cast<int>(L[k].x); o.dst = dst; o.ilabel = arc[k].ilabel; o.olabel = arc[k].olabel;
+      o.graph = arc[k].weight; o.ac = __uint_as_float(L[k].w);
       c.links[so] = o;
     }
   }
