@@ -488,7 +488,9 @@ typedef struct {
 } kamd_queue_task;
 typedef struct {
   int32_t status;            /* 0 = pending, 1 = done (written last, system-scope release) */
-  int32_t error;             /* capacity flags of kamd_decoder_sync's message; 64 = lattice pool exhausted */
+  int32_t error;             /* capacity flags of kamd_decoder_sync's message; 64 = lattice pool exhausted; 32 with one of
+                              * 512 .. 32768 = a graph lookup met a state that is no state of HCLG and the lane stopped
+                              * (which lookup: kaldi_amd/csrc/decoder.hip ERR_BAD_STATE) */
   int32_t lane, n_frames;    /* lane that decoded it; NumFramesDecoded() */
   int32_t n_tok, n_link;     /* raw lattice: states, arcs */
   int32_t n_last, pad;       /* tokens on the last frame (their final costs travel with the lattice) */

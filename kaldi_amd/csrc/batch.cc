@@ -437,7 +437,9 @@ int kamd_batch_decoder_load_host(kamd_batch_decoder *h, const float *waves, cons
   }
   // kamd_batch_decoder_set_long_decoder: the longest utterances first, as a pass of their own -- their search starts on
   // the second decoder object as soon as that pass is scored, beside the model of the others (RunImpl)
-  if (!b->iv_extractor && kamd_nnet_ivector_dim(b->nnet) == 0 && WantSplit(b, static_cast<int>(order.size()), longest_out, total_out)) {
+  // (round 4: also with an extractor -- the long utterances' pass gets its own online i-vectors and chunked forward like any
+  // other pass -- and with a log-likelihood override, whose rows follow load_row)
+  if ((b->iv_extractor || kamd_nnet_ivector_dim(b->nnet) == 0) && WantSplit(b, static_cast<int>(order.size()), longest_out, total_out)) {
     std::vector<int> by_len(order);
     std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int c) { return frames_of[a] > frames_of[c]; });
     by_len.resize(b->long_lanes);
@@ -688,7 +690,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
   if (online_iv) split = false;
   const float *ll_base = b->d_ll_override ? b->d_ll_override : b->d_ll;
   // load_host stored the long utterances first: pass 0 is theirs, the second decoder object takes them from there
-  const int Kh = (host_mode && !online_iv && !b->d_ll_override && b->dec_long && b->host_split == b->long_lanes && b->host_split < n) ? b->host_split : 0;
+  const int Kh = (host_mode && b->dec_long && b->host_split == b->long_lanes && b->host_split < n) ? b->host_split : 0;
   const bool two_queues = split || Kh > 0;
   b->last_split = two_queues;
   int n_main = n;
@@ -775,7 +777,8 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
         for (int k = Kh; k < n; k++) b->map_rest[k - Kh] = k;
         tasks.resize(Kh);
         for (int k = 0; k < Kh; k++) {                     // (stored longest first)
-          tasks[k].d_loglikes = ll_base + static_cast<size_t>(b->out_off[k]) * b->P;
+          const int64_t row = (b->d_ll_override && b->load_row.size() == static_cast<size_t>(n)) ? b->load_row[k] : b->out_off[k];
+          tasks[k].d_loglikes = ll_base + static_cast<size_t>(row) * b->P;
           tasks[k].ld = b->P; tasks[k].n_frames = static_cast<int32_t>(b->out_off[k + 1] - b->out_off[k]);
           tasks[k].utt = k; tasks[k].reserved = 0;
           b->task_ll[k] = tasks[k].d_loglikes;

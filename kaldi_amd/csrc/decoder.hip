@@ -85,6 +85,14 @@ __device__ __forceinline__ int Tid() {
 }
 
 enum { ERR_HASH = 1, ERR_TOK = 2, ERR_LINK = 4, ERR_FRAMES = 8, ERR_WL = 16, ERR_INTERNAL = 32 };
+// A state about to index the graph that is no state of the graph: the lane stops with ERR_INTERNAL instead of reading
+// wherever the index points (bits 11..14 say which lookup saw it: closure, epsilon links, best token, expansion).
+#define ERR_BAD_STATE(site) (ERR_INTERNAL | (256 << (site)))
+#ifdef KAMD_DEBUG_OOB
+#define KAMD_OOB_PRINTF(...) printf(__VA_ARGS__)
+#else
+#define KAMD_OOB_PRINTF(...) do {} while (0)
+#endif
 
 struct GraphDev {
   int num_states, start;
@@ -789,6 +797,7 @@ __device__ __forceinline__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *s
       const float cur_cost = CostOf(e);
       if (e == EMPTY64 || cur_cost > cutoff) continue;      // :867
       const int s = PlainState(StateOf(e));
+      if (static_cast<u32>(s) >= static_cast<u32>(d.g.num_states)) { atomicOr(&sh->err, ERR_BAD_STATE(1)); continue; }
       const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
       for (u32 a = a0; a < a1; a++) {
         const kamd_arc arc = d.g.n_arcs[a];
@@ -866,6 +875,7 @@ __device__ __forceinline__ void CommitFrame(const DecDev &d, const Ctx &c, Sh *s
       const int t = static_cast<int>(c.wl1[i]);
       const int s = c.tok_state[t];
       const float cur_cost = c.tok_cost[t];
+      if (static_cast<u32>(s) >= static_cast<u32>(d.g.num_states)) { atomicOr(&sh->err, ERR_BAD_STATE(2)); continue; }
       const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
       a_eps += static_cast<int>(a1 - a0);
       for (u32 a = a0; a < a1; a++) {
@@ -1126,6 +1136,10 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
       const float cur_cost = CostOf(e);
       if (e == EMPTY64 || cur_cost > cutoff) continue;      // :867
       const int s = PlainState(StateOf(e));
+      if (static_cast<u32>(s) >= static_cast<u32>(d.g.num_states)) {
+        KAMD_OOB_PRINTF("KAMD-OOB site=3 lane=%d tid=%d list=%d s=%d slot=%u e=%llx cur=%d i=%d nw=%d lcap=%d wlcap=%d\n", (int)blockIdx.x, tid, list, s, slot, (unsigned long long)e, cur, i, nw, lcap, L.wl_cap);
+        atomicOr(&sh->err, ERR_BAD_STATE(3)); continue;
+      }
       const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
       // (two records per trip, fetched together: a state with an LM backoff arc and one more is the common case)
       for (u32 ab = a0; ab < a1; ab += 2) {
@@ -1158,8 +1172,12 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
     if (err_now) break;
   }
   if (tid == 0) { sh->wl_n[0] = 0; sh->wl_n[1] = 0; }
-  LdsBarrier();
-  if (sh->n_slots > 0) __syncthreads();   // uniform: level-2 slot list (HBM) complete before it is read
+  // A FULL barrier in every frame (vmcnt(0) + s_barrier), not only when level-2 entries put the slot list in HBM: the
+  // survivors the insert sweep appended to the link arena (InsertEmitted, compacted through a wave allocator: written by one
+  // thread, resolved by another below) must have left their writers.  An LDS-only barrier orders nothing in global memory
+  // on this target -- hipcc waits for vmcnt(0) at a workgroup-scope release for that reason -- and by now those stores
+  // are a closure old: the wait is free.
+  __syncthreads();
   Stamp(sh, PH_EPS_CLOSURE);
   // ---- compaction: every table entry becomes a token of list 'list' (all of them are within
   // the cutoff: the inserts tested it; in a loose frame -- search mode 2 -- those beyond it count too: they are just not
@@ -1219,7 +1237,11 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
   float nx_cutoff = INFINITY, nx_abeam = d.cfg.beam;
   int live_base = my_base, n_live1 = n1;
   auto is_live = [&](u64 e) -> bool { return CostOf(e) <= nx_cutoff || HasEps(StateOf(e)); };
-  if (do_drop) {
+  // (a frame of no more than max_active tokens, all of them inside the next frame's beam -- the insert bound `cutoff` is not
+  // beyond it -- needs neither counts nor a select: that frame's cutoff is its beam cutoff and every token is live)
+  const bool all_live = do_drop && !loose && n_all <= d.cfg.max_active && n_all > d.cfg.min_active && cutoff <= next_beam_cutoff;
+  if (all_live) { nx_cutoff = next_beam_cutoff; nx_abeam = d.cfg.beam; }
+  if (do_drop && !all_live) {
     int cl = 0, ce = 0;
     TblLinearHist(c, tbl, ns2, best_next, d.cfg.beam, sh, [&](float w) { cl += w < next_beam_cutoff; ce += w <= next_beam_cutoff; });
     BlockSum2<true>(cl, ce, sh);
@@ -1305,7 +1327,8 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
   if (hbm_lists) __syncthreads();
   Stamp(sh, PH_COMPACT);
   auto tok_of_slot = [&](int slot) -> int {
-    return slot < lcap ? static_cast<int>(static_cast<u32>(tbl.LH[slot])) : c.slot_tok[slot];
+    if (slot < lcap) return static_cast<int>(static_cast<u32>(tbl.LH[slot]));
+    return c.slot_tok[slot];
   };
   // ---- emitting links: the survivors the insert sweep left behind the candidates become the frame's final links, dense from
   // emit_link_begin, slot -> token; a link into a token without a record (`drop`) is not written at all
@@ -1346,6 +1369,10 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
       const u64 e = TblLoad(c, tbl, static_cast<int>(slot));
       const int s = PlainState(StateOf(e));
       const int t = tok_of_slot(static_cast<int>(slot));
+      if (static_cast<u32>(s) >= static_cast<u32>(d.g.num_states)) {
+        KAMD_OOB_PRINTF("KAMD-OOB site=4 lane=%d tid=%d list=%d s=%d slot=%u e=%llx i=%d n_owner=%d owners_cap=%d lcap=%d ns2=%d drop=%d all_live=%d t=%d n_all=%d\n", (int)blockIdx.x, tid, list, s, slot, (unsigned long long)e, i, n_owner, L.owners_cap, lcap, ns2, (int)do_drop, (int)all_live, t, n_all);
+        atomicOr(&sh->err, ERR_BAD_STATE(4)); continue;
+      }
       const u32 a0 = d.g.off[s].y, a1 = d.g.off[s + 1].y;
       a_eps += static_cast<int>(a1 - a0);
       for (u32 ab = a0; ab < a1; ab += 2) {
@@ -1662,7 +1689,10 @@ __device__ __forceinline__ void PhaseExpand(int lane, Sh &sh, unsigned char *dyn
   }
   LlRow row; row.g = ll; row.l = (lds_cfloat *)L.ll; row.n_lds = d.num_pdfs_lds;
   LdsBarrier();
-  if (n > 0) {
+  if (n > 0 && static_cast<u32>(best_state) >= static_cast<u32>(d.g.num_states)) {
+    if (tid == 0) KAMD_OOB_PRINTF("KAMD-OOB site=5 lane=%d frame=%d best_state=%d n=%d n_all=%d tb=%d\n", (int)blockIdx.x, frame, best_state, n, fc.n_all, tb);
+    atomicOr(&sh.err, ERR_BAD_STATE(5));
+  } else if (n > 0) {
     const u32 a0 = d.g.off[best_state].x, a1 = d.g.off[best_state + 1].x;
     float seed = INFINITY;
     for (u32 a = a0 + tid; a < a1; a += NT) {
@@ -1700,6 +1730,13 @@ __device__ __forceinline__ void PhaseExpand(int lane, Sh &sh, unsigned char *dyn
       const int ic = min(i, n - 1);
       tcost[k] = cost[ic]; tstate[k] = state[ic];
       if (i >= n) tcost[k] = INFINITY;
+      if (static_cast<u32>(tstate[k]) >= static_cast<u32>(d.g.num_states)) {
+        if (i < n) {
+          KAMD_OOB_PRINTF("KAMD-OOB site=6 lane=%d tid=%d frame=%d state=%d cost=%f i=%d n=%d n_all=%d tb=%d\n", (int)blockIdx.x, tid, frame, tstate[k], tcost[k], i, n, fc.n_all, tb);
+          atomicOr(&sh.err, ERR_BAD_STATE(6));
+        } else atomicOr(&sh.err, ERR_BAD_STATE(7));
+        tstate[k] = 0; tcost[k] = INFINITY;
+      }
     }
 #pragma unroll
     for (int k = 0; k < EXPT; k++) {

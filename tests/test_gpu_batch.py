@@ -272,15 +272,15 @@ def test_long_utterances_searched_beside_the_acoustic_model_give_the_same_result
             assert a["words"].tolist() == c["words"].tolist() and a["graph_cost"] == c["graph_cost"] and a["acoustic_cost"] == c["acoustic_cost"]
             x, y = bh.compact_lattice(u), plain.compact_lattice(u)
             assert x.num_states == y.num_states and x.arcs.tobytes() == y.arcs.tobytes()
-    # ... and a planted matrix in LOAD order still reaches the right utterances (one queue then: the override's rows
-    # follow the caller's order, the stored order has the long ones first)
+    # ... and a planted matrix in LOAD order still reaches the right utterances, the long ones on the second decoder object
+    # included (round 4: the override's rows follow the caller's order, the stored order has the long ones first)
     fr = bh.output_frames()
     planted = [synth.random_loglikes(int(t), g.num_pdfs, seed=70 + u, scale=2.0) for u, t in enumerate(fr)]
     from kaldi_amd import decoder
     dev = decoder.DeviceMatrix(np.concatenate(planted, axis=0))
     bh.set_loglike_override(dev.ptr(0))
-    assert bh.run().long_utterances == 0
-    for u in (0, int(np.argmax(fr)), len(waves) - 1):
+    assert bh.run().long_utterances == 2
+    for u in (0, int(np.argmax(fr)), int(np.argsort(fr)[-2]), len(waves) - 1):
         o = orc.Decoder(g, cfg, 2)
         o.Decode(planted[u])
         assert lattices_equal(bh.raw_lattice(u), o.GetRawLattice())
@@ -399,3 +399,13 @@ def test_load_host_uploads_inside_run_and_changes_nothing():
     bd.set_loglike_override(None)
     bd.run()
     assert lattices_equal(bd.raw_lattice(3), ref.raw_lattice(3))
+    # kamd_batch_decoder_unload_host: the page lock goes before the memory does; the last run's outputs stay readable,
+    # another run() needs a new load; loading again (which unlocks the old buffer inside the call) works as before
+    bd.unload_host()
+    assert lattices_equal(bd.raw_lattice(3), ref.raw_lattice(3)) and bd.output(3)["words"].tolist() == ref.output(3)["words"].tolist()
+    with pytest.raises(Exception, match="released"):
+        bd.run()
+    bd.load_host(waves)
+    bd.load_host(list(waves))                                   # a second buffer while the first is still registered
+    assert bd.run().n_failed == 1
+    assert lattices_equal(bd.raw_lattice(5), ref.raw_lattice(5))

@@ -28,12 +28,13 @@ def test_two_ranks_are_launched_and_share_one_test_set():
     assert d["cpu_baseline"] is None                                                       # rank 0 at N = 1 only
 
 
-def test_four_ranks_search_their_longest_utterances_beside_the_model():
+@pytest.mark.parametrize("headline", ["random", "faithful"])
+def test_four_ranks_search_their_longest_utterances_beside_the_model(headline):
     """Ranks of 4 and more get the long-utterance decoder (kamd_batch_decoder_set_long_decoder, 32 lanes): with the upload
     inside the timed region the 32 longest utterances of a rank's shard are stored first and searched beside the model of the
     others; no utterance may fail and the line keeps its shape."""
     d = run_bench("--workload", "tiny", "--utts", "640", "--gpus", "4", "--dist-backend", "gloo", "--device", "0", "--steps", "2", "--warmup", "1",
-                  "--host-threads", "2", "--tokens-per-frame", "4000", "--headline", "random")        # (four ranks' arenas on ONE device here)
+                  "--host-threads", "2", "--tokens-per-frame", "4000", "--headline", headline)        # (four ranks' arenas on ONE device here)
     assert d["n_gpus"] == 4 and len(d["rank_wall_s"]) == 4 and d["value"] > 0
     assert d["config"]["utterances"] == 640 and d["config"]["utterances_rank0"] == 160
     assert d["config"]["long_utterances_rank0"] == 32 and d["config"]["upload_in_timed_region"] is True
@@ -65,6 +66,9 @@ def test_single_rank_line_has_roofline_cpu_baseline_and_wer():
     assert d["roofline_other_stage"]["flops_per_step"] > 0 or d["roofline"].get("flops_per_step", 0) > 0
     r = d["random_loglikes"]
     assert "error" not in r and r["value"] > 0 and r["roofline"]["bound"] == "hbm" and r["decoder"]["failed_utterances"] == 0
+    p = d["planted"]
+    assert "error" not in p and p["wer_line"].startswith("%WER") and p["failed_utterances"] == 0
+    assert "error" not in d["online_ivectors"] and d["online_ivectors"]["value"] > 0
     sl = d["streaming"]
     assert "error" not in sl and sl["ms_per_chunk"] > 0 and sl["aggregate_x_rt"] > 0 and sl["finalize_ms"] > 0 and sl["ms_per_tick_256"] > 0
 
@@ -79,7 +83,8 @@ def test_random_headline_keeps_round_3_legs():
 
 
 def test_resident_flag_keeps_round_2_contract():
-    d = run_bench("--workload", "tiny", "--steps", "1", "--warmup", "1", "--resident", "--no-cpu-baseline", "--no-wer", "--no-random-leg", "--no-streaming")
+    d = run_bench("--workload", "tiny", "--steps", "1", "--warmup", "1", "--resident", "--no-cpu-baseline", "--no-wer", "--no-random-leg", "--no-streaming",
+                  "--no-planted", "--no-ivector-leg")
     assert d["config"]["upload_in_timed_region"] is False and d["upload"] is None and "hbm_resident_value" not in d
 
 

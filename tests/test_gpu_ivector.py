@@ -5,9 +5,10 @@ fp64 on both sides, in a different order, and 15 warm-started CG steps amplify t
 import numpy as np
 import pytest
 
-from kaldi_amd import abi, feat, ivector, nnet, pipeline, synth
+from kaldi_amd import abi, decoder, feat, ivector, nnet, pipeline, synth
 from kaldi_amd._lib import KamdError
 from oracle import orc
+from tests.util import lattices_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -360,3 +361,47 @@ def test_streaming_updates_match_the_oracle_schedule():
         n0 = 2 * 9
         np.testing.assert_allclose(rec[s][n0:info.state_size()], st[n0:], rtol=1e-9, atol=1e-9 * np.abs(st).max())
     assert len(got[0]) == 5 and len(got[1]) == 5
+
+
+def test_long_utterance_split_with_an_extractor_and_a_loglike_override(monkeypatch):
+    """Round 4: kamd_batch_decoder_set_long_decoder also when the model takes online i-vectors from the device extractor and
+    when the search reads a log-likelihood override (bench.py's headline on ranks of 4 and more): the long utterances are
+    stored first, scored by a pass of their own (its own i-vectors and chunks) and searched on the second decoder object.
+    Nothing an utterance returns may depend on the way it went: log-likelihoods, lattices, best paths equal the plain run."""
+    from kaldi_amd import batch
+    monkeypatch.setenv("KAMD_BATCH_SPLIT", "1")
+    g = synth.make_hclg(num_units=40, vocab=120, n_hist=20, seed=4)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, ivector_dim=100, output_scale=3.0)
+    cfg = abi.decoder_config_recipe()
+    durs = [0.9, 2.6, 1.1, 0.8, 3.1, 1.3, 0.7, 1.6, 2.9, 1.0]
+    waves = [synth.make_wave(d, seed=300 + i) for i, d in enumerate(durs)]
+    op = abi.mfcc_opts_hires()
+    allf = feat.Mfcc(op).ComputeFeatures(waves[1])
+    ie = ivector.IvectorExtractor(ivector.make_synthetic(seed=11, feat_mean=allf.mean(0), feat_std=allf.std(0), max_count=100.0))
+    kw = dict(max_seconds=3.5, resident_lanes=4, host_threads=2, determinize=True, keep_raw_lattices=True, search_mode=2, nnet_pass_frames=400,
+              first_pass_frames=150)
+    plain = batch.NnetBatchDecoder(op, m, g, cfg, **kw)
+    plain.set_ivector_extractor(ie, 50)
+    plain.load_host(waves)
+    st0 = plain.run()
+    assert st0.n_failed == 0 and st0.long_utterances == 0
+    split = batch.NnetBatchDecoder(op, m, g, cfg, long_lanes=3, **kw)
+    split.set_ivector_extractor(ie, 50)
+    split.load_host(waves)
+    st = split.run()
+    assert st.n_failed == 0 and st.long_utterances == 3 and st.ivector_ms > 0
+    for u in range(len(waves)):
+        np.testing.assert_array_equal(split.loglikes(u), plain.loglikes(u))
+        assert lattices_equal(split.raw_lattice(u), plain.raw_lattice(u))
+        assert split.output(u)["words"].tolist() == plain.output(u)["words"].tolist()
+    # the search on planted rows (load order = the caller's order: the library maps them to where it stored the utterances)
+    fr = split.output_frames()
+    planted = [synth.random_loglikes(int(t), g.num_pdfs, seed=70 + u, scale=2.0) for u, t in enumerate(fr)]
+    dev = decoder.DeviceMatrix(np.concatenate(planted, axis=0))
+    split.set_loglike_override(dev.ptr(0))
+    st = split.run()
+    assert st.n_failed == 0 and st.long_utterances == 3
+    for u in range(len(waves)):
+        o = orc.Decoder(g, cfg, 2)
+        o.Decode(planted[u])
+        assert lattices_equal(split.raw_lattice(u), o.GetRawLattice()), u

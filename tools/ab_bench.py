@@ -25,7 +25,7 @@ def main():
     pairs = [a.rsplit("=", 1) for a in argv if "=" in a]
     out = os.path.join(ROOT, "gpurun_out", "ab")
     os.makedirs(out, exist_ok=True)
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-wer", "--no-streaming"]
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-wer", "--no-streaming", "--no-planted", "--no-ivector-leg"]
     for name, lib in pairs:
         env = dict(os.environ, KAMD_LIB=os.path.abspath(lib))
         if ":" in name:

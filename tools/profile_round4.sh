@@ -8,7 +8,7 @@ set -u
 export TMPDIR=/tmp
 O=gpurun_out/round4
 rm -rf $O; mkdir -p $O
-H="--no-random-leg --no-cpu-baseline --no-wer --no-streaming"
+H="--no-random-leg --no-planted --no-ivector-leg --no-cpu-baseline --no-wer --no-streaming"
 B="python3 bench.py --steps 2 --warmup 1 $H"
 timeout 1200 python3 bench.py --verbose > $O/bench_default.json 2> $O/bench_default.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- $B > $O/bench_under_rocprof.json 2> $O/stats.err

@@ -28,22 +28,37 @@ def main():
     ap.add_argument("--long-lanes", type=int, default=0, help="kamd_batch_decoder_set_long_decoder: lanes of the second decoder object")
     ap.add_argument("--tokens-per-frame", type=int, default=0, help="arena budget per frame and lane of both decoder objects (0 = from max-active / free HBM)")
     ap.add_argument("--host", action="store_true", help="the waveforms are uploaded inside run() (bench.py's default contract) instead of resident")
+    ap.add_argument("--faithful", action="store_true", help="bench.py's round-4 headline: the i-vector model (chunked, device extractor) on planted transcripts")
+    ap.add_argument("--no-override", action="store_true", help="(with --faithful) the search reads the model's own output, not planted rows")
+    ap.add_argument("--plain-model", action="store_true", help="(with --faithful) the model without the i-vector input, no extractor; planted rows")
     a = ap.parse_args()
     sys.argv = [sys.argv[0]] + (["--utts", str(a.utts)] if a.utts else [])
     args = bench.defaults(bench.parse_args())
     g, model, durs, cfg, _ = bench.build_workload(args)
-    bench.calibrate(model, args.ll_std)
+    extractor = None
+    if a.faithful and not a.plain_model:
+        model, extractor = bench.ivector_variant(args, g)
+    else:
+        bench.calibrate(model, args.ll_std)
     out = []
     base = None
     for world in [int(x) for x in a.worlds.split(",")]:
         mine = shard.lpt_shards(durs, world)[a.rank % world]
-        waves = synth.make_waves_fast(durs[mine], seed=1000 + a.rank)
+        pset = bench.planted_testset(g, durs, mine, synth) if a.faithful else None
+        waves = pset["waves"] if a.faithful else synth.make_waves_fast(durs[mine], seed=1000 + a.rank)
         audio = sum(w.size for w in waves) / 16000.0
-        bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=float(durs.max()) + 0.5, resident_lanes=a.lanes,
-                                    host_threads=16, determinize=True, keep_raw_lattices=False, hash_capacity=args.hash_capacity or None,
+        bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=pset["max_seconds"] if a.faithful else float(durs.max()) + 0.5,
+                                    resident_lanes=a.lanes, host_threads=16, determinize=True, keep_raw_lattices=False, hash_capacity=args.hash_capacity or None,
                                     search_mode=args.search_mode, lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), long_lanes=a.long_lanes,
-                                    tokens_per_frame=a.tokens_per_frame or None)
+                                    tokens_per_frame=a.tokens_per_frame or (11000 if a.faithful else None),
+                                    **(dict(nnet_pass_frames=400000, hbm_fraction=0.62) if a.faithful else {}))
+        planted = None
+        if extractor is not None:
+            bd.set_ivector_extractor(extractor, 50)
         (bd.load_host if a.host else bd.load)(waves)
+        if a.faithful and not a.no_override:
+            planted = synth.planted_loglikes_device(np.concatenate([p for _, p in pset["paths"]]), g.num_pdfs, args.planted_peak, args.planted_noise, seed=5)
+            bd.set_loglike_override(planted.ptr(0))
         bd.run()
         t0 = time.time()
         acc = np.zeros(5)
@@ -51,9 +66,12 @@ def main():
             st = bd.run()
             acc += [st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms]
             long_utts = st.long_utterances
+            if st.n_failed:
+                bad = [(u, bd.record(u).error, bd.record(u).n_frames) for u in range(len(waves)) if bd.record(u).error]
+                print("step %d: %d failed utterance(s): %s" % (_, st.n_failed, bad[:8]), file=sys.stderr, flush=True)
         dt = (time.time() - t0) / a.steps
         acc /= a.steps
-        total_audio = float(durs.sum())
+        total_audio = float(durs.sum()) if not a.faithful else audio * world      # (LPT shards: equal audio per rank to 0.1 %)
         rate = total_audio / dt
         if base is None:
             base = rate / world
@@ -62,7 +80,7 @@ def main():
                "implied_x_real_time_all_ranks": rate, "implied_strong_scaling_efficiency": rate / (base * world), "long_utterances": long_utts}
         out.append(row)
         print(json.dumps(row), flush=True)
-        del bd
+        del bd, planted
     return out
 
 
