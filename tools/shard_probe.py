@@ -66,6 +66,8 @@ def main():
             st = bd.run()
             acc += [st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms]
             long_utts = st.long_utterances
+            if st.n_retried:
+                print("step %d: %d utterance(s) took the second chance" % (_, st.n_retried), file=sys.stderr, flush=True)
             if st.n_failed:
                 bad = [(u, bd.record(u).error, bd.record(u).n_frames) for u in range(len(waves)) if bd.record(u).error]
                 print("step %d: %d failed utterance(s): %s" % (_, st.n_failed, bad[:8]), file=sys.stderr, flush=True)
