@@ -984,13 +984,14 @@ def failure_report(recs, limit=16):
 
 
 def library_build_id():
-    """sha256 (first 16 hex digits) of the HIP / C++ sources the library was built from: a profile taken with another
-    build says nothing about this one's traffic."""
+    """sha256 (first 16 hex digits) of the DEVICE sources the library was built from (the .hip files and the headers they
+    include): a profile taken with other kernels says nothing about these kernels' traffic.  Host-only sources (.cc: the
+    batch decoder's queueing, readers, determinization) do not enter -- they launch the same kernels."""
     import hashlib
     h = hashlib.sha256()
     src = os.path.join(ROOT, "kaldi_amd", "csrc")
     for f in sorted(os.listdir(src)):
-        if f.endswith((".hip", ".cc", ".h")):
+        if f.endswith((".hip", ".h")):
             h.update(open(os.path.join(src, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -940,7 +940,9 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
     std::vector<int> again;
     for (int k = 0; k < n; k++) {
       const kamd::UttOut &o = b->out[b->kept[k]];
-      if (o.status == KAMD_ERR_CAPACITY && (o.rec.error & (2 | 4 | 64)) != 0 && (o.rec.error & 8) == 0 && b->task_ll[k]) again.push_back(k);
+      // (32: a lane that stopped on one of its internal consistency checks -- DESIGN.md section 8.4: a transient event, once
+      // in several hundred test sets; the search is deterministic, so the second one gives the lattice the first should have)
+      if (o.status == KAMD_ERR_CAPACITY && (o.rec.error & (2 | 4 | 32 | 64)) != 0 && (o.rec.error & 8) == 0 && b->task_ll[k]) again.push_back(k);
     }
     if (again.empty()) break;
     const int max_lanes = kamd_decoder_max_lanes(b->dec);

@@ -1,0 +1,49 @@
+"""Invariants of the search kernels' source that no GPU test can see in minutes.
+
+A step soak found a wild lookup in HCLG's state-offset array once in a few hundred bench steps; since then every lookup of
+that array in device code sits behind a range check of the state and stops the lane with ERR_BAD_STATE(site).  This test
+keeps it that way: a new `d.g.off[...]` without the check fails here, on the CPU, and the bits a lane can report are all
+named in bench.py's failure report."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "kaldi_amd", "csrc", "decoder.hip")
+
+
+def _lines():
+    with open(SRC) as f:
+        return f.read().splitlines()
+
+
+def test_every_graph_offset_lookup_is_range_checked():
+    lines = _lines()
+    sites = [i for i, l in enumerate(lines) if "d.g.off[" in l]
+    assert len(sites) >= 6, sites
+    for i in sites:
+        window = "\n".join(lines[max(0, i - 16):i + 1])
+        assert "d.g.num_states" in window and "ERR_BAD_STATE(" in window, \
+            "decoder.hip:%d indexes the state-offset array without a range check in front of it:\n%s" % (i + 1, lines[i])
+
+
+def test_bad_state_sites_are_distinct_and_named_in_the_bench_report():
+    src = "\n".join(_lines())
+    sites = sorted(int(m) for m in re.findall(r"ERR_BAD_STATE\((\d+)\)", src))
+    assert sites == sorted(set(sites)) and sites[0] >= 1, sites            # one bit per lookup
+    m = re.search(r"#define ERR_BAD_STATE\(site\) \(ERR_INTERNAL \| \((\d+) << \(site\)\)\)", src)
+    assert m, "ERR_BAD_STATE changed its form"
+    base = int(m.group(1))
+    import bench
+    named = {bit for bit, _ in bench.ERROR_FLAGS}
+    for s in sites:
+        assert (base << s) in named, "bench.ERROR_FLAGS does not name bit %d (ERR_BAD_STATE(%d))" % (base << s, s)
+    enum = re.search(r"enum \{ ERR_HASH = 1, ERR_TOK = 2, ERR_LINK = 4, ERR_FRAMES = 8, ERR_WL = 16, ERR_INTERNAL = 32 \};", src)
+    assert enum and {1, 2, 4, 8, 16, 32, 64} <= named
+
+
+def test_second_chance_covers_lanes_stopped_by_an_internal_check():
+    """Arena / pool exhaustion (bits 2, 4, 64) and a lane stopped by an internal check (32, with or without a bad-state
+    bit) take the second chance -- the search is deterministic and the event transient; a frame overflow (8) does not."""
+    with open(os.path.join(ROOT, "kaldi_amd", "csrc", "batch.cc")) as f:
+        b = f.read()
+    assert "(o.rec.error & (2 | 4 | 32 | 64)) != 0 && (o.rec.error & 8) == 0" in b
