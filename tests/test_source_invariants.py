@@ -47,3 +47,17 @@ def test_second_chance_covers_lanes_stopped_by_an_internal_check():
     with open(os.path.join(ROOT, "kaldi_amd", "csrc", "batch.cc")) as f:
         b = f.read()
     assert "(o.rec.error & (2 | 4 | 32 | 64)) != 0 && (o.rec.error & 8) == 0" in b
+
+
+def test_soak_variant_transforms_still_match_the_source():
+    """tools/soak_variants.py builds the experiment libraries of the step soak from textual transforms of decoder.hip: every
+    transform must still find its text (a silent no-op would make a soak compare a build with itself)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import soak_variants as sv
+    src = "\n".join(_lines()) + "\n"
+    for name in ("noguards", "guards_commit", "guards_rest", "diag", "v110"):
+        out = sv.transform(name, src)
+        assert out != src, name
+    assert sv.transform("noguards", src).count("if (false)") == 6
+    assert "-disable-machine-licm" in sv.product_flags() and "--offload-arch=gfx950" in sv.product_flags()
