@@ -56,7 +56,7 @@ def test_soak_variant_transforms_still_match_the_source():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import soak_variants as sv
     src = "\n".join(_lines()) + "\n"
-    for name in ("noguards", "guards_commit", "guards_rest", "diag", "v110"):
+    for name in ("noguards", "guards_commit", "guards_rest", "diag", "v110", "sc1"):
         out = sv.transform(name, src)
         assert out != src, name
     assert sv.transform("noguards", src).count("if (false)") == 6
