@@ -535,10 +535,19 @@ def main():
             b.set_ivector_extractor(ie, 50)
         return b
 
+    internal_events = [0, 0]      # [utterances whose search stopped on an internal consistency check, runs] over every run of this process
+
+    def note(st):
+        internal_events[0] += int(st.n_internal_events)
+        internal_events[1] += 1
+        if st.n_internal_events:
+            log("!! %d utterance(s) stopped on an internal consistency check of the search lane (searched again: %d)" % (st.n_internal_events, st.n_retried))
+
     def timed(bd, steps, warmup):
         """`warmup` untimed runs, then `steps` runs between barriers: (wall seconds, mean stage vector, last stats)."""
         for _ in range(warmup):
             st = bd.run()
+            note(st)
             log("warmup step: feat %.1f nnet %.1f decode %.1f tail %.1f total %.1f ms, failed %d" %
                 (st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms, st.n_failed))
         sync_all()
@@ -546,6 +555,7 @@ def main():
         acc = np.zeros(11)
         for _ in range(steps):
             st = bd.run()
+            note(st)
             acc += [st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms, st.first_result_ms, st.host_thread_ms_sum,
                     st.upload_ms, st.first_pass_start_ms, st.upload_wait_ms, st.ivector_ms]
         sync_all()
@@ -823,6 +833,12 @@ def main():
             out["wer"] = wer_leg(g, cfg, args.wer_utts, min(32, cores), log, args.hash_capacity, args.search_mode)
         except Exception as e:                      # noqa: BLE001
             out["wer"] = {"error": repr(e)}
+    out["internal_events"] = {"utterances": internal_events[0], "test_set_passes": internal_events[1],
+                              "what": "utterances (rank 0, every pass of this process: warm-up, timed, legs) whose search lane stopped on one of its "
+                                      "internal consistency checks (kamd_batch_stats.n_internal_events); they are searched again and are NOT in "
+                                      "failed_utterances -- anything but 0 is a defect of the search kernel (DESIGN.md section 8.4)"}
+    if internal_events[0]:
+        print("bench.py: WARNING: %d utterance(s) stopped on an internal consistency check of the search lane" % internal_events[0], file=sys.stderr, flush=True)
     print(json.dumps(out, default=float))
     sys.stdout.flush()
 

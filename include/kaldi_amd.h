@@ -530,6 +530,8 @@ int kamd_decoder_queue_fetch_lattice(kamd_decoder *d, int32_t utt, void *copy_st
 int kamd_decoder_queue_launch_wide(kamd_decoder *d, const kamd_queue_task *tasks, int n, void *stream);
 /* kamd_decoder_sizes.max_lanes of the object. */
 int kamd_decoder_max_lanes(const kamd_decoder *d);
+/* ... and the frames per utterance its per-lane arrays were sized for (kamd_decoder_sizes.max_frames). */
+int kamd_decoder_max_frames(const kamd_decoder *d);
 int kamd_decoder_queue_wait(kamd_decoder *d, float *ms, int32_t *lanes);
 /* GetBestPath over a raw lattice given as arrays (the same ShortestPath as
  * kamd_decoder_best_path; no decoder state, thread-safe). */
@@ -1124,6 +1126,10 @@ typedef struct {
   float ivector_ms;                    /* device time of the online i-vector extraction (not part of nnet_ms), 0 without an extractor */
   int32_t n_retried;                   /* utterances searched a second time on a lane with larger arenas (their first search ran
                                         * out of token / link arena or lattice pool): inside decode_ms and total_ms */
+  int32_t n_internal_events;           /* utterances whose FIRST search stopped on one of the lane's internal consistency checks
+                                        * (kamd_queue_result.error & 32): not a capacity, a fault of the search itself.  They take
+                                        * the second chance too, are counted here whether or not it is switched on, and are named
+                                        * on stderr: anything but 0 is a defect to report */
 } kamd_batch_stats;
 typedef struct kamd_batch_decoder kamd_batch_decoder;
 /* The stages are not owned.  tid_phone as kamd_lattice_determinize_phone_pruned (NULL: word

@@ -197,7 +197,7 @@ class BatchStats(C.Structure):
                 ("host_thread_ms_sum", C.c_double), ("lanes", C.c_int32), ("nnet_passes", C.c_int32),
                 ("n_failed", C.c_int32), ("long_utterances", C.c_int32), ("upload_ms", C.c_float),
                 ("first_pass_start_ms", C.c_float), ("upload_wait_ms", C.c_float), ("upload_passes", C.c_int32),
-                ("ivector_ms", C.c_float), ("n_retried", C.c_int32)]
+                ("ivector_ms", C.c_float), ("n_retried", C.c_int32), ("n_internal_events", C.c_int32)]
 
 
 CLAT_ARC_DTYPE = np.dtype([("src", "<i4"), ("dst", "<i4"), ("label", "<i4"), ("graph_cost", "<f4"),

@@ -933,16 +933,33 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
   // searched again on a lane that owns a larger share of the pools -- a launch for the few of them, the pools split
   // between 1/8 of the lanes first, then 1/64 (kamd_decoder_queue_launch_wide).  The reference has no capacities to run out
   // of; here an unusually dense utterance costs a second search instead of a failure (KAMD_BATCH_RETRY=0 switches it off).
-  int n_retried = 0;
+  int n_retried = 0, n_internal = 0;
+  // A lane that stopped on one of its internal consistency checks (flag 32: a table entry beyond the cutoff, a state
+  // that is no state of the graph, ...) did not run out of anything: the search itself went wrong on that utterance
+  // (DESIGN.md section 8.4).  Such an utterance is searched again like one that ran out of arena -- the search is
+  // deterministic, the second one gives the lattice the first should have -- but it is COUNTED and REPORTED on its own
+  // (kamd_batch_stats.n_internal_events, a line on stderr): a run that hides it is how the event stayed unseen.
+  for (int k = 0; k < n; k++) {
+    const kamd::UttOut &o = b->out[b->kept[k]];
+    if (o.status == KAMD_ERR_CAPACITY && (o.rec.error & 32) != 0) {
+      n_internal++;
+      fprintf(stderr, "kaldi_amd: WARNING: utterance %d: the search lane stopped on an internal consistency check (flags 0x%x, frame %d of %d)\n",
+              b->kept[k], o.rec.error, o.rec.n_frames, static_cast<int>(b->out_off[k + 1] - b->out_off[k]));
+    }
+  }
   const char *retry_env = getenv("KAMD_BATCH_RETRY");        // (read per run: the tests switch it)
   const bool retry_on = !(retry_env && retry_env[0] == '0');
+  const int wide_max_frames = kamd_decoder_max_frames(b->dec);
   for (int round = 0; retry_on && round < 2; round++) {
     std::vector<int> again;
     for (int k = 0; k < n; k++) {
       const kamd::UttOut &o = b->out[b->kept[k]];
-      // (32: a lane that stopped on one of its internal consistency checks -- DESIGN.md section 8.4: a transient event, once
-      // in several hundred test sets; the search is deterministic, so the second one gives the lattice the first should have)
-      if (o.status == KAMD_ERR_CAPACITY && (o.rec.error & (2 | 4 | 32 | 64)) != 0 && (o.rec.error & 8) == 0 && b->task_ll[k]) again.push_back(k);
+      // token arena (2), link arena (4), lattice pool (64), the internal checks (32; counted above); never an utterance of more
+      // frames than the decoder holds (8), nor one longer than the main decoder's frame arrays (it was searched on the
+      // long-utterance decoder: its failure stays its own)
+      if (o.status == KAMD_ERR_CAPACITY && (o.rec.error & (2 | 4 | 32 | 64)) != 0 && (o.rec.error & 8) == 0 && b->task_ll[k] &&
+          b->out_off[k + 1] - b->out_off[k] <= wide_max_frames)
+        again.push_back(k);
     }
     if (again.empty()) break;
     const int max_lanes = kamd_decoder_max_lanes(b->dec);
@@ -957,6 +974,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
         rt[i].n_frames = static_cast<int32_t>(b->out_off[k + 1] - b->out_off[k]); rt[i].utt = i; rt[i].reserved = 0;
       }
       rc = kamd_decoder_queue_launch_wide(b->dec, rt.data(), m, st);
+      if (rc == KAMD_ERR_ARG) continue;      // the launch refused these tasks: their first failure stands, the run goes on
       if (rc != KAMD_OK) return rc;
       int got = 0;
       while (got < m) {
@@ -1019,6 +1037,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
   s.decode_ms = qms; s.total_ms = static_cast<float>(n_retried ? total_ms_all : total_ms);
   s.host_tail_ms = static_cast<float>(total_ms - t_last_done);
   s.n_retried = n_retried;
+  s.n_internal_events = n_internal;
   s.first_result_ms = static_cast<float>(t_first_done);
   s.nnet_flops = flops; s.lanes = lanes; s.nnet_passes = passes;
   s.long_utterances = two_queues ? b->long_lanes : 0;

@@ -1044,6 +1044,12 @@ __device__ __forceinline__ void TblLinearHist(const Ctx &c, const Tbl &tbl, int 
 __device__ inline float TblSelectLinear(const Ctx &c, const Tbl &tbl, int n2, int k, float best, float beam, Sh *sh) {
   const int tid = Tid();
   const float scale = static_cast<float>(SH_HIST) / beam;
+  // Sh::redi / sel_bin / scan_total are about to be rewritten: every wavefront must have finished reading what the
+  // caller's last reduction left there.  (The commit calls this right behind BlockSum2, whose readers have no barrier
+  // behind them: without this one a wavefront delayed by a few hundred cycles summed a scan value instead of another
+  // wavefront's count, took a different GetCutoff branch and ran the rest of the frame a barrier ahead of the others --
+  // clearing the table under them.  DESIGN.md section 8.4.)
+  LdsBarrier();
   // locate the bucket of rank k: SH_HIST / NT buckets per thread, workgroup scan
   constexpr int PER = SH_HIST / NT;
   static_assert(SH_HIST % NT == 0, "TblSelectLinear: whole buckets per thread");
@@ -3265,9 +3271,11 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   const size_t lds_budget = 160 * 1024 / LANES_PER_CU - sizeof(kamd::Sh) - 1024;
   const size_t fixed = kamd::AdvanceLdsBytes(0, LDS_TABLE_CAP);
   if (fixed < lds_budget) d.num_pdfs_lds = static_cast<int>(std::min<size_t>(static_cast<size_t>(num_pdfs), (lds_budget - fixed) / 4) & ~static_cast<size_t>(3));
-  // the row is filled by LDS-DMA, whose LDS base travels in M0[15:0]: keep its end below 64 KB (the row starts right behind
-  // the static part, <= 4 KB)
-  const size_t dma_reach = (65536 - 4096 - 16) / 4;
+  // the row is filled by LDS-DMA, whose LDS base travels in M0[15:0]: keep its end below 64 KB (the row starts 16 bytes
+  // into the dynamic part, which follows the kernels' static LDS: Sh, FinSh and the queue kernel's two words)
+  const size_t static_lds = (sizeof(kamd::Sh) + sizeof(kamd::FinSh) + 64 + 255) & ~static_cast<size_t>(255);
+  static_assert(sizeof(kamd::Sh) + sizeof(kamd::FinSh) + 64 < 16 * 1024, "static LDS of the search kernels");
+  const size_t dma_reach = (65536 - static_lds - 16) / 4;
   if (static_cast<size_t>(d.num_pdfs_lds) > dma_reach) d.num_pdfs_lds = static_cast<int>(dma_reach & ~static_cast<size_t>(3));
   if (d.num_pdfs_lds + 3 >= num_pdfs && static_cast<size_t>(num_pdfs) <= dma_reach && kamd::AdvanceLdsBytes(num_pdfs, LDS_TABLE_CAP) <= lds_budget) d.num_pdfs_lds = num_pdfs;
   if (ok && (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::FinalizeKernel),
@@ -4290,6 +4298,7 @@ int kamd_decoder_queue_launch_wide(kamd_decoder *h, const kamd_queue_task *tasks
 }
 
 int kamd_decoder_max_lanes(const kamd_decoder *h) { return reinterpret_cast<const Decoder *>(h)->sizes.max_lanes; }
+int kamd_decoder_max_frames(const kamd_decoder *h) { return reinterpret_cast<const Decoder *>(h)->sizes.max_frames; }
 
 static int QueueLaunch(kamd_decoder *h, const kamd_queue_task *tasks, int n, int resident_lanes, void *stream, bool wide) {
   Decoder *D = reinterpret_cast<Decoder *>(h);

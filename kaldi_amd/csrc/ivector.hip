@@ -21,6 +21,7 @@
 // HBM-bound where it is bound at all: 40 KB of U_g per selected Gaussian and frame.
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -736,8 +737,14 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
   v.I = I; v.Q = Q; v.U = e->d_U; v.SM = e->d_SM;
   v.prior_offset = d.prior_offset; v.max_count = d.max_count;
   v.period = d.ivector_period; v.ng = d.num_gselect; v.cg_iters = d.num_cg_iters;
+  // (the attribute is per kernel and process-wide, not per extractor: it only ever grows -- a second, smaller extractor
+  // must not lower the cap under the first one's launches)
+  static int solve_lds_max = 0, step_lds_max = 0;
+  static std::mutex lds_attr_mu;
+  std::lock_guard<std::mutex> lds_attr_lock(lds_attr_mu);
+  solve_lds_max = std::max(solve_lds_max, static_cast<int>((static_cast<size_t>(Q) + 6 * kamd::IV_MAX_DIM) * sizeof(double)));
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::SolveKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          static_cast<int>((static_cast<size_t>(Q) + 6 * kamd::IV_MAX_DIM) * sizeof(double))) != hipSuccess) {
+                          solve_lds_max) != hipSuccess) {
     kamd::SetError(KAMD_ERR_HIP, "i-vector extractor: cannot reserve LDS for the solver");
     kamd_ivector_extractor_destroy(reinterpret_cast<kamd_ivector_extractor *>(e));
     return NULL;
@@ -752,8 +759,9 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
       kamd_ivector_extractor_destroy(reinterpret_cast<kamd_ivector_extractor *>(e));
       return NULL;
     }
+    step_lds_max = std::max(step_lds_max, static_cast<int>(lds_step));
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::StepStatsKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            static_cast<int>(lds_step)) != hipSuccess) {
+                            step_lds_max) != hipSuccess) {
       kamd::SetError(KAMD_ERR_HIP, "i-vector extractor: cannot reserve LDS for the statistics step");
       kamd_ivector_extractor_destroy(reinterpret_cast<kamd_ivector_extractor *>(e));
       return NULL;

@@ -62,12 +62,16 @@ def main():
         bd.run()
         t0 = time.time()
         acc = np.zeros(5)
+        events = [0]
         for _ in range(a.steps):
             st = bd.run()
             acc += [st.feat_ms, st.nnet_ms, st.decode_ms, st.host_tail_ms, st.total_ms]
             long_utts = st.long_utterances
             if st.n_retried:
                 print("step %d: %d utterance(s) took the second chance" % (_, st.n_retried), file=sys.stderr, flush=True)
+            if st.n_internal_events:
+                events[0] += st.n_internal_events
+                print("step %d: %d utterance(s) stopped on an internal consistency check" % (_, st.n_internal_events), file=sys.stderr, flush=True)
             if st.n_failed:
                 bad = [(u, bd.record(u).error, bd.record(u).n_frames) for u in range(len(waves)) if bd.record(u).error]
                 print("step %d: %d failed utterance(s): %s" % (_, st.n_failed, bad[:8]), file=sys.stderr, flush=True)
@@ -79,10 +83,13 @@ def main():
             base = rate / world
         row = {"world": world, "utterances_this_rank": len(waves), "audio_this_rank_s": audio, "longest_s": float(durs[mine].max()),
                "step_ms": 1e3 * dt, "feat_ms": acc[0], "nnet_ms": acc[1], "decode_ms": acc[2], "tail_ms": acc[3],
-               "implied_x_real_time_all_ranks": rate, "implied_strong_scaling_efficiency": rate / (base * world), "long_utterances": long_utts}
+               "implied_x_real_time_all_ranks": rate, "implied_strong_scaling_efficiency": rate / (base * world), "long_utterances": long_utts,
+               "internal_events": events[0]}
         out.append(row)
         print(json.dumps(row), flush=True)
         del bd, planted
+    if any(r["internal_events"] for r in out):      # a soak is clean when NO search stopped on an internal check, retried or not
+        sys.exit(3)
     return out
 
 
