@@ -375,6 +375,15 @@ int kamd_decoder_set_options(kamd_decoder *d, const kamd_decoder_config *cfg);
  *     least as much.  On all other frames the tokens between the two bounds can never be
  *     expanded (next frame's cutoff = this frame's final bound) and the modes coincide. */
 int kamd_decoder_set_search_mode(kamd_decoder *d, int mode);
+/* Token pre-selection of the work-queue lanes (on by default; KAMD_PRESELECT=0 in the environment switches it off at
+ * creation).  On a frame that records several times max_active candidate arcs (the frames behind a word boundary) the lane
+ * inserts only the candidates under a bound that provably contains the next frame's max-active cutoff, plus those whose
+ * target state has epsilon arcs; the tokens the other candidates would create are exactly the ones the next frame's
+ * GetCutoff (lattice-faster-decoder.cc:693-702) discards unexpanded, and links from those candidates into tokens that do
+ * exist are kept.  Raw lattices, best paths, per-frame cutoffs and all work counters are unchanged, EXCEPT counters[5]
+ * (N_tok) and the per-frame token trace, which then count the tokens the lane inserted, not the ones the reference
+ * would have created.  off = every token is created and counted, as the reference does. */
+int kamd_decoder_set_token_preselection(kamd_decoder *d, int on);
 /* How a lane's 160 KB of LDS were split: entries of a frame's log-likelihood row staged in LDS
  * (pdfs beyond that are read from HBM) and words of the level-1 token table (states whose
  * probe window is full spill to the level-2 table in HBM).  Diagnostic, used by the tests. */
@@ -493,7 +502,8 @@ typedef struct {
                               * (which lookup: kaldi_amd/csrc/decoder.hip ERR_BAD_STATE) */
   int32_t lane, n_frames;    /* lane that decoded it; NumFramesDecoded() */
   int32_t n_tok, n_link;     /* raw lattice: states, arcs */
-  int32_t n_last, pad;       /* tokens on the last frame (their final costs travel with the lattice) */
+  int32_t n_last;            /* tokens on the last frame (their final costs travel with the lattice) */
+  int32_t n_preselected;     /* frames whose inserts were pre-selected (kamd_decoder_set_token_preselection): diagnostic */
   float final_relative_cost, final_best_cost;
   int64_t blob_off, blob_bytes;   /* the lattice inside the pool */
   int64_t counters[8];       /* the work counters of kamd_decoder_get_counters */

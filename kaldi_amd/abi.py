@@ -140,7 +140,7 @@ class QueueTask(C.Structure):
 class QueueResult(C.Structure):
     """kamd_queue_result: the record a lane publishes when an utterance is done."""
     _fields_ = [("status", C.c_int32), ("error", C.c_int32), ("lane", C.c_int32), ("n_frames", C.c_int32),
-                ("n_tok", C.c_int32), ("n_link", C.c_int32), ("n_last", C.c_int32), ("pad", C.c_int32),
+                ("n_tok", C.c_int32), ("n_link", C.c_int32), ("n_last", C.c_int32), ("n_preselected", C.c_int32),
                 ("final_relative_cost", C.c_float), ("final_best_cost", C.c_float),
                 ("blob_off", C.c_int64), ("blob_bytes", C.c_int64), ("counters", C.c_int64 * 8),
                 ("phase_cycles", C.c_uint64 * 16)]

@@ -114,7 +114,7 @@ struct LaneState {
   float final_relative_cost, final_best_cost;
   int out_ntok, out_nlink;
   int out_tok_base, out_lnk_base;   // where the finalized lattice starts inside the lane's arenas
-  int out_cost_in_map, pad;         // staged token costs live in tok_map (FinalizeKernel2)
+  int out_cost_in_map, presel_frames;   // staged token costs live in tok_map (FinalizeKernel2); frames with pre-selected inserts (diagnostic)
   long long counters[8];
   unsigned long long phase_cycles[16];   // diagnostic: shader cycles per phase (thread 0)
 };
@@ -130,6 +130,7 @@ struct DecDev {
   int lds_table_cap;    // level-1 (LDS) table words, power of two or 0
   int big_frame_tokens; // a frame after one that created more tokens than this inserts into the whole table region
   float good_first;     // > 0 (experiment, KAMD_GOOD_FIRST): tokens within this of the best are expanded in a pass of their own, first
+  int preselect;        // work-queue lanes: frames with several times max_active candidates insert only those that can matter (InsertEmitted)
   kamd_decoder_config cfg;
   int loose;            // search mode 2: arcs are kept against the seed cutoff (kamd_decoder_set_search_mode)
   int hash_cap, hash_mask, max_frames;
@@ -227,6 +228,7 @@ struct Sh {  // workgroup-shared state
   int sel_bin, sel_below;
   int scan_total;
   int big_total;
+  int presel_frames;     // frames of this call whose inserts were pre-selected (diagnostic)
   // per-lane running state mirrored in LDS (the global copies are written for the host and
   // for the next launch; reading them back every frame would be an L2 round trip each)
   int cur_tb, cur_n;     // newest token list: first token, count
@@ -543,7 +545,7 @@ __device__ inline u64 TblLoad(const Ctx &c, const Tbl &t, int slot) {
 // FindOrAddToken (lattice-faster-decoder.cc:266-306) on the frame's table.
 // returns slot (or -1 on overflow); *improved = created, or strictly lowered the cost.
 __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int state, float cost,
-                                 bool *improved, const Tbl &t) {
+                                 bool *improved, const Tbl &t, bool *created = nullptr) {
   const int slot_bias = t.lcap, hmask = t.hmask;
   const u64 mine = Pack(state, cost);
   u32 h = HashState(state, hmask);
@@ -561,6 +563,7 @@ __device__ inline int HashInsert(const DecDev &d, const Ctx &c, Sh *sh, int stat
         else atomicOr(&sh->err, ERR_WL);
       }
       *improved = true;
+      if (created) *created = true;
       return static_cast<int>(h);
     }
     if (StateOf(old) == state) {
@@ -590,7 +593,7 @@ __device__ __forceinline__ uint4 *CandBase(const Ctx &c, int link_base) {
   return reinterpret_cast<uint4 *>((reinterpret_cast<size_t>(c.links + link_base) + 15) & ~static_cast<size_t>(15));
 }
 __device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t, int state, float cost,
-                                bool *improved);
+                                bool *improved, bool *created = nullptr);
 // W emitting arcs of one thread (lattice-faster-decoder.cc:791-809), evaluated together:
 // all cutoff tests first (the arcs were loaded together), then the inserts and links.
 template <int W>
@@ -608,12 +611,12 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
   // of the row -- none at all for the usual chain model -- are patched from HBM afterwards
 #pragma unroll
   for (int q = 0; q < W; q++) {
-    const int pdf = ok[q] ? static_cast<int>(hot[q].y) : 0;
+    const int pdf = ok[q] ? static_cast<int>(hot[q].y & ~EPS_FLAG) : 0;
     llv[q] = ll.l[max(min(pdf, ll.n_lds - 1), 0)];
   }
 #pragma unroll
   for (int q = 0; q < W; q++)
-    if (ok[q] && static_cast<int>(hot[q].y) >= ll.n_lds) llv[q] = ll.g[hot[q].y];
+    if (ok[q] && static_cast<int>(hot[q].y & ~EPS_FLAG) >= ll.n_lds) llv[q] = ll.g[hot[q].y & ~EPS_FLAG];
 #pragma unroll
   for (int q = 0; q < W; q++) {
     ac[q] = cost_offset - llv[q];
@@ -634,7 +637,8 @@ __device__ inline void ProcessArcs(const DecDev &d, const Ctx &c, Sh *sh, const 
     if (link_base + k >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
     // a candidate is 16 bytes: source token, arc index, the arc's total cost (the insert sweep then needs no look at the
     // source token) and its acoustic part; labels, target and graph weight come from the arc record, for the survivors only
-    CandBase(c, link_base)[k] = make_uint4(static_cast<u32>(src_tok[q]), aidx[q], __float_as_uint(tot[q]), __float_as_uint(ac[q]));
+    // (bit 31 of the arc word: the target state has epsilon arcs -- InsertEmitted's pre-selection)
+    CandBase(c, link_base)[k] = make_uint4(static_cast<u32>(src_tok[q]), aidx[q] | (hot[q].y & EPS_FLAG), __float_as_uint(tot[q]), __float_as_uint(ac[q]));
   }
 }
 
@@ -652,9 +656,24 @@ static_assert(EXPT * NT == BIGCAP, "one outer expansion iteration must fit the f
 // links, dense from link_begin again (over the dead candidates: a final link's index is never beyond its survivor's,
 // which lies behind every candidate), leaving out the ones whose destination token got no record (CommitFrame2, `drop`).
 // The arena needs room for n_cand + n_surv records beyond the links in use; the records behind the final links are scratch.
+// Pre-selection (round 5; work-queue lanes, frames whose candidates are several times max_active -- the frames behind a
+// word boundary, 10^5 candidates of which the next frame's max-active cutoff keeps 7000).  Every token such a frame creates
+// beyond the NEXT frame's cutoff is deleted unexpanded, and was until now inserted all the same: 84 % of the planted load's
+// tokens, most of them in the HBM level of the table (a CAS, a slot-list word, the dense copy, the slot -> token word, the
+// clearing store: five random sectors each).  Instead: a histogram of the candidates' costs picks a bound B that about
+// 1.25 max_active candidates lie under; the sweep inserts the candidates with tot <= B and those whose target has epsilon
+// arcs (KAMD_PS_FIRST) and counts the tokens it CREATES under B.  If that count exceeds max_active, the next frame's
+// cutoff -- the max_active-th smallest token cost -- is <= B whatever the other candidates are, every token it can expand
+// is in the table with its final cost, and the others would only have been counted: they are not inserted at all, and
+// after the epsilon closure FindSkipped turns the left-out candidates whose target IS in the table into links (a link
+// into a live token from a worse arc is a lattice arc like any other).  If the count falls short (many candidates of few
+// states), KAMD_PS_REST inserts what was left out and the frame is what it always was.  Lattices, links, cutoffs and
+// every work counter but one are unchanged: N_tok (counters[5], trace_ntok) counts the tokens the lane inserted.
+enum { KAMD_PS_ALL = 0, KAMD_PS_FIRST = 1, KAMD_PS_REST = 2 };
+template <int MODE>
 __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, int link_begin,
-                                    int n_links, float cutoff) {
-  int k_surv = 0;
+                                    int n_links, float cutoff, float ps_bound, int *created_under_bound) {
+  int k_surv = 0, made = 0;
   const int le = min(link_begin + n_links, c.lnk_cap);
   const int surv_begin = le;
   // INSB links per thread per trip: the records, then the arcs, are loaded for the
@@ -662,7 +681,7 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
   const uint4 *cand = CandBase(c, link_begin);
   const int n_cand = le - link_begin;
   for (int g0 = 0; g0 * NT < n_cand; g0 += INSB) {
-    uint4 L[INSB]; kamd_arc arc[INSB];      // L: {source token, arc index, tot, acoustic cost}
+    uint4 L[INSB]; kamd_arc arc[INSB]; bool take[INSB];     // L: {source token, arc index | target's epsilon flag, tot, acoustic cost}
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
       const int ci = Tid() + (g0 + k) * NT;
@@ -671,20 +690,24 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
       const int ci = Tid() + (g0 + k) * NT;
-      // the record of the arc ProcessArcs kept by index -- only for the candidates that pass the final cutoff (2.5 were
-      // recorded per survivor at the matched load: the others all read arc 0, one cached line instead of a random 16-byte
-      // fetch each)
-      arc[k] = d.g.e_arcs[(ci < n_cand && __uint_as_float(L[k].z) <= cutoff) ? L[k].y : 0u];
+      const float tot = __uint_as_float(L[k].z);
+      // :798 with the frame's final cutoff: a candidate beyond it is simply not carried on
+      take[k] = ci < n_cand && tot <= cutoff;
+      const bool first = tot <= ps_bound || (L[k].y & EPS_FLAG) != 0;
+      if (MODE == KAMD_PS_FIRST) take[k] = take[k] && first;
+      if (MODE == KAMD_PS_REST) take[k] = take[k] && !first;
+      // the record of the arc ProcessArcs kept by index -- only for the candidates this sweep inserts (2.5 were recorded per
+      // survivor at the matched load: the others all read arc 0, one cached line instead of a random 16-byte fetch each)
+      arc[k] = d.g.e_arcs[take[k] ? (L[k].y & ~EPS_FLAG) : 0u];
     }
 #pragma unroll
     for (int k = 0; k < INSB; k++) {
-      const int ci = Tid() + (g0 + k) * NT;
-      if (ci >= n_cand) continue;
+      if (!take[k]) continue;
       const float tot = __uint_as_float(L[k].z);      // == source cost + ac + graph, as ProcessArcs summed it
-      if (!(tot <= cutoff)) continue;            // :798 with the frame's final cutoff: the candidate is simply not carried on
-      bool improved;
-      const int dst = TblInsert(d, c, sh, tbl, arc[k].nextstate, tot, &improved);
+      bool improved, created = false;
+      const int dst = TblInsert(d, c, sh, tbl, arc[k].nextstate, tot, &improved, &created);
       if (dst < 0) continue;                     // (table overflow: flagged)
+      if (MODE == KAMD_PS_FIRST && created && tot <= ps_bound) made++;
       k_surv++;
       const int so = surv_begin + WaveAlloc(&sh->n_surv);
       if (so >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
@@ -693,6 +716,7 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
       c.links[so] = o;
     }
   }
+  if (MODE == KAMD_PS_FIRST) *created_under_bound = made;
   return k_surv;
 }
 
@@ -708,8 +732,9 @@ __device__ inline int HashFind(const DecDev &d, const Ctx &c, int state, int hma
   return -1;
 }
 
+// (*created, when asked for: set to true iff this call made the state's entry; left alone otherwise)
 __device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &t, int state, float cost,
-                                bool *improved) {
+                                bool *improved, bool *created) {
   if (t.lcap > 0) {
     const u64 mine = Pack(state, cost);
     const u32 h0 = HashL(state, t.lcap), m = static_cast<u32>(t.lcap - 1);
@@ -728,7 +753,7 @@ __device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl
       while (w >= 0 && w < LWIN) {
         const u32 sl = (h0 + w0 + w) & m;
         const u64 old = atomicCAS(&t.LH[sl], EMPTY64, mine);
-        if (old == EMPTY64) { *improved = true; return static_cast<int>(sl); }
+        if (old == EMPTY64) { *improved = true; if (created) *created = true; return static_cast<int>(sl); }
         if (StateOf(old) == state) {
           if (old <= mine) { *improved = false; return static_cast<int>(sl); }
           const u64 prev = atomicMin(&t.LH[sl], mine);
@@ -740,7 +765,7 @@ __device__ inline int TblInsert(const DecDev &d, const Ctx &c, Sh *sh, const Tbl
       // (these LWIN words hold other states: the next LWIN, or level 2 once the whole window is full)
     }
   }
-  const int g = HashInsert(d, c, sh, state, cost, improved, t);
+  const int g = HashInsert(d, c, sh, state, cost, improved, t, created);
   return g < 0 ? g : g + t.lcap;
 }
 __device__ inline int TblFind(const DecDev &d, const Ctx &c, const Tbl &t, int state) {
@@ -755,6 +780,44 @@ __device__ inline int TblFind(const DecDev &d, const Ctx &c, const Tbl &t, int s
   }
   const int g = HashFind(d, c, state, t.hmask);
   return g < 0 ? g : g + t.lcap;
+}
+
+// The candidates a pre-selected insert sweep left out (InsertEmitted<KAMD_PS_FIRST>), after the epsilon closure: one whose
+// target state is in the table all the same -- created by a better arc or by the closure -- is a link into that token
+// (its cost cannot lower the token's: it is beyond the bound every inserted candidate of a non-epsilon state lies under,
+// or the token is beyond the next frame's cutoff either way and gets no record); the others would have created tokens
+// that nothing ever expands.  All of them passed the frame's cutoff: they count as survivors (K_surv) like before.
+__device__ inline int FindSkipped(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, int link_begin, int n_links, float cutoff,
+                                  float ps_bound) {
+  int k_surv = 0;
+  const int le = min(link_begin + n_links, c.lnk_cap);
+  const int surv_begin = le;
+  const uint4 *cand = CandBase(c, link_begin);
+  const int n_cand = le - link_begin;
+  for (int g0 = 0; g0 * NT < n_cand; g0 += INSB) {
+    uint4 L[INSB]; kamd_arc arc[INSB]; bool take[INSB];
+#pragma unroll
+    for (int k = 0; k < INSB; k++) L[k] = cand[min(Tid() + (g0 + k) * NT, n_cand - 1)];
+#pragma unroll
+    for (int k = 0; k < INSB; k++) {
+      const float tot = __uint_as_float(L[k].z);
+      take[k] = Tid() + (g0 + k) * NT < n_cand && tot <= cutoff && !(tot <= ps_bound || (L[k].y & EPS_FLAG) != 0);
+      arc[k] = d.g.e_arcs[take[k] ? (L[k].y & ~EPS_FLAG) : 0u];
+    }
+#pragma unroll
+    for (int k = 0; k < INSB; k++) {
+      if (!take[k]) continue;
+      k_surv++;
+      const int dst = TblFind(d, c, tbl, arc[k].nextstate);
+      if (dst < 0) continue;
+      const int so = surv_begin + WaveAlloc(&sh->n_surv);
+      if (so >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
+      Link o; o.src = static_cast<int>(L[k].x); o.dst = dst; o.ilabel = arc[k].ilabel; o.olabel = arc[k].olabel;
+      o.graph = arc[k].weight; o.ac = __uint_as_float(L[k].w);
+      c.links[so] = o;
+    }
+  }
+  return k_surv;
 }
 
 __device__ inline float LogLike(const DecDev &d, const float *ll, int ilabel) {
@@ -1113,7 +1176,8 @@ struct CommitLds {
 // lists; when a frame has none, no barrier of the commit has to wait for global memory.
 __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, float cutoff, int list,
                                              int emit_link_begin, int k_surv,
-                                             const CommitLds &L, bool loose, bool drop) {
+                                             const CommitLds &L, bool loose, bool drop, bool presel = false,
+                                             float insert_cutoff = 0.0f, float presel_bound = 0.0f) {
   const int tid = Tid();
   LaneState *S = c.st;
   const int lcap = tbl.lcap;
@@ -1185,6 +1249,13 @@ __device__ __forceinline__ void CommitFrame2(const DecDev &d, const Ctx &c, Sh *
   // are a closure old: the wait is free.
   __syncthreads();
   Stamp(sh, PH_EPS_CLOSURE);
+  // ---- a pre-selected frame: the candidates the insert sweep left out become links where their target exists
+  // (FindSkipped; the table is complete now -- the closure is done -- and still holds the costs)
+  if (presel) {     // uniform
+    k_surv += FindSkipped(d, c, sh, tbl, emit_link_begin, sh->n_links, insert_cutoff, presel_bound);
+    __syncthreads();     // the survivors it appended are resolved by other threads below
+    Stamp(sh, PH_FIXUP);
+  }
   // ---- compaction: every table entry becomes a token of list 'list' (all of them are within
   // the cutoff: the inserts tested it; in a loose frame -- search mode 2 -- those beyond it count too: they are just not
   // epsilon-expanded, :867).  First sweep: how many entries each thread owns and the list's best token (for the NEXT
@@ -1499,6 +1570,7 @@ __device__ __forceinline__ void PublishLaneEnd(const DecDev &d, const Ctx &c, Sh
     S->frame = frame;
     S->final_relative_cost = (b == INFINITY && bf == INFINITY) ? INFINITY : bf - b;  // :574-582
     S->error |= sh->err;
+    S->presel_frames += sh->presel_frames;
   }
   // (one counter per thread: unrolled on thread 0 the 24 read-modify-writes were all in flight together, 50 VGPRs)
   if (tid < 8) S->counters[tid] += sh->cnt[tid];
@@ -1509,7 +1581,7 @@ __device__ inline void InitSh(Sh *sh) {
   if (Tid() == 0) {
     sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->n_surv = 0; sh->n_final = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
     sh->bigcnt = 0; sh->hugecnt = 0; sh->n_new = 0; sh->best_key = EMPTY64; sh->c_lt = 0; sh->c_le = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
-    sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0; sh->cur_n_all = 0; sh->cutoff_ready = 0; sh->cache_valid = 0;
+    sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0; sh->cur_n_all = 0; sh->cutoff_ready = 0; sh->cache_valid = 0; sh->presel_frames = 0;
     for (int i = 0; i < 8; i++) sh->cnt[i] = 0;
     for (int i = 0; i < 16; i++) sh->ph[i] = 0;
     sh->t_prev = __builtin_amdgcn_s_memtime();
@@ -1521,7 +1593,12 @@ __device__ inline void InitSh(Sh *sh) {
 // tid -> pdf gather of TransitionIdToPdfFast from the per-arc critical path)
 __global__ void ArcHotKernel(const kamd_arc *arcs, long long n, const int *tid2pdf, uint2 *e_hot) {
   long long i = static_cast<long long>(blockIdx.x) * blockDim.x + Tid();
-  if (i < n) { const kamd_arc a = arcs[i]; e_hot[i] = make_uint2(__float_as_uint(a.weight), static_cast<u32>(tid2pdf ? tid2pdf[a.ilabel] : a.ilabel - 1)); }
+  // (.y: the pdf, and in bit 31 the "target state has epsilon arcs" flag the arc's nextstate carries: the insert sweep's
+  // pre-selection must know it without fetching the arc record)
+  if (i < n) {
+    const kamd_arc a = arcs[i];
+    e_hot[i] = make_uint2(__float_as_uint(a.weight), static_cast<u32>(tid2pdf ? tid2pdf[a.ilabel] : a.ilabel - 1) | (static_cast<u32>(a.nextstate) & EPS_FLAG));
+  }
 }
 
 // ------------------------------------------------------------------ kernels
@@ -1533,7 +1610,7 @@ __device__ __forceinline__ void InitLane(const DecDev &d, const Ctx &c, Sh *shp)
   if (Tid() == 0) {
     S->frame = 0; S->tok_used = 0; S->lnk_used = 0; S->error = 0; S->finalized = 0;
     S->final_relative_cost = INFINITY; S->final_best_cost = INFINITY;
-    S->out_ntok = 0; S->out_nlink = 0; S->out_tok_base = 0; S->out_lnk_base = 0;
+    S->out_ntok = 0; S->out_nlink = 0; S->out_tok_base = 0; S->out_lnk_base = 0; S->presel_frames = 0;
     for (int i = 0; i < 8; i++) S->counters[i] = 0;
     for (int i = 0; i < 16; i++) S->phase_cycles[i] = 0;
     c.tok_off[0] = 0; c.lnk_off[0] = 0; c.lnk_off[1] = 0;
@@ -1625,6 +1702,7 @@ struct FrameCtl {
   bool big;                        // the frame inserts into the whole table region (FrameTable)
   int hmask;                       // ... and into a level-2 table of hmask + 1 slots (FrameLevel2Mask)
   int link_base, k_surv;
+  bool presel; float presel_bound; // the insert sweep left the candidates beyond presel_bound out (InsertEmitted<KAMD_PS_FIRST>): FindSkipped after the closure
 };
 
 // ---- GetCutoff (:657-724).  The best token (ties -> smallest state, as oracle mode 1) and the two beam counts were
@@ -1703,7 +1781,7 @@ __device__ __forceinline__ void PhaseExpand(int lane, Sh &sh, unsigned char *dyn
     float seed = INFINITY;
     for (u32 a = a0 + tid; a < a1; a += NT) {
       const uint2 hot = d.e_hot[a];
-      const float new_weight = __uint_as_float(hot.x) + cost_offset - LogLikePdf(row, static_cast<int>(hot.y)) + best;
+      const float new_weight = __uint_as_float(hot.x) + cost_offset - LogLikePdf(row, static_cast<int>(hot.y & ~EPS_FLAG)) + best;
       seed = fminf(seed, new_weight + adaptive_beam);
     }
     // a minimum is a minimum in any order: the wavefronts that hold an arc of the best token put theirs straight
@@ -1862,19 +1940,89 @@ __device__ __forceinline__ void PhaseExpand(int lane, Sh &sh, unsigned char *dyn
   fc.next_cutoff = OrderedToFloat(sh.next_cutoff_u);
 }
 
-// ---- FindOrAddToken for the recorded links, against the final cutoff
-__device__ __forceinline__ void PhaseInsert(int lane, Sh &sh, unsigned char *dyn_lds, FrameCtl &fc) {
+// ---- FindOrAddToken for the recorded links, against the final cutoff.  `may_preselect`: the tokens this frame creates
+// will be looked at by nobody but the next frame of this very call (a work-queue lane, not the call's last frame).
+__device__ __forceinline__ void PhaseInsert(int lane, Sh &sh, unsigned char *dyn_lds, FrameCtl &fc, bool may_preselect) {
   const DecDev d = LoadDecDev();
   const Ctx c = MakeCtx(d, Opaque(lane));
   const AdvLds L = MakeAdvLds(dyn_lds, d.num_pdfs_lds, d.lds_table_cap);
+  const int tid = Tid();
+  const float cutoff = fc.loose ? fc.seed_cutoff : fc.next_cutoff;
+  const int n_cand = max(min(sh.n_links, c.lnk_cap - fc.link_base), 0);
   fc.hmask = FrameLevel2Mask(sh.n_links, d.hash_cap);
+  fc.presel = false; fc.presel_bound = INFINITY;
+  // ---- pre-selection (see InsertEmitted): pick the bound from a histogram of the candidates' costs
+  const int ps_target = d.cfg.max_active + max(d.cfg.max_active / 4, 16);          // candidates wanted under the bound
+  if (may_preselect && d.preselect != 0 && d.cfg.max_active < (1 << 28) && d.cfg.max_active >= d.cfg.min_active && n_cand >= ps_target + ps_target / 2) {
+    const float lo = fc.next_cutoff - fc.adaptive_beam;         // (about) the best candidate's cost
+    const float width = cutoff - lo;
+    const float scale = static_cast<float>(SH_HIST) / width;
+    constexpr int PER = SH_HIST / NT;
+    if (width > 0.0f && scale < 3.0e38f) {      // uniform
+      for (int i = tid; i < SH_HIST; i += NT) sh.hist[i] = 0;
+      if (tid == 0) { sh.sel_bin = -1; sh.sel_below = 0; }
+      LdsBarrier();
+      const uint4 *cand = CandBase(c, fc.link_base);
+      for (int i0 = tid; i0 < n_cand; i0 += INSB * NT) {
+        float tot[INSB];
+#pragma unroll
+        for (int k = 0; k < INSB; k++) tot[k] = __uint_as_float(cand[min(i0 + k * NT, n_cand - 1)].z);
+#pragma unroll
+        for (int k = 0; k < INSB; k++)
+          if (i0 + k * NT < n_cand && tot[k] <= cutoff) {
+            const float b = (tot[k] - lo) * scale;
+            atomicAdd(&sh.hist[b < 0.0f ? 0 : min(static_cast<int>(b), SH_HIST - 1)], 1u);
+          }
+      }
+      LdsBarrier();
+      // the first bucket under whose upper edge ps_target candidates lie: SH_HIST / NT buckets per thread, workgroup scan
+      int h[PER], mine = 0;
+#pragma unroll
+      for (int q = 0; q < PER; q++) { h[q] = static_cast<int>(sh.hist[PER * tid + q]); mine += h[q]; }
+      const int incl = WaveInclScanI(mine);
+      if ((tid & 63) == 63) sh.redi[tid >> 6] = incl;        // (behind two barriers since anybody read redi)
+      LdsBarrier();
+      int wbase = 0, total = 0;
+      for (int q = 0; q < NWAVES; q++) { const int v = sh.redi[q]; if (q < (tid >> 6)) wbase += v; total += v; }
+      const int excl = wbase + incl - mine;
+      if (ps_target - 1 >= excl && ps_target - 1 < excl + mine) {
+        int cum = excl, b = PER * tid;
+#pragma unroll
+        for (int q = 0; q < PER; q++) { if (cum + h[q] > ps_target - 1) break; cum += h[q]; b++; }
+        sh.sel_bin = b; sh.sel_below = cum + static_cast<int>(sh.hist[b]);     // candidates up to and including bucket b
+      }
+      LdsBarrier();
+      const int bin = sh.sel_bin, under = sh.sel_below;
+      LdsBarrier();                             // (sel_bin / redi may be rewritten by the next reduction)
+      // worth it only when the bound leaves a good part of the candidates out
+      if (bin >= 0 && bin < SH_HIST - 1 && 2 * under <= total + under / 2) {
+        fc.presel = true;
+        fc.presel_bound = lo + static_cast<float>(bin + 1) / scale;
+        if (!(fc.presel_bound < cutoff)) fc.presel = false;
+      }
+    }
+  }
+  // a pre-selected frame inserts ~1.3 max_active tokens whatever the last frame held: the whole table region then
+  if (fc.presel && !fc.big && L.cap_big > L.cap_small && ps_target > d.big_frame_tokens) fc.big = true;
   Tbl tbl = FrameTable(L, fc.big, fc.hmask);
   tbl.q_on = true; tbl.q_lds = reinterpret_cast<u32 *>(L.cost_cache); tbl.q_cap = fc.big ? 0 : (3 * BIGCAP) / 2;    // = PhaseCommit's wl0
   if (fc.big) {   // the upper half of the region was the expansion's queue: make it table
-    for (int sl = L.cap_small + Tid(); sl < L.cap_big; sl += NT) L.T[sl] = EMPTY64;
+    for (int sl = L.cap_small + tid; sl < L.cap_big; sl += NT) L.T[sl] = EMPTY64;
     LdsBarrier();
   }
-  fc.k_surv = InsertEmitted(d, c, &sh, tbl, fc.link_base, sh.n_links, fc.loose ? fc.seed_cutoff : fc.next_cutoff);
+  if (fc.presel) {
+    int made = 0, dummy = 0;
+    fc.k_surv = InsertEmitted<KAMD_PS_FIRST>(d, c, &sh, tbl, fc.link_base, sh.n_links, cutoff, fc.presel_bound, &made);
+    BlockSum2<true>(made, dummy, &sh);
+    if (made <= d.cfg.max_active) {     // uniform: the bound proves nothing -- insert the rest, the frame is an ordinary one
+      int unused = 0;
+      fc.k_surv += InsertEmitted<KAMD_PS_REST>(d, c, &sh, tbl, fc.link_base, sh.n_links, cutoff, fc.presel_bound, &unused);
+      fc.presel = false;
+    } else if (tid == 0) sh.presel_frames++;
+  } else {
+    int unused = 0;
+    fc.k_surv = InsertEmitted<KAMD_PS_ALL>(d, c, &sh, tbl, fc.link_base, sh.n_links, cutoff, INFINITY, &unused);
+  }
   Stamp(&sh, PH_FIXUP);
 }
 
@@ -1892,7 +2040,8 @@ __device__ __forceinline__ void PhaseCommit(int lane, Sh &sh, unsigned char *dyn
     cl.owners = reinterpret_cast<uint2 *>(L.lh); cl.owners_cap = (LHBINS + LHCAND > CHUNKCAP ? LHBINS + LHCAND : CHUNKCAP) / 2;
     cl.cost_cache = L.cost_cache; cl.cache_cap = 3 * BIGCAP;
   }
-  CommitFrame2(d, c, &sh, tbl, fc.next_cutoff, frame + 1, fc.link_base, fc.k_surv, cl, fc.loose, drop);
+  CommitFrame2(d, c, &sh, tbl, fc.next_cutoff, frame + 1, fc.link_base, fc.k_surv, cl, fc.loose, drop, fc.presel,
+               fc.loose ? fc.seed_cutoff : fc.next_cutoff, fc.presel_bound);
 }
 
 // AdvanceDecoding (lattice-faster-decoder.cc:593-632): the frame loop of one lane.  Every phase takes its own view of
@@ -1928,7 +2077,7 @@ __device__ __forceinline__ void AdvanceLane(int lane_in, Sh *shp, unsigned char 
     FrameCtl fc;
     PhaseCutoff(lane, sh, dyn_lds, fc);
     PhaseExpand(lane, sh, dyn_lds, frame, ll, fc);
-    PhaseInsert(lane, sh, dyn_lds, fc);
+    PhaseInsert(lane, sh, dyn_lds, fc, kDropDead && it + 1 < task.n_frames);
     // nobody reads this frame's row any more.  (Issued here and not before the inserts above: those wait for L2 hits,
     // and loads return in order -- behind a cold 24 KB read they took 2.5 us longer; the closure's first loads are
     // cold graph reads themselves.)
@@ -2793,7 +2942,7 @@ KAMD_SEARCH_KERNEL void DecodeQueueKernel(DecDev d_unused, QueueDev q_unused) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       kamd_queue_result *r = q.results + utt;
       r->error = err | ((bytes && !fits) ? ERR_POOL : 0);
-      r->lane = lane; r->n_frames = F; r->n_tok = fits ? nt : 0; r->n_link = fits ? nl : 0; r->n_last = fits ? n_last : 0;
+      r->lane = lane; r->n_frames = F; r->n_tok = fits ? nt : 0; r->n_link = fits ? nl : 0; r->n_last = fits ? n_last : 0; r->n_preselected = S->presel_frames;
       r->final_relative_cost = S->final_relative_cost; r->final_best_cost = S->final_best_cost;
       r->blob_off = static_cast<long long>(off); r->blob_bytes = fits ? static_cast<long long>(bytes) : 0;
       for (int i = 0; i < 8; i++) r->counters[i] = S->counters[i];
@@ -3114,7 +3263,8 @@ kamd_graph *kamd_graph_create(int32_t num_states, int32_t start, const int64_t *
     }
   }
   off[num_states].x = static_cast<unsigned>(ea.size()); off[num_states].y = static_cast<unsigned>(na.size());
-  if (ea.size() > 0xFFFFFFF0u || na.size() > 0xFFFFFFF0u) { kamd::SetError(KAMD_ERR_ARG, "graph too large"); return NULL; }
+  // (emitting arc indices travel in 31 bits: bit 31 of a candidate's arc word is the target's epsilon flag)
+  if (ea.size() > 0x7FFFFFF0u || na.size() > 0xFFFFFFF0u) { kamd::SetError(KAMD_ERR_ARG, "graph too large"); return NULL; }
   // epsilon cycles are illegal (lattice-faster-decoder.cc:997-998): Kahn on the eps graph
   {
     std::vector<int> indeg(num_states, 0);
@@ -3267,6 +3417,8 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   d.big_frame_tokens = BIG_FRAME_TOKENS;
   if (const char *e = getenv("KAMD_BIG_FRAME_TOKENS")) d.big_frame_tokens = atoi(e);      // (experiments: tools/ab_bench.py)
   if (const char *e = getenv("KAMD_GOOD_FIRST")) d.good_first = static_cast<float>(atof(e));
+  d.preselect = 1;
+  if (const char *e = getenv("KAMD_PRESELECT")) d.preselect = atoi(e);
   d.num_pdfs_lds = 0;
   const size_t lds_budget = 160 * 1024 / LANES_PER_CU - sizeof(kamd::Sh) - 1024;
   const size_t fixed = kamd::AdvanceLdsBytes(0, LDS_TABLE_CAP);
@@ -3384,6 +3536,11 @@ int kamd_decoder_set_level1_table(kamd_decoder *h, int32_t words) {
   Decoder *D = reinterpret_cast<Decoder *>(h);
   D->dev.lds_table_cap = words;       // (the LDS reservation stays what it was: the region is only used less)
   D->dev.big_frame_tokens = words >= LDS_TABLE_CAP ? BIG_FRAME_TOKENS : (words / 2) * 3 / 4;      // three quarters of the half-region table
+  return KAMD_OK;
+}
+
+int kamd_decoder_set_token_preselection(kamd_decoder *h, int on) {
+  reinterpret_cast<Decoder *>(h)->dev.preselect = on != 0;
   return KAMD_OK;
 }
 

@@ -574,6 +574,10 @@ class BatchDecoder:
     def SetSearchMode(self, mode):
         check(lib().kamd_decoder_set_search_mode(self._dec, int(mode)))
 
+    def SetTokenPreselection(self, on):
+        """kamd_decoder_set_token_preselection: off = every token the reference creates is created and counted."""
+        check(lib().kamd_decoder_set_token_preselection(self._dec, int(bool(on))))
+
     def SetLevel1Table(self, words):
         check(lib().kamd_decoder_set_level1_table(self._dec, int(words)))
 

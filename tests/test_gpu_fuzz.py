@@ -6,6 +6,7 @@ import pytest
 from kaldi_amd import abi, decoder, synth
 from oracle import orc
 from tests.test_gpu_decoder import assert_same, sizes
+from tests.util import assert_work_counters
 
 pytestmark = pytest.mark.gpu
 
@@ -111,7 +112,7 @@ def test_random_cases_through_the_work_queue(block):
                 continue
             from tests.util import lattice_diff, lattices_equal
             assert lattices_equal(lats[u], lo), what + ": " + lattice_diff(lats[u], lo)
-            np.testing.assert_array_equal(np.asarray(recs[u].counters[:7]), o.counters()[:7], err_msg=what)
+            assert_work_counters(recs[u], o.counters(), err_msg=what)
             assert recs[u].final_relative_cost == o.FinalRelativeCost(), what
 
 

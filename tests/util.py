@@ -35,3 +35,15 @@ def read_htk(path):
 
 
 from kaldi_amd.decoder import lattice_diff, lattices_equal  # noqa: E402,F401  (the package holds them: bench.py uses them too)
+
+
+def assert_work_counters(record, oracle_counters, err_msg=""):
+    """The seven work counters of a work-queue utterance against the oracle's.  All seven, bit for bit -- except that an
+    utterance with pre-selected frames (kamd_decoder_set_token_preselection; record.n_preselected > 0) counts in N_tok
+    (counters[5]) the tokens the lane inserted: never more than the oracle created, and every other counter unchanged."""
+    got, want = np.asarray(record.counters[:7]), np.asarray(oracle_counters[:7])
+    if getattr(record, "n_preselected", 0) > 0:
+        np.testing.assert_array_equal(np.delete(got, 5), np.delete(want, 5), err_msg=err_msg)
+        assert 0 < got[5] <= want[5], (err_msg, got[5], want[5])
+    else:
+        np.testing.assert_array_equal(got, want, err_msg=err_msg)
