@@ -85,7 +85,7 @@ def test_configs2_nnet_rows_match_the_cpu_port(world):
 def _check_against_oracle(g, cfg, bd, ll_of, utts, mode, what):
     """Raw lattice, 1-best and the work counters of the sampled utterances against the oracle in the device's search mode, bit
     for bit; the order-faithful mode 0 (the reference restated) must give the same words."""
-    seen = {"max_tok": 0, "level2": 0}
+    seen = {"max_tok": 0, "level2": 0, "preselected": 0}
     for u in utts:
         ll = ll_of(u)
         o = orc.Decoder(g, cfg, mode)
@@ -98,6 +98,7 @@ def _check_against_oracle(g, cfg, bd, ll_of, utts, mode, what):
         assert_work_counters(out["record"], o.counters())
         seen["max_tok"] = max(seen["max_tok"], int(o.trace()[0].max()))
         seen["level2"] += int(out["record"].counters[7])
+        seen["preselected"] += int(out["record"].n_preselected)
         f = orc.Decoder(g, cfg, 0)                       # the reference's own order-dependent search
         f.Decode(ll)
         bf = f.GetRawLattice().best_path()
@@ -124,6 +125,7 @@ def test_configs2_bench_loads_with_a_long_utterance(world, ll_std):
     assert st.n_failed == 0
     seen = _check_against_oracle(g, cfg, bd, bd.loglikes, (0, 2), 2, "spread %.1f" % ll_std)
     assert seen["max_tok"] > 16384 and seen["level2"] > 0          # beyond the whole level-1 region: level-2 entries were decoded
+    assert seen["preselected"] > 0                                 # ... and frames whose inserts were pre-selected (InsertEmitted<KAMD_PS_FIRST>)
     assert all(seen["mode0_same_words"]), seen
 
 
@@ -153,7 +155,7 @@ def test_configs2_planted_transcripts_with_the_ivector_model(world):
     ro = pset["row_off"]
     ll_of = lambda u: bench.planted_rows(planted, ro[u], ro[u + 1] - ro[u], g.num_pdfs)      # noqa: E731
     seen = _check_against_oracle(g, cfg, bd, ll_of, (0, 1), 2, "planted")
-    assert seen["level2"] > 0
+    assert seen["level2"] > 0 and seen["preselected"] > 0
     words = bd.output(0)["words"].tolist()
     ref = list(pset["paths"][0][0])
     assert len(words) > 30 and bench._edit_distance(ref, words) <= 0.25 * len(ref)
