@@ -639,7 +639,14 @@ def main():
                  "flops_per_step": flops_alg, "mflop_per_output_frame": 2e-6 * model.macs_per_output_frame(),
                  "executed_flops_per_step": st.nnet_flops, "executed_achieved": st.nnet_flops / (nnet_ms * 1e-3) / 1e12,
                  "stage_ms": nnet_ms, "passes": int(st.nnet_passes)}
-    dominant_is_decoder = dec_ms >= nnet_ms
+    nnet_roof["executed_frac"] = nnet_roof["executed_achieved"] / FP32_MFMA_PEAK_TFLOPS
+    nnet_roof["reading"] = ("`frac` prices SURVEY 8(d)'s flops per output frame (whole utterances, no chunk-edge recompute); `executed_frac` the "
+                            "flops the layers really multiply -- with online i-vectors the model is evaluated chunk by chunk like DecodableNnetSimple "
+                            "and every chunk recomputes its context rows with its own i-vector, as the reference does")
+    # The dominant KERNEL: the search is one launch of one kernel; the acoustic model is hundreds of launches of several GEMM kernels, the
+    # largest of which (TdnnGemmPersistKernel, the N = 160 layers) takes 0.46 of the stage (profiles/r0*_kernel_stats_bench_default.csv)
+    NNET_LARGEST_KERNEL_SHARE = 0.46
+    dominant_is_decoder = dec_ms >= NNET_LARGEST_KERNEL_SHARE * nnet_ms
     wav_bytes = 4.0 * sum(w.size for w in waves)
     load_name = "token-matched" if (args.workload == "librispeech" and args.graph == "tglarge") else "default"
     if faithful:
