@@ -408,196 +408,6 @@ __global__ __launch_bounds__(256) void StepStatsKernel(IvDev d, IvBatch b) {
   }
 }
 
-// The same statistics for SB consecutive steps of one utterance per workgroup (round 5).  StepStatsKernel reads U_g (40 KB)
-// and Sigma_inv_M_g (32 KB) once per Gaussian of a step -- 26 Gaussians of the bench's 10-frame steps, 1.9 MB per step,
-// 330 GB per test set out of the Infinity Cache: that is what its 42 ms are.  Neighbouring steps select mostly the same
-// Gaussians, so a workgroup that owns SB steps reads the UNION of their Gaussians once and keeps SB accumulators per
-// output element (a Gaussian a step did not select enters with weight 0 / a zero vector: exact).  Per step the terms are
-// summed in the union's order instead of the step's own: fp64, differences of the last bit.
-template <int SB>
-static inline size_t StepStatsBlockLdsBytes(const IvDev &d) {
-  const size_t cap = static_cast<size_t>(d.period) * d.ng;
-  const size_t doubles = static_cast<size_t>(d.period) * d.D + cap + SB * (cap + cap * d.D) + SB * SB * cap + d.D;
-  const size_t ints = 2 * cap + SB * cap + SB * cap + SB * SB * cap;
-  return doubles * sizeof(double) + ints * sizeof(int);
-}
-template <int SB>
-__global__ __launch_bounds__(256) void StepStatsBlockKernel(IvDev d, IvBatch b) {
-  extern __shared__ double ss[];
-  const int u = blockIdx.y, i0 = blockIdx.x * SB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const IvUtt ut = b.utt[u];
-  if (i0 >= ut.n_steps) return;
-  const int nb = min(SB, ut.n_steps - i0);
-  const int64_t r0 = ut.ws_row;
-  const int I = d.I, Q = d.Q, D = d.D, cap = d.period * d.ng, ucap = SB * cap;
-  // doubles: xf[period][D] | pw[cap] | uw[SB][cap] | yk[SB][cap][D] | W[SB][ucap] | zero[D];  ints: pg[cap] | pt[cap] | ug[SB][cap] | UG[ucap] | YO[SB][ucap]
-  double *xf = ss, *pw = xf + d.period * D, *uw = pw + cap, *yk = uw + SB * cap, *W = yk + static_cast<size_t>(SB) * cap * D, *zero = W + SB * ucap;
-  int *pg = reinterpret_cast<int *>(zero + D), *pt = pg + cap, *ug = pt + cap, *UG = ug + SB * cap, *YO = UG + ucap;
-  __shared__ int s_wcnt[4], s_nu[SB + 1];
-  __shared__ double s_half[SB][IV_MAX_DIM];
-  for (int a = tid; a < D; a += 256) zero[a] = 0.0;
-  for (int s2 = 0; s2 < nb; s2++) {
-    const int i = i0 + s2;
-    // the step's frames: a contiguous range, or (mode 2) `period` entries of the weighted list
-    int f0 = 0, nf;
-    const int *wl = NULL;
-    if (ut.mode == 0) { f0 = i == 0 ? 0 : (i - 1) * d.period + 1; nf = i * d.period - f0 + 1; }
-    else if (ut.mode == 1) { f0 = ut.stats_first + i * d.period; nf = min(ut.stats_end, f0 + d.period) - f0; }
-    else { wl = b.wl_frame + ut.wl_off + i * d.period; nf = max(0, min(ut.wl_n - i * d.period, d.period)); }
-    __syncthreads();                 // the previous step's scratch has been read
-    for (int k = tid; k < nf * D; k += 256) {
-      const int t = k / D, c = k - t * D;
-      xf[k] = static_cast<double>(b.raw_lda[(r0 + (wl ? wl[t] : f0 + t)) * D + c]);
-    }
-    // compact the step's (gaussian, weight, frame) triples, in frame order
-    int n_pairs = 0;
-    for (int base = 0; base < nf * d.ng; base += 256) {
-      const int e = base + tid;
-      int g = -1; float wv = 0.f;
-      if (e < nf * d.ng) {
-        const int t = e / d.ng, sl = e - t * d.ng;
-        const int64_t pr = (r0 + (wl ? wl[t] : f0 + t)) * d.ng + sl;
-        g = b.post_g[pr]; wv = b.post_w[pr];
-      }
-      const unsigned long long m = __ballot(g >= 0);
-      if (lane == 0) s_wcnt[wave] = __popcll(m);
-      __syncthreads();
-      int off = n_pairs;
-      for (int w2 = 0; w2 < wave; w2++) off += s_wcnt[w2];
-      if (g >= 0) {
-        const int pos = off + __popcll(m & ((1ull << lane) - 1));
-        pg[pos] = g; pw[pos] = static_cast<double>(wv); pt[pos] = e / d.ng;
-      }
-      n_pairs += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-      __syncthreads();
-    }
-    // the pairs of one Gaussian merged: ug / uw / yk of this step
-    int *ugs = ug + s2 * cap;
-    double *uws = uw + s2 * cap, *yks = yk + static_cast<size_t>(s2) * cap * D;
-    int n_u = 0;
-    for (int base = 0; base < n_pairs; base += 256) {
-      const int e = base + tid;
-      bool lead = false;
-      double wsum = 0;
-      if (e < n_pairs) {
-        const int g = pg[e];
-        lead = true;
-        for (int e2 = 0; e2 < e; e2++) if (pg[e2] == g) { lead = false; break; }
-        if (lead) for (int e2 = e; e2 < n_pairs; e2++) if (pg[e2] == g) wsum += pw[e2];
-      }
-      const unsigned long long m = __ballot(lead);
-      if (lane == 0) s_wcnt[wave] = __popcll(m);
-      __syncthreads();
-      int off = n_u;
-      for (int w2 = 0; w2 < wave; w2++) off += s_wcnt[w2];
-      if (lead) {
-        const int pos = off + __popcll(m & ((1ull << lane) - 1));
-        ugs[pos] = pg[e]; uws[pos] = wsum;
-      }
-      n_u += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-      __syncthreads();
-    }
-    for (int k = tid; k < n_u * D; k += 256) {
-      const int u2 = k / D, a = k - u2 * D, g = ugs[u2];
-      double y = 0;
-      for (int e = 0; e < n_pairs; e++) if (pg[e] == g) y += pw[e] * xf[pt[e] * D + a];
-      yks[k] = y;
-    }
-    if (tid == 0) {
-      s_nu[s2] = n_u;
-      double tw = 0;
-      for (int e = 0; e < n_pairs; e++) tw += pw[e];
-      b.dtotw[ut.inc_row + i] = tw;
-    }
-  }
-  __syncthreads();
-  // ---- the union of the steps' Gaussians, in first-appearance order; W[s][k]: step s's weight of union Gaussian k (0: not
-  // selected), YO[s][k]: where its y vector starts (the zero vector when not selected)
-  int off_s[SB + 1];
-  off_s[0] = 0;
-#pragma unroll
-  for (int s2 = 0; s2 < SB; s2++) off_s[s2 + 1] = off_s[s2] + (s2 < nb ? s_nu[s2] : 0);
-  const int n_tot = off_s[SB];
-  auto entry = [&](int e, int *s_out) -> int {       // e-th entry of the concatenated lists: its Gaussian, its step
-    int s2 = 0;
-#pragma unroll
-    for (int q = 1; q < SB; q++) if (e >= off_s[q]) s2 = q;
-    *s_out = s2;
-    return ug[s2 * cap + (e - off_s[s2])];
-  };
-  int n_un = 0;
-  for (int base = 0; base < n_tot; base += 256) {
-    const int e = base + tid;
-    bool lead = false; int g = -1;
-    if (e < n_tot) {
-      int sx;
-      g = entry(e, &sx);
-      lead = true;
-      for (int e2 = 0; e2 < e; e2++) { int sy; if (entry(e2, &sy) == g) { lead = false; break; } }
-    }
-    const unsigned long long m = __ballot(lead);
-    if (lane == 0) s_wcnt[wave] = __popcll(m);
-    __syncthreads();
-    int off = n_un;
-    for (int w2 = 0; w2 < wave; w2++) off += s_wcnt[w2];
-    if (lead) UG[off + __popcll(m & ((1ull << lane) - 1))] = g;
-    n_un += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-    __syncthreads();
-  }
-  const int zero_off = static_cast<int>(zero - yk);
-  for (int x = tid; x < SB * n_un; x += 256) {
-    const int s2 = x / n_un, k = x - s2 * n_un, g = UG[k];
-    double w = 0.0; int yo = zero_off;
-    if (s2 < nb)
-      for (int k2 = 0; k2 < s_nu[s2]; k2++)
-        if (ug[s2 * cap + k2] == g) { w = uw[s2 * cap + k2]; yo = (s2 * cap + k2) * D; break; }
-    W[s2 * ucap + k] = w; YO[s2 * ucap + k] = yo;
-  }
-  __syncthreads();
-  const int64_t row0 = ut.inc_row + i0;
-  for (int q = tid; q < Q; q += 256) {
-    double acc[SB];
-#pragma unroll
-    for (int s2 = 0; s2 < SB; s2++) acc[s2] = 0.0;
-#pragma unroll 4
-    for (int k = 0; k < n_un; k++) {
-      const double uv = d.U[static_cast<size_t>(UG[k]) * Q + q];
-#pragma unroll
-      for (int s2 = 0; s2 < SB; s2++) acc[s2] += W[s2 * ucap + k] * uv;
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < SB; s2++) if (s2 < nb) b.dquad[(row0 + s2) * Q + q] = acc[s2];
-  }
-  {
-    const int j = tid & 127, half = tid >> 7;
-    double acc[SB];
-#pragma unroll
-    for (int s2 = 0; s2 < SB; s2++) acc[s2] = 0.0;
-    if (j < I)
-      for (int k = 0; k < n_un; k++) {
-        const double *SM = d.SM + static_cast<size_t>(UG[k]) * D * I;
-        const double *yr[SB];
-#pragma unroll
-        for (int s2 = 0; s2 < SB; s2++) yr[s2] = yk + YO[s2 * ucap + k];
-#pragma unroll 4
-        for (int a = half; a < D; a += 2) {
-          const double smv = SM[static_cast<size_t>(a) * I + j];
-#pragma unroll
-          for (int s2 = 0; s2 < SB; s2++) acc[s2] += smv * yr[s2][a];
-        }
-      }
-    if (half == 1 && j < I) {
-#pragma unroll
-      for (int s2 = 0; s2 < SB; s2++) s_half[s2][j] = acc[s2];
-    }
-    __syncthreads();
-    if (half == 0 && j < I) {
-#pragma unroll
-      for (int s2 = 0; s2 < SB; s2++) if (s2 < nb) b.dlin[(row0 + s2) * I + j] = acc[s2] + s_half[s2][j];
-    }
-  }
-}
-
 // ---------------------------------------------------------------- running statistics + CG
 // wave-wide sum of a double with DPP row shifts / broadcasts (GFX9 row_shr, row_bcast15 / 31): six
 // dependent steps of two 32-bit moves and one add, against twelve LDS-crossbar permutes for
@@ -950,14 +760,6 @@ kamd_ivector_extractor *kamd_ivector_extractor_create(const kamd_ivector_desc *d
       return NULL;
     }
     step_lds_max = std::max(step_lds_max, static_cast<int>(lds_step));
-    static int step2_lds_max = 0, step4_lds_max = 0;
-    step2_lds_max = std::max(step2_lds_max, static_cast<int>(kamd::StepStatsBlockLdsBytes<2>(v)));
-    step4_lds_max = std::max(step4_lds_max, static_cast<int>(kamd::StepStatsBlockLdsBytes<4>(v)));
-    // (the blocked variants are used when their LDS fits: RunBatch)
-    if (step2_lds_max <= 150 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::StepStatsBlockKernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, step2_lds_max);
-    if (step4_lds_max <= 150 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::StepStatsBlockKernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, step4_lds_max);
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kamd::StepStatsKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             step_lds_max) != hipSuccess) {
       kamd::SetError(KAMD_ERR_HIP, "i-vector extractor: cannot reserve LDS for the statistics step");
@@ -1064,18 +866,8 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
     hipLaunchKernelGGL(kamd::PostKernel, dim3(kamd::CeilDiv(max_post, 4), n), dim3(256), lds_post, st, v, b);
   }
   if (max_steps > 0) {
-    // SB consecutive steps of an utterance per workgroup (they share most of their Gaussians: the extractor's matrices are
-    // read once per block); KAMD_IV_STEP_BLOCK = 1 / 2 / 4 for A/B, default 4 when its LDS fits
-    const char *sb_env = getenv("KAMD_IV_STEP_BLOCK");        // (read per call: the tests switch it)
-    int sb = sb_env ? atoi(sb_env) : 4;
-    if (sb >= 4 && kamd::StepStatsBlockLdsBytes<4>(v) > 150 * 1024) sb = 2;
-    if (sb >= 2 && sb < 4 && kamd::StepStatsBlockLdsBytes<2>(v) > 150 * 1024) sb = 1;
-    if (sb >= 4)
-      hipLaunchKernelGGL(kamd::StepStatsBlockKernel<4>, dim3(kamd::CeilDiv(max_steps, 4), n), dim3(256), kamd::StepStatsBlockLdsBytes<4>(v), st, v, b);
-    else if (sb >= 2)
-      hipLaunchKernelGGL(kamd::StepStatsBlockKernel<2>, dim3(kamd::CeilDiv(max_steps, 2), n), dim3(256), kamd::StepStatsBlockLdsBytes<2>(v), st, v, b);
-    else
-      hipLaunchKernelGGL(kamd::StepStatsKernel, dim3(max_steps, n), dim3(256), kamd::StepStatsLdsBytes(v), st, v, b);
+    const size_t lds_step = kamd::StepStatsLdsBytes(v);
+    hipLaunchKernelGGL(kamd::StepStatsKernel, dim3(max_steps, n), dim3(256), lds_step, st, v, b);
     const size_t lds_solve = (static_cast<size_t>(v.Q) + 6 * kamd::IV_MAX_DIM) * sizeof(double);
     hipLaunchKernelGGL(kamd::SolveKernel, dim3(n), dim3(256), lds_solve, st, v, b);
   }

@@ -68,29 +68,6 @@ def test_recipe_size_extractor_on_mfcc_features():
     assert np.abs(np.diff(solo[2], axis=0)).max() > 1e-3
 
 
-@pytest.mark.parametrize("block", [1, 2, 4])
-def test_step_statistics_of_blocks_of_steps(block, monkeypatch):
-    """StepStatsBlockKernel<SB>: SB consecutive steps of an utterance per workgroup, the union of their Gaussians read once
-    (KAMD_IV_STEP_BLOCK; default 4).  Every block size against the oracle, on utterances whose step counts leave every
-    remainder, and against the one-step-per-workgroup kernel to fp64 rounding."""
-    op = abi.mfcc_opts_hires()
-    feats = [feat.Mfcc(op).ComputeFeatures(synth.make_wave(d, seed=70 + i)) for i, d in enumerate((0.15, 0.9, 1.31, 2.02, 3.0))]
-    allf = np.concatenate(feats)
-    info = ivector.make_synthetic(seed=6, feat_mean=allf.mean(0), feat_std=allf.std(0), max_count=100.0)
-    ie = ivector.IvectorExtractor(info)
-    monkeypatch.setenv("KAMD_IV_STEP_BLOCK", "1")
-    ref = [ie.extract_online(f) for f in feats]
-    monkeypatch.setenv("KAMD_IV_STEP_BLOCK", str(block))
-    for f, r in zip(feats, ref):
-        got = check(info, ie, f)
-        np.testing.assert_allclose(got, r, rtol=0, atol=1e-6 * max(1.0, np.abs(r).max()))
-    small = ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=70, ivector_dim=10, seed=3, splice_left=2, splice_right=1, ivector_period=3)
-    ies = ivector.IvectorExtractor(small)
-    rng = np.random.default_rng(2)
-    for T in (1, 3, 4, 10, 13, 25, 100):
-        check(small, ies, (rng.standard_normal((T, 8)) * 1.5 + 0.3).astype(np.float32))
-
-
 def test_pipeline_with_the_extractor_equals_precomputed_online_ivectors():
     """features -> i-vectors -> chunked nnet -> search in one run(), against --online-ivectors with the
     matrices the extractor returns for the same features, and against the oracle's matrices."""
