@@ -954,10 +954,10 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
     std::vector<int> again;
     for (int k = 0; k < n; k++) {
       const kamd::UttOut &o = b->out[b->kept[k]];
-      // token arena (2), link arena (4), lattice pool (64), the internal checks (32; counted above); never an utterance of more
+      // a frame's level-2 share (1: the wide launch addresses the whole table), token arena (2), link arena (4), lattice pool (64), the internal checks (32; counted above); never an utterance of more
       // frames than the decoder holds (8), nor one longer than the main decoder's frame arrays (it was searched on the
       // long-utterance decoder: its failure stays its own)
-      if (o.status == KAMD_ERR_CAPACITY && (o.rec.error & (2 | 4 | 32 | 64)) != 0 && (o.rec.error & 8) == 0 && b->task_ll[k] &&
+      if (o.status == KAMD_ERR_CAPACITY && (o.rec.error & (1 | 2 | 4 | 32 | 64)) != 0 && (o.rec.error & 8) == 0 && b->task_ll[k] &&
           b->out_off[k + 1] - b->out_off[k] <= wide_max_frames)
         again.push_back(k);
     }

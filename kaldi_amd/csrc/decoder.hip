@@ -131,6 +131,7 @@ struct DecDev {
   int big_frame_tokens; // a frame after one that created more tokens than this inserts into the whole table region
   float good_first;     // > 0 (experiment, KAMD_GOOD_FIRST): tokens within this of the best are expanded in a pass of their own, first
   int preselect;        // work-queue lanes: frames with several times max_active candidates insert only those that can matter (InsertEmitted)
+  int full_level2;      // every frame addresses the whole level-2 table (no per-frame mask): the second-chance launch, whose first search may have filled a frame's share
   kamd_decoder_config cfg;
   int loose;            // search mode 2: arcs are kept against the seed cutoff (kamd_decoder_set_search_mode)
   int hash_cap, hash_mask, max_frames;
@@ -1949,7 +1950,7 @@ __device__ __forceinline__ void PhaseInsert(int lane, Sh &sh, unsigned char *dyn
   const int tid = Tid();
   const float cutoff = fc.loose ? fc.seed_cutoff : fc.next_cutoff;
   const int n_cand = max(min(sh.n_links, c.lnk_cap - fc.link_base), 0);
-  fc.hmask = FrameLevel2Mask(sh.n_links, d.hash_cap);
+  fc.hmask = d.full_level2 ? d.hash_mask : FrameLevel2Mask(sh.n_links, d.hash_cap);
   fc.presel = false; fc.presel_bound = INFINITY;
   // ---- pre-selection (see InsertEmitted): pick the bound from a histogram of the candidates' costs
   const int ps_target = d.cfg.max_active + max(d.cfg.max_active / 4, 16);          // candidates wanted under the bound
@@ -4510,7 +4511,11 @@ static int QueueLaunch(kamd_decoder *h, const kamd_queue_task *tasks, int n, int
   q.done_ring = static_cast<int *>(dp);
   const size_t lds = std::max<size_t>(kamd::AdvanceLdsBytes(D->dev.num_pdfs_lds, LDS_TABLE_CAP), FIN_LDS_BYTES);
   KAMD_HIP(hipEventRecord(D->qev[0], st));
-  hipLaunchKernelGGL(kamd::DecodeQueueKernel, dim3(R), dim3(NT), lds, st, D->dev, q);
+  kamd::DecDev dev = D->dev;
+  // (a frame's level-2 share is sized from its candidates; an epsilon closure far larger than them can fill it -- flag 1 --
+  // and the second chance must not meet the same wall)
+  dev.full_level2 = wide ? 1 : 0;
+  hipLaunchKernelGGL(kamd::DecodeQueueKernel, dim3(R), dim3(NT), lds, st, dev, q);
   KAMD_HIP(hipGetLastError());
   KAMD_HIP(hipEventRecord(D->qev[1], st));
   D->q_n = n; D->q_next = 0; D->q_lanes = R; D->q_stream = st; D->last_stream = st; D->cached_lane = -1;
