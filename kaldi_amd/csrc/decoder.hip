@@ -131,6 +131,9 @@ struct DecDev {
   int big_frame_tokens; // a frame after one that created more tokens than this inserts into the whole table region
   float good_first;     // > 0 (experiment, KAMD_GOOD_FIRST): tokens within this of the best are expanded in a pass of their own, first
   int preselect;        // work-queue lanes: frames with several times max_active candidates insert only those that can matter (InsertEmitted)
+  int ps_margin_pct;    // pre-selection: a lane's first margin, per cent of max_active (default 8; KAMD_PS_MARGIN_PCT); adapted per frame (Sh::ps_margin_pm)
+  int ps_adapt;         // the margin follows the frames (default); 0: fixed at ps_margin_pct (KAMD_PS_ADAPT=0, experiments)
+  int ps_worth_pct;     // pre-selection engages when the candidates within the cutoff are at least this per cent of those under the bound (default 150; KAMD_PS_WORTH_PCT)
   int full_level2;      // every frame addresses the whole level-2 table (no per-frame mask): the second-chance launch, whose first search may have filled a frame's share
   kamd_decoder_config cfg;
   int loose;            // search mode 2: arcs are kept against the seed cutoff (kamd_decoder_set_search_mode)
@@ -230,6 +233,8 @@ struct Sh {  // workgroup-shared state
   int scan_total;
   int big_total;
   int presel_frames;     // frames of this call whose inserts were pre-selected (diagnostic)
+  int ps_margin_pm;      // pre-selection: candidates wanted under the bound beyond max_active, per mille of max_active; adapted frame by
+                         // frame to the share of candidates that turned out to be second arcs into a state (PhaseInsert)
   // per-lane running state mirrored in LDS (the global copies are written for the host and
   // for the next launch; reading them back every frame would be an L2 round trip each)
   int cur_tb, cur_n;     // newest token list: first token, count
@@ -663,20 +668,23 @@ static_assert(EXPT * NT == BIGCAP, "one outer expansion iteration must fit the f
 // tokens, most of them in the HBM level of the table (a CAS, a slot-list word, the dense copy, the slot -> token word, the
 // clearing store: five random sectors each).  Instead: a histogram of the candidates' costs picks a bound B that about
 // 1.25 max_active candidates lie under; the sweep inserts the candidates with tot <= B and those whose target has epsilon
-// arcs (KAMD_PS_FIRST) and counts the tokens it CREATES under B.  If that count exceeds max_active, the next frame's
+// arcs and counts the tokens it CREATES under B.  If that count exceeds max_active, the next frame's
 // cutoff -- the max_active-th smallest token cost -- is <= B whatever the other candidates are, every token it can expand
 // is in the table with its final cost, and the others would only have been counted: they are not inserted at all, and
 // after the epsilon closure FindSkipped turns the left-out candidates whose target IS in the table into links (a link
 // into a live token from a worse arc is a lattice arc like any other).  If the count falls short (many candidates of few
-// states), KAMD_PS_REST inserts what was left out and the frame is what it always was.  Lattices, links, cutoffs and
+// states) the bound is raised and the next slab of candidates inserted, twice at most; then everything is (PhaseInsert).  Lattices, links, cutoffs and
 // every work counter but one are unchanged: N_tok (counters[5], trace_ntok) counts the tokens the lane inserted.
-enum { KAMD_PS_ALL = 0, KAMD_PS_FIRST = 1, KAMD_PS_REST = 2 };
-template <int MODE>
+// A sweep inserts one SLAB of the candidates: those with slab_lo < tot <= slab_hi; the candidates whose target has
+// epsilon arcs belong to the first slab (slab_lo = -inf) whatever they cost.  (-inf, +inf] is every candidate (a frame
+// without pre-selection), (B, +inf] what a pre-selection that proved nothing left out.  *created_in_slab: tokens this
+// sweep created with a cost <= slab_hi.
 __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const Tbl &tbl, int link_begin,
-                                    int n_links, float cutoff, float ps_bound, int *created_under_bound) {
+                                    int n_links, float cutoff, float slab_lo, float slab_hi, int *created_in_slab) {
   int k_surv = 0, made = 0;
   const int le = min(link_begin + n_links, c.lnk_cap);
   const int surv_begin = le;
+  const bool first_slab = slab_lo == -INFINITY;
   // INSB links per thread per trip: the records, then the arcs, are loaded for the
   // whole batch before the first insert (two dependent round trips per batch, not per link)
   const uint4 *cand = CandBase(c, link_begin);
@@ -692,11 +700,9 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
     for (int k = 0; k < INSB; k++) {
       const int ci = Tid() + (g0 + k) * NT;
       const float tot = __uint_as_float(L[k].z);
+      const bool eps = (L[k].y & EPS_FLAG) != 0;
       // :798 with the frame's final cutoff: a candidate beyond it is simply not carried on
-      take[k] = ci < n_cand && tot <= cutoff;
-      const bool first = tot <= ps_bound || (L[k].y & EPS_FLAG) != 0;
-      if (MODE == KAMD_PS_FIRST) take[k] = take[k] && first;
-      if (MODE == KAMD_PS_REST) take[k] = take[k] && !first;
+      take[k] = ci < n_cand && tot <= cutoff && (first_slab ? (tot <= slab_hi || eps) : (tot > slab_lo && tot <= slab_hi && !eps));
       // the record of the arc ProcessArcs kept by index -- only for the candidates this sweep inserts (2.5 were recorded per
       // survivor at the matched load: the others all read arc 0, one cached line instead of a random 16-byte fetch each)
       arc[k] = d.g.e_arcs[take[k] ? (L[k].y & ~EPS_FLAG) : 0u];
@@ -708,7 +714,7 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
       bool improved, created = false;
       const int dst = TblInsert(d, c, sh, tbl, arc[k].nextstate, tot, &improved, &created);
       if (dst < 0) continue;                     // (table overflow: flagged)
-      if (MODE == KAMD_PS_FIRST && created && tot <= ps_bound) made++;
+      if (created && tot <= slab_hi) made++;
       k_surv++;
       const int so = surv_begin + WaveAlloc(&sh->n_surv);
       if (so >= c.lnk_cap) { atomicOr(&sh->err, ERR_LINK); continue; }
@@ -717,7 +723,7 @@ __device__ inline int InsertEmitted(const DecDev &d, const Ctx &c, Sh *sh, const
       c.links[so] = o;
     }
   }
-  if (MODE == KAMD_PS_FIRST) *created_under_bound = made;
+  *created_in_slab = made;
   return k_surv;
 }
 
@@ -783,7 +789,7 @@ __device__ inline int TblFind(const DecDev &d, const Ctx &c, const Tbl &t, int s
   return g < 0 ? g : g + t.lcap;
 }
 
-// The candidates a pre-selected insert sweep left out (InsertEmitted<KAMD_PS_FIRST>), after the epsilon closure: one whose
+// The candidates a pre-selected frame's insert sweeps left out (tot beyond the proven bound, no epsilon flag), after the epsilon closure: one whose
 // target state is in the table all the same -- created by a better arc or by the closure -- is a link into that token
 // (its cost cannot lower the token's: it is beyond the bound every inserted candidate of a non-epsilon state lies under,
 // or the token is beyond the next frame's cutoff either way and gets no record); the others would have created tokens
@@ -1582,7 +1588,7 @@ __device__ inline void InitSh(Sh *sh) {
   if (Tid() == 0) {
     sh->n_slots = 0; sh->n_slots1 = 0; sh->n_links = 0; sh->n_surv = 0; sh->n_final = 0; sh->wl_n[0] = 0; sh->wl_n[1] = 0; sh->err = 0;
     sh->bigcnt = 0; sh->hugecnt = 0; sh->n_new = 0; sh->best_key = EMPTY64; sh->c_lt = 0; sh->c_le = 0; sh->next_cutoff_u = FloatToOrdered(INFINITY);
-    sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0; sh->cur_n_all = 0; sh->cutoff_ready = 0; sh->cache_valid = 0; sh->presel_frames = 0;
+    sh->cur_tb = 0; sh->cur_n = 0; sh->lnk_used = 0; sh->round = 0; sh->cur_n_all = 0; sh->cutoff_ready = 0; sh->cache_valid = 0; sh->presel_frames = 0; sh->ps_margin_pm = -1;
     for (int i = 0; i < 8; i++) sh->cnt[i] = 0;
     for (int i = 0; i < 16; i++) sh->ph[i] = 0;
     sh->t_prev = __builtin_amdgcn_s_memtime();
@@ -1953,15 +1959,47 @@ __device__ __forceinline__ void PhaseInsert(int lane, Sh &sh, unsigned char *dyn
   fc.hmask = d.full_level2 ? d.hash_mask : FrameLevel2Mask(sh.n_links, d.hash_cap);
   fc.presel = false; fc.presel_bound = INFINITY;
   // ---- pre-selection (see InsertEmitted): pick the bound from a histogram of the candidates' costs
-  const int ps_target = d.cfg.max_active + max(d.cfg.max_active / 4, 16);          // candidates wanted under the bound
-  if (may_preselect && d.preselect != 0 && d.cfg.max_active < (1 << 28) && d.cfg.max_active >= d.cfg.min_active && n_cand >= ps_target + ps_target / 2) {
-    const float lo = fc.next_cutoff - fc.adaptive_beam;         // (about) the best candidate's cost
-    const float width = cutoff - lo;
-    const float scale = static_cast<float>(SH_HIST) / width;
+  // candidates wanted under the bound: max_active plus a margin for the candidates that are second arcs into a state (they
+  // create no token).  Too small a margin and the count of created tokens falls short -- the bound is raised and another
+  // slab of candidates inserted, a sweep more; too large and tokens are created for nothing (measured at the planted
+  // load with a fixed margin: 5 % 358 ms, 25 % 372 ms, 50 % 390 ms; 1 % 450 ms when a shortfall still meant inserting
+  // everything; the random-score load has more duplicates: 8 % 262 ms, 15 % 249 ms).  The lane starts at ps_margin_pct and
+  // follows what its frames show: the candidates per created token of the last proven bound, half as much again, + 2 %.
+  const int margin_pm = (sh.ps_margin_pm >= 0 && d.ps_adapt) ? sh.ps_margin_pm : 10 * d.ps_margin_pct;
+  const int ps_target = d.cfg.max_active + max(static_cast<int>(static_cast<long long>(d.cfg.max_active) * margin_pm / 1000), 16);
+  float lo = 0.0f, scale = 0.0f;
+  int bin = -1, under = 0, total = 0;
+  // the first bucket of the candidates' cost histogram (Sh::hist) under whose upper edge `target` candidates lie, and how many
+  // lie under it; SH_HIST / NT buckets per thread, workgroup scan.  Uniform; ends on a barrier.
+  auto find_bin = [&](int target, int *bin_out, int *under_out, int *total_out) {
     constexpr int PER = SH_HIST / NT;
+    int h[PER], mine = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) { h[q] = static_cast<int>(sh.hist[PER * tid + q]); mine += h[q]; }
+    const int incl = WaveInclScanI(mine);
+    LdsBarrier();                                // (whoever read redi / sel_bin last is done)
+    if ((tid & 63) == 63) sh.redi[tid >> 6] = incl;
+    if (tid == 0) { sh.sel_bin = -1; sh.sel_below = 0; }
+    LdsBarrier();
+    int wbase = 0, tot_all = 0;
+    for (int q = 0; q < NWAVES; q++) { const int v = sh.redi[q]; if (q < (tid >> 6)) wbase += v; tot_all += v; }
+    const int excl = wbase + incl - mine;
+    if (target - 1 >= excl && target - 1 < excl + mine) {
+      int cum = excl, b = PER * tid;
+#pragma unroll
+      for (int q = 0; q < PER; q++) { if (cum + h[q] > target - 1) break; cum += h[q]; b++; }
+      sh.sel_bin = b; sh.sel_below = cum + static_cast<int>(sh.hist[b]);     // candidates up to and including bucket b
+    }
+    LdsBarrier();
+    *bin_out = sh.sel_bin; *under_out = sh.sel_below; *total_out = tot_all;
+    LdsBarrier();
+  };
+  if (may_preselect && d.preselect != 0 && d.cfg.max_active < (1 << 28) && d.cfg.max_active >= d.cfg.min_active && static_cast<long long>(n_cand) * 100 >= static_cast<long long>(ps_target) * d.ps_worth_pct) {
+    lo = fc.next_cutoff - fc.adaptive_beam;         // (about) the best candidate's cost
+    const float width = cutoff - lo;
+    scale = static_cast<float>(SH_HIST) / width;
     if (width > 0.0f && scale < 3.0e38f) {      // uniform
       for (int i = tid; i < SH_HIST; i += NT) sh.hist[i] = 0;
-      if (tid == 0) { sh.sel_bin = -1; sh.sel_below = 0; }
       LdsBarrier();
       const uint4 *cand = CandBase(c, fc.link_base);
       for (int i0 = tid; i0 < n_cand; i0 += INSB * NT) {
@@ -1976,34 +2014,13 @@ __device__ __forceinline__ void PhaseInsert(int lane, Sh &sh, unsigned char *dyn
           }
       }
       LdsBarrier();
-      // the first bucket under whose upper edge ps_target candidates lie: SH_HIST / NT buckets per thread, workgroup scan
-      int h[PER], mine = 0;
-#pragma unroll
-      for (int q = 0; q < PER; q++) { h[q] = static_cast<int>(sh.hist[PER * tid + q]); mine += h[q]; }
-      const int incl = WaveInclScanI(mine);
-      if ((tid & 63) == 63) sh.redi[tid >> 6] = incl;        // (behind two barriers since anybody read redi)
-      LdsBarrier();
-      int wbase = 0, total = 0;
-      for (int q = 0; q < NWAVES; q++) { const int v = sh.redi[q]; if (q < (tid >> 6)) wbase += v; total += v; }
-      const int excl = wbase + incl - mine;
-      if (ps_target - 1 >= excl && ps_target - 1 < excl + mine) {
-        int cum = excl, b = PER * tid;
-#pragma unroll
-        for (int q = 0; q < PER; q++) { if (cum + h[q] > ps_target - 1) break; cum += h[q]; b++; }
-        sh.sel_bin = b; sh.sel_below = cum + static_cast<int>(sh.hist[b]);     // candidates up to and including bucket b
-      }
-      LdsBarrier();
-      const int bin = sh.sel_bin, under = sh.sel_below;
-      LdsBarrier();                             // (sel_bin / redi may be rewritten by the next reduction)
+      find_bin(ps_target, &bin, &under, &total);
       // worth it only when the bound leaves a good part of the candidates out
-      if (bin >= 0 && bin < SH_HIST - 1 && 2 * under <= total + under / 2) {
-        fc.presel = true;
-        fc.presel_bound = lo + static_cast<float>(bin + 1) / scale;
-        if (!(fc.presel_bound < cutoff)) fc.presel = false;
-      }
+      fc.presel = bin >= 0 && bin < SH_HIST - 1 && static_cast<long long>(under) * d.ps_worth_pct <= 100ll * total &&
+                  lo + static_cast<float>(bin + 1) / scale < cutoff;
     }
   }
-  // a pre-selected frame inserts ~1.3 max_active tokens whatever the last frame held: the whole table region then
+  // a pre-selected frame inserts ~1.1 max_active tokens whatever the last frame held: the whole table region then
   if (fc.presel && !fc.big && L.cap_big > L.cap_small && ps_target > d.big_frame_tokens) fc.big = true;
   Tbl tbl = FrameTable(L, fc.big, fc.hmask);
   tbl.q_on = true; tbl.q_lds = reinterpret_cast<u32 *>(L.cost_cache); tbl.q_cap = fc.big ? 0 : (3 * BIGCAP) / 2;    // = PhaseCommit's wl0
@@ -2012,17 +2029,47 @@ __device__ __forceinline__ void PhaseInsert(int lane, Sh &sh, unsigned char *dyn
     LdsBarrier();
   }
   if (fc.presel) {
-    int made = 0, dummy = 0;
-    fc.k_surv = InsertEmitted<KAMD_PS_FIRST>(d, c, &sh, tbl, fc.link_base, sh.n_links, cutoff, fc.presel_bound, &made);
-    BlockSum2<true>(made, dummy, &sh);
-    if (made <= d.cfg.max_active) {     // uniform: the bound proves nothing -- insert the rest, the frame is an ordinary one
+    // slab by slab until the tokens created under the bound outnumber max_active (usually the first does it); three at most
+    float b_prev = -INFINITY;
+    int made_total = 0;
+    bool proven = false;
+    fc.k_surv = 0;
+    for (int iter = 0; iter < 3; iter++) {
+      const float b_new = lo + static_cast<float>(bin + 1) / scale;
+      int made = 0, dummy = 0;
+      fc.k_surv += InsertEmitted(d, c, &sh, tbl, fc.link_base, sh.n_links, cutoff, b_prev, b_new, &made);
+      BlockSum2<true>(made, dummy, &sh);
+      made_total += made;
+      b_prev = b_new;
+      if (made_total > d.cfg.max_active) { proven = true; break; }     // uniform
+      if (iter == 2) break;
+      // the next slab: the tokens still missing at the rate seen so far, half as many again
+      const long long miss = d.cfg.max_active + 1 - made_total;
+      const int more = static_cast<int>(min(miss * 3 * max(under, 1) / (2 * max(made_total, 1)) + 64, 1ll << 28));
+      int bin2, under2, total2;
+      find_bin(under + more, &bin2, &under2, &total2);
+      if (bin2 <= bin || bin2 >= SH_HIST - 1 || static_cast<long long>(under2) * d.ps_worth_pct > 100ll * total2 ||
+          !(lo + static_cast<float>(bin2 + 1) / scale < cutoff)) break;
+      bin = bin2; under = under2;
+    }
+    if (!proven) {     // the bounds proved nothing -- insert the rest, the frame is an ordinary one
       int unused = 0;
-      fc.k_surv += InsertEmitted<KAMD_PS_REST>(d, c, &sh, tbl, fc.link_base, sh.n_links, cutoff, fc.presel_bound, &unused);
+      fc.k_surv += InsertEmitted(d, c, &sh, tbl, fc.link_base, sh.n_links, cutoff, b_prev, INFINITY, &unused);
       fc.presel = false;
-    } else if (tid == 0) sh.presel_frames++;
+      if (tid == 0) sh.ps_margin_pm = min(2 * margin_pm + 50, 1000);
+    } else {
+      fc.presel_bound = b_prev;
+      if (tid == 0) {
+        sh.presel_frames++;
+        // candidates per created token under the proven bound, as a margin over max_active (per mille), half as much again + 2 %
+        const long long need_pm = 1000ll * max(under, 1) / max(made_total, 1) - 1000;
+        const int next_pm = static_cast<int>(min(max(need_pm * 3 / 2 + 20, 30ll), 1000ll));
+        sh.ps_margin_pm = max(next_pm, margin_pm * 3 / 4);
+      }
+    }
   } else {
     int unused = 0;
-    fc.k_surv = InsertEmitted<KAMD_PS_ALL>(d, c, &sh, tbl, fc.link_base, sh.n_links, cutoff, INFINITY, &unused);
+    fc.k_surv = InsertEmitted(d, c, &sh, tbl, fc.link_base, sh.n_links, cutoff, -INFINITY, INFINITY, &unused);
   }
   Stamp(&sh, PH_FIXUP);
 }
@@ -3420,6 +3467,12 @@ kamd_decoder *kamd_decoder_create(const kamd_graph *gh, const kamd_decoder_confi
   if (const char *e = getenv("KAMD_GOOD_FIRST")) d.good_first = static_cast<float>(atof(e));
   d.preselect = 1;
   if (const char *e = getenv("KAMD_PRESELECT")) d.preselect = atoi(e);
+  d.ps_margin_pct = 8;
+  d.ps_adapt = 1;
+  if (const char *e = getenv("KAMD_PS_ADAPT")) d.ps_adapt = atoi(e) != 0;
+  d.ps_worth_pct = 150;
+  if (const char *e = getenv("KAMD_PS_WORTH_PCT")) d.ps_worth_pct = std::max(100, std::min(100000, atoi(e)));
+  if (const char *e = getenv("KAMD_PS_MARGIN_PCT")) d.ps_margin_pct = std::max(1, std::min(400, atoi(e)));
   d.num_pdfs_lds = 0;
   const size_t lds_budget = 160 * 1024 / LANES_PER_CU - sizeof(kamd::Sh) - 1024;
   const size_t fixed = kamd::AdvanceLdsBytes(0, LDS_TABLE_CAP);
