@@ -99,7 +99,7 @@ int main(int argc, char **argv) {
     po.Register("frames-per-chunk", &frames_per_chunk, "Number of frames in each chunk that is separately evaluated by the neural net (only matters "
                 "with --ivector-extraction-config: without online iVectors whole utterances are batched, which gives the same numbers)");
     po.Register("debug-computation", &debug_computation, "(ignored)");
-    std::string word_syms_filename, ivector_rspecifier, online_ivector_rspecifier, utt2spk_rspecifier, mfcc_config, ivector_config;
+    std::string word_syms_filename, ivector_rspecifier, online_ivector_rspecifier, utt2spk_rspecifier, mfcc_config, ivector_config, chunk_rule = "simple";
     int32 online_ivector_period = 0, num_threads = 8, set_frames = 2000000, lanes_opt = 0, search_mode = 2, device = -1;
     po.Register("word-symbol-table", &word_syms_filename, "Symbol table for words [for debug output]");
     po.Register("allow-partial", &allow_partial, "If true, produce output even if end state was not reached.");
@@ -112,6 +112,8 @@ int main(int argc, char **argv) {
     po.Register("ivector-extraction-config", &ivector_config, "Configuration file for online iVector extraction (the one of the online2 binaries / "
                 "ivector-extract-online2): the iVectors are estimated on the device from the utterances' own features and the model is evaluated "
                 "in chunks of --frames-per-chunk like nnet3-latgen-faster --online-ivectors (steps/nnet3/decode.sh:105-107)");
+    po.Register("chunk-rule", &chunk_rule, "With --ivector-extraction-config: simple = DecodableNnetSimple's chunks (nnet3-latgen-faster, this "
+                "binary), batch_computer = NnetBatchComputer::SplitUtteranceIntoTasks (nnet3-latgen-faster-batch)");
     po.Register("num-threads", &num_threads, "Number of host threads for the tail of every utterance (best path, lattice determinization): "
                 "the decoder threads of nnet3-latgen-faster-batch");
     po.Register("wav", &wav, "The third argument is an scp: rspecifier of waveforms; features are computed on the device");
@@ -193,7 +195,8 @@ int main(int argc, char **argv) {
       opts.c.resident_lanes = sized_lanes; opts.c.det = det_opts.c;
       NnetBatchDecoder decoder(decode_fst, config, model.Id2Pdf(), model.TidPhone(), word_syms, allow_partial, num_threads, am_nnet,
                                wav ? &mfcc : NULL, sizes, opts);
-      if (ivector_extractor) decoder.SetIvectorExtractor(ivector_extractor->handle(), frames_per_chunk);
+      if (chunk_rule != "simple" && chunk_rule != "batch_computer") throw KaldiFatalError("--chunk-rule: simple or batch_computer");
+      if (ivector_extractor) decoder.SetIvectorExtractor(ivector_extractor->handle(), frames_per_chunk, chunk_rule == "batch_computer");
       for (const Utterance &u : *items) {
         if (wav) decoder.AcceptWaveform(u.key, u.data);
         else decoder.AcceptInput(u.key, u.data.data(), u.rows, model.InputDim(), u.ivector.empty() ? NULL : u.ivector.data(),

@@ -858,6 +858,20 @@ int kamd_nnet_forward_chunked_device(kamd_nnet *n, const float *d_feats, const i
                                      const float *d_online_ivectors, const int64_t *h_iv_row_off, int iv_dim,
                                      int ivector_period, int frames_per_chunk, int n_utts, float *d_out,
                                      const int64_t *h_out_row_off, int ld_out, void *stream);
+/* The same batch evaluated the way NnetBatchComputer does (nnet3/nnet-batch-compute.h:207; SplitUtteranceIntoTasks
+ * nnet-batch-compute.cc:774-829 with GetOutputFrameInfoForTasks :586-668, AddOnlineIvectorsToTasks :670-703,
+ * SplitInputToTasks :705-770, then Compute and MergeTaskOutput :832-870 -- i.e. what nnet3-latgen-faster-batch, the binary
+ * behind `steps/nnet3/decode.sh --use-gpu true`, feeds its decoders): tasks of frames_per_chunk / subsampling output
+ * frames (integer division: 16 for 50 / 3, where DecodableNnetSimple takes 17), the last task ending on the utterance's
+ * last frame and overlapping the one before it, an utterance shorter than a task being one task; every task with the
+ * i-vector row of ITS middle, the last row when that is at most 20 input frames beyond the table.  The default options
+ * (--extra-left-context 0, --ensure-exact-final-context false).  Every task is an item of one batched forward that
+ * computes the rows MergeTaskOutput keeps; the reference's minibatch scheduling (priorities, partial minibatches) has no
+ * counterpart: all tasks of all utterances run in one pass. */
+int kamd_nnet_forward_tasks_device(kamd_nnet *n, const float *d_feats, const int64_t *h_in_row_off, int ld_in,
+                                   const float *d_online_ivectors, const int64_t *h_iv_row_off, int iv_dim,
+                                   int ivector_period, int frames_per_chunk, int n_utts, float *d_out,
+                                   const int64_t *h_out_row_off, int ld_out, void *stream);
 
 /* ------------------------------------------------- lattice determinization -- */
 /* DeterminizeLatticePhonePrunedOptions + DeterminizeLatticePrunedOptions
@@ -1189,6 +1203,11 @@ int64_t kamd_batch_decoder_output_frames(kamd_batch_decoder *b, int32_t *frames,
  * recomputed, the i-vector row GetCurrentIvector picks; kamd_nnet_forward_chunked_device).  Set before the set is loaded
  * (kamd_batch_decoder_load / _load_host); NULL removes it.  The extractor is not owned. */
 int kamd_batch_decoder_set_ivector_extractor(kamd_batch_decoder *b, kamd_ivector_extractor *e, int frames_per_chunk);
+/* Which of the reference's two chunkings the acoustic model of a set with online i-vectors follows: 0 (default)
+ * DecodableNnetSimple's (nnet3-latgen-faster: kamd_nnet_forward_chunked_device), 1 NnetBatchComputer's tasks
+ * (nnet3-latgen-faster-batch: kamd_nnet_forward_tasks_device).  They differ in where chunks start and therefore in the
+ * i-vector row a frame is evaluated with. */
+int kamd_batch_decoder_set_chunk_rule(kamd_batch_decoder *b, int rule);
 /* AcceptInput as the reference declares it (nnet-batch-compute.h:665-669: feature matrices, not
  * waveforms, plus the optional per-utterance i-vector): rows [row_off[u], row_off[u+1]) of feats
  * (dim floats per row, dim = the model's input dim) are utterance u; ivectors is [n_utts x

@@ -1080,7 +1080,10 @@ class NnetBatchDecoder {
   /// i-vectors estimated on the device from every pass's features, the model evaluated chunk by chunk like
   /// DecodableNnetSimple with --online-ivectors (kamd_batch_decoder_set_ivector_extractor).  Before the first AcceptInput /
   /// AcceptWaveform; utterances then come without an i-vector of their own.
-  void SetIvectorExtractor(kamd_ivector_extractor *extractor, int32 frames_per_chunk = 50) {
+  /// batch_computer_tasks: the chunking of NnetBatchComputer::SplitUtteranceIntoTasks (nnet3/nnet-batch-compute.cc:774-829 -- what
+  /// the reference's NnetBatchDecoder is fed by) instead of DecodableNnetSimple's (kamd_batch_decoder_set_chunk_rule).
+  void SetIvectorExtractor(kamd_ivector_extractor *extractor, int32 frames_per_chunk = 50, bool batch_computer_tasks = false) {
+    Check(kamd_batch_decoder_set_chunk_rule(h_, batch_computer_tasks ? 1 : 0));
     Check(kamd_batch_decoder_set_ivector_extractor(h_, extractor, frames_per_chunk));
     online_ivectors_ = extractor != NULL;
   }

@@ -76,6 +76,11 @@ class NnetBatchDecoder:
         self._ie = extractor
         check(lib().kamd_batch_decoder_set_ivector_extractor(self._h, None if extractor is None else extractor._h, int(frames_per_chunk)))
 
+    def set_chunk_rule(self, rule):
+        """0 / "simple": DecodableNnetSimple's chunks (nnet3-latgen-faster; the default); 1 / "batch_computer": NnetBatchComputer's
+        tasks (nnet3-latgen-faster-batch, nnet3/nnet-batch-compute.cc:774-829).  kamd_batch_decoder_set_chunk_rule."""
+        check(lib().kamd_batch_decoder_set_chunk_rule(self._h, {"simple": 0, "batch_computer": 1}.get(rule, rule)))
+
     def load(self, waves):
         waves = [np.asarray(w, np.float32) for w in waves]
         off = np.concatenate([[0], np.cumsum([w.size for w in waves])]).astype(np.int64)

@@ -71,6 +71,7 @@ struct BatchDecoder {
   // The acoustic model then runs chunk by chunk like DecodableNnetSimple (kamd_nnet_forward_chunked_device).
   kamd_ivector_extractor *iv_extractor = NULL;
   int frames_per_chunk = 50;
+  int chunk_rule = 0;                            // 0: DecodableNnetSimple's chunks, 1: NnetBatchComputer's tasks (kamd_batch_decoder_set_chunk_rule)
   float *d_oiv = NULL; size_t oiv_cap = 0;
   std::vector<int64_t> oiv_off;
   // kamd_batch_decoder_load_host: the samples stay in the caller's memory and every run() uploads them pass by pass
@@ -315,6 +316,13 @@ int kamd_batch_decoder_set_ivector_extractor(kamd_batch_decoder *h, kamd_ivector
     return kamd::SetError(KAMD_ERR_ARG, "the extractor gives %d-dim ivectors, the model takes %d", kamd_ivector_dim(e), kamd_nnet_ivector_dim(b->nnet));
   if (b->n_utts > 0) return kamd::SetError(KAMD_ERR_STATE, "set the extractor before the test set is loaded");
   b->iv_extractor = e; b->frames_per_chunk = frames_per_chunk;
+  return KAMD_OK;
+}
+
+int kamd_batch_decoder_set_chunk_rule(kamd_batch_decoder *h, int rule) {
+  BatchDecoder *b = reinterpret_cast<BatchDecoder *>(h);
+  if (rule != 0 && rule != 1) return kamd::SetError(KAMD_ERR_ARG, "chunk rule: 0 (DecodableNnetSimple) or 1 (NnetBatchComputer)");
+  b->chunk_rule = rule;
   return KAMD_OK;
 }
 
@@ -750,9 +758,9 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
       const int u0 = pu[pass], u1 = pu[pass + 1];
       if (online_iv) {
         KAMD_HIP(hipEventRecord(b->ev_n0[pass], st));
-        rc = kamd_nnet_forward_chunked_device(b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat, b->d_oiv, b->oiv_off.data() + u0,
-                                              kamd_ivector_dim(b->iv_extractor), kamd_ivector_period(b->iv_extractor), b->frames_per_chunk,
-                                              u1 - u0, b->d_ll, b->out_off.data() + u0, b->P, st);
+        rc = (b->chunk_rule == 1 ? kamd_nnet_forward_tasks_device : kamd_nnet_forward_chunked_device)(
+            b->nnet, b->d_feats, b->feat_off.data() + u0, b->ld_feat, b->d_oiv, b->oiv_off.data() + u0, kamd_ivector_dim(b->iv_extractor),
+            kamd_ivector_period(b->iv_extractor), b->frames_per_chunk, u1 - u0, b->d_ll, b->out_off.data() + u0, b->P, st);
       } else {
         rc = features_of(pass, st);
         if (rc == KAMD_OK)

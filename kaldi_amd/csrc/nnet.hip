@@ -1837,22 +1837,28 @@ int CopyRowBlocks(const float *src, int ld_src, float *dst, int ld_dst, const in
 extern "C" {
 
 // DecodableNnetSimple with online ivectors, for a batch of utterances (nnet3/nnet-am-decodable-
-// simple.cc:93-214; the chunk arithmetic NnetBatchComputer shares, nnet-batch-compute.cc:774-829):
-// every chunk of frames_per_chunk input frames (rounded up to a multiple of the subsampling
+// simple.cc:93-214): every chunk of frames_per_chunk input frames (rounded up to a multiple of the subsampling
 // factor, :278-310) is one item of a single batched forward, with its own left / right context
 // (clamped at the utterance edges only) and the ivector row GetCurrentIvector picks for the middle
 // of the chunk (:181-211).  The context rows are recomputed per chunk, as the reference does.
-int kamd_nnet_forward_chunked_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_row_off, int ld_in,
-                                     const float *d_online_ivectors, const int64_t *h_iv_row_off, int iv_dim,
-                                     int ivector_period, int frames_per_chunk, int n_utts, float *d_out,
-                                     const int64_t *h_out_row_off, int ld_out, void *stream) {
+// rule 1 = NnetBatchComputer::SplitUtteranceIntoTasks (nnet3/nnet-batch-compute.cc:586-829; what nnet3-latgen-faster-batch
+// evaluates): tasks of frames_per_chunk / subsampling output frames (integer division), the LAST task ending on the
+// utterance's last frame and overlapping the one before it, the i-vector row of the task's middle
+// ((begin_output_t + num_output_frames / 2) * f / period, the last row when at most 20 frames beyond the table).  A task
+// is an item that computes exactly the output rows MergeTaskOutput (:832-870) keeps -- a feed-forward model's row does
+// not depend on which other rows share its task, only on the task's i-vector.
+static int ForwardChunkedRule(kamd_nnet *h, const float *d_feats, const int64_t *h_in_row_off, int ld_in,
+                              const float *d_online_ivectors, const int64_t *h_iv_row_off, int iv_dim,
+                              int ivector_period, int frames_per_chunk, int n_utts, float *d_out,
+                              const int64_t *h_out_row_off, int ld_out, void *stream, int rule) {
   Nnet *nn = reinterpret_cast<Nnet *>(h);
   if (n_utts <= 0) return KAMD_OK;
   const int sub = nn->subsampling;
   if (iv_dim != nn->L[0].ivector_dim || iv_dim <= 0) return kamd::SetError(KAMD_ERR_ARG, "model expects ivector dim %d, got %d", nn->L[0].ivector_dim, iv_dim);
   if (ivector_period <= 0 || frames_per_chunk <= 0) return kamd::SetError(KAMD_ERR_ARG, "bad ivector period / frames per chunk");
-  if (frames_per_chunk % sub != 0) frames_per_chunk = sub * ((frames_per_chunk + sub - 1) / sub);
+  if (rule == 0 && frames_per_chunk % sub != 0) frames_per_chunk = sub * ((frames_per_chunk + sub - 1) / sub);
   const int C = frames_per_chunk / sub;
+  if (C <= 0) return kamd::SetError(KAMD_ERR_ARG, "frames per chunk %d below the subsampling factor %d", frames_per_chunk, sub);
   // Every chunk is an item whose layers are evaluated at exactly the times its outputs need (what the compiled
   // computation of a chunk contains); it writes its rows of d_out in place.  Neighbouring chunks that read the SAME
   // i-vector row are one item: their computations are identical on the rows they share (at the end of an utterance,
@@ -1868,20 +1874,35 @@ int kamd_nnet_forward_chunked_device(kamd_nnet *h, const float *d_feats, const i
     if (T <= 0 || n_iv <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no frames / ivectors", u);
     const int n_out = (T + sub - 1) / sub;
     bool first = true;
-    for (int start = 0; start < n_out; start += C) {
+    const int n_tasks = (n_out + C - 1) / C;
+    for (int i = 0; i < n_tasks; i++) {
+      const int start = i * C;                                  // first output row this item writes
       const int num = std::min(n_out - start, C);
-      const int first_out = start * sub, last_out = (start + num - 1) * sub;
-      int ivf = (first_out + (last_out - first_out) / 2) / ivector_period;       // GetCurrentIvector (:181-211)
-      if (ivf >= n_iv) {
-        if ((ivf - (n_iv - 1)) * ivector_period > 50)
-          return kamd::SetError(KAMD_ERR_ARG, "utterance %d: could not get iVector for frame %d (mismatched --online-ivector-period?)", u, first_out);
-        ivf = n_iv - 1;
+      int ivf;
+      if (rule == 0) {
+        const int first_out = start * sub, last_out = (start + num - 1) * sub;
+        ivf = (first_out + (last_out - first_out) / 2) / ivector_period;       // GetCurrentIvector (:181-211)
+        if (ivf >= n_iv) {
+          if ((ivf - (n_iv - 1)) * ivector_period > 50)
+            return kamd::SetError(KAMD_ERR_ARG, "utterance %d: could not get iVector for frame %d (mismatched --online-ivector-period?)", u, first_out);
+          ivf = n_iv - 1;
+        }
+      } else {
+        // GetOutputFrameInfoForTasks: the task nominally covers C output frames from begin_output_t; the last of several
+        // tasks is shifted back to end on the last frame (its first rows are the previous task's: not written again)
+        const int begin_output_t = (n_tasks > 1 && i == n_tasks - 1) ? n_out - C : start;
+        ivf = ((begin_output_t + C / 2) * sub) / ivector_period;               // AddOnlineIvectorsToTasks (:670-703)
+        const int margin = (20 + ivector_period - 1) / ivector_period;
+        if (ivf >= n_iv) {
+          if (ivf > n_iv - margin) ivf = n_iv - 1;
+          else return kamd::SetError(KAMD_ERR_ARG, "utterance %d: could not get iVector for frame %d, online-ivectors matrix has %d rows (mismatched --online-ivector-period?)", u, ivf, n_iv);
+        }
       }
       const int32_t row = static_cast<int32_t>(h_iv_row_off[u] - iv_base + ivf);
       if (!first && !no_merge && iv_row.back() == row) { nout.back() += num; continue; }
       first = false;
       in_start.push_back(h_in_row_off[u]); in_len.push_back(T);
-      t0.push_back(first_out); nout.push_back(num);
+      t0.push_back(start * sub); nout.push_back(num);
       out_row.push_back(h_out_row_off[u] + start);
       iv_row.push_back(row);
     }
@@ -1891,6 +1912,22 @@ int kamd_nnet_forward_chunked_device(kamd_nnet *h, const float *d_feats, const i
   ChunkSpec cs = {t0.data(), nout.data(), iv_row.data()};
   return ForwardItems(h, d_feats, in_start.data(), in_len.data(), ld_in, d_online_ivectors + iv_base * iv_dim, n_items, d_out, out_row.data(),
                       ld_out, stream, NULL, &cs);
+}
+
+int kamd_nnet_forward_chunked_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_row_off, int ld_in,
+                                     const float *d_online_ivectors, const int64_t *h_iv_row_off, int iv_dim,
+                                     int ivector_period, int frames_per_chunk, int n_utts, float *d_out,
+                                     const int64_t *h_out_row_off, int ld_out, void *stream) {
+  return ForwardChunkedRule(h, d_feats, h_in_row_off, ld_in, d_online_ivectors, h_iv_row_off, iv_dim, ivector_period, frames_per_chunk, n_utts,
+                            d_out, h_out_row_off, ld_out, stream, 0);
+}
+
+int kamd_nnet_forward_tasks_device(kamd_nnet *h, const float *d_feats, const int64_t *h_in_row_off, int ld_in,
+                                   const float *d_online_ivectors, const int64_t *h_iv_row_off, int iv_dim,
+                                   int ivector_period, int frames_per_chunk, int n_utts, float *d_out,
+                                   const int64_t *h_out_row_off, int ld_out, void *stream) {
+  return ForwardChunkedRule(h, d_feats, h_in_row_off, ld_in, d_online_ivectors, h_iv_row_off, iv_dim, ivector_period, frames_per_chunk, n_utts,
+                            d_out, h_out_row_off, ld_out, stream, 1);
 }
 
 // ---- nnet3::Component::Propagate (nnet3/nnet-component-itf.h:130-132) for ONE fused layer: SURVEY 8(b)'s option (i),

@@ -104,9 +104,11 @@ class Nnet:
         out = d_o.download()
         return [out[out_off[i]:out_off[i + 1]] for i in range(n)]
 
-    def ForwardChunked(self, feats_list, online_ivectors_list, ivector_period=10, frames_per_chunk=50):
+    def ForwardChunked(self, feats_list, online_ivectors_list, ivector_period=10, frames_per_chunk=50, batch_computer=False):
         """DecodableNnetSimple with online ivectors for a batch of utterances: one ivector per
-        chunk (nnet3/nnet-am-decodable-simple.cc:93-214).  Returns one [n_out x P] array each."""
+        chunk (nnet3/nnet-am-decodable-simple.cc:93-214).  Returns one [n_out x P] array each.
+        batch_computer: NnetBatchComputer's tasks instead (SplitUtteranceIntoTasks + Compute + MergeTaskOutput,
+        nnet3/nnet-batch-compute.cc:774-870: kamd_nnet_forward_tasks_device)."""
         ld = (self.model.input_dim + 15) // 16 * 16
         n = len(feats_list)
         in_off = np.zeros(n + 1, np.int64); iv_off = np.zeros(n + 1, np.int64); out_off = np.zeros(n + 1, np.int64)
@@ -120,9 +122,9 @@ class Nnet:
         ivs = np.ascontiguousarray(np.concatenate(online_ivectors_list), np.float32)
         P = self.OutputDim()
         d_f, d_iv, d_o = DeviceMatrix(feats), DeviceMatrix(ivs), DeviceMatrix(np.zeros((int(out_off[-1]), P), np.float32))
-        check(lib().kamd_nnet_forward_chunked_device(self._h, d_f.ptr(0), abi.iptr(in_off, C.c_int64), ld, d_iv.ptr(0),
-                                                     abi.iptr(iv_off, C.c_int64), ivs.shape[1], ivector_period,
-                                                     frames_per_chunk, n, d_o.ptr(0), abi.iptr(out_off, C.c_int64), P, None))
+        fwd = lib().kamd_nnet_forward_tasks_device if batch_computer else lib().kamd_nnet_forward_chunked_device
+        check(fwd(self._h, d_f.ptr(0), abi.iptr(in_off, C.c_int64), ld, d_iv.ptr(0), abi.iptr(iv_off, C.c_int64), ivs.shape[1], ivector_period,
+                  frames_per_chunk, n, d_o.ptr(0), abi.iptr(out_off, C.c_int64), P, None))
         out = d_o.download()
         return [out[out_off[u]:out_off[u + 1]] for u in range(n)]
 

@@ -46,6 +46,8 @@ def lib():
                                              C.c_int, C.c_int, fp, C.c_int]
         L.orc_nnet_forward_chunked.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int,
                                                C.c_int, C.c_int, C.c_int, fp, C.c_int]
+        L.orc_nnet_forward_batch_computer.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, fp,
+                                                      C.c_int, C.c_int, C.c_int, C.c_int, fp, C.c_int, ip, C.c_int, ip]
         dp = C.POINTER(C.c_double)
         L.orc_ivector_extract_online.argtypes = [C.POINTER(abi.IvectorDesc), fp, C.c_int, fp, C.c_int, fp, fp, ip, fp, ip, dp, dp]
         L.orc_ivector_extract_streaming.argtypes = [C.POINTER(abi.IvectorDesc), fp, C.c_int, ip, C.c_int, fp, dp, dp]
@@ -201,6 +203,28 @@ def nnet_forward_chunked(model, feats, online_ivectors, ivector_period=10, frame
                                        abi.fptr(out), n_out)
     assert r == n_out, r
     return out
+
+
+def nnet_forward_batch_computer(model, feats, online_ivectors, ivector_period=10, frames_per_chunk=50, return_tasks=False):
+    """NnetBatchComputer::SplitUtteranceIntoTasks + ComputeSimple + MergeTaskOutput (nnet3-latgen-faster-batch's forward) for one
+    utterance: chunks of frames_per_chunk // subsampling output frames, the last one ending on the utterance's last frame, one
+    online i-vector per task.  return_tasks: also the task table [n, 6] = first_used_output_frame_index,
+    num_initial_unused_output_frames, num_used_output_frames, num_output_frames, first_input_t, i-vector row."""
+    feats = np.ascontiguousarray(feats, np.float32)
+    iv = None if online_ivectors is None else np.ascontiguousarray(online_ivectors, np.float32)
+    T = feats.shape[0]
+    n_out = (T + model.subsampling - 1) // model.subsampling
+    out = np.zeros((n_out, model.layers[-1].out_dim), np.float32)
+    cap = n_out + 2
+    tasks = np.zeros((cap, 6), np.int32)
+    n_tasks = C.c_int(0)
+    left, right = model.context()
+    r = lib().orc_nnet_forward_batch_computer(model.descs(), len(model.layers), model.input_dim, model.subsampling, int(left), int(right),
+                                              abi.fptr(feats), T, abi.fptr(iv) if iv is not None else None,
+                                              0 if iv is None else iv.shape[0], 0 if iv is None else iv.shape[1], int(ivector_period),
+                                              int(frames_per_chunk), abi.fptr(out), n_out, abi.iptr(tasks), cap, C.byref(n_tasks))
+    assert r == n_out, r
+    return (out, tasks[:n_tasks.value].copy()) if return_tasks else out
 
 
 def ivector_extract_online(info, feats, diagnostics=False, state=None, return_state=False, max_remembered_frames=1000.0):

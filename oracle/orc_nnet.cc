@@ -206,4 +206,90 @@ int orc_nnet_forward_chunked(const kamd_layer_desc *layers, int n_layers, int in
   return n_out;
 }
 
+// NnetBatchComputer::SplitUtteranceIntoTasks + ComputeSimple + MergeTaskOutput for ONE utterance with online i-vectors
+// (nnet3/nnet-batch-compute.cc): what nnet3-latgen-faster-batch evaluates, statement by statement --
+//   GetOutputFrameInfoForTasks :586-668  chunks of fpc = frames_per_chunk / f subsampled frames (integer division, no
+//       rounding up); the LAST chunk ends on the utterance's last frame and overlaps the one before it
+//       (num_initial_unused_output_frames); an utterance shorter than a chunk is ONE chunk of fpc frames
+//       (ensure_exact_final_context = false, the default);
+//   SplitInputToTasks :705-770  every task's input is [begin_output_t * f - left, end_output_t * f + right), clamped to
+//       the utterance (extra contexts 0, the defaults);
+//   AddOnlineIvectorsToTasks :670-703  the row of the task's middle: (begin_output_t + num_output_frames / 2) * f /
+//       period, the last row when that is at most 20 input frames beyond the table, an error otherwise;
+//   MergeTaskOutput :832-870  rows [num_initial_unused, + num_used) of every task's output, in order.
+// Every task is evaluated WHOLE here (all fpc output frames, the unused and the padded ones included), as the reference
+// does; the device evaluates the used rows only and must give the same numbers.  tasks_out (optional, 6 ints per task):
+// first_used_output_frame_index, num_initial_unused_output_frames, num_used_output_frames, num_output_frames,
+// first_input_t, ivector row.  Returns the number of output rows, -1: buffer too small, -2: no i-vector for a task.
+int orc_nnet_forward_batch_computer(const kamd_layer_desc *layers, int n_layers, int input_dim, int subsampling,
+                                    int left_context, int right_context,
+                                    const float *feats, int T, const float *online_ivectors, int n_iv_rows, int iv_dim,
+                                    int ivector_period, int frames_per_chunk, float *out, int out_rows_cap,
+                                    int *tasks_out, int tasks_cap, int *n_tasks_out) {
+  if (T <= 0) return 0;
+  const int f = subsampling;
+  const int num_subsampled_frames = (T + f - 1) / f;
+  if (num_subsampled_frames > out_rows_cap) return -1;
+  const int fpc = frames_per_chunk / f;
+  if (fpc <= 0) return -3;
+  const int num_tasks = (num_subsampled_frames + fpc - 1) / fpc;
+  struct Task { int first_used, unused, used, num_out, first_input_t, iv_row; };
+  std::vector<Task> tasks(num_tasks);
+  if (num_subsampled_frames <= fpc) {
+    tasks[0].first_used = 0; tasks[0].num_out = fpc; tasks[0].unused = 0; tasks[0].used = num_subsampled_frames;
+  } else {
+    for (int i = 0; i + 1 < num_tasks; i++) { tasks[i].num_out = fpc; tasks[i].unused = 0; tasks[i].used = fpc; tasks[i].first_used = i * fpc; }
+    Task &t = tasks[num_tasks - 1];
+    t.num_out = fpc;
+    t.unused = (num_tasks - 1) * fpc - (num_subsampled_frames - fpc);
+    t.used = num_subsampled_frames - (num_tasks - 1) * fpc;
+    t.first_used = (num_tasks - 1) * fpc;
+  }
+  const int P = layers[n_layers - 1].out_dim;
+  int cur = 0;
+  for (int i = 0; i < num_tasks; i++) {
+    Task &t = tasks[i];
+    const int begin_output_t = t.first_used - t.unused, end_output_t = begin_output_t + t.num_out;
+    const int begin_input_t = begin_output_t * f, end_input_t = end_output_t * f;
+    const int begin_padded = begin_input_t - left_context, end_padded = end_input_t + right_context;
+    t.first_input_t = begin_padded - begin_output_t * f;
+    // the task's own copy of its input rows, clamped like SplitInputToTasks (:755-764)
+    const int rows = end_padded - begin_padded;
+    std::vector<float> in(static_cast<size_t>(rows) * input_dim);
+    for (int tt = begin_padded; tt < end_padded; tt++) {
+      const int tc = tt < 0 ? 0 : (tt >= T ? T - 1 : tt);
+      memcpy(&in[static_cast<size_t>(tt - begin_padded) * input_dim], feats + static_cast<int64_t>(tc) * input_dim, sizeof(float) * input_dim);
+    }
+    if (online_ivectors) {
+      const int mid_output_t = begin_output_t + t.num_out / 2, mid_input_t = mid_output_t * f;
+      int ivector_frame = mid_input_t / ivector_period;
+      const int margin_in_ivector_frames = (20 + ivector_period - 1) / ivector_period;
+      if (ivector_frame >= n_iv_rows) {
+        if (n_iv_rows > 0 && ivector_frame > n_iv_rows - margin_in_ivector_frames) ivector_frame = n_iv_rows - 1;
+        else return -2;
+      }
+      t.iv_row = ivector_frame;
+    } else t.iv_row = -1;
+    // the task's computation sees ONLY its own rows: times are relative to its first row (the clamp of Eval::Input then
+    // never binds differently from the copy above, which already holds the clamped rows)
+    Eval e;
+    e.L = layers; e.n_layers = n_layers; e.input_dim = input_dim; e.T = rows;
+    e.feats = in.data(); e.ivector = online_ivectors ? online_ivectors + static_cast<int64_t>(t.iv_row) * iv_dim : NULL;
+    e.memo.resize(n_layers);
+    for (int r = 0; r < t.used; r++) {
+      const int o = t.unused + r;                                    // row of the task's output
+      const float *y = e.Get(n_layers - 1, left_context + o * f);    // output frame o of the task sits at input row left + o f
+      if (cur != t.first_used + r) return -4;
+      memcpy(out + static_cast<int64_t>(cur) * P, y, sizeof(float) * P);
+      cur++;
+    }
+    if (tasks_out && i < tasks_cap) {
+      int *w = tasks_out + 6 * i;
+      w[0] = t.first_used; w[1] = t.unused; w[2] = t.used; w[3] = t.num_out; w[4] = t.first_input_t; w[5] = t.iv_row;
+    }
+  }
+  if (n_tasks_out) *n_tasks_out = num_tasks;
+  return cur == num_subsampled_frames ? cur : -4;
+}
+
 }  // extern "C"

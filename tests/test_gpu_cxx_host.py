@@ -283,8 +283,11 @@ def test_nnet3_latgen_faster_example_writes_the_python_tools_archive(tmp_path):
     allf = np.concatenate([mf.ComputeFeatures(wv) for wv in waves])
     info = ivector.make_synthetic(num_gauss=32, ivector_dim=10, seed=6, feat_mean=allf.mean(0), feat_std=allf.std(0))
     conf = ivector.write_config_dir(tmp_path / "extractor", info)
-    for tag, inp in (("feats", ["scp:%s" % (tmp_path / "feats.scp")]), ("wav", ["--wav", "scp:%s" % (tmp_path / "wav.scp")])):
-        args = common + ["--ivector-extraction-config=%s" % conf, "--frames-per-chunk=50", "--set-frames=300", str(tmp_path / "final_iv.mdl"), fst_]
+    # (both chunkings of the reference: DecodableNnetSimple's -- nnet3-latgen-faster -- and NnetBatchComputer's tasks -- nnet3-latgen-faster-batch)
+    for tag, inp, rule in (("feats", ["scp:%s" % (tmp_path / "feats.scp")], "simple"), ("wav", ["--wav", "scp:%s" % (tmp_path / "wav.scp")], "simple"),
+                           ("feats_bc", ["scp:%s" % (tmp_path / "feats.scp")], "batch_computer")):
+        args = common + ["--ivector-extraction-config=%s" % conf, "--frames-per-chunk=50", "--chunk-rule=%s" % rule, "--set-frames=300",
+                         str(tmp_path / "final_iv.mdl"), fst_]
         args = args[:-2] + inp[:-1] + args[-2:] + inp[-1:]
         r = subprocess.run([exe] + args + ["ark:%s" % (tmp_path / ("cxx_oiv_%s.lat" % tag))], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -295,6 +298,7 @@ def test_nnet3_latgen_faster_example_writes_the_python_tools_archive(tmp_path):
         assert len(list(latbin.read_lattices("ark:%s" % (tmp_path / ("cxx_oiv_%s.lat" % tag))))) == 6
     # (the same utterances with one constant i-vector per speaker decode to other lattices: the online estimates matter)
     assert open(tmp_path / "cxx_oiv_feats.lat", "rb").read() != open(tmp_path / "cxx.lat", "rb").read()
+    assert open(tmp_path / "cxx_oiv_feats.lat", "rb").read() != open(tmp_path / "cxx_oiv_feats_bc.lat", "rb").read()      # 17 against 16 frames per chunk
     # the reference's exits: usage without arguments, 255 + a message for a model that is not there
     assert subprocess.run([exe], capture_output=True).returncode == 1
     bad = subprocess.run([exe] + common + [str(tmp_path / "absent.mdl"), fst_, "scp:%s" % (tmp_path / "feats.scp"), "ark:/dev/null"],

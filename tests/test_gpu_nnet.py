@@ -71,6 +71,28 @@ def test_chunked_forward_with_online_ivectors():
         assert np.abs(g - plain).max() < 1e-4 * np.abs(plain).max()
 
 
+def test_batch_computer_tasks_with_online_ivectors():
+    """kamd_nnet_forward_tasks_device == the oracle's NnetBatchComputer (SplitUtteranceIntoTasks + Compute + MergeTaskOutput,
+    nnet3/nnet-batch-compute.cc:586-870) for a ragged batch: utterances shorter than a task, exactly one task, one frame
+    more, several tasks with an overlapping last one; frames_per_chunk 50 (16 output frames) and 21 (7)."""
+    m = nnet.tdnnf_tiny(num_pdfs=41, ivector_dim=10, seed=7)
+    N = decoder.Nnet(m)
+    rng = np.random.default_rng(4)
+    feats, ivs = [], []
+    for T in (140, 17, 1, 48, 49, 263):
+        feats.append((2 * rng.standard_normal((T, m.input_dim))).astype(np.float32))
+        ivs.append(rng.standard_normal(((T + 9) // 10, 10)).astype(np.float32))
+    for fpc in (50, 21):
+        got = N.ForwardChunked(feats, ivs, 10, fpc, batch_computer=True)
+        for f, iv, g in zip(feats, ivs, got):
+            ref = orc.nnet_forward_batch_computer(m, f, iv, 10, fpc)
+            assert g.shape == ref.shape
+            assert np.abs(g - ref).max() < 1e-4 * np.abs(ref).max()
+    simple = N.ForwardChunked(feats, ivs, 10, 50)
+    tasks = N.ForwardChunked(feats, ivs, 10, 50, batch_computer=True)
+    assert np.abs(simple[0] - tasks[0]).max() > 1e-3          # two different chunkings of the same inputs
+
+
 def test_context_and_plan():
     m = nnet.tdnnf_mini_librispeech(num_pdfs=64)
     n = decoder.Nnet(m)

@@ -128,3 +128,41 @@ def test_blas_forward_equals_scalar_oracle():
                 assert np.abs(orc_blas.nnet_forward_blas(m, f, iv, frames_per_chunk=fpc) - want).max() < tol
                 if orc.cblas_sgemm() is not None:
                     assert np.abs(orc.nnet_forward_blas(m, f, iv, frames_per_chunk=fpc) - want).max() < tol
+
+
+def test_batch_computer_tasks_follow_the_reference_rule():
+    """NnetBatchComputer::SplitUtteranceIntoTasks (nnet3/nnet-batch-compute.cc:586-829), cases worked by hand from the rule:
+    fpc = 50 / 3 = 16 output frames per task; the last of several tasks ends on the last frame and overlaps its predecessor;
+    an utterance shorter than a task is one task of 16 frames; first_input_t = -left context; the i-vector row is
+    ((begin_output_t + 8) * 3) // period, the last row when at most 20 frames beyond the table."""
+    m = nnet.tdnnf_tiny(num_pdfs=20, ivector_dim=6, seed=3)
+    left, right = m.context()
+    rng = np.random.default_rng(0)
+
+    def run(T, n_iv=None, period=10):
+        x = rng.standard_normal((T, m.input_dim)).astype(np.float32)
+        iv = rng.standard_normal(((T + period - 1) // period if n_iv is None else n_iv, 6)).astype(np.float32)
+        out, tasks = orc.nnet_forward_batch_computer(m, x, iv, period, 50, return_tasks=True)
+        return x, iv, out, tasks.tolist()
+
+    # columns: first_used_output_frame_index, num_initial_unused, num_used, num_output_frames, first_input_t, i-vector row
+    assert run(5)[3] == [[0, 0, 2, 16, -left, 0]]                       # 2 output frames, one padded task; row (8 * 3) // 10 = 2 -> clamped to the only row
+    assert run(48)[3] == [[0, 0, 16, 16, -left, 2]]
+    assert run(49)[3] == [[0, 0, 16, 16, -left, 2], [16, 15, 1, 16, -left, 2]]      # 17 frames: the second task covers [1, 17), mid (1 + 8) * 3 // 10
+    assert run(100)[3] == [[0, 0, 16, 16, -left, 2], [16, 0, 16, 16, -left, 7], [32, 14, 2, 16, -left, 7]]
+    assert run(160)[3] == [[0, 0, 16, 16, -left, 2], [16, 0, 16, 16, -left, 7], [32, 0, 16, 16, -left, 12], [48, 10, 6, 16, -left, 13]]
+    # a table shorter than the task's middle: the last row is taken.  (As written in the reference the 20-frame margin can
+    # never refuse a non-empty table -- `ivector_frame > num_rows - margin` holds whenever `ivector_frame >= num_rows` --
+    # so neither does the restatement.)
+    assert run(160, n_iv=13)[3][-1][5] == 12
+    assert [t[5] for t in run(160, n_iv=9)[3]] == [2, 7, 8, 8]
+    # every task sees ONE i-vector: with the same row everywhere the result is the plain forward, whatever the chunking
+    x, iv, _, _ = run(100)
+    const = np.tile(iv[:1], (iv.shape[0], 1))
+    np.testing.assert_array_equal(orc.nnet_forward_batch_computer(m, x, const, 10, 50), orc.nnet_forward(m, x, iv[0]))
+    # ... and with time-varying rows every kept output row equals the plain forward with its task's row
+    out, tasks = orc.nnet_forward_batch_computer(m, x, iv, 10, 50, return_tasks=True)
+    for first, unused, used, n_out, _, row in tasks.tolist():
+        np.testing.assert_array_equal(out[first:first + used], orc.nnet_forward(m, x, iv[row])[first:first + used])
+    # the two chunkings of the reference are different functions of the same inputs (17 against 16 frames per chunk)
+    assert np.abs(out - orc.nnet_forward_chunked(m, x, iv, 10, 50)).max() > 1e-3

@@ -42,11 +42,14 @@ def test_bad_state_sites_are_distinct_and_named_in_the_bench_report():
 
 
 def test_second_chance_covers_lanes_stopped_by_an_internal_check():
-    """Arena / pool exhaustion (bits 2, 4, 64) and a lane stopped by an internal check (32, with or without a bad-state
-    bit) take the second chance -- the search is deterministic and the event transient; a frame overflow (8) does not."""
+    """Arena / pool exhaustion (bits 2, 4, 64), a frame's level-2 share filled up (1: the wide launch addresses the whole
+    table) and a lane stopped by an internal check (32, with or without a bad-state bit) take the second chance -- the
+    search is deterministic and the event transient; a frame overflow (8) does not.  Internal-check stops are counted on
+    their own (n_internal_events), whether or not the second chance is on."""
     with open(os.path.join(ROOT, "kaldi_amd", "csrc", "batch.cc")) as f:
         b = f.read()
-    assert "(o.rec.error & (2 | 4 | 32 | 64)) != 0 && (o.rec.error & 8) == 0" in b
+    assert "(o.rec.error & (1 | 2 | 4 | 32 | 64)) != 0 && (o.rec.error & 8) == 0" in b
+    assert b.index("n_internal++") < b.index("const bool retry_on")
 
 
 def test_soak_variant_transforms_still_match_the_source():

@@ -37,8 +37,10 @@ def main(argv):
     po.register("online-ivectors", str, "", "(not supported by this tool)")
     po.register("online-ivector-period", int, 0, "(not supported by this tool)")
     po.register("ivector-extraction-config", str, "", "Configuration file for online iVector extraction (the one of the online2 binaries): the "
-                "iVectors are estimated on the device from the utterances' own features, the model is evaluated in chunks of "
-                "--frames-per-chunk like nnet3-latgen-faster --online-ivectors")
+                "iVectors are estimated on the device from the utterances' own features, the model is evaluated in tasks of "
+                "--frames-per-chunk like NnetBatchComputer with --online-ivectors (--chunk-rule=simple: like nnet3-latgen-faster)")
+    po.register("chunk-rule", str, "batch_computer", "With --ivector-extraction-config: batch_computer = NnetBatchComputer::SplitUtteranceIntoTasks "
+                "(this binary in the reference), simple = DecodableNnetSimple's chunks (nnet3-latgen-faster)")
     po.register("num-threads", int, max(1, min(16, (os.cpu_count() or 2) - 1)), "Number of host threads for the tail of every "
                 "utterance (best path, lattice determinization); the reference's decoder threads")
     po.register("use-gpu", str, "yes", "(ignored: there is no CPU path)")
@@ -120,6 +122,7 @@ def main(argv):
                                                  det=dict(delta=po["delta"], phone_determinize=int(po["phone-determinize"]),
                                                           word_determinize=int(po["word-determinize"])))
             if extractor is not None:
+                state["bd"].set_chunk_rule(po["chunk-rule"])
                 state["bd"].set_ivector_extractor(extractor, po["frames-per-chunk"])
         bd = state["bd"]
         if po["wav"]:
