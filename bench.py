@@ -568,6 +568,7 @@ def main():
         dec = {"frames": frames, "tokens_per_frame": counters[5] / max(frames, 1), "expanded_per_frame": counters[0] / max(frames, 1),
                "arcs_per_frame": counters[1] / max(frames, 1), "links_per_frame": counters[4] / max(frames, 1),
                "level2_tokens_per_frame": counters[7] / max(frames, 1),
+               "preselected_frames_share": sum(int(r.n_preselected) for r in recs) / max(frames, 1),
                "failed_utterances": sum(1 for r in recs if r.error), "failures": failure_report(recs)}
         alg = float(algorithmic_bytes(counters))
         dec_ms = float(acc[2])
@@ -697,6 +698,9 @@ def main():
         "setup_s": t_build,
     }
     one = world == 1
+    out["config"]["token_preselection"] = ("off (KAMD_PRESELECT=0)" if os.environ.get("KAMD_PRESELECT") == "0" else
+                                           "on: frames with several times max-active candidate arcs insert only the candidates that can matter for the next "
+                                           "frame (DESIGN.md section 8.2); lattices and 1-best unchanged, tokens_per_frame counts the tokens inserted")
     # ------------------------------------------------------------------ the same load, waveforms already in HBM
     if args.ivectors or faithful:
         out["stage_ms"]["ivector_extraction"] = acc[10]
