@@ -103,6 +103,9 @@ def parse_args():
     ap.add_argument("--hash-capacity", type=int, default=0)
     ap.add_argument("--tokens-per-frame", type=int, default=0, help="arena budget per frame and lane (0 = from max-active / free HBM)")
     ap.add_argument("--nnet-pass-frames", type=int, default=1000000)
+    ap.add_argument("--chunked-pass-frames", type=int, default=400000, help="input frames per acoustic-model pass when the model runs chunk by chunk "
+                    "(online i-vectors: the chunks' context rows are 1.9x the activations)")
+    ap.add_argument("--hbm-fraction", type=float, default=0.62, help="share of the free HBM the search arenas of the faithful / planted decoders take")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the cpu_baseline leg (0 = min(cores, 32))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -588,9 +591,9 @@ def main():
         spread, k = calibrate(model, args.ll_std)
     head_kw = {}
     if args.ivectors or faithful:
-        head_kw["nnet_pass_frames"] = min(args.nnet_pass_frames, 400000)      # (the chunks' context rows: 1.9x the activations)
+        head_kw["nnet_pass_frames"] = min(args.nnet_pass_frames, args.chunked_pass_frames)
     if faithful:
-        head_kw.update(hbm_fraction=0.62, tokens_per_frame=args.tokens_per_frame or 11000)
+        head_kw.update(hbm_fraction=args.hbm_fraction, tokens_per_frame=args.tokens_per_frame or 11000)
     bd = make_decoder(**head_kw)
     log("batch decoder created (%d host threads)" % host_threads)
     if args.resident:
