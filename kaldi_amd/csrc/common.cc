@@ -1,5 +1,42 @@
 #include "common.h"
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+// KAMD_ABORT_BACKTRACE=1 (tests/conftest.py sets it): when the process is aborted -- by the HSA runtime after a GPU memory
+// fault, by glibc on heap corruption, by std::terminate -- the aborting thread's native stack goes to stderr before the
+// default action runs, so that a run that dies says WHO called abort() (GPUTEST_r04.json had only Python's own frames).
+struct sigaction g_prev_abort;
+void AbortBacktrace(int sig) {
+  static const char head[] = "\nkaldi_amd: SIGABRT -- native stack of the aborting thread:\n";
+  (void)!write(2, head, sizeof(head) - 1);
+  void *frames[64];
+  const int n = backtrace(frames, 64);
+  backtrace_symbols_fd(frames, n, 2);
+  sigaction(sig, &g_prev_abort, NULL);      // whoever was there before (Python's faulthandler under pytest) goes next
+  raise(sig);
+}
+struct AbortHook {
+  AbortHook() {
+    const char *e = getenv("KAMD_ABORT_BACKTRACE");
+    if (e && e[0] == '1') {
+      void *warm[2];
+      (void)backtrace(warm, 2);          // (loads libgcc now: not inside the handler)
+      struct sigaction sa;
+      memset(&sa, 0, sizeof(sa));
+      sa.sa_handler = AbortBacktrace;
+      sa.sa_flags = SA_NODEFER | SA_RESETHAND;
+      sigaction(SIGABRT, &sa, &g_prev_abort);
+    }
+  }
+} abort_hook;
+}  // namespace
+
 namespace kamd {
 std::string &LastError() {
   static thread_local std::string s;

@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# a run that dies on SIGABRT prints the aborting thread's native stack first (kaldi_amd/csrc/common.cc; read when the library is loaded)
+os.environ.setdefault("KAMD_ABORT_BACKTRACE", "1")
 
 
 def pytest_configure(config):
