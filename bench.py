@@ -103,9 +103,11 @@ def parse_args():
     ap.add_argument("--hash-capacity", type=int, default=0)
     ap.add_argument("--tokens-per-frame", type=int, default=0, help="arena budget per frame and lane (0 = from max-active / free HBM)")
     ap.add_argument("--nnet-pass-frames", type=int, default=1000000)
-    ap.add_argument("--chunked-pass-frames", type=int, default=400000, help="input frames per acoustic-model pass when the model runs chunk by chunk "
-                    "(online i-vectors: the chunks' context rows are 1.9x the activations)")
-    ap.add_argument("--hbm-fraction", type=float, default=0.62, help="share of the free HBM the search arenas of the faithful / planted decoders take")
+    ap.add_argument("--chunked-pass-frames", type=int, default=800000, help="input frames per acoustic-model pass when the model runs chunk by chunk "
+                    "(online i-vectors: the chunks' context rows are 1.9x the activations; round 5: 800 k instead of 400 k -- three passes "
+                    "instead of six, 962.7 -> 942.2 ms per step on one box: fewer GEMM tails, fewer i-vector solver chains)")
+    ap.add_argument("--hbm-fraction", type=float, default=0.40, help="share of the free HBM the search arenas of the faithful / planted decoders take "
+                    "(0.62 until round 5: the arenas no longer hold the dead tokens, the larger passes need the room)")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--cpu-cores", type=int, default=0, help="threads of the cpu_baseline leg (0 = min(cores, 32))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -274,6 +276,7 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
     from kaldi_amd import abi
     from oracle import orc
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = cpu_quota()
     cores = max(1, min(cores if cores > 0 else 32, avail))
     order = [int(i) for i in np.argsort([w.size for w in waves])]
     have_blas = orc.cblas_sgemm() is not None
@@ -368,7 +371,10 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
     used = min(cores, len(sample))
     tot = max(sum(stage_s), 1e-9)
     return {"value": audio / max(wall_w, 1e-9), "unit": "audio-sec/wall-sec", "cores": used, "kind": "port",
-            "cpu_model": cpu_model, "cores_available": avail,
+            "cpu_model": cpu_model, "cores_available": avail, "cpu_quota_cpus": quota,
+            "cores_note": None if quota is None or quota >= used else
+                          "the container's cgroup grants %.0f CPUs of time (cpu.max): the %d threads share them -- per_core_value is per THREAD-second, "
+                          "and the rate per granted CPU is value / %.0f" % (quota, used, quota),
             "per_core_value": audio / max(busy_w, 1e-9),
             "thread_busy_fraction": busy_w / max(wall_w * used, 1e-9),
             "nnet": "cblas_sgemm per Propagate (OpenBLAS, 1 thread per worker), DecodableNnetSimple chunks of 50 frames" if have_blas else
@@ -1024,6 +1030,15 @@ def library_build_id():
         if f.endswith((".hip", ".h")):
             h.update(open(os.path.join(src, f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def cpu_quota():
+    """CPUs of time the container's cgroup grants (cgroup v2 cpu.max = "<quota> <period>"), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_entry(args):

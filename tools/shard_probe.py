@@ -51,7 +51,7 @@ def main():
                                     resident_lanes=a.lanes, host_threads=16, determinize=True, keep_raw_lattices=False, hash_capacity=args.hash_capacity or None,
                                     search_mode=args.search_mode, lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), long_lanes=a.long_lanes,
                                     tokens_per_frame=a.tokens_per_frame or (11000 if a.faithful else None),
-                                    **(dict(nnet_pass_frames=400000, hbm_fraction=0.62) if a.faithful else {}))
+                                    **(dict(nnet_pass_frames=800000, hbm_fraction=0.40) if a.faithful else {}))
         planted = None
         if extractor is not None:
             bd.set_ivector_extractor(extractor, 50)
