@@ -1,11 +1,14 @@
+#define KAMD_RAW_MEMCPY
 #include "common.h"
 
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace {
 // KAMD_ABORT_BACKTRACE=1 (tests/conftest.py sets it): when the process is aborted -- by the HSA runtime after a GPU memory
@@ -38,6 +41,63 @@ struct AbortHook {
 }  // namespace
 
 namespace kamd {
+namespace {
+std::mutex g_bounce_mu;
+void *g_bounce = NULL;
+constexpr size_t kBounceBytes = 32u << 20;
+// is this host address page-locked memory the runtime knows (hipHostMalloc / hipHostRegister)?
+bool HostPinned(const void *p) {
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof(a));
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return a.type == hipMemoryTypeHost;
+}
+hipError_t EnsureBounce() {
+  if (g_bounce) return hipSuccess;
+  return hipHostMalloc(&g_bounce, kBounceBytes, hipHostMallocDefault);
+}
+}  // namespace
+
+hipError_t MemcpySafe(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  if (bytes == 0) return hipSuccess;
+  const bool h2d = kind == hipMemcpyHostToDevice && !HostPinned(src), d2h = kind == hipMemcpyDeviceToHost && !HostPinned(dst);
+  if (!h2d && !d2h) return ::hipMemcpy(dst, src, bytes, kind);
+  std::lock_guard<std::mutex> lk(g_bounce_mu);
+  hipError_t e = EnsureBounce();
+  for (size_t off = 0; e == hipSuccess && off < bytes; off += kBounceBytes) {
+    const size_t n = std::min(kBounceBytes, bytes - off);
+    if (h2d) {
+      memcpy(g_bounce, static_cast<const char *>(src) + off, n);
+      e = ::hipMemcpy(static_cast<char *>(dst) + off, g_bounce, n, hipMemcpyHostToDevice);
+    } else {
+      e = ::hipMemcpy(g_bounce, static_cast<const char *>(src) + off, n, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) memcpy(static_cast<char *>(dst) + off, g_bounce, n);
+    }
+  }
+  return e;
+}
+
+hipError_t MemcpyAsyncSafe(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  const bool h2d = kind == hipMemcpyHostToDevice && !HostPinned(src), d2h = kind == hipMemcpyDeviceToHost && !HostPinned(dst);
+  if (!h2d && !d2h) return ::hipMemcpyAsync(dst, src, bytes, kind, st);
+  std::lock_guard<std::mutex> lk(g_bounce_mu);
+  hipError_t e = EnsureBounce();
+  for (size_t off = 0; e == hipSuccess && off < bytes; off += kBounceBytes) {
+    const size_t n = std::min(kBounceBytes, bytes - off);
+    if (h2d) {
+      memcpy(g_bounce, static_cast<const char *>(src) + off, n);
+      e = ::hipMemcpyAsync(static_cast<char *>(dst) + off, g_bounce, n, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);          // (the bounce buffer is reused)
+    } else {
+      e = ::hipMemcpyAsync(g_bounce, static_cast<const char *>(src) + off, n, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e == hipSuccess) memcpy(static_cast<char *>(dst) + off, g_bounce, n);
+    }
+  }
+  return e;
+}
+
 std::string &LastError() {
   static thread_local std::string s;
   return s;

@@ -47,6 +47,17 @@ int FeatLaunchPremeta(kamd_feat *f, const float *d_waves, const int64_t *d_meta,
     }                                                                               \
   } while (0)
 
+// Copies between PAGEABLE host memory and the device go through a page-locked bounce buffer of the library's own: the GPU
+// and its copy engines then never touch the caller's pages.  Left to the runtime, such a copy pins the caller's buffer in
+// place for its duration; three runs of the GPU test suite in ~35 (rounds 4 and 5) died with "Memory access fault by GPU
+// ... on address <a page boundary inside the process's heap>" while the main thread sat in exactly such a copy (a
+// DeviceMatrix upload, kamd_nnet_forward, kamd_pipeline_load_batch), i.e. something reached one page past what had been
+// pinned.  Page-locked and registered host memory (hipHostMalloc, hipHostRegister: the bench's uploads, the descriptor
+// rings) and device-to-device copies pass through unchanged.  An "async" copy of pageable memory is synchronous here, as
+// it effectively is in the runtime.  Every hipMemcpy / hipMemcpyAsync of the library is one of these two (macros below).
+hipError_t MemcpySafe(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
+hipError_t MemcpyAsyncSafe(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st);
+
 template <typename T>
 inline T *DevAlloc(size_t n) {
   void *p = NULL;
@@ -73,4 +84,9 @@ __host__ __device__ inline float OrderedToFloat(uint32_t u) {
 }
 
 }  // namespace kamd
+
+#ifndef KAMD_RAW_MEMCPY          // (common.cc itself calls the runtime's functions)
+#define hipMemcpy(...) kamd::MemcpySafe(__VA_ARGS__)
+#define hipMemcpyAsync(...) kamd::MemcpyAsyncSafe(__VA_ARGS__)
+#endif
 #endif
