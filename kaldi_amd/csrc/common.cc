@@ -52,6 +52,12 @@ bool HostPinned(const void *p) {
   if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
   return a.type == hipMemoryTypeHost;
 }
+// ... from its first byte to its last?  (A pageable buffer that merely STARTS inside the pages of somebody's registered range
+// -- a heap neighbour of a hipHostRegister'ed array -- must not be taken for pinned memory: the copy would run off the end
+// of what is pinned.)
+bool HostPinnedRange(const void *p, size_t bytes) {
+  return HostPinned(p) && (bytes <= 1 || HostPinned(static_cast<const char *>(p) + bytes - 1));
+}
 hipError_t EnsureBounce() {
   if (g_bounce) return hipSuccess;
   return hipHostMalloc(&g_bounce, kBounceBytes, hipHostMallocDefault);
@@ -60,7 +66,7 @@ hipError_t EnsureBounce() {
 
 hipError_t MemcpySafe(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
   if (bytes == 0) return hipSuccess;
-  const bool h2d = kind == hipMemcpyHostToDevice && !HostPinned(src), d2h = kind == hipMemcpyDeviceToHost && !HostPinned(dst);
+  const bool h2d = kind == hipMemcpyHostToDevice && !HostPinnedRange(src, bytes), d2h = kind == hipMemcpyDeviceToHost && !HostPinnedRange(dst, bytes);
   if (!h2d && !d2h) return ::hipMemcpy(dst, src, bytes, kind);
   std::lock_guard<std::mutex> lk(g_bounce_mu);
   hipError_t e = EnsureBounce();
@@ -79,7 +85,7 @@ hipError_t MemcpySafe(void *dst, const void *src, size_t bytes, hipMemcpyKind ki
 
 hipError_t MemcpyAsyncSafe(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
   if (bytes == 0) return hipSuccess;
-  const bool h2d = kind == hipMemcpyHostToDevice && !HostPinned(src), d2h = kind == hipMemcpyDeviceToHost && !HostPinned(dst);
+  const bool h2d = kind == hipMemcpyHostToDevice && !HostPinnedRange(src, bytes), d2h = kind == hipMemcpyDeviceToHost && !HostPinnedRange(dst, bytes);
   if (!h2d && !d2h) return ::hipMemcpyAsync(dst, src, bytes, kind, st);
   std::lock_guard<std::mutex> lk(g_bounce_mu);
   hipError_t e = EnsureBounce();
