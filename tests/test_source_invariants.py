@@ -64,3 +64,35 @@ def test_soak_variant_transforms_still_match_the_source():
         assert out != src, name
     assert sv.transform("noguards", src).count("if (false)") == 6
     assert "-disable-machine-licm" in sv.product_flags() and "--offload-arch=gfx950" in sv.product_flags()
+
+
+def test_every_copy_of_the_library_goes_through_the_bounce_buffer_wrappers():
+    """common.h turns hipMemcpy / hipMemcpyAsync into kamd::MemcpySafe / MemcpyAsyncSafe (pageable host memory through the
+    library's page-locked bounce buffer: DESIGN.md section 0, open hazards).  Every source that copies must therefore see
+    common.h, and only common.cc may call the runtime's functions themselves."""
+    csrc = os.path.join(ROOT, "kaldi_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".cc", ".hip")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        if f == "common.cc":
+            assert "#define KAMD_RAW_MEMCPY" in text and "::hipMemcpy(" in text and "::hipMemcpyAsync(" in text
+            continue
+        assert "::hipMemcpy" not in text and "KAMD_RAW_MEMCPY" not in text, f
+        if "hipMemcpy" in text:
+            assert '#include "common.h"' in text, f
+    h = open(os.path.join(csrc, "common.h")).read()
+    assert "#define hipMemcpy(...) kamd::MemcpySafe(__VA_ARGS__)" in h and "#define hipMemcpyAsync(...) kamd::MemcpyAsyncSafe(__VA_ARGS__)" in h
+    # the hpp mirror and the examples are host programs over the C-ABI: they copy nothing themselves
+    for f in (os.path.join(ROOT, "include", "kaldi_amd.hpp"),) + tuple(os.path.join(ROOT, "examples", x) for x in os.listdir(os.path.join(ROOT, "examples"))):
+        assert "hipMemcpy" not in open(f).read(), f
+
+
+def test_a_dying_gpu_run_leaves_its_last_words_in_the_log():
+    """pytest.ini captures at the sys level (the HSA runtime's fault line and glibc's messages go to fd 2, which fd-level capture
+    swallows when the process dies) and conftest switches the library's SIGABRT backtrace on."""
+    ini = open(os.path.join(ROOT, "pytest.ini")).read()
+    assert "--capture=sys" in ini
+    conf = open(os.path.join(ROOT, "tests", "conftest.py")).read()
+    assert 'os.environ.setdefault("KAMD_ABORT_BACKTRACE", "1")' in conf
+    assert "KAMD_ABORT_BACKTRACE" in open(os.path.join(ROOT, "kaldi_amd", "csrc", "common.cc")).read()
