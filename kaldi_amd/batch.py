@@ -79,7 +79,10 @@ class NnetBatchDecoder:
     def set_chunk_rule(self, rule):
         """0 / "simple": DecodableNnetSimple's chunks (nnet3-latgen-faster; the default); 1 / "batch_computer": NnetBatchComputer's
         tasks (nnet3-latgen-faster-batch, nnet3/nnet-batch-compute.cc:774-829).  kamd_batch_decoder_set_chunk_rule."""
-        check(lib().kamd_batch_decoder_set_chunk_rule(self._h, {"simple": 0, "batch_computer": 1}.get(rule, rule)))
+        rules = {"simple": 0, "batch_computer": 1, 0: 0, 1: 1}
+        if isinstance(rule, bool) or rule not in rules:
+            raise ValueError("set_chunk_rule: %r is not one of 0 / 'simple', 1 / 'batch_computer'" % (rule,))
+        check(lib().kamd_batch_decoder_set_chunk_rule(self._h, rules[rule]))
 
     def load(self, waves):
         waves = [np.asarray(w, np.float32) for w in waves]

@@ -27,6 +27,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "common.h"
 
 namespace kamd {
@@ -79,6 +81,7 @@ struct BatchDecoder {
   bool host_unloaded = false;                    // kamd_batch_decoder_unload_host: the samples are gone, run() needs a new load
   void *h_registered = NULL;                     // ... page-locked in place by load_host (hipHostRegister) when the runtime allows it:
                                                  // the copies then read it directly; otherwise they go through h_stage
+  uintptr_t reg_lo = 0, reg_hi = 0;              // the locked bytes: the pages that lie wholly inside the caller's samples
   std::vector<int64_t> h_wave_src;
   std::vector<int> pass_u0;                      // pass p = kept utterances [pass_u0[p], pass_u0[p + 1])
   std::vector<int64_t> pass_frames;              // feature frames of pass p
@@ -517,10 +520,22 @@ int kamd_batch_decoder_load_host(kamd_batch_decoder *h, const float *waves, cons
   // that refuses (limits on locked memory) leaves the staged path.
   static const bool no_register = getenv("KAMD_BATCH_NO_REGISTER") != NULL;
   const size_t span = static_cast<size_t>(h_wave_off[n_utts] - h_wave_off[0]) * sizeof(float);
+  b->reg_lo = b->reg_hi = 0;
   if (!no_register && span > 0) {
-    void *base = const_cast<float *>(waves + h_wave_off[0]);
-    if (hipHostRegister(base, span, hipHostRegisterDefault) == hipSuccess) b->h_registered = base;
-    else (void)hipGetLastError();
+    // Only the pages that lie WHOLLY inside the caller's samples are locked.  The runtime locks whole pages: had the range
+    // been handed over as it is, the first and the last page would be shared with whatever the caller's allocator put next
+    // to the array, and to the runtime those neighbours would look like page-locked memory from then on -- a copy of the
+    // host's own (torch, a Kaldi binary) from such a neighbour is then started as a pinned copy and runs off the end of what
+    // is pinned.  The head and the tail of the array (under a page each) go through the bounce buffer instead.
+    const uintptr_t page = static_cast<uintptr_t>(sysconf(_SC_PAGESIZE) > 0 ? sysconf(_SC_PAGESIZE) : 4096);
+    const uintptr_t lo = reinterpret_cast<uintptr_t>(waves + h_wave_off[0]), hi = lo + span;
+    const uintptr_t in_lo = (lo + page - 1) / page * page, in_hi = hi / page * page;
+    if (in_hi > in_lo && hipHostRegister(reinterpret_cast<void *>(in_lo), in_hi - in_lo, hipHostRegisterDefault) == hipSuccess) {
+      b->h_registered = reinterpret_cast<void *>(in_lo);
+      b->reg_lo = in_lo; b->reg_hi = in_hi;
+    } else {
+      (void)hipGetLastError();
+    }
   }
   b->h_waves = waves;
   b->out.resize(n_utts);
@@ -636,8 +651,16 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
           const float *src = b->h_waves + b->h_wave_src[u];
           float *dst = b->d_waves + b->wave_off[u];
           if (b->h_registered) {          // page-locked in place: one copy for the whole run of utterances
-            const hipError_t e = hipMemcpyAsync(dst, src, static_cast<size_t>(b->wave_off[v] - b->wave_off[u]) * sizeof(float), hipMemcpyHostToDevice, b->s_up);
-            if (e != hipSuccess) fail(e);
+            // ... cut at the ends of the locked pages: the piece inside is read where it lies, the part of the array's first
+            // and last page outside goes through the bounce buffer (MemcpyAsyncSafe finds it pageable)
+            const uintptr_t s0 = reinterpret_cast<uintptr_t>(src), s1 = s0 + static_cast<size_t>(b->wave_off[v] - b->wave_off[u]) * sizeof(float);
+            const uintptr_t cut[4] = {s0, std::min(std::max(s0, b->reg_lo), s1), std::min(std::max(s0, b->reg_hi), s1), s1};
+            for (int i = 0; i < 3; i++)
+              if (cut[i + 1] > cut[i]) {
+                const hipError_t e = hipMemcpyAsync(reinterpret_cast<char *>(dst) + (cut[i] - s0), reinterpret_cast<const void *>(cut[i]), cut[i + 1] - cut[i],
+                                                    hipMemcpyHostToDevice, b->s_up);
+                if (e != hipSuccess) { fail(e); break; }
+              }
             u = v;
             continue;
           }
@@ -982,7 +1005,12 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
         rt[i].n_frames = static_cast<int32_t>(b->out_off[k + 1] - b->out_off[k]); rt[i].utt = i; rt[i].reserved = 0;
       }
       rc = kamd_decoder_queue_launch_wide(b->dec, rt.data(), m, st);
-      if (rc == KAMD_ERR_ARG) continue;      // the launch refused these tasks: their first failure stands, the run goes on
+      if (rc == KAMD_ERR_ARG) {
+        // the launch refused these tasks (the frame-length case is filtered above, so this is unexpected): their first
+        // failure stands and the run goes on, but not silently
+        fprintf(stderr, "kaldi_amd: second-chance launch of %d utterance(s) refused: %s\n", m, kamd_last_error());
+        continue;
+      }
       if (rc != KAMD_OK) return rc;
       int got = 0;
       while (got < m) {

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 
 namespace {
@@ -42,9 +43,38 @@ struct AbortHook {
 
 namespace kamd {
 namespace {
+// A small pool of page-locked bounce buffers: a copy takes one, the pool's lock is held only while a buffer changes hands
+// (never across a copy or a stream wait: a thread waiting for a long-running stream must not hold up the host-tail threads'
+// small reads).  A copy that finds the pool empty allocates a buffer of its own, up to kMaxBounce; beyond that it waits.
+constexpr size_t kBounceBytes = 8u << 20;
+constexpr int kMaxBounce = 8;
 std::mutex g_bounce_mu;
-void *g_bounce = NULL;
-constexpr size_t kBounceBytes = 32u << 20;
+std::condition_variable g_bounce_cv;
+void *g_bounce_free[kMaxBounce];
+int g_bounce_nfree = 0, g_bounce_made = 0;
+struct Bounce {
+  void *p = NULL;
+  hipError_t err = hipSuccess;
+  Bounce() {
+    std::unique_lock<std::mutex> lk(g_bounce_mu);
+    for (;;) {
+      if (g_bounce_nfree > 0) { p = g_bounce_free[--g_bounce_nfree]; return; }
+      if (g_bounce_made < kMaxBounce) {
+        g_bounce_made++;
+        lk.unlock();
+        err = hipHostMalloc(&p, kBounceBytes, hipHostMallocDefault);
+        if (err != hipSuccess) { p = NULL; lk.lock(); g_bounce_made--; g_bounce_cv.notify_one(); }
+        return;
+      }
+      g_bounce_cv.wait(lk);
+    }
+  }
+  ~Bounce() {
+    if (!p) return;
+    { std::lock_guard<std::mutex> lk(g_bounce_mu); g_bounce_free[g_bounce_nfree++] = p; }
+    g_bounce_cv.notify_one();
+  }
+};
 // is this host address page-locked memory the runtime knows (hipHostMalloc / hipHostRegister)?
 bool HostPinned(const void *p) {
   hipPointerAttribute_t a;
@@ -54,13 +84,14 @@ bool HostPinned(const void *p) {
 }
 // ... from its first byte to its last?  (A pageable buffer that merely STARTS inside the pages of somebody's registered range
 // -- a heap neighbour of a hipHostRegister'ed array -- must not be taken for pinned memory: the copy would run off the end
-// of what is pinned.)
+// of what is pinned.)  The runtime reports no extent for a registered host range, so the two ends (and, for a long range, its
+// middle) are what can be asked; a buffer laid over two registrations with a pageable gap between them is the caller's error.
 bool HostPinnedRange(const void *p, size_t bytes) {
-  return HostPinned(p) && (bytes <= 1 || HostPinned(static_cast<const char *>(p) + bytes - 1));
-}
-hipError_t EnsureBounce() {
-  if (g_bounce) return hipSuccess;
-  return hipHostMalloc(&g_bounce, kBounceBytes, hipHostMallocDefault);
+  if (!HostPinned(p)) return false;
+  if (bytes <= 1) return true;
+  const char *c = static_cast<const char *>(p);
+  if (!HostPinned(c + bytes - 1)) return false;
+  return bytes <= (2u << 20) || HostPinned(c + bytes / 2);
 }
 }  // namespace
 
@@ -68,16 +99,16 @@ hipError_t MemcpySafe(void *dst, const void *src, size_t bytes, hipMemcpyKind ki
   if (bytes == 0) return hipSuccess;
   const bool h2d = kind == hipMemcpyHostToDevice && !HostPinnedRange(src, bytes), d2h = kind == hipMemcpyDeviceToHost && !HostPinnedRange(dst, bytes);
   if (!h2d && !d2h) return ::hipMemcpy(dst, src, bytes, kind);
-  std::lock_guard<std::mutex> lk(g_bounce_mu);
-  hipError_t e = EnsureBounce();
+  Bounce bb;
+  hipError_t e = bb.err;
   for (size_t off = 0; e == hipSuccess && off < bytes; off += kBounceBytes) {
     const size_t n = std::min(kBounceBytes, bytes - off);
     if (h2d) {
-      memcpy(g_bounce, static_cast<const char *>(src) + off, n);
-      e = ::hipMemcpy(static_cast<char *>(dst) + off, g_bounce, n, hipMemcpyHostToDevice);
+      memcpy(bb.p, static_cast<const char *>(src) + off, n);
+      e = ::hipMemcpy(static_cast<char *>(dst) + off, bb.p, n, hipMemcpyHostToDevice);
     } else {
-      e = ::hipMemcpy(g_bounce, static_cast<const char *>(src) + off, n, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) memcpy(static_cast<char *>(dst) + off, g_bounce, n);
+      e = ::hipMemcpy(bb.p, static_cast<const char *>(src) + off, n, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) memcpy(static_cast<char *>(dst) + off, bb.p, n);
     }
   }
   return e;
@@ -87,21 +118,64 @@ hipError_t MemcpyAsyncSafe(void *dst, const void *src, size_t bytes, hipMemcpyKi
   if (bytes == 0) return hipSuccess;
   const bool h2d = kind == hipMemcpyHostToDevice && !HostPinnedRange(src, bytes), d2h = kind == hipMemcpyDeviceToHost && !HostPinnedRange(dst, bytes);
   if (!h2d && !d2h) return ::hipMemcpyAsync(dst, src, bytes, kind, st);
-  std::lock_guard<std::mutex> lk(g_bounce_mu);
-  hipError_t e = EnsureBounce();
+  Bounce bb;
+  hipError_t e = bb.err;
   for (size_t off = 0; e == hipSuccess && off < bytes; off += kBounceBytes) {
     const size_t n = std::min(kBounceBytes, bytes - off);
     if (h2d) {
-      memcpy(g_bounce, static_cast<const char *>(src) + off, n);
-      e = ::hipMemcpyAsync(static_cast<char *>(dst) + off, g_bounce, n, hipMemcpyHostToDevice, st);
+      memcpy(bb.p, static_cast<const char *>(src) + off, n);
+      e = ::hipMemcpyAsync(static_cast<char *>(dst) + off, bb.p, n, hipMemcpyHostToDevice, st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);          // (the bounce buffer is reused)
     } else {
-      e = ::hipMemcpyAsync(g_bounce, static_cast<const char *>(src) + off, n, hipMemcpyDeviceToHost, st);
+      e = ::hipMemcpyAsync(bb.p, static_cast<const char *>(src) + off, n, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
-      if (e == hipSuccess) memcpy(static_cast<char *>(dst) + off, g_bounce, n);
+      if (e == hipSuccess) memcpy(static_cast<char *>(dst) + off, bb.p, n);
     }
   }
   return e;
+}
+
+// The pitched copies: rows of `width` bytes, `spitch` / `dpitch` bytes apart.  With a pageable host side the rows are packed
+// into (unpacked from) the bounce buffer, as many whole rows per trip as fit.
+static hipError_t Memcpy2DImpl(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind,
+                               bool async, hipStream_t st) {
+  if (width == 0 || height == 0) return hipSuccess;
+  const size_t hspan_src = (height - 1) * spitch + width, hspan_dst = (height - 1) * dpitch + width;
+  const bool h2d = kind == hipMemcpyHostToDevice && !HostPinnedRange(src, hspan_src), d2h = kind == hipMemcpyDeviceToHost && !HostPinnedRange(dst, hspan_dst);
+  if (!h2d && !d2h) return async ? ::hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, st) : ::hipMemcpy2D(dst, dpitch, src, spitch, width, height, kind);
+  if (width > kBounceBytes) {                  // (a row longer than the buffer: row by row through the flat copy)
+    hipError_t e = hipSuccess;
+    for (size_t r = 0; e == hipSuccess && r < height; r++)
+      e = async ? MemcpyAsyncSafe(static_cast<char *>(dst) + r * dpitch, static_cast<const char *>(src) + r * spitch, width, kind, st)
+                : MemcpySafe(static_cast<char *>(dst) + r * dpitch, static_cast<const char *>(src) + r * spitch, width, kind);
+    return e;
+  }
+  Bounce bb;
+  hipError_t e = bb.err;
+  const size_t rows_per_trip = kBounceBytes / width;
+  for (size_t r0 = 0; e == hipSuccess && r0 < height; r0 += rows_per_trip) {
+    const size_t nr = std::min(rows_per_trip, height - r0);
+    char *b = static_cast<char *>(bb.p);
+    if (h2d) {
+      for (size_t r = 0; r < nr; r++) memcpy(b + r * width, static_cast<const char *>(src) + (r0 + r) * spitch, width);
+      e = async ? ::hipMemcpy2DAsync(static_cast<char *>(dst) + r0 * dpitch, dpitch, b, width, width, nr, hipMemcpyHostToDevice, st)
+                : ::hipMemcpy2D(static_cast<char *>(dst) + r0 * dpitch, dpitch, b, width, width, nr, hipMemcpyHostToDevice);
+      if (async && e == hipSuccess) e = hipStreamSynchronize(st);
+    } else {
+      e = async ? ::hipMemcpy2DAsync(b, width, static_cast<const char *>(src) + r0 * spitch, spitch, width, nr, hipMemcpyDeviceToHost, st)
+                : ::hipMemcpy2D(b, width, static_cast<const char *>(src) + r0 * spitch, spitch, width, nr, hipMemcpyDeviceToHost);
+      if (async && e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e == hipSuccess)
+        for (size_t r = 0; r < nr; r++) memcpy(static_cast<char *>(dst) + (r0 + r) * dpitch, b + r * width, width);
+    }
+  }
+  return e;
+}
+hipError_t Memcpy2DSafe(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind) {
+  return Memcpy2DImpl(dst, dpitch, src, spitch, width, height, kind, false, NULL);
+}
+hipError_t Memcpy2DAsyncSafe(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t st) {
+  return Memcpy2DImpl(dst, dpitch, src, spitch, width, height, kind, true, st);
 }
 
 std::string &LastError() {
@@ -154,8 +228,9 @@ void *kamd_malloc(size_t bytes) {
   return p;
 }
 int kamd_free(void *p) { KAMD_HIP(hipFree(p)); return KAMD_OK; }
-int kamd_memcpy_h2d(void *d, const void *h, size_t bytes) { KAMD_HIP(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return KAMD_OK; }
-int kamd_memcpy_d2h(void *h, const void *d, size_t bytes) { KAMD_HIP(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return KAMD_OK; }
+// (the caller's memory is pageable as a rule -- a numpy array, a std::vector: through the bounce buffer like every copy of the library)
+int kamd_memcpy_h2d(void *d, const void *h, size_t bytes) { KAMD_HIP(kamd::MemcpySafe(d, h, bytes, hipMemcpyHostToDevice)); return KAMD_OK; }
+int kamd_memcpy_d2h(void *h, const void *d, size_t bytes) { KAMD_HIP(kamd::MemcpySafe(h, d, bytes, hipMemcpyDeviceToHost)); return KAMD_OK; }
 int kamd_device_synchronize(void) { KAMD_HIP(hipDeviceSynchronize()); return KAMD_OK; }
 int kamd_device_mem_info(size_t *free_bytes, size_t *total_bytes) { KAMD_HIP(hipMemGetInfo(free_bytes, total_bytes)); return KAMD_OK; }
 void kamd_mfcc_opts_default(kamd_mfcc_opts *o) {

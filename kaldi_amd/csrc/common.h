@@ -54,9 +54,12 @@ int FeatLaunchPremeta(kamd_feat *f, const float *d_waves, const int64_t *d_meta,
 // DeviceMatrix upload, kamd_nnet_forward, kamd_pipeline_load_batch), i.e. something reached one page past what had been
 // pinned.  Page-locked and registered host memory (hipHostMalloc, hipHostRegister: the bench's uploads, the descriptor
 // rings) and device-to-device copies pass through unchanged.  An "async" copy of pageable memory is synchronous here, as
-// it effectively is in the runtime.  Every hipMemcpy / hipMemcpyAsync of the library is one of these two (macros below).
+// it effectively is in the runtime.  Every hipMemcpy / hipMemcpyAsync / hipMemcpy2D / hipMemcpy2DAsync of the library is one of
+// these four (macros below), the exported kamd_memcpy_h2d / kamd_memcpy_d2h included.
 hipError_t MemcpySafe(void *dst, const void *src, size_t bytes, hipMemcpyKind kind);
 hipError_t MemcpyAsyncSafe(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, hipStream_t st);
+hipError_t Memcpy2DSafe(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind);
+hipError_t Memcpy2DAsyncSafe(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t st);
 
 template <typename T>
 inline T *DevAlloc(size_t n) {
@@ -88,5 +91,7 @@ __host__ __device__ inline float OrderedToFloat(uint32_t u) {
 #ifndef KAMD_RAW_MEMCPY          // (common.cc itself calls the runtime's functions)
 #define hipMemcpy(...) kamd::MemcpySafe(__VA_ARGS__)
 #define hipMemcpyAsync(...) kamd::MemcpyAsyncSafe(__VA_ARGS__)
+#define hipMemcpy2D(...) kamd::Memcpy2DSafe(__VA_ARGS__)
+#define hipMemcpy2DAsync(...) kamd::Memcpy2DAsyncSafe(__VA_ARGS__)
 #endif
 #endif

@@ -67,25 +67,62 @@ def test_soak_variant_transforms_still_match_the_source():
 
 
 def test_every_copy_of_the_library_goes_through_the_bounce_buffer_wrappers():
-    """common.h turns hipMemcpy / hipMemcpyAsync into kamd::MemcpySafe / MemcpyAsyncSafe (pageable host memory through the
-    library's page-locked bounce buffer: DESIGN.md section 0, open hazards).  Every source that copies must therefore see
-    common.h, and only common.cc may call the runtime's functions themselves."""
+    """common.h turns hipMemcpy / hipMemcpyAsync / hipMemcpy2D / hipMemcpy2DAsync into kamd::Memcpy*Safe (pageable host memory
+    through the library's page-locked bounce buffers: DESIGN.md section 0).  Every source that copies must therefore see
+    common.h, no source may use a copy call of the runtime that has no wrapper, and in common.cc -- the one file that sees
+    the runtime's own functions -- every raw call is inside the wrappers: the EXPORTED copies (kamd_memcpy_h2d / _d2h) go
+    through MemcpySafe like everybody else."""
+    import re
     csrc = os.path.join(ROOT, "kaldi_amd", "csrc")
+    wrapped = {"hipMemcpy", "hipMemcpyAsync", "hipMemcpy2D", "hipMemcpy2DAsync"}
     for f in sorted(os.listdir(csrc)):
-        if not f.endswith((".cc", ".hip")):
+        if not f.endswith((".cc", ".hip", ".h")):
             continue
         text = open(os.path.join(csrc, f)).read()
+        code = re.sub(r"//[^\n]*", "", text)
+        called = set(re.findall(r"\b(hipMemcpy\w*)\s*\(", code))
+        called = {c for c in called if not c.startswith("hipMemcpyKind")}
         if f == "common.cc":
-            assert "#define KAMD_RAW_MEMCPY" in text and "::hipMemcpy(" in text and "::hipMemcpyAsync(" in text
+            assert "#define KAMD_RAW_MEMCPY" in text
+            # raw calls are written ::hipMemcpy...( and occur only before the first extern "C" (i.e. inside the wrappers)
+            head, _, exports = code.partition('extern "C"')
+            assert exports and "hipMemcpy" not in re.sub(r"hipMemcpy(HostToDevice|DeviceToHost)", "", exports), "an exported function of common.cc copies raw"
+            assert re.search(r"int kamd_memcpy_h2d\([^)]*\) \{ KAMD_HIP\(kamd::MemcpySafe\(", exports)
+            assert re.search(r"int kamd_memcpy_d2h\([^)]*\) \{ KAMD_HIP\(kamd::MemcpySafe\(", exports)
+            assert all(("::" + c + "(") in head for c in wrapped)
+            assert called <= wrapped, called
+            continue
+        if f == "common.h":
+            for c in wrapped:
+                assert re.search(r"#define %s\(\.\.\.\) kamd::Memcpy\w*Safe\(__VA_ARGS__\)" % c, text), c
             continue
         assert "::hipMemcpy" not in text and "KAMD_RAW_MEMCPY" not in text, f
-        if "hipMemcpy" in text:
+        assert called <= wrapped, (f, called - wrapped)          # (no hipMemcpyDtoH / HtoD / WithStream / 3D / Peer ... without a wrapper)
+        if called:
             assert '#include "common.h"' in text, f
-    h = open(os.path.join(csrc, "common.h")).read()
-    assert "#define hipMemcpy(...) kamd::MemcpySafe(__VA_ARGS__)" in h and "#define hipMemcpyAsync(...) kamd::MemcpyAsyncSafe(__VA_ARGS__)" in h
+    # the caller's samples are page-locked in place only over the pages that lie wholly inside them (batch.cc, load_host)
+    b = open(os.path.join(csrc, "batch.cc")).read()
+    assert b.count("hipHostRegister(") == 1 and "hipHostRegister(reinterpret_cast<void *>(in_lo), in_hi - in_lo" in b
     # the hpp mirror and the examples are host programs over the C-ABI: they copy nothing themselves
     for f in (os.path.join(ROOT, "include", "kaldi_amd.hpp"),) + tuple(os.path.join(ROOT, "examples", x) for x in os.listdir(os.path.join(ROOT, "examples"))):
         assert "hipMemcpy" not in open(f).read(), f
+
+
+def test_the_exported_copies_do_not_call_the_runtime_directly():
+    """The shipped library, disassembled: kamd_memcpy_h2d / kamd_memcpy_d2h call kamd::MemcpySafe, not hipMemcpy@plt."""
+    import shutil
+    import subprocess
+    lib = os.path.join(ROOT, "kaldi_amd", "lib", "libkaldi_amd.so")
+    if not os.path.exists(lib) or not shutil.which("objdump"):
+        import pytest
+        pytest.skip("no built library / objdump")
+    dis = subprocess.run(["objdump", "-d", "--no-show-raw-insn", lib], capture_output=True, text=True, check=True).stdout
+    for sym in ("kamd_memcpy_h2d", "kamd_memcpy_d2h"):
+        body = dis[dis.index("<%s>:" % sym):]
+        body = body[:body.index("\n\n")]
+        calls = [ln for ln in body.splitlines() if "call" in ln]
+        assert any("MemcpySafe" in c for c in calls), (sym, calls)
+        assert not any("<hipMemcpy" in c for c in calls), (sym, calls)
 
 
 def test_a_dying_gpu_run_leaves_its_last_words_in_the_log():
