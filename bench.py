@@ -262,7 +262,32 @@ def _run_threads(fn, items, threads):
     return res, time.time() - t0, sum(busy)
 
 
-def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
+def _clat_accepts(cl, words):
+    """Is `words` a path of the determinized word lattice `cl` (start state to a final state, epsilon-labelled arcs free)?"""
+    if cl is None or cl.num_states == 0 or cl.start < 0:
+        return False
+    out = {}
+    for a in cl.arcs:
+        out.setdefault(int(a["src"]), []).append((int(a["label"]), int(a["dst"])))
+
+    def closure(states):
+        todo, seen = list(states), set(states)
+        while todo:
+            for lab, d in out.get(todo.pop(), ()):
+                if lab == 0 and d not in seen:
+                    seen.add(d)
+                    todo.append(d)
+        return seen
+
+    cur = closure({int(cl.start)})
+    for w in words:
+        cur = closure({d for s_ in cur for lab, d in out.get(s_, ()) if lab == int(w)})
+        if not cur:
+            return False
+    return any(np.isfinite(cl.final[2 * s_]) for s_ in cur)
+
+
+def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None, ivec=None, transcripts=None):
     """The CPU path (a port of the reference: oracle/) on this host's cores, on a bounded sample of the same test set:
     `cores` threads, each pulling the next utterance (one LatticeFasterDecoder per thread, like nnet3-latgen-faster-
     parallel; the oracle is C behind ctypes, which releases the interpreter lock), every thread busy for the whole
@@ -272,7 +297,15 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
     reported beside it.  Second leg: the CPU decoder alone on the DEVICE's log-likelihoods (latgen-faster-mapped's job),
     which is also the 1-best parity check of the sampled utterances.  ll_of (the faithful headline): the decoder searches
     ll_of(idx) -- the planted log-likelihoods the device searched -- instead of the model's output, which is still computed
-    (the model here is the topology WITHOUT the i-vector input: the scalar / sgemm port has no extractor)."""
+    (`model` is the topology WITHOUT the i-vector input).  ivec = (model with the i-vector input, extractor description): the
+    LIKE-FOR-LIKE path then -- MFCC, ivector-extract-online2 (oracle/orc_ivector.cc: OnlineCmvn, splice, LDA, UBM posteriors,
+    stats, CG), the i-vector model in chunks of 50 with the chunk's own i-vector (sgemm), the search, the best path: every stage
+    the device ran -- is `value`, on as many threads as the cgroup grants CPUs; the path without the extractor on `cores`
+    threads (rounds 3-5's figure) stays beside it.  transcripts = {utterance: planted words}: the divergence of the device's
+    order-free search (mode 2) from the reference's order-dependent one (mode 0) on the same log-likelihoods is then reported
+    with its sign, both WERs against the transcript, and -- the yardstick -- the reference against ITSELF with another
+    --hash-ratio (its own option, which changes nothing but the HashList's bucket order)."""
+    import copy
     from kaldi_amd import abi
     from oracle import orc
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -280,14 +313,22 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
     cores = max(1, min(cores if cores > 0 else 32, avail))
     order = [int(i) for i in np.argsort([w.size for w in waves])]
     have_blas = orc.cblas_sgemm() is not None
-    stage_s = [0.0, 0.0, 0.0]
+    stage_s = [0.0, 0.0, 0.0, 0.0]          # features, i-vector extraction, model, search + best path
     ll_cache = {}
+    like = [False]          # whole() runs the like-for-like path (extractor + i-vector model)
 
     def whole(idx):
         t0 = time.time()
         feats = orc.mfcc(abi.mfcc_opts_hires(), waves[idx])
-        t1 = time.time()
-        ll = orc.nnet_forward_blas(model, feats, frames_per_chunk=50) if have_blas else orc.nnet_forward(model, feats)
+        t1 = t1b = time.time()
+        if like[0]:
+            m_iv, info = ivec
+            iv = orc.ivector_extract_online(info, feats)
+            t1b = time.time()
+            ll = (orc.nnet_forward_blas_chunked(m_iv, feats, iv, info.ivector_period, 50) if have_blas else
+                  orc.nnet_forward_chunked(m_iv, feats, iv, info.ivector_period, 50))
+        else:
+            ll = orc.nnet_forward_blas(model, feats, frames_per_chunk=50) if have_blas else orc.nnet_forward(model, feats)
         t2 = time.time()
         if ll_of is not None:
             ll = ll_cache[idx] if idx in ll_cache else ll_of(idx)       # (fetched before the timed part for the sampled utterances)
@@ -296,7 +337,7 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
         lat = d.GetRawLattice()
         bp = lat.best_path() if lat is not None else None
         t3 = time.time()
-        stage_s[0] += t1 - t0; stage_s[1] += t2 - t1; stage_s[2] += t3 - t2       # (racy sums: shares only)
+        stage_s[0] += t1 - t0; stage_s[1] += t1b - t1; stage_s[2] += t2 - t1b; stage_s[3] += t3 - t2       # (racy sums: shares only)
         return bp
 
     # the shortest utterance alone: the single-core rate sizes the sample; the same utterance through the scalar nnet
@@ -311,7 +352,6 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
     if have_blas:
         orc.nnet_forward_blas(model, f0, frames_per_chunk=50)
     t_blas_nnet = time.time() - t0
-    stage_s[:] = [0.0, 0.0, 0.0]
     a0 = waves[order[0]].size / 16000.0
     rate = a0 / max(t_first, 1e-6)
     audio_budget = rate * budget_s * cores * 0.6
@@ -328,25 +368,46 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
     k_one = min(max(k_strat, int(np.ceil(total_audio / max(rate * 8.0, 1e-9)))), max(1, len(order) // 8))
     sample_one = order[k_one // 2::k_one]
     audio_one = sum(waves[i].size for i in sample_one) / 16000.0
+    like[0] = ivec is not None
     t0 = time.time()
     for idx in sample_one:
         whole(idx)
     t_one = time.time() - t0
-    stage_s[:] = [0.0, 0.0, 0.0]
     # longest of the sample first, so the tail of the run is made of the short ones
     sample.sort(key=lambda i: -waves[i].size)
     ll_cache.update({i: (ll_of(i) if ll_of is not None else bd.loglikes(i)) for i in sample})
+    # ---- the path without the extractor on `cores` threads (rounds 3-5's figure)
+    like[0] = False
+    stage_s[:] = [0.0] * 4
     res_w, wall_w, busy_w = _run_threads(whole, sample, cores)
+    share_w = list(stage_s)
+    used = min(cores, len(sample))
+    # ---- the like-for-like path on as many threads as the cgroup grants CPUs
+    like_out = None
+    if ivec is not None:
+        like[0] = True
+        stage_s[:] = [0.0] * 4
+        thr = max(1, min(int(quota) if quota else cores, len(sample), avail))
+        res_l, wall_l, busy_l = _run_threads(whole, sample, thr)
+        tot_l = max(sum(stage_s), 1e-9)
+        like_out = {"value": audio / max(wall_l, 1e-9), "cores": thr, "per_core_value": audio / max(busy_l, 1e-9), "wall_s": wall_l,
+                    "thread_busy_fraction": busy_l / max(wall_l * thr, 1e-9),
+                    "stage_share": {"features": stage_s[0] / tot_l, "ivector_extraction": stage_s[1] / tot_l, "nnet": stage_s[2] / tot_l,
+                                    "decoder_and_best_path": stage_s[3] / tot_l}}
     bd_like = ll_cache
 
-    def dec_cached(idx):
-        d = orc.Decoder(g, cfg, 0)
-        d.Decode(bd_like[idx])
-        lat = d.GetRawLattice()
-        return lat.best_path() if lat is not None else None
+    def dec_with(c2):
+        def run(idx):
+            d = orc.Decoder(g, c2, 0)
+            d.Decode(bd_like[idx])
+            lat = d.GetRawLattice()
+            return lat.best_path() if lat is not None else None
+        return run
 
-    res_d, wall_d, busy_d = _run_threads(dec_cached, sample, cores)
+    res_d, wall_d, busy_d = _run_threads(dec_with(cfg), sample, cores)
     errs_w = errs_d = ref_w = ref_d = cost_diff = 0
+    gaps = []
+    tot_cost = lambda bp: float(bp["graph_cost"] + bp["acoustic_cost"])          # noqa: E731
     for k, idx in enumerate(sample):
         gpu = bd.output(idx)
         gw = gpu["words"].tolist() if gpu is not None else []
@@ -358,8 +419,48 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
             ref = res_d[k]["words"].tolist()
             errs_d += _edit_distance(ref, gw)
             ref_d += len(ref)
-            if gpu is None or abs((gpu["graph_cost"] + gpu["acoustic_cost"]) - (res_d[k]["graph_cost"] + res_d[k]["acoustic_cost"])) > 1e-3:
+            if gpu is None or abs(tot_cost(gpu) - tot_cost(res_d[k])) > 1e-3:
                 cost_diff += 1
+                gaps.append((idx, None if gpu is None else tot_cost(gpu) - tot_cost(res_d[k])))
+    # ---- the divergence from the reference's own search, with its sign ("next round" 1)
+    div = None
+    if transcripts is not None:
+        c3 = copy.copy(cfg)
+        c3.hash_ratio = 3.0
+        res_h, _, _ = _run_threads(dec_with(c3), sample, cores)
+        words_of = lambda r: r["words"].tolist() if r is not None else []          # noqa: E731
+        n_ref = sum(len(transcripts[i]) for i in sample)
+        e_dev = sum(_edit_distance(list(transcripts[i]), words_of(bd.output(i))) for i in sample)
+        e_m0 = sum(_edit_distance(list(transcripts[i]), words_of(res_d[k])) for k, i in enumerate(sample))
+        e_h3 = sum(_edit_distance(list(transcripts[i]), words_of(res_h[k])) for k, i in enumerate(sample))
+        detail = []
+        for idx, gap in gaps:
+            k = sample.index(idx)
+            cl = None
+            try:
+                cl = bd.compact_lattice(idx)
+            except Exception:                       # noqa: BLE001 (no determinized lattices kept: containment unknown)
+                pass
+            detail.append({"utterance": int(idx), "seconds": waves[idx].size / 16000.0, "device_cost_minus_mode0_cost": gap,
+                           "errors_device": _edit_distance(list(transcripts[idx]), words_of(bd.output(idx))),
+                           "errors_mode0": _edit_distance(list(transcripts[idx]), words_of(res_d[k])),
+                           "mode0_words_in_device_lattice": None if cl is None else bool(_clat_accepts(cl, words_of(res_d[k])))})
+        self_diff = [k for k in range(len(sample)) if (res_h[k] is None) != (res_d[k] is None) or
+                     (res_h[k] is not None and (abs(tot_cost(res_h[k]) - tot_cost(res_d[k])) > 1e-3 or words_of(res_h[k]) != words_of(res_d[k])))]
+        div = {"utterances": len(sample), "reference_words": n_ref,
+               "wer_device": 100.0 * e_dev / max(n_ref, 1), "wer_mode0": 100.0 * e_m0 / max(n_ref, 1),
+               "abs_delta": abs(100.0 * (e_dev - e_m0) / max(n_ref, 1)), "device_minus_mode0_errors": e_dev - e_m0,
+               "utterances_with_other_cost": cost_diff,
+               "device_cost_lower": sum(1 for _, gp in gaps if gp is not None and gp < -1e-3),
+               "device_cost_higher": sum(1 for _, gp in gaps if gp is None or gp > 1e-3),
+               "detail": detail,
+               "reference_against_itself": {"what": "oracle mode 0 with --hash-ratio 3 instead of 2 (lattice-faster-decoder.h:60; only the HashList's "
+                                                    "bucket order changes) on the same log-likelihoods",
+                                            "utterances_with_other_cost_or_words": len(self_diff),
+                                            "wer_mode0_hash_ratio_3": 100.0 * e_h3 / max(n_ref, 1),
+                                            "abs_delta_vs_mode0": abs(100.0 * (e_h3 - e_m0) / max(n_ref, 1))},
+               "what": "same log-likelihoods; device = the order-free search (oracle mode 2, bit-equal in the tests), mode0 = the reference's "
+                       "order-dependent search restated (oracle/orc_decoder.cc); WERs against the planted transcripts of the sampled utterances"}
     cpu_model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -368,33 +469,44 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None):
                 break
     except OSError:
         pass
-    used = min(cores, len(sample))
-    tot = max(sum(stage_s), 1e-9)
-    return {"value": audio / max(wall_w, 1e-9), "unit": "audio-sec/wall-sec", "cores": used, "kind": "port",
-            "cpu_model": cpu_model, "cores_available": avail, "cpu_quota_cpus": quota,
-            "cores_note": None if quota is None or quota >= used else
-                          "the container's cgroup grants %.0f CPUs of time (cpu.max): the %d threads share them -- per_core_value is per THREAD-second, "
-                          "and the rate per granted CPU is value / %.0f" % (quota, used, quota),
-            "per_core_value": audio / max(busy_w, 1e-9),
-            "thread_busy_fraction": busy_w / max(wall_w * used, 1e-9),
-            "nnet": "cblas_sgemm per Propagate (OpenBLAS, 1 thread per worker), DecodableNnetSimple chunks of 50 frames" if have_blas else
-                    "scalar oracle (no OpenBLAS found next to numpy)",
-            "stage_share": {"features": stage_s[0] / tot, "nnet": stage_s[1] / tot, "decoder_and_best_path": stage_s[2] / tot},
-            "nnet_only_per_core": {"sgemm": a0 / max(t_blas_nnet, 1e-9) if have_blas else None, "scalar_oracle": a0 / max(t_scalar_nnet, 1e-9),
-                                   "what": "audio seconds per second of the acoustic model alone on one core (the shortest utterance)"},
-            "sample": "duration-stratified: every %d-th utterance of the duration-sorted test set, %d utterances (%.1f s audio, %.1f-%.1f s "
-                      "each) on %d threads pulling from one list (longest first), %.1f s wall, %.1f core-s: whole path MFCC + nnet (%s) + "
-                      "LatticeFasterDecoder (order-faithful oracle, mode 0) + best path; single-utterance probe %.2f s" %
-                      (k_strat, len(sample), audio, min(waves[i].size for i in sample) / 16000.0, max(waves[i].size for i in sample) / 16000.0,
-                       used, wall_w, busy_w, "sgemm" if have_blas else "scalar", t_first),
-            "single_thread": {"value": audio_one / max(t_one, 1e-9), "cores": 1, "utterances": len(sample_one), "audio_s": audio_one, "wall_s": t_one,
-                              "what": "the same whole path, one utterance after the other on ONE thread (nnet3-latgen-faster's own shape), "
-                                      "every %d-th utterance of the duration-sorted set" % k_one},
-            "decoder_only": {"value": audio / max(wall_d, 1e-9), "per_core_value": audio / max(busy_d, 1e-9), "cores": used,
-                             "wall_s": wall_d,
-                             "what": "the CPU decoder alone (mode 0) on the device's log-likelihoods of the same utterances"},
-            "one_best_vs_cpu_whole_path": {"errors": errs_w, "ref_words": ref_w},
-            "one_best_vs_cpu_decoder_same_loglikes": {"errors": errs_d, "ref_words": ref_d, "utterances_with_other_cost": cost_diff}}
+    tot = max(sum(share_w), 1e-9)
+    nnet_how = ("cblas_sgemm per Propagate (OpenBLAS, 1 thread per worker), DecodableNnetSimple chunks of 50 frames" if have_blas else
+                "scalar oracle (no OpenBLAS found next to numpy)")
+    old_fig = {"value": audio / max(wall_w, 1e-9), "cores": used, "per_core_value": audio / max(busy_w, 1e-9),
+               "thread_busy_fraction": busy_w / max(wall_w * used, 1e-9), "wall_s": wall_w,
+               "stage_share": {"features": share_w[0] / tot, "nnet": share_w[2] / tot, "decoder_and_best_path": share_w[3] / tot}}
+    main_fig = like_out if like_out is not None else old_fig
+    out = {"value": main_fig["value"], "unit": "audio-sec/wall-sec", "cores": main_fig["cores"], "kind": "port",
+           "path": ("MFCC (orc_feat) -> ivector-extract-online2 (orc_ivector: OnlineCmvn, splice, LDA, diagonal-UBM posteriors, stats, 15 CG iterations, "
+                    "period 10) -> TDNN-F with the 100-dim i-vector input in chunks of 50 frames, each with its own i-vector (orc_nnet_blas: sgemm) -> "
+                    "LatticeFasterDecoder mode 0 (orc_decoder) -> best path: every stage the device ran, the search on the same planted log-likelihoods"
+                    if like_out is not None else
+                    "MFCC (orc_feat) -> TDNN-F without i-vector input in chunks of 50 frames (orc_nnet_blas: sgemm) -> LatticeFasterDecoder mode 0 -> best path"),
+           "cpu_model": cpu_model, "cores_available": avail, "cpu_quota_cpus": quota,
+           "cores_note": None if quota is None or quota >= main_fig["cores"] else
+                         "the container's cgroup grants %.0f CPUs of time (cpu.max): the %d threads share them -- per_core_value is per THREAD-second, "
+                         "and the rate per granted CPU is value / %.0f" % (quota, main_fig["cores"], quota),
+           "per_core_value": main_fig["per_core_value"], "thread_busy_fraction": main_fig["thread_busy_fraction"],
+           "nnet": nnet_how, "stage_share": main_fig["stage_share"],
+           "without_ivector_extraction": None if like_out is None else dict(old_fig, what="rounds 3-5's figure: the model WITHOUT the i-vector input, no "
+                                                                             "extractor, %d threads (over the cgroup's %s CPUs)" % (used, quota)),
+           "nnet_only_per_core": {"sgemm": a0 / max(t_blas_nnet, 1e-9) if have_blas else None, "scalar_oracle": a0 / max(t_scalar_nnet, 1e-9),
+                                  "what": "audio seconds per second of the acoustic model alone on one core (the shortest utterance)"},
+           "sample": "duration-stratified: every %d-th utterance of the duration-sorted test set, %d utterances (%.1f s audio, %.1f-%.1f s "
+                     "each) on %d threads pulling from one list (longest first), %.1f s wall: the whole path named in `path`; "
+                     "single-utterance probe %.2f s" %
+                     (k_strat, len(sample), audio, min(waves[i].size for i in sample) / 16000.0, max(waves[i].size for i in sample) / 16000.0,
+                      main_fig["cores"], main_fig["wall_s"], t_first),
+           "single_thread": {"value": audio_one / max(t_one, 1e-9), "cores": 1, "utterances": len(sample_one), "audio_s": audio_one, "wall_s": t_one,
+                             "what": "the same whole path, one utterance after the other on ONE thread (nnet3-latgen-faster's own shape), "
+                                     "every %d-th utterance of the duration-sorted set" % k_one},
+           "decoder_only": {"value": audio / max(wall_d, 1e-9), "per_core_value": audio / max(busy_d, 1e-9), "cores": used,
+                            "wall_s": wall_d,
+                            "what": "the CPU decoder alone (mode 0) on the device's log-likelihoods of the same utterances"},
+           "one_best_vs_cpu_whole_path": {"errors": errs_w, "ref_words": ref_w},
+           "one_best_vs_cpu_decoder_same_loglikes": {"errors": errs_d, "ref_words": ref_d, "utterances_with_other_cost": cost_diff},
+           "divergence_from_reference_search": div}
+    return out
 
 
 def wer_leg(g, cfg, n_utts, cores, log, hash_capacity=0, search_mode=2, second_scale=True):
@@ -587,6 +699,13 @@ def main():
                 "algorithmic_bytes_per_launch": alg, "launch_ms": dec_ms, "lanes": int(st.lanes),
                 "us_per_frame_per_lane": 1e3 * dec_ms * int(st.lanes) / max(frames, 1)}
         roof.update(search_counter_view(args if use_pmc else None, counters, dec_ms))
+        # what the kernel must move BY ITS OWN DESIGN: the offset pair of an expanded token, the 8-byte hot record
+        # {weight, pdf} of every expanded emitting arc, for a survivor its 16-byte arc record + the table word read-modify-write, the
+        # links and tokens written -- the honest denominator of the measured traffic (`frac` stays the contract figure)
+        dmin = float(8 * counters[0] + 8 * counters[2] + 32 * counters[3] + 20 * counters[4] + 12 * counters[5])
+        roof["design_min_bytes"] = dmin
+        roof["design_min_frac"] = dmin / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["waste"] = (roof["traffic"] / dmin) if roof.get("traffic") else None
         roof["reading"] = ("`frac` is the contract figure: SURVEY 8(d)'s algorithmic bytes over the launch time.  The kernel moves fewer bytes than "
                            "that formula prices and is bound by dependent memory round trips, not bandwidth: see counter_frac (PMC bytes / launch / "
                            "peak), wait_fraction (SQ_WAIT_ANY / SQ_WAVE_CYCLES) and write_amplification (WRITE_SIZE / algorithmic writes)")
@@ -742,7 +861,9 @@ def main():
             if faithful:
                 ro = planted_set["row_off"]
                 out["cpu_baseline"] = cpu_baseline(g, model_plain, waves, cfg, bd, args.cpu_budget, args.cpu_cores,
-                                                   ll_of=lambda i: planted_rows(planted, ro[i], ro[i + 1] - ro[i], g.num_pdfs))
+                                                   ll_of=lambda i: planted_rows(planted, ro[i], ro[i + 1] - ro[i], g.num_pdfs),
+                                                   ivec=(model, extractor.info) if extractor is not None else None,
+                                                   transcripts={k: [int(w) for w in words] for k, (words, _) in enumerate(planted_set["paths"])})
             else:
                 out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, bd, args.cpu_budget, args.cpu_cores)
         except Exception as e:                      # noqa: BLE001 - the measured line must still be printed

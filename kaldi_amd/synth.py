@@ -262,6 +262,31 @@ def planted_loglikes_device(true_pdf, num_pdfs, peak, noise, seed=1):
     return m
 
 
+def planted_loglikes_host(true_pdf, num_pdfs, peak, noise, seed=1):
+    """The host twin of planted_loglikes_device (same statistics, another random stream): noise * N(0, 1) on every pdf and
+    + peak on the pdf the planted path visits on that frame.  Seeded numpy: the same matrix on every machine."""
+    tp = np.asarray(true_pdf, np.int64)
+    rng = np.random.default_rng(seed)
+    ll = rng.standard_normal((tp.size, int(num_pdfs)), dtype=np.float32)
+    ll *= np.float32(noise)
+    ll[np.arange(tp.size), tp] += np.float32(peak)
+    return ll
+
+
+def headline_sample(g, n_utts, total=2620, peak=8.3, noise=3.0):
+    """A duration-stratified sample of the bench's planted test set (bench.planted_testset: utterance u = round(3 x seconds)
+    words through the graph, seed 900000 + u), every (total // n_utts)-th utterance of the duration-sorted set, longest first:
+    [(u, seconds, words, pdf path)].  Log-likelihoods: planted_loglikes_host(path, g.num_pdfs, peak, noise, seed=5000 + u)."""
+    durs = utterance_durations(total, seed=1, mu=6.2)
+    order = np.argsort(durs)
+    k = max(1, total // n_utts)
+    out = []
+    for u in sorted((int(x) for x in order[k // 2::k]), key=lambda x: -durs[x]):
+        words, path = sample_path(g, max(1, int(round(float(durs[u]) * 3.0))), seed=900000 + u)
+        out.append((u, float(durs[u]), [int(w) for w in words], path))
+    return out
+
+
 def random_loglikes(T, P, seed=0, scale=1.0):
     rng = np.random.default_rng(seed)
     return np.ascontiguousarray(scale * rng.standard_normal((T, P)), np.float32)

@@ -42,6 +42,8 @@ def lib():
         L.orc_nnet_forward.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp,
                                        C.c_int, fp, fp, C.c_int]
         L.orc_nnet_forward_blas.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, C.c_void_p, fp, C.c_int]
+        L.orc_nnet_forward_blas_chunked.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int,
+                                                    C.c_int, C.c_int, C.c_void_p, fp, C.c_int]
         L.orc_nnet_forward_slots.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int, C.c_int,
                                              C.c_int, C.c_int, fp, C.c_int]
         L.orc_nnet_forward_chunked.argtypes = [C.POINTER(abi.LayerDesc), C.c_int, C.c_int, C.c_int, fp, C.c_int, fp, C.c_int,
@@ -173,6 +175,24 @@ def nnet_forward_blas(model, feats, ivector=None, frames_per_chunk=50):
     iv = None if ivector is None else np.ascontiguousarray(ivector, np.float32)
     r = lib().orc_nnet_forward_blas(model.descs(), len(model.layers), model.input_dim, model.subsampling, abi.fptr(feats), T,
                                     abi.fptr(iv), int(frames_per_chunk), C.c_void_p(sg), abi.fptr(out), n_out)
+    assert r == n_out, r
+    return out
+
+
+def nnet_forward_blas_chunked(model, feats, online_ivectors, ivector_period=10, frames_per_chunk=50):
+    """nnet_forward_blas with --online-ivectors: every chunk with the row GetCurrentIvector picks for its middle (the sgemm twin of
+    nnet_forward_chunked; what nnet3-latgen-faster runs on a CPU in the recipe's decode.sh)."""
+    sg = cblas_sgemm()
+    if sg is None:
+        raise RuntimeError("no OpenBLAS with an ILP64 cblas_sgemm next to numpy")
+    feats = np.ascontiguousarray(feats, np.float32)
+    iv = np.ascontiguousarray(online_ivectors, np.float32)
+    T = feats.shape[0]
+    n_out = (T + model.subsampling - 1) // model.subsampling
+    out = np.zeros((n_out, model.layers[-1].out_dim), np.float32)
+    r = lib().orc_nnet_forward_blas_chunked(model.descs(), len(model.layers), model.input_dim, model.subsampling, abi.fptr(feats), T,
+                                            abi.fptr(iv), iv.shape[0], iv.shape[1], int(ivector_period), int(frames_per_chunk),
+                                            C.c_void_p(sg), abi.fptr(out), n_out)
     assert r == n_out, r
     return out
 

@@ -42,8 +42,12 @@ struct TimeSet {            // sorted time indexes a node is evaluated at (in on
 
 }  // namespace
 
-extern "C" int orc_nnet_forward_blas(const kamd_layer_desc *L, int n_layers, int input_dim, int subsampling, const float *feats, int T,
-                                     const float *ivector, int frames_per_chunk, void *sgemm_ptr, float *out, int out_rows_cap) {
+// online_ivectors != NULL: --online-ivectors of the recipe (steps/nnet3/decode.sh:105-107) -- every chunk is evaluated with the row
+// GetCurrentIvector (nnet-am-decodable-simple.cc:181-211) picks for its middle, as orc_nnet.cc's orc_nnet_forward_chunked does;
+// `ivector` is then ignored.  Returns -2 when a chunk has no i-vector ("Could not get iVector for frame").
+static int ForwardBlas(const kamd_layer_desc *L, int n_layers, int input_dim, int subsampling, const float *feats, int T, const float *ivector,
+                       const float *online_ivectors, int n_iv_rows, int iv_dim, int ivector_period, int frames_per_chunk, void *sgemm_ptr,
+                       float *out, int out_rows_cap) {
   SgemmFn sgemm = reinterpret_cast<SgemmFn>(sgemm_ptr);
   if (T <= 0 || !sgemm) return -1;
   for (int l = 0; l < n_layers; l++) if (L[l].multi_input) return -3;     // single-producer layers only (the bench models); orc_nnet_forward does the rest
@@ -55,6 +59,16 @@ extern "C" int orc_nnet_forward_blas(const kamd_layer_desc *L, int n_layers, int
   std::vector<float> gathered;
   for (int start = 0; start < n_out; start += C) {
     const int num = std::min(C, n_out - start);
+    if (online_ivectors) {
+      const int first_output_frame = start * sub, last_output_frame = (start + num - 1) * sub;
+      const int frame_to_search = first_output_frame + (last_output_frame - first_output_frame) / 2;
+      int ivector_frame = frame_to_search / ivector_period;
+      if (ivector_frame >= n_iv_rows) {
+        if ((ivector_frame - (n_iv_rows - 1)) * ivector_period > 50) return -2;
+        ivector_frame = n_iv_rows - 1;
+      }
+      ivector = online_ivectors + static_cast<int64_t>(ivector_frame) * iv_dim;
+    }
     for (TimeSet &r : req) r.t.clear();
     req[n_layers - 1].t.resize(num);
     for (int i = 0; i < num; i++) req[n_layers - 1].t[i] = (start + i) * sub;
@@ -125,4 +139,19 @@ extern "C" int orc_nnet_forward_blas(const kamd_layer_desc *L, int n_layers, int
     memcpy(out + static_cast<size_t>(start) * P, act[n_layers - 1].data(), sizeof(float) * static_cast<size_t>(num) * P);
   }
   return n_out;
+}
+
+extern "C" int orc_nnet_forward_blas(const kamd_layer_desc *L, int n_layers, int input_dim, int subsampling, const float *feats, int T,
+                                     const float *ivector, int frames_per_chunk, void *sgemm_ptr, float *out, int out_rows_cap) {
+  return ForwardBlas(L, n_layers, input_dim, subsampling, feats, T, ivector, NULL, 0, 0, 1, frames_per_chunk, sgemm_ptr, out, out_rows_cap);
+}
+
+extern "C" int orc_nnet_forward_blas_chunked(const kamd_layer_desc *L, int n_layers, int input_dim, int subsampling, const float *feats, int T,
+                                             const float *online_ivectors, int n_iv_rows, int iv_dim, int ivector_period, int frames_per_chunk,
+                                             void *sgemm_ptr, float *out, int out_rows_cap) {
+  if (!online_ivectors || n_iv_rows <= 0 || ivector_period <= 0) return -1;
+  int fpc = frames_per_chunk;
+  if (fpc > 0 && fpc % subsampling != 0) fpc = subsampling * ((fpc + subsampling - 1) / subsampling);
+  return ForwardBlas(L, n_layers, input_dim, subsampling, feats, T, NULL, online_ivectors, n_iv_rows, iv_dim, ivector_period, fpc, sgemm_ptr, out,
+                     out_rows_cap);
 }

@@ -130,6 +130,23 @@ def test_blas_forward_equals_scalar_oracle():
                     assert np.abs(orc.nnet_forward_blas(m, f, iv, frames_per_chunk=fpc) - want).max() < tol
 
 
+def test_blas_chunked_forward_with_online_ivectors_equals_scalar_oracle():
+    """The like-for-like CPU baseline's model: the sgemm forward with one online i-vector per chunk against the scalar
+    chunked oracle (same chunk -> i-vector rule, nnet-am-decodable-simple.cc:181-211), incl. a table that ends early."""
+    if orc.cblas_sgemm() is None:
+        pytest.skip("no OpenBLAS cblas_sgemm next to numpy")
+    rng = np.random.default_rng(5)
+    m = nnet.tdnnf_tiny(num_pdfs=50, ivector_dim=10, seed=4)
+    for T in (4, 52, 160, 333):
+        f = rng.standard_normal((T, m.input_dim)).astype(np.float32)
+        for n_iv in ((T + 9) // 10, max(1, (T + 9) // 10 - 2)):
+            iv = rng.standard_normal((n_iv, 10)).astype(np.float32)
+            for fpc in (50, 21):
+                want = orc.nnet_forward_chunked(m, f, iv, 10, fpc)
+                got = orc.nnet_forward_blas_chunked(m, f, iv, 10, fpc)
+                assert np.abs(got - want).max() < 1e-5 * max(1.0, float(np.abs(want).max()))
+
+
 def test_batch_computer_tasks_follow_the_reference_rule():
     """NnetBatchComputer::SplitUtteranceIntoTasks (nnet3/nnet-batch-compute.cc:586-829), cases worked by hand from the rule:
     fpc = 50 / 3 = 16 output frames per task; the last of several tasks ends on the last frame and overlaps its predecessor;
