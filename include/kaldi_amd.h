@@ -688,6 +688,18 @@ int kamd_ivector_num_ivectors(const kamd_ivector_extractor *e, int num_frames);
 int kamd_ivector_extract_online_device(kamd_ivector_extractor *e, const float *d_feats, const int64_t *h_row_off,
                                        int ld_feat, int n_utts, float *d_out, const int64_t *h_out_row_off,
                                        void *stream);
+/* The same in two halves, for a driver that walks a test set pass by pass (kamd_batch_decoder does): OnlineIvectorFeature's
+ * UpdateStatsUntilFrame (online2/online-ivector-feature.cc:322-364: AccStats of every frame, what does not depend on the
+ * order of the steps) for the utterances of one pass, and -- once, over ALL passes' utterances -- the per-step
+ * GetIvector chain (ivector-extractor.cc:732-756, 15 LinearCgd iterations per step, one sequential chain per utterance:
+ * a launch costs its longest utterance whatever else there is, so one launch instead of one per pass).  h_out_row_off numbers
+ * the utterances' rows in the whole set's i-vector matrix, [0, total_iv_rows); the step statistics (5151 doubles per row)
+ * stay on the device between the calls.  reserve -> stats (per pass) -> solve; the results equal the one-call form bit for bit. */
+int kamd_ivector_online_reserve_steps(kamd_ivector_extractor *e, int64_t total_iv_rows);
+int kamd_ivector_online_stats_device(kamd_ivector_extractor *e, const float *d_feats, const int64_t *h_row_off, int ld_feat,
+                                     int n_utts, const int64_t *h_out_row_off, void *stream);
+int kamd_ivector_online_solve_device(kamd_ivector_extractor *e, const int64_t *h_row_off, int n_utts, float *d_out,
+                                     const int64_t *h_out_row_off, void *stream);
 /* The same with the speaker's adaptation state (OnlineIvectorExtractorAdaptationState, SetAdaptationState /
  * GetAdaptationState, online2/online-ivector-feature.cc:400-435), as ivector-extract-online2 carries it
  * from one utterance of a speaker to the next (online2bin/ivector-extract-online2.cc:95-170).  A state is

@@ -94,6 +94,9 @@ struct BatchDecoder {
   hipStream_t s_up = NULL;
   std::vector<hipEvent_t> ev_up, ev_f0, ev_f1, ev_n1;   // per pass: copies done; features start / end; model end
   std::vector<hipEvent_t> ev_iv0, ev_iv1, ev_n0;        // per pass: i-vector extraction start / end; chunked model start
+  hipEvent_t ev_solve[2] = {};                          // the one solver launch of a run with the solver deferred
+  int64_t iv_reserved = 0;                              // i-vector rows whose step statistics the extractor holds buffers for
+  bool last_deferred_solve = false;
   const float *d_ll_override = NULL;             // kamd_batch_decoder_set_loglike_override
   hipStream_t s_main = NULL;
   hipEvent_t ev[3] = {};
@@ -277,6 +280,7 @@ void kamd_batch_decoder_destroy(kamd_batch_decoder *h) {
   if (b->s_main) (void)hipStreamDestroy(b->s_main);
   if (b->s_long) (void)hipStreamDestroy(b->s_long);
   if (b->ev_long) (void)hipEventDestroy(b->ev_long);
+  for (int i = 0; i < 2; i++) if (b->ev_solve[i]) (void)hipEventDestroy(b->ev_solve[i]);
   if (b->d_waves) (void)hipFree(b->d_waves);
   if (b->d_feats) (void)hipFree(b->d_feats);
   if (b->d_ll) (void)hipFree(b->d_ll);
@@ -776,7 +780,49 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
       KAMD_HIP(hipEventRecord(b->ev_iv1[pass], st));
       return KAMD_OK;
     };
-    if (online_iv) { rc = ivectors_of(0); if (rc != KAMD_OK) return rc; }
+    // ---- online i-vectors, the solver deferred: the statistics of every pass first (behind that pass's features, as its
+    // samples arrive), then ONE SolveKernel launch for the whole set -- the solver is a sequential chain per utterance, a
+    // launch costs its longest utterance's chain, and four passes paid four of them (31 ms of 98 on the 2620-utterance set,
+    // against ~12 for one launch).  Not when the long utterances have a search of their own waiting for pass 0's scores, not
+    // when the step statistics of the whole set (5151 doubles per i-vector row) would take more than a tenth of the free HBM.
+    bool defer_solve = false;
+    if (online_iv && np > 1 && Kh == 0) {
+      static const bool no_defer = getenv("KAMD_IV_NO_DEFER") != NULL;
+      const int I = kamd_ivector_dim(b->iv_extractor);
+      const double need = static_cast<double>(b->oiv_off.back()) * (static_cast<double>(I) * (I + 1) / 2 + I + 1) * 8.0;
+      size_t free_b = 0, total_b = 0;
+      if (!no_defer && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (need <= 0.1 * static_cast<double>(free_b) || b->iv_reserved >= b->oiv_off.back())) {
+        rc = kamd_ivector_online_reserve_steps(b->iv_extractor, b->oiv_off.back());      // (grows the buffers only when they are too small)
+        if (rc != KAMD_OK) return rc;
+        b->iv_reserved = std::max(b->iv_reserved, b->oiv_off.back());
+        defer_solve = true;
+      }
+    }
+    if (defer_solve) {
+      for (int pass = 0; pass < np; pass++) {
+        while (static_cast<int>(b->ev_iv0.size()) <= pass) {
+          hipEvent_t e0 = NULL, e1 = NULL, e2 = NULL;
+          KAMD_HIP(hipEventCreate(&e0)); KAMD_HIP(hipEventCreate(&e1)); KAMD_HIP(hipEventCreate(&e2));
+          b->ev_iv0.push_back(e0); b->ev_iv1.push_back(e1); b->ev_n0.push_back(e2);
+        }
+        rc = features_of(pass, st);
+        if (rc != KAMD_OK) return rc;
+        KAMD_HIP(hipEventRecord(b->ev_iv0[pass], st));
+        rc = kamd_ivector_online_stats_device(b->iv_extractor, b->d_feats, b->feat_off.data() + pu[pass], b->ld_feat, pu[pass + 1] - pu[pass],
+                                              b->oiv_off.data() + pu[pass], st);
+        if (rc != KAMD_OK) return rc;
+        KAMD_HIP(hipEventRecord(b->ev_iv1[pass], st));
+        mark("i-vector statistics issued, pass", pass);
+      }
+      if (!b->ev_solve[0]) { KAMD_HIP(hipEventCreate(&b->ev_solve[0])); KAMD_HIP(hipEventCreate(&b->ev_solve[1])); }
+      KAMD_HIP(hipEventRecord(b->ev_solve[0], st));
+      rc = kamd_ivector_online_solve_device(b->iv_extractor, b->feat_off.data(), n, b->d_oiv, b->oiv_off.data(), st);
+      if (rc != KAMD_OK) return rc;
+      KAMD_HIP(hipEventRecord(b->ev_solve[1], st));
+      mark("i-vector solver issued, utterances", n);
+    }
+    b->last_deferred_solve = defer_solve;
+    if (online_iv && !defer_solve) { rc = ivectors_of(0); if (rc != KAMD_OK) return rc; }
     for (int pass = 0; pass < np; pass++) {
       const int u0 = pu[pass], u1 = pu[pass + 1];
       if (online_iv) {
@@ -818,7 +864,7 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
         if (rc != KAMD_OK) return rc;
         mark("long utterances' search issued", Kh);
       }
-      if (online_iv && pass + 1 < np) { rc = ivectors_of(pass + 1); if (rc != KAMD_OK) return rc; }
+      if (online_iv && !defer_solve && pass + 1 < np) { rc = ivectors_of(pass + 1); if (rc != KAMD_OK) return rc; }
     }
     KAMD_HIP(hipEventRecord(b->ev[2], st));
     // ---- the search: one work-queue launch, longest utterance first
@@ -1068,6 +1114,11 @@ static int RunImpl(BatchDecoder *b, kamd_batch_stats *stats) {
       (void)hipEventElapsedTime(&v, b->ev_iv0[p], b->ev_iv1[p]);
       s.ivector_ms += v;
       if (!host_mode) { (void)hipEventElapsedTime(&m, b->ev_n0[p], b->ev_n1[p]); s.nnet_ms += m; }
+    }
+    if (b->last_deferred_solve && b->ev_solve[0]) {
+      float v = 0;
+      (void)hipEventElapsedTime(&v, b->ev_solve[0], b->ev_solve[1]);
+      s.ivector_ms += v;
     }
   }
   s.decode_ms = qms; s.total_ms = static_cast<float>(n_retried ? total_ms_all : total_ms);

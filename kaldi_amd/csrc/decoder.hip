@@ -4236,7 +4236,13 @@ static int FetchLattice(Decoder *D, int lane) {
   // final costs of the last frame's states
   const int lb = toff[F], le = std::min(toff[F + 1], nt);
   std::vector<float> fc(std::max(0, le - lb));
-  for (int i = lb; i < le; i++) KAMD_HIP(hipMemcpy(&fc[i - lb], D->g->dev.final + st[i], 4, hipMemcpyDeviceToHost));
+  // (from the host copy of the graph's final costs made by kamd_graph_create: until round 6 this was one synchronous 4-byte
+  // hipMemcpy per token of the last frame -- the end-of-utterance latency of a streaming host)
+  const std::vector<float> &gfin = D->g->h_final;
+  for (int i = lb; i < le; i++) {
+    if (st[i] < 0 || static_cast<size_t>(st[i]) >= gfin.size()) return kamd::SetError(KAMD_ERR_STATE, "lattice token %d: state %d out of range", i, st[i]);
+    fc[i - lb] = gfin[st[i]];
+  }
   RawLat R;
   const int rc = Canonicalize(nt, nl, F, st.data(), co.data(), toff.data(), fc.data(), lk.data(), S.out_tok_base, D->g->dev.start, &R);
   if (rc != KAMD_OK) return rc;

@@ -80,6 +80,7 @@ struct IvBatch {
   int x_off;                     // offset of the current estimate inside a record (streaming), or -1
   // mode 2: frame index within the stream, delta weight, GetMinPost(weight) and its log, per list entry
   const int *wl_frame; const float *wl_weight, *wl_minpost, *wl_logminpost;
+  int n_utts, xcd_order;         // StepStatsKernel: the number of utterances; its workgroup -> (utterance, step) order
 };
 
 // ---------------------------------------------------------------- running sums
@@ -300,7 +301,21 @@ static inline size_t StepStatsLdsBytes(const IvDev &d) {
 }
 __global__ __launch_bounds__(256) void StepStatsKernel(IvDev d, IvBatch b) {
   extern __shared__ double ss[];               // xf[period][D], pw[cap], uw[cap], yk[cap][D], then int pg[cap], pt[cap], ug[cap]
-  const int u = blockIdx.y, i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware order (b.xcd_order): the hardware deals consecutive workgroups to the 8 XCDs in turn, each with an L2 of its
+  // own (4 MB: ~55 Gaussians' U_g + Sigma_inv_M_g rows of the 512).  Neighbouring steps of an utterance select mostly the
+  // same Gaussians, so workgroup w -> (XCD w % 8, its w / 8-th workgroup) takes the w / 8-th item of that XCD's eighth of
+  // the (utterance, step) grid: the steps that run side by side on one XCD are consecutive steps of one utterance.
+  // Utterances are dealt to the XCDs in turn (u % 8: they are stored longest first, every XCD gets its share of long ones);
+  // the grid's y extent is rounded up to a multiple of 8 for this.
+  int u = blockIdx.y, i = blockIdx.x;
+  if (b.xcd_order) {
+    const long long w = static_cast<long long>(blockIdx.y) * gridDim.x + blockIdx.x;
+    const long long j = w >> 3;
+    u = static_cast<int>(j / gridDim.x) * 8 + static_cast<int>(w & 7);
+    i = static_cast<int>(j % gridDim.x);
+  }
+  if (u >= b.n_utts) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const IvUtt ut = b.utt[u];
   const int64_t r0 = ut.ws_row;
   if (i >= ut.n_steps) return;
@@ -638,6 +653,7 @@ struct IvExtractor {
   MetaRing utt_ring;              // the utterance records of a call (meta_ring.h: no copy engine, no host wait)
   int *d_wlf = NULL; float *d_wlw = NULL; size_t wlf_cap = 0, wlw_cap = 0;   // weighted list: frames | weight, min_post, log(min_post)
   int64_t last_rows = 0;
+  int64_t reserved_steps = 0;     // kamd_ivector_online_reserve_steps: rows of the step-statistic buffers a stats / solve sequence shares
 };
 
 template <typename T>
@@ -811,9 +827,12 @@ int kamd_ivector_extract_online_device(kamd_ivector_extractor *h, const float *d
 }
 
 // workspaces for ws_rows feature rows and inc_rows statistic increments; uploads the descriptors; launches
+// phase: 0 everything; 1 the statistics only (PrefixKernel .. StepStatsKernel: the step increments stay on the device);
+// 2 the solver only, over increments an earlier phase-1 call (or several) left -- inc_rows is then the capacity they were
+// written under and must not make the buffers move.
 static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std::vector<kamd::IvUtt> &utts, int64_t ws_rows,
                     int64_t inc_rows, float *d_out, const double *d_state_in, double *d_state_out, int state_size, int x_off,
-                    hipStream_t st, const std::vector<int> *wl_frame = NULL, const std::vector<float> *wl_weight = NULL) {
+                    hipStream_t st, const std::vector<int> *wl_frame = NULL, const std::vector<float> *wl_weight = NULL, int phase = 0) {
   const kamd::IvDev &v = e->dev;
   const int n = static_cast<int>(utts.size());
   const size_t n_wl = wl_frame ? wl_frame->size() : 0;
@@ -834,6 +853,8 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
     KAMD_HIP(hipStreamSynchronize(st));
   }
   kamd::IvWorkspace *w = e->ws;
+  if (phase == 2 && (static_cast<size_t>(inc_rows) * v.Q > e->dq_cap || static_cast<size_t>(inc_rows) * v.I > e->dl_cap || static_cast<size_t>(inc_rows) > e->dt_cap))
+    return kamd::SetError(KAMD_ERR_STATE, "i-vector solve: the step statistics of %lld rows were never reserved", static_cast<long long>(inc_rows));
   if (kamd::GrowDevKeep(&w->d_S, &w->S_cap, static_cast<size_t>(ws_rows) * v.sw, st) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDevKeep(&w->d_nl, &w->nl_cap, static_cast<size_t>(ws_rows) * v.D, st) != KAMD_OK) return KAMD_ERR_HIP;
   if (kamd::GrowDevKeep(&w->d_rl, &w->rl_cap, static_cast<size_t>(ws_rows) * v.D, st) != KAMD_OK) return KAMD_ERR_HIP;
@@ -854,22 +875,25 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
   b.feats = d_feats; b.ld = ld_feat; b.utt = static_cast<const kamd::IvUtt *>(d_utt);
   b.S = w->d_S; b.norm_lda = w->d_nl; b.raw_lda = w->d_rl; b.post_g = w->d_pg; b.post_w = w->d_pw; b.out = d_out;
   b.dquad = e->d_dquad; b.dlin = e->d_dlin; b.dtotw = e->d_dtotw;
+  b.n_utts = n; b.xcd_order = 0;
   b.state_in = d_state_in; b.state_out = d_state_out; b.state_size = state_size; b.x_off = x_off;
   b.wl_frame = e->d_wlf; b.wl_weight = e->d_wlw; b.wl_minpost = e->d_wlw + n_wl; b.wl_logminpost = e->d_wlw + 2 * n_wl;
-  hipLaunchKernelGGL(kamd::PrefixKernel, dim3(n), dim3(256), 0, st, v, b);
-  if (max_proc > 0) {
+  if (phase != 2) hipLaunchKernelGGL(kamd::PrefixKernel, dim3(n), dim3(256), 0, st, v, b);
+  if (phase != 2 && max_proc > 0) {
     const size_t lds_front = static_cast<size_t>(2) * (kamd::IV_FT + v.L + v.R) * v.feat_dim * sizeof(float);
     hipLaunchKernelGGL(kamd::FrontKernel, dim3(kamd::CeilDiv(max_proc, kamd::IV_FT), n), dim3(256), lds_front, st, v, b);
   }
-  if (max_post > 0) {
+  if (phase != 2 && max_post > 0) {
     const size_t lds_post = static_cast<size_t>(4) * (v.D + v.G) * sizeof(float);
     hipLaunchKernelGGL(kamd::PostKernel, dim3(kamd::CeilDiv(max_post, 4), n), dim3(256), lds_post, st, v, b);
   }
   if (max_steps > 0) {
     const size_t lds_step = kamd::StepStatsLdsBytes(v);
-    hipLaunchKernelGGL(kamd::StepStatsKernel, dim3(max_steps, n), dim3(256), lds_step, st, v, b);
+    static const bool xcd_off = getenv("KAMD_IV_XCD") != NULL && getenv("KAMD_IV_XCD")[0] == '0';     // A/B switch
+    b.n_utts = n; b.xcd_order = xcd_off ? 0 : 1;
+    if (phase != 2) hipLaunchKernelGGL(kamd::StepStatsKernel, dim3(max_steps, b.xcd_order ? (n + 7) / 8 * 8 : n), dim3(256), lds_step, st, v, b);
     const size_t lds_solve = (static_cast<size_t>(v.Q) + 6 * kamd::IV_MAX_DIM) * sizeof(double);
-    hipLaunchKernelGGL(kamd::SolveKernel, dim3(n), dim3(256), lds_solve, st, v, b);
+    if (phase != 1) hipLaunchKernelGGL(kamd::SolveKernel, dim3(n), dim3(256), lds_solve, st, v, b);
   }
   KAMD_HIP(hipGetLastError());
   return KAMD_OK;
@@ -916,6 +940,58 @@ int kamd_ivector_extract_online_adapt_device(kamd_ivector_extractor *h, const fl
     KAMD_HIP(hipStreamSynchronize(st));
   }
   return KAMD_OK;
+}
+
+// kamd_ivector_extract_online_device in two halves, for a caller that walks a test set pass by pass (kamd_batch_decoder):
+// the solver is one sequential chain per utterance, so a launch costs its longest utterance's chain whatever else the GPU
+// could do -- four passes paid four chains (31 ms of the headline's 98).  With the step statistics of every pass kept
+// (7.2 GB for the 4.84 h set) ONE solver launch pays one.  h_out_row_off: the utterances' rows in the WHOLE set's i-vector
+// matrix (the increments use the same numbering); reserve first, then `stats` pass by pass, then `solve` once.
+int kamd_ivector_online_reserve_steps(kamd_ivector_extractor *h, int64_t total_iv_rows) {
+  IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
+  const kamd::IvDev &v = e->dev;
+  if (total_iv_rows <= 0) return kamd::SetError(KAMD_ERR_ARG, "i-vector steps to reserve: %lld", static_cast<long long>(total_iv_rows));
+  if (kamd::GrowDev(&e->d_dquad, &e->dq_cap, static_cast<size_t>(total_iv_rows) * v.Q) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&e->d_dlin, &e->dl_cap, static_cast<size_t>(total_iv_rows) * v.I) != KAMD_OK) return KAMD_ERR_HIP;
+  if (kamd::GrowDev(&e->d_dtotw, &e->dt_cap, static_cast<size_t>(total_iv_rows)) != KAMD_OK) return KAMD_ERR_HIP;
+  e->reserved_steps = total_iv_rows;
+  return KAMD_OK;
+}
+
+static int OnlineHalf(kamd_ivector_extractor *h, const float *d_feats, const int64_t *h_row_off, int ld_feat, int n_utts, float *d_out,
+                      const int64_t *h_out_row_off, hipStream_t st, int phase) {
+  IvExtractor *e = reinterpret_cast<IvExtractor *>(h);
+  if (n_utts <= 0) return KAMD_OK;
+  const kamd::IvDev &v = e->dev;
+  if (ld_feat < v.feat_dim) return kamd::SetError(KAMD_ERR_ARG, "ld_feat %d < feature dim %d", ld_feat, v.feat_dim);
+  std::vector<kamd::IvUtt> utts(n_utts);
+  for (int u = 0; u < n_utts; u++) {
+    const int64_t T = h_row_off[u + 1] - h_row_off[u];
+    if (T <= 0) return kamd::SetError(KAMD_ERR_ARG, "utterance %d has no frames", u);
+    const int n_iv = static_cast<int>((T + v.period - 1) / v.period);
+    if (h_out_row_off[u + 1] - h_out_row_off[u] < n_iv || h_out_row_off[u] < 0 || h_out_row_off[u] + n_iv > e->reserved_steps)
+      return kamd::SetError(KAMD_ERR_ARG, "utterance %d: i-vector rows [%lld, +%d) outside the %lld reserved (kamd_ivector_online_reserve_steps)", u,
+                            static_cast<long long>(h_out_row_off[u]), n_iv, static_cast<long long>(e->reserved_steps));
+    kamd::IvUtt &x = utts[u];
+    x.feat_row = h_row_off[u]; x.ws_row = h_row_off[u] - h_row_off[0]; x.out_row = h_out_row_off[u]; x.inc_row = h_out_row_off[u];
+    x.T = static_cast<int>(T); x.proc_first = 0; x.proc_end = x.T; x.stats_first = 0; x.stats_end = x.T; x.mode = 0; x.n_steps = n_iv; x.wl_off = 0; x.wl_n = 0;
+    x.state_idx = -1;
+  }
+  const int64_t rows = phase == 2 ? 1 : h_row_off[n_utts] - h_row_off[0];
+  const int rc = RunBatch(e, d_feats, ld_feat, utts, rows, e->reserved_steps, d_out, NULL, NULL, kamd_ivector_state_size(h), -1, st, NULL, NULL, phase);
+  if (rc == KAMD_OK && phase == 1) e->last_rows = rows;
+  return rc;
+}
+
+int kamd_ivector_online_stats_device(kamd_ivector_extractor *h, const float *d_feats, const int64_t *h_row_off, int ld_feat, int n_utts,
+                                     const int64_t *h_out_row_off, void *stream) {
+  return OnlineHalf(h, d_feats, h_row_off, ld_feat, n_utts, NULL, h_out_row_off, static_cast<hipStream_t>(stream), 1);
+}
+
+int kamd_ivector_online_solve_device(kamd_ivector_extractor *h, const int64_t *h_row_off, int n_utts, float *d_out, const int64_t *h_out_row_off,
+                                     void *stream) {
+  if (!d_out) return kamd::SetError(KAMD_ERR_ARG, "i-vector solve: no output");
+  return OnlineHalf(h, NULL, h_row_off, reinterpret_cast<IvExtractor *>(h)->dev.feat_dim, n_utts, d_out, h_out_row_off, static_cast<hipStream_t>(stream), 2);
 }
 
 // Streaming form: OnlineIvectorFeature::GetFrame with use_most_recent_ivector = true

@@ -4,7 +4,7 @@ device equals bit for bit) and the reference's order-dependent search (oracle mo
 the planted test set, signed best-path cost gaps, both hypotheses' errors against the planted transcript, and the frames
 where the two searches' cutoffs part.  No GPU: the planted log-likelihoods are drawn by numpy with the statistics of
 kaldi_amd/csrc/synth.hip (noise * N(0,1) on every pdf, + peak on the path's pdf), not its exact stream.
-    python tools/divergence_study.py --utts 138 --threads 8 [--modes 0,2,3]"""
+    python tests/divergence_study.py --utts 138 --threads 8 [--modes 0,2,3]"""
 import argparse
 import json
 import os

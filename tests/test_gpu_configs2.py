@@ -229,10 +229,11 @@ def test_headline_divergence_from_the_reference_search_is_bounded(world):
     assert len(sample) >= 100 and sample[0][1] >= 20.0
     lls = [synth.planted_loglikes_host(path, g.num_pdfs, 8.3, 3.0, seed=5000 + u) for u, _, _, path in sample]
     T = max(ll.shape[0] for ll in lls)
-    sz = pipeline.default_sizes(cfg, 64, T + 2, int(np.mean([ll.shape[0] for ll in lls])) + 2, hash_capacity=1 << 20, tokens_per_frame=11000)
+    # (every lane's arena sized for the longest utterance, as the test-set decoder's uniform arenas are; no second chance here)
+    sz = pipeline.default_sizes(cfg, 48, T + 2, T + 2, hash_capacity=1 << 20, tokens_per_frame=16000)
     bd = decoder.BatchDecoder(G, cfg, sz)
     bd.SetSearchMode(2)
-    lats, recs, _ = bd.decode_queue(lls, resident_lanes=64)
+    lats, recs, _ = bd.decode_queue(lls, resident_lanes=48)
     assert all(r.error == 0 for r in recs), [(i, r.error) for i, r in enumerate(recs) if r.error]
     c3 = copy.copy(cfg)
     c3.hash_ratio = 3.0

@@ -98,15 +98,21 @@ def many_streams(g, N, G, cfg, ie, S, seconds=12.0, chunk=0.24, accept_each=Fals
                 pb = sb.partial_best_paths(np.arange(S), incremental=partials_incremental)
                 pb_ms.append((time.perf_counter() - t3) * 1e3)
             lat.append((t2 - t1, t1 - t0))
+        cnt = sb.dec.counters(0)                  # stream 0's work counters before the finalize: [N_exp, A_exp, A_emit, K_surv, L_kept, N_tok, frames, ..]
         t0 = time.perf_counter()
         sb.finalize(np.arange(S))
         fin = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sb.best_path(0)
+        fetch0 = time.perf_counter() - t0
     adv = np.asarray([x[0] for x in lat]) * 1e3
     up = np.asarray([x[1] for x in lat]) * 1e3
     out = {"streams": int(S), "seconds": seconds, "chunk_ms": chunk * 1e3, "ticks": int(adv.size), "frames_decoded_per_stream": int(nd[0]),
            "upload_ms_per_tick": float(np.median(up)), "ms_per_tick": float(np.median(adv)), "ms_per_tick_p95": float(np.percentile(adv, 95)),
            "ms_per_tick_max": float(adv.max()), "aggregate_x_rt": float(S * seconds * 1e3 / (adv.sum() + up.sum())),
            "aggregate_x_rt_compute_only": float(S * seconds * 1e3 / adv.sum()), "finalize_ms": float(fin * 1e3),
+           "finalize_ms_per_stream": float(fin * 1e3 / S), "lattice_fetch_and_best_path_ms_stream_0": float(fetch0 * 1e3),
+           "tokens_per_frame_stream_0": float(cnt[5] / max(cnt[6], 1)), "expanded_per_frame_stream_0": float(cnt[0] / max(cnt[6], 1)),
            "online_ivectors": ie is not None, "silence_weighting": bool(silence_weighting and ie is not None)}
     if partials and pb_ms:
         out.update({"partials_ms_per_tick": float(np.median(pb_ms)), "partials_ms_per_tick_p95": float(np.percentile(pb_ms, 95)),
@@ -145,8 +151,10 @@ def main():
                   % (r["partials_ms_per_tick"], r["partials_ms_per_tick_p95"], r["words_in_stream_0"]))
         if "endpointing_ms_per_tick" in r:
             print("endpointing for all streams: %.2f ms median per tick, mean trailing silence %.1f frames" % (r["endpointing_ms_per_tick"], r["mean_trailing_silence_frames"]))
-        print("aggregate %.0f x real time (compute only %.0f x); FinalizeDecoding of all streams %.2f ms"
-              % (r["aggregate_x_rt"], r["aggregate_x_rt_compute_only"], r["finalize_ms"]))
+        print("aggregate %.0f x real time (compute only %.0f x); FinalizeDecoding of all streams %.2f ms (%.3f per stream); stream 0: lattice fetch + "
+              "best path %.2f ms, %.0f tokens created / %.0f expanded per frame"
+              % (r["aggregate_x_rt"], r["aggregate_x_rt_compute_only"], r["finalize_ms"], r["finalize_ms_per_stream"],
+                 r["lattice_fetch_and_best_path_ms_stream_0"], r["tokens_per_frame_stream_0"], r["expanded_per_frame_stream_0"]))
         return
     r = single_stream(N, G, cfg, a.seconds, a.chunk)
     print("stream of %.1f s in %.0f ms chunks: %d chunks, %d frames decoded" % (a.seconds, a.chunk * 1e3, r["chunks"], r["frames_decoded"]))
