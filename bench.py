@@ -83,6 +83,8 @@ def parse_args():
                          "calibrated to the token-matched search load (one word per utterance); reported as the `random_loglikes` leg otherwise")
     ap.add_argument("--no-planted", action="store_true", help="skip the `planted` leg (planted transcripts, the model WITHOUT the i-vector input)")
     ap.add_argument("--no-random-leg", action="store_true", help="--headline faithful: skip the random-log-likelihood leg (round 3's headline)")
+    ap.add_argument("--full-parity", action="store_true", help="cpu_baseline also runs the reference's search (oracle mode 0) over EVERY utterance of the "
+                    "test set on the planted log-likelihoods the device searched and reports both WERs (a minute of CPU; profiles/r06_full_set_parity.json)")
     ap.add_argument("--planted-peak", type=float, default=8.3)
     ap.add_argument("--planted-noise", type=float, default=3.0)
     ap.add_argument("--ivectors", action="store_true", help="the recipe's model input (run_tdnn_1d.sh:220 `input dim=100 name=ivector`): "
@@ -287,7 +289,7 @@ def _clat_accepts(cl, words):
     return any(np.isfinite(cl.final[2 * s_]) for s_ in cur)
 
 
-def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None, ivec=None, transcripts=None):
+def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None, ivec=None, transcripts=None, full_parity=False):
     """The CPU path (a port of the reference: oracle/) on this host's cores, on a bounded sample of the same test set:
     `cores` threads, each pulling the next utterance (one LatticeFasterDecoder per thread, like nnet3-latgen-faster-
     parallel; the oracle is C behind ctypes, which releases the interpreter lock), every thread busy for the whole
@@ -461,6 +463,31 @@ def cpu_baseline(g, model, waves, cfg, bd, budget_s, cores, ll_of=None, ivec=Non
                                             "abs_delta_vs_mode0": abs(100.0 * (e_h3 - e_m0) / max(n_ref, 1))},
                "what": "same log-likelihoods; device = the order-free search (oracle mode 2, bit-equal in the tests), mode0 = the reference's "
                        "order-dependent search restated (oracle/orc_decoder.cc); WERs against the planted transcripts of the sampled utterances"}
+    # ---- --full-parity: the reference's search (mode 0) over the WHOLE test set on the log-likelihoods the device searched
+    if full_parity and transcripts is not None and ll_of is not None and div is not None:
+        def dec_fetch(idx):
+            d = orc.Decoder(g, cfg, 0)
+            d.Decode(ll_of(idx))
+            lat = d.GetRawLattice()
+            return lat.best_path() if lat is not None else None
+        everyone = sorted(range(len(waves)), key=lambda i: -waves[i].size)
+        res_a, wall_a, _ = _run_threads(dec_fetch, everyone, max(1, min(int(quota) if quota else cores, avail)))
+        n_ref = e_dev = e_m0 = lower = higher = differ = 0
+        for k, idx in enumerate(everyone):
+            gpu = bd.output(idx)
+            gw, mw = (gpu["words"].tolist() if gpu is not None else []), (res_a[k]["words"].tolist() if res_a[k] is not None else [])
+            ref = list(transcripts[idx])
+            n_ref += len(ref); e_dev += _edit_distance(ref, gw); e_m0 += _edit_distance(ref, mw)
+            gap = None if gpu is None or res_a[k] is None else tot_cost(gpu) - tot_cost(res_a[k])
+            if gap is None or abs(gap) > 1e-3 or gw != mw:
+                differ += 1
+                lower += 1 if gap is not None and gap < -1e-3 else 0
+                higher += 1 if gap is None or gap > 1e-3 else 0
+        div["full_test_set"] = {"utterances": len(everyone), "reference_words": n_ref, "wer_device": 100.0 * e_dev / max(n_ref, 1),
+                                "wer_mode0": 100.0 * e_m0 / max(n_ref, 1), "abs_delta": abs(100.0 * (e_dev - e_m0) / max(n_ref, 1)),
+                                "device_minus_mode0_errors": e_dev - e_m0, "utterances_differing": differ, "device_cost_lower": lower,
+                                "device_cost_higher": higher, "cpu_wall_s": wall_a,
+                                "what": "oracle mode 0 on the planted log-likelihoods of every utterance of the set (bench.py --full-parity)"}
     cpu_model = ""
     try:
         for line in open("/proc/cpuinfo"):
@@ -863,7 +890,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(g, model_plain, waves, cfg, bd, args.cpu_budget, args.cpu_cores,
                                                    ll_of=lambda i: planted_rows(planted, ro[i], ro[i + 1] - ro[i], g.num_pdfs),
                                                    ivec=(model, extractor.info) if extractor is not None else None,
-                                                   transcripts={k: [int(w) for w in words] for k, (words, _) in enumerate(planted_set["paths"])})
+                                                   transcripts={k: [int(w) for w in words] for k, (words, _) in enumerate(planted_set["paths"])},
+                                                   full_parity=args.full_parity)
             else:
                 out["cpu_baseline"] = cpu_baseline(g, model, waves, cfg, bd, args.cpu_budget, args.cpu_cores)
         except Exception as e:                      # noqa: BLE001 - the measured line must still be printed

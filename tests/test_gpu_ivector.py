@@ -405,3 +405,38 @@ def test_long_utterance_split_with_an_extractor_and_a_loglike_override(monkeypat
         o = orc.Decoder(g, cfg, 2)
         o.Decode(planted[u])
         assert lattices_equal(split.raw_lattice(u), o.GetRawLattice()), u
+
+
+def test_statistics_pass_by_pass_then_one_solver_launch_equals_the_one_call_form():
+    """kamd_ivector_online_reserve_steps / _stats_device (per pass) / _solve_device (once, over every pass's utterances) against
+    kamd_ivector_extract_online_device on the same device features: the same kernels on the same rows, bit for bit -- also
+    with the utterances handed to the passes out of order and with another extraction in between (the step statistics of a
+    stats / solve sequence live in rows of their own)."""
+    import ctypes as C
+    from kaldi_amd._lib import check as ck, lib
+    info = ivector.make_synthetic(feat_dim=8, lda_dim=6, num_gauss=70, ivector_dim=10, seed=3, splice_left=2, splice_right=1)
+    ie = ivector.IvectorExtractor(info)
+    rng = np.random.default_rng(11)
+    lens = [53, 7, 160, 1, 29, 88, 10, 11]
+    feats = [(rng.standard_normal((T, 8)) * 1.5 + 0.3).astype(np.float32) for T in lens]
+    dm = decoder.DeviceMatrix(np.concatenate(feats, axis=0))
+    row = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    niv = [ie.num_ivectors(T) for T in lens]
+    orow = np.concatenate([[0], np.cumsum(niv)]).astype(np.int64)
+    out_a = decoder.DeviceMatrix(np.zeros((int(orow[-1]), 10), np.float32))
+    out_b = decoder.DeviceMatrix(np.full((int(orow[-1]), 10), 7.0, np.float32))
+    ck(lib().kamd_ivector_extract_online_device(ie._h, dm.ptr(0), abi.iptr(row, C.c_int64), 8, len(lens), out_a.ptr(0), abi.iptr(orow, C.c_int64), None))
+    ck(lib().kamd_device_synchronize())
+    want = out_a.download()
+    for u, f in enumerate(feats):
+        np.testing.assert_array_equal(want[orow[u]:orow[u + 1]], ie.extract_online(f))
+    ck(lib().kamd_ivector_online_reserve_steps(ie._h, int(orow[-1])))
+    for u0, u1 in ((5, 8), (0, 2), (2, 5)):                   # three "passes", not in order
+        ck(lib().kamd_ivector_online_stats_device(ie._h, dm.ptr(0), abi.iptr(np.ascontiguousarray(row[u0:u1 + 1]), C.c_int64), 8, u1 - u0,
+                                                  abi.iptr(np.ascontiguousarray(orow[u0:u1 + 1]), C.c_int64), None))
+    ck(lib().kamd_ivector_online_solve_device(ie._h, abi.iptr(row, C.c_int64), len(lens), out_b.ptr(0), abi.iptr(orow, C.c_int64), None))
+    ck(lib().kamd_device_synchronize())
+    np.testing.assert_array_equal(out_b.download(), want)
+    # rows outside what was reserved are refused
+    bad = orow + 5
+    assert lib().kamd_ivector_online_stats_device(ie._h, dm.ptr(0), abi.iptr(row, C.c_int64), 8, len(lens), abi.iptr(bad, C.c_int64), None) < 0
