@@ -1027,12 +1027,33 @@ def streaming_leg(log, streams=256, seconds=12.0, chunk=0.24):
     gc.collect()
     log("streaming: one stream done")
     g, _, N, G, cfg, ie = ol.build(1.3, True, seconds)
-    many = ol.many_streams(g, N, G, cfg, ie, streams, seconds, chunk, partials=True, partials_incremental=True, silence_weighting=True)
+    many = ol.many_streams(g, N, G, cfg, ie, streams, seconds, chunk, partials=True, partials_incremental=True, silence_weighting=True,
+                           prune_interval=int(cfg.prune_interval))
+    # the same pass with the streams never pruned before the end of the utterance (rounds 3-5's configuration), and ONE such stream
+    # alone: what FinalizeDecoding costs when it has every frame of the utterance left to sweep
+    many_np = ol.many_streams(g, N, G, cfg, ie, streams, seconds, chunk, partials=True, partials_incremental=True, silence_weighting=True, reps=1)
+    lone = ol.many_streams(g, N, G, cfg, ie, 1, seconds, chunk, partials=True, partials_incremental=True, silence_weighting=True,
+                           prune_interval=int(cfg.prune_interval), reps=1)
     del N, G, ie
     gc.collect()
     return {"ms_per_chunk": one["ms_per_chunk"], "x_rt": one["x_rt"], "partial_ms": one["partial_ms"],
-            "ms_per_tick_%d" % streams: many["ms_per_tick"], "aggregate_x_rt": many["aggregate_x_rt"], "finalize_ms": many["finalize_ms"],
-            "one_stream": one, "streams_%d" % streams: many, "leg_wall_s": time.time() - t0,
+            "ms_per_tick_%d" % streams: many["ms_per_tick"], "aggregate_x_rt": many["aggregate_x_rt"],
+            # end of utterance: FinalizeDecoding of ONE stream of the saturated i-vector load, pruned every prune_interval frames while it
+            # ran (the figure a streaming host waits for); then all `streams` streams ending in the same tick, per stream and in total
+            "finalize_ms": lone["finalize_ms"],
+            "finalize": {"one_stream_saturated_load_ms": lone["finalize_ms"],
+                         "one_stream_lattice_fetch_and_best_path_ms": lone["lattice_fetch_and_best_path_ms_stream_0"],
+                         "all_%d_streams_at_once_ms" % streams: many["finalize_ms"], "per_stream_of_%d_ms" % streams: many["finalize_ms_per_stream"],
+                         "all_%d_streams_never_pruned_before_ms" % streams: many_np["finalize_ms"],
+                         "prune_interval": int(cfg.prune_interval), "compactions_%d_streams" % streams: many["compactions"],
+                         "ms_per_tick_with_pruning": many["ms_per_tick"], "ms_per_tick_never_pruned": many_np["ms_per_tick"],
+                         "tokens_per_frame": many["tokens_per_frame_stream_0"], "expanded_per_frame": many["expanded_per_frame_stream_0"],
+                         "what": "kamd_decoder_finalize (the backward sweep of PruneForwardLinksFinal / PruneForwardLinks over every frame not pruned "
+                                 "yet) + the sync; the lattice fetch + GetBestPath of a stream is the second figure.  The streams decode a saturated "
+                                 "load (max-active binding: frames of > 6144 tokens take the sweep's HBM mode, ~48 us per frame), so an utterance never "
+                                 "pruned before its end pays 400 such frames at once; with LatticeFasterDecoderConfig::prune_interval honoured "
+                                 "between ticks (kamd_stream_batch_set_prune_interval) the end pays the last <= prune_interval + one tick of them"},
+            "one_stream": one, "streams_%d" % streams: many, "streams_%d_never_pruned" % streams: many_np, "leg_wall_s": time.time() - t0,
             "what": "mini_librispeech-sized TDNN-F, 20 k-word synthetic HCLG, %.0f s of audio per stream in %.0f ms chunks; host wall clock around "
                     "AcceptWaveform + AdvanceDecoding (device sync included); the %d-stream pass runs online i-vector estimation, silence weighting and "
                     "incremental partial best paths of every stream per tick" % (seconds, chunk * 1e3, streams)}

@@ -831,6 +831,13 @@ int kamd_stream_batch_set_silence_weighting(kamd_stream_batch *b, const uint8_t 
  * than `fraction` at the start of a tick is compacted before it advances; default 0.5, 0 = never.  Bounds a long
  * utterance's memory by its pruned lattice; results do not change. */
 int kamd_stream_batch_set_compaction(kamd_stream_batch *b, float fraction);
+/* LatticeFasterDecoderConfig::prune_interval for streams (decoder/lattice-faster-decoder.cc:617-619: PruneActiveTokens every
+ * prune_interval frames while decoding): a stream that decoded `frames` frames since its last compaction is compacted at the
+ * start of its next tick, so that FinalizeDecoding at the end of the utterance finds all but the last frames pruned already
+ * -- the end-of-utterance latency of a streaming host (online2bin/online2-wav-nnet3-latgen-faster.cc:264-285).  0 (default):
+ * never; the final lattice and 1-best do not depend on it, a LIVE raw lattice read between ticks then holds the pruned
+ * tokens of the compacted frames (as the reference's does after its own PruneActiveTokens). */
+int kamd_stream_batch_set_prune_interval(kamd_stream_batch *b, int frames);
 int64_t kamd_stream_batch_num_compactions(const kamd_stream_batch *b);
 /* start with the speakers' adaptation states (n x kamd_ivector_state_size() doubles; NULL = fresh) and read a
  * stream's state back after its utterance (before LimitFrames) */

@@ -1342,6 +1342,8 @@ class OnlineStreamBatch {
   }
   /// arena compaction threshold of the streams (PruneActiveTokens when a stream's arena is fuller than this); 0 = never
   void SetCompaction(BaseFloat fraction) { Check(kamd_stream_batch_set_compaction(h_, fraction)); }
+  /// LatticeFasterDecoderConfig::prune_interval: PruneActiveTokens of a stream every `frames` decoded frames (0 = never)
+  void SetPruneInterval(int32 frames) { Check(kamd_stream_batch_set_prune_interval(h_, frames)); }
   /// new utterances; adaptation_states (optional): one state per stream, kamd_ivector_state_size() doubles each
   void Start(const std::vector<int32> &streams, const std::vector<double> *adaptation_states = NULL) {
     if (adaptation_states && ie_) Check(kamd_stream_batch_start_adapted(h_, streams.data(), static_cast<int>(streams.size()), adaptation_states->data()));

@@ -205,6 +205,7 @@ def lib():
     sig("kamd_silence_weighting_num_pending", C.c_int, [vp])
     sig("kamd_decoder_frame_tracebacks", C.c_int, [vp, ip, C.c_int, ip, ip, C.c_int, ip])
     sig("kamd_stream_batch_set_compaction", C.c_int, [vp, C.c_float])
+    sig("kamd_stream_batch_set_prune_interval", C.c_int, [vp, C.c_int])
     sig("kamd_stream_batch_num_compactions", C.c_int64, [vp])
     sig("kamd_decoder_compact", C.c_int, [vp, ip, C.c_int, vp])
     sig("kamd_decoder_lane_usage", C.c_int, [vp, C.c_int, ip, ip, ip, ip])
@@ -308,7 +309,7 @@ kamd_decoder_partial_best_paths kamd_decoder_partial_best_paths_incremental kamd
 kamd_decoder_get_phase_cycles kamd_decoder_last_advance_ms kamd_pipeline_create kamd_pipeline_destroy kamd_pipeline_load_batch kamd_pipeline_set_ivectors kamd_pipeline_set_online_ivectors
 kamd_pipeline_run kamd_pipeline_get_loglikes kamd_pipeline_get_features
 kamd_decoder_queue_configure kamd_decoder_queue_launch kamd_decoder_queue_poll kamd_decoder_queue_result kamd_decoder_queue_fetch_lattice kamd_decoder_queue_wait kamd_lattice_best_path
-kamd_compact_lattice_scale_graph kamd_const_arpa_build kamd_const_arpa_read kamd_const_arpa_write kamd_const_arpa_destroy kamd_const_arpa_info kamd_const_arpa_ngram_logprob kamd_arpa_parse kamd_compact_lattice_lmrescore_const_arpa kamd_stream_batch_get_status kamd_decoder_sync_lanes kamd_decoder_set_search_mode kamd_decoder_set_token_preselection kamd_decoder_lanes_per_cu kamd_decoder_lds_layout kamd_decoder_set_level1_table kamd_decoder_queue_launch_wide kamd_decoder_max_lanes kamd_decoder_max_frames kamd_device_num_cus kamd_batch_opts_default kamd_batch_decoder_create kamd_batch_decoder_destroy kamd_silence_weighting_create kamd_silence_weighting_destroy kamd_silence_weighting_reset kamd_silence_weighting_compute_traceback kamd_silence_weighting_get_delta_weights kamd_silence_weighting_pop_until kamd_silence_weighting_num_pending kamd_stream_batch_set_compaction kamd_stream_batch_num_compactions kamd_decoder_compact kamd_decoder_lane_usage kamd_decoder_frame_tracebacks kamd_decoder_frame_tracebacks_incremental kamd_stream_batch_set_silence_weighting kamd_ivector_stream_update_weighted_device kamd_compact_lattice_scale kamd_compact_lattice_copy kamd_batch_decoder_load kamd_batch_decoder_load_features kamd_nnet_input_dim kamd_nnet_ivector_dim kamd_batch_decoder_run kamd_batch_decoder_get_output kamd_batch_decoder_get_raw_lattice kamd_batch_decoder_get_compact_lattice kamd_batch_decoder_get_loglikes kamd_batch_decoder_set_long_decoder
+kamd_compact_lattice_scale_graph kamd_const_arpa_build kamd_const_arpa_read kamd_const_arpa_write kamd_const_arpa_destroy kamd_const_arpa_info kamd_const_arpa_ngram_logprob kamd_arpa_parse kamd_compact_lattice_lmrescore_const_arpa kamd_stream_batch_get_status kamd_decoder_sync_lanes kamd_decoder_set_search_mode kamd_decoder_set_token_preselection kamd_decoder_lanes_per_cu kamd_decoder_lds_layout kamd_decoder_set_level1_table kamd_decoder_queue_launch_wide kamd_decoder_max_lanes kamd_decoder_max_frames kamd_device_num_cus kamd_batch_opts_default kamd_batch_decoder_create kamd_batch_decoder_destroy kamd_silence_weighting_create kamd_silence_weighting_destroy kamd_silence_weighting_reset kamd_silence_weighting_compute_traceback kamd_silence_weighting_get_delta_weights kamd_silence_weighting_pop_until kamd_silence_weighting_num_pending kamd_stream_batch_set_compaction kamd_stream_batch_set_prune_interval kamd_stream_batch_num_compactions kamd_decoder_compact kamd_decoder_lane_usage kamd_decoder_frame_tracebacks kamd_decoder_frame_tracebacks_incremental kamd_stream_batch_set_silence_weighting kamd_ivector_stream_update_weighted_device kamd_compact_lattice_scale kamd_compact_lattice_copy kamd_batch_decoder_load kamd_batch_decoder_load_features kamd_nnet_input_dim kamd_nnet_ivector_dim kamd_batch_decoder_run kamd_batch_decoder_get_output kamd_batch_decoder_get_raw_lattice kamd_batch_decoder_get_compact_lattice kamd_batch_decoder_get_loglikes kamd_batch_decoder_set_long_decoder
 kamd_batch_decoder_load_host kamd_batch_decoder_unload_host kamd_batch_decoder_set_ivector_extractor kamd_batch_decoder_set_loglike_override kamd_batch_decoder_output_frames
 kamd_synth_planted_loglikes_device kamd_ivector_workspace_create kamd_ivector_workspace_destroy kamd_ivector_extractor_bind_workspace
 kamd_decoder_live_lattice_size kamd_decoder_get_live_raw_lattice kamd_lattice_prune""".split()

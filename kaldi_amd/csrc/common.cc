@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 
 namespace {
@@ -62,7 +63,7 @@ struct Bounce {
       if (g_bounce_made < kMaxBounce) {
         g_bounce_made++;
         lk.unlock();
-        err = hipHostMalloc(&p, kBounceBytes, hipHostMallocDefault);
+        err = ::hipHostMalloc(&p, kBounceBytes, hipHostMallocDefault);      // (never a copy's source or target as far as a caller sees: not noted)
         if (err != hipSuccess) { p = NULL; lk.lock(); g_bounce_made--; g_bounce_cv.notify_one(); }
         return;
       }
@@ -75,25 +76,54 @@ struct Bounce {
     g_bounce_cv.notify_one();
   }
 };
-// is this host address page-locked memory the runtime knows (hipHostMalloc / hipHostRegister)?
-bool HostPinned(const void *p) {
-  hipPointerAttribute_t a;
-  memset(&a, 0, sizeof(a));
-  if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return a.type == hipMemoryTypeHost;
-}
-// ... from its first byte to its last?  (A pageable buffer that merely STARTS inside the pages of somebody's registered range
-// -- a heap neighbour of a hipHostRegister'ed array -- must not be taken for pinned memory: the copy would run off the end
-// of what is pinned.)  The runtime reports no extent for a registered host range, so the two ends (and, for a long range, its
-// middle) are what can be asked; a buffer laid over two registrations with a pageable gap between them is the caller's error.
+// Which host ranges are page-locked?  The library's OWN list: what it allocated with hipHostMalloc and what it registered
+// with hipHostRegister (common.h redirects the four calls here), nothing else.  Until round 6 the runtime was asked
+// (hipPointerGetAttributes) -- but the runtime's view goes stale: a range that was registered, or that the runtime pinned for a
+// pageable copy and kept in its pin cache, and was then given back to the allocator still reads "hipMemoryTypeHost" when
+// the same addresses come back as another, pageable, buffer, and a copy started on that answer faults the GPU on the first page
+// that is no longer mapped for it (tools/repro/pinned_neighbour.cc scenario 7: "Memory access fault by GPU node-2 ... on
+// address <the mapping>", the abort of rounds 4 / 5 word for word).  A caller's own page-locked memory is therefore treated as
+// pageable -- one more memcpy, never a fault.
+std::mutex g_pin_mu;
+std::map<uintptr_t, size_t> g_pinned;            // base -> bytes
 bool HostPinnedRange(const void *p, size_t bytes) {
-  if (!HostPinned(p)) return false;
-  if (bytes <= 1) return true;
-  const char *c = static_cast<const char *>(p);
-  if (!HostPinned(c + bytes - 1)) return false;
-  return bytes <= (2u << 20) || HostPinned(c + bytes / 2);
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  auto it = g_pinned.upper_bound(a);
+  if (it == g_pinned.begin()) return false;
+  --it;
+  return a >= it->first && a + bytes <= it->first + it->second;
 }
 }  // namespace
+
+void NotePinned(const void *p, size_t bytes) {
+  if (!p || !bytes) return;
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pinned[reinterpret_cast<uintptr_t>(p)] = bytes;
+}
+void ForgetPinned(const void *p) {
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  g_pinned.erase(reinterpret_cast<uintptr_t>(p));
+}
+bool IsNotedPinned(const void *p, size_t bytes) { return HostPinnedRange(p, bytes); }
+hipError_t HostMallocNoted(void **p, size_t bytes, unsigned flags) {
+  const hipError_t e = ::hipHostMalloc(p, bytes, flags);
+  if (e == hipSuccess) NotePinned(*p, bytes);
+  return e;
+}
+hipError_t HostFreeNoted(void *p) {
+  ForgetPinned(p);
+  return ::hipHostFree(p);
+}
+hipError_t HostRegisterNoted(void *p, size_t bytes, unsigned flags) {
+  const hipError_t e = ::hipHostRegister(p, bytes, flags);
+  if (e == hipSuccess) NotePinned(p, bytes);
+  return e;
+}
+hipError_t HostUnregisterNoted(void *p) {
+  ForgetPinned(p);
+  return ::hipHostUnregister(p);
+}
 
 hipError_t MemcpySafe(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
   if (bytes == 0) return hipSuccess;

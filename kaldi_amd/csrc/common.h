@@ -61,6 +61,21 @@ hipError_t MemcpyAsyncSafe(void *dst, const void *src, size_t bytes, hipMemcpyKi
 hipError_t Memcpy2DSafe(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind);
 hipError_t Memcpy2DAsyncSafe(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t st);
 
+// The page-locked host memory the copies above may read or write in place is the library's own: every hipHostMalloc /
+// hipHostRegister of the library goes through these (macros below) and is noted in a list; everything else is pageable to
+// the wrappers (common.cc says why the runtime is not asked).
+void NotePinned(const void *p, size_t bytes);
+void ForgetPinned(const void *p);
+bool IsNotedPinned(const void *p, size_t bytes);
+hipError_t HostMallocNoted(void **p, size_t bytes, unsigned flags);
+hipError_t HostFreeNoted(void *p);
+hipError_t HostRegisterNoted(void *p, size_t bytes, unsigned flags);
+hipError_t HostUnregisterNoted(void *p);
+template <typename T>
+inline hipError_t HostMallocNotedT(T **p, size_t bytes, unsigned flags = hipHostMallocDefault) {
+  return HostMallocNoted(reinterpret_cast<void **>(p), bytes, flags);
+}
+
 template <typename T>
 inline T *DevAlloc(size_t n) {
   void *p = NULL;
@@ -93,5 +108,9 @@ __host__ __device__ inline float OrderedToFloat(uint32_t u) {
 #define hipMemcpyAsync(...) kamd::MemcpyAsyncSafe(__VA_ARGS__)
 #define hipMemcpy2D(...) kamd::Memcpy2DSafe(__VA_ARGS__)
 #define hipMemcpy2DAsync(...) kamd::Memcpy2DAsyncSafe(__VA_ARGS__)
+#define hipHostMalloc(...) kamd::HostMallocNotedT(__VA_ARGS__)
+#define hipHostFree(p) kamd::HostFreeNoted(p)
+#define hipHostRegister(...) kamd::HostRegisterNoted(__VA_ARGS__)
+#define hipHostUnregister(p) kamd::HostUnregisterNoted(p)
 #endif
 #endif

@@ -205,6 +205,11 @@ struct StreamBatch {
   // PruneActiveTokens as arena compaction: a stream whose token or link arena is fuller than this fraction at the start
   // of a tick is compacted first (kamd_decoder_compact); 0 = never
   float compact_at = 0.5f;
+  // LatticeFasterDecoderConfig::prune_interval for streams (lattice-faster-decoder.cc:617-619: PruneActiveTokens every
+  // prune_interval frames): a stream that has decoded this many frames since its last compaction is compacted at the start of
+  // its next tick.  0 = never (FinalizeDecoding then sweeps every frame of the utterance at once: the end-of-utterance latency).
+  int prune_interval = 0;
+  std::vector<int> compacted_at;        // frames decoded at the stream's last compaction
   int64_t n_compactions = 0;
   int S = 0, dim = 0, ld = 0, P = 0, max_frames = 0;
   int64_t max_samples = 0;
@@ -335,6 +340,12 @@ int kamd_stream_batch_set_compaction(kamd_stream_batch *h, float fraction) {
   StreamBatch *b = reinterpret_cast<StreamBatch *>(h);
   if (!(fraction >= 0.0f && fraction < 1.0f)) return kamd::SetError(KAMD_ERR_ARG, "compaction threshold must be in [0, 1)");
   b->compact_at = fraction;
+  return KAMD_OK;
+}
+int kamd_stream_batch_set_prune_interval(kamd_stream_batch *h, int frames) {
+  StreamBatch *b = reinterpret_cast<StreamBatch *>(h);
+  if (frames < 0) return kamd::SetError(KAMD_ERR_ARG, "prune interval must be >= 0");
+  b->prune_interval = frames;
   return KAMD_OK;
 }
 int64_t kamd_stream_batch_num_compactions(const kamd_stream_batch *h) { return reinterpret_cast<const StreamBatch *>(h)->n_compactions; }
@@ -478,13 +489,18 @@ int kamd_stream_batch_advance(kamd_stream_batch *h, const int32_t *streams, int 
         return kamd::SetError(KAMD_ERR_CAPACITY, "stream %d: more frames than reserved", s);
     }
   }
-  if (b->compact_at > 0.0f) {
+  if (b->compact_at > 0.0f || b->prune_interval > 0) {
     // the usage figures are those of the sync that ended the streams' previous tick
+    if (b->compacted_at.size() != static_cast<size_t>(b->S)) b->compacted_at.assign(b->S, 0);
     std::vector<int32_t> full;
     for (int i = 0; i < n; i++) {
+      const int s = streams[i];
       int32_t tu = 0, tc = 1, lu = 0, lc = 1;
-      if (kamd_decoder_lane_usage(b->dec, streams[i], &tu, &tc, &lu, &lc) != KAMD_OK) return KAMD_ERR_ARG;
-      if (b->decoded[streams[i]] > 0 && (tu > b->compact_at * tc || lu > b->compact_at * lc)) full.push_back(streams[i]);
+      if (kamd_decoder_lane_usage(b->dec, s, &tu, &tc, &lu, &lc) != KAMD_OK) return KAMD_ERR_ARG;
+      if (b->compacted_at[s] > b->decoded[s]) b->compacted_at[s] = 0;          // (the stream was restarted)
+      const bool arena = b->compact_at > 0.0f && (tu > b->compact_at * tc || lu > b->compact_at * lc);
+      const bool due = b->prune_interval > 0 && b->decoded[s] - b->compacted_at[s] >= b->prune_interval;
+      if (b->decoded[s] > 0 && (arena || due)) { full.push_back(s); b->compacted_at[s] = b->decoded[s]; }
     }
     if (!full.empty()) {
       int rc = kamd_decoder_compact(b->dec, full.data(), static_cast<int>(full.size()), st);

@@ -327,6 +327,11 @@ class StreamBatch:
         """PruneActiveTokens as arena compaction when a stream's arena is fuller than `fraction` (default 0.5; 0 = never)"""
         check(lib().kamd_stream_batch_set_compaction(self._h, float(fraction)))
 
+    def set_prune_interval(self, frames):
+        """LatticeFasterDecoderConfig.prune_interval for streams: PruneActiveTokens (arena compaction) of a stream every `frames`
+        decoded frames, between ticks; FinalizeDecoding then finds all but the last frames pruned.  0 = never (default)."""
+        check(lib().kamd_stream_batch_set_prune_interval(self._h, int(frames)))
+
     def num_compactions(self):
         return int(lib().kamd_stream_batch_num_compactions(self._h))
 

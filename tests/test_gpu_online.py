@@ -174,6 +174,61 @@ def test_batched_streams_equal_offline():
     assert lattices_equal(sb.raw_lattice(2), offline(waves[2]))
 
 
+def test_streams_pruned_every_prune_interval_frames_end_on_the_offline_lattice():
+    """kamd_stream_batch_set_prune_interval = LatticeFasterDecoderConfig::prune_interval (lattice-faster-decoder.cc:617-619): a
+    stream is compacted (PruneActiveTokens) whenever it has decoded that many frames since its last compaction, so that the
+    FinalizeDecoding at the end of the utterance finds all but the last frames pruned.  The final raw lattice of every stream
+    is still the offline decode of its whole waveform bit for bit, partial best paths in between stay those of the full
+    walk, and a restarted stream counts its frames from zero again."""
+    g = synth.make_hclg(num_units=20, vocab=40, n_hist=8, seed=2)
+    m = nnet.tdnnf_tiny(num_pdfs=g.num_pdfs, output_scale=3.0)
+    N, G = decoder.Nnet(m), decoder.Graph(g)
+    op, cfg = abi.mfcc_opts_hires(), abi.decoder_config_recipe()
+    S = 4
+    sb = online.StreamBatch(op, N, G, cfg, S, max_seconds=6.0, sizes=abi.DecoderSizes(S, 1 << 14, 1 << 19, 1 << 20, 512))
+    sb.set_compaction(0.0)                                    # (only the interval compacts)
+    sb.set_prune_interval(25)
+    waves = [synth.make_wave(d, seed=20 + i) for i, d in enumerate([3.9, 1.3, 5.1, 2.2])]
+    off_sz = abi.DecoderSizes(1, 1 << 14, 1 << 19, 1 << 20, 512)
+
+    def offline(w):
+        d = decoder.LatticeFasterDecoder(G, cfg, off_sz)
+        d.Decode(N.Forward(feat.Mfcc(op).ComputeFeatures(w)))
+        return d.GetRawLattice(), d.GetBestPath()
+
+    sb.start(np.arange(S))
+    pos = [0] * S
+    rng = np.random.default_rng(5)
+    while any(pos[s] < waves[s].size for s in range(S)):
+        live = [s for s in range(S) if pos[s] < waves[s].size]
+        for s in live:
+            n = int(rng.integers(1500, 5000))
+            sb.accept(s, waves[s][pos[s]:pos[s] + n], input_finished=pos[s] + n >= waves[s].size)
+            pos[s] += n
+        nd = sb.advance(live)
+        cand = [s for s, d in zip(live, nd) if d > 0]
+        if cand:
+            for a, b in zip(sb.partial_best_paths(cand, incremental=True), sb.partial_best_paths(cand)):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert a["words"].tolist() == b["words"].tolist() and a["graph_cost"] == b["graph_cost"] and a["acoustic_cost"] == b["acoustic_cost"]
+    n_comp = sb.num_compactions()
+    assert n_comp >= 3 + 1 + 4 + 2                              # output frames // (25 + a tick's worth) per stream, at least
+    sb.finalize(np.arange(S))
+    for s in range(S):
+        want, bp = offline(waves[s])
+        got = sb.raw_lattice(s)
+        assert lattices_equal(got, want), (s, lattice_diff(got, want))
+        assert sb.best_path(s)["words"].tolist() == bp["words"].tolist()
+    w2 = synth.make_wave(2.9, seed=77)                        # a slot reused: its frame count starts over
+    sb.start([2])
+    for i in range(0, w2.size, CHUNK):
+        sb.accept(2, w2[i:i + CHUNK], input_finished=i + CHUNK >= w2.size)
+        sb.advance([2])
+    sb.finalize([2])
+    assert lattices_equal(sb.raw_lattice(2), offline(w2)[0]) and sb.num_compactions() > n_comp
+
+
 def test_batched_streams_with_online_ivectors():
     """online2-wav-nnet3-latgen-faster with an i-vector extractor, two streams fed in different chunkings:
     (1) the slots' i-vectors equal the oracle's GetFrame sequence under the reference's chunk schedule

@@ -103,6 +103,20 @@ def test_every_copy_of_the_library_goes_through_the_bounce_buffer_wrappers():
     # the caller's samples are page-locked in place only over the pages that lie wholly inside them (batch.cc, load_host)
     b = open(os.path.join(csrc, "batch.cc")).read()
     assert b.count("hipHostRegister(") == 1 and "hipHostRegister(reinterpret_cast<void *>(in_lo), in_hi - in_lo" in b
+    # what counts as page-locked is the library's own list, never the runtime's (stale) view: no hipPointerGetAttributes in the
+    # wrappers, and every hipHostMalloc / hipHostFree / hipHostRegister / hipHostUnregister of the library is noted there
+    cc = re.sub(r"//[^\n]*", "", open(os.path.join(csrc, "common.cc")).read())
+    assert "hipPointerGetAttributes" not in cc and "g_pinned" in cc
+    h = open(os.path.join(csrc, "common.h")).read()
+    for name, to in (("hipHostMalloc(...)", "HostMallocNotedT(__VA_ARGS__)"), ("hipHostFree(p)", "HostFreeNoted(p)"),
+                     ("hipHostRegister(...)", "HostRegisterNoted(__VA_ARGS__)"), ("hipHostUnregister(p)", "HostUnregisterNoted(p)")):
+        assert "#define %s kamd::%s" % (name, to) in h, name
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".cc", ".hip")) and f != "common.cc":
+            text = open(os.path.join(csrc, f)).read()
+            assert "::hipHost" not in text and "hipPointerGetAttributes" not in text, f
+            if "hipHostMalloc" in text or "hipHostRegister" in text:
+                assert '#include "common.h"' in text or '#include "meta_ring.h"' in text, f
     # the hpp mirror and the examples are host programs over the C-ABI: they copy nothing themselves
     for f in (os.path.join(ROOT, "include", "kaldi_amd.hpp"),) + tuple(os.path.join(ROOT, "examples", x) for x in os.listdir(os.path.join(ROOT, "examples"))):
         assert "hipMemcpy" not in open(f).read(), f

@@ -61,13 +61,15 @@ def single_stream(N, G, cfg, seconds=12.0, chunk=0.24, reps=2):
 
 
 def many_streams(g, N, G, cfg, ie, S, seconds=12.0, chunk=0.24, accept_each=False, partials=True, partials_incremental=True,
-                 endpointing=False, silence_weighting=False, reps=2):
+                 endpointing=False, silence_weighting=False, reps=2, prune_interval=0):
     """S concurrent streams through kamd_stream_batch: one upload and one features / nnet / AdvanceDecoding tick for all."""
     from kaldi_amd import abi, online, synth
     waves = [synth.make_wave(seconds, seed=100 + i) for i in range(S)]
     sb = online.StreamBatch(abi.mfcc_opts_hires(), N, G, cfg, S, max_seconds=seconds + 1)
     num_tids = len(g.tid2pdf) - 1
     tid2phone = np.concatenate([[0], np.arange(num_tids) // 2 + 1]).astype(np.int32)
+    if prune_interval > 0:          # LatticeFasterDecoderConfig::prune_interval: PruneActiveTokens of a stream every that many frames
+        sb.set_prune_interval(prune_interval)
     if ie is not None:
         sb.set_ivector_extractor(ie, 20)
         if silence_weighting:
@@ -111,7 +113,7 @@ def many_streams(g, N, G, cfg, ie, S, seconds=12.0, chunk=0.24, accept_each=Fals
            "upload_ms_per_tick": float(np.median(up)), "ms_per_tick": float(np.median(adv)), "ms_per_tick_p95": float(np.percentile(adv, 95)),
            "ms_per_tick_max": float(adv.max()), "aggregate_x_rt": float(S * seconds * 1e3 / (adv.sum() + up.sum())),
            "aggregate_x_rt_compute_only": float(S * seconds * 1e3 / adv.sum()), "finalize_ms": float(fin * 1e3),
-           "finalize_ms_per_stream": float(fin * 1e3 / S), "lattice_fetch_and_best_path_ms_stream_0": float(fetch0 * 1e3),
+           "finalize_ms_per_stream": float(fin * 1e3 / S), "prune_interval": int(prune_interval), "compactions": int(sb.num_compactions()), "lattice_fetch_and_best_path_ms_stream_0": float(fetch0 * 1e3),
            "tokens_per_frame_stream_0": float(cnt[5] / max(cnt[6], 1)), "expanded_per_frame_stream_0": float(cnt[0] / max(cnt[6], 1)),
            "online_ivectors": ie is not None, "silence_weighting": bool(silence_weighting and ie is not None)}
     if partials and pb_ms:
@@ -136,13 +138,15 @@ def main():
     ap.add_argument("--endpointing", action="store_true", help="with --streams: EndpointDetected for all streams after every tick (one traceback launch)")
     ap.add_argument("--ivectors", action="store_true", help="with --streams: the model takes 100-dim online i-vectors, estimated per "
                     "stream on the device (512-Gaussian UBM) and fed on DecodableNnetLoopedOnline's chunk schedule (--frames-per-chunk 20)")
+    ap.add_argument("--prune-interval", type=int, default=0, help="with --streams: LatticeFasterDecoderConfig::prune_interval -- a stream is pruned "
+                    "(kamd_decoder_compact) every that many decoded frames, between ticks (the reference's default: 25); 0 = only at the end")
     ap.add_argument("--silence-weighting", action="store_true", help="with --ivectors: --ivector-silence-weighting.* on (every second "
                     "phone counts as silence, weight 0.001, max-state-duration 100): one more traceback launch per tick")
     a = ap.parse_args()
     g, model, N, G, cfg, ie = build(a.ll_std, a.ivectors, a.seconds)
     if a.streams > 0:
         r = many_streams(g, N, G, cfg, ie, a.streams, a.seconds, a.chunk, a.accept_each, a.partials, a.partials_incremental,
-                         a.endpointing, a.silence_weighting)
+                         a.endpointing, a.silence_weighting, prune_interval=a.prune_interval)
         print("%d streams x %.1f s in %.0f ms chunks: %d ticks, %d frames decoded per stream" % (r["streams"], a.seconds, a.chunk * 1e3, r["ticks"], r["frames_decoded_per_stream"]))
         print("per tick: upload (%s) %.2f ms + features/nnet/AdvanceDecoding for all streams %.2f ms median (p95 %.2f, max %.2f)"
               % ("one copy per stream" if a.accept_each else "one copy for all", r["upload_ms_per_tick"], r["ms_per_tick"], r["ms_per_tick_p95"], r["ms_per_tick_max"]))
