@@ -800,9 +800,10 @@ def main():
                             "flops the layers really multiply -- with online i-vectors the model is evaluated chunk by chunk like DecodableNnetSimple "
                             "and every chunk recomputes its context rows with its own i-vector, as the reference does")
     # The dominant KERNEL: the search is one launch of one kernel; the acoustic model is hundreds of launches of several GEMM kernels, the
-    # largest of which (TdnnGemmPersistKernel, the N = 160 layers) takes 0.46 of the stage (profiles/r0*_kernel_stats_bench_default.csv)
-    NNET_LARGEST_KERNEL_SHARE = 0.46
-    dominant_is_decoder = dec_ms >= NNET_LARGEST_KERNEL_SHARE * nnet_ms
+    # largest of which takes a share of the stage that is read from the newest committed kernel table (profiles/r*_kernel_stats_bench_
+    # default.csv; 0.46 when there is none) -- the choice and what it was made from are in the line (`dominant_kernel_choice`)
+    gemm_share, gemm_share_src = largest_gemm_kernel_share()
+    dominant_is_decoder = dec_ms >= gemm_share * nnet_ms
     wav_bytes = 4.0 * sum(w.size for w in waves)
     load_name = "token-matched" if (args.workload == "librispeech" and args.graph == "tglarge") else "default"
     if faithful:
@@ -847,6 +848,10 @@ def main():
                                                       "stream, pass by pass; the model of pass k runs while pass k + 1 is copied (first pass %d frames)" % args.first_pass_frames},
         "rank_wall_s": rank_walls, "rank0_wall_s": my_dt,
         "decoder": dec_stats,
+        "dominant_kernel_choice": {"search_kernel_ms": dec_ms, "acoustic_model_stage_ms": nnet_ms, "largest_gemm_kernel_share_of_stage": gemm_share,
+                                   "share_from": gemm_share_src, "largest_gemm_kernel_ms": gemm_share * nnet_ms,
+                                   "roofline_is": "the search kernel" if dominant_is_decoder else "the acoustic model's GEMMs",
+                                   "larger_stage": "search" if dec_ms >= nnet_ms else "acoustic model"},
         "roofline": dec_roof if dominant_is_decoder else nnet_roof,
         "roofline_other_stage": nnet_roof if dominant_is_decoder else dec_roof,
         "phase_share_longest_utterance": {k2: round(float(v / max(ph.sum(), 1.0)), 3) for k2, v in zip(PHASES, ph)},
@@ -1230,6 +1235,22 @@ def pmc_entry(args):
                 if d.get("workload_key") == key and d.get("library_build") == build:
                     best = dict(d, file=f)
     return best
+
+
+def largest_gemm_kernel_share():
+    """Share of the acoustic model's GPU time taken by its single largest GEMM kernel, from the newest committed rocprofv3 kernel
+    table of the default bench (profiles/rNN_kernel_stats_bench_default.csv): (share, where it came from)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_stats_bench_default.csv")))
+    for f in reversed(files):
+        try:
+            gemm = [float(r["TotalDurationNs"]) for r in csv.DictReader(open(f)) if "TdnnGemm" in r["Name"]]
+        except (OSError, KeyError, ValueError):
+            continue
+        if gemm and sum(gemm) > 0:
+            return max(gemm) / sum(gemm), "profiles/" + os.path.basename(f)
+    return 0.46, "no kernel table under profiles/: round 5's figure"
 
 
 def pmc_traffic(args, which):

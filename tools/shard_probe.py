@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--utts", type=int, default=0)
     ap.add_argument("--long-lanes", type=int, default=0, help="kamd_batch_decoder_set_long_decoder: lanes of the second decoder object")
+    ap.add_argument("--long-lanes-from", type=int, default=0, help="use --long-lanes (default 32) only for worlds >= this (bench.py arms the long-utterance "
+                    "decoder from 4 ranks up): one run, every row's efficiency against the SAME N = 1 row")
     ap.add_argument("--tokens-per-frame", type=int, default=0, help="arena budget per frame and lane of both decoder objects (0 = from max-active / free HBM)")
     ap.add_argument("--host", action="store_true", help="the waveforms are uploaded inside run() (bench.py's default contract) instead of resident")
     ap.add_argument("--faithful", action="store_true", help="bench.py's round-4 headline: the i-vector model (chunked, device extractor) on planted transcripts")
@@ -43,13 +45,16 @@ def main():
     out = []
     base = None
     for world in [int(x) for x in a.worlds.split(",")]:
+        long_lanes = a.long_lanes
+        if a.long_lanes_from > 0:
+            long_lanes = (a.long_lanes or 32) if world >= a.long_lanes_from else 0
         mine = shard.lpt_shards(durs, world)[a.rank % world]
         pset = bench.planted_testset(g, durs, mine, synth) if a.faithful else None
         waves = pset["waves"] if a.faithful else synth.make_waves_fast(durs[mine], seed=1000 + a.rank)
         audio = sum(w.size for w in waves) / 16000.0
         bd = batch.NnetBatchDecoder(abi.mfcc_opts_hires(), model, g, cfg, max_seconds=pset["max_seconds"] if a.faithful else float(durs.max()) + 0.5,
                                     resident_lanes=a.lanes, host_threads=16, determinize=True, keep_raw_lattices=False, hash_capacity=args.hash_capacity or None,
-                                    search_mode=args.search_mode, lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), long_lanes=a.long_lanes,
+                                    search_mode=args.search_mode, lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), long_lanes=long_lanes,
                                     tokens_per_frame=a.tokens_per_frame or (11000 if a.faithful else None),
                                     **(dict(nnet_pass_frames=800000, hbm_fraction=0.40) if a.faithful else {}))
         planted = None
@@ -80,7 +85,7 @@ def main():
         total_audio = float(durs.sum()) if not a.faithful else audio * world      # (LPT shards: equal audio per rank to 0.1 %)
         rate = total_audio / dt
         if base is None:
-            base = rate / world
+            base = rate / world          # (the first world of the list -- 1 unless asked otherwise -- is every row's base)
         row = {"world": world, "utterances_this_rank": len(waves), "audio_this_rank_s": audio, "longest_s": float(durs[mine].max()),
                "step_ms": 1e3 * dt, "feat_ms": acc[0], "nnet_ms": acc[1], "decode_ms": acc[2], "tail_ms": acc[3],
                "implied_x_real_time_all_ranks": rate, "implied_strong_scaling_efficiency": rate / (base * world), "long_utterances": long_utts,
