@@ -453,6 +453,20 @@ __device__ inline void LdsBar() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+// n doubles (n even: 16-byte chunks) from global memory into LDS by DMA, the 256 threads of the workgroup together; returns at
+// once -- the data is there after s_waitcnt vmcnt(0) + a barrier.  Inline asm like the decoder's RowDma / the GEMM's operand
+// ring: the compiler's own tracking of the builtin would drain vmcnt before every later ds_read.
+__device__ __forceinline__ void StageDma(double *lds, const double *src, int n) {
+  typedef __attribute__((address_space(3))) unsigned char lds_byte;
+  const unsigned base = static_cast<unsigned>(reinterpret_cast<size_t>((lds_byte *)lds));
+  const int tid = threadIdx.x, chunks = n / 2;                       // 16-byte chunks
+  for (int c0 = 0; c0 < chunks; c0 += 256) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(base + static_cast<unsigned>(c0 + (tid & ~63)) * 16u);
+    if (c0 + tid < chunks)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src + 2 * (c0 + tid)) : "memory");
+  }
+}
+
 // One workgroup per utterance, sequential over its i-vector steps.  The symmetric quadratic term
 // lives in REGISTERS: wavefront w owns columns [w*CW, (w+1)*CW), lane l rows l and l+64 of them
 // (2*CW doubles per thread).  y = A v is four partial products (one per wavefront, v broadcast
@@ -460,7 +474,7 @@ __device__ inline void LdsBar() {
 // products by DPP), wavefronts 1-3 serve its matrix-vector requests.  Step i+1's increment is
 // fetched into registers while step i iterates and parked in LDS between the two.
 constexpr int IV_CW = IV_MAX_DIM / 4;
-__global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
+__global__ __launch_bounds__(256, 2) void SolveKernel(IvDev d, IvBatch b) {
   extern __shared__ double sl[];               // stage[Q], v[IV_MAX_DIM], part[4][IV_MAX_DIM], lin[IV_MAX_DIM]
   const int u = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const IvUtt ut = b.utt[u];
@@ -493,7 +507,6 @@ __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
   if (rec_in && b.x_off >= 0) { if (ha) xa = rec_in[b.x_off + ra]; if (hb) xb = rec_in[b.x_off + rb]; }
   const int n_iv = ut.n_steps;
   const int64_t row0 = ut.inc_row;
-  constexpr int QPT = (IV_MAX_DIM * (IV_MAX_DIM + 1) / 2 + 255) / 256;
   for (int q = tid; q < Q; q += 256) stage[q] = b.dquad[row0 * Q + q];
   double nl = tid < I ? b.dlin[row0 * I + tid] : 0.0;
   double ntw = b.dtotw[row0];
@@ -509,24 +522,31 @@ __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
 
   for (int i = 0; i < n_iv; i++) {
     // ---- this step's increment: packed lower triangle in `stage` -> the register tile
+    // (the 64 packed-triangle positions are functions of the lane alone: the compiler would compute them once, outside the
+    // loop over the steps, and keep 64 VGPRs alive for good -- the row numbers are made opaque per step instead, a few
+    // hundred integer instructions against the step's 15 CG iterations)
+    int ra_s = ra, rb_s = rb;
+    asm volatile("" : "+v"(ra_s), "+v"(rb_s));
 #pragma unroll
     for (int k = 0; k < IV_CW; k++) {
       const int c = c0 + k;
       if (c < I) {
-        if (ha) Aa[k] += stage[ra >= c ? ra * (ra + 1) / 2 + c : c * (c + 1) / 2 + ra];
-        if (hb) Ab[k] += stage[rb >= c ? rb * (rb + 1) / 2 + c : c * (c + 1) / 2 + rb];
+        if (ha) Aa[k] += stage[ra_s >= c ? ra_s * (ra_s + 1) / 2 + c : c * (c + 1) / 2 + ra_s];
+        if (hb) Ab[k] += stage[rb_s >= c ? rb_s * (rb_s + 1) / 2 + c : c * (c + 1) / 2 + rb_s];
       }
+      // (eight columns' reads at a time: left to itself the scheduler issues all 64 reads first and holds 128 more VGPRs)
+      if ((k & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     if (tid < I) lin[tid] += nl;
     if (tid == 0) s_totw = ntw;
-    // the next step's increment, in flight during this step's CG
-    double nq[QPT];
+    // the next step's increment, in flight during this step's CG: its quadratic part travels HBM -> LDS by DMA
+    // (global_load_lds_dwordx4: no registers held -- the 66 VGPRs a register prefetch of it took were what kept the kernel
+    // at one workgroup per CU), straight into `stage`, which nobody reads between the barrier below and the end of the step
     const bool more = i + 1 < n_iv;
     const int64_t rn = row0 + i + 1;
-#pragma unroll
-    for (int m = 0; m < QPT; m++) { const int q = tid + 256 * m; nq[m] = (more && q < Q) ? b.dquad[rn * Q + q] : 0.0; }
     if (more) { nl = tid < I ? b.dlin[rn * I + tid] : 0.0; ntw = b.dtotw[rn]; }
-    LdsBar();
+    LdsBar();                                    // (everybody has taken this step's increment out of `stage`)
+    if (more) StageDma(stage, b.dquad + rn * Q, Q);
     if (d.max_count > 0.0) {
       const double old_n = s_num_frames, new_n = s_num_frames + s_totw;
       const double change = fmax(new_n, d.max_count) / d.max_count - fmax(old_n, d.max_count) / d.max_count;
@@ -602,9 +622,10 @@ __global__ __launch_bounds__(256) void SolveKernel(IvDev d, IvBatch b) {
       if (hb) o[rb] = static_cast<float>(xb);
       }
     }
-    // park the prefetched increment in LDS for the next step (everybody is past the reads of `stage`)
-#pragma unroll
-    for (int m = 0; m < QPT; m++) { const int q = tid + 256 * m; if (q < Q) stage[q] = nq[m]; }
+    // the next step's increment has landed in `stage` (this wave's DMAs: vmcnt; everybody's: the barrier); an odd Q's last
+    // double is no 16-byte chunk and follows here (not the recipe's case: Q = 5050)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (more && (Q & 1) && tid == 0) stage[Q - 1] = b.dquad[rn * Q + Q - 1];
     __syncthreads();
   }
   if (b.state_out && ut.state_idx >= 0) {        // GetAdaptationState: the statistics as of the last i-vector

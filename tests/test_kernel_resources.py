@@ -60,3 +60,24 @@ def test_search_kernels_have_register_head_room_and_no_scratch():
     for name, k in usage.items():
         assert k.get("ScratchSize [bytes/lane]", 0) == 0, (name, k)
         assert k.get("VGPRs", 0) <= 128, (name, k)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="no hipcc")
+def test_ivector_solver_fits_two_workgroups_per_cu():
+    """SolveKernel (one sequential CG chain per utterance) is bound by how many chains a CU holds at once.  Rounds 2-5's build
+    took 256 VGPRs + 160 AGPRs per thread -- one 256-thread workgroup per CU, 256 chains on the device -- because the next
+    step's increment was prefetched into 66 registers and 64 packed-triangle positions were kept alive across the steps.
+    Round 6 (DMA prefetch into LDS, positions recomputed per step): at most 256 registers, nothing in scratch, two workgroups
+    per CU."""
+    mk = open(os.path.join(ROOT, "kaldi_amd", "csrc", "Makefile")).read()
+    flags = re.search(r"^FLAGS = (.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").replace("$(KAMD_NT)", "1024").split()
+    tmp = os.path.join(ROOT, "kaldi_amd", "build", "_resources_iv")
+    os.makedirs(tmp, exist_ok=True)
+    r = subprocess.run([HIPCC] + flags + ["-Rpass-analysis=kernel-resource-usage", "-c", "-o", os.path.join(tmp, "ivector.o"),
+                                          os.path.join(ROOT, "kaldi_amd", "csrc", "ivector.hip")], capture_output=True, text=True)
+    shutil.rmtree(tmp, ignore_errors=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    block = r.stderr[r.stderr.index("SolveKernel"):]
+    get = lambda what: int(re.search(r"remark:\s+%s: (\d+)" % re.escape(what), block).group(1))      # noqa: E731
+    assert get("VGPRs") + get("AGPRs") <= 256 and get("ScratchSize [bytes/lane]") == 0 and get("VGPRs Spill") == 0
+    assert get("Occupancy [waves/SIMD]") >= 2
