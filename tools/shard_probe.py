@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--long-lanes", type=int, default=0, help="kamd_batch_decoder_set_long_decoder: lanes of the second decoder object")
     ap.add_argument("--long-lanes-from", type=int, default=0, help="use --long-lanes (default 32) only for worlds >= this (bench.py arms the long-utterance "
                     "decoder from 4 ranks up): one run, every row's efficiency against the SAME N = 1 row")
+    ap.add_argument("--hbm-fraction", type=float, default=0.40, help="(with --faithful) share of the free HBM the search arenas take")
+    ap.add_argument("--nnet-pass-frames", type=int, default=800000, help="(with --faithful) input frames per pass of the acoustic model")
     ap.add_argument("--tokens-per-frame", type=int, default=0, help="arena budget per frame and lane of both decoder objects (0 = from max-active / free HBM)")
     ap.add_argument("--host", action="store_true", help="the waveforms are uploaded inside run() (bench.py's default contract) instead of resident")
     ap.add_argument("--faithful", action="store_true", help="bench.py's round-4 headline: the i-vector model (chunked, device extractor) on planted transcripts")
@@ -56,7 +58,7 @@ def main():
                                     resident_lanes=a.lanes, host_threads=16, determinize=True, keep_raw_lattices=False, hash_capacity=args.hash_capacity or None,
                                     search_mode=args.search_mode, lattice_pool_bytes=max(1 << 30, int(audio * 3.0e5)), long_lanes=long_lanes,
                                     tokens_per_frame=a.tokens_per_frame or (11000 if a.faithful else None),
-                                    **(dict(nnet_pass_frames=800000, hbm_fraction=0.40) if a.faithful else {}))
+                                    **(dict(nnet_pass_frames=a.nnet_pass_frames, hbm_fraction=a.hbm_fraction) if a.faithful else {}))
         planted = None
         if extractor is not None:
             bd.set_ivector_extractor(extractor, 50)
