@@ -193,91 +193,137 @@ __global__ __launch_bounds__(256) void FrontKernel(IvDev d, IvBatch b) {
   }
   __syncthreads();
   const int nf = min(IV_FT, ut.proc_end - t0);
-  for (int i = tid; i < 2 * nf * d.D; i += 256) {
-    const int which = i / (nf * d.D), rem = i - which * nf * d.D;
-    const int f = rem / d.D, o = rem - f * d.D;
-    const float *src = (which ? raw : nrm) + f * dim;        // spliced vector = rows f .. f + L + R of the tile
-    float acc = d.affine ? d.ldaT[static_cast<size_t>(d.sd) * d.D + o] : 0.f;
-    for (int k = 0; k < d.sd; k++) acc = acc + d.ldaT[static_cast<size_t>(k) * d.D + o] * src[k];
-    (which ? b.raw_lda : b.norm_lda)[(ut.ws_row + t0 + f) * d.D + o] = acc;
+  // an item = (variant, output dimension o, four consecutive frames): the LDA coefficient a thread loads serves four frames
+  // (the kernel is a chain of dependent multiply-adds per output: 1400 per thread with one frame per item, 560 now); every
+  // output's sum runs over k in the same order as before
+  constexpr int FQ = 4;
+  const int nq = (nf + FQ - 1) / FQ;
+  for (int i = tid; i < 2 * nq * d.D; i += 256) {
+    const int which = i / (nq * d.D), rem = i - which * nq * d.D;
+    const int fq = rem / d.D, o = rem - fq * d.D;
+    const float *src = (which ? raw : nrm) + fq * FQ * dim;   // spliced vector of frame f = rows f .. f + L + R of the tile
+    const float a0 = d.affine ? d.ldaT[static_cast<size_t>(d.sd) * d.D + o] : 0.f;
+    float acc[FQ];
+#pragma unroll
+    for (int j = 0; j < FQ; j++) acc[j] = a0;
+    for (int k = 0; k < d.sd; k++) {
+      const float c = d.ldaT[static_cast<size_t>(k) * d.D + o];
+#pragma unroll
+      for (int j = 0; j < FQ; j++) acc[j] = acc[j] + c * src[min(j, IV_FT - 1 - fq * FQ) * dim + k];     // (rows of the tile only: the clamp repeats the last one)
+    }
+#pragma unroll
+    for (int j = 0; j < FQ; j++)
+      if (fq * FQ + j < nf) (which ? b.raw_lda : b.norm_lda)[(ut.ws_row + t0 + fq * FQ + j) * d.D + o] = acc[j];
   }
 }
 
 // ---------------------------------------------------------------- UBM posteriors
+// F frames per wavefront (batch extraction: 4; streaming / weighted lists: 1): every UBM value a lane loads serves F frames --
+// the kernel is bound by those loads (164 KB of transposed means / inverse variances per wavefront, from L2), not by the
+// arithmetic.  Per frame the sums run in the same order whatever F is.
+template <int F>
 __global__ __launch_bounds__(256) void PostKernel(IvDev d, IvBatch b) {
-  extern __shared__ float plds[];              // per wave: x[D], p[G]
+  extern __shared__ float plds[];              // per wave: x[F][D], p[F][G]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const IvUtt ut = b.utt[blockIdx.y];
-  int frame = ut.proc_first + blockIdx.x * 4 + w;
   // posterior of one frame at weight 1, or (mode 2) of one list entry at its delta weight: min_post becomes
   // GetMinPost(weight), the posteriors are scaled by posterior_scale * weight (online-ivector-feature.cc:176-227)
-  float min_post = d.min_post, log_min_post = d.log_min_post, weight = 1.0f;
-  if (ut.mode == 2) {
-    const int entry = blockIdx.x * 4 + w;
-    if (entry >= ut.wl_n) return;
-    frame = b.wl_frame[ut.wl_off + entry]; weight = b.wl_weight[ut.wl_off + entry];
-    min_post = b.wl_minpost[ut.wl_off + entry]; log_min_post = b.wl_logminpost[ut.wl_off + entry];
-  } else if (frame >= ut.proc_end) return;
-  const int64_t row = ut.ws_row + frame;
-  float *x = plds + w * (d.D + d.G), *p = x + d.D;
-  for (int k = lane; k < d.D; k += 64) x[k] = b.norm_lda[row * d.D + k];
-  __builtin_amdgcn_wave_barrier();
-  float mx = -INFINITY;
-  for (int g = lane; g < d.G; g += 64) {        // DiagGmm::LogLikelihoods: means term, then variance term
-    float acc = d.gconsts[g];
-    for (int k = 0; k < d.D; k++) acc = acc + d.mivT[static_cast<size_t>(k) * d.G + g] * x[k];
-    for (int k = 0; k < d.D; k++) acc = acc + d.ivT[static_cast<size_t>(k) * d.G + g] * (x[k] * x[k]);
-    p[g] = acc;
-    mx = fmaxf(mx, acc);
-  }
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  // VectorToPosteriorEntry (hmm/posterior.cc:440-508)
-  const float cutoff = mx + log_min_post;
-  int n_cand = 0;
-  for (int g = lane; g < d.G; g += 64) {
-    const float like = p[g];
-    const bool in = min_post == 0.0f || like > cutoff;
-    p[g] = in ? expf(like - mx) : -1.0f;
-    n_cand += in;
-  }
-  for (int o = 32; o > 0; o >>= 1) n_cand += __shfl_xor(n_cand, o, 64);
-  (void)n_cand;   // never 0: the maximum itself passes (log(min_post) < 0), or min_post == 0 takes everything
-  float sel_p[IV_MAX_NG]; int sel_g[IV_MAX_NG];
-  int n = 0;
-  bool more = true;
+  int frame[F]; float min_post[F], log_min_post[F], weight[F]; bool on[F];
+  bool any = false;
 #pragma unroll
-  for (int j = 0; j < IV_MAX_NG; j++) {         // top num_gselect, ties -> smaller index
-    sel_p[j] = 0.f; sel_g[j] = -1;
-    if (j < d.ng && more) {
-      float bp = -1.0f; int bg = 0x7fffffff;
-      for (int g = lane; g < d.G; g += 64) { const float v = p[g]; if (v > bp) { bp = v; bg = g; } }
-      for (int o = 32; o > 0; o >>= 1) {
-        const float op = __shfl_xor(bp, o, 64); const int og = __shfl_xor(bg, o, 64);
-        if (op > bp || (op == bp && og < bg)) { bp = op; bg = og; }
+  for (int f = 0; f < F; f++) {
+    min_post[f] = d.min_post; log_min_post[f] = d.log_min_post; weight[f] = 1.0f;
+    const int item = (blockIdx.x * 4 + w) * F + f;
+    frame[f] = ut.proc_first + item;
+    if (ut.mode == 2) {
+      on[f] = item < ut.wl_n;
+      if (on[f]) {
+        frame[f] = b.wl_frame[ut.wl_off + item]; weight[f] = b.wl_weight[ut.wl_off + item];
+        min_post[f] = b.wl_minpost[ut.wl_off + item]; log_min_post[f] = b.wl_logminpost[ut.wl_off + item];
       }
-      if (bp < 0.0f) more = false;
-      else {
-        sel_p[j] = bp; sel_g[j] = bg; n = j + 1;
-        if ((bg & 63) == lane) p[bg] = -1.0f;
-        __builtin_amdgcn_wave_barrier();
+    } else {
+      on[f] = frame[f] < ut.proc_end;
+    }
+    if (!on[f]) frame[f] = ut.mode == 2 ? 0 : ut.proc_first;       // (a valid row to read; nothing is written for it)
+    any = any || on[f];
+  }
+  if (!any) return;
+  float *x = plds + w * F * (d.D + d.G), *p = x + F * d.D;
+#pragma unroll
+  for (int f = 0; f < F; f++)
+    for (int k = lane; k < d.D; k += 64) x[f * d.D + k] = b.norm_lda[(ut.ws_row + frame[f]) * d.D + k];
+  __builtin_amdgcn_wave_barrier();
+  float mx[F];
+#pragma unroll
+  for (int f = 0; f < F; f++) mx[f] = -INFINITY;
+  for (int g = lane; g < d.G; g += 64) {        // DiagGmm::LogLikelihoods: means term, then variance term
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) acc[f] = d.gconsts[g];
+    for (int k = 0; k < d.D; k++) {
+      const float m = d.mivT[static_cast<size_t>(k) * d.G + g];
+#pragma unroll
+      for (int f = 0; f < F; f++) acc[f] = acc[f] + m * x[f * d.D + k];
+    }
+    for (int k = 0; k < d.D; k++) {
+      const float iv = d.ivT[static_cast<size_t>(k) * d.G + g];
+#pragma unroll
+      for (int f = 0; f < F; f++) { const float xv = x[f * d.D + k]; acc[f] = acc[f] + iv * (xv * xv); }
+    }
+#pragma unroll
+    for (int f = 0; f < F; f++) { p[f * d.G + g] = acc[f]; mx[f] = fmaxf(mx[f], acc[f]); }
+  }
+#pragma unroll
+  for (int f = 0; f < F; f++) {
+    if (!on[f]) continue;                        // (uniform over the wavefront)
+    float *pf = p + f * d.G;
+    float mxf = mx[f];
+    for (int o = 32; o > 0; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o, 64));
+    // VectorToPosteriorEntry (hmm/posterior.cc:440-508)
+    const float cutoff = mxf + log_min_post[f];
+    for (int g = lane; g < d.G; g += 64) {
+      const float like = pf[g];
+      const bool in = min_post[f] == 0.0f || like > cutoff;
+      pf[g] = in ? expf(like - mxf) : -1.0f;      // never all out: the maximum itself passes (log(min_post) < 0), or min_post == 0 takes everything
+    }
+    float sel_p[IV_MAX_NG]; int sel_g[IV_MAX_NG];
+    int n = 0;
+    bool more = true;
+#pragma unroll
+    for (int j = 0; j < IV_MAX_NG; j++) {         // top num_gselect, ties -> smaller index
+      sel_p[j] = 0.f; sel_g[j] = -1;
+      if (j < d.ng && more) {
+        float bp = -1.0f; int bg = 0x7fffffff;
+        for (int g = lane; g < d.G; g += 64) { const float v = pf[g]; if (v > bp) { bp = v; bg = g; } }
+        for (int o = 32; o > 0; o >>= 1) {
+          const float op = __shfl_xor(bp, o, 64); const int og = __shfl_xor(bg, o, 64);
+          if (op > bp || (op == bp && og < bg)) { bp = op; bg = og; }
+        }
+        if (bp < 0.0f) more = false;
+        else {
+          sel_p[j] = bp; sel_g[j] = bg; n = j + 1;
+          if ((bg & 63) == lane) pf[bg] = -1.0f;
+          __builtin_amdgcn_wave_barrier();
+        }
       }
     }
-  }
-  float tot = 0;
+    float tot = 0;
 #pragma unroll
-  for (int j = 0; j < IV_MAX_NG; j++) if (j < n) tot += sel_p[j];
-  const float cut2 = min_post * tot;
+    for (int j = 0; j < IV_MAX_NG; j++) if (j < n) tot += sel_p[j];
+    const float cut2 = min_post[f] * tot;
 #pragma unroll
-  for (int j = IV_MAX_NG - 1; j >= 1; j--)      // pop from the back while below min_post of the kept mass
-    if (j == n - 1 && sel_p[j] < cut2) { tot -= sel_p[j]; n--; }
-  const float inv = 1.0f / tot;
-  if (lane < d.ng) {
-    float wv = 0.f; int gv = -1;
+    for (int j = IV_MAX_NG - 1; j >= 1; j--)      // pop from the back while below min_post of the kept mass
+      if (j == n - 1 && sel_p[j] < cut2) { tot -= sel_p[j]; n--; }
+    const float inv = 1.0f / tot;
+    if (lane < d.ng) {
+      float wv = 0.f; int gv = -1;
 #pragma unroll
-    for (int j = 0; j < IV_MAX_NG; j++)
-      if (j == lane && j < n) { wv = sel_p[j] * inv; wv *= d.post_scale * weight; gv = sel_g[j]; }
-    b.post_g[row * d.ng + lane] = gv;
-    b.post_w[row * d.ng + lane] = wv;
+      for (int j = 0; j < IV_MAX_NG; j++)
+        if (j == lane && j < n) { wv = sel_p[j] * inv; wv *= d.post_scale * weight[f]; gv = sel_g[j]; }
+      const int64_t row = ut.ws_row + frame[f];
+      b.post_g[row * d.ng + lane] = gv;
+      b.post_w[row * d.ng + lane] = wv;
+    }
   }
 }
 
@@ -938,8 +984,16 @@ static int RunBatch(IvExtractor *e, const float *d_feats, int ld_feat, const std
     hipLaunchKernelGGL(kamd::FrontKernel, dim3(kamd::CeilDiv(max_proc, kamd::IV_FT), n), dim3(256), lds_front, st, v, b);
   }
   if (phase != 2 && max_post > 0) {
-    const size_t lds_post = static_cast<size_t>(4) * (v.D + v.G) * sizeof(float);
-    hipLaunchKernelGGL(kamd::PostKernel, dim3(kamd::CeilDiv(max_post, 4), n), dim3(256), lds_post, st, v, b);
+    // four frames per wavefront for a batch of whole utterances (every UBM load serves four frames); one for streaming updates
+    bool whole = true;
+    for (const kamd::IvUtt &u : utts) whole = whole && u.mode == 0;
+    if (whole && max_post >= 64 && static_cast<size_t>(4) * 4 * (v.D + v.G) * sizeof(float) <= 48 * 1024) {
+      const size_t lds_post = static_cast<size_t>(4) * 4 * (v.D + v.G) * sizeof(float);
+      hipLaunchKernelGGL(kamd::PostKernel<4>, dim3(kamd::CeilDiv(max_post, 16), n), dim3(256), lds_post, st, v, b);
+    } else {
+      const size_t lds_post = static_cast<size_t>(4) * (v.D + v.G) * sizeof(float);
+      hipLaunchKernelGGL(kamd::PostKernel<1>, dim3(kamd::CeilDiv(max_post, 4), n), dim3(256), lds_post, st, v, b);
+    }
   }
   if (max_steps > 0) {
     const size_t lds_step = kamd::StepStatsLdsBytes(v);
