@@ -877,6 +877,20 @@ int kamd_nnet_forward_chunked_device(kamd_nnet *n, const float *d_feats, const i
                                      const float *d_online_ivectors, const int64_t *h_iv_row_off, int iv_dim,
                                      int ivector_period, int frames_per_chunk, int n_utts, float *d_out,
                                      const int64_t *h_out_row_off, int ld_out, void *stream);
+/* One minibatch of NnetInferenceTasks (nnet3/nnet-batch-compute.h:42-110) -- what NnetBatchComputer::Compute evaluates
+ * (nnet-batch-compute.cc:398-470).  For a host that keeps the reference's scheduler (AcceptTask, priorities, full / partial
+ * minibatches, the semaphores) and hands the device the tasks it picked: task i = output frames [first_output_t,
+ * + num_output_frames) at the subsampled rate of the utterance whose features are rows [in_row, + in_len) of d_feats (the
+ * context beyond the utterance's ends is its first / last frame repeated, as SplitInputToTasks pads it), evaluated with row
+ * iv_row of d_ivectors (-1: the model has no i-vector input).  The tasks' outputs lie back to back in d_out.  The tasks of
+ * one call need not share a shape (the device compiles no computation per shape). */
+typedef struct kamd_inference_task {
+  int64_t in_row;
+  int32_t in_len, first_output_t, num_output_frames, iv_row;
+} kamd_inference_task;
+int kamd_nnet_forward_inference_tasks_device(kamd_nnet *n, const float *d_feats, int ld_in, const float *d_ivectors, int iv_dim,
+                                             const kamd_inference_task *tasks, int n_tasks, float *d_out, int ld_out,
+                                             void *stream);
 /* The same batch evaluated the way NnetBatchComputer does (nnet3/nnet-batch-compute.h:207; SplitUtteranceIntoTasks
  * nnet-batch-compute.cc:774-829 with GetOutputFrameInfoForTasks :586-668, AddOnlineIvectorsToTasks :670-703,
  * SplitInputToTasks :705-770, then Compute and MergeTaskOutput :832-870 -- i.e. what nnet3-latgen-faster-batch, the binary

@@ -263,6 +263,7 @@ def lib():
     sig("kamd_ivector_period", C.c_int, [vp])
     sig("kamd_ivector_num_ivectors", C.c_int, [vp, C.c_int])
     sig("kamd_ivector_extract_online_device", C.c_int, [vp, vp, i64p, C.c_int, C.c_int, vp, i64p, vp])
+    sig("kamd_nnet_forward_inference_tasks_device", C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp])
     sig("kamd_ivector_online_reserve_steps", C.c_int, [vp, C.c_int64])
     sig("kamd_ivector_online_stats_device", C.c_int, [vp, vp, i64p, C.c_int, C.c_int, i64p, vp])
     sig("kamd_ivector_online_solve_device", C.c_int, [vp, i64p, C.c_int, vp, i64p, vp])
@@ -298,7 +299,7 @@ kamd_graph_read_openfst kamd_openfst_read kamd_openfst_write kamd_host_free kamd
 kamd_stream_batch_create kamd_stream_batch_destroy kamd_stream_batch_start kamd_stream_batch_accept kamd_stream_batch_accept_many kamd_stream_batch_advance kamd_stream_batch_num_frames_ready kamd_stream_batch_set_ivector_extractor kamd_stream_batch_start_adapted kamd_stream_batch_get_adaptation_state kamd_stream_batch_get_ivector_slots kamd_feat_compute_ranges_device kamd_nnet_forward_slices_device kamd_nnet_forward_slices_slots_device kamd_nnet_forward_chunked_device kamd_nnet_forward_tasks_device kamd_batch_decoder_set_chunk_rule
 kamd_wave_read kamd_ark_read_matrix kamd_ark_write_matrix kamd_ark_read_int32_vector
 kamd_classify_rxfilename kamd_classify_wxfilename kamd_classify_rspecifier kamd_classify_wspecifier kamd_rx_materialize kamd_pipeline_load_features kamd_pipeline_set_overlap kamd_decoder_last_advance_launches
-kamd_am_gmm_create kamd_am_gmm_destroy kamd_am_gmm_num_pdfs kamd_am_gmm_dim kamd_am_gmm_loglikes_device kamd_am_gmm_loglikes kamd_feat_splice_transform_device kamd_feat_add_deltas_device kamd_cmvn_acc_stats_device kamd_cmvn_acc_stats_weighted_device kamd_cmvn_apply_device kamd_cmvn_apply_reverse_device kamd_ivector_extractor_create kamd_ivector_info_read kamd_ivector_info_destroy kamd_ivector_info_desc kamd_ivector_info_create_extractor kamd_ivector_extractor_destroy kamd_ivector_dim kamd_ivector_period kamd_ivector_num_ivectors kamd_ivector_extract_online_device kamd_ivector_online_reserve_steps kamd_ivector_online_stats_device kamd_ivector_online_solve_device kamd_ivector_extract_online kamd_ivector_last_posteriors kamd_pipeline_set_ivector_extractor kamd_ivector_state_size kamd_ivector_extract_online_adapt_device kamd_ivector_state_limit_frames kamd_ivector_extract_online_adapt kamd_ivector_stream_record_size kamd_ivector_stream_record_init kamd_ivector_stream_update_device
+kamd_am_gmm_create kamd_am_gmm_destroy kamd_am_gmm_num_pdfs kamd_am_gmm_dim kamd_am_gmm_loglikes_device kamd_am_gmm_loglikes kamd_feat_splice_transform_device kamd_feat_add_deltas_device kamd_cmvn_acc_stats_device kamd_cmvn_acc_stats_weighted_device kamd_cmvn_apply_device kamd_cmvn_apply_reverse_device kamd_ivector_extractor_create kamd_ivector_info_read kamd_ivector_info_destroy kamd_ivector_info_desc kamd_ivector_info_create_extractor kamd_ivector_extractor_destroy kamd_ivector_dim kamd_ivector_period kamd_ivector_num_ivectors kamd_ivector_extract_online_device kamd_nnet_forward_inference_tasks_device kamd_ivector_online_reserve_steps kamd_ivector_online_stats_device kamd_ivector_online_solve_device kamd_ivector_extract_online kamd_ivector_last_posteriors kamd_pipeline_set_ivector_extractor kamd_ivector_state_size kamd_ivector_extract_online_adapt_device kamd_ivector_state_limit_frames kamd_ivector_extract_online_adapt kamd_ivector_stream_record_size kamd_ivector_stream_record_init kamd_ivector_stream_update_device
 kamd_determinize_opts_default kamd_lattice_determinize_phone_pruned kamd_compact_lattice_destroy kamd_compact_lattice_sizes kamd_compact_lattice_get kamd_compact_lattice_write
 kamd_decoder_config_default kamd_decoder_sizes_default kamd_decoder_sizes_suggest kamd_decoder_create kamd_decoder_destroy
 kamd_decoder_set_options kamd_decoder_reserve kamd_decoder_init kamd_decoder_advance kamd_decoder_finalize

@@ -220,3 +220,9 @@ def iptr(a, t=C.c_int32):
         return C.POINTER(t)()
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.POINTER(t))
+
+
+class InferenceTask(C.Structure):
+    """kamd_inference_task: one NnetInferenceTask of a minibatch (kamd_nnet_forward_inference_tasks_device)"""
+    _fields_ = [("in_row", C.c_int64), ("in_len", C.c_int32), ("first_output_t", C.c_int32), ("num_output_frames", C.c_int32),
+                ("iv_row", C.c_int32)]

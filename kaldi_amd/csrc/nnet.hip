@@ -1930,6 +1930,36 @@ int kamd_nnet_forward_tasks_device(kamd_nnet *h, const float *d_feats, const int
                             d_out, h_out_row_off, ld_out, stream, 1);
 }
 
+// ---- one minibatch of NnetInferenceTasks (nnet3/nnet-batch-compute.h:42-110), the unit NnetBatchComputer::Compute evaluates
+// (nnet-batch-compute.cc:398-470 FormatInputs / computer.Run / FormatOutputs): the entry a Kaldi-side NnetBatchComputer binds
+// when it keeps its own scheduler (AcceptTask, priorities, full / partial minibatches) and hands the device the tasks it
+// picked.  Task i = output frames [first_output_t, + num_output_frames) (in units of the subsampled rate) of the utterance
+// whose features are rows [in_row, + in_len) of d_feats -- the context beyond the utterance's ends is the first / last frame
+// repeated, as SplitInputToTasks pads it (:705-770) -- with row iv_row of d_ivectors (an online i-vector or the utterance's
+// own; -1 for a model without the input).  Outputs: the tasks back to back in d_out, num_output_frames rows each.
+int kamd_nnet_forward_inference_tasks_device(kamd_nnet *h, const float *d_feats, int ld_in, const float *d_ivectors, int iv_dim,
+                                             const kamd_inference_task *tasks, int n_tasks, float *d_out, int ld_out, void *stream) {
+  Nnet *nn = reinterpret_cast<Nnet *>(h);
+  if (n_tasks <= 0) return KAMD_OK;
+  if (!tasks || !d_feats || !d_out) return kamd::SetError(KAMD_ERR_ARG, "inference tasks: null argument");
+  const int sub = nn->subsampling, want_iv = nn->L[0].ivector_dim;
+  if (want_iv > 0 && (!d_ivectors || iv_dim != want_iv)) return kamd::SetError(KAMD_ERR_ARG, "model expects ivector dim %d, got %d", want_iv, d_ivectors ? iv_dim : 0);
+  std::vector<int64_t> in_start(n_tasks), out_row(n_tasks + 1, 0);
+  std::vector<int32_t> in_len(n_tasks), t0(n_tasks), nout(n_tasks), iv_row(n_tasks);
+  for (int i = 0; i < n_tasks; i++) {
+    const kamd_inference_task &t = tasks[i];
+    if (t.in_len <= 0 || t.first_output_t < 0 || t.num_output_frames <= 0 || t.in_row < 0)
+      return kamd::SetError(KAMD_ERR_ARG, "inference task %d: bad range", i);
+    if (want_iv > 0 && t.iv_row < 0) return kamd::SetError(KAMD_ERR_ARG, "inference task %d: the model needs an i-vector row", i);
+    in_start[i] = t.in_row; in_len[i] = t.in_len; t0[i] = t.first_output_t * sub; nout[i] = t.num_output_frames;
+    iv_row[i] = want_iv > 0 ? t.iv_row : 0;
+    out_row[i + 1] = out_row[i] + t.num_output_frames;
+  }
+  ChunkSpec cs = {t0.data(), nout.data(), iv_row.data()};
+  return ForwardItems(h, d_feats, in_start.data(), in_len.data(), ld_in, want_iv > 0 ? d_ivectors : NULL, n_tasks, d_out, out_row.data(), ld_out,
+                      stream, NULL, &cs);
+}
+
 // ---- nnet3::Component::Propagate (nnet3/nnet-component-itf.h:130-132) for ONE fused layer: SURVEY 8(b)'s option (i),
 // the compatibility entry for a host that keeps nnet3's own computation and hands single components to the device.
 // TdnnComponent::Propagate's shape (nnet-tdnn-component.cc:181-212): `in` holds consecutive time steps, out row j is

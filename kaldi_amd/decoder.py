@@ -104,6 +104,28 @@ class Nnet:
         out = d_o.download()
         return [out[out_off[i]:out_off[i + 1]] for i in range(n)]
 
+    def ForwardInferenceTasks(self, feats_list, ivector_table, tasks):
+        """One minibatch of NnetInferenceTasks (kamd_nnet_forward_inference_tasks_device): tasks = [(utterance index, first output
+        frame, number of output frames, row of ivector_table or -1)]; returns one [num_output_frames x P] array per task."""
+        ld = (self.model.input_dim + 15) // 16 * 16
+        in_off = np.concatenate([[0], np.cumsum([f.shape[0] for f in feats_list])]).astype(np.int64)
+        feats = np.zeros((int(in_off[-1]), ld), np.float32)
+        for u, f in enumerate(feats_list):
+            feats[in_off[u]:in_off[u + 1], :f.shape[1]] = f
+        arr = (abi.InferenceTask * len(tasks))()
+        for i, (u, t, n, r) in enumerate(tasks):
+            arr[i] = abi.InferenceTask(int(in_off[u]), int(feats_list[u].shape[0]), int(t), int(n), int(r))
+        P = self.OutputDim()
+        rows = sum(int(n) for _, _, n, _ in tasks)
+        d_f, d_o = DeviceMatrix(feats), DeviceMatrix(np.zeros((rows, P), np.float32))
+        d_iv = None if ivector_table is None else DeviceMatrix(np.ascontiguousarray(ivector_table, np.float32))
+        check(lib().kamd_nnet_forward_inference_tasks_device(self._h, d_f.ptr(0), ld, d_iv.ptr(0) if d_iv is not None else None,
+                                                             0 if d_iv is None else int(np.asarray(ivector_table).shape[1]), arr, len(tasks),
+                                                             d_o.ptr(0), P, None))
+        out = d_o.download()
+        cut = np.concatenate([[0], np.cumsum([int(n) for _, _, n, _ in tasks])])
+        return [out[cut[i]:cut[i + 1]] for i in range(len(tasks))]
+
     def ForwardChunked(self, feats_list, online_ivectors_list, ivector_period=10, frames_per_chunk=50, batch_computer=False):
         """DecodableNnetSimple with online ivectors for a batch of utterances: one ivector per
         chunk (nnet3/nnet-am-decodable-simple.cc:93-214).  Returns one [n_out x P] array each.

@@ -93,6 +93,41 @@ def test_batch_computer_tasks_with_online_ivectors():
     assert np.abs(simple[0] - tasks[0]).max() > 1e-3          # two different chunkings of the same inputs
 
 
+def test_a_minibatch_of_inference_tasks_in_any_order():
+    """kamd_nnet_forward_inference_tasks_device: the unit NnetBatchComputer::Compute evaluates (nnet-batch-compute.cc:398-470), for a
+    host that keeps the reference's scheduler.  The tasks the oracle's SplitUtteranceIntoTasks makes of three utterances are
+    handed over in a shuffled order (a scheduler picks by priority, not by utterance), tasks of different shapes in ONE call;
+    every task's used rows must be the oracle's NnetBatchComputer rows for that utterance.  A second call evaluates a model
+    without the i-vector input (iv_row -1)."""
+    m = nnet.tdnnf_tiny(num_pdfs=41, ivector_dim=10, seed=7)
+    N = decoder.Nnet(m)
+    rng = np.random.default_rng(9)
+    feats, ivs, refs, tasks = [], [], [], []
+    iv_base = 0
+    for u, T in enumerate((140, 17, 263)):
+        feats.append((2 * rng.standard_normal((T, m.input_dim))).astype(np.float32))
+        ivs.append(rng.standard_normal(((T + 9) // 10, 10)).astype(np.float32))
+        ref, tab = orc.nnet_forward_batch_computer(m, feats[u], ivs[u], 10, 50, return_tasks=True)
+        refs.append(ref)
+        for first_used, _, n_used, _, _, iv_row in tab.tolist():
+            tasks.append((u, first_used, n_used, iv_base + iv_row))
+        iv_base += ivs[u].shape[0]
+    order = rng.permutation(len(tasks))
+    shuffled = [tasks[i] for i in order]
+    assert len({t[2] for t in shuffled}) > 1                    # tasks of different lengths in one minibatch
+    outs = N.ForwardInferenceTasks(feats, np.concatenate(ivs), shuffled)
+    for (u, first, n, _), got in zip(shuffled, outs):
+        want = refs[u][first:first + n]
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-4 * np.abs(refs[u]).max()
+    with pytest.raises(Exception):                             # a task beyond the utterance's last output frame
+        N.ForwardInferenceTasks(feats, np.concatenate(ivs), [(1, 4, 5, 0)])
+    m0 = nnet.tdnnf_tiny(num_pdfs=41, seed=7)
+    N0 = decoder.Nnet(m0)
+    whole = N0.Forward(feats[0])
+    got = N0.ForwardInferenceTasks(feats, None, [(0, 10, 7, -1), (0, 0, 3, -1)])
+    assert np.abs(got[0] - whole[10:17]).max() < 1e-4 * np.abs(whole).max() and np.abs(got[1] - whole[0:3]).max() < 1e-4 * np.abs(whole).max()
+
+
 def test_context_and_plan():
     m = nnet.tdnnf_mini_librispeech(num_pdfs=64)
     n = decoder.Nnet(m)
