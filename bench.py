@@ -119,6 +119,9 @@ def parse_args():
     ap.add_argument("--search-mode", type=int, default=2, choices=[1, 2], help="kamd_decoder_set_search_mode: 1 canonical (tight), "
                     "2 canonical-loose (every token the reference's order-dependent pruning can create)")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for ONE rank (RANK / WORLD_SIZE / MASTER_* from the "
+                    "environment, defaults for a lone process): the RCCL code path of an N > 1 run -- init beside the library's device "
+                    "selection, barriers, the all-gather of the rank walls, the scalar reduction -- on a one-GPU box")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real multi-GPU runs; gloo to "
                     "exercise the N>1 code path with several ranks sharing one GPU")
     ap.add_argument("--device", type=int, default=-1, help="override the HIP device of every rank (default LOCAL_RANK)")
@@ -624,9 +627,12 @@ def main():
             print("[bench %.1fs] %s" % (time.time() - T0, msg), file=sys.stderr, flush=True)
 
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch
         import torch.distributed as dist
+        if world == 1:
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29571")):
+                os.environ.setdefault(k, v)
         if args.dist_backend == "nccl":
             torch.cuda.set_device(local_rank if args.device < 0 else args.device)
         dist.init_process_group(args.dist_backend)   # nccl = RCCL; only barriers + scalar reductions use it

@@ -88,6 +88,18 @@ def test_resident_flag_keeps_round_2_contract():
     assert d["config"]["upload_in_timed_region"] is False and d["upload"] is None and "hbm_resident_value" not in d
 
 
+def test_rccl_code_path_with_one_rank():
+    """What a one-GPU box can say about the RCCL path: `--force-dist --dist-backend nccl` runs the N > 1
+    code of bench.py with ONE rank -- torch.cuda.set_device beside kamd_set_device, the RCCL communicator created in the
+    process that holds the library's streams and page-locked pools, the barriers around the timed region, the all-gather of
+    the rank walls and the scalar all-reduce on device tensors -- and the line keeps its N = 1 shape."""
+    d = run_bench("--workload", "tiny", "--gpus", "1", "--force-dist", "--dist-backend", "nccl", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                  "--no-wer", "--no-streaming", "--no-random-leg", "--no-planted", "--no-ivector-leg")
+    assert d["n_gpus"] == 1 and len(d["rank_wall_s"]) == 1 and d["value"] > 0
+    assert d["config"]["utterances"] == d["config"]["utterances_rank0"] == 12
+    assert abs(d["rank_wall_s"][0] - d["rank0_wall_s"]) < 1e-9                    # (the gathered wall is this rank's own)
+
+
 def test_rccl_ranks_when_the_box_has_more_than_one_gpu():
     """The N > 1 path over RCCL (--dist-backend nccl, one rank per GPU): runs wherever two devices are visible; the pool's
     one-GPU boxes skip it (the gloo test above covers the same code path with two ranks on one device)."""
