@@ -196,3 +196,27 @@ def test_nbest_and_oracle_against_path_enumeration():
         ref = [int(x) for x in rng.integers(1, 5, int(rng.integers(0, 5)))]
         brute = min(lb.edit_distance(ref, w)[0] for w, _ in paths)
         assert lb.oracle_errors(L, ref) == brute
+
+
+def test_bench_word_path_acceptance_on_a_determinized_lattice():
+    """bench.py's `_clat_accepts` (the containment check of cpu_baseline.divergence_from_reference_search): a word sequence is
+    a path of the determinized lattice iff start -> ... -> a final state spells it, epsilon-labelled arcs being free."""
+    import sys
+    sys.argv = ["bench.py"]
+    import bench
+    from kaldi_amd import abi
+
+    class Clat:
+        pass
+    cl = Clat()
+    cl.num_states, cl.start = 5, 0
+    cl.final = np.full(10, np.inf, np.float32)
+    cl.final[2 * 3] = 0.0
+    cl.final[2 * 4] = 0.0
+    arcs = np.zeros(6, abi.CLAT_ARC_DTYPE)
+    for i, (s, d, lab) in enumerate([(0, 1, 7), (1, 2, 0), (2, 3, 9), (0, 2, 8), (1, 4, 5), (3, 4, 0)]):
+        arcs[i]["src"], arcs[i]["dst"], arcs[i]["label"] = s, d, lab
+    cl.arcs = arcs
+    assert bench._clat_accepts(cl, [7, 9]) and bench._clat_accepts(cl, [8, 9]) and bench._clat_accepts(cl, [7, 5])
+    assert not bench._clat_accepts(cl, [7]) and not bench._clat_accepts(cl, [9]) and not bench._clat_accepts(cl, [7, 9, 9])
+    assert not bench._clat_accepts(cl, []) and not bench._clat_accepts(None, [7])
